@@ -1,0 +1,69 @@
+#!/bin/bash
+# build_ref.sh -- build oracle/_ref/libsora_ref.so from the REFERENCE's own arithmetic headers.
+#
+# TEST INFRASTRUCTURE.  Compiles the reference sources where they lie under $SORA_REFERENCE
+# (default /root/reference); nothing from the reference is copied into this repository: the
+# MSVC-only constructs are patched in a scratch directory that is removed after the compile and the
+# only output is oracle/_ref/libsora_ref.so (git-ignored).  On a box without the reference tree the
+# script is a no-op (the prebuilt .so, if any, is used as it is).
+#
+# Patches:
+#   * vector128.h: drop the hand re-declared intrinsics (lines 26-81), include <immintrin.h>, drop the
+#     two non-existent *_epi64 wrappers
+#   * stub const.h / sora.h providing FINL/SELECTANY/A16 and Windows LLP64 integer types
+#     (ULONG/ulong = 32 bits -- the reference assumes sizeof(long)==4)
+set -euo pipefail
+HERE="$(cd "$(dirname "$0")" && pwd)"
+REF="${SORA_REFERENCE:-/root/reference}"
+OUT="$HERE/_ref"
+if [ ! -d "$REF/kernel/core/inc" ]; then
+    echo "build_ref.sh: reference tree not found at $REF -- skipping (using prebuilt $OUT if present)"
+    exit 0
+fi
+CXX="${SORA_REF_CXX:-/opt/rocm/lib/llvm/bin/clang++}"
+TMP="$(mktemp -d /tmp/sora_ref_build.XXXXXX)"
+trap 'rm -rf "$TMP"' EXIT
+mkdir -p "$OUT"
+
+CI="$REF/kernel/core/inc"; BS="$REF/kernel/bb/Brick11/src"
+for f in complex.h fft_r4dif.h ifft_r4dif.h fft_lut_twiddle.h fft_lut_bitreversal.h intalg.h intalglut.h CRC32.h \
+         operator_repeater.h tpltrick.h unroll.h; do
+    cp "$CI/$f" "$TMP/$f"
+done
+for f in viterbicore.h viterbilut.h demapper.h; do cp "$BS/$f" "$TMP/$f"; done
+sed -e '26,81d' "$CI/vector128.h" \
+  | sed -e 's|#include <emmintrin.h>|#include <immintrin.h>|' \
+        -e '/_mm_sign_epi64/d' -e '/_mm_abs_epi64/d' > "$TMP/vector128.h"
+
+cat > "$TMP/const.h" <<'EOF'
+#pragma once
+#include <stdint.h>
+#include <stddef.h>
+#include <string.h>
+#include <stdlib.h>
+#include <sys/types.h>
+#include <new>
+#define _UI64_MAX UINT64_MAX
+#define _UI32_MAX UINT32_MAX
+#define FINL      __forceinline
+#define SELECTANY __declspec(selectany)
+#define A16       __declspec(align(16))
+#define IN
+#define OUT
+#define SORA_EXTERN_C extern "C"
+typedef unsigned char  uchar, UCHAR, *PUCHAR;
+typedef unsigned short ushort, USHORT;
+typedef unsigned int   uint, UINT;
+typedef uint32_t       sora_ulong32, ULONG, *PULONG;   /* Windows LLP64: long is 32 bits */
+#define ulong sora_ulong32                              /* glibc already typedefs a 64-bit ulong */
+EOF
+cat > "$TMP/sora.h" <<'EOF'
+#pragma once
+#include "const.h"
+EOF
+
+"$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden \
+    -fms-extensions -fms-compatibility -fdelayed-template-parsing -fno-operator-names \
+    -msse4.1 -mssse3 -Wno-everything \
+    -I"$TMP" "$HERE/ref_shim.cpp" -o "$OUT/libsora_ref.so"
+echo "build_ref.sh: built $OUT/libsora_ref.so"
