@@ -1,0 +1,218 @@
+"""ctypes bindings for the CPU oracle (oracle/_build/libsora_oracle.so) and, when present, the compiled
+reference kernels (oracle/_ref/libsora_ref.so).
+
+TEST INFRASTRUCTURE: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this.
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ORACLE_SO = os.path.join(HERE, "_build", "libsora_oracle.so")
+REF_SO = os.path.join(HERE, "_ref", "libsora_ref.so")
+
+E_SUCCESS = 0x0
+E_FRAME_OK = 0x1
+E_PLCP_HEADER_FAIL = 0x80000005
+E_CRC32_FAIL = 0x80000006
+CR_12, CR_23, CR_34 = 0, 1, 2
+RATES = (6000, 9000, 12000, 18000, 24000, 36000, 48000, 54000)
+
+
+def rate_params(kbps):
+    """-> (nbpsc, code_rate, ndbps)   (ieee80211a_cmn.h:65-149)"""
+    return {6000: (1, CR_12, 24), 9000: (1, CR_34, 36), 12000: (2, CR_12, 48), 18000: (2, CR_34, 72),
+            24000: (4, CR_12, 96), 36000: (4, CR_34, 144), 48000: (6, CR_23, 192), 54000: (6, CR_34, 216)}[kbps]
+
+
+class FrameResult(ctypes.Structure):
+    _fields_ = [("start_sample", ctypes.c_uint32), ("end_sample", ctypes.c_uint32), ("error_code", ctypes.c_uint32),
+                ("rate_kbps", ctypes.c_uint32), ("length", ctypes.c_uint16), ("nsym", ctypes.c_uint16),
+                ("crc32", ctypes.c_uint32), ("cfo_est", ctypes.c_int16), ("reserved", ctypes.c_uint16),
+                ("mpdu_offset", ctypes.c_uint32)]
+
+
+class RxCtx(ctypes.Structure):
+    _fields_ = [("CFO_est", ctypes.c_int16), ("FreqCoeffs", ctypes.c_int16 * 128), ("ChannelCoeffs", ctypes.c_int16 * 128),
+                ("CFO_comp", ctypes.c_int16), ("SFO_comp", ctypes.c_int16), ("CompCoeffs", ctypes.c_int16 * 128),
+                ("CFO_tracker", ctypes.c_int16), ("SFO_tracker", ctypes.c_int16), ("symbol_count", ctypes.c_uint32)]
+
+
+class Trace(ctypes.Structure):
+    _fields_ = [("ctx_after_lts", ctypes.POINTER(RxCtx)), ("eq", ctypes.c_void_p), ("tracked", ctypes.c_void_p),
+                ("soft", ctypes.c_void_p), ("decoded", ctypes.c_void_p), ("cap_syms", ctypes.c_uint32),
+                ("cap_soft", ctypes.c_uint32), ("n_syms", ctypes.c_uint32), ("n_soft", ctypes.c_uint32)]
+
+
+def build(force=False):
+    """Compile the C restatement (and oracle/_ref when the reference tree is present)."""
+    if force or not os.path.exists(ORACLE_SO) or any(
+            os.path.getmtime(os.path.join(HERE, f)) > os.path.getmtime(ORACLE_SO)
+            for f in os.listdir(HERE) if f.endswith((".c", ".h"))):
+        subprocess.check_call(["make", "-s", "-C", HERE])
+    ref_root = os.environ.get("SORA_REFERENCE", "/root/reference")
+    if os.path.isdir(os.path.join(ref_root, "kernel", "core", "inc")):
+        shim = os.path.join(HERE, "ref_shim.cpp")
+        if force or not os.path.exists(REF_SO) or os.path.getmtime(shim) > os.path.getmtime(REF_SO):
+            subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
+
+
+_P = lambda a: a.ctypes.data_as(ctypes.c_void_p)
+
+
+class Oracle:
+    def __init__(self):
+        build()
+        L = self.L = ctypes.CDLL(ORACLE_SO)
+        L.so_init()
+        L.so_crc32.restype = ctypes.c_uint32
+        L.so_uatan2.restype = ctypes.c_int16
+        L.so_viterbi_sig.restype = ctypes.c_uint32
+        L.so_desc_sink.restype = ctypes.c_uint32
+        for n in ("so_usin_lut", "so_ucos_lut", "so_uatan2_lut", "so_twiddle"):
+            getattr(L, n).restype = ctypes.POINTER(ctypes.c_int16)
+        L.so_demap_lut.restype = ctypes.POINTER(ctypes.c_uint8)
+        L.so_sts_pattern.restype = ctypes.POINTER(ctypes.c_int16)
+
+    # ---- LUTs
+    def usin_lut(self): return np.ctypeslib.as_array(self.L.so_usin_lut(), shape=(65536,)).copy()
+    def ucos_lut(self): return np.ctypeslib.as_array(self.L.so_ucos_lut(), shape=(65536,)).copy()
+    def uatan2_lut(self): return np.ctypeslib.as_array(self.L.so_uatan2_lut(), shape=(65536,)).copy()
+    def demap_lut(self, w): return np.ctypeslib.as_array(self.L.so_demap_lut(w), shape=(256,)).copy()
+    def twiddle(self, n, k): return np.ctypeslib.as_array(self.L.so_twiddle(n, k), shape=(n // 4, 2)).copy()
+    def sts_pattern(self): return np.ctypeslib.as_array(self.L.so_sts_pattern(), shape=(16, 16, 2)).copy()
+
+    # ---- primitives
+    def fft(self, x, n=64, inverse=False):
+        x = np.ascontiguousarray(x, np.int16).reshape(n, 2); o = np.zeros_like(x)
+        getattr(self.L, "so_%sfft%d" % ("i" if inverse else "", n))(_P(x), _P(o))
+        return o
+
+    def crc32(self, b):
+        a = np.frombuffer(bytes(b), np.uint8)
+        return self.L.so_crc32(_P(a), len(a))
+
+    # ---- stages
+    def new_ctx(self):
+        c = RxCtx(); self.L.so_rx11a_ctx_reset(ctypes.byref(c)); return c
+
+    def lts(self, ctx, in144):
+        a = np.ascontiguousarray(in144, np.int16).reshape(144, 2)
+        self.L.so_lts(ctypes.byref(ctx), _P(a))
+
+    def sym_front(self, ctx, in80):
+        a = np.ascontiguousarray(in80, np.int16).reshape(80, 2); o = np.zeros((64, 2), np.int16)
+        self.L.so_sym_front(ctypes.byref(ctx), _P(a), _P(o)); return o
+
+    def sym_track(self, ctx, eq):
+        a = np.ascontiguousarray(eq, np.int16).reshape(64, 2); o = np.zeros((64, 2), np.int16)
+        self.L.so_sym_track(ctypes.byref(ctx), _P(a), _P(o)); return o
+
+    def demap(self, nbpsc, x):
+        a = np.ascontiguousarray(x, np.int16).reshape(64, 2); o = np.zeros(48 * nbpsc, np.uint8)
+        self.L.so_demap(nbpsc, _P(a), _P(o)); return o
+
+    def deinterleave(self, nbpsc, s):
+        a = np.ascontiguousarray(s, np.uint8); o = np.zeros(48 * nbpsc, np.uint8)
+        self.L.so_deinterleave(nbpsc, _P(a), _P(o)); return o
+
+    def viterbi_sig(self, soft48):
+        a = np.ascontiguousarray(soft48, np.uint8); return self.L.so_viterbi_sig(_P(a))
+
+    def viterbi_frame(self, soft, code_rate, frame_length):
+        a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(frame_length + 64, np.uint8)
+        n = self.L.so_viterbi_frame(_P(a), len(a), code_rate, frame_length, _P(o)); return o[:n]
+
+    def desc_sink(self, dec, frame_length):
+        a = np.ascontiguousarray(dec, np.uint8); o = np.zeros(frame_length, np.uint8); crc = ctypes.c_uint32(0)
+        e = self.L.so_desc_sink(_P(a), frame_length, _P(o), ctypes.byref(crc)); return e, o, crc.value
+
+    # ---- whole capture
+    def rx_capture(self, iq, sample_rate_mhz=40, max_frames=64, trace=False):
+        """iq: int16 [n,2].  Returns (list of dict, optional trace dict)."""
+        iq = np.ascontiguousarray(iq, np.int16).reshape(-1, 2)
+        res = (FrameResult * max_frames)(); mp = np.zeros(max_frames * 2504, np.uint8)
+        tr = None; keep = None
+        if trace:
+            cap = 1400
+            ctx = RxCtx(); eq = np.zeros((cap, 64, 2), np.int16); trk = np.zeros((cap, 64, 2), np.int16)
+            soft = np.zeros(cap * 288, np.uint8); dec = np.zeros(2600, np.uint8)
+            tr = Trace(ctypes.pointer(ctx), eq.ctypes.data, trk.ctypes.data, soft.ctypes.data, dec.ctypes.data, cap, soft.size, 0, 0)
+            keep = (ctx, eq, trk, soft, dec)
+        n = self.L.so_rx11a_capture(_P(iq), len(iq), sample_rate_mhz, res, max_frames, _P(mp), mp.size,
+                                    ctypes.byref(tr) if tr is not None else None)
+        out = []
+        for i in range(n):
+            r = res[i]
+            d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
+            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            out.append(d)
+        if trace:
+            ctx, eq, trk, soft, dec = keep
+            return out, {"ctx": ctx, "eq": eq[:tr.n_syms], "tracked": trk[:tr.n_syms], "soft": soft[:tr.n_soft], "decoded": dec}
+        return out
+
+    def load_dump(self, path_or_bytes, raw14=False):
+        raw = np.fromfile(path_or_bytes, np.uint8) if isinstance(path_or_bytes, str) else np.frombuffer(path_or_bytes, np.uint8)
+        cap = (len(raw) // 128 + 1) * 28; iq = np.zeros((cap, 2), np.int16)
+        n = self.L.so_load_dump(_P(raw), len(raw), _P(iq), cap, 1 if raw14 else 0); return iq[:n]
+
+    # ---- transmitter
+    def tx(self, mpdu_nofcs, rate_kbps, seed=0xFF):
+        """-> int8 [n,2] COMPLEX8 @40 MHz (what `demod11 -m` writes)."""
+        a = np.frombuffer(bytes(mpdu_nofcs), np.uint8); cap = 640 + 160 * 1400
+        o = np.zeros((cap, 2), np.int8)
+        n = self.L.so_tx11a(_P(a), len(a), rate_kbps, seed, _P(o), cap)
+        if n < 0: raise ValueError("so_tx11a failed %d" % n)
+        return o[:n]
+
+    def tx_capture(self, mpdu_nofcs, rate_kbps, seed=0xFF, lead=0, tail=160, rate_mhz=40):
+        """TX -> `demod11 -c` expansion (<<8) -> int16 capture with `lead`/`tail` zero samples (@40 MHz)."""
+        s8 = self.tx(mpdu_nofcs, rate_kbps, seed)
+        x = np.zeros((lead + len(s8) + tail, 2), np.int16)
+        x[lead:lead + len(s8)] = s8.astype(np.int16) << 8
+        return x if rate_mhz == 40 else x[::2].copy()
+
+
+class Reference:
+    """The reference's own SSE kernels (oracle/_ref).  available() is False where the .so is absent."""
+    def __init__(self):
+        self.L = ctypes.CDLL(REF_SO) if os.path.exists(REF_SO) else None
+        if self.L is not None:
+            L = self.L
+            L.ref_crc32.restype = ctypes.c_uint32
+            L.ref_uatan2.restype = ctypes.c_int16; L.ref_usin.restype = ctypes.c_int16; L.ref_ucos.restype = ctypes.c_int16
+            L.ref_viterbi_sig.restype = ctypes.c_uint32
+            L.ref_vit_new.restype = ctypes.c_void_p
+            for n in ("ref_usin_lut", "ref_ucos_lut", "ref_uatan2_lut"):
+                getattr(L, n).restype = ctypes.POINTER(ctypes.c_int16)
+
+    def available(self): return self.L is not None
+
+    def fft(self, x, n=64, inverse=False):
+        x = np.ascontiguousarray(x, np.int16).reshape(n, 2); o = np.zeros_like(x)
+        getattr(self.L, "ref_%sfft%d" % ("i" if inverse else "", n))(_P(x), _P(o)); return o
+
+    def lut(self, name): return np.ctypeslib.as_array(getattr(self.L, "ref_%s_lut" % name)(), shape=(65536,)).copy()
+
+    def vcs2(self, fn, a, b, *extra):
+        a = np.ascontiguousarray(a, np.int16).reshape(4, 2); b = np.ascontiguousarray(b, np.int16).reshape(4, 2)
+        o = np.zeros((4, 2), np.int16); getattr(self.L, fn)(_P(a), _P(b), *extra, _P(o)); return o
+
+    def demap(self, nbpsc, x):
+        a = np.ascontiguousarray(x, np.int16).reshape(64, 2); lim = np.zeros_like(a); o = np.zeros(48 * nbpsc, np.uint8)
+        self.L.ref_demap_limit64(_P(a), _P(lim)); self.L.ref_demap11a(_P(lim), nbpsc, _P(o)); return o
+
+    def viterbi_sig(self, soft48):
+        a = np.ascontiguousarray(soft48, np.uint8); return self.L.ref_viterbi_sig(_P(a))
+
+    def viterbi_frame(self, soft, code_rate, frame_length):
+        a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(frame_length + 64, np.uint8)
+        h = ctypes.c_void_p(self.L.ref_vit_new())
+        n = self.L.ref_vit_decode_frame(h, _P(a), len(a), code_rate, frame_length, _P(o))
+        self.L.ref_vit_free(h); return o[:n]
+
+    def crc32(self, b):
+        a = np.frombuffer(bytes(b), np.uint8); return self.L.ref_crc32(_P(a), len(a))

@@ -1,0 +1,76 @@
+#!/usr/bin/env python3
+"""Generate the committed golden fixtures from the REFERENCE (run in the build container only).
+
+  fsample6_40mhz_i8.npz  kernel/test-data/fsample-6.dmp, de-framed (brickutil.h:20-58) and 14->16-bit
+                         sign-fixed ((int16)(raw<<2)); every value is then a multiple of 256, so the
+                         stream is stored as int8 (value>>8).  Golden: sha256 of the dump, MPDU sha256, FCS.
+  ref_vectors.npz        input/output pairs produced by the reference's OWN SSE kernels compiled into
+                         oracle/_ref/libsora_ref.so (FFT<64>/IFFT<64>/IFFT<128>, vcs mul, demap LUT walk,
+                         Viterbi_sig11, TViterbiCore frame decodes at 1/2, 2/3, 3/4 under noise).
+Both files travel to the GPU box; /root/reference does not.
+"""
+import hashlib
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+from oracle.pyoracle import Oracle, Reference, CR_12, CR_23, CR_34  # noqa: E402
+
+REF = os.environ.get("SORA_REFERENCE", "/root/reference")
+OUT = os.path.dirname(os.path.abspath(__file__))
+
+
+def main():
+    O = Oracle(); R = Reference()
+    assert R.available(), "build oracle/_ref first (oracle/build_ref.sh)"
+    dump = os.path.join(REF, "kernel", "test-data", "fsample-6.dmp")
+    raw = open(dump, "rb").read()
+    iq = O.load_dump(dump, raw14=True)
+    assert (iq % 256 == 0).all()
+    np.savez_compressed(os.path.join(OUT, "fsample6_40mhz_i8.npz"), iq_i8=(iq >> 8).astype(np.int8),
+                        dump_sha256=hashlib.sha256(raw).hexdigest())
+
+    rng = np.random.default_rng(20260925)
+    v = {}
+    amps = [32767, 20000, 8000, 500, 30]
+    x64 = np.stack([rng.integers(-amps[i % 5], amps[i % 5] + 1, size=(64, 2)) for i in range(40)]).astype(np.int16)
+    x64[3, 7] = (-32768, 32767); x64[4, 0] = (32767, -32768)
+    v["fft64_in"] = x64
+    v["fft64_out"] = np.stack([R.fft(x, 64) for x in x64])
+    v["ifft64_out"] = np.stack([R.fft(x, 64, inverse=True) for x in x64])
+    x128 = np.stack([rng.integers(-amps[i % 5], amps[i % 5] + 1, size=(128, 2)) for i in range(20)]).astype(np.int16)
+    v["fft128_in"] = x128
+    v["ifft128_out"] = np.stack([R.fft(x, 128, inverse=True) for x in x128])
+    v["fft128_out"] = np.stack([R.fft(x, 128) for x in x128])
+    a = rng.integers(-32768, 32768, size=(64, 4, 2)).astype(np.int16); b = rng.integers(-32768, 32768, size=(64, 4, 2)).astype(np.int16)
+    a[0, 0] = (-32768, -32768); b[0, 0] = (-32768, -32768)
+    v["mul_a"] = a; v["mul_b"] = b
+    v["mul_q15"] = np.stack([R.vcs2("ref_vcs_mul", x, y) for x, y in zip(a, b)])
+    dm = rng.integers(-2600, 2600, size=(16, 64, 2)).astype(np.int16)
+    v["demap_in"] = dm
+    for nb in (1, 2, 4, 6):
+        v["demap_out_%d" % nb] = np.stack([R.demap(nb, x) for x in dm])
+    sig = rng.integers(0, 8, size=(32, 48)).astype(np.uint8)
+    v["vsig_in"] = sig
+    v["vsig_out"] = np.array([R.viterbi_sig(s) for s in sig], np.uint32)
+    # noisy frames through the reference TViterbiCore with the T11aViterbi schedule
+    for name, cr, per in (("12", CR_12, 2), ("23", CR_23, 3), ("34", CR_34, 4)):
+        flen = 300
+        nsteps_in = {CR_12: 2, CR_23: 1.5, CR_34: 4 / 3}[cr]
+        nsoft = int(np.ceil((flen * 8 + 16 + 6 + 40) * nsteps_in / per) * per)
+        soft = rng.integers(0, 8, size=nsoft).astype(np.uint8)          # pure noise: worst case for tie-breaks/wrap
+        # half of the vector: a plausible code word with moderate noise
+        half = nsoft // 2
+        soft[:half] = np.clip(rng.choice([0, 7], size=half) + rng.integers(-3, 4, size=half), 0, 7)
+        v["vit%s_in" % name] = soft
+        v["vit%s_out" % name] = R.viterbi_frame(soft, cr, flen)
+        v["vit%s_len" % name] = np.array([flen])
+    np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), **v)
+    print("written", os.listdir(OUT))
+
+
+if __name__ == "__main__":
+    main()
