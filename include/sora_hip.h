@@ -1,0 +1,135 @@
+/* sora_hip.h -- C ABI of the MI355X-native 802.11a receive PHY (libsora_hip.so).
+ *
+ * The reference (microsoft/Sora) has no runtime FFI: its "operator API" is the compile-time BRICK
+ * protocol (kernel/brick/inc/brick.h:151-475 -- Process / Reset / Flush on typed burst ports, shared
+ * state in context facades, errors as bool + CF_Error::error_code).  This header is the boundary a
+ * maintainer binds instead: every entry point below names the reference brick(s) it replaces.  Bricks
+ * fire per 4/28/64 samples, a kernel launch per Process() is impossible, so the ports are kept but the
+ * BURST is a batch (BRICK allows any BURST/NSTREAM: brick.h:182-238).
+ *
+ * Conventions
+ *   - plain C, no C++/torch types; every function returns a BK_ERROR_* / E_ERROR_* compatible code
+ *     (kernel/brick/inc/dspcomm.h:22-31, kernel/bb/Brick11/src/ieee80211facade.hpp:10-19)
+ *   - pointers named d_* are DEVICE (HBM) pointers, h_* are host pointers; the caller owns every buffer
+ *   - one hipStream per sora_rx_t; calls on one handle must be serialised by the caller, different
+ *     handles are independent (no hidden globals, unlike the reference's BB11aDemodCtx,
+ *     kernel/bb/demod11/fb11ademod_config.hpp:123)
+ *   - the library never falls back to a CPU path: without a usable HIP device every compute call
+ *     returns SORA_ERR_NO_DEVICE.
+ */
+#ifndef SORA_HIP_H
+#define SORA_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SORA_HIP_ABI_VERSION 1
+
+/* COMPLEX16: kernel/core/inc/complex.h */
+typedef struct { int16_t re, im; } sora_complex16;
+
+/* status codes (values of the reference where one exists) */
+#define SORA_OK                  0           /* BK_ERROR_SUCCESS / E_ERROR_SUCCESS */
+#define SORA_E_FRAME_OK          0x00000001  /* E_ERROR_FRAME_OK */
+#define SORA_E_PARAMETER         ((int)0x80000001)
+#define SORA_E_PLCP_HEADER_FAIL  ((int)0x80000005)
+#define SORA_E_CRC32_FAIL        ((int)0x80000006)
+#define SORA_ERR_FAILED          ((int)0x8000FFFF)  /* BK_ERROR_FAILED */
+#define SORA_ERR_HARDWARE_FAILED ((int)0x8000FFFE)  /* BK_ERROR_HARDWARE_FAILED: a HIP call failed */
+#define SORA_ERR_INVALID_PARAM   (-1)               /* BK_ERROR_INVALID_PARAM */
+#define SORA_ERR_NO_DEVICE       (-5)
+#define SORA_ERR_CAPACITY        (-6)               /* a caller-provided buffer or a configured limit is too small */
+
+/* code rates: kernel/bb/Brick11/src/ieee80211const.h:14-20 */
+enum { SORA_CR_12 = 0, SORA_CR_23 = 1, SORA_CR_34 = 2 };
+
+/* ------------------------------------------------------------------------------------------------
+ * Whole-path receiver = the demod graph CreateDemodGraph11a_40M (kernel/bb/demod11/fb11ademod_config.hpp:
+ * 168-233) driven by RxThread (kernel/bb/demod11/fb11a_demod.cpp:29-81), over a BATCH of independent captures.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct sora_rx sora_rx_t;
+
+typedef struct {
+    uint32_t struct_size;           /* sizeof(sora_rx_cfg) */
+    int32_t  device;                /* HIP device ordinal */
+    uint32_t sample_rate_mhz;       /* 40: dump rate, TDownSample2 first (samples.hpp:9-47); 20: the even samples */
+    uint32_t max_captures;          /* captures per sora_rx_process call */
+    uint64_t max_total_samples;     /* sum of capture lengths per call (input-rate samples) */
+    uint32_t max_frames_per_capture;/* frame-table rows per capture */
+    uint32_t cca_pwr_threshold;     /* CF_11CCA::cca_pwr_threshold; 0 -> 1000*1000 (fb11ademod_config.hpp:107) */
+} sora_rx_cfg;
+
+typedef struct {                    /* one capture = one TMemSamples source (brick/inc/memsource.hpp:16-114) */
+    uint64_t offset;                /* first sample, in samples, from the iq base pointer; multiple of 4 (16-byte aligned) */
+    uint32_t nsamples;              /* input-rate samples */
+    uint32_t capture_id;            /* echoed into the results */
+} sora_capture_desc;
+
+typedef struct {                    /* one row per frame the reference's RxThread would have reported */
+    uint32_t capture_id;
+    uint32_t start_sample;          /* 20 MHz-rate index (in the capture) of the first sample given to T11aLTS */
+    uint32_t end_sample;            /* one past the last 20 MHz-rate sample of the frame */
+    uint32_t error_code;            /* SORA_E_FRAME_OK / SORA_E_CRC32_FAIL / SORA_E_PLCP_HEADER_FAIL */
+    uint32_t rate_kbps;             /* CF_11aRxVector::data_rate_kbps */
+    uint16_t length;                /* CF_11aRxVector::frame_length (MPDU incl. FCS) */
+    uint16_t nsym;                  /* data symbols */
+    uint32_t crc32;                 /* FCS found in the frame (CF_11aRxVector::crc32) */
+    int16_t  cfo_est;               /* CF_CFOffset::CFO_est (FP_RAD per sample) */
+    uint16_t reserved;
+    uint32_t mpdu_offset;           /* byte offset of the MPDU in the mpdu buffer */
+} sora_frame_result;
+
+/* create/destroy the graph: CreateDemodGraph11a_40M + BB11aDemodCtx.Init  /  IReferenceCounting::Release */
+int  sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out);
+void sora_rx_destroy(sora_rx_t* rx);
+/* ISource::Reset / ISource::Flush (brick.h:343-353): Reset forgets all per-call state; Flush waits for the stream */
+int  sora_rx_reset(sora_rx_t* rx);
+int  sora_rx_flush(sora_rx_t* rx);
+/* The stream every kernel of this handle is launched on (a hipStream_t), for event timing by the caller. */
+void* sora_rx_stream(sora_rx_t* rx);
+
+/* ISource::Process over a batch: enqueue the whole receive path for `ncaps` captures whose samples are
+ * resident in HBM (d_iq).  Asynchronous; results become available after sora_rx_flush / sora_rx_results. */
+int  sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* h_caps, size_t ncaps);
+/* Same with a host buffer (copied to HBM first; the PCIe time is then part of the call). */
+int  sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* h_caps, size_t ncaps);
+/* TBB11aFrameSink's frame buffer + CF_Error per frame: copies results of the last process call to the host.
+ * h_mpdu may be NULL (descriptors only).  *nout = rows written. Frames appear in (capture, time) order. */
+int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+/* Device-side views of the last call's outputs (valid until the next process/reset/destroy). */
+int  sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu);
+
+/* ------------------------------------------------------------------------------------------------
+ * Per-stage entry points with the brick port shapes, batched (n = number of bursts).  All pointers are
+ * device pointers; `stream` is a hipStream_t (NULL = default stream).  Each can sit behind a BRICK-shaped
+ * adapter (include/sora_brick.hpp) where the SSE brick sits today.
+ * ------------------------------------------------------------------------------------------------ */
+/* TFFT64  (Brick11/src/fft.hpp:108-135 -> core/inc/fft_r4dif.h FFT<64>): IPORT COMPLEX16x64 -> OPORT COMPLEX16x64 */
+int sora_hip_fft64(const sora_complex16* d_in, sora_complex16* d_out, size_t n, void* stream);
+/* T11aDemap<N_BPSC>::Filter (demapper11a.hpp:10-79): IPORT COMPLEX16x64 -> OPORT uchar x 48*n_bpsc */
+int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream);
+/* T11aDeinterleave{BPSK,QPSK,QAM16,QAM64} (deinterleaver.hpp): IPORT uchar x N_CBPS -> OPORT uchar x N_CBPS */
+int sora_hip_deinterleave11a(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, size_t n, void* stream);
+/* T11aViterbi<5000*8,48,256,24>::Filter (viterbi.hpp:103-237) over n frames: frame i reads nsoft[i] soft values at
+ * d_soft + soft_off[i] and writes frame_len[i]+2 decoded bytes at d_out + out_off[i]. */
+int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const uint32_t* d_nsoft,
+                        const uint16_t* d_frame_len, int code_rate, uint8_t* d_out, const uint32_t* d_out_off,
+                        size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Small device-memory helpers so a pure-C host needs no HIP headers.
+ * ------------------------------------------------------------------------------------------------ */
+int   sora_hip_device_count(void);
+void* sora_hip_malloc(size_t bytes);
+void  sora_hip_free(void* d_ptr);
+int   sora_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
+int   sora_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int   sora_hip_abi_version(void);
+const char* sora_hip_last_error(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SORA_HIP_H */

@@ -1,0 +1,7 @@
+"""sora_amd -- MI355X-native 802.11a receive PHY behind Sora's BRICK operator shapes.
+
+The product is sora_amd/lib/libsora_hip.so (hand-written HIP for gfx950, C ABI in include/sora_hip.h);
+this package is the thin Python binding used by the tests and bench.py.  There is no CPU compute path.
+"""
+from .capi import (Rx, SoraError, device_count, load, lib_path, fft64, demap11a, deinterleave11a, viterbi11a,  # noqa: F401
+                   E_FRAME_OK, E_CRC32_FAIL, E_PLCP_HEADER_FAIL)

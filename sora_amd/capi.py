@@ -1,0 +1,220 @@
+"""ctypes binding of the C ABI in include/sora_hip.h (libsora_hip.so).
+
+This is plumbing only: device memory comes from torch (or sora_hip_malloc), all compute is the HIP library.
+The wrapper mirrors the reference harness: `Rx.process(...)` = RxThread over a batch of captures,
+`Rx.results()` = the frames TBB11aFrameSink reported.  Nothing here falls back to a CPU implementation:
+if the library or a GPU is missing, calls raise.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import build as _build
+
+SORA_OK = 0
+E_FRAME_OK = 0x1
+E_PLCP_HEADER_FAIL = 0x80000005
+E_CRC32_FAIL = 0x80000006
+ERR_NO_DEVICE = -5
+ERR_CAPACITY = -6
+
+
+class SoraError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("sora_hip error %d (0x%08X): %s" % (code, code & 0xFFFFFFFF, msg))
+        self.code = code
+
+
+class RxCfg(ctypes.Structure):
+    _fields_ = [("struct_size", ctypes.c_uint32), ("device", ctypes.c_int32), ("sample_rate_mhz", ctypes.c_uint32),
+                ("max_captures", ctypes.c_uint32), ("max_total_samples", ctypes.c_uint64),
+                ("max_frames_per_capture", ctypes.c_uint32), ("cca_pwr_threshold", ctypes.c_uint32)]
+
+
+class CaptureDesc(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_uint64), ("nsamples", ctypes.c_uint32), ("capture_id", ctypes.c_uint32)]
+
+
+class FrameResult(ctypes.Structure):
+    _fields_ = [("capture_id", ctypes.c_uint32), ("start_sample", ctypes.c_uint32), ("end_sample", ctypes.c_uint32),
+                ("error_code", ctypes.c_uint32), ("rate_kbps", ctypes.c_uint32), ("length", ctypes.c_uint16),
+                ("nsym", ctypes.c_uint16), ("crc32", ctypes.c_uint32), ("cfo_est", ctypes.c_int16),
+                ("reserved", ctypes.c_uint16), ("mpdu_offset", ctypes.c_uint32)]
+
+
+EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
+           "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
+           "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
+           "sora_rx_results_dev", "sora_hip_fft64", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a"]
+
+_lib = None
+
+
+def lib_path():
+    return _build.LIB
+
+
+def load(build_if_missing=True):
+    """Load libsora_hip.so (building it with hipcc if absent).  Raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if build_if_missing and _build.needs_build():
+        _build.build()
+    if not os.path.exists(_build.LIB):
+        raise SoraError(-1, "libsora_hip.so is missing and could not be built; there is no CPU fallback")
+    L = ctypes.CDLL(_build.LIB)
+    L.sora_hip_last_error.restype = ctypes.c_char_p
+    L.sora_hip_malloc.restype = ctypes.c_void_p
+    L.sora_hip_malloc.argtypes = [ctypes.c_size_t]
+    L.sora_hip_free.argtypes = [ctypes.c_void_p]
+    L.sora_hip_memcpy_h2d.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_hip_memcpy_d2h.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_rx_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
+    L.sora_rx_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx_destroy.restype = None
+    L.sora_rx_reset.argtypes = [ctypes.c_void_p]
+    L.sora_rx_flush.argtypes = [ctypes.c_void_p]
+    L.sora_rx_stream.argtypes = [ctypes.c_void_p]; L.sora_rx_stream.restype = ctypes.c_void_p
+    L.sora_rx_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
+    L.sora_rx_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
+    L.sora_rx_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                  ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_hip_fft64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_demap11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_deinterleave11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_viterbi11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                      ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    _lib = L
+    return L
+
+
+def _check(rc):
+    if rc != SORA_OK:
+        raise SoraError(rc, (load().sora_hip_last_error() or b"").decode())
+
+
+def device_count():
+    return load().sora_hip_device_count()
+
+
+def _dev_ptr(x):
+    """Device pointer of a torch CUDA tensor (or an int address)."""
+    if isinstance(x, int):
+        return x
+    if hasattr(x, "data_ptr"):
+        if not x.is_cuda:
+            raise ValueError("expected a device (HBM) tensor")
+        if not x.is_contiguous():
+            raise ValueError("expected a contiguous tensor")
+        return x.data_ptr()
+    raise TypeError("expected a torch CUDA tensor or an integer device address")
+
+
+class Rx:
+    """sora_rx_t: the 802.11a demod graph over a batch of captures."""
+
+    def __init__(self, max_captures, max_total_samples, sample_rate_mhz=20, device=0, max_frames_per_capture=2,
+                 cca_pwr_threshold=0):
+        L = load()
+        cfg = RxCfg(ctypes.sizeof(RxCfg), device, sample_rate_mhz, max_captures, max_total_samples,
+                    max_frames_per_capture, cca_pwr_threshold)
+        h = ctypes.c_void_p()
+        _check(L.sora_rx_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h; self._L = L; self.cfg = cfg; self._keep = None
+
+    def close(self):
+        if self._h:
+            self._L.sora_rx_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    @property
+    def stream(self):
+        return self._L.sora_rx_stream(self._h)
+
+    @staticmethod
+    def _caps(captures):
+        arr = (CaptureDesc * len(captures))()
+        for i, c in enumerate(captures):
+            off, n = c[0], c[1]
+            arr[i] = CaptureDesc(off, n, c[2] if len(c) > 2 else i)
+        return arr
+
+    def process_dev(self, d_iq, captures):
+        """d_iq: int16 torch CUDA tensor [N,2] (resident in HBM); captures: [(offset, nsamples[, id])]."""
+        arr = self._caps(captures)
+        self._keep = d_iq
+        _check(self._L.sora_rx_process_dev(self._h, _dev_ptr(d_iq), arr, len(captures)))
+
+    def process(self, h_iq, captures):
+        a = np.ascontiguousarray(h_iq, np.int16).reshape(-1, 2)
+        arr = self._caps(captures)
+        _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), arr, len(captures)))
+
+    def flush(self):
+        _check(self._L.sora_rx_flush(self._h))
+
+    def reset(self):
+        _check(self._L.sora_rx_reset(self._h))
+
+    def results(self, with_mpdu=True, max_frames=None):
+        if max_frames is None:
+            max_frames = self.cfg.max_captures * self.cfg.max_frames_per_capture
+        res = (FrameResult * max(1, max_frames))()
+        n = ctypes.c_size_t(0)
+        mp = np.zeros(max_frames * 2504 if with_mpdu else 1, np.uint8)
+        _check(self._L.sora_rx_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        out = []
+        for i in range(n.value):
+            r = res[i]
+            d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
+            if with_mpdu:
+                d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            out.append(d)
+        return out
+
+
+# ---- per-stage entry points on torch CUDA tensors ---------------------------------------------------
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        return torch.cuda.current_stream().cuda_stream
+    return stream
+
+
+def fft64(x, stream=None):
+    """TFFT64: x int16 CUDA tensor [n,64,2] -> same shape."""
+    import torch
+    out = torch.empty_like(x)
+    _check(load().sora_hip_fft64(_dev_ptr(x), _dev_ptr(out), x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def demap11a(x, n_bpsc, stream=None):
+    import torch
+    out = torch.empty((x.shape[0], 48 * n_bpsc), dtype=torch.uint8, device=x.device)
+    _check(load().sora_hip_demap11a(_dev_ptr(x), _dev_ptr(out), n_bpsc, x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def deinterleave11a(s, n_bpsc, stream=None):
+    import torch
+    out = torch.empty_like(s)
+    _check(load().sora_hip_deinterleave11a(_dev_ptr(s), _dev_ptr(out), n_bpsc, s.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def viterbi11a(soft, soft_off, nsoft, frame_len, code_rate, out_stride=2560, stream=None):
+    """soft: uint8 CUDA tensor; soft_off/nsoft: int32 CUDA tensors [n]; frame_len: int16 CUDA [n]."""
+    import torch
+    n = soft_off.shape[0]
+    out = torch.zeros((n, out_stride), dtype=torch.uint8, device=soft.device)
+    out_off = (torch.arange(n, device=soft.device, dtype=torch.int32) * out_stride).contiguous()
+    _check(load().sora_hip_viterbi11a(_dev_ptr(soft), _dev_ptr(soft_off), _dev_ptr(nsoft), _dev_ptr(frame_len), code_rate,
+                                      _dev_ptr(out), _dev_ptr(out_off), n, _stream_ptr(stream)))
+    return out

@@ -1,0 +1,136 @@
+// dev_arith.h -- device-side fixed-point primitives of the 802.11a RX path (gfx950).
+//
+// Each function is the single-element meaning of one SSE operator the reference's bricks are built
+// from (kernel/core/inc/vector128.h); the roles and line numbers are cited so parity can be audited.
+// A COMPLEX16 lives in two sign-extended 32-bit VGPRs (re, im): int16 wrap = v_bfe_i32,
+// int16 saturation = v_med3_i32.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace sora {
+
+struct cpx { int re, im; };                                   // values always within int16 range
+
+__device__ __forceinline__ int w16(int v) { return (int)(short)v; }                    // wrapping pack (vector128.h:876-883)
+__device__ __forceinline__ int sat16(int v) { return min(max(v, -32768), 32767); }     // _mm_adds/subs_epi16, packs
+__device__ __forceinline__ int neg16(int v) { return w16(-v); }                         // _mm_sign_epi16 by a negative: -(-32768) wraps
+__device__ __forceinline__ cpx mk(int re, int im) { cpx r; r.re = re; r.im = im; return r; }
+__device__ __forceinline__ cpx unpack(uint32_t u) { return mk((int)(short)(u & 0xFFFF), (int)u >> 16); }
+__device__ __forceinline__ uint32_t pack(cpx a) { return ((uint32_t)a.re & 0xFFFFu) | ((uint32_t)a.im << 16); }
+__device__ __forceinline__ cpx sra(cpx a, int n) { return mk(a.re >> n, a.im >> n); }  // shift_right(vcs)
+__device__ __forceinline__ cpx cadds(cpx a, cpx b) { return mk(sat16(a.re + b.re), sat16(a.im + b.im)); }
+__device__ __forceinline__ cpx csubs(cpx a, cpx b) { return mk(sat16(a.re - b.re), sat16(a.im - b.im)); }
+__device__ __forceinline__ cpx cnot(cpx a) { return mk(~a.re, ~a.im); }                // xor all-ones: -x-1
+__device__ __forceinline__ cpx mul_j(cpx a) { return mk(~a.im, a.re); }                // vector128.h:1258-1261 (approximate)
+
+// a*b, 32-bit parts: mul(vi&,vi&,a,b) vector128.h:1075-1081
+__device__ __forceinline__ void mul32(cpx a, cpx b, int& re, int& im)
+{
+    re = (int)((unsigned)(a.re * b.re) + (unsigned)(a.im * neg16(b.im)));
+    im = (int)((unsigned)(a.re * b.im) + (unsigned)(a.im * b.re));
+}
+// a*conj(b), 32-bit parts: conj_mul(vi&,vi&,a,b) vector128.h:1038-1044
+__device__ __forceinline__ void conj_mul32(cpx a, cpx b, int& re, int& im)
+{
+    re = (int)((unsigned)(a.re * b.re) + (unsigned)(a.im * b.im));
+    im = (int)((unsigned)(neg16(b.im) * a.re) + (unsigned)(b.re * a.im));
+}
+// vcs mul(a,b): Q15 product, wrapping pack (vector128.h:1201-1211) -- TFreqCompensation, TPhaseCompensate, TPilotTrack
+__device__ __forceinline__ cpx mul_q15(cpx a, cpx b)
+{
+    int re, im; mul32(a, b, re, im);
+    return mk(w16(re >> 15), w16(im >> 15));
+}
+// mul_shift(a,b,15): FFT twiddle product with the xor-approximated conjugate (vector128.h:1235-1246)
+__device__ __forceinline__ cpx mul_shift15(cpx a, cpx b)
+{
+    int v0 = (int)((unsigned)(a.re * b.re) + (unsigned)(a.im * (int)(short)~b.im));
+    int v1 = (int)((unsigned)(a.re * b.im) + (unsigned)(a.im * b.re));
+    return mk(w16(v0 >> 15), w16(v1 >> 15));
+}
+__device__ __forceinline__ int sqnorm(cpx a) { return (int)((unsigned)(a.re * a.re) + (unsigned)(a.im * a.im)); }   // SquaredNorm
+
+// ---------------------------------------------------------------------------------------------
+// Tables living in HBM/L2 (uploaded once per handle by the host side).
+struct Tables {
+    const short*    usin;        // [65536]  core/inc/intalglut.h usin_lut
+    const short*    ucos;        // [65536]
+    const short*    uatan2;      // [256*256]
+    const uint8_t*  demap;       // [4][256]  bpsk, qam16_2, qam64_2, qam64_3 (demapper.h:55-130)
+    const uint32_t* tw64;        // [3][16] packed W64^{k j}, k=1,2,3   (fft_lut_twiddle.h:61433-61504)
+    const uint32_t* tw16;        // [3][4]  packed W16^{k j}
+    const uint32_t* sts;         // [16][16] packed STS correlation patterns (cca.hpp:268-277)
+    const uint16_t* deint;       // [4][288] de-interleaver source index per output position (BPSK,QPSK,QAM16,QAM64)
+    const uint32_t* crc;         // [256]
+    const uint8_t*  scr;         // [128]
+};
+
+// uatan2 (core/inc/intalg.h:100-113): highest set bit of |y|,|x| -> common shift -> 256x256 LUT
+__device__ __forceinline__ int bit_scope(int v) { unsigned a = (unsigned)(v > 0 ? v : -v); return a ? 31 - __clz(a) : 0; }
+__device__ __forceinline__ int uatan2(const Tables& T, int y, int x)
+{
+    int ys = bit_scope(y), xs = bit_scope(x);
+    int shift = max(xs, ys) - 6;
+    if (shift > 0) { y >>= shift; x >>= shift; }
+    return (int)T.uatan2[((unsigned)y & 0xFF) * 256 + ((unsigned)x & 0xFF)];
+}
+__device__ __forceinline__ cpx rot_coeff(const Tables& T, int th)        // (ucos(th), -usin(th)) with FP_RAD th
+{
+    unsigned i = (unsigned)th & 0xFFFFu;
+    return mk((int)T.ucos[i], w16(-(int)T.usin[i]));
+}
+
+// ---------------------------------------------------------------------------------------------
+// 64-point radix-4 DIF FFT (core/inc/fft_r4dif.h) for a group of 16 lanes, 4 points per lane, staged
+// through a 64-entry LDS slice `s` private to the group.  `e` = lane index within the group (0..15).
+// In: x[m] = point e+16m.  Out: y[q] = bin e+16q (natural order).  All lanes of the group must call.
+// SYNC is a barrier covering the group (block barrier, or nothing inside a single wave after a waitcnt).
+template <typename SYNC>
+__device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int e, const Tables& T, SYNC sync)
+{
+    sync();                                                                           // previous users of s[] are done
+    // stage N=64: butterfly e on points e, e+16, e+32, e+48   (FFTSSE<64>, fft_r4dif.h:11-47)
+    {
+        cpx a = sra(x[0], 2), b = sra(x[1], 2), c = sra(x[2], 2), d = sra(x[3], 2);
+        cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
+        cpx jb = mul_j(b_d);
+        s[e]      = pack(cadds(ac, bd));
+        s[e + 16] = pack(mul_shift15(csubs(ac, bd),  unpack(T.tw64[16 + e])));      // W64^{2e}
+        s[e + 32] = pack(mul_shift15(csubs(a_c, jb), unpack(T.tw64[e])));           // W64^{e}
+        s[e + 48] = pack(mul_shift15(cadds(a_c, jb), unpack(T.tw64[32 + e])));      // W64^{3e}
+    }
+    sync();
+    // stage N=16 on quarter k: butterfly i on points 16k+i+{0,4,8,12}   (FFTSSE<16>)
+    {
+        const int k = e >> 2, i = e & 3, base = 16 * k + i;
+        cpx a = sra(unpack(s[base]), 2), b = sra(unpack(s[base + 4]), 2), c = sra(unpack(s[base + 8]), 2), d = sra(unpack(s[base + 12]), 2);
+        cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
+        cpx jb = mul_j(b_d);
+        s[base]      = pack(cadds(ac, bd));                                           // in place: same lane, same slots
+        s[base + 4]  = pack(mul_shift15(csubs(ac, bd),  unpack(T.tw16[4 + i])));
+        s[base + 8]  = pack(mul_shift15(csubs(a_c, jb), unpack(T.tw16[i])));
+        s[base + 12] = pack(mul_shift15(cadds(a_c, jb), unpack(T.tw16[8 + i])));
+    }
+    sync();
+    // terminal 4-point stage on points 4e..4e+3   (FFTSSEEx<4>, fft_r4dif.h:60-83)
+    {
+        cpx c0 = sra(unpack(s[4 * e]), 2), c1 = sra(unpack(s[4 * e + 1]), 2), c2 = sra(unpack(s[4 * e + 2]), 2), c3 = sra(unpack(s[4 * e + 3]), 2);
+        cpx A0 = cadds(c0, c2), A1 = cadds(c1, c3);
+        cpx B0 = cadds(cnot(c2), c0), B1 = cadds(cnot(c3), c1);
+        cpx B1r = mk(B1.im, ~B1.re);                                                   // ~ -j*B1
+        s[4 * e]     = pack(cadds(A0, A1));
+        s[4 * e + 1] = pack(cadds(cnot(A1), A0));
+        s[4 * e + 2] = pack(cadds(B0, B1r));
+        s[4 * e + 3] = pack(cadds(cnot(B1r), B0));
+    }
+    sync();
+    // bit-reversed reorder (FFT64LUTMap, fft_lut_bitreversal.h:76-142): bin j <- slot bitrev6(j)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const unsigned j = (unsigned)(e + 16 * q);
+        y[q] = unpack(s[__brev(j) >> 26]);
+    }
+}
+
+}  // namespace sora

@@ -1,0 +1,404 @@
+// k_scan.hip -- per-capture front end: carrier sense + frame synchronisation + LTS + SIGNAL decode.
+//
+// One wave64 per capture walks the sample stream exactly the way the reference's source thread does
+// (kernel/bb/demod11/fb11a_demod.cpp:29-81 driving CreateDemodGraph11a_40M, fb11ademod_config.hpp:168-233):
+// 28 raw samples per TMemSamples::Process() call, 4-sample bursts through
+//   TDownSample2 -> TBB11bRxSwitch -> [TDCRemoveEx -> TCCA11a -> TDCEstimator] | [T11aLTS | T11aDataSymbol ...]
+// with the error_code test after every source call.  The carrier-sense state machine is inherently serial
+// and runs wave-uniform; the per-frame work it triggers (T11aLTS: CFO estimate, frequency shift, FFT<64>,
+// channel inverse; the SIGNAL symbol: FFT<64>, equalise, pilot track, BPSK demap, de-interleave, 24-step
+// Viterbi, parse) is spread over the 64 lanes.  Output: the frame table, per-frame contexts and the
+// symbol-slot map that the batched per-symbol kernels consume.  Data symbols are NOT decoded here.
+//
+// Capture contract: nsamples is a whole number of source bursts (28 raw samples @40 MHz / 14 @20 MHz) --
+// true of every Sora dump (RX_BLOCK = 28 samples, core/inc/_rx_manager.h:96-137); a trailing partial burst
+// is ignored (the reference would run it padded with stale pin-queue memory, memsource.hpp:99-107).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace sora {
+
+struct Acc4 { int e[4]; int idx; int reg; };           // CMovingWindow<int,4> + CAccumulator (dspalg.hpp:5-98)
+__device__ __forceinline__ void acc_clear(Acc4& a) { a.e[0] = a.e[1] = a.e[2] = a.e[3] = 0; a.idx = 0; a.reg = 0; }
+__device__ __forceinline__ void acc_push(Acc4& a, int d)
+{
+    int old = a.idx == 0 ? a.e[0] : a.idx == 1 ? a.e[1] : a.idx == 2 ? a.e[2] : a.e[3];
+    a.reg = (int)((unsigned)a.reg + (unsigned)d - (unsigned)old);
+    if (a.idx == 0) a.e[0] = d; else if (a.idx == 1) a.e[1] = d; else if (a.idx == 2) a.e[2] = d; else a.e[3] = d;
+    a.idx = (a.idx + 1) & 3;
+}
+
+__device__ __forceinline__ int wave_sum(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = (int)((unsigned)v + (unsigned)__shfl_xor(v, o));
+    return v;
+}
+
+// LTS_Sequence_11a (channel_11a.hpp:13-18): 1 -> +norm_one, 0 -> -norm_one
+__device__ __constant__ uint8_t kLtsSeq[64] = {
+    0,1,0,0,1,1,0,1,0,1,0,0,0,0,0,1, 1,0,0,1,0,1,0,1,1,1,1,0,0,0,0,0,
+    0,0,0,0,0,0,1,1,0,0,1,1,0,1,0,1, 1,1,1,1,1,0,0,1,1,0,1,0,1,1,1,1 };
+
+// data carrier k (0..47) -> FFT bin, in demap order -26..-1, +1..+26 without pilots (demapper11a.hpp:20-37)
+__device__ __forceinline__ int carrier_bin(int k)
+{
+    // negative half: bins 38..63 without 43, 57 ; positive half: bins 1..26 without 7, 21
+    if (k < 24) { int b = 38 + k; if (b >= 43) b++; if (b >= 57) b++; return b; }
+    int b = 1 + (k - 24); if (b >= 7) b++; if (b >= 21) b++; return b;
+}
+
+__global__ void __launch_bounds__(64) k_scan(ScanArgs A)
+{
+    const uint32_t cap_i = blockIdx.x;
+    if (cap_i >= A.ncaps) return;
+    const int lane = threadIdx.x;
+    const CapDesc cd = A.caps[cap_i];
+    const uint32_t* iq = A.iq + cd.offset;
+    const uint32_t STR = A.str, APP = 28 / (2 / STR), BUR = 8 / (2 / STR);
+    const uint32_t nunits = (cd.nsamples / APP) * APP;
+    const Tables& T = A.T;
+    __shared__ uint32_t s_fft[64];
+    __shared__ uint32_t s_x[144];
+    __shared__ uint8_t  s_soft[48];
+
+    // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
+    uint32_t his[4][4];                      // sample_his: 4 bursts of 4 packed samples (already >>2)
+    int his_idx = 0;
+    Acc4 ac_re, ac_im, energy;
+    uint32_t auto_count = 0, sense_count = 0, high_count = 0; int sync_high = 0, peak_corr = 0, peak_index = 0;
+    uint32_t dc_cnt = 8; int sum_dc_re = 0, sum_dc_im = 0;            // TDCEstimator (dc.hpp:92-166); all 4 lanes of the vcs are equal
+    int dc_re = 0, dc_im = 0;                                          // CF_VecDC (survives frame resets)
+    // ---- context
+    uint32_t error_code = 0; int cca_detected = 0, symbol_is_data = 0, plcp_is_data = 0;
+    uint32_t lts_n = 0, sym_n = 0, lts_start = 0, sym_start = 0, frame_start = 0;
+    uint32_t remain_symbols = 0, sym_idx = 0;
+    uint32_t nfr = 0;
+    FrameRow row;                                                       // being assembled (uniform)
+
+    auto cs_reset = [&]() {
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) his[a][b] = 0;
+        his_idx = 0; acc_clear(ac_re); acc_clear(ac_im); acc_clear(energy);
+        auto_count = sense_count = high_count = 0; sync_high = 0; peak_corr = 0; peak_index = 0;
+        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
+    };
+    auto frame_reset = [&]() {
+        error_code = 0; cca_detected = 0; symbol_is_data = 0; plcp_is_data = 0;
+        lts_n = sym_n = 0; remain_symbols = 0; sym_idx = 0;
+        cs_reset();
+    };
+    cs_reset();
+    auto sync = []() { __syncthreads(); };
+
+    // GetCrossCorrelation (cca.hpp:202-218) for pattern p, history read from slot k
+    auto cross_corr = [&](int k, int p) -> int {
+        int sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
+#pragma unroll
+        for (int v = 0; v < 4; v++) {
+            const int kk = (k + v) & 3;
+#pragma unroll
+            for (int e = 0; e < 4; e++) {
+                uint32_t h = kk == 0 ? his[0][e] : kk == 1 ? his[1][e] : kk == 2 ? his[2][e] : his[3][e];
+                int re, im; conj_mul32(unpack(T.sts[p * 16 + 4 * v + e]), unpack(h), re, im);
+                sre[e] = (int)((unsigned)sre[e] + (unsigned)re); sim[e] = (int)((unsigned)sim[e] + (unsigned)im);
+            }
+        }
+        int r = (int)((unsigned)sre[0] + (unsigned)sre[1] + (unsigned)sre[2] + (unsigned)sre[3]);
+        int i = (int)((unsigned)sim[0] + (unsigned)sim[1] + (unsigned)sim[2] + (unsigned)sim[3]);
+        return abs(r) + abs(i);
+    };
+
+    uint32_t vpos = 0;                              // next burst start, in queue units
+    const uint32_t nchunks = nunits / APP;
+    for (uint32_t c = 0; c < nchunks && nfr < A.max_frames; c++) {
+        const uint32_t avail_end = (c + 1) * APP;
+        while (vpos + BUR <= avail_end) {
+            const uint32_t pos20 = vpos / STR;
+            if (!cca_detected) {
+                // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
+                uint32_t raw[4]; cpx pi[4];
+#pragma unroll
+                for (int e = 0; e < 4; e++) { raw[e] = iq[vpos + e * STR]; cpx x = unpack(raw[e]); pi[e] = mk(w16(x.re - dc_re), w16(x.im - dc_im)); }
+                if (!sync_high) {
+                    cpx pii[4];
+#pragma unroll
+                    for (int e = 0; e < 4; e++) pii[e] = sra(pi[e], 2);
+                    int sr = 0, si = 0, se = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        uint32_t h = his_idx == 0 ? his[0][e] : his_idx == 1 ? his[1][e] : his_idx == 2 ? his[2][e] : his[3][e];
+                        int re, im; conj_mul32(pii[e], unpack(h), re, im);
+                        sr = (int)((unsigned)sr + (unsigned)(re >> 4)); si = (int)((unsigned)si + (unsigned)(im >> 4));
+                        se = (int)((unsigned)se + (unsigned)(sqnorm(pii[e]) >> 4));
+                    }
+                    acc_push(ac_re, sr); acc_push(ac_im, si);
+                    const int iAuto = abs(ac_re.reg) + abs(ac_im.reg);
+                    acc_push(energy, se);
+                    const int iEnergy = energy.reg;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        uint32_t pk = pack(pii[e]);
+                        if (his_idx == 0) his[0][e] = pk; else if (his_idx == 1) his[1][e] = pk; else if (his_idx == 2) his[2][e] = pk; else his[3][e] = pk;
+                    }
+                    his_idx = (his_idx + 1) & 3;
+                    sense_count += 4;
+                    if (iEnergy > (int)A.thr && iAuto >= iEnergy - (iEnergy >> 3)) {
+                        auto_count++; sense_count = 0;
+                        if (auto_count >= 4) {
+                            // establish_sync (cca.hpp:220-243): lanes 0..15 take one pattern each
+                            int corr = cross_corr(his_idx, lane & 15);
+                            int sum_corr = 0, best = 0, best_i = 0;
+#pragma unroll
+                            for (int p = 0; p < 16; p++) {
+                                int cp = __shfl(corr, p);
+                                if (cp > best) { best = cp; best_i = p; }
+                                sum_corr += cp;
+                            }
+                            peak_corr = best; if (best > 0) peak_index = best_i;
+                            if (peak_corr > (sum_corr >> 3)) {
+                                sync_high = 1; high_count = 0;
+                                if (peak_index > 3) { high_count = (uint32_t)peak_index / 4; peak_index &= 3; }
+                            }
+                        }
+                    } else {
+                        auto_count = 0;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 4; e++) {
+                        uint32_t pk = pack(sra(pi[e], 2));
+                        if (his_idx == 0) his[0][e] = pk; else if (his_idx == 1) his[1][e] = pk; else if (his_idx == 2) his[2][e] = pk; else his[3][e] = pk;
+                    }
+                    his_idx = (his_idx + 1) & 3;
+                    high_count++;
+                    if (high_count % 4 == 0) {
+                        int corr = cross_corr(his_idx, peak_index);               // check_sync (cca.hpp:245-265)
+                        bool ok;
+                        if (corr < (peak_corr >> 1)) ok = false; else { if (corr > peak_corr) peak_corr = corr; ok = true; }
+                        if (!ok) {
+                            if (high_count > 8) { cca_detected = 1; frame_start = pos20 + 4; }
+                            else { sync_high = 0; sense_count = 0; }
+                        }
+                    }
+                }
+                if (!sync_high) {
+                    int hr = 0, hi = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; e++) { hr = w16(hr + (pi[e].re >> 5)); hi = w16(hi + (pi[e].im >> 5)); }
+                    sum_dc_re = w16(sum_dc_re + hr); sum_dc_im = w16(sum_dc_im + hi);
+                    if (dc_cnt == 0) {
+                        dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
+                        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
+                    }
+                    dc_cnt--;
+                }
+                if (sense_count >= 84 && !sync_high) error_code = E_CS_TIMEOUT;     // cca.hpp:433-437
+            } else if (!symbol_is_data) {
+                // ================= T11aLTS: IPORT COMPLEX16 x 144 (channel_11a.hpp:206-229)
+                if (lts_n == 0) lts_start = vpos;
+                lts_n += 4;
+                if (lts_n == 144) {
+                    lts_n = 0; symbol_is_data = 1;
+                    // stage the 144 samples (20 MHz rate) in LDS
+                    for (int i = lane; i < 144; i += 64) s_x[i] = iq[lts_start + (uint32_t)i * STR];
+                    sync();
+                    // x[n] = s_x[8+n]; first 64 are >>1 (rep_shift_right<16>, :216)
+                    cpx x1 = sra(unpack(s_x[8 + lane]), 1);
+                    cpx x2 = unpack(s_x[8 + 64 + lane]);
+                    int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
+                    const int sum_re = wave_sum(re >> 5), sum_im = wave_sum(im >> 5);
+                    const int arg = uatan2(T, sum_im, sum_re);
+                    const int cfo = w16(arg / 64);
+                    // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
+                    const cpx fc = rot_coeff(T, w16(lane * cfo));
+                    FrameCtx* fx = A.fctx + (size_t)cap_i * A.max_frames + nfr;
+                    fx->freq[lane] = pack(fc);
+                    cpx xs = mul_q15(x1, fc);                                     // FrequencyShift (:120)
+                    sync();
+                    s_x[lane] = pack(xs);
+                    sync();
+                    // FFT<64> on lanes 0..15
+                    cpx Y[4];
+                    {
+                        const int e = lane & 15;
+                        cpx xin[4];
+#pragma unroll
+                        for (int m = 0; m < 4; m++) xin[m] = unpack(s_x[e + 16 * m]);
+                        fft64_group(xin, Y, s_fft, e, T, sync);                    // all lanes call (barriers); results identical per 16-lane group
+                    }
+                    // lane L (0..63) takes bin L: Y of group lane (L&15), register (L>>4)
+                    {
+                        cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
+                        uint32_t coef = 0;
+                        if (!(lane >= 28 && lane < 36)) {                          // _channel_estimation (:125-178)
+                            const int e = sqnorm(Yb) >> 8;
+                            const cpx L = mk(kLtsSeq[lane] ? 1600 : -1600, 0);
+                            int cre, cim; conj_mul32(L, Yb, cre, cim);
+                            int rre = 0, rim = 0;
+                            if (e != 0) { rre = cre / e; rim = cim / e; }
+                            coef = pack(mk(w16(rre), w16(rim)));
+                        }
+                        fx->chan[lane] = coef;
+                    }
+                    row.cfo_est = (int16_t)cfo;
+                    __threadfence_block();
+                    sync();
+                }
+            } else {
+                // ================= T11aDataSymbol: IPORT COMPLEX16 x 80 (PHY_11a.hpp:389-428)
+                if (sym_n == 0) sym_start = vpos;
+                sym_n += 4;
+                if (sym_n == 80) {
+                    sym_n = 0;
+                    if (sym_idx == 0) {
+                        // ---- the SIGNAL symbol: full header chain, lane-parallel
+                        FrameCtx* fx = A.fctx + (size_t)cap_i * A.max_frames + nfr;
+                        const int e = lane & 15;
+                        cpx xin[4], Y[4];
+#pragma unroll
+                        for (int m = 0; m < 4; m++) {                              // skip CP 8, >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+                            const int n = e + 16 * m;
+                            cpx x = sra(unpack(iq[sym_start + (uint32_t)(8 + n) * STR]), 1);
+                            xin[m] = mul_q15(x, unpack(fx->freq[n]));
+                        }
+                        fft64_group(xin, Y, s_fft, e, T, sync);
+                        cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
+                        cpx eq = mk(0, 0);
+                        if (!(lane >= 28 && lane < 36)) {                          // TChannelEqualization (channel_11a.hpp:548-574)
+                            int re, im; mul32(Yb, unpack(fx->chan[lane]), re, im);
+                            eq = mk(w16(re >> 8), w16(im >> 8));
+                        }
+                        const uint32_t slot0 = cd.slot_base + (sym_start / STR) / 80;
+                        A.eq[(size_t)slot0 * 64 + lane] = pack(eq);
+                        // TPhaseCompensate with the reset CompCoeffs (0x7fff, 0) (ieee80211facade.hpp:198-206)
+                        cpx pc = mul_q15(eq, mk(0x7fff, 0));
+                        sync();
+                        s_fft[lane] = pack(pc);
+                        sync();
+                        // _pilot_track (pilot.hpp:166-233), symbol_count = 127 -> PilotSgn[127] = 0
+                        cpx p43 = unpack(s_fft[43]), p57 = unpack(s_fft[57]), p7 = unpack(s_fft[7]), p21 = unpack(s_fft[21]);
+                        const int th1 = uatan2(T, p43.im, p43.re), th2 = uatan2(T, p57.im, p57.re);
+                        const int th3 = uatan2(T, p7.im, p7.re),   th4 = uatan2(T, -p21.im, -p21.re);
+                        const int avg = w16((th1 + th2 + th3 + th4) / 4);
+                        const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+                        const int cfo_tracker = w16(avg >> 2), sfo_tracker = w16(del >> 2);
+                        const int cfo_comp = w16(avg + cfo_tracker), sfo_comp = w16(del + sfo_tracker);
+                        // T11aDemapBPSK on the rotated carriers -> T11aDeinterleaveBPSK
+                        if (lane < 48) {
+                            const int bin = carrier_bin(lane);
+                            const int cidx = bin < 32 ? bin : bin - 64;            // signed carrier number
+                            cpx r = mul_q15(unpack(s_fft[bin]), rot_coeff(T, w16(avg + cidx * del)));
+                            int v = r.re >> 4; v = min(max(v, -128), 127);         // demap_limit (demapper.h:141-151)
+                            s_soft[lane] = T.demap[(unsigned)v & 0xFF];
+                        }
+                        sync();
+                        uint8_t sa = 0, sb = 0;                                     // de-interleaved soft pair of trellis step t = lane (t < 24)
+                        if (lane < 24) { sa = s_soft[T.deint[2 * lane]]; sb = s_soft[T.deint[2 * lane + 1]]; }
+                        // ---- Viterbi_sig11 (viterbicore.h:35-261): lane = state
+                        const int n = lane;
+                        const int r0 = n, r1 = 64 | n;
+                        const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
+                        const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
+                        unsigned m = (n == 0) ? 0u : 0x30u;
+                        uint64_t dec[25];
+                        dec[0] = 0;
+#pragma unroll
+                        for (int t = 1; t <= 24; t++) {
+                            const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
+                            const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
+                            const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
+                            const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
+                            const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
+                            m = min(c0, c1);
+                            dec[t] = __ballot(m & 1);
+                            if ((t & 7) == 0) {
+                                unsigned mn = m;
+#pragma unroll
+                                for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+                                m = (m - (mn & 0xFE)) & 0xFF;
+                            }
+                        }
+                        // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
+                        unsigned key = (m << 8) | ((unsigned)n << 2), kmin = key;
+#pragma unroll
+                        for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+                        int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+                        uint32_t sig = 0;
+#pragma unroll
+                        for (int b = 0; b < 24; b++) {
+                            // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
+                            sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
+                            pos = (pos >> 1) & 0x3F;
+                            pos |= (int)((dec[23 - b] >> pos) & 1) << 6;
+                        }
+                        sig >>= 6;                                                  // viterbi.hpp:39
+                        // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
+                        bool ok = true;
+                        sig &= 0xFFFFFF;
+                        if (sig & 0xFC0010) ok = false;
+                        uint32_t par = (sig >> 16) ^ sig; par = (par >> 8) ^ par; par = (par >> 4) ^ par; par = (par >> 2) ^ par; par = (par >> 1) ^ par;
+                        if (par & 1) ok = false;
+                        uint32_t kbps = 0; int nd = 0, nb = 0, cr = 0;
+                        switch (sig & 0xF) {                                        // ieee80211a_cmn.h:97-107, :65-94, :114-149
+                        case 0x8: kbps = 48000; nd = 192; nb = 6; cr = 1; break;  case 0x9: kbps = 24000; nd = 96;  nb = 4; cr = 0; break;
+                        case 0xA: kbps = 12000; nd = 48;  nb = 2; cr = 0; break;  case 0xB: kbps = 6000;  nd = 24;  nb = 1; cr = 0; break;
+                        case 0xC: kbps = 54000; nd = 216; nb = 6; cr = 2; break;  case 0xD: kbps = 36000; nd = 144; nb = 4; cr = 2; break;
+                        case 0xE: kbps = 18000; nd = 72;  nb = 2; cr = 2; break;  case 0xF: kbps = 9000;  nd = 36;  nb = 1; cr = 2; break;
+                        default: ok = false; break;
+                        }
+                        const uint32_t len = (sig >> 5) & 0xFFF;
+                        if (len > 2500) ok = false;
+                        row.capture = cap_i; row.start_sample = frame_start; row.slot0 = slot0; row.data_start = sym_start / STR;
+                        row.cfo_comp = (int16_t)cfo_comp; row.sfo_comp = (int16_t)sfo_comp;
+                        row.cfo_tracker = (int16_t)cfo_tracker; row.sfo_tracker = (int16_t)sfo_tracker;
+                        row.crc32 = 0; row.valid = 1; row.pad[0] = row.pad[1] = row.pad[2] = 0;
+                        if (ok) {
+                            const uint32_t ns = (len * 8 + 16 + 6 + (uint32_t)nd - 1) / (uint32_t)nd;   // B11aGetSymbolCount
+                            row.rate_kbps = kbps; row.length = (uint16_t)len; row.nsym = (uint16_t)ns;
+                            row.code_rate = (uint16_t)cr; row.nbpsc = (uint16_t)nb; row.error_code = 0;
+                            remain_symbols = ns + 1; plcp_is_data = 1;
+                        } else {
+                            row.rate_kbps = 0; row.length = 0; row.nsym = 0; row.code_rate = 0; row.nbpsc = 0;
+                            error_code = E_PLCP_HEADER_FAIL;
+                        }
+                        sync();
+                    }
+                    sym_idx++;
+                    remain_symbols = (remain_symbols - 1) & 0xFFFF;                // ushort (PHY_11a.hpp:405)
+                    if (remain_symbols == 0 && plcp_is_data) {
+                        // all data symbols are in: the Viterbi sub-graph will raise FRAME_OK / CRC32_FAIL
+                        row.end_sample = pos20 + 4;
+                        error_code = E_FRAME_OK;                                    // provisional: "frame complete"
+                    }
+                }
+            }
+            vpos += BUR;
+        }
+        // ---- RxThread bookkeeping after each source call (fb11a_demod.cpp:37-71)
+        if (error_code != 0) {
+            if (error_code == E_CS_TIMEOUT) {
+                error_code = 0; cca_detected = 0; cs_reset();
+            } else {
+                if (error_code == E_PLCP_HEADER_FAIL) { row.end_sample = vpos / STR; row.error_code = E_PLCP_HEADER_FAIL; }
+                else {
+                    row.error_code = 0;                                             // pending: decided by k_finish
+                    // register the frame's symbol slots
+                    for (uint32_t s = lane; s <= row.nsym; s += 64) {
+                        A.slot_frame[row.slot0 + s] = (int32_t)(cap_i * A.max_frames + nfr);
+                        A.slot_sym[row.slot0 + s] = (uint16_t)s;
+                    }
+                }
+                if (lane == 0) A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
+                nfr++;
+                vpos = avail_end;                                                   // Flush + Reset drop the queued tail
+                frame_reset();
+            }
+        }
+    }
+    if (lane == 0) A.nframes[cap_i] = nfr;
+}
+
+}  // namespace sora

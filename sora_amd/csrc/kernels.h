@@ -1,0 +1,60 @@
+// kernels.h -- argument blocks and declarations of the receive-path kernels (shared by host and device code).
+#pragma once
+#include <hip/hip_runtime.h>
+#include "dev_arith.h"
+#include "rx_types.h"
+
+namespace sora {
+
+struct ScanArgs {
+    const uint32_t* iq;         // packed COMPLEX16
+    const CapDesc*  caps;
+    uint32_t        ncaps;
+    uint32_t        str;        // 2: 40 MHz input (keep even samples), 1: 20 MHz input
+    uint32_t        thr;        // cca_pwr_threshold
+    uint32_t        max_frames; // per capture
+    Tables          T;
+    FrameRow*       frames;     // [ncaps*max_frames]
+    FrameCtx*       fctx;
+    uint32_t*       nframes;    // [ncaps]
+    int32_t*        slot_frame; // [total slots]
+    uint16_t*       slot_sym;
+    uint32_t*       eq;         // [total slots][64]: the SIGNAL symbol's equalised bins are stored too
+};
+
+struct RxArgs {
+    const uint32_t* iq;
+    const CapDesc*  caps;
+    uint32_t        str;
+    uint32_t        total_slots;
+    uint32_t        nrows;          // ncaps*max_frames
+    Tables          T;
+    FrameRow*       frames;
+    const FrameCtx* fctx;
+    const int32_t*  slot_frame;
+    const uint16_t* slot_sym;
+    uint32_t*       eq;             // [slots][64]
+    TrackRec*       track;          // [slots]
+    uint8_t*        soft;           // [slots*288]
+    uint64_t*       dec;            // [slots*216]
+    uint32_t*       tbk;            // [nrows][kMaxWindows][3] : col, look|cnt<<16, pos|ob<<8
+    uint32_t*       nwin;           // [nrows]
+    uint8_t*        vout;           // [slots*32]
+    uint8_t*        mpdu;           // [slots*32]
+    VitJob*         jobs;           // [nrows]
+};
+
+__global__ void k_scan(ScanArgs A);
+__global__ void k_sym_front(RxArgs A);
+__global__ void k_track(RxArgs A);
+__global__ void k_demap(RxArgs A);
+__global__ void k_viterbi(const VitJob* jobs, uint32_t njobs, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin);
+__global__ void k_traceback(const VitJob* jobs, uint32_t njobs, const uint64_t* dec, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out);
+__global__ void k_finish(RxArgs A);
+__global__ void k_fft64_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
+__global__ void k_demap_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n, Tables T);
+__global__ void k_deint_batch(const uint8_t* in, uint8_t* out, int nb, uint32_t n, Tables T);
+__global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
+                               const uint32_t* out_off, const uint32_t* dec_off, int code_rate, uint32_t n);
+
+}  // namespace sora

@@ -1,0 +1,76 @@
+// rx_types.h -- device-resident data layout of one sora_rx_process call (shared by host and kernels).
+//
+// HBM layout (all arrays allocated once per handle, sized by sora_rx_cfg):
+//   iq            input captures, COMPLEX16, read once per stage that needs them
+//   caps[]        per capture {offset, nsamples, id, slot_base}
+//   frames[]      frame table, max_frames_per_capture rows per capture, filled by k_scan in time order
+//   fctx[]        per frame: FreqCoeffs[64] + ChannelCoeffs[64] (CF_FreqCompensate / CF_Channel_11a)
+//   slot_frame[]  per 80-sample symbol slot: owning frame row or -1; slot_sym[]: symbol index in frame
+//   eq[]          per slot: 64 equalised COMPLEX16 (output of TChannelEqualization)
+//   track[]       per slot: {CFO_comp, SFO_comp, avgTheta, delTheta} for TPhaseCompensate/TPilotTrack
+//   soft[]        per frame: de-interleaved soft values, contiguous (frame base = slot0*288)
+//   dec[]         per frame: survivor decisions, one 64-bit word per trellis column (frame base = slot0*216)
+//   tbk[]         per frame: trace-back start states of the T11aViterbi window schedule
+//   vout[]        per frame: Viterbi output bytes (length+2), base = slot0*32
+//   mpdu[]        per frame: descrambled MPDU, base = slot0*32 (same geometry as vout)
+//   rows[]        compacted sora_frame_result rows + counter
+#pragma once
+#include <stdint.h>
+
+namespace sora {
+
+struct CapDesc {
+    uint64_t offset;        // samples from iq base
+    uint32_t nsamples;      // input-rate samples
+    uint32_t capture_id;
+    uint32_t slot_base;     // first symbol slot of this capture
+    uint32_t nslots;        // floor(n20/80)+1
+};
+
+struct FrameRow {           // 64 bytes
+    uint32_t capture;       // index into caps[]
+    uint32_t start_sample;  // 20 MHz-rate index of the first sample given to T11aLTS
+    uint32_t end_sample;
+    uint32_t error_code;    // 0: pending data decode; PLCP_HEADER_FAIL; later FRAME_OK / CRC32_FAIL
+    uint32_t rate_kbps;
+    uint16_t length, nsym;
+    uint16_t code_rate, nbpsc;
+    uint32_t slot0;         // symbol slot of the SIGNAL symbol; data symbol s (1-based) is slot0+s
+    uint32_t crc32;
+    int16_t  cfo_est;
+    int16_t  cfo_comp, sfo_comp, cfo_tracker, sfo_tracker;   // pilot-tracking state after SIGNAL
+    uint16_t valid;
+    uint32_t data_start;    // 20 MHz-rate index of the first sample of the SIGNAL symbol (80-sample window)
+    uint32_t pad[3];
+};
+
+struct FrameCtx {           // 512 bytes
+    uint32_t freq[64];      // packed COMPLEX16 FreqCoeffs
+    uint32_t chan[64];      // packed COMPLEX16 ChannelCoeffs
+};
+
+struct VitJob {             // one Viterbi decode: a frame of the RX path or one job of sora_hip_viterbi11a
+    uint32_t soft_off;      // bytes from the soft base (4-byte aligned)
+    uint32_t nsoft;
+    uint32_t length;        // frame_length (decoded bytes = length+2)
+    uint32_t dec_off;       // 64-bit words from the decision base
+    uint32_t out_off;       // bytes from the output base
+    uint32_t valid;
+    uint32_t code_rate;
+    uint32_t pad;
+};
+
+struct TrackRec {           // per data-symbol slot
+    int16_t cfo_comp, sfo_comp;   // CompCoeffs of THIS symbol = build_coeff(cfo_comp, sfo_comp)
+    int16_t avg, del;             // rotation applied by TPilotTrack to THIS symbol
+};
+
+constexpr int kSoftPerSlot = 288;      // N_CBPS max
+constexpr int kDecPerSlot  = 216;      // trellis columns per symbol max (N_DBPS)
+constexpr int kOutPerSlot  = 32;       // decoded bytes per symbol max 27 -> 32
+constexpr int kMaxWindows  = 80;       // ceil((2500*8+16)/256)+1
+
+constexpr uint32_t E_FRAME_OK = 0x00000001u, E_PLCP_HEADER_FAIL = 0x80000005u, E_CRC32_FAIL = 0x80000006u,
+                   E_CS_TIMEOUT = 0x80000007u;
+
+}  // namespace sora

@@ -1,0 +1,467 @@
+// sora_hip.cpp -- host side of libsora_hip.so: the C ABI of include/sora_hip.h.
+//
+// Owns, per handle: one HIP stream, the look-up tables in HBM, and every intermediate array of the
+// receive path (sized once from sora_rx_cfg, see rx_types.h).  There is NO CPU compute path here:
+// every entry point either enqueues HIP kernels or fails.
+#include <hip/hip_runtime.h>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "../../include/sora_hip.h"
+#include "kernels.h"
+
+using namespace sora;
+
+static thread_local std::string g_last_error;
+static int fail(int code, const char* what, hipError_t e = hipSuccess)
+{
+    char buf[256];
+    if (e != hipSuccess) snprintf(buf, sizeof(buf), "%s: %s", what, hipGetErrorString(e));
+    else snprintf(buf, sizeof(buf), "%s", what);
+    g_last_error = buf;
+    return code;
+}
+#define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, #call, _e); } while (0)
+
+// ------------------------------------------------------------------------------------------------
+// Look-up tables, regenerated from closed forms (each was checked entry-for-entry against the reference
+// header it replaces; tests/test_capi_tables.py pins their checksums through sora_hip_table_checksum).
+struct HostTables {
+    std::vector<int16_t> usin, ucos, uatan2;
+    std::vector<uint8_t> demap;
+    std::vector<uint32_t> tw64, tw16, sts, crc;
+    std::vector<uint16_t> deint;
+    std::vector<uint8_t> scr;
+};
+
+static inline uint32_t pk(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
+
+// host-side reference IFFT<64> is NOT needed: the STS pattern is the fixed-point IFFT of a constant
+// vector, computed once below with the same integer butterflies as the device FFT (conjugate form).
+namespace hostfft {
+struct c { int re, im; };
+static inline int w16(int v) { return (int)(short)v; }
+static inline int sat(int v) { return v > 32767 ? 32767 : (v < -32768 ? -32768 : v); }
+static inline c mk(int r, int i) { c x; x.re = r; x.im = i; return x; }
+static inline c sra(c a, int n) { return mk(a.re >> n, a.im >> n); }
+static inline c adds(c a, c b) { return mk(sat(a.re + b.re), sat(a.im + b.im)); }
+static inline c subs(c a, c b) { return mk(sat(a.re - b.re), sat(a.im - b.im)); }
+static inline c cnot(c a) { return mk(~a.re, ~a.im); }
+static inline c conj_mul_shift15(c a, c b)      // a*conj(b)>>15 (vector128.h:1215-1231)
+{
+    int v0 = (int)((unsigned)(a.re * b.re) + (unsigned)(a.im * b.im));
+    int v1 = (int)((unsigned)(a.im * b.re) + (unsigned)(w16(-a.re) * b.im));
+    return mk(w16(v0 >> 15), w16(v1 >> 15));
+}
+static void stage(c* x, int n, const std::vector<c>* tw)     // IFFTSSE<N> (ifft_r4dif.h:11-47)
+{
+    const int q = n / 4;
+    for (int e = 0; e < q; e++) {
+        c a = sra(x[e], 2), b = sra(x[e + q], 2), cc = sra(x[e + 2 * q], 2), d = sra(x[e + 3 * q], 2);
+        c ac = adds(a, cc), bd = adds(b, d), a_c = subs(a, cc), b_d = subs(b, d);
+        c jb = mk(~b_d.im, b_d.re);
+        x[e] = adds(ac, bd);
+        x[e + q] = conj_mul_shift15(subs(ac, bd), tw[1][e]);
+        x[e + 2 * q] = conj_mul_shift15(adds(a_c, jb), tw[0][e]);
+        x[e + 3 * q] = conj_mul_shift15(subs(a_c, jb), tw[2][e]);
+    }
+}
+static void t4(c* x)                                          // IFFTSSEEx<4> (ifft_r4dif.h:60-83)
+{
+    c s0 = sra(x[0], 2), s1 = sra(x[1], 2), s2 = sra(x[2], 2), s3 = sra(x[3], 2);
+    c A0 = adds(s0, s2), A1 = adds(s1, s3), B0 = adds(cnot(s2), s0), B1 = adds(cnot(s3), s1);
+    c B1r = mk(~B1.im, B1.re);
+    x[0] = adds(A0, A1); x[1] = adds(cnot(A1), A0); x[2] = adds(B0, B1r); x[3] = adds(cnot(B1r), B0);
+}
+}  // namespace hostfft
+
+static void build_tables(HostTables& H)
+{
+    const double GEN_PI = 3.141593;                      // the constant the reference's table generator used
+    H.usin.resize(65536); H.ucos.resize(65536); H.uatan2.resize(65536);
+    for (int i = 0; i < 65536; i++) {                    // core/inc/intalglut.h:4,3648
+        double x = (double)i * GEN_PI / 32768.0;
+        H.usin[i] = (int16_t)std::floor(32767.0 * std::sin(x) + 0.5);
+        H.ucos[i] = (int16_t)std::floor(32767.0 * std::cos(x) + 0.5);
+    }
+    for (int yi = 0; yi < 256; yi++)                     // core/inc/intalglut.h:7332
+        for (int xi = 0; xi < 256; xi++) {
+            int t = (int)(std::atan2((double)(int8_t)yi, (double)(int8_t)xi) * 32768.0 / GEN_PI);
+            H.uatan2[yi * 256 + xi] = (int16_t)(t > 32767 ? 32767 : t);
+        }
+    // DemapperCore step functions (Brick11/src/demapper.h:55-130): {first input value, soft value}
+    struct St { int at, val; };
+    static const St bpsk[] = {{-128,0},{-30,1},{-17,2},{-8,3},{0,4},{9,5},{18,6},{31,7}};
+    static const St q16[]  = {{-128,0},{-70,1},{-67,2},{-65,3},{-63,4},{-61,5},{-58,6},{-55,7},{56,6},{59,5},{62,4},{64,3},{66,2},{68,1},{71,0}};
+    static const St q64a[] = {{-128,0},{-68,1},{-65,2},{-63,3},{-61,4},{-60,5},{-58,6},{-55,7},{56,6},{59,5},{61,4},{62,3},{64,2},{66,1},{69,0}};
+    static const St q64b[] = {{-128,0},{-98,1},{-96,2},{-94,3},{-92,4},{-90,5},{-89,6},{-86,7},{-37,6},{-34,5},{-32,4},{-30,3},{-29,2},{-27,1},{-24,0},
+                              {25,1},{28,2},{30,3},{31,4},{33,5},{35,6},{38,7},{87,6},{90,5},{91,4},{93,3},{95,2},{97,1},{99,0}};
+    H.demap.assign(1024, 0);
+    auto gen = [&](int w, const St* st, int n) {
+        for (int v = -128; v < 128; v++) { int val = 0; for (int k = 0; k < n; k++) if (v >= st[k].at) val = st[k].val; H.demap[w * 256 + (uint8_t)v] = (uint8_t)val; }
+    };
+    gen(0, bpsk, 8); gen(1, q16, 15); gen(2, q64a, 15); gen(3, q64b, 29);
+    // twiddles (core/inc/fft_lut_twiddle.h): trunc(32767 cos), trunc(-32767 sin)
+    const double PI = 3.14159265358979323846;
+    std::vector<hostfft::c> t64[3], t16[3];
+    H.tw64.resize(48); H.tw16.resize(12);
+    for (int k = 1; k <= 3; k++) {
+        for (int j = 0; j < 16; j++) { double a = 2 * PI * k * j / 64.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a)); H.tw64[(k - 1) * 16 + j] = pk(re, im); t64[k - 1].push_back(hostfft::mk(re, im)); }
+        for (int j = 0; j < 4; j++)  { double a = 2 * PI * k * j / 16.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a)); H.tw16[(k - 1) * 4 + j] = pk(re, im);  t16[k - 1].push_back(hostfft::mk(re, im)); }
+    }
+    // STS correlation patterns: Generate80211aSTS<64> (brick/inc/sequence.h:5-33) + cca.hpp:268-277
+    {
+        hostfft::c f[64]; for (auto& v : f) v = hostfft::mk(0, 0);
+        const int M = 10000;
+        auto set = [&](int i, int s) { f[i] = hostfft::mk(s * M, s * M); };
+        set(4, -1); set(8, -1); set(12, 1); set(16, 1); set(20, 1); set(24, 1);
+        set(64 - 24, 1); set(64 - 20, -1); set(64 - 16, 1); set(64 - 12, -1); set(64 - 8, -1); set(64 - 4, 1);
+        hostfft::stage(f, 64, t64);
+        for (int k = 0; k < 4; k++) hostfft::stage(f + 16 * k, 16, t16);
+        for (int k = 0; k < 16; k++) hostfft::t4(f + 4 * k);
+        hostfft::c t[64];
+        for (int i = 0; i < 64; i++) { int r = 0; for (int b = 0; b < 6; b++) r |= ((i >> b) & 1) << (5 - b); t[i] = f[r]; }
+        H.sts.resize(256);
+        for (int p = 0; p < 16; p++) for (int i = 0; i < 16; i++) H.sts[p * 16 + i] = pk(t[p + i].re, t[p + i].im);
+    }
+    // de-interleaver (Brick11/src/deinterleaver.hpp = inverse of interleave.hpp:43-47): out[k] = in[j(k)]
+    H.deint.assign(4 * 288, 0);
+    const int nbs[4] = {1, 2, 4, 6};
+    for (int d = 0; d < 4; d++) {
+        const int nb = nbs[d], N = 48 * nb, s = nb / 2 > 1 ? nb / 2 : 1;
+        for (int k = 0; k < N; k++) { int i = (N / 16) * (k % 16) + k / 16; int j = s * (i / s) + (i + N - (16 * i) / N) % s; H.deint[d * 288 + k] = (uint16_t)j; }
+    }
+    H.crc.resize(256);
+    for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1; H.crc[i] = c; }
+    H.scr.resize(128);
+    for (int i = 0; i < 128; i++) { uint8_t x = (uint8_t)(i << 1); for (int k = 0; k < 8; k++) { uint8_t o1 = ((x >> 1) ^ (x >> 4)) & 1; x = (uint8_t)((x >> 1) | (o1 << 7)); } H.scr[i] = x; }
+}
+
+struct DevTables {
+    Tables T{};
+    std::vector<void*> allocs;
+    int device = -1;
+};
+
+template <typename V>
+static int upload(DevTables& D, const V& v, const void** out)
+{
+    void* p = nullptr;
+    const size_t bytes = v.size() * sizeof(v[0]);
+    HIPCHK(hipMalloc(&p, bytes));
+    D.allocs.push_back(p);
+    HIPCHK(hipMemcpy(p, v.data(), bytes, hipMemcpyHostToDevice));
+    *out = p;
+    return SORA_OK;
+}
+
+static int make_dev_tables(DevTables& D)
+{
+    HostTables H; build_tables(H);
+    int rc;
+    if ((rc = upload(D, H.usin, (const void**)&D.T.usin))) return rc;
+    if ((rc = upload(D, H.ucos, (const void**)&D.T.ucos))) return rc;
+    if ((rc = upload(D, H.uatan2, (const void**)&D.T.uatan2))) return rc;
+    if ((rc = upload(D, H.demap, (const void**)&D.T.demap))) return rc;
+    if ((rc = upload(D, H.tw64, (const void**)&D.T.tw64))) return rc;
+    if ((rc = upload(D, H.tw16, (const void**)&D.T.tw16))) return rc;
+    if ((rc = upload(D, H.sts, (const void**)&D.T.sts))) return rc;
+    if ((rc = upload(D, H.deint, (const void**)&D.T.deint))) return rc;
+    if ((rc = upload(D, H.crc, (const void**)&D.T.crc))) return rc;
+    if ((rc = upload(D, H.scr, (const void**)&D.T.scr))) return rc;
+    return SORA_OK;
+}
+static void free_dev_tables(DevTables& D) { for (void* p : D.allocs) (void)hipFree(p); D.allocs.clear(); }
+
+// per-device tables for the stand-alone stage entry points
+static DevTables* stage_tables()
+{
+    static DevTables* tabs[64] = {nullptr};
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    if (!tabs[dev]) {
+        DevTables* D = new DevTables();
+        if (make_dev_tables(*D) != SORA_OK) { free_dev_tables(*D); delete D; return nullptr; }
+        D->device = dev; tabs[dev] = D;
+    }
+    return tabs[dev];
+}
+
+// ------------------------------------------------------------------------------------------------
+struct sora_rx {
+    sora_rx_cfg cfg{};
+    hipStream_t stream = nullptr;
+    DevTables tabs;
+    uint32_t str = 1;
+    // capacities
+    uint32_t cap_slots = 0, cap_rows = 0;
+    // device arrays
+    CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
+    int32_t* d_slot_frame = nullptr; uint16_t* d_slot_sym = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr;
+    uint8_t* d_soft = nullptr; uint64_t* d_dec = nullptr; uint32_t* d_tbk = nullptr; uint32_t* d_nwin = nullptr;
+    uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; VitJob* d_jobs = nullptr;
+    sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
+    sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
+    // last call
+    std::vector<CapDesc> h_caps;
+    uint32_t ncaps = 0, total_slots = 0;
+    bool have_results = false;
+};
+
+static void rx_free(sora_rx* rx)
+{
+    if (!rx) return;
+    void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes, rx->d_slot_frame, rx->d_slot_sym, rx->d_eq, rx->d_track,
+                     rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin, rx->d_vout, rx->d_mpdu, rx->d_jobs, rx->d_iq_own, rx->d_rows, rx->d_nrows };
+    for (void* p : ptrs) if (p) (void)hipFree(p);
+    free_dev_tables(rx->tabs);
+    if (rx->stream) (void)hipStreamDestroy(rx->stream);
+    delete rx;
+}
+
+extern "C" {
+
+int sora_hip_abi_version(void) { return SORA_HIP_ABI_VERSION; }
+const char* sora_hip_last_error(void) { return g_last_error.c_str(); }
+
+int sora_hip_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+void* sora_hip_malloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
+void  sora_hip_free(void* p) { if (p) (void)hipFree(p); }
+int   sora_hip_memcpy_h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return SORA_OK; }
+int   sora_hip_memcpy_d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return SORA_OK; }
+
+int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(sora_rx_cfg)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_create: bad cfg");
+    if (cfg->sample_rate_mhz != 20 && cfg->sample_rate_mhz != 40) return fail(SORA_ERR_INVALID_PARAM, "sample_rate_mhz must be 20 or 40");
+    if (cfg->max_captures == 0 || cfg->max_total_samples == 0 || cfg->max_frames_per_capture == 0) return fail(SORA_ERR_INVALID_PARAM, "zero capacity");
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (cfg->device < 0 || cfg->device >= ndev) return fail(SORA_ERR_INVALID_PARAM, "device ordinal out of range");
+    HIPCHK(hipSetDevice(cfg->device));
+    sora_rx* rx = new sora_rx();
+    rx->cfg = *cfg;
+    if (rx->cfg.cca_pwr_threshold == 0) rx->cfg.cca_pwr_threshold = 1000 * 1000;
+    rx->str = cfg->sample_rate_mhz == 40 ? 2 : 1;
+    rx->tabs.device = cfg->device;
+    int rc = make_dev_tables(rx->tabs);
+    if (rc) { rx_free(rx); return rc; }
+    hipError_t e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "hipStreamCreate", e); }
+    const uint64_t n20 = cfg->max_total_samples / rx->str;
+    rx->cap_slots = (uint32_t)(n20 / 80 + cfg->max_captures + 16);
+    rx->cap_rows = cfg->max_captures * cfg->max_frames_per_capture;
+    struct { void** p; size_t bytes; } allocs[] = {
+        { (void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures }, { (void**)&rx->d_frames, sizeof(FrameRow) * rx->cap_rows },
+        { (void**)&rx->d_fctx, sizeof(FrameCtx) * rx->cap_rows }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
+        { (void**)&rx->d_slot_frame, 4 * (size_t)rx->cap_slots }, { (void**)&rx->d_slot_sym, 2 * (size_t)rx->cap_slots },
+        { (void**)&rx->d_eq, 256 * (size_t)rx->cap_slots }, { (void**)&rx->d_track, sizeof(TrackRec) * (size_t)rx->cap_slots },
+        { (void**)&rx->d_soft, (size_t)kSoftPerSlot * rx->cap_slots }, { (void**)&rx->d_dec, 8 * (size_t)kDecPerSlot * rx->cap_slots },
+        { (void**)&rx->d_tbk, 12 * (size_t)kMaxWindows * rx->cap_rows }, { (void**)&rx->d_nwin, 4 * (size_t)rx->cap_rows },
+        { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
+        { (void**)&rx->d_jobs, sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
+        { (void**)&rx->d_nrows, 4 },
+    };
+    for (auto& a : allocs) {
+        e = hipMalloc(a.p, a.bytes);
+        if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "hipMalloc (receive-path arrays)", e); }
+    }
+    *out = rx;
+    return SORA_OK;
+}
+
+void sora_rx_destroy(sora_rx_t* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); (void)hipStreamSynchronize(rx->stream); rx_free(rx); } }
+
+int sora_rx_reset(sora_rx_t* rx)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    HIPCHK(hipStreamSynchronize(rx->stream));
+    rx->ncaps = 0; rx->total_slots = 0; rx->have_results = false; rx->h_caps.clear();
+    return SORA_OK;
+}
+
+int sora_rx_flush(sora_rx_t* rx)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    HIPCHK(hipStreamSynchronize(rx->stream));
+    return SORA_OK;
+}
+
+void* sora_rx_stream(sora_rx_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+
+int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx || (!d_iq && ncaps) || (!caps && ncaps)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
+    if (ncaps > rx->cfg.max_captures) return fail(SORA_ERR_CAPACITY, "more captures than sora_rx_cfg.max_captures");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    rx->h_caps.resize(ncaps);
+    uint64_t total = 0; uint32_t slots = 0;
+    for (size_t i = 0; i < ncaps; i++) {
+        if (caps[i].offset & 3) return fail(SORA_ERR_INVALID_PARAM, "capture offset must be a multiple of 4 samples (16-byte alignment, memsource.hpp:59)");
+        CapDesc& c = rx->h_caps[i];
+        c.offset = caps[i].offset; c.nsamples = caps[i].nsamples; c.capture_id = caps[i].capture_id;
+        c.slot_base = slots; c.nslots = (caps[i].nsamples / rx->str) / 80 + 1;
+        slots += c.nslots; total += caps[i].nsamples;
+    }
+    if (total > rx->cfg.max_total_samples || slots > rx->cap_slots) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
+    rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
+    if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
+    hipStream_t st = rx->stream;
+    HIPCHK(hipMemcpyAsync(rx->d_caps, rx->h_caps.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, st));
+    HIPCHK(hipMemsetAsync(rx->d_slot_frame, 0xFF, 4 * (size_t)slots, st));
+    const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
+    HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
+
+    ScanArgs S{};
+    S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.thr = rx->cfg.cca_pwr_threshold;
+    S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
+    S.slot_frame = rx->d_slot_frame; S.slot_sym = rx->d_slot_sym; S.eq = rx->d_eq;
+    hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
+
+    RxArgs R{};
+    R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
+    R.frames = rx->d_frames; R.fctx = rx->d_fctx; R.slot_frame = rx->d_slot_frame; R.slot_sym = rx->d_slot_sym;
+    R.eq = rx->d_eq; R.track = rx->d_track; R.soft = rx->d_soft; R.dec = rx->d_dec; R.tbk = rx->d_tbk; R.nwin = rx->d_nwin;
+    R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs;
+    hipLaunchKernelGGL(k_sym_front, dim3((slots + 15) / 16), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(64), 0, st, R);
+    hipLaunchKernelGGL(k_demap, dim3((slots + 3) / 4), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_viterbi, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
+    hipLaunchKernelGGL(k_traceback, dim3(nrows), dim3(128), 0, st, (const VitJob*)rx->d_jobs, nrows, (const uint64_t*)rx->d_dec, (const uint32_t*)rx->d_tbk, (const uint32_t*)rx->d_nwin, rx->d_vout);
+    hipLaunchKernelGGL(k_finish, dim3((nrows + 63) / 64), dim3(64), 0, st, R);
+    HIPCHK(hipGetLastError());
+    rx->have_results = true;
+    return SORA_OK;
+}
+
+int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx || !h_iq) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process: null argument");
+    if (total_samples > rx->cfg.max_total_samples) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    if (rx->iq_own_samples < total_samples) {
+        if (rx->d_iq_own) (void)hipFree(rx->d_iq_own);
+        rx->d_iq_own = nullptr; rx->iq_own_samples = 0;
+        HIPCHK(hipMalloc((void**)&rx->d_iq_own, sizeof(sora_complex16) * (total_samples + 64)));
+        rx->iq_own_samples = total_samples;
+    }
+    HIPCHK(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * total_samples, hipMemcpyHostToDevice, rx->stream));
+    return sora_rx_process_dev(rx, rx->d_iq_own, caps, ncaps);
+}
+
+int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results: null argument");
+    *nout = 0;
+    if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
+    if (rx->ncaps == 0) return SORA_OK;
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    HIPCHK(hipStreamSynchronize(rx->stream));
+    const uint32_t mf = rx->cfg.max_frames_per_capture, nrows = rx->ncaps * mf;
+    std::vector<FrameRow> rows(nrows); std::vector<uint32_t> nfr(rx->ncaps);
+    HIPCHK(hipMemcpy(rows.data(), rx->d_frames, sizeof(FrameRow) * nrows, hipMemcpyDeviceToHost));
+    HIPCHK(hipMemcpy(nfr.data(), rx->d_nframes, 4 * (size_t)rx->ncaps, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> mp;
+    if (h_mpdu) { mp.resize((size_t)kOutPerSlot * rx->total_slots); HIPCHK(hipMemcpy(mp.data(), rx->d_mpdu, mp.size(), hipMemcpyDeviceToHost)); }
+    size_t n = 0, moff = 0; int rc = SORA_OK;
+    for (uint32_t c = 0; c < rx->ncaps; c++)
+        for (uint32_t i = 0; i < nfr[c] && i < mf; i++) {
+            const FrameRow& r = rows[(size_t)c * mf + i];
+            if (n >= max_out) { rc = SORA_ERR_CAPACITY; continue; }
+            sora_frame_result& o = out[n++];
+            o.capture_id = rx->h_caps[c].capture_id; o.start_sample = r.start_sample; o.end_sample = r.end_sample; o.error_code = r.error_code;
+            o.rate_kbps = r.rate_kbps; o.length = r.length; o.nsym = r.nsym; o.crc32 = r.crc32; o.cfo_est = r.cfo_est; o.reserved = 0; o.mpdu_offset = (uint32_t)moff;
+            if (h_mpdu && (r.error_code == E_FRAME_OK || r.error_code == E_CRC32_FAIL)) {
+                if (moff + r.length > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
+                memcpy(h_mpdu + moff, mp.data() + (size_t)r.slot0 * kOutPerSlot, r.length);
+                moff += r.length;
+            }
+        }
+    *nout = n;
+    if (rc != SORA_OK) return fail(rc, "sora_rx_results: output buffer too small");
+    return SORA_OK;
+}
+
+int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
+{
+    // Device-side packing (for the multi-GPU gather) is provided by sora_rx_pack_dev in a later revision;
+    // until then the sparse frame table is exposed through sora_rx_results only.
+    (void)rx; (void)d_rows; (void)d_nrows; (void)d_mpdu;
+    return fail(SORA_ERR_FAILED, "sora_rx_results_dev: not available in this build");
+}
+
+// ---- per-stage entry points
+int sora_hip_fft64(const sora_complex16* d_in, sora_complex16* d_out, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_fft64: null pointer");
+    if (n == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_fft64_batch, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_out), (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_soft || !(n_bpsc == 1 || n_bpsc == 2 || n_bpsc == 4 || n_bpsc == 6)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_demap11a: bad argument");
+    if (n == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_demap_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in), d_soft, n_bpsc, (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_deinterleave11a(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_out || !(n_bpsc == 1 || n_bpsc == 2 || n_bpsc == 4 || n_bpsc == 6)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_deinterleave11a: bad argument");
+    if (n == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_deint_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_bpsc, (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const uint32_t* d_nsoft, const uint16_t* d_frame_len,
+                        int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: bad argument");
+    if (n == 0) return SORA_OK;
+    hipStream_t st = (hipStream_t)stream;
+    // scratch: decisions (worst case 1/2-rate: nsoft/2+1 columns), window table, job table
+    std::vector<uint32_t> h_nsoft(n), h_dec_off(n);
+    HIPCHK(hipMemcpyAsync(h_nsoft.data(), d_nsoft, 4 * n, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    uint64_t words = 0;
+    for (size_t i = 0; i < n; i++) { h_dec_off[i] = (uint32_t)words; words += (uint64_t)h_nsoft[i] + 128; }
+    VitJob* jobs = nullptr; uint64_t* dec = nullptr; uint32_t* tbk = nullptr; uint32_t* nwin = nullptr; uint32_t* decoff = nullptr;
+    HIPCHK(hipMalloc((void**)&jobs, sizeof(VitJob) * n));
+    HIPCHK(hipMalloc((void**)&dec, 8 * words));
+    HIPCHK(hipMalloc((void**)&tbk, 12 * (size_t)kMaxWindows * n));
+    HIPCHK(hipMalloc((void**)&nwin, 4 * n));
+    HIPCHK(hipMalloc((void**)&decoff, 4 * n));
+    HIPCHK(hipMemcpyAsync(decoff, h_dec_off.data(), 4 * n, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, d_soft_off, d_nsoft, d_frame_len, d_out_off, (const uint32_t*)decoff, code_rate, (uint32_t)n);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (uint32_t)n, d_soft, dec, tbk, nwin);
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(128), 0, st, (const VitJob*)jobs, (uint32_t)n, (const uint64_t*)dec, (const uint32_t*)tbk, (const uint32_t*)nwin, d_out);
+    hipError_t e = hipStreamSynchronize(st);
+    (void)hipFree(jobs); (void)hipFree(dec); (void)hipFree(tbk); (void)hipFree(nwin); (void)hipFree(decoff);
+    if (e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_viterbi11a", e);
+    return SORA_OK;
+}
+
+}  // extern "C"

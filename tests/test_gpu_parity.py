@@ -1,0 +1,196 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the same
+inputs.  Integer/byte work throughout => bit-exact (tolerance 0 LSB on every intermediate that is compared)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import awgn, batch, make_capture, oracle_results, pad_capture, same_results
+from oracle.pyoracle import CR_12, CR_23, CR_34, E_FRAME_OK, RATES, rate_params
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def sora():
+    import sora_amd
+    sora_amd.load()
+    assert sora_amd.device_count() > 0
+    return sora_amd
+
+
+def run_rx(sora, torch, caps, rate_mhz, max_frames=4):
+    iq, descs = batch(caps)
+    rx = sora.Rx(max_captures=max(1, len(caps)), max_total_samples=max(64, len(iq)), sample_rate_mhz=rate_mhz,
+                 max_frames_per_capture=max_frames)
+    d = torch.from_numpy(iq).cuda()
+    rx.process_dev(d, descs)
+    res = rx.results()
+    rx.close()
+    return res
+
+
+# ------------------------------------------------------------------ stage kernels
+def test_fft64_bit_exact(sora, torch_cuda, oracle):
+    torch = torch_cuda
+    rng = np.random.default_rng(1)
+    n = 4099
+    amps = np.array([32767, 20000, 8000, 500, 30])[np.arange(n) % 5]
+    x = (rng.integers(-32768, 32768, size=(n, 64, 2)) % (2 * amps[:, None, None] + 1) - amps[:, None, None]).astype(np.int16)
+    x[7, 3] = (-32768, 32767); x[8] = 0; x[9] = 32767; x[10] = -32768
+    got = sora.fft64(torch.from_numpy(x).cuda()).cpu().numpy()
+    for i in range(0, n, 7):
+        assert np.array_equal(got[i], oracle.fft(x[i], 64)), i
+
+
+def test_demap_deinterleave_bit_exact(sora, torch_cuda, oracle):
+    torch = torch_cuda
+    rng = np.random.default_rng(2)
+    x = rng.integers(-3000, 3000, size=(257, 64, 2)).astype(np.int16)
+    x[0] = 32767; x[1] = -32768
+    for nb in (1, 2, 4, 6):
+        soft = sora.demap11a(torch.from_numpy(x).cuda(), nb)
+        de = sora.deinterleave11a(soft, nb).cpu().numpy(); soft = soft.cpu().numpy()
+        for i in range(len(x)):
+            want = oracle.demap(nb, x[i])
+            assert np.array_equal(soft[i], want)
+            assert np.array_equal(de[i], oracle.deinterleave(nb, want))
+
+
+@pytest.mark.parametrize("cr", [CR_12, CR_23, CR_34])
+def test_viterbi_bit_exact_on_noise(sora, torch_cuda, oracle, cr):
+    """Pure-noise and noisy-codeword soft streams: 8-bit wrapping metrics, LSB tie-breaks, window schedule."""
+    torch = torch_cuda
+    rng = np.random.default_rng(30 + cr)
+    per = {CR_12: 2, CR_23: 3, CR_34: 4}[cr]
+    lens = [1, 4, 30, 31, 32, 33, 36, 100, 1500, 2500, 257, 64]
+    softs, offs, ns = [], [], []
+    off = 0
+    for L in lens:
+        steps = L * 8 + 16 + 6 + 40
+        nsoft = int(np.ceil(steps * per / {CR_12: 1, CR_23: 2, CR_34: 3}[cr] / 48.0)) * 48
+        nsoft = (nsoft + per * 4 - 1) // (per * 4) * (per * 4)
+        s = rng.integers(0, 8, size=nsoft).astype(np.uint8)
+        h = nsoft // 2
+        s[:h] = np.clip(rng.choice([0, 7], size=h) + rng.integers(-3, 4, size=h), 0, 7)
+        softs.append(s); offs.append(off); ns.append(nsoft); off += nsoft + (-nsoft) % 4
+    buf = np.zeros(off + 64, np.uint8)
+    for s, o in zip(softs, offs):
+        buf[o:o + len(s)] = s
+    out = sora.viterbi11a(torch.from_numpy(buf).cuda(), torch.tensor(offs, dtype=torch.int32).cuda(),
+                          torch.tensor(ns, dtype=torch.int32).cuda(), torch.tensor(lens, dtype=torch.int16).cuda(), cr).cpu().numpy()
+    for i, L in enumerate(lens):
+        want = oracle.viterbi_frame(softs[i], cr, L)
+        assert len(want) == L + 2
+        assert np.array_equal(out[i, :L + 2], want), (cr, L)
+
+
+# ------------------------------------------------------------------ whole path
+def test_fsample6_golden(sora, torch_cuda, oracle, golden_dir):
+    """config[1]: the reference's only IQ dump, 6 Mbps, on the GPU; MPDU sha256 + FCS as pinned in SURVEY.md 8c."""
+    z = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))
+    iq = z["iq_i8"].astype(np.int16) << 8
+    assert len(iq) % 28 == 0
+    for rate_mhz, cap in ((40, iq), (20, pad_capture(iq[::2].copy(), 20))):
+        res = run_rx(sora, torch_cuda, [cap], rate_mhz)
+        assert len(res) == 1
+        r = res[0]
+        assert r["error_code"] == E_FRAME_OK and r["rate_kbps"] == 6000 and r["length"] == 1392 and r["nsym"] == 465
+        assert r["crc32"] == 0x80EF9B11
+        assert hashlib.sha256(r["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+        ok, why = same_results(res, oracle_results(oracle, [cap], rate_mhz))
+        assert ok, why
+
+
+@pytest.mark.parametrize("rate", RATES)
+def test_all_rates_clean_and_noisy(sora, torch_cuda, oracle, rate):
+    nb = rate_params(rate)[0]
+    sigma = {1: 2200, 2: 1500, 4: 700, 6: 330}[nb]
+    caps = []
+    for i, (L, sg, mhz_lead) in enumerate([(40, 0, 0), (300, sigma, 12), (1500, sigma, 28), (1, 0, 4), (2496, sigma // 2, 0)]):
+        c, _ = make_capture(oracle, rate, L, seed=rate + i, rate_mhz=40, sigma=sg, lead=mhz_lead)
+        caps.append(c)
+    got = run_rx(sora, torch_cuda, caps, 40)
+    want = oracle_results(oracle, caps, 40)
+    assert sum(r["error_code"] == E_FRAME_OK for r in want) >= 4
+    ok, why = same_results(got, want)
+    assert ok, why
+
+
+def test_20mhz_input(sora, torch_cuda, oracle):
+    caps = [make_capture(oracle, r, 200 + 10 * i, seed=i, rate_mhz=20, sigma=150, lead=8 * i)[0] for i, r in enumerate(RATES)]
+    got = run_rx(sora, torch_cuda, caps, 20)
+    ok, why = same_results(got, oracle_results(oracle, caps, 20))
+    assert ok, why
+    assert all(r["error_code"] == E_FRAME_OK for r in got) and len(got) == 8
+
+
+def test_cfo_and_heavy_noise(sora, torch_cuda, oracle):
+    caps = [make_capture(oracle, 24000, 400, seed=5, sigma=300, cfo_hz=40e3)[0],
+            make_capture(oracle, 54000, 800, seed=6, sigma=900)[0],          # CRC failure expected
+            make_capture(oracle, 6000, 100, seed=7, sigma=6000)[0],          # may not even sync
+            make_capture(oracle, 36000, 600, seed=8, sigma=500, cfo_hz=-60e3)[0]]
+    got = run_rx(sora, torch_cuda, caps, 40)
+    want = oracle_results(oracle, caps, 40)
+    ok, why = same_results(got, want)
+    assert ok, why
+    assert any(r["error_code"] != E_FRAME_OK for r in want)
+
+
+def test_multi_frame_and_edge_captures(sora, torch_cuda, oracle):
+    rng = np.random.default_rng(11)
+    parts = []
+    for i, rate in enumerate((54000, 6000, 36000, 48000)):
+        mp = rng.integers(0, 256, 200 + 100 * i).astype(np.uint8).tobytes()
+        parts.append(oracle.tx_capture(mp, rate, lead=0, tail=400 + 52 * i))
+    multi = pad_capture(awgn(np.concatenate(parts), 120, 3), 40)
+    silent = np.zeros((2800, 2), np.int16)
+    tiny = np.zeros((28, 2), np.int16)
+    trunc = pad_capture(oracle.tx_capture(bytes(1000), 12000)[:9000], 40)
+    overmtu = pad_capture(oracle.tx_capture(bytes(2497), 54000), 40)
+    caps = [multi, silent, tiny, trunc, overmtu]
+    got = run_rx(sora, torch_cuda, caps, 40, max_frames=8)
+    want = oracle_results(oracle, caps, 40)
+    ok, why = same_results(got, want)
+    assert ok, why
+    assert [r["capture_id"] for r in got].count(0) == 4
+
+
+def test_batch_of_frames_54mbps(sora, torch_cuda, oracle):
+    """A small version of config[2]: many independent 54 Mbps captures in one call."""
+    caps = [make_capture(oracle, 54000, 1500, seed=100 + i, rate_mhz=20, sigma=120 + 10 * (i % 7), lead=0, tail=160)[0] for i in range(48)]
+    got = run_rx(sora, torch_cuda, caps, 20, max_frames=2)
+    want = oracle_results(oracle, caps, 20)
+    ok, why = same_results(got, want)
+    assert ok, why
+    assert sum(r["error_code"] == E_FRAME_OK for r in got) >= 40
+
+
+def test_host_buffer_entry_point(sora, torch_cuda, oracle):
+    cap, mp = make_capture(oracle, 18000, 333, seed=2, rate_mhz=40, sigma=100)
+    rx = sora.Rx(1, len(cap), sample_rate_mhz=40)
+    rx.process(cap, [(0, len(cap), 77)])
+    res = rx.results()
+    assert len(res) == 1 and res[0]["capture_id"] == 77 and res[0]["mpdu"][:-4] == mp
+    rx.reset()
+    with pytest.raises(Exception):
+        rx.results()
+
+
+def test_capacity_errors(sora, torch_cuda):
+    rx = sora.Rx(1, 2800, sample_rate_mhz=40)
+    x = torch_cuda.zeros((5600, 2), dtype=torch_cuda.int16).cuda()
+    with pytest.raises(sora.SoraError):
+        rx.process_dev(x, [(0, 5600)])
+    with pytest.raises(sora.SoraError):
+        rx.process_dev(x, [(0, 1400), (1400, 1400)])
+    with pytest.raises(sora.SoraError):
+        rx.process_dev(x, [(2, 1400)])
