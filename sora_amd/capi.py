@@ -60,6 +60,13 @@ def load(build_if_missing=True):
     global _lib
     if _lib is not None:
         return _lib
+    # PyTorch-ROCm bundles its own libamdhip64 (same soname as /opt/rocm's).  Whichever copy is mapped first
+    # serves the whole process, and torch only initialises against its own: import torch BEFORE dlopen-ing
+    # libsora_hip.so so both share torch's runtime.  (A pure C host has no such concern.)
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if build_if_missing and _build.needs_build():
         _build.build()
     if not os.path.exists(_build.LIB):
