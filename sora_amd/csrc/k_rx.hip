@@ -71,14 +71,14 @@ __global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
 // only the 4 pilot bins take part.  One thread per frame, sequential over its data symbols.
 __global__ void __launch_bounds__(64) k_track(RxArgs A)
 {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= A.nrows) return;
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= *A.njobs) return;
+    const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
-    VitJob J; J.valid = 0; J.soft_off = 0; J.nsoft = 0; J.length = 0; J.dec_off = 0; J.out_off = 0; J.code_rate = 0; J.pad = 0;
-    if (!r.valid || r.error_code != 0) { A.jobs[f] = J; return; }
+    VitJob J; J.pad = 0;
     J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
     J.dec_off = r.slot0 * (uint32_t)kDecPerSlot; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
-    A.jobs[f] = J;
+    A.jobs[j] = J;
     const Tables& T = A.T;
     int cfo_comp = r.cfo_comp, sfo_comp = r.sfo_comp, cfo_tr = r.cfo_tracker, sfo_tr = r.sfo_tracker;
     unsigned symbol_count = 0;                                                 // 127 -> 0 after the SIGNAL symbol
@@ -154,134 +154,206 @@ __global__ void __launch_bounds__(256) k_demap(RxArgs A)
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_viterbi<CR>: forward add-compare-select of the K=7 (133,171) code exactly as TViterbiCore does it
-// (viterbicore.h:293-465): 8-bit WRAPPING path metrics, decision kept in the metric LSB (&0xFE / |1),
-// unsigned minimum, normalisation whenever (trellis_index & 7) == 0 after a puncture group, and the
-// window schedule of T11aViterbi<..,256,24>::Process (viterbi.hpp:189-214).  lane n = state n; the new
-// state n is reached from n>>1 (decision 0) or 32+(n>>1) (decision 1) -> two ds_bpermute per step.
-// Branch metric of soft value v for expected bit c is c ? 2*(7-v) : 2*v = (2v) ^ (c ? 14 : 0)  (VIT_MA/VIT_MB,
-// viterbilut.h:50-185); expected bits: parity((br<<6 | n) & 0155) for A, & 0117 for B.
-// The 64 decisions of a column are one wave ballot; 64 columns are gathered lane-wise and stored as
-// one coalesced 512-byte write.  At every scheduled trace-back the arg-min state (tie-break:
-// metric<<8 | state<<2, viterbicore.h:479-524) is recorded for k_traceback.
-struct VitCore {
-    unsigned m;             // path metric of state `lane` (low 8 bits)
-    int idx0, idx1;         // ds_bpermute byte addresses of the two predecessors
-    unsigned mA0, mB0, mA1, mB1;
+// k_viterbi: forward add-compare-select of the K=7 (133,171) code exactly as TViterbiCore does it
+// (viterbicore.h:293-465): 8-bit WRAPPING path metrics with the decision in the metric LSB (&0xFE / |1),
+// unsigned minimum, normalisation whenever (trellis_index & 7) == 0 after a puncture group, and the window
+// schedule of T11aViterbi<..,256,24>::Process (viterbi.hpp:189-214).
+//
+// Arithmetic.  A reference metric byte is m = 2u + d (d = decision mark).  Branch metrics are even, so
+//   c0 = (x0 + bm0) & 0xFE = 2((u0 + b0) mod 128),  c1 = ((x1 + bm1) & 0xFE) | 1 = 2((u1 + b1) mod 128) + 1,  b = bm/2
+//   min(c0, c1) picks c1 iff (u1 + b1) mod 128 < (u0 + b0) mod 128  (a tie keeps c0), and the new u is that minimum.
+// The kernel therefore carries U = u << 25 in a 32-bit VGPR: the 7-bit wrap is the natural 32-bit wrap, the
+// unsigned compare is a plain v_cmp_lt_u32, no masking at all.  Normalisation subtracts min(U) (= (min m & 0xFE)/2).
+// Branch metric of soft value v (0..7) for expected bit c: b = v ^ (c ? 7 : 0) (VIT_MA/VIT_MB, viterbilut.h:50-185,
+// halved); expected bits = parity((branch<<6 | n) & 0155) for A, & 0117 for B, n = new state.  Both generators
+// tap the oldest bit, so the decision-1 branch costs K - b0, K = 14 (7 on a punctured step).
+//
+// CDNA4 mapping.  wave64 = the 64 states, run as an in-place butterfly {p, p+32} -> {2p, 2p+1}: after t steps
+// lane L holds state rol6^t(L), and the two predecessors of its next state sit in lanes L and L ^ (32 >> (t mod 6)).
+// Every lane needs (x0, x1) = (metric of the pair member holding the decision-0 predecessor, the other one):
+//     t mod 6 = 0,1 : v_permlane32_swap / v_permlane16_swap (gfx950) return exactly that pair
+//     t mod 6 = 2,3 : two bank-masked DPP moves (row_ror:8 / row_shl:4 + row_shr:4)
+//     t mod 6 = 4,5 : quad_perm DPP operands folded into the two adds
+// i.e. ~9 VALU instructions per trellis step, no LDS, no ds_bpermute (a ds_bpermute formulation of the same
+// recurrence was bounded by the dependent LDS round trip: 3.4 ms for the 4096-frame batch).
+// Decisions: the compare result is carried into a per-lane history register with one v_addc (hist = 2 hist + d);
+// every 24 steps (4 butterfly cycles = 8 punctured groups at 3/4) the 64 lanes store their 24-bit histories as one
+// coalesced 256-byte row.  Soft values are prefetched 64 words at a time (one per lane), handed out with v_readlane and unpacked on the SALU.
+__device__ __forceinline__ unsigned rol6(unsigned v, unsigned r) { r %= 6; return ((v << r) | (v >> (6 - r))) & 63u; }
+
+__device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wide unsigned minimum, VALU latency only
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // ^1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // ^2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));   // row_ror:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));   // row_ror:8
+    auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min(r16[0], r16[1]);
+    auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min(r32[0], r32[1]);
+}
+
+struct VitLane {
+    unsigned U;              // u << 25 of the state this lane currently holds
+    unsigned hist;           // decisions of this lane, newest in bit 0
+    unsigned MA[6], MB[6];   // (expected bit ? 7 : 0) << 25 for the decision-0 branch into the lane's next state, per phase
 };
 
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+template <int PH, int WHICH>   // PH = t mod 6; WHICH 0: (A,B)  1: A only  2: B only.  a, b = soft value << 25 (wave-uniform)
+__device__ __forceinline__ void acs_bfly(VitLane& V, unsigned a, unsigned b)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = min(v, (unsigned)__shfl_xor((int)v, o));
-    return v;
+    constexpr unsigned K = (WHICH == 0 ? 14u : 7u) << 25;
+    unsigned b0;
+    if (WHICH == 0)      b0 = (a ^ V.MA[PH]) + (b ^ V.MB[PH]);
+    else if (WHICH == 1) b0 = a ^ V.MA[PH];
+    else                 b0 = b ^ V.MB[PH];
+    const unsigned b1 = K - b0;
+    unsigned x0, x1;
+    const int u = (int)V.U;
+    if (PH == 0)      { auto r = __builtin_amdgcn_permlane32_swap(V.U, V.U, false, false); x0 = r[0]; x1 = r[1]; }
+    else if (PH == 1) { auto r = __builtin_amdgcn_permlane16_swap(V.U, V.U, false, false); x0 = r[0]; x1 = r[1]; }
+    else if (PH == 2) { x0 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x128, 0xF, 0xC, false);      // lanes 8-15 of a row <- L-8
+                        x1 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x128, 0xF, 0x3, false); }    // lanes 0-7          <- L+8
+    else if (PH == 3) { x0 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x114, 0xF, 0xA, false);      // bit2 = 1 lanes <- L-4
+                        x1 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x104, 0xF, 0x5, false); }    // bit2 = 0 lanes <- L+4
+    else if (PH == 4) { x0 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x44, 0xF, 0xF, true);        // quad_perm [0,1,0,1]
+                        x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xEE, 0xF, 0xF, true); }      // quad_perm [2,3,2,3]
+    else              { x0 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xA0, 0xF, 0xF, true);        // quad_perm [0,0,2,2]
+                        x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xF5, 0xF, 0xF, true); }      // quad_perm [1,1,3,3]
+    const unsigned c0 = x0 + b0, c1 = x1 + b1;
+    const bool d = c1 < c0;
+    V.U = min(c0, c1);
+    V.hist = V.hist + V.hist + (d ? 1u : 0u);
 }
 
-template <int WHICH>    // 0: (A,B)  1: A only  2: B only
-__device__ __forceinline__ uint64_t acs_step(VitCore& V, unsigned a2, unsigned b2)
-{
-    const unsigned m0 = (unsigned)__builtin_amdgcn_ds_bpermute(V.idx0, (int)V.m);
-    const unsigned m1 = (unsigned)__builtin_amdgcn_ds_bpermute(V.idx1, (int)V.m);
-    unsigned bm0, bm1;
-    if (WHICH == 0)      { bm0 = (a2 ^ V.mA0) + (b2 ^ V.mB0); bm1 = (a2 ^ V.mA1) + (b2 ^ V.mB1); }
-    else if (WHICH == 1) { bm0 = a2 ^ V.mA0; bm1 = a2 ^ V.mA1; }
-    else                 { bm0 = b2 ^ V.mB0; bm1 = b2 ^ V.mB1; }
-    const unsigned c0 = (m0 + bm0) & 0xFEu;
-    const unsigned c1 = ((m1 + bm1) & 0xFFu) | 1u;
-    const bool d = c1 < c0;
-    V.m = d ? c1 : c0;
-    return __ballot(d);
-}
+constexpr int kColsPerRow = 24;            // trellis columns per stored 256-byte decision row
 
 template <int CR>
 __device__ __forceinline__ void viterbi_forward(const VitJob& J, const uint8_t* soft_base, uint64_t* dec_base, uint32_t* tbk, uint32_t* nwin_out)
 {
-    const int lane = threadIdx.x;
-    const uint32_t* soft = reinterpret_cast<const uint32_t*>(soft_base + J.soft_off);
-    uint64_t* dec = dec_base + J.dec_off;
+    const unsigned lane = threadIdx.x;
+    const uint32_t* __restrict__ soft = reinterpret_cast<const uint32_t*>(soft_base + J.soft_off);
+    uint32_t* decT = reinterpret_cast<uint32_t*>(dec_base + J.dec_off);
     const uint32_t nsoft = J.nsoft;
     const uint32_t tr_end = J.length * 8u + 16u + 6u;
 
-    VitCore V;
-    V.m = lane == 0 ? 0u : 0x30u;                                              // ALL_INIT0 / ALL_INIT (viterbilut.h:22-30)
-    V.idx0 = (lane >> 1) * 4; V.idx1 = (32 + (lane >> 1)) * 4;
-    V.mA0 = (__popc(lane & 0155) & 1) ? 14u : 0u;          V.mB0 = (__popc(lane & 0117) & 1) ? 14u : 0u;
-    V.mA1 = (__popc((64 | lane) & 0155) & 1) ? 14u : 0u;   V.mB1 = (__popc((64 | lane) & 0117) & 1) ? 14u : 0u;
-
-    constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft bytes per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
-    constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
-    constexpr int BLK = CR == 1 ? 192 : 256;                                    // soft bytes fetched per refill
-    constexpr int GPB = BLK / GB;                                               // groups per refill
+    VitLane V;
+    V.U = lane == 0 ? 0u : (0x18u << 25);                                      // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
+    V.hist = 0;
+#pragma unroll
+    for (int ph = 0; ph < 6; ph++) {
+        const unsigned n = rol6(lane, ph + 1);                                  // label held after a phase-ph step
+        V.MA[ph] = (__popc(n & 0155) & 1) ? (7u << 25) : 0u;
+        V.MB[ph] = (__popc(n & 0117) & 1) ? (7u << 25) : 0u;
+    }
 
     uint32_t tr = 0, ob = 0, nw = 0;
-    uint64_t mydec = 0;                                                         // decisions of column (64*j + lane)
-    if (lane == 0) dec[0] = 0;
     bool done = false;
-    const uint32_t ngroups = nsoft / GB;
-    for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += GPB) {
-        const uint32_t widx = (g0 * GB) / 4 + (uint32_t)lane;
-        uint32_t wv = 0;
-        if (widx * 4 < nsoft && lane < BLK / 4) wv = soft[widx];
-        const uint32_t gend = min((uint32_t)GPB, ngroups - g0);
-        for (uint32_t g = 0; g < gend; g++) {
-            unsigned a2, b2, c2 = 0, d2 = 0;
-            if (CR == 0) {
-                uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)(g >> 1));
-                w >>= (g & 1) * 16;
-                a2 = (w & 0xFF) * 2; b2 = ((w >> 8) & 0xFF) * 2;
-            } else if (CR == 2) {
-                uint32_t w = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)g);
-                a2 = (w & 0xFF) * 2; b2 = ((w >> 8) & 0xFF) * 2; c2 = ((w >> 16) & 0xFF) * 2; d2 = (w >> 24) * 2;
-            } else {
-                const uint32_t bo = g * 3;
-                uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)(bo >> 2));
-                uint32_t w1 = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)min((bo >> 2) + 1, 63u));
-                uint64_t ww = (((uint64_t)w1 << 32) | w0) >> ((bo & 3) * 8);
-                a2 = (unsigned)(ww & 0xFF) * 2; b2 = (unsigned)((ww >> 8) & 0xFF) * 2; c2 = (unsigned)((ww >> 16) & 0xFF) * 2;
-            }
-            // ---- the puncture group (viterbi.hpp:167-187)
-#pragma unroll
-            for (int s = 0; s < GS; s++) {
-                uint64_t bal;
-                if (s == 0) bal = acs_step<0>(V, a2, b2);
-                else if (s == 1) bal = acs_step<1>(V, c2, 0);
-                else bal = acs_step<2>(V, 0, d2);
-                tr++;
-                if ((tr & 63) == (uint32_t)lane) mydec = bal;
-                if ((tr & 63) == 63) dec[tr - 63 + lane] = mydec;               // columns tr-63 .. tr (lane j holds column with (col&63)==j)
-            }
-            if ((tr & 7) == 0) {                                                // Normalize (viterbicore.h:444-465)
-                const unsigned mn = wave_min_u32(V.m) & 0xFEu;
-                V.m = (V.m - mn) & 0xFFu;
-            }
-            // ---- trace-back schedule (viterbi.hpp:196-214)
-            uint32_t cnt = 0, look = 0;
+    uint32_t next_thr = min(tr_end, 256u + 24u + 6u);
+
+    auto normalize = [&]() { V.U -= dpp_min_u32_wave(V.U); };                   // Normalize (viterbicore.h:444-465)
+    auto check = [&]() {                                                        // trace-back schedule (viterbi.hpp:196-214)
+        if (tr >= next_thr) {
+            uint32_t cnt, look;
             if (tr >= tr_end) { cnt = tr_end - ob - 6; look = tr - tr_end; }
-            else if (tr >= ob + 256 + 24 + 6) { look = 24 + (tr - (ob + 256 + 24 + 6)) % 8; cnt = 256; }
-            if (cnt) {
-                const unsigned kmin = wave_min_u32((V.m << 8) | ((unsigned)lane << 2));
-                if (lane == 0) {
-                    tbk[nw * 3 + 0] = tr;
-                    tbk[nw * 3 + 1] = look | (cnt << 16);
-                    tbk[nw * 3 + 2] = ((kmin >> 2) & 0x3F) | (((kmin >> 8) & 1) << 6) | (ob << 8);
-                }
-                nw++; ob += cnt;
-                if (tr >= tr_end) { done = true; break; }
+            else { look = 24 + (tr - (ob + 256 + 24 + 6)) % 8; cnt = 256; }
+            // arg-min with the reference's tie-break: metric<<8 | state<<2 (viterbicore.h:479-524); metric = 2u + last decision
+            const unsigned mbyte = (V.U >> 24) | (V.hist & 1u);
+            const unsigned kmin = dpp_min_u32_wave((mbyte << 8) | (rol6(lane, tr) << 2));
+            if (lane == 0) {
+                tbk[nw * 3 + 0] = tr;
+                tbk[nw * 3 + 1] = look | (cnt << 16);
+                tbk[nw * 3 + 2] = ((kmin >> 2) & 0x3F) | (((kmin >> 8) & 1) << 6) | (ob << 8);
             }
+            nw++; ob += cnt;
+            if (tr >= tr_end) done = true;
+            next_thr = min(tr_end, ob + 256u + 24u + 6u);
+        }
+    };
+    auto sv = [](uint32_t w, int byte) -> unsigned { return ((w >> (8 * byte)) & 7u) << 25; };   // soft value -> branch-metric field
+
+    uint32_t row = 0;                                                           // decision rows written
+    if (CR == 2) {
+        // 3/4: { ACS(A,B), ACS(A), ACS(B) } per 4 soft values (viterbi.hpp:173-180); 8 groups = 24 steps per row
+        const uint32_t ngroups = nsoft / 4;
+        uint32_t wv = 0;                                                        // lane-parallel prefetch: 64 words = 8 rows of 8 groups
+        for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += 8) {
+            if ((g0 & 63) == 0) wv = (g0 + lane < ngroups) ? soft[g0 + lane] : 0u;
+            uint32_t w[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((g0 & 63) + i));
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                if (!done && g0 + i < ngroups) {
+                    if ((i & 1) == 0) { acs_bfly<0, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<1, 1>(V, sv(w[i], 2), 0); acs_bfly<2, 2>(V, 0, sv(w[i], 3)); }
+                    else              { acs_bfly<3, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<4, 1>(V, sv(w[i], 2), 0); acs_bfly<5, 2>(V, 0, sv(w[i], 3)); }
+                    tr += 3;
+                    if (i == 7) normalize();                                    // (tr & 7) == 0 <=> tr % 24 == 0 here
+                    check();
+                }
+            }
+            if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
+        }
+    } else if (CR == 0) {
+        // 1/2: ACS(A,B) per 2 soft values (viterbi.hpp:167-172); 24 steps per row
+        const uint32_t ngroups = nsoft / 2, nwords = nsoft / 4;
+        uint32_t wv = 0, rowi = 0;                                              // lane-parallel prefetch: 60 words = 5 rows of 24 groups
+        for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += 24, rowi++) {
+            if (rowi % 5 == 0) wv = (lane < 60 && g0 / 2 + lane < nwords) ? soft[g0 / 2 + lane] : 0u;
+            uint32_t w[12];
+#pragma unroll
+            for (int i = 0; i < 12; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((rowi % 5) * 12 + i));
+#pragma unroll
+            for (int i = 0; i < 24; i++) {
+                if (!done && g0 + i < ngroups) {
+                    const unsigned a = sv(w[i >> 1], 2 * (i & 1)), b = sv(w[i >> 1], 2 * (i & 1) + 1);
+                    switch (i % 6) {
+                    case 0: acs_bfly<0, 0>(V, a, b); break; case 1: acs_bfly<1, 0>(V, a, b); break; case 2: acs_bfly<2, 0>(V, a, b); break;
+                    case 3: acs_bfly<3, 0>(V, a, b); break; case 4: acs_bfly<4, 0>(V, a, b); break; default: acs_bfly<5, 0>(V, a, b); break;
+                    }
+                    tr += 1;
+                    if ((i & 7) == 7) normalize();
+                    check();
+                }
+            }
+            if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
+        }
+    } else {
+        // 2/3: { ACS(A,B), ACS(A) } per 3 soft values (viterbi.hpp:181-187); 12 groups = 24 steps = 36 bytes per row
+        const uint32_t ngroups = nsoft / 3, nwords = nsoft / 4;
+        uint32_t wv = 0, rowi = 0;                                              // lane-parallel prefetch: 63 words = 7 rows of 12 groups
+        for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += 12, rowi++) {
+            if (rowi % 7 == 0) wv = (lane < 63 && g0 * 3 / 4 + lane < nwords) ? soft[g0 * 3 / 4 + lane] : 0u;
+            uint32_t w[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((rowi % 7) * 9 + i));
+#pragma unroll
+            for (int i = 0; i < 12; i++) {
+                if (!done && g0 + i < ngroups) {
+                    const int b0 = 3 * i, b1 = 3 * i + 1, b2 = 3 * i + 2;
+                    const unsigned sa = sv(w[b0 >> 2], b0 & 3), sb = sv(w[b1 >> 2], b1 & 3), sc = sv(w[b2 >> 2], b2 & 3);
+                    switch (i % 3) {
+                    case 0: acs_bfly<0, 0>(V, sa, sb); acs_bfly<1, 1>(V, sc, 0); break;
+                    case 1: acs_bfly<2, 0>(V, sa, sb); acs_bfly<3, 1>(V, sc, 0); break;
+                    default: acs_bfly<4, 0>(V, sa, sb); acs_bfly<5, 1>(V, sc, 0); break;
+                    }
+                    tr += 2;
+                    if ((i & 3) == 3) normalize();
+                    check();
+                }
+            }
+            if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
         }
     }
-    // flush the partially gathered decision columns
-    {
-        const uint32_t basecol = tr & ~63u;
-        if ((tr & 63) != 63 && (uint32_t)lane <= (tr & 63)) dec[basecol + lane] = mydec;
-    }
+    // last, partial row: left-align so that column c always sits at bit 31 - ((c - 1) % 24)
+    if ((tr % kColsPerRow) != 0) decT[row * 64 + lane] = V.hist << (32 - (tr % kColsPerRow));
     if (lane == 0) *nwin_out = nw;
 }
 
-__global__ void __launch_bounds__(64) k_viterbi(const VitJob* jobs, uint32_t njobs, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin)
+__global__ void __launch_bounds__(64) k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin)
 {
     const uint32_t f = blockIdx.x;
-    if (f >= njobs) return;
+    if (f >= (njobs_ptr ? *njobs_ptr : njobs_max)) return;
     const VitJob J = jobs[f];
     if (!J.valid) return;
     uint32_t* t = tbk + (size_t)f * kMaxWindows * 3;
@@ -291,63 +363,112 @@ __global__ void __launch_bounds__(64) k_viterbi(const VitJob* jobs, uint32_t njo
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_traceback: TViterbiCore::Traceback (viterbicore.h:468-555) -- every window of a frame is an
-// independent walk through the stored decisions, one thread each.  Emits the bytes LSB-first in time.
-__global__ void __launch_bounds__(128) k_traceback(const VitJob* jobs, uint32_t njobs, const uint64_t* dec_base, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out_base)
+// k_traceback: TViterbiCore::Traceback (viterbicore.h:468-555) -- every window of a frame is an independent
+// walk through the stored decisions, one thread each (a 54 Mbps 1500-byte frame has 47 windows), one wave per
+// frame.  Decisions live in rows of 24 trellis columns x 64 lanes (see k_viterbi): row R, word L, bit 31-i holds
+// the decision that lane L took in column 24R+1+i, and lane L held state rol6^c(L) in column c.  Lanes walk in
+// lock-step one row (24 columns) at a time: the wave first copies every window's current 256-byte row into LDS
+// with coalesced loads, then each lane chases through its own copy.  Bytes come out LSB-first in time.
+__global__ void __launch_bounds__(64) k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec_base, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out_base)
 {
+    __shared__ uint32_t s_row[64][65];                                           // one decision row per window-thread (+1 pad)
     const uint32_t f = blockIdx.x;
-    if (f >= njobs) return;
+    if (f >= (njobs_ptr ? *njobs_ptr : njobs_max)) return;
     const VitJob J = jobs[f];
     if (!J.valid) return;
+    const int lane = threadIdx.x;
     const uint32_t nw = nwin[f];
-    const uint64_t* dec = dec_base + J.dec_off;
+    const uint32_t* decT = reinterpret_cast<const uint32_t*>(dec_base + J.dec_off);
     uint8_t* out = out_base + J.out_off;
-    for (uint32_t w = threadIdx.x; w < nw; w += blockDim.x) {
-        const uint32_t* t = tbk + ((size_t)f * kMaxWindows + w) * 3;
-        uint32_t col = t[0]; const uint32_t look = t[1] & 0xFFFF, cnt = t[1] >> 16;
-        int pos = (int)(t[2] & 0x7F); const uint32_t ob = t[2] >> 8;
-        for (uint32_t i = 0; i < look; i++) {
-            col--; pos = (pos >> 1) & 0x3F;
-            pos |= (int)((dec[col] >> pos) & 1) << 6;
+    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
+        const uint32_t w = w0 + (uint32_t)lane;
+        uint32_t col = 0, look = 0, cnt = 0, ob = 0; unsigned pos = 0; int left = 0;
+        if (w < nw) {
+            const uint32_t* t = tbk + ((size_t)f * kMaxWindows + w) * 3;
+            col = t[0]; look = t[1] & 0xFFFF; cnt = t[1] >> 16; pos = t[2] & 0x7F; ob = t[2] >> 8; left = (int)(look + cnt);
         }
-        uint8_t* po = out + (ob >> 3) + (cnt >> 3);
-        for (uint32_t i = 0; i < (cnt >> 3); i++) {
-            unsigned oc = 0;
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                oc = (oc << 1) | ((unsigned)(pos >> 6) & 1);
-                col--; pos = (pos >> 1) & 0x3F;
-                pos |= (int)((dec[col] >> pos) & 1) << 6;
+        // The walk reads columns col-1, col-2, ... (the decision of the start state is already in `pos`).
+        uint32_t c = col - 1;                                                    // next column to read (>= 6 whenever left > 0)
+        uint32_t i_out = 0;                                                      // steps taken
+        unsigned oc = 0;
+        uint8_t* ob_ptr = out + (ob >> 3);
+        int any = __any(left > 0);
+        while (any) {
+            const uint32_t rowi = left > 0 ? (c - 1) / kColsPerRow : 0xFFFFFFFFu;
+            __syncthreads();
+#pragma unroll 4
+            for (int tw = 0; tw < 64; tw++) {                                    // coalesced: the whole wave copies window tw's row
+                const uint32_t r_tw = (uint32_t)__shfl((int)rowi, tw);
+                if (r_tw != 0xFFFFFFFFu) s_row[tw][lane] = decT[(size_t)r_tw * 64 + lane];
             }
-            *--po = (uint8_t)oc;
+            __syncthreads();
+            if (left > 0) {
+                const uint32_t row_first = rowi * kColsPerRow + 1;               // first column of this row
+                unsigned r = c % 6u;
+                while (left > 0 && c >= row_first) {
+                    if (i_out >= look) {
+                        const uint32_t bi = cnt - 1 - (i_out - look);
+                        oc = (oc << 1) | ((pos >> 6) & 1u);
+                        if ((bi & 7) == 0) { ob_ptr[bi >> 3] = (uint8_t)oc; oc = 0; }
+                    }
+                    pos = (pos >> 1) & 0x3Fu;                                    // predecessor state, lives in column c
+                    const unsigned L = ((pos >> r) | (pos << (6 - r))) & 63u;    // ror6^c(state)
+                    const unsigned bit = 31u - (c - row_first);
+                    pos |= ((s_row[lane][L] >> bit) & 1u) << 6;
+                    r = r == 0 ? 5u : r - 1;
+                    c--; left--; i_out++;
+                }
+            }
+            any = __any(left > 0);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_finish: T11aDesc (scramble.hpp:267-353) + TBB11aFrameSink (PHY_11a.hpp:607-702).
+// k_finish: T11aDesc (scramble.hpp:267-353) + TBB11aFrameSink (PHY_11a.hpp:607-702).  One wave per frame.
+//   * descrambling is data-parallel: the x^7+x^4+1 sequence has period 127, every non-zero seed is a phase of
+//     the same cycle, so scrambler byte j = seqbyte[(phase(seed) + 8 j) mod 127]  (two small tables, no chain);
+//   * the 64 lanes load / descramble / store the MPDU coalesced and park it in LDS;
+//   * CRC-32 is a byte-serial recurrence: lane 0 runs it slicing-by-8 out of LDS (8 x 1 KiB tables in LDS).
 __global__ void __launch_bounds__(64) k_finish(RxArgs A)
 {
-    const uint32_t f = blockIdx.x * blockDim.x + threadIdx.x;
-    if (f >= A.nrows) return;
+    __shared__ uint32_t s_crc[8][256];
+    __shared__ uint32_t s_buf[2504 / 4 + 2];
+    if (blockIdx.x >= *A.njobs) return;
+    const uint32_t f = A.joblist[blockIdx.x];
     FrameRow& r = A.frames[f];
     if (!r.valid || r.error_code != 0) return;
+    const int lane = threadIdx.x;
     const Tables& T = A.T;
+    for (int i = lane; i < 2048; i += 64) s_crc[i >> 8][i & 255] = T.crc8[i];
     const uint8_t* dec = A.vout + (size_t)r.slot0 * kOutPerSlot;
     uint8_t* mp = A.mpdu + (size_t)r.slot0 * kOutPerSlot;
     const uint32_t L = r.length;
-    unsigned reg = dec[1] >> 1;                                                  // byte 0 dropped, byte 1 seeds the register
-    uint32_t crc = 0xFFFFFFFFu, fcs = 0;
-    for (uint32_t i = 0; i < L; i++) {
-        reg = T.scr[reg & 0x7F];
-        const unsigned o = dec[2 + i] ^ reg;
-        reg >>= 1;
+    const unsigned seed = dec[1] >> 1;                                           // byte 0 dropped, byte 1 >> 1 seeds the register
+    const unsigned phase = T.scr_phase[seed & 0x7F];                             // 255: seed 0 (sequence stays 0)
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(s_buf);
+    for (uint32_t i = lane; i < L; i += 64) {
+        const unsigned sb = phase == 255 ? 0u : T.scr_seq[(phase + 8u * i) % 127u];
+        const unsigned o = dec[2 + i] ^ sb;
+        bytes[i] = (uint8_t)o;
         mp[i] = (uint8_t)o;
-        if (i + 4 < L) crc = (crc >> 8) ^ T.crc[(o ^ crc) & 0xFF];
-        else fcs |= o << (8 * (i + 4 - L));
     }
-    r.crc32 = fcs;
-    r.error_code = ((~crc) == fcs) ? E_FRAME_OK : E_CRC32_FAIL;
+    __syncthreads();
+    if (lane == 0) {
+        uint32_t crc = 0xFFFFFFFFu;
+        const uint32_t n = L >= 4 ? L - 4 : 0;                                    // PHY_11a.hpp:668-673: the FCS bytes are not fed to the CRC
+        uint32_t i = 0;
+        for (; i + 8 <= n; i += 8) {
+            const uint32_t lo = s_buf[i >> 2] ^ crc, hi = s_buf[(i >> 2) + 1];
+            crc = s_crc[7][lo & 0xFF] ^ s_crc[6][(lo >> 8) & 0xFF] ^ s_crc[5][(lo >> 16) & 0xFF] ^ s_crc[4][lo >> 24] ^
+                  s_crc[3][hi & 0xFF] ^ s_crc[2][(hi >> 8) & 0xFF] ^ s_crc[1][(hi >> 16) & 0xFF] ^ s_crc[0][hi >> 24];
+        }
+        for (; i < n; i++) crc = (crc >> 8) ^ s_crc[0][(bytes[i] ^ crc) & 0xFF];
+        uint32_t fcs = 0;
+        if (L >= 4) fcs = (uint32_t)bytes[L - 4] | ((uint32_t)bytes[L - 3] << 8) | ((uint32_t)bytes[L - 2] << 16) | ((uint32_t)bytes[L - 1] << 24);
+        r.crc32 = fcs;
+        r.error_code = ((~crc) == fcs) ? E_FRAME_OK : E_CRC32_FAIL;              // PHY_11a.hpp:688-692
+    }
 }
 
 // ================================================================================================

@@ -111,6 +111,18 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
         return abs(r) + abs(i);
     };
 
+    // Carrier sense reads the stream 4 samples at a time, wave-uniformly: stage 64 consecutive units per
+    // coalesced 256-byte load (one per lane) and hand them out with v_readlane instead of paying one global
+    // round trip per burst.
+    uint32_t win_base = 0xFFFFFFFFu, win = 0;
+    auto sample = [&](uint32_t u) -> uint32_t {
+        if (u - win_base >= 64u) {
+            win_base = u;
+            win = (u + (uint32_t)lane < nunits) ? iq[u + (uint32_t)lane] : 0u;
+        }
+        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(u - win_base));
+    };
+
     uint32_t vpos = 0;                              // next burst start, in queue units
     const uint32_t nchunks = nunits / APP;
     for (uint32_t c = 0; c < nchunks && nfr < A.max_frames; c++) {
@@ -121,7 +133,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                 // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
                 uint32_t raw[4]; cpx pi[4];
 #pragma unroll
-                for (int e = 0; e < 4; e++) { raw[e] = iq[vpos + e * STR]; cpx x = unpack(raw[e]); pi[e] = mk(w16(x.re - dc_re), w16(x.im - dc_im)); }
+                for (int e = 0; e < 4; e++) { raw[e] = sample(vpos + e * STR); cpx x = unpack(raw[e]); pi[e] = mk(w16(x.re - dc_re), w16(x.im - dc_im)); }
                 if (!sync_high) {
                     cpx pii[4];
 #pragma unroll
@@ -368,6 +380,16 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                     }
                     sym_idx++;
                     remain_symbols = (remain_symbols - 1) & 0xFFFF;                // ushort (PHY_11a.hpp:405)
+                    if (sym_idx == 1 && plcp_is_data && remain_symbols > 1) {
+                        // Nothing observable happens between here and the last burst of the frame (no carrier sense,
+                        // no error source): jump straight to it instead of counting ~20 bursts per symbol.
+                        const uint64_t last_v = (uint64_t)sym_start + 80ull * STR * (remain_symbols + 1) - BUR;
+                        if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }   // frame runs past the capture: nothing more to report
+                        sym_idx += remain_symbols - 1; remain_symbols = 1; sym_n = 76; sym_start = (uint32_t)(last_v + BUR) - 80u * STR;
+                        vpos = (uint32_t)last_v;
+                        c = (vpos + BUR + APP - 1) / APP - 2;                               // the for-loop increment lands on the chunk that delivers that burst
+                        break;
+                    }
                     if (remain_symbols == 0 && plcp_is_data) {
                         // all data symbols are in: the Viterbi sub-graph will raise FRAME_OK / CRC32_FAIL
                         row.end_sample = pos20 + 4;
@@ -390,6 +412,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                         A.slot_frame[row.slot0 + s] = (int32_t)(cap_i * A.max_frames + nfr);
                         A.slot_sym[row.slot0 + s] = (uint16_t)s;
                     }
+                    if (lane == 0) A.joblist[atomicAdd(A.njobs, 1u)] = cap_i * A.max_frames + nfr;
                 }
                 if (lane == 0) A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
                 nfr++;

@@ -20,6 +20,9 @@ struct ScanArgs {
     int32_t*        slot_frame; // [total slots]
     uint16_t*       slot_sym;
     uint32_t*       eq;         // [total slots][64]: the SIGNAL symbol's equalised bins are stored too
+    uint32_t*       njobs;      // [1] number of frames whose data symbols must be decoded
+    uint32_t*       joblist;    // [nrows] their frame-table rows, compacted: consecutive workgroups of the per-frame
+                                //         kernels then carry live work (workgroup b runs on XCD b % 8)
 };
 
 struct RxArgs {
@@ -41,15 +44,17 @@ struct RxArgs {
     uint32_t*       nwin;           // [nrows]
     uint8_t*        vout;           // [slots*32]
     uint8_t*        mpdu;           // [slots*32]
-    VitJob*         jobs;           // [nrows]
+    VitJob*         jobs;           // [nrows] (indexed by job)
+    const uint32_t* njobs;
+    const uint32_t* joblist;
 };
 
 __global__ void k_scan(ScanArgs A);
 __global__ void k_sym_front(RxArgs A);
 __global__ void k_track(RxArgs A);
 __global__ void k_demap(RxArgs A);
-__global__ void k_viterbi(const VitJob* jobs, uint32_t njobs, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin);
-__global__ void k_traceback(const VitJob* jobs, uint32_t njobs, const uint64_t* dec, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out);
+__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin);
+__global__ void k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out);
 __global__ void k_finish(RxArgs A);
 __global__ void k_fft64_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
 __global__ void k_demap_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n, Tables T);

@@ -66,7 +66,7 @@ struct TrackRec {           // per data-symbol slot
 };
 
 constexpr int kSoftPerSlot = 288;      // N_CBPS max
-constexpr int kDecPerSlot  = 216;      // trellis columns per symbol max (N_DBPS)
+constexpr int kDecPerSlot  = 288;      // 64-bit words of decision storage per symbol slot: 216 columns -> 9 rows of 24 columns x 256 B
 constexpr int kOutPerSlot  = 32;       // decoded bytes per symbol max 27 -> 32
 constexpr int kMaxWindows  = 80;       // ceil((2500*8+16)/256)+1
 

@@ -34,7 +34,8 @@ struct HostTables {
     std::vector<uint8_t> demap;
     std::vector<uint32_t> tw64, tw16, sts, crc;
     std::vector<uint16_t> deint;
-    std::vector<uint8_t> scr;
+    std::vector<uint8_t> scr, scr_seq, scr_phase;
+    std::vector<uint32_t> crc8;
 };
 
 static inline uint32_t pk(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
@@ -136,8 +137,31 @@ static void build_tables(HostTables& H)
     }
     H.crc.resize(256);
     for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1; H.crc[i] = c; }
+    H.crc8.resize(8 * 256);                                  // slicing-by-8: T_k[i] = CRC of byte i followed by k zero bytes
+    for (uint32_t i = 0; i < 256; i++) {
+        uint32_t c = H.crc[i]; H.crc8[i] = c;
+        for (int k = 1; k < 8; k++) { c = (c >> 8) ^ H.crc[c & 0xFF]; H.crc8[k * 256 + i] = c; }
+    }
     H.scr.resize(128);
     for (int i = 0; i < 128; i++) { uint8_t x = (uint8_t)(i << 1); for (int k = 0; k < 8; k++) { uint8_t o1 = ((x >> 1) ^ (x >> 4)) & 1; x = (uint8_t)((x >> 1) | (o1 << 7)); } H.scr[i] = x; }
+    // The descrambler (scramble.hpp:319-349) walks reg -> scr[reg] -> reg>>1 ...: a period-127 cycle of 7-bit
+    // states.  Lay the cycle out once: position q holds state st[q]; byte produced from that state = scr[st[q]];
+    // 8 positions later comes the state of the next byte.
+    {
+        std::vector<uint8_t> st(127), z(127 + 16);
+        // bit sequence z: start from state 1 (bits z[-7..-1] = state bits 0..6)
+        uint8_t state = 1;
+        std::vector<int> pos_of(128, -1);
+        for (int q = 0; q < 127; q++) {
+            st[q] = state; pos_of[state] = q;
+            // advance ONE bit: new bit = z[n-7]^z[n-4] = state bit0 ^ state bit3; state = (state >> 1) | (bit << 6)
+            uint8_t nb = ((state >> 0) ^ (state >> 3)) & 1;
+            state = (uint8_t)((state >> 1) | (nb << 6));
+        }
+        H.scr_seq.resize(127); H.scr_phase.assign(128, 255);
+        for (int q = 0; q < 127; q++) H.scr_seq[q] = H.scr[st[q]];
+        for (int s7 = 1; s7 < 128; s7++) H.scr_phase[s7] = (uint8_t)pos_of[s7];
+    }
 }
 
 struct DevTables {
@@ -172,6 +196,9 @@ static int make_dev_tables(DevTables& D)
     if ((rc = upload(D, H.deint, (const void**)&D.T.deint))) return rc;
     if ((rc = upload(D, H.crc, (const void**)&D.T.crc))) return rc;
     if ((rc = upload(D, H.scr, (const void**)&D.T.scr))) return rc;
+    if ((rc = upload(D, H.crc8, (const void**)&D.T.crc8))) return rc;
+    if ((rc = upload(D, H.scr_seq, (const void**)&D.T.scr_seq))) return rc;
+    if ((rc = upload(D, H.scr_phase, (const void**)&D.T.scr_phase))) return rc;
     return SORA_OK;
 }
 static void free_dev_tables(DevTables& D) { for (void* p : D.allocs) (void)hipFree(p); D.allocs.clear(); }
@@ -202,21 +229,28 @@ struct sora_rx {
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
     int32_t* d_slot_frame = nullptr; uint16_t* d_slot_sym = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr;
     uint8_t* d_soft = nullptr; uint64_t* d_dec = nullptr; uint32_t* d_tbk = nullptr; uint32_t* d_nwin = nullptr;
-    uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; VitJob* d_jobs = nullptr;
+    uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
     // last call
     std::vector<CapDesc> h_caps;
     uint32_t ncaps = 0, total_slots = 0;
     bool have_results = false;
+    // profiling
+    bool profiling = false;
+    hipEvent_t ev[9] = {};
+    bool ev_valid = false;
 };
+
+static const char* const kKernelNames[8] = { "memset+caps", "k_scan", "k_sym_front", "k_track", "k_demap", "k_viterbi", "k_traceback", "k_finish" };
 
 static void rx_free(sora_rx* rx)
 {
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes, rx->d_slot_frame, rx->d_slot_sym, rx->d_eq, rx->d_track,
-                     rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin, rx->d_vout, rx->d_mpdu, rx->d_jobs, rx->d_iq_own, rx->d_rows, rx->d_nrows };
+                     rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin, rx->d_vout, rx->d_mpdu, rx->d_jobs, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist };
     for (void* p : ptrs) if (p) (void)hipFree(p);
+    for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     free_dev_tables(rx->tabs);
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
     delete rx;
@@ -268,7 +302,7 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
         { (void**)&rx->d_tbk, 12 * (size_t)kMaxWindows * rx->cap_rows }, { (void**)&rx->d_nwin, 4 * (size_t)rx->cap_rows },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
         { (void**)&rx->d_jobs, sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
-        { (void**)&rx->d_nrows, 4 },
+        { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_njobs, 4 }, { (void**)&rx->d_joblist, 4 * (size_t)rx->cap_rows },
     };
     for (auto& a : allocs) {
         e = hipMalloc(a.p, a.bytes);
@@ -317,29 +351,43 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
     hipStream_t st = rx->stream;
+    const bool prof = rx->profiling;
+    int evi = 0;
+    auto mark = [&]() { if (prof) (void)hipEventRecord(rx->ev[evi++], st); };
+    mark();
     HIPCHK(hipMemcpyAsync(rx->d_caps, rx->h_caps.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, st));
     HIPCHK(hipMemsetAsync(rx->d_slot_frame, 0xFF, 4 * (size_t)slots, st));
     const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
     HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
+    HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 4, st));
 
     ScanArgs S{};
     S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.thr = rx->cfg.cca_pwr_threshold;
     S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-    S.slot_frame = rx->d_slot_frame; S.slot_sym = rx->d_slot_sym; S.eq = rx->d_eq;
+    S.slot_frame = rx->d_slot_frame; S.slot_sym = rx->d_slot_sym; S.eq = rx->d_eq; S.njobs = rx->d_njobs; S.joblist = rx->d_joblist;
+    mark();
     hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
+    mark();
 
     RxArgs R{};
     R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
     R.frames = rx->d_frames; R.fctx = rx->d_fctx; R.slot_frame = rx->d_slot_frame; R.slot_sym = rx->d_slot_sym;
     R.eq = rx->d_eq; R.track = rx->d_track; R.soft = rx->d_soft; R.dec = rx->d_dec; R.tbk = rx->d_tbk; R.nwin = rx->d_nwin;
-    R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs;
+    R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
     hipLaunchKernelGGL(k_sym_front, dim3((slots + 15) / 16), dim3(256), 0, st, R);
+    mark();
     hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(64), 0, st, R);
+    mark();
     hipLaunchKernelGGL(k_demap, dim3((slots + 3) / 4), dim3(256), 0, st, R);
-    hipLaunchKernelGGL(k_viterbi, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
-    hipLaunchKernelGGL(k_traceback, dim3(nrows), dim3(128), 0, st, (const VitJob*)rx->d_jobs, nrows, (const uint64_t*)rx->d_dec, (const uint32_t*)rx->d_tbk, (const uint32_t*)rx->d_nwin, rx->d_vout);
-    hipLaunchKernelGGL(k_finish, dim3((nrows + 63) / 64), dim3(64), 0, st, R);
+    mark();
+    hipLaunchKernelGGL(k_viterbi, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
+    mark();
+    hipLaunchKernelGGL(k_traceback, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint64_t*)rx->d_dec, (const uint32_t*)rx->d_tbk, (const uint32_t*)rx->d_nwin, rx->d_vout);
+    mark();
+    hipLaunchKernelGGL(k_finish, dim3(nrows), dim3(64), 0, st, R);
+    mark();
     HIPCHK(hipGetLastError());
+    rx->ev_valid = prof;
     rx->have_results = true;
     return SORA_OK;
 }
@@ -391,6 +439,28 @@ int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_
     if (rc != SORA_OK) return fail(rc, "sora_rx_results: output buffer too small");
     return SORA_OK;
 }
+
+int sora_rx_set_profiling(sora_rx_t* rx, int enable)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    if (enable && !rx->ev[0]) for (auto& e : rx->ev) HIPCHK(hipEventCreate(&e));
+    rx->profiling = enable != 0; rx->ev_valid = false;
+    return SORA_OK;
+}
+
+int sora_rx_kernel_times(sora_rx_t* rx, float* ms, size_t cap, size_t* nout)
+{
+    if (!rx || !ms || !nout) return SORA_ERR_INVALID_PARAM;
+    *nout = 0;
+    if (!rx->ev_valid) return fail(SORA_ERR_FAILED, "no profiled process call");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    HIPCHK(hipEventSynchronize(rx->ev[8]));
+    for (size_t i = 0; i < 8 && i < cap; i++) { HIPCHK(hipEventElapsedTime(&ms[i], rx->ev[i], rx->ev[i + 1])); (*nout)++; }
+    return SORA_OK;
+}
+
+const char* sora_rx_kernel_name(size_t i) { return i < 8 ? kKernelNames[i] : ""; }
 
 int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
 {
@@ -456,8 +526,8 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
     HIPCHK(hipMalloc((void**)&decoff, 4 * n));
     HIPCHK(hipMemcpyAsync(decoff, h_dec_off.data(), 4 * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, d_soft_off, d_nsoft, d_frame_len, d_out_off, (const uint32_t*)decoff, code_rate, (uint32_t)n);
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (uint32_t)n, d_soft, dec, tbk, nwin);
-    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(128), 0, st, (const VitJob*)jobs, (uint32_t)n, (const uint64_t*)dec, (const uint32_t*)tbk, (const uint32_t*)nwin, d_out);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, d_soft, dec, tbk, nwin);
+    hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, (const uint64_t*)dec, (const uint32_t*)tbk, (const uint32_t*)nwin, d_out);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(jobs); (void)hipFree(dec); (void)hipFree(tbk); (void)hipFree(nwin); (void)hipFree(decoff);
     if (e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_viterbi11a", e);
