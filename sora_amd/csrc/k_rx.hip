@@ -396,10 +396,20 @@ __global__ void __launch_bounds__(64) k_traceback(const VitJob* jobs, const uint
         while (any) {
             const uint32_t rowi = left > 0 ? (c - 1) / kColsPerRow : 0xFFFFFFFFu;
             __syncthreads();
-#pragma unroll 4
-            for (int tw = 0; tw < 64; tw++) {                                    // coalesced: the whole wave copies window tw's row
-                const uint32_t r_tw = (uint32_t)__shfl((int)rowi, tw);
-                if (r_tw != 0xFFFFFFFFu) s_row[tw][lane] = decT[(size_t)r_tw * 64 + lane];
+            // coalesced: the whole wave copies window tw's row; all loads of a half are in flight together
+            const int nwin_here = (int)min(64u, nw - w0);
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                if (h * 32 < nwin_here) {
+                    uint32_t v[32];
+#pragma unroll
+                    for (int k = 0; k < 32; k++) {
+                        const uint32_t r_tw = (uint32_t)__builtin_amdgcn_readlane((int)rowi, h * 32 + k);
+                        v[k] = (r_tw != 0xFFFFFFFFu) ? decT[(size_t)r_tw * 64 + lane] : 0u;
+                    }
+#pragma unroll
+                    for (int k = 0; k < 32; k++) s_row[h * 32 + k][lane] = v[k];
+                }
             }
             __syncthreads();
             if (left > 0) {
