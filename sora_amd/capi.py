@@ -87,6 +87,7 @@ def load(build_if_missing=True):
     L.sora_rx_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                   ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_rx_results_dev.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
@@ -165,6 +166,22 @@ class Rx:
         a = np.ascontiguousarray(h_iq, np.int16).reshape(-1, 2)
         arr = self._caps(captures)
         _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), arr, len(captures)))
+
+    def results_dev(self):
+        """Device-resident results of the last call: (rows int32 tensor [cap_rows, 9] (36-byte sora_frame_result rows),
+        nrows int32 tensor [1], mpdu uint8 base address).  The tensors alias library memory: valid until the next call."""
+        import torch
+        rows = ctypes.c_void_p(); nrows = ctypes.c_void_p(); mpdu = ctypes.c_void_p()
+        _check(self._L.sora_rx_results_dev(self._h, ctypes.byref(rows), ctypes.byref(nrows), ctypes.byref(mpdu)))
+        cap = self.cfg.max_captures * self.cfg.max_frames_per_capture
+        dev = torch.device("cuda", self.cfg.device)
+
+        class _Arr:                                        # __cuda_array_interface__ view over library memory
+            def __init__(self, ptr, shape, typestr):
+                self.__cuda_array_interface__ = {"shape": shape, "typestr": typestr, "data": (ptr, False), "version": 2}
+        r = torch.as_tensor(_Arr(rows.value, (cap, 9), "<i4"), device=dev)
+        n = torch.as_tensor(_Arr(nrows.value, (1,), "<i4"), device=dev)
+        return r, n, mpdu.value
 
     def set_profiling(self, enable=True):
         _check(self._L.sora_rx_set_profiling(self._h, 1 if enable else 0))

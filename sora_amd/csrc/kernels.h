@@ -56,6 +56,8 @@ __global__ void k_demap(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin);
 __global__ void k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out);
 __global__ void k_finish(RxArgs A);
+struct PackedRow;
+__global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);
 __global__ void k_fft64_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
 __global__ void k_demap_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n, Tables T);
 __global__ void k_deint_batch(const uint8_t* in, uint8_t* out, int nb, uint32_t n, Tables T);

@@ -464,10 +464,18 @@ const char* sora_rx_kernel_name(size_t i) { return i < 8 ? kKernelNames[i] : "";
 
 int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
 {
-    // Device-side packing (for the multi-GPU gather) is provided by sora_rx_pack_dev in a later revision;
-    // until then the sparse frame table is exposed through sora_rx_results only.
-    (void)rx; (void)d_rows; (void)d_nrows; (void)d_mpdu;
-    return fail(SORA_ERR_FAILED, "sora_rx_results_dev: not available in this build");
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results_dev: null handle");
+    if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    static_assert(sizeof(sora_frame_result) == 36, "sora_frame_result layout");
+    if (rx->ncaps == 0) HIPCHK(hipMemsetAsync(rx->d_nrows, 0, 4, rx->stream));
+    else hipLaunchKernelGGL(k_pack, dim3(1), dim3(1024), 0, rx->stream, (const FrameRow*)rx->d_frames, (const uint32_t*)rx->d_nframes,
+                            (const CapDesc*)rx->d_caps, rx->ncaps, rx->cfg.max_frames_per_capture, reinterpret_cast<PackedRow*>(rx->d_rows), rx->d_nrows);
+    HIPCHK(hipGetLastError());
+    if (d_rows) *d_rows = rx->d_rows;
+    if (d_nrows) *d_nrows = rx->d_nrows;
+    if (d_mpdu) *d_mpdu = rx->d_mpdu;
+    return SORA_OK;
 }
 
 // ---- per-stage entry points

@@ -1,0 +1,67 @@
+"""Multi-GPU sharding of the receive path: captures are the natural shard.
+
+Independent 20 MHz captures share no state (the reference resets its context per frame,
+kernel/bb/demod11/fb11ademod_config.hpp:68-95), so rank r of W runs the whole path on a contiguous block of
+captures in its own HBM -- no collective on the data path.  The only exchange is the result gather:
+one all-gather (RCCL over xGMI when the backend is "nccl"; gloo in the CPU tests) of fixed-size
+sora_frame_result rows (9 x int32 = 36 bytes) plus their per-rank counts.
+"""
+import numpy as np
+
+ROW_WORDS = 9          # sizeof(sora_frame_result) / 4
+
+
+def partition(n_items, world_size, rank):
+    """Static block partition: -> (first, count).  Ranks differ by at most one item."""
+    base, extra = divmod(n_items, world_size)
+    first = rank * base + min(rank, extra)
+    return first, base + (1 if rank < extra else 0)
+
+
+def rows_from_results(results):
+    """list of result dicts (capi.Rx.results / oracle) -> int32 array [n, 9] in sora_frame_result layout."""
+    out = np.zeros((len(results), ROW_WORDS), np.uint32)
+    for i, r in enumerate(results):
+        out[i] = (r["capture_id"], r["start_sample"], r["end_sample"], r["error_code"], r["rate_kbps"],
+                  (r["length"] & 0xFFFF) | ((r["nsym"] & 0xFFFF) << 16), r["crc32"],
+                  (r["cfo_est"] & 0xFFFF) | ((r.get("reserved", 0) & 0xFFFF) << 16), r.get("mpdu_offset", 0))
+    return out.view(np.int32)
+
+
+def results_from_rows(rows):
+    rows = np.asarray(rows).view(np.uint32).reshape(-1, ROW_WORDS)
+    out = []
+    for w in rows:
+        cfo = int(w[7] & 0xFFFF)
+        out.append({"capture_id": int(w[0]), "start_sample": int(w[1]), "end_sample": int(w[2]), "error_code": int(w[3]),
+                    "rate_kbps": int(w[4]), "length": int(w[5] & 0xFFFF), "nsym": int(w[5] >> 16), "crc32": int(w[6]),
+                    "cfo_est": cfo - 65536 if cfo >= 32768 else cfo, "reserved": int(w[7] >> 16), "mpdu_offset": int(w[8])})
+    return out
+
+
+def gather_rows(rows, nrows, max_rows_per_rank, group=None):
+    """All-gather variable-length row blocks.  rows: int32 tensor [>=nrows, 9] on the backend's device,
+    nrows: python int.  Returns (int32 tensor [total, 9] in rank order, list of per-rank counts)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = rows.device
+    pad = torch.zeros((max_rows_per_rank, ROW_WORDS), dtype=torch.int32, device=dev)
+    pad[:nrows] = rows[:nrows]
+    counts = torch.zeros(world, dtype=torch.int32, device=dev)
+    mine = torch.tensor([nrows], dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(counts, mine, group=group)
+    allrows = torch.zeros((world * max_rows_per_rank, ROW_WORDS), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(allrows, pad, group=group)
+    cl = [int(c) for c in counts.tolist()]
+    parts = [allrows[r * max_rows_per_rank: r * max_rows_per_rank + cl[r]] for r in range(world)]
+    return torch.cat(parts) if parts else allrows[:0], cl
+
+
+def reduce_counters(values, group=None, device=None):
+    """Sum small integer counters (frames, CRC-ok, samples, bits) over the ranks."""
+    import torch
+    import torch.distributed as dist
+    t = torch.tensor(list(values), dtype=torch.int64, device=device)
+    dist.all_reduce(t, group=group)
+    return [int(v) for v in t.tolist()]

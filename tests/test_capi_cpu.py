@@ -1,0 +1,110 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library loads, exports every symbol include/sora_hip.h
+declares, keeps the struct layouts, and FAILS LOUDLY (never falls back) when no HIP device is present."""
+import ctypes
+import os
+import re
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HEADER = os.path.join(ROOT, "include", "sora_hip.h")
+
+
+@pytest.fixture(scope="module")
+def lib():
+    import sora_amd
+    return sora_amd.load()
+
+
+def declared_functions():
+    txt = open(HEADER).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(sora_[a-z0-9_]+)\s*\(", txt)) - {"sora_rx_t"})
+
+
+def test_library_exports_every_declared_symbol(lib):
+    names = declared_functions()
+    assert len(names) >= 20
+    for n in names:
+        assert hasattr(lib, n), "libsora_hip.so does not export %s" % n
+
+
+def test_binding_covers_the_header():
+    from sora_amd import capi
+    assert sorted(capi.EXPORTS) == declared_functions()
+
+
+def test_abi_version_and_struct_layout(lib):
+    from sora_amd import capi
+    assert lib.sora_hip_abi_version() == 1
+    assert ctypes.sizeof(capi.FrameResult) == 36          # 9 x 32-bit words: the unit of the multi-GPU gather
+    assert ctypes.sizeof(capi.CaptureDesc) == 16
+    assert ctypes.sizeof(capi.RxCfg) == 32
+
+
+def test_no_silent_cpu_fallback(lib):
+    """Without a GPU every compute entry point must refuse (SORA_ERR_NO_DEVICE), not compute on the host."""
+    import sora_amd
+    if sora_amd.device_count() > 0:
+        pytest.skip("a HIP device is present")
+    with pytest.raises(sora_amd.SoraError) as e:
+        sora_amd.Rx(1, 2800)
+    assert e.value.code == -5
+    assert lib.sora_hip_fft64(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, None) == -5
+    assert lib.sora_hip_demap11a(ctypes.c_void_p(16), ctypes.c_void_p(16), 1, 1, None) == -5
+    assert b"no HIP device" in lib.sora_hip_last_error()
+
+
+def test_product_does_not_link_or_import_the_oracle():
+    """The shipped library and package must not reach into oracle/ (test infrastructure only)."""
+    import sora_amd
+    out = subprocess.run(["ldd", sora_amd.lib_path()], capture_output=True, text=True).stdout
+    assert "sora_oracle" not in out and "sora_ref" not in out
+    pkg = os.path.join(ROOT, "sora_amd")
+    for dirpath, _, files in os.walk(pkg):
+        for f in files:
+            if f.endswith((".py", ".cpp", ".hip", ".h")):
+                src = open(os.path.join(dirpath, f), errors="replace").read()
+                assert "pyoracle" not in src and "so_oracle" not in src and "libsora_oracle" not in src, f
+
+
+def test_c_host_example_compiles():
+    """A plain-C host (the reference's harness language) builds against the header and links the library."""
+    src = os.path.join(ROOT, "examples", "demod11a.c")
+    if not os.path.exists(src):
+        pytest.skip("example not present")
+    import sora_amd
+    out = os.path.join(ROOT, "examples", "_build")
+    os.makedirs(out, exist_ok=True)
+    libdir = os.path.dirname(sora_amd.lib_path())
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir,
+                        "-lsora_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", os.path.join(out, "demod11a")],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_brick_adapter_header_compiles(tmp_path):
+    """The BRICK-shaped adapters instantiate into a sink-first graph exactly like CREATE_BRICK_* chains do."""
+    hdr = os.path.join(ROOT, "include", "sora_brick.hpp")
+    src = tmp_path / "graph.cpp"
+    src.write_text("""
+#include "sora_brick.hpp"
+using namespace sora_brick;
+int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, uint8_t* d_de) {
+    CF_Error ctx;
+    TDrop<CF_Error> drop(ctx);
+    THip11aDeinterleave<6, 16, CF_Error, TDrop<CF_Error>> deint(ctx, &drop, d_de);
+    THip11aDemap<6, 16, CF_Error, decltype(deint)> demap(ctx, &deint, d_soft);
+    THipFFT64<16, CF_Error, decltype(demap)> fft(ctx, &demap, d_fft);
+    DevicePin<sora_complex16, 64 * 16> src(d_in);
+    src.append();
+    bool ok = fft.Process(src);
+    fft.Reset(); fft.Flush();
+    return ok ? 0 : (int)ctx.error_code;
+}
+""")
+    assert os.path.exists(hdr)
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr

@@ -194,3 +194,24 @@ def test_capacity_errors(sora, torch_cuda):
         rx.process_dev(x, [(0, 1400), (1400, 1400)])
     with pytest.raises(sora.SoraError):
         rx.process_dev(x, [(2, 1400)])
+
+
+def test_device_resident_results_and_row_codec(sora, torch_cuda, oracle):
+    """sora_rx_results_dev packs dense rows on the device (what the RCCL all-gather ships); decode them back."""
+    from sora_amd.shard import results_from_rows
+    caps = [make_capture(oracle, r, 120 + i, seed=40 + i, rate_mhz=20, sigma=100)[0] for i, r in enumerate(RATES)]
+    caps.insert(3, np.zeros((1400, 2), np.int16))                      # a silent capture: no row
+    iq, descs = batch(caps)
+    rx = sora.Rx(len(caps), len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+    d = torch_cuda.from_numpy(iq).cuda()
+    rx.process_dev(d, descs)
+    rows, nrows, mpdu_ptr = rx.results_dev()
+    rx.flush()
+    n = int(nrows.item())
+    got = results_from_rows(rows[:n].cpu().numpy())
+    want = rx.results()
+    assert n == len(want) == 8
+    for g, w in zip(got, want):
+        for k in ("capture_id", "start_sample", "end_sample", "error_code", "rate_kbps", "length", "nsym", "crc32", "cfo_est"):
+            assert g[k] == w[k], k
+    assert mpdu_ptr != 0

@@ -1,0 +1,85 @@
+"""Multi-GPU path on CPU: world_size-2 `gloo` run of the capture sharding + result gather (sora_amd/shard.py).
+Each rank decodes ITS block of captures (with the oracle standing in for the GPU path -- the point here is the
+partition / all-gather logic, which is identical under RCCL) and every rank must end up with the full, ordered result set."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_partition_is_a_cover():
+    from sora_amd.shard import partition
+    for n in (0, 1, 7, 8, 256, 257):
+        for w in (1, 2, 3, 8):
+            blocks = [partition(n, w, r) for r in range(w)]
+            assert blocks[0][0] == 0 and sum(c for _, c in blocks) == n
+            for (a, ca), (b, _) in zip(blocks, blocks[1:]):
+                assert a + ca == b
+            assert max(c for _, c in blocks) - min(c for _, c in blocks) <= 1
+
+
+def test_row_codec_roundtrip():
+    from sora_amd.shard import results_from_rows, rows_from_results
+    rs = [{"capture_id": 5, "start_sample": 176, "end_sample": 4880, "error_code": 1, "rate_kbps": 54000, "length": 1500,
+           "nsym": 56, "crc32": 0xDEADBEEF, "cfo_est": -37, "reserved": 0, "mpdu_offset": 1234},
+          {"capture_id": 6, "start_sample": 0, "end_sample": 9, "error_code": 0x80000005, "rate_kbps": 0, "length": 0,
+           "nsym": 0, "crc32": 0, "cfo_est": 12, "reserved": 0, "mpdu_offset": 0}]
+    assert results_from_rows(rows_from_results(rs)) == rs
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from gpu_util import make_capture
+    from oracle.pyoracle import Oracle, RATES
+    from sora_amd.shard import gather_rows, partition, reduce_counters, results_from_rows, rows_from_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    ncaps = 11
+    caps = [make_capture(o, RATES[i % 8], 60 + 9 * i, seed=i, rate_mhz=20, sigma=100)[0] for i in range(ncaps)]
+    first, count = partition(ncaps, world, rank)
+    local = []
+    for i in range(first, first + count):
+        for r in o.rx_capture(caps[i], 20):
+            r = dict(r); r["capture_id"] = i; local.append(r)
+    rows = torch.from_numpy(rows_from_results(local).copy())
+    allrows, counts = gather_rows(rows, len(local), max_rows_per_rank=16)
+    tot = reduce_counters([len(local), sum(r["error_code"] == 1 for r in local)])
+    got = results_from_rows(allrows.numpy())
+    q.put((rank, counts, tot, [(g["capture_id"], g["rate_kbps"], g["length"], g["crc32"], g["error_code"]) for g in got]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    outs.sort()
+    # single-process truth
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import make_capture
+    from oracle.pyoracle import Oracle, RATES
+    o = Oracle()
+    want = []
+    for i in range(11):
+        c = make_capture(o, RATES[i % 8], 60 + 9 * i, seed=i, rate_mhz=20, sigma=100)[0]
+        for r in o.rx_capture(c, 20):
+            want.append((i, r["rate_kbps"], r["length"], r["crc32"], r["error_code"]))
+    assert len(want) == 11
+    for rank, counts, tot, got in outs:
+        assert sum(counts) == 11 and counts == [6, 5]
+        assert tot == [11, sum(1 for w in want if w[4] == 1)]
+        assert got == want            # rank order == capture order: the gather needs no re-sort
