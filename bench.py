@@ -154,7 +154,14 @@ def main():
         if not parity_ok:
             print("PARITY MISMATCH vs oracle:", why, file=sys.stderr)
     counters = torch.tensor([len(res), n_ok, n_payload_ok], device=dev, dtype=torch.int64)
+    gathered_rows = None
     if world > 1:
+        # the path's one exchange step: RCCL all-gather of the device-packed result rows + all-reduce of counters
+        from sora_amd.shard import gather_rows
+        rows, nrows, _ = rx.results_dev()
+        rx.flush()
+        allrows, per_rank = gather_rows(rows, int(nrows.item()), max_rows_per_rank=nfr * 2)
+        gathered_rows = int(allrows.shape[0])
         dist.all_reduce(counters)
     tot_frames, tot_ok, tot_payload_ok = [int(v) for v in counters.tolist()]
 
@@ -174,7 +181,7 @@ def main():
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES,
                        "sharding": "captures per rank, no data-path collective"},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
-            "frames": tot_frames, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok, "oracle_parity_sample_ok": parity_ok,
+            "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok, "oracle_parity_sample_ok": parity_ok,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK, 5), "traffic": None,
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes[dom], 4),
