@@ -18,14 +18,21 @@
 
 namespace sora {
 
-struct Acc4 { int e[4]; int idx; int reg; };           // CMovingWindow<int,4> + CAccumulator (dspalg.hpp:5-98)
-__device__ __forceinline__ void acc_clear(Acc4& a) { a.e[0] = a.e[1] = a.e[2] = a.e[3] = 0; a.idx = 0; a.reg = 0; }
+#ifdef SORA_SCAN_PROBE
+__device__ unsigned long long g_scan_probe[16];
+#define PROBE_T0() const long long _t0 = clock64()
+#define PROBE_ADD(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_scan_probe[i] += (unsigned long long)(clock64() - _t0); } while (0)
+#else
+#define PROBE_T0()
+#define PROBE_ADD(i)
+#endif
+
+struct Acc4 { int e0, e1, e2, e3; int reg; };            // CMovingWindow<int,4> + CAccumulator (dspalg.hpp:5-98), oldest first
+__device__ __forceinline__ void acc_clear(Acc4& a) { a.e0 = a.e1 = a.e2 = a.e3 = 0; a.reg = 0; }
 __device__ __forceinline__ void acc_push(Acc4& a, int d)
 {
-    int old = a.idx == 0 ? a.e[0] : a.idx == 1 ? a.e[1] : a.idx == 2 ? a.e[2] : a.e[3];
-    a.reg = (int)((unsigned)a.reg + (unsigned)d - (unsigned)old);
-    if (a.idx == 0) a.e[0] = d; else if (a.idx == 1) a.e[1] = d; else if (a.idx == 2) a.e[2] = d; else a.e[3] = d;
-    a.idx = (a.idx + 1) & 3;
+    a.reg = (int)((unsigned)a.reg + (unsigned)d - (unsigned)a.e0);
+    a.e0 = a.e1; a.e1 = a.e2; a.e2 = a.e3; a.e3 = d;
 }
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -63,8 +70,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     __shared__ uint8_t  s_soft[48];
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
-    uint32_t his[4][4];                      // sample_his: 4 bursts of 4 packed samples (already >>2)
-    int his_idx = 0;
+    uint32_t h[16];                          // sample_his in TIME ORDER (oldest first): 4 bursts of 4 packed samples, already >>2
     Acc4 ac_re, ac_im, energy;
     uint32_t auto_count = 0, sense_count = 0, high_count = 0; int sync_high = 0, peak_corr = 0, peak_index = 0;
     uint32_t dc_cnt = 8; int sum_dc_re = 0, sum_dc_im = 0;            // TDCEstimator (dc.hpp:92-166); all 4 lanes of the vcs are equal
@@ -74,14 +80,14 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     uint32_t lts_n = 0, sym_n = 0, lts_start = 0, sym_start = 0, frame_start = 0;
     uint32_t remain_symbols = 0, sym_idx = 0;
     uint32_t nfr = 0;
-    FrameRow row;                                                       // being assembled (uniform)
+    // the frame row being assembled (wave-uniform scalars; written out once)
+    uint32_t r_start = 0, r_end = 0, r_rate = 0, r_slot0 = 0, r_data_start = 0, r_len = 0, r_nsym = 0, r_cr = 0, r_nb = 0;
+    int r_cfo = 0, r_cfo_comp = 0, r_sfo_comp = 0, r_cfo_tr = 0, r_sfo_tr = 0;
 
     auto cs_reset = [&]() {
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) his[a][b] = 0;
-        his_idx = 0; acc_clear(ac_re); acc_clear(ac_im); acc_clear(energy);
+        for (int a = 0; a < 16; a++) h[a] = 0;
+        acc_clear(ac_re); acc_clear(ac_im); acc_clear(energy);
         auto_count = sense_count = high_count = 0; sync_high = 0; peak_corr = 0; peak_index = 0;
         dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
     };
@@ -93,22 +99,26 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     cs_reset();
     auto sync = []() { __syncthreads(); };
 
-    // GetCrossCorrelation (cca.hpp:202-218) for pattern p, history read from slot k
-    auto cross_corr = [&](int k, int p) -> int {
+    // GetCrossCorrelation (cca.hpp:202-218) for pattern p: the reference starts at the oldest burst, i.e. h[0]
+    auto cross_corr = [&](int p) -> int {
         int sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
 #pragma unroll
         for (int v = 0; v < 4; v++) {
-            const int kk = (k + v) & 3;
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                uint32_t h = kk == 0 ? his[0][e] : kk == 1 ? his[1][e] : kk == 2 ? his[2][e] : his[3][e];
-                int re, im; conj_mul32(unpack(T.sts[p * 16 + 4 * v + e]), unpack(h), re, im);
+                int re, im; conj_mul32(unpack(T.sts[p * 16 + 4 * v + e]), unpack(h[4 * v + e]), re, im);
                 sre[e] = (int)((unsigned)sre[e] + (unsigned)re); sim[e] = (int)((unsigned)sim[e] + (unsigned)im);
             }
         }
         int r = (int)((unsigned)sre[0] + (unsigned)sre[1] + (unsigned)sre[2] + (unsigned)sre[3]);
         int i = (int)((unsigned)sim[0] + (unsigned)sim[1] + (unsigned)sim[2] + (unsigned)sim[3]);
         return abs(r) + abs(i);
+    };
+    auto his_push = [&](const cpx (&v)[4]) {
+#pragma unroll
+        for (int a = 0; a < 12; a++) h[a] = h[a + 4];
+#pragma unroll
+        for (int e = 0; e < 4; e++) h[12 + e] = pack(v[e]);
     };
 
     // Carrier sense reads the stream 4 samples at a time, wave-uniformly: stage 64 consecutive units per
@@ -130,6 +140,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
         while (vpos + BUR <= avail_end) {
             const uint32_t pos20 = vpos / STR;
             if (!cca_detected) {
+                PROBE_T0();
                 // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
                 uint32_t raw[4]; cpx pi[4];
 #pragma unroll
@@ -141,8 +152,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                     int sr = 0, si = 0, se = 0;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        uint32_t h = his_idx == 0 ? his[0][e] : his_idx == 1 ? his[1][e] : his_idx == 2 ? his[2][e] : his[3][e];
-                        int re, im; conj_mul32(pii[e], unpack(h), re, im);
+                        int re, im; conj_mul32(pii[e], unpack(h[e]), re, im);                 // sample_his.First(): 16 samples ago
                         sr = (int)((unsigned)sr + (unsigned)(re >> 4)); si = (int)((unsigned)si + (unsigned)(im >> 4));
                         se = (int)((unsigned)se + (unsigned)(sqnorm(pii[e]) >> 4));
                     }
@@ -150,18 +160,13 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                     const int iAuto = abs(ac_re.reg) + abs(ac_im.reg);
                     acc_push(energy, se);
                     const int iEnergy = energy.reg;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        uint32_t pk = pack(pii[e]);
-                        if (his_idx == 0) his[0][e] = pk; else if (his_idx == 1) his[1][e] = pk; else if (his_idx == 2) his[2][e] = pk; else his[3][e] = pk;
-                    }
-                    his_idx = (his_idx + 1) & 3;
+                    his_push(pii);
                     sense_count += 4;
                     if (iEnergy > (int)A.thr && iAuto >= iEnergy - (iEnergy >> 3)) {
                         auto_count++; sense_count = 0;
                         if (auto_count >= 4) {
                             // establish_sync (cca.hpp:220-243): lanes 0..15 take one pattern each
-                            int corr = cross_corr(his_idx, lane & 15);
+                            int corr = cross_corr(lane & 15);
                             int sum_corr = 0, best = 0, best_i = 0;
 #pragma unroll
                             for (int p = 0; p < 16; p++) {
@@ -179,15 +184,13 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                         auto_count = 0;
                     }
                 } else {
+                    { cpx q[4];
 #pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        uint32_t pk = pack(sra(pi[e], 2));
-                        if (his_idx == 0) his[0][e] = pk; else if (his_idx == 1) his[1][e] = pk; else if (his_idx == 2) his[2][e] = pk; else his[3][e] = pk;
-                    }
-                    his_idx = (his_idx + 1) & 3;
+                      for (int e = 0; e < 4; e++) q[e] = sra(pi[e], 2);
+                      his_push(q); }
                     high_count++;
                     if (high_count % 4 == 0) {
-                        int corr = cross_corr(his_idx, peak_index);               // check_sync (cca.hpp:245-265)
+                        int corr = cross_corr(peak_index);                        // check_sync (cca.hpp:245-265)
                         bool ok;
                         if (corr < (peak_corr >> 1)) ok = false; else { if (corr > peak_corr) peak_corr = corr; ok = true; }
                         if (!ok) {
@@ -208,11 +211,13 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                     dc_cnt--;
                 }
                 if (sense_count >= 84 && !sync_high) error_code = E_CS_TIMEOUT;     // cca.hpp:433-437
+                PROBE_ADD(0);
             } else if (!symbol_is_data) {
                 // ================= T11aLTS: IPORT COMPLEX16 x 144 (channel_11a.hpp:206-229)
                 if (lts_n == 0) lts_start = vpos;
                 lts_n += 4;
                 if (lts_n == 144) {
+                    PROBE_T0();
                     lts_n = 0; symbol_is_data = 1;
                     // stage the 144 samples (20 MHz rate) in LDS
                     for (int i = lane; i < 144; i += 64) s_x[i] = iq[lts_start + (uint32_t)i * STR];
@@ -255,9 +260,10 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                         }
                         fx->chan[lane] = coef;
                     }
-                    row.cfo_est = (int16_t)cfo;
+                    r_cfo = cfo;
                     __threadfence_block();
                     sync();
+                    PROBE_ADD(1);
                 }
             } else {
                 // ================= T11aDataSymbol: IPORT COMPLEX16 x 80 (PHY_11a.hpp:389-428)
@@ -266,6 +272,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                 if (sym_n == 80) {
                     sym_n = 0;
                     if (sym_idx == 0) {
+                        PROBE_T0();
                         // ---- the SIGNAL symbol: full header chain, lane-parallel
                         FrameCtx* fx = A.fctx + (size_t)cap_i * A.max_frames + nfr;
                         const int e = lane & 15;
@@ -363,20 +370,18 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                         }
                         const uint32_t len = (sig >> 5) & 0xFFF;
                         if (len > 2500) ok = false;
-                        row.capture = cap_i; row.start_sample = frame_start; row.slot0 = slot0; row.data_start = sym_start / STR;
-                        row.cfo_comp = (int16_t)cfo_comp; row.sfo_comp = (int16_t)sfo_comp;
-                        row.cfo_tracker = (int16_t)cfo_tracker; row.sfo_tracker = (int16_t)sfo_tracker;
-                        row.crc32 = 0; row.valid = 1; row.pad[0] = row.pad[1] = row.pad[2] = 0;
+                        r_start = frame_start; r_slot0 = slot0; r_data_start = sym_start / STR;
+                        r_cfo_comp = cfo_comp; r_sfo_comp = sfo_comp; r_cfo_tr = cfo_tracker; r_sfo_tr = sfo_tracker;
                         if (ok) {
                             const uint32_t ns = (len * 8 + 16 + 6 + (uint32_t)nd - 1) / (uint32_t)nd;   // B11aGetSymbolCount
-                            row.rate_kbps = kbps; row.length = (uint16_t)len; row.nsym = (uint16_t)ns;
-                            row.code_rate = (uint16_t)cr; row.nbpsc = (uint16_t)nb; row.error_code = 0;
+                            r_rate = kbps; r_len = len; r_nsym = ns; r_cr = (uint32_t)cr; r_nb = (uint32_t)nb;
                             remain_symbols = ns + 1; plcp_is_data = 1;
                         } else {
-                            row.rate_kbps = 0; row.length = 0; row.nsym = 0; row.code_rate = 0; row.nbpsc = 0;
+                            r_rate = 0; r_len = 0; r_nsym = 0; r_cr = 0; r_nb = 0;
                             error_code = E_PLCP_HEADER_FAIL;
                         }
                         sync();
+                        PROBE_ADD(2);
                     }
                     sym_idx++;
                     remain_symbols = (remain_symbols - 1) & 0xFFFF;                // ushort (PHY_11a.hpp:405)
@@ -392,7 +397,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                     }
                     if (remain_symbols == 0 && plcp_is_data) {
                         // all data symbols are in: the Viterbi sub-graph will raise FRAME_OK / CRC32_FAIL
-                        row.end_sample = pos20 + 4;
+                        r_end = pos20 + 4;
                         error_code = E_FRAME_OK;                                    // provisional: "frame complete"
                     }
                 }
@@ -404,17 +409,27 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
             if (error_code == E_CS_TIMEOUT) {
                 error_code = 0; cca_detected = 0; cs_reset();
             } else {
-                if (error_code == E_PLCP_HEADER_FAIL) { row.end_sample = vpos / STR; row.error_code = E_PLCP_HEADER_FAIL; }
+                const bool plcp_fail = error_code == E_PLCP_HEADER_FAIL;
+                if (plcp_fail) r_end = vpos / STR;
                 else {
-                    row.error_code = 0;                                             // pending: decided by k_finish
-                    // register the frame's symbol slots
-                    for (uint32_t s = lane; s <= row.nsym; s += 64) {
-                        A.slot_frame[row.slot0 + s] = (int32_t)(cap_i * A.max_frames + nfr);
-                        A.slot_sym[row.slot0 + s] = (uint16_t)s;
+                    // register the frame's symbol slots and queue it for the per-frame kernels
+                    for (uint32_t s = lane; s <= r_nsym; s += 64) {
+                        A.slot_frame[r_slot0 + s] = (int32_t)(cap_i * A.max_frames + nfr);
+                        A.slot_sym[r_slot0 + s] = (uint16_t)s;
                     }
                     if (lane == 0) A.joblist[atomicAdd(A.njobs, 1u)] = cap_i * A.max_frames + nfr;
                 }
-                if (lane == 0) A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
+                if (lane == 0) {
+                    FrameRow row;
+                    row.capture = cap_i; row.start_sample = r_start; row.end_sample = r_end;
+                    row.error_code = plcp_fail ? E_PLCP_HEADER_FAIL : 0u;                 // 0 = pending: decided by k_finish
+                    row.rate_kbps = r_rate; row.length = (uint16_t)r_len; row.nsym = (uint16_t)r_nsym;
+                    row.code_rate = (uint16_t)r_cr; row.nbpsc = (uint16_t)r_nb; row.slot0 = r_slot0; row.crc32 = 0;
+                    row.cfo_est = (int16_t)r_cfo; row.cfo_comp = (int16_t)r_cfo_comp; row.sfo_comp = (int16_t)r_sfo_comp;
+                    row.cfo_tracker = (int16_t)r_cfo_tr; row.sfo_tracker = (int16_t)r_sfo_tr; row.valid = 1;
+                    row.data_start = r_data_start; row.pad[0] = row.pad[1] = row.pad[2] = 0;
+                    A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
+                }
                 nfr++;
                 vpos = avail_end;                                                   // Flush + Reset drop the queued tail
                 frame_reset();
@@ -425,3 +440,12 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
 }
 
 }  // namespace sora
+
+#ifdef SORA_SCAN_PROBE
+extern "C" int sora_debug_scan_probe(unsigned long long* out, int reset)
+{
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sora::g_scan_probe), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sora::g_scan_probe), z, sizeof(z)); }
+    return 0;
+}
+#endif
