@@ -221,9 +221,10 @@ __device__ __forceinline__ void acs_bfly(VitLane& V, unsigned a, unsigned b)
     else              { x0 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xA0, 0xF, 0xF, true);        // quad_perm [0,0,2,2]
                         x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xF5, 0xF, 0xF, true); }      // quad_perm [1,1,3,3]
     const unsigned c0 = x0 + b0, c1 = x1 + b1;
-    const bool d = c1 < c0;
+    const uint64_t d = __ballot(c1 < c0);                                      // v_cmp_lt_u32 into an SGPR pair
     V.U = min(c0, c1);
-    V.hist = V.hist + V.hist + (d ? 1u : 0u);
+    uint64_t carry_out;
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(V.hist), "=s"(carry_out) : "s"(d));   // hist = 2*hist + decision, one VALU op
 }
 
 constexpr int kColsPerRow = 24;            // trellis columns per stored 256-byte decision row
@@ -231,7 +232,7 @@ constexpr int kColsPerRow = 24;            // trellis columns per stored 256-byt
 template <int CR>
 __device__ __forceinline__ void viterbi_forward(const VitJob& J, const uint8_t* soft_base, uint64_t* dec_base, uint32_t* tbk, uint32_t* nwin_out)
 {
-    const unsigned lane = threadIdx.x;
+    const unsigned lane = threadIdx.x & 63;
     const uint32_t* __restrict__ soft = reinterpret_cast<const uint32_t*>(soft_base + J.soft_off);
     uint32_t* decT = reinterpret_cast<uint32_t*>(dec_base + J.dec_off);
     const uint32_t nsoft = J.nsoft;
@@ -282,14 +283,25 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& J, const uint8_t* 
             uint32_t w[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((g0 & 63) + i));
+            if (g0 + 8 <= ngroups && next_thr > tr + 24) {
+                // fast path (9 rows out of 10): a whole row with no trace-back due -- straight-line, no per-group tests
 #pragma unroll
-            for (int i = 0; i < 8; i++) {
-                if (!done && g0 + i < ngroups) {
-                    if ((i & 1) == 0) { acs_bfly<0, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<1, 1>(V, sv(w[i], 2), 0); acs_bfly<2, 2>(V, 0, sv(w[i], 3)); }
-                    else              { acs_bfly<3, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<4, 1>(V, sv(w[i], 2), 0); acs_bfly<5, 2>(V, 0, sv(w[i], 3)); }
-                    tr += 3;
-                    if (i == 7) normalize();                                    // (tr & 7) == 0 <=> tr % 24 == 0 here
-                    check();
+                for (int i = 0; i < 8; i += 2) {
+                    acs_bfly<0, 0>(V, sv(w[i], 0), sv(w[i], 1));         acs_bfly<1, 1>(V, sv(w[i], 2), 0);     acs_bfly<2, 2>(V, 0, sv(w[i], 3));
+                    acs_bfly<3, 0>(V, sv(w[i + 1], 0), sv(w[i + 1], 1)); acs_bfly<4, 1>(V, sv(w[i + 1], 2), 0); acs_bfly<5, 2>(V, 0, sv(w[i + 1], 3));
+                }
+                tr += 24;
+                normalize();                                                    // (tr & 7) == 0 <=> tr % 24 == 0 at rate 3/4
+            } else {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    if (!done && g0 + i < ngroups) {
+                        if ((i & 1) == 0) { acs_bfly<0, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<1, 1>(V, sv(w[i], 2), 0); acs_bfly<2, 2>(V, 0, sv(w[i], 3)); }
+                        else              { acs_bfly<3, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<4, 1>(V, sv(w[i], 2), 0); acs_bfly<5, 2>(V, 0, sv(w[i], 3)); }
+                        tr += 3;
+                        if (i == 7) normalize();
+                        check();
+                    }
                 }
             }
             if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
@@ -350,9 +362,11 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& J, const uint8_t* 
     if (lane == 0) *nwin_out = nw;
 }
 
-__global__ void __launch_bounds__(64) k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin)
+// Four frames per 256-thread workgroup (one wave each, no cross-wave traffic): with one-wave workgroups the
+// dispatcher kept only 8 of them per CU, i.e. 2 waves per SIMD and a second round for a 4096-frame batch.
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin)
 {
-    const uint32_t f = blockIdx.x;
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (f >= (njobs_ptr ? *njobs_ptr : njobs_max)) return;
     const VitJob J = jobs[f];
     if (!J.valid) return;
@@ -440,17 +454,20 @@ __global__ void __launch_bounds__(64) k_traceback(const VitJob* jobs, const uint
 //     the same cycle, so scrambler byte j = seqbyte[(phase(seed) + 8 j) mod 127]  (two small tables, no chain);
 //   * the 64 lanes load / descramble / store the MPDU coalesced and park it in LDS;
 //   * CRC-32 is a byte-serial recurrence: lane 0 runs it slicing-by-8 out of LDS (8 x 1 KiB tables in LDS).
-__global__ void __launch_bounds__(64) k_finish(RxArgs A)
+__global__ void __launch_bounds__(256) k_finish(RxArgs A)
 {
     __shared__ uint32_t s_crc[8][256];
-    __shared__ uint32_t s_buf[2504 / 4 + 2];
-    if (blockIdx.x >= *A.njobs) return;
-    const uint32_t f = A.joblist[blockIdx.x];
+    __shared__ uint32_t s_bufs[4][2504 / 4 + 2];
+    for (int i = threadIdx.x; i < 2048; i += 256) s_crc[i >> 8][i & 255] = A.T.crc8[i];
+    __syncthreads();
+    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (j >= *A.njobs) return;
+    const uint32_t f = A.joblist[j];
     FrameRow& r = A.frames[f];
     if (!r.valid || r.error_code != 0) return;
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
     const Tables& T = A.T;
-    for (int i = lane; i < 2048; i += 64) s_crc[i >> 8][i & 255] = T.crc8[i];
+    uint32_t* s_buf = s_bufs[threadIdx.x >> 6];
     const uint8_t* dec = A.vout + (size_t)r.slot0 * kOutPerSlot;
     uint8_t* mp = A.mpdu + (size_t)r.slot0 * kOutPerSlot;
     const uint32_t L = r.length;
@@ -463,7 +480,8 @@ __global__ void __launch_bounds__(64) k_finish(RxArgs A)
         bytes[i] = (uint8_t)o;
         mp[i] = (uint8_t)o;
     }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();                                             // the LDS buffer is private to this wave
     if (lane == 0) {
         uint32_t crc = 0xFFFFFFFFu;
         const uint32_t n = L >= 4 ? L - 4 : 0;                                    // PHY_11a.hpp:668-673: the FCS bytes are not fed to the CRC

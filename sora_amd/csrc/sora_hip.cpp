@@ -380,11 +380,11 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     mark();
     hipLaunchKernelGGL(k_demap, dim3((slots + 3) / 4), dim3(256), 0, st, R);
     mark();
-    hipLaunchKernelGGL(k_viterbi, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
+    hipLaunchKernelGGL(k_viterbi, dim3((nrows + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
     mark();
     hipLaunchKernelGGL(k_traceback, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint64_t*)rx->d_dec, (const uint32_t*)rx->d_tbk, (const uint32_t*)rx->d_nwin, rx->d_vout);
     mark();
-    hipLaunchKernelGGL(k_finish, dim3(nrows), dim3(64), 0, st, R);
+    hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
     mark();
     HIPCHK(hipGetLastError());
     rx->ev_valid = prof;
@@ -534,7 +534,7 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
     HIPCHK(hipMalloc((void**)&decoff, 4 * n));
     HIPCHK(hipMemcpyAsync(decoff, h_dec_off.data(), 4 * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, d_soft_off, d_nsoft, d_frame_len, d_out_off, (const uint32_t*)decoff, code_rate, (uint32_t)n);
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, d_soft, dec, tbk, nwin);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, d_soft, dec, tbk, nwin);
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, (const uint64_t*)dec, (const uint32_t*)tbk, (const uint32_t*)nwin, d_out);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(jobs); (void)hipFree(dec); (void)hipFree(tbk); (void)hipFree(nwin); (void)hipFree(decoff);
