@@ -115,6 +115,22 @@ int  sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const 
  * ------------------------------------------------------------------------------------------------ */
 /* TFFT64  (Brick11/src/fft.hpp:108-135 -> core/inc/fft_r4dif.h FFT<64>): IPORT COMPLEX16x64 -> OPORT COMPLEX16x64 */
 int sora_hip_fft64(const sora_complex16* d_in, sora_complex16* d_out, size_t n, void* stream);
+/* FFT<128> (core/inc/fft_r4dif.h: 4 x 32, 8-point terminal stage; used by the reference's oversampled TX and the
+ * shape a 40 MHz HT receiver needs): IPORT COMPLEX16x128 -> OPORT COMPLEX16x128 */
+int sora_hip_fft128(const sora_complex16* d_in, sora_complex16* d_out, size_t n, void* stream);
+/* T11aLTS (channel_11a.hpp:33-230): IPORT COMPLEX16 x 144 -> the context facades it fills:
+ * CF_CFOffset::CFO_est, CF_FreqCompensate::Coeffs[16 vcs], CF_Channel_11a::ChannelCoeffs[16 vcs] */
+typedef struct { int16_t cfo_est; int16_t reserved; sora_complex16 freq[64]; sora_complex16 chan[64]; } sora_lts11a_ctx;
+int sora_hip_lts11a(const sora_complex16* d_in, sora_lts11a_ctx* d_ctx, size_t n, void* stream);
+/* T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization (PHY_11a.hpp:361-430, channel_11a.hpp:532-653):
+ * IPORT COMPLEX16 x 80 -> OPORT COMPLEX16 x 64; symbol i uses d_ctx[d_ctx_index[i]] (d_ctx_index NULL: d_ctx[0]) */
+int sora_hip_symfront11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_eq, size_t n, void* stream);
+/* TPhaseCompensate + TPilotTrack (freqoffset.hpp:14-66, pilot.hpp:121-269) over the symbols of n frames, in order:
+ * frame f owns symbols d_first[f] .. d_first[f]+d_nsym[f]-1 of d_eq; d_state[f] = CF_PhaseCompensate + CF_PilotTrack,
+ * read at entry and written back.  Bins 0 and 27..37 of the output are not defined by the reference and are written 0. */
+typedef struct { int16_t cfo_comp, sfo_comp, cfo_tracker, sfo_tracker; uint32_t symbol_count; sora_complex16 comp[64]; } sora_track11a_state;
+int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state,
+                            sora_complex16* d_out, size_t nframes, void* stream);
 /* T11aDemap<N_BPSC>::Filter (demapper11a.hpp:10-79): IPORT COMPLEX16x64 -> OPORT uchar x 48*n_bpsc */
 int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream);
 /* T11aDeinterleave{BPSK,QPSK,QAM16,QAM64} (deinterleaver.hpp): IPORT uchar x N_CBPS -> OPORT uchar x N_CBPS */

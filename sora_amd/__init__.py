@@ -3,5 +3,5 @@
 The product is sora_amd/lib/libsora_hip.so (hand-written HIP for gfx950, C ABI in include/sora_hip.h);
 this package is the thin Python binding used by the tests and bench.py.  There is no CPU compute path.
 """
-from .capi import (Rx, SoraError, device_count, load, lib_path, fft64, demap11a, deinterleave11a, viterbi11a,  # noqa: F401
+from .capi import (Rx, SoraError, device_count, load, lib_path, fft64, fft128, lts11a, symfront11a, pilot_track11a, demap11a, deinterleave11a, viterbi11a,  # noqa: F401
                    E_FRAME_OK, E_CRC32_FAIL, E_PLCP_HEADER_FAIL)

@@ -46,7 +46,7 @@ class FrameResult(ctypes.Structure):
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
-           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_hip_fft64", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a"]
+           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a"]
 
 _lib = None
 
@@ -92,6 +92,10 @@ def load(build_if_missing=True):
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
     L.sora_hip_fft64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_fft128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_lts11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_symfront11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_pilot_track11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_demap11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_deinterleave11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_viterbi11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
@@ -228,6 +232,39 @@ def fft64(x, stream=None):
     import torch
     out = torch.empty_like(x)
     _check(load().sora_hip_fft64(_dev_ptr(x), _dev_ptr(out), x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def fft128(x, stream=None):
+    """FFT<128>: x int16 CUDA tensor [n,128,2] -> same shape."""
+    import torch
+    out = torch.empty_like(x)
+    _check(load().sora_hip_fft128(_dev_ptr(x), _dev_ptr(out), x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def lts11a(x, stream=None):
+    """T11aLTS: x int16 CUDA [n,144,2] -> int16 CUDA [n,258]: (cfo_est, reserved, freq[64][2], chan[64][2])."""
+    import torch
+    out = torch.zeros((x.shape[0], 258), dtype=torch.int16, device=x.device)
+    _check(load().sora_hip_lts11a(_dev_ptr(x), _dev_ptr(out), x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def symfront11a(x, ctx, ctx_index=None, stream=None):
+    """x int16 CUDA [n,80,2], ctx = lts11a() output [m,258], ctx_index int32 CUDA [n] or None -> eq int16 [n,64,2]."""
+    import torch
+    out = torch.empty((x.shape[0], 64, 2), dtype=torch.int16, device=x.device)
+    _check(load().sora_hip_symfront11a(_dev_ptr(x), _dev_ptr(ctx), _dev_ptr(ctx_index) if ctx_index is not None else None,
+                                       _dev_ptr(out), x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def pilot_track11a(eq, first, nsym, state, stream=None):
+    """eq int16 CUDA [total,64,2]; first/nsym int32 CUDA [f]; state int16 CUDA [f,134] (in/out) -> tracked [total,64,2]."""
+    import torch
+    out = torch.zeros_like(eq)
+    _check(load().sora_hip_pilot_track11a(_dev_ptr(eq), _dev_ptr(first), _dev_ptr(nsym), _dev_ptr(state), _dev_ptr(out), first.shape[0], _stream_ptr(stream)))
     return out
 
 

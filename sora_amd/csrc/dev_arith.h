@@ -67,6 +67,9 @@ struct Tables {
     const uint32_t* crc8;        // [8][256] slicing-by-8 CRC-32 tables (table 0 == crc)
     const uint8_t*  scr_seq;     // [127] scrambler byte starting at cycle position q
     const uint8_t*  scr_phase;   // [128] cycle position of a 7-bit descrambler seed (255 for seed 0)
+    const uint32_t* tw128;       // [3][32] packed W128^{k j}
+    const uint32_t* tw32;        // [3][8]  packed W32^{k j}
+    const uint32_t* tw8;         // [4]     {W8^0, W8^1, W8^0, W8^3} (fft_lut_twiddle.h:61575-61581)
 };
 
 // uatan2 (core/inc/intalg.h:100-113): highest set bit of |y|,|x| -> common shift -> 256x256 LUT

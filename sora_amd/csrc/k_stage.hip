@@ -1,0 +1,204 @@
+// k_stage.hip -- stand-alone, batched versions of the remaining receive-path bricks, one C entry point each
+// (include/sora_hip.h), so every stage can be parity-tested on its own and sit behind a BRICK adapter:
+//   k_lts_batch       T11aLTS                                        (channel_11a.hpp:33-230)
+//   k_symfront_batch  T11aDataSymbol + TFreqCompensation + TFFT64 + TChannelEqualization
+//   k_ptrack_batch    TPhaseCompensate + TPilotTrack, symbol by symbol (freqoffset.hpp:14-66, pilot.hpp:121-269)
+//   k_fft128_batch    FFT<128>   (core/inc/fft_r4dif.h: 128 = 4 x 32, 32 = 4 x 8, 8-point terminal stage)
+#include "kernels.h"
+
+namespace sora {
+
+__device__ __constant__ uint8_t kLtsSeqS[64] = {        // LTS_Sequence_11a (channel_11a.hpp:13-18)
+    0,1,0,0,1,1,0,1,0,1,0,0,0,0,0,1, 1,0,0,1,0,1,0,1,1,1,1,0,0,0,0,0,
+    0,0,0,0,0,0,1,1,0,0,1,1,0,1,0,1, 1,1,1,1,1,0,0,1,1,0,1,0,1,1,1,1 };
+__device__ __constant__ uint8_t kPilotSgnS[128] = {     // pilot.hpp:10-28: 1 <=> polarity -1
+    0,0,0,1,1,1,0,1, 1,1,1,0,0,1,0,1, 1,0,0,1,0,0,1,0, 0,0,0,0,0,1,0,0,
+    0,1,0,0,1,1,0,0, 0,1,0,1,1,1,0,1, 0,1,1,0,1,1,0,0, 0,0,0,1,1,0,0,1,
+    1,0,1,0,1,0,0,1, 1,1,0,0,1,1,1,1, 0,1,1,0,1,0,0,0, 0,1,0,1,0,1,0,1,
+    1,1,1,1,0,1,0,0, 1,0,1,0,0,0,1,1, 0,1,1,1,0,0,0,1, 1,1,1,1,1,1,0,0 };
+
+__device__ __forceinline__ int wave_sum_i(int v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = (int)((unsigned)v + (unsigned)__shfl_xor(v, o));
+    return v;
+}
+
+// sora_lts11a_ctx: { int16 cfo_est; int16 reserved; COMPLEX16 freq[64]; COMPLEX16 chan[64]; } = 129 words
+__global__ void __launch_bounds__(64) k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Tables T)
+{
+    __shared__ uint32_t s_fft[64];
+    __shared__ uint32_t s_x[144];
+    const uint32_t f = blockIdx.x;
+    if (f >= n) return;
+    const int lane = threadIdx.x;
+    auto sync = []() { __syncthreads(); };
+    for (int i = lane; i < 144; i += 64) s_x[i] = in[(size_t)f * 144 + i];
+    sync();
+    cpx x1 = sra(unpack(s_x[8 + lane]), 1);                                    // skip_cp = 8; first 64 samples >> 1 (:211-216)
+    cpx x2 = unpack(s_x[8 + 64 + lane]);
+    int re, im; conj_mul32(x2, x1, re, im);                                    // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
+    const int sum_re = wave_sum_i(re >> 5), sum_im = wave_sum_i(im >> 5);
+    const int cfo = w16(uatan2(T, sum_im, sum_re) / 64);
+    const cpx fc = rot_coeff(T, w16(lane * cfo));                               // BuildFrequencyShiftCoeffs<64> (dspalg.hpp:200-208)
+    uint32_t* o = ctx + (size_t)f * 129;
+    if (lane == 0) o[0] = (uint32_t)cfo & 0xFFFFu;
+    o[1 + lane] = pack(fc);
+    cpx xs = mul_q15(x1, fc);                                                   // FrequencyShift (:120)
+    sync();
+    s_x[lane] = pack(xs);
+    sync();
+    cpx Y[4];
+    {
+        const int e = lane & 15;
+        cpx xin[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) xin[m] = unpack(s_x[e + 16 * m]);
+        fft64_group(xin, Y, s_fft, e, T, sync);
+    }
+    cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
+    uint32_t coef = 0;
+    if (!(lane >= 28 && lane < 36)) {                                           // _channel_estimation (:125-178)
+        const int e = sqnorm(Yb) >> 8;
+        const cpx L = mk(kLtsSeqS[lane] ? 1600 : -1600, 0);
+        int cre, cim; conj_mul32(L, Yb, cre, cim);
+        int rre = 0, rim = 0;
+        if (e != 0) { rre = cre / e; rim = cim / e; }
+        coef = pack(mk(w16(rre), w16(rim)));
+    }
+    o[65 + lane] = coef;
+}
+
+__global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T)
+{
+    __shared__ uint32_t s_all[16][64];
+    const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
+    const uint32_t i = blockIdx.x * 16 + g;
+    const bool active = i < n;
+    const uint32_t* c = ctx + (size_t)(active && ctx_index ? ctx_index[i] : 0u) * 129;
+    cpx x[4], Y[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int k = e + 16 * m;
+        x[m] = active ? mul_q15(sra(unpack(in[(size_t)i * 80 + 8 + k]), 1), unpack(c[1 + k])) : mk(0, 0);
+    }
+    fft64_group(x, Y, s_all[g], e, T, []() { __syncthreads(); });
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const int bin = e + 16 * q;
+            cpx o = mk(0, 0);
+            if (!(bin >= 28 && bin < 36)) { int re, im; mul32(Y[q], unpack(c[65 + bin]), re, im); o = mk(w16(re >> 8), w16(im >> 8)); }
+            eq[(size_t)i * 64 + bin] = pack(o);
+        }
+    }
+}
+
+// sora_track11a_state: { int16 cfo_comp, sfo_comp, cfo_tracker, sfo_tracker; uint32 symbol_count; COMPLEX16 comp[64]; } = 67 words
+__global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T)
+{
+    const uint32_t f = blockIdx.x;
+    if (f >= nframes) return;
+    const int lane = threadIdx.x;
+    uint32_t* st = state + (size_t)f * 67;
+    int cfo_comp = (int)(short)(st[0] & 0xFFFF), sfo_comp = (int)st[0] >> 16;
+    int cfo_tr = (int)(short)(st[1] & 0xFFFF), sfo_tr = (int)st[1] >> 16;
+    unsigned symbol_count = st[2];
+    cpx comp = unpack(st[3 + lane]);                                            // CompCoeffs[lane]
+    const int c = lane < 32 ? lane : lane - 64;                                 // signed carrier number of bin `lane`
+    const bool data_bin = (lane >= 1 && lane <= 26) || lane >= 38;              // bins _build_coeff writes (pilot.hpp:138-164)
+    const uint32_t s0 = first[f], ns = nsym[f];
+    for (uint32_t s = 0; s < ns; s++) {
+        const cpx pc = mul_q15(unpack(eq[(size_t)(s0 + s) * 64 + lane]), comp);    // TPhaseCompensate: rep_mul<16>
+        const uint32_t pk = pack(pc);
+        const cpx p43 = unpack((uint32_t)__shfl((int)pk, 43)), p57 = unpack((uint32_t)__shfl((int)pk, 57));
+        const cpx p7 = unpack((uint32_t)__shfl((int)pk, 7)),   p21 = unpack((uint32_t)__shfl((int)pk, 21));
+        int th1 = uatan2(T, p43.im, p43.re), th2 = uatan2(T, p57.im, p57.re);
+        int th3 = uatan2(T, p7.im, p7.re),   th4 = uatan2(T, -p21.im, -p21.re);
+        if (kPilotSgnS[symbol_count & 127]) { th1 = w16(th1 + 0x8000); th2 = w16(th2 + 0x8000); th3 = w16(th3 + 0x8000); th4 = w16(th4 + 0x8000); }
+        symbol_count++; if (symbol_count >= 127) symbol_count = 0;
+        const int avg = w16((th1 + th2 + th3 + th4) / 4);
+        const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+        cpx o = mk(0, 0);                                                        // bins 0, 27..37: not produced by _rotate / undefined in the reference
+        if (data_bin) o = mul_q15(pc, rot_coeff(T, w16(avg + c * del)));
+        out[(size_t)(s0 + s) * 64 + lane] = pack(o);
+        cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
+        cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
+        if (data_bin) comp = rot_coeff(T, w16(cfo_comp + c * sfo_comp));         // _build_coeff(CompCoeffs, CFO_comp, SFO_comp)
+    }
+    st[3 + lane] = pack(comp);
+    if (lane == 0) {
+        st[0] = ((uint32_t)cfo_comp & 0xFFFFu) | ((uint32_t)sfo_comp << 16);
+        st[1] = ((uint32_t)cfo_tr & 0xFFFFu) | ((uint32_t)sfo_tr << 16);
+        st[2] = symbol_count;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// FFT<128>: 32 lanes per transform, 4 points per lane, 8 transforms per 256-thread block.
+__device__ __forceinline__ void r4_bfly(cpx a, cpx b, cpx c, cpx d, cpx w1, cpx w2, cpx w3, cpx& y0, cpx& y1, cpx& y2, cpx& y3)
+{
+    a = sra(a, 2); b = sra(b, 2); c = sra(c, 2); d = sra(d, 2);                 // FFTSSE<N> (fft_r4dif.h:11-47)
+    cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
+    cpx jb = mul_j(b_d);
+    y0 = cadds(ac, bd);
+    y1 = mul_shift15(csubs(ac, bd), w2);
+    y2 = mul_shift15(csubs(a_c, jb), w1);
+    y3 = mul_shift15(cadds(a_c, jb), w3);
+}
+
+__global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T)
+{
+    __shared__ uint32_t s_all[8][128];
+    const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
+    const uint32_t i = blockIdx.x * 8 + g;
+    uint32_t* s = s_all[g];
+    const bool active = i < n;
+    // stage N=128: butterfly e on points e, e+32, e+64, e+96
+    {
+        cpx a = active ? unpack(in[(size_t)i * 128 + e]) : mk(0, 0), b = active ? unpack(in[(size_t)i * 128 + e + 32]) : mk(0, 0);
+        cpx c = active ? unpack(in[(size_t)i * 128 + e + 64]) : mk(0, 0), d = active ? unpack(in[(size_t)i * 128 + e + 96]) : mk(0, 0);
+        cpx y0, y1, y2, y3;
+        r4_bfly(a, b, c, d, unpack(T.tw128[e]), unpack(T.tw128[32 + e]), unpack(T.tw128[64 + e]), y0, y1, y2, y3);
+        s[e] = pack(y0); s[e + 32] = pack(y1); s[e + 64] = pack(y2); s[e + 96] = pack(y3);
+    }
+    __syncthreads();
+    // stage N=32 on quarter k = e>>3: butterfly j = e&7 on points 32k + j + {0,8,16,24}
+    {
+        const int k = e >> 3, j = e & 7, base = 32 * k + j;
+        cpx y0, y1, y2, y3;
+        r4_bfly(unpack(s[base]), unpack(s[base + 8]), unpack(s[base + 16]), unpack(s[base + 24]),
+                unpack(T.tw32[j]), unpack(T.tw32[8 + j]), unpack(T.tw32[16 + j]), y0, y1, y2, y3);
+        s[base] = pack(y0); s[base + 8] = pack(y1); s[base + 16] = pack(y2); s[base + 24] = pack(y3);
+    }
+    __syncthreads();
+    // terminal 8-point stage (FFTSSEEx<8>, fft_r4dif.h:86-130) on points 8m..8m+7, m = 0..15: lanes 0..15
+    if (e < 16) {
+        uint32_t* p = s + 8 * e;
+        cpx a[4], b[4], d[4], sm[4], ee[4], gg[4], ff[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { a[q] = sra(unpack(p[q]), 3); b[q] = sra(unpack(p[4 + q]), 3); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { d[q] = csubs(a[q], b[q]); sm[q] = cadds(a[q], b[q]); }
+        ee[0] = d[0]; ee[1] = d[1]; ee[2] = mk(d[2].im, ~d[2].re); ee[3] = mk(d[3].im, ~d[3].re);
+        gg[0] = cadds(ee[0], ee[2]); gg[1] = cadds(ee[1], ee[3]); gg[2] = cadds(cnot(ee[2]), ee[0]); gg[3] = cadds(cnot(ee[3]), ee[1]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ff[q] = mul_shift15(gg[q], unpack(T.tw8[q]));
+        p[4] = pack(cadds(ff[0], ff[1])); p[5] = pack(cadds(cnot(ff[1]), ff[0]));
+        p[6] = pack(cadds(ff[2], ff[3])); p[7] = pack(cadds(cnot(ff[3]), ff[2]));
+        cpx A0 = cadds(sm[0], sm[2]), A1 = cadds(sm[1], sm[3]);
+        cpx B0 = cadds(cnot(sm[2]), sm[0]), B1 = cadds(cnot(sm[3]), sm[1]);
+        cpx B1r = mk(B1.im, ~B1.re);
+        p[0] = pack(cadds(A0, A1)); p[1] = pack(cadds(cnot(A1), A0)); p[2] = pack(cadds(B0, B1r)); p[3] = pack(cadds(cnot(B1r), B0));
+    }
+    __syncthreads();
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const unsigned j = (unsigned)(e + 32 * q);
+            out[(size_t)i * 128 + j] = s[__brev(j) >> 25];                         // FFT128LUTMap = 7-bit bit reversal
+        }
+    }
+}
+
+}  // namespace sora

@@ -61,6 +61,10 @@ __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const Ca
 __global__ void k_fft64_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
 __global__ void k_demap_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n, Tables T);
 __global__ void k_deint_batch(const uint8_t* in, uint8_t* out, int nb, uint32_t n, Tables T);
+__global__ void k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Tables T);
+__global__ void k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T);
+__global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
+__global__ void k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
 __global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
                                const uint32_t* out_off, const uint32_t* dec_off, int code_rate, uint32_t n);
 

@@ -32,7 +32,7 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 struct HostTables {
     std::vector<int16_t> usin, ucos, uatan2;
     std::vector<uint8_t> demap;
-    std::vector<uint32_t> tw64, tw16, sts, crc;
+    std::vector<uint32_t> tw64, tw16, sts, crc, tw128, tw32, tw8;
     std::vector<uint16_t> deint;
     std::vector<uint8_t> scr, scr_seq, scr_phase;
     std::vector<uint32_t> crc8;
@@ -113,6 +113,13 @@ static void build_tables(HostTables& H)
         for (int j = 0; j < 16; j++) { double a = 2 * PI * k * j / 64.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a)); H.tw64[(k - 1) * 16 + j] = pk(re, im); t64[k - 1].push_back(hostfft::mk(re, im)); }
         for (int j = 0; j < 4; j++)  { double a = 2 * PI * k * j / 16.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a)); H.tw16[(k - 1) * 4 + j] = pk(re, im);  t16[k - 1].push_back(hostfft::mk(re, im)); }
     }
+    H.tw128.resize(96); H.tw32.resize(24); H.tw8.resize(4);
+    for (int k = 1; k <= 3; k++) {
+        for (int j = 0; j < 32; j++) { double a = 2 * PI * k * j / 128.0; H.tw128[(k - 1) * 32 + j] = pk((int)(32767.0 * std::cos(a)), (int)(-32767.0 * std::sin(a))); }
+        for (int j = 0; j < 8; j++)  { double a = 2 * PI * k * j / 32.0;  H.tw32[(k - 1) * 8 + j]   = pk((int)(32767.0 * std::cos(a)), (int)(-32767.0 * std::sin(a))); }
+    }
+    H.tw8[0] = pk(32767, 0); H.tw8[1] = pk((int)(32767.0 * std::cos(PI / 4)), (int)(-32767.0 * std::sin(PI / 4)));
+    H.tw8[2] = pk(32767, 0); H.tw8[3] = pk((int)(32767.0 * std::cos(3 * PI / 4)), (int)(-32767.0 * std::sin(3 * PI / 4)));
     // STS correlation patterns: Generate80211aSTS<64> (brick/inc/sequence.h:5-33) + cca.hpp:268-277
     {
         hostfft::c f[64]; for (auto& v : f) v = hostfft::mk(0, 0);
@@ -199,6 +206,9 @@ static int make_dev_tables(DevTables& D)
     if ((rc = upload(D, H.crc8, (const void**)&D.T.crc8))) return rc;
     if ((rc = upload(D, H.scr_seq, (const void**)&D.T.scr_seq))) return rc;
     if ((rc = upload(D, H.scr_phase, (const void**)&D.T.scr_phase))) return rc;
+    if ((rc = upload(D, H.tw128, (const void**)&D.T.tw128))) return rc;
+    if ((rc = upload(D, H.tw32, (const void**)&D.T.tw32))) return rc;
+    if ((rc = upload(D, H.tw8, (const void**)&D.T.tw8))) return rc;
     return SORA_OK;
 }
 static void free_dev_tables(DevTables& D) { for (void* p : D.allocs) (void)hipFree(p); D.allocs.clear(); }
@@ -487,6 +497,55 @@ int sora_hip_fft64(const sora_complex16* d_in, sora_complex16* d_out, size_t n, 
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
     hipLaunchKernelGGL(k_fft64_batch, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_out), (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_fft128(const sora_complex16* d_in, sora_complex16* d_out, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_fft128: null pointer");
+    if (n == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_fft128_batch, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_out), (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_lts11a(const sora_complex16* d_in, sora_lts11a_ctx* d_ctx, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_ctx) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_lts11a: null pointer");
+    static_assert(sizeof(sora_lts11a_ctx) == 516, "sora_lts11a_ctx layout");
+    if (n == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_lts_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_ctx), (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_symfront11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_eq, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_ctx || !d_eq) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_symfront11a: null pointer");
+    if (n == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_symfront_batch, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in),
+                       reinterpret_cast<const uint32_t*>(d_ctx), d_ctx_index, reinterpret_cast<uint32_t*>(d_eq), (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_eq || !d_first || !d_nsym || !d_state || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_pilot_track11a: null pointer");
+    static_assert(sizeof(sora_track11a_state) == 268, "sora_track11a_state layout");
+    if (nframes == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipLaunchKernelGGL(k_ptrack_batch, dim3((unsigned)nframes), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_eq), d_first, d_nsym,
+                       reinterpret_cast<uint32_t*>(d_state), reinterpret_cast<uint32_t*>(d_out), (uint32_t)nframes, D->T);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }

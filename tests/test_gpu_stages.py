@@ -1,0 +1,104 @@
+"""GPU parity of the per-stage entry points (the brick-by-brick boundary) against the oracle's stage functions:
+T11aLTS, the symbol front end, TPhaseCompensate+TPilotTrack, FFT<128>.  0 LSB everywhere."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from gpu_util import awgn
+from oracle.pyoracle import RATES
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import sora_amd
+    sora_amd.load()
+    assert torch.cuda.is_available()
+    return torch, sora_amd
+
+
+def frames_for_stage_tests(oracle, n=6):
+    """Noisy captures -> (capture@20MHz, frame start, nsym) using the oracle's own receiver for the timing."""
+    out = []
+    for i in range(n):
+        rate = RATES[i % 8]
+        rng = np.random.default_rng(500 + i)
+        mp = rng.integers(0, 256, 150 + 40 * i).astype(np.uint8).tobytes()
+        cap = awgn(oracle.tx_capture(mp, rate, lead=8 * i), 250, i)[::2].copy()
+        z = (cap[:, 0].astype(np.float64) + 1j * cap[:, 1]) * np.exp(2j * np.pi * (i - 2) * 15e3 * np.arange(len(cap)) / 20e6)
+        cap = np.stack([np.rint(z.real), np.rint(z.imag)], 1).astype(np.int16)
+        res = oracle.rx_capture(cap, 20)
+        if len(res) == 1 and res[0]["length"]:
+            out.append((cap, res[0]["start_sample"], res[0]["nsym"]))
+    assert len(out) >= 4
+    return out
+
+
+def test_lts_symfront_track_chain(env, oracle):
+    torch, sora = env
+    frames = frames_for_stage_tests(oracle)
+    lts_in = np.stack([c[s:s + 144] for c, s, _ in frames])
+    ctx_gpu = sora.lts11a(torch.from_numpy(lts_in).cuda())
+    ctx_h = ctx_gpu.cpu().numpy()
+    # ---- T11aLTS
+    octx = []
+    for i, (c, s, _) in enumerate(frames):
+        k = oracle.new_ctx(); oracle.lts(k, c[s:s + 144]); octx.append(k)
+        assert ctx_h[i, 0] == k.CFO_est
+        assert np.array_equal(ctx_h[i, 2:130], np.array(k.FreqCoeffs[:], np.int16))
+        assert np.array_equal(ctx_h[i, 130:258], np.array(k.ChannelCoeffs[:], np.int16))
+    assert any(k.CFO_est != 0 for k in octx)
+    # ---- symbol front end over every symbol (SIGNAL + data) of every frame
+    syms, idx, first, nsym = [], [], [], []
+    for i, (c, s, ns) in enumerate(frames):
+        first.append(len(syms)); nsym.append(ns + 1)
+        for k in range(ns + 1):
+            p = s + 144 + 80 * k
+            syms.append(c[p:p + 80]); idx.append(i)
+    x = torch.from_numpy(np.stack(syms)).cuda()
+    eq = sora.symfront11a(x, ctx_gpu, torch.tensor(idx, dtype=torch.int32).cuda())
+    eq_h = eq.cpu().numpy()
+    want_eq = np.stack([oracle.sym_front(octx[i], sy) for sy, i in zip(syms, idx)])
+    assert np.array_equal(eq_h, want_eq)
+    # ---- pilot tracking, frame by frame, from the reset state (CompCoeffs = 0x7fff, symbol_count = 127)
+    st = np.zeros((len(frames), 134), np.int16)
+    st[:, 4] = 127                                                     # symbol_count (uint32 at int16 index 4..5)
+    st[:, 6::2] = 0x7fff                                               # comp[k].re
+    st_d = torch.from_numpy(st).cuda()
+    trk = sora.pilot_track11a(eq, torch.tensor(first, dtype=torch.int32).cuda(), torch.tensor(nsym, dtype=torch.int32).cuda(), st_d)
+    trk_h = trk.cpu().numpy(); st_h = st_d.cpu().numpy()
+    used = [b for b in range(64) if (1 <= b <= 26 or b >= 38)]
+    for i in range(len(frames)):
+        k = octx[i]
+        for s_i in range(nsym[i]):
+            w = oracle.sym_track(k, want_eq[first[i] + s_i])
+            assert np.array_equal(trk_h[first[i] + s_i][used], w[used]), (i, s_i)
+        assert (st_h[i, 0], st_h[i, 1], st_h[i, 2], st_h[i, 3]) == (k.CFO_comp, k.SFO_comp, k.CFO_tracker, k.SFO_tracker)
+        assert int(st_h[i, 4:6].view(np.uint32)[0]) == k.symbol_count
+        assert np.array_equal(st_h[i, 6:].reshape(64, 2)[used], np.array(k.CompCoeffs[:], np.int16).reshape(64, 2)[used])
+
+
+def test_fft128_bit_exact(env, oracle):
+    torch, sora = env
+    rng = np.random.default_rng(9)
+    n = 301
+    amps = np.array([32767, 20000, 8000, 500, 30])[np.arange(n) % 5]
+    x = (rng.integers(-32768, 32768, size=(n, 128, 2)) % (2 * amps[:, None, None] + 1) - amps[:, None, None]).astype(np.int16)
+    x[5, 9] = (-32768, 32767); x[6] = 32767; x[7] = -32768
+    got = sora.fft128(torch.from_numpy(x).cuda()).cpu().numpy()
+    for i in range(n):
+        assert np.array_equal(got[i], oracle.fft(x[i], 128)), i
+
+
+def test_fft128_matches_reference_vectors(env, golden_dir):
+    """The committed vectors produced by the reference's own FFT<128> (tests/golden/ref_vectors.npz)."""
+    import os
+    torch, sora = env
+    v = np.load(os.path.join(golden_dir, "ref_vectors.npz"))
+    got = sora.fft128(torch.from_numpy(v["fft128_in"]).cuda()).cpu().numpy()
+    assert np.array_equal(got, v["fft128_out"])
+    got64 = sora.fft64(torch.from_numpy(v["fft64_in"]).cuda()).cpu().numpy()
+    assert np.array_equal(got64, v["fft64_out"])
