@@ -8,6 +8,7 @@
 //   k_finish      T11aDesc + TBB11aFrameSink (descramble, CRC-32, FRAME_OK / CRC32_FAIL)   (one thread per frame)
 // plus the stand-alone stage kernels behind the per-stage C entry points.
 #include <hip/hip_runtime.h>
+#include <utility>
 #include "kernels.h"
 
 namespace sora {
@@ -76,7 +77,7 @@ __global__ void __launch_bounds__(64) k_track(RxArgs A)
     const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
     VitJob J; J.pad = 0;
-    J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+    J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot * 2u; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
     J.dec_off = r.slot0 * (uint32_t)kDecPerSlot; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
     A.jobs[j] = J;
     const Tables& T = A.T;
@@ -143,13 +144,10 @@ __global__ void __launch_bounds__(256) k_demap(RxArgs A)
         const int ncbps = 48 * nb;
         const int di = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3;
         const uint16_t* map = T.deint + di * 288;
-        uint8_t* dst = A.soft + (size_t)slot0 * kSoftPerSlot + (size_t)(sym - 1) * ncbps;
-        for (int k4 = lane; k4 < ncbps / 4; k4 += 64) {                             // T11aDeinterleave* : out[k] = in[j(k)]
-            uint32_t v = 0;
-#pragma unroll
-            for (int b = 0; b < 4; b++) v |= (uint32_t)s_soft[w][map[4 * k4 + b]] << (8 * b);
-            reinterpret_cast<uint32_t*>(dst)[k4] = v;
-        }
+        // soft stream of the frame, one 16-bit field per soft value, already in the Viterbi kernel's metric format (v << 9)
+        uint32_t* dst = reinterpret_cast<uint32_t*>(A.soft + ((size_t)slot0 * kSoftPerSlot + (size_t)(sym - 1) * ncbps) * 2);
+        for (int k2 = lane; k2 < ncbps / 2; k2 += 64)                               // T11aDeinterleave* : out[k] = in[j(k)]
+            dst[k2] = ((uint32_t)s_soft[w][map[2 * k2]] << 9) | ((uint32_t)s_soft[w][map[2 * k2 + 1]] << 25);
     }
 }
 
@@ -193,18 +191,42 @@ __device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wi
     return min(r32[0], r32[1]);
 }
 
+// Two frames per wave.  The metric of frame A lives in the low 16-bit half of the lane's register (u in bits 15:9),
+// frame B's in the high half (bits 31:25): v_pk_add_u16 / v_pk_min_u16 run both trellises with one instruction,
+// and the cross-lane exchanges move both halves at once.  Integer VALU ops issue at one wave64 instruction per
+// ~4.4 cycles per SIMD on this part (measured: 10.3 VALU/step <-> 46 cycles/step at 4 waves/SIMD), so the kernel
+// is bound by VALU instructions per trellis step per frame: 10.3 with one frame per wave, 6.5 with two.
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ unsigned pk_min16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
+
+__device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-half wave-wide unsigned minimum, broadcast to all lanes
+{
+    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // ^1
+    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // ^2
+    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));   // row_ror:4
+    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));   // row_ror:8
+    auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = pk_min16(r16[0], r16[1]);
+    auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return pk_min16(r32[0], r32[1]);
+}
+
 struct VitLane {
-    unsigned U;              // u << 25 of the state this lane currently holds
-    unsigned hist;           // decisions of this lane, newest in bit 0
-    unsigned MA[6], MB[6];   // (expected bit ? 7 : 0) << 25 for the decision-0 branch into the lane's next state, per phase
+    unsigned U;              // (u_B << 25) | (u_A << 9): metrics of the state this lane currently holds, frames A and B
+    unsigned histA, histB;   // decisions of this lane, newest in bit 0
+    unsigned MA[6], MB[6];   // (expected bit ? 7 : 0) in both fields, for the decision-0 branch into the lane's next state, per phase
 };
 
-template <int PH, int WHICH>   // PH = t mod 6; WHICH 0: (A,B)  1: A only  2: B only.  a, b = soft value << 25 (wave-uniform)
+constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
+
+template <int PH, int WHICH>   // PH = t mod 6; WHICH 0: (A,B)  1: A only  2: B only.  a, b = packed soft values (wave-uniform)
 __device__ __forceinline__ void acs_bfly(VitLane& V, unsigned a, unsigned b)
 {
-    constexpr unsigned K = (WHICH == 0 ? 14u : 7u) << 25;
+    constexpr unsigned K = (WHICH == 0 ? 14u : 7u) * kFld;
     unsigned b0;
-    if (WHICH == 0)      b0 = (a ^ V.MA[PH]) + (b ^ V.MB[PH]);
+    if (WHICH == 0)      b0 = (a ^ V.MA[PH]) + (b ^ V.MB[PH]);                   // per field <= 14: no carry between the halves
     else if (WHICH == 1) b0 = a ^ V.MA[PH];
     else                 b0 = b ^ V.MB[PH];
     const unsigned b1 = K - b0;
@@ -220,160 +242,199 @@ __device__ __forceinline__ void acs_bfly(VitLane& V, unsigned a, unsigned b)
                         x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xEE, 0xF, 0xF, true); }      // quad_perm [2,3,2,3]
     else              { x0 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xA0, 0xF, 0xF, true);        // quad_perm [0,0,2,2]
                         x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xF5, 0xF, 0xF, true); }      // quad_perm [1,1,3,3]
-    const unsigned c0 = x0 + b0, c1 = x1 + b1;
-    const uint64_t d = __ballot(c1 < c0);                                      // v_cmp_lt_u32 into an SGPR pair
-    V.U = min(c0, c1);
+    const unsigned c0 = pk_add16(x0, b0), c1 = pk_add16(x1, b1);
+    const uint64_t dA = __ballot((unsigned short)c1 < (unsigned short)c0);      // decision of frame A: strict compare, a tie keeps branch 0
+    const uint64_t dB = __ballot((c1 >> 16) < (c0 >> 16));                      // decision of frame B
+    V.U = pk_min16(c0, c1);
     uint64_t carry_out;
-    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(V.hist), "=s"(carry_out) : "s"(d));   // hist = 2*hist + decision, one VALU op
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(V.histA), "=s"(carry_out) : "s"(dA));   // hist = 2*hist + decision, one VALU op
+    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(V.histB), "=s"(carry_out) : "s"(dB));
 }
 
 constexpr int kColsPerRow = 24;            // trellis columns per stored 256-byte decision row
 
+struct VitSide {            // wave-uniform per-frame bookkeeping
+    const uint32_t* soft; uint32_t* decT; uint32_t* tbk; uint32_t nsteps, last_chunk, tr_end, nw; bool on, done;
+};
+
+// Soft input: 16 bits per soft value, v << 9 (what k_demap / k_soft_widen write), so a packed branch-metric operand is
+// one s_pack_ll/hh_b32_b16 of a word of frame A and a word of frame B.  The words arrive through the scalar cache
+// (s_load_dwordx8 per 12-step chunk per frame, prefetched one chunk ahead): no VALU work, no LDS.
 template <int CR>
-__device__ __forceinline__ void viterbi_forward(const VitJob& J, const uint8_t* soft_base, uint64_t* dec_base, uint32_t* tbk, uint32_t* nwin_out)
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint64_t* __restrict__ dec_base,
+                                                uint32_t* __restrict__ tbkA, uint32_t* __restrict__ tbkB, uint32_t* __restrict__ nwinA, uint32_t* __restrict__ nwinB)
 {
+    constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
+    constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
+    constexpr int CW = 12 / GS * GB / 2;                                        // 32-bit soft words per 12-step chunk: 12 / 9 / 8
     const unsigned lane = threadIdx.x & 63;
-    const uint32_t* __restrict__ soft = reinterpret_cast<const uint32_t*>(soft_base + J.soft_off);
-    uint32_t* decT = reinterpret_cast<uint32_t*>(dec_base + J.dec_off);
-    const uint32_t nsoft = J.nsoft;
-    const uint32_t tr_end = J.length * 8u + 16u + 6u;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    VitSide A, B;
+    const uint32_t softA = uni(JA.soft_off), softB = uni(hasB ? JB.soft_off : JA.soft_off);
+    const uint32_t nsA = uni(JA.nsoft), nsB = uni(hasB ? JB.nsoft : JA.nsoft);
+    A.soft = reinterpret_cast<const uint32_t*>(soft_base + softA); A.decT = reinterpret_cast<uint32_t*>(dec_base + uni(JA.dec_off));
+    A.tbk = tbkA; A.nsteps = nsA / GB * GS; A.last_chunk = (A.nsteps - 1) / 12; A.tr_end = uni(JA.length) * 8u + 16u + 6u; A.nw = 0; A.on = true; A.done = false;
+    B.soft = reinterpret_cast<const uint32_t*>(soft_base + softB); B.decT = reinterpret_cast<uint32_t*>(dec_base + uni(hasB ? JB.dec_off : JA.dec_off));
+    B.tbk = tbkB; B.nsteps = hasB ? nsB / GB * GS : 0u; B.last_chunk = (nsB / GB * GS - 1) / 12; B.tr_end = hasB ? uni(JB.length) * 8u + 16u + 6u : 0u; B.nw = 0; B.on = hasB; B.done = !hasB;
 
     VitLane V;
-    V.U = lane == 0 ? 0u : (0x18u << 25);                                      // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
-    V.hist = 0;
+    V.U = lane == 0 ? 0u : 0x18u * kFld;                                       // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
+    V.histA = V.histB = 0;
 #pragma unroll
     for (int ph = 0; ph < 6; ph++) {
         const unsigned n = rol6(lane, ph + 1);                                  // label held after a phase-ph step
-        V.MA[ph] = (__popc(n & 0155) & 1) ? (7u << 25) : 0u;
-        V.MB[ph] = (__popc(n & 0117) & 1) ? (7u << 25) : 0u;
+        V.MA[ph] = (__popc(n & 0155) & 1) ? 7u * kFld : 0u;
+        V.MB[ph] = (__popc(n & 0117) & 1) ? 7u * kFld : 0u;
     }
 
-    uint32_t tr = 0, ob = 0, nw = 0;
-    bool done = false;
-    uint32_t next_thr = min(tr_end, 256u + 24u + 6u);
+    const uint32_t nsteps = max(A.nsteps, B.nsteps);
+    uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
-    auto normalize = [&]() { V.U -= dpp_min_u32_wave(V.U); };                   // Normalize (viterbicore.h:444-465)
-    auto check = [&]() {                                                        // trace-back schedule (viterbi.hpp:196-214)
+    auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };       // Normalize (viterbicore.h:444-465), both frames
+    auto record = [&](VitSide& S, unsigned mbyte, uint32_t cnt, uint32_t look) {
+        // arg-min with the reference's tie-break: metric<<8 | state<<2 (viterbicore.h:479-524); metric = 2u + last decision
+        const unsigned kmin = dpp_min_u32_wave((mbyte << 8) | (rol6(lane, tr) << 2));
+        if (lane == 0) {
+            S.tbk[S.nw * 3 + 0] = tr;
+            S.tbk[S.nw * 3 + 1] = look | (cnt << 16);
+            S.tbk[S.nw * 3 + 2] = ((kmin >> 2) & 0x3F) | (((kmin >> 8) & 1) << 6) | (ob << 8);
+        }
+        S.nw++;
+    };
+    auto next_event = [&]() -> uint32_t {
+        uint32_t t = ob + 256u + 24u + 6u;
+        if (!A.done) t = min(t, A.tr_end);
+        if (!B.done) t = min(t, B.tr_end);
+        return t;
+    };
+    uint32_t next_thr = next_event();
+    auto check = [&]() {                                                        // trace-back schedule (viterbi.hpp:196-214), per frame
         if (tr >= next_thr) {
-            uint32_t cnt, look;
-            if (tr >= tr_end) { cnt = tr_end - ob - 6; look = tr - tr_end; }
-            else { look = 24 + (tr - (ob + 256 + 24 + 6)) % 8; cnt = 256; }
-            // arg-min with the reference's tie-break: metric<<8 | state<<2 (viterbicore.h:479-524); metric = 2u + last decision
-            const unsigned mbyte = (V.U >> 24) | (V.hist & 1u);
-            const unsigned kmin = dpp_min_u32_wave((mbyte << 8) | (rol6(lane, tr) << 2));
-            if (lane == 0) {
-                tbk[nw * 3 + 0] = tr;
-                tbk[nw * 3 + 1] = look | (cnt << 16);
-                tbk[nw * 3 + 2] = ((kmin >> 2) & 0x3F) | (((kmin >> 8) & 1) << 6) | (ob << 8);
+            const unsigned mA = ((V.U & 0xFFFFu) >> 8) | (V.histA & 1u), mB = (V.U >> 24) | (V.histB & 1u);
+            const bool partial = tr >= ob + 256u + 24u + 6u;
+            const uint32_t plook = 24 + (tr - (ob + 256 + 24 + 6)) % 8;
+            if (!A.done) {
+                if (tr >= A.tr_end) { record(A, mA, A.tr_end - ob - 6, tr - A.tr_end); A.done = true; }
+                else if (partial) record(A, mA, 256, plook);
             }
-            nw++; ob += cnt;
-            if (tr >= tr_end) done = true;
-            next_thr = min(tr_end, ob + 256u + 24u + 6u);
+            if (!B.done) {
+                if (tr >= B.tr_end) { record(B, mB, B.tr_end - ob - 6, tr - B.tr_end); B.done = true; }
+                else if (partial) record(B, mB, 256, plook);
+            }
+            if (partial) ob += 256;
+            next_thr = next_event();
         }
     };
-    auto sv = [](uint32_t w, int byte) -> unsigned { return ((w >> (8 * byte)) & 7u) << 25; };   // soft value -> branch-metric field
+    auto store_row = [&](uint32_t row, unsigned sh) {
+        if (row * kColsPerRow < A.nsteps + kColsPerRow) A.decT[row * 64 + lane] = V.histA << sh;
+        if (B.on && row * kColsPerRow < B.nsteps + kColsPerRow) B.decT[row * 64 + lane] = V.histB << sh;
+    };
+    struct Chunk { uint32_t a[CW], b[CW]; };
+    auto load_chunk = [&](uint32_t c, uint32_t zero) -> Chunk {                 // chunk c of both frames; past a frame's end: its last chunk again
+        Chunk K;                                                                //   (that frame is done by then; the frame's spare slot covers a ragged tail)
+        const uint32_t* pa = A.soft + min(c, A.last_chunk) * CW + zero;
+        const uint32_t* pb = B.soft + min(c, B.last_chunk) * CW + zero;
+#pragma unroll
+        for (int i = 0; i < CW; i++) { K.a[i] = pa[i]; K.b[i] = pb[i]; }
+        return K;
+    };
+    auto sv = [](const Chunk& K, int k) -> unsigned {                           // soft value k of the chunk, frames A | B
+        return (k & 1) ? ((K.a[k >> 1] >> 16) | (K.b[k >> 1] & 0xFFFF0000u)) : ((K.a[k >> 1] & 0xFFFFu) | (K.b[k >> 1] << 16));
+    };
+    auto step = [&](int ph, int which, unsigned a, unsigned b) {               // ph, which are constants after unrolling
+        switch (ph * 3 + which) {
+        case 0:  acs_bfly<0, 0>(V, a, b); break; case 1:  acs_bfly<0, 1>(V, a, b); break; case 2:  acs_bfly<0, 2>(V, a, b); break;
+        case 3:  acs_bfly<1, 0>(V, a, b); break; case 4:  acs_bfly<1, 1>(V, a, b); break; case 5:  acs_bfly<1, 2>(V, a, b); break;
+        case 6:  acs_bfly<2, 0>(V, a, b); break; case 7:  acs_bfly<2, 1>(V, a, b); break; case 8:  acs_bfly<2, 2>(V, a, b); break;
+        case 9:  acs_bfly<3, 0>(V, a, b); break; case 10: acs_bfly<3, 1>(V, a, b); break; case 11: acs_bfly<3, 2>(V, a, b); break;
+        case 12: acs_bfly<4, 0>(V, a, b); break; case 13: acs_bfly<4, 1>(V, a, b); break; case 14: acs_bfly<4, 2>(V, a, b); break;
+        case 15: acs_bfly<5, 0>(V, a, b); break; case 16: acs_bfly<5, 1>(V, a, b); break; default: acs_bfly<5, 2>(V, a, b); break;
+        }
+    };
+    // one puncture group = GS steps starting at step index i0 of a 12-step chunk (tr % 12 == 0 at the chunk start, so phase = i0 % 6)
+    auto group = [&](const Chunk& K, int i0) {
+        const int k0 = i0 / GS * GB;
+        step(i0 % 6, 0, sv(K, k0), sv(K, k0 + 1));                              // ACS(A,B)
+        if (CR != 0) step((i0 + 1) % 6, 1, sv(K, k0 + 2), 0);                   // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
+        if (CR == 2) step((i0 + 2) % 6, 2, 0, sv(K, k0 + 3));                   // ACS(B)     3/4
+    };
+    auto chunk = [&](const Chunk& K) {                                          // up to 12 steps
+        if (tr + 12 <= nsteps && next_thr > tr + 12) {
+            // fast path: no trace-back due inside the chunk -- straight-line code, no per-group tests.
+            // Normalize whenever (trellis index & 7) == 0 after a group: tr % 8 is 0 or 4 here.
+            const bool lo = (tr & 7) == 0;
+#pragma unroll
+            for (int g = 0; g < 12 / GS; g++) {
+                group(K, g * GS);
+                const int s = (g + 1) * GS;
+                if (s == 4 && !lo) normalize();
+                if (s == 8 && lo) normalize();
+            }
+            tr += 12;
+            if (!lo) normalize();
+        } else {
+#pragma unroll
+            for (int g = 0; g < 12 / GS; g++) {
+                if (tr < nsteps && !(A.done && B.done)) {
+                    group(K, g * GS);
+                    tr += GS;
+                    if ((tr & 7) == 0) normalize();
+                    check();
+                }
+            }
+        }
+    };
 
-    uint32_t row = 0;                                                           // decision rows written
-    if (CR == 2) {
-        // 3/4: { ACS(A,B), ACS(A), ACS(B) } per 4 soft values (viterbi.hpp:173-180); 8 groups = 24 steps per row
-        const uint32_t ngroups = nsoft / 4;
-        uint32_t wv = 0;                                                        // lane-parallel prefetch: 64 words = 8 rows of 8 groups
-        for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += 8) {
-            if ((g0 & 63) == 0) wv = (g0 + lane < ngroups) ? soft[g0 + lane] : 0u;
-            uint32_t w[8];
-#pragma unroll
-            for (int i = 0; i < 8; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((g0 & 63) + i));
-            if (g0 + 8 <= ngroups && next_thr > tr + 24) {
-                // fast path (9 rows out of 10): a whole row with no trace-back due -- straight-line, no per-group tests
-#pragma unroll
-                for (int i = 0; i < 8; i += 2) {
-                    acs_bfly<0, 0>(V, sv(w[i], 0), sv(w[i], 1));         acs_bfly<1, 1>(V, sv(w[i], 2), 0);     acs_bfly<2, 2>(V, 0, sv(w[i], 3));
-                    acs_bfly<3, 0>(V, sv(w[i + 1], 0), sv(w[i + 1], 1)); acs_bfly<4, 1>(V, sv(w[i + 1], 2), 0); acs_bfly<5, 2>(V, 0, sv(w[i + 1], 3));
-                }
-                tr += 24;
-                normalize();                                                    // (tr & 7) == 0 <=> tr % 24 == 0 at rate 3/4
-            } else {
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    if (!done && g0 + i < ngroups) {
-                        if ((i & 1) == 0) { acs_bfly<0, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<1, 1>(V, sv(w[i], 2), 0); acs_bfly<2, 2>(V, 0, sv(w[i], 3)); }
-                        else              { acs_bfly<3, 0>(V, sv(w[i], 0), sv(w[i], 1)); acs_bfly<4, 1>(V, sv(w[i], 2), 0); acs_bfly<5, 2>(V, 0, sv(w[i], 3)); }
-                        tr += 3;
-                        if (i == 7) normalize();
-                        check();
-                    }
-                }
-            }
-            if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
-        }
-    } else if (CR == 0) {
-        // 1/2: ACS(A,B) per 2 soft values (viterbi.hpp:167-172); 24 steps per row
-        const uint32_t ngroups = nsoft / 2, nwords = nsoft / 4;
-        uint32_t wv = 0, rowi = 0;                                              // lane-parallel prefetch: 60 words = 5 rows of 24 groups
-        for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += 24, rowi++) {
-            if (rowi % 5 == 0) wv = (lane < 60 && g0 / 2 + lane < nwords) ? soft[g0 / 2 + lane] : 0u;
-            uint32_t w[12];
-#pragma unroll
-            for (int i = 0; i < 12; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((rowi % 5) * 12 + i));
-#pragma unroll
-            for (int i = 0; i < 24; i++) {
-                if (!done && g0 + i < ngroups) {
-                    const unsigned a = sv(w[i >> 1], 2 * (i & 1)), b = sv(w[i >> 1], 2 * (i & 1) + 1);
-                    switch (i % 6) {
-                    case 0: acs_bfly<0, 0>(V, a, b); break; case 1: acs_bfly<1, 0>(V, a, b); break; case 2: acs_bfly<2, 0>(V, a, b); break;
-                    case 3: acs_bfly<3, 0>(V, a, b); break; case 4: acs_bfly<4, 0>(V, a, b); break; default: acs_bfly<5, 0>(V, a, b); break;
-                    }
-                    tr += 1;
-                    if ((i & 7) == 7) normalize();
-                    check();
-                }
-            }
-            if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
-        }
-    } else {
-        // 2/3: { ACS(A,B), ACS(A) } per 3 soft values (viterbi.hpp:181-187); 12 groups = 24 steps = 36 bytes per row
-        const uint32_t ngroups = nsoft / 3, nwords = nsoft / 4;
-        uint32_t wv = 0, rowi = 0;                                              // lane-parallel prefetch: 63 words = 7 rows of 12 groups
-        for (uint32_t g0 = 0; g0 < ngroups && !done; g0 += 12, rowi++) {
-            if (rowi % 7 == 0) wv = (lane < 63 && g0 * 3 / 4 + lane < nwords) ? soft[g0 * 3 / 4 + lane] : 0u;
-            uint32_t w[9];
-#pragma unroll
-            for (int i = 0; i < 9; i++) w[i] = (uint32_t)__builtin_amdgcn_readlane((int)wv, (int)((rowi % 7) * 9 + i));
-#pragma unroll
-            for (int i = 0; i < 12; i++) {
-                if (!done && g0 + i < ngroups) {
-                    const int b0 = 3 * i, b1 = 3 * i + 1, b2 = 3 * i + 2;
-                    const unsigned sa = sv(w[b0 >> 2], b0 & 3), sb = sv(w[b1 >> 2], b1 & 3), sc = sv(w[b2 >> 2], b2 & 3);
-                    switch (i % 3) {
-                    case 0: acs_bfly<0, 0>(V, sa, sb); acs_bfly<1, 1>(V, sc, 0); break;
-                    case 1: acs_bfly<2, 0>(V, sa, sb); acs_bfly<3, 1>(V, sc, 0); break;
-                    default: acs_bfly<4, 0>(V, sa, sb); acs_bfly<5, 1>(V, sc, 0); break;
-                    }
-                    tr += 2;
-                    if ((i & 3) == 3) normalize();
-                    check();
-                }
-            }
-            if ((tr % kColsPerRow) == 0) { decT[row * 64 + lane] = V.hist << 8; row++; }
-        }
+    // Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0), and the compiler puts it at the
+    // first use of the loaded registers.  The prefetch of chunk c+1 must therefore be ISSUED after the first use of chunk c
+    // (or that wait would cover the prefetch too) and is then covered by a whole chunk of ACS work.  The order is pinned by
+    // data flow: the prefetch address takes a bit of chunk c that is always zero (soft fields are v << 9).
+    uint32_t row = 0, c = 0;
+    Chunk cur = load_chunk(0, 0);
+    while (tr < nsteps && !(A.done && B.done)) {
+        const Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
+        chunk(cur);
+        if ((tr % kColsPerRow) == 0) { store_row(row, 8); row++; }
+        cur = nxt; c++;
     }
     // last, partial row: left-align so that column c always sits at bit 31 - ((c - 1) % 24)
-    if ((tr % kColsPerRow) != 0) decT[row * 64 + lane] = V.hist << (32 - (tr % kColsPerRow));
-    if (lane == 0) *nwin_out = nw;
+    if ((tr % kColsPerRow) != 0) store_row(row, 32 - (tr % kColsPerRow));
+    if (lane == 0) { *nwinA = A.nw; if (hasB) *nwinB = B.nw; }
 }
 
-// Four frames per 256-thread workgroup (one wave each, no cross-wave traffic): with one-wave workgroups the
-// dispatcher kept only 8 of them per CU, i.e. 2 waves per SIMD and a second round for a 4096-frame batch.
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin)
+// Four waves per 256-thread workgroup, two frames per wave (no cross-wave traffic).  One-wave workgroups were kept to
+// 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.
+// Frames are paired in job order when their code rates agree; otherwise each runs alone in the low half.
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs_ptr, uint32_t njobs_max, const uint8_t* __restrict__ soft, uint64_t* __restrict__ dec, uint32_t* __restrict__ tbk, uint32_t* __restrict__ nwin)
 {
-    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (f >= (njobs_ptr ? *njobs_ptr : njobs_max)) return;
-    const VitJob J = jobs[f];
-    if (!J.valid) return;
-    uint32_t* t = tbk + (size_t)f * kMaxWindows * 3;
-    if (J.code_rate == 0)      viterbi_forward<0>(J, soft, dec, t, nwin + f);
-    else if (J.code_rate == 1) viterbi_forward<1>(J, soft, dec, t, nwin + f);
-    else                       viterbi_forward<2>(J, soft, dec, t, nwin + f);
+    const uint32_t njobs = njobs_ptr ? *njobs_ptr : njobs_max;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
+    const uint32_t fa = uni((blockIdx.x * 4 + (threadIdx.x >> 6)) * 2), fb = fa + 1;
+    if (fa >= njobs) return;
+    auto load_job = [&](uint32_t f) {
+        const VitJob& G = jobs[f];
+        VitJob J;
+        J.soft_off = uni(G.soft_off); J.nsoft = uni(G.nsoft); J.length = uni(G.length); J.dec_off = uni(G.dec_off);
+        J.out_off = uni(G.out_off); J.valid = uni(G.valid); J.code_rate = uni(G.code_rate); J.pad = 0;
+        return J;
+    };
+    const VitJob JA = load_job(fa);
+    VitJob JB = JA;
+    bool hasB = fb < njobs;
+    if (hasB) { JB = load_job(fb); hasB = JB.valid != 0; }
+    uint32_t* ta = tbk + (size_t)fa * kMaxWindows * 3;
+    uint32_t* tb = tbk + (size_t)fb * kMaxWindows * 3;
+    const bool pair = JA.valid && hasB && JA.code_rate == JB.code_rate;
+    for (int pass = 0; pass < (pair ? 1 : 2); pass++) {                         // unpaired: A alone, then B alone (one call site per code rate)
+        const bool second = pass == 1;
+        if (second ? !hasB : !JA.valid) continue;
+        const VitJob X = second ? JB : JA;
+        uint32_t* tx = second ? tb : ta;
+        uint32_t* nx = nwin + (second ? fb : fa);
+        if (X.code_rate == 0)      viterbi_forward<0>(X, JB, pair, soft, dec, tx, tb, nx, nwin + fb);
+        else if (X.code_rate == 1) viterbi_forward<1>(X, JB, pair, soft, dec, tx, tb, nx, nwin + fb);
+        else                       viterbi_forward<2>(X, JB, pair, soft, dec, tx, tb, nx, nwin + fb);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -578,6 +639,16 @@ __global__ void __launch_bounds__(64) k_deint_batch(const uint8_t* in, uint8_t* 
     if (i >= n) return;
     const int ncbps = 48 * nb, di = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3;
     for (int k = threadIdx.x; k < ncbps; k += 64) out[(size_t)i * ncbps + k] = in[(size_t)i * ncbps + T.deint[di * 288 + k]];
+}
+
+// sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits);
+// the trellis kernel reads 16-bit fields v << 9.
+__global__ void __launch_bounds__(256) k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16)
+{
+    const uint32_t j = blockIdx.x;
+    const uint8_t* in = soft8 + off8[j];
+    uint16_t* out = reinterpret_cast<uint16_t*>(soft16 + off16[j]);
+    for (uint32_t k = threadIdx.x; k < nsoft[j]; k += blockDim.x) out[k] = (uint16_t)((in[k] & 7u) << 9);
 }
 
 __global__ void __launch_bounds__(64) k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,

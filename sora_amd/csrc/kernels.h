@@ -38,7 +38,7 @@ struct RxArgs {
     const uint16_t* slot_sym;
     uint32_t*       eq;             // [slots][64]
     TrackRec*       track;          // [slots]
-    uint8_t*        soft;           // [slots*288]
+    uint8_t*        soft;           // [slots*288] 16-bit fields (v << 9)
     uint64_t*       dec;            // [slots*216]
     uint32_t*       tbk;            // [nrows][kMaxWindows][3] : col, look|cnt<<16, pos|ob<<8
     uint32_t*       nwin;           // [nrows]
@@ -65,6 +65,7 @@ __global__ void k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Table
 __global__ void k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T);
 __global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
 __global__ void k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
+__global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16);
 __global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
                                const uint32_t* out_off, const uint32_t* dec_off, int code_rate, uint32_t n);
 

@@ -308,7 +308,7 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
         { (void**)&rx->d_fctx, sizeof(FrameCtx) * rx->cap_rows }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
         { (void**)&rx->d_slot_frame, 4 * (size_t)rx->cap_slots }, { (void**)&rx->d_slot_sym, 2 * (size_t)rx->cap_slots },
         { (void**)&rx->d_eq, 256 * (size_t)rx->cap_slots }, { (void**)&rx->d_track, sizeof(TrackRec) * (size_t)rx->cap_slots },
-        { (void**)&rx->d_soft, (size_t)kSoftPerSlot * rx->cap_slots }, { (void**)&rx->d_dec, 8 * (size_t)kDecPerSlot * rx->cap_slots },
+        { (void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64 }, { (void**)&rx->d_dec, 8 * (size_t)kDecPerSlot * rx->cap_slots },
         { (void**)&rx->d_tbk, 12 * (size_t)kMaxWindows * rx->cap_rows }, { (void**)&rx->d_nwin, 4 * (size_t)rx->cap_rows },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
         { (void**)&rx->d_jobs, sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
@@ -390,7 +390,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     mark();
     hipLaunchKernelGGL(k_demap, dim3((slots + 3) / 4), dim3(256), 0, st, R);
     mark();
-    hipLaunchKernelGGL(k_viterbi, dim3((nrows + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
+    hipLaunchKernelGGL(k_viterbi, dim3((nrows + 7) / 8), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
     mark();
     hipLaunchKernelGGL(k_traceback, dim3(nrows), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint64_t*)rx->d_dec, (const uint32_t*)rx->d_tbk, (const uint32_t*)rx->d_nwin, rx->d_vout);
     mark();
@@ -580,23 +580,35 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
     if (n == 0) return SORA_OK;
     hipStream_t st = (hipStream_t)stream;
     // scratch: decisions (worst case 1/2-rate: nsoft/2+1 columns), window table, job table
-    std::vector<uint32_t> h_nsoft(n), h_dec_off(n);
+    std::vector<uint32_t> h_nsoft(n), h_dec_off(n), h_s16_off(n);
     HIPCHK(hipMemcpyAsync(h_nsoft.data(), d_nsoft, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
     uint64_t words = 0;
-    for (size_t i = 0; i < n; i++) { h_dec_off[i] = (uint32_t)words; words += (uint64_t)h_nsoft[i] + 128; }
+    uint64_t s16 = 0;
+    for (size_t i = 0; i < n; i++) {
+        if (h_nsoft[i] < 24) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: a job needs at least one OFDM symbol of soft values");
+        h_dec_off[i] = (uint32_t)words; words += (uint64_t)h_nsoft[i] + 128;
+        h_s16_off[i] = (uint32_t)s16; s16 += ((uint64_t)h_nsoft[i] * 2 + 64 + 3) & ~3ull;      // + slack for the last 12-step chunk
+    }
+    if (s16 >> 32) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
     VitJob* jobs = nullptr; uint64_t* dec = nullptr; uint32_t* tbk = nullptr; uint32_t* nwin = nullptr; uint32_t* decoff = nullptr;
+    uint8_t* soft16 = nullptr; uint32_t* s16off = nullptr;
+    HIPCHK(hipMalloc((void**)&soft16, s16 + 64));
+    HIPCHK(hipMalloc((void**)&s16off, 4 * n));
+    HIPCHK(hipMemsetAsync(soft16, 0, s16 + 64, st));
+    HIPCHK(hipMemcpyAsync(s16off, h_s16_off.data(), 4 * n, hipMemcpyHostToDevice, st));
     HIPCHK(hipMalloc((void**)&jobs, sizeof(VitJob) * n));
     HIPCHK(hipMalloc((void**)&dec, 8 * words));
     HIPCHK(hipMalloc((void**)&tbk, 12 * (size_t)kMaxWindows * n));
     HIPCHK(hipMalloc((void**)&nwin, 4 * n));
     HIPCHK(hipMalloc((void**)&decoff, 4 * n));
     HIPCHK(hipMemcpyAsync(decoff, h_dec_off.data(), 4 * n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, d_soft_off, d_nsoft, d_frame_len, d_out_off, (const uint32_t*)decoff, code_rate, (uint32_t)n);
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 3) / 4)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, d_soft, dec, tbk, nwin);
+    hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, (const uint32_t*)s16off, soft16);
+    hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, (const uint32_t*)s16off, d_nsoft, d_frame_len, d_out_off, (const uint32_t*)decoff, code_rate, (uint32_t)n);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, (const uint8_t*)soft16, dec, tbk, nwin);
     hipLaunchKernelGGL(k_traceback, dim3((unsigned)n), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, (const uint64_t*)dec, (const uint32_t*)tbk, (const uint32_t*)nwin, d_out);
     hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(jobs); (void)hipFree(dec); (void)hipFree(tbk); (void)hipFree(nwin); (void)hipFree(decoff);
+    (void)hipFree(jobs); (void)hipFree(dec); (void)hipFree(tbk); (void)hipFree(nwin); (void)hipFree(decoff); (void)hipFree(soft16); (void)hipFree(s16off);
     if (e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_viterbi11a", e);
     return SORA_OK;
 }
