@@ -160,23 +160,33 @@ __global__ void __launch_bounds__(256) k_demap(RxArgs A)
 // Arithmetic.  A reference metric byte is m = 2u + d (d = decision mark).  Branch metrics are even, so
 //   c0 = (x0 + bm0) & 0xFE = 2((u0 + b0) mod 128),  c1 = ((x1 + bm1) & 0xFE) | 1 = 2((u1 + b1) mod 128) + 1,  b = bm/2
 //   min(c0, c1) picks c1 iff (u1 + b1) mod 128 < (u0 + b0) mod 128  (a tie keeps c0), and the new u is that minimum.
-// The kernel therefore carries U = u << 25 in a 32-bit VGPR: the 7-bit wrap is the natural 32-bit wrap, the
-// unsigned compare is a plain v_cmp_lt_u32, no masking at all.  Normalisation subtracts min(U) (= (min m & 0xFE)/2).
+// The kernel carries u in the top 7 bits of a 16-bit field (u << 9): the 7-bit wrap is the natural 16-bit wrap and the
+// unsigned minimum needs no masking.  Normalisation subtracts min(u) (= (min m & 0xFE)/2).
 // Branch metric of soft value v (0..7) for expected bit c: b = v ^ (c ? 7 : 0) (VIT_MA/VIT_MB, viterbilut.h:50-185,
 // halved); expected bits = parity((branch<<6 | n) & 0155) for A, & 0117 for B, n = new state.  Both generators
 // tap the oldest bit, so the decision-1 branch costs K - b0, K = 14 (7 on a punctured step).
 //
+// Decisions without a compare.  The reference marks the decision in the metric LSB; here the nine spare low bits of
+// the field do the same job: step k of an 8-step block adds 1 << k to the decision-1 candidate.  That bit breaks
+// ties exactly like the reference's LSB (a tie keeps branch 0), marks of earlier steps sit BELOW it and can never
+// decide a comparison, and after the minimum it IS the decision.  Because the marks travel with the metric through
+// the butterfly, after 8 steps the low byte of a lane is the decision history of the SURVIVOR PATH into the state
+// the lane holds (register exchange, 8 deep, for free).  Every 8 steps the byte is moved to a history register
+// (one v_perm_b32 per frame) and cleared; every 24 steps the 64 lanes store 3 such bytes as one coalesced 256-byte
+// row.  The trace-back then walks 8 columns per lookup: the 6 oldest decisions of a block are the state 8 columns
+// earlier, the 8 decisions are the decoded bits.
+//
 // CDNA4 mapping.  wave64 = the 64 states, run as an in-place butterfly {p, p+32} -> {2p, 2p+1}: after t steps
-// lane L holds state rol6^t(L), and the two predecessors of its next state sit in lanes L and L ^ (32 >> (t mod 6)).
-// Every lane needs (x0, x1) = (metric of the pair member holding the decision-0 predecessor, the other one):
-//     t mod 6 = 0,1 : v_permlane32_swap / v_permlane16_swap (gfx950) return exactly that pair
-//     t mod 6 = 2,3 : two bank-masked DPP moves (row_ror:8 / row_shl:4 + row_shr:4)
-//     t mod 6 = 4,5 : quad_perm DPP operands folded into the two adds
-// i.e. ~9 VALU instructions per trellis step, no LDS, no ds_bpermute (a ds_bpermute formulation of the same
-// recurrence was bounded by the dependent LDS round trip: 3.4 ms for the 4096-frame batch).
-// Decisions: the compare result is carried into a per-lane history register with one v_addc (hist = 2 hist + d);
-// every 24 steps (4 butterfly cycles = 8 punctured groups at 3/4) the 64 lanes store their 24-bit histories as one
-// coalesced 256-byte row.  Soft values are prefetched 64 words at a time (one per lane), handed out with v_readlane and unpacked on the SALU.
+// lane L holds state rol6^t(L), and the two predecessors of its next state sit in lanes L and P = L ^ (32 >> (t mod 6)).
+//     t mod 6 = 0,1 : v_permlane32_swap / v_permlane16_swap (gfx950) return (metric of the decision-0 predecessor,
+//                     metric of the decision-1 predecessor) directly
+//     t mod 6 = 2..5: the lane adds its OWN metric and the partner's (one DPP move: row_ror:8, quad_perm; two for ^4);
+//                     which of the two is the decision-1 candidate depends on the lane, so the lane's soft masks are
+//                     complemented (K - b = b ^ 7) and carry the mark for the lanes whose own metric is candidate 1.
+// Two frames per wave: frame A in the low 16-bit half of every register, frame B in the high half (v_pk_add_u16,
+// v_pk_min_u16; the cross-lane moves carry both).  Measured issue cost on gfx950 at 2 waves/SIMD (tools/gen_probe_issue.py):
+// VOP2 add/sub/xor/and/mov 5.0, VOP3/VOP3P/DPP 9.4, compare->SGPR / v_addc 9.9, permlane swap 16.9 (units of 0.67 ns).
+// Per packed step: 1 move + 2 adds + 1 min + 2..3 for the branch metrics; no compare, no carry chain, no LDS.
 __device__ __forceinline__ unsigned rol6(unsigned v, unsigned r) { r %= 6; return ((v << r) | (v >> (6 - r))) & 63u; }
 
 __device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wide unsigned minimum, VALU latency only
@@ -191,11 +201,6 @@ __device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wi
     return min(r32[0], r32[1]);
 }
 
-// Two frames per wave.  The metric of frame A lives in the low 16-bit half of the lane's register (u in bits 15:9),
-// frame B's in the high half (bits 31:25): v_pk_add_u16 / v_pk_min_u16 run both trellises with one instruction,
-// and the cross-lane exchanges move both halves at once.  Integer VALU ops issue at one wave64 instruction per
-// ~4.4 cycles per SIMD on this part (measured: 10.3 VALU/step <-> 46 cycles/step at 4 waves/SIMD), so the kernel
-// is bound by VALU instructions per trellis step per frame: 10.3 with one frame per wave, 6.5 with two.
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
 __device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b))); }
@@ -213,45 +218,47 @@ __device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-ha
     return pk_min16(r32[0], r32[1]);
 }
 
+constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
+constexpr unsigned kOne = 0x00010001u;                    // bit 0 of both halves
+constexpr int kColsPerRow = 24;                           // trellis columns per stored 256-byte decision row (3 blocks of 8)
+
 struct VitLane {
-    unsigned U;              // (u_B << 25) | (u_A << 9): metrics of the state this lane currently holds, frames A and B
-    unsigned histA, histB;   // decisions of this lane, newest in bit 0
-    unsigned MA[6], MB[6];   // (expected bit ? 7 : 0) in both fields, for the decision-0 branch into the lane's next state, per phase
+    unsigned U;              // (field B << 16) | field A; field = u << 9 | marks of the current 8-step block
+    unsigned histA, histB;   // survivor-path decision bytes of the blocks of the current row: byte j = block j
+    unsigned MX[24];         // soft mask (+ mark, + complement for own-is-candidate-1 lanes) of the mark-carrying operand, per t mod 24
+    unsigned MY[6];          // soft mask of the second operand of a two-input step, per t mod 6
 };
 
-constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
-
-template <int PH, int WHICH>   // PH = t mod 6; WHICH 0: (A,B)  1: A only  2: B only.  a, b = packed soft values (wave-uniform)
-__device__ __forceinline__ void acs_bfly(VitLane& V, unsigned a, unsigned b)
+// WHICH 0: (A,B) two soft values, 1: A only, 2: B only.  t24 = trellis step index mod 24 (a constant after unrolling).
+template <int WHICH>
+__device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsigned b)
 {
-    constexpr unsigned K = (WHICH == 0 ? 14u : 7u) * kFld;
-    unsigned b0;
-    if (WHICH == 0)      b0 = (a ^ V.MA[PH]) + (b ^ V.MB[PH]);                   // per field <= 14: no carry between the halves
-    else if (WHICH == 1) b0 = a ^ V.MA[PH];
-    else                 b0 = b ^ V.MB[PH];
-    const unsigned b1 = K - b0;
-    unsigned x0, x1;
+    const int ph = t24 % 6, k = t24 % 8;
+    const unsigned Kp = (WHICH == 0 ? 14u : 7u) * kFld + (kOne << k);           // K + mark
+    unsigned bm;                                                                // cost added to X (per field: b, or b + mark)
+    if (WHICH == 0)      bm = (a ^ V.MX[t24]) + (b ^ V.MY[ph]);                  // per field <= 14 << 9 | mark: no carry between the halves
+    else if (WHICH == 1) bm = a ^ V.MX[t24];
+    else                 bm = b ^ V.MX[t24];
+    const unsigned bo = Kp - bm;                                                // cost added to Y
+    unsigned X, Y;
     const int u = (int)V.U;
-    if (PH == 0)      { auto r = __builtin_amdgcn_permlane32_swap(V.U, V.U, false, false); x0 = r[0]; x1 = r[1]; }
-    else if (PH == 1) { auto r = __builtin_amdgcn_permlane16_swap(V.U, V.U, false, false); x0 = r[0]; x1 = r[1]; }
-    else if (PH == 2) { x0 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x128, 0xF, 0xC, false);      // lanes 8-15 of a row <- L-8
-                        x1 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x128, 0xF, 0x3, false); }    // lanes 0-7          <- L+8
-    else if (PH == 3) { x0 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x114, 0xF, 0xA, false);      // bit2 = 1 lanes <- L-4
-                        x1 = (unsigned)__builtin_amdgcn_update_dpp(u, u, 0x104, 0xF, 0x5, false); }    // bit2 = 0 lanes <- L+4
-    else if (PH == 4) { x0 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x44, 0xF, 0xF, true);        // quad_perm [0,1,0,1]
-                        x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xEE, 0xF, 0xF, true); }      // quad_perm [2,3,2,3]
-    else              { x0 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xA0, 0xF, 0xF, true);        // quad_perm [0,0,2,2]
-                        x1 = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xF5, 0xF, 0xF, true); }      // quad_perm [1,1,3,3]
-    const unsigned c0 = pk_add16(x0, b0), c1 = pk_add16(x1, b1);
-    const uint64_t dA = __ballot((unsigned short)c1 < (unsigned short)c0);      // decision of frame A: strict compare, a tie keeps branch 0
-    const uint64_t dB = __ballot((c1 >> 16) < (c0 >> 16));                      // decision of frame B
-    V.U = pk_min16(c0, c1);
-    uint64_t carry_out;
-    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(V.histA), "=s"(carry_out) : "s"(dA));   // hist = 2*hist + decision, one VALU op
-    asm("v_addc_co_u32 %0, %1, %0, %0, %2" : "+v"(V.histB), "=s"(carry_out) : "s"(dB));
+    switch (ph) {
+    case 0: { auto r = __builtin_amdgcn_permlane32_swap(V.U, V.U, false, false); X = r[0]; Y = r[1]; break; }
+    case 1: { auto r = __builtin_amdgcn_permlane16_swap(V.U, V.U, false, false); X = r[0]; Y = r[1]; break; }
+    case 2: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x128, 0xF, 0xF, true); break;                  // L ^ 8: row_ror:8
+    case 3: { const int t = __builtin_amdgcn_mov_dpp(u, 0x114, 0xF, 0xA, false);                                      // L ^ 4: row_shr:4 into lanes with bit 2 set,
+              X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(t, u, 0x104, 0xF, 0x5, false); break; }              //        row_shl:4 into the others
+    case 4: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x4E, 0xF, 0xF, true); break;                   // L ^ 2: quad_perm [2,3,0,1]
+    default: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, true); break;                  // L ^ 1: quad_perm [1,0,3,2]
+    }
+    V.U = pk_min16(pk_add16(X, bm), pk_add16(Y, bo));
+    if (k == 7) {                                                               // end of an 8-step block: bank the path history, clear the marks
+        const int j = t24 / 8;
+        V.histA = __builtin_amdgcn_perm(V.U, V.histA, j == 0 ? 0x03020104u : j == 1 ? 0x03020400u : 0x03040100u);   // byte j <- U byte 0
+        V.histB = __builtin_amdgcn_perm(V.U, V.histB, j == 0 ? 0x03020106u : j == 1 ? 0x03020600u : 0x03060100u);   // byte j <- U byte 2
+        V.U &= 0xFE00FE00u;
+    }
 }
-
-constexpr int kColsPerRow = 24;            // trellis columns per stored 256-byte decision row
 
 struct VitSide {            // wave-uniform per-frame bookkeeping
     const uint32_t* soft; uint32_t* decT; uint32_t* tbk; uint32_t nsteps, last_chunk, tr_end, nw; bool on, done;
@@ -268,36 +275,42 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
     constexpr int CW = 12 / GS * GB / 2;                                        // 32-bit soft words per 12-step chunk: 12 / 9 / 8
     const unsigned lane = threadIdx.x & 63;
-    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     VitSide A, B;
-    const uint32_t softA = uni(JA.soft_off), softB = uni(hasB ? JB.soft_off : JA.soft_off);
-    const uint32_t nsA = uni(JA.nsoft), nsB = uni(hasB ? JB.nsoft : JA.nsoft);
-    A.soft = reinterpret_cast<const uint32_t*>(soft_base + softA); A.decT = reinterpret_cast<uint32_t*>(dec_base + uni(JA.dec_off));
-    A.tbk = tbkA; A.nsteps = nsA / GB * GS; A.last_chunk = (A.nsteps - 1) / 12; A.tr_end = uni(JA.length) * 8u + 16u + 6u; A.nw = 0; A.on = true; A.done = false;
-    B.soft = reinterpret_cast<const uint32_t*>(soft_base + softB); B.decT = reinterpret_cast<uint32_t*>(dec_base + uni(hasB ? JB.dec_off : JA.dec_off));
-    B.tbk = tbkB; B.nsteps = hasB ? nsB / GB * GS : 0u; B.last_chunk = (nsB / GB * GS - 1) / 12; B.tr_end = hasB ? uni(JB.length) * 8u + 16u + 6u : 0u; B.nw = 0; B.on = hasB; B.done = !hasB;
+    A.soft = reinterpret_cast<const uint32_t*>(soft_base + JA.soft_off); A.decT = reinterpret_cast<uint32_t*>(dec_base + JA.dec_off);
+    A.tbk = tbkA; A.nsteps = JA.nsoft / GB * GS; A.last_chunk = (A.nsteps - 1) / 12; A.tr_end = JA.length * 8u + 16u + 6u; A.nw = 0; A.on = true; A.done = false;
+    const VitJob& JBx = hasB ? JB : JA;
+    B.soft = reinterpret_cast<const uint32_t*>(soft_base + JBx.soft_off); B.decT = reinterpret_cast<uint32_t*>(dec_base + JBx.dec_off);
+    B.tbk = tbkB; B.nsteps = hasB ? JBx.nsoft / GB * GS : 0u; B.last_chunk = (JBx.nsoft / GB * GS - 1) / 12; B.tr_end = hasB ? JBx.length * 8u + 16u + 6u : 0u; B.nw = 0; B.on = hasB; B.done = !hasB;
 
+    auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };   // step kinds of a puncture group (viterbi.hpp:167-187)
     VitLane V;
     V.U = lane == 0 ? 0u : 0x18u * kFld;                                       // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
     V.histA = V.histB = 0;
 #pragma unroll
-    for (int ph = 0; ph < 6; ph++) {
+    for (int t = 0; t < 24; t++) {
+        const int ph = t % 6, k = t % 8;
         const unsigned n = rol6(lane, ph + 1);                                  // label held after a phase-ph step
-        V.MA[ph] = (__popc(n & 0155) & 1) ? 7u * kFld : 0u;
-        V.MB[ph] = (__popc(n & 0117) & 1) ? 7u * kFld : 0u;
+        const bool own1 = ph >= 2 && ((lane >> (5 - ph)) & 1);                  // DPP phases: the lane's own metric is the decision-1 candidate
+        const unsigned ma = (__popc(n & 0155) & 1) ? 7u * kFld : 0u, mb = (__popc(n & 0117) & 1) ? 7u * kFld : 0u;
+        const unsigned mx = which_of(ph) == 2 ? mb : ma;
+        V.MX[t] = own1 ? ((mx ^ (7u * kFld)) | (kOne << k)) : mx;
+        if (t < 6) V.MY[t] = own1 ? (mb ^ (7u * kFld)) : mb;
     }
 
     const uint32_t nsteps = max(A.nsteps, B.nsteps);
     uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
-    auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };       // Normalize (viterbicore.h:444-465), both frames
-    auto record = [&](VitSide& S, unsigned mbyte, uint32_t cnt, uint32_t look) {
-        // arg-min with the reference's tie-break: metric<<8 | state<<2 (viterbicore.h:479-524); metric = 2u + last decision
-        const unsigned kmin = dpp_min_u32_wave((mbyte << 8) | (rol6(lane, tr) << 2));
+    auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };       // Normalize (viterbicore.h:444-465), both frames; marks are clear here
+    // A window: arg-min with the reference's tie-break metric<<8 | state<<2 (viterbicore.h:479-524), metric = 2u + last decision.
+    // The record carries the start state and the decisions of the unfinished block (tr % 8 of them) along its path.
+    auto record = [&](VitSide& S, unsigned mbyte, unsigned fieldbyte, uint32_t cnt, uint32_t look) {
+        const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mbyte << 8) | (rol6(lane, tr) << 2)));
+        const unsigned state = (kmin >> 2) & 0x3F;
+        const unsigned part = (unsigned)__builtin_amdgcn_readlane((int)fieldbyte, (int)rol6(state, 6u - tr % 6u)) & ((1u << (tr & 7)) - 1u);
         if (lane == 0) {
             S.tbk[S.nw * 3 + 0] = tr;
             S.tbk[S.nw * 3 + 1] = look | (cnt << 16);
-            S.tbk[S.nw * 3 + 2] = ((kmin >> 2) & 0x3F) | (((kmin >> 8) & 1) << 6) | (ob << 8);
+            S.tbk[S.nw * 3 + 2] = state | (part << 8) | ((ob >> 8) << 16);
         }
         S.nw++;
     };
@@ -308,26 +321,29 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         return t;
     };
     uint32_t next_thr = next_event();
-    auto check = [&]() {                                                        // trace-back schedule (viterbi.hpp:196-214), per frame
+    auto check = [&](int t24_last) {                                            // trace-back schedule (viterbi.hpp:196-214), per frame
         if (tr >= next_thr) {
-            const unsigned mA = ((V.U & 0xFFFFu) >> 8) | (V.histA & 1u), mB = (V.U >> 24) | (V.histB & 1u);
+            const int k = t24_last % 8, j = t24_last / 8;                       // the last decision: mark k of the field, or bit 7 of the block just banked
+            const unsigned dA = k == 7 ? (V.histA >> (8 * j + 7)) & 1u : (V.U >> k) & 1u;
+            const unsigned dB = k == 7 ? (V.histB >> (8 * j + 7)) & 1u : (V.U >> (16 + k)) & 1u;
+            const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | dA, mB = (V.U >> 25 << 1) | dB;
             const bool partial = tr >= ob + 256u + 24u + 6u;
             const uint32_t plook = 24 + (tr - (ob + 256 + 24 + 6)) % 8;
             if (!A.done) {
-                if (tr >= A.tr_end) { record(A, mA, A.tr_end - ob - 6, tr - A.tr_end); A.done = true; }
-                else if (partial) record(A, mA, 256, plook);
+                if (tr >= A.tr_end) { record(A, mA, V.U & 0xFFu, A.tr_end - ob - 6, tr - A.tr_end); A.done = true; }
+                else if (partial) record(A, mA, V.U & 0xFFu, 256, plook);
             }
             if (!B.done) {
-                if (tr >= B.tr_end) { record(B, mB, B.tr_end - ob - 6, tr - B.tr_end); B.done = true; }
-                else if (partial) record(B, mB, 256, plook);
+                if (tr >= B.tr_end) { record(B, mB, (V.U >> 16) & 0xFFu, B.tr_end - ob - 6, tr - B.tr_end); B.done = true; }
+                else if (partial) record(B, mB, (V.U >> 16) & 0xFFu, 256, plook);
             }
             if (partial) ob += 256;
             next_thr = next_event();
         }
     };
-    auto store_row = [&](uint32_t row, unsigned sh) {
-        if (row * kColsPerRow < A.nsteps + kColsPerRow) A.decT[row * 64 + lane] = V.histA << sh;
-        if (B.on && row * kColsPerRow < B.nsteps + kColsPerRow) B.decT[row * 64 + lane] = V.histB << sh;
+    auto store_row = [&](uint32_t row) {
+        if (row * kColsPerRow < A.nsteps + kColsPerRow) A.decT[row * 64 + lane] = V.histA;
+        if (B.on && row * kColsPerRow < B.nsteps + kColsPerRow) B.decT[row * 64 + lane] = V.histB;
     };
     struct Chunk { uint32_t a[CW], b[CW]; };
     auto load_chunk = [&](uint32_t c, uint32_t zero) -> Chunk {                 // chunk c of both frames; past a frame's end: its last chunk again
@@ -339,47 +355,32 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         return K;
     };
     auto sv = [](const Chunk& K, int k) -> unsigned {                           // soft value k of the chunk, frames A | B
-        return (k & 1) ? ((K.a[k >> 1] >> 16) | (K.b[k >> 1] & 0xFFFF0000u)) : ((K.a[k >> 1] & 0xFFFFu) | (K.b[k >> 1] << 16));
+        unsigned r;
+        if (k & 1) asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(r) : "s"(K.a[k >> 1]), "s"(K.b[k >> 1]));
+        else       asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(K.a[k >> 1]), "s"(K.b[k >> 1]));
+        return r;
     };
-    auto step = [&](int ph, int which, unsigned a, unsigned b) {               // ph, which are constants after unrolling
-        switch (ph * 3 + which) {
-        case 0:  acs_bfly<0, 0>(V, a, b); break; case 1:  acs_bfly<0, 1>(V, a, b); break; case 2:  acs_bfly<0, 2>(V, a, b); break;
-        case 3:  acs_bfly<1, 0>(V, a, b); break; case 4:  acs_bfly<1, 1>(V, a, b); break; case 5:  acs_bfly<1, 2>(V, a, b); break;
-        case 6:  acs_bfly<2, 0>(V, a, b); break; case 7:  acs_bfly<2, 1>(V, a, b); break; case 8:  acs_bfly<2, 2>(V, a, b); break;
-        case 9:  acs_bfly<3, 0>(V, a, b); break; case 10: acs_bfly<3, 1>(V, a, b); break; case 11: acs_bfly<3, 2>(V, a, b); break;
-        case 12: acs_bfly<4, 0>(V, a, b); break; case 13: acs_bfly<4, 1>(V, a, b); break; case 14: acs_bfly<4, 2>(V, a, b); break;
-        case 15: acs_bfly<5, 0>(V, a, b); break; case 16: acs_bfly<5, 1>(V, a, b); break; default: acs_bfly<5, 2>(V, a, b); break;
-        }
+    // one puncture group = GS steps; i0 = step index inside the 12-step chunk, h = which half of the 24-step row
+    auto group = [&](const Chunk& K, int h, int i0) {
+        const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
+        acs_step<0>(V, t24, sv(K, k0), sv(K, k0 + 1));                          // ACS(A,B)
+        if (CR != 0) acs_step<1>(V, t24 + 1, sv(K, k0 + 2), 0);                 // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
+        if (CR == 2) acs_step<2>(V, t24 + 2, 0, sv(K, k0 + 3));                 // ACS(B)     3/4
+        if ((t24 + GS) % 8 == 0) normalize();                                   // (trellis index & 7) == 0 after a group
     };
-    // one puncture group = GS steps starting at step index i0 of a 12-step chunk (tr % 12 == 0 at the chunk start, so phase = i0 % 6)
-    auto group = [&](const Chunk& K, int i0) {
-        const int k0 = i0 / GS * GB;
-        step(i0 % 6, 0, sv(K, k0), sv(K, k0 + 1));                              // ACS(A,B)
-        if (CR != 0) step((i0 + 1) % 6, 1, sv(K, k0 + 2), 0);                   // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
-        if (CR == 2) step((i0 + 2) % 6, 2, 0, sv(K, k0 + 3));                   // ACS(B)     3/4
-    };
-    auto chunk = [&](const Chunk& K) {                                          // up to 12 steps
+    auto chunk = [&](const Chunk& K, int h) {                                   // up to 12 steps; tr % 24 == 12 h on entry
         if (tr + 12 <= nsteps && next_thr > tr + 12) {
-            // fast path: no trace-back due inside the chunk -- straight-line code, no per-group tests.
-            // Normalize whenever (trellis index & 7) == 0 after a group: tr % 8 is 0 or 4 here.
-            const bool lo = (tr & 7) == 0;
+            // fast path: no trace-back due inside the chunk -- straight-line code, no per-group tests
 #pragma unroll
-            for (int g = 0; g < 12 / GS; g++) {
-                group(K, g * GS);
-                const int s = (g + 1) * GS;
-                if (s == 4 && !lo) normalize();
-                if (s == 8 && lo) normalize();
-            }
+            for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
             tr += 12;
-            if (!lo) normalize();
         } else {
 #pragma unroll
             for (int g = 0; g < 12 / GS; g++) {
                 if (tr < nsteps && !(A.done && B.done)) {
-                    group(K, g * GS);
+                    group(K, h, g * GS);
                     tr += GS;
-                    if ((tr & 7) == 0) normalize();
-                    check();
+                    check(12 * h + g * GS + GS - 1);
                 }
             }
         }
@@ -392,13 +393,16 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     uint32_t row = 0, c = 0;
     Chunk cur = load_chunk(0, 0);
     while (tr < nsteps && !(A.done && B.done)) {
-        const Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
-        chunk(cur);
-        if ((tr % kColsPerRow) == 0) { store_row(row, 8); row++; }
-        cur = nxt; c++;
+        Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
+        chunk(cur, 0);
+        if (!(tr < nsteps && !(A.done && B.done))) break;
+        cur = load_chunk(c + 2, (nxt.a[0] | nxt.b[0]) & 1u);
+        chunk(nxt, 1);
+        c += 2;
+        if ((tr % kColsPerRow) == 0) { store_row(row); row++; }
     }
-    // last, partial row: left-align so that column c always sits at bit 31 - ((c - 1) % 24)
-    if ((tr % kColsPerRow) != 0) store_row(row, 32 - (tr % kColsPerRow));
+    // last, partial row: the blocks finished so far (the unfinished block travels in the window record)
+    if ((tr % kColsPerRow) != 0) store_row(row);
     if (lane == 0) { *nwinA = A.nw; if (hasB) *nwinB = B.nw; }
 }
 
@@ -439,72 +443,45 @@ __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs
 
 // ------------------------------------------------------------------------------------------------
 // k_traceback: TViterbiCore::Traceback (viterbicore.h:468-555) -- every window of a frame is an independent
-// walk through the stored decisions, one thread each (a 54 Mbps 1500-byte frame has 47 windows), one wave per
-// frame.  Decisions live in rows of 24 trellis columns x 64 lanes (see k_viterbi): row R, word L, bit 31-i holds
-// the decision that lane L took in column 24R+1+i, and lane L held state rol6^c(L) in column c.  Lanes walk in
-// lock-step one row (24 columns) at a time: the wave first copies every window's current 256-byte row into LDS
-// with coalesced loads, then each lane chases through its own copy.  Bytes come out LSB-first in time.
+// walk, one thread each (a 54 Mbps 1500-byte frame has 47 windows), one wave per frame.
+// k_viterbi stores, per 8-column block j (columns 8j+1..8j+8) and lane, the 8 decisions of the survivor path into the
+// state that lane held at column 8j+8 (bit i = column 8j+1+i): row j/3, word L, byte j%3, L = ror6^(8j+8)(state).
+// One lookup therefore walks 8 columns: the decisions are the decoded bits, and the state at column 8j is the 6 oldest
+// decisions, newest in bit 0 (s' = d << 5 | s >> 1 applied 8 times).  Decoded bit i of the frame is the decision at
+// column i + 7 on the traced path (6-bit decoder delay, viterbi.hpp:196-214), so output byte m is
+// (block m >> 6) | (block m+1 & 0x3F) << 2 -- no bit loop.
 __global__ void __launch_bounds__(64) k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec_base, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out_base)
 {
-    __shared__ uint32_t s_row[64][65];                                           // one decision row per window-thread (+1 pad)
     const uint32_t f = blockIdx.x;
     if (f >= (njobs_ptr ? *njobs_ptr : njobs_max)) return;
     const VitJob J = jobs[f];
     if (!J.valid) return;
-    const int lane = threadIdx.x;
     const uint32_t nw = nwin[f];
     const uint32_t* decT = reinterpret_cast<const uint32_t*>(dec_base + J.dec_off);
     uint8_t* out = out_base + J.out_off;
-    for (uint32_t w0 = 0; w0 < nw; w0 += 64) {
-        const uint32_t w = w0 + (uint32_t)lane;
-        uint32_t col = 0, look = 0, cnt = 0, ob = 0; unsigned pos = 0; int left = 0;
-        if (w < nw) {
-            const uint32_t* t = tbk + ((size_t)f * kMaxWindows + w) * 3;
-            col = t[0]; look = t[1] & 0xFFFF; cnt = t[1] >> 16; pos = t[2] & 0x7F; ob = t[2] >> 8; left = (int)(look + cnt);
-        }
-        // The walk reads columns col-1, col-2, ... (the decision of the start state is already in `pos`).
-        uint32_t c = col - 1;                                                    // next column to read (>= 6 whenever left > 0)
-        uint32_t i_out = 0;                                                      // steps taken
-        unsigned oc = 0;
-        uint8_t* ob_ptr = out + (ob >> 3);
-        int any = __any(left > 0);
-        while (any) {
-            const uint32_t rowi = left > 0 ? (c - 1) / kColsPerRow : 0xFFFFFFFFu;
-            __syncthreads();
-            // coalesced: the whole wave copies window tw's row; all loads of a half are in flight together
-            const int nwin_here = (int)min(64u, nw - w0);
-#pragma unroll
-            for (int h = 0; h < 2; h++) {
-                if (h * 32 < nwin_here) {
-                    uint32_t v[32];
-#pragma unroll
-                    for (int k = 0; k < 32; k++) {
-                        const uint32_t r_tw = (uint32_t)__builtin_amdgcn_readlane((int)rowi, h * 32 + k);
-                        v[k] = (r_tw != 0xFFFFFFFFu) ? decT[(size_t)r_tw * 64 + lane] : 0u;
-                    }
-#pragma unroll
-                    for (int k = 0; k < 32; k++) s_row[h * 32 + k][lane] = v[k];
-                }
-            }
-            __syncthreads();
-            if (left > 0) {
-                const uint32_t row_first = rowi * kColsPerRow + 1;               // first column of this row
-                unsigned r = c % 6u;
-                while (left > 0 && c >= row_first) {
-                    if (i_out >= look) {
-                        const uint32_t bi = cnt - 1 - (i_out - look);
-                        oc = (oc << 1) | ((pos >> 6) & 1u);
-                        if ((bi & 7) == 0) { ob_ptr[bi >> 3] = (uint8_t)oc; oc = 0; }
-                    }
-                    pos = (pos >> 1) & 0x3Fu;                                    // predecessor state, lives in column c
-                    const unsigned L = ((pos >> r) | (pos << (6 - r))) & 63u;    // ror6^c(state)
-                    const unsigned bit = 31u - (c - row_first);
-                    pos |= ((s_row[lane][L] >> bit) & 1u) << 6;
-                    r = r == 0 ? 5u : r - 1;
-                    c--; left--; i_out++;
-                }
-            }
-            any = __any(left > 0);
+    auto rev6 = [](unsigned x) { return __brev(x) >> 26; };
+    auto lookup = [&](uint32_t m, unsigned state) -> unsigned {                  // block m along the path that is in `state` at column 8m+8
+        const unsigned r = (2u * m + 2u) % 6u;                                   // (8m + 8) mod 6
+        const unsigned L = ((state >> r) | (state << (6 - r))) & 63u;            // ror6^(8m+8)(state)
+        return (decT[(size_t)(m / 3u) * 64 + L] >> (8u * (m % 3u))) & 0xFFu;
+    };
+    for (uint32_t w = threadIdx.x; w < nw; w += 64) {
+        const uint32_t* t = tbk + ((size_t)f * kMaxWindows + w) * 3;
+        const uint32_t col = t[0], look = t[1] & 0xFFFF, cnt = t[1] >> 16, ob = (t[2] >> 16) << 8;
+        unsigned state = t[2] & 0x3F;
+        const unsigned part = (t[2] >> 8) & 0xFF;
+        (void)look;
+        if (cnt == 0) continue;
+        const int m_lo = (int)(ob >> 3), m_hi = (int)((ob + cnt) >> 3);          // this window decodes output bytes [m_lo, m_hi)
+        const int j = (int)((col - 1) >> 3);                                     // block holding the start column; j >= m_hi
+        const unsigned n = col - 8u * (unsigned)j;                               // its decisions known at the start: 1..8
+        unsigned Hn = n == 8 ? lookup((uint32_t)j, state) : part;
+        state = ((state >> n) | rev6(Hn & ((1u << n) - 1u) & 0x3Fu)) & 0x3Fu;    // state at column 8j
+        for (int m = j - 1; m >= m_lo; m--) {
+            const unsigned Hm = lookup((uint32_t)m, state);
+            state = rev6(Hm & 0x3Fu);
+            if (m < m_hi) out[m] = (uint8_t)((Hm >> 6) | ((Hn & 0x3Fu) << 2));
+            Hn = Hm;
         }
     }
 }
