@@ -242,8 +242,10 @@ struct sora_rx {
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
-    // last call
+    // last call.  Descriptors go up through a pinned staging buffer (a pageable source would make the "async" copy wait for
+    // the stream to drain and expose every launch latency of the call) and only when they differ from the resident set.
     std::vector<CapDesc> h_caps;
+    CapDesc* h_caps_pinned = nullptr; size_t caps_resident = 0; hipEvent_t ev_caps = nullptr;
     uint32_t ncaps = 0, total_slots = 0;
     bool have_results = false;
     // profiling
@@ -261,6 +263,8 @@ static void rx_free(sora_rx* rx)
                      rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin, rx->d_vout, rx->d_mpdu, rx->d_jobs, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
+    if (rx->ev_caps) (void)hipEventDestroy(rx->ev_caps);
+    if (rx->h_caps_pinned) (void)hipHostFree(rx->h_caps_pinned);
     free_dev_tables(rx->tabs);
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
     delete rx;
@@ -300,6 +304,9 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     if (rc) { rx_free(rx); return rc; }
     hipError_t e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "hipStreamCreate", e); }
+    e = hipHostMalloc((void**)&rx->h_caps_pinned, sizeof(CapDesc) * cfg->max_captures, hipHostMallocDefault);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&rx->ev_caps, hipEventDisableTiming);
+    if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "pinned descriptor buffer", e); }
     const uint64_t n20 = cfg->max_total_samples / rx->str;
     rx->cap_slots = (uint32_t)(n20 / 80 + cfg->max_captures + 16);
     rx->cap_rows = cfg->max_captures * cfg->max_frames_per_capture;
@@ -365,7 +372,13 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(rx->ev[evi++], st); };
     mark();
-    HIPCHK(hipMemcpyAsync(rx->d_caps, rx->h_caps.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, st));
+    if (rx->caps_resident != ncaps || memcmp(rx->h_caps_pinned, rx->h_caps.data(), sizeof(CapDesc) * ncaps) != 0) {
+        if (rx->caps_resident) HIPCHK(hipEventSynchronize(rx->ev_caps));        // the staging buffer's last upload has left it
+        memcpy(rx->h_caps_pinned, rx->h_caps.data(), sizeof(CapDesc) * ncaps);
+        HIPCHK(hipMemcpyAsync(rx->d_caps, rx->h_caps_pinned, sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, st));
+        HIPCHK(hipEventRecord(rx->ev_caps, st));
+        rx->caps_resident = ncaps;
+    }
     HIPCHK(hipMemsetAsync(rx->d_slot_frame, 0xFF, 4 * (size_t)slots, st));
     const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
     HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
