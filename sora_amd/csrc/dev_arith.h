@@ -92,8 +92,14 @@ __device__ __forceinline__ cpx rot_coeff(const Tables& T, int th)        // (uco
 // through a 64-entry LDS slice `s` private to the group.  `e` = lane index within the group (0..15).
 // In: x[m] = point e+16m.  Out: y[q] = bin e+16q (natural order).  All lanes of the group must call.
 // SYNC is a barrier covering the group (block barrier, or nothing inside a single wave after a waitcnt).
+struct Fft64Tw { uint32_t w64_1, w64_2, w64_3, w16_1, w16_2, w16_3; };   // the six twiddles lane e of a group needs (loop-invariant)
+__device__ __forceinline__ Fft64Tw fft64_twiddles(const Tables& T, int e)
+{
+    const int i = e & 3;
+    return Fft64Tw{ T.tw64[e], T.tw64[16 + e], T.tw64[32 + e], T.tw16[i], T.tw16[4 + i], T.tw16[8 + i] };
+}
 template <typename SYNC>
-__device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int e, const Tables& T, SYNC sync)
+__device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int e, const Fft64Tw& W, SYNC sync)
 {
     sync();                                                                           // previous users of s[] are done
     // stage N=64: butterfly e on points e, e+16, e+32, e+48   (FFTSSE<64>, fft_r4dif.h:11-47)
@@ -102,9 +108,9 @@ __device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int
         cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
         cpx jb = mul_j(b_d);
         s[e]      = pack(cadds(ac, bd));
-        s[e + 16] = pack(mul_shift15(csubs(ac, bd),  unpack(T.tw64[16 + e])));      // W64^{2e}
-        s[e + 32] = pack(mul_shift15(csubs(a_c, jb), unpack(T.tw64[e])));           // W64^{e}
-        s[e + 48] = pack(mul_shift15(cadds(a_c, jb), unpack(T.tw64[32 + e])));      // W64^{3e}
+        s[e + 16] = pack(mul_shift15(csubs(ac, bd),  unpack(W.w64_2)));              // W64^{2e}
+        s[e + 32] = pack(mul_shift15(csubs(a_c, jb), unpack(W.w64_1)));              // W64^{e}
+        s[e + 48] = pack(mul_shift15(cadds(a_c, jb), unpack(W.w64_3)));              // W64^{3e}
     }
     sync();
     // stage N=16 on quarter k: butterfly i on points 16k+i+{0,4,8,12}   (FFTSSE<16>)
@@ -114,9 +120,9 @@ __device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int
         cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
         cpx jb = mul_j(b_d);
         s[base]      = pack(cadds(ac, bd));                                           // in place: same lane, same slots
-        s[base + 4]  = pack(mul_shift15(csubs(ac, bd),  unpack(T.tw16[4 + i])));
-        s[base + 8]  = pack(mul_shift15(csubs(a_c, jb), unpack(T.tw16[i])));
-        s[base + 12] = pack(mul_shift15(cadds(a_c, jb), unpack(T.tw16[8 + i])));
+        s[base + 4]  = pack(mul_shift15(csubs(ac, bd),  unpack(W.w16_2)));
+        s[base + 8]  = pack(mul_shift15(csubs(a_c, jb), unpack(W.w16_1)));
+        s[base + 12] = pack(mul_shift15(cadds(a_c, jb), unpack(W.w16_3)));
     }
     sync();
     // terminal 4-point stage on points 4e..4e+3   (FFTSSEEx<4>, fft_r4dif.h:60-83)
@@ -137,6 +143,12 @@ __device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int
         const unsigned j = (unsigned)(e + 16 * q);
         y[q] = unpack(s[__brev(j) >> 26]);
     }
+}
+
+template <typename SYNC>
+__device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int e, const Tables& T, SYNC sync)
+{
+    fft64_group(x, y, s, e, fft64_twiddles(T, e), sync);
 }
 
 }  // namespace sora

@@ -1,11 +1,10 @@
 // k_rx.hip -- batched per-symbol / per-frame kernels of the 802.11a receive path (gfx950).
 //
-//   k_sym_front   T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization   (parallel over symbols)
-//   k_track       TPhaseCompensate/TPilotTrack loop-carried state on the 4 pilots          (serial per frame)
-//   k_demap       TPhaseCompensate + TPilotTrack rotation + T11aDemap<N> + T11aDeinterleave (parallel over symbols)
-//   k_viterbi<CR> T11aViterbi<5000*8,48,256,24>: 64-state ACS, wave64 = 64 states          (one wave per frame)
+//   k_frame       T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization -> TPhaseCompensate ->
+//                 TPilotTrack -> T11aDemap<N> -> T11aDeinterleave                           (one wave per frame, 4 symbols per pass)
+//   k_viterbi<CR> T11aViterbi<5000*8,48,256,24>: 64-state ACS, wave64 = 64 states          (one wave per two frames)
 //   k_traceback   TViterbiCore::Traceback for every window of the schedule                 (one thread per window)
-//   k_finish      T11aDesc + TBB11aFrameSink (descramble, CRC-32, FRAME_OK / CRC32_FAIL)   (one thread per frame)
+//   k_finish      T11aDesc + TBB11aFrameSink (descramble, CRC-32, FRAME_OK / CRC32_FAIL)   (one wave per frame)
 // plus the stand-alone stage kernels behind the per-stage C entry points.
 #include <hip/hip_runtime.h>
 #include <utility>
@@ -26,128 +25,140 @@ __device__ __forceinline__ int carrier_bin48(int k)       // demap order -26..-1
 }
 
 // ------------------------------------------------------------------------------------------------
-// k_sym_front: 16 lanes per OFDM symbol, 16 symbols per 256-thread block.
-//   algorithmic bytes per symbol: 256 read (64 samples) + 256 written (64 equalised bins)
-__global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
+// k_frame: everything between the frame table and the soft stream, one wave per frame:
+//   TFreqCompensation -> TFFT64 -> TChannelEqualization -> TPhaseCompensate -> TPilotTrack -> T11aDemap -> T11aDeinterleave
+// (fb11ademod_config.hpp:200-222).  Four OFDM symbols per pass, one per 16-lane group.  The front end (FFT, equaliser)
+// and the back end (rotation, demap, de-interleave) of a symbol do not depend on the tracking state; the tracking loop
+// itself (freqoffset.hpp:28-30, pilot.hpp:166-233: four pilot bins, two dependent LUT reads per symbol) is run for
+// the pass's four symbols in order, pilot k in lane k, the loop state in scalar registers.  The equalised symbol never
+// leaves LDS; the small tables (demap steps, de-interleaver map) live in LDS, the FFT twiddles in registers; the next
+// pass's samples are requested before the tracking loop so that their latency hides behind it.
+//   algorithmic bytes per data symbol: 256 read (64 of the 80 samples) + 2 N_CBPS written (16-bit soft fields)
+__global__ void __launch_bounds__(256) k_frame(RxArgs A)
 {
-    __shared__ uint32_t s_all[16][64];
-    const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
-    const uint32_t slot = blockIdx.x * 16 + g;
-    int fr = -1, sym = 0;
-    if (slot < A.total_slots) { fr = A.slot_frame[slot]; sym = A.slot_sym[slot]; }
-    const bool active = fr >= 0 && sym > 0;
-    cpx x[4], Y[4];
-    const FrameCtx* fx = A.fctx + (active ? fr : 0);
-    if (active) {
-        const FrameRow& r = A.frames[fr];
-        const uint32_t* iq = A.iq + A.caps[r.capture].offset;
-        const uint32_t p0 = r.data_start + 80u * (uint32_t)sym + 8u;           // skip_cp = 8 (PHY_11a.hpp:365,394)
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-            const int n = e + 16 * m;
-            cpx s = sra(unpack(iq[(size_t)(p0 + n) * A.str]), 1);             // TFreqCompensation: >>1 (channel_11a.hpp:643)
-            x[m] = mul_q15(s, unpack(fx->freq[n]));                            //   x FreqCoeffs (:644)
-        }
-    } else {
-#pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = mk(0, 0);
-    }
-    fft64_group(x, Y, s_all[g], e, A.T, []() { __syncthreads(); });           // TFFT64
-    if (active) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) {                                          // TChannelEqualization (channel_11a.hpp:548-574)
-            const int bin = e + 16 * q;
-            cpx o = mk(0, 0);
-            if (!(bin >= 28 && bin < 36)) {
-                int re, im; mul32(Y[q], unpack(fx->chan[bin]), re, im);
-                o = mk(w16(re >> 8), w16(im >> 8));
-            }
-            A.eq[(size_t)slot * 64 + bin] = pack(o);
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_track: the loop-carried part of TPhaseCompensate/TPilotTrack (freqoffset.hpp:28-30, pilot.hpp:166-233):
-// only the 4 pilot bins take part.  One thread per frame, sequential over its data symbols.
-__global__ void __launch_bounds__(64) k_track(RxArgs A)
-{
-    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    __shared__ uint32_t s_eq[4][4][64];                                          // [wave][symbol of the pass]: FFT staging, then the equalised bins
+    __shared__ uint8_t  s_soft[4][4][288];                                       // [wave][symbol of the pass]: soft values in carrier order
+    __shared__ uint8_t  s_demap[1024];                                           // DemapperCore step tables
+    __shared__ uint16_t s_map[4][288];                                           // [wave] de-interleaver source index of the frame's modulation
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
+    const Tables& T = A.T;
+    reinterpret_cast<uint32_t*>(s_demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(T.demap)[threadIdx.x];
+    __syncthreads();                                                             // the only block barrier: the waves are independent from here on
+    const uint32_t j = blockIdx.x * 4 + w;
     if (j >= *A.njobs) return;
     const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
-    VitJob J; J.pad = 0;
-    J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot * 2u; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
-    J.dec_off = r.slot0 * (uint32_t)kDecPerSlot; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
-    A.jobs[j] = J;
-    const Tables& T = A.T;
+    if (lane == 0) {
+        VitJob J; J.pad = 0;
+        J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot * 2u; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+        J.dec_off = r.slot0 * (uint32_t)kDecPerSlot; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
+        A.jobs[j] = J;
+    }
+    const FrameCtx* fx = A.fctx + f;
+    const uint32_t* iq = A.iq + A.caps[r.capture].offset;
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    const Fft64Tw W = fft64_twiddles(T, e);
+    cpx fq[4], ch[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) { fq[m] = unpack(fx->freq[e + 16 * m]); ch[m] = unpack(fx->chan[e + 16 * m]); }
+    const int nb = r.nbpsc, ncbps = 48 * nb, nsym = r.nsym;
+    {
+        const uint16_t* map = T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
+        for (int i = lane; i < ncbps; i += 64) s_map[w][i] = map[i];
+    }
+    uint32_t* dst = reinterpret_cast<uint32_t*>(A.soft + (size_t)r.slot0 * kSoftPerSlot * 2);
+    // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
+    const int pk = lane & 3;
+    const int pbin = pk == 0 ? 43 : pk == 1 ? 57 : pk == 2 ? 7 : 21, pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
     int cfo_comp = r.cfo_comp, sfo_comp = r.sfo_comp, cfo_tr = r.cfo_tracker, sfo_tr = r.sfo_tracker;
-    unsigned symbol_count = 0;                                                 // 127 -> 0 after the SIGNAL symbol
-    for (uint32_t s = 1; s <= r.nsym; s++) {
-        const uint32_t slot = r.slot0 + s;
-        const uint32_t* eq = A.eq + (size_t)slot * 64;
-        // CompCoeffs at carriers -21, -7, +7, +21: th = CFO_comp + c*SFO_comp (pilot.hpp:138-164)
-        cpx p43 = mul_q15(unpack(eq[43]), rot_coeff(T, w16(cfo_comp - 21 * sfo_comp)));
-        cpx p57 = mul_q15(unpack(eq[57]), rot_coeff(T, w16(cfo_comp - 7 * sfo_comp)));
-        cpx p7  = mul_q15(unpack(eq[7]),  rot_coeff(T, w16(cfo_comp + 7 * sfo_comp)));
-        cpx p21 = mul_q15(unpack(eq[21]), rot_coeff(T, w16(cfo_comp + 21 * sfo_comp)));
-        int th1 = uatan2(T, p43.im, p43.re), th2 = uatan2(T, p57.im, p57.re);
-        int th3 = uatan2(T, p7.im, p7.re),   th4 = uatan2(T, -p21.im, -p21.re);
-        if (kPilotSgn[symbol_count]) { th1 = w16(th1 + 0x8000); th2 = w16(th2 + 0x8000); th3 = w16(th3 + 0x8000); th4 = w16(th4 + 0x8000); }
-        symbol_count++; if (symbol_count >= 127) symbol_count = 0;
-        const int avg = w16((th1 + th2 + th3 + th4) / 4);
-        const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
-        TrackRec tr; tr.cfo_comp = (int16_t)cfo_comp; tr.sfo_comp = (int16_t)sfo_comp; tr.avg = (int16_t)avg; tr.del = (int16_t)del;
-        A.track[slot] = tr;
-        cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
-        cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
-    }
-}
+    unsigned symbol_count = 0;                                                   // 127 -> 0 after the SIGNAL symbol
 
-// ------------------------------------------------------------------------------------------------
-// k_demap: one wave per data symbol (4 symbols per block): 48 data carriers -> phase compensation ->
-// pilot rotation -> soft demap -> de-interleave -> contiguous per-frame soft stream.
-//   algorithmic bytes per symbol: 256 read + N_CBPS written
-__global__ void __launch_bounds__(256) k_demap(RxArgs A)
-{
-    __shared__ uint8_t s_soft[4][288];
-    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const uint32_t slot = blockIdx.x * 4 + w;
-    int fr = -1, sym = 0;
-    if (slot < A.total_slots) { fr = A.slot_frame[slot]; sym = A.slot_sym[slot]; }
-    const bool active = fr >= 0 && sym > 0;
-    const Tables& T = A.T;
-    int nb = 1; uint32_t slot0 = 0;
-    if (active) {
-        const FrameRow& r = A.frames[fr];
-        nb = r.nbpsc; slot0 = r.slot0;
-        if (lane < 48) {
-            const TrackRec tr = A.track[slot];
-            const int bin = carrier_bin48(lane);
-            const int c = bin < 32 ? bin : bin - 64;
-            cpx v = unpack(A.eq[(size_t)slot * 64 + bin]);
-            v = mul_q15(v, rot_coeff(T, w16(tr.cfo_comp + c * tr.sfo_comp)));      // TPhaseCompensate
-            v = mul_q15(v, rot_coeff(T, w16(tr.avg + c * tr.del)));                // TPilotTrack::_rotate
-            int re = v.re >> 4, im = v.im >> 4;                                     // demap_limit<64> (demapper.h:141-151)
-            re = min(max(re, -128), 127); im = min(max(im, -128), 127);
-            const unsigned ur = (unsigned)re & 0xFF, ui = (unsigned)im & 0xFF;
-            uint8_t* o = s_soft[w] + lane * nb;                                     // DemapperCore::Demap<N_BPSC> (demapper.h:16-45)
-            if (nb == 1) { o[0] = T.demap[ur]; }
-            else if (nb == 2) { o[0] = T.demap[ur]; o[1] = T.demap[ui]; }
-            else if (nb == 4) { o[0] = T.demap[ur]; o[1] = T.demap[256 + ur]; o[2] = T.demap[ui]; o[3] = T.demap[256 + ui]; }
-            else { o[0] = T.demap[ur]; o[1] = T.demap[512 + ur]; o[2] = T.demap[768 + ur];
-                   o[3] = T.demap[ui]; o[4] = T.demap[512 + ui]; o[5] = T.demap[768 + ui]; }
+    auto load_samples = [&](int s0, uint32_t raw[4]) {                           // the 64 samples after the cyclic prefix, symbol s0 + g
+        const uint32_t p0 = r.data_start + 80u * (uint32_t)(s0 + g) + 8u;        // skip_cp = 8 (PHY_11a.hpp:365,394)
+#pragma unroll
+        for (int m = 0; m < 4; m++) raw[m] = (s0 + g <= nsym) ? iq[(size_t)(p0 + (uint32_t)(e + 16 * m)) * A.str] : 0u;
+    };
+    uint32_t raw[4];
+    load_samples(1, raw);
+    for (int s0 = 1; s0 <= nsym; s0 += 4) {
+        const int sym = s0 + g;
+        const bool active = sym <= nsym;
+        // ---- TFreqCompensation + TFFT64 + TChannelEqualization, symbol `sym` in group g
+        cpx x[4], Y[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = mul_q15(sra(unpack(raw[m]), 1), fq[m]);   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+        if (s0 + 4 <= nsym) load_samples(s0 + 4, raw);                           // next pass: in flight during the tracking loop
+        fft64_group(x, Y, s_eq[w][g], e, W, wsync);
+        wsync();
+#pragma unroll
+        for (int q = 0; q < 4; q++) {                                            // channel_11a.hpp:548-574
+            const int bin = e + 16 * q;
+            cpx o = mk(0, 0);
+            if (!(bin >= 28 && bin < 36)) { int re, im; mul32(Y[q], ch[q], re, im); o = mk(w16(re >> 8), w16(im >> 8)); }
+            s_eq[w][g][bin] = pack(o);
         }
-    }
-    __syncthreads();
-    if (active) {
-        const int ncbps = 48 * nb;
-        const int di = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3;
-        const uint16_t* map = T.deint + di * 288;
-        // soft stream of the frame, one 16-bit field per soft value, already in the Viterbi kernel's metric format (v << 9)
-        uint32_t* dst = reinterpret_cast<uint32_t*>(A.soft + ((size_t)slot0 * kSoftPerSlot + (size_t)(sym - 1) * ncbps) * 2);
-        for (int k2 = lane; k2 < ncbps / 2; k2 += 64)                               // T11aDeinterleave* : out[k] = in[j(k)]
-            dst[k2] = ((uint32_t)s_soft[w][map[2 * k2]] << 9) | ((uint32_t)s_soft[w][map[2 * k2 + 1]] << 25);
+        wsync();
+        // ---- the loop-carried part, symbols s0 .. s0+3 in order
+        int t_cfo[4], t_sfo[4], t_avg[4], t_del[4];
+#pragma unroll
+        for (int gg = 0; gg < 4; gg++) {
+            t_cfo[gg] = cfo_comp; t_sfo[gg] = sfo_comp; t_avg[gg] = 0; t_del[gg] = 0;
+            if (s0 + gg <= nsym) {
+                cpx p = mul_q15(unpack(s_eq[w][gg][pbin]), rot_coeff(T, w16(cfo_comp + pc * sfo_comp)));
+                int th = pk == 3 ? uatan2(T, -p.im, -p.re) : uatan2(T, p.im, p.re);
+                if (kPilotSgn[symbol_count]) th = w16(th + 0x8000);
+                symbol_count++; if (symbol_count >= 127) symbol_count = 0;
+                const int th1 = __builtin_amdgcn_readlane(th, 0), th2 = __builtin_amdgcn_readlane(th, 1);
+                const int th3 = __builtin_amdgcn_readlane(th, 2), th4 = __builtin_amdgcn_readlane(th, 3);
+                const int avg = w16((th1 + th2 + th3 + th4) / 4);
+                const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+                t_avg[gg] = avg; t_del[gg] = del;
+                cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
+                cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
+            }
+        }
+        // ---- TPhaseCompensate + TPilotTrack::_rotate + T11aDemap, 3 data carriers per lane
+        if (active) {
+            const int my_cfo = g == 0 ? t_cfo[0] : g == 1 ? t_cfo[1] : g == 2 ? t_cfo[2] : t_cfo[3];
+            const int my_sfo = g == 0 ? t_sfo[0] : g == 1 ? t_sfo[1] : g == 2 ? t_sfo[2] : t_sfo[3];
+            const int my_avg = g == 0 ? t_avg[0] : g == 1 ? t_avg[1] : g == 2 ? t_avg[2] : t_avg[3];
+            const int my_del = g == 0 ? t_del[0] : g == 1 ? t_del[1] : g == 2 ? t_del[2] : t_del[3];
+            cpx c1[3], c2[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) {                                        // all six coefficient reads in flight together
+                const int bin = carrier_bin48(e + 16 * m);
+                const int c = bin < 32 ? bin : bin - 64;
+                c1[m] = rot_coeff(T, w16(my_cfo + c * my_sfo));
+                c2[m] = rot_coeff(T, w16(my_avg + c * my_del));
+            }
+#pragma unroll
+            for (int m = 0; m < 3; m++) {
+                const int k = e + 16 * m;
+                cpx v = unpack(s_eq[w][g][carrier_bin48(k)]);
+                v = mul_q15(v, c1[m]);
+                v = mul_q15(v, c2[m]);
+                int re = v.re >> 4, im = v.im >> 4;                               // demap_limit<64> (demapper.h:141-151)
+                re = min(max(re, -128), 127); im = min(max(im, -128), 127);
+                const unsigned ur = (unsigned)re & 0xFF, ui = (unsigned)im & 0xFF;
+                uint8_t* o = s_soft[w][g] + k * nb;                               // DemapperCore::Demap<N_BPSC> (demapper.h:16-45)
+                if (nb == 1) { o[0] = s_demap[ur]; }
+                else if (nb == 2) { o[0] = s_demap[ur]; o[1] = s_demap[ui]; }
+                else if (nb == 4) { o[0] = s_demap[ur]; o[1] = s_demap[256 + ur]; o[2] = s_demap[ui]; o[3] = s_demap[256 + ui]; }
+                else { o[0] = s_demap[ur]; o[1] = s_demap[512 + ur]; o[2] = s_demap[768 + ur];
+                       o[3] = s_demap[ui]; o[4] = s_demap[512 + ui]; o[5] = s_demap[768 + ui]; }
+            }
+        }
+        wsync();
+        // ---- T11aDeinterleave*: out[k] = in[j(k)]; the pass's symbols are contiguous in the frame's soft stream (16-bit fields v << 9)
+        {
+            const int nact = min(4, nsym - s0 + 1), wps = ncbps / 2;
+            uint32_t* d = dst + (size_t)(s0 - 1) * wps;
+            for (int i = lane; i < nact * wps; i += 64) {
+                const int gs = i / wps, k2 = i - gs * wps;
+                d[i] = ((uint32_t)s_soft[w][gs][s_map[w][2 * k2]] << 9) | ((uint32_t)s_soft[w][gs][s_map[w][2 * k2 + 1]] << 25);
+            }
+        }
+        wsync();
     }
 }
 
@@ -264,7 +275,7 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
     const uint32_t* soft; uint32_t* decT; uint32_t* tbk; uint32_t nsteps, last_chunk, tr_end, nw; bool on, done;
 };
 
-// Soft input: 16 bits per soft value, v << 9 (what k_demap / k_soft_widen write), so a packed branch-metric operand is
+// Soft input: 16 bits per soft value, v << 9 (what k_frame / k_soft_widen write), so a packed branch-metric operand is
 // one s_pack_ll/hh_b32_b16 of a word of frame A and a word of frame B.  The words arrive through the scalar cache
 // (s_load_dwordx8 per 12-step chunk per frame, prefetched one chunk ahead): no VALU work, no LDS.
 template <int CR>

@@ -50,9 +50,7 @@ struct RxArgs {
 };
 
 __global__ void k_scan(ScanArgs A);
-__global__ void k_sym_front(RxArgs A);
-__global__ void k_track(RxArgs A);
-__global__ void k_demap(RxArgs A);
+__global__ void k_frame(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin);
 __global__ void k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out);
 __global__ void k_finish(RxArgs A);

@@ -254,7 +254,8 @@ struct sora_rx {
     bool ev_valid = false;
 };
 
-static const char* const kKernelNames[8] = { "memset+caps", "k_scan", "k_sym_front", "k_track", "k_demap", "k_viterbi", "k_traceback", "k_finish" };
+static constexpr size_t kNumTimed = 6;
+static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_traceback", "k_finish" };
 
 static void rx_free(sora_rx* rx)
 {
@@ -397,11 +398,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     R.frames = rx->d_frames; R.fctx = rx->d_fctx; R.slot_frame = rx->d_slot_frame; R.slot_sym = rx->d_slot_sym;
     R.eq = rx->d_eq; R.track = rx->d_track; R.soft = rx->d_soft; R.dec = rx->d_dec; R.tbk = rx->d_tbk; R.nwin = rx->d_nwin;
     R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
-    hipLaunchKernelGGL(k_sym_front, dim3((slots + 15) / 16), dim3(256), 0, st, R);
-    mark();
-    hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(64), 0, st, R);
-    mark();
-    hipLaunchKernelGGL(k_demap, dim3((slots + 3) / 4), dim3(256), 0, st, R);
+    hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
     mark();
     hipLaunchKernelGGL(k_viterbi, dim3((nrows + 7) / 8), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_dec, rx->d_tbk, rx->d_nwin);
     mark();
@@ -478,12 +475,12 @@ int sora_rx_kernel_times(sora_rx_t* rx, float* ms, size_t cap, size_t* nout)
     *nout = 0;
     if (!rx->ev_valid) return fail(SORA_ERR_FAILED, "no profiled process call");
     HIPCHK(hipSetDevice(rx->cfg.device));
-    HIPCHK(hipEventSynchronize(rx->ev[8]));
-    for (size_t i = 0; i < 8 && i < cap; i++) { HIPCHK(hipEventElapsedTime(&ms[i], rx->ev[i], rx->ev[i + 1])); (*nout)++; }
+    HIPCHK(hipEventSynchronize(rx->ev[kNumTimed]));
+    for (size_t i = 0; i < kNumTimed && i < cap; i++) { HIPCHK(hipEventElapsedTime(&ms[i], rx->ev[i], rx->ev[i + 1])); (*nout)++; }
     return SORA_OK;
 }
 
-const char* sora_rx_kernel_name(size_t i) { return i < 8 ? kKernelNames[i] : ""; }
+const char* sora_rx_kernel_name(size_t i) { return i < kNumTimed ? kKernelNames[i] : ""; }
 
 int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
 {

@@ -4,7 +4,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 so = "/tmp/libsora_probe.so"
-src = [os.path.join(ROOT, "sora_amd", "csrc", f) for f in ("k_scan.hip", "k_rx.hip", "sora_hip.cpp")]
+src = [os.path.join(ROOT, "sora_amd", "csrc", f) for f in ("k_scan.hip", "k_rx.hip", "k_stage.hip", "sora_hip.cpp")]
 subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-DSORA_SCAN_PROBE"] + src + ["-o", so])
 import torch
 from sora_amd import build as b
