@@ -102,6 +102,7 @@ def main():
     nfr = args.frames
     iq, descs, payloads = make_workload(oracle, nfr, seed0=rank * 100003)
     d_iq = torch.from_numpy(iq).to(dev)
+    descs = sora_amd.Rx.captures(descs)           # packed sora_capture_desc[]: built once, submitted every step
     rx = sora_amd.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, device=local_rank, max_frames_per_capture=2)
 
     def barrier():
@@ -121,10 +122,13 @@ def main():
         # events of the previous call are read while the next one runs: no sync added inside the timed region
     barrier()
     t1 = time.perf_counter()
-    # per-kernel durations: a separate profiled pass of the same steps (reading events needs the call finished)
+    # per-kernel durations: a separate profiled pass of the same steps, back to back like the timed region (the HIP events
+    # of a call are read after the burst it belongs to; reading needs that call finished)
     acc = {}
-    for _ in range(max(3, min(args.steps, 10))):
-        rx.process_dev(d_iq, descs); rx.flush()
+    for _ in range(3):
+        for _ in range(max(3, min(args.steps, 10))):
+            rx.process_dev(d_iq, descs)
+        rx.flush()
         for k, v in rx.kernel_times().items():
             acc.setdefault(k, []).append(v)
     ktimes = {k: float(np.mean(v)) for k, v in acc.items()}

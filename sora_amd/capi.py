@@ -152,24 +152,38 @@ class Rx:
     def stream(self):
         return self._L.sora_rx_stream(self._h)
 
-    @staticmethod
-    def _caps(captures):
-        arr = (CaptureDesc * len(captures))()
-        for i, c in enumerate(captures):
-            off, n = c[0], c[1]
-            arr[i] = CaptureDesc(off, n, c[2] if len(c) > 2 else i)
+    CAPTURE_DTYPE = np.dtype([("offset", "<u8"), ("nsamples", "<u4"), ("capture_id", "<u4")])   # = sora_capture_desc
+
+    @classmethod
+    def captures(cls, captures):
+        """[(offset, nsamples[, id])] -> packed sora_capture_desc array (build it once when the same set is submitted repeatedly)."""
+        if isinstance(captures, np.ndarray) and captures.dtype == cls.CAPTURE_DTYPE:
+            return np.ascontiguousarray(captures)
+        arr = np.zeros(len(captures), cls.CAPTURE_DTYPE)
+        if len(captures):
+            if all(len(c) > 2 for c in captures):
+                a = np.asarray(captures, dtype=np.uint64).reshape(len(captures), -1)
+                arr["offset"] = a[:, 0]; arr["nsamples"] = a[:, 1]; arr["capture_id"] = a[:, 2]
+            else:
+                for i, c in enumerate(captures):
+                    arr[i] = (c[0], c[1], c[2] if len(c) > 2 else i)
         return arr
+
+    @classmethod
+    def _caps(cls, captures):
+        arr = cls.captures(captures)
+        return arr, arr.ctypes.data_as(ctypes.POINTER(CaptureDesc))
 
     def process_dev(self, d_iq, captures):
         """d_iq: int16 torch CUDA tensor [N,2] (resident in HBM); captures: [(offset, nsamples[, id])]."""
-        arr = self._caps(captures)
+        arr, ptr = self._caps(captures)
         self._keep = d_iq
-        _check(self._L.sora_rx_process_dev(self._h, _dev_ptr(d_iq), arr, len(captures)))
+        _check(self._L.sora_rx_process_dev(self._h, _dev_ptr(d_iq), ptr, len(arr)))
 
     def process(self, h_iq, captures):
         a = np.ascontiguousarray(h_iq, np.int16).reshape(-1, 2)
-        arr = self._caps(captures)
-        _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), arr, len(captures)))
+        arr, ptr = self._caps(captures)
+        _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), ptr, len(arr)))
 
     def results_dev(self):
         """Device-resident results of the last call: (rows int32 tensor [cap_rows, 9] (36-byte sora_frame_result rows),

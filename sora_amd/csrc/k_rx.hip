@@ -2,8 +2,7 @@
 //
 //   k_frame       T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization -> TPhaseCompensate ->
 //                 TPilotTrack -> T11aDemap<N> -> T11aDeinterleave                           (one wave per frame, 4 symbols per pass)
-//   k_viterbi<CR> T11aViterbi<5000*8,48,256,24>: 64-state ACS, wave64 = 64 states          (one wave per two frames)
-//   k_traceback   TViterbiCore::Traceback for every window of the schedule                 (one thread per window)
+//   k_viterbi<CR> T11aViterbi<5000*8,48,256,24>: 64-state ACS + windowed trace-back out of LDS (one wave per two frames)
 //   k_finish      T11aDesc + TBB11aFrameSink (descramble, CRC-32, FRAME_OK / CRC32_FAIL)   (one wave per frame)
 // plus the stand-alone stage kernels behind the per-stage C entry points.
 #include <hip/hip_runtime.h>
@@ -51,7 +50,7 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     if (lane == 0) {
         VitJob J; J.pad = 0;
         J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot * 2u; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
-        J.dec_off = r.slot0 * (uint32_t)kDecPerSlot; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
+        J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
         A.jobs[j] = J;
     }
     const FrameCtx* fx = A.fctx + f;
@@ -231,13 +230,16 @@ __device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-ha
 
 constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
 constexpr unsigned kOne = 0x00010001u;                    // bit 0 of both halves
-constexpr int kColsPerRow = 24;                           // trellis columns per stored 256-byte decision row (3 blocks of 8)
+
+constexpr int kRingBlocks = 48;                           // 8-step blocks of survivor history kept in LDS per wave: a window walks <= 37 of them
 
 struct VitLane {
     unsigned U;              // (field B << 16) | field A; field = u << 9 | marks of the current 8-step block
-    unsigned histA, histB;   // survivor-path decision bytes of the blocks of the current row: byte j = block j
     unsigned MX[24];         // soft mask (+ mark, + complement for own-is-candidate-1 lanes) of the mark-carrying operand, per t mod 24
     unsigned MY[6];          // soft mask of the second operand of a two-input step, per t mod 6
+    uint32_t* ring;          // LDS: [kRingBlocks][64] the U word (marks of both frames) at the block's end, indexed by rev6(state)
+    unsigned roff;           // slot of the block being filled, in words: (block index % kRingBlocks) * 64   (wave-uniform)
+    unsigned sidx[3];        // ring index of the state this lane holds at the end of block j, by j % 3: rev6(rol6^(8j+8)(lane))
 };
 
 // WHICH 0: (A,B) two soft values, 1: A only, 2: B only.  t24 = trellis step index mod 24 (a constant after unrolling).
@@ -263,40 +265,106 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     default: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, true); break;                  // L ^ 1: quad_perm [1,0,3,2]
     }
     V.U = pk_min16(pk_add16(X, bm), pk_add16(Y, bo));
-    if (k == 7) {                                                               // end of an 8-step block: bank the path history, clear the marks
-        const int j = t24 / 8;
-        V.histA = __builtin_amdgcn_perm(V.U, V.histA, j == 0 ? 0x03020104u : j == 1 ? 0x03020400u : 0x03040100u);   // byte j <- U byte 0
-        V.histB = __builtin_amdgcn_perm(V.U, V.histB, j == 0 ? 0x03020106u : j == 1 ? 0x03020600u : 0x03060100u);   // byte j <- U byte 2
+    if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
+        V.ring[V.roff + V.sidx[t24 / 8]] = V.U;                                 // one ds_write_b32: byte 0 = frame A's block, byte 2 = frame B's
+        V.roff = V.roff + 64 == kRingBlocks * 64 ? 0u : V.roff + 64;
         V.U &= 0xFE00FE00u;
     }
 }
 
+// Trace-back of one window per frame (cnt = 0: none), called from the forward loop whenever the schedule fires (once per
+// 256 columns): start at the arg-min state with the reference's tie-break metric<<8 | state<<2 (viterbicore.h:479-524),
+// metric = 2u + last decision; walk back look + cnt columns, write cnt / 8 decoded bytes at bit `ob` of the frame.
+// The ring is indexed by q = rev6(state), so the index of the next (earlier) block is simply the low 6 bits of the
+// block just read.  All blocks the walk can touch (<= 38) are first fetched into registers, lane = ring index, with
+// independent LDS reads; the walk itself is then v_readlane + two scalar ops per block and frame, no memory latency.
+// Kept out of line: it is reached from every puncture group of the slow path.
+__device__ __noinline__ void viterbi_trace(unsigned U, const uint32_t* ring, uint32_t tr_, uint32_t ob_, unsigned mA, unsigned mB,
+                                           uint32_t cntA_, uint32_t cntB_, uint8_t* outA, uint8_t* outB)
+{
+    constexpr int kMaxWalk = 38;
+    const unsigned lane = threadIdx.x & 63;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // arguments arrive in VGPRs; these are wave-uniform
+    const uint32_t tr = uni(tr_), ob = uni(ob_), cntA = uni(cntA_), cntB = uni(cntB_);
+    auto rev6 = [](unsigned x) { return __brev(x) >> 26; };
+    auto writelane = [](unsigned& vec, unsigned val, unsigned ln) {             // vec[lane ln] = val (one SGPR operand per VALU op: the lane select goes through M0)
+        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(ln) : "m0");
+    };
+    const unsigned lbl = rol6(lane, tr) << 2;
+    const unsigned kA = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mA << 8) | lbl));
+    const unsigned kB = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mB << 8) | lbl));
+    const unsigned stA = (kA >> 2) & 0x3F, stB = (kB >> 2) & 0x3F;
+    const unsigned back = 6u - tr % 6u;                                         // lane holding state s now: rol6(s, 6 - tr mod 6)
+    const unsigned pA = (unsigned)__builtin_amdgcn_readlane((int)U, (int)rol6(stA, back)) & 0xFFu;            // decisions of the unfinished block
+    const unsigned pB = ((unsigned)__builtin_amdgcn_readlane((int)U, (int)rol6(stB, back)) >> 16) & 0xFFu;    //   along the start state's path
+    const int m_lo = (int)(ob >> 3);                                            // first output byte of the window
+    const int j = (int)((tr - 1) >> 3);                                         // block holding the start column
+    const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8
+    const int nblk = j - m_lo;                                                  // blocks below j on the walk
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint32_t W[kMaxWalk];                                                       // W[i] = block j - i, all 64 ring entries (one per lane)
+    const int sl0 = (j % kRingBlocks) * 64;
+#pragma unroll
+    for (int i = 0; i < kMaxWalk; i++) {
+        const int sl = sl0 - 64 * i;
+        W[i] = ring[(sl < 0 ? sl + kRingBlocks * 64 : sl) + (int)lane];
+    }
+    unsigned HA, HB;
+    if (n == 8) {
+        HA = (unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stA)) & 0xFFu;
+        HB = ((unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stB)) >> 16) & 0xFFu;
+    } else { HA = pA & ((1u << n) - 1u); HB = pB & ((1u << n) - 1u); }
+    unsigned qA = rev6(((stA >> n) | rev6(HA & 0x3Fu)) & 0x3Fu), qB = rev6(((stB >> n) | rev6(HB & 0x3Fu)) & 0x3Fu);   // ring index at column 8j
+    unsigned hvA = 0, hvB = 0;                                                  // lane i <- decisions of block m_lo + i
+    writelane(hvA, HA, (unsigned)nblk); writelane(hvB, HB, (unsigned)nblk);
+#pragma unroll
+    for (int i = 1; i < kMaxWalk; i++) {
+        if (i <= nblk) {
+            HA = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qA) & 0xFFu;          qA = HA & 0x3Fu;
+            HB = ((unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB) >> 16) & 0xFFu;  qB = HB & 0x3Fu;
+            writelane(hvA, HA, (unsigned)(nblk - i)); writelane(hvB, HB, (unsigned)(nblk - i));
+        }
+    }
+    // decoded byte m = (block m >> 6) | (block m+1 & 0x3F) << 2, lane i <-> byte m_lo + i
+    const unsigned upA = (unsigned)__shfl_down((int)hvA, 1), upB = (unsigned)__shfl_down((int)hvB, 1);
+    if (lane < (cntA >> 3)) outA[m_lo + (int)lane] = (uint8_t)((hvA >> 6) | ((upA & 0x3Fu) << 2));
+    if (lane < (cntB >> 3)) outB[m_lo + (int)lane] = (uint8_t)((hvB >> 6) | ((upB & 0x3Fu) << 2));
+}
+
 struct VitSide {            // wave-uniform per-frame bookkeeping
-    const uint32_t* soft; uint32_t* decT; uint32_t* tbk; uint32_t nsteps, last_chunk, tr_end, nw; bool on, done;
+    const uint32_t* soft; uint8_t* out; uint32_t nsteps, last_chunk, tr_end; bool done;
 };
 
 // Soft input: 16 bits per soft value, v << 9 (what k_frame / k_soft_widen write), so a packed branch-metric operand is
 // one s_pack_ll/hh_b32_b16 of a word of frame A and a word of frame B.  The words arrive through the scalar cache
-// (s_load_dwordx8 per 12-step chunk per frame, prefetched one chunk ahead): no VALU work, no LDS.
+// (s_load_dwordx8 per 12-step chunk per frame, prefetched one chunk ahead): no VALU work.
+//
+// Trace-back (TViterbiCore::Traceback, viterbicore.h:468-555) runs in the same wave, out of LDS, whenever the window
+// schedule of T11aViterbi<..,256,24>::Process (viterbi.hpp:196-214) fires: the ring holds, per 8-column block j
+// (columns 8j+1..8j+8) and per state at column 8j+8, the 8 decisions of the survivor path into that state (bit i =
+// column 8j+1+i).  One lookup walks 8 columns: the decisions are the decoded bits, and the state at column 8j is the 6
+// oldest decisions, newest in bit 0 (s' = d << 5 | s >> 1 applied 8 times).  Decoded bit i of the frame is the
+// decision at column i + 7 on the traced path (6-bit decoder delay), so output byte m is (block m >> 6) | (block m+1
+// & 0x3F) << 2.
 template <int CR>
-__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint64_t* __restrict__ dec_base,
-                                                uint32_t* __restrict__ tbkA, uint32_t* __restrict__ tbkB, uint32_t* __restrict__ nwinA, uint32_t* __restrict__ nwinB)
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint32_t* ring)
 {
     constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
     constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
     constexpr int CW = 12 / GS * GB / 2;                                        // 32-bit soft words per 12-step chunk: 12 / 9 / 8
     const unsigned lane = threadIdx.x & 63;
     VitSide A, B;
-    A.soft = reinterpret_cast<const uint32_t*>(soft_base + JA.soft_off); A.decT = reinterpret_cast<uint32_t*>(dec_base + JA.dec_off);
-    A.tbk = tbkA; A.nsteps = JA.nsoft / GB * GS; A.last_chunk = (A.nsteps - 1) / 12; A.tr_end = JA.length * 8u + 16u + 6u; A.nw = 0; A.on = true; A.done = false;
+    A.soft = reinterpret_cast<const uint32_t*>(soft_base + JA.soft_off); A.out = out_base + JA.out_off;
+    A.nsteps = JA.nsoft / GB * GS; A.last_chunk = (A.nsteps - 1) / 12; A.tr_end = JA.length * 8u + 16u + 6u; A.done = false;
     const VitJob& JBx = hasB ? JB : JA;
-    B.soft = reinterpret_cast<const uint32_t*>(soft_base + JBx.soft_off); B.decT = reinterpret_cast<uint32_t*>(dec_base + JBx.dec_off);
-    B.tbk = tbkB; B.nsteps = hasB ? JBx.nsoft / GB * GS : 0u; B.last_chunk = (JBx.nsoft / GB * GS - 1) / 12; B.tr_end = hasB ? JBx.length * 8u + 16u + 6u : 0u; B.nw = 0; B.on = hasB; B.done = !hasB;
+    B.soft = reinterpret_cast<const uint32_t*>(soft_base + JBx.soft_off); B.out = out_base + JBx.out_off;
+    B.nsteps = hasB ? JBx.nsoft / GB * GS : 0u; B.last_chunk = (JBx.nsoft / GB * GS - 1) / 12; B.tr_end = hasB ? JBx.length * 8u + 16u + 6u : 0u; B.done = !hasB;
 
     auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };   // step kinds of a puncture group (viterbi.hpp:167-187)
     VitLane V;
     V.U = lane == 0 ? 0u : 0x18u * kFld;                                       // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
-    V.histA = V.histB = 0;
+    V.ring = ring; V.roff = 0;
+    V.sidx[0] = __brev(rol6(lane, 2)) >> 26; V.sidx[1] = __brev(rol6(lane, 4)) >> 26; V.sidx[2] = __brev(lane) >> 26;   // rev6 of the state: (8j + 8) mod 6 = 2, 4, 0
 #pragma unroll
     for (int t = 0; t < 24; t++) {
         const int ph = t % 6, k = t % 8;
@@ -312,19 +380,7 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
     auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };       // Normalize (viterbicore.h:444-465), both frames; marks are clear here
-    // A window: arg-min with the reference's tie-break metric<<8 | state<<2 (viterbicore.h:479-524), metric = 2u + last decision.
-    // The record carries the start state and the decisions of the unfinished block (tr % 8 of them) along its path.
-    auto record = [&](VitSide& S, unsigned mbyte, unsigned fieldbyte, uint32_t cnt, uint32_t look) {
-        const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mbyte << 8) | (rol6(lane, tr) << 2)));
-        const unsigned state = (kmin >> 2) & 0x3F;
-        const unsigned part = (unsigned)__builtin_amdgcn_readlane((int)fieldbyte, (int)rol6(state, 6u - tr % 6u)) & ((1u << (tr & 7)) - 1u);
-        if (lane == 0) {
-            S.tbk[S.nw * 3 + 0] = tr;
-            S.tbk[S.nw * 3 + 1] = look | (cnt << 16);
-            S.tbk[S.nw * 3 + 2] = state | (part << 8) | ((ob >> 8) << 16);
-        }
-        S.nw++;
-    };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + 256u + 24u + 6u;
         if (!A.done) t = min(t, A.tr_end);
@@ -334,27 +390,23 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     uint32_t next_thr = next_event();
     auto check = [&](int t24_last) {                                            // trace-back schedule (viterbi.hpp:196-214), per frame
         if (tr >= next_thr) {
-            const int k = t24_last % 8, j = t24_last / 8;                       // the last decision: mark k of the field, or bit 7 of the block just banked
-            const unsigned dA = k == 7 ? (V.histA >> (8 * j + 7)) & 1u : (V.U >> k) & 1u;
-            const unsigned dB = k == 7 ? (V.histB >> (8 * j + 7)) & 1u : (V.U >> (16 + k)) & 1u;
-            const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | dA, mB = (V.U >> 25 << 1) | dB;
+            const int k = t24_last % 8;                                         // the last decision: mark k of the field, or bit 7 of the block just banked
+            const unsigned last = k == 7 ? ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]] >> 7 : V.U >> k;
+            const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | (last & 1u), mB = (V.U >> 25 << 1) | ((last >> 16) & 1u);
             const bool partial = tr >= ob + 256u + 24u + 6u;
-            const uint32_t plook = 24 + (tr - (ob + 256 + 24 + 6)) % 8;
+            uint32_t cntA = 0, cntB = 0;
             if (!A.done) {
-                if (tr >= A.tr_end) { record(A, mA, V.U & 0xFFu, A.tr_end - ob - 6, tr - A.tr_end); A.done = true; }
-                else if (partial) record(A, mA, V.U & 0xFFu, 256, plook);
+                if (tr >= A.tr_end) { cntA = A.tr_end - ob - 6; A.done = true; }
+                else if (partial) cntA = 256;
             }
             if (!B.done) {
-                if (tr >= B.tr_end) { record(B, mB, (V.U >> 16) & 0xFFu, B.tr_end - ob - 6, tr - B.tr_end); B.done = true; }
-                else if (partial) record(B, mB, (V.U >> 16) & 0xFFu, 256, plook);
+                if (tr >= B.tr_end) { cntB = B.tr_end - ob - 6; B.done = true; }
+                else if (partial) cntB = 256;
             }
+            if (cntA | cntB) trace(mA, mB, cntA, cntB);
             if (partial) ob += 256;
             next_thr = next_event();
         }
-    };
-    auto store_row = [&](uint32_t row) {
-        if (row * kColsPerRow < A.nsteps + kColsPerRow) A.decT[row * 64 + lane] = V.histA;
-        if (B.on && row * kColsPerRow < B.nsteps + kColsPerRow) B.decT[row * 64 + lane] = V.histB;
     };
     struct Chunk { uint32_t a[CW], b[CW]; };
     auto load_chunk = [&](uint32_t c, uint32_t zero) -> Chunk {                 // chunk c of both frames; past a frame's end: its last chunk again
@@ -401,7 +453,7 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     // first use of the loaded registers.  The prefetch of chunk c+1 must therefore be ISSUED after the first use of chunk c
     // (or that wait would cover the prefetch too) and is then covered by a whole chunk of ACS work.  The order is pinned by
     // data flow: the prefetch address takes a bit of chunk c that is always zero (soft fields are v << 9).
-    uint32_t row = 0, c = 0;
+    uint32_t c = 0;
     Chunk cur = load_chunk(0, 0);
     while (tr < nsteps && !(A.done && B.done)) {
         Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
@@ -410,22 +462,20 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         cur = load_chunk(c + 2, (nxt.a[0] | nxt.b[0]) & 1u);
         chunk(nxt, 1);
         c += 2;
-        if ((tr % kColsPerRow) == 0) { store_row(row); row++; }
     }
-    // last, partial row: the blocks finished so far (the unfinished block travels in the window record)
-    if ((tr % kColsPerRow) != 0) store_row(row);
-    if (lane == 0) { *nwinA = A.nw; if (hasB) *nwinB = B.nw; }
 }
 
 // Four waves per 256-thread workgroup, two frames per wave (no cross-wave traffic).  One-wave workgroups were kept to
 // 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.
 // Frames are paired in job order when their code rates agree; otherwise each runs alone in the low half.
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs_ptr, uint32_t njobs_max, const uint8_t* __restrict__ soft, uint64_t* __restrict__ dec, uint32_t* __restrict__ tbk, uint32_t* __restrict__ nwin)
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs_ptr, uint32_t njobs_max, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
+    __shared__ uint32_t s_ring[4][kRingBlocks * 64];                             // 48 KB: survivor history of the last 384 columns, per wave
     const uint32_t njobs = njobs_ptr ? *njobs_ptr : njobs_max;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
     const uint32_t fa = uni((blockIdx.x * 4 + (threadIdx.x >> 6)) * 2), fb = fa + 1;
     if (fa >= njobs) return;
+    uint32_t* ring = s_ring[threadIdx.x >> 6];
     auto load_job = [&](uint32_t f) {
         const VitJob& G = jobs[f];
         VitJob J;
@@ -437,63 +487,14 @@ __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs
     VitJob JB = JA;
     bool hasB = fb < njobs;
     if (hasB) { JB = load_job(fb); hasB = JB.valid != 0; }
-    uint32_t* ta = tbk + (size_t)fa * kMaxWindows * 3;
-    uint32_t* tb = tbk + (size_t)fb * kMaxWindows * 3;
     const bool pair = JA.valid && hasB && JA.code_rate == JB.code_rate;
     for (int pass = 0; pass < (pair ? 1 : 2); pass++) {                         // unpaired: A alone, then B alone (one call site per code rate)
         const bool second = pass == 1;
         if (second ? !hasB : !JA.valid) continue;
         const VitJob X = second ? JB : JA;
-        uint32_t* tx = second ? tb : ta;
-        uint32_t* nx = nwin + (second ? fb : fa);
-        if (X.code_rate == 0)      viterbi_forward<0>(X, JB, pair, soft, dec, tx, tb, nx, nwin + fb);
-        else if (X.code_rate == 1) viterbi_forward<1>(X, JB, pair, soft, dec, tx, tb, nx, nwin + fb);
-        else                       viterbi_forward<2>(X, JB, pair, soft, dec, tx, tb, nx, nwin + fb);
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// k_traceback: TViterbiCore::Traceback (viterbicore.h:468-555) -- every window of a frame is an independent
-// walk, one thread each (a 54 Mbps 1500-byte frame has 47 windows), one wave per frame.
-// k_viterbi stores, per 8-column block j (columns 8j+1..8j+8) and lane, the 8 decisions of the survivor path into the
-// state that lane held at column 8j+8 (bit i = column 8j+1+i): row j/3, word L, byte j%3, L = ror6^(8j+8)(state).
-// One lookup therefore walks 8 columns: the decisions are the decoded bits, and the state at column 8j is the 6 oldest
-// decisions, newest in bit 0 (s' = d << 5 | s >> 1 applied 8 times).  Decoded bit i of the frame is the decision at
-// column i + 7 on the traced path (6-bit decoder delay, viterbi.hpp:196-214), so output byte m is
-// (block m >> 6) | (block m+1 & 0x3F) << 2 -- no bit loop.
-__global__ void __launch_bounds__(64) k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec_base, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out_base)
-{
-    const uint32_t f = blockIdx.x;
-    if (f >= (njobs_ptr ? *njobs_ptr : njobs_max)) return;
-    const VitJob J = jobs[f];
-    if (!J.valid) return;
-    const uint32_t nw = nwin[f];
-    const uint32_t* decT = reinterpret_cast<const uint32_t*>(dec_base + J.dec_off);
-    uint8_t* out = out_base + J.out_off;
-    auto rev6 = [](unsigned x) { return __brev(x) >> 26; };
-    auto lookup = [&](uint32_t m, unsigned state) -> unsigned {                  // block m along the path that is in `state` at column 8m+8
-        const unsigned r = (2u * m + 2u) % 6u;                                   // (8m + 8) mod 6
-        const unsigned L = ((state >> r) | (state << (6 - r))) & 63u;            // ror6^(8m+8)(state)
-        return (decT[(size_t)(m / 3u) * 64 + L] >> (8u * (m % 3u))) & 0xFFu;
-    };
-    for (uint32_t w = threadIdx.x; w < nw; w += 64) {
-        const uint32_t* t = tbk + ((size_t)f * kMaxWindows + w) * 3;
-        const uint32_t col = t[0], look = t[1] & 0xFFFF, cnt = t[1] >> 16, ob = (t[2] >> 16) << 8;
-        unsigned state = t[2] & 0x3F;
-        const unsigned part = (t[2] >> 8) & 0xFF;
-        (void)look;
-        if (cnt == 0) continue;
-        const int m_lo = (int)(ob >> 3), m_hi = (int)((ob + cnt) >> 3);          // this window decodes output bytes [m_lo, m_hi)
-        const int j = (int)((col - 1) >> 3);                                     // block holding the start column; j >= m_hi
-        const unsigned n = col - 8u * (unsigned)j;                               // its decisions known at the start: 1..8
-        unsigned Hn = n == 8 ? lookup((uint32_t)j, state) : part;
-        state = ((state >> n) | rev6(Hn & ((1u << n) - 1u) & 0x3Fu)) & 0x3Fu;    // state at column 8j
-        for (int m = j - 1; m >= m_lo; m--) {
-            const unsigned Hm = lookup((uint32_t)m, state);
-            state = rev6(Hm & 0x3Fu);
-            if (m < m_hi) out[m] = (uint8_t)((Hm >> 6) | ((Hn & 0x3Fu) << 2));
-            Hn = Hm;
-        }
+        if (X.code_rate == 0)      viterbi_forward<0>(X, JB, pair, soft, out, ring);
+        else if (X.code_rate == 1) viterbi_forward<1>(X, JB, pair, soft, out, ring);
+        else                       viterbi_forward<2>(X, JB, pair, soft, out, ring);
     }
 }
 
@@ -640,11 +641,11 @@ __global__ void __launch_bounds__(256) k_soft_widen(const uint8_t* soft8, const 
 }
 
 __global__ void __launch_bounds__(64) k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
-                                                      const uint32_t* out_off, const uint32_t* dec_off, int code_rate, uint32_t n)
+                                                      const uint32_t* out_off, int code_rate, uint32_t n)
 {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    VitJob J; J.soft_off = soft_off[i]; J.nsoft = nsoft[i]; J.length = flen[i]; J.dec_off = dec_off[i]; J.out_off = out_off[i];
+    VitJob J; J.soft_off = soft_off[i]; J.nsoft = nsoft[i]; J.length = flen[i]; J.dec_off = 0; J.out_off = out_off[i];
     J.valid = 1; J.code_rate = (uint32_t)code_rate; J.pad = 0;
     jobs[i] = J;
 }

@@ -291,7 +291,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                             eq = mk(w16(re >> 8), w16(im >> 8));
                         }
                         const uint32_t slot0 = cd.slot_base + (sym_start / STR) / 80;
-                        A.eq[(size_t)slot0 * 64 + lane] = pack(eq);
                         // TPhaseCompensate with the reset CompCoeffs (0x7fff, 0) (ieee80211facade.hpp:198-206)
                         cpx pc = mul_q15(eq, mk(0x7fff, 0));
                         sync();

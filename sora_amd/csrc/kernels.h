@@ -19,7 +19,6 @@ struct ScanArgs {
     uint32_t*       nframes;    // [ncaps]
     int32_t*        slot_frame; // [total slots]
     uint16_t*       slot_sym;
-    uint32_t*       eq;         // [total slots][64]: the SIGNAL symbol's equalised bins are stored too
     uint32_t*       njobs;      // [1] number of frames whose data symbols must be decoded
     uint32_t*       joblist;    // [nrows] their frame-table rows, compacted: consecutive workgroups of the per-frame
                                 //         kernels then carry live work (workgroup b runs on XCD b % 8)
@@ -36,12 +35,7 @@ struct RxArgs {
     const FrameCtx* fctx;
     const int32_t*  slot_frame;
     const uint16_t* slot_sym;
-    uint32_t*       eq;             // [slots][64]
-    TrackRec*       track;          // [slots]
     uint8_t*        soft;           // [slots*288] 16-bit fields (v << 9)
-    uint64_t*       dec;            // [slots*216]
-    uint32_t*       tbk;            // [nrows][kMaxWindows][3] : col, look|cnt<<16, pos|ob<<8
-    uint32_t*       nwin;           // [nrows]
     uint8_t*        vout;           // [slots*32]
     uint8_t*        mpdu;           // [slots*32]
     VitJob*         jobs;           // [nrows] (indexed by job)
@@ -51,8 +45,7 @@ struct RxArgs {
 
 __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
-__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint64_t* dec, uint32_t* tbk, uint32_t* nwin);
-__global__ void k_traceback(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint64_t* dec, const uint32_t* tbk, const uint32_t* nwin, uint8_t* out);
+__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint8_t* out);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);
@@ -65,6 +58,6 @@ __global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const 
 __global__ void k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
 __global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16);
 __global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
-                               const uint32_t* out_off, const uint32_t* dec_off, int code_rate, uint32_t n);
+                               const uint32_t* out_off, int code_rate, uint32_t n);
 
 }  // namespace sora

@@ -6,11 +6,7 @@
 //   frames[]      frame table, max_frames_per_capture rows per capture, filled by k_scan in time order
 //   fctx[]        per frame: FreqCoeffs[64] + ChannelCoeffs[64] (CF_FreqCompensate / CF_Channel_11a)
 //   slot_frame[]  per 80-sample symbol slot: owning frame row or -1; slot_sym[]: symbol index in frame
-//   eq[]          per slot: 64 equalised COMPLEX16 (output of TChannelEqualization)
-//   track[]       per slot: {CFO_comp, SFO_comp, avgTheta, delTheta} for TPhaseCompensate/TPilotTrack
-//   soft[]        per frame: de-interleaved soft values, contiguous (frame base = slot0*288)
-//   dec[]         per frame: survivor decisions, one 64-bit word per trellis column (frame base = slot0*216)
-//   tbk[]         per frame: trace-back start states of the T11aViterbi window schedule
+//   soft[]        per frame: de-interleaved soft values, 16-bit fields v << 9, contiguous (frame base = slot0*576 bytes)
 //   vout[]        per frame: Viterbi output bytes (length+2), base = slot0*32
 //   mpdu[]        per frame: descrambled MPDU, base = slot0*32 (same geometry as vout)
 //   rows[]        compacted sora_frame_result rows + counter
@@ -53,7 +49,7 @@ struct VitJob {             // one Viterbi decode: a frame of the RX path or one
     uint32_t soft_off;      // bytes from the soft base (4-byte aligned)
     uint32_t nsoft;
     uint32_t length;        // frame_length (decoded bytes = length+2)
-    uint32_t dec_off;       // 64-bit words from the decision base
+    uint32_t dec_off;       // unused (decisions live in LDS)
     uint32_t out_off;       // bytes from the output base
     uint32_t valid;
     uint32_t code_rate;
@@ -66,9 +62,7 @@ struct TrackRec {           // per data-symbol slot
 };
 
 constexpr int kSoftPerSlot = 288;      // N_CBPS max
-constexpr int kDecPerSlot  = 288;      // 64-bit words of decision storage per symbol slot: 216 columns -> 9 rows of 24 columns x 256 B
 constexpr int kOutPerSlot  = 32;       // decoded bytes per symbol max 27 -> 32
-constexpr int kMaxWindows  = 80;       // ceil((2500*8+16)/256)+1
 
 constexpr uint32_t E_FRAME_OK = 0x00000001u, E_PLCP_HEADER_FAIL = 0x80000005u, E_CRC32_FAIL = 0x80000006u,
                    E_CS_TIMEOUT = 0x80000007u;

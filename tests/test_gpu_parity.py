@@ -174,6 +174,28 @@ def test_batch_of_frames_54mbps(sora, torch_cuda, oracle):
     assert sum(r["error_code"] == E_FRAME_OK for r in got) >= 40
 
 
+def test_repeated_calls_replay_graph(sora, torch_cuda, oracle):
+    """Identical consecutive calls are replayed as one hipGraph launch; a different capture set drops the graph."""
+    capsA = [make_capture(oracle, 36000, 400 + 11 * i, seed=500 + i, rate_mhz=20, sigma=100, tail=160)[0] for i in range(6)]
+    capsB = [make_capture(oracle, 12000, 150 + 7 * i, seed=600 + i, rate_mhz=20, sigma=100, tail=160)[0] for i in range(5)]
+    iqA, dA = batch(capsA); iqB, dB = batch(capsB)
+    rx = sora.Rx(max_captures=8, max_total_samples=max(len(iqA), len(iqB)), sample_rate_mhz=20, max_frames_per_capture=2)
+    tA = torch_cuda.from_numpy(iqA).cuda(); tB = torch_cuda.from_numpy(iqB).cuda()
+    wantA = oracle_results(oracle, capsA, 20); wantB = oracle_results(oracle, capsB, 20)
+    for k in range(4):
+        rx.process_dev(tA, dA)
+        ok, why = same_results(rx.results(), wantA); assert ok, (k, why)
+    for k in range(3):
+        rx.process_dev(tB, dB)
+        ok, why = same_results(rx.results(), wantB); assert ok, (k, why)
+    tA.add_(0)                                     # same buffer, same descriptors, new contents are picked up by the replay
+    tA.copy_(torch_cuda.from_numpy(iqA[::-1].copy()).cuda()); tA.copy_(torch_cuda.from_numpy(iqA).cuda())
+    for k in range(3):
+        rx.process_dev(tA, dA)
+        ok, why = same_results(rx.results(), wantA); assert ok, (k, why)
+    rx.close()
+
+
 def test_host_buffer_entry_point(sora, torch_cuda, oracle):
     cap, mp = make_capture(oracle, 18000, 333, seed=2, rate_mhz=40, sigma=100)
     rx = sora.Rx(1, len(cap), sample_rate_mhz=40)
