@@ -81,6 +81,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="captures per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--depth", type=int, default=0, help="process calls in flight on the handle's internal pipelines (0 = library default)")
     ap.add_argument("--check", type=int, default=32, help="captures compared with the oracle after the timed region")
     args = ap.parse_args()
 
@@ -104,6 +105,10 @@ def main():
     d_iq = torch.from_numpy(iq).to(dev)
     descs = sora_amd.Rx.captures(descs)           # packed sora_capture_desc[]: built once, submitted every step
     rx = sora_amd.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, device=local_rank, max_frames_per_capture=2)
+
+    if args.depth:
+        rx.set_depth(args.depth)
+    depth = rx.set_depth(0)
 
     def barrier():
         if world > 1:
@@ -182,7 +187,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 IQ / u8 path metrics", "data": "synthetic",
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
-                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES,
+                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth,
                        "sharding": "captures per rank, no data-path collective"},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok, "oracle_parity_sample_ok": parity_ok,

@@ -105,6 +105,14 @@ int  sora_rx_set_profiling(sora_rx_t* rx, int enable);
 int  sora_rx_kernel_times(sora_rx_t* rx, float* h_ms, size_t cap, size_t* nout);
 const char* sora_rx_kernel_name(size_t index);
 
+/* Consecutive process calls rotate over `depth` internal pipelines (own stream, own intermediate arrays), so the
+ * latency-bound front end of one call overlaps the trellis kernel of the call before it -- what the reference gets from
+ * running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120).  Default 3 (environment SORA_HIP_DEPTH), 1 = strictly
+ * one call at a time, at most 4.  Returns the previous value; depth <= 0 only queries.  The results/results_dev/stream/
+ * kernel_times calls refer to the MOST RECENT process call; sora_rx_flush waits for every call in flight; an input buffer
+ * must stay untouched until the call that reads it has finished (as with any asynchronous call). */
+int  sora_rx_set_depth(sora_rx_t* rx, int depth);
+
 /* Device-side views of the last call's outputs (valid until the next process/reset/destroy). */
 int  sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu);
 

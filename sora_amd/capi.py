@@ -46,7 +46,7 @@ class FrameResult(ctypes.Structure):
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
-           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a"]
+           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a"]
 
 _lib = None
 
@@ -91,6 +91,7 @@ def load(build_if_missing=True):
     L.sora_rx_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
+    L.sora_rx_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_hip_fft64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_fft128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_lts11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -203,6 +204,10 @@ class Rx:
 
     def set_profiling(self, enable=True):
         _check(self._L.sora_rx_set_profiling(self._h, 1 if enable else 0))
+
+    def set_depth(self, depth=0):
+        """number of process calls kept in flight on internal pipelines (1..4); returns the previous value"""
+        return int(self._L.sora_rx_set_depth(self._h, int(depth)))
 
     def kernel_times(self):
         """{kernel name: ms} of the last profiled process call (HIP events on the handle's stream)."""

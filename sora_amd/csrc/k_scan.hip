@@ -411,11 +411,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                 const bool plcp_fail = error_code == E_PLCP_HEADER_FAIL;
                 if (plcp_fail) r_end = vpos / STR;
                 else {
-                    // register the frame's symbol slots and queue it for the per-frame kernels
-                    for (uint32_t s = lane; s <= r_nsym; s += 64) {
-                        A.slot_frame[r_slot0 + s] = (int32_t)(cap_i * A.max_frames + nfr);
-                        A.slot_sym[r_slot0 + s] = (uint16_t)s;
-                    }
+                    // queue the frame for the per-frame kernels
                     if (lane == 0) A.joblist[atomicAdd(A.njobs, 1u)] = cap_i * A.max_frames + nfr;
                 }
                 if (lane == 0) {

@@ -17,8 +17,6 @@ struct ScanArgs {
     FrameRow*       frames;     // [ncaps*max_frames]
     FrameCtx*       fctx;
     uint32_t*       nframes;    // [ncaps]
-    int32_t*        slot_frame; // [total slots]
-    uint16_t*       slot_sym;
     uint32_t*       njobs;      // [1] number of frames whose data symbols must be decoded
     uint32_t*       joblist;    // [nrows] their frame-table rows, compacted: consecutive workgroups of the per-frame
                                 //         kernels then carry live work (workgroup b runs on XCD b % 8)
@@ -33,8 +31,6 @@ struct RxArgs {
     Tables          T;
     FrameRow*       frames;
     const FrameCtx* fctx;
-    const int32_t*  slot_frame;
-    const uint16_t* slot_sym;
     uint8_t*        soft;           // [slots*288] 16-bit fields (v << 9)
     uint8_t*        vout;           // [slots*32]
     uint8_t*        mpdu;           // [slots*32]

@@ -5,7 +5,6 @@
 //   caps[]        per capture {offset, nsamples, id, slot_base}
 //   frames[]      frame table, max_frames_per_capture rows per capture, filled by k_scan in time order
 //   fctx[]        per frame: FreqCoeffs[64] + ChannelCoeffs[64] (CF_FreqCompensate / CF_Channel_11a)
-//   slot_frame[]  per 80-sample symbol slot: owning frame row or -1; slot_sym[]: symbol index in frame
 //   soft[]        per frame: de-interleaved soft values, 16-bit fields v << 9, contiguous (frame base = slot0*576 bytes)
 //   vout[]        per frame: Viterbi output bytes (length+2), base = slot0*32
 //   mpdu[]        per frame: descrambled MPDU, base = slot0*32 (same geometry as vout)

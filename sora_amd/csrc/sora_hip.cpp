@@ -228,7 +228,8 @@ static DevTables* stage_tables()
 }
 
 // ------------------------------------------------------------------------------------------------
-struct sora_rx {
+// One receive pipeline: a stream, the device arrays of one call in flight, and that call's bookkeeping.
+struct RxPipe {
     sora_rx_cfg cfg{};
     hipStream_t stream = nullptr;
     DevTables tabs;
@@ -237,7 +238,6 @@ struct sora_rx {
     uint32_t cap_slots = 0, cap_rows = 0;
     // device arrays
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
-    int32_t* d_slot_frame = nullptr; uint16_t* d_slot_sym = nullptr;
     uint8_t* d_soft = nullptr;
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
@@ -262,10 +262,10 @@ struct sora_rx {
 static constexpr size_t kNumTimed = 5;
 static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_finish" };
 
-static void rx_free(sora_rx* rx)
+static void rx_free(RxPipe* rx)
 {
     if (!rx) return;
-    void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes, rx->d_slot_frame, rx->d_slot_sym,
+    void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes,
                      rx->d_soft, rx->d_vout, rx->d_mpdu, rx->d_jobs, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
@@ -294,7 +294,7 @@ void  sora_hip_free(void* p) { if (p) (void)hipFree(p); }
 int   sora_hip_memcpy_h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return SORA_OK; }
 int   sora_hip_memcpy_d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return SORA_OK; }
 
-int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
+static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
 {
     if (!cfg || !out || cfg->struct_size != sizeof(sora_rx_cfg)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_create: bad cfg");
     if (cfg->sample_rate_mhz != 20 && cfg->sample_rate_mhz != 40) return fail(SORA_ERR_INVALID_PARAM, "sample_rate_mhz must be 20 or 40");
@@ -303,7 +303,7 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
     if (cfg->device < 0 || cfg->device >= ndev) return fail(SORA_ERR_INVALID_PARAM, "device ordinal out of range");
     HIPCHK(hipSetDevice(cfg->device));
-    sora_rx* rx = new sora_rx();
+    RxPipe* rx = new RxPipe();
     rx->cfg = *cfg;
     if (rx->cfg.cca_pwr_threshold == 0) rx->cfg.cca_pwr_threshold = 1000 * 1000;
     rx->str = cfg->sample_rate_mhz == 40 ? 2 : 1;
@@ -322,7 +322,6 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     struct { void** p; size_t bytes; } allocs[] = {
         { (void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures }, { (void**)&rx->d_frames, sizeof(FrameRow) * rx->cap_rows },
         { (void**)&rx->d_fctx, sizeof(FrameCtx) * rx->cap_rows }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
-        { (void**)&rx->d_slot_frame, 4 * (size_t)rx->cap_slots }, { (void**)&rx->d_slot_sym, 2 * (size_t)rx->cap_slots },
         { (void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64 },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
         { (void**)&rx->d_jobs, sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
@@ -336,9 +335,9 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     return SORA_OK;
 }
 
-void sora_rx_destroy(sora_rx_t* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); (void)hipStreamSynchronize(rx->stream); rx_free(rx); } }
+static void pipe_destroy(RxPipe* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); (void)hipStreamSynchronize(rx->stream); rx_free(rx); } }
 
-int sora_rx_reset(sora_rx_t* rx)
+static int pipe_reset(RxPipe* rx)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     HIPCHK(hipSetDevice(rx->cfg.device));
@@ -347,7 +346,7 @@ int sora_rx_reset(sora_rx_t* rx)
     return SORA_OK;
 }
 
-int sora_rx_flush(sora_rx_t* rx)
+static int pipe_flush(RxPipe* rx)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     HIPCHK(hipSetDevice(rx->cfg.device));
@@ -355,9 +354,9 @@ int sora_rx_flush(sora_rx_t* rx)
     return SORA_OK;
 }
 
-void* sora_rx_stream(sora_rx_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+static void* pipe_stream(RxPipe* rx) { return rx ? (void*)rx->stream : nullptr; }
 
-int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
+static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx || (!d_iq && ncaps) || (!caps && ncaps)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
     if (ncaps > rx->cfg.max_captures) return fail(SORA_ERR_CAPACITY, "more captures than sora_rx_cfg.max_captures");
@@ -391,19 +390,18 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
 
     auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
-        HIPCHK(hipMemsetAsync(rx->d_slot_frame, 0xFF, 4 * (size_t)slots, st));
         HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
         HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 4, st));
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-        S.slot_frame = rx->d_slot_frame; S.slot_sym = rx->d_slot_sym; S.njobs = rx->d_njobs; S.joblist = rx->d_joblist;
+        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist;
         mark();
         hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
         RxArgs R{};
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
-        R.frames = rx->d_frames; R.fctx = rx->d_fctx; R.slot_frame = rx->d_slot_frame; R.slot_sym = rx->d_slot_sym;
+        R.frames = rx->d_frames; R.fctx = rx->d_fctx;
         R.soft = rx->d_soft;
         R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
         hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
@@ -441,7 +439,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     return SORA_OK;
 }
 
-int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* caps, size_t ncaps)
+static int pipe_process(RxPipe* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx || !h_iq) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process: null argument");
     if (total_samples > rx->cfg.max_total_samples) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
@@ -453,10 +451,10 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
         rx->iq_own_samples = total_samples;
     }
     HIPCHK(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * total_samples, hipMemcpyHostToDevice, rx->stream));
-    return sora_rx_process_dev(rx, rx->d_iq_own, caps, ncaps);
+    return pipe_process_dev(rx, rx->d_iq_own, caps, ncaps);
 }
 
-int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+static int pipe_results(RxPipe* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
 {
     if (!rx || !nout) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results: null argument");
     *nout = 0;
@@ -489,7 +487,7 @@ int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_
     return SORA_OK;
 }
 
-int sora_rx_set_profiling(sora_rx_t* rx, int enable)
+static int pipe_set_profiling(RxPipe* rx, int enable)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     HIPCHK(hipSetDevice(rx->cfg.device));
@@ -498,7 +496,7 @@ int sora_rx_set_profiling(sora_rx_t* rx, int enable)
     return SORA_OK;
 }
 
-int sora_rx_kernel_times(sora_rx_t* rx, float* ms, size_t cap, size_t* nout)
+static int pipe_kernel_times(RxPipe* rx, float* ms, size_t cap, size_t* nout)
 {
     if (!rx || !ms || !nout) return SORA_ERR_INVALID_PARAM;
     *nout = 0;
@@ -511,7 +509,7 @@ int sora_rx_kernel_times(sora_rx_t* rx, float* ms, size_t cap, size_t* nout)
 
 const char* sora_rx_kernel_name(size_t i) { return i < kNumTimed ? kKernelNames[i] : ""; }
 
-int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
+static int pipe_results_dev(RxPipe* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results_dev: null handle");
     if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
@@ -525,6 +523,126 @@ int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const u
     if (d_nrows) *d_nrows = rx->d_nrows;
     if (d_mpdu) *d_mpdu = rx->d_mpdu;
     return SORA_OK;
+}
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// The public handle: up to kMaxDepth pipelines used round-robin by consecutive process calls, so that the latency-bound
+// front end of one call (k_scan, k_frame) overlaps the issue-bound trellis kernel of the call before it -- the overlap
+// the reference gets from running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120, TThreadSeparator
+// stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
+struct sora_rx {
+    static constexpr int kMaxDepth = 4;
+    sora_rx_cfg cfg{};
+    int depth = 3;
+    int cur = 0;                 // pipeline of the most recent process call
+    bool started = false;
+    bool profiling = false;
+    RxPipe* pipes[kMaxDepth] = {};
+};
+
+static RxPipe* pipe_at(sora_rx* rx, int i)
+{
+    if (!rx->pipes[i]) {
+        if (pipe_create(&rx->cfg, &rx->pipes[i]) != SORA_OK) return nullptr;
+        if (rx->profiling) (void)pipe_set_profiling(rx->pipes[i], 1);
+    }
+    return rx->pipes[i];
+}
+
+extern "C" {
+
+int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
+{
+    if (!out) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_create: bad cfg");
+    RxPipe* p0 = nullptr;
+    const int rc = pipe_create(cfg, &p0);
+    if (rc != SORA_OK) return rc;
+    sora_rx* rx = new sora_rx();
+    rx->cfg = *cfg; rx->pipes[0] = p0;
+    if (const char* env = getenv("SORA_HIP_DEPTH")) rx->depth = std::max(1, std::min((int)sora_rx::kMaxDepth, atoi(env)));
+    *out = rx;
+    return SORA_OK;
+}
+
+void sora_rx_destroy(sora_rx_t* rx)
+{
+    if (!rx) return;
+    for (RxPipe* p : rx->pipes) if (p) pipe_destroy(p);
+    delete rx;
+}
+
+int sora_rx_set_depth(sora_rx_t* rx, int depth)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->depth;
+    if (depth > 0) rx->depth = std::min(depth, (int)sora_rx::kMaxDepth);
+    return old;
+}
+
+int sora_rx_reset(sora_rx_t* rx)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    for (RxPipe* p : rx->pipes) if (p) { const int rc = pipe_reset(p); if (rc) return rc; }
+    return SORA_OK;
+}
+
+int sora_rx_flush(sora_rx_t* rx)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    for (RxPipe* p : rx->pipes) if (p) { const int rc = pipe_flush(p); if (rc) return rc; }
+    return SORA_OK;
+}
+
+void* sora_rx_stream(sora_rx_t* rx) { return rx ? pipe_stream(rx->pipes[rx->cur]) : nullptr; }
+
+int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
+    const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
+    RxPipe* p = pipe_at(rx, next);
+    if (!p) return SORA_ERR_HARDWARE_FAILED;
+    const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; }
+    return rc;
+}
+
+int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process: null argument");
+    const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
+    RxPipe* p = pipe_at(rx, next);
+    if (!p) return SORA_ERR_HARDWARE_FAILED;
+    const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; }
+    return rc;
+}
+
+int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results: null argument");
+    return pipe_results(rx->pipes[rx->cur], out, max_out, nout, h_mpdu, mpdu_cap);
+}
+
+int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
+{
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results_dev: null handle");
+    return pipe_results_dev(rx->pipes[rx->cur], d_rows, d_nrows, d_mpdu);
+}
+
+int sora_rx_set_profiling(sora_rx_t* rx, int enable)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    rx->profiling = enable != 0;
+    for (RxPipe* p : rx->pipes) if (p) { const int rc = pipe_set_profiling(p, enable); if (rc) return rc; }
+    return SORA_OK;
+}
+
+int sora_rx_kernel_times(sora_rx_t* rx, float* ms, size_t cap, size_t* nout)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    return pipe_kernel_times(rx->pipes[rx->cur], ms, cap, nout);
 }
 
 // ---- per-stage entry points

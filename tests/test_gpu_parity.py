@@ -196,6 +196,29 @@ def test_repeated_calls_replay_graph(sora, torch_cuda, oracle):
     rx.close()
 
 
+@pytest.mark.parametrize("depth", [1, 2, 4])
+def test_calls_in_flight(sora, torch_cuda, oracle, depth):
+    """Consecutive calls rotate over internal pipelines; results() always reports the most recent call."""
+    sets = []
+    for s in range(3):
+        caps = [make_capture(oracle, [54000, 24000, 9000][s], 200 + 50 * s + 13 * i, seed=700 + 10 * s + i, rate_mhz=20, sigma=100, tail=160)[0] for i in range(4 + s)]
+        iq, d = batch(caps)
+        sets.append((torch_cuda.from_numpy(iq).cuda(), d, oracle_results(oracle, caps, 20)))
+    rx = sora.Rx(max_captures=8, max_total_samples=max(len(t) for t, _, _ in sets), sample_rate_mhz=20, max_frames_per_capture=2)
+    assert rx.set_depth(depth) == 3 and rx.set_depth(0) == depth
+    for k in range(9):
+        t, d, want = sets[k % 3]
+        rx.process_dev(t, d)
+        if k % 2:                                   # sometimes let several calls pile up before looking
+            ok, why = same_results(rx.results(), want); assert ok, (k, why)
+    rx.flush()
+    ok, why = same_results(rx.results(), sets[8 % 3][2]); assert ok, why
+    rx.reset()
+    with pytest.raises(Exception):
+        rx.results()
+    rx.close()
+
+
 def test_host_buffer_entry_point(sora, torch_cuda, oracle):
     cap, mp = make_capture(oracle, 18000, 333, seed=2, rate_mhz=40, sigma=100)
     rx = sora.Rx(1, len(cap), sample_rate_mhz=40)
