@@ -34,6 +34,17 @@ FRAME_SAMPLES = 4880       # 160 STS + 160 LTS + 80 SIGNAL + 56*80 data @20 MHz
 CAPTURE_SAMPLES = 5040     # + 160 silence; 360 source bursts of 14
 ALG_BYTES_PER_SAMPLE = 4.0 + 216 / 8.0 / 80.0     # 4.3375
 HBM_PEAK = 8.0e12
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r01_traffic.json")     # rocprofv3 --pmc summary (tools/collect_profiles.sh)
+
+
+def measured_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed PMC summary (FETCH_SIZE x2 + WRITE_SIZE, see the file), or None."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        return t["kernels"][kernel]["hbm_bytes"] if t.get("frames_per_launch") == FRAMES_PER_GPU else None
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def make_workload(oracle, nframes, seed0, distinct=512):
@@ -118,25 +129,23 @@ def main():
     for _ in range(args.warmup):
         rx.process_dev(d_iq, descs)
     rx.flush()
-    rx.set_profiling(True)
-    ktimes = {}
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         rx.process_dev(d_iq, descs)
-        # events of the previous call are read while the next one runs: no sync added inside the timed region
     barrier()
     t1 = time.perf_counter()
-    # per-kernel durations: a separate profiled pass of the same steps, back to back like the timed region (the HIP events
-    # of a call are read after the burst it belongs to; reading needs that call finished)
-    acc = {}
-    for _ in range(3):
-        for _ in range(max(3, min(args.steps, 10))):
-            rx.process_dev(d_iq, descs)
-        rx.flush()
-        for k, v in rx.kernel_times().items():
-            acc.setdefault(k, []).append(v)
-    ktimes = {k: float(np.mean(v)) for k, v in acc.items()}
+    # the same K steps once more with HIP events around every kernel launch (on the streams the kernels run on): the
+    # roofline's launch durations are means over this region; `value` comes from the un-instrumented region above
+    # (recording 6 events per call costs a few percent, reported as ms_per_step_profiled)
+    rx.set_profiling(True)
+    barrier()
+    t2 = time.perf_counter()
+    for _ in range(args.steps):
+        rx.process_dev(d_iq, descs)
+    barrier()
+    t3 = time.perf_counter()
+    ktimes = rx.kernel_times()
     rx.set_profiling(False)
 
     elapsed = t1 - t0
@@ -184,7 +193,7 @@ def main():
         out = {
             "metric": "IQ Msamples/s through 802.11a 54 Mbps RX PHY",
             "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 4), "ms_per_step_profiled": round((t3 - t2) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 IQ / u8 path metrics", "data": "synthetic",
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth,
@@ -192,7 +201,7 @@ def main():
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok, "oracle_parity_sample_ok": parity_ok,
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK, 5), "traffic": None,
+                         "frac": round(ach / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes[dom], 4),
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},

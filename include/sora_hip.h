@@ -98,9 +98,11 @@ int  sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_sam
 /* TBB11aFrameSink's frame buffer + CF_Error per frame: copies results of the last process call to the host.
  * h_mpdu may be NULL (descriptors only).  *nout = rows written. Frames appear in (capture, time) order. */
 int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
-/* Per-kernel timing with HIP events recorded on the handle's own stream (SoraStopwatch / MACStopwatch analogue,
- * kernel/bb/demod11/MACStopwatch.h:84-128).  With profiling enabled every process call brackets each kernel
- * launch with events; sora_rx_kernel_times returns the durations (ms) of the LAST call in launch order. */
+/* Per-kernel timing with HIP events recorded on the streams the kernels run on (SoraStopwatch / MACStopwatch analogue,
+ * kernel/bb/demod11/MACStopwatch.h:84-128).  With profiling enabled every process call brackets each kernel launch
+ * with events; sora_rx_kernel_times waits for the calls in flight and returns, in launch order, the MEAN duration (ms)
+ * of each kernel over all process calls since profiling was (re-)enabled.  Calls in flight on different pipelines
+ * share the CUs, so these are the durations the kernels really had, not what each would take alone. */
 int  sora_rx_set_profiling(sora_rx_t* rx, int enable);
 int  sora_rx_kernel_times(sora_rx_t* rx, float* h_ms, size_t cap, size_t* nout);
 const char* sora_rx_kernel_name(size_t index);

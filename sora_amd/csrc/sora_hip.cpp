@@ -248,19 +248,31 @@ struct RxPipe {
     CapDesc* h_caps_pinned = nullptr; size_t caps_resident = 0; hipEvent_t ev_caps = nullptr;
     uint32_t ncaps = 0, total_slots = 0;
     bool have_results = false;
-    // A call that repeats the previous one's geometry (same IQ buffer, same capture set) replays the kernel chain as one
-    // hipGraph launch: the chain is ten short enqueues, and their host cost shows up between the kernels otherwise.
-    bool use_graph = true;
+    // Opt-in (SORA_HIP_GRAPH=1): a call that repeats the previous one's geometry (same IQ buffer, same capture set) replays
+    // the kernel chain as one hipGraph launch.  Off by default: on this path the GPU time per call dwarfs the six enqueues,
+    // and instantiating the graph on the second identical call costs more than it saves for short runs.
+    bool use_graph = false;
     const void* last_iq = nullptr; bool last_valid = false;
     hipGraph_t graph = nullptr; hipGraphExec_t graph_exec = nullptr;
     // profiling
     bool profiling = false;
     hipEvent_t ev[9] = {};
-    bool ev_valid = false;
+    bool ev_valid = false;       // ev[] hold a call whose durations have not been folded into t_sum yet
+    double t_sum[8] = {}; uint64_t t_calls = 0;   // per-kernel durations (ms) summed over the profiled calls of this pipeline
 };
 
 static constexpr size_t kNumTimed = 5;
 static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_finish" };
+
+// Adds the durations of the pipeline's last profiled call to its running sums (waits for that call).
+static int fold_profile(RxPipe* rx)
+{
+    if (!rx->ev_valid) return SORA_OK;
+    HIPCHK(hipEventSynchronize(rx->ev[kNumTimed]));
+    for (size_t i = 0; i < kNumTimed; i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, rx->ev[i], rx->ev[i + 1])); rx->t_sum[i] += t; }
+    rx->t_calls++; rx->ev_valid = false;
+    return SORA_OK;
+}
 
 static void rx_free(RxPipe* rx)
 {
@@ -315,7 +327,7 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     e = hipHostMalloc((void**)&rx->h_caps_pinned, sizeof(CapDesc) * cfg->max_captures, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&rx->ev_caps, hipEventDisableTiming);
     if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "pinned descriptor buffer", e); }
-    if (getenv("SORA_HIP_NO_GRAPH")) rx->use_graph = false;
+    if (const char* g = getenv("SORA_HIP_GRAPH")) rx->use_graph = atoi(g) != 0;
     const uint64_t n20 = cfg->max_total_samples / rx->str;
     rx->cap_slots = (uint32_t)(n20 / 80 + cfg->max_captures + 16);
     rx->cap_rows = cfg->max_captures * cfg->max_frames_per_capture;
@@ -375,6 +387,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
     hipStream_t st = rx->stream;
     const bool prof = rx->profiling;
+    if (prof) { const int rc = fold_profile(rx); if (rc) return rc; }
     int evi = 0;
     auto mark = [&]() { if (prof) (void)hipEventRecord(rx->ev[evi++], st); };
     mark();
@@ -493,17 +506,8 @@ static int pipe_set_profiling(RxPipe* rx, int enable)
     HIPCHK(hipSetDevice(rx->cfg.device));
     if (enable && !rx->ev[0]) for (auto& e : rx->ev) HIPCHK(hipEventCreate(&e));
     rx->profiling = enable != 0; rx->ev_valid = false;
-    return SORA_OK;
-}
-
-static int pipe_kernel_times(RxPipe* rx, float* ms, size_t cap, size_t* nout)
-{
-    if (!rx || !ms || !nout) return SORA_ERR_INVALID_PARAM;
-    *nout = 0;
-    if (!rx->ev_valid) return fail(SORA_ERR_FAILED, "no profiled process call");
-    HIPCHK(hipSetDevice(rx->cfg.device));
-    HIPCHK(hipEventSynchronize(rx->ev[kNumTimed]));
-    for (size_t i = 0; i < kNumTimed && i < cap; i++) { HIPCHK(hipEventElapsedTime(&ms[i], rx->ev[i], rx->ev[i + 1])); (*nout)++; }
+    for (auto& t : rx->t_sum) t = 0.0;
+    rx->t_calls = 0;
     return SORA_OK;
 }
 
@@ -641,8 +645,18 @@ int sora_rx_set_profiling(sora_rx_t* rx, int enable)
 
 int sora_rx_kernel_times(sora_rx_t* rx, float* ms, size_t cap, size_t* nout)
 {
-    if (!rx) return SORA_ERR_INVALID_PARAM;
-    return pipe_kernel_times(rx->pipes[rx->cur], ms, cap, nout);
+    if (!rx || !ms || !nout) return SORA_ERR_INVALID_PARAM;
+    *nout = 0;
+    double sum[kNumTimed] = {}; uint64_t calls = 0;
+    for (RxPipe* p : rx->pipes) if (p) {
+        HIPCHK(hipSetDevice(p->cfg.device));
+        const int rc = fold_profile(p); if (rc) return rc;
+        for (size_t i = 0; i < kNumTimed; i++) sum[i] += p->t_sum[i];
+        calls += p->t_calls;
+    }
+    if (!calls) return fail(SORA_ERR_FAILED, "no profiled process call");
+    for (size_t i = 0; i < kNumTimed && i < cap; i++) { ms[i] = (float)(sum[i] / (double)calls); (*nout)++; }
+    return SORA_OK;
 }
 
 // ---- per-stage entry points

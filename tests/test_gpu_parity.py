@@ -174,12 +174,15 @@ def test_batch_of_frames_54mbps(sora, torch_cuda, oracle):
     assert sum(r["error_code"] == E_FRAME_OK for r in got) >= 40
 
 
-def test_repeated_calls_replay_graph(sora, torch_cuda, oracle):
-    """Identical consecutive calls are replayed as one hipGraph launch; a different capture set drops the graph."""
+@pytest.mark.parametrize("graph", ["0", "1"])
+def test_repeated_calls_replay_graph(sora, torch_cuda, oracle, graph, monkeypatch):
+    """Identical consecutive calls (optionally replayed as one hipGraph launch, SORA_HIP_GRAPH=1); a different capture set drops the graph."""
+    monkeypatch.setenv("SORA_HIP_GRAPH", graph)
     capsA = [make_capture(oracle, 36000, 400 + 11 * i, seed=500 + i, rate_mhz=20, sigma=100, tail=160)[0] for i in range(6)]
     capsB = [make_capture(oracle, 12000, 150 + 7 * i, seed=600 + i, rate_mhz=20, sigma=100, tail=160)[0] for i in range(5)]
     iqA, dA = batch(capsA); iqB, dB = batch(capsB)
     rx = sora.Rx(max_captures=8, max_total_samples=max(len(iqA), len(iqB)), sample_rate_mhz=20, max_frames_per_capture=2)
+    rx.set_depth(1)
     tA = torch_cuda.from_numpy(iqA).cuda(); tB = torch_cuda.from_numpy(iqB).cuda()
     wantA = oracle_results(oracle, capsA, 20); wantB = oracle_results(oracle, capsB, 20)
     for k in range(4):

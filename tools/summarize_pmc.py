@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""summarize_pmc.py -- per-kernel HBM traffic of one receive call from two rocprofv3 --pmc passes.
+
+    python tools/summarize_pmc.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <frames per launch> > profiles/rNN_traffic.json
+
+FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (they come from the L2's memory-side request counters).
+Corrections applied as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950: FETCH_SIZE is doubled
+(128-byte requests tallied at 64 bytes); WRITE_SIZE is taken as reported (uncalibrated).  The two counters cannot share
+a pass, so each file comes from its own run of the same command.
+"""
+import csv
+import json
+import sys
+from collections import defaultdict
+
+
+def per_kernel(path, counter):
+    acc = defaultdict(list)
+    with open(path, newline="") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != counter:
+                continue
+            name = row["Kernel_Name"]
+            name = name.split("(")[0].replace("sora::", "").replace("void ", "").strip()
+            acc[name].append(float(row["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch = per_kernel(sys.argv[1], "FETCH_SIZE")
+    write = per_kernel(sys.argv[2], "WRITE_SIZE")
+    frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
+    out = {"unit": "bytes per launch", "frames_per_launch": frames,
+           "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024 as reported",
+           "kernels": {}}
+    total = 0.0
+    for k in sorted(set(fetch) | set(write)):
+        if not k.startswith("k_"):
+            continue
+        fb = fetch.get(k, (0.0, 0))[0] * 1024 * 2
+        wb = write.get(k, (0.0, 0))[0] * 1024
+        out["kernels"][k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb),
+                             "launches_sampled": fetch.get(k, (0.0, 0))[1]}
+        total += fb + wb
+    out["total_hbm_bytes_per_call"] = round(total)
+    out["algorithmic_bytes_per_call"] = round(frames * 4880 * 4.3375)
+    json.dump(out, sys.stdout, indent=1)
+    print()
+
+
+if __name__ == "__main__":
+    main()
