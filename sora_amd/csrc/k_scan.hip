@@ -71,6 +71,8 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
     uint32_t h[16];                          // sample_his in TIME ORDER (oldest first): 4 bursts of 4 packed samples, already >>2
+    uint32_t Hv = 0;                         // the same 16 samples one per lane (lane & 15), used by the idle fast path
+    bool h_cur = true, hv_cur = true;        // which of the two representations is up to date
     Acc4 ac_re, ac_im, energy;
     uint32_t auto_count = 0, sense_count = 0, high_count = 0; int sync_high = 0, peak_corr = 0, peak_index = 0;
     uint32_t dc_cnt = 8; int sum_dc_re = 0, sum_dc_im = 0;            // TDCEstimator (dc.hpp:92-166); all 4 lanes of the vcs are equal
@@ -87,6 +89,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     auto cs_reset = [&]() {
 #pragma unroll
         for (int a = 0; a < 16; a++) h[a] = 0;
+        Hv = 0; h_cur = hv_cur = true;
         acc_clear(ac_re); acc_clear(ac_im); acc_clear(energy);
         auto_count = sense_count = high_count = 0; sync_high = 0; peak_corr = 0; peak_index = 0;
         dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
@@ -134,13 +137,86 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     };
 
     uint32_t vpos = 0;                              // next burst start, in queue units
+    // ---- idle fast path.  While no carrier is in sight (energy/auto-correlation test false, cca.hpp:386-437) a burst only
+    // feeds the sliding sums, the history, the DC estimator and the time-out counter.  Up to 4 bursts are then taken at
+    // once, one sample per lane (lane = 4 b + e): the per-sample products run once instead of per burst per lane, the
+    // per-burst bookkeeping (12 sliding-sum updates, the test, counters) stays scalar.  The group never crosses a source
+    // call (error_code is examined there) nor a DC update (the estimate changes what the next burst sees), and stops in
+    // front of the first burst whose test is true -- that burst goes through the full path below.
+    auto fast_idle = [&](uint32_t K) -> uint32_t {
+        if (!hv_cur) {                                                          // history: registers -> one sample per lane
+            const int l = lane & 15;
+            uint32_t v = h[0];
+#pragma unroll
+            for (int a = 1; a < 16; a++) v = l == a ? h[a] : v;
+            Hv = v; hv_cur = true;
+        }
+        if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) {      // stage the next 64 units (one coalesced load)
+            win_base = vpos;
+            win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
+        }
+        const uint32_t l = (uint32_t)lane & 15u;
+        const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
+        const cpx x = unpack(raw);
+        const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));                // TDCRemoveEx
+        const cpx pii = sra(pi, 2);
+        int re, im; conj_mul32(pii, unpack(Hv), re, im);                        // against the sample 16 earlier
+        unsigned vr = (unsigned)(re >> 4), vi = (unsigned)(im >> 4), ve = (unsigned)(sqnorm(pii) >> 4);
+        unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);     // TDCEstimator terms
+        vr += (unsigned)__shfl_xor((int)vr, 1); vi += (unsigned)__shfl_xor((int)vi, 1); ve += (unsigned)__shfl_xor((int)ve, 1);
+        dr += (unsigned)__shfl_xor((int)dr, 1); di += (unsigned)__shfl_xor((int)di, 1);
+        vr += (unsigned)__shfl_xor((int)vr, 2); vi += (unsigned)__shfl_xor((int)vi, 2); ve += (unsigned)__shfl_xor((int)ve, 2);
+        dr += (unsigned)__shfl_xor((int)dr, 2); di += (unsigned)__shfl_xor((int)di, 2);
+        uint32_t done = 0;
+#pragma unroll
+        for (int b = 0; b < 4; b++) {
+            if ((uint32_t)b < K && done == (uint32_t)b) {
+                const int sr = __builtin_amdgcn_readlane((int)vr, 4 * b), si = __builtin_amdgcn_readlane((int)vi, 4 * b), se = __builtin_amdgcn_readlane((int)ve, 4 * b);
+                Acc4 tr_ = ac_re, ti_ = ac_im, te_ = energy;
+                acc_push(tr_, sr); acc_push(ti_, si); acc_push(te_, se);
+                const int iAuto = abs(tr_.reg) + abs(ti_.reg), iEnergy = te_.reg;
+                if (!(iEnergy > (int)A.thr && iAuto >= iEnergy - (iEnergy >> 3))) {
+                    ac_re = tr_; ac_im = ti_; energy = te_;
+                    auto_count = 0; sense_count += 4;
+                    sum_dc_re = w16(sum_dc_re + w16(__builtin_amdgcn_readlane((int)dr, 4 * b)));
+                    sum_dc_im = w16(sum_dc_im + w16(__builtin_amdgcn_readlane((int)di, 4 * b)));
+                    if (dc_cnt == 0) {
+                        dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
+                        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
+                    }
+                    dc_cnt--;
+                    if (sense_count >= 84) error_code = E_CS_TIMEOUT;           // cca.hpp:433-437
+                    done++;
+                }
+            }
+        }
+        if (done) {                                                             // history <- its last 16 samples
+            const uint32_t src = ((uint32_t)lane & 48u) | ((l + 4u * done) & 15u);
+            const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)src), fresh = (uint32_t)__shfl((int)pack(pii), (int)src);
+            Hv = (l + 4u * done < 16u) ? keep : fresh;
+            h_cur = false;
+            vpos += done * BUR;
+        }
+        return done;
+    };
+
     const uint32_t nchunks = nunits / APP;
     for (uint32_t c = 0; c < nchunks && nfr < A.max_frames; c++) {
         const uint32_t avail_end = (c + 1) * APP;
         while (vpos + BUR <= avail_end) {
+            if (!cca_detected && !sync_high && auto_count == 0) {
+                const uint32_t K = min(min((avail_end - vpos) / BUR, dc_cnt + 1u), 4u);
+                if (fast_idle(K)) continue;
+            }
             const uint32_t pos20 = vpos / STR;
             if (!cca_detected) {
                 PROBE_T0();
+                if (!h_cur) {                                                   // history: one sample per lane -> registers
+#pragma unroll
+                    for (int a = 0; a < 16; a++) h[a] = (uint32_t)__builtin_amdgcn_readlane((int)Hv, a);
+                    h_cur = true;
+                }
+                hv_cur = false;
                 // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
                 uint32_t raw[4]; cpx pi[4];
 #pragma unroll
