@@ -237,7 +237,7 @@ struct VitLane {
     unsigned U;              // (field B << 16) | field A; field = u << 9 | marks of the current 8-step block
     unsigned MX[24];         // soft mask (+ mark, + complement for own-is-candidate-1 lanes) of the mark-carrying operand, per t mod 24
     unsigned MY[6];          // soft mask of the second operand of a two-input step, per t mod 6
-    uint32_t* ring;          // LDS: [kRingBlocks][64] the U word (marks of both frames) at the block's end, indexed by rev6(state)
+    uint16_t* ring;          // LDS: [kRingBlocks][64] {frame A's block, frame B's block} (one byte each) at the block's end, indexed by rev6(state)
     unsigned roff;           // slot of the block being filled, in words: (block index % kRingBlocks) * 64   (wave-uniform)
     unsigned sidx[3];        // ring index of the state this lane holds at the end of block j, by j % 3: rev6(rol6^(8j+8)(lane))
 };
@@ -266,7 +266,8 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     }
     V.U = pk_min16(pk_add16(X, bm), pk_add16(Y, bo));
     if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
-        V.ring[V.roff + V.sidx[t24 / 8]] = V.U;                                 // one ds_write_b32: byte 0 = frame A's block, byte 2 = frame B's
+        uint8_t* e = reinterpret_cast<uint8_t*>(V.ring + V.roff + V.sidx[t24 / 8]);
+        e[0] = (uint8_t)V.U; e[1] = (uint8_t)(V.U >> 16);                       // ds_write_b8 + ds_write_b8_d16_hi: frame A's block, frame B's block
         V.roff = V.roff + 64 == kRingBlocks * 64 ? 0u : V.roff + 64;
         V.U &= 0xFE00FE00u;
     }
@@ -279,7 +280,7 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
 // block just read.  All blocks the walk can touch (<= 38) are first fetched into registers, lane = ring index, with
 // independent LDS reads; the walk itself is then v_readlane + two scalar ops per block and frame, no memory latency.
 // Kept out of line: it is reached from every puncture group of the slow path.
-__device__ __noinline__ void viterbi_trace(unsigned U, const uint32_t* ring, uint32_t tr_, uint32_t ob_, unsigned mA, unsigned mB,
+__device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uint32_t tr_, uint32_t ob_, unsigned mA, unsigned mB,
                                            uint32_t cntA_, uint32_t cntB_, uint8_t* outA, uint8_t* outB)
 {
     constexpr int kMaxWalk = 38;
@@ -312,7 +313,7 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint32_t* ring, uin
     unsigned HA, HB;
     if (n == 8) {
         HA = (unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stA)) & 0xFFu;
-        HB = ((unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stB)) >> 16) & 0xFFu;
+        HB = ((unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stB)) >> 8) & 0xFFu;
     } else { HA = pA & ((1u << n) - 1u); HB = pB & ((1u << n) - 1u); }
     unsigned qA = rev6(((stA >> n) | rev6(HA & 0x3Fu)) & 0x3Fu), qB = rev6(((stB >> n) | rev6(HB & 0x3Fu)) & 0x3Fu);   // ring index at column 8j
     unsigned hvA = 0, hvB = 0;                                                  // lane i <- decisions of block m_lo + i
@@ -321,7 +322,7 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint32_t* ring, uin
     for (int i = 1; i < kMaxWalk; i++) {
         if (i <= nblk) {
             HA = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qA) & 0xFFu;          qA = HA & 0x3Fu;
-            HB = ((unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB) >> 16) & 0xFFu;  qB = HB & 0x3Fu;
+            HB = ((unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB) >> 8) & 0xFFu;   qB = HB & 0x3Fu;
             writelane(hvA, HA, (unsigned)(nblk - i)); writelane(hvB, HB, (unsigned)(nblk - i));
         }
     }
@@ -347,7 +348,7 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
 // decision at column i + 7 on the traced path (6-bit decoder delay), so output byte m is (block m >> 6) | (block m+1
 // & 0x3F) << 2.
 template <int CR>
-__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint32_t* ring)
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring)
 {
     constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
     constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
@@ -391,8 +392,10 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     auto check = [&](int t24_last) {                                            // trace-back schedule (viterbi.hpp:196-214), per frame
         if (tr >= next_thr) {
             const int k = t24_last % 8;                                         // the last decision: mark k of the field, or bit 7 of the block just banked
-            const unsigned last = k == 7 ? ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]] >> 7 : V.U >> k;
-            const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | (last & 1u), mB = (V.U >> 25 << 1) | ((last >> 16) & 1u);
+            unsigned lastA, lastB;
+            if (k == 7) { const unsigned w = ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
+            else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (16 + k)) & 1u; }
+            const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
             const bool partial = tr >= ob + 256u + 24u + 6u;
             uint32_t cntA = 0, cntB = 0;
             if (!A.done) {
@@ -417,11 +420,10 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         for (int i = 0; i < CW; i++) { K.a[i] = pa[i]; K.b[i] = pb[i]; }
         return K;
     };
-    auto sv = [](const Chunk& K, int k) -> unsigned {                           // soft value k of the chunk, frames A | B
-        unsigned r;
-        if (k & 1) asm("s_pack_hh_b32_b16 %0, %1, %2" : "=s"(r) : "s"(K.a[k >> 1]), "s"(K.b[k >> 1]));
-        else       asm("s_pack_ll_b32_b16 %0, %1, %2" : "=s"(r) : "s"(K.a[k >> 1]), "s"(K.b[k >> 1]));
-        return r;
+    auto sv = [](const Chunk& K, int k) -> unsigned {                           // soft value k of the chunk, frames A | B: s_pack_ll/hh_b32_b16
+        const uint32_t a = K.a[k >> 1], b = K.b[k >> 1];
+        const u16x2_t v = (k & 1) ? u16x2_t{(unsigned short)(a >> 16), (unsigned short)(b >> 16)} : u16x2_t{(unsigned short)a, (unsigned short)b};
+        return __builtin_bit_cast(unsigned, v);
     };
     // one puncture group = GS steps; i0 = step index inside the 12-step chunk, h = which half of the 24-step row
     auto group = [&](const Chunk& K, int h, int i0) {
@@ -431,22 +433,23 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         if (CR == 2) acs_step<2>(V, t24 + 2, 0, sv(K, k0 + 3));                 // ACS(B)     3/4
         if ((t24 + GS) % 8 == 0) normalize();                                   // (trellis index & 7) == 0 after a group
     };
-    auto chunk = [&](const Chunk& K, int h) {                                   // up to 12 steps; tr % 24 == 12 h on entry
-        if (tr + 12 <= nsteps && next_thr > tr + 12) {
-            // fast path: no trace-back due inside the chunk -- straight-line code, no per-group tests
+    auto fast_chunk = [&](const Chunk& K, int h) {                              // 12 steps, no trace-back due inside: straight-line code
 #pragma unroll
-            for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
-            tr += 12;
-        } else {
+        for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
+        tr += 12;
+    };
+    auto slow_chunk = [&](const Chunk& K, int h) {                              // up to 12 steps with the schedule examined after every group
 #pragma unroll
-            for (int g = 0; g < 12 / GS; g++) {
-                if (tr < nsteps && !(A.done && B.done)) {
-                    group(K, h, g * GS);
-                    tr += GS;
-                    check(12 * h + g * GS + GS - 1);
-                }
+        for (int g = 0; g < 12 / GS; g++) {
+            if (tr < nsteps && !(A.done && B.done)) {
+                group(K, h, g * GS);
+                tr += GS;
+                check(12 * h + g * GS + GS - 1);
             }
         }
+    };
+    auto chunk = [&](const Chunk& K, int h) {                                   // tr % 24 == 12 h on entry
+        if (tr + 12 <= nsteps && next_thr > tr + 12) fast_chunk(K, h); else slow_chunk(K, h);
     };
 
     // Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0), and the compiler puts it at the
@@ -456,6 +459,16 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     uint32_t c = 0;
     Chunk cur = load_chunk(0, 0);
     while (tr < nsteps && !(A.done && B.done)) {
+        // rows (2 chunks) that certainly need no look at the schedule: run them back to back, 9 rows out of 10
+        const uint32_t lim = min(nsteps, next_thr - 1);
+        for (uint32_t rows = lim > tr ? (lim - tr) / 24 : 0; rows > 0; rows--) {
+            Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
+            fast_chunk(cur, 0);
+            cur = load_chunk(c + 2, (nxt.a[0] | nxt.b[0]) & 1u);
+            fast_chunk(nxt, 1);
+            c += 2;
+        }
+        if (!(tr < nsteps)) break;
         Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
         chunk(cur, 0);
         if (!(tr < nsteps && !(A.done && B.done))) break;
@@ -470,12 +483,12 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 // Frames are paired in job order when their code rates agree; otherwise each runs alone in the low half.
 __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs_ptr, uint32_t njobs_max, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
-    __shared__ uint32_t s_ring[4][kRingBlocks * 64];                             // 48 KB: survivor history of the last 384 columns, per wave
+    __shared__ uint16_t s_ring[4][kRingBlocks * 64];                             // 24 KB: survivor history of the last 384 columns, per wave
     const uint32_t njobs = njobs_ptr ? *njobs_ptr : njobs_max;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
     const uint32_t fa = uni((blockIdx.x * 4 + (threadIdx.x >> 6)) * 2), fb = fa + 1;
     if (fa >= njobs) return;
-    uint32_t* ring = s_ring[threadIdx.x >> 6];
+    uint16_t* ring = s_ring[threadIdx.x >> 6];
     auto load_job = [&](uint32_t f) {
         const VitJob& G = jobs[f];
         VitJob J;
