@@ -68,6 +68,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     __shared__ uint32_t s_fft[64];
     __shared__ uint32_t s_x[144];
     __shared__ uint8_t  s_soft[48];
+    __shared__ uint64_t s_dec[25];                   // Viterbi_sig11 decision words (wave-uniform ballots)
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
     uint32_t h[16];                          // sample_his in TIME ORDER (oldest first): 4 bursts of 4 packed samples, already >>2
@@ -397,8 +398,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                         const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
                         const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
                         unsigned m = (n == 0) ? 0u : 0x30u;
-                        uint64_t dec[25];
-                        dec[0] = 0;
+                        if (lane == 0) s_dec[0] = 0;
 #pragma unroll
                         for (int t = 1; t <= 24; t++) {
                             const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
@@ -407,7 +407,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                             const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
                             const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
                             m = min(c0, c1);
-                            dec[t] = __ballot(m & 1);
+                            { const uint64_t d = __ballot(m & 1); if (lane == 0) s_dec[t] = d; }
                             if ((t & 7) == 0) {
                                 unsigned mn = m;
 #pragma unroll
@@ -420,13 +420,14 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
                         int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+                        sync();                                                     // s_dec complete
                         uint32_t sig = 0;
 #pragma unroll
                         for (int b = 0; b < 24; b++) {
                             // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
                             sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
                             pos = (pos >> 1) & 0x3F;
-                            pos |= (int)((dec[23 - b] >> pos) & 1) << 6;
+                            pos |= (int)((s_dec[23 - b] >> pos) & 1) << 6;
                         }
                         sig >>= 6;                                                  // viterbi.hpp:39
                         // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
