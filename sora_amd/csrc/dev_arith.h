@@ -70,6 +70,7 @@ struct Tables {
     const uint32_t* tw128;       // [3][32] packed W128^{k j}
     const uint32_t* tw32;        // [3][8]  packed W32^{k j}
     const uint32_t* tw8;         // [4]     {W8^0, W8^1, W8^0, W8^3} (fft_lut_twiddle.h:61575-61581)
+    const uint32_t* crcz;        // [6][8][16] CRC-32 register after 40 * 2^k zero bytes, per nibble of the start value (parallel CRC)
 };
 
 // uatan2 (core/inc/intalg.h:100-113): highest set bit of |y|,|x| -> common shift -> 256x256 LUT

@@ -35,7 +35,7 @@ struct HostTables {
     std::vector<uint32_t> tw64, tw16, sts, crc, tw128, tw32, tw8;
     std::vector<uint16_t> deint;
     std::vector<uint8_t> scr, scr_seq, scr_phase;
-    std::vector<uint32_t> crc8;
+    std::vector<uint32_t> crc8, crcz;
 };
 
 static inline uint32_t pk(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
@@ -149,6 +149,16 @@ static void build_tables(HostTables& H)
         uint32_t c = H.crc[i]; H.crc8[i] = c;
         for (int k = 1; k < 8; k++) { c = (c >> 8) ^ H.crc[c & 0xFF]; H.crc8[k * 256 + i] = c; }
     }
+    // parallel CRC (k_finish): Z_m(x) = register x after m zero bytes is linear in x, so it is the xor of 8 nibble look-ups;
+    // levels m = 40 * 2^k combine the 64 lanes' 40-byte segment CRCs in a tree
+    H.crcz.resize(6 * 8 * 16);
+    for (int k = 0; k < 6; k++)
+        for (int j = 0; j < 8; j++)
+            for (uint32_t v = 0; v < 16; v++) {
+                uint32_t c = v << (4 * j);
+                for (int z = 0; z < (40 << k); z++) c = (c >> 8) ^ H.crc[c & 0xFF];
+                H.crcz[(k * 8 + j) * 16 + v] = c;
+            }
     H.scr.resize(128);
     for (int i = 0; i < 128; i++) { uint8_t x = (uint8_t)(i << 1); for (int k = 0; k < 8; k++) { uint8_t o1 = ((x >> 1) ^ (x >> 4)) & 1; x = (uint8_t)((x >> 1) | (o1 << 7)); } H.scr[i] = x; }
     // The descrambler (scramble.hpp:319-349) walks reg -> scr[reg] -> reg>>1 ...: a period-127 cycle of 7-bit
@@ -209,6 +219,7 @@ static int make_dev_tables(DevTables& D)
     if ((rc = upload(D, H.tw128, (const void**)&D.T.tw128))) return rc;
     if ((rc = upload(D, H.tw32, (const void**)&D.T.tw32))) return rc;
     if ((rc = upload(D, H.tw8, (const void**)&D.T.tw8))) return rc;
+    if ((rc = upload(D, H.crcz, (const void**)&D.T.crcz))) return rc;
     return SORA_OK;
 }
 static void free_dev_tables(DevTables& D) { for (void* p : D.allocs) (void)hipFree(p); D.allocs.clear(); }
