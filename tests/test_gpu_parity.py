@@ -133,6 +133,17 @@ def test_20mhz_input(sora, torch_cuda, oracle):
     assert all(r["error_code"] == E_FRAME_OK for r in got) and len(got) == 8
 
 
+def test_short_mpdus_crc_paths(sora, torch_cuda, oracle):
+    """Payloads around the limits of the parallel CRC (serial below 4 bytes, 40-byte lane segments, ragged first segment)."""
+    lens = [2, 3, 4, 5, 7, 8, 35, 36, 37, 39, 40, 41, 76, 80, 81, 119]
+    caps = [make_capture(oracle, [12000, 54000][i % 2], L, seed=900 + i, rate_mhz=20, sigma=60, tail=160)[0] for i, L in enumerate(lens)]
+    got = run_rx(sora, torch_cuda, caps, 20)
+    want = oracle_results(oracle, caps, 20)
+    ok, why = same_results(got, want)
+    assert ok, why
+    assert sum(r["error_code"] == E_FRAME_OK for r in got) == len(lens)
+
+
 def test_cfo_and_heavy_noise(sora, torch_cuda, oracle):
     caps = [make_capture(oracle, 24000, 400, seed=5, sigma=300, cfo_hz=40e3)[0],
             make_capture(oracle, 54000, 800, seed=6, sigma=900)[0],          # CRC failure expected
