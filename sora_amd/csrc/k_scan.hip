@@ -201,6 +201,58 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
         return done;
     };
 
+    // ---- the same for the phase between establish_sync and the end of the short training symbols (check_sync,
+    // cca.hpp:245-265): a burst only enters the history; every fourth one the history is correlated with the winning
+    // STS pattern.  Up to 4 bursts per pass, one sample per lane; the correlation runs one tap per lane.
+    auto fast_sync = [&](uint32_t K) {                                          // K = bursts taken (1..4), at most up to the next check
+        if (!hv_cur) {
+            const int l = lane & 15;
+            uint32_t v = h[0];
+#pragma unroll
+            for (int a = 1; a < 16; a++) v = l == a ? h[a] : v;
+            Hv = v; hv_cur = true;
+        }
+        if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) {
+            win_base = vpos;
+            win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
+        }
+        const uint32_t l = (uint32_t)lane & 15u;
+        const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
+        const cpx x = unpack(raw);
+        const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));
+        const uint32_t src = ((uint32_t)lane & 48u) | ((l + 4u * K) & 15u);
+        const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)src), fresh = (uint32_t)__shfl((int)pack(sra(pi, 2)), (int)src);
+        Hv = (l + 4u * K < 16u) ? keep : fresh;
+        h_cur = false;
+        const uint32_t last_v = vpos + (K - 1u) * BUR;                          // the burst that may carry the check
+        vpos += K * BUR;
+        high_count += K;
+        if (high_count % 4 == 0) {
+            int re, im; conj_mul32(unpack(T.sts[peak_index * 16 + (int)l]), unpack(Hv), re, im);   // GetCrossCorrelation, one tap per lane
+            unsigned ur = (unsigned)re, ui = (unsigned)im;
+#pragma unroll
+            for (int o = 1; o < 16; o <<= 1) { ur += (unsigned)__shfl_xor((int)ur, o); ui += (unsigned)__shfl_xor((int)ui, o); }
+            const int corr = abs(__builtin_amdgcn_readfirstlane((int)ur)) + abs(__builtin_amdgcn_readfirstlane((int)ui));
+            if (corr < (peak_corr >> 1)) {
+                if (high_count > 8) { cca_detected = 1; frame_start = last_v / STR + 4; }
+                else {
+                    sync_high = 0; sense_count = 0;
+                    // the burst that dropped the lock also feeds TDCEstimator (dc.hpp:92-166)
+                    unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);
+                    dr += (unsigned)__shfl_xor((int)dr, 1); di += (unsigned)__shfl_xor((int)di, 1);
+                    dr += (unsigned)__shfl_xor((int)dr, 2); di += (unsigned)__shfl_xor((int)di, 2);
+                    sum_dc_re = w16(sum_dc_re + w16(__builtin_amdgcn_readlane((int)dr, (int)(4 * (K - 1)))));
+                    sum_dc_im = w16(sum_dc_im + w16(__builtin_amdgcn_readlane((int)di, (int)(4 * (K - 1)))));
+                    if (dc_cnt == 0) {
+                        dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
+                        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
+                    }
+                    dc_cnt--;
+                }
+            } else if (corr > peak_corr) peak_corr = corr;
+        }
+    };
+
     const uint32_t nchunks = nunits / APP;
     for (uint32_t c = 0; c < nchunks && nfr < A.max_frames; c++) {
         const uint32_t avail_end = (c + 1) * APP;
@@ -208,6 +260,10 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
             if (!cca_detected && !sync_high && auto_count == 0) {
                 const uint32_t K = min(min((avail_end - vpos) / BUR, dc_cnt + 1u), 4u);
                 if (fast_idle(K)) continue;
+            }
+            if (!cca_detected && sync_high) {
+                fast_sync(min((avail_end - vpos) / BUR, 4u - high_count % 4u));
+                continue;
             }
             const uint32_t pos20 = vpos / STR;
             if (!cca_detected) {
@@ -259,21 +315,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                         }
                     } else {
                         auto_count = 0;
-                    }
-                } else {
-                    { cpx q[4];
-#pragma unroll
-                      for (int e = 0; e < 4; e++) q[e] = sra(pi[e], 2);
-                      his_push(q); }
-                    high_count++;
-                    if (high_count % 4 == 0) {
-                        int corr = cross_corr(peak_index);                        // check_sync (cca.hpp:245-265)
-                        bool ok;
-                        if (corr < (peak_corr >> 1)) ok = false; else { if (corr > peak_corr) peak_corr = corr; ok = true; }
-                        if (!ok) {
-                            if (high_count > 8) { cca_detected = 1; frame_start = pos20 + 4; }
-                            else { sync_high = 0; sense_count = 0; }
-                        }
                     }
                 }
                 if (!sync_high) {
