@@ -71,9 +71,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     __shared__ uint64_t s_dec[25];                   // Viterbi_sig11 decision words (wave-uniform ballots)
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
-    uint32_t h[16];                          // sample_his in TIME ORDER (oldest first): 4 bursts of 4 packed samples, already >>2
-    uint32_t Hv = 0;                         // the same 16 samples one per lane (lane & 15), used by the idle fast path
-    bool h_cur = true, hv_cur = true;        // which of the two representations is up to date
+    uint32_t Hv = 0;                         // sample_his in TIME ORDER, one packed sample per lane (lane & 15, oldest = 0): 4 bursts of 4, already >>2
     Acc4 ac_re, ac_im, energy;
     uint32_t auto_count = 0, sense_count = 0, high_count = 0; int sync_high = 0, peak_corr = 0, peak_index = 0;
     uint32_t dc_cnt = 8; int sum_dc_re = 0, sum_dc_im = 0;            // TDCEstimator (dc.hpp:92-166); all 4 lanes of the vcs are equal
@@ -88,9 +86,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     int r_cfo = 0, r_cfo_comp = 0, r_sfo_comp = 0, r_cfo_tr = 0, r_sfo_tr = 0;
 
     auto cs_reset = [&]() {
-#pragma unroll
-        for (int a = 0; a < 16; a++) h[a] = 0;
-        Hv = 0; h_cur = hv_cur = true;
+        Hv = 0;
         acc_clear(ac_re); acc_clear(ac_im); acc_clear(energy);
         auto_count = sense_count = high_count = 0; sync_high = 0; peak_corr = 0; peak_index = 0;
         dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
@@ -110,7 +106,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
         for (int v = 0; v < 4; v++) {
 #pragma unroll
             for (int e = 0; e < 4; e++) {
-                int re, im; conj_mul32(unpack(T.sts[p * 16 + 4 * v + e]), unpack(h[4 * v + e]), re, im);
+                int re, im; conj_mul32(unpack(T.sts[p * 16 + 4 * v + e]), unpack((uint32_t)__builtin_amdgcn_readlane((int)Hv, 4 * v + e)), re, im);
                 sre[e] = (int)((unsigned)sre[e] + (unsigned)re); sim[e] = (int)((unsigned)sim[e] + (unsigned)im);
             }
         }
@@ -118,11 +114,11 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
         int i = (int)((unsigned)sim[0] + (unsigned)sim[1] + (unsigned)sim[2] + (unsigned)sim[3]);
         return abs(r) + abs(i);
     };
-    auto his_push = [&](const cpx (&v)[4]) {
-#pragma unroll
-        for (int a = 0; a < 12; a++) h[a] = h[a + 4];
-#pragma unroll
-        for (int e = 0; e < 4; e++) h[12 + e] = pack(v[e]);
+    auto his_push = [&](const cpx (&v)[4]) {                                    // drop the oldest burst, append v (wave-uniform values)
+        const uint32_t l = (uint32_t)lane & 15u;
+        const uint32_t fresh = (l & 3u) == 0 ? pack(v[0]) : (l & 3u) == 1 ? pack(v[1]) : (l & 3u) == 2 ? pack(v[2]) : pack(v[3]);
+        const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)(((uint32_t)lane & 48u) | ((l + 4u) & 15u)));
+        Hv = l < 12u ? keep : fresh;
     };
 
     // Carrier sense reads the stream 4 samples at a time, wave-uniformly: stage 64 consecutive units per
@@ -145,13 +141,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     // call (error_code is examined there) nor a DC update (the estimate changes what the next burst sees), and stops in
     // front of the first burst whose test is true -- that burst goes through the full path below.
     auto fast_idle = [&](uint32_t K) -> uint32_t {
-        if (!hv_cur) {                                                          // history: registers -> one sample per lane
-            const int l = lane & 15;
-            uint32_t v = h[0];
-#pragma unroll
-            for (int a = 1; a < 16; a++) v = l == a ? h[a] : v;
-            Hv = v; hv_cur = true;
-        }
         if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) {      // stage the next 64 units (one coalesced load)
             win_base = vpos;
             win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
@@ -195,7 +184,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
             const uint32_t src = ((uint32_t)lane & 48u) | ((l + 4u * done) & 15u);
             const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)src), fresh = (uint32_t)__shfl((int)pack(pii), (int)src);
             Hv = (l + 4u * done < 16u) ? keep : fresh;
-            h_cur = false;
             vpos += done * BUR;
         }
         return done;
@@ -205,13 +193,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
     // cca.hpp:245-265): a burst only enters the history; every fourth one the history is correlated with the winning
     // STS pattern.  Up to 4 bursts per pass, one sample per lane; the correlation runs one tap per lane.
     auto fast_sync = [&](uint32_t K) {                                          // K = bursts taken (1..4), at most up to the next check
-        if (!hv_cur) {
-            const int l = lane & 15;
-            uint32_t v = h[0];
-#pragma unroll
-            for (int a = 1; a < 16; a++) v = l == a ? h[a] : v;
-            Hv = v; hv_cur = true;
-        }
         if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) {
             win_base = vpos;
             win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
@@ -223,7 +204,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
         const uint32_t src = ((uint32_t)lane & 48u) | ((l + 4u * K) & 15u);
         const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)src), fresh = (uint32_t)__shfl((int)pack(sra(pi, 2)), (int)src);
         Hv = (l + 4u * K < 16u) ? keep : fresh;
-        h_cur = false;
         const uint32_t last_v = vpos + (K - 1u) * BUR;                          // the burst that may carry the check
         vpos += K * BUR;
         high_count += K;
@@ -268,12 +248,6 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
             const uint32_t pos20 = vpos / STR;
             if (!cca_detected) {
                 PROBE_T0();
-                if (!h_cur) {                                                   // history: one sample per lane -> registers
-#pragma unroll
-                    for (int a = 0; a < 16; a++) h[a] = (uint32_t)__builtin_amdgcn_readlane((int)Hv, a);
-                    h_cur = true;
-                }
-                hv_cur = false;
                 // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
                 uint32_t raw[4]; cpx pi[4];
 #pragma unroll
@@ -285,7 +259,7 @@ __global__ void __launch_bounds__(64) k_scan(ScanArgs A)
                     int sr = 0, si = 0, se = 0;
 #pragma unroll
                     for (int e = 0; e < 4; e++) {
-                        int re, im; conj_mul32(pii[e], unpack(h[e]), re, im);                 // sample_his.First(): 16 samples ago
+                        int re, im; conj_mul32(pii[e], unpack((uint32_t)__builtin_amdgcn_readlane((int)Hv, e)), re, im);   // sample_his.First(): 16 samples ago
                         sr = (int)((unsigned)sr + (unsigned)(re >> 4)); si = (int)((unsigned)si + (unsigned)(im >> 4));
                         se = (int)((unsigned)se + (unsigned)(sqnorm(pii[e]) >> 4));
                     }
