@@ -55,7 +55,7 @@ __device__ __forceinline__ int carrier_bin(int k)
     int b = 1 + (k - 24); if (b >= 7) b++; if (b >= 21) b++; return b;
 }
 
-__global__ void __launch_bounds__(64) k_scan(ScanArgs A)
+__global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
 {
     const uint32_t cap_i = blockIdx.x;
     if (cap_i >= A.ncaps) return;
