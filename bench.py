@@ -85,6 +85,27 @@ def cpu_baseline(oracle, iq, nframes, budget_s=12.0):
             "frames_ok": ok}
 
 
+def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
+    """Row f3 (capture ingest): a 44 MHz RX_BLOCK dump resident in HBM -> de-framed, sign-fixed, resampled 40 MHz stream.
+    A pure streaming kernel: algorithmic bytes = dump bytes read + samples written, against the HBM roofline."""
+    flags = sora_amd.INGEST_RXBLOCK | sora_amd.INGEST_RAW14 | sora_amd.INGEST_44TO40
+    raw = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev)
+    n_out = sora_amd.ingest_count(nbytes, flags)
+    for _ in range(3):
+        out = sora_amd.ingest(raw, flags, sync=False)
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps):
+        out = sora_amd.ingest(raw, flags, sync=False)
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    alg = nbytes + 4 * n_out
+    del raw, out
+    return {"workload": "%d MiB Sora RX_BLOCK dump @44 MHz -> de-frame + 14->16 bit + 44->40 MHz (%d samples out)" % (nbytes >> 20, n_out),
+            "bound": "hbm", "ms": round(ms, 4), "algorithmic_bytes": alg, "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -206,6 +227,8 @@ def main():
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         }
+        if world == 1:
+            out["ingest"] = bench_ingest(torch, sora_amd, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(oracle, iq, nfr)
         print(json.dumps(out))

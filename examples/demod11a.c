@@ -3,7 +3,7 @@
  * Loads a Sora RX_BLOCK dump (kernel/brick/inc/brickutil.h:20-58: 16-byte descriptor + 28 COMPLEX16 per 128-byte
  * block), hands it to the GPU receive path as ONE capture and prints what RxThread would have reported.
  * Build: gcc -std=c11 -Iinclude examples/demod11a.c -Lsora_amd/lib -lsora_hip -Wl,-rpath,$PWD/sora_amd/lib -o demod11a
- * Usage: demod11a <file.dmp> [--raw14] [--rate 40|20] [--out mpdu.bin]
+ * Usage: demod11a <file.dmp> [--raw14] [--rate 44|40|20] [--out mpdu.bin]     (--rate = sampling rate of the dump)
  */
 #include <stdint.h>
 #include <stdio.h>
@@ -11,28 +11,20 @@
 #include <string.h>
 #include "sora_hip.h"
 
-static long load_dump(const char* path, sora_complex16** out, int raw14)
+/* The dump goes to the GPU as it is on disk; de-framing, the sign fix, the optional 44 -> 40 MHz resampler and the
+ * optional /2 decimation run there (sora_hip_ingest).  Returns the raw bytes (malloc'd). */
+static long load_file(const char* path, unsigned char** out)
 {
     FILE* f = fopen(path, "rb");
     if (!f) return -2;                                   /* BK_ERROR_FILE_NOT_FOUND */
     fseek(f, 0, SEEK_END);
     long bytes = ftell(f);
     fseek(f, 0, SEEK_SET);
-    long nblk = bytes / 128, n = 0;
-    sora_complex16* iq = (sora_complex16*)malloc((size_t)(nblk * 28 + 28) * sizeof(sora_complex16));
-    unsigned char blk[128];
-    while (fread(blk, 1, 128, f) == 128) {
-        memcpy(iq + n, blk + 16, 28 * sizeof(sora_complex16));
-        if (raw14)                                       /* 14-bit two's complement, zero-extended */
-            for (int i = 0; i < 28; i++) {
-                iq[n + i].re = (int16_t)(uint16_t)((uint16_t)iq[n + i].re << 2);
-                iq[n + i].im = (int16_t)(uint16_t)((uint16_t)iq[n + i].im << 2);
-            }
-        n += 28;
-    }
+    unsigned char* buf = (unsigned char*)malloc((size_t)bytes + 16);
+    if (!buf || fread(buf, 1, (size_t)bytes, f) != (size_t)bytes) { fclose(f); free(buf); return -1; }
     fclose(f);
-    *out = iq;
-    return n;
+    *out = buf;
+    return bytes;
 }
 
 int main(int argc, char** argv)
@@ -44,21 +36,33 @@ int main(int argc, char** argv)
         else if (!strcmp(argv[i], "--out") && i + 1 < argc) outp = argv[++i];
         else path = argv[i];
     }
-    if (!path) { fprintf(stderr, "usage: %s <file.dmp> [--raw14] [--rate 40|20] [--out mpdu.bin]\n", argv[0]); return 2; }
-    sora_complex16* iq = NULL;
-    long n = load_dump(path, &iq, raw14);
-    if (n <= 0) { fprintf(stderr, "Failed to load input file.\n"); return 1; }
-    printf("Demodulate 11a on MI355X: %ld samples @%u MHz\n", n, rate);
+    if (!path) { fprintf(stderr, "usage: %s <file.dmp> [--raw14] [--rate 44|40|20] [--out mpdu.bin]\n", argv[0]); return 2; }
+    unsigned char* file = NULL;
+    long bytes = load_file(path, &file);
+    if (bytes <= 0) { fprintf(stderr, "Failed to load input file.\n"); return 1; }
+    /* LoadSoraDumpFile + (TDownSample44_40) on the device */
+    unsigned flags = SORA_INGEST_RXBLOCK | (raw14 ? SORA_INGEST_RAW14 : 0u) | (rate == 44 ? SORA_INGEST_44TO40 : 0u);
+    if (rate == 44) rate = 40;
+    size_t n = sora_hip_ingest_count((size_t)bytes, flags);
+    n -= n % (rate == 40 ? 28 : 14);                     /* whole source bursts (memsource.hpp:87-114) */
+    void* d_file = sora_hip_malloc((size_t)bytes + 16);
+    sora_complex16* d_iq = (sora_complex16*)sora_hip_malloc((n + 64) * sizeof(sora_complex16));
+    if (!d_file || !d_iq || sora_hip_memcpy_h2d(d_file, file, (size_t)bytes) != SORA_OK) { fprintf(stderr, "device memory: %s\n", sora_hip_last_error()); return 1; }
+    size_t got = 0;
+    int rc = sora_hip_ingest(d_file, (size_t)bytes, flags, d_iq, n + 64, &got, NULL);
+    if (rc == SORA_OK) rc = sora_hip_stream_synchronize(NULL);   /* the handle's streams do not follow the null stream */
+    if (rc != SORA_OK || n == 0) { fprintf(stderr, "sora_hip_ingest: %d (%s)\n", rc, sora_hip_last_error()); return 1; }
+    printf("Demodulate 11a on MI355X: %zu samples @%u MHz\n", n, rate);
 
     sora_rx_cfg cfg; memset(&cfg, 0, sizeof(cfg));
     cfg.struct_size = sizeof(cfg); cfg.device = 0; cfg.sample_rate_mhz = rate; cfg.max_captures = 1;
     cfg.max_total_samples = (uint64_t)n; cfg.max_frames_per_capture = 64;
     sora_rx_t* rx = NULL;
-    int rc = sora_rx_create(&cfg, &rx);
+    rc = sora_rx_create(&cfg, &rx);
     if (rc != SORA_OK) { fprintf(stderr, "sora_rx_create: %d (%s)\n", rc, sora_hip_last_error()); return 1; }
     sora_capture_desc cap; cap.offset = 0; cap.nsamples = (uint32_t)n; cap.capture_id = 0;
-    rc = sora_rx_process(rx, iq, (size_t)n, &cap, 1);
-    if (rc != SORA_OK) { fprintf(stderr, "sora_rx_process: %d (%s)\n", rc, sora_hip_last_error()); return 1; }
+    rc = sora_rx_process_dev(rx, d_iq, &cap, 1);
+    if (rc != SORA_OK) { fprintf(stderr, "sora_rx_process_dev: %d (%s)\n", rc, sora_hip_last_error()); return 1; }
     sora_frame_result res[64]; size_t nres = 0;
     uint8_t* mpdu = (uint8_t*)malloc(64 * 2504);
     rc = sora_rx_results(rx, res, 64, &nres, mpdu, 64 * 2504);
@@ -77,6 +81,7 @@ int main(int argc, char** argv)
         if (fo) { fwrite(mpdu + res[0].mpdu_offset, 1, res[0].length, fo); fclose(fo); }
     }
     sora_rx_destroy(rx);
-    free(mpdu); free(iq);
+    sora_hip_free(d_file); sora_hip_free(d_iq);
+    free(mpdu); free(file);
     return 0;
 }

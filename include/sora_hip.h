@@ -151,6 +151,22 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
                         const uint16_t* d_frame_len, int code_rate, uint8_t* d_out, const uint32_t* d_out_off,
                         size_t n, void* stream);
 
+/* Capture ingest in front of the receive graph, one streaming pass on the device:
+ *   SORA_INGEST_RXBLOCK    the input is a Sora dump: 128-byte RX_BLOCKs = 16-byte descriptor + 28 COMPLEX16
+ *                          (LoadSoraDumpFile, kernel/brick/inc/brickutil.h:20-58; kernel/core/inc/_rx_manager.h:96-137)
+ *   SORA_INGEST_RAW14      samples are 14-bit two's complement, zero-extended: x = (int16)(raw << 2)
+ *   SORA_INGEST_44TO40     TDownSample44_40 / Down44to40 (Brick11/src/sampling.hpp:35-66, 44MTo40M.hpp:62-123)
+ *   SORA_INGEST_DECIMATE2  TDownSample2 (Brick11/src/samples.hpp:9-47): keep the even samples (40 -> 20 MHz)
+ * applied in that order.  d_raw: the dump bytes (or, without RXBLOCK, a COMPLEX16 stream) in device memory;
+ * sora_hip_ingest_count gives the number of samples the call writes (a function of the size and flags only). */
+#define SORA_INGEST_RXBLOCK   1u
+#define SORA_INGEST_RAW14     2u
+#define SORA_INGEST_44TO40    4u
+#define SORA_INGEST_DECIMATE2 8u
+size_t sora_hip_ingest_count(size_t raw_bytes, unsigned flags);
+int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_complex16* d_out, size_t out_capacity,
+                    size_t* n_out, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small device-memory helpers so a pure-C host needs no HIP headers.
  * ------------------------------------------------------------------------------------------------ */
@@ -159,6 +175,8 @@ void* sora_hip_malloc(size_t bytes);
 void  sora_hip_free(void* d_ptr);
 int   sora_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int   sora_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+/* wait for a stream (NULL = the null stream); the streams of a sora_rx_t do not follow the null stream */
+int   sora_hip_stream_synchronize(void* stream);
 int   sora_hip_abi_version(void);
 const char* sora_hip_last_error(void);
 

@@ -30,7 +30,8 @@ for f in complex.h fft_r4dif.h ifft_r4dif.h fft_lut_twiddle.h fft_lut_bitreversa
          operator_repeater.h tpltrick.h unroll.h; do
     cp "$CI/$f" "$TMP/$f"
 done
-for f in viterbicore.h viterbilut.h demapper.h; do cp "$BS/$f" "$TMP/$f"; done
+for f in viterbicore.h viterbilut.h demapper.h 44MTo40M.hpp; do cp "$BS/$f" "$TMP/$f"; done
+mkdir -p "$TMP/bb"; printf '#pragma once\n#include "const.h"\n' > "$TMP/bb/bba.h"      # 44MTo40M.hpp only needs the integer types from it
 sed -e '26,81d' "$CI/vector128.h" \
   | sed -e 's|#include <emmintrin.h>|#include <immintrin.h>|' \
         -e '/_mm_sign_epi64/d' -e '/_mm_abs_epi64/d' > "$TMP/vector128.h"
@@ -56,6 +57,9 @@ typedef unsigned short ushort, USHORT;
 typedef unsigned int   uint, UINT;
 typedef uint32_t       sora_ulong32, ULONG, *PULONG;   /* Windows LLP64: long is 32 bits */
 #define ulong sora_ulong32                              /* glibc already typedefs a 64-bit ulong */
+#define MEM_ALIGN(n) __declspec(align(n))
+#define SORA_RX_SIGNAL_UNIT_NUM_PER_DESC  7               /* _rx_manager.h:79-81: 7 x 16-byte units = 28 COMPLEX16 per RX_BLOCK */
+#define SORA_RX_SIGNAL_UNIT_COMPLEX16_NUM 4
 EOF
 cat > "$TMP/sora.h" <<'EOF'
 #pragma once

@@ -159,6 +159,15 @@ class Oracle:
         cap = (len(raw) // 128 + 1) * 28; iq = np.zeros((cap, 2), np.int16)
         n = self.L.so_load_dump(_P(raw), len(raw), _P(iq), cap, 1 if raw14 else 0); return iq[:n]
 
+    def down44to40(self, iq):
+        """TDownSample44_40 over whole 28-sample blocks (sampling.hpp:35-66, 44MTo40M.hpp:62-123)"""
+        a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2); o = np.zeros((len(a) + 28, 2), np.int16)
+        n = self.L.so_down44to40(_P(a), len(a), _P(o), len(o)); return o[:n]
+
+    def downsample2(self, iq):
+        a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2); o = np.zeros((len(a) // 2 + 4, 2), np.int16)
+        n = self.L.so_downsample2(_P(a), len(a), _P(o), len(o)); return o[:n]
+
     # ---- transmitter
     def tx(self, mpdu_nofcs, rate_kbps, seed=0xFF):
         """-> int8 [n,2] COMPLEX8 @40 MHz (what `demod11 -m` writes)."""
@@ -207,6 +216,11 @@ class Reference:
 
     def viterbi_sig(self, soft48):
         a = np.ascontiguousarray(soft48, np.uint8); return self.L.ref_viterbi_sig(_P(a))
+
+    def down44to40(self, iq):
+        """the reference's Down44to40 driven block by block as TDownSample44_40 does"""
+        a = np.ascontiguousarray(iq, np.int16).reshape(-1, 2); o = np.zeros((len(a) + 28, 2), np.int16)
+        n = self.L.ref_down44to40(_P(a), len(a) // 28, _P(o), len(o)); return o[:n]
 
     def viterbi_frame(self, soft, code_rate, frame_length):
         a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(frame_length + 64, np.uint8)

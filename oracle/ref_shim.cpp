@@ -21,6 +21,7 @@
 #include "CRC32.h"
 #include "viterbicore.h"
 #include "demapper.h"
+#include "44MTo40M.hpp"
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
 
@@ -130,4 +131,24 @@ EXPORT int ref_vit_decode_frame(void* h, const uint8_t* soft, uint32_t nsoft, in
         }
     }
     return nout;
+}
+
+// TDownSample44_40 (sampling.hpp:35-66) over the REFERENCE resampler (44MTo40M.hpp:62-123): feed whole 28-sample
+// RX blocks, collect the 28-sample output blocks exactly as the brick forwards them.  Returns samples written.
+EXPORT int ref_down44to40(const int16_t* in_iq, uint32_t nblocks, int16_t* out_iq, uint32_t max_out)
+{
+    Down44to40 r;
+    uint32_t n = 0;
+    for (uint32_t b = 0; b < nblocks; b++) {
+        SignalBlock blk;
+        memcpy(&blk, in_iq + (size_t)b * 56, 112);
+        r.Resample(blk);
+        COMPLEX16* p = r.GetOutStream(28);
+        if (p) {
+            if (n + 28 > max_out) break;
+            memcpy(out_iq + (size_t)n * 2, p, 112);
+            n += 28;
+        }
+    }
+    return (int)n;
 }

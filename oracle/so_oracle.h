@@ -103,6 +103,9 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
 
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */
 int so_load_dump(const uint8_t* file, uint32_t file_bytes, so_c16* out, uint32_t max_samples, int raw14);
+/* capture ingest (so_ingest.c): TDownSample44_40 / Down44to40 (sampling.hpp:35-66, 44MTo40M.hpp:62-123), TDownSample2 (samples.hpp:9-47) */
+int so_down44to40(const so_c16* in, uint32_t n_in, so_c16* out, uint32_t max_out);
+int so_downsample2(const so_c16* in, uint32_t n_in, so_c16* out, uint32_t max_out);
 
 /* ---- transmitter (test-vector generator), fb11amod_config.hpp:74-110 ---- */
 /* mpdu_nofcs: MPDU without FCS (FCS appended).  out8: COMPLEX8 samples @40 MHz (preamble 640 + 160/symbol).

@@ -44,9 +44,10 @@ class FrameResult(ctypes.Structure):
 
 
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
-           "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
+           "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
-           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a"]
+           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
+           "sora_hip_ingest", "sora_hip_ingest_count"]
 
 _lib = None
 
@@ -101,6 +102,10 @@ def load(build_if_missing=True):
     L.sora_hip_deinterleave11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_viterbi11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_stream_synchronize.argtypes = [ctypes.c_void_p]
+    L.sora_hip_ingest_count.argtypes = [ctypes.c_size_t, ctypes.c_uint]; L.sora_hip_ingest_count.restype = ctypes.c_size_t
+    L.sora_hip_ingest.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t,
+                                  ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     _lib = L
     return L
 
@@ -310,3 +315,24 @@ def viterbi11a(soft, soft_off, nsoft, frame_len, code_rate, out_stride=2560, str
     _check(load().sora_hip_viterbi11a(_dev_ptr(soft), _dev_ptr(soft_off), _dev_ptr(nsoft), _dev_ptr(frame_len), code_rate,
                                       _dev_ptr(out), _dev_ptr(out_off), n, _stream_ptr(stream)))
     return out
+
+
+INGEST_RXBLOCK, INGEST_RAW14, INGEST_44TO40, INGEST_DECIMATE2 = 1, 2, 4, 8
+
+
+def ingest_count(raw_bytes, flags):
+    return int(load().sora_hip_ingest_count(int(raw_bytes), int(flags)))
+
+
+def ingest(raw, flags, stream=None, sync=True):
+    """raw: uint8 (dump bytes) or int16 [n,2] CUDA tensor -> int16 [m,2] CUDA tensor (de-framed / sign-fixed / 44->40 / decimated).
+    sync: wait for the kernel, so that the result can go straight to Rx.process_dev (whose streams do not follow the null stream)."""
+    import torch
+    nbytes = raw.numel() * raw.element_size()
+    n = ingest_count(nbytes, flags)
+    out = torch.empty((max(n, 1), 2), dtype=torch.int16, device=raw.device)
+    got = ctypes.c_size_t(0)
+    _check(load().sora_hip_ingest(_dev_ptr(raw), nbytes, int(flags), _dev_ptr(out), n, ctypes.byref(got), _stream_ptr(stream)))
+    if sync:
+        _check(load().sora_hip_stream_synchronize(_stream_ptr(stream)))
+    return out[:got.value]

@@ -201,4 +201,74 @@ __global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* in, uint32
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// k_ingest: capture ingest in one streaming pass, one output sample per thread (HBM bound: ~4.6 B read + 4 B written
+// per 40 MHz sample for a 44 MHz RX_BLOCK dump):
+//   RX_BLOCK de-framing   128-byte block = 16-byte descriptor + 28 COMPLEX16 (brickutil.h:40-55, _rx_manager.h:96-137)
+//   14 -> 16-bit sign fix (int16)(raw << 2)   (the fixture's samples are 14-bit two's complement, zero-extended)
+//   TDownSample44_40      Down44to40::Resample (44MTo40M.hpp:62-123): period 11 -> 10, out[10p] = x[11p],
+//                         out[10p+k] = (x[11p+k] R[k] + x[11p+k+1] L[k+1]) >> 7 -- stateless per period, so parallel
+//   TDownSample2          out[j] = in[2j] (samples.hpp:36-39)
+__device__ __constant__ int kLinR[11] = { 1, 115, 102, 90, 77, 64, 51, 38, 26, 13, 0 };      // 44MTo40M.hpp:35-39
+__device__ __constant__ int kLinL[11] = { 0, 0, 13, 26, 38, 51, 64, 77, 90, 102, 115 };
+
+__global__ void __launch_bounds__(256) k_ingest(const uint8_t* __restrict__ raw, uint32_t* __restrict__ out, uint64_t m0, uint64_t n_out, unsigned flags)
+{
+    const uint64_t m = m0 + (uint64_t)blockIdx.x * 256 + threadIdx.x;
+    if (m >= n_out) return;
+    auto X = [&](uint64_t i) -> cpx {                                            // sample i of the de-framed, sign-fixed stream
+        const uint64_t off = (flags & 1u) ? (i / 28) * 128 + 16 + (i % 28) * 4 : i * 4;
+        const uint32_t w = *reinterpret_cast<const uint32_t*>(raw + off);
+        cpx x = unpack(w);
+        if (flags & 2u) { x.re = w16(x.re << 2); x.im = w16(x.im << 2); }
+        return x;
+    };
+    const uint64_t m1 = (flags & 8u) ? 2 * m : m;
+    cpx s;
+    if (flags & 4u) {
+        const uint64_t p = m1 / 10; const int k = (int)(m1 % 10);
+        if (k == 0) s = X(11 * p);
+        else {
+            const cpx a = X(11 * p + k), b = X(11 * p + k + 1);
+            s = mk(w16((a.re * kLinR[k] + b.re * kLinL[k + 1]) >> 7), w16((a.im * kLinR[k] + b.im * kLinL[k + 1]) >> 7));
+        }
+    } else s = X(m1);
+    out[m] = pack(s);
+}
+
+// The common case (a 44 MHz dump: de-frame + resample, optionally sign fix / decimate) tiled so that every byte moves in
+// 16-byte coalesced accesses: a tile is 55 RX_BLOCKs = 1540 input samples = 140 resampler periods = 1400 output samples
+// (lcm(28, 11) x 5); the 7040 raw bytes are staged in LDS, the index arithmetic is 32-bit and local.
+constexpr int kTileBlocks = 55, kTileRaw = kTileBlocks * 128, kTileOut = 1400;
+
+__global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__ raw, uint32_t* __restrict__ out, unsigned flags)
+{
+    __shared__ uint32_t s_raw[kTileRaw / 4];
+    __shared__ uint32_t s_out[kTileOut];
+    const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)blockIdx.x * kTileRaw);
+    for (int i = threadIdx.x; i < kTileRaw / 16; i += 256) reinterpret_cast<uint4*>(s_raw)[i] = src[i];
+    __syncthreads();
+    const bool dec = (flags & 8u) != 0, fix = (flags & 2u) != 0;
+    const int nout = dec ? kTileOut / 2 : kTileOut;
+    auto X = [&](int i) -> cpx {                                                 // input sample i of the tile
+        cpx x = unpack(s_raw[(i / 28) * 32 + 4 + (i % 28)]);
+        if (fix) { x.re = w16(x.re << 2); x.im = w16(x.im << 2); }
+        return x;
+    };
+    for (int m = threadIdx.x; m < nout; m += 256) {
+        const int m1 = dec ? 2 * m : m;
+        const int p = m1 / 10, k = m1 - 10 * p;
+        cpx s;
+        if (k == 0) s = X(11 * p);
+        else {
+            const cpx a = X(11 * p + k), b = X(11 * p + k + 1);
+            s = mk(w16((a.re * kLinR[k] + b.re * kLinL[k + 1]) >> 7), w16((a.im * kLinR[k] + b.im * kLinL[k + 1]) >> 7));
+        }
+        s_out[m] = pack(s);
+    }
+    __syncthreads();
+    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * nout);     // nout * 4 bytes is a multiple of 16
+    for (int i = threadIdx.x; i < nout / 4; i += 256) dst[i] = reinterpret_cast<const uint4*>(s_out)[i];
+}
+
 }  // namespace sora

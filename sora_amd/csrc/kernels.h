@@ -52,6 +52,8 @@ __global__ void k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Table
 __global__ void k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T);
 __global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
 __global__ void k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
+__global__ void k_ingest(const uint8_t* raw, uint32_t* out, uint64_t m0, uint64_t n_out, unsigned flags);
+__global__ void k_ingest_tile(const uint8_t* raw, uint32_t* out, unsigned flags);
 __global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16);
 __global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
                                const uint32_t* out_off, int code_rate, uint32_t n);

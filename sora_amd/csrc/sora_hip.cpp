@@ -315,6 +315,7 @@ int sora_hip_device_count(void)
 void* sora_hip_malloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
 void  sora_hip_free(void* p) { if (p) (void)hipFree(p); }
 int   sora_hip_memcpy_h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return SORA_OK; }
+int   sora_hip_stream_synchronize(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return SORA_OK; }
 int   sora_hip_memcpy_d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return SORA_OK; }
 
 static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
@@ -750,6 +751,49 @@ int sora_hip_deinterleave11a(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, si
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
     hipLaunchKernelGGL(k_deint_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_bpsc, (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+// ---- capture ingest
+size_t sora_hip_ingest_count(size_t raw_bytes, unsigned flags)
+{
+    uint64_t n;
+    if (flags & SORA_INGEST_RXBLOCK) {                          // LoadSoraDumpFile (brickutil.h:40-55): a short last block gives what it holds
+        const uint64_t full = raw_bytes / 128, rem = raw_bytes % 128;
+        n = full * 28 + (rem > 16 ? std::min<uint64_t>(28, (rem - 16) / 4) : 0);
+    } else n = raw_bytes / 4;
+    if (flags & SORA_INGEST_44TO40) {                           // whole 28-sample blocks in, whole 28-sample blocks out (sampling.hpp:47-62)
+        const uint64_t nin = n / 28 * 28;
+        const uint64_t produced = nin - (nin + 9) / 11;         // every input except those with index % 11 == 1
+        n = produced / 28 * 28;
+    }
+    if (flags & SORA_INGEST_DECIMATE2) n = n / 8 * 4;          // TDownSample2: bursts of 8 -> 4 (samples.hpp:9-47)
+    return (size_t)n;
+}
+
+int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_complex16* d_out, size_t out_capacity, size_t* n_out, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_raw || !d_out || (flags & ~15u)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_ingest: bad argument");
+    if (((uintptr_t)d_raw & 3) || ((uintptr_t)d_out & 3)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_ingest: buffers must be 4-byte aligned");
+    const size_t n = sora_hip_ingest_count(raw_bytes, flags);
+    if (n_out) *n_out = n;
+    if (n > out_capacity) return fail(SORA_ERR_CAPACITY, "sora_hip_ingest: output buffer too small");
+    if (n == 0) return SORA_OK;
+    uint64_t done = 0;
+    if ((flags & (SORA_INGEST_RXBLOCK | SORA_INGEST_44TO40)) == (SORA_INGEST_RXBLOCK | SORA_INGEST_44TO40) &&
+        !((uintptr_t)d_raw & 15) && !((uintptr_t)d_out & 15)) {
+        // whole tiles of 55 RX_BLOCKs -> 1400 (700 when decimating) samples through the LDS-staged kernel
+        const uint64_t per_tile = (flags & SORA_INGEST_DECIMATE2) ? 700 : 1400;
+        const uint64_t tiles = std::min<uint64_t>(raw_bytes / (55 * 128), n / per_tile);
+        if (tiles) {
+            hipLaunchKernelGGL(k_ingest_tile, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw, reinterpret_cast<uint32_t*>(d_out), flags);
+            done = tiles * per_tile;
+        }
+    }
+    if (done < n)
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n - done + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw, reinterpret_cast<uint32_t*>(d_out), done, (uint64_t)n, flags);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }

@@ -6,7 +6,7 @@
                          stream is stored as int8 (value>>8).  Golden: sha256 of the dump, MPDU sha256, FCS.
   ref_vectors.npz        input/output pairs produced by the reference's OWN SSE kernels compiled into
                          oracle/_ref/libsora_ref.so (FFT<64>/IFFT<64>/IFFT<128>, vcs mul, demap LUT walk,
-                         Viterbi_sig11, TViterbiCore frame decodes at 1/2, 2/3, 3/4 under noise).
+                         Viterbi_sig11, TViterbiCore frame decodes at 1/2, 2/3, 3/4 under noise, Down44to40).
 Both files travel to the GPU box; /root/reference does not.
 """
 import hashlib
@@ -68,6 +68,11 @@ def main():
         v["vit%s_in" % name] = soft
         v["vit%s_out" % name] = R.viterbi_frame(soft, cr, flen)
         v["vit%s_len" % name] = np.array([flen])
+    # the reference's Down44to40 driven as TDownSample44_40 does (drawn last: the vectors above keep their values)
+    r44 = rng.integers(-32768, 32768, size=(28 * 45, 2)).astype(np.int16)
+    r44[5] = (-32768, 32767); r44[16] = (32767, -32768)
+    v["down44_in"] = r44
+    v["down44_out"] = R.down44to40(r44)
     np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), **v)
     print("written", os.listdir(OUT))
 
