@@ -43,8 +43,9 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     const Tables& T = A.T;
     reinterpret_cast<uint32_t*>(s_demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(T.demap)[threadIdx.x];
     __syncthreads();                                                             // the only block barrier: the waves are independent from here on
-    const uint32_t j = blockIdx.x * 4 + w;
-    if (j >= *A.njobs) return;
+    const JobRef jr = locate_job(blockIdx.x * 4 + w, A.njobs);
+    if (!jr.ok) return;
+    const uint32_t j = jr.list * A.nrows + jr.idx;                               // slot of the job in jobs[] / joblist[]
     const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
     if (lane == 0) {
@@ -480,14 +481,21 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 
 // Four waves per 256-thread workgroup, two frames per wave (no cross-wave traffic).  One-wave workgroups were kept to
 // 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.
-// Frames are paired in job order when their code rates agree; otherwise each runs alone in the low half.
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs_ptr, uint32_t njobs_max, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+// Frames are queued per code rate (k_scan), so the two frames of a wave always share the puncture pattern; the last
+// frame of an odd list runs alone in the low half.  (Jobs given through sora_hip_viterbi11a are one list of one rate.)
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
     __shared__ uint16_t s_ring[4][kRingBlocks * 64];                             // 24 KB: survivor history of the last 384 columns, per wave
-    const uint32_t njobs = njobs_ptr ? *njobs_ptr : njobs_max;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
-    const uint32_t fa = uni((blockIdx.x * 4 + (threadIdx.x >> 6)) * 2), fb = fa + 1;
-    if (fa >= njobs) return;
+    // wave -> (code-rate list, pair): list r has ceil(n_r / 2) pairs (njobs3 == nullptr: one list of njobs_single jobs)
+    uint32_t n[3] = { njobs_single, 0, 0 };
+    if (njobs3) { n[0] = njobs3[0]; n[1] = njobs3[1]; n[2] = njobs3[2]; }
+    uint32_t pw = uni(blockIdx.x * 4 + (threadIdx.x >> 6)), list = 0;
+    while (list < 3 && pw >= (n[list] + 1) / 2) { pw -= (n[list] + 1) / 2; list++; }
+    if (list >= 3) return;
+    const uint32_t njobs = uni(n[list]);
+    jobs += (size_t)list * stride;
+    const uint32_t fa = pw * 2, fb = fa + 1;
     uint16_t* ring = s_ring[threadIdx.x >> 6];
     auto load_job = [&](uint32_t f) {
         const VitJob& G = jobs[f];
@@ -529,9 +537,9 @@ __global__ void __launch_bounds__(256) k_finish(RxArgs A)
     s_crc[threadIdx.x] = A.T.crc[threadIdx.x];
     for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) s_z[i] = A.T.crcz[i];
     __syncthreads();
-    const uint32_t j = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (j >= *A.njobs) return;
-    const uint32_t f = A.joblist[j];
+    const JobRef jr = locate_job(blockIdx.x * 4 + (threadIdx.x >> 6), A.njobs);
+    if (!jr.ok) return;
+    const uint32_t f = A.joblist[jr.list * A.nrows + jr.idx];
     FrameRow& r = A.frames[f];
     if (!r.valid || r.error_code != 0) return;
     const int lane = threadIdx.x & 63;

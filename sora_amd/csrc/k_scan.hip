@@ -504,7 +504,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                 if (plcp_fail) r_end = vpos / STR;
                 else {
                     // queue the frame for the per-frame kernels
-                    if (lane == 0) A.joblist[atomicAdd(A.njobs, 1u)] = cap_i * A.max_frames + nfr;
+                    if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
                 }
                 if (lane == 0) {
                     FrameRow row;

@@ -17,9 +17,10 @@ struct ScanArgs {
     FrameRow*       frames;     // [ncaps*max_frames]
     FrameCtx*       fctx;
     uint32_t*       nframes;    // [ncaps]
-    uint32_t*       njobs;      // [1] number of frames whose data symbols must be decoded
-    uint32_t*       joblist;    // [nrows] their frame-table rows, compacted: consecutive workgroups of the per-frame
-                                //         kernels then carry live work (workgroup b runs on XCD b % 8)
+    uint32_t*       njobs;      // [3] frames whose data symbols must be decoded, per code rate (1/2, 2/3, 3/4)
+    uint32_t*       joblist;    // [3][nrows] their frame-table rows, compacted: consecutive workgroups of the per-frame
+                                //            kernels then carry live work (workgroup b runs on XCD b % 8)
+    uint32_t        nrows;      // list stride = ncaps * max_frames
 };
 
 struct RxArgs {
@@ -41,7 +42,7 @@ struct RxArgs {
 
 __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
-__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs_ptr, uint32_t njobs_max, const uint8_t* soft, uint8_t* out);
+__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);

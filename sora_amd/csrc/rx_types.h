@@ -60,6 +60,21 @@ struct TrackRec {           // per data-symbol slot
     int16_t avg, del;             // rotation applied by TPilotTrack to THIS symbol
 };
 
+// Frames are queued per code rate (1/2, 2/3, 3/4): k_viterbi runs two frames per wave and both must step through the
+// same puncture pattern.  List r holds njobs[r] frame rows at joblist[r * stride ...]; job g of a call = element
+// g - (jobs of the lists before) of its list.
+struct JobRef { uint32_t list, idx; bool ok; };
+__host__ __device__ inline JobRef locate_job(uint32_t g, const uint32_t* njobs)
+{
+    JobRef r; r.ok = true;
+    const uint32_t n0 = njobs[0], n1 = njobs[1], n2 = njobs[2];
+    if (g < n0) { r.list = 0; r.idx = g; }
+    else if (g < n0 + n1) { r.list = 1; r.idx = g - n0; }
+    else if (g < n0 + n1 + n2) { r.list = 2; r.idx = g - n0 - n1; }
+    else { r.list = 0; r.idx = 0; r.ok = false; }
+    return r;
+}
+
 constexpr int kSoftPerSlot = 288;      // N_CBPS max
 constexpr int kOutPerSlot  = 32;       // decoded bytes per symbol max 27 -> 32
 

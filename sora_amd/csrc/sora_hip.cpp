@@ -348,8 +348,8 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
         { (void**)&rx->d_fctx, sizeof(FrameCtx) * rx->cap_rows }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
         { (void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64 },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
-        { (void**)&rx->d_jobs, sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
-        { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_njobs, 4 }, { (void**)&rx->d_joblist, 4 * (size_t)rx->cap_rows },
+        { (void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
+        { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_njobs, 12 }, { (void**)&rx->d_joblist, 3 * 4 * (size_t)rx->cap_rows },
     };
     for (auto& a : allocs) {
         e = hipMalloc(a.p, a.bytes);
@@ -416,11 +416,11 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 
     auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
         HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
-        HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 4, st));
+        HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 12, st));
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist;
+        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows;
         mark();
         hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
@@ -431,7 +431,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
         hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
         mark();
-        hipLaunchKernelGGL(k_viterbi, dim3((nrows + 7) / 8), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
+        hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
         mark();
         hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
         mark();
@@ -823,7 +823,7 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
     HIPCHK(hipMemcpyAsync(s16off, h_s16_off.data(), 4 * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, (const uint32_t*)s16off, soft16);
     hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, (const uint32_t*)s16off, d_nsoft, d_frame_len, d_out_off, code_rate, (uint32_t)n);
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, (const uint8_t*)soft16, d_out);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)soft16, d_out);
     hipError_t e = hipStreamSynchronize(st);
     (void)hipFree(jobs); (void)hipFree(soft16); (void)hipFree(s16off);
     if (e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_viterbi11a", e);
