@@ -199,6 +199,11 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
 // VOP2 add/sub/xor/and/mov 5.0, VOP3/VOP3P/DPP 9.4, compare->SGPR / v_addc 9.9, permlane swap 16.9 (units of 0.67 ns).
 // Per packed step: 1 move + 2 adds + 1 min + 2..3 for the branch metrics; no compare, no carry chain, no LDS.
 __device__ __forceinline__ unsigned rol6(unsigned v, unsigned r) { r %= 6; return ((v << r) | (v >> (6 - r))) & 63u; }
+// Physical lane <-> label lane.  The butterfly partner of label lane v at phase ph is v ^ (32 >> ph); every XOR distance
+// except 4 is one cross-lane move (permlane swaps for 32/16, row_ror:8, quad_perm for 2/1).  Placing label lane v in
+// physical lane v ^ (v & 4 ? 3 : 0) turns the label distance 4 into the physical distance 7 = row_half_mirror, one DPP
+// move too; the other distances are unchanged.  The map is its own inverse.
+__device__ __forceinline__ unsigned lane_map(unsigned x) { return x ^ ((x & 4u) ? 3u : 0u); }
 
 __device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wide unsigned minimum, VALU latency only
 {
@@ -260,8 +265,7 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     case 0: { auto r = __builtin_amdgcn_permlane32_swap(V.U, V.U, false, false); X = r[0]; Y = r[1]; break; }
     case 1: { auto r = __builtin_amdgcn_permlane16_swap(V.U, V.U, false, false); X = r[0]; Y = r[1]; break; }
     case 2: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x128, 0xF, 0xF, true); break;                  // L ^ 8: row_ror:8
-    case 3: { const int t = __builtin_amdgcn_mov_dpp(u, 0x114, 0xF, 0xA, false);                                      // L ^ 4: row_shr:4 into lanes with bit 2 set,
-              X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(t, u, 0x104, 0xF, 0x5, false); break; }              //        row_shl:4 into the others
+    case 3: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x141, 0xF, 0xF, true); break;                  // label ^ 4 = lane ^ 7: row_half_mirror
     case 4: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x4E, 0xF, 0xF, true); break;                   // L ^ 2: quad_perm [2,3,0,1]
     default: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, true); break;                  // L ^ 1: quad_perm [1,0,3,2]
     }
@@ -292,13 +296,13 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     auto writelane = [](unsigned& vec, unsigned val, unsigned ln) {             // vec[lane ln] = val (one SGPR operand per VALU op: the lane select goes through M0)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(ln) : "m0");
     };
-    const unsigned lbl = rol6(lane, tr) << 2;
+    const unsigned lbl = rol6(lane_map(lane), tr) << 2;
     const unsigned kA = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mA << 8) | lbl));
     const unsigned kB = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mB << 8) | lbl));
     const unsigned stA = (kA >> 2) & 0x3F, stB = (kB >> 2) & 0x3F;
-    const unsigned back = 6u - tr % 6u;                                         // lane holding state s now: rol6(s, 6 - tr mod 6)
-    const unsigned pA = (unsigned)__builtin_amdgcn_readlane((int)U, (int)rol6(stA, back)) & 0xFFu;            // decisions of the unfinished block
-    const unsigned pB = ((unsigned)__builtin_amdgcn_readlane((int)U, (int)rol6(stB, back)) >> 16) & 0xFFu;    //   along the start state's path
+    const unsigned back = 6u - tr % 6u;                                         // label lane holding state s now: rol6(s, 6 - tr mod 6)
+    const unsigned pA = (unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stA, back))) & 0xFFu;  // decisions of the unfinished block
+    const unsigned pB = ((unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stB, back))) >> 16) & 0xFFu;  // along the start state's path
     const int m_lo = (int)(ob >> 3);                                            // first output byte of the window
     const int j = (int)((tr - 1) >> 3);                                         // block holding the start column
     const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8
@@ -364,14 +368,15 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 
     auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };   // step kinds of a puncture group (viterbi.hpp:167-187)
     VitLane V;
-    V.U = lane == 0 ? 0u : 0x18u * kFld;                                       // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
+    const unsigned vl = lane_map(lane);                                         // label lane: holds state rol6^t(vl) after t steps
+    V.U = vl == 0 ? 0u : 0x18u * kFld;                                         // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
     V.ring = ring; V.roff = 0;
-    V.sidx[0] = __brev(rol6(lane, 2)) >> 26; V.sidx[1] = __brev(rol6(lane, 4)) >> 26; V.sidx[2] = __brev(lane) >> 26;   // rev6 of the state: (8j + 8) mod 6 = 2, 4, 0
+    V.sidx[0] = __brev(rol6(vl, 2)) >> 26; V.sidx[1] = __brev(rol6(vl, 4)) >> 26; V.sidx[2] = __brev(vl) >> 26;   // rev6 of the state: (8j + 8) mod 6 = 2, 4, 0
 #pragma unroll
     for (int t = 0; t < 24; t++) {
         const int ph = t % 6, k = t % 8;
-        const unsigned n = rol6(lane, ph + 1);                                  // label held after a phase-ph step
-        const bool own1 = ph >= 2 && ((lane >> (5 - ph)) & 1);                  // DPP phases: the lane's own metric is the decision-1 candidate
+        const unsigned n = rol6(vl, ph + 1);                                    // state held after a phase-ph step
+        const bool own1 = ph >= 2 && ((vl >> (5 - ph)) & 1);                    // DPP phases: the lane's own metric is the decision-1 candidate
         const unsigned ma = (__popc(n & 0155) & 1) ? 7u * kFld : 0u, mb = (__popc(n & 0117) & 1) ? 7u * kFld : 0u;
         const unsigned mx = which_of(ph) == 2 ? mb : ma;
         V.MX[t] = own1 ? ((mx ^ (7u * kFld)) | (kOne << k)) : mx;
