@@ -106,6 +106,36 @@ def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
 
 
+def bench_tx(torch, sora_amd, nframes=4096, reps=10):
+    """Row f2 (transmitter): the same 4096 x 1500-byte 54 Mbps frames modulated on the GPU (COMPLEX8 @40 MHz out)."""
+    rng = np.random.default_rng(0x5EED)
+    mpdus = [bytes(rng.integers(0, 256, MPDU_LEN - 4).astype(np.uint8)) for _ in range(64)] * (nframes // 64)
+    out, off = sora_amd.tx11a(mpdus, [RATE_KBPS] * nframes)                  # builds the device arrays; also the warm-up
+    import ctypes
+    from sora_amd import capi
+    lens = torch.full((nframes,), MPDU_LEN - 4, dtype=torch.int32, device=out.device)
+    rate = torch.full((nframes,), RATE_KBPS, dtype=torch.int32, device=out.device)
+    seed = torch.full((nframes,), 0xFF, dtype=torch.uint8, device=out.device)
+    moff = torch.arange(nframes, dtype=torch.int32, device=out.device) * (MPDU_LEN - 4)
+    blob = torch.randint(0, 256, (nframes * (MPDU_LEN - 4),), dtype=torch.uint8, device=out.device)
+    ooff = torch.arange(nframes, dtype=torch.int64, device=out.device) * (off[1] - off[0])
+    L = capi.load()
+    call = lambda: L.sora_hip_tx11a(capi._dev_ptr(blob), capi._dev_ptr(moff), capi._dev_ptr(lens), capi._dev_ptr(rate), capi._dev_ptr(seed),
+                                    nframes, capi._dev_ptr(out), capi._dev_ptr(ooff), capi._stream_ptr(None))
+    call()
+    e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize(); e0.record()
+    for _ in range(reps):
+        call()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / reps
+    nsamp = int(off[1] - off[0]) * nframes
+    alg = nframes * (MPDU_LEN - 4) + 2 * nsamp
+    return {"workload": "%d frames x %d-byte MPDU at 54 Mbps -> COMPLEX8 @40 MHz (%d samples)" % (nframes, MPDU_LEN, nsamp),
+            "bound": "hbm", "ms": round(ms, 4), "msamples_per_s_out": round(nsamp / ms / 1e3, 1), "algorithmic_bytes": alg,
+            "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -229,6 +259,7 @@ def main():
         }
         if world == 1:
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
+            out["tx"] = bench_tx(torch, sora_amd)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(oracle, iq, nfr)
         print(json.dumps(out))

@@ -167,6 +167,17 @@ size_t sora_hip_ingest_count(size_t raw_bytes, unsigned flags);
 int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_complex16* d_out, size_t out_capacity,
                     size_t* n_out, void* stream);
 
+/* 802.11a transmitter: the modulation graph CreateModGraph11a_* of the reference
+ * (kernel/bb/demod11/fb11amod_config.hpp:74-110: TBB11aSrc -> T11aSc -> TConvEncode_* -> T11aInterleave* -> TMap11a* ->
+ * T11aAddPilot -> TIFFTx -> TPackSample16to8) plus the preamble (Brick11/src/preamble11a.hpp:19-140), a batch of frames per
+ * call.  Frame f: MPDU WITHOUT FCS (the FCS is appended, PHY_11a.hpp:160-170) of d_len[f] bytes at d_mpdu + d_off[f], data
+ * rate d_rate_kbps[f] (6000..54000), scrambler seed d_seed[f] (the reference harness uses 0xFF, fb11amod_config.hpp:53);
+ * writes sora_hip_tx11a_samples(len, rate) COMPLEX8 samples (int8 re, int8 im) at 40 MHz -- what `demod11 -m` writes --
+ * at sample d_out_off[f] of d_out.  A frame with an unknown rate must not be submitted (sora_hip_tx11a_samples = 0). */
+size_t sora_hip_tx11a_samples(uint32_t mpdu_len_nofcs, uint32_t rate_kbps);
+int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t* d_len, const uint32_t* d_rate_kbps,
+                   const uint8_t* d_seed, size_t nframes, int8_t* d_out, const uint64_t* d_out_off, void* stream);
+
 /* ------------------------------------------------------------------------------------------------
  * Small device-memory helpers so a pure-C host needs no HIP headers.
  * ------------------------------------------------------------------------------------------------ */

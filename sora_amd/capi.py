@@ -47,7 +47,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
-           "sora_hip_ingest", "sora_hip_ingest_count"]
+           "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples"]
 
 _lib = None
 
@@ -103,6 +103,8 @@ def load(build_if_missing=True):
     L.sora_hip_viterbi11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_stream_synchronize.argtypes = [ctypes.c_void_p]
+    L.sora_hip_tx11a_samples.argtypes = [ctypes.c_uint32, ctypes.c_uint32]; L.sora_hip_tx11a_samples.restype = ctypes.c_size_t
+    L.sora_hip_tx11a.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
     L.sora_hip_ingest_count.argtypes = [ctypes.c_size_t, ctypes.c_uint]; L.sora_hip_ingest_count.restype = ctypes.c_size_t
     L.sora_hip_ingest.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t,
                                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
@@ -336,3 +338,35 @@ def ingest(raw, flags, stream=None, sync=True):
     if sync:
         _check(load().sora_hip_stream_synchronize(_stream_ptr(stream)))
     return out[:got.value]
+
+
+def tx11a_samples(mpdu_len_nofcs, rate_kbps):
+    return int(load().sora_hip_tx11a_samples(int(mpdu_len_nofcs), int(rate_kbps)))
+
+
+def tx11a(mpdus, rates_kbps, seeds=None, device=0, stream=None, sync=True):
+    """Modulate a batch of MPDUs (bytes WITHOUT FCS) on the GPU.  -> (int8 CUDA tensor [total,2] COMPLEX8 @40 MHz, offsets list).
+    Frame f occupies samples offsets[f] .. offsets[f+1]."""
+    import torch
+    n = len(mpdus)
+    seeds = [0xFF] * n if seeds is None else list(seeds)
+    lens = [len(m) for m in mpdus]
+    off = np.zeros(n + 1, np.int64); np.cumsum([(l + 3) // 4 * 4 for l in lens], out=off[1:])
+    blob = np.zeros(max(int(off[-1]), 4), np.uint8)
+    for f, m in enumerate(mpdus):
+        blob[off[f]:off[f] + lens[f]] = np.frombuffer(bytes(m), np.uint8)
+    ns = [tx11a_samples(l, r) for l, r in zip(lens, rates_kbps)]
+    if any(v == 0 for v in ns):
+        raise SoraError(-1, "tx11a: unsupported rate or length")
+    ooff = np.zeros(n + 1, np.uint64); np.cumsum(ns, out=ooff[1:])
+    dev = torch.device("cuda", device)
+    t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
+    d_blob = t(blob, np.uint8); d_off = torch.from_numpy(off[:-1].astype(np.int32)).to(dev)
+    d_len = torch.from_numpy(np.asarray(lens, np.int32)).to(dev); d_rate = torch.from_numpy(np.asarray(rates_kbps, np.int32)).to(dev)
+    d_seed = t(np.asarray(seeds, np.uint8), np.uint8); d_ooff = torch.from_numpy(ooff[:-1].astype(np.int64)).to(dev)
+    out = torch.zeros((int(ooff[-1]), 2), dtype=torch.int8, device=dev)
+    _check(load().sora_hip_tx11a(_dev_ptr(d_blob), _dev_ptr(d_off), _dev_ptr(d_len), _dev_ptr(d_rate), _dev_ptr(d_seed), n,
+                                 _dev_ptr(out), _dev_ptr(d_ooff), _stream_ptr(stream)))
+    if sync:
+        _check(load().sora_hip_stream_synchronize(_stream_ptr(stream)))
+    return out, [int(v) for v in ooff]

@@ -152,4 +152,97 @@ __device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int
     fft64_group(x, y, s, e, fft64_twiddles(T, e), sync);
 }
 
+// a*conj(b) >> 15 with the xor-approximated negation of the reference (conj_mul_shift, vector128.h:1248-1256): IFFT twiddles
+__device__ __forceinline__ cpx conj_mul_shift15(cpx a, cpx b)
+{
+    int v0 = (int)((unsigned)(a.re * b.re) + (unsigned)(a.im * b.im));
+    int v1 = (int)((unsigned)(a.im * b.re) + (unsigned)(neg16(a.re) * b.im));
+    return mk(w16(v0 >> 15), w16(v1 >> 15));
+}
+
+// ---------------------------------------------------------------------------------------------
+// 128-point radix-4 DIF FFT / IFFT (core/inc/fft_r4dif.h, ifft_r4dif.h: 128 = 4 x 32, 32 = 4 x 8, 8-point terminal
+// stage with input shift 3) for a group of 32 lanes, 4 points per lane, staged through a 128-entry LDS slice `s`.
+// In: x[m] = point e + 32 m.  Out: y[q] = point e + 32 q (natural order).  All lanes of the group must call; SYNC is a
+// barrier covering the group.
+template <bool INV>
+__device__ __forceinline__ void r4_bfly128(cpx a, cpx b, cpx c, cpx d, cpx w1, cpx w2, cpx w3, cpx& y0, cpx& y1, cpx& y2, cpx& y3)
+{
+    a = sra(a, 2); b = sra(b, 2); c = sra(c, 2); d = sra(d, 2);                 // FFTSSE<N> / IFFTSSE<N> (:11-47)
+    cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
+    cpx jb = mul_j(b_d);
+    y0 = cadds(ac, bd);
+    if (!INV) { y1 = mul_shift15(csubs(ac, bd), w2); y2 = mul_shift15(csubs(a_c, jb), w1); y3 = mul_shift15(cadds(a_c, jb), w3); }
+    else      { y1 = conj_mul_shift15(csubs(ac, bd), w2); y2 = conj_mul_shift15(cadds(a_c, jb), w1); y3 = conj_mul_shift15(csubs(a_c, jb), w3); }
+}
+
+template <bool INV, typename SYNC>
+__device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t* s, int e, const Tables& T, SYNC sync)
+{
+    sync();
+    {   // stage N=128: butterfly e on points e, e+32, e+64, e+96
+        cpx y0, y1, y2, y3;
+        r4_bfly128<INV>(x[0], x[1], x[2], x[3], unpack(T.tw128[e]), unpack(T.tw128[32 + e]), unpack(T.tw128[64 + e]), y0, y1, y2, y3);
+        s[e] = pack(y0); s[e + 32] = pack(y1); s[e + 64] = pack(y2); s[e + 96] = pack(y3);
+    }
+    sync();
+    {   // stage N=32 on quarter k = e>>3: butterfly j = e&7 on points 32k + j + {0,8,16,24}
+        const int k = e >> 3, j = e & 7, base = 32 * k + j;
+        cpx y0, y1, y2, y3;
+        r4_bfly128<INV>(unpack(s[base]), unpack(s[base + 8]), unpack(s[base + 16]), unpack(s[base + 24]),
+                        unpack(T.tw32[j]), unpack(T.tw32[8 + j]), unpack(T.tw32[16 + j]), y0, y1, y2, y3);
+        s[base] = pack(y0); s[base + 8] = pack(y1); s[base + 16] = pack(y2); s[base + 24] = pack(y3);
+    }
+    sync();
+    if (e < 16) {   // terminal 8-point stage (FFTSSEEx<8> / IFFTSSEEx<8>, :86-130) on points 8m..8m+7, m = lane
+        uint32_t* p = s + 8 * e;
+        cpx a[4], b[4], d[4], sm[4], ee[4], gg[4], ff[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) { a[q] = sra(unpack(p[q]), 3); b[q] = sra(unpack(p[4 + q]), 3); }
+#pragma unroll
+        for (int q = 0; q < 4; q++) { d[q] = csubs(a[q], b[q]); sm[q] = cadds(a[q], b[q]); }
+        ee[0] = d[0]; ee[1] = d[1];
+        ee[2] = INV ? mk(~d[2].im, d[2].re) : mk(d[2].im, ~d[2].re);
+        ee[3] = INV ? mk(~d[3].im, d[3].re) : mk(d[3].im, ~d[3].re);
+        gg[0] = cadds(ee[0], ee[2]); gg[1] = cadds(ee[1], ee[3]); gg[2] = cadds(cnot(ee[2]), ee[0]); gg[3] = cadds(cnot(ee[3]), ee[1]);
+#pragma unroll
+        for (int q = 0; q < 4; q++) ff[q] = INV ? conj_mul_shift15(gg[q], unpack(T.tw8[q])) : mul_shift15(gg[q], unpack(T.tw8[q]));
+        p[4] = pack(cadds(ff[0], ff[1])); p[5] = pack(cadds(cnot(ff[1]), ff[0]));
+        p[6] = pack(cadds(ff[2], ff[3])); p[7] = pack(cadds(cnot(ff[3]), ff[2]));
+        cpx A0 = cadds(sm[0], sm[2]), A1 = cadds(sm[1], sm[3]);
+        cpx B0 = cadds(cnot(sm[2]), sm[0]), B1 = cadds(cnot(sm[3]), sm[1]);
+        cpx B1r = INV ? mk(~B1.im, B1.re) : mk(B1.im, ~B1.re);
+        p[0] = pack(cadds(A0, A1)); p[1] = pack(cadds(cnot(A1), A0)); p[2] = pack(cadds(B0, B1r)); p[3] = pack(cadds(cnot(B1r), B0));
+    }
+    sync();
+#pragma unroll
+    for (int q = 0; q < 4; q++) y[q] = unpack(s[__brev((unsigned)(e + 32 * q)) >> 25]);   // FFT128LUTMap = 7-bit bit reversal
+}
+
+// ---------------------------------------------------------------------------------------------
+// CRC-32 (reflected, init 0xFFFFFFFF, no final xor here) of n >= 4 bytes in LDS by one wave.  The register update is
+// linear over GF(2): CRC(init, M) = CRC(0, M') with the first four bytes complemented, and
+// CRC(0, M1 | M2) = Z_|M2|(CRC(0, M1)) ^ CRC(0, M2) with Z_m = "m zero bytes".  Lane l takes the 40 bytes that END 40 l
+// bytes before the end (byte table s_crc), then six tree levels fold lane l + 2^k into lane l through Z_(40 * 2^k)
+// (8 nibble look-ups in s_z each).  Lane 0 returns the register after the whole message.
+__device__ __forceinline__ uint32_t crc32_wave(const uint8_t* bytes, int n, const uint32_t* s_crc, const uint32_t* s_z, int lane)
+{
+    uint32_t c = 0;
+    const int i0 = n - 40 * (lane + 1);
+#pragma unroll 8
+    for (int q = 0; q < 40; q++) {
+        const int i = i0 + q;
+        if (i >= 0) c = (c >> 8) ^ s_crc[(c ^ bytes[i] ^ (i < 4 ? 0xFFu : 0u)) & 0xFFu];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const uint32_t o = (uint32_t)__shfl_down((int)c, 1 << k);
+        uint32_t z = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) z ^= s_z[(k * 8 + q) * 16 + ((o >> (4 * q)) & 15u)];
+        c ^= z;
+    }
+    return c;
+}
+
 }  // namespace sora

@@ -568,22 +568,7 @@ __global__ void __launch_bounds__(256) k_finish(RxArgs A)
     const int n = L >= 4 ? (int)L - 4 : 0;                                       // PHY_11a.hpp:668-673: the FCS bytes are not fed to the CRC
     uint32_t crc;
     if (n >= 4) {
-        uint32_t c = 0;
-        const int i0 = n - 40 * (lane + 1);
-#pragma unroll 8
-        for (int q = 0; q < 40; q++) {
-            const int i = i0 + q;
-            if (i >= 0) c = (c >> 8) ^ s_crc[(c ^ bytes[i] ^ (i < 4 ? 0xFFu : 0u)) & 0xFFu];
-        }
-#pragma unroll
-        for (int k = 0; k < 6; k++) {
-            const uint32_t o = (uint32_t)__shfl_down((int)c, 1 << k);
-            uint32_t z = 0;
-#pragma unroll
-            for (int q = 0; q < 8; q++) z ^= s_z[(k * 8 + q) * 16 + ((o >> (4 * q)) & 15u)];
-            c ^= z;
-        }
-        crc = c;                                                                  // lane 0 holds the register after the whole message
+        crc = crc32_wave(bytes, n, s_crc, s_z, lane);                             // lane 0 holds the register after the whole message
     } else {
         crc = 0xFFFFFFFFu;
         for (int i = 0; i < n; i++) crc = (crc >> 8) ^ s_crc[(bytes[i] ^ crc) & 0xFF];

@@ -135,69 +135,20 @@ __global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const u
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// FFT<128>: 32 lanes per transform, 4 points per lane, 8 transforms per 256-thread block.
-__device__ __forceinline__ void r4_bfly(cpx a, cpx b, cpx c, cpx d, cpx w1, cpx w2, cpx w3, cpx& y0, cpx& y1, cpx& y2, cpx& y3)
-{
-    a = sra(a, 2); b = sra(b, 2); c = sra(c, 2); d = sra(d, 2);                 // FFTSSE<N> (fft_r4dif.h:11-47)
-    cpx ac = cadds(a, c), bd = cadds(b, d), a_c = csubs(a, c), b_d = csubs(b, d);
-    cpx jb = mul_j(b_d);
-    y0 = cadds(ac, bd);
-    y1 = mul_shift15(csubs(ac, bd), w2);
-    y2 = mul_shift15(csubs(a_c, jb), w1);
-    y3 = mul_shift15(cadds(a_c, jb), w3);
-}
-
+// FFT<128>: 32 lanes per transform, 4 points per lane, 8 transforms per 256-thread block (fft128_group, dev_arith.h).
 __global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T)
 {
     __shared__ uint32_t s_all[8][128];
     const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
     const uint32_t i = blockIdx.x * 8 + g;
-    uint32_t* s = s_all[g];
     const bool active = i < n;
-    // stage N=128: butterfly e on points e, e+32, e+64, e+96
-    {
-        cpx a = active ? unpack(in[(size_t)i * 128 + e]) : mk(0, 0), b = active ? unpack(in[(size_t)i * 128 + e + 32]) : mk(0, 0);
-        cpx c = active ? unpack(in[(size_t)i * 128 + e + 64]) : mk(0, 0), d = active ? unpack(in[(size_t)i * 128 + e + 96]) : mk(0, 0);
-        cpx y0, y1, y2, y3;
-        r4_bfly(a, b, c, d, unpack(T.tw128[e]), unpack(T.tw128[32 + e]), unpack(T.tw128[64 + e]), y0, y1, y2, y3);
-        s[e] = pack(y0); s[e + 32] = pack(y1); s[e + 64] = pack(y2); s[e + 96] = pack(y3);
-    }
-    __syncthreads();
-    // stage N=32 on quarter k = e>>3: butterfly j = e&7 on points 32k + j + {0,8,16,24}
-    {
-        const int k = e >> 3, j = e & 7, base = 32 * k + j;
-        cpx y0, y1, y2, y3;
-        r4_bfly(unpack(s[base]), unpack(s[base + 8]), unpack(s[base + 16]), unpack(s[base + 24]),
-                unpack(T.tw32[j]), unpack(T.tw32[8 + j]), unpack(T.tw32[16 + j]), y0, y1, y2, y3);
-        s[base] = pack(y0); s[base + 8] = pack(y1); s[base + 16] = pack(y2); s[base + 24] = pack(y3);
-    }
-    __syncthreads();
-    // terminal 8-point stage (FFTSSEEx<8>, fft_r4dif.h:86-130) on points 8m..8m+7, m = 0..15: lanes 0..15
-    if (e < 16) {
-        uint32_t* p = s + 8 * e;
-        cpx a[4], b[4], d[4], sm[4], ee[4], gg[4], ff[4];
+    cpx x[4], y[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) { a[q] = sra(unpack(p[q]), 3); b[q] = sra(unpack(p[4 + q]), 3); }
-#pragma unroll
-        for (int q = 0; q < 4; q++) { d[q] = csubs(a[q], b[q]); sm[q] = cadds(a[q], b[q]); }
-        ee[0] = d[0]; ee[1] = d[1]; ee[2] = mk(d[2].im, ~d[2].re); ee[3] = mk(d[3].im, ~d[3].re);
-        gg[0] = cadds(ee[0], ee[2]); gg[1] = cadds(ee[1], ee[3]); gg[2] = cadds(cnot(ee[2]), ee[0]); gg[3] = cadds(cnot(ee[3]), ee[1]);
-#pragma unroll
-        for (int q = 0; q < 4; q++) ff[q] = mul_shift15(gg[q], unpack(T.tw8[q]));
-        p[4] = pack(cadds(ff[0], ff[1])); p[5] = pack(cadds(cnot(ff[1]), ff[0]));
-        p[6] = pack(cadds(ff[2], ff[3])); p[7] = pack(cadds(cnot(ff[3]), ff[2]));
-        cpx A0 = cadds(sm[0], sm[2]), A1 = cadds(sm[1], sm[3]);
-        cpx B0 = cadds(cnot(sm[2]), sm[0]), B1 = cadds(cnot(sm[3]), sm[1]);
-        cpx B1r = mk(B1.im, ~B1.re);
-        p[0] = pack(cadds(A0, A1)); p[1] = pack(cadds(cnot(A1), A0)); p[2] = pack(cadds(B0, B1r)); p[3] = pack(cadds(cnot(B1r), B0));
-    }
-    __syncthreads();
+    for (int m = 0; m < 4; m++) x[m] = active ? unpack(in[(size_t)i * 128 + e + 32 * m]) : mk(0, 0);
+    fft128_group<false>(x, y, s_all[g], e, T, []() { __syncthreads(); });
     if (active) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-            const unsigned j = (unsigned)(e + 32 * q);
-            out[(size_t)i * 128 + j] = s[__brev(j) >> 25];                         // FFT128LUTMap = 7-bit bit reversal
-        }
+        for (int q = 0; q < 4; q++) out[(size_t)i * 128 + e + 32 * q] = pack(y[q]);
     }
 }
 

@@ -1,0 +1,215 @@
+// k_tx.hip -- 802.11a transmitter on the GPU: the modulation graph
+//   TBB11aSrc -> T11aSc -> TBB11aMRSelect -> TConvEncode_{12,23,34} -> T11aInterleave* -> TMap11a* -> T11aAddPilot
+//   -> TIFFTx -> TPackSample16to8 -> TModSink          (kernel/bb/demod11/fb11amod_config.hpp:74-110)
+// plus the preamble source (kernel/bb/Brick11/src/preamble11a.hpp:19-140).  Output: COMPLEX8 at 40 MHz, what
+// `demod11 -m` writes.  Every stage is data-parallel once restated:
+//   * scrambler (scramble.hpp:237-251): the register sequence is a phase of one period-127 cycle -> two table reads
+//   * convolutional encoder (conv_enc.hpp:6-14): coded bit = xor of five of the last seven input bits; the puncturing
+//     patterns map a coded-bit index to (input bit, generator) in closed form
+//   * interleaver (interleave.hpp:43-58): coded bit k -> position j(k), the table the receiver's de-interleaver reads
+//   * FCS: the parallel CRC-32 of k_finish
+// One 256-thread block per frame; eight OFDM symbols per pass, 32 lanes each (IFFT<128>: 4 points per lane).
+#include <hip/hip_runtime.h>
+#include "kernels.h"
+
+namespace sora {
+
+__device__ __constant__ uint8_t kLtsPos[64] = {              // LTS_Positive_table (ieee80211const.h:23-28)
+    0,1,0,0,1,1,0,1,0,1,0,0,0,0,0,1, 1,0,0,1,0,1,0,1,1,1,1,0,0,0,0,0,
+    0,0,0,0,0,0,1,1,0,0,1,1,0,1,0,1, 1,1,1,1,1,0,0,1,1,0,1,0,1,1,1,1 };
+__device__ __constant__ uint8_t kPilotSgnTx[128] = {         // pilot.hpp:10-28: 1 <=> polarity -1
+    0,0,0,1,1,1,0,1, 1,1,1,0,0,1,0,1, 1,0,0,1,0,0,1,0, 0,0,0,0,0,1,0,0,
+    0,1,0,0,1,1,0,0, 0,1,0,1,1,1,0,1, 0,1,1,0,1,1,0,0, 0,0,0,1,1,0,0,1,
+    1,0,1,0,1,0,0,1, 1,1,0,0,1,1,1,1, 0,1,1,0,1,0,0,0, 0,1,0,1,0,1,0,1,
+    1,1,1,1,0,1,0,0, 1,0,1,0,0,0,1,1, 0,1,1,1,0,0,0,1, 1,1,1,1,1,1,0,0 };
+
+constexpr int kBpskMod = 10720;                              // mapper11a.hpp:8-11
+__device__ __forceinline__ int kmod_of(int nb) { return nb == 1 ? kBpskMod : nb == 2 ? (int)(kBpskMod / 1.414) : nb == 4 ? (int)(kBpskMod / 3.162) : (int)(kBpskMod / 6.481); }
+__device__ __forceinline__ int sat8(int v) { return min(max(v, -128), 127); }          // _mm_packs_epi16 (stdbrick.hpp:430)
+
+// InitQamMapLut (mapper11a.hpp:16-43): M bits, first-transmitted = MSB after reversal, Gray -> level
+__device__ __forceinline__ int qam_level(const uint8_t* bits, int M, int kmod)
+{
+    unsigned rev = 0;
+    for (int i = 0; i < M; i++) rev |= (unsigned)bits[i] << (M - 1 - i);
+    unsigned b = rev ^ (rev >> 1); b ^= b >> 2;                                         // Gray -> binary (M <= 3)
+    return ((int)b * 2 - ((1 << M) - 1)) * kmod;
+}
+
+// 160 time samples of one OFDM symbol from its 64 frequency bins (TIFFTx, fft.hpp:21-59): bins 0..31 -> 0..31, 32..63 ->
+// 96..127 of a 128-point IFFT, >> 4, GI = last 32, first/last two samples halved, saturating 16 -> 8 bit pack.
+// s_bins: 128 words (zero outside the 64 bins), s_sym: 160 words; 32 lanes, e = lane of the group.
+template <typename SYNC>
+__device__ __forceinline__ void ifft_emit(uint32_t* s_bins, uint32_t* s_sym, int e, const Tables& T, int8_t* out8, SYNC sync)
+{
+    cpx x[4], y[4];
+    sync();
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = unpack(s_bins[e + 32 * m]);
+    fft128_group<true>(x, y, s_bins, e, T, sync);
+#pragma unroll
+    for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pack(sra(y[q], 4));
+    sync();
+    s_sym[e] = s_sym[128 + e];
+    sync();
+    if (out8 == nullptr) return;                                                 // (a group past the last symbol only keeps the barriers company)
+    for (int i = e; i < 160; i += 32) {
+        cpx v = unpack(s_sym[i]);
+        if (i < 2 || i >= 158) v = sra(v, 1);
+        reinterpret_cast<uint16_t*>(out8)[i] = (uint16_t)(((unsigned)sat8(v.re) & 0xFFu) | (((unsigned)sat8(v.im) & 0xFFu) << 8));
+    }
+}
+
+// The 640-sample preamble (preamble11a.hpp:19-100), computed once per device into a table.
+__global__ void __launch_bounds__(64) k_tx_preamble(int8_t* out8, Tables T)
+{
+    __shared__ uint32_t s_f[2][128];
+    __shared__ uint32_t s_t[2][128];
+    __shared__ uint32_t s_lut[640];
+    const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
+    auto sync = []() { __syncthreads(); };
+    for (int i = e; i < 128; i += 32) s_f[g][i] = 0;
+    sync();
+    if (g == 0 && e == 0) {                                                      // short training symbol: 12 carriers
+        const int m = (int)(uint16_t)(1.0 * kBpskMod * 1.472);
+        const int idx[12] = { 4, 8, 12, 16, 20, 24, 104, 108, 112, 116, 120, 124 };
+        const int sg[12]  = { -1, -1, 1, 1, 1, 1, 1, -1, 1, -1, -1, 1 };
+        for (int k = 0; k < 12; k++) { const int v = w16(sg[k] * m); s_f[0][idx[k]] = pack(mk(v, v)); }
+    }
+    if (g == 1) {                                                                // long training symbol
+        for (int i = 1 + e; i <= 26; i += 32) s_f[1][i] = pack(mk(kLtsPos[i] ? kBpskMod : -kBpskMod, 0));
+        for (int i = 64 - 26 + e; i < 64; i += 32) s_f[1][i + 64] = pack(mk(kLtsPos[i] ? kBpskMod : -kBpskMod, 0));
+    }
+    sync();
+    cpx x[4], y[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = unpack(s_f[g][e + 32 * m]);
+    fft128_group<true>(x, y, s_f[g], e, T, sync);
+#pragma unroll
+    for (int q = 0; q < 4; q++) s_t[g][e + 32 * q] = pack(sra(y[q], 4));
+    sync();
+    // STS: 128 samples repeated periodically over 320; LTS: GI2 (last 64 of the symbol) + two copies of 128
+    for (int i = threadIdx.x; i < 320; i += 64) s_lut[i] = s_t[0][i & 127];
+    for (int i = threadIdx.x; i < 256; i += 64) s_lut[320 + 64 + i] = s_t[1][i & 127];
+    for (int i = threadIdx.x; i < 64; i += 64) s_lut[320 + i] = s_t[1][64 + i];
+    sync();
+    for (int i = threadIdx.x; i < 640; i += 64) {
+        cpx v = unpack(s_lut[i]);
+        if (i == 0 || i == 1 || i == 318 || i == 319 || i == 320 || i == 321 || i == 638 || i == 639) v = sra(v, 1);
+        out8[2 * i] = (int8_t)sat8(v.re); out8[2 * i + 1] = (int8_t)sat8(v.im);
+    }
+}
+
+// coded bit c of a stream whose input bits are read by `bit(i)` (0 for i < 0); code_rate 0 = 1/2, 1 = 2/3, 2 = 3/4
+// (TConvEncode_12/_23/_34, conv_enc.hpp:18-330: 2/3 sends A B A per 2 bits, 3/4 sends A1 B1 A2 B3 per 3 bits)
+template <typename BIT>
+__device__ __forceinline__ unsigned coded_bit(BIT bit, int c, int code_rate)
+{
+    int i, which;
+    if (code_rate == 0) { i = c >> 1; which = c & 1; }
+    else if (code_rate == 1) { const int g = c / 3, r = c - 3 * g; i = 2 * g + (r == 2); which = r == 1; }
+    else { const int g = c >> 2, r = c & 3; i = 3 * g + (r == 2 ? 1 : r == 3 ? 2 : 0); which = r & 1; }
+    const unsigned x = bit(i), s1 = bit(i - 1), s2 = bit(i - 2), s3 = bit(i - 3), s5 = bit(i - 5), s6 = bit(i - 6);
+    return which ? (x ^ s1 ^ s2 ^ s3 ^ s6) : (x ^ s2 ^ s3 ^ s5 ^ s6);           // G1 = 171, G0 = 133 (conv_enc.hpp:6-14)
+}
+
+__global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
+{
+    __shared__ uint8_t  s_data[2600];
+    __shared__ uint32_t s_crc[256];
+    __shared__ uint32_t s_z[6 * 8 * 16];
+    __shared__ uint32_t s_bins[8][128];
+    __shared__ uint32_t s_sym[8][160];
+    __shared__ uint8_t  s_ib[8][288];
+    __shared__ uint32_t s_fcs;
+    const uint32_t f = blockIdx.x;
+    const int tid = threadIdx.x, g = tid >> 5, e = tid & 31;
+    const Tables& T = A.T;
+    const uint32_t L = A.len[f], kbps = A.rate[f];
+    const uint8_t* mp = A.mpdu + A.off[f];
+    int8_t* out = A.out8 + A.out_off[f] * 2;
+    int nb, cr, nd, rc;
+    switch (kbps) {                                                              // ieee80211a_cmn.h:65-149, ieee80211const.h:3-10
+    case 6000:  nb = 1; cr = 0; nd = 24;  rc = 0xB; break;  case 9000:  nb = 1; cr = 2; nd = 36;  rc = 0xF; break;
+    case 12000: nb = 2; cr = 0; nd = 48;  rc = 0xA; break;  case 18000: nb = 2; cr = 2; nd = 72;  rc = 0xE; break;
+    case 24000: nb = 4; cr = 0; nd = 96;  rc = 0x9; break;  case 36000: nb = 4; cr = 2; nd = 144; rc = 0xD; break;
+    case 48000: nb = 6; cr = 1; nd = 192; rc = 0x8; break;  default:    nb = 6; cr = 2; nd = 216; rc = 0xC; break;
+    }
+    // TBB11aSrc::Process (PHY_11a.hpp:132-202): SERVICE(2) + MPDU + FCS(4) + tail(1) + pad; rate 9 pads to two symbols
+    const uint32_t ndp = kbps == 9000 ? (uint32_t)nd * 2 : (uint32_t)nd;
+    const uint32_t dbytes = 2 + (L + 4) + 1;
+    const uint32_t rem = (dbytes * 8) % ndp, pad_bits = rem ? ndp - rem : 0;
+    const uint32_t nbytes = dbytes + (pad_bits + 7) / 8;
+    const uint32_t nsym = nbytes * 8 / (uint32_t)nd;
+
+    s_crc[tid] = T.crc[tid];
+    for (int i = tid; i < 6 * 8 * 16; i += 256) s_z[i] = T.crcz[i];
+    for (uint32_t i = tid; i < nbytes + 8; i += 256) s_data[i] = (i >= 2 && i < 2 + L) ? mp[i - 2] : (uint8_t)0;
+    __syncthreads();
+    if (tid < 64) {                                                              // FCS of the MPDU (PHY_11a.hpp:87,160-170)
+        uint32_t crc;
+        if (L >= 4) crc = crc32_wave(s_data + 2, (int)L, s_crc, s_z, tid);
+        else { crc = 0xFFFFFFFFu; for (uint32_t i = 0; i < L; i++) crc = (crc >> 8) ^ s_crc[(s_data[2 + i] ^ crc) & 0xFF]; }
+        if (tid == 0) s_fcs = ~crc;
+    }
+    __syncthreads();
+    if (tid < 4) s_data[2 + L + tid] = (uint8_t)(s_fcs >> (8 * tid));
+    __syncthreads();
+    {   // T11aSc (scramble.hpp:237-251): register = previous 8 output bits; the tail byte keeps only its two pad bits
+        const unsigned s7 = A.seed[f] >> 1;
+        const unsigned phase = T.scr_phase[s7];                                  // 255: the all-zero state stays zero
+        for (uint32_t i = tid; i < nbytes; i += 256) {
+            unsigned c = s_data[i] ^ (phase == 255 ? 0u : T.scr_seq[(phase + 8u * i) % 127u]);
+            if (i == dbytes - 1) c &= 0xC0u;
+            s_data[i] = (uint8_t)c;
+        }
+    }
+    for (int i = tid; i < 640; i += 256) reinterpret_cast<uint16_t*>(out)[i] = reinterpret_cast<const uint16_t*>(A.preamble)[i];
+    __syncthreads();
+
+    // PLCP SIGNAL (ieee80211a_cmn.h:8-26): RATE, LENGTH, even parity
+    uint32_t sig = (uint32_t)rc | ((L + 4) << 5);
+    sig |= (uint32_t)(__popc(sig) & 1) << 17;
+    auto sync = []() { __syncthreads(); };
+    const uint32_t total = 1 + nsym;                                             // SIGNAL + data symbols
+    for (uint32_t s0 = 0; s0 < total; s0 += 8) {
+        const uint32_t s = s0 + (uint32_t)g;
+        const bool active = s < total;
+        const bool is_sig = s == 0;
+        const int snb = is_sig ? 1 : nb, N = 48 * snb;
+        for (int i = e; i < 128; i += 32) s_bins[g][i] = 0;
+        if (active) {
+            // coded bits of the symbol, written at their interleaved positions
+            const uint16_t* map = T.deint + (snb == 1 ? 0 : snb == 2 ? 1 : snb == 4 ? 2 : 3) * 288;
+            for (int k = e; k < N; k += 32) {
+                unsigned b;
+                if (is_sig) b = coded_bit([&](int i) -> unsigned { return i < 0 ? 0u : (sig >> i) & 1u; }, k, 0);
+                else b = coded_bit([&](int i) -> unsigned { return i < 0 ? 0u : (s_data[i >> 3] >> (i & 7)) & 1u; }, (int)(s - 1) * N + k, cr);
+                s_ib[g][map[k]] = (uint8_t)b;
+            }
+        }
+        __syncthreads();
+        if (active) {
+            // TMap11a* + T11aAddPilot (mapper11a.hpp, pilot.hpp:76-118): carriers in the order -26..-1, +1..+26 without pilots
+            const int kmod = kmod_of(snb);
+            for (int c = e; c < 48; c += 32) {
+                const uint8_t* b = s_ib[g] + c * snb;
+                cpx v = snb == 1 ? mk(b[0] ? kBpskMod : -kBpskMod, 0) : mk(w16(qam_level(b, snb / 2, kmod)), w16(qam_level(b + snb / 2, snb / 2, kmod)));
+                int bin;
+                if (c < 24) { bin = 38 + c; if (bin >= 43) bin++; if (bin >= 57) bin++; }
+                else { bin = 1 + (c - 24); if (bin >= 7) bin++; if (bin >= 21) bin++; }
+                s_bins[g][bin < 32 ? bin : bin + 64] = pack(v);                   // TIFFTx: bins 32..63 go to 96..127
+            }
+            if (e < 4) {
+                const unsigned pidx = is_sig ? 127u : (unsigned)((s - 1) % 127u);  // m_PilotIndex 127 -> 0 after SIGNAL (pilot.hpp:66-69)
+                const int p = kPilotSgnTx[pidx] ? -kBpskMod : kBpskMod;
+                const int bin = e == 0 ? 7 : e == 1 ? 21 : e == 2 ? 64 - 7 : 64 - 21;
+                s_bins[g][bin < 32 ? bin : bin + 64] = pack(mk(e == 1 ? -p : p, 0));
+            }
+        }
+        ifft_emit(s_bins[g], s_sym[g], e, T, active ? out + 2 * (640 + 160 * (size_t)s) : (int8_t*)nullptr, sync);
+        __syncthreads();
+    }
+}
+
+}  // namespace sora

@@ -53,6 +53,19 @@ __global__ void k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Table
 __global__ void k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T);
 __global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
 __global__ void k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
+struct TxArgs {                // sora_hip_tx11a (k_tx.hip)
+    const uint8_t*  mpdu;      // MPDUs without FCS, frame f at mpdu + off[f]
+    const uint32_t* off;
+    const uint32_t* len;       // bytes without FCS (LENGTH = len + 4)
+    const uint32_t* rate;      // kbps
+    const uint8_t*  seed;      // scrambler register before the first byte (the harness uses 0xFF)
+    int8_t*         out8;      // COMPLEX8 stream
+    const uint64_t* out_off;   // first sample of frame f
+    const int8_t*   preamble;  // 640 samples
+    Tables          T;
+};
+__global__ void k_tx_preamble(int8_t* out8, Tables T);
+__global__ void k_tx11a(TxArgs A);
 __global__ void k_ingest(const uint8_t* raw, uint32_t* out, uint64_t m0, uint64_t n_out, unsigned flags);
 __global__ void k_ingest_tile(const uint8_t* raw, uint32_t* out, unsigned flags);
 __global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16);

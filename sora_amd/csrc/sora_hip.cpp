@@ -185,6 +185,7 @@ struct DevTables {
     Tables T{};
     std::vector<void*> allocs;
     int device = -1;
+    int8_t* tx_preamble = nullptr;      // 640 COMPLEX8 samples (k_tx_preamble), built on first use of the transmitter
 };
 
 template <typename V>
@@ -751,6 +752,48 @@ int sora_hip_deinterleave11a(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, si
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
     hipLaunchKernelGGL(k_deint_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_bpsc, (uint32_t)n, D->T);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+// ---- transmitter (row f2)
+static int tx_params(uint32_t kbps, int* nd)
+{
+    switch (kbps) { case 6000: *nd = 24; return 1; case 9000: *nd = 36; return 1; case 12000: *nd = 48; return 1; case 18000: *nd = 72; return 1;
+                    case 24000: *nd = 96; return 1; case 36000: *nd = 144; return 1; case 48000: *nd = 192; return 1; case 54000: *nd = 216; return 1; }
+    return 0;
+}
+
+size_t sora_hip_tx11a_samples(uint32_t mpdu_len_nofcs, uint32_t rate_kbps)
+{
+    int nd = 0;
+    if (!tx_params(rate_kbps, &nd) || mpdu_len_nofcs + 4 > 4095) return 0;
+    const uint32_t ndp = rate_kbps == 9000 ? (uint32_t)nd * 2 : (uint32_t)nd;     // PHY_11a.hpp:120-123
+    const uint32_t dbytes = 2 + (mpdu_len_nofcs + 4) + 1;
+    const uint32_t rem = (dbytes * 8) % ndp, pad_bits = rem ? ndp - rem : 0;
+    const uint32_t nbytes = dbytes + (pad_bits + 7) / 8;
+    return 640 + 160 * (size_t)(1 + nbytes * 8 / (uint32_t)nd);
+}
+
+int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t* d_len, const uint32_t* d_rate_kbps, const uint8_t* d_seed,
+                   size_t nframes, int8_t* d_out, const uint64_t* d_out_off, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_mpdu || !d_off || !d_len || !d_rate_kbps || !d_seed || !d_out || !d_out_off) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_tx11a: null pointer");
+    if (nframes == 0) return SORA_OK;
+    DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
+    hipStream_t st = (hipStream_t)stream;
+    if (!D->tx_preamble) {
+        int8_t* p = nullptr;
+        HIPCHK(hipMalloc((void**)&p, 1280));
+        hipLaunchKernelGGL(k_tx_preamble, dim3(1), dim3(64), 0, st, p, D->T);
+        HIPCHK(hipGetLastError());
+        D->tx_preamble = p; D->allocs.push_back(p);
+    }
+    TxArgs A{};
+    A.mpdu = d_mpdu; A.off = d_off; A.len = d_len; A.rate = d_rate_kbps; A.seed = d_seed; A.out8 = d_out; A.out_off = d_out_off;
+    A.preamble = D->tx_preamble; A.T = D->T;
+    hipLaunchKernelGGL(k_tx11a, dim3((unsigned)nframes), dim3(256), 0, st, A);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
