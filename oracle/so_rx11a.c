@@ -626,6 +626,7 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
     uint32_t w_cnt = 0, r_cnt = 0;
     uint32_t q_base = 0;                                                   /* source index (queue units) of q[0] */
     uint32_t src = 0, remain = nsamples;                                   /* in queue units (raw @40, samples @20) */
+    uint32_t consumed = 0;                                                 /* 20 MHz index behind the last burst handed to the graph */
     int ret = 1;
     while (ret) {
         /* ---- ssrc->Process() */
@@ -644,6 +645,7 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
                 for (uint32_t e = 0; e < 4; e++) v.v[e] = q[r_cnt + e * STR];
                 rx->pos20 = (q_base + r_cnt) / STR;
                 r_cnt += BUR;
+                consumed = (q_base + r_cnt) / STR;                         /* before the drained queue forgets its extent */
                 if (r_cnt == w_cnt) r_cnt = w_cnt = 0;
                 push_vcs(rx, &v);
             }
@@ -656,7 +658,7 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
                 rx->error_code = SO_E_SUCCESS; rx->cca_detected = 0;
                 cs_brick_reset(&rx->cs);
             } else {
-                rx->pos20 = (q_base + r_cnt) / STR;
+                rx->pos20 = consumed;                                      /* end_sample of a PLCP failure: the samples taken from the source so far */
                 emit_result(rx, err);
                 /* Flush + Reset: every pin queue is cleared, including the source's partial burst */
                 w_cnt = r_cnt = 0;
