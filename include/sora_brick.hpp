@@ -130,6 +130,34 @@ public:
     template <class T_IPIN> bool Process(T_IPIN& ipin) { while (ipin.check_read()) ipin.pop(); return true; }
 };
 
+// TDownSample44_40 (sampling.hpp:35-66) / TDownSample2 (samples.hpp:9-47) as one filter over a whole capture: the
+// input pin holds NIN COMPLEX16 (a multiple of 28), the output pin what sora_hip_ingest_count says comes out of it.
+template <size_t NIN, unsigned FLAGS, class T_CTX, class T_NEXT>
+class THipResample : public HipFilter<T_CTX, T_NEXT> {
+    static_assert(NIN % 28 == 0 && !(FLAGS & SORA_INGEST_RXBLOCK), "whole RX blocks of plain samples");
+public:
+    static constexpr size_t NOUT = NIN;                          // capacity; the produced count is returned by produced()
+    using iport_traits = port_traits<sora_complex16, NIN>;
+    using oport_traits = port_traits<sora_complex16, NOUT>;
+    THipResample(T_CTX& ctx, T_NEXT* next, sora_complex16* d_out, void* stream = nullptr)
+        : HipFilter<T_CTX, T_NEXT>(ctx, next, stream), opin_(d_out) {}
+    template <class T_IPIN> bool Process(T_IPIN& ipin)
+    {
+        while (ipin.check_read()) {
+            sora_complex16* out = opin_.append();
+            if (!this->raise(sora_hip_ingest(ipin.peek(), NIN * sizeof(sora_complex16), FLAGS, out, NOUT, &produced_, this->stream_))) return false;
+            ipin.pop();
+            if (this->next_ && !this->next_->Process(opin_)) return false;
+        }
+        return true;
+    }
+    size_t produced() const { return produced_; }
+    DevicePin<sora_complex16, NOUT>& opin() { return opin_; }
+private:
+    DevicePin<sora_complex16, NOUT> opin_;
+    size_t produced_ = 0;
+};
+
 // ISource over a batch of captures = the whole demod graph behind one handle (brick.h:343-353: Process/Seek/Reset/Flush).
 class THipRx11aSource {
 public:

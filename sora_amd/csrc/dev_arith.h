@@ -64,7 +64,6 @@ struct Tables {
     const uint16_t* deint;       // [4][288] de-interleaver source index per output position (BPSK,QPSK,QAM16,QAM64)
     const uint32_t* crc;         // [256]
     const uint8_t*  scr;         // [128]
-    const uint32_t* crc8;        // [8][256] slicing-by-8 CRC-32 tables (table 0 == crc)
     const uint8_t*  scr_seq;     // [127] scrambler byte starting at cycle position q
     const uint8_t*  scr_phase;   // [128] cycle position of a 7-bit descrambler seed (255 for seed 0)
     const uint32_t* tw128;       // [3][32] packed W128^{k j}

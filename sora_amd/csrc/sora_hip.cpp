@@ -35,7 +35,7 @@ struct HostTables {
     std::vector<uint32_t> tw64, tw16, sts, crc, tw128, tw32, tw8;
     std::vector<uint16_t> deint;
     std::vector<uint8_t> scr, scr_seq, scr_phase;
-    std::vector<uint32_t> crc8, crcz;
+    std::vector<uint32_t> crcz;
 };
 
 static inline uint32_t pk(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
@@ -144,11 +144,6 @@ static void build_tables(HostTables& H)
     }
     H.crc.resize(256);
     for (uint32_t i = 0; i < 256; i++) { uint32_t c = i; for (int k = 0; k < 8; k++) c = (c & 1) ? (c >> 1) ^ 0xEDB88320u : c >> 1; H.crc[i] = c; }
-    H.crc8.resize(8 * 256);                                  // slicing-by-8: T_k[i] = CRC of byte i followed by k zero bytes
-    for (uint32_t i = 0; i < 256; i++) {
-        uint32_t c = H.crc[i]; H.crc8[i] = c;
-        for (int k = 1; k < 8; k++) { c = (c >> 8) ^ H.crc[c & 0xFF]; H.crc8[k * 256 + i] = c; }
-    }
     // parallel CRC (k_finish): Z_m(x) = register x after m zero bytes is linear in x, so it is the xor of 8 nibble look-ups;
     // levels m = 40 * 2^k combine the 64 lanes' 40-byte segment CRCs in a tree
     H.crcz.resize(6 * 8 * 16);
@@ -214,7 +209,6 @@ static int make_dev_tables(DevTables& D)
     if ((rc = upload(D, H.deint, (const void**)&D.T.deint))) return rc;
     if ((rc = upload(D, H.crc, (const void**)&D.T.crc))) return rc;
     if ((rc = upload(D, H.scr, (const void**)&D.T.scr))) return rc;
-    if ((rc = upload(D, H.crc8, (const void**)&D.T.crc8))) return rc;
     if ((rc = upload(D, H.scr_seq, (const void**)&D.T.scr_seq))) return rc;
     if ((rc = upload(D, H.scr_phase, (const void**)&D.T.scr_phase))) return rc;
     if ((rc = upload(D, H.tw128, (const void**)&D.T.tw128))) return rc;

@@ -101,6 +101,11 @@ int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, ui
     src.append();
     bool ok = fft.Process(src);
     fft.Reset(); fft.Flush();
+    // TDownSample44_40 in front of a graph: 44 MHz samples in, 40 MHz out
+    THipResample<28 * 40, SORA_INGEST_44TO40, CF_Error, TDrop<CF_Error>> down(ctx, &drop, d_fft);
+    DevicePin<sora_complex16, 28 * 40> raw(d_in);
+    raw.append();
+    ok = ok && down.Process(raw) && down.produced() <= 28 * 40;
     return ok ? 0 : (int)ctx.error_code;
 }
 """)
