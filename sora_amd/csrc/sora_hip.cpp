@@ -1,7 +1,7 @@
 // sora_hip.cpp -- host side of libsora_hip.so: the C ABI of include/sora_hip.h.
 //
-// Owns, per handle: one HIP stream, the look-up tables in HBM, and every intermediate array of the
-// receive path (sized once from sora_rx_cfg, see rx_types.h).  There is NO CPU compute path here:
+// Owns, per handle: up to four pipelines (a HIP stream, the look-up tables in HBM and every intermediate array of the
+// receive path, sized once from sora_rx_cfg, see rx_types.h) used round-robin by consecutive process calls.  There is NO CPU compute path here:
 // every entry point either enqueues HIP kernels or fails.
 #include <hip/hip_runtime.h>
 #include <cmath>
@@ -27,8 +27,9 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 #define HIPCHK(call) do { hipError_t _e = (call); if (_e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, #call, _e); } while (0)
 
 // ------------------------------------------------------------------------------------------------
-// Look-up tables, regenerated from closed forms (each was checked entry-for-entry against the reference
-// header it replaces; tests/test_capi_tables.py pins their checksums through sora_hip_table_checksum).
+// Look-up tables, regenerated from closed forms (each was checked entry-for-entry against the reference header it
+// replaces; the oracle's copies of the same closed forms are sha256-pinned in tests/test_oracle_luts.py, and every GPU
+// parity test exercises these).
 struct HostTables {
     std::vector<int16_t> usin, ucos, uatan2;
     std::vector<uint8_t> demap;
