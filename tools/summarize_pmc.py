@@ -34,6 +34,7 @@ def main():
            "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024 as reported",
            "kernels": {}}
     total = 0.0
+    rx_path = ("k_scan", "k_frame", "k_viterbi", "k_finish")                  # one receive call; other kernels (ingest, tx) are listed only
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
@@ -41,7 +42,8 @@ def main():
         wb = write.get(k, (0.0, 0))[0] * 1024
         out["kernels"][k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb),
                              "launches_sampled": fetch.get(k, (0.0, 0))[1]}
-        total += fb + wb
+        if k in rx_path:
+            total += fb + wb
     out["total_hbm_bytes_per_call"] = round(total)
     out["algorithmic_bytes_per_call"] = round(frames * 4880 * 4.3375)
     json.dump(out, sys.stdout, indent=1)
