@@ -135,22 +135,25 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
 
     uint32_t vpos = 0;                              // next burst start, in queue units
     // ---- idle fast path.  While no carrier is in sight (energy/auto-correlation test false, cca.hpp:386-437) a burst only
-    // feeds the sliding sums, the history, the DC estimator and the time-out counter.  Up to 4 bursts are then taken at
+    // feeds the sliding sums, the history, the DC estimator and the time-out counter.  Up to 8 bursts are then taken at
     // once, one sample per lane (lane = 4 b + e): the per-sample products run once instead of per burst per lane, the
-    // per-burst bookkeeping (12 sliding-sum updates, the test, counters) stays scalar.  The group never crosses a source
-    // call (error_code is examined there) nor a DC update (the estimate changes what the next burst sees), and stops in
-    // front of the first burst whose test is true -- that burst goes through the full path below.
+    // per-burst bookkeeping (sliding-sum updates, the test, counters) stays scalar.  The group contains a DC update at
+    // most at its last burst (the estimate changes what the next burst sees), stays inside the source call when the
+    // carrier-sense time-out will fire in it (error_code is examined, and the brick reset, at the end of that call), and
+    // stops in front of the first burst whose test is true -- that burst goes through the full path below.
     auto fast_idle = [&](uint32_t K) -> uint32_t {
-        if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) {      // stage the next 64 units (one coalesced load)
+        if (vpos - win_base + K * BUR > 64u || win_base == 0xFFFFFFFFu) {       // stage the next 64 units (one coalesced load)
             win_base = vpos;
             win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
         }
-        const uint32_t l = (uint32_t)lane & 15u;
+        const uint32_t l = (uint32_t)lane & 31u, hi = (uint32_t)lane & 32u;    // lanes 32..63 mirror lanes 0..31
         const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
         const cpx x = unpack(raw);
         const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));                // TDCRemoveEx
         const cpx pii = sra(pi, 2);
-        int re, im; conj_mul32(pii, unpack(Hv), re, im);                        // against the sample 16 earlier
+        const uint32_t ppk = pack(pii);
+        const uint32_t prev = (uint32_t)__shfl((int)ppk, (int)(hi | ((l - 16u) & 31u)));
+        int re, im; conj_mul32(pii, unpack(l < 16u ? Hv : prev), re, im);       // against the sample 16 earlier
         unsigned vr = (unsigned)(re >> 4), vi = (unsigned)(im >> 4), ve = (unsigned)(sqnorm(pii) >> 4);
         unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);     // TDCEstimator terms
         vr += (unsigned)__shfl_xor((int)vr, 1); vi += (unsigned)__shfl_xor((int)vi, 1); ve += (unsigned)__shfl_xor((int)ve, 1);
@@ -159,7 +162,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
         dr += (unsigned)__shfl_xor((int)dr, 2); di += (unsigned)__shfl_xor((int)di, 2);
         uint32_t done = 0;
 #pragma unroll
-        for (int b = 0; b < 4; b++) {
+        for (int b = 0; b < 8; b++) {
             if ((uint32_t)b < K && done == (uint32_t)b) {
                 const int sr = __builtin_amdgcn_readlane((int)vr, 4 * b), si = __builtin_amdgcn_readlane((int)vi, 4 * b), se = __builtin_amdgcn_readlane((int)ve, 4 * b);
                 Acc4 tr_ = ac_re, ti_ = ac_im, te_ = energy;
@@ -181,9 +184,10 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
             }
         }
         if (done) {                                                             // history <- its last 16 samples
-            const uint32_t src = ((uint32_t)lane & 48u) | ((l + 4u * done) & 15u);
-            const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)src), fresh = (uint32_t)__shfl((int)pack(pii), (int)src);
-            Hv = (l + 4u * done < 16u) ? keep : fresh;
+            const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;   // index in {old history 0..15, new samples 16..47}
+            const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)(((uint32_t)lane & 48u) | (src & 15u)));
+            const uint32_t fresh = (uint32_t)__shfl((int)ppk, (int)(hi | ((src - 16u) & 31u)));
+            Hv = src < 16u ? keep : fresh;
             vpos += done * BUR;
         }
         return done;
@@ -238,8 +242,10 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
         const uint32_t avail_end = (c + 1) * APP;
         while (vpos + BUR <= avail_end) {
             if (!cca_detected && !sync_high && auto_count == 0) {
-                const uint32_t K = min(min((avail_end - vpos) / BUR, dc_cnt + 1u), 4u);
-                if (fast_idle(K)) continue;
+                // bursts until the carrier-sense time-out is raised; if that is near, stay inside this source call
+                const uint32_t to_timeout = sense_count >= 84 ? 0u : (84u - sense_count + 3u) / 4u;
+                const uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
+                if (fast_idle(min(min(room, dc_cnt + 1u), 8u))) continue;
             }
             if (!cca_detected && sync_high) {
                 fast_sync(min((avail_end - vpos) / BUR, 4u - high_count % 4u));
