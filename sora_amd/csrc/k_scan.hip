@@ -283,7 +283,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                             int sum_corr = 0, best = 0, best_i = 0;
 #pragma unroll
                             for (int p = 0; p < 16; p++) {
-                                int cp = __shfl(corr, p);
+                                const int cp = __builtin_amdgcn_readlane(corr, p);          // wave-uniform from here on
                                 if (cp > best) { best = cp; best_i = p; }
                                 sum_corr += cp;
                             }
@@ -324,8 +324,8 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                     cpx x1 = sra(unpack(s_x[8 + lane]), 1);
                     cpx x2 = unpack(s_x[8 + 64 + lane]);
                     int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
-                    const int sum_re = wave_sum(re >> 5), sum_im = wave_sum(im >> 5);
-                    const int arg = uatan2(T, sum_im, sum_re);
+                    const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
+                    const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
                     const int cfo = w16(arg / 64);
                     // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
                     const cpx fc = rot_coeff(T, w16(lane * cfo));
@@ -396,8 +396,8 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                         sync();
                         // _pilot_track (pilot.hpp:166-233), symbol_count = 127 -> PilotSgn[127] = 0
                         cpx p43 = unpack(s_fft[43]), p57 = unpack(s_fft[57]), p7 = unpack(s_fft[7]), p21 = unpack(s_fft[21]);
-                        const int th1 = uatan2(T, p43.im, p43.re), th2 = uatan2(T, p57.im, p57.re);
-                        const int th3 = uatan2(T, p7.im, p7.re),   th4 = uatan2(T, -p21.im, -p21.re);
+                        const int th1 = __builtin_amdgcn_readfirstlane(uatan2(T, p43.im, p43.re)), th2 = __builtin_amdgcn_readfirstlane(uatan2(T, p57.im, p57.re));
+                        const int th3 = __builtin_amdgcn_readfirstlane(uatan2(T, p7.im, p7.re)),   th4 = __builtin_amdgcn_readfirstlane(uatan2(T, -p21.im, -p21.re));
                         const int avg = w16((th1 + th2 + th3 + th4) / 4);
                         const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
                         const int cfo_tracker = w16(avg >> 2), sfo_tracker = w16(del >> 2);
@@ -440,6 +440,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                         unsigned key = (m << 8) | ((unsigned)n << 2), kmin = key;
 #pragma unroll
                         for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+                        kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
                         int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
                         sync();                                                     // s_dec complete
                         uint32_t sig = 0;
@@ -450,7 +451,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                             pos = (pos >> 1) & 0x3F;
                             pos |= (int)((s_dec[23 - b] >> pos) & 1) << 6;
                         }
-                        sig >>= 6;                                                  // viterbi.hpp:39
+                        sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;     // viterbi.hpp:39 (wave-uniform)
                         // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
                         bool ok = true;
                         sig &= 0xFFFFFF;
