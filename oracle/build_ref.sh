@@ -71,3 +71,12 @@ EOF
     -msse4.1 -mssse3 -Wno-everything \
     -I"$TMP" "$HERE/ref_shim.cpp" -o "$OUT/libsora_ref.so"
 echo "build_ref.sh: built $OUT/libsora_ref.so"
+
+# ---- the reference's BRICK graphs themselves (oracle/ref_flatten.py patches a scratch copy; oracle/ref_compat.h
+#      supplies the Windows integer model) -> oracle/_ref/libsora_refgraph.so
+python3 "$HERE/ref_flatten.py" "$TMP/flat"
+"$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden \
+    -fms-extensions -fms-compatibility -fms-compatibility-version=19.00 -fdelayed-template-parsing -fno-operator-names \
+    -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" \
+    -I"$TMP/flat" "$HERE/ref_graph_shim.cpp" -o "$OUT/libsora_refgraph.so"
+echo "build_ref.sh: built $OUT/libsora_refgraph.so"

@@ -12,6 +12,7 @@ import numpy as np
 HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "libsora_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsora_ref.so")
+REFGRAPH_SO = os.path.join(HERE, "_ref", "libsora_refgraph.so")
 
 E_SUCCESS = 0x0
 E_FRAME_OK = 0x1
@@ -54,8 +55,9 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE])
     ref_root = os.environ.get("SORA_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref_root, "kernel", "core", "inc")):
-        shim = os.path.join(HERE, "ref_shim.cpp")
-        if force or not os.path.exists(REF_SO) or os.path.getmtime(shim) > os.path.getmtime(REF_SO):
+        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_flatten.py", "ref_compat.h", "build_ref.sh")]
+        if force or any(not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
+                        for so in (REF_SO, REFGRAPH_SO)):
             subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
 
 
@@ -230,3 +232,29 @@ class Reference:
 
     def crc32(self, b):
         a = np.frombuffer(bytes(b), np.uint8); return self.L.ref_crc32(_P(a), len(a))
+
+
+class RefFrame(ctypes.Structure):
+    _fields_ = [(n, ctypes.c_uint32) for n in ("error_code", "sample_index", "rate_kbps", "length", "crc32", "mpdu_offset")]
+
+
+class ReferenceGraph:
+    """The reference's own BRICK graphs compiled from its sources (oracle/_ref/libsora_refgraph.so, build_ref.sh).
+    NOT thread-safe and one instance per process: the reference keeps its graph context in globals."""
+    def __init__(self):
+        self.L = ctypes.CDLL(REFGRAPH_SO) if os.path.exists(REFGRAPH_SO) else None
+
+    def available(self): return self.L is not None
+
+    def rx11a(self, iq40, max_frames=64):
+        """iq40: int16 [n,2] at 40 MHz.  -> list of dict(error_code, sample_index (40 MHz source position when
+        RxThread sees the event), rate_kbps, length, crc32, mpdu)."""
+        iq = np.ascontiguousarray(iq40, np.int16).reshape(-1, 2)
+        res = (RefFrame * max_frames)(); mp = np.zeros(max_frames * 2504, np.uint8)
+        n = self.L.ref_rx11a_capture(_P(iq), len(iq), res, max_frames, _P(mp), mp.size)
+        out = []
+        for r in res[:n]:
+            d = {f: getattr(r, f) for f, _ in RefFrame._fields_}
+            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            out.append(d)
+        return out

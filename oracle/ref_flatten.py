@@ -1,0 +1,93 @@
+#!/usr/bin/env python3
+"""ref_flatten.py <scratch-dir> -- TEST INFRASTRUCTURE ONLY (used by oracle/build_ref.sh).
+
+Lays the reference's BRICK headers (kernel/core/inc, kernel/brick/inc, kernel/bb/Brick11/src, kernel/bb/demod11,
+kernel/inc) out flat in a SCRATCH directory and patches, there, the constructs that only MSVC accepts, so that clang in
+-fms-compatibility mode can compile the reference's own demodulation / modulation graphs on Linux.  Nothing is written
+into this repository: the scratch directory is deleted by build_ref.sh after the compile, the only product is
+oracle/_ref/libsora_refgraph.so (git-ignored).  Every patch below names what it works around; none changes arithmetic.
+"""
+import glob
+import os
+import re
+import shutil
+import sys
+
+REF = os.environ.get("SORA_REFERENCE", "/root/reference") + "/kernel"
+OUT = sys.argv[1]
+
+shutil.rmtree(OUT, ignore_errors=True)
+os.makedirs(OUT + "/bb")
+for d in ("core/inc", "brick/inc", "bb/Brick11/src", "bb/demod11", "inc"):
+    for f in glob.glob(f"{REF}/{d}/*.h") + glob.glob(f"{REF}/{d}/*.hpp"):
+        shutil.copy(f, OUT + "/" + os.path.basename(f))
+for f in glob.glob(f"{REF}/inc/bb/*.h"):
+    shutil.copy(f, OUT + "/bb/" + os.path.basename(f))
+
+
+def write(name, text, mode="w"):
+    with open(OUT + "/" + name, mode, encoding="latin-1") as fh:
+        fh.write(text)
+
+
+def edit(name, fn):
+    p = OUT + "/" + name
+    s = open(p, encoding="latin-1").read()
+    t = fn(s)
+    if t == s:
+        raise SystemExit("ref_flatten.py: patch had no effect on " + name + " (reference layout changed?)")
+    write(name, t)
+
+
+# ---- Windows SDK / WDK headers the sources include by name: empty stand-ins (types come from ref_compat.h)
+for h in ("windows.h", "Windows.h", "winerror.h", "guiddef.h", "process.h", "windef.h"):
+    write(h, "#pragma once\n")
+write("typeinfo.h", "#pragma once\n#include <typeinfo>\n")
+write("new.h", "#pragma once\n#include <new>\n")
+
+# ---- vector128.h: hand re-declared intrinsics (lines 26-81) and two wrappers of intrinsics that do not exist
+def v128(s):
+    lines = s.split("\n")
+    del lines[25:81]
+    s = "\n".join(lines).replace("#include <emmintrin.h>", "#include <immintrin.h>")
+    return "\n".join(l for l in s.split("\n") if "_mm_sign_epi64" not in l and "_mm_abs_epi64" not in l)
+edit("vector128.h", v128)
+
+# ---- driver-side umbrella headers: the offline graphs need only the arithmetic headers behind them
+write("sora.h", '#pragma once\n#include "const.h"\n#include "complex.h"\n#include "vector128.h"\n#include "func.h"\n'
+                "typedef struct _SORA_RADIO_RX_STREAM SORA_RADIO_RX_STREAM, *PSORA_RADIO_RX_STREAM;\n")
+write("soratypes.h", '#pragma once\n#include "const.h"\n#include "complex.h"\n'
+                     "typedef COMPLEX16 SAMPLE, *PSAMPLE, RXSAMPLE, *PRXSAMPLE; typedef COMPLEX8 TXSAMPLE, *PTXSAMPLE;\n"
+                     "typedef char FLAG, *PFLAG;\n#define MAX_RADIO_NUMBER 8\n")
+write("brickutil.h", "#pragma once\n")           # dump-file loader (the shim gets samples from its caller)
+write("soratime.h", "#pragma once\nstruct SoraStopwatch { SoraStopwatch(bool = false) {} void Restart() {} void Stop() {} void Start() {} void Reset() {} };\n")
+write("MACStopwatch.h", "#pragma once\nstruct MACStopwatch { template<class... A> void LeaveRX(A...) {} template<class... A> void EnterRX(A...) {}"
+                        " template<class... A> void LeaveCS(A...) {} template<class... A> void EnterCS(A...) {} void OutputStats() {} };\n")
+edit("dspcomm.h", lambda s: s.replace("typedef unsigned long\tulong;", "").replace("typedef COMPLEX8        TXSAMPLE;", "")
+     .replace("typedef COMPLEX16       RXSAMPLE;", ""))
+edit("stdbrick.hpp", lambda s: s.replace("#include <rxstream.hpp>", ""))      # live radio source
+edit("bb/bba.h", lambda s: s.replace('"../../brick/inc/bb_debug.h"', '"bb_debug.h"'))
+
+# ---- brick.h: MSVC lets trailing macro arguments be omitted, accepts "(TYPE) (&NAME)" declarators and binds the
+#      base-class names of templates late (IControlPoint / DummyBrickInstance are used before they are declared)
+def brick(s):
+    for m in ("FACADE_FIELD", "REFERENCE_SHARED_VAR", "DEFINE_SHARED_VAR", "CTX_VAR_RW", "CTX_VAR_RO"):
+        s = s.replace("#define %s(TYPE, NAME, DIMENSIONS)" % m, "#define %s(TYPE, NAME, ...)" % m)
+    s = (s.replace("__##NAME##__ DIMENSIONS;", "__##NAME##__ __VA_ARGS__;")
+          .replace("(&NAME()) DIMENSIONS {", "(&NAME()) __VA_ARGS__ {")
+          .replace("shared_var_reference<TYPE DIMENSIONS> NAME;", "shared_var_reference<TYPE __VA_ARGS__> NAME;")
+          .replace("TYPE NAME DIMENSIONS;", "TYPE NAME __VA_ARGS__;")
+          .replace("(TYPE) (&NAME) DIMENSIONS;", "TYPE (&NAME) __VA_ARGS__;")
+          .replace("(TYPE) const (&NAME) DIMENSIONS;", "TYPE const (&NAME) __VA_ARGS__;"))
+    body = re.search(r"struct IControlPoint : public IQueryable\s*\{.*?\};\s*", s, flags=re.S).group(0)
+    s = s.replace(body, "").replace("// Brick - Sink", body + "\n// Brick - Sink", 1)
+    return s.replace('#include "demux.h"', "", 1) + '\n#include "demux.h"\n'
+edit("brick.h", brick)
+# ---- pinqueue.h: members of a dependent base named at class scope
+edit("pinqueue.h", lambda s: s.replace("[nstream][qsize]", "[NSTREAM][lcm<N,M>::value]")
+     .replace("[NSTREAM][lcm<N,M>::value], unsigned int cnt)", "[NSTREAM][N], unsigned int cnt)"))
+
+# ---- the 11a receive graph: the hop to the decoder thread becomes a same-thread pass-through (TNoInline swallows the
+#      sink's "stop" like the thread boundary does).  This is the deterministic limit of the two-thread harness -- an
+#      infinitely fast ViterbiThread -- which is also what oracle/so_rx11a.c and the GPU path implement.
+edit("fb11ademod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))

@@ -1,0 +1,53 @@
+// ref_graph_shim.cpp -- TEST INFRASTRUCTURE ONLY (not shipped, not linked into libsora_hip.so).
+//
+// extern "C" entry points around the REFERENCE's own BRICK graphs, compiled from the sources where they lie under
+// /root/reference by oracle/build_ref.sh (clang -fms-compatibility over a scratch copy patched by oracle/ref_flatten.py)
+// into oracle/_ref/libsora_refgraph.so.  This is the reference's receive path itself -- every brick, pin queue and
+// facade of kernel/bb/demod11/fb11ademod_config.hpp:168-233 -- so tests/ can pin the C restatement (oracle/so_rx11a.c)
+// and the GPU path on arbitrary captures, and bench.py can time "the reference SSE path on this box's host cores".
+#include "MACStopwatch.h"      // scratch stand-in (ref_flatten.py); the .cpp files of demod11 include it before the configs
+#include "stdbrick.hpp"
+#include "fb11ademod_config.hpp"
+
+#define EXPORT extern "C" __attribute__((visibility("default")))
+
+struct ref_frame { uint32_t error_code, sample_index, rate_kbps, length, crc32, mpdu_offset; };
+
+static ISource* g_src; static ISource* g_vit; static IControlPoint* g_cs;
+static unsigned char g_out[4096];                    // OUTPUTBUF_SIZE (fb11a_demod.cpp:20)
+static COMPLEX16* g_buf; static uint32_t g_cap;
+
+// Test11A_FB_Demod + RxThread (fb11a_demod.cpp:29-81, 88-120) over a capture in memory, the events recorded instead
+// of printed.  sample_index = CF_MemSamples::mem_sample_index() when RxThread sees the event (40 MHz samples).
+// Returns the number of events (frames and header failures); CS time-outs are handled as RxThread handles them.
+EXPORT int ref_rx11a_capture(const int16_t* iq, uint32_t nsamples40, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
+{
+    if (g_cap < nsamples40 + 64) { free(g_buf); g_cap = nsamples40 + 64; g_buf = (COMPLEX16*)aligned_alloc(16, ((size_t)g_cap * 4 + 15) & ~(size_t)15); }
+    memcpy(g_buf, iq, (size_t)nsamples40 * 4);
+    BB11aDemodCtx.Init(g_buf, nsamples40 * sizeof(COMPLEX16), g_out, sizeof(g_out));
+    if (!g_src) CreateDemodGraph11a_40M(g_src, g_vit, g_cs);
+    else g_src->Seek(ISource::START_POS);             // the graph is built once; rewind the memory source
+    g_src->Flush(); BB11aDemodCtx.Reset(); g_src->Reset();
+    int n = 0; uint32_t used = 0; uint nWaitCounter = 12;
+    for (;;) {
+        bool rc = g_src->Process();
+        ulong err = BB11aDemodCtx.CF_Error::error_code();
+        if (err != E_ERROR_SUCCESS) {
+            if (err == E_ERROR_CS_TIMEOUT) {
+                BB11aDemodCtx.ResetCarrierSense(); g_cs->Reset();
+                if (nWaitCounter > 0) { nWaitCounter--; continue; }
+                nWaitCounter = 12; continue;         // RxThread returns TRUE here and the thread wrapper calls it again (AllocStartThread)
+            }
+            if (n < max_res) {
+                ref_frame& f = res[n++];
+                f.error_code = err; f.sample_index = BB11aDemodCtx.CF_MemSamples::mem_sample_index();
+                f.rate_kbps = BB11aDemodCtx.CF_11aRxVector::data_rate_kbps(); f.length = BB11aDemodCtx.CF_11aRxVector::frame_length();
+                f.crc32 = BB11aDemodCtx.CF_11aRxVector::crc32(); f.mpdu_offset = used;
+                if ((err == E_ERROR_FRAME_OK || err == E_ERROR_CRC32_FAIL) && used + f.length <= mpdu_cap) { memcpy(mpdu + used, g_out, f.length); used += f.length; }
+            }
+            g_src->Flush(); BB11aDemodCtx.Reset(); g_src->Reset();
+        }
+        if (!rc) break;
+    }
+    return n;
+}

@@ -46,7 +46,9 @@ void so_lts(so_rx11a_ctx* c, const so_c16 in144[144])
         sum_re = so_w32((int64_t)sum_re + sr); sum_im = so_w32((int64_t)sum_im + si);
     }
     int16_t arg = so_uatan2(sum_im, sum_re);
-    c->CFO_est = (int16_t)(arg / 64);                                  /* C division, truncating */
+    /* "arg / (LEN*vcs::size)": the divisor is a size_t, so arg is converted to UNSIGNED first and the quotient, cut
+     * back to 16 bits, is the FLOOR of arg/64 (-438 -> -7, not -6) -- on 32- and 64-bit builds alike (dspalg.hpp:242) */
+    c->CFO_est = (int16_t)(arg >> 6);
     c->CFO_comp = c->SFO_comp = 0; c->CFO_tracker = c->SFO_tracker = 0;/* :107-112 */
 
     /* BuildFrequencyShiftCoeffs<64>(FreqCoeffs, 0, CFO_est): dspalg.hpp:200-208 */

@@ -326,7 +326,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                     int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
                     const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
                     const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
-                    const int cfo = w16(arg / 64);
+                    const int cfo = arg >> 6;                   // size_t divisor: unsigned division = floor (dspalg.hpp:242)
                     // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
                     const cpx fc = rot_coeff(T, w16(lane * cfo));
                     FrameCtx* fx = A.fctx + (size_t)cap_i * A.max_frames + nfr;

@@ -39,7 +39,7 @@ __global__ void __launch_bounds__(64) k_lts_batch(const uint32_t* in, uint32_t* 
     cpx x2 = unpack(s_x[8 + 64 + lane]);
     int re, im; conj_mul32(x2, x1, re, im);                                    // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
     const int sum_re = wave_sum_i(re >> 5), sum_im = wave_sum_i(im >> 5);
-    const int cfo = w16(uatan2(T, sum_im, sum_re) / 64);
+    const int cfo = uatan2(T, sum_im, sum_re) >> 6;          // size_t divisor: unsigned division = floor (dspalg.hpp:242)
     const cpx fc = rot_coeff(T, w16(lane * cfo));                               // BuildFrequencyShiftCoeffs<64> (dspalg.hpp:200-208)
     uint32_t* o = ctx + (size_t)f * 129;
     if (lane == 0) o[0] = (uint32_t)cfo & 0xFFFFu;

@@ -7,7 +7,11 @@
   ref_vectors.npz        input/output pairs produced by the reference's OWN SSE kernels compiled into
                          oracle/_ref/libsora_ref.so (FFT<64>/IFFT<64>/IFFT<128>, vcs mul, demap LUT walk,
                          Viterbi_sig11, TViterbiCore frame decodes at 1/2, 2/3, 3/4 under noise, Down44to40).
-Both files travel to the GPU box; /root/reference does not.
+  refgraph_events.npz    what the reference's OWN receive graph (oracle/_ref/libsora_refgraph.so = CreateDemodGraph11a_40M
+                         compiled from the reference sources) reports for 400 seeded random captures
+                         (tests/gpu_util.random_capture): per event the capture index, error code, source position,
+                         FCS and the first 8 bytes of the MPDU's sha256.
+All files travel to the GPU box; /root/reference does not.
 """
 import hashlib
 import os
@@ -17,7 +21,9 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
-from oracle.pyoracle import Oracle, Reference, CR_12, CR_23, CR_34  # noqa: E402
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+from oracle.pyoracle import Oracle, Reference, ReferenceGraph, CR_12, CR_23, CR_34  # noqa: E402
+from gpu_util import random_capture  # noqa: E402
 
 REF = os.environ.get("SORA_REFERENCE", "/root/reference")
 OUT = os.path.dirname(os.path.abspath(__file__))
@@ -74,6 +80,21 @@ def main():
     v["down44_in"] = r44
     v["down44_out"] = R.down44to40(r44)
     np.savez_compressed(os.path.join(OUT, "ref_vectors.npz"), **v)
+
+    # events of the reference's own receive graph on seeded random captures
+    G = ReferenceGraph()
+    assert G.available(), "build oracle/_ref first (oracle/build_ref.sh)"
+    seed, ncap = 20260926, 400
+    rng = np.random.default_rng(seed)
+    ev = {"capture": [], "error": [], "position": [], "crc32": [], "sha": []}
+    for i in range(ncap):
+        for e in G.rx11a(random_capture(O, rng, 40)):
+            ev["capture"].append(i); ev["error"].append(e["error_code"]); ev["position"].append(e["sample_index"])
+            ev["crc32"].append(e["crc32"]); ev["sha"].append(np.frombuffer(hashlib.sha256(e["mpdu"]).digest()[:8], np.uint8))
+    np.savez_compressed(os.path.join(OUT, "refgraph_events.npz"), seed=seed, captures=ncap,
+                        ev_capture=np.array(ev["capture"], np.int32), ev_error=np.array(ev["error"], np.uint32),
+                        ev_position=np.array(ev["position"], np.uint32), ev_crc32=np.array(ev["crc32"], np.uint32),
+                        ev_mpdu_sha=np.stack(ev["sha"]))
     print("written", os.listdir(OUT))
 
 

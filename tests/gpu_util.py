@@ -31,6 +31,42 @@ def make_capture(oracle, rate_kbps, length, seed, rate_mhz=40, sigma=0.0, lead=0
     return pad_capture(cap, rate_mhz), mp
 
 
+_RATES = (6000, 9000, 12000, 18000, 24000, 36000, 48000, 54000)
+
+
+def random_capture(o, rng, mhz):
+    kind = rng.integers(0, 10)
+    parts = []
+    if kind == 0:                                                        # noise only, sometimes loud enough to trip carrier sense
+        n = int(rng.integers(2, 200)) * 28
+        return pad_capture(np.rint(rng.normal(0, rng.choice([30, 300, 3000]), (n, 2))).astype(np.int16), mhz)
+    nfr = int(rng.choice([1, 1, 1, 2, 3]))
+    for _ in range(nfr):
+        rate = int(rng.choice(_RATES)); L = int(rng.choice([1, 5, 20, 60, 150, 400, 900, 1500]))
+        mp = rng.integers(0, 256, L).astype(np.uint8).tobytes()
+        cap = o.tx_capture(mp, rate, seed=int(rng.integers(1, 128)), lead=int(rng.integers(0, 120)), tail=int(rng.choice([40, 160, 200, 400, 900])))
+        parts.append(cap)
+    x = np.concatenate(parts)
+    if kind == 1:                                                        # truncated: the last frame runs past the capture
+        x = x[:int(len(x) * rng.uniform(0.3, 0.95))]
+    if rng.random() < 0.3:                                               # carrier frequency offset
+        f = rng.uniform(-80e3, 80e3)
+        z = (x[:, 0].astype(np.float64) + 1j * x[:, 1]) * np.exp(2j * np.pi * f * np.arange(len(x)) / 40e6)
+        x = np.stack([np.rint(z.real), np.rint(z.imag)], 1)
+    x = x.astype(np.float64)
+    if rng.random() < 0.3:                                               # DC offset (TDCRemoveEx / TDCEstimator path)
+        x += rng.uniform(-600, 600, size=(1, 2))
+    if rng.random() < 0.2:                                               # gain
+        x *= rng.uniform(0.25, 1.6)
+    x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    sigma = float(rng.choice([0, 0, 60, 150, 400, 900, 2000]))
+    if sigma:
+        x = awgn(x, sigma, int(rng.integers(1 << 30)))
+    if mhz == 20:
+        x = x[::2].copy()
+    return pad_capture(x, mhz)
+
+
 def batch(caps):
     """Concatenate captures with 4-sample aligned offsets -> (iq [N,2] int16, [(offset, nsamples, id)])."""
     descs, parts, off = [], [], 0
@@ -62,4 +98,26 @@ def same_results(got, want):
         for k in KEYS:
             if g[k] != w[k]:
                 return False, "frame %d field %s: %r != %r" % (i, k, g[k] if k != "mpdu" else g[k][:16].hex(), w[k] if k != "mpdu" else w[k][:16].hex())
+    return True, ""
+
+
+def source_position(end_sample20):
+    """40 MHz source position at which RxThread sees a frame event: the end of the 28-sample source call that consumed
+    20 MHz sample end_sample20 - 1 (memsource.hpp:87-114; error_code is tested after every source call)."""
+    return -(-end_sample20 * 2 // 28) * 28
+
+
+def same_as_reference_graph(rows, ref_events):
+    """rows: oracle / GPU result dicts of ONE 40 MHz capture; ref_events: ReferenceGraph.rx11a() of the same capture."""
+    if len(rows) != len(ref_events):
+        return False, "event count %d vs reference %d" % (len(rows), len(ref_events))
+    for i, (x, y) in enumerate(zip(rows, ref_events)):
+        if x["error_code"] != y["error_code"]:
+            return False, "event %d: error_code %#x vs reference %#x" % (i, x["error_code"], y["error_code"])
+        if source_position(x["end_sample"]) != y["sample_index"]:
+            return False, "event %d: position %d vs reference %d" % (i, source_position(x["end_sample"]), y["sample_index"])
+        if x["error_code"] in (0x1, 0x80000006):
+            for f in ("rate_kbps", "length", "crc32", "mpdu"):
+                if x[f] != y[f]:
+                    return False, "event %d: %s differs from the reference" % (i, f)
     return True, ""

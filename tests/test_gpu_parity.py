@@ -279,12 +279,33 @@ def test_device_resident_results_and_row_codec(sora, torch_cuda, oracle):
 def test_randomised_captures_match_the_oracle(sora, torch_cuda, oracle):
     """A slice of tools/stress_parity.py: random rates, lengths, noise, CFO, DC, gaps, several frames per capture,
     truncated frames, pure noise -- every result row identical (the full hunt ran over 24,000 captures)."""
-    import sys
-    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
-    from stress_parity import random_capture
+    from gpu_util import random_capture
     rng = np.random.default_rng(20260925)
     for mhz in (20, 40):
         caps = [random_capture(oracle, rng, mhz) for _ in range(150)]
         got = run_rx(sora, torch_cuda, caps, mhz, max_frames=8)
         ok, why = same_results(got, oracle_results(oracle, caps, mhz))
         assert ok, (mhz, why)
+
+
+def test_gpu_equals_the_reference_graph(sora, torch_cuda, oracle):
+    """The GPU path against the reference ITSELF: oracle/_ref/libsora_refgraph.so is CreateDemodGraph11a_40M compiled
+    from the reference sources (oracle/build_ref.sh; it travels with the snapshot).  Every event the reference's
+    RxThread loop reports -- error code, source position, rate, length, FCS, MPDU bytes -- must be what the GPU reports."""
+    from gpu_util import random_capture, same_as_reference_graph
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    rng = np.random.default_rng(20260927)
+    caps = [random_capture(oracle, rng, 40) for _ in range(300)]
+    for k in range(40):                                                  # negative frequency offsets (floored CFO estimate)
+        caps.append(make_capture(oracle, RATES[k % 8], 40 + 37 * k, 500 + k, cfo_hz=-20e3 - 1500 * k, sigma=30)[0])
+    got = run_rx(sora, torch_cuda, caps, 40, max_frames=8)
+    nev = 0
+    for i, c in enumerate(caps):
+        ev = g.rx11a(c)
+        ok, why = same_as_reference_graph([r for r in got if r["capture_id"] == i], ev)
+        assert ok, "capture %d: %s" % (i, why)
+        nev += len(ev)
+    assert nev > 300

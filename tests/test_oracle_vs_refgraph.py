@@ -1,0 +1,89 @@
+"""The C restatement (oracle/so_rx11a.c) against the REFERENCE'S OWN receive graph.
+
+oracle/_ref/libsora_refgraph.so is every brick of CreateDemodGraph11a_40M (kernel/bb/demod11/fb11ademod_config.hpp:168-233)
+compiled from the reference sources (oracle/build_ref.sh) and driven by the RxThread loop (fb11a_demod.cpp:29-81).
+Where the library exists (build container, and the GPU box: it travels with the snapshot) the oracle is compared with it
+live on random captures; everywhere, it is compared with the events that library produced for a committed list of
+seeded captures (tests/golden/refgraph_events.npz, written by tests/golden/make_golden.py)."""
+import hashlib
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import random_capture, same_as_reference_graph, source_position
+from oracle.pyoracle import Oracle, ReferenceGraph
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def o():
+    return Oracle()
+
+
+@pytest.fixture(scope="module")
+def graph():
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not built (needs the reference tree)")
+    return g
+
+
+def test_reference_graph_decodes_the_fixture(o, graph):
+    z = np.load(os.path.join(GOLD, "fsample6_40mhz_i8.npz"))
+    iq = z["iq_i8"].astype(np.int16) << 8
+    ev = graph.rx11a(iq)
+    assert len(ev) == 1 and ev[0]["error_code"] == 1 and ev[0]["rate_kbps"] == 6000 and ev[0]["length"] == 1392
+    assert ev[0]["crc32"] == 0x80EF9B11
+    assert hashlib.sha256(ev[0]["mpdu"]).hexdigest().startswith("5a13a477")
+    ok, why = same_as_reference_graph(o.rx_capture(iq, 40), ev)
+    assert ok, why
+
+
+@pytest.mark.parametrize("seed", [11, 12, 13])
+def test_oracle_equals_reference_graph_on_random_captures(o, graph, seed):
+    rng = np.random.default_rng(seed)
+    nframes = 0
+    for i in range(250):
+        cap = random_capture(o, rng, 40)
+        ev = graph.rx11a(cap)
+        ok, why = same_as_reference_graph(o.rx_capture(cap, 40), ev)
+        assert ok, "seed %d capture %d: %s" % (seed, i, why)
+        nframes += len(ev)
+    assert nframes > 150
+
+
+def test_negative_cfo_estimate_is_floored(o, graph):
+    """FreqOffsetEstimate divides by a size_t: a negative angle is floored, not truncated (dspalg.hpp:242).  The
+    recorded fixture has a non-negative offset, so only the reference graph itself shows this."""
+    from gpu_util import make_capture
+    seen = 0
+    for seed in range(40):
+        cap, mp = make_capture(o, 54000, 300, 100 + seed, cfo_hz=-30e3 - 700 * seed, sigma=40)
+        rows = o.rx_capture(cap, 40)
+        assert rows and rows[0]["cfo_est"] < 0
+        ok, why = same_as_reference_graph(rows, graph.rx11a(cap))
+        assert ok, why
+        seen += rows[0]["error_code"] == 1
+    assert seen >= 35
+
+
+def test_oracle_equals_recorded_reference_events(o):
+    """Runs everywhere: the events the compiled reference graph produced for seeded captures (make_golden.py)."""
+    z = np.load(os.path.join(GOLD, "refgraph_events.npz"))
+    seed = int(z["seed"]); n = int(z["captures"])
+    rng = np.random.default_rng(seed)
+    k = 0
+    ev_cap, ev_err, ev_pos, ev_crc, ev_sha = z["ev_capture"], z["ev_error"], z["ev_position"], z["ev_crc32"], z["ev_mpdu_sha"]
+    for i in range(n):
+        cap = random_capture(o, rng, 40)
+        rows = o.rx_capture(cap, 40)
+        assert len(rows) == int((ev_cap == i).sum()), "capture %d: event count" % i
+        for r in rows:
+            assert ev_cap[k] == i and r["error_code"] == ev_err[k] and source_position(r["end_sample"]) == ev_pos[k], "capture %d" % i
+            if r["error_code"] in (0x1, 0x80000006):
+                assert r["crc32"] == ev_crc[k]
+                assert hashlib.sha256(r["mpdu"]).digest()[:8] == ev_sha[k].tobytes(), "capture %d: MPDU bytes" % i
+            k += 1
+    assert k == len(ev_cap)

@@ -12,41 +12,8 @@ import numpy as np
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-from gpu_util import awgn, batch, pad_capture, same_results            # noqa: E402
+from gpu_util import batch, random_capture, same_results                # noqa: E402
 from oracle.pyoracle import Oracle, RATES                              # noqa: E402
-
-
-def random_capture(o, rng, mhz):
-    kind = rng.integers(0, 10)
-    parts = []
-    if kind == 0:                                                        # noise only, sometimes loud enough to trip carrier sense
-        n = int(rng.integers(2, 200)) * 28
-        return pad_capture(np.rint(rng.normal(0, rng.choice([30, 300, 3000]), (n, 2))).astype(np.int16), mhz)
-    nfr = int(rng.choice([1, 1, 1, 2, 3]))
-    for _ in range(nfr):
-        rate = int(rng.choice(RATES)); L = int(rng.choice([1, 5, 20, 60, 150, 400, 900, 1500]))
-        mp = rng.integers(0, 256, L).astype(np.uint8).tobytes()
-        cap = o.tx_capture(mp, rate, seed=int(rng.integers(1, 128)), lead=int(rng.integers(0, 120)), tail=int(rng.choice([40, 160, 200, 400, 900])))
-        parts.append(cap)
-    x = np.concatenate(parts)
-    if kind == 1:                                                        # truncated: the last frame runs past the capture
-        x = x[:int(len(x) * rng.uniform(0.3, 0.95))]
-    if rng.random() < 0.3:                                               # carrier frequency offset
-        f = rng.uniform(-80e3, 80e3)
-        z = (x[:, 0].astype(np.float64) + 1j * x[:, 1]) * np.exp(2j * np.pi * f * np.arange(len(x)) / 40e6)
-        x = np.stack([np.rint(z.real), np.rint(z.imag)], 1)
-    x = x.astype(np.float64)
-    if rng.random() < 0.3:                                               # DC offset (TDCRemoveEx / TDCEstimator path)
-        x += rng.uniform(-600, 600, size=(1, 2))
-    if rng.random() < 0.2:                                               # gain
-        x *= rng.uniform(0.25, 1.6)
-    x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
-    sigma = float(rng.choice([0, 0, 60, 150, 400, 900, 2000]))
-    if sigma:
-        x = awgn(x, sigma, int(rng.integers(1 << 30)))
-    if mhz == 20:
-        x = x[::2].copy()
-    return pad_capture(x, mhz)
 
 
 def main():
