@@ -72,17 +72,27 @@ def make_workload(oracle, nframes, seed0, distinct=512):
 
 
 def _cpu_worker(args):
-    """One host process of the CPU baseline: the oracle over its share of the captures (cycled) for `seconds`."""
-    path, nframes, first, stride, seconds = args
-    from oracle.pyoracle import Oracle
-    o = Oracle()
+    """One host process of the CPU baseline over its share of the captures (cycled) for `seconds`.  kind "reference":
+    the reference's own brick graph compiled from its sources (oracle/_ref/libsora_refgraph.so; it takes the 40 MHz
+    stream its harness reads, so every 20 MHz sample is doubled -- TDownSample2 drops the copies); kind "port": the
+    scalar C restatement."""
+    path, nframes, first, stride, seconds, kind = args
     x = np.load(path, mmap_mode="r").reshape(nframes, CAPTURE_SAMPLES, 2)
-    o.rx_capture(np.array(x[first % nframes]), 20)                      # tables + page-in, untimed
-    t0 = time.perf_counter(); n = 0; ok = 0; i = first
+    caps = np.stack([np.array(x[(first + k * stride) % nframes]) for k in range(max(1, min(64, nframes // max(1, stride))))])
+    if kind == "reference":
+        from oracle.pyoracle import ReferenceGraph
+        g = ReferenceGraph()
+        caps = np.repeat(caps, 2, axis=1)                                 # input preparation, not timed
+        run = lambda: g.rx11a_bench(caps)                                 # noqa: E731  (the loop over captures is inside the library)
+    else:
+        from oracle.pyoracle import Oracle
+        o = Oracle()
+        run = lambda: sum(int(len(r) == 1 and r[0]["error_code"] == 1) for r in (o.rx_capture(c, 20) for c in caps))  # noqa: E731
+    run()                                                                # tables + page-in, untimed
+    t0 = time.perf_counter(); n = 0; ok = 0
     while time.perf_counter() - t0 < seconds:
-        r = o.rx_capture(np.array(x[i % nframes]), 20)
-        ok += int(len(r) == 1 and r[0]["error_code"] == 1)
-        n += 1; i += stride
+        ok += run()
+        n += len(caps)
     return n, ok, time.perf_counter() - t0
 
 
@@ -103,25 +113,38 @@ def host_cores():
     return max(1, min(n, 256))
 
 
-def cpu_baseline(iq, nframes, budget_s=12.0):
-    """The scalar C oracle (a port of the reference path) on the host cores over a bounded sample of the same captures:
-    one process per usable core (affinity and cgroup quota), each cycling through its share of the captures for about budget_s seconds; the
-    single-process rate is measured first (2 s) and reported next to it."""
+def cpu_baseline(iq, nframes, budget_s=10.0):
+    """The reference receive path on this box's host cores over a bounded sample of the same captures: one process per
+    usable core (affinity and cgroup quota), each cycling through its share of the captures for about budget_s seconds.
+    kind "reference" = the reference's own SSE brick graph (CreateDemodGraph11a_40M + the RxThread loop) compiled from
+    its sources into oracle/_ref; where that library is absent, kind "port" = the scalar C restatement.  The other one
+    and the single-process rates are reported beside it."""
     import multiprocessing as mp
     import tempfile
+    from oracle.pyoracle import ReferenceGraph
     cores = host_cores()
+    have_ref = ReferenceGraph().available()
+    out = {}
     with tempfile.TemporaryDirectory() as d:
         path = os.path.join(d, "iq.npy")
         np.save(path, iq)
-        one = _cpu_worker((path, nframes, 0, 1, 2.0))
         with mp.get_context("spawn").Pool(cores) as pool:
-            res = pool.map(_cpu_worker, [(path, nframes, k, cores, budget_s) for k in range(cores)])
-    n = sum(r[0] for r in res); ok = sum(r[1] for r in res)
-    rate = sum(r[0] * FRAME_SAMPLES / r[2] for r in res) / 1e6             # processes run side by side: rates add
-    return {"value": round(rate, 3), "unit": "Msamples/s", "cores": cores, "kind": "port",
-            "single_core_value": round(one[0] * FRAME_SAMPLES / one[2] / 1e6, 4),
-            "sample": "%d captures of this workload (cycled), %d processes x %.0f s, oracle/so_rx11a.c" % (n, cores, budget_s),
-            "frames_ok": ok}
+            for kind, secs in ((("reference", budget_s),) if have_ref else ()) + (("port", budget_s if not have_ref else 4.0),):
+                one = pool.apply(_cpu_worker, ((path, nframes, 0, 1, 2.0, kind),))
+                res = pool.map(_cpu_worker, [(path, nframes, k, cores, secs, kind) for k in range(cores)])
+                out[kind] = {"value": round(sum(r[0] * FRAME_SAMPLES / r[2] for r in res) / 1e6, 3),   # side by side: rates add
+                             "single": round(one[0] * FRAME_SAMPLES / one[2] / 1e6, 4),
+                             "n": sum(r[0] for r in res), "ok": sum(r[1] for r in res), "secs": secs}
+    kind = "reference" if have_ref else "port"
+    m = out[kind]
+    what = ("the reference's brick graph compiled from its sources (oracle/_ref/libsora_refgraph.so, SSE)" if have_ref
+            else "oracle/so_rx11a.c (scalar C restatement)")
+    r = {"value": m["value"], "unit": "Msamples/s", "cores": cores, "kind": kind, "single_core_value": m["single"],
+         "sample": "%d captures of this workload (cycled), %d processes x %.0f s, %s" % (m["n"], cores, m["secs"], what),
+         "frames_ok": m["ok"], "frames_run": m["n"]}
+    if have_ref:
+        r["port_value"] = out["port"]["value"]; r["port_single_core_value"] = out["port"]["single"]
+    return r
 
 
 def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):

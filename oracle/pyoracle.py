@@ -246,6 +246,20 @@ class ReferenceGraph:
 
     def available(self): return self.L is not None
 
+    def rx11a_bench(self, iq40_caps, reps=1):
+        """iq40_caps: int16 [ncap, n, 2]; runs every capture `reps` times inside the library -> FRAME_OK count."""
+        a = np.ascontiguousarray(iq40_caps, np.int16)
+        self.L.ref_rx11a_bench.restype = ctypes.c_uint32
+        return self.L.ref_rx11a_bench(_P(a), a.shape[0], a.shape[1], reps)
+
+    def tx11a(self, mpdu_nofcs, rate_kbps, seed=0xFF):
+        """The reference's preamble + modulation graphs (Test11A_FB_Mod) -> int8 [n,2] COMPLEX8 @40 MHz."""
+        a = np.frombuffer(bytes(mpdu_nofcs), np.uint8); cap = 640 + 160 * 1400
+        o = np.zeros((cap, 2), np.int8)
+        n = self.L.ref_tx11a(_P(a), len(a), rate_kbps, seed, _P(o), cap)
+        if n < 0: raise ValueError("ref_tx11a failed")
+        return o[:n]
+
     def rx11a(self, iq40, max_frames=64):
         """iq40: int16 [n,2] at 40 MHz.  -> list of dict(error_code, sample_index (40 MHz source position when
         RxThread sees the event), rate_kbps, length, crc32, mpdu)."""

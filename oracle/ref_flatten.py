@@ -91,3 +91,5 @@ edit("pinqueue.h", lambda s: s.replace("[nstream][qsize]", "[NSTREAM][lcm<N,M>::
 #      sink's "stop" like the thread boundary does).  This is the deterministic limit of the two-thread harness -- an
 #      infinitely fast ViterbiThread -- which is also what oracle/so_rx11a.c and the GPU path implement.
 edit("fb11ademod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))
+# ---- mapper11a.hpp: an array bound that this clang's declaration/expression disambiguation trips over (same value)
+edit("mapper11a.hpp", lambda s: s.replace("(&lut)[intpow<2, LUT_BITS>::value][LUT_BITS/M/2]", "(&lut)[(1 << LUT_BITS)][LUT_BITS/M/2]"))

@@ -51,3 +51,46 @@ EXPORT int ref_rx11a_capture(const int16_t* iq, uint32_t nsamples40, ref_frame* 
     }
     return n;
 }
+
+// The same loop over `ncap` equal-sized captures laid end to end, `reps` times, with nothing but a counter coming
+// back: what bench.py times as the reference path on a host core (no per-capture binding overhead).
+EXPORT uint32_t ref_rx11a_bench(const int16_t* iq, uint32_t ncap, uint32_t nsamples40, uint32_t reps)
+{
+    static uint8_t mpdu[4096]; ref_frame res[8]; uint32_t ok = 0;
+    for (uint32_t r = 0; r < reps; r++)
+        for (uint32_t c = 0; c < ncap; c++) {
+            int n = ref_rx11a_capture(iq + (size_t)c * nsamples40 * 2, nsamples40, res, 8, mpdu, sizeof(mpdu));
+            for (int i = 0; i < n; i++) ok += res[i].error_code == E_ERROR_FRAME_OK;
+        }
+    return ok;
+}
+
+// ---------------------------------------------------------------- 802.11a transmitter: Test11A_FB_Mod (fb11a_mod.cpp:26-70)
+#include "CRC32.h"
+#include "scramble.hpp"
+#include "samples.hpp"
+#include "fb11amod_config.hpp"
+
+// Preamble graph, then the modulation graph, into one COMPLEX8 buffer at 40 MHz -- what "demod11 -m" writes.
+// mpdu: the payload file of the harness (FCS is appended by TBB11aSrc); seed: CF_ScramblerSeed (the harness uses 0xFF).
+// Returns the number of complex samples, or -1.
+EXPORT int ref_tx11a(const uint8_t* mpdu, uint32_t len, uint32_t rate_kbps, uint32_t seed, int8_t* out8, uint32_t max_samples)
+{
+    static ISource* ssrc; static ISource* tssrc;
+    static unsigned char data[4096 + 16];
+    if (len > 4096 - 4) return -1;
+    if (!ssrc) { ssrc = CreateModGraph11a_40M(); tssrc = CreatePreamble11a_40M(); }
+    COMPLEX8* buf = (COMPLEX8*)out8;
+    BB11aModCtx.set_mod_buffer(buf, max_samples);
+    tssrc->Reset();
+    if (BB11aModCtx.CF_Error::error_code() != E_ERROR_SUCCESS) return -1;
+    tssrc->Process();
+    uint ts_len = BB11aModCtx.CF_TxSampleBuffer::tx_sample_cnt();
+    memset(data, 0, sizeof(data)); memcpy(data, mpdu, len);
+    BB11aModCtx.init(rate_kbps, data, (ushort)len, buf + ts_len, max_samples - ts_len);
+    BB11aModCtx.CF_ScramblerSeed::sc_seed() = (uchar)seed;
+    ssrc->Reset();
+    if (BB11aModCtx.CF_Error::error_code() != E_ERROR_SUCCESS) return -1;
+    ssrc->Process(); ssrc->Flush();
+    return (int)(ts_len + BB11aModCtx.CF_TxSampleBuffer::tx_sample_cnt());
+}

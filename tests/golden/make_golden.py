@@ -10,7 +10,8 @@
   refgraph_events.npz    what the reference's OWN receive graph (oracle/_ref/libsora_refgraph.so = CreateDemodGraph11a_40M
                          compiled from the reference sources) reports for 400 seeded random captures
                          (tests/gpu_util.random_capture): per event the capture index, error code, source position,
-                         FCS and the first 8 bytes of the MPDU's sha256.
+                         FCS and the first 8 bytes of the MPDU's sha256; and length + sha256 prefix of what the reference's
+                         modulation graph (CreateModGraph11a_40M) emits for a list of frames.
 All files travel to the GPU box; /root/reference does not.
 """
 import hashlib
@@ -91,7 +92,12 @@ def main():
         for e in G.rx11a(random_capture(O, rng, 40)):
             ev["capture"].append(i); ev["error"].append(e["error_code"]); ev["position"].append(e["sample_index"])
             ev["crc32"].append(e["crc32"]); ev["sha"].append(np.frombuffer(hashlib.sha256(e["mpdu"]).digest()[:8], np.uint8))
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from test_oracle_vs_refgraph import TX_CASES, _tx_payload               # the reference modulator's output for the listed frames
+    tx = [G.tx11a(_tx_payload(rate, ln), rate, seed=sd) for rate, ln, sd in TX_CASES]
     np.savez_compressed(os.path.join(OUT, "refgraph_events.npz"), seed=seed, captures=ncap,
+                        tx_len=np.array([len(x) for x in tx], np.int32),
+                        tx_sha=np.stack([np.frombuffer(hashlib.sha256(x.tobytes()).digest()[:8], np.uint8) for x in tx]),
                         ev_capture=np.array(ev["capture"], np.int32), ev_error=np.array(ev["error"], np.uint32),
                         ev_position=np.array(ev["position"], np.uint32), ev_crc32=np.array(ev["crc32"], np.uint32),
                         ev_mpdu_sha=np.stack(ev["sha"]))

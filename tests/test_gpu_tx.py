@@ -30,6 +30,23 @@ def test_tx_matches_oracle(sora, oracle, rate):
         assert np.array_equal(got[off[f]:off[f + 1]], want), (rate, len(mp), hex(sd))
 
 
+def test_tx_matches_the_reference_modulation_graph(sora):
+    """Against the reference itself: CreateModGraph11a_40M + CreatePreamble11a_40M compiled from the reference sources
+    (oracle/_ref/libsora_refgraph.so, oracle/build_ref.sh)."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    rng = np.random.default_rng(4242)
+    rates = [RATES[i % 8] for i in range(40)]
+    mpdus = [bytes(rng.integers(0, 256, 1 + 61 * i).astype(np.uint8)) for i in range(40)]
+    seeds = [int(rng.integers(0, 256)) for _ in range(40)]
+    out, off = sora.tx11a(mpdus, rates, seeds)
+    got = out.cpu().numpy()
+    for f in range(40):
+        assert np.array_equal(got[off[f]:off[f + 1]], g.tx11a(mpdus[f], rates[f], seed=seeds[f])), (rates[f], len(mpdus[f]), seeds[f])
+
+
 def test_tx_mixed_batch_loops_back_through_the_gpu_receiver(sora, oracle):
     import torch
     rng = np.random.default_rng(77)
