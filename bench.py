@@ -47,6 +47,18 @@ def measured_traffic(kernel):
         return None
 
 
+def measured_valu(kernel=None):
+    """Wave-level VALU instructions per launch (SQ_INSTS_VALU, same PMC summary): of `kernel`, or of the whole call."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+        if t.get("frames_per_launch") != FRAMES_PER_GPU:
+            return None
+        return t["kernels"][kernel]["valu_insts"] if kernel else t["total_valu_insts_per_call"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def make_workload(oracle, nframes, seed0, distinct=512):
     """-> (iq int16 [nframes*CAPTURE_SAMPLES, 2], descs, payloads)"""
     from gpu_util import pad_capture
@@ -147,6 +159,19 @@ def cpu_baseline(iq, nframes, budget_s=10.0):
     return r
 
 
+def valu_roofline(nframes, ms_step):
+    """What actually bounds this path: vector-ALU issue.  Wave-level VALU instructions of one receive call (rocprofv3
+    SQ_INSTS_VALU, profiles/r01_traffic.json) over the measured step time, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
+    per wave64 instruction (MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles)."""
+    n = measured_valu() if nframes == FRAMES_PER_GPU else None
+    if not n:
+        return None
+    peak = 256 * 4 * 2.4e9 / 2
+    ach = n / (ms_step * 1e-3)
+    return {"insts_per_call": n, "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
+            "frac": round(ach / peak, 4), "dominant_kernel_insts": measured_valu("k_viterbi")}
+
+
 def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
     """Row f3 (capture ingest): a 44 MHz RX_BLOCK dump resident in HBM -> de-framed, sign-fixed, resampled 40 MHz stream.
     A pure streaming kernel: algorithmic bytes = dump bytes read + samples written, against the HBM roofline."""
@@ -201,8 +226,8 @@ def bench_tx(torch, sora_amd, nframes=4096, reps=10):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=60)
+    ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="captures per GPU (default: the BASELINE config)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--depth", type=int, default=0, help="process calls in flight on the handle's internal pipelines (0 = library default)")
@@ -316,7 +341,8 @@ def main():
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(ach / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes[dom], 4),
-                         "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5)},
+                         "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
+                         "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
         }
         if world == 1:

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """summarize_pmc.py -- per-kernel HBM traffic of one receive call from two rocprofv3 --pmc passes.
 
-    python tools/summarize_pmc.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <frames per launch> > profiles/rNN_traffic.json
+    python tools/summarize_pmc.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <frames per launch> [<SQ_INSTS counter_collection.csv>] > profiles/rNN_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (they come from the L2's memory-side request counters).
 Corrections applied as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950: FETCH_SIZE is doubled
@@ -44,6 +44,14 @@ def main():
                              "launches_sampled": fetch.get(k, (0.0, 0))[1]}
         if k in rx_path:
             total += fb + wb
+    if len(sys.argv) > 4:                                                     # third pass: SQ_INSTS_VALU / SQ_INSTS_SALU per dispatch
+        valu = per_kernel(sys.argv[4], "SQ_INSTS_VALU"); salu = per_kernel(sys.argv[4], "SQ_INSTS_SALU")
+        tv = 0.0
+        for k in out["kernels"]:
+            out["kernels"][k]["valu_insts"] = round(valu.get(k, (0.0, 0))[0]); out["kernels"][k]["salu_insts"] = round(salu.get(k, (0.0, 0))[0])
+            if k in rx_path:
+                tv += valu.get(k, (0.0, 0))[0]
+        out["total_valu_insts_per_call"] = round(tv)
     out["total_hbm_bytes_per_call"] = round(total)
     out["algorithmic_bytes_per_call"] = round(frames * 4880 * 4.3375)
     json.dump(out, sys.stdout, indent=1)
