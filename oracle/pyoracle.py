@@ -260,12 +260,27 @@ class ReferenceGraph:
         if n < 0: raise ValueError("ref_tx11a failed")
         return o[:n]
 
+    def tx11b(self, mpdu_nofcs, rate_kbps):
+        """The reference's 802.11b modulation graph (Test11B_FB_Mod) -> int8 [n,2] COMPLEX8 @44 MHz."""
+        a = np.frombuffer(bytes(mpdu_nofcs), np.uint8); cap = 1 << 20
+        o = np.zeros((cap, 2), np.int8)
+        n = self.L.ref_tx11b(_P(a), len(a), rate_kbps, _P(o), cap)
+        if n < 0: raise ValueError("ref_tx11b failed")
+        return o[:n]
+
+    def rx11b(self, iq44, max_frames=16):
+        """The reference's 802.11b receive graph (Test11B_FB_Demod / MAC11b_Receive) over int16 [n,2] @44 MHz."""
+        return self._events(self.L.ref_rx11b_capture, iq44, max_frames)
+
     def rx11a(self, iq40, max_frames=64):
         """iq40: int16 [n,2] at 40 MHz.  -> list of dict(error_code, sample_index (40 MHz source position when
         RxThread sees the event), rate_kbps, length, crc32, mpdu)."""
-        iq = np.ascontiguousarray(iq40, np.int16).reshape(-1, 2)
-        res = (RefFrame * max_frames)(); mp = np.zeros(max_frames * 2504, np.uint8)
-        n = self.L.ref_rx11a_capture(_P(iq), len(iq), res, max_frames, _P(mp), mp.size)
+        return self._events(self.L.ref_rx11a_capture, iq40, max_frames)
+
+    def _events(self, fn, iq, max_frames):
+        iq = np.ascontiguousarray(iq, np.int16).reshape(-1, 2)
+        res = (RefFrame * max_frames)(); mp = np.zeros(max_frames * 4096, np.uint8)
+        n = fn(_P(iq), len(iq), res, max_frames, _P(mp), mp.size)
         out = []
         for r in res[:n]:
             d = {f: getattr(r, f) for f, _ in RefFrame._fields_}

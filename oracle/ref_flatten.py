@@ -93,3 +93,9 @@ edit("pinqueue.h", lambda s: s.replace("[nstream][qsize]", "[NSTREAM][lcm<N,M>::
 edit("fb11ademod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))
 # ---- mapper11a.hpp: an array bound that this clang's declaration/expression disambiguation trips over (same value)
 edit("mapper11a.hpp", lambda s: s.replace("(&lut)[intpow<2, LUT_BITS>::value][LUT_BITS/M/2]", "(&lut)[(1 << LUT_BITS)][LUT_BITS/M/2]"))
+
+# ---- 11b graphs: bbb.h drags in the live RX-stream helpers; Windows file systems ignore the case of include names
+write("rxstream.h", "#pragma once\n")
+for lower, real in (("phy_11b.hpp", "PHY_11b.hpp"), ("phy_11a.hpp", "PHY_11a.hpp"), ("phy_11n.hpp", "PHY_11n.hpp")):
+    if os.path.exists(OUT + "/" + real) and not os.path.exists(OUT + "/" + lower):
+        write(lower, '#pragma once\n#include "%s"\n' % real)

@@ -94,3 +94,69 @@ EXPORT int ref_tx11a(const uint8_t* mpdu, uint32_t len, uint32_t rate_kbps, uint
     ssrc->Process(); ssrc->Flush();
     return (int)(ts_len + BB11aModCtx.CF_TxSampleBuffer::tx_sample_cnt());
 }
+
+// ---------------------------------------------------------------- 802.11b (SURVEY row f4 / BASELINE configs[0]): the reference's own graphs
+#include "bb/bbb.h"
+#include "bb/DataRate.h"
+#include "dot11_plcp.h"
+#include "pulse.hpp"
+#include "phy_11b.hpp"
+#include "barkerspread.hpp"
+#include "fb11bdemod_config.hpp"
+#include "fb11bmod_config.hpp"
+
+// Test11B_FB_Mod (fb11b_mod.cpp:40-70): CreateModGraph (fb11bmod_config.hpp:28-50) over one MPDU; COMPLEX8 at 44 MHz.
+// rate_kbps 1000/2000/5500/11000.  Returns the number of complex samples, or -1.
+EXPORT int ref_tx11b(const uint8_t* mpdu, uint32_t len, uint32_t rate_kbps, int8_t* out8, uint32_t max_samples)
+{
+    static ISource* ssrc;
+    static unsigned char data[4096 + 16];
+    if (len > 4096 - 4) return -1;
+    if (!ssrc) ssrc = CreateModGraph();
+    memset(data, 0, sizeof(data)); memcpy(data, mpdu, len);
+    InitModGraphCtx(rate_kbps, data, (int)len, (COMPLEX8*)out8, max_samples);
+    if (BB11bModCtx.CF_Error::error_code() != E_ERROR_SUCCESS) return -1;
+    *(PULONG)(data + len) = BB11bModCtx.CF_11bTxVector::crc32();        // "append CRC32 to the data stream"
+    ssrc->Reset();
+    if (BB11bModCtx.CF_Error::error_code() != E_ERROR_SUCCESS) return -1;
+    ssrc->Process(); ssrc->Flush();
+    return (int)BB11bModCtx.CF_TxSampleBuffer::tx_sample_cnt();
+}
+
+// Test11B_FB_Demod + MAC11b_Receive (fb11b_demod.cpp:27-76, 79-117) over a 44 MHz capture in memory.
+EXPORT int ref_rx11b_capture(const int16_t* iq, uint32_t nsamples44, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
+{
+    static unsigned char out[4096];                                      // OUTPUTBUF_SIZE
+    if (g_cap < nsamples44 + 64) { free(g_buf); g_cap = nsamples44 + 64; g_buf = (COMPLEX16*)aligned_alloc(16, ((size_t)g_cap * 4 + 15) & ~(size_t)15); }
+    memcpy(g_buf, iq, (size_t)nsamples44 * 4);
+    BB11bDemodCtx.init(g_buf, nsamples44 * sizeof(COMPLEX16), out, sizeof(out));
+    if (!pRxSource) pRxSource = CreateDemodGraph();
+    else pRxSource->Seek(ISource::START_POS);
+    pRxSource->Flush(); BB11bDemodCtx.reset(); pRxSource->Reset();
+    int n = 0; uint32_t used = 0;
+    for (;;) {                                                           // MAC11b_Receive is called until it returns false
+        bool rc = pRxSource->Process();
+        ulong err = BB11bDemodCtx.CF_Error::error_code();
+        if (err != BK_ERROR_SUCCESS) {
+            if (err != E_ERROR_CS_TIMEOUT && n < max_res) {
+                ref_frame& f = res[n++];
+                f.error_code = err; f.sample_index = BB11bDemodCtx.CF_MemSamples::mem_sample_index();
+                f.rate_kbps = BB11bDemodCtx.CF_11bRxVector::data_rate_kbps(); f.length = BB11bDemodCtx.CF_11bRxVector::frame_length();
+                f.crc32 = BB11bDemodCtx.CF_11bRxVector::crc32(); f.mpdu_offset = used;
+                if ((err == E_ERROR_FRAME_OK || err == E_ERROR_CRC32_FAIL) && used + f.length <= mpdu_cap) { memcpy(mpdu + used, out, f.length); used += f.length; }
+            }
+            if (err == E_ERROR_FRAME_OK || err == E_ERROR_CRC32_FAIL) {  // "TRICK: jump advance of the last CRC byte"
+                switch (BB11bDemodCtx.CF_11bRxVector::data_rate_kbps()) {
+                case 1000:  pRxSource->Seek(8 * 11 * 4); break;
+                case 2000:  pRxSource->Seek(4 * 11 * 4); break;
+                case 5500:  pRxSource->Seek(8 * 2 * 4); break;
+                case 11000: pRxSource->Seek(8 * 1 * 4); break;
+                }
+            }
+            pRxSource->Flush(); BB11bDemodCtx.reset(); pRxSource->Reset();
+            continue;
+        }
+        if (!rc) break;
+    }
+    return n;
+}

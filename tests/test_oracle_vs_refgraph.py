@@ -110,3 +110,21 @@ def test_oracle_transmitter_equals_recorded_reference_samples(o):
     for i, (rate, ln, seed) in enumerate(TX_CASES):
         x = o.tx(_tx_payload(rate, ln), rate, seed=seed)
         assert len(x) == z["tx_len"][i] and hashlib.sha256(x.tobytes()).digest()[:8] == z["tx_sha"][i].tobytes(), (rate, ln, seed)
+
+
+def test_reference_11b_brick_path_runs_on_the_cpu(graph):
+    """BASELINE configs[0] (plumbing, no GPU): the reference's own 802.11b BRICK receive path (CreateDemodGraph,
+    fb11bdemod_config.hpp:122-172, driven as MAC11b_Receive does) decodes what the reference's own modulation graph
+    (fb11bmod_config.hpp:28-50) emits: 1 Mbps DBPSK and 2 Mbps DQPSK, long preamble, 44 MHz samples, with noise.
+    (The 5.5/11 Mbps CCK branches parse the header but do not loop back in this build; not investigated.)"""
+    rng = np.random.default_rng(802)
+    for rate in (1000, 2000):
+        for ln in (14, 300, 1500):
+            mp = rng.integers(0, 256, ln).astype(np.uint8).tobytes()
+            s8 = graph.tx11b(mp, rate)
+            x = np.zeros((2000 + len(s8) + 2800, 2), np.int16)
+            x[2000:2000 + len(s8)] = s8.astype(np.int16) << 8                 # `demod11 -c` (modulate11a.cpp:131-190)
+            x = np.clip(x + np.rint(rng.normal(0, 150, x.shape)), -32768, 32767).astype(np.int16)[:len(x) // 28 * 28]
+            ev = graph.rx11b(x)
+            assert len(ev) == 1 and ev[0]["error_code"] == 1 and ev[0]["rate_kbps"] == rate and ev[0]["length"] == ln + 4, (rate, ln, ev)
+            assert ev[0]["mpdu"][:ln] == mp
