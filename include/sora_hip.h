@@ -54,7 +54,11 @@ typedef struct sora_rx sora_rx_t;
 typedef struct {
     uint32_t struct_size;           /* sizeof(sora_rx_cfg) */
     int32_t  device;                /* HIP device ordinal */
-    uint32_t sample_rate_mhz;       /* 40: dump rate, TDownSample2 first (samples.hpp:9-47); 20: the even samples */
+    uint32_t sample_rate_mhz;       /* 40: dump rate, TDownSample2 first (samples.hpp:9-47); 20: the even samples;
+                                     * 44: CreateDemodGraph11a_44M (fb11ademod_config.hpp:236-300) -- iq is the 40 MHz stream
+                                     * sora_hip_ingest(SORA_INGEST_44TO40) makes of a 44 MHz dump; as in that graph, the
+                                     * resampler's queued samples survive the reset after a frame (TDownSample44_40 has no
+                                     * Reset/Flush).  Positions are 20 MHz-rate samples of the resampled stream. */
     uint32_t max_captures;          /* captures per sora_rx_process call */
     uint64_t max_total_samples;     /* sum of capture lengths per call (input-rate samples) */
     uint32_t max_frames_per_capture;/* frame-table rows per capture */

@@ -272,6 +272,10 @@ class ReferenceGraph:
         """The reference's 802.11b receive graph (Test11B_FB_Demod / MAC11b_Receive) over int16 [n,2] @44 MHz."""
         return self._events(self.L.ref_rx11b_capture, iq44, max_frames)
 
+    def rx11a_44(self, iq44, max_frames=64):
+        """CreateDemodGraph11a_44M (TDownSample44_40 in front) over int16 [n,2] @44 MHz; sample_index in 44 MHz samples."""
+        return self._events(self.L.ref_rx11a_capture44, iq44, max_frames)
+
     def rx11a(self, iq40, max_frames=64):
         """iq40: int16 [n,2] at 40 MHz.  -> list of dict(error_code, sample_index (40 MHz source position when
         RxThread sees the event), rate_kbps, length, crc32, mpdu)."""

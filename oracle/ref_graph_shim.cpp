@@ -20,12 +20,14 @@ static COMPLEX16* g_buf; static uint32_t g_cap;
 // Test11A_FB_Demod + RxThread (fb11a_demod.cpp:29-81, 88-120) over a capture in memory, the events recorded instead
 // of printed.  sample_index = CF_MemSamples::mem_sample_index() when RxThread sees the event (40 MHz samples).
 // Returns the number of events (frames and header failures); CS time-outs are handled as RxThread handles them.
-EXPORT int ref_rx11a_capture(const int16_t* iq, uint32_t nsamples40, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
+static ISource* g_src44; static ISource* g_vit44; static IControlPoint* g_cs44;
+static int rx11a_run(int mhz, const int16_t* iq, uint32_t nsamples40, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
 {
+    ISource*& g_src = mhz == 44 ? g_src44 : ::g_src; ISource*& g_vit = mhz == 44 ? g_vit44 : ::g_vit; IControlPoint*& g_cs = mhz == 44 ? g_cs44 : ::g_cs;
     if (g_cap < nsamples40 + 64) { free(g_buf); g_cap = nsamples40 + 64; g_buf = (COMPLEX16*)aligned_alloc(16, ((size_t)g_cap * 4 + 15) & ~(size_t)15); }
     memcpy(g_buf, iq, (size_t)nsamples40 * 4);
     BB11aDemodCtx.Init(g_buf, nsamples40 * sizeof(COMPLEX16), g_out, sizeof(g_out));
-    if (!g_src) CreateDemodGraph11a_40M(g_src, g_vit, g_cs);
+    if (!g_src) { if (mhz == 44) CreateDemodGraph11a_44M(g_src, g_vit, g_cs); else CreateDemodGraph11a_40M(g_src, g_vit, g_cs); }
     else g_src->Seek(ISource::START_POS);             // the graph is built once; rewind the memory source
     g_src->Flush(); BB11aDemodCtx.Reset(); g_src->Reset();
     int n = 0; uint32_t used = 0; uint nWaitCounter = 12;
@@ -50,6 +52,16 @@ EXPORT int ref_rx11a_capture(const int16_t* iq, uint32_t nsamples40, ref_frame* 
         if (!rc) break;
     }
     return n;
+}
+
+EXPORT int ref_rx11a_capture(const int16_t* iq, uint32_t nsamples40, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
+{ return rx11a_run(40, iq, nsamples40, res, max_res, mpdu, mpdu_cap); }
+// CreateDemodGraph11a_44M (fb11ademod_config.hpp:236-300): TDownSample44_40 in front of the same graph; positions in 44 MHz samples.
+// A fresh resampler is needed per capture (the brick has no Reset), so the graph is rebuilt on every call.
+EXPORT int ref_rx11a_capture44(const int16_t* iq, uint32_t nsamples44, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
+{
+    if (g_src44) { IReferenceCounting::Release(g_src44); g_src44 = NULL; }
+    return rx11a_run(44, iq, nsamples44, res, max_res, mpdu, mpdu_cap);
 }
 
 // The same loop over `ncap` equal-sized captures laid end to end, `reps` times, with nothing but a counter coming
@@ -160,3 +172,7 @@ EXPORT int ref_rx11b_capture(const int16_t* iq, uint32_t nsamples44, ref_frame* 
     }
     return n;
 }
+
+// Drop the cached 40 MHz receive graph so that the next call builds a fresh one (tests use it to show that no result
+// depends on what an earlier capture left in the bricks).
+EXPORT void ref_rx11a_fresh_graph(void) { if (g_src) { IReferenceCounting::Release(g_src); g_src = NULL; } }

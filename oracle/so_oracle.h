@@ -96,7 +96,8 @@ typedef struct {             /* optional intermediates of the FIRST decoded fram
     uint32_t n_syms, n_soft; /* filled */
 } so_trace;
 
-/* sample_rate_mhz: 40 (dump rate; TDownSample2 first) or 20 (already decimated: the even samples).
+/* sample_rate_mhz: 40 (dump rate; TDownSample2 first), 20 (already decimated: the even samples) or 44 (the 40 MHz
+ * stream of TDownSample44_40 under the 44 MHz graph's reset semantics, see so_rx11a.c).
  * Returns number of frame results written. */
 int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
                      so_frame_result* res, int max_res, uint8_t* mpdu_buf, uint32_t mpdu_cap, so_trace* trace);

@@ -620,7 +620,12 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
      * stream, i.e. the same machine in units of raw pairs: queue 28, 14 per call, bursts of 4.
      * The queue is emulated literally because the LAST, partial source call still appends a full burst
      * whose tail is stale queue memory (memsource.hpp:99-107). */
-    const uint32_t STR  = (sample_rate_mhz == 40) ? 2 : 1;                 /* raw samples per queue unit kept */
+    /* sample_rate_mhz == 44: the graph of CreateDemodGraph11a_44M (fb11ademod_config.hpp:236-300) over the 40 MHz stream
+     * that TDownSample44_40 produces.  That brick declares no Reset/Flush of its own (sampling.hpp:35-66), so the base
+     * TFilter::Reset/Flush (brick.h:310-311) neither clear nor pad ITS output queue: the raw samples waiting in front of
+     * TDownSample2 survive the reset that follows a frame, where TMemSamples' queue (40 MHz graph) is flushed. */
+    const int keep_queue = (sample_rate_mhz == 44);
+    const uint32_t STR  = (sample_rate_mhz != 20) ? 2 : 1;                 /* raw samples per queue unit kept */
     const uint32_t APP  = 28 / (2 / STR);                                  /* 28 raw  | 14 */
     const uint32_t BUR  = 8 / (2 / STR);                                   /* 8 raw   | 4  */
     const uint32_t QSZ  = 56 / (2 / STR);
@@ -663,7 +668,7 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
                 rx->pos20 = consumed;                                      /* end_sample of a PLCP failure: the samples taken from the source so far */
                 emit_result(rx, err);
                 /* Flush + Reset: every pin queue is cleared, including the source's partial burst */
-                w_cnt = r_cnt = 0;
+                if (!keep_queue) w_cnt = r_cnt = 0;
                 frame_reset(rx);
             }
         }

@@ -525,7 +525,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                     A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
                 }
                 nfr++;
-                vpos = avail_end;                                                   // Flush + Reset drop the queued tail
+                if (!A.keep_queue) vpos = avail_end;                                // Flush + Reset drop the queued tail (TMemSamples' queue; not TDownSample44_40's)
                 frame_reset();
             }
         }

@@ -11,6 +11,7 @@ struct ScanArgs {
     const CapDesc*  caps;
     uint32_t        ncaps;
     uint32_t        str;        // 2: 40 MHz input (keep even samples), 1: 20 MHz input
+    uint32_t        keep_queue; // 1: the 44 MHz graph (TDownSample44_40 has no Reset/Flush: its queued samples survive a frame reset)
     uint32_t        thr;        // cca_pwr_threshold
     uint32_t        max_frames; // per capture
     Tables          T;

@@ -317,7 +317,7 @@ int   sora_hip_memcpy_d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpy(h
 static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
 {
     if (!cfg || !out || cfg->struct_size != sizeof(sora_rx_cfg)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_create: bad cfg");
-    if (cfg->sample_rate_mhz != 20 && cfg->sample_rate_mhz != 40) return fail(SORA_ERR_INVALID_PARAM, "sample_rate_mhz must be 20 or 40");
+    if (cfg->sample_rate_mhz != 20 && cfg->sample_rate_mhz != 40 && cfg->sample_rate_mhz != 44) return fail(SORA_ERR_INVALID_PARAM, "sample_rate_mhz must be 20, 40 or 44");
     if (cfg->max_captures == 0 || cfg->max_total_samples == 0 || cfg->max_frames_per_capture == 0) return fail(SORA_ERR_INVALID_PARAM, "zero capacity");
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
@@ -326,7 +326,7 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     RxPipe* rx = new RxPipe();
     rx->cfg = *cfg;
     if (rx->cfg.cca_pwr_threshold == 0) rx->cfg.cca_pwr_threshold = 1000 * 1000;
-    rx->str = cfg->sample_rate_mhz == 40 ? 2 : 1;
+    rx->str = cfg->sample_rate_mhz == 20 ? 1 : 2;
     rx->tabs.device = cfg->device;
     int rc = make_dev_tables(rx->tabs);
     if (rc) { rx_free(rx); return rc; }
@@ -414,7 +414,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
         HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 12, st));
         ScanArgs S{};
-        S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.thr = rx->cfg.cca_pwr_threshold;
+        S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
         S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows;
         mark();

@@ -107,15 +107,36 @@ def source_position(end_sample20):
     return -(-end_sample20 * 2 // 28) * 28
 
 
-def same_as_reference_graph(rows, ref_events):
+def upsample_40_to_44(x40):
+    """Some 44 MHz capture: linear interpolation of a 40 MHz one, whole 28-sample source bursts (test input only)."""
+    n44 = len(x40) * 11 // 10 // 28 * 28
+    t = np.arange(n44) * (10 / 11.0)
+    i = np.minimum(t.astype(np.int64), len(x40) - 2); f = (t - i)[:, None]
+    x = x40.astype(np.float64)
+    return np.rint(x[i] * (1 - f) + x[i + 1] * f).astype(np.int16)
+
+
+def source_position_44(end_sample20):
+    """44 MHz source position at which RxThread sees an event under CreateDemodGraph11a_44M: TDownSample44_40 hands on
+    its k-th 28-sample burst during the first source call n after which it holds 28k samples (one output per input
+    except input indexes = 1 mod 11; 44MTo40M.hpp:83-123, sampling.hpp:48-63)."""
+    k = -(-end_sample20 * 2 // 28)
+    n = 0
+    while (28 * n - (28 * n + 9) // 11) // 28 < k:
+        n += 1
+    return 28 * n
+
+
+def same_as_reference_graph(rows, ref_events, position=None):
     """rows: oracle / GPU result dicts of ONE 40 MHz capture; ref_events: ReferenceGraph.rx11a() of the same capture."""
     if len(rows) != len(ref_events):
         return False, "event count %d vs reference %d" % (len(rows), len(ref_events))
     for i, (x, y) in enumerate(zip(rows, ref_events)):
         if x["error_code"] != y["error_code"]:
             return False, "event %d: error_code %#x vs reference %#x" % (i, x["error_code"], y["error_code"])
-        if source_position(x["end_sample"]) != y["sample_index"]:
-            return False, "event %d: position %d vs reference %d" % (i, source_position(x["end_sample"]), y["sample_index"])
+        pos = (position or source_position)(x["end_sample"])
+        if pos != y["sample_index"]:
+            return False, "event %d: position %d vs reference %d" % (i, pos, y["sample_index"])
         if x["error_code"] in (0x1, 0x80000006):
             for f in ("rate_kbps", "length", "crc32", "mpdu"):
                 if x[f] != y[f]:

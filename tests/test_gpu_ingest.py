@@ -77,3 +77,32 @@ def test_fixture_dump_from_hbm_to_mpdu(sora, oracle, golden_dir):
     rx20.process_dev(d20, [(0, n20, 0)])
     r20 = rx20.results()
     assert len(r20) == 1 and r20[0]["mpdu"] == res[0]["mpdu"]
+
+
+def test_44mhz_graph_on_the_gpu_equals_the_reference_44m_graph(sora, oracle):
+    """Row f3 end to end against the reference itself: 44 MHz captures -> sora_hip_ingest(44->40) -> sora_rx with
+    sample_rate_mhz = 44, compared event for event with CreateDemodGraph11a_44M compiled from the reference sources."""
+    import torch
+    from gpu_util import random_capture, same_as_reference_graph, source_position_44, upsample_40_to_44
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    rng = np.random.default_rng(4441)
+    caps44 = [upsample_40_to_44(random_capture(oracle, rng, 40)) for _ in range(200)]
+    parts, descs, pos = [], [], 0
+    for i, c in enumerate(caps44):
+        x = sora.ingest(torch.from_numpy(c).cuda(), sora.INGEST_44TO40)
+        n = x.shape[0] // 28 * 28                                       # whole bursts of TDownSample44_40
+        parts.append(x[:n]); descs.append((pos, n, i)); pos += n
+    iq = torch.cat(parts)
+    rx = sora.Rx(len(caps44), iq.shape[0], sample_rate_mhz=44, max_frames_per_capture=8)
+    rx.process_dev(iq, descs)
+    got = rx.results(); rx.close()
+    nev = 0
+    for i, c in enumerate(caps44):
+        ev = g.rx11a_44(c)
+        ok, why = same_as_reference_graph([r for r in got if r["capture_id"] == i], ev, position=source_position_44)
+        assert ok, "capture %d: %s" % (i, why)
+        nev += len(ev)
+    assert nev > 120

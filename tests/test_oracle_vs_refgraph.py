@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from gpu_util import random_capture, same_as_reference_graph, source_position
+from gpu_util import random_capture, same_as_reference_graph, source_position, source_position_44, upsample_40_to_44
 from oracle.pyoracle import Oracle, ReferenceGraph
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -128,3 +128,19 @@ def test_reference_11b_brick_path_runs_on_the_cpu(graph):
             ev = graph.rx11b(x)
             assert len(ev) == 1 and ev[0]["error_code"] == 1 and ev[0]["rate_kbps"] == rate and ev[0]["length"] == ln + 4, (rate, ln, ev)
             assert ev[0]["mpdu"][:ln] == mp
+
+
+def test_oracle_44mhz_mode_equals_the_reference_44m_graph(o, graph):
+    """CreateDemodGraph11a_44M = TDownSample44_40 in front of the same bricks.  The resampled stream is what
+    so_down44to40 makes, but that brick has no Reset/Flush, so the samples queued behind it survive the reset that
+    follows a frame (the 40 MHz graph flushes TMemSamples' queue): sample_rate_mhz = 44 selects that behaviour."""
+    rng = np.random.default_rng(4440)
+    nev = 0
+    for i in range(250):
+        c44 = upsample_40_to_44(random_capture(o, rng, 40))
+        ev = graph.rx11a_44(c44)
+        x40 = o.down44to40(c44)
+        ok, why = same_as_reference_graph(o.rx_capture(x40[:len(x40) // 28 * 28], 44), ev, position=source_position_44)
+        assert ok, "capture %d: %s" % (i, why)
+        nev += len(ev)
+    assert nev > 150
