@@ -272,6 +272,21 @@ class ReferenceGraph:
         """The reference's 802.11b receive graph (Test11B_FB_Demod / MAC11b_Receive) over int16 [n,2] @44 MHz."""
         return self._events(self.L.ref_rx11b_capture, iq44, max_frames)
 
+    def tx11n(self, mpdu_nofcs, mcs):
+        """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""
+        a = np.frombuffer(bytes(mpdu_nofcs), np.uint8); cap = 1 << 20
+        o0 = np.zeros((cap, 2), np.int16); o1 = np.zeros((cap, 2), np.int16)
+        n = self.L.ref_tx11n(_P(a), len(a), mcs, _P(o0), _P(o1), cap)
+        if n < 0: raise ValueError("ref_tx11n failed")
+        return o0[:n], o1[:n]
+
+    def rx11n(self, iq0, iq1, max_frames=16):
+        """The reference's 802.11n 2x2 receive graph (Test11N_FB_Demod / RxThread) over two int16 [n,2] captures @40 MHz.
+        rate_kbps carries the MCS index."""
+        a = np.ascontiguousarray(iq0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(iq1, np.int16).reshape(-1, 2)
+        assert len(a) == len(b)
+        return self._events(lambda p, n, res, mf, mp, cap: self.L.ref_rx11n_capture(p, _P(b), n, res, mf, mp, cap), a, max_frames)
+
     def rx11a_44(self, iq44, max_frames=64):
         """CreateDemodGraph11a_44M (TDownSample44_40 in front) over int16 [n,2] @44 MHz; sample_index in 44 MHz samples."""
         return self._events(self.L.ref_rx11a_capture44, iq44, max_frames)

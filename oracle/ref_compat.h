@@ -6,6 +6,7 @@
 #define _MSC_VER 1900                       /* selects the decltype-based TYPEOF and static_assert-based CCASSERT */
 #include <type_traits>
 #include <typeinfo>
+#include <cxxabi.h>
 #include <new>
 #include <stdint.h>
 #include <stddef.h>
@@ -20,6 +21,9 @@
 #define _UI32_MAX UINT32_MAX
 #define IN
 #define OUT
+#define __in
+#define __out
+#define __inout
 #define __stdcall
 #define __cdecl
 #define TRUE 1
@@ -50,5 +54,11 @@ static inline int QueryPerformanceFrequency(LARGE_INTEGER* p) { p->QuadPart = 1;
 #define SORA_RX_SIGNAL_UNIT_COMPLEX16_NUM 4
 #define SORA_RX_SIGNAL_UNIT_SIZE          16
 #define M128_WORD_NUM                     8
+static inline void* _aligned_malloc(size_t size, size_t align) { return aligned_alloc(align, (size + align - 1) / align * align); }
+static inline void  _aligned_free(void* p) { free(p); }
+/* the sources pass "unsigned long*" (32 bits on Windows, 64 here) to the intrinsic */
+template<class T> static inline unsigned char sora_bit_scan_reverse(T* index, uint32_t mask)
+{ if (!mask) return 0; *index = (T)(31 - __builtin_clz(mask)); return 1; }
+#define _BitScanReverse sora_bit_scan_reverse
 #define min(a, b) (((a) < (b)) ? (a) : (b))
 #define max(a, b) (((a) > (b)) ? (a) : (b))

@@ -99,3 +99,16 @@ write("rxstream.h", "#pragma once\n")
 for lower, real in (("phy_11b.hpp", "PHY_11b.hpp"), ("phy_11a.hpp", "PHY_11a.hpp"), ("phy_11n.hpp", "PHY_11n.hpp")):
     if os.path.exists(OUT + "/" + real) and not os.path.exists(OUT + "/" + lower):
         write(lower, '#pragma once\n#include "%s"\n' % real)
+
+# ---- 11n graphs: casts of an rvalue to a reference (an MSVC extension) go through a named temporary
+_RV = re.compile(r"c = \((\w+)&\)(_mm_shuffle_p[sd]\(.*\)); return c;")
+for h in ("sora_matrix.h", "vector128.h"):
+    edit(h, lambda s: _RV.sub(r"{ auto t_ = \2; c = (\1&)t_; } return c;", s))
+# ---- the 11n receive graph: same thread-hop substitution as the 11a graph
+edit("fb11ndemod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))
+# ---- stdbrick.hpp: a temporary bound to a non-const reference parameter (an MSVC extension)
+edit("stdbrick.hpp", lambda s: s.replace("Next0()->Process(ipin.clone());", "{ auto c_ = ipin.clone(); Next0()->Process(c_); }"))
+# ---- brick.h: TraverseGraph finds bricks by MSVC's spelling of typeid names ("class Name<...>")
+edit("brick.h", lambda s: s.replace("        const char *self = typeid(*this).name();",
+     '        char self[2048]; { int st_; char* d_ = abi::__cxa_demangle(typeid(*this).name(), 0, 0, &st_);'
+     ' snprintf(self, sizeof(self), "class %s", d_ ? d_ : ""); free(d_); }'))

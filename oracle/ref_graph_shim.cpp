@@ -176,3 +176,72 @@ EXPORT int ref_rx11b_capture(const int16_t* iq, uint32_t nsamples44, ref_frame* 
 // Drop the cached 40 MHz receive graph so that the next call builds a fresh one (tests use it to show that no result
 // depends on what an earlier capture left in the bricks).
 EXPORT void ref_rx11a_fresh_graph(void) { if (g_src) { IReferenceCounting::Release(g_src); g_src = NULL; } }
+
+// ---------------------------------------------------------------- 802.11n 2x2: the reference's own graphs
+#include "phy_11n.hpp"
+#include "fb11nmod_config.hpp"
+#include "fb11ndemod_config.hpp"
+
+// Test11N_FB_Mod (fb11n_mod.cpp:28-70): L-STF/L-LTF, L-SIG/HT-SIG, HT-STF/HT-LTF and data graphs into two COMPLEX16
+// streams (one per TX chain) at 40 MHz.  mcs: what the harness passes as "bit rate" (8..15 in this tree).
+// Returns samples per chain, or -1.
+EXPORT int ref_tx11n(const uint8_t* mpdu, uint32_t len, uint32_t mcs, int16_t* out0, int16_t* out1, uint32_t max_samples)
+{
+    static ISource *lsrc, *htsrc, *sigsrc, *ssrc;
+    static unsigned char data[4096 + 16];
+    if (len > 4096 - 4) return -1;
+    if (!ssrc) { CreatePreambleGraph11n(lsrc, htsrc); sigsrc = CreateSigGraph11n(); ssrc = CreateModGraph11n(); }
+    COMPLEX16* bufs[2] = { (COMPLEX16*)out0, (COMPLEX16*)out1 };
+    memset(data, 0, sizeof(data)); memcpy(data, mpdu, len);
+    BB11nModCtx.init((ushort)mcs, data, (ushort)len, bufs, max_samples);
+    ISource* seq[4] = { lsrc, sigsrc, htsrc, ssrc };
+    for (int i = 0; i < 4; i++) {
+        seq[i]->Reset();
+        if (BB11nModCtx.CF_Error::error_code() != E_ERROR_SUCCESS) return -1;
+        seq[i]->Process();
+    }
+    ssrc->Flush();
+    return (int)BB11nModCtx.GetSinkSampleCount();
+}
+
+// Test11N_FB_Demod + RxThread (fb11n_demod.cpp:30-85, 92-140) over two 40 MHz captures (one per RX chain) in memory.
+EXPORT int ref_rx11n_capture(const int16_t* iq0, const int16_t* iq1, uint32_t nsamples40, ref_frame* res, int max_res, uint8_t* mpdu, uint32_t mpdu_cap)
+{
+    static ISource *ssrc, *svit; static IControlPoint* scs;
+    static unsigned char out[4096];
+    static COMPLEX16* buf[2]; static uint32_t cap;
+    if (cap < nsamples40 + 64) {
+        for (int k = 0; k < 2; k++) { free(buf[k]); buf[k] = (COMPLEX16*)aligned_alloc(16, ((size_t)(nsamples40 + 64) * 4 + 15) & ~(size_t)15); }
+        cap = nsamples40 + 64;
+    }
+    memcpy(buf[0], iq0, (size_t)nsamples40 * 4); memcpy(buf[1], iq1, (size_t)nsamples40 * 4);
+    BB11nDemodCtx.Init(out, sizeof(out));
+    if (ssrc) { IReferenceCounting::Release(ssrc); ssrc = NULL; }     // a fresh graph per capture (the harness builds one per run)
+    CreateDemodGraph11n(ssrc, svit, scs);
+    IQuery* q;
+    if (!ssrc->TraverseGraph(&q, "TMemSamples2", 1)) return -1;
+    MemSamplesDesc* ms = q->QueryInterface<MemSamplesDesc>();
+    ms->Init(2, buf, nsamples40);
+    ssrc->Reset();
+    int n = 0; uint32_t used = 0; uint nWaitCounter = 12;
+    for (;;) {
+        bool rc = ssrc->Process();
+        ulong err = BB11nDemodCtx.CF_Error::error_code();
+        if (err != E_ERROR_SUCCESS) {
+            if (err == E_ERROR_CS_TIMEOUT) {
+                BB11nDemodCtx.ResetCarrierSense(); scs->Reset();
+                if (nWaitCounter > 0) { nWaitCounter--; continue; }
+                nWaitCounter = 12; continue;
+            }
+            if (n < max_res) {
+                ref_frame& f = res[n++];
+                f.error_code = err; f.sample_index = 0; f.rate_kbps = BB11nDemodCtx.CF_HTRxVector::ht_frame_mcs();
+                f.length = BB11nDemodCtx.CF_HTRxVector::ht_frame_length(); f.crc32 = BB11nDemodCtx.CF_11aRxVector::crc32(); f.mpdu_offset = used;
+                if ((err == E_ERROR_FRAME_OK || err == E_ERROR_CRC32_FAIL) && used + f.length <= mpdu_cap) { memcpy(mpdu + used, out, f.length); used += f.length; }
+            }
+            ssrc->Flush(); BB11nDemodCtx.Reset(); ssrc->Reset();
+        }
+        if (!rc) break;
+    }
+    return n;
+}

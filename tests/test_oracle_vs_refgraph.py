@@ -144,3 +144,26 @@ def test_oracle_44mhz_mode_equals_the_reference_44m_graph(o, graph):
         assert ok, "capture %d: %s" % (i, why)
         nev += len(ev)
     assert nev > 150
+
+
+def test_reference_11n_2x2_brick_path_runs_on_the_cpu(graph):
+    """SURVEY row f1 / BASELINE configs[3], plumbing: the reference's own 802.11n 2x2 graphs (fb11nmod_config.hpp,
+    fb11ndemod_config.hpp:167-264 -- two 64-point FFTs, ZF detection, one Viterbi) compiled from the reference sources
+    loop back through a 2x2 channel with cross-talk and noise at MCS 8, 9 and 10, the three the reference's receiver
+    accepts (its SIG parser refuses MCS 11-14, which its modulator can emit: PLCP_HEADER_FAIL)."""
+    rng = np.random.default_rng(1109)
+    for mcs in (8, 9, 10, 12):
+        for ln in (60, 1000):
+            mp = rng.integers(0, 256, ln).astype(np.uint8).tobytes()
+            s0, s1 = graph.tx11n(mp, mcs)
+            n = (len(s0) + 1400) // 28 * 28
+            a = np.zeros((n, 2)); b = np.zeros((n, 2))
+            a[400:400 + len(s0)] = s0 + 0.1 * s1; b[400:400 + len(s0)] = s1 + 0.1 * s0
+            a = np.clip(np.rint(a + rng.normal(0, 20, a.shape)), -32768, 32767).astype(np.int16)
+            b = np.clip(np.rint(b + rng.normal(0, 20, b.shape)), -32768, 32767).astype(np.int16)
+            ev = graph.rx11n(a, b)
+            assert len(ev) == 1 and ev[0]["rate_kbps"] == mcs, (mcs, ln, ev)
+            if mcs <= 10:
+                assert ev[0]["error_code"] == 1 and ev[0]["length"] == ln + 4 and ev[0]["mpdu"][:ln] == mp, (mcs, ln)
+            else:
+                assert ev[0]["error_code"] == 0x80000005
