@@ -156,6 +156,18 @@ class Oracle:
             return out, {"ctx": ctx, "eq": eq[:tr.n_syms], "tracked": trk[:tr.n_syms], "soft": soft[:tr.n_soft], "decoded": dec}
         return out
 
+    def rx11b_capture(self, iq44, max_frames=16):
+        """802.11b receive graph over int16 [n,2] @44 MHz -> list of dict (end_sample = 44 MHz source position)."""
+        iq = np.ascontiguousarray(iq44, np.int16).reshape(-1, 2)
+        res = (FrameResult * max_frames)(); mp = np.zeros(max_frames * 4096, np.uint8)
+        n = self.L.so_rx11b_capture(_P(iq), len(iq), res, max_frames, _P(mp), mp.size)
+        out = []
+        for r in res[:n]:
+            d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
+            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            out.append(d)
+        return out
+
     def load_dump(self, path_or_bytes, raw14=False):
         raw = np.fromfile(path_or_bytes, np.uint8) if isinstance(path_or_bytes, str) else np.frombuffer(path_or_bytes, np.uint8)
         cap = (len(raw) // 128 + 1) * 28; iq = np.zeros((cap, 2), np.int16)

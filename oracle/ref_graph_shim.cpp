@@ -147,8 +147,11 @@ EXPORT int ref_rx11b_capture(const int16_t* iq, uint32_t nsamples44, ref_frame* 
     if (g_cap < nsamples44 + 64) { free(g_buf); g_cap = nsamples44 + 64; g_buf = (COMPLEX16*)aligned_alloc(16, ((size_t)g_cap * 4 + 15) & ~(size_t)15); }
     memcpy(g_buf, iq, (size_t)nsamples44 * 4);
     BB11bDemodCtx.init(g_buf, nsamples44 * sizeof(COMPLEX16), out, sizeof(out));
-    if (!pRxSource) pRxSource = CreateDemodGraph();
-    else pRxSource->Seek(ISource::START_POS);
+    memset(out, 0, sizeof(out));                                         // as at the start of the harness process: static buffers and
+    memset(&BB11bDemodCtx.CF_DifferentialDemap::last_symbol(), 0, sizeof(COMPLEX16));   // the two context fields that no reset touches
+    BB11bDemodCtx.CF_Descramber::byte_reg() = 0;
+    if (pRxSource) { IReferenceCounting::Release(pRxSource); pRxSource = NULL; }   // a fresh graph per capture, as the harness has
+    pRxSource = CreateDemodGraph();
     pRxSource->Flush(); BB11bDemodCtx.reset(); pRxSource->Reset();
     int n = 0; uint32_t used = 0;
     for (;;) {                                                           // MAC11b_Receive is called until it returns false

@@ -23,6 +23,10 @@ typedef struct { int16_t re, im; } so_c16;
 #define SO_E_PLCP_HEADER_FAIL 0x80000005u
 #define SO_E_CRC32_FAIL       0x80000006u
 #define SO_E_CS_TIMEOUT       0x80000007u
+#define SO_E_NOT_SUPPORTED    0x80000003u
+#define SO_E_SFD_FAIL         0x80000004u
+#define SO_E_SFD_TIMEOUT      0x80000008u
+#define SO_E_SYNC_TIMEOUT     0x80000009u
 #define SO_E_FAILED           0x8000FFFFu
 
 /* code rates: ieee80211const.h:14-20 */
@@ -101,6 +105,10 @@ typedef struct {             /* optional intermediates of the FIRST decoded fram
  * Returns number of frame results written. */
 int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
                      so_frame_result* res, int max_res, uint8_t* mpdu_buf, uint32_t mpdu_cap, so_trace* trace);
+
+/* 802.11b receive graph (so_rx11b.c): one 44 MHz capture; end_sample = source position (44 MHz samples) at which the
+ * harness sees the event, rate_kbps/length/crc32 as the reference's CF_11bRxVector holds them (crc32: 3 FCS bytes + 1 stale). */
+int so_rx11b_capture(const so_c16* iq, uint32_t nsamples, so_frame_result* res, int max_res, uint8_t* mpdu_buf, uint32_t mpdu_cap);
 
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */
 int so_load_dump(const uint8_t* file, uint32_t file_bytes, so_c16* out, uint32_t max_samples, int raw14);

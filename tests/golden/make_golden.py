@@ -12,6 +12,8 @@
                          (tests/gpu_util.random_capture): per event the capture index, error code, source position,
                          FCS and the first 8 bytes of the MPDU's sha256; and length + sha256 prefix of what the reference's
                          modulation graph (CreateModGraph11a_40M) emits for a list of frames.
+  refgraph_11b.npz       802.11b: the reference modulator's output (COMPLEX8 @44 MHz) for six 1/2 Mbps frames and the events
+                         its receive graph reports for captures made of them (tests/test_oracle_11b.channel_11b).
 All files travel to the GPU box; /root/reference does not.
 """
 import hashlib
@@ -101,6 +103,25 @@ def main():
                         ev_capture=np.array(ev["capture"], np.int32), ev_error=np.array(ev["error"], np.uint32),
                         ev_position=np.array(ev["position"], np.uint32), ev_crc32=np.array(ev["crc32"], np.uint32),
                         ev_mpdu_sha=np.stack(ev["sha"]))
+    # 802.11b: what the reference's modulation graph emits for a few frames, and what its receive graph reports for the
+    # captures tests/test_oracle_11b.channel_11b makes of them
+    from test_oracle_11b import channel_11b
+    b = {"frames": 6}; evs = {"count": [], "error": [], "position": [], "rate": [], "length": [], "crc": []}
+    rng = np.random.default_rng(1102)
+    for f, (rate, ln) in enumerate([(1000, 1), (1000, 14), (1000, 40), (2000, 5), (2000, 60), (2000, 200)]):
+        s8 = G.tx11b(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), rate)
+        b["tx_%d" % f] = s8
+        for rep in range(3):
+            ev = G.rx11b(channel_11b(s8, 100 * f + rep))
+            evs["count"].append(len(ev))
+            for e in ev:
+                b["mpdu_%d" % len(evs["error"])] = np.frombuffer(e["mpdu"], np.uint8)
+                evs["error"].append(e["error_code"]); evs["position"].append(e["sample_index"]); evs["rate"].append(e["rate_kbps"])
+                evs["length"].append(e["length"]); evs["crc"].append(e["crc32"])
+    np.savez_compressed(os.path.join(OUT, "refgraph_11b.npz"), ev_count=np.array(evs["count"], np.int32),
+                        ev_error=np.array(evs["error"], np.uint32), ev_position=np.array(evs["position"], np.uint32),
+                        ev_rate=np.array(evs["rate"], np.uint32), ev_length=np.array(evs["length"], np.uint32),
+                        ev_crc=np.array(evs["crc"], np.uint32), **b)
     print("written", os.listdir(OUT))
 
 

@@ -142,3 +142,53 @@ def same_as_reference_graph(rows, ref_events, position=None):
                 if x[f] != y[f]:
                     return False, "event %d: %s differs from the reference" % (i, f)
     return True, ""
+
+
+def random_capture_11b(graph, rng):
+    """A random 44 MHz capture for the 802.11b receive graph: 1-3 frames of the REFERENCE's own modulator (1 or 2 Mbps,
+    long preamble; graph = oracle.pyoracle.ReferenceGraph) with gaps, gain, DC offset, a small carrier offset, noise,
+    sometimes truncated, sometimes noise only."""
+    kind = rng.integers(0, 10)
+    if kind == 0:
+        n = int(rng.integers(4, 400)) * 28
+        return np.rint(rng.normal(0, rng.choice([30, 300, 3000]), (n, 2))).astype(np.int16)
+    parts = []
+    for _ in range(int(rng.choice([1, 1, 1, 2, 3]))):
+        rate = int(rng.choice([1000, 2000])); ln = int(rng.choice([1, 5, 14, 20, 60, 150, 400]))
+        s8 = graph.tx11b(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), rate)
+        x = np.zeros((int(rng.integers(0, 3000)) + len(s8) + int(rng.choice([400, 1600, 2800, 6000])), 2), np.int16)
+        lead = len(x) - len(s8) - int(rng.choice([400, 1600, 2800, 6000][:1])) if False else int(rng.integers(0, len(x) - len(s8) + 1))
+        x[lead:lead + len(s8)] = s8.astype(np.int16) << 8
+        parts.append(x)
+    x = np.concatenate(parts).astype(np.float64)
+    if kind == 1:
+        x = x[:int(len(x) * rng.uniform(0.3, 0.95))]
+    if rng.random() < 0.3:
+        f = rng.uniform(-20e3, 20e3)
+        z = (x[:, 0] + 1j * x[:, 1]) * np.exp(2j * np.pi * f * np.arange(len(x)) / 44e6)
+        x = np.stack([z.real, z.imag], 1)
+    if rng.random() < 0.3:
+        x += rng.uniform(-600, 600, size=(1, 2))
+    if rng.random() < 0.3:
+        x *= rng.uniform(0.2, 1.5)
+    sigma = float(rng.choice([0, 40, 150, 400, 1200, 3000]))
+    if sigma:
+        x += rng.normal(0, sigma, x.shape)
+    x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    return x[:len(x) // 28 * 28]
+
+
+def same_as_reference_11b(rows, ref_events):
+    """rows: oracle / GPU results of one 44 MHz capture; ref_events: ReferenceGraph.rx11b().  The FCS word of the
+    reference holds three FCS bytes and one stale buffer byte (PHY_11b.hpp:725-731): its top byte is not compared."""
+    if len(rows) != len(ref_events):
+        return False, "event count %d vs reference %d" % (len(rows), len(ref_events))
+    for i, (x, y) in enumerate(zip(rows, ref_events)):
+        if x["error_code"] != y["error_code"]:
+            return False, "event %d: error_code %#x vs reference %#x" % (i, x["error_code"], y["error_code"])
+        if x["end_sample"] != y["sample_index"]:
+            return False, "event %d: position %d vs reference %d" % (i, x["end_sample"], y["sample_index"])
+        if x["error_code"] in (0x1, 0x80000006):
+            if (x["rate_kbps"], x["length"], x["crc32"] & 0xFFFFFF, x["mpdu"]) != (y["rate_kbps"], y["length"], y["crc32"] & 0xFFFFFF, y["mpdu"]):
+                return False, "event %d: rate/length/FCS/MPDU differ from the reference" % i
+    return True, ""
