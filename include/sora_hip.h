@@ -183,6 +183,27 @@ int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t*
                    const uint8_t* d_seed, size_t nframes, int8_t* d_out, const uint64_t* d_out_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
+ * MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76) over a batch of independent 44 MHz captures: TDCRemove,
+ * TEnergyDetect / TDCEstimator, TSymTiming, TBarkerSync, TBB11bDespread, TSFDSync, TDBPSKDemap / TDQPSKDemap, TDesc741,
+ * TBB11bPlcpParser, TBB11bFrameSink.  cfg->sample_rate_mhz must be 44; capture lengths are whole 28-sample bursts.
+ * Result rows: end_sample = CF_MemSamples::mem_sample_index() when the harness sees the event (44 MHz samples);
+ * error_code also takes SORA_E_SFD_FAIL / SORA_E_SFD_TIMEOUT / SORA_E_SYNC_TIMEOUT; crc32 = the reference's FCS word (three
+ * FCS bytes and one stale buffer byte, PHY_11b.hpp:725-731); start_sample, nsym and cfo_est are 0.  Long preamble, 1 Mbps
+ * DBPSK and 2 Mbps DQPSK payloads; a header announcing 5.5 / 11 Mbps (CCK) ends the frame with SORA_E_NOT_SUPPORTED.
+ * ------------------------------------------------------------------------------------------------ */
+#define SORA_E_NOT_SUPPORTED     ((int)0x80000003)
+#define SORA_E_SFD_FAIL          ((int)0x80000004)
+#define SORA_E_SFD_TIMEOUT       ((int)0x80000008)
+#define SORA_E_SYNC_TIMEOUT      ((int)0x80000009)
+typedef struct sora_rx11b sora_rx11b_t;
+int  sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out);
+void sora_rx11b_destroy(sora_rx11b_t* rx);
+int  sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps);
+int  sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsamples, const sora_capture_desc* caps, size_t ncaps);
+int  sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+
+/* ------------------------------------------------------------------------------------------------
  * Small device-memory helpers so a pure-C host needs no HIP headers.
  * ------------------------------------------------------------------------------------------------ */
 int   sora_hip_device_count(void);

@@ -73,4 +73,23 @@ __global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const u
 __global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
                                const uint32_t* out_off, int code_rate, uint32_t n);
 
+// ---- 802.11b receive graph (k_rx11b.hip)
+struct Rx11bRow { uint32_t end_sample, error_code, rate_kbps, length, crc32; };
+struct Rx11bArgs {
+    const uint32_t* iq;         // packed COMPLEX16 @44 MHz
+    const CapDesc*  caps;
+    uint32_t        ncaps;
+    uint32_t        thr;        // cca_pwr_threshold
+    uint32_t        max_frames; // rows per capture
+    Rx11bRow*       rows;       // [ncaps*max_frames]
+    uint32_t*       nframes;    // [ncaps]
+    uint8_t*        mpdu;       // [ncaps*max_frames][4096]
+    const uint32_t* crc;        // CRC-32 table
+};
+__global__ void k_rx11b(Rx11bArgs A);
+
 }  // namespace sora
+
+// sora_hip.cpp: records the message sora_hip_last_error() returns; hip_error = 0 for none
+int sora_internal_fail(int code, const char* what, int hip_error);
+const uint32_t* sora_internal_crc_table(int device);   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr

@@ -234,6 +234,14 @@ static DevTables* stage_tables()
     return tabs[dev];
 }
 
+int sora_internal_fail(int code, const char* what, int hip_error) { return fail(code, what, (hipError_t)hip_error); }
+const uint32_t* sora_internal_crc_table(int device)
+{
+    if (hipSetDevice(device) != hipSuccess) return nullptr;
+    DevTables* D = stage_tables();
+    return D ? D->T.crc : nullptr;
+}
+
 // ------------------------------------------------------------------------------------------------
 // One receive pipeline: a stream, the device arrays of one call in flight, and that call's bookkeeping.
 struct RxPipe {

@@ -1,0 +1,86 @@
+"""GPU 802.11b receive graph (sora_rx11b_*, row f4) against the reference's own graph compiled from its sources and against
+the C restatement, event for event: error code, source position, rate, length, FCS word, MPDU bytes."""
+import os
+
+import numpy as np
+import pytest
+
+from gpu_util import random_capture_11b, same_as_reference_11b
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def sora():
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    return sora_amd
+
+
+def run_11b(sora, caps, max_frames=16):
+    import torch
+    parts, descs, pos = [], [], 0
+    for i, c in enumerate(caps):
+        descs.append((pos, len(c), i)); parts.append(c); pos += len(c)
+    iq = np.concatenate(parts) if parts else np.zeros((0, 2), np.int16)
+    rx = sora.Rx11b(max(1, len(caps)), max(28, len(iq)), max_frames_per_capture=max_frames)
+    rx.process_dev(torch.from_numpy(iq).cuda(), descs)
+    res = rx.results(); rx.close()
+    return res
+
+
+def oracle_rows(oracle, c):
+    rows = oracle.rx11b_capture(c, max_frames=64)
+    return [dict(r, sample_index=r["end_sample"]) for r in rows]
+
+
+def test_gpu_11b_equals_recorded_reference_events(sora, oracle):
+    from test_oracle_11b import channel_11b
+    z = np.load(os.path.join(GOLD, "refgraph_11b.npz"))
+    caps = [channel_11b(z["tx_%d" % f], 100 * f + rep) for f in range(int(z["frames"])) for rep in range(3)]
+    got = run_11b(sora, caps)
+    k = 0
+    for i in range(len(caps)):
+        rows = [r for r in got if r["capture_id"] == i]
+        assert len(rows) == int(z["ev_count"][i])
+        for r in rows:
+            assert (r["error_code"], r["end_sample"]) == (z["ev_error"][k], z["ev_position"][k]), i
+            if r["error_code"] in (1, 0x80000006):
+                assert (r["rate_kbps"], r["length"], r["crc32"] & 0xFFFFFF) == (z["ev_rate"][k], z["ev_length"][k], z["ev_crc"][k] & 0xFFFFFF)
+                assert np.array_equal(np.frombuffer(r["mpdu"], np.uint8), z["mpdu_%d" % k])
+            k += 1
+    assert k == len(z["ev_error"])
+
+
+def test_gpu_11b_equals_reference_graph_and_oracle_on_random_captures(sora, oracle):
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present (the captures come from the reference's modulator)")
+    rng = np.random.default_rng(1111)
+    caps = [random_capture_11b(g, rng) for _ in range(400)]
+    got = run_11b(sora, caps, max_frames=64)
+    nev = nok = 0
+    for i, c in enumerate(caps):
+        rows = [r for r in got if r["capture_id"] == i]
+        ev = g.rx11b(c, max_frames=64)
+        ok, why = same_as_reference_11b(rows, ev)
+        assert ok, "capture %d vs the reference graph: %s" % (i, why)
+        ok, why = same_as_reference_11b(rows, oracle_rows(oracle, c))
+        assert ok, "capture %d vs oracle/so_rx11b.c: %s" % (i, why)
+        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev)
+    assert nev > 1000 and nok > 300
+
+
+def test_11b_capacity_and_argument_errors(sora):
+    import torch
+    with pytest.raises(Exception):
+        sora.Rx11b(0, 28)
+    rx = sora.Rx11b(1, 280)
+    with pytest.raises(Exception):
+        rx.process_dev(torch.zeros((30, 2), dtype=torch.int16).cuda(), [(0, 30, 0)])      # not whole source bursts
+    with pytest.raises(Exception):
+        rx.process_dev(torch.zeros((560, 2), dtype=torch.int16).cuda(), [(0, 560, 0)])    # more than max_total_samples
+    rx.close()
