@@ -193,6 +193,50 @@ def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
 
 
+def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
+    """Row f4 (802.11b receive graph): `ncaps` 44 MHz captures of one 1 Mbps DBPSK frame each (the modulator output recorded
+    in tests/golden/refgraph_11b.npz, or a 500-byte frame from the compiled reference modulator when that library is
+    here), noise added on the device.  A streaming integer path: 4 B per sample against the HBM roofline; the reference's
+    own 11b graph is timed on one host core beside it when oracle/_ref is present."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if g.available():
+        s8 = g.tx11b(np.random.default_rng(11).integers(0, 256, 500).astype(np.uint8).tobytes(), 1000); what = "500-byte MPDU"
+    else:
+        s8 = np.load(os.path.join(ROOT, "tests", "golden", "refgraph_11b.npz"))["tx_2"]; what = "40-byte MPDU (recorded modulator output)"
+    n = (len(s8) + 1200 + 2800 + 27) // 28 * 28
+    base = np.zeros((n, 2), np.int16); base[1200:1200 + len(s8)] = s8.astype(np.int16) << 8
+    b = torch.from_numpy(base).to(dev).to(torch.float32)
+    gen = torch.Generator(device=dev); gen.manual_seed(1102)
+    iq = torch.empty((ncaps, n, 2), dtype=torch.int16, device=dev)
+    for i in range(0, ncaps, 64):
+        k = min(64, ncaps - i)
+        iq[i:i + k] = (b[None] + 40.0 * torch.randn((k, n, 2), generator=gen, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+    descs = sora_amd.Rx.captures([(i * n, n, i) for i in range(ncaps)])
+    rx = sora_amd.Rx11b(ncaps, ncaps * n, max_frames_per_capture=4)
+    flat = iq.view(-1, 2)
+    torch.cuda.synchronize()                                            # the handle's stream does not follow torch's
+    rx.process_dev(flat, descs); res = rx.results()
+    ok = sum(r["error_code"] == 1 for r in res)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        rx.process_dev(flat, descs)
+    rx.results(); ms = (time.perf_counter() - t0) / reps * 1e3          # results() waits for the handle's stream
+    out = {"workload": "%d captures x one 1 Mbps DBPSK frame, %s, long preamble (%d samples @44 MHz each), AWGN" % (ncaps, what, n),
+           "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
+           "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
+           "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
+    if g.available():
+        sample = iq[:8].cpu().numpy()
+        g.rx11b_bench(sample[:1])
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 2.0:
+            g.rx11b_bench(sample); k += 8
+        out["cpu_reference_msamples_per_s_one_core"] = round(k * n / (time.perf_counter() - t0) / 1e6, 2)
+    rx.close(); del iq, flat
+    return out
+
+
 def bench_tx(torch, sora_amd, nframes=4096, reps=10):
     """Row f2 (transmitter): the same 4096 x 1500-byte 54 Mbps frames modulated on the GPU (COMPLEX8 @40 MHz out)."""
     rng = np.random.default_rng(0x5EED)
@@ -348,6 +392,7 @@ def main():
         if world == 1:
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
             out["tx"] = bench_tx(torch, sora_amd)
+            out["rx11b"] = bench_11b(torch, sora_amd, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(iq, nfr)
         print(json.dumps(out))

@@ -258,6 +258,12 @@ class ReferenceGraph:
 
     def available(self): return self.L is not None
 
+    def rx11b_bench(self, iq44_caps, reps=1):
+        """iq44_caps: int16 [ncap, n, 2]; runs every capture `reps` times inside the library -> FRAME_OK count."""
+        a = np.ascontiguousarray(iq44_caps, np.int16)
+        self.L.ref_rx11b_bench.restype = ctypes.c_uint32
+        return self.L.ref_rx11b_bench(_P(a), a.shape[0], a.shape[1], reps)
+
     def rx11a_bench(self, iq40_caps, reps=1):
         """iq40_caps: int16 [ncap, n, 2]; runs every capture `reps` times inside the library -> FRAME_OK count."""
         a = np.ascontiguousarray(iq40_caps, np.int16)

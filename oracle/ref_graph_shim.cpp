@@ -253,3 +253,15 @@ EXPORT int ref_rx11n_capture(const int16_t* iq0, const int16_t* iq1, uint32_t ns
     }
     return n;
 }
+
+// The 802.11b loop over `ncap` equal-sized captures, `reps` times (bench.py: the reference 11b path on a host core).
+EXPORT uint32_t ref_rx11b_bench(const int16_t* iq, uint32_t ncap, uint32_t nsamples44, uint32_t reps)
+{
+    static uint8_t mpdu[8192]; ref_frame res[8]; uint32_t ok = 0;
+    for (uint32_t r = 0; r < reps; r++)
+        for (uint32_t c = 0; c < ncap; c++) {
+            int n = ref_rx11b_capture(iq + (size_t)c * nsamples44 * 2, nsamples44, res, 8, mpdu, sizeof(mpdu));
+            for (int i = 0; i < n; i++) ok += res[i].error_code == E_ERROR_FRAME_OK;
+        }
+    return ok;
+}

@@ -29,35 +29,45 @@ constexpr uint32_t kOutBuf = 4096;                                    // OUTPUTB
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int lane_of(int v, int l) { return __builtin_amdgcn_readlane(v, uni(l)); }
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // lanes without a source read 0
+__device__ __forceinline__ int quad_sum(int v) { v += dpp<0xB1>(v); return v + dpp<0x4E>(v); }                   // quad_perm [1,0,3,2], [2,3,0,1]: every lane of a quad gets its sum
+__device__ __forceinline__ int sum8(int v) { v = quad_sum(v); return v + dpp<0x104>(v); }                        // + row_shl:4: lanes 0..3 hold lanes 0..7
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ uint32_t dot_sign(int rre, int rim, int xre, int xim)          // (ulong)(ref.re*s.re + ref.im*s.im) >> 31
 { return ((uint32_t)(rre * xre) + (uint32_t)(rim * xim)) >> 31; }
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
+__global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
 {
     __shared__ uint8_t s_out_all[4][kOutBuf];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __shared__ int s_state_all[4][32];                                  // per wave: [0..19] TBarkerSync partial sums, [20..27] TEnergyDetect window
+    const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));      // wave-uniform values are told to be so: state then lives in SGPRs
     const uint32_t cap_i = blockIdx.x * 4 + wave;
     if (cap_i >= A.ncaps) return;
     uint8_t* s_out = s_out_all[wave];
+    int* const p_re = s_state_all[wave]; int* const p_im = p_re + 10; uint32_t* const win = reinterpret_cast<uint32_t*>(p_re + 20);
+    if (lane < 32) p_re[lane] = 0;
     for (int i = lane; i < (int)kOutBuf / 4; i += 64) reinterpret_cast<uint32_t*>(s_out)[i] = 0;
     lds_order();
     const CapDesc cap = A.caps[cap_i];
-    const uint32_t* x = A.iq + cap.offset;
+    const uint32_t cap_n = (uint32_t)uni((int)cap.nsamples);
+    const uint32_t* x = A.iq + (((uint64_t)(uint32_t)uni((int)(cap.offset >> 32)) << 32) | (uint32_t)uni((int)(uint32_t)cap.offset));
     const uint32_t thr = A.thr;
 
     // ---- context facades: survive every reset except as noted (ieee80211facade.hpp:21-135, stdfacade.h:51-57)
+    // NOTE on code shape: all of this state is wave-uniform and must stay in scalar registers.  Two constructs silently break that:
+    // "if (c) a++; else b++;" and "if (c) a = 1; else b = 1;" are merged by the optimiser into a store through a SELECTED POINTER, which pins
+    // both variables to private memory; loads from there count as divergent and drag every branch of the state machine into exec-masked
+    // vector code (3x the instructions).  Hence the select-style updates below.  Check: opt -passes='print<uniformity>' on the device IR.
     uint32_t error_code = 0; int power = 0, rxrate = RATE_SYNC, plcp_data = 0;
     int dc_re = 0, dc_im = 0;                                          // CF_VecDC
     int last_re = 0, last_im = 0; uint32_t byte_reg = 0;              // CF_DifferentialDemap::last_symbol, CF_Descramber::byte_reg: never reset
     uint32_t frame_length = 0, rate_kbps = 0, frame_crc32 = 0;
     // ---- brick state
-    uint32_t avg_energy = 0, win[8] = {0, 0, 0, 0, 0, 0, 0, 0}, ecount = 0;               // TEnergyDetect
+    uint32_t avg_energy = 0, ecount = 0;                                                  // TEnergyDetect (window in LDS)
     uint32_t update_cnt = 8; int sdc_re = 0, sdc_im = 0;                                  // TDCEstimator
     int m_index = 2, m_frag = 0;                                                          // TSymTiming
     int sync_flag = NO_PEAK_FOUND, last_peak_cnt = -1, m_max = 0, search_count = 0;      // TBarkerSync
-    int p_re[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, p_im[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
     int chip_n = 0, acc_re = 0, acc_im = 0;                                               // the current port's despreader
     int bit_one_found = 0; uint32_t word = 0; int bit_err_cnt = 0; uint32_t sync_cnt = 0; // TSFDSync
     int sym_n = 0; uint32_t sym_byte = 0; int ref_re = 0, ref_im = 0;                     // TDBPSKDemap / TDQPSKDemap burst in progress
@@ -65,16 +75,14 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
     uint32_t byte_count = 0, crc32 = 0xFFFFFFFFu;                                         // TBB11bFrameSink
     uint32_t nfr = 0;
 
-    auto graph_reset = [&]() {                                          // BB11bDemodCtx.reset() + pRxSource->Reset()
+    // (every lambda below is force-inlined: a called closure would keep the state it captures in scratch memory)
+    auto graph_reset = [&]() __attribute__((always_inline)) {                                          // BB11bDemodCtx.reset() + pRxSource->Reset()
         error_code = 0; power = 0; rxrate = RATE_SYNC; plcp_data = 0;
         avg_energy = 0; ecount = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) win[i] = 0;
         update_cnt = 8; sdc_re = sdc_im = 0;
         m_index = 2; m_frag = 0;
         sync_flag = NO_PEAK_FOUND; last_peak_cnt = -1; m_max = 0; search_count = 0;
-#pragma unroll
-        for (int i = 0; i < 10; i++) { p_re[i] = 0; p_im[i] = 0; }
+        lds_order(); if (lane < 32) p_re[lane] = 0; lds_order();
         chip_n = 0; acc_re = acc_im = 0;
         bit_one_found = 0; word = 0; bit_err_cnt = 0; sync_cnt = 0;
         sym_n = 0; sym_byte = 0; hdr_n = 0; hdr_lo = hdr_hi = 0;
@@ -82,11 +90,11 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
     };
 
     // ---- TBB11bFrameSink (PHY_11b.hpp:700-740)
-    auto frame_sink = [&](uint32_t b) {
+    auto frame_sink = [&](uint32_t b) __attribute__((always_inline)) {
         if (byte_count < (uint32_t)((int)frame_length - 4)) {
             if (lane == 0 && byte_count < kOutBuf) s_out[byte_count] = (uint8_t)b;
             byte_count++;
-            crc32 = A.crc[(crc32 ^ b) & 0xFF] ^ (crc32 >> 8);
+            crc32 = (uint32_t)uni((int)A.crc[(crc32 ^ b) & 0xFF]) ^ (crc32 >> 8);
         } else if (byte_count < frame_length) {
             if (lane == 0 && byte_count < kOutBuf) s_out[byte_count] = (uint8_t)b;
             byte_count++;
@@ -102,7 +110,7 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
         }
     };
     // ---- TBB11bPlcpParser (PHY_11b.hpp:560-640)
-    auto plcp_parser = [&]() {
+    auto plcp_parser = [&]() __attribute__((always_inline)) {
         uint32_t c = 0xFFFF;                                            // CalcCRC16 over the first four bytes (CRC16.h: reflected 0x8408, init 0xFFFF, ~)
 #pragma unroll
         for (int i = 0; i < 4; i++) {
@@ -120,10 +128,10 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
         default:   rate_kbps = 0; len = 0;
         }
         frame_length = len; plcp_data = 1;
-        if (rxrate > RATE_2M) error_code = E_NOT_SUPPORTED;             // CCK branches (cck.hpp) are not implemented
+        if (uni(rxrate) > RATE_2M) error_code = E_NOT_SUPPORTED;             // CCK branches (cck.hpp) are not implemented
     };
     // ---- TDesc741 (scramble.hpp:93-170) -> TBB11bPlcpSwitch (PHY_11b.hpp:459-519)
-    auto byte_out = [&](uint32_t b) {
+    auto byte_out = [&](uint32_t b) __attribute__((always_inline)) {
         uint32_t st = byte_reg & 0x7F, xx = b, o = 0;
 #pragma unroll
         for (int k = 0; k < 8; k++) {
@@ -133,13 +141,14 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
             xx >>= 1;
         }
         byte_reg = b >> 1;
-        if (!plcp_data) {
-            if (hdr_n < 4) hdr_lo |= o << (8 * hdr_n); else hdr_hi |= o << (8 * (hdr_n - 4));
+        if (!uni(plcp_data)) {
+            const uint32_t sh = o << (8 * (hdr_n & 3));                 // (no pointer select between the two words: that would pin them to memory)
+            hdr_lo |= hdr_n < 4 ? sh : 0u; hdr_hi |= hdr_n < 4 ? 0u : sh;
             if (++hdr_n == 6) { plcp_parser(); hdr_n = 0; hdr_lo = hdr_hi = 0; }
         } else frame_sink(o);
     };
     // ---- one despread symbol into the brick the rate selector's port leads to
-    auto symbol_out = [&](int port, int sre, int sim) {
+    auto symbol_out = [&](int port, int sre, int sim) __attribute__((always_inline)) {
         if (port == RATE_SYNC) {                                        // TSFDSync (sfd_sync.hpp:76-126)
             const uint32_t bit = dot_sign(last_re, last_im, sre, sim);
             last_re = sre; last_im = sim;
@@ -148,9 +157,10 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
             byte_reg = (byte_reg >> 1) | (bit << 6);
             word = ((word >> 1) | (sbit << 15)) & 0xFFFF;
             sync_cnt++;
-            if (!bit_one_found) { if (word == 0xFFFF) bit_one_found = 1; }
-            else if (word == 0xF3A0) rxrate = RATE_1M;                  // DOT11B_PLCP_LONG_PREAMBLE_SFD
-            else if (word != 0xFFFF) { if (bit_err_cnt++ > 32) { error_code = E_SFD_FAIL; return; } }
+            const bool ones = word == 0xFFFF, sfd = word == 0xF3A0, found = bit_one_found != 0;     // DOT11B_PLCP_LONG_PREAMBLE_SFD
+            bit_one_found |= ones ? 1 : 0;                              // (selects, not "store 1 to one of two variables": that becomes a pointer
+            rxrate = found && sfd ? RATE_1M : rxrate;                   //  select and pins both to memory)
+            if (found && !sfd && !ones) { if (bit_err_cnt++ > 32) { error_code = E_SFD_FAIL; return; } }
             if (sync_cnt > 128 + 16) error_code = E_SFD_TIMEOUT;
         } else if (port == RATE_1M) {                                   // TDBPSKDemap (barkerspread.hpp:312-390): 8 symbols -> 1 byte
             if (sym_n == 0) { ref_re = last_re; ref_im = last_im; }
@@ -168,10 +178,10 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
         }
     };
     // ---- TBarkerSync (symtiming.hpp:229-313) -> TBB11bRxRateSel -> TBB11bDespread::QuickBarkerDespread (barkerspread.hpp:277-303)
-    auto chip_in = [&](int cre, int cim) {
+    auto chip_in = [&](int cre, int cim) __attribute__((always_inline)) {
         if (sync_flag == BARKER_SYNCED) {
-            if (rxrate > RATE_2M) return;
-            const int port = rxrate;
+            if (uni(rxrate) > RATE_2M) return;
+            const int port = uni(rxrate);
             int tre, tim;
             if (chip_n == 1 || chip_n == 4) { tre = neg16(cre) >> 4; tim = neg16(cim) >> 4; }          // negated before the shift
             else { tre = cre >> 4; tim = cim >> 4; if (chip_n >= 8) { tre = -tre; tim = -tim; } }       // chips 8..10 subtracted after it
@@ -182,9 +192,10 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
         search_count++;
         if (search_count >= 11 * 4) { error_code = E_SYNC_TIMEOUT; return; }
         const int sr = cre >> 4, si = cim >> 4;
-        const int o_re = w16(p_re[0] - sr), o_im = w16(p_im[0] - si);
-#define P_SUB(d, s) p_re[d] = w16(p_re[s] - sr); p_im[d] = w16(p_im[s] - si);
-#define P_ADD(d, s) p_re[d] = w16(p_re[s] + sr); p_im[d] = w16(p_im[s] + si);
+        // (values read back from LDS are wave-uniform; saying so keeps everything derived from them -- the whole state machine -- scalar)
+        const int o_re = w16(uni(p_re[0]) - sr), o_im = w16(uni(p_im[0]) - si);
+#define P_SUB(d, s) p_re[d] = w16(uni(p_re[s]) - sr); p_im[d] = w16(uni(p_im[s]) - si);
+#define P_ADD(d, s) p_re[d] = w16(uni(p_re[s]) + sr); p_im[d] = w16(uni(p_im[s]) + si);
         P_SUB(0, 1) P_SUB(1, 2) P_ADD(2, 3) P_ADD(3, 4) P_ADD(4, 5) P_SUB(5, 6) P_ADD(6, 7) P_ADD(7, 8) P_SUB(8, 9)
 #undef P_SUB
 #undef P_ADD
@@ -205,58 +216,100 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
         }
     };
     // ---- TSymTiming::Process on one 28-sample block held one sample per lane (symtiming.hpp:42-170)
-    auto sym_timing = [&](int bre, int bim) {
-        int idx = m_index;
-        while (idx < 28) {                                              // Decimation: every 4th sample from the current phase
-            int at = idx;
-            if (idx < 0) { at = 0; m_index += 4; }
-            idx += 4;
-            chip_in(lane_of(bre, at), lane_of(bim, at));
+    auto sym_timing = [&](uint32_t braw) __attribute__((always_inline)) {
+        const cpx bu = unpack(braw);
+        const int bre = w16(bu.re - dc_re), bim = w16(bu.im - dc_im);      // TDCRemove (dc.hpp:6-38): the estimate is frozen while demodulating
+        if (sync_flag == BARKER_SYNCED && uni(rxrate) <= RATE_2M) {          // (uni: see the note at rxrate's declaration)
+            // Decimation + rate selector + despreader for the whole block at once: chip k of the block in lane k.  A block
+            // yields 6..8 chips and a symbol takes 11, so at most one symbol ends inside it; every operation of the
+            // despreader is a wrapping add, so the two partial sums (before / after that boundary) are lane reductions.
+            const int mi = m_index;
+            const int cnt = mi < 0 ? 8 : (28 - mi + 3) >> 2;
+            const int at = max(mi + 4 * lane, 0);                       // idx < 0 reads sample 0 (symtiming.hpp:72-75)
+            const cpx cu = unpack((uint32_t)__shfl((int)braw, at));
+            const int cre = w16(cu.re - dc_re), cim = w16(cu.im - dc_im);
+            if (mi < 0) m_index += 4;
+            int c = chip_n + lane; const bool first = c < 11; if (!first) c -= 11;
+            int tre, tim;
+            if (c == 1 || c == 4) { tre = neg16(cre) >> 4; tim = neg16(cim) >> 4; }
+            else { tre = cre >> 4; tim = cim >> 4; if (c >= 8) { tre = -tre; tim = -tim; } }
+            const bool valid = lane < cnt;
+            int a_re = valid && first ? tre : 0, a_im = valid && first ? tim : 0, b_re = valid && !first ? tre : 0, b_im = valid && !first ? tim : 0;
+            a_re = uni(sum8(a_re)); a_im = uni(sum8(a_im)); b_re = uni(sum8(b_re)); b_im = uni(sum8(b_im));
+            if (chip_n + cnt >= 11) {
+                const int port = uni(rxrate), sre = w16(acc_re + a_re), sim = w16(acc_im + a_im);
+                acc_re = w16(b_re); acc_im = w16(b_im); chip_n = chip_n + cnt - 11;
+                symbol_out(port, sre, sim);
+            } else { acc_re = w16(acc_re + a_re); acc_im = w16(acc_im + a_im); chip_n += cnt; }
+        } else {
+            int idx = m_index;
+            while (idx < 28) {                                          // Decimation: every 4th sample from the current phase
+                int at = idx;
+                if (idx < 0) { at = 0; m_index += 4; }
+                idx += 4;
+                chip_in(lane_of(bre, at), lane_of(bim, at));
+            }
         }
         if (m_index >= 4) m_index = 0;
         // AdjustTiming: energies of the four sampling phases over the block, early-late decision
         const int er = bre >> 3, ei = bim >> 3;
-        uint32_t e = lane < 28 ? (uint32_t)(er * er) + (uint32_t)(ei * ei) : 0u;
-        e += (uint32_t)__shfl_down((int)e, 16);                         // lanes 0..15 += lanes 16..31 (28..31 hold 0)
-        e += (uint32_t)__shfl_down((int)e, 8);
-        e += (uint32_t)__shfl_down((int)e, 4);
-        const int s0 = lane_of((int)e, 0), s1 = lane_of((int)e, 1), s2 = lane_of((int)e, 2), s3 = lane_of((int)e, 3);
+        int e = lane < 28 ? (int)((uint32_t)(er * er) + (uint32_t)(ei * ei)) : 0;
+        e += dpp<0x104>(e); e += dpp<0x108>(e);                         // row_shl:4, row_shl:8: lanes 0..3 of each 16-lane row hold that row's phase sums
+        const int s0 = (int)((uint32_t)lane_of(e, 0) + (uint32_t)lane_of(e, 16)), s1 = (int)((uint32_t)lane_of(e, 1) + (uint32_t)lane_of(e, 17)),
+                  s2 = (int)((uint32_t)lane_of(e, 2) + (uint32_t)lane_of(e, 18)), s3 = (int)((uint32_t)lane_of(e, 3) + (uint32_t)lane_of(e, 19));
         const int mi = m_index;
         const int sm = mi == 0 ? s0 : mi == 1 ? s1 : mi == 2 ? s2 : s3;
         const int se = mi == 0 ? s3 : mi == 1 ? s0 : mi == 2 ? s1 : s2;
         const int sl = mi == 0 ? s1 : mi == 1 ? s2 : mi == 2 ? s3 : s0;
-        if (se < sl) {
-            if (sm < se) { m_index++; m_frag = 0; } else if (sm < sl) m_frag++;
-        } else {
-            if (sm < sl) { m_index--; m_frag = 0; } else if (sm < se) m_frag--;
-        }
-        if (m_frag >= 4) { m_index++; m_frag = -3; } else if (m_frag <= -4) { m_index--; m_frag = 3; }
+        int di = 0, df = 0; bool jump = false;                          // (as deltas: "m_index++ else m_frag++" becomes a pointer select that pins both to memory)
+        if (se < sl) { if (sm < se) { di = 1; jump = true; } else if (sm < sl) df = 1; }
+        else { if (sm < sl) { di = -1; jump = true; } else if (sm < se) df = -1; }
+        m_index += di; m_frag = jump ? 0 : m_frag + df;
+        if (m_frag >= 4) { m_index += 1; m_frag = -3; } else if (m_frag <= -4) { m_index -= 1; m_frag = 3; }
     };
 
-    uint32_t pos = 0, remain = cap.nsamples;
-    uint32_t raw = 0;                                                   // the source's output burst: lanes beyond a partial call keep the previous call's sample
-    int prev_re = 0, prev_im = 0;                                       // previous call, DC removed (what may still be queued in front of TSymTiming)
-    int qoff = 0;                                                       // samples queued in front of TSymTiming (multiple of 4, < 28)
+    uint32_t pos = 0, remain = cap_n;
+    // TMemSamples appends 28 entries per call to its output queue; a call that finds fewer than 28 samples left (possible
+    // after the Seek that follows a frame) leaves the tail of the previous call's burst in place (memsource.hpp:99-107).
+    // Entry j of a call is therefore sample  j < take ? start + j : stale + j  of the capture; nothing is copied: the two
+    // most recent calls are kept as (start, take, stale) and every consumer computes its own addresses.
+    uint32_t c_start = 0, c_take = 28, c_stale = 0;                    // the current call
+    uint32_t p_start = 0, p_take = 28, p_stale = 0;                    // the call before it (its last qoff entries may still be queued)
+    int qoff = 0;                                                       // entries queued in front of TSymTiming (a multiple of 4, < 28)
+    auto entry = [&](uint32_t start, uint32_t take, uint32_t stale, int j) __attribute__((always_inline)) { return (uint32_t)j < take ? start + (uint32_t)j : stale + (uint32_t)j; };
     while (nfr < A.max_frames) {
+        // All of the state is wave-uniform by construction, but the compiler's uniformity analysis loses that across the loop
+        // (3342 values of this kernel count as divergent without the lines below, 614 with them -- the genuinely per-lane ones);
+        // re-asserting it once per source call keeps the state machine in scalar registers and its branches scalar.
+#define U(v) v = (decltype(v))uni((int)v)
+        U(error_code); U(power); U(rxrate); U(plcp_data); U(dc_re); U(dc_im); U(last_re); U(last_im); U(byte_reg); U(frame_length); U(rate_kbps);
+        U(frame_crc32); U(avg_energy); U(ecount); U(update_cnt); U(sdc_re); U(sdc_im); U(m_index); U(m_frag); U(sync_flag); U(last_peak_cnt); U(m_max);
+        U(search_count); U(chip_n); U(acc_re); U(acc_im); U(bit_one_found); U(word); U(bit_err_cnt); U(sync_cnt); U(sym_n); U(sym_byte);
+        U(ref_re); U(ref_im); U(hdr_n); U(hdr_lo); U(hdr_hi); U(byte_count); U(crc32); U(nfr); U(pos); U(remain); U(qoff);
+        U(c_start); U(c_take); U(c_stale); U(p_start); U(p_take); U(p_stale);
+#undef U
         // ---- TMemSamples::Process (memsource.hpp:87-114)
-        bool ret = true;
-        if (remain > 28) { if (lane < 28) raw = x[pos + lane]; pos += 28; remain -= 28; }
-        else if (remain == 0) ret = false;
-        else { if (lane < (int)remain) raw = x[pos + lane]; pos += remain; remain = 0; }
+        const bool ret = remain != 0;
         if (ret) {
-            const cpx r = unpack(raw);
-            int first_queued = 0;                                       // first burst (of 7) of this call that goes to TSymTiming
+            p_start = c_start; p_take = c_take; p_stale = c_stale;
+            c_stale = c_start; c_start = pos; c_take = remain > 28 ? 28u : remain;
+            pos += c_take; remain -= c_take;
             if (!power) {
-                first_queued = 7;
+                const cpx r = unpack(lane < 28 ? x[entry(c_start, c_take, c_stale, lane)] : 0u);
+                int first_queued = 7;                                   // first burst (of 7) of this call that goes to TSymTiming
                 for (int i = 0; i < 7; i++) {                          // TDCRemove -> TBB11bRxSwitch -> TEnergyDetect -> TDCEstimator, burst by burst
                     const int vre = w16(r.re - dc_re), vim = w16(r.im - dc_im);
                     uint32_t en = (uint32_t)(((int)((uint32_t)(vre * vre) + (uint32_t)(vim * vim))) >> 5);
-                    en += (uint32_t)__shfl_xor((int)en, 1); en += (uint32_t)__shfl_xor((int)en, 2);
+                    en = (uint32_t)quad_sum((int)en);
                     const uint32_t ave = (uint32_t)lane_of((int)en, 4 * i);
-                    avg_energy = avg_energy - win[0] + ave;             // the 8-entry window as a FIFO (same order as the circular buffer)
-#pragma unroll
-                    for (int k = 0; k < 7; k++) win[k] = win[k + 1];
-                    win[7] = ave;
+                    {                                                   // the 8-entry window as a FIFO in LDS (same order as the circular buffer)
+                        const uint32_t w = lane < 8 ? win[lane] : 0u;
+                        avg_energy = avg_energy - (uint32_t)lane_of((int)w, 0) + ave;
+                        lds_order();
+                        const uint32_t nxt = (uint32_t)__shfl_down((int)w, 1);
+                        if (lane < 8) win[lane] = lane < 7 ? nxt : ave;
+                        lds_order();
+                    }
                     ecount++;
                     if (ecount >= 32) {
                         if (ecount >= 100) { error_code = E_CS_TIMEOUT; break; }
@@ -264,20 +317,15 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
                     }
                     if (power) { first_queued = i + 1; break; }         // energy gating: this burst reaches neither estimator nor demodulator
                     int hr = vre >> 5, hi = vim >> 5;                   // TDCEstimator: hadd(shift_right(pi, 5)) in wrapping int16
-                    hr += __shfl_xor(hr, 1); hi += __shfl_xor(hi, 1); hr += __shfl_xor(hr, 2); hi += __shfl_xor(hi, 2);
+                    hr = quad_sum(hr); hi = quad_sum(hi);
                     sdc_re = w16(sdc_re + w16(lane_of(hr, 4 * i))); sdc_im = w16(sdc_im + w16(lane_of(hi, 4 * i)));
                     if (update_cnt == 0) { dc_re = w16(dc_re + (sdc_re >> 2)); dc_im = w16(dc_im + (sdc_im >> 2)); update_cnt = 8; sdc_re = sdc_im = 0; }
                     update_cnt--;
                 }
-            }
-            if (power && error_code != E_CS_TIMEOUT) {
-                const int cre = w16(r.re - dc_re), cim = w16(r.im - dc_im);
-                if (first_queued == 0) {                                // a whole call: the queue hands TSymTiming one block of 28
-                    const int src = lane < qoff ? 28 - qoff + lane : lane - qoff;
-                    const int a_re = __shfl(prev_re, src), a_im = __shfl(prev_im, src), b_re = __shfl(cre, src), b_im = __shfl(cim, src);
-                    sym_timing(lane < qoff ? a_re : b_re, lane < qoff ? a_im : b_im);
-                } else qoff = 4 * (7 - first_queued);                   // the call in which power was detected: its tail is queued
-                prev_re = cre; prev_im = cim;
+                if (power) qoff = 4 * (7 - first_queued);               // the tail of the call in which power came up is queued
+            } else {                                                    // a whole call: the queue hands TSymTiming one block of 28
+                const uint32_t at = lane < qoff ? entry(p_start, p_take, p_stale, 28 - qoff + lane) : entry(c_start, c_take, c_stale, lane - qoff);
+                sym_timing(lane < 28 ? x[at] : 0u);
             }
         }
         // ---- MAC11b_Receive bookkeeping after the source call (fb11b_demod.cpp:31-70)
@@ -303,11 +351,12 @@ __global__ void __launch_bounds__(256) k_rx11b(Rx11bArgs A)
             // pRxSource->Flush(): what is queued is padded with zero samples and pushed through (brick.h FlushPort);
             // the switch flushes the branch its state selects, the rate selector pads its current port only
             if (power) {
-                if (qoff > 0) {
-                    const int a_re = __shfl(prev_re, 28 - qoff + lane), a_im = __shfl(prev_im, 28 - qoff + lane);
-                    sym_timing(lane < qoff ? a_re : 0, lane < qoff ? a_im : 0); qoff = 0;
+                if (qoff > 0) {                                         // pad() fills with COMPLEX16() = 0: TDCRemove has already been applied upstream,
+                    const cpx q = unpack(lane < qoff ? x[entry(c_start, c_take, c_stale, 28 - qoff + lane)] : 0u);   // so the padding must come out of sym_timing's subtraction as 0
+                    const uint32_t padded = lane < qoff ? pack(mk(q.re, q.im)) : pack(mk(dc_re, dc_im));
+                    sym_timing(padded); qoff = 0;
                 }
-                if (rxrate <= RATE_2M && chip_n > 0) { const int sre = acc_re, sim = acc_im; chip_n = 0; acc_re = acc_im = 0; symbol_out(rxrate, sre, sim); }
+                if (uni(rxrate) <= RATE_2M && chip_n > 0) { const int sre = acc_re, sim = acc_im; chip_n = 0; acc_re = acc_im = 0; symbol_out(uni(rxrate), sre, sim); }
             }
             graph_reset();
             continue;                                                   // the routine returns and is called again: rc is not looked at
