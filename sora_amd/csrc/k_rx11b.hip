@@ -278,15 +278,11 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
     int qoff = 0;                                                       // entries queued in front of TSymTiming (a multiple of 4, < 28)
     auto entry = [&](uint32_t start, uint32_t take, uint32_t stale, int j) __attribute__((always_inline)) { return (uint32_t)j < take ? start + (uint32_t)j : stale + (uint32_t)j; };
     while (nfr < A.max_frames) {
-        // All of the state is wave-uniform by construction, but the compiler's uniformity analysis loses that across the loop
-        // (3342 values of this kernel count as divergent without the lines below, 614 with them -- the genuinely per-lane ones);
-        // re-asserting it once per source call keeps the state machine in scalar registers and its branches scalar.
+        // All of the state is wave-uniform by construction, but the compiler's uniformity analysis loses that for the values
+        // that live across the event handling below (3342 values of this kernel count as divergent without these lines, 614
+        // with them -- the genuinely per-lane ones; tools/min_uniform_set.py found the smallest set that is needed).
 #define U(v) v = (decltype(v))uni((int)v)
-        U(error_code); U(power); U(rxrate); U(plcp_data); U(dc_re); U(dc_im); U(last_re); U(last_im); U(byte_reg); U(frame_length); U(rate_kbps);
-        U(frame_crc32); U(avg_energy); U(ecount); U(update_cnt); U(sdc_re); U(sdc_im); U(m_index); U(m_frag); U(sync_flag); U(last_peak_cnt); U(m_max);
-        U(search_count); U(chip_n); U(acc_re); U(acc_im); U(bit_one_found); U(word); U(bit_err_cnt); U(sync_cnt); U(sym_n); U(sym_byte);
-        U(ref_re); U(ref_im); U(hdr_n); U(hdr_lo); U(hdr_hi); U(byte_count); U(crc32); U(nfr); U(pos); U(remain); U(qoff);
-        U(c_start); U(c_take); U(c_stale); U(p_start); U(p_take); U(p_stale);
+        U(last_re); U(last_im); U(byte_reg); U(frame_length); U(rate_kbps); U(frame_crc32); U(ref_re); U(ref_im); U(qoff);
 #undef U
         // ---- TMemSamples::Process (memsource.hpp:87-114)
         const bool ret = remain != 0;
