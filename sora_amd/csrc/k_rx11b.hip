@@ -277,6 +277,16 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
     uint32_t p_start = 0, p_take = 28, p_stale = 0;                    // the call before it (its last qoff entries may still be queued)
     int qoff = 0;                                                       // entries queued in front of TSymTiming (a multiple of 4, < 28)
     auto entry = [&](uint32_t start, uint32_t take, uint32_t stale, int j) __attribute__((always_inline)) { return (uint32_t)j < take ? start + (uint32_t)j : stale + (uint32_t)j; };
+    // The next 28 samples are requested one source call ahead (the chain is latency-bound: a block's arithmetic must not
+    // wait for its own HBM read).  pf_raw holds samples pf_base .. pf_base+27 when pf_ok; a Seek or a partial call simply misses.
+    uint32_t pf_base = 0, pf_raw = lane < 28 && cap_n >= 28 ? x[lane] : 0u; bool pf_ok = cap_n >= 28;
+    auto fetch28 = [&](uint32_t base, bool contiguous, uint32_t at) __attribute__((always_inline)) {
+        const bool hit = contiguous && pf_ok && pf_base == base;        // wave-uniform
+        const uint32_t v = hit ? pf_raw : (lane < 28 ? x[at] : 0u);
+        pf_base = base + 28; pf_ok = contiguous && pf_base + 28 <= cap_n;
+        if (pf_ok) pf_raw = lane < 28 ? x[pf_base + lane] : 0u;
+        return v;
+    };
     while (nfr < A.max_frames) {
         // All of the state is wave-uniform by construction, but the compiler's uniformity analysis loses that for the values
         // that live across the event handling below (3342 values of this kernel count as divergent without these lines, 614
@@ -291,7 +301,7 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
             c_stale = c_start; c_start = pos; c_take = remain > 28 ? 28u : remain;
             pos += c_take; remain -= c_take;
             if (!power) {
-                const cpx r = unpack(lane < 28 ? x[entry(c_start, c_take, c_stale, lane)] : 0u);
+                const cpx r = unpack(fetch28(c_start, c_take == 28, entry(c_start, c_take, c_stale, lane)));
                 int first_queued = 7;                                   // first burst (of 7) of this call that goes to TSymTiming
                 for (int i = 0; i < 7; i++) {                          // TDCRemove -> TBB11bRxSwitch -> TEnergyDetect -> TDCEstimator, burst by burst
                     const int vre = w16(r.re - dc_re), vim = w16(r.im - dc_im);
@@ -321,7 +331,8 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
                 if (power) qoff = 4 * (7 - first_queued);               // the tail of the call in which power came up is queued
             } else {                                                    // a whole call: the queue hands TSymTiming one block of 28
                 const uint32_t at = lane < qoff ? entry(p_start, p_take, p_stale, 28 - qoff + lane) : entry(c_start, c_take, c_stale, lane - qoff);
-                sym_timing(lane < 28 ? x[at] : 0u);
+                const bool contiguous = c_take == 28 && (qoff == 0 || (p_take == 28 && p_start + 28 == c_start));
+                sym_timing(fetch28(c_start - (uint32_t)qoff, contiguous, at));
             }
         }
         // ---- MAC11b_Receive bookkeeping after the source call (fb11b_demod.cpp:31-70)
