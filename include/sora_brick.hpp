@@ -181,4 +181,27 @@ private:
     const sora_complex16* d_iq_ = nullptr; const sora_capture_desc* caps_ = nullptr; size_t ncaps_ = 0;
 };
 
+// The 802.11b graph as one ISource: CreateDemodGraph (fb11bdemod_config.hpp:122-172) + MAC11b_Receive over a batch of 44 MHz captures.
+class THipRx11bSource {
+public:
+    THipRx11bSource(CF_Error& ctx, const sora_rx_cfg& cfg) : ctx_(ctx), rx_(nullptr) { ctx_.error_code = (uint32_t)sora_rx11b_create(&cfg, &rx_); }
+    ~THipRx11bSource() { if (rx_) sora_rx11b_destroy(rx_); }
+    THipRx11bSource(const THipRx11bSource&) = delete;
+    THipRx11bSource& operator=(const THipRx11bSource&) = delete;
+    void Bind(const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps) { d_iq_ = d_iq; caps_ = caps; ncaps_ = ncaps; }
+    bool Process()
+    {
+        if (!rx_) return false;
+        const int rc = sora_rx11b_process_dev(rx_, d_iq_, caps_, ncaps_);
+        if (rc != SORA_OK) { ctx_.error_code = (uint32_t)rc; return false; }
+        return true;
+    }
+    void Reset() {}                                      // every call starts from the graph's initial state
+    void Flush() {}
+    sora_rx11b_t* handle() { return rx_; }
+private:
+    CF_Error& ctx_; sora_rx11b_t* rx_;
+    const sora_complex16* d_iq_ = nullptr; const sora_capture_desc* caps_ = nullptr; size_t ncaps_ = 0;
+};
+
 }  // namespace sora_brick

@@ -106,6 +106,12 @@ int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, ui
     DevicePin<sora_complex16, 28 * 40> raw(d_in);
     raw.append();
     ok = ok && down.Process(raw) && down.produced() <= 28 * 40;
+    // the 802.11b graph as a source over a batch of 44 MHz captures
+    sora_rx_cfg cfg{}; cfg.struct_size = sizeof(cfg); cfg.sample_rate_mhz = 44; cfg.max_captures = 1; cfg.max_total_samples = 2800; cfg.max_frames_per_capture = 4;
+    THipRx11bSource rx11b(ctx, cfg);
+    sora_capture_desc cap{0, 2800, 0};
+    rx11b.Bind(d_in, &cap, 1);
+    ok = ok && (rx11b.handle() == nullptr || rx11b.Process());
     return ok ? 0 : (int)ctx.error_code;
 }
 """)
