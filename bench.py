@@ -221,7 +221,7 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
         rx.process_dev(flat, descs)
-    rx.results(); ms = (time.perf_counter() - t0) / reps * 1e3          # results() waits for the handle's stream
+    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
     out = {"workload": "%d captures x one 1 Mbps DBPSK frame, %s, long preamble (%d samples @44 MHz each), AWGN" % (ncaps, what, n),
            "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,

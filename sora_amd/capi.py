@@ -48,7 +48,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
 
 _lib = None
 
@@ -111,6 +111,7 @@ def load(build_if_missing=True):
                                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
+    L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
     L.sora_rx11b_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx11b_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx11b_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
@@ -271,6 +272,9 @@ class Rx11b:
             self.close()
         except Exception:
             pass
+
+    def synchronize(self):
+        _check(self._L.sora_hip_stream_synchronize(self._L.sora_rx11b_stream(self._h)))
 
     def process_dev(self, d_iq, captures):
         arr, ptr = Rx._caps(captures)

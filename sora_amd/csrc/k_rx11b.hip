@@ -37,7 +37,7 @@ __device__ __forceinline__ uint32_t dot_sign(int rre, int rim, int xre, int xim)
 { return ((uint32_t)(rre * xre) + (uint32_t)(rim * xim)) >> 31; }
 }  // namespace
 
-__global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
+__global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
 {
     __shared__ uint8_t s_out_all[4][kOutBuf];
     __shared__ int s_state_all[4][32];                                  // per wave: [0..19] TBarkerSync partial sums, [20..27] TEnergyDetect window
@@ -261,11 +261,15 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
         const int sm = mi == 0 ? s0 : mi == 1 ? s1 : mi == 2 ? s2 : s3;
         const int se = mi == 0 ? s3 : mi == 1 ? s0 : mi == 2 ? s1 : s2;
         const int sl = mi == 0 ? s1 : mi == 1 ? s2 : mi == 2 ? s3 : s0;
-        int di = 0, df = 0; bool jump = false;                          // (as deltas: "m_index++ else m_frag++" becomes a pointer select that pins both to memory)
-        if (se < sl) { if (sm < se) { di = 1; jump = true; } else if (sm < sl) df = 1; }
-        else { if (sm < sl) { di = -1; jump = true; } else if (sm < se) df = -1; }
-        m_index += di; m_frag = jump ? 0 : m_frag + df;
-        if (m_frag >= 4) { m_index += 1; m_frag = -3; } else if (m_frag <= -4) { m_index -= 1; m_frag = 3; }
+        // (branch-free, as selects: "m_index++ else m_frag++" would become a pointer select that pins both to memory, and the scalar
+        //  unit is what this kernel runs out of -- every avoided branch counts)
+        const bool late_better = se < sl, a = sm < se, b = sm < sl;
+        const bool jump = late_better ? a : b;
+        const int di = late_better ? (a ? 1 : 0) : (b ? -1 : 0);
+        const int df = late_better ? (!a && b ? 1 : 0) : (!b && a ? -1 : 0);
+        int mf = jump ? 0 : m_frag + df;
+        const int carry = mf >= 4 ? 1 : (mf <= -4 ? -1 : 0);
+        m_index += di + carry; m_frag = carry > 0 ? -3 : (carry < 0 ? 3 : mf);
     };
 
     uint32_t pos = 0, remain = cap_n;
@@ -389,6 +393,7 @@ struct sora_rx11b {
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
     std::vector<sora_capture_desc> h_caps;
+    std::vector<CapDesc> h_desc;                 // staging for the descriptor upload (kept until the next call)
     uint32_t ncaps = 0; bool have_results = false;
 };
 
@@ -427,6 +432,8 @@ int sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out)
     return SORA_OK;
 }
 
+void* sora_rx11b_stream(sora_rx11b_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+
 void sora_rx11b_destroy(sora_rx11b_t* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); rx11b_free(rx); } }
 
 int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
@@ -434,7 +441,9 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     if (!rx || (ncaps && (!d_iq || !caps))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_process_dev: null argument", 0);
     if (ncaps > rx->cfg.max_captures) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process_dev: more captures than max_captures", 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
-    std::vector<CapDesc> h(ncaps);
+    std::vector<CapDesc>& h = rx->h_desc;
+    HIPCHK11(hipStreamSynchronize(rx->stream));                                       // the previous call may still be reading d_caps / writing results
+    h.resize(ncaps);
     uint64_t total = 0;
     for (size_t i = 0; i < ncaps; i++) {
         if (caps[i].offset % 4 != 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture offset must be a multiple of 4 samples", 0);
@@ -446,7 +455,6 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     rx->h_caps.assign(caps, caps + ncaps); rx->ncaps = (uint32_t)ncaps; rx->have_results = true;
     if (ncaps == 0) return SORA_OK;
     HIPCHK11(hipMemcpyAsync(rx->d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, rx->stream));
-    HIPCHK11(hipStreamSynchronize(rx->stream));                                       // h is a local
     Rx11bArgs A;
     A.iq = reinterpret_cast<const uint32_t*>(d_iq); A.caps = rx->d_caps; A.ncaps = (uint32_t)ncaps; A.thr = rx->cfg.cca_pwr_threshold;
     A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.crc = rx->d_crc;
@@ -477,6 +485,15 @@ int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out,
     std::vector<Rx11bRow> rows((size_t)rx->ncaps * mf); std::vector<uint32_t> nfr(rx->ncaps);
     HIPCHK11(hipMemcpy(rows.data(), rx->d_rows, sizeof(Rx11bRow) * rows.size(), hipMemcpyDeviceToHost));
     HIPCHK11(hipMemcpy(nfr.data(), rx->d_nframes, 4 * (size_t)rx->ncaps, hipMemcpyDeviceToHost));
+    // MPDU bytes: one bulk copy of the per-frame slots that are in use when that is cheap, else frame by frame
+    size_t used_rows = 0;
+    for (uint32_t c = 0; c < rx->ncaps; c++) used_rows += nfr[c] < mf ? nfr[c] : mf;
+    std::vector<uint8_t> bulk;
+    const size_t slots = (size_t)rx->ncaps * mf;
+    if (h_mpdu && used_rows > 16 && slots * 4096 <= ((size_t)1 << 30)) {
+        bulk.resize(slots * 4096);
+        HIPCHK11(hipMemcpy(bulk.data(), rx->d_mpdu, bulk.size(), hipMemcpyDeviceToHost));
+    }
     size_t n = 0, moff = 0; int rc = SORA_OK;
     for (uint32_t c = 0; c < rx->ncaps; c++)
         for (uint32_t i = 0; i < nfr[c] && i < mf; i++) {
@@ -489,7 +506,8 @@ int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out,
             if (h_mpdu && (r.error_code == 1u || r.error_code == 0x80000006u)) {
                 const size_t len = r.length < 4096 ? r.length : 4096;
                 if (moff + len > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
-                HIPCHK11(hipMemcpy(h_mpdu + moff, rx->d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
+                if (!bulk.empty()) memcpy(h_mpdu + moff, bulk.data() + ((size_t)c * mf + i) * 4096, len);
+                else HIPCHK11(hipMemcpy(h_mpdu + moff, rx->d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
                 moff += len;
             }
         }
