@@ -309,3 +309,19 @@ def test_gpu_equals_the_reference_graph(sora, torch_cuda, oracle):
         assert ok, "capture %d: %s" % (i, why)
         nev += len(ev)
     assert nev > 300
+
+
+def test_20mhz_mode_equals_the_reference_graph_on_the_40mhz_stream(sora, torch_cuda, oracle):
+    """sample_rate_mhz = 20 is DEFINED as the even samples of a 40 MHz stream (what TDownSample2 keeps): the GPU on x[::2]
+    must report what the reference's 40 MHz graph reports on x."""
+    from gpu_util import random_capture, same_as_reference_graph
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    rng = np.random.default_rng(20260928)
+    caps40 = [random_capture(oracle, rng, 40) for _ in range(200)]
+    got = run_rx(sora, torch_cuda, [c[::2].copy() for c in caps40], 20, max_frames=8)
+    for i, c in enumerate(caps40):
+        ok, why = same_as_reference_graph([r for r in got if r["capture_id"] == i], g.rx11a(c))
+        assert ok, "capture %d: %s" % (i, why)
