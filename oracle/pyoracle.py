@@ -254,6 +254,11 @@ class ReferenceGraph:
     """The reference's own BRICK graphs compiled from its sources (oracle/_ref/libsora_refgraph.so, build_ref.sh).
     NOT thread-safe and one instance per process: the reference keeps its graph context in globals."""
     def __init__(self):
+        if not os.path.exists(REFGRAPH_SO):
+            try:
+                build()                                                  # builds oracle/_ref where the reference tree is present; a no-op elsewhere
+            except Exception:
+                pass
         self.L = ctypes.CDLL(REFGRAPH_SO) if os.path.exists(REFGRAPH_SO) else None
 
     def available(self): return self.L is not None
