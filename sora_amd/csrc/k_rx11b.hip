@@ -337,6 +337,15 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
                 const uint32_t at = lane < qoff ? entry(p_start, p_take, p_stale, 28 - qoff + lane) : entry(c_start, c_take, c_stale, lane - qoff);
                 const bool contiguous = c_take == 28 && (qoff == 0 || (p_take == 28 && p_start + 28 == c_start));
                 sym_timing(fetch28(c_start - (uint32_t)qoff, contiguous, at));
+                // Steady state (aligned to the Barker code, no event pending, whole calls that follow one another): further source
+                // calls are taken right here.  Same semantics as going round the outer loop -- MAC11b_Receive only looks at
+                // error_code after a call -- but in a loop of its own the compiler keeps just this phase's state in registers.
+                while (error_code == 0 && sync_flag == BARKER_SYNCED && uni(rxrate) <= RATE_2M && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
+                    p_start = c_start; p_take = 28; p_stale = c_stale;
+                    c_stale = c_start; c_start = pos; pos += 28; remain -= 28;
+                    const uint32_t base = c_start - (uint32_t)qoff;
+                    sym_timing(fetch28(base, true, base + (uint32_t)lane));
+                }
             }
         }
         // ---- MAC11b_Receive bookkeeping after the source call (fb11b_demod.cpp:31-70)
