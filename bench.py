@@ -108,6 +108,19 @@ def _cpu_worker(args):
     return n, ok, time.perf_counter() - t0
 
 
+def _cpu_worker_11b(args):
+    """One host process of the 802.11b CPU baseline: the reference's own 11b graph over the sample captures for `seconds`."""
+    path, seconds = args
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    sample = np.load(path)
+    g.rx11b_bench(sample[:1])
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < seconds:
+        g.rx11b_bench(sample); k += len(sample)
+    return k * sample.shape[1] / (time.perf_counter() - t0) / 1e6
+
+
 def host_cores():
     """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -226,13 +239,17 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
            "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
            "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
-    if g.available():
-        sample = iq[:8].cpu().numpy()
-        g.rx11b_bench(sample[:1])
-        t0 = time.perf_counter(); k = 0
-        while time.perf_counter() - t0 < 2.0:
-            g.rx11b_bench(sample); k += 8
-        out["cpu_reference_msamples_per_s_one_core"] = round(k * n / (time.perf_counter() - t0) / 1e6, 2)
+    if g.available():                                                   # the reference's 11b graph on this box's host cores, side by side
+        import multiprocessing as mp
+        import tempfile
+        cores = host_cores()
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "iq11b.npy"); np.save(path, iq[:8].cpu().numpy())
+            with mp.get_context("spawn").Pool(cores) as pool:
+                one = pool.apply(_cpu_worker_11b, ((path, 2.0),))
+                allc = pool.map(_cpu_worker_11b, [(path, 4.0)] * cores)
+        out["cpu_reference_msamples_per_s_one_core"] = round(one, 2)
+        out["cpu_reference_msamples_per_s"] = round(sum(allc), 1); out["cpu_reference_cores"] = cores
     rx.close(); del iq, flat
     return out
 
