@@ -183,6 +183,15 @@ int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t*
                    const uint8_t* d_seed, size_t nframes, int8_t* d_out, const uint64_t* d_out_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 802.11n 2x2, stage level -- the whole-path graph is not built yet.  Batched bricks, n symbols per call:
+ * T11nDemap{BPSK,QPSK,QAM16,QAM64} (kernel/bb/Brick11/src/demapper11n.hpp:89-309): IPORT COMPLEX16 x 64 (one pilot-tracked
+ * symbol of one spatial stream) -> OPORT uint8 x 52*N_BPSC soft values 0..7;
+ * T11nDeinterleave{...}_S0/_S1 (deinterleaver_11n.hpp:4-1618): 52*N_BPSC soft values of spatial stream 0 or 1 -> de-interleaved.
+ * ------------------------------------------------------------------------------------------------ */
+int sora_hip_demap11n(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream);
+int sora_hip_deinterleave11n(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, int spatial_stream, size_t n, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
  * MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76) over a batch of independent 44 MHz captures: TDCRemove,
  * TEnergyDetect / TDCEstimator, TSymTiming, TBarkerSync, TBB11bDespread, TSFDSync, TDBPSKDemap / TDQPSKDemap, TDesc741,

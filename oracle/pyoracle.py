@@ -156,6 +156,14 @@ class Oracle:
             return out, {"ctx": ctx, "eq": eq[:tr.n_syms], "tracked": trk[:tr.n_syms], "soft": soft[:tr.n_soft], "decoded": dec}
         return out
 
+    def demap11n(self, nbpsc, sym64):
+        a = np.ascontiguousarray(sym64, np.int16).reshape(64, 2); o = np.zeros(52 * nbpsc, np.uint8)
+        assert self.L.so_demap11n(nbpsc, _P(a), _P(o)) == 52 * nbpsc; return o
+
+    def deinterleave11n(self, nbpsc, stream, soft):
+        a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(52 * nbpsc, np.uint8)
+        assert len(a) == 52 * nbpsc and self.L.so_deinterleave11n(nbpsc, stream, _P(a), _P(o)) == 52 * nbpsc; return o
+
     def rx11b_capture(self, iq44, max_frames=16):
         """802.11b receive graph over int16 [n,2] @44 MHz -> list of dict (end_sample = 44 MHz source position)."""
         iq = np.ascontiguousarray(iq44, np.int16).reshape(-1, 2)
@@ -294,6 +302,16 @@ class ReferenceGraph:
     def rx11b(self, iq44, max_frames=16):
         """The reference's 802.11b receive graph (Test11B_FB_Demod / MAC11b_Receive) over int16 [n,2] @44 MHz."""
         return self._events(self.L.ref_rx11b_capture, iq44, max_frames)
+
+    def demap11n(self, nbpsc, sym64):
+        """T11nDemap{BPSK,QPSK,QAM16,QAM64}: one burst through the reference's own brick."""
+        a = np.ascontiguousarray(sym64, np.int16).reshape(64, 2); o = np.zeros(52 * nbpsc, np.uint8)
+        assert self.L.ref_11n_demap(nbpsc, _P(a), _P(o)) == 52 * nbpsc; return o
+
+    def deinterleave11n(self, nbpsc, stream, soft):
+        """T11nDeinterleave*_S{0,1}: one burst through the reference's own brick."""
+        a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(52 * nbpsc, np.uint8)
+        assert self.L.ref_11n_deinterleave(nbpsc, stream, _P(a), _P(o)) == 52 * nbpsc; return o
 
     def tx11n(self, mpdu_nofcs, mcs):
         """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""

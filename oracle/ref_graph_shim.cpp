@@ -265,3 +265,60 @@ EXPORT uint32_t ref_rx11b_bench(const int16_t* iq, uint32_t ncap, uint32_t nsamp
         }
     return ok;
 }
+
+// ---------------------------------------------------------------- single 802.11n bricks (row f1, stage level): one burst through one brick
+// What a brick's Process() needs of its input pin (pinqueue.h), over a caller's buffer.
+template <class T, size_t N> struct OneBurstPin {
+    typedef T DataType; static const size_t nstream = 1; static const size_t rsize = N;
+    const T* p; bool full;
+    bool check_read() const { return full; }
+    const T* peek() const { return p; }
+    const T* peek(size_t) const { return p; }
+    void pop() { full = false; }
+    void clear() { full = false; }
+};
+template <class T_CTX, size_t N> class TCaptureSink : public TSink<T_CTX> {           // keeps the last burst it was handed
+public:
+    DEFINE_IPORT(uchar, N);
+    uchar last[N];
+    TCaptureSink(T_CTX& ctx) : TSink<T_CTX>(ctx) { memset(last, 0, N); }
+    template <class T_IPIN> bool Process(T_IPIN& ipin) { while (ipin.check_read()) { memcpy(last, ipin.peek(), N); ipin.pop(); } return true; }
+};
+template <template <class, class> class BRICK, size_t NIN, class TIN, size_t NOUT>
+static void run_brick_once(const TIN* in, uint8_t* out)
+{
+    typedef TCaptureSink<BB11nDemodContext, NOUT> Sink;
+    typedef BRICK<BB11nDemodContext, Sink> Brick;
+    static Sink* sink = new Sink(BB11nDemodCtx);
+    static Brick* brick = new Brick(BB11nDemodCtx, sink);
+    OneBurstPin<TIN, NIN> pin = { in, true };
+    brick->Process(pin);
+    memcpy(out, sink->last, NOUT);
+}
+// T11nDemap{BPSK,QPSK,QAM16,QAM64} (demapper11n.hpp:89-309): 64 COMPLEX16 (one pilot-tracked symbol of one stream) -> 52*nbpsc soft bits
+EXPORT int ref_11n_demap(int nbpsc, const int16_t* sym64, uint8_t* soft)
+{
+    A16 COMPLEX16 x[64]; memcpy(x, sym64, sizeof(x));
+    switch (nbpsc) {
+    case 1: run_brick_once<T11nDemapBPSK, 64, COMPLEX16, 52>(x, soft); return 52;
+    case 2: run_brick_once<T11nDemapQPSK, 64, COMPLEX16, 104>(x, soft); return 104;
+    case 4: run_brick_once<T11nDemapQAM16, 64, COMPLEX16, 208>(x, soft); return 208;
+    case 6: run_brick_once<T11nDemapQAM64, 64, COMPLEX16, 312>(x, soft); return 312;
+    }
+    return -1;
+}
+// T11nDeinterleave{BPSK,QPSK,QAM16,QAM64}_S{0,1} (deinterleaver_11n.hpp): 52*nbpsc soft bits of spatial stream `stream` -> de-interleaved
+EXPORT int ref_11n_deinterleave(int nbpsc, int stream, const uint8_t* in, uint8_t* out)
+{
+    switch (nbpsc * 2 + stream) {
+    case 2:  run_brick_once<T11nDeinterleaveBPSK_S0, 52, uchar, 52>(in, out); return 52;
+    case 3:  run_brick_once<T11nDeinterleaveBPSK_S1, 52, uchar, 52>(in, out); return 52;
+    case 4:  run_brick_once<T11nDeinterleaveQPSK_S0, 104, uchar, 104>(in, out); return 104;
+    case 5:  run_brick_once<T11nDeinterleaveQPSK_S1, 104, uchar, 104>(in, out); return 104;
+    case 8:  run_brick_once<T11nDeinterleaveQAM16_S0, 208, uchar, 208>(in, out); return 208;
+    case 9:  run_brick_once<T11nDeinterleaveQAM16_S1, 208, uchar, 208>(in, out); return 208;
+    case 12: run_brick_once<T11nDeinterleaveQAM64_S0, 312, uchar, 312>(in, out); return 312;
+    case 13: run_brick_once<T11nDeinterleaveQAM64_S1, 312, uchar, 312>(in, out); return 312;
+    }
+    return -1;
+}

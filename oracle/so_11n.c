@@ -1,0 +1,71 @@
+/* so_11n.c -- TEST INFRASTRUCTURE: 802.11n (row f1) bricks restated so far, stage level.
+ *   so_demap11n        T11nDemap{BPSK,QPSK,QAM16,QAM64}  (kernel/bb/Brick11/src/demapper11n.hpp:89-309 over dsp_demap.h)
+ *   so_deinterleave11n T11nDeinterleave{BPSK,QPSK,QAM16,QAM64}_S{0,1}  (deinterleaver_11n.hpp:4-1618)
+ * Pinned by the reference's own bricks compiled from its sources (oracle/_ref/libsora_refgraph.so: ref_11n_demap,
+ * ref_11n_deinterleave) -- live and through tests/golden/ref_vectors_11n.npz.
+ * The soft-value tables of dsp_demap.h ("constructed at Eb/N0 about 4 dB") are step functions of the limited coordinate
+ * v in [-128,127]; they are regenerated here from their run lengths (value, count from v = -128 upward), checked
+ * entry for entry against the reference bricks.  The de-interleavers are the standard HT interleaver
+ * (N_COL 13, N_ROW 4 N_BPSC, N_ROT 11) inverted: out[k] = in[r(k)]. */
+#include <string.h>
+#include "so_internal.h"
+
+typedef struct { uint8_t v, n; } run_t;
+static const run_t RL_BPSK[]   = {{0,97},{1,10},{2,10},{3,11},{4,11},{5,10},{6,10},{7,97}};                       /* also QPSK */
+static const run_t RL_16_0[]   = {{0,113},{1,7},{2,4},{3,4},{4,5},{5,4},{6,7},{7,112}};
+static const run_t RL_16_1[]   = {{0,58},{1,3},{2,2},{3,2},{4,2},{5,3},{6,3},{7,111},{6,3},{5,3},{4,2},{3,2},{2,2},{1,3},{0,57}};
+static const run_t RL_64_0[]   = {{0,122},{1,3},{2,2},{3,1},{4,2},{5,2},{6,3},{7,121}};
+static const run_t RL_64_1[]   = {{0,52},{1,3},{2,2},{3,2},{4,1},{5,2},{6,3},{7,127},{6,3},{5,2},{4,1},{3,2},{2,2},{1,3},{0,51}};
+static const run_t RL_64_2[]   = {{0,18},{1,2},{2,2},{3,2},{4,2},{5,1},{6,3},{7,57},{6,3},{5,2},{4,2},{3,1},{2,2},{1,3},{0,57},
+                                  {1,3},{2,2},{3,1},{4,2},{5,2},{6,3},{7,57},{6,3},{5,1},{4,2},{3,2},{2,2},{1,2},{0,17}};
+static uint8_t g_lut[6][256]; static int g_ready;
+static void expand(uint8_t* lut, const run_t* r, int nr) { int k = 0; for (int i = 0; i < nr; i++) for (int j = 0; j < r[i].n; j++) lut[k++] = r[i].v; }
+static void init11n(void)
+{
+    if (g_ready) return;
+    expand(g_lut[0], RL_BPSK, 8); expand(g_lut[1], RL_16_0, 8); expand(g_lut[2], RL_16_1, 15);
+    expand(g_lut[3], RL_64_0, 8); expand(g_lut[4], RL_64_1, 15); expand(g_lut[5], RL_64_2, 29);
+    g_ready = 1;
+}
+const uint8_t* so_demap11n_lut(int which) { init11n(); return g_lut[which]; }   /* [v + 128]; 0 bpsk/qpsk, 1-2 16-QAM, 3-5 64-QAM */
+
+static inline int lim(int v) { return v < -128 ? -128 : (v > 127 ? 127 : v); }   /* demap_limit (dsp_demap.h) */
+
+int so_demap11n(int nbpsc, const so_c16 in[64], uint8_t* out)
+{
+    init11n();
+    int j = 0;
+    for (int pass = 0; pass < 2; pass++) {
+        const int lo = pass ? 1 : 64 - 28, hi = pass ? 28 : 63;
+        for (int i = lo; i <= hi; i++) {
+            if (i == 64 - 21 || i == 64 - 7 || i == 7 || i == 21) continue;         /* pilots */
+            const int re = lim(in[i].re) + 128, im = lim(in[i].im) + 128;
+            switch (nbpsc) {
+            case 1: out[j++] = g_lut[0][re]; break;                                 /* demap_bpsk_i */
+            case 2: out[j++] = g_lut[0][re]; out[j++] = g_lut[0][im]; break;
+            case 4: out[j++] = g_lut[1][re]; out[j++] = g_lut[2][re]; out[j++] = g_lut[1][im]; out[j++] = g_lut[2][im]; break;
+            case 6: out[j++] = g_lut[3][re]; out[j++] = g_lut[4][re]; out[j++] = g_lut[5][re];
+                    out[j++] = g_lut[3][im]; out[j++] = g_lut[4][im]; out[j++] = g_lut[5][im]; break;
+            default: return -1;
+            }
+        }
+    }
+    return j;
+}
+
+int so_deinterleave11n_index(int nbpsc, int stream, int k)     /* r(k): where output bit k of the de-interleaver comes from */
+{
+    const int n = 52 * nbpsc, s = nbpsc / 2 > 1 ? nbpsc / 2 : 1, nrow = 4 * nbpsc;
+    const int i = nrow * (k % 13) + k / 13;
+    int j = s * (i / s) + (i + n - (13 * i) / n) % s;
+    if (stream > 0) j = ((j - ((stream * 2) % 3 + 3 * (stream / 3)) * 11 * nbpsc) % n + n) % n;
+    return j;
+}
+
+int so_deinterleave11n(int nbpsc, int stream, const uint8_t* in, uint8_t* out)
+{
+    if (nbpsc != 1 && nbpsc != 2 && nbpsc != 4 && nbpsc != 6) return -1;
+    const int n = 52 * nbpsc;
+    for (int k = 0; k < n; k++) out[k] = in[so_deinterleave11n_index(nbpsc, stream, k)];
+    return n;
+}

@@ -110,6 +110,12 @@ int so_rx11a_capture(const so_c16* iq, uint32_t nsamples, int sample_rate_mhz,
  * harness sees the event, rate_kbps/length/crc32 as the reference's CF_11bRxVector holds them (crc32: 3 FCS bytes + 1 stale). */
 int so_rx11b_capture(const so_c16* iq, uint32_t nsamples, so_frame_result* res, int max_res, uint8_t* mpdu_buf, uint32_t mpdu_cap);
 
+/* 802.11n stage bricks (so_11n.c): T11nDemap* and T11nDeinterleave*_S{0,1}; return the number of soft values (52 * nbpsc) */
+int so_demap11n(int nbpsc, const so_c16 in[64], uint8_t* out);
+int so_deinterleave11n(int nbpsc, int stream, const uint8_t* in, uint8_t* out);
+int so_deinterleave11n_index(int nbpsc, int stream, int k);
+const uint8_t* so_demap11n_lut(int which);
+
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */
 int so_load_dump(const uint8_t* file, uint32_t file_bytes, so_c16* out, uint32_t max_samples, int raw14);
 /* capture ingest (so_ingest.c): TDownSample44_40 / Down44to40 (sampling.hpp:35-66, 44MTo40M.hpp:62-123), TDownSample2 (samples.hpp:9-47) */

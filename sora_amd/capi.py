@@ -48,7 +48,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
 
 _lib = None
 
@@ -109,6 +109,8 @@ def load(build_if_missing=True):
     L.sora_hip_ingest_count.argtypes = [ctypes.c_size_t, ctypes.c_uint]; L.sora_hip_ingest_count.restype = ctypes.c_size_t
     L.sora_hip_ingest.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.c_void_p, ctypes.c_size_t,
                                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
+    L.sora_hip_demap11n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_deinterleave11n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
     L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
@@ -353,6 +355,22 @@ def demap11a(x, n_bpsc, stream=None):
     import torch
     out = torch.empty((x.shape[0], 48 * n_bpsc), dtype=torch.uint8, device=x.device)
     _check(load().sora_hip_demap11a(_dev_ptr(x), _dev_ptr(out), n_bpsc, x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def demap11n(x, n_bpsc, stream=None):
+    """x: int16 CUDA tensor [n,64,2] (pilot-tracked symbols of one spatial stream) -> uint8 [n, 52*n_bpsc]."""
+    import torch
+    out = torch.empty((x.shape[0], 52 * n_bpsc), dtype=torch.uint8, device=x.device)
+    _check(load().sora_hip_demap11n(_dev_ptr(x), _dev_ptr(out), n_bpsc, x.shape[0], _stream_ptr(stream)))
+    return out
+
+
+def deinterleave11n(s, n_bpsc, spatial_stream, stream=None):
+    """s: uint8 CUDA tensor [n, 52*n_bpsc] of spatial stream 0 or 1 -> de-interleaved, same shape."""
+    import torch
+    out = torch.empty_like(s)
+    _check(load().sora_hip_deinterleave11n(_dev_ptr(s), _dev_ptr(out), n_bpsc, spatial_stream, s.shape[0], _stream_ptr(stream)))
     return out
 
 

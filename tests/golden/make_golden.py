@@ -14,6 +14,7 @@
                          modulation graph (CreateModGraph11a_40M) emits for a list of frames.
   refgraph_11b.npz       802.11b: the reference modulator's output (COMPLEX8 @44 MHz) for six 1/2 Mbps frames and the events
                          its receive graph reports for captures made of them (tests/test_oracle_11b.channel_11b).
+  ref_vectors_11n.npz    802.11n stage bricks: inputs and what the reference's own T11nDemap* / T11nDeinterleave*_S{0,1} bricks make of them.
 All files travel to the GPU box; /root/reference does not.
 """
 import hashlib
@@ -122,6 +123,19 @@ def main():
                         ev_error=np.array(evs["error"], np.uint32), ev_position=np.array(evs["position"], np.uint32),
                         ev_rate=np.array(evs["rate"], np.uint32), ev_length=np.array(evs["length"], np.uint32),
                         ev_crc=np.array(evs["crc"], np.uint32), **b)
+    # 802.11n stage bricks: one burst each through the reference's own T11nDemap* / T11nDeinterleave*_S{0,1}
+    rng = np.random.default_rng(1111)
+    n11 = {}
+    sym = np.stack([rng.integers(-a, a + 1, size=(64, 2)) for a in (100, 150, 300, 3000, 32767) for _ in range(4)]).astype(np.int16)
+    sym[0, 1] = (127, -128); sym[0, 2] = (128, -129); sym[1, 40] = (-32768, 32767)
+    n11["demap_in"] = sym
+    for nb in (1, 2, 4, 6):
+        n11["demap_out_%d" % nb] = np.stack([G.demap11n(nb, x) for x in sym])
+        soft = rng.integers(0, 8, size=(6, 52 * nb)).astype(np.uint8)
+        n11["deint_in_%d" % nb] = soft
+        for st in (0, 1):
+            n11["deint_out_%d_%d" % (nb, st)] = np.stack([G.deinterleave11n(nb, st, x) for x in soft])
+    np.savez_compressed(os.path.join(OUT, "ref_vectors_11n.npz"), **n11)
     print("written", os.listdir(OUT))
 
 
