@@ -190,6 +190,15 @@ int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t*
  * ------------------------------------------------------------------------------------------------ */
 int sora_hip_demap11n(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream);
 int sora_hip_deinterleave11n(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, int spatial_stream, size_t n, void* stream);
+/* TMimoChannelEst (channel_11n.hpp:329-443), a batch of frames: d_ltf_r[f][128] = the two HT-LTF symbols of RX chain r after the
+ * FFT (first 64, second 64) -> CF_ChannelMimo per frame: d_h[f][2][128] (row = RX chain; columns 0..63 / 64..127 = spatial stream
+ * 1 / 2) and d_hinv[f][2][128] = its 2x2 inverse x 2^16 per carrier, computed in single-precision floats operation for operation as
+ * the reference's SSE code (brick/inc/sora_matrix.h:134-148,305-313) and packed with saturation.
+ * TMimoChannelComp (channel_11n.hpp:445-521), a batch of symbols: x = (Hinv y) >> 9 with saturation; symbol s uses
+ * d_hinv[d_frame_index[s]] (d_frame_index NULL: frame 0); y_r = RX chain r after the FFT, x_k = spatial stream k. */
+int sora_hip_mimo_est11n(const sora_complex16* d_ltf0, const sora_complex16* d_ltf1, sora_complex16* d_h, sora_complex16* d_hinv, size_t nframes, void* stream);
+int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
+                          sora_complex16* d_x0, sora_complex16* d_x1, size_t nsym, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by

@@ -164,6 +164,17 @@ class Oracle:
         a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(52 * nbpsc, np.uint8)
         assert len(a) == 52 * nbpsc and self.L.so_deinterleave11n(nbpsc, stream, _P(a), _P(o)) == 52 * nbpsc; return o
 
+    def mimo_est11n(self, ltf0, ltf1):
+        a = np.ascontiguousarray(ltf0, np.int16).reshape(128, 2); b = np.ascontiguousarray(ltf1, np.int16).reshape(128, 2)
+        h = np.zeros((2, 128, 2), np.int16); hi = np.zeros((2, 128, 2), np.int16)
+        self.L.so_mimo_est11n(_P(a), _P(b), _P(h), _P(hi)); return h, hi
+
+    def mimo_comp11n(self, hinv, y0, y1):
+        hi = np.ascontiguousarray(hinv, np.int16).reshape(2, 128, 2)
+        a = np.ascontiguousarray(y0, np.int16).reshape(64, 2); b = np.ascontiguousarray(y1, np.int16).reshape(64, 2)
+        x0 = np.zeros((64, 2), np.int16); x1 = np.zeros((64, 2), np.int16)
+        self.L.so_mimo_comp11n(_P(hi), _P(a), _P(b), _P(x0), _P(x1)); return x0, x1
+
     def rx11b_capture(self, iq44, max_frames=16):
         """802.11b receive graph over int16 [n,2] @44 MHz -> list of dict (end_sample = 44 MHz source position)."""
         iq = np.ascontiguousarray(iq44, np.int16).reshape(-1, 2)
@@ -312,6 +323,19 @@ class ReferenceGraph:
         """T11nDeinterleave*_S{0,1}: one burst through the reference's own brick."""
         a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(52 * nbpsc, np.uint8)
         assert self.L.ref_11n_deinterleave(nbpsc, stream, _P(a), _P(o)) == 52 * nbpsc; return o
+
+    def mimo_est11n(self, ltf0, ltf1):
+        """TMimoChannelEst: one burst through the reference's own brick -> (h, hinv), each int16 [2,128,2]."""
+        a = np.ascontiguousarray(ltf0, np.int16).reshape(128, 2); b = np.ascontiguousarray(ltf1, np.int16).reshape(128, 2)
+        h = np.zeros((2, 128, 2), np.int16); hi = np.zeros((2, 128, 2), np.int16)
+        self.L.ref_11n_mimo_est(_P(a), _P(b), _P(h), _P(hi)); return h, hi
+
+    def mimo_comp11n(self, hinv, y0, y1):
+        """TMimoChannelComp: one burst through the reference's own brick -> (x0, x1)."""
+        hi = np.ascontiguousarray(hinv, np.int16).reshape(2, 128, 2)
+        a = np.ascontiguousarray(y0, np.int16).reshape(64, 2); b = np.ascontiguousarray(y1, np.int16).reshape(64, 2)
+        x0 = np.zeros((64, 2), np.int16); x1 = np.zeros((64, 2), np.int16)
+        self.L.ref_11n_mimo_comp(_P(hi), _P(a), _P(b), _P(x0), _P(x1)); return x0, x1
 
     def tx11n(self, mpdu_nofcs, mcs):
         """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""

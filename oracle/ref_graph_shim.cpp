@@ -322,3 +322,44 @@ EXPORT int ref_11n_deinterleave(int nbpsc, int stream, const uint8_t* in, uint8_
     }
     return -1;
 }
+
+// two-stream variants of the helpers above (the MIMO bricks take one burst per RX chain)
+template <class T, size_t N> struct TwoStreamPin {
+    typedef T DataType; static const size_t nstream = 2; static const size_t rsize = N;
+    const T* p[2]; bool full;
+    bool check_read() const { return full; }
+    const T* peek(size_t iss = 0) const { return p[iss]; }
+    void pop() { full = false; }
+    void clear() { full = false; }
+};
+template <class T_CTX, size_t N> class TCaptureSink2 : public TSink<T_CTX> {
+public:
+    DEFINE_IPORT(COMPLEX16, N, 2);
+    COMPLEX16 last[2][N];
+    TCaptureSink2(T_CTX& ctx) : TSink<T_CTX>(ctx) { memset(last, 0, sizeof(last)); }
+    template <class T_IPIN> bool Process(T_IPIN& ipin)
+    { while (ipin.check_read()) { memcpy(last[0], ipin.peek(0), N * sizeof(COMPLEX16)); memcpy(last[1], ipin.peek(1), N * sizeof(COMPLEX16)); ipin.pop(); } return true; }
+};
+// TMimoChannelEst (channel_11n.hpp:329-443): the two HT-LTF symbols of each RX chain after the FFT (chain r: ltf_r[0..63] = first
+// HT-LTF, [64..127] = second) -> CF_ChannelMimo: h[2][128] and its scaled inverse hinv[2][128] (float 2x2 inverse x 2^16)
+EXPORT void ref_11n_mimo_est(const int16_t* ltf0, const int16_t* ltf1, int16_t* h, int16_t* hinv)
+{
+    static TMimoChannelEst<BB11nDemodContext>* est = new TMimoChannelEst<BB11nDemodContext>(BB11nDemodCtx);
+    A16 COMPLEX16 a[128], b[128]; memcpy(a, ltf0, sizeof(a)); memcpy(b, ltf1, sizeof(b));
+    TwoStreamPin<COMPLEX16, 128> pin = { { a, b }, true };
+    est->Process(pin);
+    memcpy(h, BB11nDemodCtx.CF_ChannelMimo::dot11n_2x2_channel(), sizeof(MIMO_2x2_H));
+    memcpy(hinv, BB11nDemodCtx.CF_ChannelMimo::dot11n_2x2_channel_inv(), sizeof(MIMO_2x2_H));
+}
+// TMimoChannelComp (channel_11n.hpp:445-521): one data symbol of both RX chains (after the FFT) x hinv -> the two spatial streams
+EXPORT void ref_11n_mimo_comp(const int16_t* hinv, const int16_t* y0, const int16_t* y1, int16_t* x0, int16_t* x1)
+{
+    typedef TCaptureSink2<BB11nDemodContext, 64> Sink;
+    static Sink* sink = new Sink(BB11nDemodCtx);
+    static TMimoChannelComp<BB11nDemodContext, Sink>* comp = new TMimoChannelComp<BB11nDemodContext, Sink>(BB11nDemodCtx, sink);
+    memcpy(BB11nDemodCtx.CF_ChannelMimo::dot11n_2x2_channel_inv(), hinv, sizeof(MIMO_2x2_H));
+    A16 COMPLEX16 a[64], b[64]; memcpy(a, y0, sizeof(a)); memcpy(b, y1, sizeof(b));
+    TwoStreamPin<COMPLEX16, 64> pin = { { a, b }, true };
+    comp->Process(pin);
+    memcpy(x0, sink->last[0], 256); memcpy(x1, sink->last[1], 256);
+}

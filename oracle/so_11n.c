@@ -69,3 +69,70 @@ int so_deinterleave11n(int nbpsc, int stream, const uint8_t* in, uint8_t* out)
     for (int k = 0; k < n; k++) out[k] = in[so_deinterleave11n_index(nbpsc, stream, k)];
     return n;
 }
+
+/* ------------------------------------------------------------------ MIMO 2x2 channel estimation / zero-forcing detection
+ *   so_mimo_est11n   TMimoChannelEst  (channel_11n.hpp:329-443): the two HT-LTF symbols of each RX chain (after the FFT) ->
+ *                    H (P-matrix combination, HT-LTF signs removed) and its inverse x 2^16, computed in single-precision
+ *                    floats exactly as the SSE code does (brick/inc/sora_matrix.h:134-148,305-313; vector128.h:1107-1116):
+ *                    every product and every sum is rounded on its own (no fused multiply-add), division is IEEE,
+ *                    conversion back is round-to-nearest-even with 0x80000000 for anything out of range (cvtps2dq),
+ *                    then a saturating pack.
+ *   so_mimo_comp11n  TMimoChannelComp (channel_11n.hpp:445-521): x = (Hinv y) >> 9, saturating pack.
+ * Pinned by the reference's own bricks (ref_11n_mimo_est / ref_11n_mimo_comp). */
+#include <math.h>
+
+static const int8_t HTLTF_K[57] = {  /* HT-LTF, carriers -28..28 (IEEE 802.11n 20 MHz) */
+    1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+    1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1, -1, -1 };
+static inline int htltf_negate(int bin)      /* _80211n_HTLTFMask: every bin whose HT-LTF value is not +1 is negated (unused bins too) */
+{
+    const int k = bin < 32 ? bin : bin - 64;
+    return !(k >= -28 && k <= 28 && HTLTF_K[k + 28] == 1);
+}
+typedef struct { float re, im; } cf_t;
+static inline cf_t cf_mul(cf_t a, cf_t b)    /* vcf mul: moveldup/movehdup, two mul_ps, flip, addsub_ps */
+{
+    const float acr = a.re * b.re, aci = a.im * b.re, adr = a.re * b.im, adi = a.im * b.im;
+    cf_t r; r.re = acr - adi; r.im = aci + adr; return r;
+}
+static inline int32_t cvtps(float x) { return (x >= -2147483648.0f && x < 2147483648.0f) ? (int32_t)lrintf(x) : INT32_MIN; }
+
+void so_mimo_est11n(const so_c16 ltf0[128], const so_c16 ltf1[128], so_c16 h[2][128], so_c16 hinv[2][128])
+{
+    const so_c16* ltf[2] = { ltf0, ltf1 };
+    for (int r = 0; r < 2; r++)
+        for (int i = 0; i < 64; i++) {
+            so_c16 d = so_sra(so_csubs(ltf[r][i], ltf[r][i + 64]), 1), s = so_sra(so_cadds(ltf[r][i], ltf[r][i + 64]), 1);
+            if (htltf_negate(i)) { d = so_c(so_neg16(d.re), so_neg16(d.im)); s = so_c(so_neg16(s.re), so_neg16(s.im)); }
+            h[r][i] = d; h[r][i + 64] = s;
+        }
+    for (int i = 0; i < 64; i++) {
+        const cf_t a00 = { (float)h[0][i].re, (float)h[0][i].im }, a01 = { (float)h[0][i + 64].re, (float)h[0][i + 64].im };
+        const cf_t a10 = { (float)h[1][i].re, (float)h[1][i].im }, a11 = { (float)h[1][i + 64].re, (float)h[1][i + 64].im };
+        const cf_t ad = cf_mul(a00, a11), bc = cf_mul(a01, a10);
+        const cf_t det = { ad.re - bc.re, ad.im - bc.im };
+        const float t0 = det.re * det.re, t1 = det.im * det.im;
+        const float n = (t0 + t1) / 65536.0f;                                     /* SquaredNorm, then div(n, scale) */
+        const cf_t ds = { det.re, -det.im };
+        const cf_t m01 = { -a01.re, -a01.im }, m10 = { -a10.re, -a10.im };
+        const cf_t r00 = cf_mul(a11, ds), r01 = cf_mul(m01, ds), r10 = cf_mul(m10, ds), r11 = cf_mul(a00, ds);
+        const cf_t* rr[4] = { &r00, &r01, &r10, &r11 };
+        so_c16* dst[4] = { &hinv[0][i], &hinv[0][i + 64], &hinv[1][i], &hinv[1][i + 64] };
+        for (int k = 0; k < 4; k++) {
+            const float qre = rr[k]->re / n, qim = rr[k]->im / n;
+            int32_t ire = cvtps(qre), iim = cvtps(qim);
+            dst[k]->re = so_sat16(ire); dst[k]->im = so_sat16(iim);
+        }
+    }
+}
+
+void so_mimo_comp11n(const so_c16 hinv[2][128], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64])
+{
+    for (int i = 0; i < 64; i++) {
+        int32_t ar, ai, br, bi;
+        so_mul32(hinv[0][i], y0[i], &ar, &ai); so_mul32(hinv[0][i + 64], y1[i], &br, &bi);
+        x0[i] = so_c(so_sat16(so_w32((int64_t)ar + br) >> 9), so_sat16(so_w32((int64_t)ai + bi) >> 9));
+        so_mul32(hinv[1][i], y0[i], &ar, &ai); so_mul32(hinv[1][i + 64], y1[i], &br, &bi);
+        x1[i] = so_c(so_sat16(so_w32((int64_t)ar + br) >> 9), so_sat16(so_w32((int64_t)ai + bi) >> 9));
+    }
+}

@@ -115,6 +115,9 @@ int so_demap11n(int nbpsc, const so_c16 in[64], uint8_t* out);
 int so_deinterleave11n(int nbpsc, int stream, const uint8_t* in, uint8_t* out);
 int so_deinterleave11n_index(int nbpsc, int stream, int k);
 const uint8_t* so_demap11n_lut(int which);
+/* TMimoChannelEst / TMimoChannelComp (channel_11n.hpp:329-521); ltf_r = the two HT-LTF symbols of RX chain r after the FFT */
+void so_mimo_est11n(const so_c16 ltf0[128], const so_c16 ltf1[128], so_c16 h[2][128], so_c16 hinv[2][128]);
+void so_mimo_comp11n(const so_c16 hinv[2][128], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
 
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */
 int so_load_dump(const uint8_t* file, uint32_t file_bytes, so_c16* out, uint32_t max_samples, int raw14);

@@ -48,7 +48,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
 
 _lib = None
 
@@ -111,6 +111,8 @@ def load(build_if_missing=True):
                                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     L.sora_hip_demap11n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_deinterleave11n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_mimo_est11n.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_mimo_comp11n.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
     L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
@@ -372,6 +374,25 @@ def deinterleave11n(s, n_bpsc, spatial_stream, stream=None):
     out = torch.empty_like(s)
     _check(load().sora_hip_deinterleave11n(_dev_ptr(s), _dev_ptr(out), n_bpsc, spatial_stream, s.shape[0], _stream_ptr(stream)))
     return out
+
+
+def mimo_est11n(ltf0, ltf1, stream=None):
+    """ltf0/ltf1: int16 CUDA tensors [n,128,2] (the two HT-LTF symbols of RX chain 0 / 1 after the FFT) -> (h, hinv) int16 [n,2,128,2]."""
+    import torch
+    n = ltf0.shape[0]
+    h = torch.empty((n, 2, 128, 2), dtype=torch.int16, device=ltf0.device); hinv = torch.empty_like(h)
+    _check(load().sora_hip_mimo_est11n(_dev_ptr(ltf0), _dev_ptr(ltf1), _dev_ptr(h), _dev_ptr(hinv), n, _stream_ptr(stream)))
+    return h, hinv
+
+
+def mimo_comp11n(hinv, y0, y1, frame_index=None, stream=None):
+    """hinv: int16 [nframes,2,128,2]; y0/y1: int16 [nsym,64,2] (RX chain 0 / 1 after the FFT); frame_index: int32/uint32 [nsym] or None
+    -> (x0, x1) int16 [nsym,64,2], the two spatial streams."""
+    import torch
+    x0 = torch.empty_like(y0); x1 = torch.empty_like(y1)
+    _check(load().sora_hip_mimo_comp11n(_dev_ptr(hinv), _dev_ptr(frame_index) if frame_index is not None else None, _dev_ptr(y0), _dev_ptr(y1),
+                                        _dev_ptr(x0), _dev_ptr(x1), y0.shape[0], _stream_ptr(stream)))
+    return x0, x1
 
 
 def deinterleave11a(s, n_bpsc, stream=None):

@@ -71,6 +71,74 @@ __global__ void __launch_bounds__(256) k_deint11n_batch(const uint8_t* in, uint8
     out[g] = in[(uint64_t)sym * per + j];
 }
 
+// ---- TMimoChannelEst (channel_11n.hpp:329-443): one thread per carrier, 64 per frame
+namespace {
+__constant__ int8_t kHtLtf[57] = {   // HT-LTF, carriers -28..28 (IEEE 802.11n, 20 MHz)
+    1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+    1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1, -1, -1 };
+struct cf { float re, im; };
+// vcf mul (vector128.h:1107-1116): every product and every sum rounded on its own -- no fused multiply-add
+// (the default -ffp-contract=fast-honor-pragmas would fuse a*b - c*d into an fma: one rounding less than the reference's
+//  mulps / addsubps.  The pragma keeps every operation on its own; plain operators are IEEE single precision on gfx950.)
+__device__ __forceinline__ cf cf_mul(cf a, cf b)
+{
+#pragma clang fp contract(off)
+    cf r; r.re = (a.re * b.re) - (a.im * b.im); r.im = (a.im * b.re) + (a.re * b.im); return r;
+}
+__device__ __forceinline__ int cvtps_sat16(float x)    // cvtps2dq (nearest even; 0x80000000 when out of range or NaN), then packssdw
+{
+    const int v = (x >= -2147483648.0f && x < 2147483648.0f) ? (int)rintf(x) : (int)0x80000000;
+    return sat16(v);
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_mimo_est11n_batch(const uint32_t* ltf0, const uint32_t* ltf1, uint32_t* h, uint32_t* hinv, uint32_t nframes)
+{
+#pragma clang fp contract(off)
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6); const int i = threadIdx.x & 63;
+    if (f >= nframes) return;
+    const int k = i < 32 ? i : i - 64;
+    const bool negate = !(k >= -28 && k <= 28 && kHtLtf[k + 28] == 1);             // _80211n_HTLTFMask: every bin whose HT-LTF value is not +1
+    cpx hh[2][2];
+#pragma unroll
+    for (int r = 0; r < 2; r++) {
+        const uint32_t* l = (r ? ltf1 : ltf0) + (size_t)f * 128;
+        const cpx a = unpack(l[i]), b = unpack(l[i + 64]);
+        cpx d = sra(csubs(a, b), 1), s = sra(cadds(a, b), 1);                      // P-matrix combination of the two HT-LTFs
+        if (negate) { d = mk(neg16(d.re), neg16(d.im)); s = mk(neg16(s.re), neg16(s.im)); }
+        hh[r][0] = d; hh[r][1] = s;
+        h[((size_t)f * 2 + r) * 128 + i] = pack(d); h[((size_t)f * 2 + r) * 128 + 64 + i] = pack(s);
+    }
+    // 2x2 inverse x 2^16 in single precision, operation for operation as brick/inc/sora_matrix.h:134-148,305-313
+    const cf a00 = { (float)hh[0][0].re, (float)hh[0][0].im }, a01 = { (float)hh[0][1].re, (float)hh[0][1].im };
+    const cf a10 = { (float)hh[1][0].re, (float)hh[1][0].im }, a11 = { (float)hh[1][1].re, (float)hh[1][1].im };
+    const cf ad = cf_mul(a00, a11), bc = cf_mul(a01, a10);
+    const cf det = { ad.re - bc.re, ad.im - bc.im };
+    const float n = ((det.re * det.re) + (det.im * det.im)) / 65536.0f;
+    const cf ds = { det.re, -det.im }, m01 = { -a01.re, -a01.im }, m10 = { -a10.re, -a10.im };
+    const cf r00 = cf_mul(a11, ds), r01 = cf_mul(m01, ds), r10 = cf_mul(m10, ds), r11 = cf_mul(a00, ds);
+    uint32_t* o = hinv + (size_t)f * 256;
+    o[i]       = pack(mk(cvtps_sat16(r00.re / n), cvtps_sat16(r00.im / n)));
+    o[64 + i]  = pack(mk(cvtps_sat16(r01.re / n), cvtps_sat16(r01.im / n)));
+    o[128 + i] = pack(mk(cvtps_sat16(r10.re / n), cvtps_sat16(r10.im / n)));
+    o[192 + i] = pack(mk(cvtps_sat16(r11.re / n), cvtps_sat16(r11.im / n)));
+}
+
+// ---- TMimoChannelComp (channel_11n.hpp:445-521): x = (Hinv y) >> 9, saturating pack; one thread per carrier
+__global__ void __launch_bounds__(256) k_mimo_comp11n_batch(const uint32_t* hinv, const uint32_t* frame_index, const uint32_t* y0, const uint32_t* y1,
+                                                            uint32_t* x0, uint32_t* x1, uint32_t nsym)
+{
+    const uint32_t sidx = blockIdx.x * 4 + (threadIdx.x >> 6); const int i = threadIdx.x & 63;
+    if (sidx >= nsym) return;
+    const uint32_t* hi = hinv + (size_t)(frame_index ? frame_index[sidx] : 0u) * 256;
+    const cpx a = unpack(y0[(size_t)sidx * 64 + i]), b = unpack(y1[(size_t)sidx * 64 + i]);
+    int ar, ai, br, bi;
+    mul32(unpack(hi[i]), a, ar, ai); mul32(unpack(hi[64 + i]), b, br, bi);
+    x0[(size_t)sidx * 64 + i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+    mul32(unpack(hi[128 + i]), a, ar, ai); mul32(unpack(hi[192 + i]), b, br, bi);
+    x1[(size_t)sidx * 64 + i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+}
+
 }  // namespace sora
 
 using namespace sora;
@@ -95,4 +163,27 @@ int sora_hip_deinterleave11n(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, in
     hipLaunchKernelGGL(k_deint11n_batch, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_in, d_out, n_bpsc, spatial_stream, (uint32_t)n);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SORA_OK : sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "k_deint11n_batch", (int)e);
+}
+
+int sora_hip_mimo_est11n(const sora_complex16* d_ltf0, const sora_complex16* d_ltf1, sora_complex16* d_h, sora_complex16* d_hinv, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_ltf0 || !d_ltf1 || !d_h || !d_hinv) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_mimo_est11n: null argument", 0);
+    if (nframes == 0) return SORA_OK;
+    hipLaunchKernelGGL(k_mimo_est11n_batch, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_ltf0),
+                       reinterpret_cast<const uint32_t*>(d_ltf1), reinterpret_cast<uint32_t*>(d_h), reinterpret_cast<uint32_t*>(d_hinv), (uint32_t)nframes);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SORA_OK : sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "k_mimo_est11n_batch", (int)e);
+}
+
+int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
+                          sora_complex16* d_x0, sora_complex16* d_x1, size_t nsym, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_hinv || !d_y0 || !d_y1 || !d_x0 || !d_x1) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_mimo_comp11n: null argument", 0);
+    if (nsym == 0) return SORA_OK;
+    hipLaunchKernelGGL(k_mimo_comp11n_batch, dim3((unsigned)((nsym + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_hinv), d_frame_index,
+                       reinterpret_cast<const uint32_t*>(d_y0), reinterpret_cast<const uint32_t*>(d_y1), reinterpret_cast<uint32_t*>(d_x0), reinterpret_cast<uint32_t*>(d_x1), (uint32_t)nsym);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SORA_OK : sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "k_mimo_comp11n_batch", (int)e);
 }

@@ -135,6 +135,17 @@ def main():
         n11["deint_in_%d" % nb] = soft
         for st in (0, 1):
             n11["deint_out_%d_%d" % (nb, st)] = np.stack([G.deinterleave11n(nb, st, x) for x in soft])
+    # TMimoChannelEst / TMimoChannelComp: random, singular and zero channels
+    l0 = np.stack([rng.integers(-a, a + 1, size=(128, 2)) for a in (30, 400, 3000, 32767) for _ in range(3)]).astype(np.int16)
+    l1 = np.stack([rng.integers(-a, a + 1, size=(128, 2)) for a in (30, 400, 3000, 32767) for _ in range(3)]).astype(np.int16)
+    l1[1] = l0[1]; l0[2, 5] = 0; l0[2, 69] = 0; l1[2, 5] = 0; l1[2, 69] = 0
+    est = [G.mimo_est11n(a, b) for a, b in zip(l0, l1)]
+    n11["mimo_ltf0"] = l0; n11["mimo_ltf1"] = l1
+    n11["mimo_h"] = np.stack([e[0] for e in est]); n11["mimo_hinv"] = np.stack([e[1] for e in est])
+    y0 = rng.integers(-3000, 3001, size=(len(l0), 64, 2)).astype(np.int16); y1 = rng.integers(-3000, 3001, size=(len(l0), 64, 2)).astype(np.int16)
+    cmp = [G.mimo_comp11n(e[1], a, b) for e, a, b in zip(est, y0, y1)]
+    n11["mimo_y0"] = y0; n11["mimo_y1"] = y1
+    n11["mimo_x0"] = np.stack([c[0] for c in cmp]); n11["mimo_x1"] = np.stack([c[1] for c in cmp])
     np.savez_compressed(os.path.join(OUT, "ref_vectors_11n.npz"), **n11)
     print("written", os.listdir(OUT))
 

@@ -44,6 +44,61 @@ def test_oracle_11n_bricks_equal_reference_bricks_live(o):
             assert np.array_equal(lo | (hi << 8), mine) and sorted(mine) == list(idx), (nb, st)
 
 
+def test_oracle_mimo_bricks(o):
+    """TMimoChannelEst (float 2x2 inverse, operation for operation) and TMimoChannelComp against the recorded output of the
+    reference's bricks, and live against the bricks on random / singular / zero channels."""
+    z = np.load(GOLD)
+    for i in range(len(z["mimo_ltf0"])):
+        h, hi = o.mimo_est11n(z["mimo_ltf0"][i], z["mimo_ltf1"][i])
+        assert np.array_equal(h, z["mimo_h"][i]) and np.array_equal(hi, z["mimo_hinv"][i]), i
+        x0, x1 = o.mimo_comp11n(z["mimo_hinv"][i], z["mimo_y0"][i], z["mimo_y1"][i])
+        assert np.array_equal(x0, z["mimo_x0"][i]) and np.array_equal(x1, z["mimo_x1"][i]), i
+    g = ReferenceGraph()
+    if not g.available():
+        return
+    rng = np.random.default_rng(8)
+    for t in range(300):
+        amp = (30, 400, 3000, 32767)[t % 4]
+        l0 = rng.integers(-amp, amp + 1, size=(128, 2)).astype(np.int16); l1 = rng.integers(-amp, amp + 1, size=(128, 2)).astype(np.int16)
+        if t % 7 == 0:
+            l1[:] = l0
+        h, hi = o.mimo_est11n(l0, l1); rh, rhi = g.mimo_est11n(l0, l1)
+        assert np.array_equal(h, rh) and np.array_equal(hi, rhi), t
+        y0 = rng.integers(-amp, amp + 1, size=(64, 2)).astype(np.int16); y1 = rng.integers(-amp, amp + 1, size=(64, 2)).astype(np.int16)
+        a = o.mimo_comp11n(rhi, y0, y1); b = g.mimo_comp11n(rhi, y0, y1)
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), t
+
+
+@pytest.mark.gpu
+def test_gpu_mimo_stage_kernels(o):
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    z = np.load(GOLD)
+    rng = np.random.default_rng(9)
+    n = 500
+    l0 = np.concatenate([z["mimo_ltf0"], np.stack([rng.integers(-a, a + 1, size=(128, 2)) for a in rng.choice([30, 400, 3000, 32767], n)]).astype(np.int16)])
+    l1 = np.concatenate([z["mimo_ltf1"], np.stack([rng.integers(-a, a + 1, size=(128, 2)) for a in rng.choice([30, 400, 3000, 32767], n)]).astype(np.int16)])
+    l1[20] = l0[20]
+    h, hinv = sora_amd.mimo_est11n(torch.from_numpy(l0).cuda(), torch.from_numpy(l1).cuda())
+    h = h.cpu().numpy(); hinv = hinv.cpu().numpy()
+    k = len(z["mimo_ltf0"])
+    assert np.array_equal(h[:k], z["mimo_h"]) and np.array_equal(hinv[:k], z["mimo_hinv"])
+    for i in range(k, len(l0)):
+        wh, whi = o.mimo_est11n(l0[i], l1[i])
+        assert np.array_equal(h[i], wh) and np.array_equal(hinv[i], whi), i
+    nsym = 3000
+    fidx = rng.integers(0, len(l0), nsym).astype(np.uint32)
+    y0 = rng.integers(-4000, 4001, size=(nsym, 64, 2)).astype(np.int16); y1 = rng.integers(-4000, 4001, size=(nsym, 64, 2)).astype(np.int16)
+    x0, x1 = sora_amd.mimo_comp11n(torch.from_numpy(hinv).cuda(), torch.from_numpy(y0).cuda(), torch.from_numpy(y1).cuda(),
+                                   frame_index=torch.from_numpy(fidx.astype(np.int32)).cuda())
+    x0 = x0.cpu().numpy(); x1 = x1.cpu().numpy()
+    for s in range(0, nsym, 13):
+        w0, w1 = o.mimo_comp11n(hinv[fidx[s]], y0[s], y1[s])
+        assert np.array_equal(x0[s], w0) and np.array_equal(x1[s], w1), s
+
+
 @pytest.mark.gpu
 def test_gpu_11n_stage_kernels(o):
     import torch
