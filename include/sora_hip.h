@@ -196,6 +196,21 @@ int sora_hip_deinterleave11n(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, in
  * the reference's SSE code (brick/inc/sora_matrix.h:134-148,305-313) and packed with saturation.
  * TMimoChannelComp (channel_11n.hpp:445-521), a batch of symbols: x = (Hinv y) >> 9 with saturation; symbol s uses
  * d_hinv[d_frame_index[s]] (d_frame_index NULL: frame 0); y_r = RX chain r after the FFT, x_k = spatial stream k. */
+/* The CFO / phase bricks (Brick11/src/dsp_math.h tables, generated with the C library as the reference does at start-up).
+ * d_state[f][24] = CF_FreqOffset_11n of frame f: vfo_delta_i[8] | vfo_step_i[8] | vfo_theta_i[8] (int16).
+ * sora_hip_cfo_est11n     TFreqEstimator_11n (freqoffset_11n.hpp:42-160): d_lltf_r[f][128] = the L-LTF of RX chain r (two 64-sample
+ *                         halves) -> d_state[f] (vfo_delta_i = {0..7} x CFO, vfo_step_i = 8 x CFO, vfo_theta_i = 0; CFO_est = state[1])
+ * sora_hip_freq_comp11n   TFreqComp_11n (freqoffset_11n.hpp:162-280): frame f owns d_nbursts[f] bursts of 8 samples starting at sample
+ *                         d_first[f] of both chains; out = sat((in * sincos(vfo_delta_i - vfo_theta_i)) >> 15); vfo_delta_i advances by
+ *                         vfo_step_i per burst and is written back.  max_bursts >= every d_nbursts[f].
+ * sora_hip_pilot_track11n TPilotTrack_11n (pilot_11n.hpp:84-141): frame f owns symbols d_first[f] .. +d_nsym[f]-1 of the two spatial
+ *                         streams (after TMimoChannelComp); vfo_theta_i of d_state[f] accumulates the mean pilot phase; d_theta[s][8]
+ *                         (optional) receives vfo_theta_i as it stands after symbol s. */
+int sora_hip_cfo_est11n(const sora_complex16* d_lltf0, const sora_complex16* d_lltf1, int16_t* d_state, size_t nframes, void* stream);
+int sora_hip_freq_comp11n(const sora_complex16* d_in0, const sora_complex16* d_in1, sora_complex16* d_out0, sora_complex16* d_out1,
+                          const uint32_t* d_first, const uint32_t* d_nbursts, int16_t* d_state, size_t nframes, size_t max_bursts, void* stream);
+int sora_hip_pilot_track11n(const sora_complex16* d_x0, const sora_complex16* d_x1, const uint32_t* d_first, const uint32_t* d_nsym, int16_t* d_state,
+                            int16_t* d_theta, size_t nframes, void* stream);
 int sora_hip_mimo_est11n(const sora_complex16* d_ltf0, const sora_complex16* d_ltf1, sora_complex16* d_h, sora_complex16* d_hinv, size_t nframes, void* stream);
 int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
                           sora_complex16* d_x0, sora_complex16* d_x1, size_t nsym, void* stream);

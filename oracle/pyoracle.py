@@ -175,6 +175,20 @@ class Oracle:
         x0 = np.zeros((64, 2), np.int16); x1 = np.zeros((64, 2), np.int16)
         self.L.so_mimo_comp11n(_P(hi), _P(a), _P(b), _P(x0), _P(x1)); return x0, x1
 
+    def cfo_est11n(self, l0, l1):
+        a = np.ascontiguousarray(l0, np.int16).reshape(128, 2); b = np.ascontiguousarray(l1, np.int16).reshape(128, 2)
+        st = np.zeros(24, np.int16); self.L.so_cfo_est11n(_P(a), _P(b), _P(st)); return st
+
+    def freq_comp11n(self, state, in0, in1):
+        a = np.ascontiguousarray(in0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(in1, np.int16).reshape(-1, 2)
+        st = np.array(state, np.int16).copy(); o0 = np.zeros_like(a); o1 = np.zeros_like(b)
+        self.L.so_freq_comp11n(_P(st), _P(a), _P(b), _P(o0), _P(o1), len(a) // 8); return st, o0, o1
+
+    def pilot_track11n(self, theta8, x0, x1):
+        th = np.array(theta8, np.int16).copy()
+        a = np.ascontiguousarray(x0, np.int16).reshape(64, 2); b = np.ascontiguousarray(x1, np.int16).reshape(64, 2)
+        self.L.so_pilot_track11n(_P(th), _P(a), _P(b)); return th
+
     def rx11b_capture(self, iq44, max_frames=16):
         """802.11b receive graph over int16 [n,2] @44 MHz -> list of dict (end_sample = 44 MHz source position)."""
         iq = np.ascontiguousarray(iq44, np.int16).reshape(-1, 2)
@@ -336,6 +350,21 @@ class ReferenceGraph:
         a = np.ascontiguousarray(y0, np.int16).reshape(64, 2); b = np.ascontiguousarray(y1, np.int16).reshape(64, 2)
         x0 = np.zeros((64, 2), np.int16); x1 = np.zeros((64, 2), np.int16)
         self.L.ref_11n_mimo_comp(_P(hi), _P(a), _P(b), _P(x0), _P(x1)); return x0, x1
+
+    def cfo_est11n(self, l0, l1):
+        """TFreqEstimator_11n through the reference's own brick -> state int16 [24] (vfo_delta_i | vfo_step_i | vfo_theta_i)."""
+        a = np.ascontiguousarray(l0, np.int16).reshape(128, 2); b = np.ascontiguousarray(l1, np.int16).reshape(128, 2)
+        st = np.zeros(24, np.int16); self.L.ref_11n_cfo_est(_P(a), _P(b), _P(st)); return st
+
+    def freq_comp11n(self, state, in0, in1):
+        a = np.ascontiguousarray(in0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(in1, np.int16).reshape(-1, 2)
+        st = np.array(state, np.int16).copy(); o0 = np.zeros_like(a); o1 = np.zeros_like(b)
+        self.L.ref_11n_freq_comp(_P(st), _P(a), _P(b), _P(o0), _P(o1), len(a) // 8); return st, o0, o1
+
+    def pilot_track11n(self, theta8, x0, x1):
+        th = np.array(theta8, np.int16).copy()
+        a = np.ascontiguousarray(x0, np.int16).reshape(64, 2); b = np.ascontiguousarray(x1, np.int16).reshape(64, 2)
+        self.L.ref_11n_pilot_track(_P(th), _P(a), _P(b)); return th
 
     def tx11n(self, mpdu_nofcs, mcs):
         """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""

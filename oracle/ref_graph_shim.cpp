@@ -363,3 +363,50 @@ EXPORT void ref_11n_mimo_comp(const int16_t* hinv, const int16_t* y0, const int1
     comp->Process(pin);
     memcpy(x0, sink->last[0], 256); memcpy(x1, sink->last[1], 256);
 }
+
+// ---- dsp_math (Brick11/src/dsp_math.h): the 11n path's trigonometry, tables generated at start-up with libm
+EXPORT int  ref_dsp_atan(int x, int y, int wide) { const dsp_math& dm = dsp_math::singleton(); return wide ? dm.atan(x, y) : dm.atan((short)x, (short)y); }
+EXPORT void ref_dsp_sincos_table(int16_t* out) { const dsp_math& dm = dsp_math::singleton(); for (int i = 0; i < 65536; i++) { COMPLEX16 c = dm.sincos((short)i); out[2 * i] = c.re; out[2 * i + 1] = c.im; } }
+// TFreqEstimator_11n (freqoffset_11n.hpp:86-160): the L-LTF of both RX chains (128 samples each: two 64-sample halves) -> CFO_est;
+// state[0..7] = vfo_delta_i, [8..15] = vfo_step_i, [16..23] = vfo_theta_i afterwards
+EXPORT int ref_11n_cfo_est(const int16_t* l0, const int16_t* l1, int16_t* state)
+{
+    typedef TCaptureSink2<BB11nDemodContext, 128> Sink;
+    static Sink* sink = new Sink(BB11nDemodCtx);
+    static TFreqEstimator_11n<BB11nDemodContext, Sink>* est = new TFreqEstimator_11n<BB11nDemodContext, Sink>(BB11nDemodCtx, sink);
+    A16 COMPLEX16 a[128], b[128]; memcpy(a, l0, sizeof(a)); memcpy(b, l1, sizeof(b));
+    TwoStreamPin<COMPLEX16, 128> pin = { { a, b }, true };
+    est->Process(pin);
+    memcpy(state, &BB11nDemodCtx.CF_FreqOffset_11n::vfo_delta_i(), 16); memcpy(state + 8, &BB11nDemodCtx.CF_FreqOffset_11n::vfo_step_i(), 16);
+    memcpy(state + 16, &BB11nDemodCtx.CF_FreqOffset_11n::vfo_theta_i(), 16);
+    return (short)BB11nDemodCtx.CF_CFOffset::CFO_est();
+}
+// TFreqComp_11n (freqoffset_11n.hpp:218-280): nbursts x 8 samples of both RX chains with the context state (layout as above) going in
+// and coming out
+EXPORT void ref_11n_freq_comp(int16_t* state, const int16_t* in0, const int16_t* in1, int16_t* out0, int16_t* out1, int nbursts)
+{
+    typedef TCaptureSink2<BB11nDemodContext, 8> Sink;
+    static Sink* sink = new Sink(BB11nDemodCtx);
+    static TFreqComp_11n<BB11nDemodContext, Sink>* comp = new TFreqComp_11n<BB11nDemodContext, Sink>(BB11nDemodCtx, sink);
+    memcpy(&BB11nDemodCtx.CF_FreqOffset_11n::vfo_delta_i(), state, 16); memcpy(&BB11nDemodCtx.CF_FreqOffset_11n::vfo_step_i(), state + 8, 16);
+    memcpy(&BB11nDemodCtx.CF_FreqOffset_11n::vfo_theta_i(), state + 16, 16);
+    for (int k = 0; k < nbursts; k++) {
+        A16 COMPLEX16 a[8], b[8]; memcpy(a, in0 + 16 * k, 32); memcpy(b, in1 + 16 * k, 32);
+        TwoStreamPin<COMPLEX16, 8> pin = { { a, b }, true };
+        comp->Process(pin);
+        memcpy(out0 + 16 * k, sink->last[0], 32); memcpy(out1 + 16 * k, sink->last[1], 32);
+    }
+    memcpy(state, &BB11nDemodCtx.CF_FreqOffset_11n::vfo_delta_i(), 16);
+}
+// TPilotTrack_11n (pilot_11n.hpp:97-141): one symbol of both spatial streams; theta[8] = vfo_theta_i going in and coming out
+EXPORT void ref_11n_pilot_track(int16_t* theta, const int16_t* x0, const int16_t* x1)
+{
+    typedef TCaptureSink2<BB11nDemodContext, 64> Sink;
+    static Sink* sink = new Sink(BB11nDemodCtx);
+    static TPilotTrack_11n<BB11nDemodContext, Sink>* trk = new TPilotTrack_11n<BB11nDemodContext, Sink>(BB11nDemodCtx, sink);
+    memcpy(&BB11nDemodCtx.CF_FreqOffset_11n::vfo_theta_i(), theta, 16);
+    A16 COMPLEX16 a[64], b[64]; memcpy(a, x0, sizeof(a)); memcpy(b, x1, sizeof(b));
+    TwoStreamPin<COMPLEX16, 64> pin = { { a, b }, true };
+    trk->Process(pin);
+    memcpy(theta, &BB11nDemodCtx.CF_FreqOffset_11n::vfo_theta_i(), 16);
+}

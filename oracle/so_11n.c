@@ -7,8 +7,14 @@
  * v in [-128,127]; they are regenerated here from their run lengths (value, count from v = -128 upward), checked
  * entry for entry against the reference bricks.  The de-interleavers are the standard HT interleaver
  * (N_COL 13, N_ROW 4 N_BPSC, N_ROT 11) inverted: out[k] = in[r(k)]. */
+#define _USE_MATH_DEFINES
+#define _DEFAULT_SOURCE              /* M_PI under -std=c11 */
+#include <math.h>
 #include <string.h>
 #include "so_internal.h"
+#ifndef M_PI
+#define M_PI 3.14159265358979323846
+#endif
 
 typedef struct { uint8_t v, n; } run_t;
 static const run_t RL_BPSK[]   = {{0,97},{1,10},{2,10},{3,11},{4,11},{5,10},{6,10},{7,97}};                       /* also QPSK */
@@ -135,4 +141,105 @@ void so_mimo_comp11n(const so_c16 hinv[2][128], const so_c16 y0[64], const so_c1
         so_mul32(hinv[1][i], y0[i], &ar, &ai); so_mul32(hinv[1][i + 64], y1[i], &br, &bi);
         x1[i] = so_c(so_sat16(so_w32((int64_t)ar + br) >> 9), so_sat16(so_w32((int64_t)ai + bi) >> 9));
     }
+}
+
+/* ------------------------------------------------------------------ dsp_math (Brick11/src/dsp_math.h) and the bricks built on it
+ * The 11n path does its trigonometry with two tables generated at start-up with the C library's double-precision cos / sin /
+ * atan (dsp_math.h:215-245); they are generated here the same way (the parity claim is for the same libm -- the reference
+ * compiled in this image uses the very same one).
+ *   so_cfo_est11n       TFreqEstimator_11n (freqoffset_11n.hpp:42-160): joint estimate over both RX chains' L-LTF
+ *   so_freq_comp11n     TFreqComp_11n      (freqoffset_11n.hpp:162-280): 8-sample bursts, phase ramp minus tracked phase
+ *   so_pilot_track11n   TPilotTrack_11n    (pilot_11n.hpp:84-141): mean pilot phase of both streams into vfo_theta_i */
+static so_c16 g_sincos[65536]; static int16_t g_atan[4097]; static int g_dsp_ready;
+static void dsp_init(void)
+{
+    if (g_dsp_ready) return;
+    for (unsigned i = 0; i < 65536; i++) {
+        const double r = (double)i * 2.0 * M_PI / 65535.0;
+        g_sincos[i].re = (int16_t)(cos(r) * 32767.5); g_sincos[i].im = (int16_t)(sin(r) * 32767.5);
+    }
+    for (int i = 0; i <= 4096; i++) g_atan[i] = (int16_t)(atan((double)i / 4096.0) / (M_PI / 4.0) * 8192);
+    g_dsp_ready = 1;
+}
+const so_c16* so_dsp_sincos_table(void) { dsp_init(); return g_sincos; }
+const int16_t* so_dsp_atan_table(void) { dsp_init(); return g_atan; }
+
+static inline int32_t iabs32(int32_t x) { const int32_t t = x >> 31; return so_w32((int64_t)(x ^ t) - t); }
+static inline int32_t imax32(int32_t x, int32_t y) { return (int32_t)(so_w32((int64_t)so_w32((int64_t)x + y) + iabs32(so_w32((int64_t)x - y))) >> 1); }
+int16_t so_dsp_atan16(int16_t x, int16_t y)                               /* dsp_math::atan(short, short) */
+{
+    dsp_init();
+    const int16_t sign = (int16_t)((x ^ y) >> 15);
+    const int16_t absx = (int16_t)((x ^ (x >> 15)) - (x >> 15)), absy = (int16_t)((y ^ (y >> 15)) - (y >> 15));
+    const int16_t tsign = (int16_t)(((int)absx - (int)absy) >> 15);
+    int tmax = absx, tmin = absy; const int tsum = tmax + tmin;
+    tmax = imax32(tmax, tmin); tmin = tsum - tmax;
+    if (tmax == 0) return 0;
+    int idx = so_w32(((int64_t)so_w32((int64_t)tmin << 16) + (tmax >> 1))) / tmax;
+    idx >>= 4;
+    if (idx < 0 || idx >= 4097) return 0;
+    int16_t srad = g_atan[idx];
+    srad = (int16_t)((16384 & tsign) + ((srad ^ tsign) - tsign));
+    srad ^= sign; srad = (int16_t)(srad - sign);
+    return srad;
+}
+int16_t so_dsp_atan32(int32_t x, int32_t y)                               /* dsp_math::atan(int, int) */
+{
+    dsp_init();
+    const int16_t sign = (int16_t)(((x ^ y) >> 31) & 0xFFFF);
+    const int32_t absx = iabs32(x), absy = iabs32(y);
+    const int16_t tsign = (int16_t)((so_w32((int64_t)absx - absy) >> 31) & 0xFFFF);
+    int32_t tmax = absx, tmin = absy; const int32_t tsum = so_w32((int64_t)tmax + tmin);
+    tmax = imax32(tmax, tmin); tmin = so_w32((int64_t)tsum - tmax);
+    int64_t i64x = (int64_t)tmin << 16, i64y = tmax;
+    if (i64y == 0) i64y = 1;
+    int idx = (int)((i64x + (i64y >> 1)) / i64y);
+    idx >>= 4;
+    if (idx < 0 || idx >= 4097) return 0;
+    int16_t srad = g_atan[idx];
+    srad = (int16_t)((16384 & tsign) + ((srad ^ tsign) - tsign));
+    srad ^= sign; srad = (int16_t)(srad - sign);
+    return srad;
+}
+
+/* state[0..7] = vfo_delta_i, [8..15] = vfo_step_i, [16..23] = vfo_theta_i (CF_FreqOffset_11n); returns CFO_est */
+int16_t so_cfo_est11n(const so_c16 l0[128], const so_c16 l1[128], int16_t state[24])
+{
+    int32_t sre = 0, sim = 0;
+    const so_c16* l[2] = { l0, l1 };
+    for (int c = 0; c < 2; c++)
+        for (int i = 0; i < 64; i++) {
+            int32_t re, im; so_conj_mul32(l[c][i], l[c][i + 64], &re, &im);
+            sre = so_w32((int64_t)sre + (re >> 7)); sim = so_w32((int64_t)sim + (im >> 7));
+        }
+    int16_t d = so_dsp_atan32(sre, sim);
+    d = (int16_t)(d >> 6);
+    for (int k = 0; k < 8; k++) { state[k] = so_w16(k * d); state[8 + k] = so_w16(d << 3); state[16 + k] = 0; }
+    return d;
+}
+
+void so_freq_comp11n(int16_t state[24], const so_c16* in0, const so_c16* in1, so_c16* out0, so_c16* out1, int nbursts)
+{
+    dsp_init();
+    for (int b = 0; b < nbursts; b++) {
+        for (int k = 0; k < 8; k++) {
+            const so_c16 cof = g_sincos[(uint16_t)so_w16(state[k] - state[16 + k])];
+            int32_t re, im;
+            so_mul32(in0[8 * b + k], cof, &re, &im); out0[8 * b + k] = so_c(so_sat16(re >> 15), so_sat16(im >> 15));
+            so_mul32(in1[8 * b + k], cof, &re, &im); out1[8 * b + k] = so_c(so_sat16(re >> 15), so_sat16(im >> 15));
+        }
+        for (int k = 0; k < 8; k++) state[k] = so_w16(state[k] + state[8 + k]);
+    }
+}
+
+void so_pilot_track11n(int16_t theta[8], const so_c16 x0[64], const so_c16 x1[64])
+{
+    const so_c16* x[2] = { x0, x1 }; int t[2];
+    for (int s = 0; s < 2; s++) {
+        const int th = so_dsp_atan16(x[s][64 - 21].re, x[s][64 - 21].im) + so_dsp_atan16(x[s][64 - 7].re, x[s][64 - 7].im)
+                     + so_dsp_atan16(x[s][7].re, x[s][7].im) + so_dsp_atan16(x[s][21].re, x[s][21].im);
+        t[s] = (int16_t)(th >> 2);
+    }
+    const int16_t th = (int16_t)((t[0] + t[1]) >> 1);
+    for (int k = 0; k < 8; k++) theta[k] = so_w16(theta[k] + th);
 }

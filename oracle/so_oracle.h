@@ -117,6 +117,14 @@ int so_deinterleave11n_index(int nbpsc, int stream, int k);
 const uint8_t* so_demap11n_lut(int which);
 /* TMimoChannelEst / TMimoChannelComp (channel_11n.hpp:329-521); ltf_r = the two HT-LTF symbols of RX chain r after the FFT */
 void so_mimo_est11n(const so_c16 ltf0[128], const so_c16 ltf1[128], so_c16 h[2][128], so_c16 hinv[2][128]);
+/* dsp_math (dsp_math.h) and the bricks built on it; state[24] = vfo_delta_i | vfo_step_i | vfo_theta_i (8 int16 each) */
+const so_c16* so_dsp_sincos_table(void);
+const int16_t* so_dsp_atan_table(void);
+int16_t so_dsp_atan16(int16_t x, int16_t y);
+int16_t so_dsp_atan32(int32_t x, int32_t y);
+int16_t so_cfo_est11n(const so_c16 l0[128], const so_c16 l1[128], int16_t state[24]);
+void so_freq_comp11n(int16_t state[24], const so_c16* in0, const so_c16* in1, so_c16* out0, so_c16* out1, int nbursts);
+void so_pilot_track11n(int16_t theta[8], const so_c16 x0[64], const so_c16 x1[64]);
 void so_mimo_comp11n(const so_c16 hinv[2][128], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
 
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */

@@ -48,7 +48,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
 
 _lib = None
 
@@ -111,6 +111,9 @@ def load(build_if_missing=True):
                                   ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p]
     L.sora_hip_demap11n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_deinterleave11n.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_cfo_est11n.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_freq_comp11n.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_pilot_track11n.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_mimo_est11n.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_mimo_comp11n.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
@@ -374,6 +377,33 @@ def deinterleave11n(s, n_bpsc, spatial_stream, stream=None):
     out = torch.empty_like(s)
     _check(load().sora_hip_deinterleave11n(_dev_ptr(s), _dev_ptr(out), n_bpsc, spatial_stream, s.shape[0], _stream_ptr(stream)))
     return out
+
+
+def cfo_est11n(lltf0, lltf1, stream=None):
+    """lltf0/lltf1: int16 CUDA [n,128,2] -> state int16 CUDA [n,24] (vfo_delta_i | vfo_step_i | vfo_theta_i)."""
+    import torch
+    st = torch.empty((lltf0.shape[0], 24), dtype=torch.int16, device=lltf0.device)
+    _check(load().sora_hip_cfo_est11n(_dev_ptr(lltf0), _dev_ptr(lltf1), _dev_ptr(st), lltf0.shape[0], _stream_ptr(stream)))
+    return st
+
+
+def freq_comp11n(in0, in1, first, nbursts, state, stream=None):
+    """in0/in1: int16 CUDA [N,2]; first/nbursts: int32 CUDA [nframes]; state: int16 CUDA [nframes,24] (updated in place) -> (out0, out1)."""
+    import torch
+    o0 = in0.clone(); o1 = in1.clone()
+    mx = int(nbursts.max().item()) if nbursts.numel() else 0
+    _check(load().sora_hip_freq_comp11n(_dev_ptr(in0), _dev_ptr(in1), _dev_ptr(o0), _dev_ptr(o1), _dev_ptr(first), _dev_ptr(nbursts), _dev_ptr(state),
+                                        state.shape[0], mx, _stream_ptr(stream)))
+    return o0, o1
+
+
+def pilot_track11n(x0, x1, first, nsym, state, want_theta=True, stream=None):
+    """x0/x1: int16 CUDA [nsym_total,64,2]; first/nsym: int32 CUDA [nframes]; state updated in place -> theta int16 [nsym_total,8] or None."""
+    import torch
+    th = torch.zeros((x0.shape[0], 8), dtype=torch.int16, device=x0.device) if want_theta else None
+    _check(load().sora_hip_pilot_track11n(_dev_ptr(x0), _dev_ptr(x1), _dev_ptr(first), _dev_ptr(nsym), _dev_ptr(state),
+                                          _dev_ptr(th) if want_theta else None, state.shape[0], _stream_ptr(stream)))
+    return th
 
 
 def mimo_est11n(ltf0, ltf1, stream=None):

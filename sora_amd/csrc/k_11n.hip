@@ -139,6 +139,117 @@ __global__ void __launch_bounds__(256) k_mimo_comp11n_batch(const uint32_t* hinv
     x1[(size_t)sidx * 64 + i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
 }
 
+// ---- dsp_math (Brick11/src/dsp_math.h:96-213): arctangent through a 4097-entry table, exactly as the reference indexes it
+namespace {
+__device__ __forceinline__ int atan_tail(const short* tab, int idx, int tsign, int sign)
+{
+    if (idx < 0 || idx >= 4097) return 0;
+    int srad = tab[idx];
+    srad = (int)(short)((16384 & tsign) + ((srad ^ tsign) - tsign));
+    srad ^= sign; return (int)(short)(srad - sign);
+}
+__device__ __forceinline__ int dsp_atan16(const short* tab, int x, int y)      // dsp_math::atan(short, short); x, y already int16 values
+{
+    const int sign = (x ^ y) >> 15;                                            // -1 / 0
+    const int absx = (int)(short)((x ^ (x >> 15)) - (x >> 15)), absy = (int)(short)((y ^ (y >> 15)) - (y >> 15));
+    const int tsign = (int)(short)((absx - absy) >> 15);
+    const int tsum = absx + absy, d = absx - absy;
+    const int tmax = (tsum + ((d ^ (d >> 31)) - (d >> 31))) >> 1, tmin = tsum - tmax;
+    if (tmax == 0) return 0;
+    const int idx = (int)(((unsigned)tmin << 16) + (unsigned)(tmax >> 1)) / tmax;
+    return atan_tail(tab, idx >> 4, tsign, sign);
+}
+__device__ __forceinline__ int dsp_atan32(const short* tab, int x, int y)      // dsp_math::atan(int, int), for |x| + |y| < 2^31
+{
+    const int sign = (int)(short)(((x ^ y) >> 31) & 0xFFFF);
+    const int absx = (x ^ (x >> 31)) - (x >> 31), absy = (y ^ (y >> 31)) - (y >> 31);
+    const int tsign = (int)(short)(((absx - absy) >> 31) & 0xFFFF);
+    const int tsum = absx + absy, d = absx - absy;
+    const int tmax = (tsum + ((d ^ (d >> 31)) - (d >> 31))) >> 1, tmin = tsum - tmax;
+    const long long i64y = tmax == 0 ? 1 : tmax;
+    const int idx = (int)((((long long)tmin << 16) + (i64y >> 1)) / i64y);
+    return atan_tail(tab, idx >> 4, tsign, sign);
+}
+}  // namespace
+
+// TFreqEstimator_11n (freqoffset_11n.hpp:42-160): one wave per frame, lane = sample of the first L-LTF half, both RX chains
+__global__ void __launch_bounds__(256) k_cfo_est11n_batch(const uint32_t* l0, const uint32_t* l1, short* state, uint32_t nframes, const short* atan_tab)
+{
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6); const int i = threadIdx.x & 63;
+    if (f >= nframes) return;
+    int re, im, sre, sim;
+    conj_mul32(unpack(l0[(size_t)f * 128 + i]), unpack(l0[(size_t)f * 128 + 64 + i]), re, im); sre = re >> 7; sim = im >> 7;
+    conj_mul32(unpack(l1[(size_t)f * 128 + i]), unpack(l1[(size_t)f * 128 + 64 + i]), re, im); sre += re >> 7; sim += im >> 7;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { sre += __shfl_xor(sre, d); sim += __shfl_xor(sim, d); }       // wrapping 32-bit sums: order does not matter
+    if (i < 8) {
+        const int delta = dsp_atan32(atan_tab, sre, sim) >> 6;
+        short* st = state + (size_t)f * 24;
+        st[i] = (short)(i * delta); st[8 + i] = (short)(delta << 3); st[16 + i] = 0;
+    }
+}
+
+// TFreqComp_11n (freqoffset_11n.hpp:162-280): frame f owns nbursts[f] bursts of 8 samples from sample first[f] of both chains;
+// one thread per sample; the running phase is delta0 + burst * step - theta in wrapping int16
+__global__ void __launch_bounds__(256) k_freq_comp11n_batch(const uint32_t* in0, const uint32_t* in1, uint32_t* out0, uint32_t* out1, const uint32_t* first,
+                                                            const uint32_t* nbursts, const short* state, const uint32_t* sincos)
+{
+    const uint32_t f = blockIdx.y, nb = nbursts[f];
+    const short* st = state + (size_t)f * 24;
+    for (uint32_t m = blockIdx.x * 256 + threadIdx.x; m < nb * 8; m += gridDim.x * 256) {
+        const int k = m & 7, b = m >> 3;
+        const int ph = (int)(short)(st[k] + (short)(b * st[8 + k]) - st[16 + k]);
+        const cpx cof = unpack(sincos[(unsigned)ph & 0xFFFFu]);
+        const size_t at = (size_t)first[f] + m;
+        int re, im;
+        mul32(unpack(in0[at]), cof, re, im); out0[at] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+        mul32(unpack(in1[at]), cof, re, im); out1[at] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+    }
+}
+__global__ void k_freq_comp11n_advance(const uint32_t* nbursts, short* state, uint32_t nframes)       // vfo_delta_i += nbursts * vfo_step_i
+{
+    const uint32_t t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= nframes * 8) return;
+    short* st = state + (size_t)(t >> 3) * 24; const int k = t & 7;
+    st[k] = (short)(st[k] + (short)(nbursts[t >> 3] * st[8 + k]));
+}
+
+// TPilotTrack_11n (pilot_11n.hpp:84-141): one wave per frame, 64 symbols per pass: per-symbol mean pilot phase, then a wrapping prefix sum
+__global__ void __launch_bounds__(256) k_pilot_track11n_batch(const uint32_t* x0, const uint32_t* x1, const uint32_t* first, const uint32_t* nsym,
+                                                              short* state, short* theta_out, uint32_t nframes, const short* atan_tab)
+{
+    const uint32_t f = blockIdx.x * 4 + (threadIdx.x >> 6); const int lane = threadIdx.x & 63;
+    if (f >= nframes) return;
+    short* st = state + (size_t)f * 24;
+    int base[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) base[k] = st[16 + k];
+    const uint32_t n = nsym[f], s0 = first[f];
+    int run = 0;                                                           // sum of the increments so far (the same for all 8 entries)
+    for (uint32_t p = 0; p < n; p += 64) {
+        const uint32_t s = p + lane;
+        int inc = 0;
+        if (s < n) {
+            int t[2];
+#pragma unroll
+            for (int c = 0; c < 2; c++) {
+                const uint32_t* x = (c ? x1 : x0) + (size_t)(s0 + s) * 64;
+                const cpx a = unpack(x[64 - 21]), b = unpack(x[64 - 7]), d = unpack(x[7]), e = unpack(x[21]);
+                t[c] = (int)(short)((dsp_atan16(atan_tab, a.re, a.im) + dsp_atan16(atan_tab, b.re, b.im) + dsp_atan16(atan_tab, d.re, d.im) + dsp_atan16(atan_tab, e.re, e.im)) >> 2);
+            }
+            inc = (int)(short)((t[0] + t[1]) >> 1);
+        }
+        int pre = inc;                                                     // inclusive prefix sum over the pass (wrapping in the end)
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) { const int v = __shfl_up(pre, d); if (lane >= d) pre += v; }
+        if (theta_out && s < n)
+#pragma unroll
+            for (int k = 0; k < 8; k++) theta_out[(size_t)(s0 + s) * 8 + k] = (short)(base[k] + run + pre);
+        run += __shfl(pre, 63);
+    }
+    if (lane < 8) st[16 + lane] = (short)(base[lane] + run);
+}
+
 }  // namespace sora
 
 using namespace sora;
@@ -186,4 +297,71 @@ int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_
                        reinterpret_cast<const uint32_t*>(d_y0), reinterpret_cast<const uint32_t*>(d_y1), reinterpret_cast<uint32_t*>(d_x0), reinterpret_cast<uint32_t*>(d_x1), (uint32_t)nsym);
     const hipError_t e = hipGetLastError();
     return e == hipSuccess ? SORA_OK : sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "k_mimo_comp11n_batch", (int)e);
+}
+
+// ---- dsp_math tables (dsp_math.h:215-245): generated once per device with the C library, as the reference generates them at start-up
+#include <cmath>
+#include <vector>
+namespace {
+struct DspTables { uint32_t* sincos = nullptr; short* atan = nullptr; };
+const DspTables* dsp_tables()
+{
+    static DspTables tabs[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    DspTables& T = tabs[dev];
+    if (!T.sincos) {
+        std::vector<uint32_t> sc(65536); std::vector<short> at(4097);
+        for (unsigned i = 0; i < 65536; i++) {
+            const double r = (double)i * 2.0 * M_PI / 65535.0;
+            const short c = (short)(cos(r) * 32767.5), s = (short)(sin(r) * 32767.5);
+            sc[i] = ((uint32_t)(uint16_t)c) | ((uint32_t)(uint16_t)s << 16);
+        }
+        for (int i = 0; i <= 4096; i++) at[i] = (short)(atan((double)i / 4096.0) / (M_PI / 4.0) * 8192);
+        uint32_t* d_sc = nullptr; short* d_at = nullptr;
+        if (hipMalloc((void**)&d_sc, sc.size() * 4) != hipSuccess || hipMalloc((void**)&d_at, at.size() * 2) != hipSuccess) return nullptr;
+        if (hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_at, at.data(), at.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
+        T.sincos = d_sc; T.atan = d_at;
+    }
+    return &T;
+}
+int launch_result(const char* what) { const hipError_t e = hipGetLastError(); return e == hipSuccess ? SORA_OK : sora_internal_fail(SORA_ERR_HARDWARE_FAILED, what, (int)e); }
+}  // namespace
+
+int sora_hip_cfo_est11n(const sora_complex16* d_lltf0, const sora_complex16* d_lltf1, int16_t* d_state, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_lltf0 || !d_lltf1 || !d_state) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_cfo_est11n: null argument", 0);
+    if (nframes == 0) return SORA_OK;
+    const DspTables* T = dsp_tables(); if (!T) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "dsp_math table upload failed", 0);
+    hipLaunchKernelGGL(k_cfo_est11n_batch, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_lltf0),
+                       reinterpret_cast<const uint32_t*>(d_lltf1), d_state, (uint32_t)nframes, T->atan);
+    return launch_result("k_cfo_est11n_batch");
+}
+
+int sora_hip_freq_comp11n(const sora_complex16* d_in0, const sora_complex16* d_in1, sora_complex16* d_out0, sora_complex16* d_out1,
+                          const uint32_t* d_first, const uint32_t* d_nbursts, int16_t* d_state, size_t nframes, size_t max_bursts, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_in0 || !d_in1 || !d_out0 || !d_out1 || !d_first || !d_nbursts || !d_state) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_freq_comp11n: null argument", 0);
+    if (nframes == 0 || max_bursts == 0) return SORA_OK;
+    if (nframes > 65535) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_hip_freq_comp11n: at most 65535 frames per call", 0);
+    const DspTables* T = dsp_tables(); if (!T) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "dsp_math table upload failed", 0);
+    const unsigned gx = (unsigned)((max_bursts * 8 + 255) / 256);
+    hipLaunchKernelGGL(k_freq_comp11n_batch, dim3(gx < 64 ? gx : 64, (unsigned)nframes), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in0),
+                       reinterpret_cast<const uint32_t*>(d_in1), reinterpret_cast<uint32_t*>(d_out0), reinterpret_cast<uint32_t*>(d_out1), d_first, d_nbursts, d_state, T->sincos);
+    hipLaunchKernelGGL(k_freq_comp11n_advance, dim3((unsigned)((nframes * 8 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, d_nbursts, d_state, (uint32_t)nframes);
+    return launch_result("k_freq_comp11n_batch");
+}
+
+int sora_hip_pilot_track11n(const sora_complex16* d_x0, const sora_complex16* d_x1, const uint32_t* d_first, const uint32_t* d_nsym, int16_t* d_state,
+                            int16_t* d_theta, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_x0 || !d_x1 || !d_first || !d_nsym || !d_state) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_pilot_track11n: null argument", 0);
+    if (nframes == 0) return SORA_OK;
+    const DspTables* T = dsp_tables(); if (!T) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "dsp_math table upload failed", 0);
+    hipLaunchKernelGGL(k_pilot_track11n_batch, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_x0),
+                       reinterpret_cast<const uint32_t*>(d_x1), d_first, d_nsym, d_state, d_theta, (uint32_t)nframes, T->atan);
+    return launch_result("k_pilot_track11n_batch");
 }

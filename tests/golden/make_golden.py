@@ -146,6 +146,24 @@ def main():
     cmp = [G.mimo_comp11n(e[1], a, b) for e, a, b in zip(est, y0, y1)]
     n11["mimo_y0"] = y0; n11["mimo_y1"] = y1
     n11["mimo_x0"] = np.stack([c[0] for c in cmp]); n11["mimo_x1"] = np.stack([c[1] for c in cmp])
+    # TFreqEstimator_11n / TFreqComp_11n / TPilotTrack_11n (dsp_math tables generated with this image's libm)
+    ll0 = rng.integers(-3000, 3001, size=(8, 128, 2)).astype(np.int16); ll1 = rng.integers(-3000, 3001, size=(8, 128, 2)).astype(np.int16)
+    for l in (ll0, ll1):
+        for f in range(8):
+            z = (l[f, :64, 0] + 1j * l[f, :64, 1]) * np.exp(1j * (f - 4) * 0.07)
+            l[f, 64:, 0] = np.rint(z.real); l[f, 64:, 1] = np.rint(z.imag)
+    n11["cfo_l0"] = ll0; n11["cfo_l1"] = ll1
+    n11["cfo_state"] = np.stack([G.cfo_est11n(a, b) for a, b in zip(ll0, ll1)])
+    fin0 = rng.integers(-20000, 20001, size=(8, 160, 2)).astype(np.int16); fin1 = rng.integers(-20000, 20001, size=(8, 160, 2)).astype(np.int16)
+    st_in = n11["cfo_state"].copy(); st_in[:, 16:] = rng.integers(-4000, 4000, size=(8, 1))
+    fc = [G.freq_comp11n(st, a, b) for st, a, b in zip(st_in, fin0, fin1)]
+    n11["fc_state_in"] = st_in; n11["fc_in0"] = fin0; n11["fc_in1"] = fin1
+    n11["fc_state_out"] = np.stack([c[0] for c in fc]); n11["fc_out0"] = np.stack([c[1] for c in fc]); n11["fc_out1"] = np.stack([c[2] for c in fc])
+    px0 = rng.integers(-6000, 6001, size=(40, 64, 2)).astype(np.int16); px1 = rng.integers(-6000, 6001, size=(40, 64, 2)).astype(np.int16)
+    th = np.full(8, 123, np.int16); ths = []
+    for a, b in zip(px0, px1):
+        th = G.pilot_track11n(th, a, b); ths.append(th.copy())
+    n11["pt_x0"] = px0; n11["pt_x1"] = px1; n11["pt_theta"] = np.stack(ths)
     np.savez_compressed(os.path.join(OUT, "ref_vectors_11n.npz"), **n11)
     print("written", os.listdir(OUT))
 

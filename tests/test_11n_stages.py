@@ -69,6 +69,60 @@ def test_oracle_mimo_bricks(o):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]), t
 
 
+def test_oracle_phase_bricks(o):
+    """TFreqEstimator_11n, TFreqComp_11n, TPilotTrack_11n (dsp_math tables from libm) against recorded reference-brick output."""
+    z = np.load(GOLD)
+    for i in range(len(z["cfo_l0"])):
+        assert np.array_equal(o.cfo_est11n(z["cfo_l0"][i], z["cfo_l1"][i]), z["cfo_state"][i])
+        st, o0, o1 = o.freq_comp11n(z["fc_state_in"][i], z["fc_in0"][i], z["fc_in1"][i])
+        assert np.array_equal(st, z["fc_state_out"][i]) and np.array_equal(o0, z["fc_out0"][i]) and np.array_equal(o1, z["fc_out1"][i])
+    th = np.full(8, 123, np.int16)
+    for a, b, want in zip(z["pt_x0"], z["pt_x1"], z["pt_theta"]):
+        th = o.pilot_track11n(th, a, b)
+        assert np.array_equal(th, want)
+    assert len(set(z["cfo_state"][:, 1].tolist())) > 4                     # the recorded offsets really differ
+
+
+@pytest.mark.gpu
+def test_gpu_phase_stage_kernels(o):
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    z = np.load(GOLD)
+    st = sora_amd.cfo_est11n(torch.from_numpy(z["cfo_l0"]).cuda(), torch.from_numpy(z["cfo_l1"]).cuda())
+    assert np.array_equal(st.cpu().numpy(), z["cfo_state"])
+    rng = np.random.default_rng(12)
+    l0 = rng.integers(-32767, 32768, size=(300, 128, 2)).astype(np.int16); l1 = rng.integers(-32767, 32768, size=(300, 128, 2)).astype(np.int16)
+    st = sora_amd.cfo_est11n(torch.from_numpy(l0).cuda(), torch.from_numpy(l1).cuda()).cpu().numpy()
+    for i in range(300):
+        assert np.array_equal(st[i], o.cfo_est11n(l0[i], l1[i])), i
+    # frequency compensation: 8 frames laid end to end, different burst counts
+    nb = np.array([20, 20, 7, 20, 1, 20, 13, 20], np.int32); first = np.arange(8, dtype=np.int32) * 160
+    state = torch.from_numpy(z["fc_state_in"].copy()).cuda()
+    o0, o1 = sora_amd.freq_comp11n(torch.from_numpy(z["fc_in0"].reshape(-1, 2)).cuda(), torch.from_numpy(z["fc_in1"].reshape(-1, 2)).cuda(),
+                                   torch.from_numpy(first).cuda(), torch.from_numpy(nb).cuda(), state)
+    o0 = o0.cpu().numpy().reshape(8, 160, 2); o1 = o1.cpu().numpy().reshape(8, 160, 2); state = state.cpu().numpy()
+    for f in range(8):
+        wst, w0, w1 = o.freq_comp11n(z["fc_state_in"][f], z["fc_in0"][f][:8 * nb[f]], z["fc_in1"][f][:8 * nb[f]])
+        assert np.array_equal(state[f], wst) and np.array_equal(o0[f][:8 * nb[f]], w0) and np.array_equal(o1[f][:8 * nb[f]], w1), f
+        if nb[f] == 20:
+            assert np.array_equal(o0[f], z["fc_out0"][f]) and np.array_equal(state[f], z["fc_state_out"][f])
+    # pilot tracking: the recorded 40-symbol frame plus a long random one (more than one 64-symbol pass)
+    x0 = np.concatenate([z["pt_x0"], rng.integers(-9000, 9001, size=(150, 64, 2)).astype(np.int16)])
+    x1 = np.concatenate([z["pt_x1"], rng.integers(-9000, 9001, size=(150, 64, 2)).astype(np.int16)])
+    state = np.zeros((2, 24), np.int16); state[0, 16:] = 123; state[1, 16:] = -7
+    dstate = torch.from_numpy(state.copy()).cuda()
+    th = sora_amd.pilot_track11n(torch.from_numpy(x0).cuda(), torch.from_numpy(x1).cuda(), torch.tensor([0, 40], dtype=torch.int32).cuda(),
+                                 torch.tensor([40, 150], dtype=torch.int32).cuda(), dstate).cpu().numpy()
+    assert np.array_equal(th[:40], z["pt_theta"])
+    t = np.full(8, -7, np.int16)
+    for s in range(40, 190):
+        t = o.pilot_track11n(t, x0[s], x1[s])
+        assert np.array_equal(th[s], t), s
+    assert np.array_equal(dstate.cpu().numpy()[1, 16:], t) and np.array_equal(dstate.cpu().numpy()[0, 16:], z["pt_theta"][-1])
+
+
 @pytest.mark.gpu
 def test_gpu_mimo_stage_kernels(o):
     import torch
