@@ -211,6 +211,19 @@ int sora_hip_freq_comp11n(const sora_complex16* d_in0, const sora_complex16* d_i
                           const uint32_t* d_first, const uint32_t* d_nbursts, int16_t* d_state, size_t nframes, size_t max_bursts, void* stream);
 int sora_hip_pilot_track11n(const sora_complex16* d_x0, const sora_complex16* d_x1, const uint32_t* d_first, const uint32_t* d_nsym, int16_t* d_state,
                             int16_t* d_theta, size_t nframes, void* stream);
+/* The legacy part of the HT-mixed preamble (both RX chains), a batch of frames:
+ * sora_hip_siso_est11n   TSisoChannelEst (channel_11n.hpp:33-231): d_lltf_r[f][128] = the two L-LTF symbols of chain r after the FFT ->
+ *                        d_ch[f][2][64], 1 / H per chain in Q16 with the reference's rounding lanes; bins 28..35, which the brick
+ *                        leaves unwritten, are 0.
+ * sora_hip_siso_comp11n  TSisoChannelComp (channel_11n.hpp:233-297) + TMrcCombine (PHY_11n.hpp:362-398): x_r = sat((y_r c_r) >> 9),
+ *                        mrc = (x_0 + x_1) >> 1; symbol s uses d_ch[d_frame_index[s]] (NULL: frame 0); any of d_x0 / d_x1 / d_mrc may be
+ *                        NULL (not all three).
+ * sora_hip_sig_demap11n  T11nSigDemap (demapper11n.hpp:6-87): d_sym[f][3][64] = L-SIG, HT-SIG1, HT-SIG2 after MRC -> d_soft[f][144]
+ *                        (L-SIG demapped on I, the HT-SIG symbols on Q; 48 carriers each). */
+int sora_hip_siso_est11n(const sora_complex16* d_lltf0, const sora_complex16* d_lltf1, sora_complex16* d_ch, size_t nframes, void* stream);
+int sora_hip_siso_comp11n(const sora_complex16* d_ch, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
+                          sora_complex16* d_x0, sora_complex16* d_x1, sora_complex16* d_mrc, size_t nsym, void* stream);
+int sora_hip_sig_demap11n(const sora_complex16* d_sym, uint8_t* d_soft, size_t nframes, void* stream);
 int sora_hip_mimo_est11n(const sora_complex16* d_ltf0, const sora_complex16* d_ltf1, sora_complex16* d_h, sora_complex16* d_hinv, size_t nframes, void* stream);
 int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
                           sora_complex16* d_x0, sora_complex16* d_x1, size_t nsym, void* stream);

@@ -189,6 +189,21 @@ class Oracle:
         a = np.ascontiguousarray(x0, np.int16).reshape(64, 2); b = np.ascontiguousarray(x1, np.int16).reshape(64, 2)
         self.L.so_pilot_track11n(_P(th), _P(a), _P(b)); return th
 
+    def siso_est11n(self, l0, l1):
+        a = np.ascontiguousarray(l0, np.int16).reshape(128, 2); b = np.ascontiguousarray(l1, np.int16).reshape(128, 2)
+        ch = np.zeros((2, 64, 2), np.int16); self.L.so_siso_est11n(_P(a), _P(b), _P(ch)); return ch
+
+    def siso_comp11n(self, ch, y0, y1):
+        """TSisoChannelComp then TMrcCombine -> (x0, x1, mrc)"""
+        c = np.ascontiguousarray(ch, np.int16).reshape(2, 64, 2)
+        a = np.ascontiguousarray(y0, np.int16).reshape(64, 2); b = np.ascontiguousarray(y1, np.int16).reshape(64, 2)
+        x0 = np.zeros((64, 2), np.int16); x1 = np.zeros((64, 2), np.int16); m = np.zeros((64, 2), np.int16)
+        self.L.so_siso_comp11n(_P(c), _P(a), _P(b), _P(x0), _P(x1)); self.L.so_mrc11n(_P(x0), _P(x1), _P(m)); return x0, x1, m
+
+    def sig_demap11n(self, sym3):
+        a = np.ascontiguousarray(sym3, np.int16).reshape(192, 2); o = np.zeros(144, np.uint8)
+        self.L.so_sig_demap11n(_P(a), _P(o)); return o
+
     def rx11b_capture(self, iq44, max_frames=16):
         """802.11b receive graph over int16 [n,2] @44 MHz -> list of dict (end_sample = 44 MHz source position)."""
         iq = np.ascontiguousarray(iq44, np.int16).reshape(-1, 2)
@@ -365,6 +380,22 @@ class ReferenceGraph:
         th = np.array(theta8, np.int16).copy()
         a = np.ascontiguousarray(x0, np.int16).reshape(64, 2); b = np.ascontiguousarray(x1, np.int16).reshape(64, 2)
         self.L.ref_11n_pilot_track(_P(th), _P(a), _P(b)); return th
+
+    def siso_est11n(self, l0, l1):
+        """TSisoChannelEst through the reference's own brick -> ch int16 [2,64,2] (bins 28..35, which the brick never writes, zeroed)."""
+        a = np.ascontiguousarray(l0, np.int16).reshape(128, 2); b = np.ascontiguousarray(l1, np.int16).reshape(128, 2)
+        ch = np.zeros((2, 64, 2), np.int16); self.L.ref_11n_siso_est(_P(a), _P(b), _P(ch)); return ch
+
+    def siso_comp11n(self, ch, y0, y1):
+        """TSisoChannelComp -> TMrcCombine through the reference's own bricks -> (x0, x1, mrc)."""
+        c = np.ascontiguousarray(ch, np.int16).reshape(2, 64, 2)
+        a = np.ascontiguousarray(y0, np.int16).reshape(64, 2); b = np.ascontiguousarray(y1, np.int16).reshape(64, 2)
+        x0 = np.zeros((64, 2), np.int16); x1 = np.zeros((64, 2), np.int16); m = np.zeros((64, 2), np.int16)
+        self.L.ref_11n_siso_comp_mrc(_P(c), _P(a), _P(b), _P(x0), _P(x1), _P(m)); return x0, x1, m
+
+    def sig_demap11n(self, sym3):
+        a = np.ascontiguousarray(sym3, np.int16).reshape(192, 2); o = np.zeros(144, np.uint8)
+        self.L.ref_11n_sig_demap(_P(a), _P(o)); return o
 
     def tx11n(self, mpdu_nofcs, mcs):
         """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""

@@ -410,3 +410,43 @@ EXPORT void ref_11n_pilot_track(int16_t* theta, const int16_t* x0, const int16_t
     trk->Process(pin);
     memcpy(theta, &BB11nDemodCtx.CF_FreqOffset_11n::vfo_theta_i(), 16);
 }
+
+// TSisoChannelEst (channel_11n.hpp:33-231): the L-LTF of both RX chains after the FFT (two 64-bin halves each) -> CF_Channel_11n;
+// bins 28..35 are never written by the brick (left 0 here).  TSisoChannelComp (:233-297), TMrcCombine (PHY_11n.hpp:362-398),
+// T11nSigDemap (demapper11n.hpp:6-87) on the three SIG symbols.
+EXPORT void ref_11n_siso_est(const int16_t* l0, const int16_t* l1, int16_t* ch)      // ch[2][64] complex
+{
+    static TSisoChannelEst<BB11nDemodContext>* est = new TSisoChannelEst<BB11nDemodContext>(BB11nDemodCtx);
+    A16 COMPLEX16 a[128], b[128]; memcpy(a, l0, sizeof(a)); memcpy(b, l1, sizeof(b));
+    TwoStreamPin<COMPLEX16, 128> pin = { { a, b }, true };
+    est->Process(pin);
+    memcpy(ch, BB11nDemodCtx.CF_Channel_11n::dot11a_siso_channel_1(), 256); memcpy(ch + 128, BB11nDemodCtx.CF_Channel_11n::dot11a_siso_channel_2(), 256);
+    memset(ch + 2 * 28, 0, 32); memset(ch + 128 + 2 * 28, 0, 32);
+}
+struct CSink : public TSink<BB11nDemodContext> {                           // one stream of 64 COMPLEX16
+    DEFINE_IPORT(COMPLEX16, 64); COMPLEX16 last[64];
+    CSink(BB11nDemodContext& c) : TSink<BB11nDemodContext>(c) { memset(last, 0, sizeof(last)); }
+    template <class P> bool Process(P& ipin) { while (ipin.check_read()) { memcpy(last, ipin.peek(), 256); ipin.pop(); } return true; }
+};
+EXPORT void ref_11n_siso_comp_mrc(const int16_t* ch, const int16_t* y0, const int16_t* y1, int16_t* x0, int16_t* x1, int16_t* mrc)
+{
+    typedef TCaptureSink2<BB11nDemodContext, 64> Sink;
+    static Sink* sink = new Sink(BB11nDemodCtx);
+    static TSisoChannelComp<BB11nDemodContext, Sink>* comp = new TSisoChannelComp<BB11nDemodContext, Sink>(BB11nDemodCtx, sink);
+    memcpy(BB11nDemodCtx.CF_Channel_11n::dot11a_siso_channel_1(), ch, 256); memcpy(BB11nDemodCtx.CF_Channel_11n::dot11a_siso_channel_2(), ch + 128, 256);
+    A16 COMPLEX16 a[64], b[64]; memcpy(a, y0, sizeof(a)); memcpy(b, y1, sizeof(b));
+    TwoStreamPin<COMPLEX16, 64> pin = { { a, b }, true };
+    comp->Process(pin);
+    memcpy(x0, sink->last[0], 256); memcpy(x1, sink->last[1], 256);
+    static CSink* s1 = new CSink(BB11nDemodCtx);
+    static TMrcCombine<BB11nDemodContext, CSink>* m = new TMrcCombine<BB11nDemodContext, CSink>(BB11nDemodCtx, s1);
+    A16 COMPLEX16 c[64], d[64]; memcpy(c, x0, 256); memcpy(d, x1, 256);
+    TwoStreamPin<COMPLEX16, 64> pin2 = { { c, d }, true };
+    m->Process(pin2);
+    memcpy(mrc, s1->last, 256);
+}
+EXPORT void ref_11n_sig_demap(const int16_t* sym3, uint8_t* soft144)
+{
+    A16 COMPLEX16 x[192]; memcpy(x, sym3, sizeof(x));
+    run_brick_once<T11nSigDemap, 192, COMPLEX16, 144>(x, soft144);
+}

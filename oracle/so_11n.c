@@ -243,3 +243,65 @@ void so_pilot_track11n(int16_t theta[8], const so_c16 x0[64], const so_c16 x1[64
     const int16_t th = (int16_t)((t[0] + t[1]) >> 1);
     for (int k = 0; k < 8; k++) theta[k] = so_w16(theta[k] + th);
 }
+
+/* ------------------------------------------------------------------ the legacy (SISO) part of the 11n preamble
+ *   so_siso_est11n   TSisoChannelEst  (channel_11n.hpp:33-231): per RX chain and L-LTF half c = trunc((x << 16 + |x|^2 / 2) / |x|^2),
+ *                    saturating pack, conjugate and L-LTF sign folded into one masked negation (_80211_LLTFMask: im negated where
+ *                    the L-LTF is +1, re elsewhere), the two halves averaged with a wrapping add; bins 28..35 are never written
+ *                    by the brick (0 here)
+ *   so_siso_comp11n  TSisoChannelComp (channel_11n.hpp:233-297): sat((y * c) >> 9) per chain
+ *   so_mrc11n        TMrcCombine      (PHY_11n.hpp:362-398): (a + b) >> 1, wrapping add
+ *   so_sig_demap11n  T11nSigDemap     (demapper11n.hpp:6-87): L-SIG on I, the two HT-SIG symbols on Q (rotated BPSK), 48 carriers each */
+static const int8_t LLTF_K[53] = {   /* L-LTF, carriers -26..26 */
+    1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+    1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
+static inline int lltf_plus(int bin) { const int k = bin < 32 ? bin : bin - 64; return k >= -26 && k <= 26 && LLTF_K[k + 26] == 1; }
+
+/* The rounding term is the reference's, lane for lane: the vector of four |x|^2 >> 1 (one per carrier) is added to vectors that hold
+ * (re, im) pairs, so component c of carrier j of a group of four gets |x[(2j + c) mod 4]|^2 >> 1 (channel_11n.hpp:47-56). */
+static so_c16 siso_one(const so_c16* x4, int j, int bin)
+{
+    int32_t sq = so_sqnorm(x4[j]);
+    if (sq == 0) sq = 1;
+    const int32_t hr = so_sqnorm(x4[(2 * j) & 3]) >> 1, hi = so_sqnorm(x4[(2 * j + 1) & 3]) >> 1;
+    const int32_t re = so_w32(((int64_t)x4[j].re << 16) + hr) / sq, im = so_w32(((int64_t)x4[j].im << 16) + hi) / sq;
+    so_c16 c = so_c(so_sat16(re), so_sat16(im));
+    if (lltf_plus(bin)) c.im = so_neg16(c.im); else c.re = so_neg16(c.re);
+    return c;
+}
+void so_siso_est11n(const so_c16 l0[128], const so_c16 l1[128], so_c16 ch[2][64])
+{
+    const so_c16* l[2] = { l0, l1 };
+    for (int r = 0; r < 2; r++)
+        for (int i = 0; i < 64; i++) {
+            if (i >= 28 && i < 36) { ch[r][i] = so_c(0, 0); continue; }
+            const so_c16 a = siso_one(l[r] + (i & ~3), i & 3, i), b = siso_one(l[r] + 64 + (i & ~3), i & 3, i);
+            ch[r][i] = so_c((int16_t)(so_w16(a.re + b.re) >> 1), (int16_t)(so_w16(a.im + b.im) >> 1));
+        }
+}
+void so_siso_comp11n(const so_c16 ch[2][64], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64])
+{
+    for (int i = 0; i < 64; i++) {
+        int32_t re, im;
+        so_mul32(y0[i], ch[0][i], &re, &im); x0[i] = so_c(so_sat16(re >> 9), so_sat16(im >> 9));
+        so_mul32(y1[i], ch[1][i], &re, &im); x1[i] = so_c(so_sat16(re >> 9), so_sat16(im >> 9));
+    }
+}
+void so_mrc11n(const so_c16 a[64], const so_c16 b[64], so_c16 out[64])
+{
+    for (int i = 0; i < 64; i++) out[i] = so_c((int16_t)(so_w16(a[i].re + b[i].re) >> 1), (int16_t)(so_w16(a[i].im + b[i].im) >> 1));
+}
+void so_sig_demap11n(const so_c16 sym[192], uint8_t soft[144])
+{
+    init11n();
+    int j = 0;
+    for (int s = 0; s < 3; s++)
+        for (int pass = 0; pass < 2; pass++) {
+            const int lo = pass ? 1 : 64 - 26, hi = pass ? 26 : 63;
+            for (int i = lo; i <= hi; i++) {
+                if (i == 64 - 21 || i == 64 - 7 || i == 7 || i == 21) continue;
+                const so_c16 v = sym[64 * s + i];
+                soft[j++] = g_lut[0][lim(s == 0 ? v.re : v.im) + 128];
+            }
+        }
+}

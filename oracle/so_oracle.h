@@ -125,6 +125,10 @@ int16_t so_dsp_atan32(int32_t x, int32_t y);
 int16_t so_cfo_est11n(const so_c16 l0[128], const so_c16 l1[128], int16_t state[24]);
 void so_freq_comp11n(int16_t state[24], const so_c16* in0, const so_c16* in1, so_c16* out0, so_c16* out1, int nbursts);
 void so_pilot_track11n(int16_t theta[8], const so_c16 x0[64], const so_c16 x1[64]);
+void so_siso_est11n(const so_c16 l0[128], const so_c16 l1[128], so_c16 ch[2][64]);
+void so_siso_comp11n(const so_c16 ch[2][64], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
+void so_mrc11n(const so_c16 a[64], const so_c16 b[64], so_c16 out[64]);
+void so_sig_demap11n(const so_c16 sym[192], uint8_t soft[144]);
 void so_mimo_comp11n(const so_c16 hinv[2][128], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
 
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */

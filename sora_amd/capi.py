@@ -48,7 +48,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
 
 _lib = None
 
@@ -116,6 +116,9 @@ def load(build_if_missing=True):
     L.sora_hip_pilot_track11n.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_mimo_est11n.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_mimo_comp11n.argtypes = [ctypes.c_void_p] * 6 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_siso_est11n.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_siso_comp11n.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_sig_demap11n.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
     L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
@@ -423,6 +426,32 @@ def mimo_comp11n(hinv, y0, y1, frame_index=None, stream=None):
     _check(load().sora_hip_mimo_comp11n(_dev_ptr(hinv), _dev_ptr(frame_index) if frame_index is not None else None, _dev_ptr(y0), _dev_ptr(y1),
                                         _dev_ptr(x0), _dev_ptr(x1), y0.shape[0], _stream_ptr(stream)))
     return x0, x1
+
+
+def siso_est11n(lltf0, lltf1, stream=None):
+    """lltf0/lltf1: int16 CUDA tensors [n,128,2] (the two L-LTF symbols of RX chain 0 / 1 after the FFT) -> ch int16 [n,2,64,2]."""
+    import torch
+    n = lltf0.shape[0]
+    ch = torch.empty((n, 2, 64, 2), dtype=torch.int16, device=lltf0.device)
+    _check(load().sora_hip_siso_est11n(_dev_ptr(lltf0), _dev_ptr(lltf1), _dev_ptr(ch), n, _stream_ptr(stream)))
+    return ch
+
+
+def siso_comp11n(ch, y0, y1, frame_index=None, stream=None):
+    """ch: int16 [nframes,2,64,2]; y0/y1: int16 [nsym,64,2] -> (x0, x1, mrc) int16 [nsym,64,2] (TSisoChannelComp then TMrcCombine)."""
+    import torch
+    x0 = torch.empty_like(y0); x1 = torch.empty_like(y1); m = torch.empty_like(y0)
+    _check(load().sora_hip_siso_comp11n(_dev_ptr(ch), _dev_ptr(frame_index) if frame_index is not None else None, _dev_ptr(y0), _dev_ptr(y1),
+                                        _dev_ptr(x0), _dev_ptr(x1), _dev_ptr(m), y0.shape[0], _stream_ptr(stream)))
+    return x0, x1, m
+
+
+def sig_demap11n(sym, stream=None):
+    """sym: int16 [n,3,64,2] (L-SIG, HT-SIG1, HT-SIG2 after MRC) -> soft uint8 [n,144]."""
+    import torch
+    soft = torch.empty((sym.shape[0], 144), dtype=torch.uint8, device=sym.device)
+    _check(load().sora_hip_sig_demap11n(_dev_ptr(sym), _dev_ptr(soft), sym.shape[0], _stream_ptr(stream)))
+    return soft
 
 
 def deinterleave11a(s, n_bpsc, stream=None):

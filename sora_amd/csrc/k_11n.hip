@@ -30,18 +30,21 @@ __device__ __forceinline__ int data_bin(int l)               // carrier walk of 
 }
 }  // namespace
 
+__device__ __forceinline__ void fill_demap_luts(uint8_t (*lut)[256])      // the six step tables of dsp_demap.h, index v + 128; blockDim.x == 256
+{
+    const int t = threadIdx.x;
+    for (int w = 0; w < 6; w++) {
+        int acc = 0; uint8_t val = 0;
+        for (int r = kRunFirst[w]; r < kRunFirst[w + 1]; r++) { if (t >= acc && t < acc + kRuns[r].n) val = kRuns[r].v; acc += kRuns[r].n; }
+        lut[w][t] = val;
+    }
+}
+
 // one wave per symbol, four symbols per block; lane l < 52 = data carrier l
 __global__ void __launch_bounds__(256) k_demap11n_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n)
 {
     __shared__ uint8_t s_lut[6][256];
-    {   // the six step tables, index v + 128
-        const int t = threadIdx.x;
-        for (int w = 0; w < 6; w++) {
-            int acc = 0; uint8_t val = 0;
-            for (int r = kRunFirst[w]; r < kRunFirst[w + 1]; r++) { if (t >= acc && t < acc + kRuns[r].n) val = kRuns[r].v; acc += kRuns[r].n; }
-            s_lut[w][t] = val;
-        }
-    }
+    fill_demap_luts(s_lut);
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const uint32_t sym = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -137,6 +140,68 @@ __global__ void __launch_bounds__(256) k_mimo_comp11n_batch(const uint32_t* hinv
     x0[(size_t)sidx * 64 + i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
     mul32(unpack(hi[128 + i]), a, ar, ai); mul32(unpack(hi[192 + i]), b, br, bi);
     x1[(size_t)sidx * 64 + i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+}
+
+// ---- TSisoChannelEst (channel_11n.hpp:33-231): one thread per (frame, RX chain, carrier).  The rounding term is added lane for lane as
+// the reference's vectors line up: component c of carrier j of a group of four gets |x[(2j + c) mod 4]|^2 >> 1.
+namespace {
+__constant__ unsigned long long kLLtfPlus = 0xF59FACC007A982B2ull;     // bit i: the L-LTF is +1 on FFT bin i (_80211_LLTFMask 0xFFFF0000 lanes)
+__device__ __forceinline__ int sqn_wrap(cpx v) { return (int)((unsigned)(v.re * v.re) + (unsigned)(v.im * v.im)); }
+__device__ __forceinline__ cpx siso_one(const uint32_t* x4, int j, int bin)
+{
+    const cpx x = unpack(x4[j]), xr = unpack(x4[(2 * j) & 3]), xi = unpack(x4[(2 * j + 1) & 3]);
+    int sq = sqn_wrap(x);                                                  // pmaddwd: (-32768, -32768) wraps to INT_MIN
+    if (sq == 0) sq = 1;
+    const int hr = sqn_wrap(xr) >> 1, hi = sqn_wrap(xi) >> 1;
+    const int re = (int)(((unsigned)x.re << 16) + (unsigned)hr) / sq, im = (int)(((unsigned)x.im << 16) + (unsigned)hi) / sq;
+    cpx c = mk(sat16(re), sat16(im));
+    if ((kLLtfPlus >> bin) & 1) c.im = (short)-c.im; else c.re = (short)-c.re;
+    return c;
+}
+}  // namespace
+__global__ void __launch_bounds__(256) k_siso_est11n_batch(const uint32_t* l0, const uint32_t* l1, uint32_t* ch, uint32_t nframes)
+{
+    const uint32_t f = blockIdx.x * 2 + (threadIdx.x >> 7); const int r = (threadIdx.x >> 6) & 1, i = threadIdx.x & 63;
+    if (f >= nframes) return;
+    uint32_t out = 0;
+    if (i < 28 || i >= 36) {
+        const uint32_t* l = (r ? l1 : l0) + (size_t)f * 128 + (i & ~3);
+        const cpx a = siso_one(l, i & 3, i), b = siso_one(l + 64, i & 3, i);
+        out = pack(mk((short)((short)(a.re + b.re) >> 1), (short)((short)(a.im + b.im) >> 1)));
+    }
+    ch[(size_t)f * 128 + r * 64 + i] = out;
+}
+
+// ---- TSisoChannelComp (channel_11n.hpp:233-297) + TMrcCombine (PHY_11n.hpp:362-398): x_r = sat((y_r * c_r) >> 9), mrc = (x_0 + x_1) >> 1
+__global__ void __launch_bounds__(256) k_siso_comp11n_batch(const uint32_t* ch, const uint32_t* frame_index, const uint32_t* y0, const uint32_t* y1,
+                                                            uint32_t* x0, uint32_t* x1, uint32_t* mrc, uint32_t nsym)
+{
+    const uint32_t sidx = blockIdx.x * 4 + (threadIdx.x >> 6); const int i = threadIdx.x & 63;
+    if (sidx >= nsym) return;
+    const uint32_t* c = ch + (size_t)(frame_index ? frame_index[sidx] : 0u) * 128;
+    int re, im;
+    mul32(unpack(y0[(size_t)sidx * 64 + i]), unpack(c[i]), re, im);      const cpx a = mk(sat16(re >> 9), sat16(im >> 9));
+    mul32(unpack(y1[(size_t)sidx * 64 + i]), unpack(c[64 + i]), re, im); const cpx b = mk(sat16(re >> 9), sat16(im >> 9));
+    if (x0) x0[(size_t)sidx * 64 + i] = pack(a);
+    if (x1) x1[(size_t)sidx * 64 + i] = pack(b);
+    if (mrc) mrc[(size_t)sidx * 64 + i] = pack(mk((short)((short)(a.re + b.re) >> 1), (short)((short)(a.im + b.im) >> 1)));
+}
+
+// ---- T11nSigDemap (demapper11n.hpp:6-87): three symbols per frame, L-SIG on I, HT-SIG 1/2 on Q; one wave per symbol, lane < 48 = carrier
+__global__ void __launch_bounds__(256) k_sig_demap11n_batch(const uint32_t* sym, uint8_t* soft, uint32_t nframes)
+{
+    __shared__ uint8_t s_lut[6][256];
+    fill_demap_luts(s_lut);
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const uint32_t g = blockIdx.x * 4 + (threadIdx.x >> 6);                  // symbol number = 3 * frame + s
+    if (g >= nframes * 3u || lane >= 48) return;
+    const int s = (int)(g % 3u);
+    int bin;                                                                 // carriers -26..-1 then 1..26 without the pilots
+    if (lane < 24) bin = 38 + lane + (lane >= 5) + (lane >= 18); else { const int m = lane - 24; bin = 1 + m + (m >= 6) + (m >= 19); }
+    const cpx v = unpack(sym[(size_t)g * 64 + bin]);
+    const int q = s == 0 ? v.re : v.im;
+    soft[(size_t)g * 48 + lane] = s_lut[0][min(max(q, -128), 127) + 128];
 }
 
 // ---- dsp_math (Brick11/src/dsp_math.h:96-213): arctangent through a 4097-entry table, exactly as the reference indexes it
@@ -364,4 +429,35 @@ int sora_hip_pilot_track11n(const sora_complex16* d_x0, const sora_complex16* d_
     hipLaunchKernelGGL(k_pilot_track11n_batch, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_x0),
                        reinterpret_cast<const uint32_t*>(d_x1), d_first, d_nsym, d_state, d_theta, (uint32_t)nframes, T->atan);
     return launch_result("k_pilot_track11n_batch");
+}
+
+int sora_hip_siso_est11n(const sora_complex16* d_lltf0, const sora_complex16* d_lltf1, sora_complex16* d_ch, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_lltf0 || !d_lltf1 || !d_ch) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_siso_est11n: null argument", 0);
+    if (nframes == 0) return SORA_OK;
+    hipLaunchKernelGGL(k_siso_est11n_batch, dim3((unsigned)((nframes + 1) / 2)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_lltf0),
+                       reinterpret_cast<const uint32_t*>(d_lltf1), reinterpret_cast<uint32_t*>(d_ch), (uint32_t)nframes);
+    return launch_result("k_siso_est11n_batch");
+}
+
+int sora_hip_siso_comp11n(const sora_complex16* d_ch, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
+                          sora_complex16* d_x0, sora_complex16* d_x1, sora_complex16* d_mrc, size_t nsym, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_ch || !d_y0 || !d_y1 || !(d_x0 || d_x1 || d_mrc)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_siso_comp11n: null argument", 0);
+    if (nsym == 0) return SORA_OK;
+    hipLaunchKernelGGL(k_siso_comp11n_batch, dim3((unsigned)((nsym + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_ch), d_frame_index,
+                       reinterpret_cast<const uint32_t*>(d_y0), reinterpret_cast<const uint32_t*>(d_y1), reinterpret_cast<uint32_t*>(d_x0),
+                       reinterpret_cast<uint32_t*>(d_x1), reinterpret_cast<uint32_t*>(d_mrc), (uint32_t)nsym);
+    return launch_result("k_siso_comp11n_batch");
+}
+
+int sora_hip_sig_demap11n(const sora_complex16* d_sym, uint8_t* d_soft, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_sym || !d_soft) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_sig_demap11n: null argument", 0);
+    if (nframes == 0) return SORA_OK;
+    hipLaunchKernelGGL(k_sig_demap11n_batch, dim3((unsigned)((nframes * 3 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_sym), d_soft, (uint32_t)nframes);
+    return launch_result("k_sig_demap11n_batch");
 }

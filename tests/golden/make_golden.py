@@ -164,6 +164,17 @@ def main():
     for a, b in zip(px0, px1):
         th = G.pilot_track11n(th, a, b); ths.append(th.copy())
     n11["pt_x0"] = px0; n11["pt_x1"] = px1; n11["pt_theta"] = np.stack(ths)
+    # the legacy part of the preamble: TSisoChannelEst, TSisoChannelComp -> TMrcCombine, T11nSigDemap
+    sl0 = np.stack([rng.integers(-a, a + 1, size=(128, 2)) for a in (20, 300, 3000, 32767) for _ in range(3)]).astype(np.int16)
+    sl1 = np.stack([rng.integers(-a, a + 1, size=(128, 2)) for a in (20, 300, 3000, 32767) for _ in range(3)]).astype(np.int16)
+    sl0[0, 3] = 0; sl0[0, 67] = 0; sl1[4, 9] = (-32768, -32768); sl0[5, 70] = (32767, -32768)
+    sch = np.stack([G.siso_est11n(a, b) for a, b in zip(sl0, sl1)])
+    sy0 = rng.integers(-3000, 3001, size=(len(sl0), 64, 2)).astype(np.int16); sy1 = rng.integers(-3000, 3001, size=(len(sl0), 64, 2)).astype(np.int16)
+    sc = [G.siso_comp11n(c, a, b) for c, a, b in zip(sch, sy0, sy1)]
+    n11["siso_l0"] = sl0; n11["siso_l1"] = sl1; n11["siso_ch"] = sch; n11["siso_y0"] = sy0; n11["siso_y1"] = sy1
+    n11["siso_x0"] = np.stack([c[0] for c in sc]); n11["siso_x1"] = np.stack([c[1] for c in sc]); n11["siso_mrc"] = np.stack([c[2] for c in sc])
+    sig = rng.integers(-300, 301, size=(10, 3, 64, 2)).astype(np.int16)
+    n11["sig_sym"] = sig; n11["sig_soft"] = np.stack([G.sig_demap11n(x) for x in sig])
     np.savez_compressed(os.path.join(OUT, "ref_vectors_11n.npz"), **n11)
     print("written", os.listdir(OUT))
 

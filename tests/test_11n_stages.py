@@ -83,6 +83,66 @@ def test_oracle_phase_bricks(o):
     assert len(set(z["cfo_state"][:, 1].tolist())) > 4                     # the recorded offsets really differ
 
 
+def test_oracle_legacy_preamble_bricks(o):
+    """TSisoChannelEst, TSisoChannelComp -> TMrcCombine, T11nSigDemap against recorded reference-brick output, and live where oracle/_ref exists."""
+    z = np.load(GOLD)
+    for i in range(len(z["siso_l0"])):
+        assert np.array_equal(o.siso_est11n(z["siso_l0"][i], z["siso_l1"][i]), z["siso_ch"][i]), i
+        x0, x1, m = o.siso_comp11n(z["siso_ch"][i], z["siso_y0"][i], z["siso_y1"][i])
+        assert np.array_equal(x0, z["siso_x0"][i]) and np.array_equal(x1, z["siso_x1"][i]) and np.array_equal(m, z["siso_mrc"][i]), i
+    for x, want in zip(z["sig_sym"], z["sig_soft"]):
+        assert np.array_equal(o.sig_demap11n(x), want)
+    assert z["siso_ch"].any() and len(np.unique(z["sig_soft"])) == 8
+    g = ReferenceGraph()
+    if not g.available():
+        return
+    rng = np.random.default_rng(77)
+    for t in range(300):
+        amp = (20, 300, 3000, 32767)[t % 4]
+        l0 = rng.integers(-amp, amp + 1, size=(128, 2)).astype(np.int16); l1 = rng.integers(-amp, amp + 1, size=(128, 2)).astype(np.int16)
+        ch = g.siso_est11n(l0, l1)
+        assert np.array_equal(o.siso_est11n(l0, l1), ch), t
+        y0 = rng.integers(-amp, amp + 1, size=(64, 2)).astype(np.int16); y1 = rng.integers(-amp, amp + 1, size=(64, 2)).astype(np.int16)
+        c = ch if t % 2 else rng.integers(-amp, amp + 1, size=(2, 64, 2)).astype(np.int16)
+        assert all(np.array_equal(a, b) for a, b in zip(o.siso_comp11n(c, y0, y1), g.siso_comp11n(c, y0, y1))), t
+        s3 = rng.integers(-min(amp, 400), min(amp, 400) + 1, size=(3, 64, 2)).astype(np.int16)
+        assert np.array_equal(o.sig_demap11n(s3), g.sig_demap11n(s3)), t
+
+
+@pytest.mark.gpu
+def test_gpu_legacy_preamble_stage_kernels(o):
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    z = np.load(GOLD)
+    ch = sora_amd.siso_est11n(torch.from_numpy(z["siso_l0"]).cuda(), torch.from_numpy(z["siso_l1"]).cuda())
+    assert np.array_equal(ch.cpu().numpy(), z["siso_ch"]), np.argwhere(ch.cpu().numpy() != z["siso_ch"])[:8].tolist()
+    n = len(z["siso_y0"])
+    x0, x1, m = sora_amd.siso_comp11n(ch, torch.from_numpy(z["siso_y0"]).cuda(), torch.from_numpy(z["siso_y1"]).cuda(),
+                                      frame_index=torch.arange(n, dtype=torch.int32).cuda())
+    assert np.array_equal(x0.cpu().numpy(), z["siso_x0"]) and np.array_equal(x1.cpu().numpy(), z["siso_x1"]) and np.array_equal(m.cpu().numpy(), z["siso_mrc"])
+    assert np.array_equal(sora_amd.sig_demap11n(torch.from_numpy(z["sig_sym"]).cuda()).cpu().numpy(), z["sig_soft"])
+    rng = np.random.default_rng(13)
+    nf = 501                                                             # odd: the last block is half empty
+    l0 = rng.integers(-32767, 32768, size=(nf, 128, 2)).astype(np.int16); l1 = rng.integers(-300, 301, size=(nf, 128, 2)).astype(np.int16)
+    l0[7] = 0; l1[9, 5] = (-32768, -32768)
+    ch = sora_amd.siso_est11n(torch.from_numpy(l0).cuda(), torch.from_numpy(l1).cuda())
+    chn = ch.cpu().numpy()
+    for f in range(nf):
+        assert np.array_equal(chn[f], o.siso_est11n(l0[f], l1[f])), f
+    ns = 1003; fi = rng.integers(0, nf, size=ns).astype(np.int32)
+    y0 = rng.integers(-32767, 32768, size=(ns, 64, 2)).astype(np.int16); y1 = rng.integers(-2000, 2001, size=(ns, 64, 2)).astype(np.int16)
+    x0, x1, m = (t.cpu().numpy() for t in sora_amd.siso_comp11n(ch, torch.from_numpy(y0).cuda(), torch.from_numpy(y1).cuda(), frame_index=torch.from_numpy(fi).cuda()))
+    for s_ in range(ns):
+        w = o.siso_comp11n(chn[fi[s_]], y0[s_], y1[s_])
+        assert np.array_equal(x0[s_], w[0]) and np.array_equal(x1[s_], w[1]) and np.array_equal(m[s_], w[2]), s_
+    sig = rng.integers(-400, 401, size=(333, 3, 64, 2)).astype(np.int16)
+    soft = sora_amd.sig_demap11n(torch.from_numpy(sig).cuda()).cpu().numpy()
+    for f in range(len(sig)):
+        assert np.array_equal(soft[f], o.sig_demap11n(sig[f])), f
+
+
 @pytest.mark.gpu
 def test_gpu_phase_stage_kernels(o):
     import torch
