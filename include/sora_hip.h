@@ -224,6 +224,12 @@ int sora_hip_siso_est11n(const sora_complex16* d_lltf0, const sora_complex16* d_
 int sora_hip_siso_comp11n(const sora_complex16* d_ch, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
                           sora_complex16* d_x0, sora_complex16* d_x1, sora_complex16* d_mrc, size_t nsym, void* stream);
 int sora_hip_sig_demap11n(const sora_complex16* d_sym, uint8_t* d_soft, size_t nframes, void* stream);
+/* sora_hip_sig_decode11n  T11aDeinterleaveBPSK x3 -> T11nViterbiSig (viterbi.hpp:51-99) -> T11nSigParser (PHY_11n.hpp:432-513):
+ *                        d_soft[f][144] (sora_hip_sig_demap11n's output) -> d_rec[f][12] = error_code (0 or SORA_E_PLCP_HEADER_FAIL),
+ *                        data_rate_kbps, frame_length, ht_frame_mcs, ht_frame_length, code_rate, total_symbols, remain_symbols,
+ *                        symbol_type (the context fields, from 0, as the parser leaves them -- partial on a failed parse),
+ *                        then the decoded L-SIG (24 bits) and HT-SIG (bits 0..31, bits 32..41). */
+int sora_hip_sig_decode11n(const uint8_t* d_soft, uint32_t* d_rec, size_t nframes, void* stream);
 int sora_hip_mimo_est11n(const sora_complex16* d_ltf0, const sora_complex16* d_ltf1, sora_complex16* d_h, sora_complex16* d_hinv, size_t nframes, void* stream);
 int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_index, const sora_complex16* d_y0, const sora_complex16* d_y1,
                           sora_complex16* d_x0, sora_complex16* d_x1, size_t nsym, void* stream);

@@ -204,6 +204,12 @@ class Oracle:
         a = np.ascontiguousarray(sym3, np.int16).reshape(192, 2); o = np.zeros(144, np.uint8)
         self.L.so_sig_demap11n(_P(a), _P(o)); return o
 
+    def sig_decode11n(self, soft144):
+        """T11aDeinterleaveBPSK x3 -> T11nViterbiSig -> T11nSigParser -> (ok, out9 bytes, fields uint32[9])"""
+        a = np.ascontiguousarray(soft144, np.uint8); o9 = np.zeros(9, np.uint8); f = np.zeros(9, np.uint32)
+        assert a.size == 144
+        ok = self.L.so_sig_decode11n(_P(a), _P(o9), _P(f)); return ok, o9, f
+
     def rx11b_capture(self, iq44, max_frames=16):
         """802.11b receive graph over int16 [n,2] @44 MHz -> list of dict (end_sample = 44 MHz source position)."""
         iq = np.ascontiguousarray(iq44, np.int16).reshape(-1, 2)
@@ -396,6 +402,12 @@ class ReferenceGraph:
     def sig_demap11n(self, sym3):
         a = np.ascontiguousarray(sym3, np.int16).reshape(192, 2); o = np.zeros(144, np.uint8)
         self.L.ref_11n_sig_demap(_P(a), _P(o)); return o
+
+    def sig_decode11n(self, soft144):
+        """the same three bricks of the reference, one burst; the parser's context fields are zeroed first"""
+        a = np.ascontiguousarray(soft144, np.uint8); o9 = np.zeros(9, np.uint8); f = np.zeros(9, np.uint32)
+        assert a.size == 144
+        ok = self.L.ref_11n_sig_decode(_P(a), _P(o9), _P(f)); return ok, o9, f
 
     def tx11n(self, mpdu_nofcs, mcs):
         """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""

@@ -450,3 +450,24 @@ EXPORT void ref_11n_sig_demap(const int16_t* sym3, uint8_t* soft144)
     A16 COMPLEX16 x[192]; memcpy(x, sym3, sizeof(x));
     run_brick_once<T11nSigDemap, 192, COMPLEX16, 144>(x, soft144);
 }
+
+// T11aDeinterleaveBPSK x3 -> T11nViterbiSig (viterbi.hpp:51-99) -> T11nSigParser (PHY_11n.hpp:400-514) on the 144 soft values of
+// one frame's L-SIG + HT-SIG.  The context fields the parser writes are zeroed first; fields[] = error_code, data_rate_kbps,
+// frame_length, ht_frame_mcs, ht_frame_length, code_rate, total_symbols, remain_symbols, symbol_type.  Returns the parser's verdict.
+EXPORT int ref_11n_sig_decode(const uint8_t* soft144, uint8_t* out9, uint32_t* fields)
+{
+    uint8_t di[144];
+    for (int s = 0; s < 3; s++) run_brick_once<T11aDeinterleaveBPSK, 48, uchar, 48>(soft144 + 48 * s, di + 48 * s);
+    run_brick_once<T11nViterbiSig, 144, uchar, 9>(di, out9);
+    static T11nSigParser<BB11nDemodContext>* parser = new T11nSigParser<BB11nDemodContext>(BB11nDemodCtx);
+    BB11nDemodContext& c = BB11nDemodCtx;
+    c.CF_Error::error_code() = 0; c.CF_11aRxVector::data_rate_kbps() = 0; c.CF_11aRxVector::frame_length() = 0;
+    c.CF_HTRxVector::ht_frame_mcs() = 0; c.CF_HTRxVector::ht_frame_length() = 0; c.CF_11aRxVector::code_rate() = 0;
+    c.CF_11aRxVector::total_symbols() = 0; c.CF_11aRxVector::remain_symbols() = 0; c.CF_11nSymState::symbol_type() = 0;
+    OneBurstPin<uchar, 9> pin = { out9, true };
+    const bool ok = parser->Process(pin);
+    fields[0] = c.CF_Error::error_code(); fields[1] = c.CF_11aRxVector::data_rate_kbps(); fields[2] = c.CF_11aRxVector::frame_length();
+    fields[3] = c.CF_HTRxVector::ht_frame_mcs(); fields[4] = c.CF_HTRxVector::ht_frame_length(); fields[5] = c.CF_11aRxVector::code_rate();
+    fields[6] = c.CF_11aRxVector::total_symbols(); fields[7] = c.CF_11aRxVector::remain_symbols(); fields[8] = c.CF_11nSymState::symbol_type();
+    return ok ? 1 : 0;
+}

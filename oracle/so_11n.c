@@ -305,3 +305,58 @@ void so_sig_demap11n(const so_c16 sym[192], uint8_t soft[144])
             }
         }
 }
+
+/* ------------------------------------------------------------------ L-SIG / HT-SIG decoding
+ * T11aDeinterleaveBPSK on each of the three symbols -> T11nViterbiSig (viterbi.hpp:51-99: Viterbi_sig11 over 24 and over 48 trellis
+ * steps, each >> 6 to drop the zero prefix; 3 + 6 output bytes) -> T11nSigParser (PHY_11n.hpp:432-513).  The parser's context fields
+ * start at 0 and are written exactly where the reference writes them, so a failed parse reports the same partial state. */
+static uint8_t crc8_htsig(const uint8_t* p)                                 /* CalcCRC8(p, 4, 2) (core/inc/CRC8.h): reflected, poly 0xE0 */
+{
+    uint8_t crc = 0xFF;
+    for (int i = 0; i < 4; i++) { crc ^= p[i]; for (int b = 0; b < 8; b++) crc = (crc & 1) ? (uint8_t)((crc >> 1) ^ 0xE0) : (uint8_t)(crc >> 1); }
+    crc ^= p[4] & 3;
+    for (int b = 0; b < 2; b++) crc = (crc & 1) ? (uint8_t)((crc >> 1) ^ 0xE0) : (uint8_t)(crc >> 1);
+    return (uint8_t)~crc;
+}
+int so_sig_decode11n(const uint8_t soft[144], uint8_t out9[9], uint32_t f[9])
+{
+    static const uint32_t rate[16] = { 0,0,0,0,0,0,0,0, 48000,24000,12000,6000,54000,36000,18000,9000 };   /* ieee80211a_cmn.h:97-107 */
+    static const int ndbps[3] = { 52, 104, 156 };                            /* DOT11N_RATE_PARAMS[8..10] (ieee80211const.h:46-49) */
+    uint8_t di[144], b[8];
+    for (int s = 0; s < 3; s++) so_deinterleave(1, soft + 48 * s, di + 48 * s);
+    so_viterbi_sig_bits(di, 24, b);
+    const uint32_t lsig = ((uint32_t)b[0] | (uint32_t)b[1] << 8 | (uint32_t)b[2] << 16) >> 6;
+    so_viterbi_sig_bits(di + 48, 48, b);
+    uint64_t ht = 0; for (int i = 0; i < 6; i++) ht |= (uint64_t)b[i] << (8 * i);
+    ht >>= 6;
+    out9[0] = (uint8_t)lsig; out9[1] = (uint8_t)(lsig >> 8); out9[2] = (uint8_t)(lsig >> 16);
+    for (int i = 0; i < 6; i++) out9[3 + i] = (uint8_t)(ht >> (8 * i));
+    memset(f, 0, 9 * sizeof(uint32_t));
+    const uint8_t* ip = out9 + 3;
+    int ok = 0;
+    do {
+        /* _parse_plcp on the 32-bit read of bytes 0..3 (byte 3 = HT-SIG byte 0 is masked off) */
+        const uint32_t sig = lsig & 0xFFFFFF;
+        if (sig & 0xFC0010) break;
+        uint32_t par = (sig >> 16) ^ sig; par ^= par >> 8; par ^= par >> 4; par ^= par >> 2; par ^= par >> 1;
+        if (par & 1) break;
+        f[1] = rate[sig & 0xF];
+        if (f[1] == 0) break;
+        f[2] = ((sig >> 5) & 0xFFF) * 2;
+        if (f[2] > 1500) break;
+        /* _parse_htsig: the comparison is made in int, so any of the six tail bits set (ip[5] >> 2) fails it */
+        if ((int)crc8_htsig(ip) != ((ip[4] >> 2) | (ip[5] << 6))) break;        /* mcs and length stay 0 */
+        f[3] = ip[0] & 0x7F;
+        if (f[3] < 8 || f[3] >= 11) break;
+        f[4] = (uint32_t)ip[1] | (uint32_t)ip[2] << 8;
+        if (f[4] > 1500) break;
+        f[5] = (f[3] % 8 == 2) ? SO_CR_34 : SO_CR_12;                        /* BB11nGetCodingRateFromMcsIndex for MCS 8..10 */
+        const int bits = (int)f[4] * 8 + 16 + 6, nd = ndbps[f[3] - 8];
+        f[6] = f[7] = (uint32_t)((bits + nd - 1) / nd + 4);
+        f[2] = f[4];                                                         /* frame_length = ht_frame_length */
+        f[8] = 3;                                                            /* SYMBOL_HT_STF, checked against the brick below */
+        ok = 1;
+    } while (0);
+    if (!ok) f[0] = SO_E_PLCP_HEADER_FAIL;
+    return ok;
+}

@@ -129,6 +129,9 @@ void so_siso_est11n(const so_c16 l0[128], const so_c16 l1[128], so_c16 ch[2][64]
 void so_siso_comp11n(const so_c16 ch[2][64], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
 void so_mrc11n(const so_c16 a[64], const so_c16 b[64], so_c16 out[64]);
 void so_sig_demap11n(const so_c16 sym[192], uint8_t soft[144]);
+void so_viterbi_sig_bits(const uint8_t* soft, int nbits, uint8_t* out);
+/* fields[9] = error_code, data_rate_kbps, frame_length, ht_frame_mcs, ht_frame_length, code_rate, total_symbols, remain_symbols, symbol_type */
+int so_sig_decode11n(const uint8_t soft[144], uint8_t out9[9], uint32_t fields[9]);
 void so_mimo_comp11n(const so_c16 hinv[2][128], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
 
 /* RX_BLOCK dump de-framing (brick/inc/brickutil.h:20-58); raw14: apply the (int16)(x<<2) sign fix. */

@@ -263,6 +263,22 @@ uint32_t so_viterbi_sig(const uint8_t soft48[48])                      /* Viterb
     return v >> 6;
 }
 
+/* Viterbi_sig11 with its output_bit argument (viterbicore.h:36): nbits = 24 or 48 trellis steps from 2*nbits soft values, the 6-bit
+ * zero prefix still in place; out receives nbits/8 bytes.  T11nViterbiSig (viterbi.hpp:82-90) uses it for L-SIG (24) and HT-SIG (48). */
+void so_viterbi_sig_bits(const uint8_t* soft, int nbits, uint8_t* out)
+{
+    vit_init();
+    uint8_t m[64]; uint64_t dec[50];
+    vit_reset(m);
+    dec[0] = 0; for (int n = 0; n < 64; n++) dec[0] |= (uint64_t)(m[n] & 1) << n;
+    for (int t = 1; t <= nbits; t++) {
+        dec[t] = acs(m, 0, soft[2 * (t - 1)], soft[2 * (t - 1) + 1]);
+        if ((t & 7) == 0) normalize(m);
+    }
+    normalize(m);
+    traceback(dec, (uint32_t)nbits, m, out, (uint32_t)nbits, 0);
+}
+
 int so_viterbi_frame(const uint8_t* soft, uint32_t nsoft, int code_rate, uint32_t frame_length, uint8_t* out)
 {
     /* T11aViterbi<5000*8,48,256,24>::Filter::Process (viterbi.hpp:148-235) */

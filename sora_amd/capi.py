@@ -48,7 +48,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
 
 _lib = None
 
@@ -119,6 +119,7 @@ def load(build_if_missing=True):
     L.sora_hip_siso_est11n.argtypes = [ctypes.c_void_p] * 3 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_siso_comp11n.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_sig_demap11n.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_sig_decode11n.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
     L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
@@ -452,6 +453,15 @@ def sig_demap11n(sym, stream=None):
     soft = torch.empty((sym.shape[0], 144), dtype=torch.uint8, device=sym.device)
     _check(load().sora_hip_sig_demap11n(_dev_ptr(sym), _dev_ptr(soft), sym.shape[0], _stream_ptr(stream)))
     return soft
+
+
+def sig_decode11n(soft, stream=None):
+    """soft: uint8 [n,144] (sig_demap11n's output) -> int32 [n,12]: error_code, data_rate_kbps, frame_length, ht_frame_mcs, ht_frame_length,
+    code_rate, total_symbols, remain_symbols, symbol_type, L-SIG, HT-SIG bits 0..31, HT-SIG bits 32..41."""
+    import torch
+    rec = torch.empty((soft.shape[0], 12), dtype=torch.int32, device=soft.device)
+    _check(load().sora_hip_sig_decode11n(_dev_ptr(soft), _dev_ptr(rec), soft.shape[0], _stream_ptr(stream)))
+    return rec
 
 
 def deinterleave11a(s, n_bpsc, stream=None):

@@ -204,6 +204,90 @@ __global__ void __launch_bounds__(256) k_sig_demap11n_batch(const uint32_t* sym,
     soft[(size_t)g * 48 + lane] = s_lut[0][min(max(q, -128), 127) + 128];
 }
 
+// ---- T11aDeinterleaveBPSK x3 -> T11nViterbiSig (viterbi.hpp:51-99) -> T11nSigParser (PHY_11n.hpp:432-513): one wave per frame,
+// lane = trellis state (Viterbi_sig11, viterbicore.h:36-261, over NB = 24 and NB = 48 steps)
+namespace {
+template <int NB>
+__device__ __forceinline__ uint64_t viterbi_sig_wave(const uint8_t* soft, uint64_t* dec, int lane)     // soft[2 * NB] de-interleaved, dec[NB + 1] in LDS
+{
+    const int n = lane, r0 = n, r1 = 64 | n;
+    const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1, cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
+    unsigned m = (n == 0) ? 0u : 0x30u;
+    if (lane == 0) dec[0] = 0;
+#pragma unroll 8
+    for (int t = 1; t <= NB; t++) {
+        const int va = soft[2 * (t - 1)], vb = soft[2 * (t - 1) + 1];
+        const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
+        const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
+        const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
+        const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
+        m = min(c0, c1);
+        { const uint64_t d = __ballot(m & 1); if (lane == 0) dec[t] = d; }
+        if ((t & 7) == 0) {
+            unsigned mn = m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+            m = (m - (mn & 0xFE)) & 0xFF;
+        }
+    }
+    unsigned kmin = (m << 8) | ((unsigned)n << 2);                           // smallest metric, then smallest state (INDEXES, hmin)
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+    int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+    uint64_t out = 0;
+    for (int b = 0; b < NB; b++) {                                           // bit b of the walk is output bit NB - 1 - b
+        out |= (uint64_t)((pos >> 6) & 1) << (NB - 1 - b);
+        pos = (pos >> 1) & 0x3F;
+        pos |= (int)((dec[NB - 1 - b] >> pos) & 1) << 6;
+    }
+    return out;
+}
+}  // namespace
+__global__ void __launch_bounds__(256) k_sig_decode11n_batch(const uint8_t* soft, uint32_t* rec, uint32_t nframes)
+{
+    __shared__ uint8_t s_soft[4][144];
+    __shared__ uint64_t s_dec[4][50];
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const uint32_t f = blockIdx.x * 4 + w;
+    if (f >= nframes) return;                                                // whole waves leave; no block-wide barrier below
+    for (int k = lane; k < 144; k += 64) { const int s3 = k / 48, kk = k - 48 * s3; s_soft[w][k] = soft[(size_t)f * 144 + 48 * s3 + 3 * (kk & 15) + (kk >> 4)]; }
+    __builtin_amdgcn_s_waitcnt(0); __builtin_amdgcn_wave_barrier();
+    const uint32_t lsig = (uint32_t)(viterbi_sig_wave<24>(s_soft[w], s_dec[w], lane) >> 6);
+    __builtin_amdgcn_wave_barrier();
+    const uint64_t ht = viterbi_sig_wave<48>(s_soft[w] + 48, s_dec[w], lane) >> 6;
+    if (lane != 0) return;
+    uint32_t fl[9] = { 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+    bool ok = false;
+    do {
+        const uint32_t sig = lsig & 0xFFFFFF;
+        if (sig & 0xFC0010) break;
+        if (__popc(sig) & 1) break;
+        const uint32_t code = sig & 0xF;                                     // ieee80211a_cmn.h:97-107
+        fl[1] = code == 0x8 ? 48000u : code == 0x9 ? 24000u : code == 0xA ? 12000u : code == 0xB ? 6000u : code == 0xC ? 54000u
+              : code == 0xD ? 36000u : code == 0xE ? 18000u : code == 0xF ? 9000u : 0u;
+        if (fl[1] == 0) break;
+        fl[2] = ((sig >> 5) & 0xFFF) * 2;
+        if (fl[2] > 1500) break;
+        uint32_t crc = 0xFF;                                                 // CalcCRC8(ip, 4, 2): reflected, polynomial 0xE0, over HT-SIG bits 0..33
+        for (int b = 0; b < 34; b++) { crc ^= (uint32_t)(ht >> b) & 1; crc = (crc & 1) ? (crc >> 1) ^ 0xE0 : crc >> 1; }
+        if (((~crc) & 0xFF) != (uint32_t)((ht >> 34) & 0x3FFF)) break;      // compared in int: bits 42.. (always 0 after the >> 6) included
+        fl[3] = (uint32_t)ht & 0x7F;
+        if (fl[3] < 8 || fl[3] >= 11) break;
+        fl[4] = (uint32_t)(ht >> 8) & 0xFFFF;
+        if (fl[4] > 1500) break;
+        fl[5] = fl[3] == 10 ? 2u : 0u;                                       // CR_34 : CR_12
+        const uint32_t nd = 52u * (fl[3] - 7);                               // DOT11N_RATE_PARAMS[8..10].ndbps
+        fl[6] = fl[7] = (fl[4] * 8 + 22 + nd - 1) / nd + 4;
+        fl[2] = fl[4]; fl[8] = 3;                                            // frame_length = ht_frame_length; SYMBOL_HT_STF
+        ok = true;
+    } while (0);
+    if (!ok) fl[0] = 0x80000005u;                                            // E_ERROR_PLCP_HEADER_FAIL
+    uint32_t* o = rec + (size_t)f * 12;
+    for (int i = 0; i < 9; i++) o[i] = fl[i];
+    o[9] = lsig & 0xFFFFFF; o[10] = (uint32_t)ht; o[11] = (uint32_t)(ht >> 32);
+}
+
 // ---- dsp_math (Brick11/src/dsp_math.h:96-213): arctangent through a 4097-entry table, exactly as the reference indexes it
 namespace {
 __device__ __forceinline__ int atan_tail(const short* tab, int idx, int tsign, int sign)
@@ -460,4 +544,13 @@ int sora_hip_sig_demap11n(const sora_complex16* d_sym, uint8_t* d_soft, size_t n
     if (nframes == 0) return SORA_OK;
     hipLaunchKernelGGL(k_sig_demap11n_batch, dim3((unsigned)((nframes * 3 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_sym), d_soft, (uint32_t)nframes);
     return launch_result("k_sig_demap11n_batch");
+}
+
+int sora_hip_sig_decode11n(const uint8_t* d_soft, uint32_t* d_rec, size_t nframes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (!d_soft || !d_rec) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_sig_decode11n: null argument", 0);
+    if (nframes == 0) return SORA_OK;
+    hipLaunchKernelGGL(k_sig_decode11n_batch, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, d_soft, d_rec, (uint32_t)nframes);
+    return launch_result("k_sig_decode11n_batch");
 }

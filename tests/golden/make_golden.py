@@ -175,6 +175,12 @@ def main():
     n11["siso_x0"] = np.stack([c[0] for c in sc]); n11["siso_x1"] = np.stack([c[1] for c in sc]); n11["siso_mrc"] = np.stack([c[2] for c in sc])
     sig = rng.integers(-300, 301, size=(10, 3, 64, 2)).astype(np.int16)
     n11["sig_sym"] = sig; n11["sig_soft"] = np.stack([G.sig_demap11n(x) for x in sig])
+    # T11aDeinterleaveBPSK x3 -> T11nViterbiSig -> T11nSigParser
+    from gpu_util import htsig_cases
+    hs = htsig_cases(2024, 120)
+    dec = [G.sig_decode11n(x) for x in hs]
+    n11["sigdec_soft"] = hs; n11["sigdec_ok"] = np.array([d[0] for d in dec], np.int32)
+    n11["sigdec_bytes"] = np.stack([d[1] for d in dec]); n11["sigdec_fields"] = np.stack([d[2] for d in dec])
     np.savez_compressed(os.path.join(OUT, "ref_vectors_11n.npz"), **n11)
     print("written", os.listdir(OUT))
 

@@ -192,3 +192,49 @@ def same_as_reference_11b(rows, ref_events):
             if (x["rate_kbps"], x["length"], x["crc32"] & 0xFFFFFF, x["mpdu"]) != (y["rate_kbps"], y["length"], y["crc32"] & 0xFFFFFF, y["mpdu"]):
                 return False, "event %d: rate/length/FCS/MPDU differ from the reference" % i
     return True, ""
+
+
+def htsig_soft(rng, rate4, lsig_len, mcs, ht_len, flips=0, noise=0):
+    """144 soft values (as T11nSigDemap emits them) of an L-SIG + HT-SIG with the given fields: rate-1/2 K=7 code, BPSK interleaver
+    per 48, bit 1 -> 6 / bit 0 -> 1, optional noise and hard flips.  Written from IEEE 802.11n (HT-mixed format), not from the reference."""
+    def crc8(bits34):
+        crc = 0xFF
+        for b in bits34:
+            crc ^= b
+            crc = (crc >> 1) ^ 0xE0 if crc & 1 else crc >> 1
+        return (~crc) & 0xFF
+
+    def enc(bits):
+        r = 0; out = []
+        for u in bits:
+            r = ((r << 1) | u) & 127
+            out += [bin(r & 0o155).count("1") & 1, bin(r & 0o117).count("1") & 1]
+        return out
+    ls = [(rate4 >> i) & 1 for i in range(4)] + [0] + [(lsig_len >> i) & 1 for i in range(12)]
+    ls += [sum(ls) & 1] + [0] * 6
+    h = [(mcs >> i) & 1 for i in range(7)] + [0] + [(ht_len >> i) & 1 for i in range(16)] + [1, 1, 1, 0, 0, 0, 0, 0, 0, 0]
+    c = crc8(h); h += [(c >> i) & 1 for i in range(8)] + [0] * 6
+    coded = enc(ls) + enc(h)
+    k = np.arange(48); idx = 3 * (k % 16) + k // 16                         # de-interleaved position k comes from interleaved idx[k]
+    soft = np.zeros(144, np.uint8)
+    for s_ in range(3):
+        inter = np.zeros(48, int); inter[idx] = coded[48 * s_:48 * s_ + 48]
+        soft[48 * s_:48 * s_ + 48] = np.where(inter == 1, 6, 1)
+    if noise:
+        soft = np.clip(soft.astype(int) + rng.integers(-noise, noise + 1, size=144), 0, 7).astype(np.uint8)
+    for _ in range(flips):
+        j = rng.integers(0, 144); soft[j] = 7 - soft[j]
+    return soft
+
+
+def htsig_cases(seed, n):
+    """n soft-value bursts: mostly decodable SIG fields, plus every failure path of T11nSigParser and some pure noise."""
+    rng = np.random.default_rng(seed); out = []
+    for t in range(n):
+        rate4 = int(rng.choice([0xB, 0xB, 0xB, 0xF, 0x3, 0x8])); llen = int(rng.integers(0, 1200)) if t % 7 else int(rng.integers(0, 4096))
+        mcs = int(rng.choice([8, 9, 10, 10, 9, 8, 11, 0, 15, 7])); hlen = int(rng.integers(0, 1501)) if t % 5 else int(rng.integers(0, 65536))
+        soft = htsig_soft(rng, rate4, llen, mcs, hlen, flips=int(rng.integers(0, 6)) if t % 3 == 0 else 0, noise=t % 4)
+        if t % 50 == 49:
+            soft = rng.integers(0, 8, size=144).astype(np.uint8)
+        out.append(soft)
+    return np.stack(out)

@@ -109,6 +109,51 @@ def test_oracle_legacy_preamble_bricks(o):
         assert np.array_equal(o.sig_demap11n(s3), g.sig_demap11n(s3)), t
 
 
+def _sig_record(ok, out9, fields):
+    """the 12-word record sora_hip_sig_decode11n writes, from the (ok, bytes, fields) form of oracle and reference"""
+    b = [int(x) for x in out9]
+    return [int(x) for x in fields] + [b[0] | b[1] << 8 | b[2] << 16, b[3] | b[4] << 8 | b[5] << 16 | b[6] << 24, b[7] | b[8] << 8]
+
+
+def test_oracle_sig_decode(o):
+    """T11aDeinterleaveBPSK x3 -> T11nViterbiSig -> T11nSigParser: recorded reference-brick output, and live where oracle/_ref exists."""
+    from gpu_util import htsig_cases
+    z = np.load(GOLD)
+    assert np.array_equal(htsig_cases(2024, 120), z["sigdec_soft"])
+    for x, ok, by, f in zip(z["sigdec_soft"], z["sigdec_ok"], z["sigdec_bytes"], z["sigdec_fields"]):
+        got = o.sig_decode11n(x)
+        assert got[0] == ok and np.array_equal(got[1], by) and np.array_equal(got[2], f)
+    ok = z["sigdec_ok"] == 1
+    assert 10 < ok.sum() < 100 and set(z["sigdec_fields"][ok][:, 3].tolist()) == {8, 9, 10}      # all three MCS decode, failures present
+    assert (z["sigdec_fields"][~ok][:, 0] == 0x80000005).all()
+    g = ReferenceGraph()
+    if not g.available():
+        return
+    for x in htsig_cases(7, 1500):
+        a, b = o.sig_decode11n(x), g.sig_decode11n(x)
+        assert a[0] == b[0] and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+
+
+@pytest.mark.gpu
+def test_gpu_sig_decode(o):
+    import torch
+    import sora_amd
+    from gpu_util import htsig_cases
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    z = np.load(GOLD)
+    rec = sora_amd.sig_decode11n(torch.from_numpy(z["sigdec_soft"]).cuda()).cpu().numpy().view(np.uint32)
+    for i in range(len(rec)):
+        assert rec[i].tolist() == _sig_record(z["sigdec_ok"][i], z["sigdec_bytes"][i], z["sigdec_fields"][i]), i
+    soft = htsig_cases(99, 3001)                                          # not a multiple of four: a partly empty last block
+    rec = sora_amd.sig_decode11n(torch.from_numpy(soft).cuda()).cpu().numpy().view(np.uint32)
+    nok = 0
+    for i in range(len(soft)):
+        want = o.sig_decode11n(soft[i]); nok += want[0]
+        assert rec[i].tolist() == _sig_record(*want), i
+    assert nok > 500
+
+
 @pytest.mark.gpu
 def test_gpu_legacy_preamble_stage_kernels(o):
     import torch
