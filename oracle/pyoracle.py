@@ -204,6 +204,24 @@ class Oracle:
         a = np.ascontiguousarray(sym3, np.int16).reshape(192, 2); o = np.zeros(144, np.uint8)
         self.L.so_sig_demap11n(_P(a), _P(o)); return o
 
+    def rx11n_capture(self, iq0, iq1, max_frames=16):
+        """802.11n 2x2 receive graph over two int16 [n,2] captures @40 MHz -> list of dict (rate_kbps = MCS index)."""
+        a = np.ascontiguousarray(iq0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(iq1, np.int16).reshape(-1, 2)
+        assert len(a) == len(b)
+        res = (FrameResult * max_frames)(); mp = np.zeros(max_frames * 4096, np.uint8)
+        n = self.L.so_rx11n_capture(_P(a), _P(b), len(a), res, max_frames, _P(mp), mp.size)
+        out = []
+        for r in res[:n]:
+            d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
+            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            out.append(d)
+        return out
+
+    def cca11n(self, iq0, iq1, skip=0, max_detect=64):
+        """TCCA11n over two int16 [4n,2] streams @20 MHz -> indices of the 4-sample bursts in which power was detected."""
+        a = np.ascontiguousarray(iq0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(iq1, np.int16).reshape(-1, 2)
+        d = np.zeros(max_detect, np.uint32); n = self.L.so_cca11n(_P(a), _P(b), len(a) // 4, skip, _P(d), max_detect); return d[:min(n, max_detect)].tolist()
+
     def sig_decode11n(self, soft144):
         """T11aDeinterleaveBPSK x3 -> T11nViterbiSig -> T11nSigParser -> (ok, out9 bytes, fields uint32[9])"""
         a = np.ascontiguousarray(soft144, np.uint8); o9 = np.zeros(9, np.uint8); f = np.zeros(9, np.uint32)
@@ -408,6 +426,11 @@ class ReferenceGraph:
         a = np.ascontiguousarray(soft144, np.uint8); o9 = np.zeros(9, np.uint8); f = np.zeros(9, np.uint32)
         assert a.size == 144
         ok = self.L.ref_11n_sig_decode(_P(a), _P(o9), _P(f)); return ok, o9, f
+
+    def cca11n(self, iq0, iq1, skip=0, max_detect=64):
+        """a fresh TCCA11n brick over two int16 [4n,2] streams @20 MHz; `skip` bursts withheld after each detection, then Reset"""
+        a = np.ascontiguousarray(iq0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(iq1, np.int16).reshape(-1, 2)
+        d = np.zeros(max_detect, np.uint32); n = self.L.ref_11n_cca(_P(a), _P(b), len(a) // 4, skip, _P(d), max_detect); return d[:min(n, max_detect)].tolist()
 
     def tx11n(self, mpdu_nofcs, mcs):
         """The reference's 802.11n 2x2 modulation graphs (Test11N_FB_Mod) -> two int16 [n,2] COMPLEX16 streams @40 MHz."""

@@ -471,3 +471,38 @@ EXPORT int ref_11n_sig_decode(const uint8_t* soft144, uint8_t* out9, uint32_t* f
     fields[6] = c.CF_11aRxVector::total_symbols(); fields[7] = c.CF_11aRxVector::remain_symbols(); fields[8] = c.CF_11nSymState::symbol_type();
     return ok ? 1 : 0;
 }
+
+// MimoAutoCorr (autocorr.hpp:5-147) and TCCA11n (cca_11n.hpp) over a run of 4-sample bursts of both RX chains at 20 MHz.
+// ref_11n_autocorr: the four (auto-correlation energy, mean energy squared) pairs per burst from a fresh MimoAutoCorr.
+EXPORT void ref_11n_autocorr(const int16_t* iq0, const int16_t* iq1, uint32_t nbursts, int64_t* acorr, int64_t* energy)
+{
+    MimoAutoCorr* core = new MimoAutoCorr();
+    for (uint32_t b = 0; b < nbursts; b++) {
+        A16 COMPLEX16 x0[4], x1[4]; memcpy(x0, iq0 + 8 * b, 16); memcpy(x1, iq1 + 8 * b, 16);
+        vq a[2], e[2];
+        core->CalcAutoCorrAndEnergy(*(vcs*)x0, *(vcs*)x1, a, e);
+        memcpy(acorr + 4 * b, a, 32); memcpy(energy + 4 * b, e, 32);
+    }
+    delete core;
+}
+// ref_11n_cca: a fresh TCCA11n brick; after each detection the next `skip` bursts are withheld (the graph routes them to the frame
+// bricks), then the context and the brick are Reset as RxThread does after a frame.  CS_TIMEOUT is cleared as RxThread clears it.
+// Returns the number of detections; detect[k] = index of the burst in which detection k was raised.
+EXPORT int ref_11n_cca(const int16_t* iq0, const int16_t* iq1, uint32_t nbursts, uint32_t skip, uint32_t* detect, int max_detect)
+{
+    TCCA11n<BB11nDemodContext>* cca = new TCCA11n<BB11nDemodContext>(BB11nDemodCtx);
+    BB11nDemodCtx.Reset();
+    int n = 0;
+    for (uint32_t b = 0; b < nbursts; b++) {
+        A16 COMPLEX16 x0[4], x1[4]; memcpy(x0, iq0 + 8 * b, 16); memcpy(x1, iq1 + 8 * b, 16);
+        TwoStreamPin<COMPLEX16, 4> pin = { { x0, x1 }, true };
+        cca->Process(pin);
+        if (BB11nDemodCtx.CF_Error::error_code() == E_ERROR_CS_TIMEOUT) { BB11nDemodCtx.ResetCarrierSense(); cca->Reset(); }
+        if (BB11nDemodCtx.CF_11CCA::cca_state() == CF_11CCA::power_detected) {
+            if (n < max_detect) detect[n] = b;
+            n++; b += skip;
+            BB11nDemodCtx.Reset(); cca->Reset();
+        }
+    }
+    return n;                                                        // the brick is left to the process (its allocator is not delete's)
+}

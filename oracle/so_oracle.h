@@ -72,6 +72,7 @@ uint32_t so_viterbi_sig(const uint8_t soft48[48]);                           /* 
 int  so_parse_plcp(uint32_t sig, uint32_t* rate_kbps, uint16_t* length, uint16_t* code_rate, uint16_t* nsym); /* 1 ok */
 /* T11aViterbi<5000*8,48,256,24> schedule over a whole frame; returns bytes written (frame_length+2) */
 int  so_viterbi_frame(const uint8_t* soft, uint32_t nsoft, int code_rate, uint32_t frame_length, uint8_t* out);
+int  so_viterbi_frame_ex(const uint8_t* soft, uint32_t nsoft, int code_rate, uint32_t frame_length, uint8_t* out, uint32_t depth, uint32_t lookahead);   /* depth <= 256 */
 /* T11aDesc + TBB11aFrameSink: in = frame_length+2 decoded bytes; mpdu gets frame_length bytes; returns error code */
 uint32_t so_desc_sink(const uint8_t* dec, uint32_t frame_length, uint8_t* mpdu, uint32_t* crc_in_frame);
 
@@ -129,6 +130,12 @@ void so_siso_est11n(const so_c16 l0[128], const so_c16 l1[128], so_c16 ch[2][64]
 void so_siso_comp11n(const so_c16 ch[2][64], const so_c16 y0[64], const so_c16 y1[64], so_c16 x0[64], so_c16 x1[64]);
 void so_mrc11n(const so_c16 a[64], const so_c16 b[64], so_c16 out[64]);
 void so_sig_demap11n(const so_c16 sym[192], uint8_t soft[144]);
+/* 802.11n receive graph (so_rx11n.c): two 40 MHz captures -> events (rate_kbps = MCS index) */
+int so_rx11n_capture(const so_c16* iq0, const so_c16* iq1, uint32_t nsamples, so_frame_result* res, int max_res, uint8_t* mpdu_buf, uint32_t mpdu_cap);
+size_t so_autocorr11n_size(void);
+void so_autocorr11n_reset(void* state);
+void so_autocorr11n_burst(void* state, const so_c16 x0[4], const so_c16 x1[4], int64_t acorr[4], int64_t energy[4]);
+int so_cca11n(const so_c16* iq0, const so_c16* iq1, uint32_t nbursts, uint32_t skip, uint32_t* detect, int max_detect);
 void so_viterbi_sig_bits(const uint8_t* soft, int nbits, uint8_t* out);
 /* fields[9] = error_code, data_rate_kbps, frame_length, ht_frame_mcs, ht_frame_length, code_rate, total_symbols, remain_symbols, symbol_type */
 int so_sig_decode11n(const uint8_t soft[144], uint8_t out9[9], uint32_t fields[9]);

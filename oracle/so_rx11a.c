@@ -281,12 +281,18 @@ void so_viterbi_sig_bits(const uint8_t* soft, int nbits, uint8_t* out)
 
 int so_viterbi_frame(const uint8_t* soft, uint32_t nsoft, int code_rate, uint32_t frame_length, uint8_t* out)
 {
-    /* T11aViterbi<5000*8,48,256,24>::Filter::Process (viterbi.hpp:148-235) */
+    return so_viterbi_frame_ex(soft, nsoft, code_rate, frame_length, out, 256, 24);       /* T11aViterbi<5000*8,48,256,24> (11a graph) */
+}
+
+int so_viterbi_frame_ex(const uint8_t* soft, uint32_t nsoft, int code_rate, uint32_t frame_length, uint8_t* out, uint32_t DEPTH, uint32_t LOOK)
+{
+    /* T11aViterbi<TRELLIS_MAX, N_INPUT, TRELLIS_DEPTH, TRELLIS_LOOKAHEAD>::Filter::Process (viterbi.hpp:148-235); N_INPUT only sets
+     * the burst size and has no effect on the output */
     vit_init();
-    const uint32_t DEPTH = 256, LOOK = 24, PREFIX = 6;
+    const uint32_t PREFIX = 6;
     uint32_t maxcol = nsoft + 8;
     uint64_t* dec = (uint64_t*)malloc((size_t)maxcol * sizeof(uint64_t));
-    uint8_t m[64], buf[DEPTH / 8 + 1];
+    uint8_t m[64], buf[256 / 8 + 1];
     vit_reset(m);
     dec[0] = 0; for (int n = 0; n < 64; n++) dec[0] |= (uint64_t)(m[n] & 1) << n;
     uint32_t tr = 0, ob = 0; int nout = 0;

@@ -182,6 +182,31 @@ def main():
     n11["sigdec_soft"] = hs; n11["sigdec_ok"] = np.array([d[0] for d in dec], np.int32)
     n11["sigdec_bytes"] = np.stack([d[1] for d in dec]); n11["sigdec_fields"] = np.stack([d[2] for d in dec])
     np.savez_compressed(os.path.join(OUT, "ref_vectors_11n.npz"), **n11)
+    # 802.11n 2x2 receive graph: four transmit waveforms of the reference modulator, captures built from them with gpu_util.capture_11n,
+    # the events of the reference receive graph, and TCCA11n's detections on the decimated streams
+    from gpu_util import capture_11n
+    rng = np.random.default_rng(1144)
+    g11 = {}; frames = []
+    for i, (mcs, ln) in enumerate(((8, 40), (9, 90), (10, 150), (12, 30))):
+        mp = rng.integers(0, 256, ln).astype(np.uint8)
+        s0, s1 = G.tx11n(mp.tobytes(), mcs)
+        g11["tx%d_0" % i] = s0; g11["tx%d_1" % i] = s1; g11["mpdu%d" % i] = mp; frames.append((s0, s1))
+    plan = [((0,), None, 20), ((1, 2), None, 40), ((3, 0, 1), None, 10), ((2,), 0.97, 20), ((0, 1), 0.6, 30), ((1,), 0.35, 20), ((2, 2, 0), None, 150), ((0,), 0.995, 5)]
+    g11["plan_frames"] = np.array([",".join(map(str, p[0])) for p in plan]); g11["plan_cut"] = np.array([-1.0 if p[1] is None else p[1] for p in plan])
+    g11["plan_sigma"] = np.array([p[2] for p in plan], np.float64)
+    ev = {"count": [], "err": [], "mcs": [], "length": [], "crc": []}; det = []
+    rng = np.random.default_rng(1145)
+    for fr, cut, sg in plan:
+        a, b = capture_11n(rng, [frames[i] for i in fr], sigma=sg, cut=cut)
+        e = G.rx11n(a, b)
+        ev["count"].append(len(e))
+        for x in e:
+            ev["err"].append(x["error_code"]); ev["mcs"].append(x["rate_kbps"]); ev["length"].append(x["length"]); ev["crc"].append(x["crc32"])
+        n4 = len(a) // 2 // 4 * 4
+        d = G.cca11n(a[::2][:n4], b[::2][:n4], skip=0); det.append(",".join(map(str, d)))
+    g11["ev_count"] = np.array(ev["count"], np.int32); g11["ev_err"] = np.array(ev["err"], np.uint32); g11["ev_mcs"] = np.array(ev["mcs"], np.uint32)
+    g11["ev_length"] = np.array(ev["length"], np.uint32); g11["ev_crc"] = np.array(ev["crc"], np.uint32); g11["cca_detect"] = np.array(det)
+    np.savez_compressed(os.path.join(OUT, "refgraph_11n.npz"), **g11)
     print("written", os.listdir(OUT))
 
 

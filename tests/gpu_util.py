@@ -238,3 +238,38 @@ def htsig_cases(seed, n):
             soft = rng.integers(0, 8, size=144).astype(np.uint8)
         out.append(soft)
     return np.stack(out)
+
+
+def capture_11n(rng, frames, sigma=20.0, cut=None):
+    """Two-chain 40 MHz capture (int16 [n,2] each, n a multiple of 28) from `frames` = [(s0, s1)] transmit waveforms of the two TX
+    chains: per frame a random gap, gain, per-chain phase, cross-talk and CFO; white noise on top; `cut` (0..1) truncates the last frame."""
+    segs0, segs1 = [], []
+    for i, (s0, s1) in enumerate(frames):
+        gap = int(rng.integers(200, 1500)); x = float(rng.choice([0.0, 0.1, 0.3])); gain = float(rng.choice([0.3, 1.0, 2.0]))
+        ph = np.exp(1j * rng.uniform(0, 2 * np.pi, 2)); cfo = rng.uniform(-3e-4, 3e-4)
+        c0 = s0[:, 0] + 1j * s0[:, 1]; c1 = s1[:, 0] + 1j * s1[:, 1]; k = np.arange(len(c0))
+        r0 = gain * (ph[0] * c0 + x * c1) * np.exp(1j * cfo * k); r1 = gain * (ph[1] * c1 + x * c0) * np.exp(1j * cfo * k)
+        if cut is not None and i == len(frames) - 1:
+            r0 = r0[:int(len(r0) * cut)]; r1 = r1[:len(r0)]
+        segs0 += [np.zeros(gap, complex), r0]; segs1 += [np.zeros(gap, complex), r1]
+    tail = 600 if cut is None else 0
+    a = np.concatenate(segs0 + [np.zeros(tail, complex)]); b = np.concatenate(segs1 + [np.zeros(tail, complex)])
+    n = len(a) // 28 * 28
+
+    def q(z):
+        z = z[:n] + rng.normal(0, sigma, n) + 1j * rng.normal(0, sigma, n)
+        return np.stack([np.clip(np.rint(z.real), -32768, 32767), np.clip(np.rint(z.imag), -32768, 32767)], 1).astype(np.int16)
+    return q(a), q(b)
+
+
+def same_events_11n(got, want):
+    """events of the 802.11n graph: error code always; MCS, length, FCS and MPDU unless the header failed (the reference then reports
+    whatever an earlier frame left in its context)"""
+    if len(got) != len(want):
+        return False, "event count %d != %d" % (len(got), len(want))
+    for i, (x, y) in enumerate(zip(got, want)):
+        if x["error_code"] != y["error_code"]:
+            return False, "event %d: error %#x != %#x" % (i, x["error_code"], y["error_code"])
+        if x["error_code"] != 0x80000005 and (x["rate_kbps"], x["length"], x["crc32"], x["mpdu"]) != (y["rate_kbps"], y["length"], y["crc32"], y["mpdu"]):
+            return False, "event %d differs" % i
+    return True, ""
