@@ -235,6 +235,22 @@ int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_
                           sora_complex16* d_x0, sora_complex16* d_x1, size_t nsym, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * 802.11n 2x2 receive graph = CreateDemodGraph11n (kernel/bb/demod11/fb11ndemod_config.hpp:166-257) driven by
+ * RxThread (kernel/bb/demod11/fb11n_demod.cpp:30-85) over a batch of independent captures of TWO RX chains at 40 MHz (the two
+ * dump files Test11N_FB_Demod loads).  cfg->sample_rate_mhz must be 40; capture lengths are whole 28-sample source bursts; one
+ * descriptor addresses the same range of both chain buffers.  Results as sora_rx_results reports them, with rate_kbps = the MCS
+ * index (8..10: what the reference's SIG parser accepts), end_sample = the 40 MHz source position when RxThread sees the event,
+ * start_sample / nsym / cfo_est 0.  A frame cut short by the end of its capture is decoded from zero-padded symbols, as the
+ * reference's final flush does. */
+typedef struct sora_rx11n sora_rx11n_t;
+int   sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out);
+void  sora_rx11n_destroy(sora_rx11n_t* rx);
+void* sora_rx11n_stream(sora_rx11n_t* rx);
+int   sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps);
+int   sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const sora_complex16* h_iq1, size_t nsamples_per_chain, const sora_capture_desc* caps, size_t ncaps);
+int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+
+/* ------------------------------------------------------------------------------------------------
  * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
  * MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76) over a batch of independent 44 MHz captures: TDCRemove,
  * TEnergyDetect / TDCEstimator, TSymTiming, TBarkerSync, TBB11bDespread, TSFDSync, TDBPSKDemap / TDQPSKDemap, TDesc741,

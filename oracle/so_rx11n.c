@@ -315,7 +315,7 @@ int so_rx11n_capture(const so_c16* iq0, const so_c16* iq1, uint32_t nsamples, so
                 if (rx->nres < rx->max_res) {
                     so_frame_result* f = &rx->res[rx->nres++];
                     memset(f, 0, sizeof(*f));
-                    f->error_code = err;
+                    f->error_code = err; f->end_sample = src;                      /* 40 MHz source position as RxThread sees the event */
                     if (err != SO_E_PLCP_HEADER_FAIL) {
                         f->rate_kbps = rx->mcs; f->length = (uint16_t)rx->ht_length; f->crc32 = rx->frame_crc; f->mpdu_offset = rx->mpdu_used;
                         if (rx->mpdu_used + rx->ht_length <= rx->mpdu_cap) rx->mpdu_used += rx->ht_length;

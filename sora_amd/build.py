@@ -7,8 +7,8 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "lib", "libsora_hip.so")
-SOURCES = ["k_scan.hip", "k_rx.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "sora_hip.cpp"]
-HEADERS = ["dev_arith.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
+SOURCES = ["k_scan.hip", "k_rx.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "sora_hip.cpp"]
+HEADERS = ["dev_arith.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
 
 
 def hipcc():

@@ -48,7 +48,8 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results"]
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
+           "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results"]
 
 _lib = None
 
@@ -120,6 +121,13 @@ def load(build_if_missing=True):
     L.sora_hip_siso_comp11n.argtypes = [ctypes.c_void_p] * 7 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_sig_demap11n.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_sig_decode11n.argtypes = [ctypes.c_void_p] * 2 + [ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_rx11n_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
+    L.sora_rx11n_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11n_destroy.restype = None
+    L.sora_rx11n_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11n_stream.restype = ctypes.c_void_p
+    L.sora_rx11n_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
+    L.sora_rx11n_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
+    L.sora_rx11n_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                     ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
     L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
@@ -303,6 +311,54 @@ class Rx11b:
         n = ctypes.c_size_t(0)
         mp = np.zeros(max_frames * 4096, np.uint8)
         _check(self._L.sora_rx11b_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data, mp.size))
+        out = []
+        for r in res[:n.value]:
+            d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
+            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + min(r.length, 4096)].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            out.append(d)
+        return out
+
+
+class Rx11n:
+    """sora_rx11n_t: the 802.11n 2x2 demod graph (two RX chains at 40 MHz) over a batch of captures; rate_kbps = MCS index."""
+
+    def __init__(self, max_captures, max_total_samples, device=0, max_frames_per_capture=8):
+        L = load()
+        cfg = RxCfg(ctypes.sizeof(RxCfg), device, 40, max_captures, max_total_samples, max_frames_per_capture, 0)
+        h = ctypes.c_void_p()
+        _check(L.sora_rx11n_create(ctypes.byref(cfg), ctypes.byref(h)))
+        self._h = h; self._L = L; self.cfg = cfg; self._keep = None
+
+    def close(self):
+        if self._h:
+            self._L.sora_rx11n_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._L.sora_hip_stream_synchronize(self._L.sora_rx11n_stream(self._h)))
+
+    def process_dev(self, d_iq0, d_iq1, captures):
+        arr, ptr = Rx._caps(captures)
+        self._keep = (d_iq0, d_iq1)
+        _check(self._L.sora_rx11n_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), ptr, len(arr)))
+
+    def process(self, h_iq0, h_iq1, captures):
+        a = np.ascontiguousarray(h_iq0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(h_iq1, np.int16).reshape(-1, 2)
+        assert len(a) == len(b)
+        arr, ptr = Rx._caps(captures)
+        _check(self._L.sora_rx11n_process(self._h, a.ctypes.data, b.ctypes.data, len(a), ptr, len(arr)))
+
+    def results(self):
+        max_frames = self.cfg.max_captures * self.cfg.max_frames_per_capture
+        res = (FrameResult * max(1, max_frames))()
+        n = ctypes.c_size_t(0)
+        mp = np.zeros(max_frames * 4096, np.uint8)
+        _check(self._L.sora_rx11n_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data, mp.size))
         out = []
         for r in res[:n.value]:
             d = {f: getattr(r, f) for f, _ in FrameResult._fields_}

@@ -1,0 +1,588 @@
+// k_rx11n.hip -- the reference's 802.11n 2x2 receive graph over a batch of independent two-chain captures:
+// CreateDemodGraph11n (kernel/bb/demod11/fb11ndemod_config.hpp:166-257) driven as RxThread drives it (fb11n_demod.cpp:30-85).
+//
+//   TMemSamples2 -> TDownSample2 -> RxSwitch -> TCCA11n (MimoAutoCorr)                                   carrier sense
+//                                            -> TFreqEstimator_11n -> TFreqComp_11n -> TFFT64 x4 -> TSisoChannelEst    L-LTF
+//                                            -> TFreqComp_11n -> T11nDataSymbol -> TFFT64 x2 -> T11nSymSel
+//       SIG:    TSisoChannelComp -> TMrcCombine -> T11nSigDemap -> T11aDeinterleaveBPSK -> T11nViterbiSig -> T11nSigParser
+//       HT-LTF: TMimoChannelEst
+//       DATA:   TMimoChannelComp -> TPilotTrack_11n -> T11nDemap* -> T11nDeinterleave*_S0/_S1 -> TStreamJoin -> TStreamConcat<2,1>
+//               -> T11aViterbi<5000*8, 312, 192, 36> -> T11aDesc -> TBB11aFrameSink
+//
+// One wave per capture (four per workgroup); all control flow is wave-uniform, the 64 lanes are the 64 samples / carriers / trellis
+// states of the step at hand.  The graph's queues reduce to positions in the 20 MHz stream:
+//   * a source call brings 14 samples; a frame event is seen when the call that completed its last burst returns, the queues are
+//     cleared and the stream restarts at the next call boundary;
+//   * carrier sense runs in blocks of 64 samples: the moving sums are prefix sums over the lanes on top of the rings MimoAutoCorr
+//     keeps, the peak counter walks the two ballots of its conditions;
+//   * TFreqComp_11n's running phase is n * CFO - theta (mod 2^16) for the n-th sample after detection;
+//   * samples past the end of the capture read as zero: that is the flush TMemSamples2 issues when it runs dry, which pads every
+//     partly filled queue with zero items (see oracle/so_rx11n.c, flush_graph).
+// HBM traffic = the samples, once (8 bytes per 40 MHz sample pair of the two chains, of which the even half is used).
+#include "kernels.h"
+#include "dev_11n.h"
+#include "../../include/sora_hip.h"
+
+namespace sora {
+
+struct Rx11nArgs {
+    const uint32_t* iq0; const uint32_t* iq1;    // packed COMPLEX16 @40 MHz, RX chain 0 / 1
+    const CapDesc*  caps; uint32_t ncaps, max_frames;
+    Rx11bRow*       rows;                          // [ncaps * max_frames]: end_sample = 40 MHz source position, rate_kbps = MCS index
+    uint32_t*       nframes;                       // [ncaps]
+    uint8_t*        mpdu;                          // [ncaps * max_frames][4096]
+    Tables          T;
+    const uint32_t* sincos; const short* atan;     // dsp_math tables
+};
+
+namespace {
+constexpr uint32_t E_OK = 1u, E_PLCP = 0x80000005u, E_CRC = 0x80000006u;
+enum { SYM_SIG = 2, SYM_HT_STF, SYM_HT_LTF, SYM_DATA };
+
+struct WaveLds {
+    uint32_t his[2][32]; int hcr[2][32], hci[2][32], he[2][32];     // MimoAutoCorr rings
+    long long his_e[64];                                            // TCCA11n::his_moving_energy
+    uint32_t buf[2][128];                                           // compensated samples in front of the FFTs
+    uint32_t fft[4][64];                                            // FFT staging, one slice per 16-lane group
+    uint32_t y[2][128];                                             // FFT output per chain (L-LTF: both halves; HT-LTF: both symbols)
+    uint32_t ch[2][64]; uint32_t hinv[4][64];
+    uint32_t sig[192];
+    uint32_t xs[2][64];                                             // spatial streams after TMimoChannelComp
+    uint8_t  soft[2][160];                                          // demapped soft values per stream (<= 104); [0] doubles as SIG scratch
+    uint8_t  joined[208];                                           // stream-parsed, de-interleaved soft values of one symbol
+    uint8_t  sigsoft[144];
+    unsigned long long dec[256];                                    // decision words of the last 256 trellis columns
+    uint8_t  out[1536];                                             // decoded bytes (service field first)
+};
+
+__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+
+__device__ __forceinline__ int scan_add(int v, int lane)               // inclusive prefix sum over the wave, wrapping
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v = (int)((unsigned)v + (unsigned)o); }
+    return v;
+}
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
+{
+    __shared__ WaveLds s_w[4];
+    __shared__ uint8_t s_lut[6][256];
+    __shared__ uint32_t s_crc[256];
+    __shared__ uint32_t s_z[6 * 8 * 16];
+    fill_demap_luts(s_lut);
+    s_crc[threadIdx.x] = A.T.crc[threadIdx.x];
+    for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) s_z[i] = A.T.crcz[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const uint32_t cap = blockIdx.x * 4 + wv;
+    if (cap >= A.ncaps) return;                                              // whole waves leave; no block barrier below
+    WaveLds& W = s_w[wv];
+    const CapDesc cd = A.caps[cap];
+    const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
+    const uint32_t n20 = cd.nsamples / 2;                                    // 20 MHz samples (TDownSample2 keeps the even ones)
+    auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t { return i < n20 ? iq[r][2 * (size_t)i] : 0u; };
+    const Fft64Tw tw = fft64_twiddles(A.T, lane & 15);
+    auto nosync = []() __attribute__((always_inline)) { wsync(); };
+
+    // MimoAutoCorr / TCCA11n state: lives for the whole capture (only the peak counter is reset between frames)
+    for (int k = lane; k < 64; k += 64) { W.his[0][k & 31] = 0; W.his[1][k & 31] = 0; W.hcr[k >> 5][k & 31] = 0; W.hci[k >> 5][k & 31] = 0; W.he[k >> 5][k & 31] = 0; W.his_e[k] = 0x7FFFFFFFFFFFFFFFll; }
+    wsync();
+    int sr[2] = { 0, 0 }, si[2] = { 0, 0 }, se[2] = { 0, 0 };                // running sums
+    int ring_pos = 0, his_index = 0;
+    uint32_t origin = 0, nfr = 0;                                            // stream origin (20 MHz index), frames reported
+    Rx11bRow* rows = A.rows + (size_t)cap * A.max_frames;
+
+    while (origin < n20) {
+        // ================================================================ carrier sense from `origin`
+        const uint32_t nb_total = (n20 - origin + 3) / 4;                    // bursts TDownSample2 will deliver (the last one zero-padded)
+        bool pf = false; int pc = 0;                                         // peak_found, peak_count (_reset)
+        int64_t det_at = -1;                                                 // sample (relative to origin) at which power was detected
+        for (uint32_t base = 0; base < nb_total * 4 && det_at < 0; base += 64) {
+            const int lim = (int)min(64u, nb_total * 4 - base);
+            int pr[2], pi[2], pe[2], cre[2], cim[2], een[2]; uint32_t xr[2];
+            const int slot = (ring_pos + lane) & 31;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                xr[r] = fetch(r, origin + base + lane);
+                const cpx x = unpack(xr[r]);
+                const uint32_t dl = (uint32_t)__shfl((int)xr[r], lane - 32);
+                const cpx delayed = unpack(lane < 32 ? W.his[r][slot] : dl);
+                int re, im; conj_mul32(x, delayed, re, im); re >>= 5; im >>= 5;
+                const int ore = __shfl(re, lane - 32), oim = __shfl(im, lane - 32);
+                const int e = sqnorm(x) >> 5, oe = __shfl(e, lane - 32);
+                const int dre = (int)((unsigned)re - (unsigned)(lane < 32 ? W.hcr[r][slot] : ore));
+                const int dim = (int)((unsigned)im - (unsigned)(lane < 32 ? W.hci[r][slot] : oim));
+                const int den = (int)((unsigned)e - (unsigned)(lane < 32 ? W.he[r][slot] : oe));
+                pr[r] = (int)((unsigned)sr[r] + (unsigned)scan_add(dre, lane)); pi[r] = (int)((unsigned)si[r] + (unsigned)scan_add(dim, lane));
+                pe[r] = (int)((unsigned)se[r] + (unsigned)scan_add(den, lane));
+                cre[r] = re; cim[r] = im; een[r] = e;
+            }
+            const int are = (int)((unsigned)(pr[0] >> 1) + (unsigned)(pr[1] >> 1)), aim = (int)((unsigned)(pi[0] >> 1) + (unsigned)(pi[1] >> 1));
+            const long long acorr = (long long)((unsigned long long)((long long)are * are) + (unsigned long long)((long long)aim * aim));
+            const int ev = (int)((unsigned)(pe[0] >> 1) + (unsigned)(pe[1] >> 1));
+            const long long energy = (long long)ev * ev;
+            const long long olde = W.his_e[(his_index + lane) & 63];
+            // eb = energy / (olde + 1) > 5  <=>  olde + 1 <= energy / 6   (olde = LLONG_MAX: the sum wraps negative and eb is 0)
+            const bool cA = olde != 0x7FFFFFFFFFFFFFFFll && (olde + 1) <= energy / 6 && acorr > (energy >> 1);
+            const bool cB = acorr < (energy >> 3);
+            const unsigned long long bA = __ballot(cA), bB = __ballot(cB);
+            int det = -1;
+            for (int i = 0; i < lim; i++) {                                  // cca_11n.hpp:46-121, on the two ballots
+                const bool a = (bA >> i) & 1, b = (bB >> i) & 1;
+                if (!pf) { if (a) { pc++; pf = true; } else pc = 0; }
+                else if (b) { const bool good = pc > 96 && pc < 160; pf = false; pc = 0; if (good) { det = i; break; } }
+                else { pc++; if (pc > 160) { pf = false; pc = 0; } }
+            }
+            const int ne = det >= 0 ? det : lim;                             // samples recorded in his_moving_energy
+            const int na = det >= 0 ? (det | 3) + 1 : lim;                   // samples MimoAutoCorr has taken (whole bursts)
+            if (lane < ne) W.his_e[(his_index + lane) & 63] = energy;
+            if (lane < na && lane >= na - 32) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) { W.his[r][slot] = xr[r]; W.hcr[r][slot] = cre[r]; W.hci[r][slot] = cim[r]; W.he[r][slot] = een[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) { sr[r] = __shfl(pr[r], na - 1); si[r] = __shfl(pi[r], na - 1); se[r] = __shfl(pe[r], na - 1); }
+            his_index = (his_index + ne) & 63; ring_pos = (ring_pos + na) & 31;
+            wsync();
+            if (det >= 0) det_at = (int64_t)base + na;                       // first sample behind the detecting burst
+        }
+        if (det_at < 0) break;                                               // nothing (more) in this capture
+        const uint32_t n_real = n20 - origin;                                // real samples of this segment
+        const uint32_t l0 = (uint32_t)det_at;                                // L-LTF start, relative to origin
+        if (l0 + 128 > ((n_real + 3) & ~3u)) break;                          // the L-LTF queue never fills: its flush is not an event
+        // ================================================================ L-LTF: CFO, compensation, four FFTs, SISO channel
+        int cfo;
+        {
+            int sre = 0, sim = 0;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int re, im; conj_mul32(unpack(fetch(r, origin + l0 + lane)), unpack(fetch(r, origin + l0 + 64 + lane)), re, im);
+                sre += re >> 7; sim += im >> 7;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { sre += __shfl_xor(sre, d); sim += __shfl_xor(sim, d); }
+            cfo = dsp_atan32(A.atan, sre, sim) >> 6;
+        }
+        int theta = 0;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int n = 64 * h + lane;
+                const cpx cof = unpack(A.sincos[(unsigned)(n * cfo) & 0xFFFFu]);
+                int re, im; mul32(unpack(fetch(r, origin + l0 + n)), cof, re, im);
+                W.buf[r][n] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+            }
+        wsync();
+        {   // group g = 2 r + half
+            const int g = lane >> 4, e = lane & 15; cpx x[4], yy[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) x[m] = unpack(W.buf[g >> 1][64 * (g & 1) + e + 16 * m]);
+            fft64_group(x, yy, W.fft[g], e, tw, nosync);
+#pragma unroll
+            for (int q = 0; q < 4; q++) W.y[g >> 1][64 * (g & 1) + e + 16 * q] = pack(yy[q]);
+        }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            uint32_t o = 0;
+            if (lane < 28 || lane >= 36) {
+                const uint32_t* l = W.y[r] + (lane & ~3);
+                const cpx a = siso_one(l, lane & 3, lane), b = siso_one(l + 64, lane & 3, lane);
+                o = pack(mk((short)((short)(a.re + b.re) >> 1), (short)((short)(a.im + b.im) >> 1)));
+            }
+            W.ch[r][lane] = o;
+        }
+        wsync();
+        // ================================================================ symbols
+        int type = SYM_SIG, nsig = 0, nltf = 0;
+        uint32_t err = 0, mcs = 0, ht_len = 0, code_rate = 0, frame_crc = 0;
+        unsigned m = (lane == 0) ? 0u : 0x30u;                               // Viterbi metrics, lane = state
+        uint32_t tr = 0, ob = 0, nout = 0, soft_n = 0, tr_end = 0;
+        if (lane == 0) W.dec[0] = 0;
+        const int cA0 = __popc(lane & 0155) & 1, cB0 = __popc(lane & 0117) & 1, cA1 = __popc((64 | lane) & 0155) & 1, cB1 = __popc((64 | lane) & 0117) & 1;
+        uint32_t last_burst_end = 0;                                         // sample (relative) behind the burst that raised the event
+
+        // one trellis step; which: 0 = (A,B), 1 = A only, 2 = B only (viterbi.hpp:166-187)
+        auto acs = [&](int which, int va, int vb) __attribute__((always_inline)) {
+            const unsigned m0 = (unsigned)__shfl((int)m, lane >> 1), m1 = (unsigned)__shfl((int)m, 32 + (lane >> 1));
+            unsigned b0 = 0, b1 = 0;
+            if (which != 2) { b0 += cA0 ? 2 * (7 - va) : 2 * va; b1 += cA1 ? 2 * (7 - va) : 2 * va; }
+            if (which != 1) { b0 += cB0 ? 2 * (7 - vb) : 2 * vb; b1 += cB1 ? 2 * (7 - vb) : 2 * vb; }
+            const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
+            m = min(c0, c1);
+            tr++;
+            const unsigned long long d = __ballot(m & 1);
+            if (lane == 0) W.dec[tr & 255] = d;
+        };
+        auto normalize = [&]() __attribute__((always_inline)) {
+            unsigned mn = m;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+            m = (m - (mn & 0xFE)) & 0xFF;
+        };
+        // Traceback (viterbicore.h:468-555) of `bits` bits behind `look` columns, appended to W.out
+        auto traceback = [&](uint32_t bits, uint32_t look) __attribute__((always_inline)) {
+            unsigned kmin = (m << 8) | ((unsigned)lane << 2);
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+            kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
+            int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+            wsync();
+            uint32_t col = tr;
+            for (uint32_t i = 0; i < look; i++) { col--; pos = (pos >> 1) & 0x3F; pos |= (int)((W.dec[col & 255] >> pos) & 1) << 6; }
+            uint32_t po = nout + (bits >> 3);
+            for (uint32_t i = 0; i < bits >> 3; i++) {
+                unsigned oc = 0;
+                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | ((unsigned)(pos >> 6) & 1u)) & 0xFF; col--; pos = (pos >> 1) & 0x3F; pos |= (int)((W.dec[col & 255] >> pos) & 1) << 6; }
+                po--;
+                if (lane == 0 && po < sizeof(W.out)) W.out[po] = (uint8_t)oc;
+            }
+            nout += bits >> 3; ob += bits;
+        };
+        // the check T11aViterbi makes after every puncture group (viterbi.hpp:189-231); returns true when the frame is complete
+        auto vit_check = [&]() __attribute__((always_inline)) -> bool {
+            if ((tr & 7) == 0) normalize();
+            if (tr >= tr_end) { traceback(tr_end - ob - 6, tr - tr_end); return true; }
+            if (tr >= ob + 192 + 36 + 6) { const uint32_t rem = (tr - (ob + 192 + 36 + 6)) % 8; traceback(192, 36 + rem); }
+            return false;
+        };
+        // soft values [0, n) of W.joined (or zeros when pad) through the decoder; returns true when the frame is complete
+        auto vit_run = [&](uint32_t n, bool pad) __attribute__((always_inline)) -> bool {
+            for (uint32_t k = 0; k < n;) {
+                if (code_rate == 0) { acs(0, pad ? 0 : W.joined[k], pad ? 0 : W.joined[k + 1]); k += 2; }
+                else { acs(0, pad ? 0 : W.joined[k], pad ? 0 : W.joined[k + 1]); acs(1, pad ? 0 : W.joined[k + 2], 0); acs(2, 0, pad ? 0 : W.joined[k + 3]); k += 4; }
+                if (vit_check()) return true;
+            }
+            return false;
+        };
+        // T11aDesc + TBB11aFrameSink (scramble.hpp:319-349, PHY_11a.hpp:660-692) on W.out -> MPDU slot, error code
+        auto finish_frame = [&]() __attribute__((always_inline)) {
+            wsync();
+            uint8_t* mp = A.mpdu + ((size_t)cap * A.max_frames + min(nfr, A.max_frames - 1)) * 4096;
+            const unsigned seed = W.out[1] >> 1;
+            const unsigned phase = A.T.scr_phase[seed & 0x7F];
+            uint8_t* bytes = reinterpret_cast<uint8_t*>(W.buf);              // 1024 bytes + W.fft behind it: 2048 >= 1500
+            for (uint32_t i = lane; i < ht_len; i += 64) {
+                const unsigned sb = phase == 255 ? 0u : A.T.scr_seq[(phase + 8u * i) % 127u];
+                const unsigned o = W.out[2 + i] ^ sb;
+                bytes[i] = (uint8_t)o; mp[i] = (uint8_t)o;
+            }
+            wsync();
+            const int n = ht_len >= 4 ? (int)ht_len - 4 : 0;
+            uint32_t crc;
+            if (n >= 4) crc = crc32_wave(bytes, n, s_crc, s_z, lane);
+            else { crc = 0xFFFFFFFFu; for (int i = 0; i < n; i++) crc = (crc >> 8) ^ s_crc[(bytes[i] ^ crc) & 0xFF]; }
+            crc = (uint32_t)__builtin_amdgcn_readfirstlane((int)crc);
+            uint32_t fcs = 0;
+            if (ht_len >= 4) fcs = (uint32_t)bytes[ht_len - 4] | ((uint32_t)bytes[ht_len - 3] << 8) | ((uint32_t)bytes[ht_len - 2] << 16) | ((uint32_t)bytes[ht_len - 1] << 24);
+            frame_crc = fcs;
+            err = ((~crc) == fcs) ? E_OK : E_CRC;
+            wsync();
+        };
+        // T11nSigDemap -> T11aDeinterleaveBPSK -> T11nViterbiSig -> T11nSigParser on W.sig
+        auto decode_sig = [&]() __attribute__((always_inline)) {
+            wsync();
+            for (int g = lane; g < 144; g += 64) {
+                const int s3 = g / 48, k = g - 48 * s3;
+                int bin; if (k < 24) bin = 38 + k + (k >= 5) + (k >= 18); else { const int q = k - 24; bin = 1 + q + (q >= 6) + (q >= 19); }
+                const cpx v = unpack(W.sig[64 * s3 + bin]);
+                const int qv = s3 == 0 ? v.re : v.im;
+                W.soft[0][g] = s_lut[0][min(max(qv, -128), 127) + 128];
+            }
+            wsync();
+            for (int g = lane; g < 144; g += 64) { const int s3 = g / 48, kk = g - 48 * s3; W.sigsoft[g] = W.soft[0][48 * s3 + 3 * (kk & 15) + (kk >> 4)]; }
+            wsync();
+            const uint32_t lsig = (uint32_t)(viterbi_sig_wave<24>(W.sigsoft, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6);
+            wsync();
+            const unsigned long long ht = viterbi_sig_wave<48>(W.sigsoft + 48, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6;
+            wsync();
+            bool ok = false;
+            do {
+                const uint32_t sg = lsig & 0xFFFFFF;
+                if (sg & 0xFC0010) break;
+                if (__popc(sg) & 1) break;
+                const uint32_t code = sg & 0xF;
+                if (code < 8) break;                                         // BB11aParseDataRate: 0
+                if (((sg >> 5) & 0xFFF) * 2 > 1500) break;
+                uint32_t crc = 0xFF;
+                for (int b = 0; b < 34; b++) { crc ^= (uint32_t)(ht >> b) & 1; crc = (crc & 1) ? (crc >> 1) ^ 0xE0 : crc >> 1; }
+                if (((~crc) & 0xFF) != (uint32_t)((ht >> 34) & 0x3FFF)) break;
+                const uint32_t mc = (uint32_t)ht & 0x7F;
+                if (mc < 8 || mc >= 11) break;
+                const uint32_t hl = (uint32_t)(ht >> 8) & 0xFFFF;
+                if (hl > 1500) break;
+                mcs = mc; ht_len = hl; code_rate = mc == 10 ? 2u : 0u;
+                tr_end = hl * 8 + 16 + 6;
+                ok = true;
+            } while (0);
+            if (ok) type = SYM_HT_STF; else err = E_PLCP;
+            // the Viterbi of the data field starts from a clean trellis (T11aViterbi::Reset at the frame reset)
+            m = (lane == 0) ? 0u : 0x30u; tr = 0; ob = 0; nout = 0; soft_n = 0;
+            if (lane == 0) W.dec[0] = 0;
+            wsync();
+        };
+
+        uint32_t a = l0 + 128;                                               // start of the next symbol, relative to origin
+        bool more = true;
+        while (more) {
+            const uint32_t n_pad = (n_real + 3) & ~3u;                       // the last burst is delivered zero-padded
+            if (a >= n_pad) {
+                // ------------------------------------------------------- end of the capture: T11nSymSel::Flush on the empty symbol queue
+                if (type == SYM_SIG && nsig > 0 && err == 0) {
+                    for (int k = lane; k < 64 * (3 - nsig); k += 64) W.sig[64 * nsig + k] = 0;
+                    nsig = 0; decode_sig();
+                } else if (type == SYM_DATA && err == 0 && (soft_n % 312) != 0) {
+                    if (vit_run(312 - soft_n % 312, true)) finish_frame();
+                }
+                last_burst_end = n_pad; more = false;
+                break;
+            }
+            // ----------------------------------------------------------- one OFDM symbol of both chains: TFreqComp_11n, CP dropped, two FFTs
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint32_t n = a - l0 + 16 + lane;                       // samples since the L-LTF began
+                const cpx cof = unpack(A.sincos[(unsigned)((int)n * cfo - theta) & 0xFFFFu]);
+                int re, im; mul32(unpack(fetch(r, origin + a + 16 + lane)), cof, re, im);
+                W.buf[r][lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+            }
+            wsync();
+            {
+                const int g = lane >> 4, e = lane & 15; cpx x[4], yy[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) x[q] = unpack(W.buf[g & 1][e + 16 * q]);
+                fft64_group(x, yy, W.fft[g], e, tw, nosync);
+                if (g < 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) W.y[g][64 * (type == SYM_HT_LTF ? nltf : 0) + e + 16 * q] = pack(yy[q]);
+                }
+            }
+            wsync();
+            bool complete = false;
+            if (type == SYM_SIG) {
+                int re, im;
+                mul32(unpack(W.y[0][lane]), unpack(W.ch[0][lane]), re, im); const cpx x0 = mk(sat16(re >> 9), sat16(im >> 9));
+                mul32(unpack(W.y[1][lane]), unpack(W.ch[1][lane]), re, im); const cpx x1 = mk(sat16(re >> 9), sat16(im >> 9));
+                W.sig[64 * nsig + lane] = pack(mk((short)((short)(x0.re + x1.re) >> 1), (short)((short)(x0.im + x1.im) >> 1)));
+                if (++nsig == 3) { nsig = 0; decode_sig(); }
+            } else if (type == SYM_HT_STF) {
+                type = SYM_HT_LTF;
+            } else if (type == SYM_HT_LTF) {
+                if (++nltf == 2) {
+#pragma clang fp contract(off)
+                    // TMimoChannelEst (channel_11n.hpp:329-443), as k_mimo_est11n_batch
+                    nltf = 0; type = SYM_DATA;
+                    const int i = lane, k = i < 32 ? i : i - 64;
+                    const bool negate = !(k >= -28 && k <= 28 && kHtLtf[k + 28] == 1);
+                    cpx hh[2][2];
+#pragma unroll
+                    for (int r = 0; r < 2; r++) {
+                        const cpx p = unpack(W.y[r][i]), q = unpack(W.y[r][i + 64]);
+                        cpx d = sra(csubs(p, q), 1), s = sra(cadds(p, q), 1);
+                        if (negate) { d = mk(neg16(d.re), neg16(d.im)); s = mk(neg16(s.re), neg16(s.im)); }
+                        hh[r][0] = d; hh[r][1] = s;
+                    }
+                    const cf a00 = { (float)hh[0][0].re, (float)hh[0][0].im }, a01 = { (float)hh[0][1].re, (float)hh[0][1].im };
+                    const cf a10 = { (float)hh[1][0].re, (float)hh[1][0].im }, a11 = { (float)hh[1][1].re, (float)hh[1][1].im };
+                    const cf ad = cf_mul(a00, a11), bc = cf_mul(a01, a10);
+                    const cf det = { ad.re - bc.re, ad.im - bc.im };
+                    const float nn = ((det.re * det.re) + (det.im * det.im)) / 65536.0f;
+                    const cf ds = { det.re, -det.im }, m01 = { -a01.re, -a01.im }, m10 = { -a10.re, -a10.im };
+                    const cf r00 = cf_mul(a11, ds), r01 = cf_mul(m01, ds), r10 = cf_mul(m10, ds), r11 = cf_mul(a00, ds);
+                    W.hinv[0][i] = pack(mk(cvtps_sat16(r00.re / nn), cvtps_sat16(r00.im / nn)));
+                    W.hinv[1][i] = pack(mk(cvtps_sat16(r01.re / nn), cvtps_sat16(r01.im / nn)));
+                    W.hinv[2][i] = pack(mk(cvtps_sat16(r10.re / nn), cvtps_sat16(r10.im / nn)));
+                    W.hinv[3][i] = pack(mk(cvtps_sat16(r11.re / nn), cvtps_sat16(r11.im / nn)));
+                }
+            } else if (err == 0) {
+                // TMimoChannelComp -> TPilotTrack_11n -> demap -> de-interleave -> stream parser -> Viterbi
+                const cpx p = unpack(W.y[0][lane]), q = unpack(W.y[1][lane]);
+                int ar, ai, br, bi;
+                mul32(unpack(W.hinv[0][lane]), p, ar, ai); mul32(unpack(W.hinv[1][lane]), q, br, bi);
+                W.xs[0][lane] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+                mul32(unpack(W.hinv[2][lane]), p, ar, ai); mul32(unpack(W.hinv[3][lane]), q, br, bi);
+                W.xs[1][lane] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+                wsync();
+                {
+                    const int pb[4] = { 64 - 21, 64 - 7, 7, 21 };
+                    int t[2];
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        int th = 0;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) { const cpx v = unpack(W.xs[s][pb[k]]); th += dsp_atan16(A.atan, v.re, v.im); }
+                        t[s] = (int)(short)(th >> 2);
+                    }
+                    theta = (int)(short)(theta + (int)(short)((t[0] + t[1]) >> 1));
+                }
+                const int nb = mcs == 8 ? 1 : 2;
+                if (lane < 52) {
+#pragma unroll
+                    for (int s = 0; s < 2; s++) {
+                        const cpx x = unpack(W.xs[s][data_bin(lane)]);
+                        const int re = min(max(x.re, -128), 127) + 128, im = min(max(x.im, -128), 127) + 128;
+                        if (nb == 1) W.soft[s][lane] = s_lut[0][re];
+                        else { W.soft[s][2 * lane] = s_lut[0][re]; W.soft[s][2 * lane + 1] = s_lut[0][im]; }
+                    }
+                }
+                wsync();
+                for (int g = lane; g < 104 * nb; g += 64) { const int s = g & 1, k = g >> 1; W.joined[g] = W.soft[s][deint11n_index(nb, s, k)]; }
+                wsync();
+                soft_n += 104 * nb;
+                complete = vit_run(104 * nb, false);
+            }
+            if (complete) finish_frame();
+            a += 80;
+            if (err != 0) { last_burst_end = min(a, n_pad); more = false; }
+        }
+        if (err == 0) break;                                                 // the capture ended inside a frame without an event
+        // ================================================================ the event, as RxThread sees it after the source call returns
+        const uint32_t abs_end = origin + last_burst_end;                    // 20 MHz index behind the last burst handed to the graph
+        const uint32_t call = (abs_end - 1) / 14;                            // the call that delivered that burst's last sample
+        const uint32_t next = min(14 * (call + 1), n20);
+        if (lane == 0 && nfr < A.max_frames) {
+            Rx11bRow r; r.end_sample = 2 * next; r.error_code = err; r.rate_kbps = err == E_PLCP ? 0u : mcs; r.length = err == E_PLCP ? 0u : ht_len; r.crc32 = err == E_PLCP ? 0u : frame_crc;
+            rows[nfr] = r;
+        }
+        nfr++;
+        origin = 14 * (call + 1);
+    }
+    if (lane == 0) A.nframes[cap] = nfr;
+}
+
+}  // namespace sora
+
+// ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
+#include <vector>
+#include <string.h>
+using namespace sora;
+
+
+struct sora_rx11n {
+    sora_rx_cfg cfg{};
+    hipStream_t stream = nullptr;
+    CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr;
+    sora_complex16* d_iq_own[2] = { nullptr, nullptr };
+    Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
+    std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
+    uint32_t ncaps = 0; bool have_results = false;
+};
+
+#define HIPCHK11N(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
+
+static void rx11n_free(sora_rx11n_t* rx)
+{
+    if (!rx) return;
+    if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
+    (void)hipFree(rx->d_caps); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_nframes); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_iq_own[0]); (void)hipFree(rx->d_iq_own[1]);
+    delete rx;
+}
+
+int sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out)
+{
+    if (!cfg || !out || cfg->struct_size != sizeof(sora_rx_cfg)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_create: bad cfg", 0);
+    if (cfg->sample_rate_mhz != 40) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_create: the 802.11n graph takes 40 MHz samples (sample_rate_mhz = 40)", 0);
+    if (cfg->max_captures == 0 || cfg->max_total_samples == 0 || cfg->max_frames_per_capture == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "zero capacity", 0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (cfg->device < 0 || cfg->device >= ndev) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "device ordinal out of range", 0);
+    HIPCHK11N(hipSetDevice(cfg->device));
+    sora_rx11n_t* rx = new sora_rx11n();
+    rx->cfg = *cfg;
+    const size_t rows = (size_t)cfg->max_captures * cfg->max_frames_per_capture;
+    hipError_t e = (sora_internal_tables(cfg->device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK) ? hipSuccess : hipErrorUnknown;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, rows * 4096);
+    if (e != hipSuccess) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: device allocation / tables", (int)e); }
+    *out = rx;
+    return SORA_OK;
+}
+
+void* sora_rx11n_stream(sora_rx11n_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+void sora_rx11n_destroy(sora_rx11n_t* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); rx11n_free(rx); } }
+
+int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_process_dev: null argument", 0);
+    if (ncaps > rx->cfg.max_captures) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more captures than max_captures", 0);
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    std::vector<CapDesc>& h = rx->h_desc;
+    HIPCHK11N(hipStreamSynchronize(rx->stream));
+    h.resize(ncaps);
+    uint64_t total = 0;
+    for (size_t i = 0; i < ncaps; i++) {
+        if (caps[i].nsamples % 28 != 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture length must be a whole number of 28-sample source bursts", 0);
+        h[i].offset = caps[i].offset; h[i].nsamples = caps[i].nsamples; h[i].capture_id = caps[i].capture_id; h[i].slot_base = 0; h[i].nslots = 0;
+        total += caps[i].nsamples;
+    }
+    if (total > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more samples than max_total_samples", 0);
+    rx->h_caps.assign(caps, caps + ncaps); rx->ncaps = (uint32_t)ncaps; rx->have_results = true;
+    if (ncaps == 0) return SORA_OK;
+    HIPCHK11N(hipMemcpyAsync(rx->d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, rx->stream));
+    Rx11nArgs A;
+    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.caps = rx->d_caps; A.ncaps = (uint32_t)ncaps;
+    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan;
+    hipLaunchKernelGGL(k_rx11n, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);
+    HIPCHK11N(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const sora_complex16* h_iq1, size_t nsamples, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx || (nsamples && (!h_iq0 || !h_iq1))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_process: null argument", 0);
+    if (nsamples > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process: more samples than max_total_samples", 0);
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    const sora_complex16* src[2] = { h_iq0, h_iq1 };
+    for (int k = 0; k < 2; k++) {
+        if (!rx->d_iq_own[k]) HIPCHK11N(hipMalloc((void**)&rx->d_iq_own[k], sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
+        HIPCHK11N(hipMemcpyAsync(rx->d_iq_own[k], src[k], sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice, rx->stream));
+    }
+    return sora_rx11n_process_dev(rx, rx->d_iq_own[0], rx->d_iq_own[1], caps, ncaps);
+}
+
+int sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results: null argument", 0);
+    *nout = 0;
+    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
+    if (rx->ncaps == 0) return SORA_OK;
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    HIPCHK11N(hipStreamSynchronize(rx->stream));
+    const uint32_t mf = rx->cfg.max_frames_per_capture;
+    std::vector<Rx11bRow> rows((size_t)rx->ncaps * mf); std::vector<uint32_t> nfr(rx->ncaps);
+    HIPCHK11N(hipMemcpy(rows.data(), rx->d_rows, sizeof(Rx11bRow) * rows.size(), hipMemcpyDeviceToHost));
+    HIPCHK11N(hipMemcpy(nfr.data(), rx->d_nframes, 4 * (size_t)rx->ncaps, hipMemcpyDeviceToHost));
+    size_t used_rows = 0;
+    for (uint32_t c = 0; c < rx->ncaps; c++) used_rows += nfr[c] < mf ? nfr[c] : mf;
+    std::vector<uint8_t> bulk;
+    const size_t slots = (size_t)rx->ncaps * mf;
+    if (h_mpdu && used_rows > 16 && slots * 4096 <= ((size_t)1 << 30)) {
+        bulk.resize(slots * 4096);
+        HIPCHK11N(hipMemcpy(bulk.data(), rx->d_mpdu, bulk.size(), hipMemcpyDeviceToHost));
+    }
+    size_t n = 0, moff = 0; int rc = SORA_OK;
+    for (uint32_t c = 0; c < rx->ncaps; c++)
+        for (uint32_t i = 0; i < nfr[c] && i < mf; i++) {
+            const Rx11bRow& r = rows[(size_t)c * mf + i];
+            if (n >= max_out) { rc = SORA_ERR_CAPACITY; continue; }
+            sora_frame_result& o = out[n++];
+            memset(&o, 0, sizeof(o));
+            o.capture_id = rx->h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
+            o.length = (uint16_t)r.length; o.crc32 = r.crc32; o.mpdu_offset = (uint32_t)moff;
+            if (h_mpdu && (r.error_code == 1u || r.error_code == 0x80000006u)) {
+                const size_t len = r.length < 4096 ? r.length : 4096;
+                if (moff + len > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
+                if (!bulk.empty()) memcpy(h_mpdu + moff, bulk.data() + ((size_t)c * mf + i) * 4096, len);
+                else HIPCHK11N(hipMemcpy(h_mpdu + moff, rx->d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
+                moff += len;
+            }
+        }
+    *nout = n;
+    if (rc != SORA_OK) return sora_internal_fail(rc, "sora_rx11n_results: output buffer too small", 0);
+    return SORA_OK;
+}

@@ -92,4 +92,6 @@ __global__ void k_rx11b(Rx11bArgs A);
 
 // sora_hip.cpp: records the message sora_hip_last_error() returns; hip_error = 0 for none
 int sora_internal_fail(int code, const char* what, int hip_error);
-const uint32_t* sora_internal_crc_table(int device);   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr
+const uint32_t* sora_internal_crc_table(int device);
+int sora_internal_tables(int device, sora::Tables* out);                  // the per-device tables of the stage entry points (uploaded on first use)
+int sora_internal_dsp_tables(const uint32_t** sincos, const short** atan);  // dsp_math tables of the current device (k_11n.hip)   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr

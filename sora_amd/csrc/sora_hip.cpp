@@ -235,6 +235,13 @@ static DevTables* stage_tables()
 }
 
 int sora_internal_fail(int code, const char* what, int hip_error) { return fail(code, what, (hipError_t)hip_error); }
+int sora_internal_tables(int device, sora::Tables* out)
+{
+    if (hipSetDevice(device) != hipSuccess) return SORA_ERR_HARDWARE_FAILED;
+    DevTables* D = stage_tables();
+    if (!D) return SORA_ERR_HARDWARE_FAILED;
+    *out = D->T; return SORA_OK;
+}
 const uint32_t* sora_internal_crc_table(int device)
 {
     if (hipSetDevice(device) != hipSuccess) return nullptr;

@@ -1,0 +1,63 @@
+"""802.11n 2x2 receive graph on the GPU (sora_rx11n_*, k_rx11n.hip) against the recorded events of the reference graph
+(tests/golden/refgraph_11n.npz) and against the CPU oracle on random two-chain captures."""
+import numpy as np
+import pytest
+
+from gpu_util import capture_11n, same_events_11n
+from oracle.pyoracle import Oracle
+from test_oracle_11n_graph import golden_captures
+
+pytestmark = pytest.mark.gpu
+
+
+def run_batch(caps, max_frames=8):
+    import torch
+    import sora_amd
+    n = sum(len(a) for a, _ in caps)
+    iq0 = np.concatenate([a for a, _ in caps]); iq1 = np.concatenate([b for _, b in caps])
+    descs = []; off = 0
+    for i, (a, _) in enumerate(caps):
+        descs.append((off, len(a), i)); off += len(a)
+    rx = sora_amd.Rx11n(len(caps), n, max_frames_per_capture=max_frames)
+    rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), descs)
+    per = [[] for _ in caps]
+    for r in rx.results():
+        per[r["capture_id"]].append(r)
+    return per
+
+
+def test_gpu_equals_recorded_reference_events():
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    gold = list(golden_captures())
+    got = run_batch([(a, b) for a, b, _, _, _ in gold])
+    for i, (a, b, want, _, z) in enumerate(gold):
+        key = lambda e: (e["error_code"], e["rate_kbps"], e["length"], e["crc32"]) if e["error_code"] != 0x80000005 else (e["error_code"],)
+        assert [key(e) for e in got[i]] == [key(e) for e in want], i
+        for e in got[i]:
+            if e["error_code"] == 1:
+                assert e["mpdu"][:-4] == z["mpdu%d" % {8: 0, 9: 1, 10: 2}[e["rate_kbps"]]].tobytes()
+
+
+def test_gpu_equals_oracle_on_random_captures():
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    o = Oracle()
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rng = np.random.default_rng(77)
+    caps = []
+    for t in range(160):
+        fr = [frames[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 4)))]
+        caps.append(capture_11n(rng, fr, sigma=float(rng.choice([5, 20, 60, 200, 600])), cut=float(rng.uniform(0.2, 1.0)) if t % 3 == 2 else None))
+    got = run_batch(caps)
+    nev = 0
+    for i, (a, b) in enumerate(caps):
+        want = o.rx11n_capture(a, b)
+        ok, why = same_events_11n(got[i], want)
+        assert ok, (i, why, [(hex(e["error_code"]), e["rate_kbps"], e["length"]) for e in got[i]], [(hex(e["error_code"]), e["rate_kbps"], e["length"]) for e in want])
+        assert [e["end_sample"] for e in got[i]] == [e["end_sample"] for e in want], i
+        nev += len(want)
+    assert nev > 150
