@@ -121,6 +121,19 @@ def _cpu_worker_11b(args):
     return k * sample.shape[1] / (time.perf_counter() - t0) / 1e6
 
 
+def _cpu_worker_11n(args):
+    """One host process of the 802.11n CPU baseline: the reference's own 2x2 graph over the sample captures for `seconds`."""
+    path, seconds = args
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    z = np.load(path); a = z["a"]; b = z["b"]
+    g.rx11n_bench(a[:1], b[:1])
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < seconds:
+        g.rx11n_bench(a, b); k += len(a)
+    return k * a.shape[1] / (time.perf_counter() - t0) / 1e6
+
+
 def host_cores():
     """CPUs this process may really use: affinity mask, capped by the cgroup CPU quota when there is one."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -251,6 +264,56 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
         out["cpu_reference_msamples_per_s_one_core"] = round(one, 2)
         out["cpu_reference_msamples_per_s"] = round(sum(allc), 1); out["cpu_reference_cores"] = cores
     rx.close(); del iq, flat
+    return out
+
+
+def bench_11n(torch, sora_amd, dev, ncaps=4096, reps=5):
+    """Row f1 (802.11n 2x2 receive graph): `ncaps` two-chain 40 MHz captures of one MCS 10 frame each (a 1000-byte MPDU from the
+    compiled reference modulator when that library is here, else the recorded 150-byte one of tests/golden/refgraph_11n.npz)
+    through a 2x2 channel with cross-talk, noise added on the device.  8 B per sample pair against the HBM roofline; the
+    reference's own graph is timed on the host cores beside it when oracle/_ref is present."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if g.available():
+        s0, s1 = g.tx11n(np.random.default_rng(12).integers(0, 256, 1000).astype(np.uint8).tobytes(), 10); what = "1000-byte MPDU"
+    else:
+        z = np.load(os.path.join(ROOT, "tests", "golden", "refgraph_11n.npz")); s0, s1 = z["tx2_0"], z["tx2_1"]; what = "150-byte MPDU (recorded modulator output)"
+    n = (len(s0) + 800 + 1200 + 27) // 28 * 28
+    base = np.zeros((2, n, 2), np.float32)
+    base[0, 800:800 + len(s0)] = s0 + 0.1 * s1; base[1, 800:800 + len(s0)] = s1 + 0.1 * s0
+    b = torch.from_numpy(base).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(1103)
+    iq = torch.empty((2, ncaps, n, 2), dtype=torch.int16, device=dev)
+    for i in range(0, ncaps, 64):
+        k = min(64, ncaps - i)
+        for c in range(2):
+            iq[c, i:i + k] = (b[c][None] + 20.0 * torch.randn((k, n, 2), generator=gen, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+    descs = sora_amd.Rx.captures([(i * n, n, i) for i in range(ncaps)])
+    rx = sora_amd.Rx11n(ncaps, ncaps * n, max_frames_per_capture=4)
+    f0 = iq[0].view(-1, 2); f1 = iq[1].view(-1, 2)
+    torch.cuda.synchronize()
+    rx.process_dev(f0, f1, descs); res = rx.results()
+    ok = sum(r["error_code"] == 1 for r in res)
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        rx.process_dev(f0, f1, descs)
+    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    out = {"workload": "%d two-chain captures x one MCS 10 frame, %s (%d samples @40 MHz per chain each), 2x2 cross-talk, AWGN" % (ncaps, what, n),
+           "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
+           "bound": "hbm", "algorithmic_bytes": 8 * ncaps * n, "achieved": round(8.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
+           "unit": "GB/s", "frac": round(8.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
+    if g.available():
+        import multiprocessing as mp
+        import tempfile
+        cores = host_cores()
+        with tempfile.TemporaryDirectory() as d:
+            path = os.path.join(d, "iq11n.npz"); np.savez(path, a=iq[0, :8].cpu().numpy(), b=iq[1, :8].cpu().numpy())
+            with mp.get_context("spawn").Pool(cores) as pool:
+                one = pool.apply(_cpu_worker_11n, ((path, 2.0),))
+                allc = pool.map(_cpu_worker_11n, [(path, 4.0)] * cores)
+        out["cpu_reference_msamples_per_s_one_core"] = round(one, 2)
+        out["cpu_reference_msamples_per_s"] = round(sum(allc), 1); out["cpu_reference_cores"] = cores
+    rx.close(); del iq, f0, f1
     return out
 
 
@@ -410,6 +473,7 @@ def main():
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
             out["tx"] = bench_tx(torch, sora_amd)
             out["rx11b"] = bench_11b(torch, sora_amd, dev)
+            out["rx11n"] = bench_11n(torch, sora_amd, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(iq, nfr)
         print(json.dumps(out))

@@ -447,6 +447,11 @@ class ReferenceGraph:
         assert len(a) == len(b)
         return self._events(lambda p, n, res, mf, mp, cap: self.L.ref_rx11n_capture(p, _P(b), n, res, mf, mp, cap), a, max_frames)
 
+    def rx11n_bench(self, iq0_caps, iq1_caps, reps=1):
+        """iq*_caps: int16 [ncap, n, 2] -> decoded-OK frame count; the RxThread loop of the 11n graph runs inside the library."""
+        a = np.ascontiguousarray(iq0_caps, np.int16); b = np.ascontiguousarray(iq1_caps, np.int16)
+        return self.L.ref_rx11n_bench(_P(a), _P(b), a.shape[0], a.shape[1], reps)
+
     def rx11a_44(self, iq44, max_frames=64):
         """CreateDemodGraph11a_44M (TDownSample44_40 in front) over int16 [n,2] @44 MHz; sample_index in 44 MHz samples."""
         return self._events(self.L.ref_rx11a_capture44, iq44, max_frames)

@@ -243,7 +243,7 @@ EXPORT int ref_rx11n_capture(const int16_t* iq0, const int16_t* iq1, uint32_t ns
             }
             if (n < max_res) {
                 ref_frame& f = res[n++];
-                f.error_code = err; f.sample_index = 0; f.rate_kbps = BB11nDemodCtx.CF_HTRxVector::ht_frame_mcs();
+                f.error_code = err; f.sample_index = BB11nDemodCtx.CF_MemSamples::mem_sample_index(); f.rate_kbps = BB11nDemodCtx.CF_HTRxVector::ht_frame_mcs();
                 f.length = BB11nDemodCtx.CF_HTRxVector::ht_frame_length(); f.crc32 = BB11nDemodCtx.CF_11aRxVector::crc32(); f.mpdu_offset = used;
                 if ((err == E_ERROR_FRAME_OK || err == E_ERROR_CRC32_FAIL) && used + f.length <= mpdu_cap) { memcpy(mpdu + used, out, f.length); used += f.length; }
             }
@@ -252,6 +252,18 @@ EXPORT int ref_rx11n_capture(const int16_t* iq0, const int16_t* iq1, uint32_t ns
         if (!rc) break;
     }
     return n;
+}
+
+// The 802.11n loop over `ncap` equal-sized two-chain captures, `reps` times (bench.py: the reference 11n path on a host core).
+EXPORT uint32_t ref_rx11n_bench(const int16_t* iq0, const int16_t* iq1, uint32_t ncap, uint32_t nsamples40, uint32_t reps)
+{
+    static uint8_t mpdu[16384]; ref_frame res[8]; uint32_t ok = 0;
+    for (uint32_t r = 0; r < reps; r++)
+        for (uint32_t c = 0; c < ncap; c++) {
+            int n = ref_rx11n_capture(iq0 + (size_t)c * nsamples40 * 2, iq1 + (size_t)c * nsamples40 * 2, nsamples40, res, 8, mpdu, sizeof(mpdu));
+            for (int i = 0; i < n; i++) ok += res[i].error_code == E_ERROR_FRAME_OK;
+        }
+    return ok;
 }
 
 // The 802.11b loop over `ncap` equal-sized captures, `reps` times (bench.py: the reference 11b path on a host core).

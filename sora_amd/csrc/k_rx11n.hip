@@ -97,7 +97,7 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
     while (origin < n20) {
         // ================================================================ carrier sense from `origin`
         const uint32_t nb_total = (n20 - origin + 3) / 4;                    // bursts TDownSample2 will deliver (the last one zero-padded)
-        bool pf = false; int pc = 0;                                         // peak_found, peak_count (_reset)
+        bool pf = false, timeout = false; int pc = 0, sense = 0;             // peak_found, peak_count, sense_count (_reset)
         int64_t det_at = -1;                                                 // sample (relative to origin) at which power was detected
         for (uint32_t base = 0; base < nb_total * 4 && det_at < 0; base += 64) {
             const int lim = (int)min(64u, nb_total * 4 - base);
@@ -131,9 +131,17 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             int det = -1;
             for (int i = 0; i < lim; i++) {                                  // cca_11n.hpp:46-121, on the two ballots
                 const bool a = (bA >> i) & 1, b = (bB >> i) & 1;
-                if (!pf) { if (a) { pc++; pf = true; } else pc = 0; }
+                if (!pf) { sense++; if (a) { sense = 0; pc++; pf = true; } else pc = 0; }
                 else if (b) { const bool good = pc > 96 && pc < 160; pf = false; pc = 0; if (good) { det = i; break; } }
                 else { pc++; if (pc > 160) { pf = false; pc = 0; } }
+                if ((i & 3) == 3) {
+                    // end of a burst: the carrier-sense timeout is raised here (cca_11n.hpp:124-127) and acted on by RxThread when the
+                    // source call returns (ResetCarrierSense + scs->Reset, fb11n_demod.cpp:44-52) -- which clears the peak counter
+                    // even if a plateau has begun in the bursts between
+                    if (sense >= 84) timeout = true;
+                    const uint32_t s4 = base + (uint32_t)i - 3;             // first sample of this burst, relative to origin
+                    if (timeout && (s4 + 3) / 14 != (s4 + 7) / 14) { timeout = false; pf = false; pc = 0; sense = 0; }
+                }
             }
             const int ne = det >= 0 ? det : lim;                             // samples recorded in his_moving_energy
             const int na = det >= 0 ? (det | 3) + 1 : lim;                   // samples MimoAutoCorr has taken (whole bursts)

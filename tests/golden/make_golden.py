@@ -194,18 +194,18 @@ def main():
     plan = [((0,), None, 20), ((1, 2), None, 40), ((3, 0, 1), None, 10), ((2,), 0.97, 20), ((0, 1), 0.6, 30), ((1,), 0.35, 20), ((2, 2, 0), None, 150), ((0,), 0.995, 5)]
     g11["plan_frames"] = np.array([",".join(map(str, p[0])) for p in plan]); g11["plan_cut"] = np.array([-1.0 if p[1] is None else p[1] for p in plan])
     g11["plan_sigma"] = np.array([p[2] for p in plan], np.float64)
-    ev = {"count": [], "err": [], "mcs": [], "length": [], "crc": []}; det = []
+    ev = {"count": [], "err": [], "mcs": [], "length": [], "crc": [], "pos": []}; det = []
     rng = np.random.default_rng(1145)
     for fr, cut, sg in plan:
         a, b = capture_11n(rng, [frames[i] for i in fr], sigma=sg, cut=cut)
         e = G.rx11n(a, b)
         ev["count"].append(len(e))
         for x in e:
-            ev["err"].append(x["error_code"]); ev["mcs"].append(x["rate_kbps"]); ev["length"].append(x["length"]); ev["crc"].append(x["crc32"])
+            ev["pos"].append(x["sample_index"]); ev["err"].append(x["error_code"]); ev["mcs"].append(x["rate_kbps"]); ev["length"].append(x["length"]); ev["crc"].append(x["crc32"])
         n4 = len(a) // 2 // 4 * 4
         d = G.cca11n(a[::2][:n4], b[::2][:n4], skip=0); det.append(",".join(map(str, d)))
     g11["ev_count"] = np.array(ev["count"], np.int32); g11["ev_err"] = np.array(ev["err"], np.uint32); g11["ev_mcs"] = np.array(ev["mcs"], np.uint32)
-    g11["ev_length"] = np.array(ev["length"], np.uint32); g11["ev_crc"] = np.array(ev["crc"], np.uint32); g11["cca_detect"] = np.array(det)
+    g11["ev_pos"] = np.array(ev["pos"], np.uint32); g11["ev_length"] = np.array(ev["length"], np.uint32); g11["ev_crc"] = np.array(ev["crc"], np.uint32); g11["cca_detect"] = np.array(det)
     np.savez_compressed(os.path.join(OUT, "refgraph_11n.npz"), **g11)
     print("written", os.listdir(OUT))
 

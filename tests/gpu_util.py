@@ -262,14 +262,16 @@ def capture_11n(rng, frames, sigma=20.0, cut=None):
     return q(a), q(b)
 
 
-def same_events_11n(got, want):
-    """events of the 802.11n graph: error code always; MCS, length, FCS and MPDU unless the header failed (the reference then reports
+def same_events_11n(got, want, position=None):
+    """events of the 802.11n graph: error code always (and the 40 MHz source position, `position` = key of it in `want`); MCS, length, FCS and MPDU unless the header failed (the reference then reports
     whatever an earlier frame left in its context)"""
     if len(got) != len(want):
         return False, "event count %d != %d" % (len(got), len(want))
     for i, (x, y) in enumerate(zip(got, want)):
         if x["error_code"] != y["error_code"]:
             return False, "event %d: error %#x != %#x" % (i, x["error_code"], y["error_code"])
+        if position is not None and x["end_sample"] != y[position]:
+            return False, "event %d: position %d != %d" % (i, x["end_sample"], y[position])
         if x["error_code"] != 0x80000005 and (x["rate_kbps"], x["length"], x["crc32"], x["mpdu"]) != (y["rate_kbps"], y["length"], y["crc32"], y["mpdu"]):
             return False, "event %d differs" % i
     return True, ""

@@ -35,6 +35,7 @@ def test_gpu_equals_recorded_reference_events():
     for i, (a, b, want, _, z) in enumerate(gold):
         key = lambda e: (e["error_code"], e["rate_kbps"], e["length"], e["crc32"]) if e["error_code"] != 0x80000005 else (e["error_code"],)
         assert [key(e) for e in got[i]] == [key(e) for e in want], i
+        assert [e["end_sample"] for e in got[i]] == [e["sample_index"] for e in want], i
         for e in got[i]:
             if e["error_code"] == 1:
                 assert e["mpdu"][:-4] == z["mpdu%d" % {8: 0, 9: 1, 10: 2}[e["rate_kbps"]]].tobytes()

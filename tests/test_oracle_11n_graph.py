@@ -23,7 +23,7 @@ def golden_captures():
     rng = np.random.default_rng(1145); k = 0
     for fr, cut, sg, cnt, det in zip(z["plan_frames"], z["plan_cut"], z["plan_sigma"], z["ev_count"], z["cca_detect"]):
         a, b = capture_11n(rng, [frames[int(i)] for i in str(fr).split(",")], sigma=float(sg), cut=None if cut < 0 else float(cut))
-        want = [dict(error_code=int(z["ev_err"][j]), rate_kbps=int(z["ev_mcs"][j]), length=int(z["ev_length"][j]), crc32=int(z["ev_crc"][j])) for j in range(k, k + cnt)]
+        want = [dict(sample_index=int(z["ev_pos"][j]), error_code=int(z["ev_err"][j]), rate_kbps=int(z["ev_mcs"][j]), length=int(z["ev_length"][j]), crc32=int(z["ev_crc"][j])) for j in range(k, k + cnt)]
         k += cnt
         yield a, b, want, [int(x) for x in str(det).split(",") if x], z
 
@@ -34,6 +34,7 @@ def test_oracle_equals_recorded_reference_events(o):
         got = o.rx11n_capture(a, b)
         assert [(e["error_code"], e["rate_kbps"], e["length"], e["crc32"]) if e["error_code"] != 0x80000005 else (e["error_code"],) for e in got] == \
                [(e["error_code"], e["rate_kbps"], e["length"], e["crc32"]) if e["error_code"] != 0x80000005 else (e["error_code"],) for e in want]
+        assert [e["end_sample"] for e in got] == [e["sample_index"] for e in want]
         for e in got:
             if e["error_code"] == 1:
                 i = {8: 0, 9: 1, 10: 2}[e["rate_kbps"]]
@@ -58,7 +59,7 @@ def test_oracle_equals_reference_graph_live(o):
             frames.append(g.tx11n(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), mcs))
         a, b = capture_11n(rng, frames, sigma=float(rng.choice([5, 20, 60, 200])), cut=float(rng.uniform(0.3, 1.0)) if t % 3 == 2 else None)
         want = g.rx11n(a, b); got = o.rx11n_capture(a, b)
-        ok, why = same_events_11n(got, want)
+        ok, why = same_events_11n(got, want, position="sample_index")
         assert ok, (t, why)
         nev += len(want)
         n4 = len(a) // 2 // 4 * 4; skip = int(rng.integers(0, 500))
