@@ -51,12 +51,18 @@ struct WaveLds {
     uint8_t  soft[2][160];                                          // demapped soft values per stream (<= 104); [0] doubles as SIG scratch
     uint8_t  joined[208];                                           // stream-parsed, de-interleaved soft values of one symbol
     uint8_t  sigsoft[144];
+    uint8_t  dtab[208];                                             // joined position g (stream g & 1) <- soft[g & 1][dtab[g]], for this frame's N_BPSC
     unsigned long long dec[256];                                    // decision words of the last 256 trellis columns
     uint8_t  out[1536];                                             // decoded bytes (service field first)
 };
 
 __device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
+__device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }            // a value every lane holds alike -> SGPR
+__device__ __forceinline__ unsigned long long uni64(unsigned long long v)
+{
+    return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
+}
 __device__ __forceinline__ int scan_add(int v, int lane)               // inclusive prefix sum over the wave, wrapping
 {
 #pragma unroll
@@ -75,7 +81,7 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
     s_crc[threadIdx.x] = A.T.crc[threadIdx.x];
     for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) s_z[i] = A.T.crcz[i];
     __syncthreads();
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));       // wave-uniform by construction: keep it in an SGPR
     const uint32_t cap = blockIdx.x * 4 + wv;
     if (cap >= A.ncaps) return;                                              // whole waves leave; no block barrier below
     WaveLds& W = s_w[wv];
@@ -125,10 +131,24 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             const long long energy = (long long)ev * ev;
             const long long olde = W.his_e[(his_index + lane) & 63];
             // eb = energy / (olde + 1) > 5  <=>  olde + 1 <= energy / 6   (olde = LLONG_MAX: the sum wraps negative and eb is 0)
-            const bool cA = olde != 0x7FFFFFFFFFFFFFFFll && (olde + 1) <= energy / 6 && acorr > (energy >> 1);
+            // (den <= energy / 6  <=>  6 den <= energy; the first test keeps 6 den inside 63 bits)
+            const bool cA = olde != 0x7FFFFFFFFFFFFFFFll && (olde + 1) <= (energy >> 2) && 6 * (olde + 1) <= energy && acorr > (energy >> 1);
             const bool cB = acorr < (energy >> 3);
             const unsigned long long bA = __ballot(cA), bB = __ballot(cB);
             int det = -1;
+            const unsigned long long lmask = lim >= 64 ? ~0ull : ((1ull << lim) - 1);
+            if (!pf && (bA & lmask) == 0) {
+                // idle block: no sample starts a plateau; only the timeout bookkeeping moves, burst by burst
+                for (int i = 3; i < lim; i += 4) {
+                    sense += 4;
+                    if (sense >= 84) timeout = true;
+                    const uint32_t s4 = base + (uint32_t)i - 3;
+                    if (timeout && (s4 + 3) / 14 != (s4 + 7) / 14) { timeout = false; sense = 0; }
+                }
+                pc = 0;
+            } else if (pf && !timeout && (bB & lmask) == 0 && pc + lim <= 160) {
+                pc += lim;                                                   // inside a plateau: every sample counts, nothing else changes
+            } else
             for (int i = 0; i < lim; i++) {                                  // cca_11n.hpp:46-121, on the two ballots
                 const bool a = (bA >> i) & 1, b = (bB >> i) & 1;
                 if (!pf) { sense++; if (a) { sense = 0; pc++; pf = true; } else pc = 0; }
@@ -171,7 +191,7 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             }
 #pragma unroll
             for (int d = 32; d >= 1; d >>= 1) { sre += __shfl_xor(sre, d); sim += __shfl_xor(sim, d); }
-            cfo = dsp_atan32(A.atan, sre, sim) >> 6;
+            cfo = uni(dsp_atan32(A.atan, sre, sim) >> 6);
         }
         int theta = 0;
 #pragma unroll
@@ -240,12 +260,16 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
             wsync();
             uint32_t col = tr;
-            for (uint32_t i = 0; i < look; i++) { col--; pos = (pos >> 1) & 0x3F; pos |= (int)((W.dec[col & 255] >> pos) & 1) << 6; }
+            for (uint32_t i = 0; i < look; i++) { col--; pos = (pos >> 1) & 0x3F; pos |= (int)((uni64(W.dec[col & 255]) >> pos) & 1) << 6; }
             uint32_t po = nout + (bits >> 3);
             for (uint32_t i = 0; i < bits >> 3; i++) {
+                unsigned long long d[8];
+#pragma unroll
+                for (int j = 0; j < 8; j++) d[j] = uni64(W.dec[(col - 1 - j) & 255]);      // the eight columns of this byte do not depend on the walk
                 unsigned oc = 0;
-                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | ((unsigned)(pos >> 6) & 1u)) & 0xFF; col--; pos = (pos >> 1) & 0x3F; pos |= (int)((W.dec[col & 255] >> pos) & 1) << 6; }
-                po--;
+#pragma unroll
+                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | ((unsigned)(pos >> 6) & 1u)) & 0xFF; pos = (pos >> 1) & 0x3F; pos |= (int)((d[j] >> pos) & 1) << 6; }
+                col -= 8; po--;
                 if (lane == 0 && po < sizeof(W.out)) W.out[po] = (uint8_t)oc;
             }
             nout += bits >> 3; ob += bits;
@@ -286,8 +310,8 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             crc = (uint32_t)__builtin_amdgcn_readfirstlane((int)crc);
             uint32_t fcs = 0;
             if (ht_len >= 4) fcs = (uint32_t)bytes[ht_len - 4] | ((uint32_t)bytes[ht_len - 3] << 8) | ((uint32_t)bytes[ht_len - 2] << 16) | ((uint32_t)bytes[ht_len - 1] << 24);
-            frame_crc = fcs;
-            err = ((~crc) == fcs) ? E_OK : E_CRC;
+            frame_crc = (uint32_t)uni((int)fcs);
+            err = ((~crc) == frame_crc) ? E_OK : E_CRC;
             wsync();
         };
         // T11nSigDemap -> T11aDeinterleaveBPSK -> T11nViterbiSig -> T11nSigParser on W.sig
@@ -303,9 +327,9 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             wsync();
             for (int g = lane; g < 144; g += 64) { const int s3 = g / 48, kk = g - 48 * s3; W.sigsoft[g] = W.soft[0][48 * s3 + 3 * (kk & 15) + (kk >> 4)]; }
             wsync();
-            const uint32_t lsig = (uint32_t)(viterbi_sig_wave<24>(W.sigsoft, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6);
+            const uint32_t lsig = (uint32_t)uni((int)(uint32_t)(viterbi_sig_wave<24>(W.sigsoft, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6));
             wsync();
-            const unsigned long long ht = viterbi_sig_wave<48>(W.sigsoft + 48, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6;
+            const unsigned long long ht = uni64(viterbi_sig_wave<48>(W.sigsoft + 48, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6);
             wsync();
             bool ok = false;
             do {
@@ -326,10 +350,11 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
                 tr_end = hl * 8 + 16 + 6;
                 ok = true;
             } while (0);
-            if (ok) type = SYM_HT_STF; else err = E_PLCP;
+            type = ok ? (int)SYM_HT_STF : type; err = ok ? err : E_PLCP;     // (two selects: `if (ok) a = ..; else b = ..;` would become a store through a selected pointer and pin both to scratch)
             // the Viterbi of the data field starts from a clean trellis (T11aViterbi::Reset at the frame reset)
             m = (lane == 0) ? 0u : 0x30u; tr = 0; ob = 0; nout = 0; soft_n = 0;
             if (lane == 0) W.dec[0] = 0;
+            { const int nb = mcs == 8 ? 1 : 2; for (int g = lane; g < 104 * nb; g += 64) W.dtab[g] = (uint8_t)deint11n_index(nb, g & 1, g >> 1); }
             wsync();
         };
 
@@ -413,17 +438,14 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
                 mul32(unpack(W.hinv[2][lane]), p, ar, ai); mul32(unpack(W.hinv[3][lane]), q, br, bi);
                 W.xs[1][lane] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
                 wsync();
-                {
-                    const int pb[4] = { 64 - 21, 64 - 7, 7, 21 };
-                    int t[2];
-#pragma unroll
-                    for (int s = 0; s < 2; s++) {
-                        int th = 0;
-#pragma unroll
-                        for (int k = 0; k < 4; k++) { const cpx v = unpack(W.xs[s][pb[k]]); th += dsp_atan16(A.atan, v.re, v.im); }
-                        t[s] = (int)(short)(th >> 2);
-                    }
-                    theta = (int)(short)(theta + (int)(short)((t[0] + t[1]) >> 1));
+                {   // TPilotTrack_11n: lane 4 s + k takes pilot k of stream s
+                    const int k = lane & 3, sidx = (lane >> 2) & 1;
+                    const int pbin = k == 0 ? 64 - 21 : k == 1 ? 64 - 7 : k == 2 ? 7 : 21;
+                    const cpx v = unpack(W.xs[sidx][pbin]);
+                    int th = dsp_atan16(A.atan, v.re, v.im);
+                    th += __shfl_xor(th, 1); th += __shfl_xor(th, 2);
+                    const int t0 = (int)(short)(uni(__shfl(th, 0)) >> 2), t1 = (int)(short)(uni(__shfl(th, 4)) >> 2);
+                    theta = (int)(short)(theta + (int)(short)((t0 + t1) >> 1));
                 }
                 const int nb = mcs == 8 ? 1 : 2;
                 if (lane < 52) {
@@ -436,7 +458,7 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
                     }
                 }
                 wsync();
-                for (int g = lane; g < 104 * nb; g += 64) { const int s = g & 1, k = g >> 1; W.joined[g] = W.soft[s][deint11n_index(nb, s, k)]; }
+                for (int g = lane; g < 104 * nb; g += 64) W.joined[g] = W.soft[g & 1][W.dtab[g]];
                 wsync();
                 soft_n += 104 * nb;
                 complete = vit_run(104 * nb, false);
