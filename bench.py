@@ -267,7 +267,7 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
     return out
 
 
-def bench_11n(torch, sora_amd, dev, ncaps=4096, reps=5):
+def bench_11n(torch, sora_amd, dev, ncaps=8192, reps=5):
     """Row f1 (802.11n 2x2 receive graph): `ncaps` two-chain 40 MHz captures of one MCS 10 frame each (a 1000-byte MPDU from the
     compiled reference modulator when that library is here, else the recorded 150-byte one of tests/golden/refgraph_11n.npz)
     through a 2x2 channel with cross-talk, noise added on the device.  8 B per sample pair against the HBM roofline; the

@@ -22,6 +22,7 @@
 #include "kernels.h"
 #include "dev_11n.h"
 #include "../../include/sora_hip.h"
+#include <type_traits>
 
 namespace sora {
 
@@ -49,7 +50,7 @@ struct WaveLds {
     uint32_t sig[192];
     uint32_t xs[2][64];                                             // spatial streams after TMimoChannelComp
     uint8_t  soft[2][160];                                          // demapped soft values per stream (<= 104); [0] doubles as SIG scratch
-    uint8_t  joined[208];                                           // stream-parsed, de-interleaved soft values of one symbol
+    alignas(4) uint8_t joined[256];                                           // stream-parsed, de-interleaved soft values of one symbol
     uint8_t  sigsoft[144];
     uint8_t  dtab[208];                                             // joined position g (stream g & 1) <- soft[g & 1][dtab[g]], for this frame's N_BPSC
     unsigned long long dec[256];                                    // decision words of the last 256 trellis columns
@@ -71,7 +72,7 @@ __device__ __forceinline__ int scan_add(int v, int lane)               // inclus
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
+__global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
 {
     __shared__ WaveLds s_w[4];
     __shared__ uint8_t s_lut[6][256];
@@ -230,20 +231,50 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
         unsigned m = (lane == 0) ? 0u : 0x30u;                               // Viterbi metrics, lane = state
         uint32_t tr = 0, ob = 0, nout = 0, soft_n = 0, tr_end = 0;
         if (lane == 0) W.dec[0] = 0;
-        const int cA0 = __popc(lane & 0155) & 1, cB0 = __popc(lane & 0117) & 1, cA1 = __popc((64 | lane) & 0155) & 1, cB1 = __popc((64 | lane) & 0117) & 1;
+        // The data Viterbi keeps a ROTATING state-to-lane map: at trellis column c lane l holds state rotl6(l, c mod 6).  The two
+        // predecessors j and j + 32 of states 2j and 2j + 1 then sit in lanes that differ in ONE lane bit (5 - c mod 6), so a step needs a
+        // single exchange -- v_permlane32_swap, v_permlane16_swap or a DPP move -- instead of two ds_bpermute round trips.
+        int ph = 0;                                                          // tr mod 6
+        unsigned pbits = 0;                                                  // per column phase q: expected code bits (A0, B0, A1, B1) of this lane's state
+#pragma unroll
+        for (int q = 0; q < 6; q++) {
+            const unsigned n = (((unsigned)lane << q) | ((unsigned)lane >> (6 - q))) & 63u;
+            pbits |= (unsigned)((__popc(n & 0155) & 1) | ((__popc(n & 0117) & 1) << 1) | ((__popc((64 | n) & 0155) & 1) << 2) | ((__popc((64 | n) & 0117) & 1) << 3)) << (4 * q);
+        }
         uint32_t last_burst_end = 0;                                         // sample (relative) behind the burst that raised the event
 
         // one trellis step; which: 0 = (A,B), 1 = A only, 2 = B only (viterbi.hpp:166-187)
-        auto acs = [&](int which, int va, int vb) __attribute__((always_inline)) {
-            const unsigned m0 = (unsigned)__shfl((int)m, lane >> 1), m1 = (unsigned)__shfl((int)m, 32 + (lane >> 1));
-            unsigned b0 = 0, b1 = 0;
-            if (which != 2) { b0 += cA0 ? 2 * (7 - va) : 2 * va; b1 += cA1 ? 2 * (7 - va) : 2 * va; }
-            if (which != 1) { b0 += cB0 ? 2 * (7 - vb) : 2 * vb; b1 += cB1 ? 2 * (7 - vb) : 2 * vb; }
+        // one trellis step from column phase PH (= tr mod 6, a compile-time constant); which: 0 = (A,B), 1 = A only, 2 = B only (viterbi.hpp:166-187)
+        auto acs_c = [&](auto PHC, int which, int va, int vb) __attribute__((always_inline)) {
+            constexpr int PH = decltype(PHC)::value, Q = PH == 5 ? 0 : PH + 1;
+            unsigned other;                                                  // the metric of the lane whose state differs in the top state bit
+            if constexpr (PH == 0) { const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false); other = lane < 32 ? r[1] : r[0]; }
+            else if constexpr (PH == 1) { const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false); other = (lane & 16) ? r[0] : r[1]; }
+            else if constexpr (PH == 2) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true);                     // row_ror:8 = lane ^ 8
+            else if constexpr (PH == 3) other = (unsigned)__builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);   // row_half_mirror, then quads reversed = lane ^ 4
+            else if constexpr (PH == 4) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);                      // quad_perm [2,3,0,1] = lane ^ 2
+            else other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);                                          // quad_perm [1,0,3,2] = lane ^ 1
+            const bool hi = (lane >> (5 - PH)) & 1;                          // this lane holds predecessor j + 32 (and will hold successor 2j + 1)
+            const unsigned m0 = hi ? other : m, m1 = hi ? m : other;
+            const unsigned pb = pbits >> (4 * Q);
+            unsigned b0 = 0, b1 = 0;                                         // bm(v, bit) = bit ? 2 (7 - v) : 2 v = 2 (v ^ (bit ? 7 : 0))
+            if (which != 2) { b0 += 2 * ((unsigned)va ^ ((0u - (pb & 1)) & 7u)); b1 += 2 * ((unsigned)va ^ ((0u - ((pb >> 2) & 1)) & 7u)); }
+            if (which != 1) { b0 += 2 * ((unsigned)vb ^ ((0u - ((pb >> 1) & 1)) & 7u)); b1 += 2 * ((unsigned)vb ^ ((0u - ((pb >> 3) & 1)) & 7u)); }
             const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
             m = min(c0, c1);
-            tr++;
+            tr++; ph = Q;
             const unsigned long long d = __ballot(m & 1);
-            if (lane == 0) W.dec[tr & 255] = d;
+            W.dec[tr & 255] = d;                                             // every lane stores the same word: no exec juggling in the step
+        };
+        auto acs = [&](int which, int va, int vb) __attribute__((always_inline)) {      // the same from a run-time phase (symbol edges)
+            switch (ph) {
+            case 0: acs_c(std::integral_constant<int, 0>{}, which, va, vb); break;
+            case 1: acs_c(std::integral_constant<int, 1>{}, which, va, vb); break;
+            case 2: acs_c(std::integral_constant<int, 2>{}, which, va, vb); break;
+            case 3: acs_c(std::integral_constant<int, 3>{}, which, va, vb); break;
+            case 4: acs_c(std::integral_constant<int, 4>{}, which, va, vb); break;
+            default: acs_c(std::integral_constant<int, 5>{}, which, va, vb); break;
+            }
         };
         auto normalize = [&]() __attribute__((always_inline)) {
             unsigned mn = m;
@@ -253,14 +284,20 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
         };
         // Traceback (viterbicore.h:468-555) of `bits` bits behind `look` columns, appended to W.out
         auto traceback = [&](uint32_t bits, uint32_t look) __attribute__((always_inline)) {
-            unsigned kmin = (m << 8) | ((unsigned)lane << 2);
+            const unsigned st = (((unsigned)lane << ph) | ((unsigned)lane >> (6 - ph))) & 63u;     // the state this lane holds now
+            unsigned kmin = (m << 8) | (st << 2);
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
             kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
             int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
             wsync();
-            uint32_t col = tr;
-            for (uint32_t i = 0; i < look; i++) { col--; pos = (pos >> 1) & 0x3F; pos |= (int)((uni64(W.dec[col & 255]) >> pos) & 1) << 6; }
+            uint32_t col = tr; int cm = ph;                                  // cm = col mod 6: the decision of state s at column c is bit rotr6(s, c mod 6)
+            auto back = [&](unsigned long long d) __attribute__((always_inline)) {
+                pos = (pos >> 1) & 0x3F;
+                const unsigned ln = (((unsigned)pos >> cm) | ((unsigned)pos << (6 - cm))) & 63u;
+                pos |= (int)((d >> ln) & 1) << 6;
+            };
+            for (uint32_t i = 0; i < look; i++) { col--; cm = cm == 0 ? 5 : cm - 1; back(uni64(W.dec[col & 255])); }
             uint32_t po = nout + (bits >> 3);
             for (uint32_t i = 0; i < bits >> 3; i++) {
                 unsigned long long d[8];
@@ -268,7 +305,7 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
                 for (int j = 0; j < 8; j++) d[j] = uni64(W.dec[(col - 1 - j) & 255]);      // the eight columns of this byte do not depend on the walk
                 unsigned oc = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | ((unsigned)(pos >> 6) & 1u)) & 0xFF; pos = (pos >> 1) & 0x3F; pos |= (int)((d[j] >> pos) & 1) << 6; }
+                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | ((unsigned)(pos >> 6) & 1u)) & 0xFF; cm = cm == 0 ? 5 : cm - 1; back(d[j]); }
                 col -= 8; po--;
                 if (lane == 0 && po < sizeof(W.out)) W.out[po] = (uint8_t)oc;
             }
@@ -283,10 +320,34 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
         };
         // soft values [0, n) of W.joined (or zeros when pad) through the decoder; returns true when the frame is complete
         auto vit_run = [&](uint32_t n, bool pad) __attribute__((always_inline)) -> bool {
-            for (uint32_t k = 0; k < n;) {
-                if (code_rate == 0) { acs(0, pad ? 0 : W.joined[k], pad ? 0 : W.joined[k + 1]); k += 2; }
-                else { acs(0, pad ? 0 : W.joined[k], pad ? 0 : W.joined[k + 1]); acs(1, pad ? 0 : W.joined[k + 2], 0); acs(2, 0, pad ? 0 : W.joined[k + 3]); k += 4; }
-                if (vit_check()) return true;
+            uint32_t k = 0;
+            // the symbol's soft values, four per lane, fetched from LDS once; a step reads them with v_readlane (no LDS round trip per step)
+            const uint32_t jw = pad ? 0u : reinterpret_cast<const uint32_t*>(W.joined)[lane & 63];
+            auto sv = [&](uint32_t i) __attribute__((always_inline)) -> int { return (int)(((uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(i >> 2)) >> (8 * (i & 3))) & 0xFFu); };
+            using std::integral_constant;
+            while (k < n) {
+                // six steps with the exchange pattern known at compile time, where no trace-back can become due inside them (only the
+                // normalisation, every eighth column, has to be looked after)
+                const uint32_t due = min(tr_end, ob + 192 + 36 + 6);
+                if (ph == 0 && tr + 6 < due && code_rate == 0 && k + 12 <= n) {
+                    acs_c(integral_constant<int, 0>{}, 0, sv(k), sv(k + 1));       if ((tr & 7) == 0) normalize();
+                    acs_c(integral_constant<int, 1>{}, 0, sv(k + 2), sv(k + 3));   if ((tr & 7) == 0) normalize();
+                    acs_c(integral_constant<int, 2>{}, 0, sv(k + 4), sv(k + 5));   if ((tr & 7) == 0) normalize();
+                    acs_c(integral_constant<int, 3>{}, 0, sv(k + 6), sv(k + 7));   if ((tr & 7) == 0) normalize();
+                    acs_c(integral_constant<int, 4>{}, 0, sv(k + 8), sv(k + 9));   if ((tr & 7) == 0) normalize();
+                    acs_c(integral_constant<int, 5>{}, 0, sv(k + 10), sv(k + 11)); if ((tr & 7) == 0) normalize();
+                    k += 12;
+                } else if (ph == 0 && tr + 6 < due && code_rate != 0 && k + 8 <= n) {
+                    acs_c(integral_constant<int, 0>{}, 0, sv(k), sv(k + 1)); acs_c(integral_constant<int, 1>{}, 1, sv(k + 2), 0); acs_c(integral_constant<int, 2>{}, 2, 0, sv(k + 3));
+                    if ((tr & 7) == 0) normalize();
+                    acs_c(integral_constant<int, 3>{}, 0, sv(k + 4), sv(k + 5)); acs_c(integral_constant<int, 4>{}, 1, sv(k + 6), 0); acs_c(integral_constant<int, 5>{}, 2, 0, sv(k + 7));
+                    if ((tr & 7) == 0) normalize();
+                    k += 8;
+                } else {
+                    acs(0, sv(k), sv(k + 1));
+                    if (code_rate != 0) { acs(1, sv(k + 2), 0); acs(2, 0, sv(k + 3)); k += 4; } else k += 2;
+                    if (vit_check()) return true;
+                }
             }
             return false;
         };
@@ -352,7 +413,7 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
             } while (0);
             type = ok ? (int)SYM_HT_STF : type; err = ok ? err : E_PLCP;     // (two selects: `if (ok) a = ..; else b = ..;` would become a store through a selected pointer and pin both to scratch)
             // the Viterbi of the data field starts from a clean trellis (T11aViterbi::Reset at the frame reset)
-            m = (lane == 0) ? 0u : 0x30u; tr = 0; ob = 0; nout = 0; soft_n = 0;
+            m = (lane == 0) ? 0u : 0x30u; tr = 0; ph = 0; ob = 0; nout = 0; soft_n = 0;
             if (lane == 0) W.dec[0] = 0;
             { const int nb = mcs == 8 ? 1 : 2; for (int g = lane; g < 104 * nb; g += 64) W.dtab[g] = (uint8_t)deint11n_index(nb, g & 1, g >> 1); }
             wsync();
@@ -362,17 +423,17 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
         bool more = true;
         while (more) {
             const uint32_t n_pad = (n_real + 3) & ~3u;                       // the last burst is delivered zero-padded
-            if (a >= n_pad) {
+            const bool at_end = a >= n_pad;
+            bool do_sig = false, do_vit = false; uint32_t vit_n = 0;         // the SIG decoder and the Viterbi are entered from one place each (code size)
+            if (at_end) {
                 // ------------------------------------------------------- end of the capture: T11nSymSel::Flush on the empty symbol queue
                 if (type == SYM_SIG && nsig > 0 && err == 0) {
                     for (int k = lane; k < 64 * (3 - nsig); k += 64) W.sig[64 * nsig + k] = 0;
-                    nsig = 0; decode_sig();
+                    nsig = 0; do_sig = true;
                 } else if (type == SYM_DATA && err == 0 && (soft_n % 312) != 0) {
-                    if (vit_run(312 - soft_n % 312, true)) finish_frame();
+                    do_vit = true; vit_n = 312 - soft_n % 312;
                 }
-                last_burst_end = n_pad; more = false;
-                break;
-            }
+            } else {
             // ----------------------------------------------------------- one OFDM symbol of both chains: TFreqComp_11n, CP dropped, two FFTs
 #pragma unroll
             for (int r = 0; r < 2; r++) {
@@ -393,13 +454,12 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
                 }
             }
             wsync();
-            bool complete = false;
             if (type == SYM_SIG) {
                 int re, im;
                 mul32(unpack(W.y[0][lane]), unpack(W.ch[0][lane]), re, im); const cpx x0 = mk(sat16(re >> 9), sat16(im >> 9));
                 mul32(unpack(W.y[1][lane]), unpack(W.ch[1][lane]), re, im); const cpx x1 = mk(sat16(re >> 9), sat16(im >> 9));
                 W.sig[64 * nsig + lane] = pack(mk((short)((short)(x0.re + x1.re) >> 1), (short)((short)(x0.im + x1.im) >> 1)));
-                if (++nsig == 3) { nsig = 0; decode_sig(); }
+                if (++nsig == 3) { nsig = 0; do_sig = true; }
             } else if (type == SYM_HT_STF) {
                 type = SYM_HT_LTF;
             } else if (type == SYM_HT_LTF) {
@@ -461,11 +521,13 @@ __global__ void __launch_bounds__(256) k_rx11n(Rx11nArgs A)
                 for (int g = lane; g < 104 * nb; g += 64) W.joined[g] = W.soft[g & 1][W.dtab[g]];
                 wsync();
                 soft_n += 104 * nb;
-                complete = vit_run(104 * nb, false);
+                do_vit = true; vit_n = 104 * nb;
             }
-            if (complete) finish_frame();
-            a += 80;
-            if (err != 0) { last_burst_end = min(a, n_pad); more = false; }
+            }
+            if (do_sig) decode_sig();
+            if (do_vit && vit_run(vit_n, at_end)) finish_frame();
+            if (at_end) { last_burst_end = n_pad; more = false; }
+            else { a += 80; if (err != 0) { last_burst_end = min(a, n_pad); more = false; } }
         }
         if (err == 0) break;                                                 // the capture ended inside a frame without an event
         // ================================================================ the event, as RxThread sees it after the source call returns
