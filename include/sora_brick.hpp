@@ -204,4 +204,28 @@ private:
     const sora_complex16* d_iq_ = nullptr; const sora_capture_desc* caps_ = nullptr; size_t ncaps_ = 0;
 };
 
+// The 802.11n 2x2 graph as one ISource: CreateDemodGraph11n (fb11ndemod_config.hpp:166-257) + RxThread over a batch of two-chain
+// 40 MHz captures (what TMemSamples2 is initialised with: MemSamplesDesc::Init(2, InputBuf, nCnt), fb11n_demod.cpp:113-117).
+class THipRx11nSource {
+public:
+    THipRx11nSource(CF_Error& ctx, const sora_rx_cfg& cfg) : ctx_(ctx), rx_(nullptr) { ctx_.error_code = (uint32_t)sora_rx11n_create(&cfg, &rx_); }
+    ~THipRx11nSource() { if (rx_) sora_rx11n_destroy(rx_); }
+    THipRx11nSource(const THipRx11nSource&) = delete;
+    THipRx11nSource& operator=(const THipRx11nSource&) = delete;
+    void Bind(const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps) { d_iq_[0] = d_iq0; d_iq_[1] = d_iq1; caps_ = caps; ncaps_ = ncaps; }
+    bool Process()
+    {
+        if (!rx_) return false;
+        const int rc = sora_rx11n_process_dev(rx_, d_iq_[0], d_iq_[1], caps_, ncaps_);
+        if (rc != SORA_OK) { ctx_.error_code = (uint32_t)rc; return false; }
+        return true;
+    }
+    void Reset() {}                                      // every call starts from the graph's initial state
+    void Flush() {}
+    sora_rx11n_t* handle() { return rx_; }
+private:
+    CF_Error& ctx_; sora_rx11n_t* rx_;
+    const sora_complex16* d_iq_[2] = { nullptr, nullptr }; const sora_capture_desc* caps_ = nullptr; size_t ncaps_ = 0;
+};
+
 }  // namespace sora_brick

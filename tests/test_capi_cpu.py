@@ -70,12 +70,12 @@ def test_product_does_not_link_or_import_the_oracle():
 
 
 def test_c_host_example_compiles():
-    """Plain-C hosts (the reference's harness language: `demod11 -d` for 11a and 11b) build against the header and link the library."""
+    """Plain-C hosts (the reference's harness language: `demod11 -d` for 11a, 11b and 11n) build against the header and link the library."""
     import sora_amd
     out = os.path.join(ROOT, "examples", "_build")
     os.makedirs(out, exist_ok=True)
     libdir = os.path.dirname(sora_amd.lib_path())
-    for name in ("demod11a", "demod11b"):
+    for name in ("demod11a", "demod11b", "demod11n"):
         src = os.path.join(ROOT, "examples", name + ".c")
         r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir,
                             "-lsora_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", os.path.join(out, name)],
@@ -111,6 +111,11 @@ int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, ui
     sora_capture_desc cap{0, 2800, 0};
     rx11b.Bind(d_in, &cap, 1);
     ok = ok && (rx11b.handle() == nullptr || rx11b.Process());
+    // the 802.11n 2x2 graph over two-chain 40 MHz captures
+    cfg.sample_rate_mhz = 40;
+    THipRx11nSource rx11n(ctx, cfg);
+    rx11n.Bind(d_in, d_fft, &cap, 1);
+    ok = ok && (rx11n.handle() == nullptr || rx11n.Process());
     return ok ? 0 : (int)ctx.error_code;
 }
 """)
