@@ -62,3 +62,42 @@ def test_gpu_equals_oracle_on_random_captures():
         assert [e["end_sample"] for e in got[i]] == [e["end_sample"] for e in want], i
         nev += len(want)
     assert nev > 150
+
+
+def test_gpu_edge_cases():
+    """Empty batch, silent and tiny captures, more frames than rows, captures at odd offsets inside one buffer."""
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    o = Oracle()
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rx = sora_amd.Rx11n(4, 1000)
+    rx.process_dev(torch.zeros((28, 2), dtype=torch.int16).cuda(), torch.zeros((28, 2), dtype=torch.int16).cuda(), [])
+    assert rx.results() == []
+    rng = np.random.default_rng(5)
+    a3, b3 = capture_11n(rng, [frames[0], frames[1], frames[0]], sigma=10.0)
+    silent = np.zeros((28 * 40, 2), np.int16); tiny = rng.integers(-50, 51, size=(28, 2)).astype(np.int16)
+    caps = [(silent, silent), (tiny, tiny), (a3, b3), (a3[:28 * 3], b3[:28 * 3])]
+    got = run_batch(caps)
+    for i, (a, b) in enumerate(caps):
+        ok, why = same_events_11n(got[i], o.rx11n_capture(a, b), position="end_sample")
+        assert ok, (i, why)
+    assert got[0] == [] and got[1] == [] and len(got[2]) == 3
+    # fewer rows than frames: the first rows are reported
+    one = run_batch([(a3, b3)], max_frames=1)
+    ok, why = same_events_11n(one[0], o.rx11n_capture(a3, b3)[:1], position="end_sample")
+    assert ok, why
+    # the same captures addressed at odd offsets of one buffer (descriptors need not be aligned)
+    pad = 13
+    iq0 = np.concatenate([np.zeros((pad, 2), np.int16), a3, np.zeros((7, 2), np.int16), a3[:2800]])
+    iq1 = np.concatenate([np.zeros((pad, 2), np.int16), b3, np.zeros((7, 2), np.int16), b3[:2800]])
+    rx = sora_amd.Rx11n(2, len(iq0))
+    rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), [(pad, len(a3), 7), (pad + len(a3) + 7, 2800, 9)])
+    res = rx.results()
+    for cid, (a, b) in ((7, (a3, b3)), (9, (a3[:2800], b3[:2800]))):
+        ok, why = same_events_11n([r for r in res if r["capture_id"] == cid], o.rx11n_capture(a, b), position="end_sample")
+        assert ok, (cid, why)
+    with pytest.raises(sora_amd.SoraError):
+        rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), [(0, 27, 0)])       # not a whole source burst
