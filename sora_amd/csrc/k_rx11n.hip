@@ -64,6 +64,16 @@ __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
 {
     return ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(v >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)v);
 }
+__device__ __forceinline__ unsigned wave_min(unsigned v)                // minimum over the 64 lanes, in every lane: four DPP moves, two lane swaps
+{
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));       // lane ^ 1
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));       // lane ^ 2
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));      // row_ror:4
+    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));      // row_ror:8: each row of 16 is done
+    { const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false); v = min(r[0], r[1]); }
+    { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = min(r[0], r[1]); }
+    return v;
+}
 __device__ __forceinline__ int scan_add(int v, int lane)               // inclusive prefix sum over the wave, wrapping
 {
 #pragma unroll
@@ -277,18 +287,13 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
             }
         };
         auto normalize = [&]() __attribute__((always_inline)) {
-            unsigned mn = m;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+            const unsigned mn = wave_min(m);
             m = (m - (mn & 0xFE)) & 0xFF;
         };
         // Traceback (viterbicore.h:468-555) of `bits` bits behind `look` columns, appended to W.out
         auto traceback = [&](uint32_t bits, uint32_t look) __attribute__((always_inline)) {
             const unsigned st = (((unsigned)lane << ph) | ((unsigned)lane >> (6 - ph))) & 63u;     // the state this lane holds now
-            unsigned kmin = (m << 8) | (st << 2);
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
-            kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
+            const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min((m << 8) | (st << 2)));
             int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
             wsync();
             uint32_t col = tr; int cm = ph;                                  // cm = col mod 6: the decision of state s at column c is bit rotr6(s, c mod 6)
