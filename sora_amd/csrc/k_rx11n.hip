@@ -255,7 +255,7 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
 
         // one trellis step; which: 0 = (A,B), 1 = A only, 2 = B only (viterbi.hpp:166-187)
         // one trellis step from column phase PH (= tr mod 6, a compile-time constant); which: 0 = (A,B), 1 = A only, 2 = B only (viterbi.hpp:166-187)
-        auto acs_c = [&](auto PHC, int which, int va, int vb) __attribute__((always_inline)) {
+        auto acs_c = [&](auto PHC, int which, int va, int vb, unsigned long long* dslot) __attribute__((always_inline)) {
             constexpr int PH = decltype(PHC)::value, Q = PH == 5 ? 0 : PH + 1;
             unsigned other;                                                  // the metric of the lane whose state differs in the top state bit
             if constexpr (PH == 0) { const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false); other = lane < 32 ? r[1] : r[0]; }
@@ -274,16 +274,16 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
             m = min(c0, c1);
             tr++; ph = Q;
             const unsigned long long d = __ballot(m & 1);
-            W.dec[tr & 255] = d;                                             // every lane stores the same word: no exec juggling in the step
+            *dslot = d;                                                      // the decision word of column tr; every lane stores the same word: no exec juggling in the step
         };
         auto acs = [&](int which, int va, int vb) __attribute__((always_inline)) {      // the same from a run-time phase (symbol edges)
             switch (ph) {
-            case 0: acs_c(std::integral_constant<int, 0>{}, which, va, vb); break;
-            case 1: acs_c(std::integral_constant<int, 1>{}, which, va, vb); break;
-            case 2: acs_c(std::integral_constant<int, 2>{}, which, va, vb); break;
-            case 3: acs_c(std::integral_constant<int, 3>{}, which, va, vb); break;
-            case 4: acs_c(std::integral_constant<int, 4>{}, which, va, vb); break;
-            default: acs_c(std::integral_constant<int, 5>{}, which, va, vb); break;
+            case 0: acs_c(std::integral_constant<int, 0>{}, which, va, vb, &W.dec[(tr + 1) & 255]); break;
+            case 1: acs_c(std::integral_constant<int, 1>{}, which, va, vb, &W.dec[(tr + 1) & 255]); break;
+            case 2: acs_c(std::integral_constant<int, 2>{}, which, va, vb, &W.dec[(tr + 1) & 255]); break;
+            case 3: acs_c(std::integral_constant<int, 3>{}, which, va, vb, &W.dec[(tr + 1) & 255]); break;
+            case 4: acs_c(std::integral_constant<int, 4>{}, which, va, vb, &W.dec[(tr + 1) & 255]); break;
+            default: acs_c(std::integral_constant<int, 5>{}, which, va, vb, &W.dec[(tr + 1) & 255]); break;
             }
         };
         auto normalize = [&]() __attribute__((always_inline)) {
@@ -294,15 +294,20 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
         auto traceback = [&](uint32_t bits, uint32_t look) __attribute__((always_inline)) {
             const unsigned st = (((unsigned)lane << ph) | ((unsigned)lane >> (6 - ph))) & 63u;     // the state this lane holds now
             const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min((m << 8) | (st << 2)));
-            int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+            const unsigned smin = (kmin >> 2) & 0x3F;
+            // The walk runs in LANE space: going back from column c to c - 1 the state loses its lowest bit and gains the decision as its
+            // top bit -- under the rotating map that is ONE lane bit, e = 5 - (c - 1) mod 6, being replaced by the decision.
+            unsigned L = ((smin >> ph) | (smin << (6 - ph))) & 63u;          // the lane that holds the arg-min state
+            unsigned b = (kmin >> 8) & 1;                                    // its decision (mark) bit = the reference's pos bit 6
+            unsigned e = (6 - ph) % 6;
             wsync();
-            uint32_t col = tr; int cm = ph;                                  // cm = col mod 6: the decision of state s at column c is bit rotr6(s, c mod 6)
+            uint32_t col = tr;
             auto back = [&](unsigned long long d) __attribute__((always_inline)) {
-                pos = (pos >> 1) & 0x3F;
-                const unsigned ln = (((unsigned)pos >> cm) | ((unsigned)pos << (6 - cm))) & 63u;
-                pos |= (int)((d >> ln) & 1) << 6;
+                L = (L & ~(1u << e)) | (b << e);
+                b = (unsigned)(d >> L) & 1u;
+                e = e == 5 ? 0 : e + 1;
             };
-            for (uint32_t i = 0; i < look; i++) { col--; cm = cm == 0 ? 5 : cm - 1; back(uni64(W.dec[col & 255])); }
+            for (uint32_t i = 0; i < look; i++) { col--; back(uni64(W.dec[col & 255])); }
             uint32_t po = nout + (bits >> 3);
             for (uint32_t i = 0; i < bits >> 3; i++) {
                 unsigned long long d[8];
@@ -310,7 +315,7 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
                 for (int j = 0; j < 8; j++) d[j] = uni64(W.dec[(col - 1 - j) & 255]);      // the eight columns of this byte do not depend on the walk
                 unsigned oc = 0;
 #pragma unroll
-                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | ((unsigned)(pos >> 6) & 1u)) & 0xFF; cm = cm == 0 ? 5 : cm - 1; back(d[j]); }
+                for (int j = 0; j < 8; j++) { oc = ((oc << 1) | b) & 0xFF; back(d[j]); }
                 col -= 8; po--;
                 if (lane == 0 && po < sizeof(W.out)) W.out[po] = (uint8_t)oc;
             }
@@ -334,18 +339,28 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
                 // six steps with the exchange pattern known at compile time, where no trace-back can become due inside them (only the
                 // normalisation, every eighth column, has to be looked after)
                 const uint32_t due = min(tr_end, ob + 192 + 36 + 6);
-                if (ph == 0 && tr + 6 < due && code_rate == 0 && k + 12 <= n) {
-                    acs_c(integral_constant<int, 0>{}, 0, sv(k), sv(k + 1));       if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 1>{}, 0, sv(k + 2), sv(k + 3));   if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 2>{}, 0, sv(k + 4), sv(k + 5));   if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 3>{}, 0, sv(k + 6), sv(k + 7));   if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 4>{}, 0, sv(k + 8), sv(k + 9));   if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 5>{}, 0, sv(k + 10), sv(k + 11)); if ((tr & 7) == 0) normalize();
+                const bool room = (tr & 255) + 6 <= 255;                     // the six decision words do not wrap around the ring
+                if (ph == 0 && room && tr + 6 < due && code_rate == 0 && k + 12 <= n) {
+                    using IC0 = integral_constant<int, 0>; using IC1 = integral_constant<int, 1>; using IC2 = integral_constant<int, 2>;
+                    using IC3 = integral_constant<int, 3>; using IC4 = integral_constant<int, 4>; using IC5 = integral_constant<int, 5>;
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(k >> 2)), w1 = (uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(k >> 2) + 1),
+                                   w2 = (uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(k >> 2) + 2);
+                    unsigned long long* d0 = &W.dec[(tr & 255) + 1];
+                    acs_c(IC0{}, 0, (int)(w0 & 255), (int)((w0 >> 8) & 255), d0);         if ((tr & 7) == 0) normalize();
+                    acs_c(IC1{}, 0, (int)((w0 >> 16) & 255), (int)(w0 >> 24), d0 + 1);    if ((tr & 7) == 0) normalize();
+                    acs_c(IC2{}, 0, (int)(w1 & 255), (int)((w1 >> 8) & 255), d0 + 2);     if ((tr & 7) == 0) normalize();
+                    acs_c(IC3{}, 0, (int)((w1 >> 16) & 255), (int)(w1 >> 24), d0 + 3);    if ((tr & 7) == 0) normalize();
+                    acs_c(IC4{}, 0, (int)(w2 & 255), (int)((w2 >> 8) & 255), d0 + 4);     if ((tr & 7) == 0) normalize();
+                    acs_c(IC5{}, 0, (int)((w2 >> 16) & 255), (int)(w2 >> 24), d0 + 5);    if ((tr & 7) == 0) normalize();
                     k += 12;
-                } else if (ph == 0 && tr + 6 < due && code_rate != 0 && k + 8 <= n) {
-                    acs_c(integral_constant<int, 0>{}, 0, sv(k), sv(k + 1)); acs_c(integral_constant<int, 1>{}, 1, sv(k + 2), 0); acs_c(integral_constant<int, 2>{}, 2, 0, sv(k + 3));
+                } else if (ph == 0 && room && tr + 6 < due && code_rate != 0 && k + 8 <= n) {
+                    const uint32_t w0 = (uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(k >> 2)), w1 = (uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(k >> 2) + 1);
+                    unsigned long long* d0 = &W.dec[(tr & 255) + 1];
+                    acs_c(integral_constant<int, 0>{}, 0, (int)(w0 & 255), (int)((w0 >> 8) & 255), d0); acs_c(integral_constant<int, 1>{}, 1, (int)((w0 >> 16) & 255), 0, d0 + 1);
+                    acs_c(integral_constant<int, 2>{}, 2, 0, (int)(w0 >> 24), d0 + 2);
                     if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 3>{}, 0, sv(k + 4), sv(k + 5)); acs_c(integral_constant<int, 4>{}, 1, sv(k + 6), 0); acs_c(integral_constant<int, 5>{}, 2, 0, sv(k + 7));
+                    acs_c(integral_constant<int, 3>{}, 0, (int)(w1 & 255), (int)((w1 >> 8) & 255), d0 + 3); acs_c(integral_constant<int, 4>{}, 1, (int)((w1 >> 16) & 255), 0, d0 + 4);
+                    acs_c(integral_constant<int, 5>{}, 2, 0, (int)(w1 >> 24), d0 + 5);
                     if ((tr & 7) == 0) normalize();
                     k += 8;
                 } else {
