@@ -83,3 +83,54 @@ def test_two_rank_gloo_gather():
         assert sum(counts) == 11 and counts == [6, 5]
         assert tot == [11, sum(1 for w in want if w[4] == 1)]
         assert got == want            # rank order == capture order: the gather needs no re-sort
+
+
+def _worker_11n(rank, world, port, q):
+    """the same sharding for the 802.11n graph: two-chain captures are independent units too (rows carry the MCS index as rate_kbps)"""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from oracle.pyoracle import Oracle
+    from sora_amd.shard import gather_rows, partition, reduce_counters, results_from_rows, rows_from_results
+    from test_oracle_11n_graph import golden_captures
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    caps = [(a, b) for a, b, _, _, _ in golden_captures()]
+    first, count = partition(len(caps), world, rank)
+    local = []
+    for i in range(first, first + count):
+        for r in o.rx11n_capture(*caps[i]):
+            r = {k: v for k, v in r.items() if k != "mpdu"}; r["capture_id"] = i; local.append(r)
+    rows = torch.from_numpy(rows_from_results(local).copy())
+    allrows, counts = gather_rows(rows, len(local), max_rows_per_rank=32)
+    tot = reduce_counters([len(local), sum(r["error_code"] == 1 for r in local)])
+    got = results_from_rows(allrows.numpy())
+    q.put((rank, counts, tot, [(g["capture_id"], g["end_sample"], g["rate_kbps"], g["length"], g["crc32"], g["error_code"]) for g in got]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_11n():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_11n, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from oracle.pyoracle import Oracle
+    from test_oracle_11n_graph import golden_captures
+    o = Oracle(); want = []
+    for i, (a, b, _, _, _) in enumerate(golden_captures()):
+        for r in o.rx11n_capture(a, b):
+            want.append((i, r["end_sample"], r["rate_kbps"], r["length"], r["crc32"], r["error_code"]))
+    assert len(want) >= 12
+    for rank, counts, tot, got in outs:
+        assert sum(counts) == len(want) and len(counts) == 2 and min(counts) > 0
+        assert tot == [len(want), sum(1 for w in want if w[5] == 1)]
+        assert got == want
