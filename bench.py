@@ -12,8 +12,14 @@ Multi-GPU (--gpus N, launched by torch.distributed.run): captures are the natura
 its own 4096-capture batch end to end (weak scaling), no data-path collective; one all-reduce of the
 frame counters after the timed region is the only exchange.
 
-Prints ONE JSON line on rank 0 (see the contract in the task description), with `roofline` for the
-dominant kernel (HIP events on the library's own stream) and `cpu_baseline` (the oracle timed on one host core).
+The timed region: the K-step block (--steps) is repeated until at least --min-seconds have passed; every step is a
+process call whose dense result rows AND MPDU array are delivered to page-locked host memory behind the kernels, and the
+oldest call in flight is waited for and its rows compared with the verified ones.  Before anything is timed, the first
+call's rows are compared, capture by capture, with what the compiled reference graph reports (--check 0 = all captures).
+
+Prints ONE JSON line on rank 0 (see the contract in the task description), with `roofline` for the dominant kernel (HIP
+events on the library's own streams, one call in flight) and `cpu_baseline` (the reference's SSE graph compiled from its
+sources, on all usable host cores; the scalar restatement where that library is absent).
 """
 import argparse
 import json
@@ -347,15 +353,51 @@ def bench_tx(torch, sora_amd, nframes=4096, reps=10):
             "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
 
 
+def reference_rows(iq, nfr, oracle):
+    """What the reference reports for every capture of the workload: the compiled reference graph (oracle/_ref, fresh
+    graph state per capture is not needed: a capture ends in silence and the graph resets after every frame) where it is
+    present, else the C restatement.  -> (kind, {capture: [events]})"""
+    from oracle.pyoracle import ReferenceGraph
+    x = iq.reshape(nfr, CAPTURE_SAMPLES, 2)
+    g = ReferenceGraph()
+    if g.available():
+        return "reference", {i: g.rx11a(np.repeat(x[i], 2, axis=0)) for i in range(nfr)}     # the 40 MHz stream TDownSample2 halves
+    return "port", {i: oracle.rx_capture(x[i], 20) for i in range(nfr)}
+
+
+def check_against_reference(res, kind, want, idx):
+    """GPU rows of the captures `idx` against the reference's events (every field the reference reports)."""
+    from gpu_util import same_as_reference_graph, same_results
+    by_cap = {}
+    for r in res:
+        by_cap.setdefault(r["capture_id"], []).append(r)
+    for i in idx:
+        got = by_cap.get(i, [])
+        if kind == "reference":
+            ok, why = same_as_reference_graph(got, want[i])
+        else:
+            w = []
+            for r in want[i]:
+                r = dict(r); r["capture_id"] = i; w.append(r)
+            ok, why = same_results(got, w)
+        if not ok:
+            return False, "capture %d: %s" % (i, why)
+    return True, ""
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="captures per GPU (default: the BASELINE config)")
+    ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="captures per GPU (default: the BASELINE config; "
+                    "--gpus 8 --frames 32 is BASELINE configs[4] literally: 256 captures over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the stage / ingest / tx / 11b / 11n sections")
     ap.add_argument("--depth", type=int, default=0, help="process calls in flight on the handle's internal pipelines (0 = library default)")
-    ap.add_argument("--check", type=int, default=32, help="captures compared with the oracle after the timed region")
+    ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
+    ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
+    ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
     args = ap.parse_args()
 
     import torch
@@ -374,10 +416,11 @@ def main():
 
     oracle = Oracle()
     nfr = args.frames
+    MAXF = 2
     iq, descs, payloads = make_workload(oracle, nfr, seed0=rank * 100003)
     d_iq = torch.from_numpy(iq).to(dev)
     descs = sora_amd.Rx.captures(descs)           # packed sora_capture_desc[]: built once, submitted every step
-    rx = sora_amd.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, device=local_rank, max_frames_per_capture=2)
+    rx = sora_amd.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, device=local_rank, max_frames_per_capture=MAXF)
 
     if args.depth:
         rx.set_depth(args.depth)
@@ -388,27 +431,89 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        rx.process_dev(d_iq, descs)
+    # ---- the first call is checked before anything is timed: every capture against the reference (or --check of them)
+    t = rx.process_dev(d_iq, descs)
+    res = rx.results(ticket=t)
+    kind, want = reference_rows(iq, nfr, oracle)
+    idx = list(range(nfr)) if args.check <= 0 or args.check >= nfr else list(range(0, nfr, max(1, nfr // args.check)))[:args.check]
+    parity_ok, why = check_against_reference(res, kind, want, idx)
+    if not parity_ok:
+        print("PARITY MISMATCH vs %s: %s" % (kind, why), file=sys.stderr)
+    n_ok = sum(1 for r in res if r["error_code"] == sora_amd.E_FRAME_OK)
+    n_payload_ok = sum(1 for r in res if r["error_code"] == sora_amd.E_FRAME_OK and r["mpdu"][:-4] == payloads[r["capture_id"]])
+
+    # ---- result delivery inside the timed region: after every process call its dense rows and its MPDU array are copied
+    # to page-locked host memory behind the kernels (sora_rx_deliver_async), and the oldest call in flight is waited for
+    # and its rows compared with the verified ones -- what RxThread does per frame (fb11a_demod.cpp:37-71), per call.
+    bufs = [sora_amd.HostResults(nfr * MAXF, rx.mpdu_bytes(t)) for _ in range(depth)]
+    rx.deliver_async(t, bufs[0]); rx.wait(t)
+    exp_n = int(bufs[0].nrows[0]); exp_rows = bufs[0].rows[:exp_n].copy(); exp_mpdu = bufs[0].mpdu.copy()
+    exp_bytes = exp_rows.tobytes()
+    host_rows_ok = exp_n == len(res) and all(int(exp_rows[k]["crc32"]) == res[k]["crc32"] and int(exp_rows[k]["error_code"]) == res[k]["error_code"] for k in range(exp_n)) \
+        and all(bytes(exp_mpdu[int(r["mpdu_offset"]):int(r["mpdu_offset"]) + int(r["length"])]) == res[k]["mpdu"] for k, r in enumerate(exp_rows) if int(r["error_code"]) == 1)
+    stats = {"delivered": 0, "bad": 0}
+
+    def consume(tk):
+        rx.wait(tk)
+        b = bufs[tk % depth]
+        stats["delivered"] += 1
+        if int(b.nrows[0]) != exp_n or b.rows[:exp_n].tobytes() != exp_bytes:
+            stats["bad"] += 1
+
+    def run_block(k, deliver):
+        first = None
+        for _ in range(k):
+            tk = rx.process_dev(d_iq, descs)
+            if deliver:
+                rx.deliver_async(tk, bufs[tk % depth])
+                if first is None:
+                    first = tk
+                if tk - first >= depth - 1:
+                    consume(tk - (depth - 1))
+        if deliver and first is not None:
+            for old in range(max(first, tk - (depth - 1) + 1), tk + 1):
+                consume(old)
+
+    deliver = not args.no_deliver
+    run_block(args.warmup, deliver)
     rx.flush()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        rx.process_dev(d_iq, descs)
+    run_block(args.steps, deliver); rx.flush()
+    probe = time.perf_counter() - t0
+    repeats = max(1, int(np.ceil(args.min_seconds / max(probe, 1e-6))))
+    if world > 1:                                  # every rank runs the same number of blocks
+        r_t = torch.tensor([repeats], device=dev, dtype=torch.int64); dist.all_reduce(r_t, op=dist.ReduceOp.MAX); repeats = int(r_t.item())
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(repeats):
+        run_block(args.steps, deliver)
+    rx.flush()
     barrier()
     t1 = time.perf_counter()
+    timed_steps = args.steps * repeats
+    mpdu_ok = bool(deliver) and all((b.mpdu == exp_mpdu).all() for b in bufs)     # the last `depth` calls' MPDU arrays, byte for byte
     # the same K steps once more with HIP events around every kernel launch (on the streams the kernels run on): the
     # roofline's launch durations are means over this region; `value` comes from the un-instrumented region above
     # (recording 6 events per call costs a few percent, reported as ms_per_step_profiled)
     rx.set_profiling(True)
     barrier()
     t2 = time.perf_counter()
-    for _ in range(args.steps):
-        rx.process_dev(d_iq, descs)
+    run_block(args.steps, deliver)
+    rx.flush()
     barrier()
     t3 = time.perf_counter()
     ktimes = rx.kernel_times()
     rx.set_profiling(False)
+    # and with ONE call in flight: each kernel alone on the chip (the per-kernel roofline without the CU sharing of overlapped calls)
+    rx.set_depth(1); rx.flush()
+    rx.set_profiling(True)
+    for _ in range(max(10, args.steps // 2)):
+        rx.process_dev(d_iq, descs)
+    rx.flush()
+    ktimes1 = rx.kernel_times()
+    rx.set_profiling(False)
+    rx.set_depth(depth)
 
     elapsed = t1 - t0
     if world > 1:
@@ -416,66 +521,64 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    # ---- correctness of what was timed
-    res = rx.results()
-    n_ok = sum(1 for r in res if r["error_code"] == sora_amd.E_FRAME_OK)
-    n_payload_ok = sum(1 for r in res if r["error_code"] == sora_amd.E_FRAME_OK and r["mpdu"][:-4] == payloads[r["capture_id"]])
-    parity_ok = None
-    if args.check:
-        from gpu_util import oracle_results, same_results
-        x = iq.reshape(nfr, CAPTURE_SAMPLES, 2)
-        idx = list(range(0, nfr, max(1, nfr // args.check)))[:args.check]
-        want = []
-        for i in idx:
-            for r in oracle.rx_capture(x[i], 20):
-                r = dict(r); r["capture_id"] = i; want.append(r)
-        got = [r for r in res if r["capture_id"] in set(idx)]
-        parity_ok, why = same_results(got, want)
-        if not parity_ok:
-            print("PARITY MISMATCH vs oracle:", why, file=sys.stderr)
-    counters = torch.tensor([len(res), n_ok, n_payload_ok], device=dev, dtype=torch.int64)
+    counters = torch.tensor([len(res), n_ok, n_payload_ok, stats["delivered"], stats["bad"]], device=dev, dtype=torch.int64)
     gathered_rows = None
     if world > 1:
         # the path's one exchange step: RCCL all-gather of the device-packed result rows + all-reduce of counters
         from sora_amd.shard import gather_rows
+        rx.process_dev(d_iq, descs)
         rows, nrows, _ = rx.results_dev()
         rx.flush()
         allrows, per_rank = gather_rows(rows, int(nrows.item()), max_rows_per_rank=nfr * 2)
         gathered_rows = int(allrows.shape[0])
         dist.all_reduce(counters)
-    tot_frames, tot_ok, tot_payload_ok = [int(v) for v in counters.tolist()]
+    tot_frames, tot_ok, tot_payload_ok, tot_delivered, tot_bad = [int(v) for v in counters.tolist()]
 
-    total_samples = float(nfr) * FRAME_SAMPLES * world * args.steps
+    total_samples = float(nfr) * FRAME_SAMPLES * world * timed_steps
     msps = total_samples / elapsed / 1e6
-    ms_per_step = elapsed / args.steps * 1e3
+    ms_per_step = elapsed / timed_steps * 1e3
     if rank == 0:
         dom = max((k for k in ktimes if k.startswith("k_")), key=lambda k: ktimes[k])
         launch_bytes = nfr * FRAME_SAMPLES * ALG_BYTES_PER_SAMPLE
         ach = launch_bytes / (ktimes[dom] * 1e-3)
+        ach1 = launch_bytes / (ktimes1[dom] * 1e-3)
+        air_s = nfr * CAPTURE_SAMPLES / 20e6                                   # what one step's captures last on the air
         out = {
             "metric": "IQ Msamples/s through 802.11a 54 Mbps RX PHY",
             "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "timed_steps": timed_steps, "timed_seconds": round(elapsed, 4),
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_profiled": round((t3 - t2) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 IQ / u8 path metrics", "data": "synthetic",
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth,
-                       "sharding": "captures per rank, no data-path collective"},
+                       "sharding": "captures per rank, no data-path collective",
+                       "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait/compare of the oldest call in flight" % (repeats, args.steps)
+                                       if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
-            "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok, "oracle_parity_sample_ok": parity_ok,
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(ach / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
-                         "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes[dom], 4),
+            "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
+            "parity": {"against": kind, "captures_checked": len(idx), "ok": parity_ok, "host_rows_ok": host_rows_ok},
+            "delivery": {"enabled": deliver, "calls_delivered_and_compared": tot_delivered, "calls_with_wrong_rows": tot_bad, "rows_per_call": exp_n,
+                         "row_bytes_per_call": 36 * nfr * MAXF, "mpdu_bytes_per_call": int(exp_mpdu.size), "last_calls_mpdu_ok": mpdu_ok},
+            # the reference's own figure of merit (MACStopwatch.h:84-128): cost / required time, < 1 = faster than real time
+            "realtime": {"factor": round(ms_per_step * 1e-3 / air_s, 7), "channels_20mhz_in_real_time": round(air_s / (ms_per_step * 1e-3), 1),
+                         "call_latency_ms_one_in_flight": round(sum(v for k, v in ktimes1.items()), 4)},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach1 / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                         "frac": round(ach1 / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
+                         "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes1[dom], 4),
+                         "kernel_ms_note": "mean launch duration with ONE call in flight (the kernel alone on the chip); with %d calls overlapped the same launch lasts %.4f ms (frac %.5f) because it shares the CUs" % (depth, ktimes[dom], ach / HBM_PEAK),
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
                          "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
+            "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
-        if world == 1:
+        if world == 1 and not args.no_extras:
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
             out["tx"] = bench_tx(torch, sora_amd)
             out["rx11b"] = bench_11b(torch, sora_amd, dev)
             out["rx11n"] = bench_11n(torch, sora_amd, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(iq, nfr)
+            out["realtime"]["cpu_reference_factor_one_core"] = round(20.0 / out["cpu_baseline"]["single_core_value"], 4) if out["cpu_baseline"].get("single_core_value") else None
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

@@ -11,9 +11,10 @@
  *   - plain C, no C++/torch types; every function returns a BK_ERROR_* / E_ERROR_* compatible code
  *     (kernel/brick/inc/dspcomm.h:22-31, kernel/bb/Brick11/src/ieee80211facade.hpp:10-19)
  *   - pointers named d_* are DEVICE (HBM) pointers, h_* are host pointers; the caller owns every buffer
- *   - one hipStream per sora_rx_t; calls on one handle must be serialised by the caller, different
- *     handles are independent (no hidden globals, unlike the reference's BB11aDemodCtx,
- *     kernel/bb/demod11/fb11ademod_config.hpp:123)
+ *   - calls on one handle must be serialised by the caller, different handles are independent and may be used from
+ *     different threads (no hidden globals, unlike the reference's BB11aDemodCtx,
+ *     kernel/bb/demod11/fb11ademod_config.hpp:123; the per-device look-up tables of the stage entry points are
+ *     created once under a lock)
  *   - the library never falls back to a CPU path: without a usable HIP device every compute call
  *     returns SORA_ERR_NO_DEVICE.
  */
@@ -25,7 +26,7 @@
 extern "C" {
 #endif
 
-#define SORA_HIP_ABI_VERSION 1
+#define SORA_HIP_ABI_VERSION 2
 
 /* COMPLEX16: kernel/core/inc/complex.h */
 typedef struct { int16_t re, im; } sora_complex16;
@@ -81,9 +82,13 @@ typedef struct {                    /* one row per frame the reference's RxThrea
     uint16_t nsym;                  /* data symbols */
     uint32_t crc32;                 /* FCS found in the frame (CF_11aRxVector::crc32) */
     int16_t  cfo_est;               /* CF_CFOffset::CFO_est (FP_RAD per sample) */
-    uint16_t reserved;
+    uint16_t flags;                 /* SORA_ROW_TRUNCATED on the LAST row of a capture that held more frames than
+                                     * max_frames_per_capture: the reference's RxThread reports every frame, the frames after
+                                     * this one were found but have no row */
     uint32_t mpdu_offset;           /* byte offset of the MPDU in the mpdu buffer */
 } sora_frame_result;
+
+#define SORA_ROW_TRUNCATED 1u
 
 /* create/destroy the graph: CreateDemodGraph11a_40M + BB11aDemodCtx.Init  /  IReferenceCounting::Release */
 int  sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out);
@@ -102,6 +107,27 @@ int  sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_sam
 /* TBB11aFrameSink's frame buffer + CF_Error per frame: copies results of the last process call to the host.
  * h_mpdu may be NULL (descriptors only).  *nout = rows written. Frames appear in (capture, time) order. */
 int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+
+/* Tickets.  With several calls in flight (sora_rx_set_depth) every process call has a TICKET, a positive number that
+ * identifies the call until `depth` further process calls have been made on the handle (its pipeline is then reused).
+ * What fb11a_demod.cpp:37-71 does per frame -- look at the result, hand the MPDU to the MAC -- is done per call with these:
+ *   sora_rx_ticket          ticket of the most recent process call (0: none yet)
+ *   sora_rx_wait            block until that call has finished (its kernels and any sora_rx_deliver_async copies)
+ *   sora_rx_results_of      sora_rx_results for that call
+ *   sora_rx_results_dev_of  sora_rx_results_dev for that call
+ *   sora_rx_stream_of       the HIP stream that call runs on
+ *   sora_rx_deliver_async   enqueue, behind the call's kernels and without blocking the host, the delivery of its results
+ *                           into host memory: the dense rows (capture, time order; at most max_rows are copied), their
+ *                           number, and -- h_mpdu != NULL -- the MPDU array (row.mpdu_offset indexes it; mpdu_bytes must be
+ *                           at least sora_rx_mpdu_bytes(rx, ticket)).  The buffers should be page-locked
+ *                           (sora_hip_host_alloc) so that the copies overlap later calls; they are valid after sora_rx_wait.
+ * A stale ticket gives SORA_ERR_INVALID_PARAM. */
+int    sora_rx_ticket(sora_rx_t* rx);
+int    sora_rx_wait(sora_rx_t* rx, int ticket);
+int    sora_rx_results_of(sora_rx_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+void*  sora_rx_stream_of(sora_rx_t* rx, int ticket);
+size_t sora_rx_mpdu_bytes(sora_rx_t* rx, int ticket);
+int    sora_rx_deliver_async(sora_rx_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_nrows, uint8_t* h_mpdu, size_t mpdu_bytes);
 /* Per-kernel timing with HIP events recorded on the streams the kernels run on (SoraStopwatch / MACStopwatch analogue,
  * kernel/bb/demod11/MACStopwatch.h:84-128).  With profiling enabled every process call brackets each kernel launch
  * with events; sora_rx_kernel_times waits for the calls in flight and returns, in launch order, the MEAN duration (ms)
@@ -114,13 +140,15 @@ const char* sora_rx_kernel_name(size_t index);
 /* Consecutive process calls rotate over `depth` internal pipelines (own stream, own intermediate arrays), so the
  * latency-bound front end of one call overlaps the trellis kernel of the call before it -- what the reference gets from
  * running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120).  Default 3 (environment SORA_HIP_DEPTH), 1 = strictly
- * one call at a time, at most 4.  Returns the previous value; depth <= 0 only queries.  The results/results_dev/stream/
- * kernel_times calls refer to the MOST RECENT process call; sora_rx_flush waits for every call in flight; an input buffer
- * must stay untouched until the call that reads it has finished (as with any asynchronous call). */
+ * one call at a time, at most 4.  Returns the previous value; depth <= 0 only queries.  sora_rx_results / _results_dev /
+ * _stream refer to the MOST RECENT process call, the *_of forms to the call whose ticket is given; sora_rx_flush waits for
+ * every call in flight; an input buffer must stay untouched until the call that reads it has finished (as with any
+ * asynchronous call). */
 int  sora_rx_set_depth(sora_rx_t* rx, int depth);
 
 /* Device-side views of the last call's outputs (valid until the next process/reset/destroy). */
 int  sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu);
+int  sora_rx_results_dev_of(sora_rx_t* rx, int ticket, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu);
 
 /* ------------------------------------------------------------------------------------------------
  * Per-stage entry points with the brick port shapes, batched (n = number of bursts).  All pointers are
@@ -183,7 +211,7 @@ int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t*
                    const uint8_t* d_seed, size_t nframes, int8_t* d_out, const uint64_t* d_out_off, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
- * 802.11n 2x2, stage level -- the whole-path graph is not built yet.  Batched bricks, n symbols per call:
+ * 802.11n 2x2, stage level (the whole-path graph is sora_rx11n_* below).  Batched bricks, n symbols per call:
  * T11nDemap{BPSK,QPSK,QAM16,QAM64} (kernel/bb/Brick11/src/demapper11n.hpp:89-309): IPORT COMPLEX16 x 64 (one pilot-tracked
  * symbol of one spatial stream) -> OPORT uint8 x 52*N_BPSC soft values 0..7;
  * T11nDeinterleave{...}_S0/_S1 (deinterleaver_11n.hpp:4-1618): 52*N_BPSC soft values of spatial stream 0 or 1 -> de-interleaved.
@@ -280,6 +308,9 @@ void* sora_hip_malloc(size_t bytes);
 void  sora_hip_free(void* d_ptr);
 int   sora_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int   sora_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+/* page-locked host memory (the target of asynchronous result delivery) */
+void* sora_hip_host_alloc(size_t bytes);
+void  sora_hip_host_free(void* h_ptr);
 /* wait for a stream (NULL = the null stream); the streams of a sora_rx_t do not follow the null stream */
 int   sora_hip_stream_synchronize(void* stream);
 int   sora_hip_abi_version(void);

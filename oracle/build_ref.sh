@@ -69,8 +69,8 @@ EOF
 "$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden \
     -fms-extensions -fms-compatibility -fdelayed-template-parsing -fno-operator-names \
     -msse4.1 -mssse3 -Wno-everything \
-    -I"$TMP" "$HERE/ref_shim.cpp" -o "$OUT/libsora_ref.so"
-echo "build_ref.sh: built $OUT/libsora_ref.so"
+    -I"$TMP" "$HERE/ref_shim.cpp" -o "$OUT/libsora_ref.so" &
+PID_KERNELS=$!
 
 # ---- the reference's BRICK graphs themselves (oracle/ref_flatten.py patches a scratch copy; oracle/ref_compat.h
 #      supplies the Windows integer model) -> oracle/_ref/libsora_refgraph.so
@@ -78,5 +78,17 @@ python3 "$HERE/ref_flatten.py" "$TMP/flat"
 "$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden \
     -fms-extensions -fms-compatibility -fms-compatibility-version=19.00 -fdelayed-template-parsing -fno-operator-names \
     -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" \
-    -I"$TMP/flat" "$HERE/ref_graph_shim.cpp" -o "$OUT/libsora_refgraph.so"
-echo "build_ref.sh: built $OUT/libsora_refgraph.so"
+    -I"$TMP/flat" "$HERE/ref_graph_shim.cpp" -o "$OUT/libsora_refgraph.so" &
+PID_GRAPH=$!
+
+# ---- the 11a receive graph once more WITH the reference's thread boundary (TThreadSeparator + a joined Viterbi thread):
+#      only there to show that the two-thread harness reports what the same-thread build reports (tests/test_oracle_vs_refgraph.py)
+python3 "$HERE/ref_flatten.py" "$TMP/flat_mt" mt
+"$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden -pthread \
+    -fms-extensions -fms-compatibility -fms-compatibility-version=19.00 -fdelayed-template-parsing -fno-operator-names \
+    -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" \
+    -I"$TMP/flat_mt" "$HERE/ref_graph_mt_shim.cpp" -o "$OUT/libsora_refgraph_mt.so" &
+PID_MT=$!
+wait $PID_KERNELS; echo "build_ref.sh: built $OUT/libsora_ref.so"          # the three compiles run side by side; set -e stops on the first failure
+wait $PID_GRAPH;   echo "build_ref.sh: built $OUT/libsora_refgraph.so"
+wait $PID_MT;      echo "build_ref.sh: built $OUT/libsora_refgraph_mt.so"

@@ -55,9 +55,9 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE])
     ref_root = os.environ.get("SORA_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref_root, "kernel", "core", "inc")):
-        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_flatten.py", "ref_compat.h", "build_ref.sh")]
+        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_graph_mt_shim.cpp", "ref_flatten.py", "ref_compat.h", "build_ref.sh")]
         if force or any(not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
-                        for so in (REF_SO, REFGRAPH_SO)):
+                        for so in (REF_SO, REFGRAPH_SO, os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_mt.so"))):
             subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
 
 
@@ -455,6 +455,16 @@ class ReferenceGraph:
     def rx11a_44(self, iq44, max_frames=64):
         """CreateDemodGraph11a_44M (TDownSample44_40 in front) over int16 [n,2] @44 MHz; sample_index in 44 MHz samples."""
         return self._events(self.L.ref_rx11a_capture44, iq44, max_frames)
+
+    def rx11a_two_threads(self, iq40, max_frames=64):
+        """The same graph WITH the reference's thread boundary (TThreadSeparator + a joined ViterbiThread), from
+        oracle/_ref/libsora_refgraph_mt.so (a separate library: the reference keeps its graph context in globals).  None if absent."""
+        p = os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_mt.so")
+        if not os.path.exists(p):
+            return None
+        if not hasattr(self, "_mt"):
+            self._mt = ctypes.CDLL(p)
+        return self._events(self._mt.ref_rx11a_capture_mt, iq40, max_frames)
 
     def rx11a(self, iq40, max_frames=64):
         """iq40: int16 [n,2] at 40 MHz.  -> list of dict(error_code, sample_index (40 MHz source position when

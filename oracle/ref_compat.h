@@ -8,6 +8,7 @@
 #include <typeinfo>
 #include <cxxabi.h>
 #include <new>
+#include <pthread.h>                        /* (system headers come before the SAL macros below: libc / libstdc++ use names like __in) */
 #include <stdint.h>
 #include <stddef.h>
 #include <string.h>

@@ -15,6 +15,7 @@ import sys
 
 REF = os.environ.get("SORA_REFERENCE", "/root/reference") + "/kernel"
 OUT = sys.argv[1]
+KEEP_SEPARATOR_11A = len(sys.argv) > 2 and sys.argv[2] == "mt"     # libsora_refgraph_mt.so: the 11a graph with its real thread boundary
 
 shutil.rmtree(OUT, ignore_errors=True)
 os.makedirs(OUT + "/bb")
@@ -90,7 +91,8 @@ edit("pinqueue.h", lambda s: s.replace("[nstream][qsize]", "[NSTREAM][lcm<N,M>::
 # ---- the 11a receive graph: the hop to the decoder thread becomes a same-thread pass-through (TNoInline swallows the
 #      sink's "stop" like the thread boundary does).  This is the deterministic limit of the two-thread harness -- an
 #      infinitely fast ViterbiThread -- which is also what oracle/so_rx11a.c and the GPU path implement.
-edit("fb11ademod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))
+if not KEEP_SEPARATOR_11A:
+    edit("fb11ademod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))
 # ---- mapper11a.hpp: an array bound that this clang's declaration/expression disambiguation trips over (same value)
 edit("mapper11a.hpp", lambda s: s.replace("(&lut)[intpow<2, LUT_BITS>::value][LUT_BITS/M/2]", "(&lut)[(1 << LUT_BITS)][LUT_BITS/M/2]"))
 

@@ -1,14 +1,20 @@
-"""Build libsora_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  `python -m sora_amd.build`."""
+"""Build libsora_hip.so (hand-written HIP for gfx950) in-tree with hipcc.  `python -m sora_amd.build`.
+
+Every source is compiled to its own object (in parallel, only when it or a header changed) and the objects are linked
+into sora_amd/lib/libsora_hip.so.  hipcc cross-compiles for gfx950 without a GPU."""
 import os
 import shutil
 import subprocess
 import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
+OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsora_hip.so")
 SOURCES = ["k_scan.hip", "k_rx.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "sora_hip.cpp"]
 HEADERS = ["dev_arith.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip"]
 
 
 def hipcc():
@@ -16,6 +22,19 @@ def hipcc():
         if c and os.path.exists(c):
             return c
     raise RuntimeError("hipcc not found: libsora_hip.so cannot be built (there is no CPU fallback)")
+
+
+def _newest_header():
+    return max(os.path.getmtime(os.path.join(CSRC, h)) for h in HEADERS)
+
+
+def _obj(src):
+    return os.path.join(OBJ, os.path.splitext(src)[0] + ".o")
+
+
+def _stale(src, hdr_t):
+    o = _obj(src)
+    return not os.path.exists(o) or os.path.getmtime(o) < max(os.path.getmtime(os.path.join(CSRC, src)), hdr_t)
 
 
 def needs_build():
@@ -28,9 +47,22 @@ def needs_build():
 def build(force=False, verbose=False):
     if not force and not needs_build():
         return LIB
-    os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [hipcc(), "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip"]
-    cmd += [os.path.join(CSRC, f) for f in SOURCES] + ["-o", LIB]
+    os.makedirs(OBJ, exist_ok=True)
+    cc = hipcc()
+    hdr_t = _newest_header()
+    todo = [s for s in SOURCES if force or _stale(s, hdr_t)]
+
+    def compile_one(src):
+        cmd = [cc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", _obj(src)]
+        if verbose:
+            print(" ".join(cmd))
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError("hipcc failed on %s:\n%s" % (src, r.stderr[-4000:]))
+
+    with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
+        list(ex.map(compile_one, todo))
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

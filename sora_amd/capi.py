@@ -40,13 +40,14 @@ class FrameResult(ctypes.Structure):
     _fields_ = [("capture_id", ctypes.c_uint32), ("start_sample", ctypes.c_uint32), ("end_sample", ctypes.c_uint32),
                 ("error_code", ctypes.c_uint32), ("rate_kbps", ctypes.c_uint32), ("length", ctypes.c_uint16),
                 ("nsym", ctypes.c_uint16), ("crc32", ctypes.c_uint32), ("cfo_est", ctypes.c_int16),
-                ("reserved", ctypes.c_uint16), ("mpdu_offset", ctypes.c_uint32)]
+                ("flags", ctypes.c_uint16), ("mpdu_offset", ctypes.c_uint32)]
 
 
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
-           "sora_rx_results_dev", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
+           "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
+           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results"]
@@ -91,6 +92,16 @@ def load(build_if_missing=True):
     L.sora_rx_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                   ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx_results_dev.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    L.sora_rx_ticket.argtypes = [ctypes.c_void_p]
+    L.sora_rx_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_results_of.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
+                                     ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_rx_results_dev_of.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
+    L.sora_rx_stream_of.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.sora_rx_stream_of.restype = ctypes.c_void_p
+    L.sora_rx_mpdu_bytes.argtypes = [ctypes.c_void_p, ctypes.c_int]; L.sora_rx_mpdu_bytes.restype = ctypes.c_size_t
+    L.sora_rx_deliver_async.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_hip_host_alloc.argtypes = [ctypes.c_size_t]; L.sora_hip_host_alloc.restype = ctypes.c_void_p
+    L.sora_hip_host_free.argtypes = [ctypes.c_void_p]; L.sora_hip_host_free.restype = None
     L.sora_rx_set_profiling.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
@@ -214,18 +225,39 @@ class Rx:
         arr, ptr = self._caps(captures)
         self._keep = d_iq
         _check(self._L.sora_rx_process_dev(self._h, _dev_ptr(d_iq), ptr, len(arr)))
+        return self._L.sora_rx_ticket(self._h)
 
     def process(self, h_iq, captures):
         a = np.ascontiguousarray(h_iq, np.int16).reshape(-1, 2)
         arr, ptr = self._caps(captures)
         _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), ptr, len(arr)))
+        return self._L.sora_rx_ticket(self._h)
 
-    def results_dev(self):
-        """Device-resident results of the last call: (rows int32 tensor [cap_rows, 9] (36-byte sora_frame_result rows),
-        nrows int32 tensor [1], mpdu uint8 base address).  The tensors alias library memory: valid until the next call."""
+    def ticket(self):
+        """ticket of the most recent process call (0: none)"""
+        return self._L.sora_rx_ticket(self._h)
+
+    def wait(self, ticket):
+        _check(self._L.sora_rx_wait(self._h, int(ticket)))
+
+    def mpdu_bytes(self, ticket):
+        return int(self._L.sora_rx_mpdu_bytes(self._h, int(ticket)))
+
+    def deliver_async(self, ticket, buf):
+        """Enqueue the delivery of the call's rows (+ MPDU array when buf.mpdu is not None) into the page-locked HostResults `buf`."""
+        _check(self._L.sora_rx_deliver_async(self._h, int(ticket), buf.rows.ctypes.data, len(buf.rows), buf.nrows.ctypes.data,
+                                             buf.mpdu.ctypes.data if buf.mpdu is not None else None, buf.mpdu.size if buf.mpdu is not None else 0))
+
+    def results_dev(self, ticket=None):
+        """Device-resident results of the last call (or of the call `ticket` names): (rows int32 tensor [cap_rows, 9] (36-byte
+        sora_frame_result rows), nrows int32 tensor [1], mpdu uint8 base address).  The tensors alias library memory: valid
+        until that pipeline's next call."""
         import torch
         rows = ctypes.c_void_p(); nrows = ctypes.c_void_p(); mpdu = ctypes.c_void_p()
-        _check(self._L.sora_rx_results_dev(self._h, ctypes.byref(rows), ctypes.byref(nrows), ctypes.byref(mpdu)))
+        if ticket is None:
+            _check(self._L.sora_rx_results_dev(self._h, ctypes.byref(rows), ctypes.byref(nrows), ctypes.byref(mpdu)))
+        else:
+            _check(self._L.sora_rx_results_dev_of(self._h, int(ticket), ctypes.byref(rows), ctypes.byref(nrows), ctypes.byref(mpdu)))
         cap = self.cfg.max_captures * self.cfg.max_frames_per_capture
         dev = torch.device("cuda", self.cfg.device)
 
@@ -255,13 +287,17 @@ class Rx:
     def reset(self):
         _check(self._L.sora_rx_reset(self._h))
 
-    def results(self, with_mpdu=True, max_frames=None):
+    def results(self, with_mpdu=True, max_frames=None, ticket=None):
+        """Frames of the most recent process call, or of the call `ticket` names."""
         if max_frames is None:
             max_frames = self.cfg.max_captures * self.cfg.max_frames_per_capture
         res = (FrameResult * max(1, max_frames))()
         n = ctypes.c_size_t(0)
         mp = np.zeros(max_frames * 2504 if with_mpdu else 1, np.uint8)
-        _check(self._L.sora_rx_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        if ticket is None:
+            _check(self._L.sora_rx_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        else:
+            _check(self._L.sora_rx_results_of(self._h, int(ticket), res, max_frames, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
         out = []
         for i in range(n.value):
             r = res[i]
@@ -270,6 +306,47 @@ class Rx:
                 d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
             out.append(d)
         return out
+
+
+ROW_DTYPE = np.dtype([("capture_id", "<u4"), ("start_sample", "<u4"), ("end_sample", "<u4"), ("error_code", "<u4"), ("rate_kbps", "<u4"),
+                      ("length", "<u2"), ("nsym", "<u2"), ("crc32", "<u4"), ("cfo_est", "<i2"), ("flags", "<u2"), ("mpdu_offset", "<u4")])   # = sora_frame_result
+ROW_TRUNCATED = 1
+
+
+class HostResults:
+    """Page-locked host buffers for Rx.deliver_async: rows (ROW_DTYPE), nrows (uint32[1]) and, optionally, the MPDU array
+    (row["mpdu_offset"] indexes it).  Memory comes from sora_hip_host_alloc; close() releases it."""
+
+    def __init__(self, max_rows, mpdu_bytes=0):
+        L = load()
+        self._L = L
+        assert ROW_DTYPE.itemsize == ctypes.sizeof(FrameResult) == 36
+        sizes = [max(1, max_rows) * 36, 64, max(0, int(mpdu_bytes))]
+        self._ptrs = []
+        arrs = []
+        for nbytes in sizes:
+            if nbytes == 0:
+                arrs.append(None); continue
+            p = L.sora_hip_host_alloc(nbytes)
+            if not p:
+                raise SoraError(-1, "sora_hip_host_alloc failed")
+            self._ptrs.append(p)
+            arrs.append(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p)))
+        self.rows = arrs[0].view(ROW_DTYPE)
+        self.nrows = arrs[1][:4].view(np.uint32)
+        self.mpdu = arrs[2]
+
+    def close(self):
+        for p in self._ptrs:
+            self._L.sora_hip_host_free(p)
+        self._ptrs = []
+        self.rows = self.nrows = self.mpdu = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class Rx11b:

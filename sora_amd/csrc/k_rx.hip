@@ -585,7 +585,7 @@ __global__ void __launch_bounds__(256) k_finish(RxArgs A)
 // k_pack: compacts the per-capture frame table into dense sora_frame_result rows in (capture, time) order, on the
 // device, so the rows can feed an RCCL all-gather without a host round trip.  mpdu_offset = slot0 * 32 indexes the
 // device MPDU array directly.  One 1024-thread block: captures are scanned in tiles of 1024.
-struct PackedRow { uint32_t capture_id, start_sample, end_sample, error_code, rate_kbps; uint16_t length, nsym; uint32_t crc32; int16_t cfo_est; uint16_t reserved; uint32_t mpdu_offset; };
+struct PackedRow { uint32_t capture_id, start_sample, end_sample, error_code, rate_kbps; uint16_t length, nsym; uint32_t crc32; int16_t cfo_est; uint16_t flags; uint32_t mpdu_offset; };
 __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames,
                                                PackedRow* rows, uint32_t* nrows_out)
 {
@@ -596,7 +596,8 @@ __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uin
     __syncthreads();
     for (uint32_t c0 = 0; c0 < ncaps; c0 += 1024) {
         const uint32_t c = c0 + t;
-        const uint32_t n = c < ncaps ? min(nframes[c], max_frames) : 0u;
+        const uint32_t found = c < ncaps ? nframes[c] : 0u;                      // k_scan counts every frame, also those past the row limit
+        const uint32_t n = min(found, max_frames);
         s_scan[t] = n;
         __syncthreads();
         for (uint32_t o = 1; o < 1024; o <<= 1) {                                // Hillis-Steele inclusive scan
@@ -610,7 +611,8 @@ __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uin
             const FrameRow& r = frames[(size_t)c * max_frames + i];
             PackedRow o;
             o.capture_id = caps[c].capture_id; o.start_sample = r.start_sample; o.end_sample = r.end_sample; o.error_code = r.error_code;
-            o.rate_kbps = r.rate_kbps; o.length = r.length; o.nsym = r.nsym; o.crc32 = r.crc32; o.cfo_est = r.cfo_est; o.reserved = 0;
+            o.rate_kbps = r.rate_kbps; o.length = r.length; o.nsym = r.nsym; o.crc32 = r.crc32; o.cfo_est = r.cfo_est;
+            o.flags = (i + 1 == n && found > max_frames) ? 1u : 0u;               // SORA_ROW_TRUNCATED: later frames of this capture have no row
             o.mpdu_offset = r.slot0 * (uint32_t)kOutPerSlot;
             rows[first + i] = o;
         }

@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
         if (pf_ok) pf_raw = lane < 28 ? x[pf_base + lane] : 0u;
         return v;
     };
-    while (nfr < A.max_frames) {
+    while (true) {                                                      // every frame is found and counted; rows / MPDUs only up to max_frames
         // All of the state is wave-uniform by construction, but the compiler's uniformity analysis loses that for the values
         // that live across the event handling below (3342 values of this kernel count as divergent without these lines, 614
         // with them -- the genuinely per-lane ones; tools/min_uniform_set.py found the smallest set that is needed).
@@ -352,11 +352,11 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
         if (error_code != 0) {
             const uint32_t err = error_code;
             if (err != E_CS_TIMEOUT) {
-                if (lane == 0) {
+                if (lane == 0 && nfr < A.max_frames) {
                     Rx11bRow row; row.end_sample = pos; row.error_code = err; row.rate_kbps = rate_kbps; row.length = frame_length; row.crc32 = frame_crc32;
                     A.rows[(size_t)cap_i * A.max_frames + nfr] = row;
                 }
-                if (err == E_FRAME_OK || err == E_CRC32_FAIL) {
+                if ((err == E_FRAME_OK || err == E_CRC32_FAIL) && nfr < A.max_frames) {
                     uint8_t* dst = A.mpdu + ((size_t)cap_i * A.max_frames + nfr) * kOutBuf;
                     const uint32_t n = min(frame_length, kOutBuf);
                     lds_order();
@@ -476,6 +476,8 @@ int sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsam
 {
     if (!rx || (nsamples && !h_iq)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_process: null argument", 0);
     if (nsamples > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process: more samples than max_total_samples", 0);
+    for (size_t i = 0; i < ncaps; i++)                                               // the buffer's size is known here: no descriptor may reach past it
+        if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer", 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
     if (!rx->d_iq_own) HIPCHK11(hipMalloc((void**)&rx->d_iq_own, sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
     HIPCHK11(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice, rx->stream));
@@ -512,6 +514,7 @@ int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out,
             memset(&o, 0, sizeof(o));
             o.capture_id = rx->h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
             o.length = (uint16_t)r.length; o.crc32 = r.crc32; o.mpdu_offset = (uint32_t)moff;
+            if (i + 1 == mf && nfr[c] > mf) o.flags = SORA_ROW_TRUNCATED;             // more frames were found than the capture has rows
             if (h_mpdu && (r.error_code == 1u || r.error_code == 0x80000006u)) {
                 const size_t len = r.length < 4096 ? r.length : 4096;
                 if (moff + len > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }

@@ -374,14 +374,15 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
         // T11aDesc + TBB11aFrameSink (scramble.hpp:319-349, PHY_11a.hpp:660-692) on W.out -> MPDU slot, error code
         auto finish_frame = [&]() __attribute__((always_inline)) {
             wsync();
-            uint8_t* mp = A.mpdu + ((size_t)cap * A.max_frames + min(nfr, A.max_frames - 1)) * 4096;
+            const bool has_row = nfr < A.max_frames;                         // frames past the row limit are decoded and counted, not stored
+            uint8_t* mp = A.mpdu + ((size_t)cap * A.max_frames + (has_row ? nfr : 0u)) * 4096;
             const unsigned seed = W.out[1] >> 1;
             const unsigned phase = A.T.scr_phase[seed & 0x7F];
             uint8_t* bytes = reinterpret_cast<uint8_t*>(W.buf);              // 1024 bytes + W.fft behind it: 2048 >= 1500
             for (uint32_t i = lane; i < ht_len; i += 64) {
                 const unsigned sb = phase == 255 ? 0u : A.T.scr_seq[(phase + 8u * i) % 127u];
                 const unsigned o = W.out[2 + i] ^ sb;
-                bytes[i] = (uint8_t)o; mp[i] = (uint8_t)o;
+                bytes[i] = (uint8_t)o; if (has_row) mp[i] = (uint8_t)o;
             }
             wsync();
             const int n = ht_len >= 4 ? (int)ht_len - 4 : 0;
@@ -648,6 +649,8 @@ int sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const sora
 {
     if (!rx || (nsamples && (!h_iq0 || !h_iq1))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_process: null argument", 0);
     if (nsamples > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process: more samples than max_total_samples", 0);
+    for (size_t i = 0; i < ncaps; i++)                                               // the buffer's size is known here: no descriptor may reach past it
+        if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     const sora_complex16* src[2] = { h_iq0, h_iq1 };
     for (int k = 0; k < 2; k++) {
@@ -686,6 +689,7 @@ int sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out,
             memset(&o, 0, sizeof(o));
             o.capture_id = rx->h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
             o.length = (uint16_t)r.length; o.crc32 = r.crc32; o.mpdu_offset = (uint32_t)moff;
+            if (i + 1 == mf && nfr[c] > mf) o.flags = SORA_ROW_TRUNCATED;             // more frames were found than the capture has rows
             if (h_mpdu && (r.error_code == 1u || r.error_code == 0x80000006u)) {
                 const size_t len = r.length < 4096 ? r.length : 4096;
                 if (moff + len > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }

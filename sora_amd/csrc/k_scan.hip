@@ -238,7 +238,10 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
     };
 
     const uint32_t nchunks = nunits / APP;
-    for (uint32_t c = 0; c < nchunks && nfr < A.max_frames; c++) {
+    // Every frame of the capture is found and counted, as RxThread reports every frame; those past the row limit get no row and
+    // no decode job (their per-frame context goes to the capture's spare FrameCtx), and the host flags the capture's last row.
+    auto ctx_of = [&](uint32_t k) { return A.fctx + (k < A.max_frames ? (size_t)cap_i * A.max_frames + k : (size_t)A.nrows + cap_i); };
+    for (uint32_t c = 0; c < nchunks; c++) {
         const uint32_t avail_end = (c + 1) * APP;
         while (vpos + BUR <= avail_end) {
             if (!cca_detected && !sync_high && auto_count == 0) {
@@ -329,7 +332,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                     const int cfo = arg >> 6;                   // size_t divisor: unsigned division = floor (dspalg.hpp:242)
                     // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
                     const cpx fc = rot_coeff(T, w16(lane * cfo));
-                    FrameCtx* fx = A.fctx + (size_t)cap_i * A.max_frames + nfr;
+                    FrameCtx* fx = ctx_of(nfr);
                     fx->freq[lane] = pack(fc);
                     cpx xs = mul_q15(x1, fc);                                     // FrequencyShift (:120)
                     sync();
@@ -372,7 +375,7 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                     if (sym_idx == 0) {
                         PROBE_T0();
                         // ---- the SIGNAL symbol: full header chain, lane-parallel
-                        FrameCtx* fx = A.fctx + (size_t)cap_i * A.max_frames + nfr;
+                        FrameCtx* fx = ctx_of(nfr);
                         const int e = lane & 15;
                         cpx xin[4], Y[4];
 #pragma unroll
@@ -508,12 +511,13 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                 error_code = 0; cca_detected = 0; cs_reset();
             } else {
                 const bool plcp_fail = error_code == E_PLCP_HEADER_FAIL;
+                const bool has_row = nfr < A.max_frames;
                 if (plcp_fail) r_end = vpos / STR;
-                else {
+                else if (has_row) {
                     // queue the frame for the per-frame kernels
                     if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
                 }
-                if (lane == 0) {
+                if (lane == 0 && has_row) {
                     FrameRow row;
                     row.capture = cap_i; row.start_sample = r_start; row.end_sample = r_end;
                     row.error_code = plcp_fail ? E_PLCP_HEADER_FAIL : 0u;                 // 0 = pending: decided by k_finish

@@ -8,6 +8,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 #include "../../include/sora_hip.h"
@@ -220,12 +222,15 @@ static int make_dev_tables(DevTables& D)
 }
 static void free_dev_tables(DevTables& D) { for (void* p : D.allocs) (void)hipFree(p); D.allocs.clear(); }
 
-// per-device tables for the stand-alone stage entry points
+// per-device tables for the stand-alone stage entry points: created once per device, under a lock (stage calls on
+// different handles / threads are independent, include/sora_hip.h)
+static std::mutex g_stage_mutex;
 static DevTables* stage_tables()
 {
     static DevTables* tabs[64] = {nullptr};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_stage_mutex);
     if (!tabs[dev]) {
         DevTables* D = new DevTables();
         if (make_dev_tables(*D) != SORA_OK) { free_dev_tables(*D); delete D; return nullptr; }
@@ -270,6 +275,7 @@ struct RxPipe {
     CapDesc* h_caps_pinned = nullptr; size_t caps_resident = 0; hipEvent_t ev_caps = nullptr;
     uint32_t ncaps = 0, total_slots = 0;
     bool have_results = false;
+    int ticket = 0;              // the process call this pipeline holds (sora_rx_ticket); 0 = none
     // Opt-in (SORA_HIP_GRAPH=1): a call that repeats the previous one's geometry (same IQ buffer, same capture set) replays
     // the kernel chain as one hipGraph launch.  Off by default: on this path the GPU time per call dwarfs the six enqueues,
     // and instantiating the graph on the second identical call costs more than it saves for short runs.
@@ -328,6 +334,8 @@ void  sora_hip_free(void* p) { if (p) (void)hipFree(p); }
 int   sora_hip_memcpy_h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return SORA_OK; }
 int   sora_hip_stream_synchronize(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return SORA_OK; }
 int   sora_hip_memcpy_d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return SORA_OK; }
+void* sora_hip_host_alloc(size_t bytes) { void* p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
+void  sora_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
 static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
 {
@@ -352,11 +360,18 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "pinned descriptor buffer", e); }
     if (const char* g = getenv("SORA_HIP_GRAPH")) rx->use_graph = atoi(g) != 0;
     const uint64_t n20 = cfg->max_total_samples / rx->str;
-    rx->cap_slots = (uint32_t)(n20 / 80 + cfg->max_captures + 16);
-    rx->cap_rows = cfg->max_captures * cfg->max_frames_per_capture;
+    // Symbol slots, frame rows and the byte offsets derived from them are 32-bit on the device (VitJob::soft_off = slot x 576):
+    // a configuration that would wrap them is refused here instead of decoding garbage later.
+    const uint64_t want_slots = n20 / 80 + cfg->max_captures + 16, want_rows = (uint64_t)cfg->max_captures * cfg->max_frames_per_capture;
+    if (want_slots * (2ull * kSoftPerSlot) >= (1ull << 32) || want_rows >= (1ull << 31) / 3 || cfg->max_total_samples >= (1ull << 32)) {
+        rx_free(rx);
+        return fail(SORA_ERR_CAPACITY, "sora_rx_create: max_total_samples / max_captures x max_frames_per_capture exceed the 32-bit slot geometry of one handle (split the batch over several handles)");
+    }
+    rx->cap_slots = (uint32_t)want_slots;
+    rx->cap_rows = (uint32_t)want_rows;
     struct { void** p; size_t bytes; } allocs[] = {
         { (void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures }, { (void**)&rx->d_frames, sizeof(FrameRow) * rx->cap_rows },
-        { (void**)&rx->d_fctx, sizeof(FrameCtx) * rx->cap_rows }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
+        { (void**)&rx->d_fctx, sizeof(FrameCtx) * ((size_t)rx->cap_rows + cfg->max_captures) }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
         { (void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64 },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
         { (void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
@@ -377,7 +392,7 @@ static int pipe_reset(RxPipe* rx)
     if (!rx) return SORA_ERR_INVALID_PARAM;
     HIPCHK(hipSetDevice(rx->cfg.device));
     HIPCHK(hipStreamSynchronize(rx->stream));
-    rx->ncaps = 0; rx->total_slots = 0; rx->have_results = false; rx->h_caps.clear();
+    rx->ncaps = 0; rx->total_slots = 0; rx->have_results = false; rx->h_caps.clear(); rx->ticket = 0;
     return SORA_OK;
 }
 
@@ -391,21 +406,25 @@ static int pipe_flush(RxPipe* rx)
 
 static void* pipe_stream(RxPipe* rx) { return rx ? (void*)rx->stream : nullptr; }
 
-static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
+static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps, uint64_t iq_samples = 0)
 {
     if (!rx || (!d_iq && ncaps) || (!caps && ncaps)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
     if (ncaps > rx->cfg.max_captures) return fail(SORA_ERR_CAPACITY, "more captures than sora_rx_cfg.max_captures");
     HIPCHK(hipSetDevice(rx->cfg.device));
-    rx->h_caps.resize(ncaps);
-    uint64_t total = 0; uint32_t slots = 0;
+    std::vector<CapDesc> hc(ncaps);                                              // validated first: a refused call leaves the handle's last call intact
+    uint64_t total = 0, slots64 = 0;
     for (size_t i = 0; i < ncaps; i++) {
         if (caps[i].offset & 3) return fail(SORA_ERR_INVALID_PARAM, "capture offset must be a multiple of 4 samples (16-byte alignment, memsource.hpp:59)");
-        CapDesc& c = rx->h_caps[i];
+        CapDesc& c = hc[i];
         c.offset = caps[i].offset; c.nsamples = caps[i].nsamples; c.capture_id = caps[i].capture_id;
-        c.slot_base = slots; c.nslots = (caps[i].nsamples / rx->str) / 80 + 1;
-        slots += c.nslots; total += caps[i].nsamples;
+        c.slot_base = (uint32_t)slots64; c.nslots = (caps[i].nsamples / rx->str) / 80 + 1;
+        slots64 += c.nslots; total += caps[i].nsamples;
+        if (iq_samples && (caps[i].offset > iq_samples || caps[i].nsamples > iq_samples - caps[i].offset))
+            return fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer");
     }
-    if (total > rx->cfg.max_total_samples || slots > rx->cap_slots) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
+    if (total > rx->cfg.max_total_samples || slots64 > rx->cap_slots) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
+    const uint32_t slots = (uint32_t)slots64;
+    rx->h_caps.swap(hc);
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
     hipStream_t st = rx->stream;
@@ -487,7 +506,17 @@ static int pipe_process(RxPipe* rx, const sora_complex16* h_iq, size_t total_sam
         rx->iq_own_samples = total_samples;
     }
     HIPCHK(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * total_samples, hipMemcpyHostToDevice, rx->stream));
-    return pipe_process_dev(rx, rx->d_iq_own, caps, ncaps);
+    return pipe_process_dev(rx, rx->d_iq_own, caps, ncaps, total_samples);
+}
+
+static int pipe_pack(RxPipe* rx)                                                // dense rows of the pipeline's call -> d_rows / d_nrows, in stream order
+{
+    static_assert(sizeof(sora_frame_result) == 36, "sora_frame_result layout");
+    if (rx->ncaps == 0) HIPCHK(hipMemsetAsync(rx->d_nrows, 0, 4, rx->stream));
+    else hipLaunchKernelGGL(k_pack, dim3(1), dim3(1024), 0, rx->stream, (const FrameRow*)rx->d_frames, (const uint32_t*)rx->d_nframes,
+                            (const CapDesc*)rx->d_caps, rx->ncaps, rx->cfg.max_frames_per_capture, reinterpret_cast<PackedRow*>(rx->d_rows), rx->d_nrows);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
 }
 
 static int pipe_results(RxPipe* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
@@ -497,27 +526,27 @@ static int pipe_results(RxPipe* rx, sora_frame_result* out, size_t max_out, size
     if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
     if (rx->ncaps == 0) return SORA_OK;
     HIPCHK(hipSetDevice(rx->cfg.device));
+    { const int rc = pipe_pack(rx); if (rc) return rc; }
+    uint32_t nrows = 0;
+    HIPCHK(hipMemcpyAsync(&nrows, rx->d_nrows, 4, hipMemcpyDeviceToHost, rx->stream));
     HIPCHK(hipStreamSynchronize(rx->stream));
-    const uint32_t mf = rx->cfg.max_frames_per_capture, nrows = rx->ncaps * mf;
-    std::vector<FrameRow> rows(nrows); std::vector<uint32_t> nfr(rx->ncaps);
-    HIPCHK(hipMemcpy(rows.data(), rx->d_frames, sizeof(FrameRow) * nrows, hipMemcpyDeviceToHost));
-    HIPCHK(hipMemcpy(nfr.data(), rx->d_nframes, 4 * (size_t)rx->ncaps, hipMemcpyDeviceToHost));
+    std::vector<sora_frame_result> rows(nrows);
+    if (nrows) HIPCHK(hipMemcpy(rows.data(), rx->d_rows, sizeof(sora_frame_result) * (size_t)nrows, hipMemcpyDeviceToHost));
     std::vector<uint8_t> mp;
-    if (h_mpdu) { mp.resize((size_t)kOutPerSlot * rx->total_slots); HIPCHK(hipMemcpy(mp.data(), rx->d_mpdu, mp.size(), hipMemcpyDeviceToHost)); }
+    if (h_mpdu && nrows) { mp.resize((size_t)kOutPerSlot * rx->total_slots); HIPCHK(hipMemcpy(mp.data(), rx->d_mpdu, mp.size(), hipMemcpyDeviceToHost)); }
     size_t n = 0, moff = 0; int rc = SORA_OK;
-    for (uint32_t c = 0; c < rx->ncaps; c++)
-        for (uint32_t i = 0; i < nfr[c] && i < mf; i++) {
-            const FrameRow& r = rows[(size_t)c * mf + i];
-            if (n >= max_out) { rc = SORA_ERR_CAPACITY; continue; }
-            sora_frame_result& o = out[n++];
-            o.capture_id = rx->h_caps[c].capture_id; o.start_sample = r.start_sample; o.end_sample = r.end_sample; o.error_code = r.error_code;
-            o.rate_kbps = r.rate_kbps; o.length = r.length; o.nsym = r.nsym; o.crc32 = r.crc32; o.cfo_est = r.cfo_est; o.reserved = 0; o.mpdu_offset = (uint32_t)moff;
-            if (h_mpdu && (r.error_code == E_FRAME_OK || r.error_code == E_CRC32_FAIL)) {
-                if (moff + r.length > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
-                memcpy(h_mpdu + moff, mp.data() + (size_t)r.slot0 * kOutPerSlot, r.length);
-                moff += r.length;
-            }
+    for (uint32_t i = 0; i < nrows; i++) {
+        if (n >= max_out) { rc = SORA_ERR_CAPACITY; break; }
+        sora_frame_result& o = out[n++];
+        o = rows[i];
+        const size_t src = o.mpdu_offset;                                        // slot0 * 32 in the device array
+        o.mpdu_offset = (uint32_t)moff;                                          // dense in the caller's buffer
+        if (h_mpdu && (o.error_code == E_FRAME_OK || o.error_code == E_CRC32_FAIL)) {
+            if (moff + o.length > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
+            memcpy(h_mpdu + moff, mp.data() + src, o.length);
+            moff += o.length;
         }
+    }
     *nout = n;
     if (rc != SORA_OK) return fail(rc, "sora_rx_results: output buffer too small");
     return SORA_OK;
@@ -541,14 +570,28 @@ static int pipe_results_dev(RxPipe* rx, const sora_frame_result** d_rows, const 
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results_dev: null handle");
     if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
     HIPCHK(hipSetDevice(rx->cfg.device));
-    static_assert(sizeof(sora_frame_result) == 36, "sora_frame_result layout");
-    if (rx->ncaps == 0) HIPCHK(hipMemsetAsync(rx->d_nrows, 0, 4, rx->stream));
-    else hipLaunchKernelGGL(k_pack, dim3(1), dim3(1024), 0, rx->stream, (const FrameRow*)rx->d_frames, (const uint32_t*)rx->d_nframes,
-                            (const CapDesc*)rx->d_caps, rx->ncaps, rx->cfg.max_frames_per_capture, reinterpret_cast<PackedRow*>(rx->d_rows), rx->d_nrows);
-    HIPCHK(hipGetLastError());
+    { const int rc = pipe_pack(rx); if (rc) return rc; }
     if (d_rows) *d_rows = rx->d_rows;
     if (d_nrows) *d_nrows = rx->d_nrows;
     if (d_mpdu) *d_mpdu = rx->d_mpdu;
+    return SORA_OK;
+}
+
+// Result delivery without a host wait: pack, then copy rows / count / MPDU array behind the call's kernels on its own stream.
+static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_nrows, uint8_t* h_mpdu, size_t mpdu_bytes)
+{
+    if (!rx || !h_rows || !h_nrows) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_deliver_async: null argument");
+    if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    { const int rc = pipe_pack(rx); if (rc) return rc; }
+    const size_t nr = std::min<size_t>(max_rows, (size_t)rx->ncaps * rx->cfg.max_frames_per_capture);
+    HIPCHK(hipMemcpyAsync(h_nrows, rx->d_nrows, 4, hipMemcpyDeviceToHost, rx->stream));
+    if (nr) HIPCHK(hipMemcpyAsync(h_rows, rx->d_rows, sizeof(sora_frame_result) * nr, hipMemcpyDeviceToHost, rx->stream));
+    if (h_mpdu) {
+        const size_t need = (size_t)kOutPerSlot * rx->total_slots;
+        if (mpdu_bytes < need) return fail(SORA_ERR_CAPACITY, "sora_rx_deliver_async: h_mpdu is smaller than sora_rx_mpdu_bytes()");
+        if (need) HIPCHK(hipMemcpyAsync(h_mpdu, rx->d_mpdu, need, hipMemcpyDeviceToHost, rx->stream));
+    }
     return SORA_OK;
 }
 
@@ -566,8 +609,16 @@ struct sora_rx {
     int cur = 0;                 // pipeline of the most recent process call
     bool started = false;
     bool profiling = false;
+    int seq = 0;                 // ticket of the most recent process call
     RxPipe* pipes[kMaxDepth] = {};
 };
+
+static RxPipe* pipe_of(sora_rx* rx, int ticket)
+{
+    if (!rx || ticket <= 0) return nullptr;
+    for (RxPipe* p : rx->pipes) if (p && p->ticket == ticket) return p;
+    return nullptr;
+}
 
 static RxPipe* pipe_at(sora_rx* rx, int i)
 {
@@ -631,7 +682,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
-    if (rc == SORA_OK) { rx->cur = next; rx->started = true; }
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
 }
 
@@ -642,7 +693,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
-    if (rc == SORA_OK) { rx->cur = next; rx->started = true; }
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
 }
 
@@ -656,6 +707,42 @@ int sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const u
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_results_dev: null handle");
     return pipe_results_dev(rx->pipes[rx->cur], d_rows, d_nrows, d_mpdu);
+}
+
+int sora_rx_ticket(sora_rx_t* rx) { return rx && rx->started ? rx->pipes[rx->cur]->ticket : 0; }
+
+static const char* const kStale = "stale ticket: its pipeline has been reused by a later process call (or the ticket was never issued)";
+
+int sora_rx_wait(sora_rx_t* rx, int ticket)
+{
+    RxPipe* p = pipe_of(rx, ticket);
+    if (!p) return fail(SORA_ERR_INVALID_PARAM, kStale);
+    return pipe_flush(p);
+}
+
+void* sora_rx_stream_of(sora_rx_t* rx, int ticket) { RxPipe* p = pipe_of(rx, ticket); return p ? pipe_stream(p) : nullptr; }
+
+int sora_rx_results_of(sora_rx_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    RxPipe* p = pipe_of(rx, ticket);
+    if (!p) return fail(SORA_ERR_INVALID_PARAM, kStale);
+    return pipe_results(p, out, max_out, nout, h_mpdu, mpdu_cap);
+}
+
+int sora_rx_results_dev_of(sora_rx_t* rx, int ticket, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
+{
+    RxPipe* p = pipe_of(rx, ticket);
+    if (!p) return fail(SORA_ERR_INVALID_PARAM, kStale);
+    return pipe_results_dev(p, d_rows, d_nrows, d_mpdu);
+}
+
+size_t sora_rx_mpdu_bytes(sora_rx_t* rx, int ticket) { RxPipe* p = pipe_of(rx, ticket); return p ? (size_t)kOutPerSlot * p->total_slots : 0; }
+
+int sora_rx_deliver_async(sora_rx_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_nrows, uint8_t* h_mpdu, size_t mpdu_bytes)
+{
+    RxPipe* p = pipe_of(rx, ticket);
+    if (!p) return fail(SORA_ERR_INVALID_PARAM, kStale);
+    return pipe_deliver_async(p, h_rows, max_rows, h_nrows, h_mpdu, mpdu_bytes);
 }
 
 int sora_rx_set_profiling(sora_rx_t* rx, int enable)
@@ -793,12 +880,19 @@ int sora_hip_tx11a(const uint8_t* d_mpdu, const uint32_t* d_off, const uint32_t*
     if (nframes == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
     hipStream_t st = (hipStream_t)stream;
-    if (!D->tx_preamble) {
-        int8_t* p = nullptr;
-        HIPCHK(hipMalloc((void**)&p, 1280));
-        hipLaunchKernelGGL(k_tx_preamble, dim3(1), dim3(64), 0, st, p, D->T);
-        HIPCHK(hipGetLastError());
-        D->tx_preamble = p; D->allocs.push_back(p);
+    {
+        // built once per device, under the lock, and complete before it is published: a call on another stream or thread
+        // must never see a half-written preamble
+        std::lock_guard<std::mutex> lock(g_stage_mutex);
+        if (!D->tx_preamble) {
+            int8_t* p = nullptr;
+            HIPCHK(hipMalloc((void**)&p, 1280));
+            hipLaunchKernelGGL(k_tx_preamble, dim3(1), dim3(64), 0, st, p, D->T);
+            hipError_t e = hipGetLastError();
+            if (e == hipSuccess) e = hipStreamSynchronize(st);
+            if (e != hipSuccess) { (void)hipFree(p); return fail(SORA_ERR_HARDWARE_FAILED, "k_tx_preamble", e); }
+            D->tx_preamble = p; D->allocs.push_back(p);
+        }
     }
     TxArgs A{};
     A.mpdu = d_mpdu; A.off = d_off; A.len = d_len; A.rate = d_rate_kbps; A.seed = d_seed; A.out8 = d_out; A.out_off = d_out_off;
@@ -868,18 +962,18 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
         h_s16_off[i] = (uint32_t)s16; s16 += ((uint64_t)h_nsoft[i] * 2 + 64 + 3) & ~3ull;      // + slack for the last 12-step chunk
     }
     if (s16 >> 32) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
-    VitJob* jobs = nullptr; uint8_t* soft16 = nullptr; uint32_t* s16off = nullptr;
-    HIPCHK(hipMalloc((void**)&soft16, s16 + 64));
-    HIPCHK(hipMalloc((void**)&s16off, 4 * n));
-    HIPCHK(hipMalloc((void**)&jobs, sizeof(VitJob) * n));
+    // scratch (the 16-bit soft stream, its offsets, the job table) in one allocation, released on every path
+    struct Scratch { void* p = nullptr; ~Scratch() { if (p) (void)hipFree(p); } } scratch;
+    const size_t soft_bytes = (s16 + 64 + 255) & ~(size_t)255, off_bytes = (4 * n + 255) & ~(size_t)255;
+    HIPCHK(hipMalloc(&scratch.p, soft_bytes + off_bytes + sizeof(VitJob) * n));
+    uint8_t* soft16 = (uint8_t*)scratch.p; uint32_t* s16off = (uint32_t*)(soft16 + soft_bytes); VitJob* jobs = (VitJob*)(soft16 + soft_bytes + off_bytes);
     HIPCHK(hipMemsetAsync(soft16, 0, s16 + 64, st));
     HIPCHK(hipMemcpyAsync(s16off, h_s16_off.data(), 4 * n, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, (const uint32_t*)s16off, soft16);
     hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, (const uint32_t*)s16off, d_nsoft, d_frame_len, d_out_off, code_rate, (uint32_t)n);
     hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)soft16, d_out);
-    hipError_t e = hipStreamSynchronize(st);
-    (void)hipFree(jobs); (void)hipFree(soft16); (void)hipFree(s16off);
-    if (e != hipSuccess) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_viterbi11a", e);
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(st));                                             // the scratch is released when this function returns
     return SORA_OK;
 }
 

@@ -24,7 +24,7 @@ def rows_from_results(results):
     for i, r in enumerate(results):
         out[i] = (r["capture_id"], r["start_sample"], r["end_sample"], r["error_code"], r["rate_kbps"],
                   (r["length"] & 0xFFFF) | ((r["nsym"] & 0xFFFF) << 16), r["crc32"],
-                  (r["cfo_est"] & 0xFFFF) | ((r.get("reserved", 0) & 0xFFFF) << 16), r.get("mpdu_offset", 0))
+                  (r["cfo_est"] & 0xFFFF) | ((r.get("flags", 0) & 0xFFFF) << 16), r.get("mpdu_offset", 0))
     return out.view(np.int32)
 
 
@@ -35,7 +35,7 @@ def results_from_rows(rows):
         cfo = int(w[7] & 0xFFFF)
         out.append({"capture_id": int(w[0]), "start_sample": int(w[1]), "end_sample": int(w[2]), "error_code": int(w[3]),
                     "rate_kbps": int(w[4]), "length": int(w[5] & 0xFFFF), "nsym": int(w[5] >> 16), "crc32": int(w[6]),
-                    "cfo_est": cfo - 65536 if cfo >= 32768 else cfo, "reserved": int(w[7] >> 16), "mpdu_offset": int(w[8])})
+                    "cfo_est": cfo - 65536 if cfo >= 32768 else cfo, "flags": int(w[7] >> 16), "mpdu_offset": int(w[8])})
     return out
 
 

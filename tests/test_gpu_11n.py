@@ -86,9 +86,14 @@ def test_gpu_edge_cases():
         assert ok, (i, why)
     assert got[0] == [] and got[1] == [] and len(got[2]) == 3
     # fewer rows than frames: the first rows are reported
-    one = run_batch([(a3, b3)], max_frames=1)
-    ok, why = same_events_11n(one[0], o.rx11n_capture(a3, b3)[:1], position="end_sample")
-    assert ok, why
+    for mf in (1, 2):
+        one = run_batch([(a3, b3)], max_frames=mf)
+        ok, why = same_events_11n(one[0], o.rx11n_capture(a3, b3)[:mf], position="end_sample")
+        assert ok, why
+        # ... with their own MPDU bytes (no later frame's payload in the last row) and the last row flagged
+        assert [r["mpdu"] for r in one[0]] == [r["mpdu"] for r in got[2][:mf]]
+        assert [r["flags"] for r in one[0]] == [0] * (mf - 1) + [sora_amd.ROW_TRUNCATED]
+    assert all(r["flags"] == 0 for r in got[2])
     # the same captures addressed at odd offsets of one buffer (descriptors need not be aligned)
     pad = 13
     iq0 = np.concatenate([np.zeros((pad, 2), np.int16), a3, np.zeros((7, 2), np.int16), a3[:2800]])
@@ -101,3 +106,39 @@ def test_gpu_edge_cases():
         assert ok, (cid, why)
     with pytest.raises(sora_amd.SoraError):
         rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), [(0, 27, 0)])       # not a whole source burst
+
+
+def test_gpu_equals_the_live_reference_graph():
+    """The GPU path against the reference ITSELF, directly: CreateDemodGraph11n compiled from the reference sources
+    (oracle/_ref/libsora_refgraph.so, ref_rx11n_capture = the RxThread loop of fb11n_demod.cpp:30-85) on random two-chain
+    captures -- frames of the compiled reference modulator at MCS 8, 9, 10 (decoded) and 11-14 (refused by the SIG parser),
+    random lengths, 1-3 frames per capture, gain / phase / cross-talk / CFO / noise up to failure, frames cut by the end of
+    the capture.  Error code, 40 MHz source position, MCS, length, FCS and MPDU bytes of every event."""
+    import sora_amd
+    from oracle.pyoracle import ReferenceGraph
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    rng = np.random.default_rng(20260926)
+    frames = []
+    for k in range(40):
+        mcs = [8, 9, 10, 8, 9, 10, 10, 11, 12, 13, 14][k % 11]
+        ln = int(rng.integers(1, 1497)) if k % 3 else int(rng.integers(1, 80))
+        frames.append(g.tx11n(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), mcs))
+    caps = []
+    for t in range(320):
+        fr = [frames[int(i)] for i in rng.integers(0, len(frames), size=int(rng.integers(1, 4)))]
+        caps.append(capture_11n(rng, fr, sigma=float(rng.choice([3, 20, 60, 200, 600, 1500])), cut=float(rng.uniform(0.05, 1.0)) if t % 3 == 2 else None))
+    got = run_batch(caps)
+    nev = 0; kinds = {}
+    for i, (a, b) in enumerate(caps):
+        want = g.rx11n(a, b)
+        ok, why = same_events_11n(got[i], want, position="sample_index")
+        assert ok, (i, why, [(hex(e["error_code"]), e["rate_kbps"], e["length"], e["end_sample"]) for e in got[i]],
+                    [(hex(e["error_code"]), e["rate_kbps"], e["length"], e["sample_index"]) for e in want])
+        nev += len(want)
+        for e in want:
+            kinds[e["error_code"]] = kinds.get(e["error_code"], 0) + 1
+    assert nev > 320 and kinds.get(1, 0) > 100 and kinds.get(0x80000005, 0) > 50, kinds

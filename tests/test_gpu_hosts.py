@@ -1,0 +1,98 @@
+"""Hosts other than the Python binding, EXECUTED on the GPU box (-m gpu): the plain-C example hosts (the reference's
+harness language, `demod11 -d`) and a BRICK-shaped C++ graph built from include/sora_brick.hpp.  They link
+libsora_hip.so like any user would (gcc / g++, -lsora_hip) and run as separate processes."""
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+OUT = os.path.join(ROOT, "examples", "_build")
+
+
+def build(cc, std, src, name, extra=()):
+    import sora_amd
+    sora_amd.load()
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    os.makedirs(OUT, exist_ok=True)
+    libdir = os.path.dirname(sora_amd.lib_path())
+    exe = os.path.join(OUT, name)
+    r = subprocess.run([cc, std, "-O1", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir, "-lsora_hip",
+                        "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib", "-Wl,--allow-shlib-undefined", "-o", exe] + list(extra),
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def run(cmd):
+    env = dict(os.environ); env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, (r.stdout[-2000:], r.stderr[-2000:])
+    return r.stdout
+
+
+def make_dump(iq, raw14):
+    """int16 [n,2] -> Sora dump bytes: 128-byte RX_BLOCKs = 16-byte descriptor + 28 COMPLEX16 (brickutil.h:40-55)."""
+    n = len(iq) // 28 * 28
+    x = iq[:n].astype(np.int16)
+    if raw14:
+        x = ((x.astype(np.int32) >> 2) & 0x3FFF).astype(np.uint16).view(np.int16)
+    blocks = np.zeros((n // 28, 64), np.int16)
+    blocks[:, 0] = 1                                                    # descriptor: valid flag, rest unused by the loader
+    blocks[:, 8:] = x.reshape(-1, 56)
+    return blocks.tobytes()
+
+
+def test_plain_c_host_decodes_the_recorded_dump(tmp_path, golden_dir):
+    """examples/demod11a.c (the reference's `demod11 --802.11a.brick -d -f fsample-6.dmp -p 40`) on kernel/test-data's
+    fsample-6 re-framed as the dump it came from: 6 Mbps, 1392 bytes, FCS 0x80ef9b11, MPDU sha256 5a13a477..."""
+    exe = build("gcc", "-std=c11", os.path.join(ROOT, "examples", "demod11a.c"), "demod11a")
+    iq = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8
+    dump = tmp_path / "fsample6.dmp"; dump.write_bytes(make_dump(iq, raw14=True))
+    mp = tmp_path / "mpdu.bin"
+    out = run([exe, str(dump), "--raw14", "--rate", "40", "--out", str(mp)])
+    assert "6000 kbps" in out and "length 1392" in out and "FCS 80ef9b11" in out and "FRAME_OK" in out and "good 1 / bad 0" in out, out
+    assert hashlib.sha256(mp.read_bytes()).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+
+
+def test_plain_c_hosts_of_the_11b_and_11n_graphs_run(tmp_path, golden_dir, oracle):
+    """examples/demod11b.c / demod11n.c on recorded modulator output (tests/golden): every frame the oracle reports."""
+    from test_oracle_11b import channel_11b
+    from gpu_util import capture_11n
+    z = np.load(os.path.join(golden_dir, "refgraph_11b.npz"))
+    c = channel_11b(z["tx_1"], 101)
+    want = oracle.rx11b_capture(c)
+    f = tmp_path / "b.dmp"; f.write_bytes(make_dump(c, raw14=False))
+    exe = build("gcc", "-std=c11", os.path.join(ROOT, "examples", "demod11b.c"), "demod11b")
+    out = run([exe, str(f)])
+    assert out.count("FRAME_OK") == sum(1 for r in want if r["error_code"] == 1) >= 1, out
+    zn = np.load(os.path.join(golden_dir, "refgraph_11n.npz"))
+    a, b = capture_11n(np.random.default_rng(3), [(zn["tx1_0"], zn["tx1_1"])], sigma=20.0)
+    wn = oracle.rx11n_capture(a, b)
+    (tmp_path / "n_0.dmp").write_bytes(make_dump(a, raw14=False)); (tmp_path / "n_1.dmp").write_bytes(make_dump(b, raw14=False))
+    exe = build("gcc", "-std=c11", os.path.join(ROOT, "examples", "demod11n.c"), "demod11n")
+    out = run([exe, str(tmp_path / "n")])
+    assert out.count("FRAME_OK") == sum(1 for r in wn if r["error_code"] == 1) >= 1, out
+
+
+@pytest.mark.parametrize("nb", [1, 2, 4, 6])
+def test_brick_adapter_chain_runs_on_the_gpu(tmp_path, oracle, nb):
+    """THipFFT64 -> THip11aDemap<N> -> THip11aDeinterleave<N> -> sink, built and driven like a CREATE_BRICK_* chain
+    (tests/cxx/brick_chain.cpp): what comes out of the sink is deinterleave(demap(FFT<64>(x))) of the oracle, bit for bit."""
+    exe = build("g++", "-std=c++17", os.path.join(ROOT, "tests", "cxx", "brick_chain.cpp"), "brick_chain")
+    rng = np.random.default_rng(40 + nb)
+    n = 64
+    x = rng.integers(-9000, 9000, size=(n, 64, 2)).astype(np.int16)
+    fin = tmp_path / "in.bin"; fout = tmp_path / "out.bin"
+    fin.write_bytes(x.tobytes())
+    out = run([exe, str(nb), str(fin), str(fout)])
+    assert "%d symbols" % n in out
+    got = np.frombuffer(fout.read_bytes(), np.uint8).reshape(n, 48 * nb)
+    for i in range(n):
+        want = oracle.deinterleave(nb, oracle.demap(nb, oracle.fft(x[i], 64)))
+        assert np.array_equal(got[i], want), i

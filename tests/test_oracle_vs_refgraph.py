@@ -54,6 +54,25 @@ def test_oracle_equals_reference_graph_on_random_captures(o, graph, seed):
     assert nframes > 150
 
 
+def test_the_two_thread_harness_reports_the_same_events(o, graph):
+    """oracle/_ref/libsora_refgraph.so replaces the hop to the decoder thread (TThreadSeparator, stdbrick.hpp:89-248) by the
+    reference's same-thread pass-through TNoInline -- the one non-syntactic patch of the compiled oracle.  This test runs
+    the graph WITH the real separator, a second (joined) thread executing ViterbiThread (fb11a_demod.cpp:83-86) and the
+    RxThread loop on the caller's thread (libsora_refgraph_mt.so), and shows the same events: error code, source position,
+    rate, length, FCS, MPDU bytes.  (T11aDataSymbol flushes the decoder branch after the last symbol, PHY_11a.hpp:407-420,
+    so the event is raised before the source call returns whatever the thread timing.)"""
+    if graph.rx11a_two_threads(np.zeros((280, 2), np.int16)) is None:
+        pytest.skip("oracle/_ref/libsora_refgraph_mt.so not built (needs the reference tree)")
+    rng = np.random.default_rng(20260929)
+    nev = 0; kinds = set()
+    for i in range(1000):
+        cap = random_capture(o, rng, 40)
+        one = graph.rx11a(cap); two = graph.rx11a_two_threads(cap)
+        assert one == two, "capture %d: %r vs %r" % (i, [(hex(e["error_code"]), e["sample_index"]) for e in one], [(hex(e["error_code"]), e["sample_index"]) for e in two])
+        nev += len(one); kinds |= {e["error_code"] for e in one}
+    assert nev > 1000 and {0x1, 0x80000005, 0x80000006} <= kinds
+
+
 def test_negative_cfo_estimate_is_floored(o, graph):
     """FreqOffsetEstimate divides by a size_t: a negative angle is floored, not truncated (dspalg.hpp:242).  The
     recorded fixture has a non-negative offset, so only the reference graph itself shows this."""

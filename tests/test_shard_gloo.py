@@ -24,9 +24,9 @@ def test_partition_is_a_cover():
 def test_row_codec_roundtrip():
     from sora_amd.shard import results_from_rows, rows_from_results
     rs = [{"capture_id": 5, "start_sample": 176, "end_sample": 4880, "error_code": 1, "rate_kbps": 54000, "length": 1500,
-           "nsym": 56, "crc32": 0xDEADBEEF, "cfo_est": -37, "reserved": 0, "mpdu_offset": 1234},
+           "nsym": 56, "crc32": 0xDEADBEEF, "cfo_est": -37, "flags": 0, "mpdu_offset": 1234},
           {"capture_id": 6, "start_sample": 0, "end_sample": 9, "error_code": 0x80000005, "rate_kbps": 0, "length": 0,
-           "nsym": 0, "crc32": 0, "cfo_est": 12, "reserved": 0, "mpdu_offset": 0}]
+           "nsym": 0, "crc32": 0, "cfo_est": 12, "flags": 0, "mpdu_offset": 0}]
     assert results_from_rows(rows_from_results(rs)) == rs
 
 
