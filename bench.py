@@ -204,6 +204,60 @@ def valu_roofline(nframes, ms_step):
             "frac": round(ach / peak, 4), "dominant_kernel_insts": measured_valu("k_viterbi")}
 
 
+def bench_stages(torch, sora_amd, dev, nsym=1 << 20, reps=10):
+    """The per-stage entry points (what the BRICK adapters call), each over `nsym` OFDM symbols resident in HBM, against the
+    HBM roofline with SURVEY.md section 8(d)'s algorithmic bytes per symbol: FFT 256 in + 256 out; symbol front end
+    (T11aDataSymbol..TChannelEqualization) 320 in + 256 out; demap (64-QAM) 256 in + 288 out; de-interleave 288 + 288;
+    Viterbi (54 Mbps frames of 56 symbols) 288 soft bytes in + 27 decoded bytes out; FFT<128> 512 + 512."""
+    from sora_amd import capi
+    L = capi.load()
+    out = {}
+    g = torch.Generator(device=dev); g.manual_seed(7)
+
+    def timed(fn, nbytes, label, n=nsym):
+        for _ in range(2):
+            fn()
+        e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
+        torch.cuda.synchronize(); e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record(); torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / reps
+        out[label] = {"symbols": n, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
+                      "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "gsymbols_per_s": round(n / ms / 1e6, 3)}
+
+    st = capi._stream_ptr(None)
+    x = torch.randint(-6000, 6000, (nsym, 64, 2), dtype=torch.int16, device=dev, generator=g)
+    y = torch.empty_like(x)
+    timed(lambda: L.sora_hip_fft64(capi._dev_ptr(x), capi._dev_ptr(y), nsym, st), nsym * 512, "fft64")
+    soft = torch.empty((nsym, 288), dtype=torch.uint8, device=dev)
+    timed(lambda: L.sora_hip_demap11a(capi._dev_ptr(x), capi._dev_ptr(soft), 6, nsym, st), nsym * (256 + 288), "demap11a_qam64")
+    de = torch.empty_like(soft)
+    timed(lambda: L.sora_hip_deinterleave11a(capi._dev_ptr(soft), capi._dev_ptr(de), 6, nsym, st), nsym * 576, "deinterleave11a_qam64")
+    del y
+    x80 = torch.randint(-6000, 6000, (nsym, 80, 2), dtype=torch.int16, device=dev, generator=g)
+    nctx = 4096
+    lts_in = torch.randint(-6000, 6000, (nctx, 144, 2), dtype=torch.int16, device=dev, generator=g)
+    ctx = sora_amd.lts11a(lts_in)
+    idx = (torch.arange(nsym, device=dev, dtype=torch.int32) // 256) % nctx
+    eq = torch.empty((nsym, 64, 2), dtype=torch.int16, device=dev)
+    timed(lambda: L.sora_hip_symfront11a(capi._dev_ptr(x80), capi._dev_ptr(ctx), capi._dev_ptr(idx), capi._dev_ptr(eq), nsym, st), nsym * 576, "symfront11a")
+    del x80, eq, idx
+    n128 = nsym // 2
+    x128 = x.view(n128, 128, 2); y128 = torch.empty_like(x128)
+    timed(lambda: L.sora_hip_fft128(capi._dev_ptr(x128), capi._dev_ptr(y128), n128, st), n128 * 1024, "fft128", n128)
+    del y128, x128, x
+    # Viterbi: frames of 56 symbols x 216 soft values (the bench frame), random soft values 0..7
+    nfr = 8192; nso = 56 * 288
+    sv = torch.randint(0, 8, (nfr * nso,), dtype=torch.uint8, device=dev, generator=g)
+    so = (torch.arange(nfr, device=dev, dtype=torch.int32) * nso).contiguous(); ns = torch.full((nfr,), nso, dtype=torch.int32, device=dev)
+    fl = torch.full((nfr,), MPDU_LEN, dtype=torch.int16, device=dev)
+    vo = torch.zeros((nfr, 1536), dtype=torch.uint8, device=dev); oo = (torch.arange(nfr, device=dev, dtype=torch.int32) * 1536).contiguous()
+    timed(lambda: L.sora_hip_viterbi11a(capi._dev_ptr(sv), capi._dev_ptr(so), capi._dev_ptr(ns), capi._dev_ptr(fl), 2, capi._dev_ptr(vo), capi._dev_ptr(oo), nfr, st),
+          nfr * 56 * (288 + 27), "viterbi11a_r34", nfr * 56)
+    return out
+
+
 def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
     """Row f3 (capture ingest): a 44 MHz RX_BLOCK dump resident in HBM -> de-framed, sign-fixed, resampled 40 MHz stream.
     A pure streaming kernel: algorithmic bytes = dump bytes read + samples written, against the HBM roofline."""
@@ -572,6 +626,7 @@ def main():
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
         if world == 1 and not args.no_extras:
+            out["stages"] = bench_stages(torch, sora_amd, dev)
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
             out["tx"] = bench_tx(torch, sora_amd)
             out["rx11b"] = bench_11b(torch, sora_amd, dev)

