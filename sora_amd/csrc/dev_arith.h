@@ -87,6 +87,18 @@ __device__ __forceinline__ cpx rot_coeff(const Tables& T, int th)        // (uco
     return mk((int)T.ucos[i], w16(-(int)T.usin[i]));
 }
 
+// data carrier k (0..47) -> FFT bin, in demap order -26..-1, +1..+26 without the pilots (demapper11a.hpp:20-37)
+__device__ __forceinline__ int carrier_bin48(int k)
+{
+    if (k < 24) { int b = 38 + k; if (b >= 43) b++; if (b >= 57) b++; return b; }
+    int b = 1 + (k - 24); if (b >= 7) b++; if (b >= 21) b++; return b;
+}
+// wave-level barrier for LDS that only one wave touches
+__device__ __forceinline__ void wave_lds_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 // ---------------------------------------------------------------------------------------------
 // 64-point radix-4 DIF FFT (core/inc/fft_r4dif.h) for a group of 16 lanes, 4 points per lane, staged
 // through a 64-entry LDS slice `s` private to the group.  `e` = lane index within the group (0..15).
@@ -99,7 +111,7 @@ __device__ __forceinline__ Fft64Tw fft64_twiddles(const Tables& T, int e)
     return Fft64Tw{ T.tw64[e], T.tw64[16 + e], T.tw64[32 + e], T.tw16[i], T.tw16[4 + i], T.tw16[8 + i] };
 }
 template <typename SYNC>
-__device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int e, const Fft64Tw& W, SYNC sync)
+__device__ __forceinline__ void fft64_core(cpx x[4], uint32_t* s, int e, const Fft64Tw& W, SYNC sync)   // result left in s[]: bin j at slot bitrev6(j)
 {
     sync();                                                                           // previous users of s[] are done
     // stage N=64: butterfly e on points e, e+16, e+32, e+48   (FFTSSE<64>, fft_r4dif.h:11-47)
@@ -137,6 +149,11 @@ __device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int
         s[4 * e + 3] = pack(cadds(cnot(B1r), B0));
     }
     sync();
+}
+template <typename SYNC>
+__device__ __forceinline__ void fft64_group(cpx x[4], cpx y[4], uint32_t* s, int e, const Fft64Tw& W, SYNC sync)
+{
+    fft64_core(x, s, e, W, sync);
     // bit-reversed reorder (FFT64LUTMap, fft_lut_bitreversal.h:76-142): bin j <- slot bitrev6(j)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
@@ -175,13 +192,19 @@ __device__ __forceinline__ void r4_bfly128(cpx a, cpx b, cpx c, cpx d, cpx w1, c
     else      { y1 = conj_mul_shift15(csubs(ac, bd), w2); y2 = conj_mul_shift15(cadds(a_c, jb), w1); y3 = conj_mul_shift15(csubs(a_c, jb), w3); }
 }
 
+struct Fft128Tw { uint32_t w128[3], w32[3], w8[4]; };               // the twiddles lane e of a 32-lane group needs (loop-invariant)
+__device__ __forceinline__ Fft128Tw fft128_twiddles(const Tables& T, int e)
+{
+    const int j = e & 7;
+    return Fft128Tw{ { T.tw128[e], T.tw128[32 + e], T.tw128[64 + e] }, { T.tw32[j], T.tw32[8 + j], T.tw32[16 + j] }, { T.tw8[0], T.tw8[1], T.tw8[2], T.tw8[3] } };
+}
 template <bool INV, typename SYNC>
-__device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t* s, int e, const Tables& T, SYNC sync)
+__device__ __forceinline__ void fft128_core(const cpx x[4], uint32_t* s, int e, const Fft128Tw& T, SYNC sync)   // result left in s[]: point j at slot bitrev7(j)
 {
     sync();
     {   // stage N=128: butterfly e on points e, e+32, e+64, e+96
         cpx y0, y1, y2, y3;
-        r4_bfly128<INV>(x[0], x[1], x[2], x[3], unpack(T.tw128[e]), unpack(T.tw128[32 + e]), unpack(T.tw128[64 + e]), y0, y1, y2, y3);
+        r4_bfly128<INV>(x[0], x[1], x[2], x[3], unpack(T.w128[0]), unpack(T.w128[1]), unpack(T.w128[2]), y0, y1, y2, y3);
         s[e] = pack(y0); s[e + 32] = pack(y1); s[e + 64] = pack(y2); s[e + 96] = pack(y3);
     }
     sync();
@@ -189,7 +212,7 @@ __device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t*
         const int k = e >> 3, j = e & 7, base = 32 * k + j;
         cpx y0, y1, y2, y3;
         r4_bfly128<INV>(unpack(s[base]), unpack(s[base + 8]), unpack(s[base + 16]), unpack(s[base + 24]),
-                        unpack(T.tw32[j]), unpack(T.tw32[8 + j]), unpack(T.tw32[16 + j]), y0, y1, y2, y3);
+                        unpack(T.w32[0]), unpack(T.w32[1]), unpack(T.w32[2]), y0, y1, y2, y3);
         s[base] = pack(y0); s[base + 8] = pack(y1); s[base + 16] = pack(y2); s[base + 24] = pack(y3);
     }
     sync();
@@ -205,7 +228,7 @@ __device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t*
         ee[3] = INV ? mk(~d[3].im, d[3].re) : mk(d[3].im, ~d[3].re);
         gg[0] = cadds(ee[0], ee[2]); gg[1] = cadds(ee[1], ee[3]); gg[2] = cadds(cnot(ee[2]), ee[0]); gg[3] = cadds(cnot(ee[3]), ee[1]);
 #pragma unroll
-        for (int q = 0; q < 4; q++) ff[q] = INV ? conj_mul_shift15(gg[q], unpack(T.tw8[q])) : mul_shift15(gg[q], unpack(T.tw8[q]));
+        for (int q = 0; q < 4; q++) ff[q] = INV ? conj_mul_shift15(gg[q], unpack(T.w8[q])) : mul_shift15(gg[q], unpack(T.w8[q]));
         p[4] = pack(cadds(ff[0], ff[1])); p[5] = pack(cadds(cnot(ff[1]), ff[0]));
         p[6] = pack(cadds(ff[2], ff[3])); p[7] = pack(cadds(cnot(ff[3]), ff[2]));
         cpx A0 = cadds(sm[0], sm[2]), A1 = cadds(sm[1], sm[3]);
@@ -214,6 +237,11 @@ __device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t*
         p[0] = pack(cadds(A0, A1)); p[1] = pack(cadds(cnot(A1), A0)); p[2] = pack(cadds(B0, B1r)); p[3] = pack(cadds(cnot(B1r), B0));
     }
     sync();
+}
+template <bool INV, typename SYNC>
+__device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t* s, int e, const Tables& T, SYNC sync)
+{
+    fft128_core<INV>(x, s, e, fft128_twiddles(T, e), sync);
 #pragma unroll
     for (int q = 0; q < 4; q++) y[q] = unpack(s[__brev((unsigned)(e + 32 * q)) >> 25]);   // FFT128LUTMap = 7-bit bit reversal
 }

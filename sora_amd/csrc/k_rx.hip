@@ -17,12 +17,6 @@ __device__ __constant__ uint8_t kPilotSgn[128] = {        // pilot.hpp:10-28: 1 
     1,0,1,0,1,0,0,1, 1,1,0,0,1,1,1,1, 0,1,1,0,1,0,0,0, 0,1,0,1,0,1,0,1,
     1,1,1,1,0,1,0,0, 1,0,1,0,0,0,1,1, 0,1,1,1,0,0,0,1, 1,1,1,1,1,1,0,0 };
 
-__device__ __forceinline__ int carrier_bin48(int k)       // demap order -26..-1,+1..+26 without pilots (demapper11a.hpp:20-37)
-{
-    if (k < 24) { int b = 38 + k; if (b >= 43) b++; if (b >= 57) b++; return b; }
-    int b = 1 + (k - 24); if (b >= 7) b++; if (b >= 21) b++; return b;
-}
-
 // ------------------------------------------------------------------------------------------------
 // k_frame: everything between the frame table and the soft stream, one wave per frame:
 //   TFreqCompensation -> TFFT64 -> TChannelEqualization -> TPhaseCompensate -> TPilotTrack -> T11aDemap -> T11aDeinterleave
@@ -625,44 +619,7 @@ __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uin
 
 // ================================================================================================
 // stand-alone stage kernels (per-stage C entry points)
-__global__ void __launch_bounds__(256) k_fft64_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T)
-{
-    __shared__ uint32_t s_all[16][64];
-    const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
-    const uint32_t i = blockIdx.x * 16 + g;
-    cpx x[4], Y[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = i < n ? unpack(in[(size_t)i * 64 + e + 16 * m]) : mk(0, 0);
-    fft64_group(x, Y, s_all[g], e, T, []() { __syncthreads(); });
-    if (i < n) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) out[(size_t)i * 64 + e + 16 * q] = pack(Y[q]);
-    }
-}
-
-__global__ void __launch_bounds__(64) k_demap_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n, Tables T)
-{
-    const uint32_t i = blockIdx.x; const int lane = threadIdx.x;
-    if (i >= n || lane >= 48) return;
-    const int bin = carrier_bin48(lane);
-    cpx v = unpack(in[(size_t)i * 64 + bin]);
-    int re = v.re >> 4, im = v.im >> 4;
-    re = min(max(re, -128), 127); im = min(max(im, -128), 127);
-    const unsigned ur = (unsigned)re & 0xFF, ui = (unsigned)im & 0xFF;
-    uint8_t* o = soft + (size_t)i * 48 * nb + lane * nb;
-    if (nb == 1) { o[0] = T.demap[ur]; }
-    else if (nb == 2) { o[0] = T.demap[ur]; o[1] = T.demap[ui]; }
-    else if (nb == 4) { o[0] = T.demap[ur]; o[1] = T.demap[256 + ur]; o[2] = T.demap[ui]; o[3] = T.demap[256 + ui]; }
-    else { o[0] = T.demap[ur]; o[1] = T.demap[512 + ur]; o[2] = T.demap[768 + ur]; o[3] = T.demap[ui]; o[4] = T.demap[512 + ui]; o[5] = T.demap[768 + ui]; }
-}
-
-__global__ void __launch_bounds__(64) k_deint_batch(const uint8_t* in, uint8_t* out, int nb, uint32_t n, Tables T)
-{
-    const uint32_t i = blockIdx.x;
-    if (i >= n) return;
-    const int ncbps = 48 * nb, di = nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3;
-    for (int k = threadIdx.x; k < ncbps; k += 64) out[(size_t)i * ncbps + k] = in[(size_t)i * ncbps + T.deint[di * 288 + k]];
-}
+// (k_fft64_batch, k_demap_batch, k_deint_batch: k_stage.hip)
 
 // sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits);
 // the trellis kernel reads 16-bit fields v << 9.

@@ -4,6 +4,15 @@
 //   k_symfront_batch  T11aDataSymbol + TFreqCompensation + TFFT64 + TChannelEqualization
 //   k_ptrack_batch    TPhaseCompensate + TPilotTrack, symbol by symbol (freqoffset.hpp:14-66, pilot.hpp:121-269)
 //   k_fft128_batch    FFT<128>   (core/inc/fft_r4dif.h: 128 = 4 x 32, 32 = 4 x 8, 8-point terminal stage)
+//   k_fft64_batch     TFFT64, k_demap_batch T11aDemap<N>, k_deint_batch T11aDeinterleave*
+//
+// The per-symbol bricks (FFT, symbol front end, demap, de-interleave, ingest) are STREAMING kernels: a few hundred bytes in,
+// a few hundred out, a few hundred integer operations per symbol -- bound by HBM.  They share one shape: a block owns tiles
+// of consecutive symbols; every global access is a 16-byte-per-lane coalesced load or store of a contiguous tile (the
+// symbol-internal reshuffling -- 4 points per lane for the butterflies, carrier order, the interleaver permutation --
+// happens in LDS); and a thread issues the loads of ALL its tiles before it touches the first, so that every CU keeps
+// >= 64 KB of reads in flight (6.3 TB/s x ~2 us of latency = ~50 KB per CU is what the chip needs to stay busy).
+// Pointers given to these entry points must be 16-byte aligned (any hipMalloc'd buffer is).
 #include "kernels.h"
 
 namespace sora {
@@ -69,30 +78,161 @@ __global__ void __launch_bounds__(64) k_lts_batch(const uint32_t* in, uint32_t* 
     o[65 + lane] = coef;
 }
 
-__global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T)
+constexpr int kFftTiles = 4;                                                 // tiles of 16 symbols per 256-thread block
+
+// T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization.  16 lanes per symbol, 16 symbols per tile; the 64
+// samples behind the cyclic prefix arrive as one 16-byte load per lane (samples 4e..4e+3), go through the group's LDS
+// slice to the 4-points-per-lane layout of the butterflies, and the equalised bins 4e..4e+3 leave as one 16-byte store.
+__global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* __restrict__ in, const uint32_t* __restrict__ ctx, const uint32_t* __restrict__ ctx_index, uint32_t* __restrict__ eq, uint32_t n, Tables T)
 {
     __shared__ uint32_t s_all[16][64];
     const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
-    const uint32_t i = blockIdx.x * 16 + g;
-    const bool active = i < n;
-    const uint32_t* c = ctx + (size_t)(active && ctx_index ? ctx_index[i] : 0u) * 129;
-    cpx x[4], Y[4];
+    const Fft64Tw W = fft64_twiddles(T, e);
+    uint32_t* s = s_all[g];
+    uint4 v[kFftTiles];
 #pragma unroll
-    for (int m = 0; m < 4; m++) {
-        const int k = e + 16 * m;
-        x[m] = active ? mul_q15(sra(unpack(in[(size_t)i * 80 + 8 + k]), 1), unpack(c[1 + k])) : mk(0, 0);
+    for (int t = 0; t < kFftTiles; t++) {
+        const uint32_t i = (blockIdx.x * kFftTiles + t) * 16 + g;
+        v[t] = i < n ? reinterpret_cast<const uint4*>(in)[(size_t)i * 20 + 2 + e] : uint4{0, 0, 0, 0};   // sample i*80 + 8 + 4e (skip_cp = 8)
     }
-    fft64_group(x, Y, s_all[g], e, T, []() { __syncthreads(); });
-    if (active) {
+#pragma unroll
+    for (int t = 0; t < kFftTiles; t++) {
+        const uint32_t i = (blockIdx.x * kFftTiles + t) * 16 + g;
+        const bool active = i < n;
+        const uint32_t* c = ctx + (size_t)(active && ctx_index ? ctx_index[i] : 0u) * 129;
+        wave_lds_sync();
+        reinterpret_cast<uint4*>(s)[e] = v[t];
+        wave_lds_sync();
+        cpx x[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { const int k = e + 16 * m; x[m] = mul_q15(sra(unpack(s[k]), 1), unpack(c[1 + k])); }   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+        fft64_core(x, s, e, W, wave_lds_sync);
+        uint32_t o[4];
+        const unsigned r = __brev((unsigned)e) >> 28;                                // bin 4e+q sits at slot bitrev6(4e+q) = bitrev4(e) + 16 bitrev2(q)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-            const int bin = e + 16 * q;
-            cpx o = mk(0, 0);
-            if (!(bin >= 28 && bin < 36)) { int re, im; mul32(Y[q], unpack(c[65 + bin]), re, im); o = mk(w16(re >> 8), w16(im >> 8)); }
-            eq[(size_t)i * 64 + bin] = pack(o);
+            const int bin = 4 * e + q;
+            const cpx Y = unpack(s[r + 16u * ((q & 1) * 2 + (q >> 1))]);
+            cpx w = mk(0, 0);
+            if (!(bin >= 28 && bin < 36)) { int re, im; mul32(Y, unpack(c[65 + bin]), re, im); w = mk(w16(re >> 8), w16(im >> 8)); }   // channel_11a.hpp:548-574
+            o[q] = pack(w);
         }
+        if (active) reinterpret_cast<uint4*>(eq)[(size_t)i * 16 + e] = uint4{o[0], o[1], o[2], o[3]};
     }
 }
+
+// TFFT64: the same shape without the context.
+__global__ void __launch_bounds__(256) k_fft64_batch(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, Tables T)
+{
+    __shared__ uint32_t s_all[16][64];
+    const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
+    const Fft64Tw W = fft64_twiddles(T, e);
+    uint32_t* s = s_all[g];
+    uint4 v[kFftTiles];
+#pragma unroll
+    for (int t = 0; t < kFftTiles; t++) {
+        const uint32_t i = (blockIdx.x * kFftTiles + t) * 16 + g;
+        v[t] = i < n ? reinterpret_cast<const uint4*>(in)[(size_t)i * 16 + e] : uint4{0, 0, 0, 0};
+    }
+#pragma unroll
+    for (int t = 0; t < kFftTiles; t++) {
+        const uint32_t i = (blockIdx.x * kFftTiles + t) * 16 + g;
+        wave_lds_sync();
+        reinterpret_cast<uint4*>(s)[e] = v[t];
+        wave_lds_sync();
+        cpx x[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = unpack(s[e + 16 * m]);
+        fft64_core(x, s, e, W, wave_lds_sync);
+        const unsigned r = __brev((unsigned)e) >> 28;
+        if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 16 + e] = uint4{s[r], s[r + 32], s[r + 16], s[r + 48]};
+    }
+}
+
+// T11aDemap<NB>::Filter (demapper11a.hpp:10-79 over DemapperCore, demapper.h:16-45): a tile of 32 symbols is loaded into
+// LDS as it lies in memory, every thread demaps (symbol, carrier) items out of LDS through the step tables (LDS too) and
+// writes the NB soft values of the carrier into the tile's output image, which leaves with 16-byte stores.
+constexpr int kDmSyms = 32;
+template <int NB>
+__global__ void __launch_bounds__(256) k_demap_batch(const uint32_t* __restrict__ in, uint8_t* __restrict__ soft, uint32_t n, Tables T)
+{
+    constexpr int NCB = 48 * NB;
+    __shared__ uint32_t s_in[kDmSyms * 64];
+    __shared__ uint32_t s_out[kDmSyms * NCB / 4];
+    __shared__ uint8_t  s_lut[1024];
+    const int tid = threadIdx.x;
+    const uint32_t s0 = blockIdx.x * kDmSyms;
+    const int ns = (int)min((uint32_t)kDmSyms, n - s0);
+    const uint4* in4 = reinterpret_cast<const uint4*>(in) + (size_t)s0 * 16;
+    const uint4 a = tid < ns * 16 ? in4[tid] : uint4{0, 0, 0, 0};
+    const uint4 b = tid + 256 < ns * 16 ? in4[tid + 256] : uint4{0, 0, 0, 0};
+    reinterpret_cast<uint32_t*>(s_lut)[tid] = reinterpret_cast<const uint32_t*>(T.demap)[tid];
+    reinterpret_cast<uint4*>(s_in)[tid] = a; reinterpret_cast<uint4*>(s_in)[tid + 256] = b;
+    __syncthreads();
+    uint16_t* o16 = reinterpret_cast<uint16_t*>(s_out);
+    uint8_t* o8 = reinterpret_cast<uint8_t*>(s_out);
+    for (int it = tid; it < ns * 48; it += 256) {
+        const int sym = it / 48, k = it - sym * 48;
+        const cpx v = unpack(s_in[sym * 64 + carrier_bin48(k)]);
+        int re = v.re >> 4, im = v.im >> 4;                                       // demap_limit<64> (demapper.h:141-151)
+        re = min(max(re, -128), 127); im = min(max(im, -128), 127);
+        const unsigned ur = (unsigned)re & 0xFF, ui = (unsigned)im & 0xFF;
+        const int at = sym * NCB + k * NB;                                        // byte position of the carrier's first soft value
+        if (NB == 1) o8[at] = s_lut[ur];
+        else if (NB == 2) o16[at >> 1] = (uint16_t)(s_lut[ur] | (s_lut[ui] << 8));
+        else if (NB == 4) s_out[at >> 2] = (uint32_t)s_lut[ur] | ((uint32_t)s_lut[256 + ur] << 8) | ((uint32_t)s_lut[ui] << 16) | ((uint32_t)s_lut[256 + ui] << 24);
+        else {
+            o16[(at >> 1)]     = (uint16_t)(s_lut[ur] | (s_lut[512 + ur] << 8));
+            o16[(at >> 1) + 1] = (uint16_t)(s_lut[768 + ur] | (s_lut[ui] << 8));
+            o16[(at >> 1) + 2] = (uint16_t)(s_lut[512 + ui] | (s_lut[768 + ui] << 8));
+        }
+    }
+    __syncthreads();
+    uint4* o4 = reinterpret_cast<uint4*>(soft + (size_t)s0 * NCB);                 // 48 NB bytes per symbol: every tile starts 16-byte aligned
+    for (int k = tid; k < ns * NCB / 16; k += 256) o4[k] = reinterpret_cast<const uint4*>(s_out)[k];
+}
+
+// T11aDeinterleave{BPSK,QPSK,QAM16,QAM64} (deinterleaver.hpp): out[k] = in[j(k)] within a symbol.  A tile of 32 symbols is
+// loaded into LDS with 16-byte loads; a thread gathers the 16 bytes of one output quad-word through the map and stores it.
+template <int NB>
+__global__ void __launch_bounds__(256) k_deint_batch(const uint8_t* __restrict__ in, uint8_t* __restrict__ out, uint32_t n, Tables T)
+{
+    constexpr int NCB = 48 * NB, QW = NCB / 16, TILE_QW = kDmSyms * QW, PER = (TILE_QW + 255) / 256;
+    __shared__ uint32_t s_in[kDmSyms * NCB / 4];
+    __shared__ uint16_t s_map[NCB];
+    const int tid = threadIdx.x;
+    const uint32_t s0 = blockIdx.x * kDmSyms;
+    const int ns = (int)min((uint32_t)kDmSyms, n - s0), nqw = ns * QW;
+    const uint4* in4 = reinterpret_cast<const uint4*>(in + (size_t)s0 * NCB);
+    uint4 v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) v[j] = tid + 256 * j < nqw ? in4[tid + 256 * j] : uint4{0, 0, 0, 0};
+    constexpr int di = NB == 1 ? 0 : NB == 2 ? 1 : NB == 4 ? 2 : 3;
+    for (int i = tid; i < NCB; i += 256) s_map[i] = T.deint[di * 288 + i];
+#pragma unroll
+    for (int j = 0; j < PER; j++) if (tid + 256 * j < TILE_QW) reinterpret_cast<uint4*>(s_in)[tid + 256 * j] = v[j];
+    __syncthreads();
+    const uint8_t* b = reinterpret_cast<const uint8_t*>(s_in);
+    uint4* o4 = reinterpret_cast<uint4*>(out + (size_t)s0 * NCB);
+    for (int q = tid; q < nqw; q += 256) {
+        const int sym = q / QW, w = q - sym * QW;
+        const uint8_t* src = b + sym * NCB;
+        const uint16_t* m = s_map + 16 * w;
+        uint32_t r[4];
+#pragma unroll
+        for (int d = 0; d < 4; d++)
+            r[d] = (uint32_t)src[m[4 * d]] | ((uint32_t)src[m[4 * d + 1]] << 8) | ((uint32_t)src[m[4 * d + 2]] << 16) | ((uint32_t)src[m[4 * d + 3]] << 24);
+        o4[q] = uint4{r[0], r[1], r[2], r[3]};
+    }
+}
+template __global__ void k_demap_batch<1>(const uint32_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_demap_batch<2>(const uint32_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_demap_batch<4>(const uint32_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_demap_batch<6>(const uint32_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_deint_batch<1>(const uint8_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_deint_batch<2>(const uint8_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_deint_batch<4>(const uint8_t*, uint8_t*, uint32_t, Tables);
+template __global__ void k_deint_batch<6>(const uint8_t*, uint8_t*, uint32_t, Tables);
 
 // sora_track11a_state: { int16 cfo_comp, sfo_comp, cfo_tracker, sfo_tracker; uint32 symbol_count; COMPLEX16 comp[64]; } = 67 words
 __global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T)
@@ -135,20 +275,32 @@ __global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const u
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// FFT<128>: 32 lanes per transform, 4 points per lane, 8 transforms per 256-thread block (fft128_group, dev_arith.h).
-__global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T)
+// FFT<128>: 32 lanes per transform, 4 points per lane, 8 transforms per tile, 4 tiles per 256-thread block (fft128_core,
+// dev_arith.h); points 4e..4e+3 in and out as one 16-byte access per lane, twiddles in registers.
+__global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, Tables T)
 {
     __shared__ uint32_t s_all[8][128];
     const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
-    const uint32_t i = blockIdx.x * 8 + g;
-    const bool active = i < n;
-    cpx x[4], y[4];
+    const Fft128Tw W = fft128_twiddles(T, e);
+    uint32_t* s = s_all[g];
+    uint4 v[kFftTiles];
 #pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = active ? unpack(in[(size_t)i * 128 + e + 32 * m]) : mk(0, 0);
-    fft128_group<false>(x, y, s_all[g], e, T, []() { __syncthreads(); });
-    if (active) {
+    for (int t = 0; t < kFftTiles; t++) {
+        const uint32_t i = (blockIdx.x * kFftTiles + t) * 8 + g;
+        v[t] = i < n ? reinterpret_cast<const uint4*>(in)[(size_t)i * 32 + e] : uint4{0, 0, 0, 0};
+    }
 #pragma unroll
-        for (int q = 0; q < 4; q++) out[(size_t)i * 128 + e + 32 * q] = pack(y[q]);
+    for (int t = 0; t < kFftTiles; t++) {
+        const uint32_t i = (blockIdx.x * kFftTiles + t) * 8 + g;
+        wave_lds_sync();
+        reinterpret_cast<uint4*>(s)[e] = v[t];
+        wave_lds_sync();
+        cpx x[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = unpack(s[e + 32 * m]);
+        fft128_core<false>(x, s, e, W, wave_lds_sync);
+        const unsigned r = __brev((unsigned)e) >> 27;                               // point 4e+q sits at slot bitrev7(4e+q) = bitrev5(e) + 32 bitrev2(q)
+        if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 32 + e] = uint4{s[r], s[r + 64], s[r + 32], s[r + 96]};
     }
 }
 
@@ -192,13 +344,12 @@ __global__ void __launch_bounds__(256) k_ingest(const uint8_t* __restrict__ raw,
 // (lcm(28, 11) x 5); the 7040 raw bytes are staged in LDS, the index arithmetic is 32-bit and local.
 constexpr int kTileBlocks = 55, kTileRaw = kTileBlocks * 128, kTileOut = 1400;
 
-__global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__ raw, uint32_t* __restrict__ out, unsigned flags)
+__global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__ raw, uint32_t* __restrict__ out, unsigned flags, uint32_t tiles)
 {
     __shared__ uint32_t s_raw[kTileRaw / 4];
     __shared__ uint32_t s_out[kTileOut];
-    const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)blockIdx.x * kTileRaw);
-    for (int i = threadIdx.x; i < kTileRaw / 16; i += 256) reinterpret_cast<uint4*>(s_raw)[i] = src[i];
-    __syncthreads();
+    constexpr int NQ = kTileRaw / 16;                                              // 440 quad-words per tile: two per thread (the second for 184 threads)
+    const int tid = threadIdx.x;
     const bool dec = (flags & 8u) != 0, fix = (flags & 2u) != 0;
     const int nout = dec ? kTileOut / 2 : kTileOut;
     auto X = [&](int i) -> cpx {                                                 // input sample i of the tile
@@ -206,20 +357,37 @@ __global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__
         if (fix) { x.re = w16(x.re << 2); x.im = w16(x.im << 2); }
         return x;
     };
-    for (int m = threadIdx.x; m < nout; m += 256) {
-        const int m1 = dec ? 2 * m : m;
-        const int p = m1 / 10, k = m1 - 10 * p;
-        cpx s;
-        if (k == 0) s = X(11 * p);
-        else {
-            const cpx a = X(11 * p + k), b = X(11 * p + k + 1);
-            s = mk(w16((a.re * kLinR[k] + b.re * kLinL[k + 1]) >> 7), w16((a.im * kLinR[k] + b.im * kLinL[k + 1]) >> 7));
+    uint32_t tile = blockIdx.x;
+    if (tile >= tiles) return;
+    const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)tile * kTileRaw);
+    uint4 r0 = src[tid], r1 = tid + 256 < NQ ? src[tid + 256] : uint4{0, 0, 0, 0};
+    for (;;) {
+        reinterpret_cast<uint4*>(s_raw)[tid] = r0;
+        if (tid + 256 < NQ) reinterpret_cast<uint4*>(s_raw)[tid + 256] = r1;
+        const uint32_t next = tile + gridDim.x;                                    // the next tile's reads are in flight while this one is computed and stored
+        if (next < tiles) {
+            const uint4* nsrc = reinterpret_cast<const uint4*>(raw + (size_t)next * kTileRaw);
+            r0 = nsrc[tid]; if (tid + 256 < NQ) r1 = nsrc[tid + 256];
         }
-        s_out[m] = pack(s);
+        __syncthreads();
+        for (int m = tid; m < nout; m += 256) {
+            const int m1 = dec ? 2 * m : m;
+            const int p = m1 / 10, k = m1 - 10 * p;
+            cpx v;
+            if (k == 0) v = X(11 * p);
+            else {
+                const cpx a = X(11 * p + k), b = X(11 * p + k + 1);
+                v = mk(w16((a.re * kLinR[k] + b.re * kLinL[k + 1]) >> 7), w16((a.im * kLinR[k] + b.im * kLinL[k + 1]) >> 7));
+            }
+            s_out[m] = pack(v);
+        }
+        __syncthreads();
+        uint4* dst = reinterpret_cast<uint4*>(out + (size_t)tile * nout);          // nout * 4 bytes is a multiple of 16
+        for (int i = tid; i < nout / 4; i += 256) dst[i] = reinterpret_cast<const uint4*>(s_out)[i];
+        if (next >= tiles) break;
+        tile = next;
+        __syncthreads();                                                           // s_raw / s_out are rewritten by the next round
     }
-    __syncthreads();
-    uint4* dst = reinterpret_cast<uint4*>(out + (size_t)blockIdx.x * nout);     // nout * 4 bytes is a multiple of 16
-    for (int i = threadIdx.x; i < nout / 4; i += 256) dst[i] = reinterpret_cast<const uint4*>(s_out)[i];
 }
 
 }  // namespace sora

@@ -48,8 +48,8 @@ __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);
 __global__ void k_fft64_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
-__global__ void k_demap_batch(const uint32_t* in, uint8_t* soft, int nb, uint32_t n, Tables T);
-__global__ void k_deint_batch(const uint8_t* in, uint8_t* out, int nb, uint32_t n, Tables T);
+template <int NB> __global__ void k_demap_batch(const uint32_t* in, uint8_t* soft, uint32_t n, Tables T);
+template <int NB> __global__ void k_deint_batch(const uint8_t* in, uint8_t* out, uint32_t n, Tables T);
 __global__ void k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Tables T);
 __global__ void k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T);
 __global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
@@ -68,7 +68,7 @@ struct TxArgs {                // sora_hip_tx11a (k_tx.hip)
 __global__ void k_tx_preamble(int8_t* out8, Tables T);
 __global__ void k_tx11a(TxArgs A);
 __global__ void k_ingest(const uint8_t* raw, uint32_t* out, uint64_t m0, uint64_t n_out, unsigned flags);
-__global__ void k_ingest_tile(const uint8_t* raw, uint32_t* out, unsigned flags);
+__global__ void k_ingest_tile(const uint8_t* raw, uint32_t* out, unsigned flags, uint32_t tiles);
 __global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16);
 __global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
                                const uint32_t* out_off, int code_rate, uint32_t n);

@@ -776,7 +776,8 @@ int sora_hip_fft64(const sora_complex16* d_in, sora_complex16* d_out, size_t n, 
     if (!d_in || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_fft64: null pointer");
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_fft64_batch, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream,
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_fft64: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_fft64_batch, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_out), (uint32_t)n, D->T);
     HIPCHK(hipGetLastError());
     return SORA_OK;
@@ -788,7 +789,8 @@ int sora_hip_fft128(const sora_complex16* d_in, sora_complex16* d_out, size_t n,
     if (!d_in || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_fft128: null pointer");
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_fft128_batch, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, (hipStream_t)stream,
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_fft128: buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_fft128_batch, dim3((unsigned)((n + 31) / 32)), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_out), (uint32_t)n, D->T);
     HIPCHK(hipGetLastError());
     return SORA_OK;
@@ -812,7 +814,8 @@ int sora_hip_symfront11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ct
     if (!d_in || !d_ctx || !d_eq) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_symfront11a: null pointer");
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_symfront_batch, dim3((unsigned)((n + 15) / 16)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in),
+    if (((uintptr_t)d_in | (uintptr_t)d_eq) & 15) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_symfront11a: sample and output buffers must be 16-byte aligned");
+    hipLaunchKernelGGL(k_symfront_batch, dim3((unsigned)((n + 63) / 64)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in),
                        reinterpret_cast<const uint32_t*>(d_ctx), d_ctx_index, reinterpret_cast<uint32_t*>(d_eq), (uint32_t)n, D->T);
     HIPCHK(hipGetLastError());
     return SORA_OK;
@@ -837,7 +840,14 @@ int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, s
     if (!d_in || !d_soft || !(n_bpsc == 1 || n_bpsc == 2 || n_bpsc == 4 || n_bpsc == 6)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_demap11a: bad argument");
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_demap_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in), d_soft, n_bpsc, (uint32_t)n, D->T);
+    if (((uintptr_t)d_in | (uintptr_t)d_soft) & 15) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_demap11a: buffers must be 16-byte aligned");
+    const dim3 grid((unsigned)((n + 31) / 32)); const uint32_t* in32 = reinterpret_cast<const uint32_t*>(d_in); hipStream_t st = (hipStream_t)stream;
+    switch (n_bpsc) {
+    case 1: hipLaunchKernelGGL(k_demap_batch<1>, grid, dim3(256), 0, st, in32, d_soft, (uint32_t)n, D->T); break;
+    case 2: hipLaunchKernelGGL(k_demap_batch<2>, grid, dim3(256), 0, st, in32, d_soft, (uint32_t)n, D->T); break;
+    case 4: hipLaunchKernelGGL(k_demap_batch<4>, grid, dim3(256), 0, st, in32, d_soft, (uint32_t)n, D->T); break;
+    default: hipLaunchKernelGGL(k_demap_batch<6>, grid, dim3(256), 0, st, in32, d_soft, (uint32_t)n, D->T); break;
+    }
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
@@ -848,7 +858,14 @@ int sora_hip_deinterleave11a(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, si
     if (!d_in || !d_out || !(n_bpsc == 1 || n_bpsc == 2 || n_bpsc == 4 || n_bpsc == 6)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_deinterleave11a: bad argument");
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_deint_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, d_in, d_out, n_bpsc, (uint32_t)n, D->T);
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_deinterleave11a: buffers must be 16-byte aligned");
+    const dim3 grid((unsigned)((n + 31) / 32)); hipStream_t st = (hipStream_t)stream;
+    switch (n_bpsc) {
+    case 1: hipLaunchKernelGGL(k_deint_batch<1>, grid, dim3(256), 0, st, d_in, d_out, (uint32_t)n, D->T); break;
+    case 2: hipLaunchKernelGGL(k_deint_batch<2>, grid, dim3(256), 0, st, d_in, d_out, (uint32_t)n, D->T); break;
+    case 4: hipLaunchKernelGGL(k_deint_batch<4>, grid, dim3(256), 0, st, d_in, d_out, (uint32_t)n, D->T); break;
+    default: hipLaunchKernelGGL(k_deint_batch<6>, grid, dim3(256), 0, st, d_in, d_out, (uint32_t)n, D->T); break;
+    }
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
@@ -935,7 +952,7 @@ int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_co
         const uint64_t per_tile = (flags & SORA_INGEST_DECIMATE2) ? 700 : 1400;
         const uint64_t tiles = std::min<uint64_t>(raw_bytes / (55 * 128), n / per_tile);
         if (tiles) {
-            hipLaunchKernelGGL(k_ingest_tile, dim3((unsigned)tiles), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw, reinterpret_cast<uint32_t*>(d_out), flags);
+            hipLaunchKernelGGL(k_ingest_tile, dim3((unsigned)std::min<uint64_t>(tiles, 8 * 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw, reinterpret_cast<uint32_t*>(d_out), flags, (uint32_t)tiles);
             done = tiles * per_tile;
         }
     }
