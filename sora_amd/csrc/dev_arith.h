@@ -247,6 +247,123 @@ __device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
+// The same arithmetic on PACKED COMPLEX16 (re in the low, im in the high half of one VGPR), for the streaming kernels.
+// On gfx950 the simple VOP2 integer ops issue at full rate and everything VOP3-encoded (v_med3, v_bfe, v_mad ...) at half
+// rate (profiles/r01_issue_probe_table.txt); one v_pk_add_i16 ... clamp replaces the two adds and two v_med3 of a
+// saturating complex add, v_pk_ashrrev_i16 the two shifts, and a twiddle product is two v_dot2c_i32_i16 (a 16x16+16x16
+// multiply-add that wraps like pmaddwd) and a bit-field insert.  Same results, bit for bit (tests/test_gpu_stages.py).
+typedef short s16x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t pcx;                                          // packed COMPLEX16
+__device__ __forceinline__ pcx pk_sra(pcx a, int n) { return __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, a) >> (short)n)); }
+__device__ __forceinline__ pcx pk_adds(pcx a, pcx b) { return __builtin_bit_cast(pcx, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b))); }
+__device__ __forceinline__ pcx pk_subs(pcx a, pcx b) { return __builtin_bit_cast(pcx, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b))); }
+__device__ __forceinline__ pcx pk_swap(pcx a) { return (a >> 16) | (a << 16); }
+__device__ __forceinline__ pcx pk_mul_j(pcx a) { return pk_swap(a) ^ 0x0000FFFFu; }           // (~im, re)   mul_j
+__device__ __forceinline__ pcx pk_neg_j(pcx a) { return pk_swap(a) ^ 0xFFFF0000u; }           // (im, ~re)   the 4-point terminal stage's -j
+__device__ __forceinline__ pcx pk_neg16_hi(pcx b) { return (b & 0xFFFFu) | ((0u - (b >> 16)) << 16); }   // (re, neg16(im))
+struct PkTw { pcx a, b; };                                     // second operands of the two dot products of a complex product
+__device__ __forceinline__ PkTw pk_tw_fft(pcx w) { return PkTw{ w ^ 0xFFFF0000u, pk_swap(w) }; }         // mul_shift15: (re, ~im), (im, re)
+__device__ __forceinline__ PkTw pk_tw_mul(pcx w) { return PkTw{ pk_neg16_hi(w), pk_swap(w) }; }           // mul / mul_q15: (re, neg16(im)), (im, re)
+template <int SHIFT>
+__device__ __forceinline__ pcx pk_cmul(pcx x, PkTw t)         // ((x.re t.a.lo + x.im t.a.hi) >> SHIFT, (x.re t.b.lo + x.im t.b.hi) >> SHIFT), wrapping packs
+{
+    const int v0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, x), __builtin_bit_cast(s16x2_t, t.a), 0, false);
+    const int v1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, x), __builtin_bit_cast(s16x2_t, t.b), 0, false);
+    return (((uint32_t)v0 >> SHIFT) & 0xFFFFu) | (((uint32_t)v1 << (16 - SHIFT)) & 0xFFFF0000u);
+}
+
+struct Fft64TwPk { PkTw w64[3], w16[3]; };
+__device__ __forceinline__ Fft64TwPk fft64_twiddles_pk(const Tables& T, int e)
+{
+    const Fft64Tw W = fft64_twiddles(T, e);
+    return Fft64TwPk{ { pk_tw_fft(W.w64_1), pk_tw_fft(W.w64_2), pk_tw_fft(W.w64_3) }, { pk_tw_fft(W.w16_1), pk_tw_fft(W.w16_2), pk_tw_fft(W.w16_3) } };
+}
+// radix-4 DIF butterfly of FFTSSE<N> (fft_r4dif.h:11-47) on packed values: y0 = sum, y1 (x W^2), y2 (x W^1), y3 (x W^3)
+__device__ __forceinline__ void pk_r4(pcx x0, pcx x1, pcx x2, pcx x3, const PkTw (&w)[3], pcx& y0, pcx& y1, pcx& y2, pcx& y3)
+{
+    const pcx a = pk_sra(x0, 2), b = pk_sra(x1, 2), c = pk_sra(x2, 2), d = pk_sra(x3, 2);
+    const pcx ac = pk_adds(a, c), bd = pk_adds(b, d), a_c = pk_subs(a, c), b_d = pk_subs(b, d);
+    const pcx jb = pk_mul_j(b_d);
+    y0 = pk_adds(ac, bd);
+    y1 = pk_cmul<15>(pk_subs(ac, bd), w[1]);
+    y2 = pk_cmul<15>(pk_subs(a_c, jb), w[0]);
+    y3 = pk_cmul<15>(pk_adds(a_c, jb), w[2]);
+}
+// 4-point terminal stage (FFTSSEEx<4>, fft_r4dif.h:60-83), input shift 2
+__device__ __forceinline__ void pk_t4(pcx c0, pcx c1, pcx c2, pcx c3, pcx& y0, pcx& y1, pcx& y2, pcx& y3)
+{
+    c0 = pk_sra(c0, 2); c1 = pk_sra(c1, 2); c2 = pk_sra(c2, 2); c3 = pk_sra(c3, 2);
+    const pcx A0 = pk_adds(c0, c2), A1 = pk_adds(c1, c3), B0 = pk_adds(~c2, c0), B1 = pk_adds(~c3, c1);
+    const pcx B1r = pk_neg_j(B1);
+    y0 = pk_adds(A0, A1); y1 = pk_adds(~A1, A0); y2 = pk_adds(B0, B1r); y3 = pk_adds(~B1r, B0);
+}
+// fft64_core on packed values: x[m] = point e + 16 m in, result in s[] (bin j at slot bitrev6(j))
+template <typename SYNC>
+__device__ __forceinline__ void fft64_core_pk(const pcx x[4], uint32_t* s, int e, const Fft64TwPk& W, SYNC sync)
+{
+    sync();
+    pk_r4(x[0], x[1], x[2], x[3], W.w64, s[e], s[e + 16], s[e + 32], s[e + 48]);
+    sync();
+    {
+        const int base = 16 * (e >> 2) + (e & 3);
+        pcx y0, y1, y2, y3;
+        pk_r4(s[base], s[base + 4], s[base + 8], s[base + 12], W.w16, y0, y1, y2, y3);
+        s[base] = y0; s[base + 4] = y1; s[base + 8] = y2; s[base + 12] = y3;
+    }
+    sync();
+    {
+        const uint4 c = reinterpret_cast<const uint4*>(s)[e];
+        uint4 y;
+        pk_t4(c.x, c.y, c.z, c.w, y.x, y.y, y.z, y.w);
+        reinterpret_cast<uint4*>(s)[e] = y;
+    }
+    sync();
+}
+
+struct Fft128TwPk { PkTw w128[3], w32[3], w8[4]; };
+__device__ __forceinline__ Fft128TwPk fft128_twiddles_pk(const Tables& T, int e)
+{
+    const Fft128Tw W = fft128_twiddles(T, e);
+    return Fft128TwPk{ { pk_tw_fft(W.w128[0]), pk_tw_fft(W.w128[1]), pk_tw_fft(W.w128[2]) }, { pk_tw_fft(W.w32[0]), pk_tw_fft(W.w32[1]), pk_tw_fft(W.w32[2]) },
+                       { pk_tw_fft(W.w8[0]), pk_tw_fft(W.w8[1]), pk_tw_fft(W.w8[2]), pk_tw_fft(W.w8[3]) } };
+}
+// forward FFT<128> on packed values (fft128_core<false>): the 8-point terminal stage (FFTSSEEx<8>, fft_r4dif.h:86-130) of block
+// e >> 1 is shared by a lane pair -- lane 2m takes the sum half (outputs 0..3), lane 2m+1 the difference half (outputs 4..7),
+// expressed without a branch: v = sat(a +- b), the -j rotation and the W8 products selected per lane.
+template <typename SYNC>
+__device__ __forceinline__ void fft128_core_pk(const pcx x[4], uint32_t* s, int e, const Fft128TwPk& W, SYNC sync)
+{
+    sync();
+    pk_r4(x[0], x[1], x[2], x[3], W.w128, s[e], s[e + 32], s[e + 64], s[e + 96]);
+    sync();
+    {
+        const int base = 32 * (e >> 3) + (e & 7);
+        pcx y0, y1, y2, y3;
+        pk_r4(s[base], s[base + 8], s[base + 16], s[base + 24], W.w32, y0, y1, y2, y3);
+        s[base] = y0; s[base + 8] = y1; s[base + 16] = y2; s[base + 24] = y3;
+    }
+    sync();
+    {
+        const bool hi = e & 1;                                                    // difference half
+        uint32_t* p = s + 8 * (e >> 1);
+        const uint4 A = reinterpret_cast<const uint4*>(p)[0], B = reinterpret_cast<const uint4*>(p)[1];
+        pcx v[4];
+        const pcx a[4] = { pk_sra(A.x, 3), pk_sra(A.y, 3), pk_sra(A.z, 3), pk_sra(A.w, 3) }, b[4] = { pk_sra(B.x, 3), pk_sra(B.y, 3), pk_sra(B.z, 3), pk_sra(B.w, 3) };
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = hi ? pk_subs(a[q], b[q]) : pk_adds(a[q], b[q]);
+        if (hi) { v[2] = pk_neg_j(v[2]); v[3] = pk_neg_j(v[3]); }                 // ee[2], ee[3] = -j d
+        pcx g0 = pk_adds(v[0], v[2]), g1 = pk_adds(v[1], v[3]), g2 = pk_adds(~v[2], v[0]), g3 = pk_adds(~v[3], v[1]);
+        if (hi) { g0 = pk_cmul<15>(g0, W.w8[0]); g1 = pk_cmul<15>(g1, W.w8[1]); g2 = pk_cmul<15>(g2, W.w8[2]); g3 = pk_cmul<15>(g3, W.w8[3]); }
+        else g3 = pk_neg_j(g3);                                                   // B1r
+        uint4 y;
+        y.x = pk_adds(g0, g1); y.y = pk_adds(~g1, g0); y.z = pk_adds(g2, g3); y.w = pk_adds(~g3, g2);
+        sync();                                                                   // both lanes of a pair have read the block before either half is rewritten
+        reinterpret_cast<uint4*>(p)[hi ? 1 : 0] = y;
+    }
+    sync();
+}
+
+// ---------------------------------------------------------------------------------------------
 // CRC-32 (reflected, init 0xFFFFFFFF, no final xor here) of n >= 4 bytes in LDS by one wave.  The register update is
 // linear over GF(2): CRC(init, M) = CRC(0, M') with the first four bytes complemented, and
 // CRC(0, M1 | M2) = Z_|M2|(CRC(0, M1)) ^ CRC(0, M2) with Z_m = "m zero bytes".  Lane l takes the 40 bytes that END 40 l

@@ -87,37 +87,37 @@ __global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* __restri
 {
     __shared__ uint32_t s_all[16][64];
     const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
-    const Fft64Tw W = fft64_twiddles(T, e);
+    const Fft64TwPk W = fft64_twiddles_pk(T, e);
     uint32_t* s = s_all[g];
-    uint4 v[kFftTiles];
+    uint4 v[kFftTiles]; uint32_t ci[kFftTiles];
 #pragma unroll
     for (int t = 0; t < kFftTiles; t++) {
         const uint32_t i = (blockIdx.x * kFftTiles + t) * 16 + g;
         v[t] = i < n ? reinterpret_cast<const uint4*>(in)[(size_t)i * 20 + 2 + e] : uint4{0, 0, 0, 0};   // sample i*80 + 8 + 4e (skip_cp = 8)
+        ci[t] = (i < n && ctx_index) ? ctx_index[i] : 0u;
     }
 #pragma unroll
     for (int t = 0; t < kFftTiles; t++) {
         const uint32_t i = (blockIdx.x * kFftTiles + t) * 16 + g;
-        const bool active = i < n;
-        const uint32_t* c = ctx + (size_t)(active && ctx_index ? ctx_index[i] : 0u) * 129;
+        const uint32_t* c = ctx + (size_t)ci[t] * 129;
+        uint32_t fq[4], ch[4];                                                       // the frame's FreqCoeffs / ChannelCoeffs this lane needs (L2-resident)
+#pragma unroll
+        for (int m = 0; m < 4; m++) { fq[m] = c[1 + e + 16 * m]; ch[m] = c[65 + 4 * e + m]; }
         wave_lds_sync();
         reinterpret_cast<uint4*>(s)[e] = v[t];
         wave_lds_sync();
-        cpx x[4];
+        pcx x[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) { const int k = e + 16 * m; x[m] = mul_q15(sra(unpack(s[k]), 1), unpack(c[1 + k])); }   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
-        fft64_core(x, s, e, W, wave_lds_sync);
+        for (int m = 0; m < 4; m++) x[m] = pk_cmul<15>(pk_sra(s[e + 16 * m], 1), pk_tw_mul(fq[m]));   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+        fft64_core_pk(x, s, e, W, wave_lds_sync);
         uint32_t o[4];
         const unsigned r = __brev((unsigned)e) >> 28;                                // bin 4e+q sits at slot bitrev6(4e+q) = bitrev4(e) + 16 bitrev2(q)
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const int bin = 4 * e + q;
-            const cpx Y = unpack(s[r + 16u * ((q & 1) * 2 + (q >> 1))]);
-            cpx w = mk(0, 0);
-            if (!(bin >= 28 && bin < 36)) { int re, im; mul32(Y, unpack(c[65 + bin]), re, im); w = mk(w16(re >> 8), w16(im >> 8)); }   // channel_11a.hpp:548-574
-            o[q] = pack(w);
+            o[q] = (bin >= 28 && bin < 36) ? 0u : pk_cmul<8>(s[r + 16u * ((q & 1) * 2 + (q >> 1))], pk_tw_mul(ch[q]));   // channel_11a.hpp:548-574
         }
-        if (active) reinterpret_cast<uint4*>(eq)[(size_t)i * 16 + e] = uint4{o[0], o[1], o[2], o[3]};
+        if (i < n) reinterpret_cast<uint4*>(eq)[(size_t)i * 16 + e] = uint4{o[0], o[1], o[2], o[3]};
     }
 }
 
@@ -126,7 +126,7 @@ __global__ void __launch_bounds__(256) k_fft64_batch(const uint32_t* __restrict_
 {
     __shared__ uint32_t s_all[16][64];
     const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
-    const Fft64Tw W = fft64_twiddles(T, e);
+    const Fft64TwPk W = fft64_twiddles_pk(T, e);
     uint32_t* s = s_all[g];
     uint4 v[kFftTiles];
 #pragma unroll
@@ -140,10 +140,10 @@ __global__ void __launch_bounds__(256) k_fft64_batch(const uint32_t* __restrict_
         wave_lds_sync();
         reinterpret_cast<uint4*>(s)[e] = v[t];
         wave_lds_sync();
-        cpx x[4];
+        pcx x[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = unpack(s[e + 16 * m]);
-        fft64_core(x, s, e, W, wave_lds_sync);
+        for (int m = 0; m < 4; m++) x[m] = s[e + 16 * m];
+        fft64_core_pk(x, s, e, W, wave_lds_sync);
         const unsigned r = __brev((unsigned)e) >> 28;
         if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 16 + e] = uint4{s[r], s[r + 32], s[r + 16], s[r + 48]};
     }
@@ -281,7 +281,7 @@ __global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* __restrict
 {
     __shared__ uint32_t s_all[8][128];
     const int g = threadIdx.x >> 5, e = threadIdx.x & 31;
-    const Fft128Tw W = fft128_twiddles(T, e);
+    const Fft128TwPk W = fft128_twiddles_pk(T, e);
     uint32_t* s = s_all[g];
     uint4 v[kFftTiles];
 #pragma unroll
@@ -295,10 +295,10 @@ __global__ void __launch_bounds__(256) k_fft128_batch(const uint32_t* __restrict
         wave_lds_sync();
         reinterpret_cast<uint4*>(s)[e] = v[t];
         wave_lds_sync();
-        cpx x[4];
+        pcx x[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = unpack(s[e + 32 * m]);
-        fft128_core<false>(x, s, e, W, wave_lds_sync);
+        for (int m = 0; m < 4; m++) x[m] = s[e + 32 * m];
+        fft128_core_pk(x, s, e, W, wave_lds_sync);
         const unsigned r = __brev((unsigned)e) >> 27;                               // point 4e+q sits at slot bitrev7(4e+q) = bitrev5(e) + 32 bitrev2(q)
         if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 32 + e] = uint4{s[r], s[r + 64], s[r + 32], s[r + 96]};
     }
@@ -348,8 +348,10 @@ __global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__
 {
     __shared__ uint32_t s_raw[kTileRaw / 4];
     __shared__ uint32_t s_out[kTileOut];
+    __shared__ int s_lin[2][12];                                                   // the interpolation weights, out of LDS (a per-lane index into constant memory is a cached global load)
     constexpr int NQ = kTileRaw / 16;                                              // 440 quad-words per tile: two per thread (the second for 184 threads)
     const int tid = threadIdx.x;
+    if (tid < 11) { s_lin[0][tid] = kLinR[tid]; s_lin[1][tid] = kLinL[tid]; }
     const bool dec = (flags & 8u) != 0, fix = (flags & 2u) != 0;
     const int nout = dec ? kTileOut / 2 : kTileOut;
     auto X = [&](int i) -> cpx {                                                 // input sample i of the tile
@@ -377,7 +379,8 @@ __global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__
             if (k == 0) v = X(11 * p);
             else {
                 const cpx a = X(11 * p + k), b = X(11 * p + k + 1);
-                v = mk(w16((a.re * kLinR[k] + b.re * kLinL[k + 1]) >> 7), w16((a.im * kLinR[k] + b.im * kLinL[k + 1]) >> 7));
+                const int R = s_lin[0][k], L = s_lin[1][k + 1];
+                v = mk(w16((a.re * R + b.re * L) >> 7), w16((a.im * R + b.im * L) >> 7));
             }
             s_out[m] = pack(v);
         }
