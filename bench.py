@@ -514,7 +514,8 @@ def main():
         if int(b.nrows[0]) != exp_n or b.rows[:exp_n].tobytes() != exp_bytes:
             stats["bad"] += 1
 
-    def run_block(k, deliver):
+    def run_block(k, deliver, dep=None):
+        dep = dep or depth                                          # calls in flight on the handle right now (<= len(bufs))
         first = None
         for _ in range(k):
             tk = rx.process_dev(d_iq, descs)
@@ -522,10 +523,10 @@ def main():
                 rx.deliver_async(tk, bufs[tk % depth])
                 if first is None:
                     first = tk
-                if tk - first >= depth - 1:
-                    consume(tk - (depth - 1))
+                if tk - first >= dep - 1:
+                    consume(tk - (dep - 1))
         if deliver and first is not None:
-            for old in range(max(first, tk - (depth - 1) + 1), tk + 1):
+            for old in range(max(first, tk - (dep - 1) + 1), tk + 1):
                 consume(old)
 
     deliver = not args.no_deliver
@@ -568,6 +569,37 @@ def main():
     ktimes1 = rx.kernel_times()
     rx.set_profiling(False)
     rx.set_depth(depth)
+
+    # ---- the other implementation of the data field: k_decode (symbol and trellis waves in one kernel, soft values in LDS)
+    fused = None
+    if world == 1 and not args.no_extras:
+        fused = {}
+        rx.flush(); rx.set_fused(1)
+        for dname, dval in (("one_call_in_flight", 1), ("calls_in_flight_%d" % depth, depth)):
+            rx.set_depth(dval); rx.flush()
+            run_block(args.warmup, deliver, dval); rx.flush()
+            stats_before = dict(stats)
+            tf0 = time.perf_counter()
+            nblk = max(1, repeats // 4)
+            for _ in range(nblk):
+                run_block(args.steps, deliver, dval)
+            rx.flush()
+            tf1 = time.perf_counter()
+            fused[dname] = {"ms_per_step": round((tf1 - tf0) / (nblk * args.steps) * 1e3, 4), "steps": nblk * args.steps,
+                            "calls_with_wrong_rows": stats["bad"] - stats_before["bad"]}
+        rx.set_depth(1); rx.flush(); rx.set_profiling(True)
+        for _ in range(max(10, args.steps // 2)):
+            rx.process_dev(d_iq, descs)
+        rx.flush()
+        fused["kernel_ms_one_call_in_flight"] = {k: round(v, 4) for k, v in rx.kernel_times().items()}
+        rx.set_profiling(False)
+        tk = rx.process_dev(d_iq, descs)
+        fres = rx.results(ticket=tk)
+        okf, whyf = check_against_reference(fres, kind, want, idx)
+        fused["parity"] = {"against": kind, "captures_checked": len(idx), "ok": okf}
+        if not okf:
+            print("PARITY MISMATCH (fused path) vs %s: %s" % (kind, whyf), file=sys.stderr)
+        rx.set_fused(0); rx.set_depth(depth); rx.flush()
 
     elapsed = t1 - t0
     if world > 1:
@@ -625,6 +657,9 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
+        if fused is not None:
+            fused["note"] = "sora_rx_set_fused(1): the same workload and timed-region protocol with the data field decoded by k_decode"
+            out["fused_decode"] = fused
         if world == 1 and not args.no_extras:
             out["stages"] = bench_stages(torch, sora_amd, dev)
             out["ingest"] = bench_ingest(torch, sora_amd, dev)

@@ -146,6 +146,17 @@ const char* sora_rx_kernel_name(size_t index);
  * asynchronous call). */
 int  sora_rx_set_depth(sora_rx_t* rx, int depth);
 
+/* Two implementations of the data field (T11aDataSymbol .. T11aViterbi) with identical results:
+ *   0 (default)  k_frame (symbol chain, soft values to HBM as 16-bit fields) then k_viterbi (two frames per wave);
+ *   1            k_decode: both in one kernel, symbol waves feeding trellis waves through a ring in LDS the way the
+ *                reference's RxThread feeds its ViterbiThread through TThreadSeparator (stdbrick.hpp:89-248) -- a quarter of
+ *                the HBM traffic, the better choice for one call at a time; with several calls in flight the split form is
+ *                faster because its kernels leave room for each other on the CUs.
+ * Returns the previous value; enable < 0 only queries.  Environment SORA_HIP_FUSED sets the default of new handles.
+ * sora_rx_kernel_name_fused(i) names the kernels of the fused chain for sora_rx_kernel_times ("" = slot not used). */
+int  sora_rx_set_fused(sora_rx_t* rx, int enable);
+const char* sora_rx_kernel_name_fused(size_t index);
+
 /* Device-side views of the last call's outputs (valid until the next process/reset/destroy). */
 int  sora_rx_results_dev(sora_rx_t* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu);
 int  sora_rx_results_dev_of(sora_rx_t* rx, int ticket, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu);

@@ -12,8 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsora_hip.so")
-SOURCES = ["k_scan.hip", "k_rx.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "sora_hip.cpp"]
-HEADERS = ["dev_arith.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
+SOURCES = ["k_scan.hip", "k_rx.hip", "k_decode.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "sora_hip.cpp"]
+HEADERS = ["dev_arith.h", "dev_viterbi.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip"]
 
 
@@ -42,6 +42,16 @@ def needs_build():
         return True
     t = os.path.getmtime(LIB)
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
+
+
+def build_variant(name, defines):
+    """An experimental build of the whole library with extra -D flags -> sora_amd/lib/variants/<name>.so (A/B measurements:
+    run any entry point with SORA_HIP_LIB=<that file>)."""
+    out_dir = os.path.join(HERE, "lib", "variants"); os.makedirs(out_dir, exist_ok=True)
+    out = os.path.join(out_dir, name + ".so")
+    cmd = [hipcc()] + FLAGS + ["-shared", "-w"] + ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES] + ["-o", out]
+    subprocess.check_call(cmd)
+    return out
 
 
 def build(force=False, verbose=False):

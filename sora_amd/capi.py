@@ -47,7 +47,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
-           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
+           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results"]
@@ -71,11 +71,12 @@ def load(build_if_missing=True):
         import torch  # noqa: F401
     except Exception:
         pass
-    if build_if_missing and _build.needs_build():
+    path = os.environ.get("SORA_HIP_LIB") or _build.LIB             # SORA_HIP_LIB: an experimental build of the same library (tools/ab_*.sh)
+    if path == _build.LIB and build_if_missing and _build.needs_build():
         _build.build()
-    if not os.path.exists(_build.LIB):
+    if not os.path.exists(path):
         raise SoraError(-1, "libsora_hip.so is missing and could not be built; there is no CPU fallback")
-    L = ctypes.CDLL(_build.LIB)
+    L = ctypes.CDLL(path)
     L.sora_hip_last_error.restype = ctypes.c_char_p
     L.sora_hip_malloc.restype = ctypes.c_void_p
     L.sora_hip_malloc.argtypes = [ctypes.c_size_t]
@@ -106,6 +107,8 @@ def load(build_if_missing=True):
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
     L.sora_rx_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_set_fused.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_kernel_name_fused.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name_fused.restype = ctypes.c_char_p
     L.sora_hip_fft64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_fft128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_lts11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -275,11 +278,16 @@ class Rx:
         """number of process calls kept in flight on internal pipelines (1..4); returns the previous value"""
         return int(self._L.sora_rx_set_depth(self._h, int(depth)))
 
+    def set_fused(self, enable=-1):
+        """1: decode the data field with the fused kernel (k_decode), 0: k_frame + k_viterbi; returns the previous setting"""
+        return int(self._L.sora_rx_set_fused(self._h, int(enable)))
+
     def kernel_times(self):
-        """{kernel name: ms} of the last profiled process call (HIP events on the handle's stream)."""
+        """{kernel name: ms} of the profiled process calls (HIP events on the handle's streams)."""
         ms = (ctypes.c_float * 8)(); n = ctypes.c_size_t(0)
         _check(self._L.sora_rx_kernel_times(self._h, ms, 8, ctypes.byref(n)))
-        return {self._L.sora_rx_kernel_name(i).decode(): ms[i] for i in range(n.value)}
+        name = self._L.sora_rx_kernel_name_fused if self.set_fused(-1) else self._L.sora_rx_kernel_name
+        return {name(i).decode(): ms[i] for i in range(n.value) if name(i)}
 
     def flush(self):
         _check(self._L.sora_rx_flush(self._h))

@@ -8,6 +8,7 @@
 #include <hip/hip_runtime.h>
 #include <utility>
 #include "kernels.h"
+#include "dev_viterbi.h"
 
 namespace sora {
 
@@ -51,10 +52,10 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     const FrameCtx* fx = A.fctx + f;
     const uint32_t* iq = A.iq + A.caps[r.capture].offset;
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
-    const Fft64Tw W = fft64_twiddles(T, e);
-    cpx fq[4], ch[4];
+    const Fft64TwPk W = fft64_twiddles_pk(T, e);
+    PkTw fq[4], ch[4];                                                           // FreqCoeffs / ChannelCoeffs as the operand pairs of the packed complex product
 #pragma unroll
-    for (int m = 0; m < 4; m++) { fq[m] = unpack(fx->freq[e + 16 * m]); ch[m] = unpack(fx->chan[e + 16 * m]); }
+    for (int m = 0; m < 4; m++) { fq[m] = pk_tw_mul(fx->freq[e + 16 * m]); ch[m] = pk_tw_mul(fx->chan[e + 16 * m]); }
     const int nb = r.nbpsc, ncbps = 48 * nb, nsym = r.nsym;
     {
         const uint16_t* map = T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
@@ -77,19 +78,19 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     for (int s0 = 1; s0 <= nsym; s0 += 4) {
         const int sym = s0 + g;
         const bool active = sym <= nsym;
-        // ---- TFreqCompensation + TFFT64 + TChannelEqualization, symbol `sym` in group g
-        cpx x[4], Y[4];
+        // ---- TFreqCompensation + TFFT64 + TChannelEqualization on packed COMPLEX16 (dev_arith.h), symbol `sym` in group g
+        pcx x[4], Y[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = mul_q15(sra(unpack(raw[m]), 1), fq[m]);   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+        for (int m = 0; m < 4; m++) x[m] = pk_cmul<15>(pk_sra(raw[m], 1), fq[m]);   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
         if (s0 + 4 <= nsym) load_samples(s0 + 4, raw);                           // next pass: in flight during the tracking loop
-        fft64_group(x, Y, s_eq[w][g], e, W, wsync);
+        fft64_core_pk(x, s_eq[w][g], e, W, wsync);
+#pragma unroll
+        for (int q = 0; q < 4; q++) Y[q] = s_eq[w][g][__brev((unsigned)(e + 16 * q)) >> 26];
         wsync();
 #pragma unroll
         for (int q = 0; q < 4; q++) {                                            // channel_11a.hpp:548-574
             const int bin = e + 16 * q;
-            cpx o = mk(0, 0);
-            if (!(bin >= 28 && bin < 36)) { int re, im; mul32(Y[q], ch[q], re, im); o = mk(w16(re >> 8), w16(im >> 8)); }
-            s_eq[w][g][bin] = pack(o);
+            s_eq[w][g][bin] = (bin >= 28 && bin < 36) ? 0u : pk_cmul<8>(Y[q], ch[q]);
         }
         wsync();
         // ---- the loop-carried part, symbols s0 .. s0+3 in order
@@ -156,181 +157,7 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     }
 }
 
-// ------------------------------------------------------------------------------------------------
-// k_viterbi: forward add-compare-select of the K=7 (133,171) code exactly as TViterbiCore does it
-// (viterbicore.h:293-465): 8-bit WRAPPING path metrics with the decision in the metric LSB (&0xFE / |1),
-// unsigned minimum, normalisation whenever (trellis_index & 7) == 0 after a puncture group, and the window
-// schedule of T11aViterbi<..,256,24>::Process (viterbi.hpp:189-214).
-//
-// Arithmetic.  A reference metric byte is m = 2u + d (d = decision mark).  Branch metrics are even, so
-//   c0 = (x0 + bm0) & 0xFE = 2((u0 + b0) mod 128),  c1 = ((x1 + bm1) & 0xFE) | 1 = 2((u1 + b1) mod 128) + 1,  b = bm/2
-//   min(c0, c1) picks c1 iff (u1 + b1) mod 128 < (u0 + b0) mod 128  (a tie keeps c0), and the new u is that minimum.
-// The kernel carries u in the top 7 bits of a 16-bit field (u << 9): the 7-bit wrap is the natural 16-bit wrap and the
-// unsigned minimum needs no masking.  Normalisation subtracts min(u) (= (min m & 0xFE)/2).
-// Branch metric of soft value v (0..7) for expected bit c: b = v ^ (c ? 7 : 0) (VIT_MA/VIT_MB, viterbilut.h:50-185,
-// halved); expected bits = parity((branch<<6 | n) & 0155) for A, & 0117 for B, n = new state.  Both generators
-// tap the oldest bit, so the decision-1 branch costs K - b0, K = 14 (7 on a punctured step).
-//
-// Decisions without a compare.  The reference marks the decision in the metric LSB; here the nine spare low bits of
-// the field do the same job: step k of an 8-step block adds 1 << k to the decision-1 candidate.  That bit breaks
-// ties exactly like the reference's LSB (a tie keeps branch 0), marks of earlier steps sit BELOW it and can never
-// decide a comparison, and after the minimum it IS the decision.  Because the marks travel with the metric through
-// the butterfly, after 8 steps the low byte of a lane is the decision history of the SURVIVOR PATH into the state
-// the lane holds (register exchange, 8 deep, for free).  Every 8 steps the byte is moved to a history register
-// (one v_perm_b32 per frame) and cleared; every 24 steps the 64 lanes store 3 such bytes as one coalesced 256-byte
-// row.  The trace-back then walks 8 columns per lookup: the 6 oldest decisions of a block are the state 8 columns
-// earlier, the 8 decisions are the decoded bits.
-//
-// CDNA4 mapping.  wave64 = the 64 states, run as an in-place butterfly {p, p+32} -> {2p, 2p+1}: after t steps
-// lane L holds state rol6^t(L), and the two predecessors of its next state sit in lanes L and P = L ^ (32 >> (t mod 6)).
-//     t mod 6 = 0,1 : v_permlane32_swap / v_permlane16_swap (gfx950) return (metric of the decision-0 predecessor,
-//                     metric of the decision-1 predecessor) directly
-//     t mod 6 = 2..5: the lane adds its OWN metric and the partner's (one DPP move: row_ror:8, quad_perm; two for ^4);
-//                     which of the two is the decision-1 candidate depends on the lane, so the lane's soft masks are
-//                     complemented (K - b = b ^ 7) and carry the mark for the lanes whose own metric is candidate 1.
-// Two frames per wave: frame A in the low 16-bit half of every register, frame B in the high half (v_pk_add_u16,
-// v_pk_min_u16; the cross-lane moves carry both).  Measured issue cost on gfx950 at 2 waves/SIMD (tools/gen_probe_issue.py):
-// VOP2 add/sub/xor/and/mov 5.0, VOP3/VOP3P/DPP 9.4, compare->SGPR / v_addc 9.9, permlane swap 16.9 (units of 0.67 ns).
-// Per packed step: 1 move + 2 adds + 1 min + 2..3 for the branch metrics; no compare, no carry chain, no LDS.
-__device__ __forceinline__ unsigned rol6(unsigned v, unsigned r) { r %= 6; return ((v << r) | (v >> (6 - r))) & 63u; }
-// Physical lane <-> label lane.  The butterfly partner of label lane v at phase ph is v ^ (32 >> ph); every XOR distance
-// except 4 is one cross-lane move (permlane swaps for 32/16, row_ror:8, quad_perm for 2/1).  Placing label lane v in
-// physical lane v ^ (v & 4 ? 3 : 0) turns the label distance 4 into the physical distance 7 = row_half_mirror, one DPP
-// move too; the other distances are unchanged.  The map is its own inverse.
-__device__ __forceinline__ unsigned lane_map(unsigned x) { return x ^ ((x & 4u) ? 3u : 0u); }
-
-__device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wide unsigned minimum, VALU latency only
-{
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // ^1
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // ^2
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));   // row_ror:4
-    v = min(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));   // row_ror:8
-    auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = min(r16[0], r16[1]);
-    auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return min(r32[0], r32[1]);
-}
-
-typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ unsigned pk_min16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
-
-__device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-half wave-wide unsigned minimum, broadcast to all lanes
-{
-    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true));    // ^1
-    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true));    // ^2
-    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x124, 0xF, 0xF, true));   // row_ror:4
-    v = pk_min16(v, (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x128, 0xF, 0xF, true));   // row_ror:8
-    auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
-    v = pk_min16(r16[0], r16[1]);
-    auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
-    return pk_min16(r32[0], r32[1]);
-}
-
-constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
-constexpr unsigned kOne = 0x00010001u;                    // bit 0 of both halves
-
-constexpr int kRingBlocks = 48;                           // 8-step blocks of survivor history kept in LDS per wave: a window walks <= 37 of them
-
-struct VitLane {
-    unsigned U;              // (field B << 16) | field A; field = u << 9 | marks of the current 8-step block
-    unsigned MX[24];         // soft mask (+ mark, + complement for own-is-candidate-1 lanes) of the mark-carrying operand, per t mod 24
-    unsigned MY[6];          // soft mask of the second operand of a two-input step, per t mod 6
-    uint16_t* ring;          // LDS: [kRingBlocks][64] {frame A's block, frame B's block} (one byte each) at the block's end, indexed by rev6(state)
-    unsigned roff;           // slot of the block being filled, in words: (block index % kRingBlocks) * 64   (wave-uniform)
-    unsigned sidx[3];        // ring index of the state this lane holds at the end of block j, by j % 3: rev6(rol6^(8j+8)(lane))
-};
-
-// WHICH 0: (A,B) two soft values, 1: A only, 2: B only.  t24 = trellis step index mod 24 (a constant after unrolling).
-template <int WHICH>
-__device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsigned b)
-{
-    const int ph = t24 % 6, k = t24 % 8;
-    const unsigned Kp = (WHICH == 0 ? 14u : 7u) * kFld + (kOne << k);           // K + mark
-    unsigned bm;                                                                // cost added to X (per field: b, or b + mark)
-    if (WHICH == 0)      bm = (a ^ V.MX[t24]) + (b ^ V.MY[ph]);                  // per field <= 14 << 9 | mark: no carry between the halves
-    else if (WHICH == 1) bm = a ^ V.MX[t24];
-    else                 bm = b ^ V.MX[t24];
-    const unsigned bo = Kp - bm;                                                // cost added to Y
-    unsigned X, Y;
-    const int u = (int)V.U;
-    switch (ph) {
-    case 0: { auto r = __builtin_amdgcn_permlane32_swap(V.U, V.U, false, false); X = r[0]; Y = r[1]; break; }
-    case 1: { auto r = __builtin_amdgcn_permlane16_swap(V.U, V.U, false, false); X = r[0]; Y = r[1]; break; }
-    case 2: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x128, 0xF, 0xF, true); break;                  // L ^ 8: row_ror:8
-    case 3: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x141, 0xF, 0xF, true); break;                  // label ^ 4 = lane ^ 7: row_half_mirror
-    case 4: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x4E, 0xF, 0xF, true); break;                   // L ^ 2: quad_perm [2,3,0,1]
-    default: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, true); break;                  // L ^ 1: quad_perm [1,0,3,2]
-    }
-    V.U = pk_min16(pk_add16(X, bm), pk_add16(Y, bo));
-    if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
-        uint8_t* e = reinterpret_cast<uint8_t*>(V.ring + V.roff + V.sidx[t24 / 8]);
-        e[0] = (uint8_t)V.U; e[1] = (uint8_t)(V.U >> 16);                       // ds_write_b8 + ds_write_b8_d16_hi: frame A's block, frame B's block
-        V.roff = V.roff + 64 == kRingBlocks * 64 ? 0u : V.roff + 64;
-        V.U &= 0xFE00FE00u;
-    }
-}
-
-// Trace-back of one window per frame (cnt = 0: none), called from the forward loop whenever the schedule fires (once per
-// 256 columns): start at the arg-min state with the reference's tie-break metric<<8 | state<<2 (viterbicore.h:479-524),
-// metric = 2u + last decision; walk back look + cnt columns, write cnt / 8 decoded bytes at bit `ob` of the frame.
-// The ring is indexed by q = rev6(state), so the index of the next (earlier) block is simply the low 6 bits of the
-// block just read.  All blocks the walk can touch (<= 38) are first fetched into registers, lane = ring index, with
-// independent LDS reads; the walk itself is then v_readlane + two scalar ops per block and frame, no memory latency.
-// Kept out of line: it is reached from every puncture group of the slow path.
-__device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uint32_t tr_, uint32_t ob_, unsigned mA, unsigned mB,
-                                           uint32_t cntA_, uint32_t cntB_, uint8_t* outA, uint8_t* outB)
-{
-    constexpr int kMaxWalk = 38;
-    const unsigned lane = threadIdx.x & 63;
-    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // arguments arrive in VGPRs; these are wave-uniform
-    const uint32_t tr = uni(tr_), ob = uni(ob_), cntA = uni(cntA_), cntB = uni(cntB_);
-    auto rev6 = [](unsigned x) { return __brev(x) >> 26; };
-    auto writelane = [](unsigned& vec, unsigned val, unsigned ln) {             // vec[lane ln] = val (one SGPR operand per VALU op: the lane select goes through M0)
-        asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(ln) : "m0");
-    };
-    const unsigned lbl = rol6(lane_map(lane), tr) << 2;
-    const unsigned kA = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mA << 8) | lbl));
-    const unsigned kB = (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave((mB << 8) | lbl));
-    const unsigned stA = (kA >> 2) & 0x3F, stB = (kB >> 2) & 0x3F;
-    const unsigned back = 6u - tr % 6u;                                         // label lane holding state s now: rol6(s, 6 - tr mod 6)
-    const unsigned pA = (unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stA, back))) & 0xFFu;  // decisions of the unfinished block
-    const unsigned pB = ((unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stB, back))) >> 16) & 0xFFu;  // along the start state's path
-    const int m_lo = (int)(ob >> 3);                                            // first output byte of the window
-    const int j = (int)((tr - 1) >> 3);                                         // block holding the start column
-    const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8
-    const int nblk = j - m_lo;                                                  // blocks below j on the walk
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t W[kMaxWalk];                                                       // W[i] = block j - i, all 64 ring entries (one per lane)
-    const int sl0 = (j % kRingBlocks) * 64;
-#pragma unroll
-    for (int i = 0; i < kMaxWalk; i++) {
-        const int sl = sl0 - 64 * i;
-        W[i] = ring[(sl < 0 ? sl + kRingBlocks * 64 : sl) + (int)lane];
-    }
-    unsigned HA, HB;
-    if (n == 8) {
-        HA = (unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stA)) & 0xFFu;
-        HB = ((unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stB)) >> 8) & 0xFFu;
-    } else { HA = pA & ((1u << n) - 1u); HB = pB & ((1u << n) - 1u); }
-    unsigned qA = rev6(((stA >> n) | rev6(HA & 0x3Fu)) & 0x3Fu), qB = rev6(((stB >> n) | rev6(HB & 0x3Fu)) & 0x3Fu);   // ring index at column 8j
-    unsigned hvA = 0, hvB = 0;                                                  // lane i <- decisions of block m_lo + i
-    writelane(hvA, HA, (unsigned)nblk); writelane(hvB, HB, (unsigned)nblk);
-#pragma unroll
-    for (int i = 1; i < kMaxWalk; i++) {
-        if (i <= nblk) {
-            HA = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qA) & 0xFFu;          qA = HA & 0x3Fu;
-            HB = ((unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB) >> 8) & 0xFFu;   qB = HB & 0x3Fu;
-            writelane(hvA, HA, (unsigned)(nblk - i)); writelane(hvB, HB, (unsigned)(nblk - i));
-        }
-    }
-    // decoded byte m = (block m >> 6) | (block m+1 & 0x3F) << 2, lane i <-> byte m_lo + i
-    const unsigned upA = (unsigned)__shfl_down((int)hvA, 1), upB = (unsigned)__shfl_down((int)hvB, 1);
-    if (lane < (cntA >> 3)) outA[m_lo + (int)lane] = (uint8_t)((hvA >> 6) | ((upA & 0x3Fu) << 2));
-    if (lane < (cntB >> 3)) outB[m_lo + (int)lane] = (uint8_t)((hvB >> 6) | ((upB & 0x3Fu) << 2));
-}
-
+// (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
 struct VitSide {            // wave-uniform per-frame bookkeeping
     const uint32_t* soft; uint8_t* out; uint32_t nsteps, last_chunk, tr_end; bool done;
 };

@@ -33,16 +33,17 @@ struct RxArgs {
     Tables          T;
     FrameRow*       frames;
     const FrameCtx* fctx;
-    uint8_t*        soft;           // [slots*288] 16-bit fields (v << 9)
+    uint8_t*        soft;           // [slots*288] 16-bit fields (v << 9); unused by the fused decode kernel
     uint8_t*        vout;           // [slots*32]
     uint8_t*        mpdu;           // [slots*32]
-    VitJob*         jobs;           // [nrows] (indexed by job)
+    VitJob*         jobs;           // [3][nrows] (indexed by job); unused by the fused decode kernel
     const uint32_t* njobs;
     const uint32_t* joblist;
 };
 
 __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
+__global__ void k_decode(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;

@@ -265,8 +265,9 @@ struct RxPipe {
     uint32_t cap_slots = 0, cap_rows = 0;
     // device arrays
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
-    uint8_t* d_soft = nullptr;
-    uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
+    uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
+    bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
+    uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
     // last call.  Descriptors go up through a pinned staging buffer (a pageable source would make the "async" copy wait for
@@ -291,6 +292,7 @@ struct RxPipe {
 
 static constexpr size_t kNumTimed = 5;
 static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_finish" };
+static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
 
 // Adds the durations of the pipeline's last profiled call to its running sums (waits for that call).
 static int fold_profile(RxPipe* rx)
@@ -306,7 +308,7 @@ static void rx_free(RxPipe* rx)
 {
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes,
-                     rx->d_soft, rx->d_vout, rx->d_mpdu, rx->d_jobs, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist };
+                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -359,9 +361,10 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     if (e == hipSuccess) e = hipEventCreateWithFlags(&rx->ev_caps, hipEventDisableTiming);
     if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "pinned descriptor buffer", e); }
     if (const char* g = getenv("SORA_HIP_GRAPH")) rx->use_graph = atoi(g) != 0;
+    if (const char* g = getenv("SORA_HIP_FUSED")) rx->fused = atoi(g) != 0;
     const uint64_t n20 = cfg->max_total_samples / rx->str;
-    // Symbol slots, frame rows and the byte offsets derived from them are 32-bit on the device (VitJob::soft_off = slot x 576):
-    // a configuration that would wrap them is refused here instead of decoding garbage later.
+    // Symbol slots, frame rows and the byte offsets derived from them are 32-bit on the device: a configuration that would
+    // wrap them is refused here instead of decoding garbage later.
     const uint64_t want_slots = n20 / 80 + cfg->max_captures + 16, want_rows = (uint64_t)cfg->max_captures * cfg->max_frames_per_capture;
     if (want_slots * (2ull * kSoftPerSlot) >= (1ull << 32) || want_rows >= (1ull << 31) / 3 || cfg->max_total_samples >= (1ull << 32)) {
         rx_free(rx);
@@ -372,9 +375,8 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     struct { void** p; size_t bytes; } allocs[] = {
         { (void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures }, { (void**)&rx->d_frames, sizeof(FrameRow) * rx->cap_rows },
         { (void**)&rx->d_fctx, sizeof(FrameCtx) * ((size_t)rx->cap_rows + cfg->max_captures) }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
-        { (void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64 },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
-        { (void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows }, { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
+        { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
         { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_njobs, 12 }, { (void**)&rx->d_joblist, 3 * 4 * (size_t)rx->cap_rows },
     };
     for (auto& a : allocs) {
@@ -427,6 +429,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     rx->h_caps.swap(hc);
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
+    if (!rx->fused && !rx->d_soft) {                                             // the 16-bit soft stream and the job table exist only for the split path
+        HIPCHK(hipMalloc((void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64));
+        HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
+    }
     hipStream_t st = rx->stream;
     const bool prof = rx->profiling;
     if (prof) { const int rc = fold_profile(rx); if (rc) return rc; }
@@ -457,12 +463,19 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         RxArgs R{};
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
         R.frames = rx->d_frames; R.fctx = rx->d_fctx;
-        R.soft = rx->d_soft;
-        R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.jobs = rx->d_jobs; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
-        hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
-        mark();
-        hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
-        mark();
+        R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
+        if (rx->fused) {
+            // the data field of every frame, samples -> decoded bytes, in one kernel: two frames per trellis wave, two pairs per
+            // workgroup (at most ceil(n / 2) + 2 pairs over the three code-rate lists; surplus workgroups return at once)
+            hipLaunchKernelGGL(k_decode, dim3(((nrows + 1) / 2 + 2 + 1) / 2), dim3(256), 0, st, R);
+            mark(); mark();
+        } else {
+            R.soft = rx->d_soft; R.jobs = rx->d_jobs;
+            hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+            mark();
+            hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
+            mark();
+        }
         hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
         mark();
         return SORA_OK;
@@ -564,6 +577,7 @@ static int pipe_set_profiling(RxPipe* rx, int enable)
 }
 
 const char* sora_rx_kernel_name(size_t i) { return i < kNumTimed ? kKernelNames[i] : ""; }
+const char* sora_rx_kernel_name_fused(size_t i) { return i < kNumTimed ? kKernelNamesFused[i] : ""; }
 
 static int pipe_results_dev(RxPipe* rx, const sora_frame_result** d_rows, const uint32_t** d_nrows, const uint8_t** d_mpdu)
 {
@@ -599,7 +613,7 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
 
 // ------------------------------------------------------------------------------------------------
 // The public handle: up to kMaxDepth pipelines used round-robin by consecutive process calls, so that the latency-bound
-// front end of one call (k_scan, k_frame) overlaps the issue-bound trellis kernel of the call before it -- the overlap
+// front end of one call (k_scan) overlaps the issue-bound decode kernel of the call before it -- the overlap
 // the reference gets from running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120, TThreadSeparator
 // stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
 struct sora_rx {
@@ -609,6 +623,7 @@ struct sora_rx {
     int cur = 0;                 // pipeline of the most recent process call
     bool started = false;
     bool profiling = false;
+    bool fused = false;
     int seq = 0;                 // ticket of the most recent process call
     RxPipe* pipes[kMaxDepth] = {};
 };
@@ -624,6 +639,7 @@ static RxPipe* pipe_at(sora_rx* rx, int i)
 {
     if (!rx->pipes[i]) {
         if (pipe_create(&rx->cfg, &rx->pipes[i]) != SORA_OK) return nullptr;
+        rx->pipes[i]->fused = rx->fused;
         if (rx->profiling) (void)pipe_set_profiling(rx->pipes[i], 1);
     }
     return rx->pipes[i];
@@ -638,7 +654,7 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     const int rc = pipe_create(cfg, &p0);
     if (rc != SORA_OK) return rc;
     sora_rx* rx = new sora_rx();
-    rx->cfg = *cfg; rx->pipes[0] = p0;
+    rx->cfg = *cfg; rx->pipes[0] = p0; rx->fused = p0->fused;
     if (const char* env = getenv("SORA_HIP_DEPTH")) rx->depth = std::max(1, std::min((int)sora_rx::kMaxDepth, atoi(env)));
     *out = rx;
     return SORA_OK;
@@ -649,6 +665,17 @@ void sora_rx_destroy(sora_rx_t* rx)
     if (!rx) return;
     for (RxPipe* p : rx->pipes) if (p) pipe_destroy(p);
     delete rx;
+}
+
+int sora_rx_set_fused(sora_rx_t* rx, int enable)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->fused ? 1 : 0;
+    if (enable >= 0) {
+        rx->fused = enable != 0;
+        for (RxPipe* p : rx->pipes) if (p) { p->fused = rx->fused; p->last_valid = false; }      // (a recorded hipGraph holds the other kernel chain)
+    }
+    return old;
 }
 
 int sora_rx_set_depth(sora_rx_t* rx, int depth)

@@ -27,10 +27,12 @@ def sora():
     return sora_amd
 
 
-def run_rx(sora, torch, caps, rate_mhz, max_frames=4):
+def run_rx(sora, torch, caps, rate_mhz, max_frames=4, fused=None):
     iq, descs = batch(caps)
     rx = sora.Rx(max_captures=max(1, len(caps)), max_total_samples=max(64, len(iq)), sample_rate_mhz=rate_mhz,
                  max_frames_per_capture=max_frames)
+    if fused is not None:
+        rx.set_fused(fused)
     d = torch.from_numpy(iq).cuda()
     rx.process_dev(d, descs)
     res = rx.results()
@@ -457,3 +459,56 @@ def test_config3_full_batch_equals_the_reference_graph(sora, torch_cuda, oracle)
     assert ok, why
     good = sum(1 for r in res if r["error_code"] == E_FRAME_OK and r["mpdu"][:-4] == payloads[r["capture_id"]])
     assert good >= nfr * 0.95, good                                   # ~2 % of the 27 dB captures fail their FCS -- in the reference too (compared above)
+
+
+# ------------------------------------------------------------------ the fused decode kernel (k_decode)
+def test_fused_decode_kernel_equals_the_oracle_on_random_captures(sora, torch_cuda, oracle):
+    """sora_rx_set_fused(1): symbol waves feeding trellis waves through an LDS ring inside one kernel.  Same rows as the oracle,
+    and as the split path, on random captures: all rates (so frames of different modulation share a trellis wave), lengths,
+    noise up to failure, several frames per capture, truncation, pure noise."""
+    from gpu_util import random_capture
+    rng = np.random.default_rng(20261001)
+    for mhz in (20, 40):
+        caps = [random_capture(oracle, rng, mhz) for _ in range(200)]
+        want = oracle_results(oracle, caps, mhz)
+        got = run_rx(sora, torch_cuda, caps, mhz, max_frames=8, fused=1)
+        ok, why = same_results(got, want)
+        assert ok, (mhz, why)
+        ok, why = same_results(run_rx(sora, torch_cuda, caps, mhz, max_frames=8, fused=0), want)
+        assert ok, (mhz, why)
+
+
+def test_fused_decode_kernel_on_lengths_rates_and_odd_lists(sora, torch_cuda, oracle):
+    """Every rate at lengths around the window schedule's corners, list sizes 1..5 per code rate (the last frame of an odd list
+    runs alone in its trellis wave), frames of very different length sharing a wave."""
+    caps = []
+    for i, rate in enumerate(RATES):
+        for j, ln in enumerate((1, 5, 29, 30, 31, 33, 100, 257, 1024, 1500, 2304)[: 3 + (i % 5) * 2]):
+            caps.append(make_capture(oracle, rate, ln, seed=3000 + 20 * i + j, rate_mhz=20, sigma=60 + 15 * j, tail=160)[0])
+    want = oracle_results(oracle, caps, 20)
+    ok, why = same_results(run_rx(sora, torch_cuda, caps, 20, max_frames=2, fused=1), want)
+    assert ok, why
+    for n in (1, 2, 3):                                               # a single frame, a single pair, an odd list
+        ok, why = same_results(run_rx(sora, torch_cuda, caps[:n], 20, max_frames=2, fused=1), oracle_results(oracle, caps[:n], 20))
+        assert ok, (n, why)
+
+
+def test_fused_decode_kernel_full_batch_equals_the_reference_graph(sora, torch_cuda, oracle):
+    """The bench workload (BASELINE configs[2], 4096 x 1500 B at 54 Mbps) through k_decode, every capture against the compiled reference graph."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from oracle.pyoracle import ReferenceGraph
+    if not ReferenceGraph().available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    nfr = bench.FRAMES_PER_GPU
+    iq, descs, _ = bench.make_workload(oracle, nfr, seed0=0)
+    rx = sora.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+    assert rx.set_fused(1) == 0 and rx.set_fused(-1) == 1
+    d = torch_cuda.from_numpy(iq).cuda(); dd = sora.Rx.captures(descs)
+    tickets = [rx.process_dev(d, dd) for _ in range(3)]              # three calls in flight on the fused path
+    kind, want = bench.reference_rows(iq, nfr, oracle)
+    for t in tickets:
+        ok, why = bench.check_against_reference(rx.results(ticket=t), kind, want, range(nfr))
+        assert ok, why
+    rx.close()
