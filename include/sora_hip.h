@@ -292,12 +292,12 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
 /* ------------------------------------------------------------------------------------------------
  * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
  * MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76) over a batch of independent 44 MHz captures: TDCRemove,
- * TEnergyDetect / TDCEstimator, TSymTiming, TBarkerSync, TBB11bDespread, TSFDSync, TDBPSKDemap / TDQPSKDemap, TDesc741,
- * TBB11bPlcpParser, TBB11bFrameSink.  cfg->sample_rate_mhz must be 44; capture lengths are whole 28-sample bursts.
+ * TEnergyDetect / TDCEstimator, TSymTiming, TBarkerSync, TBB11bDespread, TSFDSync, TDBPSKDemap / TDQPSKDemap,
+ * TCCK5P5Decoder / TCCK11Decoder (kernel/bb/Brick11/src/cck.hpp), TDesc741, TBB11bPlcpParser, TBB11bFrameSink.  cfg->sample_rate_mhz must be 44; capture lengths are whole 28-sample bursts.
  * Result rows: end_sample = CF_MemSamples::mem_sample_index() when the harness sees the event (44 MHz samples);
  * error_code also takes SORA_E_SFD_FAIL / SORA_E_SFD_TIMEOUT / SORA_E_SYNC_TIMEOUT; crc32 = the reference's FCS word (three
- * FCS bytes and one stale buffer byte, PHY_11b.hpp:725-731); start_sample, nsym and cfo_est are 0.  Long preamble, 1 Mbps
- * DBPSK and 2 Mbps DQPSK payloads; a header announcing 5.5 / 11 Mbps (CCK) ends the frame with SORA_E_NOT_SUPPORTED.
+ * FCS bytes and one stale buffer byte, PHY_11b.hpp:725-731); start_sample, nsym and cfo_est are 0.  Long preamble; 1 Mbps
+ * DBPSK, 2 Mbps DQPSK, 5.5 and 11 Mbps CCK payloads (all four rates of the reference graph).
  * ------------------------------------------------------------------------------------------------ */
 #define SORA_E_NOT_SUPPORTED     ((int)0x80000003)
 #define SORA_E_SFD_FAIL          ((int)0x80000004)

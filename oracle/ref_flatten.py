@@ -26,6 +26,25 @@ for f in glob.glob(f"{REF}/inc/bb/*.h"):
     shutil.copy(f, OUT + "/bb/" + os.path.basename(f))
 
 
+# ---- the Windows integer model (LLP64): the keyword `long` is 32 bits for the compiler the reference was written for, 64 here.
+#      The typedef'd spellings (ULONG, ulong, LONG) come from ref_compat.h; the literal keyword is respelt in the scratch copy
+#      (`long long` stays).  It matters: demap_dqpsk_bits (soradsp.h:190-198) computes `(UCHAR)((unsigned long)(re+im) >> 31) << pos`,
+#      which is 1 << pos with a 32-bit long and 0xFF << pos with a 64-bit one -- the CCK decoders (cck.hpp) decode garbage otherwise.
+_LONG = re.compile(r"(?<![A-Za-z0-9_])long(?![A-Za-z0-9_])")
+def llp64(text):
+    out = []
+    for line in text.split("\n"):
+        if "long" in line and "long long" not in line and not line.lstrip().startswith(("//", "*", "/*")):
+            line = _LONG.sub("int", line)
+        out.append(line)
+    return "\n".join(out)
+for f in sorted(glob.glob(OUT + "/*.h") + glob.glob(OUT + "/*.hpp") + glob.glob(OUT + "/bb/*.h")):
+    s = open(f, encoding="latin-1").read()
+    t = llp64(s)
+    if t != s:
+        with open(f, "w", encoding="latin-1") as fh:
+            fh.write(t)
+
 def write(name, text, mode="w"):
     with open(OUT + "/" + name, mode, encoding="latin-1") as fh:
         fh.write(text)

@@ -3,17 +3,19 @@
  *                                        +-> TSymTiming -> TBarkerSync -> TBB11bRxRateSel -+-> despread -> TSFDSync
  *                                                                                          +-> despread -> TDBPSKDemap -+
  *                                                                                          +-> despread -> TDQPSKDemap -+-> TDesc741 ->
+ *                                                                                          +-> TCCK5P5Decoder ----------+
+ *                                                                                          +-> TCCK11Decoder -----------+
  *   TBB11bPlcpSwitch -+-> TBB11bPlcpParser
  *                     +-> TBB11bFrameSink
  * (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76),
- * 44 MHz samples in, long preamble, 1 Mbps DBPSK and 2 Mbps DQPSK payloads.  Every pin queue, Flush (pad + process) and
+ * 44 MHz samples in, long preamble, 1 Mbps DBPSK, 2 Mbps DQPSK, 5.5 and 11 Mbps CCK payloads.  Every pin queue, Flush (pad + process) and
  * Reset of the brick framework is emulated as such, because what a frame leaves behind (CF_DifferentialDemap::last_symbol,
  * CF_Descramber::byte_reg, the DC estimate) is what the next frame starts from.
  * Pinned by the reference's own graph compiled from its sources (oracle/_ref/libsora_refgraph.so: ref_rx11b_capture),
  * tests/test_oracle_11b.py.
- * NOT restated: the 5.5 / 11 Mbps CCK decoders (cck.hpp).  A header that announces one of those rates ends the frame here
- * with SO_E_NOT_SUPPORTED; the reference goes on into its CCK branch (which does not decode its own modulator's output in
- * this build).  Such frames are outside the parity claim. */
+ * The 5.5 / 11 Mbps payloads go through TCCK5P5Decoder / TCCK11Decoder (kernel/bb/Brick11/src/cck.hpp:9-207, 209-763), restated
+ * below hypothesis by hypothesis with the reference's 32-bit arithmetic, its comparison order (ties!) and its own DQPSK helper
+ * (core/inc/soradsp.h:190-198 -- which, unlike the one in barkerspread.hpp, halves re/im first). */
 #include <stdlib.h>
 #include <string.h>
 #include "so_internal.h"
@@ -42,6 +44,8 @@ typedef struct {
     int sync_flag, last_peak_cnt, m_max, search_count; so_c16 partial[11];
     /* ---- TBB11bRxRateSel.opin0..2 -> TBB11bDespread (1 -> 11) */
     so_c16 chipq[3][11]; int chipq_n[3];
+    /* ---- TBB11bRxRateSel.opin3 -> TCCK5P5Decoder (1 -> 16), .opin4 -> TCCK11Decoder (1 -> 8; is_even is brick state, cleared by Reset) */
+    so_c16 cckq[16]; int cckq_n; int cck_even;
     /* ---- TSFDSync (sfd_sync.hpp:10-134) */
     int bit_one_found; uint16_t word; int bit_err_cnt; uint32_t sync_cnt;
     /* ---- despread -> TDBPSKDemap (1 -> 8), despread -> TDQPSKDemap (1 -> 4) */
@@ -103,7 +107,6 @@ static void plcp_parser(rx11b_t* s, const uint8_t h[6])               /* TBB11bP
     case 11000: s->rxrate_state = RATE_11M; break;
     }
     s->plcp_data = 1;
-    if (s->rxrate_state == RATE_5P5M || s->rxrate_state == RATE_11M) s->error_code = SO_E_NOT_SUPPORTED;   /* see the header of this file */
 }
 
 static void plcp_switch(rx11b_t* s, uint8_t b)                         /* TBB11bPlcpSwitch (PHY_11b.hpp:459-519) */
@@ -192,6 +195,101 @@ static so_c16 despread(const so_c16 c[11])
     return so_c(so_w16(re[0] + re[1] + re[2] + re[3]), so_w16(im[0] + im[1] + im[2] + im[3]));
 }
 
+
+/* ------------------------------------------------------------------ CCK (cck.hpp) */
+typedef struct { int32_t re, im; } c32_t;
+static inline c32_t c32(int32_t re, int32_t im) { c32_t r; r.re = re; r.im = im; return r; }
+static inline c32_t c32_add(c32_t a, c32_t b) { return c32(so_w32((int64_t)a.re + b.re), so_w32((int64_t)a.im + b.im)); }
+static inline c32_t c32_sra2(c32_t a) { return c32(a.re >> 2, a.im >> 2); }                       /* shift_right(vci, 2) */
+static inline c32_t c32_rot(c32_t a, int k)                              /* a * j^k, exact (components come from int16 sums) */
+{ switch (k & 3) { case 0: return a; case 1: return c32(-a.im, a.re); case 2: return c32(-a.re, -a.im); default: return c32(a.im, -a.re); } }
+static inline c32_t c32_of(so_c16 a) { return c32(a.re, a.im); }
+static inline int32_t neg32(int32_t a) { return so_w32(-(int64_t)a); }
+
+/* The four partial sums of one phi2 hypothesis, phi2 = m * pi/2 (r = (-j)^m):
+ *   A1 = P1 + r P0, A2 = r P2 - P3, A3 = P5 + r P4, A4 = P7 - r P6
+ * -- cck.hpp:268-275 (m = 0), 392-399 (m = 1), 514-521 (m = 2), 635-642 (m = 3), and the two hypotheses of the 5.5 Mbps decoder
+ * (m = 1: cck.hpp:81-88, m = 3: 103-110). */
+static void cck_partial(const so_c16 P[8], int m, c32_t A[4])
+{
+    const int k = (4 - m) & 3;                                           /* r = j^k */
+    A[0] = c32_add(c32_of(P[1]), c32_rot(c32_of(P[0]), k));
+    A[1] = c32_add(c32_rot(c32_of(P[2]), k), c32_rot(c32_of(P[3]), 2));
+    A[2] = c32_add(c32_of(P[5]), c32_rot(c32_of(P[4]), k));
+    A[3] = c32_add(c32_of(P[7]), c32_rot(c32_of(P[6]), k + 2));
+}
+
+/* One "Module" of CCK11_DECODER (e.g. cck.hpp:277-390): the four phi3 hypotheses L1..L4 = conj((A2 + q A1) >> 2) * ((A4 + q A3) >> 2),
+ * q = 1, j, -1, -j with value bits 0x00, 0x30, 0x10, 0x20; per L the larger of |re|, |im| picks phi4; then the reference's comparison tree. */
+static void cck11_module(const c32_t A[4], int32_t* max_out, uint8_t* val_out)
+{
+    static const int     q_of[4]   = { 0, 1, 2, 3 };
+    static const uint8_t base_of[4] = { 0x00, 0x30, 0x10, 0x20 };
+    int32_t M[4]; uint8_t V[4];
+    for (int s = 0; s < 4; s++) {
+        const c32_t bx = c32_sra2(c32_add(A[1], c32_rot(A[0], q_of[s]))), by = c32_sra2(c32_add(A[3], c32_rot(A[2], q_of[s])));
+        const int32_t lre = so_w32((int64_t)so_w32((int64_t)bx.re * by.re) + so_w32((int64_t)bx.im * by.im));
+        const int32_t lim = so_w32((int64_t)so_w32((int64_t)bx.re * by.im) - so_w32((int64_t)bx.im * by.re));
+        const int32_t a1 = lre < 0 ? neg32(lre) : lre, a2 = lim < 0 ? neg32(lim) : lim;
+        if (a1 > a2) { if (lre > 0) { M[s] = lre; V[s] = base_of[s] | 0x00; } else { M[s] = neg32(lre); V[s] = base_of[s] | 0x40; } }
+        else         { if (lim > 0) { M[s] = lim; V[s] = base_of[s] | 0xC0; } else { M[s] = neg32(lim); V[s] = base_of[s] | 0x80; } }
+    }
+    int32_t mm; uint8_t vv;
+    if (M[0] > M[1]) { mm = M[0]; vv = V[0]; } else { mm = M[1]; vv = V[1]; }
+    if (M[2] > M[3]) { if (M[2] > mm) { mm = M[2]; vv = V[2]; } } else { if (M[3] > mm) { mm = M[3]; vv = V[3]; } }
+    *max_out = mm; *val_out = vv;
+}
+
+static inline void cck_dqpsk_bits(uint8_t* r, int pos, so_c16 ref, so_c16 x)                    /* demap_dqpsk_bits, core/inc/soradsp.h:190-198 */
+{
+    int32_t re = so_w32((int64_t)ref.re * x.re + (int64_t)ref.im * x.im), im = so_w32((int64_t)ref.re * x.im - (int64_t)ref.im * x.re);
+    re >>= 1; im >>= 1;
+    *r |= (uint8_t)(((uint32_t)so_w32((int64_t)re + im) >> 31) << pos);
+    *r |= (uint8_t)(((uint32_t)so_w32((int64_t)re - im) >> 31) << (pos + 1));
+}
+
+static uint8_t cck11_decode(rx11b_t* s, const so_c16 P[8])             /* TCCK11Decoder::CCK11_DECODER (cck.hpp:255-763) */
+{
+    c32_t A[4]; int32_t m1, m2, m34; uint8_t v1, v2, v34, out;
+    cck_partial(P, 0, A); cck11_module(A, &m1, &v1);
+    cck_partial(P, 1, A); cck11_module(A, &m2, &v2); v2 |= 0x08;
+    if (m1 > m2) { cck_partial(P, 3, A); cck11_module(A, &m34, &v34); v34 |= 0x0C; out = m1 > m34 ? v1 : v34; }       /* "lable4" */
+    else         { cck_partial(P, 2, A); cck11_module(A, &m34, &v34); v34 |= 0x04; out = m2 > m34 ? v2 : v34; }
+    cck_dqpsk_bits(&out, 0, s->last_symbol, P[7]);
+    out ^= (uint8_t)((s->cck_even << 1) | s->cck_even);
+    s->cck_even ^= 1;
+    s->last_symbol = P[7];
+    return out;
+}
+
+/* One half byte of TCCK5P5Decoder (cck.hpp:70-206): phi2 = pi/2 against 3pi/2 with phi3 = 0; only Re of
+ * ((-conj-ish B0) >> 2) * (B1 >> 2) is looked at -- the imaginary part of B0 is negated BEFORE the shift. */
+static int32_t cck5_metric(const so_c16 P[8], int m, int* neg)
+{
+    c32_t A[4]; cck_partial(P, m, A);
+    c32_t b0 = c32_add(A[0], A[1]), b1 = c32_add(A[2], A[3]);
+    b0.im = neg32(b0.im);
+    b0 = c32_sra2(b0); b1 = c32_sra2(b1);
+    const int32_t lre = so_w32((int64_t)so_w32((int64_t)b0.re * b1.re) - so_w32((int64_t)b0.im * b1.im));
+    *neg = !(lre > 0);
+    return lre > 0 ? lre : neg32(lre);
+}
+
+static uint8_t cck5p5_decode(rx11b_t* s, const so_c16 P[16])           /* TCCK5P5Decoder::Process: b_isEven is a local, so every byte is even + odd */
+{
+    uint8_t out = 0;
+    for (int half = 0; half < 2; half++) {
+        const so_c16* Q = P + 8 * half; int n1, n2;
+        const int32_t max1 = cck5_metric(Q, 1, &n1), max2 = cck5_metric(Q, 3, &n2);
+        const uint8_t nib = max1 > max2 ? (uint8_t)(n1 ? 0x08 : 0x00) : (uint8_t)(n2 ? 0x0C : 0x04);
+        if (half == 0) out = nib; else out |= (uint8_t)(nib << 4);
+        cck_dqpsk_bits(&out, 4 * half, s->last_symbol, Q[7]);
+        if (half == 1) out ^= 0x30;
+        s->last_symbol = Q[7];
+    }
+    return out;
+}
+
 static void symbol_out(rx11b_t* s, int port, so_c16 sym)               /* what follows each despreader */
 {
     if (port == 0) sfd_sync(s, sym);
@@ -202,7 +300,12 @@ static void symbol_out(rx11b_t* s, int port, so_c16 sym)               /* what f
 static void rate_sel(rx11b_t* s, so_c16 chip)                          /* TBB11bRxRateSel::Process (PHY_11b.hpp:421-452) */
 {
     const int port = s->rxrate_state;
-    if (port > RATE_2M) return;                                         /* CCK branches: not restated */
+    if (port > RATE_2M) {                                               /* opin3 / opin4 -> the CCK decoders -> TDesc741 */
+        const int need = port == RATE_5P5M ? 16 : 8;
+        s->cckq[s->cckq_n++] = chip;
+        if (s->cckq_n == need) { s->cckq_n = 0; desc741(s, port == RATE_5P5M ? cck5p5_decode(s, s->cckq) : cck11_decode(s, s->cckq)); }
+        return;
+    }
     s->chipq[port][s->chipq_n[port]++] = chip;
     if (s->chipq_n[port] == 11) { s->chipq_n[port] = 0; symbol_out(s, port, despread(s->chipq[port])); }
 }
@@ -316,6 +419,11 @@ static void graph_flush(rx11b_t* s)
         memset(s->chipq[port] + s->chipq_n[port], 0, (size_t)(11 - s->chipq_n[port]) * sizeof(so_c16)); s->chipq_n[port] = 0;
         symbol_out(s, port, despread(s->chipq[port]));
     }
+    if (port > RATE_2M && s->cckq_n > 0) {                              /* opin3/4().pad(); Next3/4()->Process(): one more byte out of zero chips */
+        const int need = port == RATE_5P5M ? 16 : 8;
+        memset(s->cckq + s->cckq_n, 0, (size_t)(need - s->cckq_n) * sizeof(so_c16)); s->cckq_n = 0;
+        desc741(s, port == RATE_5P5M ? cck5p5_decode(s, s->cckq) : cck11_decode(s, s->cckq));
+    }
 }
 
 static void graph_reset(rx11b_t* s)                                    /* BB11bDemodCtx.reset() + pRxSource->Reset() (fb11b_demod.cpp:68-70) */
@@ -326,7 +434,7 @@ static void graph_reset(rx11b_t* s)                                    /* BB11bD
     /* stq (the switch's port towards TSymTiming) is NOT cleared: the switch's Reset only forwards (PHY_11b.hpp:336-339) */
     s->m_index = 2; s->m_frag = 0;                                                                 /* TSymTiming::_init */
     s->sync_flag = NO_PEAK_FOUND; s->last_peak_cnt = -1; s->m_max = 0; s->search_count = 0; memset(s->partial, 0, sizeof(s->partial));
-    memset(s->chipq_n, 0, sizeof(s->chipq_n));
+    memset(s->chipq_n, 0, sizeof(s->chipq_n)); s->cckq_n = 0; s->cck_even = 0;
     s->bit_one_found = 0; s->word = 0; s->bit_err_cnt = 0; s->sync_cnt = 0;
     s->symq1_n = s->symq2_n = 0; s->hdrq_n = 0;
     s->crc32 = 0xFFFFFFFFu; s->byte_count = 0;
@@ -369,7 +477,7 @@ int so_rx11b_capture(const so_c16* iq, uint32_t nsamples, so_frame_result* res, 
                 }
             }
             if (err == SO_E_FRAME_OK || err == SO_E_CRC32_FAIL) {       /* "jump advance of the last CRC byte" (fb11b_demod.cpp:47-63) */
-                uint32_t off = s->data_rate_kbps == 1000 ? 8 * 11 * 4 : s->data_rate_kbps == 2000 ? 4 * 11 * 4 : 0;
+                uint32_t off = s->data_rate_kbps == 1000 ? 8 * 11 * 4 : s->data_rate_kbps == 2000 ? 4 * 11 * 4 : s->data_rate_kbps == 5500 ? 8 * 2 * 4 : s->data_rate_kbps == 11000 ? 8 * 1 * 4 : 0;
                 off = (off + 3) / 4 * 4; if (off > remain) off = remain;
                 pos += off; remain -= off;
             }

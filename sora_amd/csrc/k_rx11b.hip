@@ -1,9 +1,10 @@
-// k_rx11b.hip -- the 802.11b receive graph for gfx950: 44 MHz samples in, long preamble, 1 Mbps DBPSK
-// and 2 Mbps DQPSK payloads.  Reference: CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
+// k_rx11b.hip -- the 802.11b receive graph for gfx950: 44 MHz samples in, long preamble, 1 Mbps DBPSK,
+// 2 Mbps DQPSK, 5.5 and 11 Mbps CCK payloads.  Reference: CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
 // MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76):
 //   src -> TDCRemove -> TBB11bRxSwitch -+-> TEnergyDetect -> TDCEstimator                                  (carrier sense)
 //                                        +-> TSymTiming -> TBarkerSync -> TBB11bRxRateSel -> TBB11bDespread ->
 //       TSFDSync | TDBPSKDemap | TDQPSKDemap -> TDesc741 -> TBB11bPlcpSwitch -> TBB11bPlcpParser | TBB11bFrameSink
+//                                                         TBB11bRxRateSel -> TCCK5P5Decoder | TCCK11Decoder -> TDesc741 (kernel/bb/Brick11/src/cck.hpp)
 //
 // Mapping: one wavefront per capture (captures are independent; a capture is one serial state machine because the
 // early-late symbol timing, the Barker alignment and the differential demapper all carry state from sample to sample).
@@ -15,8 +16,10 @@
 // end up in the reported FCS word and last MPDU byte) lives in LDS, 4 KiB per wave.
 // HBM: 4 B per input sample read once; results are a few bytes per frame.  Bound: latency of the serial chain per
 // capture, hidden by running 16 captures per CU.
-// Not implemented (as in oracle/so_rx11b.c): the CCK decoders; a header announcing 5.5/11 Mbps ends the frame with
-// SORA_E_NOT_SUPPORTED.
+// CCK: the chips of a block stay one per lane and are appended to a per-wave chip queue held in a register (lane j = j-th queued
+// chip).  A code word is decoded across 16 lanes: lane 4m+s evaluates the hypothesis phi2 = m pi/2, phi3 = s-th of (0, pi/2, pi, 3pi/2)
+// -- the reference's three "modules" of four correlations each (cck.hpp:268-745) are the quads of that grid -- and the reference's
+// comparison tree (ties included) runs as two quad_perm exchanges plus four scalar compares.  phi4 and the DQPSK bits are scalar.
 #include "kernels.h"
 
 namespace sora {
@@ -37,7 +40,7 @@ __device__ __forceinline__ uint32_t dot_sign(int rre, int rim, int xre, int xim)
 { return ((uint32_t)(rre * xre) + (uint32_t)(rim * xim)) >> 31; }
 }  // namespace
 
-__global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
+__global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
 {
     __shared__ uint8_t s_out_all[4][kOutBuf];
     __shared__ int s_state_all[4][32];                                  // per wave: [0..19] TBarkerSync partial sums, [20..27] TEnergyDetect window
@@ -69,6 +72,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
     int m_index = 2, m_frag = 0;                                                          // TSymTiming
     int sync_flag = NO_PEAK_FOUND, last_peak_cnt = -1, m_max = 0, search_count = 0;      // TBarkerSync
     int chip_n = 0, acc_re = 0, acc_im = 0;                                               // the current port's despreader
+    int cck_n = 0; uint32_t cck_even = 0; uint32_t cbuf = 0;                              // TCCK5P5Decoder / TCCK11Decoder: queued chips (lane j = j-th chip, packed), is_even
     int bit_one_found = 0; uint32_t word = 0; int bit_err_cnt = 0; uint32_t sync_cnt = 0; // TSFDSync
     int sym_n = 0; uint32_t sym_byte = 0; int ref_re = 0, ref_im = 0;                     // TDBPSKDemap / TDQPSKDemap burst in progress
     int hdr_n = 0; uint32_t hdr_lo = 0, hdr_hi = 0;                                       // TBB11bPlcpParser's 6-byte burst
@@ -83,7 +87,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
         m_index = 2; m_frag = 0;
         sync_flag = NO_PEAK_FOUND; last_peak_cnt = -1; m_max = 0; search_count = 0;
         lds_order(); if (lane < 32) p_re[lane] = 0; lds_order();
-        chip_n = 0; acc_re = acc_im = 0;
+        chip_n = 0; acc_re = acc_im = 0; cck_n = 0; cck_even = 0;
         bit_one_found = 0; word = 0; bit_err_cnt = 0; sync_cnt = 0;
         sym_n = 0; sym_byte = 0; hdr_n = 0; hdr_lo = hdr_hi = 0;
         byte_count = 0; crc32 = 0xFFFFFFFFu;
@@ -128,7 +132,6 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
         default:   rate_kbps = 0; len = 0;
         }
         frame_length = len; plcp_data = 1;
-        if (uni(rxrate) > RATE_2M) error_code = E_NOT_SUPPORTED;             // CCK branches (cck.hpp) are not implemented
     };
     // ---- TDesc741 (scramble.hpp:93-170) -> TBB11bPlcpSwitch (PHY_11b.hpp:459-519)
     auto byte_out = [&](uint32_t b) __attribute__((always_inline)) {
@@ -146,6 +149,92 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
             hdr_lo |= hdr_n < 4 ? sh : 0u; hdr_hi |= hdr_n < 4 ? 0u : sh;
             if (++hdr_n == 6) { plcp_parser(); hdr_n = 0; hdr_lo = hdr_hi = 0; }
         } else frame_sink(o);
+    };
+    // ---- TCCK11Decoder / TCCK5P5Decoder (cck.hpp): one code word = the chips in lanes 0..7 of `w` (packed COMPLEX16), wave-uniform result.
+    // Lane 4m+s (m, s = 0..3): r = (-j)^m, q = j^s;  A1 = P1 + r P0, A2 = r P2 - P3, A3 = P5 + r P4, A4 = P7 - r P6;
+    // Bx = (A2 + q A1) >> 2, By = (A4 + q A3) >> 2;  L = conj(Bx) By  (cck.hpp:268-303 and its three repetitions).
+    struct CckLane { int lre, lim, l5; };
+    auto cck_correlate = [&](uint32_t w, int first) __attribute__((always_inline)) {
+        int pre[8], pim[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const int v = lane_of((int)w, first + i); pre[i] = (int)(short)v; pim[i] = v >> 16; }
+        const int k = (4 - (lane >> 2)) & 3, sq = lane & 3;
+        auto rot = [](int re, int im, int kk, int& ore, int& oim) __attribute__((always_inline)) {     // (re + j im) * j^kk, exact in 32 bits
+            const int xr = (kk & 1) ? im : re, xi = (kk & 1) ? re : im;
+            ore = ((kk + 1) & 2) ? -xr : xr; oim = (kk & 2) ? -xi : xi;
+        };
+        int t_re, t_im, a1r, a1i, a2r, a2i, a3r, a3i, a4r, a4i;
+        rot(pre[0], pim[0], k, t_re, t_im); a1r = pre[1] + t_re; a1i = pim[1] + t_im;
+        rot(pre[2], pim[2], k, t_re, t_im); a2r = t_re - pre[3]; a2i = t_im - pim[3];
+        rot(pre[4], pim[4], k, t_re, t_im); a3r = pre[5] + t_re; a3i = pim[5] + t_im;
+        rot(pre[6], pim[6], k, t_re, t_im); a4r = pre[7] - t_re; a4i = pim[7] - t_im;
+        rot(a1r, a1i, sq, t_re, t_im); const int bxr0 = a2r + t_re, bxi0 = a2i + t_im;
+        rot(a3r, a3i, sq, t_re, t_im); const int byr0 = a4r + t_re, byi0 = a4i + t_im;
+        const int bxr = bxr0 >> 2, bxi = bxi0 >> 2, byr = byr0 >> 2, byi = byi0 >> 2;
+        CckLane o;
+        o.lre = (int)((uint32_t)(bxr * byr) + (uint32_t)(bxi * byi));
+        o.lim = (int)((uint32_t)(bxr * byi) - (uint32_t)(bxi * byr));
+        o.l5  = (int)((uint32_t)(bxr * byr) - (uint32_t)(((-bxi0) >> 2) * byi));     // 5.5 Mbps: B[0].im is negated BEFORE the shift (cck.hpp:94-98)
+        return o;
+    };
+    auto cck_dqpsk = [&](int pos, int xre, int xim) __attribute__((always_inline)) {                   // demap_dqpsk_bits (core/inc/soradsp.h:190-198): halves first
+        const int re = (int)((uint32_t)(last_re * xre) + (uint32_t)(last_im * xim)) >> 1, im = (int)((uint32_t)(last_re * xim) - (uint32_t)(last_im * xre)) >> 1;
+        return ((((uint32_t)re + (uint32_t)im) >> 31) << pos) | ((((uint32_t)re - (uint32_t)im) >> 31) << (pos + 1));
+    };
+    auto cck11_decode = [&](uint32_t w) __attribute__((always_inline)) {                               // CCK11_DECODER (cck.hpp:255-763)
+        const CckLane c = cck_correlate(w, 0);
+        const int a1 = c.lre < 0 ? -c.lre : c.lre, a2 = c.lim < 0 ? -c.lim : c.lim;                   // (wrapping negation, as the reference's)
+        const int sq = lane & 3;
+        const uint32_t base = sq == 0 ? 0x00u : sq == 1 ? 0x30u : sq == 2 ? 0x10u : 0x20u;
+        int M; uint32_t V;
+        if (a1 > a2) { M = c.lre > 0 ? c.lre : -c.lre; V = base | (c.lre > 0 ? 0x00u : 0x40u); }
+        else         { M = c.lim > 0 ? c.lim : -c.lim; V = base | (c.lim > 0 ? 0xC0u : 0x80u); }
+        {   // "if (Max1 > Max2) 1 else 2", "if (Max3 > Max4) 3 else 4": the even lane keeps its own only when strictly larger
+            const int oM = dpp<0xB1>(M); const uint32_t oV = (uint32_t)dpp<0xB1>((int)V);
+            const bool other = (lane & 1) ? (oM > M) : !(M > oM);
+            M = other ? oM : M; V = other ? oV : V;
+        }
+        {   // "if (Max34 > Module) Module = Max34": the pair (3,4) replaces the pair (1,2) only when strictly larger
+            const int oM = dpp<0x4E>(M); const uint32_t oV = (uint32_t)dpp<0x4E>((int)V);
+            const bool other = (lane & 2) ? !(M > oM) : (oM > M);
+            M = other ? oM : M; V = other ? oV : V;
+        }
+        const int m1 = lane_of(M, 0), m2 = lane_of(M, 4), m3 = lane_of(M, 8), m4 = lane_of(M, 12);
+        const uint32_t v1 = (uint32_t)lane_of((int)V, 0), v2 = (uint32_t)lane_of((int)V, 4) | 0x08u, v3 = (uint32_t)lane_of((int)V, 8) | 0x04u, v4 = (uint32_t)lane_of((int)V, 12) | 0x0Cu;
+        uint32_t out = m1 > m2 ? (m1 > m4 ? v1 : v4) : (m2 > m3 ? v2 : v3);                          // "lable4" tests 3pi/2 against module 1, else pi against module 2
+        const int p7 = lane_of((int)w, 7); const int xre = (int)(short)p7, xim = p7 >> 16;
+        out |= cck_dqpsk(0, xre, xim);
+        out ^= (cck_even << 1) | cck_even; cck_even ^= 1u;
+        last_re = xre; last_im = xim;
+        return out & 0xFFu;
+    };
+    auto cck5p5_decode = [&](uint32_t w) __attribute__((always_inline)) {                              // TCCK5P5Decoder: even + odd half byte (cck.hpp:26-46, 70-206)
+        uint32_t out = 0;
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const CckLane c = cck_correlate(w, 8 * half);
+            const int l1 = lane_of(c.l5, 4), l2 = lane_of(c.l5, 12);                                  // phi2 = pi/2 and 3pi/2, phi3 = 0
+            const int max1 = l1 > 0 ? l1 : -l1, max2 = l2 > 0 ? l2 : -l2;
+            const uint32_t nib = max1 > max2 ? (l1 > 0 ? 0x0u : 0x8u) : (l2 > 0 ? 0x4u : 0xCu);
+            out |= nib << (4 * half);
+            const int p7 = lane_of((int)w, 8 * half + 7); const int xre = (int)(short)p7, xim = p7 >> 16;
+            out |= cck_dqpsk(4 * half, xre, xim);
+            last_re = xre; last_im = xim;
+        }
+        return (out ^ 0x30u) & 0xFFu;
+    };
+    // ---- TBB11bRxRateSel ports 3 / 4: chips k0 .. k0+n-1 of the block (lane k = chip k, packed) join the queue; a full burst is decoded
+    auto cck_push = [&](uint32_t chips, int k0, int n) __attribute__((always_inline)) {
+        const uint32_t moved = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane - cck_n + k0) & 63), (int)chips);
+        if (lane >= cck_n && lane < cck_n + n) cbuf = moved;
+        cck_n += n;
+        const int need = uni(rxrate) == RATE_5P5M ? 16 : 8;
+        if (cck_n >= need) {
+            const uint32_t b = need == 8 ? cck11_decode(cbuf) : cck5p5_decode(cbuf);
+            cbuf = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane + need) & 63), (int)cbuf);
+            cck_n -= need;
+            byte_out(b);
+        }
     };
     // ---- one despread symbol into the brick the rate selector's port leads to
     auto symbol_out = [&](int port, int sre, int sim) __attribute__((always_inline)) {
@@ -180,8 +269,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
     // ---- TBarkerSync (symtiming.hpp:229-313) -> TBB11bRxRateSel -> TBB11bDespread::QuickBarkerDespread (barkerspread.hpp:277-303)
     auto chip_in = [&](int cre, int cim) __attribute__((always_inline)) {
         if (sync_flag == BARKER_SYNCED) {
-            if (uni(rxrate) > RATE_2M) return;
-            const int port = uni(rxrate);
+            const int port = uni(rxrate);                               // (a CCK rate never gets here: its blocks take the lane-parallel path of sym_timing)
             int tre, tim;
             if (chip_n == 1 || chip_n == 4) { tre = neg16(cre) >> 4; tim = neg16(cim) >> 4; }          // negated before the shift
             else { tre = cre >> 4; tim = cim >> 4; if (chip_n >= 8) { tre = -tre; tim = -tim; } }       // chips 8..10 subtracted after it
@@ -219,7 +307,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
     auto sym_timing = [&](uint32_t braw) __attribute__((always_inline)) {
         const cpx bu = unpack(braw);
         const int bre = w16(bu.re - dc_re), bim = w16(bu.im - dc_im);      // TDCRemove (dc.hpp:6-38): the estimate is frozen while demodulating
-        if (sync_flag == BARKER_SYNCED && uni(rxrate) <= RATE_2M) {          // (uni: see the note at rxrate's declaration)
+        if (sync_flag == BARKER_SYNCED) {
             // Decimation + rate selector + despreader for the whole block at once: chip k of the block in lane k.  A block
             // yields 6..8 chips and a symbol takes 11, so at most one symbol ends inside it; every operation of the
             // despreader is a wrapping add, so the two partial sums (before / after that boundary) are lane reductions.
@@ -229,6 +317,8 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
             const cpx cu = unpack((uint32_t)__shfl((int)braw, at));
             const int cre = w16(cu.re - dc_re), cim = w16(cu.im - dc_im);
             if (mi < 0) m_index += 4;
+            if (uni(rxrate) > RATE_2M) cck_push(pack(mk(cre, cim)), 0, cnt);     // (uni: see the note at rxrate's declaration)
+            else {
             int c = chip_n + lane; const bool first = c < 11; if (!first) c -= 11;
             int tre, tim;
             if (c == 1 || c == 4) { tre = neg16(cre) >> 4; tim = neg16(cim) >> 4; }
@@ -240,7 +330,13 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
                 const int port = uni(rxrate), sre = w16(acc_re + a_re), sim = w16(acc_im + a_im);
                 acc_re = w16(b_re); acc_im = w16(b_im); chip_n = chip_n + cnt - 11;
                 symbol_out(port, sre, sim);
+                if (uni(rxrate) > RATE_2M) {                            // the header has just announced a CCK rate: the chips after the symbol boundary are the first of the payload
+                    const int k0 = cnt - chip_n, n = chip_n;
+                    chip_n = 0; acc_re = acc_im = 0;
+                    cck_push(pack(mk(cre, cim)), k0, n);
+                }
             } else { acc_re = w16(acc_re + a_re); acc_im = w16(acc_im + a_im); chip_n += cnt; }
+            }
         } else {
             int idx = m_index;
             while (idx < 28) {                                          // Decimation: every 4th sample from the current phase
@@ -296,7 +392,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
         // that live across the event handling below (3342 values of this kernel count as divergent without these lines, 614
         // with them -- the genuinely per-lane ones; tools/min_uniform_set.py found the smallest set that is needed).
 #define U(v) v = (decltype(v))uni((int)v)
-        U(last_re); U(last_im); U(byte_reg); U(frame_length); U(rate_kbps); U(frame_crc32); U(ref_re); U(ref_im); U(qoff);
+        U(last_re); U(last_im); U(byte_reg); U(frame_length); U(rate_kbps); U(frame_crc32); U(ref_re); U(ref_im); U(qoff); U(cck_n); U(cck_even);
 #undef U
         // ---- TMemSamples::Process (memsource.hpp:87-114)
         const bool ret = remain != 0;
@@ -340,7 +436,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
                 // Steady state (aligned to the Barker code, no event pending, whole calls that follow one another): further source
                 // calls are taken right here.  Same semantics as going round the outer loop -- MAC11b_Receive only looks at
                 // error_code after a call -- but in a loop of its own the compiler keeps just this phase's state in registers.
-                while (error_code == 0 && sync_flag == BARKER_SYNCED && uni(rxrate) <= RATE_2M && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
+                while (error_code == 0 && sync_flag == BARKER_SYNCED && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
                     p_start = c_start; p_take = 28; p_stale = c_stale;
                     c_stale = c_start; c_start = pos; pos += 28; remain -= 28;
                     const uint32_t base = c_start - (uint32_t)qoff;
@@ -365,7 +461,7 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
                 nfr++;
             }
             if (err == E_FRAME_OK || err == E_CRC32_FAIL) {             // "jump advance of the last CRC byte": Seek (memsource.hpp:116-150)
-                uint32_t off = rate_kbps == 1000 ? 8 * 11 * 4 : rate_kbps == 2000 ? 4 * 11 * 4 : 0;
+                uint32_t off = rate_kbps == 1000 ? 8 * 11 * 4 : rate_kbps == 2000 ? 4 * 11 * 4 : rate_kbps == 5500 ? 8 * 2 * 4 : rate_kbps == 11000 ? 8 * 1 * 4 : 0;
                 off = min(off, remain); pos += off; remain -= off;
             }
             // pRxSource->Flush(): what is queued is padded with zero samples and pushed through (brick.h FlushPort);
@@ -377,6 +473,10 @@ __global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A)
                     sym_timing(padded); qoff = 0;
                 }
                 if (uni(rxrate) <= RATE_2M && chip_n > 0) { const int sre = acc_re, sim = acc_im; chip_n = 0; acc_re = acc_im = 0; symbol_out(uni(rxrate), sre, sim); }
+                if (uni(rxrate) > RATE_2M && cck_n > 0) {               // opin3/4().pad(): zero chips complete the burst, one more byte comes out
+                    const uint32_t w = lane < cck_n ? cbuf : 0u; cck_n = 0;
+                    byte_out(uni(rxrate) == RATE_5P5M ? cck5p5_decode(w) : cck11_decode(w));
+                }
             }
             graph_reset();
             continue;                                                   // the routine returns and is called again: rc is not looked at

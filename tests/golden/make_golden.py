@@ -14,6 +14,7 @@
                          modulation graph (CreateModGraph11a_40M) emits for a list of frames.
   refgraph_11b.npz       802.11b: the reference modulator's output (COMPLEX8 @44 MHz) for six 1/2 Mbps frames and the events
                          its receive graph reports for captures made of them (tests/test_oracle_11b.channel_11b).
+  refgraph_11b_cck.npz   the same for six 5.5 / 11 Mbps CCK frames (`python make_golden.py 11b_cck` writes only this file).
   ref_vectors_11n.npz    802.11n stage bricks: inputs and what the reference's own T11nDemap* / T11nDeinterleave*_S{0,1} bricks make of them.
 All files travel to the GPU box; /root/reference does not.
 """
@@ -33,7 +34,36 @@ REF = os.environ.get("SORA_REFERENCE", "/root/reference")
 OUT = os.path.dirname(os.path.abspath(__file__))
 
 
+def record_11b(G, name, cases, seed):
+    """What the reference's 11b modulation graph emits for `cases` = [(rate_kbps, mpdu_bytes)], and what its receive graph reports
+    for the captures tests/test_oracle_11b.channel_11b makes of them."""
+    from test_oracle_11b import channel_11b
+    b = {"frames": len(cases)}; evs = {"count": [], "error": [], "position": [], "rate": [], "length": [], "crc": []}
+    rng = np.random.default_rng(seed)
+    for f, (rate, ln) in enumerate(cases):
+        s8 = G.tx11b(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), rate)
+        b["tx_%d" % f] = s8
+        for rep in range(3):
+            ev = G.rx11b(channel_11b(s8, 100 * f + rep))
+            evs["count"].append(len(ev))
+            for e in ev:
+                b["mpdu_%d" % len(evs["error"])] = np.frombuffer(e["mpdu"], np.uint8)
+                evs["error"].append(e["error_code"]); evs["position"].append(e["sample_index"]); evs["rate"].append(e["rate_kbps"])
+                evs["length"].append(e["length"]); evs["crc"].append(e["crc32"])
+    np.savez_compressed(os.path.join(OUT, name), ev_count=np.array(evs["count"], np.int32),
+                        ev_error=np.array(evs["error"], np.uint32), ev_position=np.array(evs["position"], np.uint32),
+                        ev_rate=np.array(evs["rate"], np.uint32), ev_length=np.array(evs["length"], np.uint32),
+                        ev_crc=np.array(evs["crc"], np.uint32), **b)
+
+
+CCK_CASES = [(5500, 1), (5500, 30), (5500, 200), (11000, 2), (11000, 77), (11000, 400)]
+
+
 def main():
+    if sys.argv[1:] == ["11b_cck"]:
+        G = ReferenceGraph(); assert G.available()
+        record_11b(G, "refgraph_11b_cck.npz", CCK_CASES, 1103)
+        return
     O = Oracle(); R = Reference()
     assert R.available(), "build oracle/_ref first (oracle/build_ref.sh)"
     dump = os.path.join(REF, "kernel", "test-data", "fsample-6.dmp")
@@ -106,23 +136,8 @@ def main():
                         ev_mpdu_sha=np.stack(ev["sha"]))
     # 802.11b: what the reference's modulation graph emits for a few frames, and what its receive graph reports for the
     # captures tests/test_oracle_11b.channel_11b makes of them
-    from test_oracle_11b import channel_11b
-    b = {"frames": 6}; evs = {"count": [], "error": [], "position": [], "rate": [], "length": [], "crc": []}
-    rng = np.random.default_rng(1102)
-    for f, (rate, ln) in enumerate([(1000, 1), (1000, 14), (1000, 40), (2000, 5), (2000, 60), (2000, 200)]):
-        s8 = G.tx11b(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), rate)
-        b["tx_%d" % f] = s8
-        for rep in range(3):
-            ev = G.rx11b(channel_11b(s8, 100 * f + rep))
-            evs["count"].append(len(ev))
-            for e in ev:
-                b["mpdu_%d" % len(evs["error"])] = np.frombuffer(e["mpdu"], np.uint8)
-                evs["error"].append(e["error_code"]); evs["position"].append(e["sample_index"]); evs["rate"].append(e["rate_kbps"])
-                evs["length"].append(e["length"]); evs["crc"].append(e["crc32"])
-    np.savez_compressed(os.path.join(OUT, "refgraph_11b.npz"), ev_count=np.array(evs["count"], np.int32),
-                        ev_error=np.array(evs["error"], np.uint32), ev_position=np.array(evs["position"], np.uint32),
-                        ev_rate=np.array(evs["rate"], np.uint32), ev_length=np.array(evs["length"], np.uint32),
-                        ev_crc=np.array(evs["crc"], np.uint32), **b)
+    record_11b(G, "refgraph_11b.npz", [(1000, 1), (1000, 14), (1000, 40), (2000, 5), (2000, 60), (2000, 200)], 1102)
+    record_11b(G, "refgraph_11b_cck.npz", CCK_CASES, 1103)
     # 802.11n stage bricks: one burst each through the reference's own T11nDemap* / T11nDeinterleave*_S{0,1}
     rng = np.random.default_rng(1111)
     n11 = {}

@@ -145,7 +145,7 @@ def same_as_reference_graph(rows, ref_events, position=None):
 
 
 def random_capture_11b(graph, rng):
-    """A random 44 MHz capture for the 802.11b receive graph: 1-3 frames of the REFERENCE's own modulator (1 or 2 Mbps,
+    """A random 44 MHz capture for the 802.11b receive graph: 1-3 frames of the REFERENCE's own modulator (1, 2, 5.5 or 11 Mbps,
     long preamble; graph = oracle.pyoracle.ReferenceGraph) with gaps, gain, DC offset, a small carrier offset, noise,
     sometimes truncated, sometimes noise only."""
     kind = rng.integers(0, 10)
@@ -154,7 +154,7 @@ def random_capture_11b(graph, rng):
         return np.rint(rng.normal(0, rng.choice([30, 300, 3000]), (n, 2))).astype(np.int16)
     parts = []
     for _ in range(int(rng.choice([1, 1, 1, 2, 3]))):
-        rate = int(rng.choice([1000, 2000])); ln = int(rng.choice([1, 5, 14, 20, 60, 150, 400]))
+        rate = int(rng.choice([1000, 2000, 5500, 11000])); ln = int(rng.choice([1, 5, 14, 20, 60, 150, 400]))
         s8 = graph.tx11b(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), rate)
         x = np.zeros((int(rng.integers(0, 3000)) + len(s8) + int(rng.choice([400, 1600, 2800, 6000])), 2), np.int16)
         lead = len(x) - len(s8) - int(rng.choice([400, 1600, 2800, 6000][:1])) if False else int(rng.integers(0, len(x) - len(s8) + 1))

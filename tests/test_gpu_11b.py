@@ -36,9 +36,10 @@ def oracle_rows(oracle, c):
     return [dict(r, sample_index=r["end_sample"]) for r in rows]
 
 
-def test_gpu_11b_equals_recorded_reference_events(sora, oracle):
+@pytest.mark.parametrize("fixture", ["refgraph_11b.npz", "refgraph_11b_cck.npz"])
+def test_gpu_11b_equals_recorded_reference_events(sora, oracle, fixture):
     from test_oracle_11b import channel_11b
-    z = np.load(os.path.join(GOLD, "refgraph_11b.npz"))
+    z = np.load(os.path.join(GOLD, fixture))
     caps = [channel_11b(z["tx_%d" % f], 100 * f + rep) for f in range(int(z["frames"])) for rep in range(3)]
     got = run_11b(sora, caps)
     k = 0
@@ -62,7 +63,7 @@ def test_gpu_11b_equals_reference_graph_and_oracle_on_random_captures(sora, orac
     rng = np.random.default_rng(1111)
     caps = [random_capture_11b(g, rng) for _ in range(400)]
     got = run_11b(sora, caps, max_frames=64)
-    nev = nok = 0
+    nev = nok = ncck = 0
     for i, c in enumerate(caps):
         rows = [r for r in got if r["capture_id"] == i]
         ev = g.rx11b(c, max_frames=64)
@@ -70,8 +71,8 @@ def test_gpu_11b_equals_reference_graph_and_oracle_on_random_captures(sora, orac
         assert ok, "capture %d vs the reference graph: %s" % (i, why)
         ok, why = same_as_reference_11b(rows, oracle_rows(oracle, c))
         assert ok, "capture %d vs oracle/so_rx11b.c: %s" % (i, why)
-        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev)
-    assert nev > 1000 and nok > 300
+        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev); ncck += sum(e["error_code"] == 1 and e["rate_kbps"] > 2000 for e in ev)
+    assert nev > 1000 and nok > 300 and ncck > 100                      # all four rates decode, the CCK ones included
 
 
 def test_11b_capacity_and_argument_errors(sora):

@@ -34,18 +34,19 @@ def test_oracle_11b_equals_reference_graph_on_random_captures(o, seed):
     if not g.available():
         pytest.skip("oracle/_ref/libsora_refgraph.so not built (needs the reference tree)")
     rng = np.random.default_rng(seed)
-    nev = nok = 0
+    nev = nok = ncck = 0
     for i in range(400):
         c = random_capture_11b(g, rng)
         ev = g.rx11b(c)
         ok, why = same_as_reference_11b(o.rx11b_capture(c), ev)
         assert ok, "seed %d capture %d: %s" % (seed, i, why)
-        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev)
-    assert nev > 1000 and nok > 300
+        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev); ncck += sum(e["error_code"] == 1 and e["rate_kbps"] > 2000 for e in ev)
+    assert nev > 1000 and nok > 300 and ncck > 100
 
 
-def test_oracle_11b_equals_recorded_reference_events(o):
-    z = np.load(os.path.join(GOLD, "refgraph_11b.npz"))
+@pytest.mark.parametrize("fixture", ["refgraph_11b.npz", "refgraph_11b_cck.npz"])
+def test_oracle_11b_equals_recorded_reference_events(o, fixture):
+    z = np.load(os.path.join(GOLD, fixture))
     k = 0
     for f in range(int(z["frames"])):
         for rep in range(3):

@@ -134,10 +134,12 @@ def test_oracle_transmitter_equals_recorded_reference_samples(o):
 def test_reference_11b_brick_path_runs_on_the_cpu(graph):
     """BASELINE configs[0] (plumbing, no GPU): the reference's own 802.11b BRICK receive path (CreateDemodGraph,
     fb11bdemod_config.hpp:122-172, driven as MAC11b_Receive does) decodes what the reference's own modulation graph
-    (fb11bmod_config.hpp:28-50) emits: 1 Mbps DBPSK and 2 Mbps DQPSK, long preamble, 44 MHz samples, with noise.
-    (The 5.5/11 Mbps CCK branches parse the header but do not loop back in this build; not investigated.)"""
+    (fb11bmod_config.hpp:28-50) emits: 1 Mbps DBPSK, 2 Mbps DQPSK, 5.5 and 11 Mbps CCK, long preamble, 44 MHz samples, with noise.
+    (The CCK branches only loop back when the build has the reference's integer model: demap_dqpsk_bits, core/inc/soradsp.h:190-198,
+    shifts an `unsigned long` by 31 -- one bit with the 32-bit long the code was written for, 0xFF.. with an LP64 long.  oracle/ref_flatten.py
+    respells the keyword in the scratch copy; this test is what pins that.)"""
     rng = np.random.default_rng(802)
-    for rate in (1000, 2000):
+    for rate in (1000, 2000, 5500, 11000):
         for ln in (14, 300, 1500):
             mp = rng.integers(0, 256, ln).astype(np.uint8).tobytes()
             s8 = graph.tx11b(mp, rate)
