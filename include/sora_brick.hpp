@@ -158,6 +158,142 @@ private:
     size_t produced_ = 0;
 };
 
+// ------------------------------------------------------------------------------------------------
+// The remaining stage bricks.  They all have the shape spelt out above (peek / append / call / pop / Next()->Process), so they are
+// one template: IPORT IT x IB -> OPORT OT x OB with the C entry point supplied as a callable `int(const IT*, OT*, void* stream)`.
+template <class IT, size_t IB, class OT, size_t OB, class CALL, class T_CTX, class T_NEXT>
+class THipStage : public HipFilter<T_CTX, T_NEXT> {
+public:
+    using iport_traits = port_traits<IT, IB>;
+    using oport_traits = port_traits<OT, OB>;
+    THipStage(T_CTX& ctx, T_NEXT* next, OT* d_out, CALL call, void* stream = nullptr)
+        : HipFilter<T_CTX, T_NEXT>(ctx, next, stream), opin_(d_out), call_(call) {}
+    template <class T_IPIN> bool Process(T_IPIN& ipin)
+    {
+        while (ipin.check_read()) {
+            OT* out = opin_.append();
+            if (!this->raise(call_(ipin.peek(), out, this->stream_))) return false;
+            ipin.pop();
+            if (this->next_ && !this->next_->Process(opin_)) return false;
+        }
+        return true;
+    }
+    DevicePin<OT, OB>& opin() { return opin_; }
+private:
+    DevicePin<OT, OB> opin_; CALL call_;
+};
+
+// FFT<128> (core/inc/fft_r4dif.h): IPORT COMPLEX16 x 128 -> OPORT COMPLEX16 x 128, N transforms per burst.
+struct CallFFT128 { size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_fft128(in, out, n, st); } };
+template <size_t N, class T_CTX, class T_NEXT>
+struct THipFFT128 : THipStage<sora_complex16, 128 * N, sora_complex16, 128 * N, CallFFT128, T_CTX, T_NEXT> {
+    THipFFT128(T_CTX& ctx, T_NEXT* next, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 128 * N, sora_complex16, 128 * N, CallFFT128, T_CTX, T_NEXT>(ctx, next, d_out, CallFFT128{ N }, stream) {}
+};
+
+// T11aLTS (channel_11a.hpp:33-230): IPORT COMPLEX16 x 144.  The reference brick is a sink that fills the context facades
+// CF_CFOffset / CF_FreqCompensate / CF_Channel_11a; here they are the device record `d_ctx` (sora_lts11a_ctx) the later bricks are bound to.
+template <class T_CTX>
+class THip11aLTS {
+public:
+    using iport_traits = port_traits<sora_complex16, 144>;
+    THip11aLTS(T_CTX& ctx, sora_lts11a_ctx* d_ctx, void* stream = nullptr) : ctx_(ctx), d_ctx_(d_ctx), stream_(stream) {}
+    void Reset() {}
+    void Flush() {}
+    template <class T_IPIN> bool Process(T_IPIN& ipin)
+    {
+        while (ipin.check_read()) {
+            const int rc = sora_hip_lts11a(ipin.peek(), d_ctx_, 1, stream_);
+            if (rc != SORA_OK) { ctx_.error_code = (uint32_t)rc; return false; }
+            ipin.pop();
+        }
+        return true;
+    }
+private:
+    T_CTX& ctx_; sora_lts11a_ctx* d_ctx_; void* stream_;
+};
+
+// T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization (PHY_11a.hpp:361-430, channel_11a.hpp:532-653) as one brick:
+// IPORT COMPLEX16 x 80 -> OPORT COMPLEX16 x 64, N symbols per burst, bound to the frame's T11aLTS record.
+struct CallSymFront11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_symfront11a(in, d_ctx, nullptr, out, n, st); } };
+template <size_t N, class T_CTX, class T_NEXT>
+struct THip11aSymFront : THipStage<sora_complex16, 80 * N, sora_complex16, 64 * N, CallSymFront11a, T_CTX, T_NEXT> {
+    THip11aSymFront(T_CTX& ctx, T_NEXT* next, const sora_lts11a_ctx* d_ctx, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 80 * N, sora_complex16, 64 * N, CallSymFront11a, T_CTX, T_NEXT>(ctx, next, d_out, CallSymFront11a{ d_ctx, N }, stream) {}
+};
+
+// TPhaseCompensate -> TPilotTrack (freqoffset.hpp:14-66, pilot.hpp:121-269): IPORT COMPLEX16 x 64 -> OPORT COMPLEX16 x 64, N symbols of ONE
+// frame per burst; CF_PhaseCompensate / CF_PilotTrack live in `d_state` and carry over from burst to burst.  d_first / d_nsym: device words
+// holding 0 and N (the C entry point takes frame tables).
+struct CallPilotTrack11a {
+    const uint32_t* d_first; const uint32_t* d_nsym; sora_track11a_state* d_state;
+    int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_pilot_track11a(in, d_first, d_nsym, d_state, out, 1, st); }
+};
+template <size_t N, class T_CTX, class T_NEXT>
+struct THip11aPilotTrack : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallPilotTrack11a, T_CTX, T_NEXT> {
+    THip11aPilotTrack(T_CTX& ctx, T_NEXT* next, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallPilotTrack11a, T_CTX, T_NEXT>(ctx, next, d_out, CallPilotTrack11a{ d_first, d_nsym, d_state }, stream) {}
+};
+
+// T11aViterbi<5000*8,48,256,24> (viterbi.hpp:103-237): IPORT uchar x 48*N_BPSC (one symbol's soft values) -> OPORT uchar x frame_length + 2.
+// Like the reference brick it consumes symbol bursts and knows the frame from the context (SetFrame = CF_11aRxVector: length, code rate,
+// symbols); the trellis is run when the last symbol has arrived.  d_frame: device scratch of nsym x 48*N_BPSC soft values + 16 bytes of tables.
+template <int N_BPSC, class T_CTX, class T_NEXT>
+class THip11aViterbi : public HipFilter<T_CTX, T_NEXT> {
+public:
+    using iport_traits = port_traits<uint8_t, 48 * N_BPSC>;
+    THip11aViterbi(T_CTX& ctx, T_NEXT* next, uint8_t* d_frame, uint8_t* d_out, void* stream = nullptr)
+        : HipFilter<T_CTX, T_NEXT>(ctx, next, stream), d_soft_(d_frame + 16), d_tab_(d_frame), d_out_(d_out) {}
+    void SetFrame(uint16_t frame_length, int code_rate, uint32_t nsym) { len_ = frame_length; cr_ = code_rate; nsym_ = nsym; got_ = 0; }
+    void Reset() { got_ = 0; HipFilter<T_CTX, T_NEXT>::Reset(); }
+    template <class T_IPIN> bool Process(T_IPIN& ipin)
+    {
+        while (ipin.check_read()) {
+            if (got_ < nsym_ && sora_hip_memcpy_d2d(d_soft_ + (size_t)got_ * 48 * N_BPSC, ipin.peek(), 48 * N_BPSC, this->stream_) != SORA_OK) return this->raise(SORA_ERR_HARDWARE_FAILED);
+            ipin.pop();
+            if (++got_ == nsym_) {
+                const uint32_t tab[4] = { 0u, nsym_ * 48u * (uint32_t)N_BPSC, (uint32_t)len_, 0u };   // soft_off, nsoft, frame_len (uint16), out_off
+                if (sora_hip_memcpy_h2d(d_tab_, tab, sizeof(tab)) != SORA_OK) return this->raise(SORA_ERR_HARDWARE_FAILED);
+                const uint32_t* t = reinterpret_cast<const uint32_t*>(d_tab_);
+                if (!this->raise(sora_hip_viterbi11a(d_soft_, t, t + 1, reinterpret_cast<const uint16_t*>(t + 2), cr_, d_out_, t + 3, 1, this->stream_))) return false;
+                decoded_ = true;
+            }
+        }
+        return true;
+    }
+    bool decoded() const { return decoded_; }
+    const uint8_t* output() const { return d_out_; }
+private:
+    uint8_t* d_soft_; uint8_t* d_tab_; uint8_t* d_out_;
+    uint16_t len_ = 0; int cr_ = 0; uint32_t nsym_ = 0, got_ = 0; bool decoded_ = false;
+};
+
+// 802.11n stage bricks (one burst = N symbols / frames), each forwarding to its entry point:
+//   T11nDemap* (demapper11n.hpp:89-309), T11nDeinterleave*_S0/_S1 (deinterleaver_11n.hpp), TMimoChannelComp (channel_11n.hpp:445-521)
+struct CallDemap11n { int nb; size_t n; int operator()(const sora_complex16* in, uint8_t* out, void* st) const { return sora_hip_demap11n(in, out, nb, n, st); } };
+template <int N_BPSC, size_t N, class T_CTX, class T_NEXT>
+struct THip11nDemap : THipStage<sora_complex16, 64 * N, uint8_t, 52 * N_BPSC * N, CallDemap11n, T_CTX, T_NEXT> {
+    THip11nDemap(T_CTX& ctx, T_NEXT* next, uint8_t* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 64 * N, uint8_t, 52 * N_BPSC * N, CallDemap11n, T_CTX, T_NEXT>(ctx, next, d_out, CallDemap11n{ N_BPSC, N }, stream) {}
+};
+struct CallDeint11n { int nb, ss; size_t n; int operator()(const uint8_t* in, uint8_t* out, void* st) const { return sora_hip_deinterleave11n(in, out, nb, ss, n, st); } };
+template <int N_BPSC, int SPATIAL_STREAM, size_t N, class T_CTX, class T_NEXT>
+struct THip11nDeinterleave : THipStage<uint8_t, 52 * N_BPSC * N, uint8_t, 52 * N_BPSC * N, CallDeint11n, T_CTX, T_NEXT> {
+    THip11nDeinterleave(T_CTX& ctx, T_NEXT* next, uint8_t* d_out, void* stream = nullptr)
+        : THipStage<uint8_t, 52 * N_BPSC * N, uint8_t, 52 * N_BPSC * N, CallDeint11n, T_CTX, T_NEXT>(ctx, next, d_out, CallDeint11n{ N_BPSC, SPATIAL_STREAM, N }, stream) {}
+};
+// TMimoChannelComp: NSTREAM = 2 ports in the reference (two RX chains in, two spatial streams out); here the two streams are the two halves of
+// one burst: IPORT COMPLEX16 x 2 x 64N (chain 0 symbols, then chain 1) -> OPORT COMPLEX16 x 2 x 64N (stream 0, then stream 1).
+struct CallMimoComp11n {
+    const sora_complex16* d_hinv; size_t n;
+    int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_mimo_comp11n(d_hinv, nullptr, in, in + 64 * n, out, out + 64 * n, n, st); }
+};
+template <size_t N, class T_CTX, class T_NEXT>
+struct THip11nMimoComp : THipStage<sora_complex16, 128 * N, sora_complex16, 128 * N, CallMimoComp11n, T_CTX, T_NEXT> {
+    THip11nMimoComp(T_CTX& ctx, T_NEXT* next, const sora_complex16* d_hinv, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 128 * N, sora_complex16, 128 * N, CallMimoComp11n, T_CTX, T_NEXT>(ctx, next, d_out, CallMimoComp11n{ d_hinv, N }, stream) {}
+};
+
 // ISource over a batch of captures = the whole demod graph behind one handle (brick.h:343-353: Process/Seek/Reset/Flush).
 class THipRx11aSource {
 public:

@@ -290,6 +290,33 @@ int   sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const so
 int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------
+ * Multi-GPU sharding for a C host.  Captures are independent -- the reference resets its context per
+ * frame (kernel/bb/demod11/fb11ademod_config.hpp:68-95) and RxThread walks one dump at a time (fb11a_demod.cpp:29-81) -- so
+ * rank r of W runs sora_rx_* on its own block of captures in its own HBM (sora_shard_partition) and nothing is exchanged on
+ * the data path.  These calls are the result exchange: ncclAllGather of the dense 36-byte result rows and of the per-rank row
+ * counts, ncclAllReduce(sum) of counters, on RCCL over xGMI, one process per GPU.  The 128-byte id is made on rank 0 and
+ * carried to the other ranks by the host (file, socket, MPI ...).  RCCL is loaded on the first sora_shard_* call.
+ *   sora_shard_gather_rows     device buffers, asynchronous on `stream`: d_rows must hold max_rows_per_rank rows (rows past
+ *                              *d_nrows are padding), d_all_rows world x max_rows_per_rank rows, d_all_counts world counts
+ *   sora_shard_gather_results  convenience for sora_rx_t: the rows of a finished process call (ticket, or 0 = the most recent)
+ *                              of every rank, compacted in rank order into h_all_rows (world x max_rows_per_rank rows of room),
+ *                              h_counts[world], *n_total; blocks until done.  capture_id is the caller's own numbering, so a
+ *                              host that numbers captures globally gets a table it can use as it is.
+ * ------------------------------------------------------------------------------------------------ */
+#define SORA_SHARD_ID_BYTES 128
+typedef struct sora_shard sora_shard_t;
+int  sora_shard_unique_id(uint8_t id[SORA_SHARD_ID_BYTES]);
+int  sora_shard_create(const uint8_t id[SORA_SHARD_ID_BYTES], int world_size, int rank, int device, sora_shard_t** out);
+void sora_shard_destroy(sora_shard_t* sh);
+int  sora_shard_world(const sora_shard_t* sh, int* world_size, int* rank);
+void sora_shard_partition(size_t n_items, int world_size, int rank, size_t* first, size_t* count);
+int  sora_shard_gather_rows(sora_shard_t* sh, const sora_frame_result* d_rows, const uint32_t* d_nrows, size_t max_rows_per_rank,
+                            sora_frame_result* d_all_rows, uint32_t* d_all_counts, void* stream);
+int  sora_shard_reduce_counters(sora_shard_t* sh, uint64_t* d_counters, size_t n, void* stream);
+int  sora_shard_gather_results(sora_shard_t* sh, sora_rx_t* rx, int ticket, size_t max_rows_per_rank,
+                               sora_frame_result* h_all_rows, uint32_t* h_counts, size_t* n_total);
+
+/* ------------------------------------------------------------------------------------------------
  * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
  * MAC11b_Receive (kernel/bb/demod11/fb11b_demod.cpp:27-76) over a batch of independent 44 MHz captures: TDCRemove,
  * TEnergyDetect / TDCEstimator, TSymTiming, TBarkerSync, TBB11bDespread, TSFDSync, TDBPSKDemap / TDQPSKDemap,
@@ -319,6 +346,7 @@ void* sora_hip_malloc(size_t bytes);
 void  sora_hip_free(void* d_ptr);
 int   sora_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);
 int   sora_hip_memcpy_d2h(void* h_dst, const void* d_src, size_t bytes);
+int   sora_hip_memcpy_d2d(void* d_dst, const void* d_src, size_t bytes, void* stream);   /* asynchronous on `stream` */
 /* page-locked host memory (the target of asynchronous result delivery) */
 void* sora_hip_host_alloc(size_t bytes);
 void  sora_hip_host_free(void* h_ptr);

@@ -12,7 +12,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsora_hip.so")
-SOURCES = ["k_scan.hip", "k_rx.hip", "k_decode.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "sora_hip.cpp"]
+SOURCES = ["k_scan.hip", "k_rx.hip", "k_decode.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "sora_hip.cpp", "sora_shard.cpp"]
 HEADERS = ["dev_arith.h", "dev_viterbi.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip"]
 
@@ -72,7 +72,7 @@ def build(force=False, verbose=False):
 
     with ThreadPoolExecutor(max_workers=min(8, max(1, len(todo)))) as ex:
         list(ex.map(compile_one, todo))
-    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-o", LIB]
+    cmd = [cc, "--offload-arch=gfx950", "-shared", "-fPIC"] + [_obj(s) for s in SOURCES] + ["-ldl", "-o", LIB]
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)

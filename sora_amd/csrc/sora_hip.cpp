@@ -336,6 +336,7 @@ void  sora_hip_free(void* p) { if (p) (void)hipFree(p); }
 int   sora_hip_memcpy_h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return SORA_OK; }
 int   sora_hip_stream_synchronize(void* stream) { HIPCHK(hipStreamSynchronize((hipStream_t)stream)); return SORA_OK; }
 int   sora_hip_memcpy_d2h(void* h, const void* d, size_t n) { HIPCHK(hipMemcpy(h, d, n, hipMemcpyDeviceToHost)); return SORA_OK; }
+int   sora_hip_memcpy_d2d(void* dd, const void* ds, size_t n, void* stream) { HIPCHK(hipMemcpyAsync(dd, ds, n, hipMemcpyDeviceToDevice, (hipStream_t)stream)); return SORA_OK; }
 void* sora_hip_host_alloc(size_t bytes) { void* p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 void  sora_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 

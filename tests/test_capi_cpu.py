@@ -75,7 +75,7 @@ def test_c_host_example_compiles():
     out = os.path.join(ROOT, "examples", "_build")
     os.makedirs(out, exist_ok=True)
     libdir = os.path.dirname(sora_amd.lib_path())
-    for name in ("demod11a", "demod11b", "demod11n"):
+    for name in ("demod11a", "demod11b", "demod11n", "shard11a"):
         src = os.path.join(ROOT, "examples", name + ".c")
         r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-L", libdir,
                             "-lsora_hip", "-Wl,-rpath," + libdir, "-Wl,--allow-shlib-undefined", "-o", os.path.join(out, name)],
@@ -116,6 +116,14 @@ int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, ui
     THipRx11nSource rx11n(ctx, cfg);
     rx11n.Bind(d_in, d_fft, &cap, 1);
     ok = ok && (rx11n.handle() == nullptr || rx11n.Process());
+    // the 802.11n stage bricks and FFT<128>
+    THip11nDeinterleave<4, 1, 8, CF_Error, TDrop<CF_Error>> d11n(ctx, &drop, d_de);
+    THip11nDemap<4, 8, CF_Error, decltype(d11n)> m11n(ctx, &d11n, d_soft);
+    THip11nMimoComp<4, CF_Error, TDrop<CF_Error>> zf(ctx, &drop, d_in, d_fft);
+    THipFFT128<8, CF_Error, TDrop<CF_Error>> f128(ctx, &drop, d_fft);
+    DevicePin<sora_complex16, 64 * 8> p64(d_in); p64.append(); ok = ok && m11n.Process(p64);
+    DevicePin<sora_complex16, 128 * 4> p2(d_in); p2.append(); ok = ok && zf.Process(p2);
+    DevicePin<sora_complex16, 128 * 8> p128(d_in); p128.append(); ok = ok && f128.Process(p128);
     return ok ? 0 : (int)ctx.error_code;
 }
 """)
@@ -123,3 +131,7 @@ int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, ui
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), str(src)],
                        capture_output=True, text=True)
     assert r.returncode == 0, r.stderr
+    for chain in ("brick_chain.cpp", "frame_chain.cpp"):                   # the graphs tests/test_gpu_hosts.py executes on the GPU box
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", chain)],
+                           capture_output=True, text=True)
+        assert r.returncode == 0, r.stderr

@@ -96,3 +96,63 @@ def test_brick_adapter_chain_runs_on_the_gpu(tmp_path, oracle, nb):
     for i in range(n):
         want = oracle.deinterleave(nb, oracle.demap(nb, oracle.fft(x[i], 64)))
         assert np.array_equal(got[i], want), i
+
+
+@pytest.mark.parametrize("rate", [6000, 24000, 48000, 54000])
+def test_brick_graph_decodes_a_whole_frame_on_the_gpu(tmp_path, oracle, rate):
+    """tests/cxx/frame_chain.cpp: T11aLTS, then per symbol T11aDataSymbol..TChannelEqualization -> TPilotTrack -> T11aDemap<N> ->
+    T11aDeinterleave<N> -> T11aViterbi as BRICK adapters (one symbol per Process(), like the reference's bricks), with the timing and RX
+    vector the oracle's receiver found.  What the Viterbi brick emits descrambles to the transmitted MPDU with a good FCS."""
+    from gpu_util import awgn
+    from oracle.pyoracle import rate_params
+    exe = build("g++", "-std=c++17", os.path.join(ROOT, "tests", "cxx", "frame_chain.cpp"), "frame_chain")
+    rng = np.random.default_rng(rate)
+    mp = rng.integers(0, 256, 333).astype(np.uint8).tobytes()
+    cap = awgn(oracle.tx_capture(mp, rate, lead=40), 200, rate)[::2].copy()
+    res = oracle.rx_capture(cap, 20)
+    assert len(res) == 1 and res[0]["error_code"] == 1
+    nb, cr, _ = rate_params(rate)
+    fin = tmp_path / "cap.bin"; fout = tmp_path / "dec.bin"; fin.write_bytes(cap.tobytes())
+    out = run([exe, str(fin), str(res[0]["start_sample"]), str(res[0]["nsym"]), str(nb), str(cr), str(res[0]["length"]), str(fout)])
+    assert "%d symbols" % res[0]["nsym"] in out
+    dec = np.frombuffer(fout.read_bytes(), np.uint8)
+    e, mpdu, crc = oracle.desc_sink(dec, res[0]["length"])
+    assert e == 1 and mpdu.tobytes()[:len(mp)] == mp and crc == res[0]["crc32"]
+
+
+def test_c_host_shards_captures_and_gathers_over_rccl(tmp_path, golden_dir):
+    """examples/shard11a.c: the C-level multi-GPU entry points (sora_shard_*: partition, ncclAllGather of the result rows over
+    RCCL).  This box has one GPU, so the world is one rank -- the collectives run all the same; the 8-GPU run is the same
+    command once per rank."""
+    exe = build("gcc", "-std=c11", os.path.join(ROOT, "examples", "shard11a.c"), "shard11a")
+    iq = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8
+    dump = tmp_path / "fsample6.dmp"; dump.write_bytes(make_dump(iq, raw14=True))
+    out = run([exe, str(dump), "--raw14", "--rate", "40", "--captures", "5", "--world", "1", "--rank", "0", "--id-file", str(tmp_path / "sora.id")])
+    assert "world 1: 5 captures, 5 frames gathered (5), good 5 / bad 0" in out and "6000 kbps length 1392 FCS 80ef9b11, last: capture 4" in out, out
+
+
+def test_shard_api_from_python_matches_results(golden_dir):
+    """sora_shard_gather_results through the binding (world of one): the gathered table is sora_rx_results' table."""
+    import ctypes
+    import torch
+    import sora_amd
+    from sora_amd.capi import FrameResult
+    L = sora_amd.load()
+    iq = (np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8)
+    n = len(iq) // 28 * 28
+    rx = sora_amd.Rx(3, 3 * n, sample_rate_mhz=40, max_frames_per_capture=4)
+    d = torch.from_numpy(np.concatenate([iq[:n]] * 3)).cuda()
+    rx.process_dev(d, [(0, n, 10), (n, n, 11), (2 * n, n, 12)])
+    want = rx.results(with_mpdu=False)
+    ident = (ctypes.c_uint8 * 128)(); assert L.sora_shard_unique_id(ident) == 0
+    sh = ctypes.c_void_p(); assert L.sora_shard_create(ident, 1, 0, 0, ctypes.byref(sh)) == 0, L.sora_hip_last_error()
+    rows = (FrameResult * 12)(); counts = (ctypes.c_uint32 * 1)(); total = ctypes.c_size_t(0)
+    assert L.sora_shard_gather_results(sh, rx._h, 0, 12, rows, counts, ctypes.byref(total)) == 0, L.sora_hip_last_error()
+    assert total.value == len(want) == 3 and counts[0] == 3
+    for r, w in zip(rows, want):
+        assert (r.capture_id, r.end_sample, r.error_code, r.rate_kbps, r.length, r.crc32) == (w["capture_id"], w["end_sample"], w["error_code"], w["rate_kbps"], w["length"], w["crc32"])
+    first = ctypes.c_size_t(); cnt = ctypes.c_size_t(); got = []
+    for r in range(3):
+        L.sora_shard_partition(256, 3, r, ctypes.byref(first), ctypes.byref(cnt)); got.append((first.value, cnt.value))
+    assert got == [(0, 86), (86, 85), (171, 85)]
+    L.sora_shard_destroy(sh); rx.close()
