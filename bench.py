@@ -354,6 +354,10 @@ def bench_11n(torch, sora_amd, dev, ncaps=8192, reps=5):
     torch.cuda.synchronize()
     rx.process_dev(f0, f1, descs); res = rx.results()
     ok = sum(r["error_code"] == 1 for r in res)
+    for _ in range(3):                                                       # (the first calls after a result read-back are slower: warm up, then time)
+        rx.process_dev(f0, f1, descs)
+    rx.synchronize()
+    reps = max(reps, 20)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
         rx.process_dev(f0, f1, descs)
@@ -452,6 +456,7 @@ def main():
     ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
+    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11n) and print its object: for profiling that section alone")
     args = ap.parse_args()
 
     import torch
@@ -468,6 +473,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
+    if args.only:
+        sections = {"stages": lambda: bench_stages(torch, sora_amd, dev), "ingest": lambda: bench_ingest(torch, sora_amd, dev), "tx": lambda: bench_tx(torch, sora_amd),
+                    "rx11b": lambda: bench_11b(torch, sora_amd, dev), "rx11n": lambda: bench_11n(torch, sora_amd, dev)}
+        print(json.dumps({args.only: sections[args.only]()}))
+        return
     oracle = Oracle()
     nfr = args.frames
     MAXF = 2

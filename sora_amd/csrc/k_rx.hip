@@ -173,7 +173,9 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
 // oldest decisions, newest in bit 0 (s' = d << 5 | s >> 1 applied 8 times).  Decoded bit i of the frame is the
 // decision at column i + 7 on the traced path (6-bit decoder delay), so output byte m is (block m >> 6) | (block m+1
 // & 0x3F) << 2.
-template <int CR>
+// WIN / LOOK: the window schedule of T11aViterbi<.., N_INPUT, TRELLIS_DEPTH = WIN, TRELLIS_LOOKAHEAD = LOOK> -- 256 / 24 in the 802.11a graph
+// (fb11ademod_config.hpp:199), 192 / 36 in the 802.11n graph (fb11ndemod_config.hpp:199); a walk touches at most (WIN + LOOK + 7) / 8 + 2 <= 38 blocks.
+template <int CR, int WIN, int LOOK>
 __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring)
 {
     constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
@@ -210,7 +212,7 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };       // Normalize (viterbicore.h:444-465), both frames; marks are clear here
     auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
     auto next_event = [&]() -> uint32_t {
-        uint32_t t = ob + 256u + 24u + 6u;
+        uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
         if (!A.done) t = min(t, A.tr_end);
         if (!B.done) t = min(t, B.tr_end);
         return t;
@@ -223,18 +225,18 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
             if (k == 7) { const unsigned w = ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
             else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (16 + k)) & 1u; }
             const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
-            const bool partial = tr >= ob + 256u + 24u + 6u;
+            const bool partial = tr >= ob + (uint32_t)(WIN + LOOK + 6);
             uint32_t cntA = 0, cntB = 0;
             if (!A.done) {
                 if (tr >= A.tr_end) { cntA = A.tr_end - ob - 6; A.done = true; }
-                else if (partial) cntA = 256;
+                else if (partial) cntA = WIN;
             }
             if (!B.done) {
                 if (tr >= B.tr_end) { cntB = B.tr_end - ob - 6; B.done = true; }
-                else if (partial) cntB = 256;
+                else if (partial) cntB = WIN;
             }
             if (cntA | cntB) trace(mA, mB, cntA, cntB);
-            if (partial) ob += 256;
+            if (partial) ob += WIN;
             next_thr = next_event();
         }
     };
@@ -309,7 +311,8 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 // 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.
 // Frames are queued per code rate (k_scan), so the two frames of a wave always share the puncture pattern; the last
 // frame of an odd list runs alone in the low half.  (Jobs given through sora_hip_viterbi11a are one list of one rate.)
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+template <int WIN, int LOOK>
+__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
     __shared__ uint16_t s_ring[4][kRingBlocks * 64];                             // 24 KB: survivor history of the last 384 columns, per wave
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
@@ -339,11 +342,17 @@ __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs
         const bool second = pass == 1;
         if (second ? !hasB : !JA.valid) continue;
         const VitJob X = second ? JB : JA;
-        if (X.code_rate == 0)      viterbi_forward<0>(X, JB, pair, soft, out, ring);
-        else if (X.code_rate == 1) viterbi_forward<1>(X, JB, pair, soft, out, ring);
-        else                       viterbi_forward<2>(X, JB, pair, soft, out, ring);
+        if (X.code_rate == 0)      viterbi_forward<0, WIN, LOOK>(X, JB, pair, soft, out, ring);
+        else if (X.code_rate == 1) viterbi_forward<1, WIN, LOOK>(X, JB, pair, soft, out, ring);
+        else                       viterbi_forward<2, WIN, LOOK>(X, JB, pair, soft, out, ring);
     }
 }
+
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+{ viterbi_kernel_body<256, 24>(jobs, njobs3, njobs_single, stride, soft, out); }
+// the 802.11n graph's decoder: T11aViterbi<5000*8, 312, 192, 36> (fb11ndemod_config.hpp:199)
+__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+{ viterbi_kernel_body<192, 36>(jobs, njobs3, njobs_single, stride, soft, out); }
 
 // ------------------------------------------------------------------------------------------------
 // k_finish: T11aDesc (scramble.hpp:267-353) + TBB11aFrameSink (PHY_11a.hpp:607-702).  One wave per frame.

@@ -82,7 +82,7 @@ __device__ __forceinline__ int scan_add(int v, int lane)               // inclus
 }
 }  // namespace
 
-__global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
+__global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
 {
     __shared__ WaveLds s_w[4];
     __shared__ uint8_t s_lut[6][256];
@@ -565,11 +565,499 @@ __global__ void __launch_bounds__(256, 3) k_rx11n(Rx11nArgs A)
     if (lane == 0) A.nframes[cap] = nfr;
 }
 
+
+// ================================================================================================================================
+// The same graph as a chain of kernels, the way the 802.11a path is built (k_scan -> k_frame -> k_viterbi -> k_finish):
+//   k_scan11n     one wave per capture: carrier sense, L-LTF (CFO, four FFTs, TSisoChannelEst), the three SIG symbols and their decoder,
+//                 RxThread's bookkeeping.  What follows the SIG field never feeds back into carrier sense -- the event of a frame is
+//                 raised at its last data symbol, whose position the SIG field fixes (T11nSymSel counts remain_symbols down,
+//                 PHY_11n.hpp:331; equivalently the Viterbi passes frame_length * 8 + 22 steps in that symbol) -- so the scan jumps
+//                 over the data field and queues it as a job: (capture, L-LTF position, CFO, MCS, length, symbols, soft values incl.
+//                 the zero padding of a flush at the end of the capture).
+//   k_frame11n    one wave per queued frame: the two HT-LTF symbols -> TMimoChannelEst, then symbol by symbol (the pilot phase of
+//                 symbol s rotates symbol s + 1: a serial chain) TFreqComp_11n, two FFTs, TMimoChannelComp, TPilotTrack_11n, demap,
+//                 de-interleave, stream join; soft values leave as the 16-bit fields v << 9 the trellis kernel reads.
+//   k_viterbi11n  k_rx.hip: the two-frames-per-wave trellis kernel of the 802.11a path with the 192 / 36 window schedule.
+//   k_finish11n   T11aDesc + TBB11aFrameSink: descrambler phase table, parallel CRC-32; fills error code, FCS and the MPDU slot of the row.
+struct N11Frame {                  // one queued data field
+    uint32_t cap;                  // capture index
+    uint32_t row;                  // index into rows[] / mpdu slots
+    uint32_t l0;                   // 20 MHz index (in the capture) of the first L-LTF sample
+    int32_t  cfo;
+    uint32_t mcs, ht_len, code_rate;
+    uint32_t nproc;                // data symbols that start inside the (padded) capture
+    uint32_t nsoft;                // soft values handed to the decoder, zero padding of a final flush included
+    uint32_t slot0;                // first symbol slot (global) of the frame's soft / decoded-byte storage
+    uint32_t pad[6];
+};
+struct Scan11nArgs {
+    const uint32_t* iq0; const uint32_t* iq1; const CapDesc* caps; uint32_t ncaps, max_frames;
+    Rx11bRow* rows; uint32_t* nframes; Tables T; const uint32_t* sincos; const short* atan;
+    N11Frame* frames;              // [3][nrows], by code-rate list, compacted
+    VitJob*   jobs;                // [3][nrows], same order
+    uint32_t* njobs;               // [3]
+    uint32_t  nrows;
+};
+struct Frame11nArgs {
+    const uint32_t* iq0; const uint32_t* iq1; const CapDesc* caps;
+    const N11Frame* frames; const uint32_t* njobs; uint32_t nrows;
+    Tables T; const uint32_t* sincos; const short* atan;
+    uint8_t* soft;                 // [slots * 576]: 16-bit fields v << 9, contiguous per frame
+    const uint8_t* vout;           // [slots * 32]
+    Rx11bRow* rows; uint8_t* mpdu;
+};
+
+namespace {
+struct ScanLds {
+    uint32_t his[2][32]; int hcr[2][32], hci[2][32], he[2][32];
+    long long his_e[64];
+    uint32_t buf[2][128];
+    uint32_t fft[4][64];
+    uint32_t y[2][128];
+    uint32_t ch[2][64];
+    uint32_t sig[192];
+    uint8_t  soft0[160];
+    uint8_t  sigsoft[144];
+    unsigned long long dec[52];
+};
+struct FrameLds {
+    uint32_t buf[2][64];
+    uint32_t fft[4][64];
+    uint32_t y[2][128];
+    uint32_t hinv[4][64];
+    uint32_t xs[2][64];
+    uint8_t  soft[2][160];
+    alignas(4) uint8_t joined[256];
+    uint8_t  dtab[208];
+};
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
+{
+    __shared__ ScanLds s_w[4];
+    __shared__ uint8_t s_lut[6][256];
+    fill_demap_luts(s_lut);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t cap = blockIdx.x * 4 + wv;
+    if (cap >= A.ncaps) return;
+    ScanLds& W = s_w[wv];
+    const CapDesc cd = A.caps[cap];
+    const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
+    const uint32_t n20 = cd.nsamples / 2;
+    auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t { return i < n20 ? iq[r][2 * (size_t)i] : 0u; };
+    const Fft64Tw tw = fft64_twiddles(A.T, lane & 15);
+    auto nosync = []() __attribute__((always_inline)) { wsync(); };
+
+    for (int k = lane; k < 64; k += 64) { W.his[0][k & 31] = 0; W.his[1][k & 31] = 0; W.hcr[k >> 5][k & 31] = 0; W.hci[k >> 5][k & 31] = 0; W.he[k >> 5][k & 31] = 0; W.his_e[k] = 0x7FFFFFFFFFFFFFFFll; }
+    wsync();
+    int sr[2] = { 0, 0 }, si[2] = { 0, 0 }, se[2] = { 0, 0 };
+    int ring_pos = 0, his_index = 0;
+    uint32_t origin = 0, nfr = 0;
+    Rx11bRow* rows = A.rows + (size_t)cap * A.max_frames;
+
+    while (origin < n20) {
+        // ================================================================ carrier sense from `origin` (as k_rx11n_mono; cca_11n.hpp:46-127)
+        const uint32_t nb_total = (n20 - origin + 3) / 4;
+        bool pf = false, timeout = false; int pc = 0, sense = 0;
+        int64_t det_at = -1;
+        for (uint32_t base = 0; base < nb_total * 4 && det_at < 0; base += 64) {
+            const int lim = (int)min(64u, nb_total * 4 - base);
+            int pr[2], pi[2], pe[2], cre[2], cim[2], een[2]; uint32_t xr[2];
+            const int slot = (ring_pos + lane) & 31;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                xr[r] = fetch(r, origin + base + lane);
+                const cpx x = unpack(xr[r]);
+                const uint32_t dl = (uint32_t)__shfl((int)xr[r], lane - 32);
+                const cpx delayed = unpack(lane < 32 ? W.his[r][slot] : dl);
+                int re, im; conj_mul32(x, delayed, re, im); re >>= 5; im >>= 5;
+                const int ore = __shfl(re, lane - 32), oim = __shfl(im, lane - 32);
+                const int e = sqnorm(x) >> 5, oe = __shfl(e, lane - 32);
+                const int dre = (int)((unsigned)re - (unsigned)(lane < 32 ? W.hcr[r][slot] : ore));
+                const int dim = (int)((unsigned)im - (unsigned)(lane < 32 ? W.hci[r][slot] : oim));
+                const int den = (int)((unsigned)e - (unsigned)(lane < 32 ? W.he[r][slot] : oe));
+                pr[r] = (int)((unsigned)sr[r] + (unsigned)scan_add(dre, lane)); pi[r] = (int)((unsigned)si[r] + (unsigned)scan_add(dim, lane));
+                pe[r] = (int)((unsigned)se[r] + (unsigned)scan_add(den, lane));
+                cre[r] = re; cim[r] = im; een[r] = e;
+            }
+            const int are = (int)((unsigned)(pr[0] >> 1) + (unsigned)(pr[1] >> 1)), aim = (int)((unsigned)(pi[0] >> 1) + (unsigned)(pi[1] >> 1));
+            const long long acorr = (long long)((unsigned long long)((long long)are * are) + (unsigned long long)((long long)aim * aim));
+            const int ev = (int)((unsigned)(pe[0] >> 1) + (unsigned)(pe[1] >> 1));
+            const long long energy = (long long)ev * ev;
+            const long long olde = W.his_e[(his_index + lane) & 63];
+            const bool cA = olde != 0x7FFFFFFFFFFFFFFFll && (olde + 1) <= (energy >> 2) && 6 * (olde + 1) <= energy && acorr > (energy >> 1);
+            const bool cB = acorr < (energy >> 3);
+            const unsigned long long bA = __ballot(cA), bB = __ballot(cB);
+            int det = -1;
+            const unsigned long long lmask = lim >= 64 ? ~0ull : ((1ull << lim) - 1);
+            if (!pf && (bA & lmask) == 0) {
+                for (int i = 3; i < lim; i += 4) {
+                    sense += 4;
+                    if (sense >= 84) timeout = true;
+                    const uint32_t s4 = base + (uint32_t)i - 3;
+                    if (timeout && (s4 + 3) / 14 != (s4 + 7) / 14) { timeout = false; sense = 0; }
+                }
+                pc = 0;
+            } else if (pf && !timeout && (bB & lmask) == 0 && pc + lim <= 160) {
+                pc += lim;
+            } else
+            for (int i = 0; i < lim; i++) {
+                const bool a = (bA >> i) & 1, b = (bB >> i) & 1;
+                if (!pf) { sense++; if (a) { sense = 0; pc++; pf = true; } else pc = 0; }
+                else if (b) { const bool good = pc > 96 && pc < 160; pf = false; pc = 0; if (good) { det = i; break; } }
+                else { pc++; if (pc > 160) { pf = false; pc = 0; } }
+                if ((i & 3) == 3) {
+                    if (sense >= 84) timeout = true;
+                    const uint32_t s4 = base + (uint32_t)i - 3;
+                    if (timeout && (s4 + 3) / 14 != (s4 + 7) / 14) { timeout = false; pf = false; pc = 0; sense = 0; }
+                }
+            }
+            const int ne = det >= 0 ? det : lim;
+            const int na = det >= 0 ? (det | 3) + 1 : lim;
+            if (lane < ne) W.his_e[(his_index + lane) & 63] = energy;
+            if (lane < na && lane >= na - 32) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) { W.his[r][slot] = xr[r]; W.hcr[r][slot] = cre[r]; W.hci[r][slot] = cim[r]; W.he[r][slot] = een[r]; }
+            }
+#pragma unroll
+            for (int r = 0; r < 2; r++) { sr[r] = __shfl(pr[r], na - 1); si[r] = __shfl(pi[r], na - 1); se[r] = __shfl(pe[r], na - 1); }
+            his_index = (his_index + ne) & 63; ring_pos = (ring_pos + na) & 31;
+            wsync();
+            if (det >= 0) det_at = (int64_t)base + na;
+        }
+        if (det_at < 0) break;
+        const uint32_t n_real = n20 - origin;
+        const uint32_t n_pad = (n_real + 3) & ~3u;                           // the last burst is delivered zero-padded
+        const uint32_t l0 = (uint32_t)det_at;
+        if (l0 + 128 > n_pad) break;
+        // ================================================================ L-LTF: CFO, compensation, four FFTs, SISO channel
+        int cfo;
+        {
+            int sre = 0, sim = 0;
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int re, im; conj_mul32(unpack(fetch(r, origin + l0 + lane)), unpack(fetch(r, origin + l0 + 64 + lane)), re, im);
+                sre += re >> 7; sim += im >> 7;
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) { sre += __shfl_xor(sre, d); sim += __shfl_xor(sim, d); }
+            cfo = uni(dsp_atan32(A.atan, sre, sim) >> 6);
+        }
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int h = 0; h < 2; h++) {
+                const int n = 64 * h + lane;
+                const cpx cof = unpack(A.sincos[(unsigned)(n * cfo) & 0xFFFFu]);
+                int re, im; mul32(unpack(fetch(r, origin + l0 + n)), cof, re, im);
+                W.buf[r][n] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+            }
+        wsync();
+        {
+            const int g = lane >> 4, e = lane & 15; cpx x[4], yy[4];
+#pragma unroll
+            for (int m = 0; m < 4; m++) x[m] = unpack(W.buf[g >> 1][64 * (g & 1) + e + 16 * m]);
+            fft64_group(x, yy, W.fft[g], e, tw, nosync);
+#pragma unroll
+            for (int q = 0; q < 4; q++) W.y[g >> 1][64 * (g & 1) + e + 16 * q] = pack(yy[q]);
+        }
+        wsync();
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            uint32_t o = 0;
+            if (lane < 28 || lane >= 36) {
+                const uint32_t* l = W.y[r] + (lane & ~3);
+                const cpx a = siso_one(l, lane & 3, lane), b = siso_one(l + 64, lane & 3, lane);
+                o = pack(mk((short)((short)(a.re + b.re) >> 1), (short)((short)(a.im + b.im) >> 1)));
+            }
+            W.ch[r][lane] = o;
+        }
+        wsync();
+        // ================================================================ the SIG field: three symbols, theta = 0 (no pilot tracking before the data field)
+        uint32_t err = 0, mcs = 0, ht_len = 0, code_rate = 0;
+        bool sig_ok = false, decoded = false;
+        uint32_t a = l0 + 128;
+        int nsig = 0;
+        bool at_end = false;
+        for (int s3 = 0; s3 < 3; s3++) {
+            if (a >= n_pad) { at_end = true; break; }
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                const uint32_t n = a - l0 + 16 + lane;
+                const cpx cof = unpack(A.sincos[(unsigned)((int)n * cfo) & 0xFFFFu]);
+                int re, im; mul32(unpack(fetch(r, origin + a + 16 + lane)), cof, re, im);
+                W.buf[r][lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+            }
+            wsync();
+            {
+                const int g = lane >> 4, e = lane & 15; cpx x[4], yy[4];
+#pragma unroll
+                for (int q = 0; q < 4; q++) x[q] = unpack(W.buf[g & 1][e + 16 * q]);
+                fft64_group(x, yy, W.fft[g], e, tw, nosync);
+                if (g < 2) {
+#pragma unroll
+                    for (int q = 0; q < 4; q++) W.y[g][e + 16 * q] = pack(yy[q]);
+                }
+            }
+            wsync();
+            {
+                int re, im;
+                mul32(unpack(W.y[0][lane]), unpack(W.ch[0][lane]), re, im); const cpx x0 = mk(sat16(re >> 9), sat16(im >> 9));
+                mul32(unpack(W.y[1][lane]), unpack(W.ch[1][lane]), re, im); const cpx x1 = mk(sat16(re >> 9), sat16(im >> 9));
+                W.sig[64 * nsig + lane] = pack(mk((short)((short)(x0.re + x1.re) >> 1), (short)((short)(x0.im + x1.im) >> 1)));
+            }
+            nsig++; a += 80;
+            wsync();
+        }
+        if (at_end && nsig > 0) { for (int k = lane; k < 64 * (3 - nsig); k += 64) W.sig[64 * nsig + k] = 0; }   // T11nSymSel::Flush: the missing symbols are zeros
+        if (!at_end || nsig > 0) {
+            // T11nSigDemap -> T11aDeinterleaveBPSK -> T11nViterbiSig -> T11nSigParser on W.sig
+            decoded = true;
+            wsync();
+            for (int g = lane; g < 144; g += 64) {
+                const int s3 = g / 48, k = g - 48 * s3;
+                int bin; if (k < 24) bin = 38 + k + (k >= 5) + (k >= 18); else { const int q = k - 24; bin = 1 + q + (q >= 6) + (q >= 19); }
+                const cpx v = unpack(W.sig[64 * s3 + bin]);
+                const int qv = s3 == 0 ? v.re : v.im;
+                W.soft0[g] = s_lut[0][min(max(qv, -128), 127) + 128];
+            }
+            wsync();
+            for (int g = lane; g < 144; g += 64) { const int s3 = g / 48, kk = g - 48 * s3; W.sigsoft[g] = W.soft0[48 * s3 + 3 * (kk & 15) + (kk >> 4)]; }
+            wsync();
+            const uint32_t lsig = (uint32_t)uni((int)(uint32_t)(viterbi_sig_wave<24>(W.sigsoft, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6));
+            wsync();
+            const unsigned long long ht = uni64(viterbi_sig_wave<48>(W.sigsoft + 48, reinterpret_cast<uint64_t*>(W.dec), lane) >> 6);
+            wsync();
+            do {
+                const uint32_t sg = lsig & 0xFFFFFF;
+                if (sg & 0xFC0010) break;
+                if (__popc(sg) & 1) break;
+                const uint32_t code = sg & 0xF;
+                if (code < 8) break;
+                if (((sg >> 5) & 0xFFF) * 2 > 1500) break;
+                uint32_t crc = 0xFF;
+                for (int b = 0; b < 34; b++) { crc ^= (uint32_t)(ht >> b) & 1; crc = (crc & 1) ? (crc >> 1) ^ 0xE0 : crc >> 1; }
+                if (((~crc) & 0xFF) != (uint32_t)((ht >> 34) & 0x3FFF)) break;
+                const uint32_t mc = (uint32_t)ht & 0x7F;
+                if (mc < 8 || mc >= 11) break;
+                const uint32_t hl = (uint32_t)(ht >> 8) & 0xFFFF;
+                if (hl > 1500) break;
+                mcs = mc; ht_len = hl; code_rate = mc == 10 ? 2u : 0u;
+                sig_ok = true;
+            } while (0);
+            if (!sig_ok) err = E_PLCP;
+        }
+        // ================================================================ what happens to the frame, without looking at its data field
+        uint32_t last_burst_end = n_pad;                                     // (relative to origin) behind the burst that raises the event
+        bool event = false, queue = false;
+        uint32_t nproc = 0, nsoft = 0;
+        if (decoded && err != 0) { event = true; last_burst_end = at_end ? n_pad : min(a, n_pad); }
+        else if (decoded && !at_end) {
+            // HT-STF at a, HT-LTF at a + 80 / a + 160, data symbol d at a + 240 + 80 d; a symbol is processed when it starts inside the
+            // padded capture (its missing samples read as zero: the flush of the partly filled queues)
+            const uint32_t tr_end = ht_len * 8 + 16 + 6;
+            const uint32_t S = mcs == 8 ? 104u : 208u, sps = code_rate == 0 ? S / 2 : S / 4 * 3;     // soft values / trellis steps per symbol
+            const uint32_t nsym = (tr_end + sps - 1) / sps;                  // the symbol in which the decoder passes tr_end
+            const uint32_t a_data = a + 240;
+            if (a_data < n_pad) nproc = min(nsym, (n_pad - a_data + 79) / 80);
+            if (nproc == nsym) { event = true; queue = true; nsoft = nsym * S; last_burst_end = min(a_data + 80 * nsym, n_pad); }
+            else if (a + 160 < n_pad && nproc > 0 && (nproc * S) % 312 != 0) {
+                // the capture ends inside the data field: T11aViterbi's 312-value input burst is padded with zero soft values; an
+                // event only if that takes the decoder past tr_end
+                nsoft = (nproc * S + 311) / 312 * 312;
+                const uint32_t steps = code_rate == 0 ? nsoft / 2 : nsoft / 4 * 3;
+                if (steps >= tr_end) { event = true; queue = true; last_burst_end = n_pad; }
+            }
+        }
+        if (!event) break;                                                   // the capture ended inside a frame without an event
+        const uint32_t abs_end = origin + last_burst_end;
+        const uint32_t call = (abs_end - 1) / 14;
+        const uint32_t next = min(14 * (call + 1), n20);
+        if (nfr < A.max_frames) {
+            const uint32_t row = cap * A.max_frames + nfr;
+            if (lane == 0) {
+                Rx11bRow r; r.end_sample = 2 * next; r.error_code = queue ? 0u : err; r.rate_kbps = queue ? mcs : 0u; r.length = queue ? ht_len : 0u; r.crc32 = 0u;
+                rows[nfr] = r;
+                if (queue) {
+                    const uint32_t list = code_rate;
+                    const uint32_t idx = atomicAdd(&A.njobs[list], 1u);
+                    N11Frame F; F.cap = cap; F.row = row; F.l0 = origin + l0; F.cfo = cfo; F.mcs = mcs; F.ht_len = ht_len; F.code_rate = code_rate;
+                    F.nproc = nproc; F.nsoft = nsoft; F.slot0 = cd.slot_base + (origin + a + 240) / 80;
+                    for (int k = 0; k < 6; k++) F.pad[k] = 0;
+                    A.frames[(size_t)list * A.nrows + idx] = F;
+                    VitJob J; J.soft_off = F.slot0 * (uint32_t)kSoftPerSlot * 2u; J.nsoft = nsoft; J.length = ht_len; J.dec_off = 0; J.out_off = F.slot0 * (uint32_t)kOutPerSlot;
+                    J.valid = 1; J.code_rate = code_rate; J.pad = 0;
+                    A.jobs[(size_t)list * A.nrows + idx] = J;
+                }
+            }
+        }
+        nfr++;
+        origin = 14 * (call + 1);
+    }
+    if (lane == 0) A.nframes[cap] = nfr;
+}
+
+__global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
+{
+    __shared__ FrameLds s_w[4];
+    __shared__ uint8_t s_lut[6][256];
+    fill_demap_luts(s_lut);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const JobRef jr = locate_job(blockIdx.x * 4 + wv, A.njobs);
+    if (!jr.ok) return;
+    const N11Frame F = A.frames[(size_t)jr.list * A.nrows + jr.idx];
+    FrameLds& W = s_w[wv];
+    const CapDesc cd = A.caps[F.cap];
+    const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
+    const uint32_t n20 = cd.nsamples / 2;
+    auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t { return i < n20 ? iq[r][2 * (size_t)i] : 0u; };
+    const Fft64Tw tw = fft64_twiddles(A.T, lane & 15);
+    auto nosync = []() __attribute__((always_inline)) { wsync(); };
+    const int cfo = uni(F.cfo);
+    const uint32_t l0 = (uint32_t)uni((int)F.l0), mcs = (uint32_t)uni((int)F.mcs), nproc = (uint32_t)uni((int)F.nproc);
+    const int nb = mcs == 8 ? 1 : 2;
+    for (int g = lane; g < 104 * nb; g += 64) W.dtab[g] = (uint8_t)deint11n_index(nb, g & 1, g >> 1);
+    int theta = 0;
+    // one symbol at 20 MHz index `pos` (its CP included): TFreqComp_11n (running phase n * CFO - theta, n counted from the L-LTF), two FFTs -> W.y[.][64 * half ..]
+    auto symbol_fft = [&](uint32_t pos, uint32_t x0, uint32_t x1, int half) __attribute__((always_inline)) {
+        const uint32_t n = pos - l0 + 16 + (uint32_t)lane;
+        const cpx cof = unpack(A.sincos[(unsigned)((int)n * cfo - theta) & 0xFFFFu]);
+        int re, im;
+        mul32(unpack(x0), cof, re, im); W.buf[0][lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+        mul32(unpack(x1), cof, re, im); W.buf[1][lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+        wsync();
+        const int g = lane >> 4, e = lane & 15; cpx x[4], yy[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) x[q] = unpack(W.buf[g & 1][e + 16 * q]);
+        fft64_group(x, yy, W.fft[g], e, tw, nosync);
+        if (g < 2) {
+#pragma unroll
+            for (int q = 0; q < 4; q++) W.y[g][64 * half + e + 16 * q] = pack(yy[q]);
+        }
+        wsync();
+    };
+    const uint32_t a_ltf = l0 + 128 + 320;                                   // L-LTF (128), three SIG symbols, HT-STF
+    // ---- the two HT-LTF symbols -> TMimoChannelEst (channel_11n.hpp:329-443), as k_mimo_est11n_batch
+    symbol_fft(a_ltf, fetch(0, a_ltf + 16 + lane), fetch(1, a_ltf + 16 + lane), 0);
+    symbol_fft(a_ltf + 80, fetch(0, a_ltf + 96 + lane), fetch(1, a_ltf + 96 + lane), 1);
+    {
+#pragma clang fp contract(off)
+        const int i = lane, k = i < 32 ? i : i - 64;
+        const bool negate = !(k >= -28 && k <= 28 && kHtLtf[k + 28] == 1);
+        cpx hh[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const cpx p = unpack(W.y[r][i]), q = unpack(W.y[r][i + 64]);
+            cpx d = sra(csubs(p, q), 1), s = sra(cadds(p, q), 1);
+            if (negate) { d = mk(neg16(d.re), neg16(d.im)); s = mk(neg16(s.re), neg16(s.im)); }
+            hh[r][0] = d; hh[r][1] = s;
+        }
+        const cf a00 = { (float)hh[0][0].re, (float)hh[0][0].im }, a01 = { (float)hh[0][1].re, (float)hh[0][1].im };
+        const cf a10 = { (float)hh[1][0].re, (float)hh[1][0].im }, a11 = { (float)hh[1][1].re, (float)hh[1][1].im };
+        const cf ad = cf_mul(a00, a11), bc = cf_mul(a01, a10);
+        const cf det = { ad.re - bc.re, ad.im - bc.im };
+        const float nn = ((det.re * det.re) + (det.im * det.im)) / 65536.0f;
+        const cf ds = { det.re, -det.im }, m01 = { -a01.re, -a01.im }, m10 = { -a10.re, -a10.im };
+        const cf r00 = cf_mul(a11, ds), r01 = cf_mul(m01, ds), r10 = cf_mul(m10, ds), r11 = cf_mul(a00, ds);
+        W.hinv[0][i] = pack(mk(cvtps_sat16(r00.re / nn), cvtps_sat16(r00.im / nn)));
+        W.hinv[1][i] = pack(mk(cvtps_sat16(r01.re / nn), cvtps_sat16(r01.im / nn)));
+        W.hinv[2][i] = pack(mk(cvtps_sat16(r10.re / nn), cvtps_sat16(r10.im / nn)));
+        W.hinv[3][i] = pack(mk(cvtps_sat16(r11.re / nn), cvtps_sat16(r11.im / nn)));
+    }
+    wsync();
+    // ---- the data symbols, in order
+    const uint32_t a_data = a_ltf + 160;
+    const uint32_t S = 104u * (uint32_t)nb;
+    uint32_t* dst = reinterpret_cast<uint32_t*>(A.soft + (size_t)F.slot0 * kSoftPerSlot * 2);
+    uint32_t nx0 = fetch(0, a_data + 16 + lane), nx1 = fetch(1, a_data + 16 + lane);     // the next symbol's samples are requested one symbol ahead
+    for (uint32_t d = 0; d < nproc; d++) {
+        const uint32_t pos = a_data + 80 * d;
+        const uint32_t x0 = nx0, x1 = nx1;
+        if (d + 1 < nproc) { nx0 = fetch(0, pos + 96 + lane); nx1 = fetch(1, pos + 96 + lane); }
+        symbol_fft(pos, x0, x1, 0);
+        // TMimoChannelComp -> TPilotTrack_11n -> demap -> de-interleave -> stream parser
+        const cpx p = unpack(W.y[0][lane]), q = unpack(W.y[1][lane]);
+        int ar, ai, br, bi;
+        mul32(unpack(W.hinv[0][lane]), p, ar, ai); mul32(unpack(W.hinv[1][lane]), q, br, bi);
+        W.xs[0][lane] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+        mul32(unpack(W.hinv[2][lane]), p, ar, ai); mul32(unpack(W.hinv[3][lane]), q, br, bi);
+        W.xs[1][lane] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+        wsync();
+        {
+            const int k = lane & 3, sidx = (lane >> 2) & 1;
+            const int pbin = k == 0 ? 64 - 21 : k == 1 ? 64 - 7 : k == 2 ? 7 : 21;
+            const cpx v = unpack(W.xs[sidx][pbin]);
+            int th = dsp_atan16(A.atan, v.re, v.im);
+            th += __shfl_xor(th, 1); th += __shfl_xor(th, 2);
+            const int t0 = (int)(short)(uni(__shfl(th, 0)) >> 2), t1 = (int)(short)(uni(__shfl(th, 4)) >> 2);
+            theta = (int)(short)(theta + (int)(short)((t0 + t1) >> 1));
+        }
+        if (lane < 52) {
+#pragma unroll
+            for (int s = 0; s < 2; s++) {
+                const cpx x = unpack(W.xs[s][data_bin(lane)]);
+                const int re = min(max(x.re, -128), 127) + 128, im = min(max(x.im, -128), 127) + 128;
+                if (nb == 1) W.soft[s][lane] = s_lut[0][re];
+                else { W.soft[s][2 * lane] = s_lut[0][re]; W.soft[s][2 * lane + 1] = s_lut[0][im]; }
+            }
+        }
+        wsync();
+        // joined position g (stream g & 1) <- soft[g & 1][dtab[g]]; two soft values per 32-bit word, 16-bit fields v << 9
+        for (uint32_t w = lane; w < S / 2; w += 64) {
+            const uint32_t g = 2 * w;
+            dst[(size_t)d * (S / 2) + w] = ((uint32_t)W.soft[0][W.dtab[g]] << 9) | ((uint32_t)W.soft[1][W.dtab[g + 1]] << 25);
+        }
+        wsync();
+    }
+    for (uint32_t w = nproc * (S / 2) + lane; w < F.nsoft / 2; w += 64) dst[w] = 0;      // the zero soft values of a flush at the end of the capture
+}
+
+// T11aDesc + TBB11aFrameSink (scramble.hpp:319-349, PHY_11a.hpp:660-692) on the decoded bytes of a queued frame -> MPDU slot, error code, FCS
+__global__ void __launch_bounds__(256) k_finish11n(Frame11nArgs A)
+{
+    __shared__ uint32_t s_crc[256];
+    __shared__ uint32_t s_z[6 * 8 * 16];
+    __shared__ uint32_t s_bufs[4][1504 / 4 + 2];
+    s_crc[threadIdx.x] = A.T.crc[threadIdx.x];
+    for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) s_z[i] = A.T.crcz[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const JobRef jr = locate_job(blockIdx.x * 4 + wv, A.njobs);
+    if (!jr.ok) return;
+    const N11Frame F = A.frames[(size_t)jr.list * A.nrows + jr.idx];
+    const uint8_t* dec = A.vout + (size_t)F.slot0 * kOutPerSlot;
+    uint8_t* mp = A.mpdu + (size_t)F.row * 4096;
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(s_bufs[wv]);
+    const uint32_t L = F.ht_len;
+    const unsigned seed = dec[1] >> 1;
+    const unsigned phase = A.T.scr_phase[seed & 0x7F];
+    for (uint32_t i = lane; i < L; i += 64) {
+        const unsigned sb = phase == 255 ? 0u : A.T.scr_seq[(phase + 8u * i) % 127u];
+        const unsigned o = dec[2 + i] ^ sb;
+        bytes[i] = (uint8_t)o; mp[i] = (uint8_t)o;
+    }
+    wsync();
+    const int n = L >= 4 ? (int)L - 4 : 0;
+    uint32_t crc;
+    if (n >= 4) crc = crc32_wave(bytes, n, s_crc, s_z, lane);
+    else { crc = 0xFFFFFFFFu; for (int i = 0; i < n; i++) crc = (crc >> 8) ^ s_crc[(bytes[i] ^ crc) & 0xFF]; }
+    if (lane == 0) {
+        uint32_t fcs = 0;
+        if (L >= 4) fcs = (uint32_t)bytes[L - 4] | ((uint32_t)bytes[L - 3] << 8) | ((uint32_t)bytes[L - 2] << 16) | ((uint32_t)bytes[L - 1] << 24);
+        Rx11bRow& r = A.rows[F.row];
+        r.crc32 = fcs;
+        r.error_code = ((~crc) == fcs) ? E_OK : E_CRC;
+    }
+}
+
 }  // namespace sora
 
 // ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
 #include <vector>
 #include <string.h>
+#include <stdlib.h>
 using namespace sora;
 
 
@@ -581,6 +1069,10 @@ struct sora_rx11n {
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
     std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
     uint32_t ncaps = 0; bool have_results = false;
+    // the staged chain (k_scan11n -> k_frame11n -> k_viterbi11n -> k_finish11n); SORA_HIP_11N_MONO=1 selects the one-kernel form instead
+    bool mono = false;
+    N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
+    uint64_t cap_slots = 0;
 };
 
 #define HIPCHK11N(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -590,6 +1082,7 @@ static void rx11n_free(sora_rx11n_t* rx)
     if (!rx) return;
     if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
     (void)hipFree(rx->d_caps); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_nframes); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_iq_own[0]); (void)hipFree(rx->d_iq_own[1]);
+    (void)hipFree(rx->d_frames); (void)hipFree(rx->d_jobs); (void)hipFree(rx->d_njobs); (void)hipFree(rx->d_soft); (void)hipFree(rx->d_vout);
     delete rx;
 }
 
@@ -611,7 +1104,24 @@ int sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out)
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * rows);
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures);
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, rows * 4096);
+    { const char* m = getenv("SORA_HIP_11N_MONO"); rx->mono = m && m[0] == '1'; }
+    if (!rx->mono) {
+        // symbol slots: 80 samples at 20 MHz each, + 4 per capture (the decoder's padded last burst and its chunked reads may reach past the last symbol)
+        rx->cap_slots = cfg->max_total_samples / 2 / 80 + 4 * (uint64_t)cfg->max_captures + 4;
+        if (rx->cap_slots * (uint64_t)kSoftPerSlot * 2 >= (1ull << 32)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_create: max_total_samples exceeds the 32-bit slot geometry of one handle (split the batch over several handles)", 0); }
+        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_frames, 3 * sizeof(N11Frame) * rows);
+        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rows);
+        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_njobs, 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_soft, (size_t)rx->cap_slots * kSoftPerSlot * 2 + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_vout, (size_t)rx->cap_slots * kOutPerSlot + 256);
+    }
     if (e != hipSuccess) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: device allocation / tables", (int)e); }
+    // every array starts out defined: the decoder reads its soft stream in 12-step chunks (the tail of a frame's last chunk is read, never used)
+    if (!rx->mono) {
+        (void)hipMemsetAsync(rx->d_frames, 0, 3 * sizeof(N11Frame) * rows, rx->stream); (void)hipMemsetAsync(rx->d_jobs, 0, 3 * sizeof(VitJob) * rows, rx->stream);
+        (void)hipMemsetAsync(rx->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot * 2 + 256, rx->stream); (void)hipMemsetAsync(rx->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, rx->stream);
+    }
+    (void)hipMemsetAsync(rx->d_rows, 0, sizeof(Rx11bRow) * rows, rx->stream); (void)hipMemsetAsync(rx->d_nframes, 0, 4 * (size_t)cfg->max_captures, rx->stream);
     *out = rx;
     return SORA_OK;
 }
@@ -627,20 +1137,37 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     std::vector<CapDesc>& h = rx->h_desc;
     HIPCHK11N(hipStreamSynchronize(rx->stream));
     h.resize(ncaps);
-    uint64_t total = 0;
+    uint64_t total = 0, slots = 0;
     for (size_t i = 0; i < ncaps; i++) {
         if (caps[i].nsamples % 28 != 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture length must be a whole number of 28-sample source bursts", 0);
-        h[i].offset = caps[i].offset; h[i].nsamples = caps[i].nsamples; h[i].capture_id = caps[i].capture_id; h[i].slot_base = 0; h[i].nslots = 0;
-        total += caps[i].nsamples;
+        h[i].offset = caps[i].offset; h[i].nsamples = caps[i].nsamples; h[i].capture_id = caps[i].capture_id;
+        h[i].slot_base = (uint32_t)slots; h[i].nslots = caps[i].nsamples / 2 / 80 + 4;
+        slots += h[i].nslots; total += caps[i].nsamples;
     }
-    if (total > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more samples than max_total_samples", 0);
+    if (total > rx->cfg.max_total_samples || (!rx->mono && slots > rx->cap_slots)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more samples than max_total_samples", 0);
     rx->h_caps.assign(caps, caps + ncaps); rx->ncaps = (uint32_t)ncaps; rx->have_results = true;
     if (ncaps == 0) return SORA_OK;
     HIPCHK11N(hipMemcpyAsync(rx->d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, rx->stream));
     Rx11nArgs A;
     A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.caps = rx->d_caps; A.ncaps = (uint32_t)ncaps;
     A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan;
-    hipLaunchKernelGGL(k_rx11n, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);
+    if (rx->mono) {
+        hipLaunchKernelGGL(k_rx11n_mono, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);
+        HIPCHK11N(hipGetLastError());
+        return SORA_OK;
+    }
+    const uint32_t nrows = (uint32_t)ncaps * rx->cfg.max_frames_per_capture;
+    HIPCHK11N(hipMemsetAsync(rx->d_njobs, 0, 16, rx->stream));
+    Scan11nArgs S;
+    S.iq0 = A.iq0; S.iq1 = A.iq1; S.caps = rx->d_caps; S.ncaps = (uint32_t)ncaps; S.max_frames = A.max_frames; S.rows = rx->d_rows; S.nframes = rx->d_nframes;
+    S.T = rx->T; S.sincos = rx->sincos; S.atan = rx->atan; S.frames = rx->d_frames; S.jobs = rx->d_jobs; S.njobs = rx->d_njobs; S.nrows = nrows;
+    hipLaunchKernelGGL(k_scan11n, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, S);
+    Frame11nArgs F;
+    F.iq0 = A.iq0; F.iq1 = A.iq1; F.caps = rx->d_caps; F.frames = rx->d_frames; F.njobs = rx->d_njobs; F.nrows = nrows; F.T = rx->T; F.sincos = rx->sincos; F.atan = rx->atan;
+    F.soft = rx->d_soft; F.vout = rx->d_vout; F.rows = rx->d_rows; F.mpdu = rx->d_mpdu;
+    hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, rx->stream, F);
+    hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, rx->stream, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
+    hipLaunchKernelGGL(k_finish11n, dim3((nrows + 3) / 4), dim3(256), 0, rx->stream, F);
     HIPCHK11N(hipGetLastError());
     return SORA_OK;
 }

@@ -34,7 +34,7 @@ def test_gpu_equals_recorded_reference_events():
     got = run_batch([(a, b) for a, b, _, _, _ in gold])
     for i, (a, b, want, _, z) in enumerate(gold):
         key = lambda e: (e["error_code"], e["rate_kbps"], e["length"], e["crc32"]) if e["error_code"] != 0x80000005 else (e["error_code"],)
-        assert [key(e) for e in got[i]] == [key(e) for e in want], i
+        assert [key(e) for e in got[i]] == [key(e) for e in want], (i, [key(e) for e in got[i]], [key(e) for e in want])
         assert [e["end_sample"] for e in got[i]] == [e["sample_index"] for e in want], i
         for e in got[i]:
             if e["error_code"] == 1:
@@ -142,3 +142,25 @@ def test_gpu_equals_the_live_reference_graph():
         for e in want:
             kinds[e["error_code"]] = kinds.get(e["error_code"], 0) + 1
     assert nev > 320 and kinds.get(1, 0) > 100 and kinds.get(0x80000005, 0) > 50, kinds
+
+
+def test_staged_chain_equals_the_one_kernel_form(monkeypatch):
+    """The default chain (k_scan11n -> k_frame11n -> k_viterbi11n -> k_finish11n) and the one-wave-per-capture kernel of round 1
+    (SORA_HIP_11N_MONO=1, kept for A/B runs) report the same rows and MPDUs, frames cut by the end of the capture included."""
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rng = np.random.default_rng(78)
+    caps = []
+    for t in range(300):
+        fr = [frames[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 5)))]
+        caps.append(capture_11n(rng, fr, sigma=float(rng.choice([5, 60, 600, 1500])), cut=float(rng.uniform(0.05, 1.0)) if t % 2 else None))
+    staged = run_batch(caps)
+    monkeypatch.setenv("SORA_HIP_11N_MONO", "1")
+    mono = run_batch(caps)
+    key = lambda e: (e["error_code"], e["end_sample"], e["rate_kbps"], e["length"], e["crc32"], e["mpdu"])
+    assert sum(len(x) for x in staged) > 300
+    for i in range(len(caps)):
+        assert [key(e) for e in staged[i]] == [key(e) for e in mono[i]], i
