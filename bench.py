@@ -443,6 +443,50 @@ def check_against_reference(res, kind, want, idx):
     return True, ""
 
 
+
+def bench_ht40(torch, sora_amd, dev, nframes=4096):
+    """BASELINE configs[3] (802.11n 2x2 40 MHz HT: 128-point FFT, MMSE detection, one decoder per spatial stream) -- PARITY UNPINNED, the
+    reference has no such receiver.  `nframes` frames of 64-QAM 3/4 on both streams (MCS 15's modulation), a 1500-byte
+    PSDU per stream, from the independent numpy model of the format (oracle/py_ht40.py) through a 2x2 channel with cross-talk; noise added on
+    the device.  Input = the data field as the 20 MHz front end would hand it over (two HT-LTF symbols + data symbols, both chains, HBM resident)."""
+    from oracle import py_ht40 as m
+    rng = np.random.default_rng(40)
+    ps = [m.add_fcs(rng.integers(0, 256, 1496, dtype=np.uint8).tobytes()) for _ in range(2)]
+    x, nsym = m.tx(ps, 6, 2)
+    H = np.array([[1.0, 0.3j], [0.25, 0.9 * np.exp(0.7j)]])
+    y = (H @ x) * 250.0
+    n = (y.shape[1] + 63) // 64 * 64
+    base = np.zeros((2, n, 2), np.float32); base[:, :y.shape[1], 0] = y.real; base[:, :y.shape[1], 1] = y.imag
+    b = torch.from_numpy(base).to(dev)
+    gen = torch.Generator(device=dev); gen.manual_seed(4040)
+    iq = torch.empty((2, nframes, n, 2), dtype=torch.int16, device=dev)
+    sigma = 12.0
+    for i in range(0, nframes, 64):
+        k = min(64, nframes - i)
+        for c in range(2):
+            iq[c, i:i + k] = (b[c][None] + sigma * torch.randn((k, n, 2), generator=gen, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
+    descs = sora_amd.RxHt40.frames([(i * n, 6, 2, 1500, 1500, 0, 2 * sigma * sigma / 128.0, i) for i in range(nframes)])
+    rx = sora_amd.RxHt40(nframes, nframes * 2 * (nsym * 648 + 64))
+    f0 = iq[0].view(-1, 2); f1 = iq[1].view(-1, 2)
+    rx.process_dev(f0, f1, descs); res = rx.results()
+    ok = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] for r in res)
+    for _ in range(3):
+        rx.process_dev(f0, f1, descs)
+    rx.synchronize()
+    reps = 20
+    torch.cuda.synchronize(); t0 = time.perf_counter()
+    for _ in range(reps):
+        rx.process_dev(f0, f1, descs)
+    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    samples = nframes * (2 + nsym) * 160                                     # per chain, 40 MHz
+    alg = 8.0 * samples + 2.0 * 1500 * nframes                               # both chains read once + the decoded PSDUs
+    return {"workload": "%d frames x 2 spatial streams, 64-QAM 3/4, 1500-byte PSDU per stream (%d data symbols, %d samples @40 MHz per chain each), 2x2 cross-talk, AWGN; unbiased MMSE" % (nframes, nsym, (2 + nsym) * 160),
+            "parity": "unpinned: the reference has no 40 MHz / MMSE / per-stream-decoder receiver; loop-back against oracle/py_ht40.py, the reference's own bricks inside are pinned (tests/test_gpu_ht40.py)",
+            "ms": round(ms, 3), "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
+            "psdus_ok": ok, "psdus": 2 * nframes, "bound": "hbm", "algorithmic_bytes": int(alg), "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -456,7 +500,7 @@ def main():
     ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
-    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11n) and print its object: for profiling that section alone")
+    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11n, rx11n_40) and print its object: for profiling that section alone")
     args = ap.parse_args()
 
     import torch
@@ -475,7 +519,8 @@ def main():
 
     if args.only:
         sections = {"stages": lambda: bench_stages(torch, sora_amd, dev), "ingest": lambda: bench_ingest(torch, sora_amd, dev), "tx": lambda: bench_tx(torch, sora_amd),
-                    "rx11b": lambda: bench_11b(torch, sora_amd, dev), "rx11n": lambda: bench_11n(torch, sora_amd, dev)}
+                    "rx11b": lambda: bench_11b(torch, sora_amd, dev), "rx11n": lambda: bench_11n(torch, sora_amd, dev),
+                    "rx11n_40": lambda: bench_ht40(torch, sora_amd, dev)}
         print(json.dumps({args.only: sections[args.only]()}))
         return
     oracle = Oracle()
@@ -676,6 +721,7 @@ def main():
             out["tx"] = bench_tx(torch, sora_amd)
             out["rx11b"] = bench_11b(torch, sora_amd, dev)
             out["rx11n"] = bench_11n(torch, sora_amd, dev)
+            out["rx11n_40"] = bench_ht40(torch, sora_amd, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(iq, nfr)
             out["realtime"]["cpu_reference_factor_one_core"] = round(20.0 / out["cpu_baseline"]["single_core_value"], 4) if out["cpu_baseline"].get("single_core_value") else None

@@ -290,6 +290,36 @@ int   sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const so
 int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------
+ * The data field of an HT-mixed 40 MHz, two-stream frame (BASELINE.json configs[3]: 128-point FFT, MMSE MIMO detection, one decoder per
+ * spatial stream).  PARITY UNPINNED: the reference has no such graph (its 802.11n receiver is 20 MHz, zero-forcing, one decoder, MCS 8-10:
+ * kernel/bb/Brick11/src/PHY_11n.hpp:497, channel_11n.hpp:423-433); every brick it does have is used with the reference's arithmetic
+ * (FFT<128>, TFreqComp_11n, TMimoChannelEst / TMimoChannelComp -- noise_var = 0 gives exactly their zero-forcing weights --, TPilotTrack_11n,
+ * T11nDemap*, T11aViterbi<..,192,36>, T11aDesc, CRC-32), the 40 MHz carrier plan / HT-LTF / interleaver come from IEEE 802.11n-2009 and
+ * are modelled independently in oracle/py_ht40.py.  The caller supplies what the (20 MHz, reference-pinned) front end finds: where the first
+ * HT-LTF symbol starts, modulation, code rate, PSDU lengths, CFO.  A frame = 2 HT-LTF symbols + nsym data symbols of 160 samples at 40 MHz on
+ * two RX chains; each spatial stream carries its own PSDU (SERVICE + PSDU incl. FCS + tail, scrambled, K = 7 coded, punctured, interleaved).
+ * Results: two rows per frame (start_sample = spatial stream 0 / 1, error_code FRAME_OK / CRC32_FAIL, length, crc32, nsym;
+ * rate_kbps = 10 n_bpsc + code_rate); d_weights (optional, [nframes][4][128] COMPLEX16) receives the detection weights x 2^16.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    uint64_t offset;        /* 40 MHz samples from both iq bases to the first sample (cyclic prefix) of HT-LTF 1 */
+    uint32_t n_bpsc;        /* 1, 2, 4, 6 */
+    uint32_t code_rate;     /* SORA_CR_12 / _23 / _34 */
+    uint32_t length[2];     /* PSDU bytes (FCS included) of spatial stream 0 / 1, <= 4000 */
+    int32_t  cfo;           /* phase step per 40 MHz sample, 65536 = 2 pi (TFreqComp_11n: the running phase is n * cfo - theta) */
+    float    noise_var;     /* noise variance per carrier in LSB^2 of the FFT<128> output; 0 = zero forcing; > 0: unbiased MMSE,
+                             * W = diag((W'H)_ss)^-1 W', W' = (H^H H + noise_var I)^-1 H^H */
+    uint32_t frame_id;      /* echoed into the rows' capture_id */
+} sora_ht40_frame;
+typedef struct sora_ht40 sora_ht40_t;
+uint32_t sora_ht40_symbols(uint32_t length0, uint32_t length1, uint32_t n_bpsc, uint32_t code_rate);   /* data symbols of such a frame (0: bad arguments) */
+int   sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out);  /* max_soft_values >= sum over frames of 2 x nsym x 108 n_bpsc (+ 64 per frame) */
+void  sora_ht40_destroy(sora_ht40_t* rx);
+void* sora_ht40_stream(sora_ht40_t* rx);
+int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);
+int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+
+/* ------------------------------------------------------------------------------------------------
  * Multi-GPU sharding for a C host.  Captures are independent -- the reference resets its context per
  * frame (kernel/bb/demod11/fb11ademod_config.hpp:68-95) and RxThread walks one dump at a time (fb11a_demod.cpp:29-81) -- so
  * rank r of W runs sora_rx_* on its own block of captures in its own HBM (sora_shard_partition) and nothing is exchanged on

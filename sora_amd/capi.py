@@ -43,6 +43,11 @@ class FrameResult(ctypes.Structure):
                 ("flags", ctypes.c_uint16), ("mpdu_offset", ctypes.c_uint32)]
 
 
+class Ht40Frame(ctypes.Structure):
+    _fields_ = [("offset", ctypes.c_uint64), ("n_bpsc", ctypes.c_uint32), ("code_rate", ctypes.c_uint32), ("length", ctypes.c_uint32 * 2),
+                ("cfo", ctypes.c_int32), ("noise_var", ctypes.c_float), ("frame_id", ctypes.c_uint32)]
+
+
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
@@ -51,6 +56,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
+           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_process_dev", "sora_ht40_results",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results"]
 
@@ -111,6 +117,12 @@ def load(build_if_missing=True):
     L.sora_rx_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_set_fused.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_kernel_name_fused.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name_fused.restype = ctypes.c_char_p
+    L.sora_ht40_symbols.argtypes = [ctypes.c_uint32] * 4; L.sora_ht40_symbols.restype = ctypes.c_uint32
+    L.sora_ht40_create.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
+    L.sora_ht40_destroy.argtypes = [ctypes.c_void_p]; L.sora_ht40_destroy.restype = None
+    L.sora_ht40_stream.argtypes = [ctypes.c_void_p]; L.sora_ht40_stream.restype = ctypes.c_void_p
+    L.sora_ht40_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Ht40Frame), ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_ht40_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t]
     L.sora_shard_unique_id.argtypes = [ctypes.c_void_p]
     L.sora_shard_create.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p)]
     L.sora_shard_destroy.argtypes = [ctypes.c_void_p]; L.sora_shard_destroy.restype = None
@@ -462,6 +474,64 @@ class Rx11n:
             d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + min(r.length, 4096)].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
             out.append(d)
         return out
+
+
+class RxHt40:
+    """sora_ht40_t: the data field of HT-mixed 40 MHz two-stream frames (BASELINE configs[3]; parity unpinned, see include/sora_hip.h)."""
+
+    def __init__(self, max_frames, max_soft_values, device=0):
+        L = load()
+        h = ctypes.c_void_p()
+        _check(L.sora_ht40_create(device, max_frames, max_soft_values, ctypes.byref(h)))
+        self._h = h; self._L = L; self.max_frames = max_frames; self._keep = None
+
+    def close(self):
+        if self._h:
+            self._L.sora_ht40_destroy(self._h); self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def synchronize(self):
+        _check(self._L.sora_hip_stream_synchronize(self._L.sora_ht40_stream(self._h)))
+
+    @staticmethod
+    def frames(descs):
+        """[(offset, n_bpsc, code_rate, length0, length1, cfo, noise_var[, id])] -> packed descriptor array (reusable)"""
+        if isinstance(descs, ctypes.Array):
+            return descs
+        arr = (Ht40Frame * max(1, len(descs)))()
+        for i, d in enumerate(descs):
+            arr[i].offset = d[0]; arr[i].n_bpsc = d[1]; arr[i].code_rate = d[2]; arr[i].length[0] = d[3]; arr[i].length[1] = d[4]
+            arr[i].cfo = d[5]; arr[i].noise_var = d[6]; arr[i].frame_id = d[7] if len(d) > 7 else i
+        arr._n = len(descs)
+        return arr
+
+    def process_dev(self, d_iq0, d_iq1, descs, d_weights=None):
+        arr = self.frames(descs); n = getattr(arr, "_n", len(arr))
+        self._keep = (d_iq0, d_iq1, d_weights); self._n = n
+        _check(self._L.sora_ht40_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), arr, n, _dev_ptr(d_weights) if d_weights is not None else None))
+
+    def results(self, with_mpdu=True):
+        n2 = 2 * self._n
+        res = (FrameResult * max(1, n2))(); n = ctypes.c_size_t(0)
+        mp = np.zeros(n2 * 4096 if with_mpdu else 1, np.uint8)
+        _check(self._L.sora_ht40_results(self._h, res, n2, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        out = []
+        for r in res[:n.value]:
+            d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
+            d["stream"] = d["start_sample"]
+            if with_mpdu:
+                d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + r.length].tobytes()
+            out.append(d)
+        return out
+
+
+def ht40_symbols(length0, length1, n_bpsc, code_rate):
+    return load().sora_ht40_symbols(length0, length1, n_bpsc, code_rate)
 
 
 # ---- per-stage entry points on torch CUDA tensors ---------------------------------------------------

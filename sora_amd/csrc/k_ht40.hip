@@ -1,0 +1,399 @@
+// k_ht40.hip -- the data field of an 802.11n HT-mixed 40 MHz, two-stream frame (BASELINE.json configs[3]: "2x2 MIMO 40 MHz HT, 128-pt FFT,
+// MMSE MIMO detect, dual Viterbi"), SURVEY.md section 8(f)1 extension.  PARITY UNPINNED: the reference has no 40 MHz receive graph -- its
+// 802.11n graph is 20 MHz, zero-forcing, one decoder, MCS 8-10 (kernel/bb/Brick11/src/PHY_11n.hpp:497, channel_11n.hpp:423-433).  What IS
+// pinned is every piece the reference does have, used here unchanged:
+//   FFT<128>                      core/inc/fft_r4dif.h (fft128_group, pinned by tests/golden/ref_vectors.npz)
+//   TFreqComp_11n                 freqoffset_11n.hpp:162-280: sat((x * sincos(n cfo - theta)) >> 15), dsp_math tables
+//   TMimoChannelEst               channel_11n.hpp:329-443: P-matrix combination of the two HT-LTFs; with noise_var = 0 the weights are its
+//                                 2x2 inverse x 2^16, operation for operation (bit-exact with sora_hip_mimo_est11n on the same carriers)
+//   TMimoChannelComp              channel_11n.hpp:445-521: x = sat((W y) >> 9)
+//   TPilotTrack_11n               pilot_11n.hpp:84-141: theta += mean pilot phase (here over 6 pilots per stream, sum / 6)
+//   T11nDemap*                    demapper11n.hpp:89-309 and the dsp_demap.h tables (dev_11n.h)
+//   T11aViterbi<.., 192, 36>      k_viterbi11n, one decoder per spatial stream: the two streams of a frame are the two halves of one wave
+//   T11aDesc + TBB11aFrameSink    descrambler phase table + parallel CRC-32
+// New, from IEEE 802.11n-2009 clause 20: the 40 MHz carrier plan (108 data + 6 pilots per stream), the HT-LTF sequence for 40 MHz, the HT
+// interleaver parameters for 40 MHz (N_COL 18, N_ROW 6 N_BPSC, N_ROT 29), per-stream encoding, and the MMSE weights
+// W = diag((W' H)_ss)^-1 W', W' = (H^H H + s2 I)^-1 H^H (unbiased MMSE) in single precision (documented tolerance: +-1 LSB of the int16 weight against a float64 evaluation,
+// tests/test_gpu_ht40.py).  The model the tests generate captures with is oracle/py_ht40.py.
+#include <vector>
+#include <algorithm>
+#include <string.h>
+#include "kernels.h"
+#include "dev_11n.h"
+#include "../../include/sora_hip.h"
+
+namespace sora {
+
+struct Ht40Frame {
+    uint64_t offset;            // 40 MHz samples from the iq bases to the first sample (CP) of HT-LTF 1
+    uint32_t nsym, nb, code_rate;
+    uint32_t length[2];
+    int32_t  cfo;               // phase per 40 MHz sample, 65536 = 2 pi (TFreqComp_11n's vfo_step convention)
+    float    noise_var;         // per carrier, in LSB^2 of the FFT output; 0 = zero forcing
+    uint32_t soft_off[2];       // bytes from the soft base, per stream
+    uint32_t pad[3];
+};
+struct Ht40Args {
+    const uint32_t* iq0; const uint32_t* iq1; const Ht40Frame* frames; uint32_t nframes;
+    Tables T; const uint32_t* sincos; const short* atan;
+    uint8_t* soft;
+    uint32_t* w_out;            // optional [nframes][4][128]: the detection weights (tests)
+};
+struct Ht40Job { uint32_t out_off, length, row, pad; };
+struct Ht40FinishArgs { const Ht40Job* jobs; uint32_t njobs; const uint8_t* vout; uint8_t* mpdu; Rx11bRow* rows; Tables T; };
+
+namespace {
+static __constant__ int8_t kHtLtf40[117] = {    // carriers -58..58 (IEEE 802.11n-2009 eq. 20-24)
+    1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1,
+    -1, -1, -1, 1, 0, 0, 0, -1, 1, 1, -1,
+    1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
+__device__ __forceinline__ void wsync40() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ int data_bin40(int c)          // data carrier c (0..107) -> FFT bin: -58..-2 then 2..58 without +-11, +-25, +-53
+{
+    int k;
+    if (c < 54) { k = -58 + c; if (k >= -53) k++; if (k >= -25) k++; if (k >= -11) k++; }
+    else { k = 2 + (c - 54); if (k >= 11) k++; if (k >= 25) k++; if (k >= 53) k++; }
+    return k & 127;
+}
+__device__ __forceinline__ int deint40_index(int nb, int iss, int k)     // HT interleaver for 40 MHz: where coded bit k of stream iss sits in the symbol
+{
+    const int s = nb / 2 > 1 ? nb / 2 : 1, nrow = 6 * nb, np = 108 * nb;
+    const int i = nrow * (k % 18) + k / 18;
+    int j = s * (i / s) + (i + np - (18 * i) / np) % s;
+    if (iss > 0) j = ((j - ((iss * 2) % 3 + 3 * (iss / 3)) * 29 * nb) % np + np) % np;
+    return j;
+}
+struct Ht40Lds {
+    uint32_t buf[2][128];
+    uint32_t fft[2][128];
+    uint32_t y[2][2][128];          // [HT-LTF symbol / scratch][chain][bin]
+    uint32_t w[4][128];
+    uint32_t xs[2][128];
+    uint8_t  soft[2][656];
+    uint16_t dtab[2][648];
+};
+}  // namespace
+
+__global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
+{
+    __shared__ Ht40Lds s_w[4];
+    __shared__ uint8_t s_lut[6][256];
+    fill_demap_luts(s_lut);
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    const uint32_t f = blockIdx.x * 4 + wv;
+    if (f >= A.nframes) return;
+    Ht40Lds& W = s_w[wv];
+    const Ht40Frame F = A.frames[f];
+    const uint32_t* iq[2] = { A.iq0 + F.offset, A.iq1 + F.offset };
+    const int nb = (int)F.nb, cfo = F.cfo;
+    const int ncb = 108 * nb;
+    for (int k = lane; k < ncb; k += 64) { W.dtab[0][k] = (uint16_t)deint40_index(nb, 0, k); W.dtab[1][k] = (uint16_t)deint40_index(nb, 1, k); }
+    int theta = 0;
+    auto nosync = []() __attribute__((always_inline)) { wsync40(); };
+    // one 160-sample symbol starting at sample `pos` of the frame: TFreqComp_11n, cyclic prefix dropped, FFT<128> per chain (32 lanes each) -> W.y[slot]
+    auto symbol_fft = [&](uint32_t pos, int slot) __attribute__((always_inline)) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t n = pos + 32 + 64 * h + (uint32_t)lane;
+            const cpx cof = unpack(A.sincos[(unsigned)((int)n * cfo - theta) & 0xFFFFu]);
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                int re, im; mul32(unpack(iq[r][n]), cof, re, im);
+                W.buf[r][64 * h + lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
+            }
+        }
+        wsync40();
+        const int r = lane >> 5, e = lane & 31; cpx x[4], yy[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) x[m] = unpack(W.buf[r][e + 32 * m]);
+        fft128_group<false>(x, yy, W.fft[r], e, A.T, nosync);
+#pragma unroll
+        for (int q = 0; q < 4; q++) W.y[slot][r][e + 32 * q] = pack(yy[q]);
+        wsync40();
+    };
+    symbol_fft(0, 0);
+    symbol_fft(160, 1);
+    // ---- channel matrix per carrier (TMimoChannelEst's combination) and detection weights
+#pragma unroll
+    for (int hb = 0; hb < 2; hb++) {
+#pragma clang fp contract(off)
+        const int i = lane + 64 * hb, k = i < 64 ? i : i - 128;
+        const int ltf = (k >= -58 && k <= 58) ? (int)kHtLtf40[k + 58] : 0;
+        const bool negate = ltf != 1;
+        cpx hh[2][2];
+#pragma unroll
+        for (int r = 0; r < 2; r++) {
+            const cpx p = unpack(W.y[0][r][i]), q = unpack(W.y[1][r][i]);
+            cpx d = sra(csubs(p, q), 1), s = sra(cadds(p, q), 1);
+            if (negate) { d = mk(neg16(d.re), neg16(d.im)); s = mk(neg16(s.re), neg16(s.im)); }
+            hh[r][0] = d; hh[r][1] = s;
+        }
+        const cf a00 = { (float)hh[0][0].re, (float)hh[0][0].im }, a01 = { (float)hh[0][1].re, (float)hh[0][1].im };
+        const cf a10 = { (float)hh[1][0].re, (float)hh[1][0].im }, a11 = { (float)hh[1][1].re, (float)hh[1][1].im };
+        cf w00, w01, w10, w11;
+        if (F.noise_var == 0.0f) {
+            // zero forcing, exactly as TMimoChannelEst computes the inverse (brick/inc/sora_matrix.h:134-148,305-313)
+            const cf ad = cf_mul(a00, a11), bc = cf_mul(a01, a10);
+            const cf det = { ad.re - bc.re, ad.im - bc.im };
+            const float nn = ((det.re * det.re) + (det.im * det.im)) / 65536.0f;
+            const cf ds = { det.re, -det.im }, m01 = { -a01.re, -a01.im }, m10 = { -a10.re, -a10.im };
+            const cf r00 = cf_mul(a11, ds), r01 = cf_mul(m01, ds), r10 = cf_mul(m10, ds), r11 = cf_mul(a00, ds);
+            w00 = { r00.re / nn, r00.im / nn }; w01 = { r01.re / nn, r01.im / nn }; w10 = { r10.re / nn, r10.im / nn }; w11 = { r11.re / nn, r11.im / nn };
+        } else {
+            // MMSE: W = (H^H H + s2 I)^-1 H^H = adj(G) H^H / det(G), G Hermitian
+            auto cj = [](cf a) { return cf{ a.re, -a.im }; };
+            auto n2 = [](cf a) { return (a.re * a.re) + (a.im * a.im); };
+            const float g00 = (n2(a00) + n2(a10)) + F.noise_var, g11 = (n2(a01) + n2(a11)) + F.noise_var;
+            const cf t0 = cf_mul(cj(a00), a01), t1 = cf_mul(cj(a10), a11);
+            const cf g01 = { t0.re + t1.re, t0.im + t1.im };
+            const float det = ((g00 * g11) - n2(g01)) / 65536.0f;
+            auto row0 = [&](cf hc0, cf hc1) { const cf u = cf_mul(g01, hc1); return cf{ ((g11 * hc0.re) - u.re) / det, ((g11 * hc0.im) - u.im) / det }; };   // g11 conj(h_r0) - g01 conj(h_r1)
+            auto row1 = [&](cf hc0, cf hc1) { const cf u = cf_mul(cj(g01), hc0); return cf{ ((g00 * hc1.re) - u.re) / det, ((g00 * hc1.im) - u.im) / det }; }; // g00 conj(h_r1) - g10 conj(h_r0)
+            w00 = row0(cj(a00), cj(a01)); w01 = row0(cj(a10), cj(a11));
+            w10 = row1(cj(a00), cj(a01)); w11 = row1(cj(a10), cj(a11));
+            // unbiased: row s is divided by (W H)_ss = the gain the stream's own symbol comes out with, so that the constellation sits where
+            // the demapper's fixed tables expect it (at s2 = 0 that gain is 1)
+            const cf e0 = cf_mul(w00, a00), e1 = cf_mul(w01, a10), e2 = cf_mul(w10, a01), e3 = cf_mul(w11, a11);
+            const float beta0 = (e0.re + e1.re) / 65536.0f, beta1 = (e2.re + e3.re) / 65536.0f;
+            w00 = { w00.re / beta0, w00.im / beta0 }; w01 = { w01.re / beta0, w01.im / beta0 };
+            w10 = { w10.re / beta1, w10.im / beta1 }; w11 = { w11.re / beta1, w11.im / beta1 };
+        }
+        W.w[0][i] = pack(mk(cvtps_sat16(w00.re), cvtps_sat16(w00.im))); W.w[1][i] = pack(mk(cvtps_sat16(w01.re), cvtps_sat16(w01.im)));
+        W.w[2][i] = pack(mk(cvtps_sat16(w10.re), cvtps_sat16(w10.im))); W.w[3][i] = pack(mk(cvtps_sat16(w11.re), cvtps_sat16(w11.im)));
+        if (A.w_out) {
+#pragma unroll
+            for (int m = 0; m < 4; m++) A.w_out[((size_t)f * 4 + m) * 128 + i] = W.w[m][i];
+        }
+    }
+    wsync40();
+    // ---- data symbols, in order (the pilot phase of symbol d rotates symbol d + 1)
+    uint32_t* dst[2] = { reinterpret_cast<uint32_t*>(A.soft + F.soft_off[0]), reinterpret_cast<uint32_t*>(A.soft + F.soft_off[1]) };
+    for (uint32_t d = 0; d < F.nsym; d++) {
+        symbol_fft(320 + 160 * d, 0);
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {                                     // TMimoChannelComp
+            const int i = lane + 64 * hb;
+            const cpx p = unpack(W.y[0][0][i]), q = unpack(W.y[0][1][i]);
+            int ar, ai, br, bi;
+            mul32(unpack(W.w[0][i]), p, ar, ai); mul32(unpack(W.w[1][i]), q, br, bi);
+            W.xs[0][i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+            mul32(unpack(W.w[2][i]), p, ar, ai); mul32(unpack(W.w[3][i]), q, br, bi);
+            W.xs[1][i] = pack(mk(sat16((int)((unsigned)ar + (unsigned)br) >> 9), sat16((int)((unsigned)ai + (unsigned)bi) >> 9)));
+        }
+        wsync40();
+        {   // pilot phases: lane 8 s + k (k < 6) takes pilot k of stream s
+            const int k = lane & 7, sidx = (lane >> 3) & 1;
+            const int pk = k == 0 ? -53 : k == 1 ? -25 : k == 2 ? -11 : k == 3 ? 11 : k == 4 ? 25 : 53;
+            const cpx v = unpack(W.xs[sidx][pk & 127]);
+            int th = (k < 6) ? dsp_atan16(A.atan, v.re, v.im) : 0;
+            th += __shfl_xor(th, 1); th += __shfl_xor(th, 2); th += __shfl_xor(th, 4);
+            const int t0 = (int)(short)(__builtin_amdgcn_readfirstlane(__shfl(th, 0)) / 6), t1 = (int)(short)(__builtin_amdgcn_readfirstlane(__shfl(th, 8)) / 6);
+            theta = (int)(short)(theta + (int)(short)((t0 + t1) >> 1));
+        }
+#pragma unroll
+        for (int hb = 0; hb < 2; hb++) {                                     // T11nDemap*: I bits then Q bits per carrier
+            const int c = lane + 64 * hb;
+            if (c < 108) {
+                const int bin = data_bin40(c);
+#pragma unroll
+                for (int s = 0; s < 2; s++) {
+                    const cpx x = unpack(W.xs[s][bin]);
+                    const int re = min(max(x.re, -128), 127) + 128, im = min(max(x.im, -128), 127) + 128;
+                    uint8_t* o = W.soft[s] + c * nb;
+                    switch (nb) {
+                    case 1: o[0] = s_lut[0][re]; break;
+                    case 2: o[0] = s_lut[0][re]; o[1] = s_lut[0][im]; break;
+                    case 4: o[0] = s_lut[1][re]; o[1] = s_lut[2][re]; o[2] = s_lut[1][im]; o[3] = s_lut[2][im]; break;
+                    default: o[0] = s_lut[3][re]; o[1] = s_lut[4][re]; o[2] = s_lut[5][re]; o[3] = s_lut[3][im]; o[4] = s_lut[4][im]; o[5] = s_lut[5][im];
+                    }
+                }
+            }
+        }
+        wsync40();
+        // de-interleave per stream into its own decoder's soft stream: 16-bit fields v << 9, two per word
+#pragma unroll
+        for (int s = 0; s < 2; s++)
+            for (int w = lane; w < ncb / 2; w += 64)
+                dst[s][(size_t)d * (ncb / 2) + w] = ((uint32_t)W.soft[s][W.dtab[s][2 * w]] << 9) | ((uint32_t)W.soft[s][W.dtab[s][2 * w + 1]] << 25);
+        wsync40();
+    }
+}
+
+__global__ void __launch_bounds__(256) k_ht40_finish(Ht40FinishArgs A)
+{
+    __shared__ uint32_t s_crc[256];
+    __shared__ uint32_t s_z[6 * 8 * 16];
+    __shared__ uint32_t s_bufs[4][4096 / 4 + 2];
+    s_crc[threadIdx.x] = A.T.crc[threadIdx.x];
+    for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) s_z[i] = A.T.crcz[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
+    const uint32_t j = blockIdx.x * 4 + wv;
+    if (j >= A.njobs) return;
+    const Ht40Job J = A.jobs[j];
+    const uint8_t* dec = A.vout + J.out_off;
+    uint8_t* mp = A.mpdu + (size_t)J.row * 4096;
+    uint8_t* bytes = reinterpret_cast<uint8_t*>(s_bufs[wv]);
+    const uint32_t L = J.length;
+    const unsigned seed = dec[1] >> 1;
+    const unsigned phase = A.T.scr_phase[seed & 0x7F];
+    for (uint32_t i = lane; i < L; i += 64) {
+        const unsigned sb = phase == 255 ? 0u : A.T.scr_seq[(phase + 8u * i) % 127u];
+        const unsigned o = dec[2 + i] ^ sb;
+        bytes[i] = (uint8_t)o; mp[i] = (uint8_t)o;
+    }
+    wsync40();
+    const int n = L >= 4 ? (int)L - 4 : 0;
+    uint32_t crc;
+    if (n >= 4) crc = crc32_wave(bytes, n, s_crc, s_z, lane);
+    else { crc = 0xFFFFFFFFu; for (int i = 0; i < n; i++) crc = (crc >> 8) ^ s_crc[(bytes[i] ^ crc) & 0xFF]; }
+    if (lane == 0) {
+        uint32_t fcs = 0;
+        if (L >= 4) fcs = (uint32_t)bytes[L - 4] | ((uint32_t)bytes[L - 3] << 8) | ((uint32_t)bytes[L - 2] << 16) | ((uint32_t)bytes[L - 1] << 24);
+        Rx11bRow r; r.end_sample = 0; r.rate_kbps = 0; r.length = L; r.crc32 = fcs; r.error_code = ((~crc) == fcs) ? 1u : 0x80000006u;
+        A.rows[J.row] = r;
+    }
+}
+
+}  // namespace sora
+
+// ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
+using namespace sora;
+
+struct sora_ht40 {
+    int device = 0; uint32_t max_frames = 0; uint64_t max_soft = 0;
+    hipStream_t stream = nullptr;
+    Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
+    Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
+    uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_w = nullptr;
+    std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0; bool have_results = false;
+};
+
+#define HIPCHK40(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
+static constexpr uint32_t kVoutStride = 4352;
+
+static void ht40_free(sora_ht40_t* rx)
+{
+    if (!rx) return;
+    if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
+    (void)hipFree(rx->d_frames); (void)hipFree(rx->d_jobs); (void)hipFree(rx->d_njobs); (void)hipFree(rx->d_fjobs); (void)hipFree(rx->d_soft);
+    (void)hipFree(rx->d_vout); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_w);
+    delete rx;
+}
+
+static uint32_t ht40_ndbps(uint32_t nb, uint32_t cr) { return 108u * nb * (cr == 0 ? 1u : cr == 1 ? 2u : 3u) / (cr == 0 ? 2u : cr == 1 ? 3u : 4u); }
+
+uint32_t sora_ht40_symbols(uint32_t length0, uint32_t length1, uint32_t n_bpsc, uint32_t code_rate)
+{
+    if (!(n_bpsc == 1 || n_bpsc == 2 || n_bpsc == 4 || n_bpsc == 6) || code_rate > 2) return 0;
+    const uint32_t L = length0 > length1 ? length0 : length1, nd = ht40_ndbps(n_bpsc, code_rate);
+    return (16u + 8u * L + 6u + nd - 1) / nd;
+}
+
+int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out)
+{
+    if (!out || max_frames == 0 || max_soft_values == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_create: bad argument", 0);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
+    if (device < 0 || device >= ndev) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "device ordinal out of range", 0);
+    if (max_soft_values * 2 + 1024 >= (1ull << 32)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_create: max_soft_values exceeds the 32-bit offsets of one handle", 0);
+    HIPCHK40(hipSetDevice(device));
+    sora_ht40_t* rx = new sora_ht40();
+    rx->device = device; rx->max_frames = max_frames; rx->max_soft = max_soft_values;
+    const size_t nj = 2 * (size_t)max_frames;
+    hipError_t e = (sora_internal_tables(device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK) ? hipSuccess : hipErrorUnknown;
+    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_frames, sizeof(Ht40Frame) * max_frames);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * nj);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_njobs, 16);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_fjobs, sizeof(Ht40Job) * nj);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_soft, max_soft_values * 2 + 1024);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_vout, nj * kVoutStride + 256);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, nj * 4096);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * nj);
+    if (e == hipSuccess) e = hipMemset(rx->d_soft, 0, max_soft_values * 2 + 1024);
+    if (e == hipSuccess) e = hipMemset(rx->d_vout, 0, nj * kVoutStride + 256);
+    if (e != hipSuccess) { ht40_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_create: device allocation / tables", (int)e); }
+    *out = rx;
+    return SORA_OK;
+}
+
+void  sora_ht40_destroy(sora_ht40_t* rx) { if (rx) { (void)hipSetDevice(rx->device); ht40_free(rx); } }
+void* sora_ht40_stream(sora_ht40_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+
+int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
+{
+    if (!rx || (nframes && (!d_iq0 || !d_iq1 || !frames))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: null argument", 0);
+    if (nframes > rx->max_frames) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more frames than max_frames", 0);
+    HIPCHK40(hipSetDevice(rx->device));
+    HIPCHK40(hipStreamSynchronize(rx->stream));
+    std::vector<Ht40Frame> hf(nframes); std::vector<VitJob> hj(3 * 2 * (size_t)rx->max_frames); std::vector<Ht40Job> fj(2 * nframes);
+    uint32_t nj[4] = { 0, 0, 0, 0 };
+    uint64_t soft = 0;
+    const size_t stride = 2 * (size_t)rx->max_frames;
+    for (size_t i = 0; i < nframes; i++) {
+        const sora_ht40_frame& s = frames[i];
+        const uint32_t nsym = sora_ht40_symbols(s.length[0], s.length[1], s.n_bpsc, s.code_rate);
+        if (nsym == 0 || s.length[0] > 4000 || s.length[1] > 4000 || !(s.noise_var >= 0.0f)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: bad frame descriptor (n_bpsc 1/2/4/6, code_rate 0..2, PSDU <= 4000 bytes, noise_var >= 0)", 0);
+        Ht40Frame& F = hf[i];
+        F.offset = s.offset; F.nsym = nsym; F.nb = s.n_bpsc; F.code_rate = s.code_rate; F.length[0] = s.length[0]; F.length[1] = s.length[1]; F.cfo = s.cfo; F.noise_var = s.noise_var;
+        const uint64_t per = (uint64_t)nsym * 108 * s.n_bpsc;                       // soft values per stream
+        for (int k = 0; k < 2; k++) {
+            F.soft_off[k] = (uint32_t)(soft * 2);
+            VitJob& J = hj[s.code_rate * stride + nj[s.code_rate]++];                // the two streams of a frame are neighbours in their list: one wave decodes both
+            J.soft_off = F.soft_off[k]; J.nsoft = (uint32_t)per; J.length = s.length[k]; J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate; J.pad = 0;
+            fj[2 * i + k] = Ht40Job{ J.out_off, s.length[k], (uint32_t)(2 * i + k), 0 };
+            soft += (per + 31) / 32 * 32;
+        }
+        F.pad[0] = F.pad[1] = F.pad[2] = 0;
+    }
+    if (soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
+    rx->h_frames.assign(frames, frames + nframes); rx->nframes = (uint32_t)nframes; rx->have_results = true;
+    if (nframes == 0) return SORA_OK;
+    HIPCHK40(hipMemcpy(rx->d_frames, hf.data(), sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice));
+    HIPCHK40(hipMemcpy(rx->d_jobs, hj.data(), sizeof(VitJob) * hj.size(), hipMemcpyHostToDevice));
+    HIPCHK40(hipMemcpy(rx->d_njobs, nj, 16, hipMemcpyHostToDevice));
+    HIPCHK40(hipMemcpy(rx->d_fjobs, fj.data(), sizeof(Ht40Job) * fj.size(), hipMemcpyHostToDevice));
+    Ht40Args A;
+    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = rx->d_frames; A.nframes = (uint32_t)nframes;
+    A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = rx->d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights);
+    hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, rx->stream, A);
+    const uint32_t njobs = 2 * (uint32_t)nframes;
+    hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, rx->stream, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, (uint32_t)stride, (const uint8_t*)rx->d_soft, rx->d_vout);
+    Ht40FinishArgs Fi; Fi.jobs = rx->d_fjobs; Fi.njobs = njobs; Fi.vout = rx->d_vout; Fi.mpdu = rx->d_mpdu; Fi.rows = rx->d_rows; Fi.T = rx->T;
+    hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, rx->stream, Fi);
+    HIPCHK40(hipGetLastError());
+    return SORA_OK;
+}
+
+int sora_ht40_results(sora_ht40_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout || !out) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_results: null argument", 0);
+    *nout = 0;
+    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
+    if (rx->nframes == 0) return SORA_OK;
+    HIPCHK40(hipSetDevice(rx->device));
+    HIPCHK40(hipStreamSynchronize(rx->stream));
+    const size_t nj = 2 * (size_t)rx->nframes;
+    if (nj > max_out) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: two rows per frame are reported", 0);
+    std::vector<Rx11bRow> rows(nj);
+    HIPCHK40(hipMemcpy(rows.data(), rx->d_rows, sizeof(Rx11bRow) * nj, hipMemcpyDeviceToHost));
+    std::vector<uint8_t> bulk;
+    if (h_mpdu) { bulk.resize(nj * 4096); HIPCHK40(hipMemcpy(bulk.data(), rx->d_mpdu, bulk.size(), hipMemcpyDeviceToHost)); }
+    size_t moff = 0;
+    for (size_t j = 0; j < nj; j++) {
+        sora_frame_result& o = out[j];
+        memset(&o, 0, sizeof(o));
+        o.capture_id = rx->h_frames[j / 2].frame_id; o.start_sample = (uint32_t)(j & 1);                  // start_sample carries the spatial stream
+        o.error_code = rows[j].error_code; o.length = (uint16_t)rows[j].length; o.crc32 = rows[j].crc32; o.rate_kbps = rx->h_frames[j / 2].n_bpsc * 10 + rx->h_frames[j / 2].code_rate;
+        o.nsym = (uint16_t)sora_ht40_symbols(rx->h_frames[j / 2].length[0], rx->h_frames[j / 2].length[1], rx->h_frames[j / 2].n_bpsc, rx->h_frames[j / 2].code_rate);
+        o.mpdu_offset = (uint32_t)moff;
+        if (h_mpdu) {
+            if (moff + rows[j].length > mpdu_cap) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: MPDU buffer too small", 0);
+            memcpy(h_mpdu + moff, bulk.data() + j * 4096, rows[j].length); moff += rows[j].length;
+        }
+    }
+    *nout = nj;
+    return SORA_OK;
+}

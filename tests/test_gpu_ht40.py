@@ -1,0 +1,162 @@
+"""The 40 MHz HT two-stream data field on the GPU (sora_ht40_*, k_ht40.hip; BASELINE configs[3]).  PARITY UNPINNED -- the reference has no such
+receiver.  What is checked: (1) loop-back with the independent numpy model of the format (oracle/py_ht40.py, written from IEEE 802.11n-2009):
+every modulation and code rate, 2x2 channels with cross-talk, CFO, noise -- both streams' PSDUs come back with a good FCS; (2) the pieces the
+reference does have: with noise_var = 0 the detection weights are TMimoChannelEst's zero-forcing inverse bit for bit (sora_hip_mimo_est11n, itself
+pinned to the reference brick, on the same channel matrices); (3) the MMSE weights against a float64 evaluation, tolerance +-1 LSB of the int16
+weight (single-precision arithmetic on the GPU); (4) the unchanged trellis kernel decodes the two streams of a frame in one wave."""
+import numpy as np
+import pytest
+
+from oracle import py_ht40 as m
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    return torch, sora_amd
+
+
+def make_frames(rng, specs, sigma=8.0, cfo_step=0.0):
+    """specs: [(nbpsc, code_rate, len0, len1)] -> (iq [2, n, 2] int16, descriptors, psdus)"""
+    parts, descs, psdus, pos = [], [], [], 0
+    for i, (nb, cr, l0, l1) in enumerate(specs):
+        ps = [m.add_fcs(rng.integers(0, 256, l0 - 4, dtype=np.uint8).tobytes()), m.add_fcs(rng.integers(0, 256, l1 - 4, dtype=np.uint8).tobytes())]
+        x, nsym = m.tx(ps, nb, cr, seeds=(int(rng.integers(1, 128)), int(rng.integers(1, 128))))
+        ph = rng.uniform(0, 2 * np.pi, 4)
+        H = np.array([[1.0 * np.exp(1j * ph[0]), 0.35 * np.exp(1j * ph[1])], [0.3 * np.exp(1j * ph[2]), 0.9 * np.exp(1j * ph[3])]])
+        lead = 64 * int(rng.integers(0, 4))
+        y = m.channel(x, H, sigma, rng, cfo_step=cfo_step, lead=lead)
+        pad = (-y.shape[1]) % 64
+        y = np.concatenate([y, np.zeros((2, pad + 64, 2), np.int16)], axis=1)
+        descs.append((pos + lead, nb, cr, l0, l1, int(round(-cfo_step)), float(2 * sigma * sigma / 128.0), i))
+        parts.append(y); psdus.append(ps); pos += y.shape[1]
+    return np.concatenate(parts, axis=1), descs, psdus
+
+
+def comp0(x):
+    """TFreqComp_11n at cfo = 0, theta = 0: sat((x * (32767 + 0j)) >> 15) -- not the identity (positive values lose one LSB)"""
+    return ((x.astype(np.int64) * 32767) >> 15).astype(np.int16)
+
+
+def run(env, iq, descs, want_w=False):
+    torch, sora = env
+    nsoft = sum(2 * (sora.ht40_symbols(d[3], d[4], d[1], d[2]) * 108 * d[1] + 64) for d in descs)
+    rx = sora.RxHt40(len(descs), nsoft)
+    w = torch.zeros((len(descs), 4, 128, 2), dtype=torch.int16, device="cuda") if want_w else None
+    rx.process_dev(torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda(), descs, w)
+    res = rx.results(); rx.close()
+    return res, (w.cpu().numpy() if want_w else None)
+
+
+@pytest.mark.parametrize("nb,cr", [(1, 0), (2, 0), (2, 2), (4, 0), (4, 2), (6, 1), (6, 2)])
+def test_loopback_every_modulation_and_rate(env, nb, cr):
+    rng = np.random.default_rng(100 * nb + cr)
+    specs = [(nb, cr, int(rng.integers(30, 700)), int(rng.integers(30, 700))) for _ in range(6)] + [(nb, cr, 40, 1500), (nb, cr, 1500, 1500)]
+    iq, descs, psdus = make_frames(rng, specs, sigma=6.0)
+    res, _ = run(env, iq, descs)
+    assert len(res) == 2 * len(specs)
+    for r in res:
+        f, s = r["capture_id"], r["stream"]
+        assert r["error_code"] == 1, (nb, cr, f, s, hex(r["error_code"]))
+        assert r["mpdu"] == psdus[f][s], (nb, cr, f, s)
+
+
+def test_loopback_with_carrier_offset_and_mixed_batch(env):
+    rng = np.random.default_rng(7)
+    specs = [(int(rng.choice([1, 2, 4, 6])), int(rng.choice([0, 1, 2])), int(rng.integers(20, 900)), int(rng.integers(20, 900))) for _ in range(40)]
+    iq, descs, psdus = make_frames(rng, specs, sigma=5.0, cfo_step=37.0)      # 37 / 65536 of a turn per 40 MHz sample = 22.6 kHz
+    res, _ = run(env, iq, descs)
+    ok = sum(r["error_code"] == 1 and r["mpdu"] == psdus[r["capture_id"]][r["stream"]] for r in res)
+    assert ok == 2 * len(specs), ok
+
+
+def test_noise_decides_and_mmse_is_not_worse_than_zf(env):
+    """Over noise levels around the point where 64-QAM 3/4 begins to fail, the MMSE weights lose no more PSDUs than zero forcing (same captures)."""
+    good = {"zf": 0, "mmse": 0}; total = 0
+    for sigma in (90.0, 120.0, 150.0, 180.0):
+        rng = np.random.default_rng(int(sigma))
+        specs = [(6, 2, 300, 300)] * 32
+        iq, descs, psdus = make_frames(rng, specs, sigma=sigma)
+        for name, nv in (("zf", 0.0), ("mmse", None)):
+            d2 = [d if nv is None else d[:6] + (nv,) + d[7:] for d in descs]
+            res, _ = run(env, iq, d2)
+            good[name] += sum(r["error_code"] == 1 and r["mpdu"] == psdus[r["capture_id"]][r["stream"]] for r in res)
+        total += 2 * len(specs)
+    assert 0 < good["zf"] < total, (good, total)                            # the operating points really are marginal
+    assert good["mmse"] >= good["zf"], (good, total)
+
+
+def test_zero_forcing_weights_are_the_reference_bricks(env):
+    """noise_var = 0: the detection weights of carrier k equal TMimoChannelEst's inverse for the same channel matrix.  The 20 MHz brick
+    (sora_hip_mimo_est11n, pinned to the reference in tests/test_11n_stages.py) is fed the HT-LTF bins of 57 carriers at a time, with the
+    sign of the 40 MHz HT-LTF moved into the input so that both see the same H."""
+    torch, sora = env
+    rng = np.random.default_rng(5)
+    iq, descs, _ = make_frames(rng, [(2, 0, 60, 60)] * 3, sigma=4.0)
+    descs = [d[:6] + (0.0,) + d[7:] for d in descs]
+    _, w = run(env, iq, descs, want_w=True)
+    ltf20 = np.array([1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                      1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1, -1, -1])      # 20 MHz HT-LTF, -28..28
+    for f, d in enumerate(descs):
+        # the kernel's own FFT outputs are not exposed; rebuild them with the pinned FFT<128> stage from the frequency-compensated samples (cfo = 0 here)
+        off = d[0]
+        sym = comp0(np.stack([iq[r, off + 160 * s + 32: off + 160 * s + 160] for s in range(2) for r in range(2)]))   # [ltf sym, chain]
+        Y = sora.fft128(torch.from_numpy(sym.copy()).cuda()).cpu().numpy().reshape(2, 2, 128, 2)                      # [sym][chain][bin]
+        # a 40 MHz carrier is given to a 20 MHz bin whose HT-LTF sign is the same, so that the brick's sign rule is the kernel's
+        pool = {1: [b for b in range(-28, 29) if ltf20[b + 28] == 1], -1: [b for b in range(-28, 29) if ltf20[b + 28] == -1]}
+        todo = {1: [k for k in range(-58, 59) if m.HTLTF40[k + 58] == 1], -1: [k for k in range(-58, 59) if m.HTLTF40[k + 58] == -1]}
+        checked = 0
+        for sgn in (1, -1):
+            for k0 in range(0, len(todo[sgn]), len(pool[sgn])):
+                grp = todo[sgn][k0:k0 + len(pool[sgn])]
+                l0 = np.zeros((1, 128, 2), np.int16); l1 = np.zeros((1, 128, 2), np.int16)
+                for k, b20 in zip(grp, pool[sgn]):
+                    for sy in range(2):
+                        l0[0, 64 * sy + (b20 % 64)] = Y[sy, 0, k % 128]; l1[0, 64 * sy + (b20 % 64)] = Y[sy, 1, k % 128]
+                _, hinv = sora.mimo_est11n(torch.from_numpy(l0).cuda(), torch.from_numpy(l1).cuda())
+                hinv = hinv.cpu().numpy().reshape(2, 128, 2)
+                for k, b20 in zip(grp, pool[sgn]):
+                    got = w[f, :, k % 128]                                   # [4][2]: w00, w01, w10, w11
+                    want = np.stack([hinv[0, b20 % 64], hinv[0, 64 + b20 % 64], hinv[1, b20 % 64], hinv[1, 64 + b20 % 64]])
+                    assert np.array_equal(got, want), (f, k, got, want)
+                    checked += 1
+        assert checked == 114
+
+
+def test_mmse_weights_against_float64(env):
+    torch, sora = env
+    rng = np.random.default_rng(6)
+    iq, descs, _ = make_frames(rng, [(4, 0, 80, 80)] * 4, sigma=10.0)
+    nv = 3000.0
+    descs = [d[:6] + (nv,) + d[7:] for d in descs]
+    _, w = run(env, iq, descs, want_w=True)
+    worst = 0
+    for f, d in enumerate(descs):
+        off = d[0]
+        sym = comp0(np.stack([iq[r, off + 160 * s + 32: off + 160 * s + 160] for s in range(2) for r in range(2)]))
+        Y = sora.fft128(torch.from_numpy(sym.copy()).cuda()).cpu().numpy().reshape(2, 2, 128, 2).astype(np.int64)
+        for k in range(-58, 59):
+            v = int(m.HTLTF40[k + 58])
+            if v == 0:
+                continue
+            b = k % 128
+            def sat_half(a, c, sub):                                          # sra(csubs / cadds, 1) then the sign of the HT-LTF
+                z = np.clip(a - c if sub else a + c, -32768, 32767) >> 1
+                return z if v == 1 else -z
+            H = np.zeros((2, 2), complex)
+            for r in range(2):
+                p, q = Y[0, r, b], Y[1, r, b]
+                dd = sat_half(p, q, True); ss = sat_half(p, q, False)
+                H[r, 0] = dd[0] + 1j * dd[1]; H[r, 1] = ss[0] + 1j * ss[1]
+            W = np.linalg.solve(H.conj().T @ H + nv * np.eye(2), H.conj().T)
+            W = W / np.real(np.diag(W @ H))[:, None] * 65536.0                # unbiased: each stream's own gain is 1
+            want = np.array([[W[0, 0].real, W[0, 0].imag], [W[0, 1].real, W[0, 1].imag], [W[1, 0].real, W[1, 0].imag], [W[1, 1].real, W[1, 1].imag]])
+            if np.abs(want).max() > 32000:
+                continue
+            worst = max(worst, float(np.abs(w[f, :, b].astype(float) - want).max()))
+    assert worst <= 1.0, worst
