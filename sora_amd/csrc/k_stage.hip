@@ -348,19 +348,27 @@ __global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__
 {
     __shared__ uint32_t s_raw[kTileRaw / 4];
     __shared__ uint32_t s_out[kTileOut];
-    __shared__ int s_lin[2][12];                                                   // the interpolation weights, out of LDS (a per-lane index into constant memory is a cached global load)
     constexpr int NQ = kTileRaw / 16;                                              // 440 quad-words per tile: two per thread (the second for 184 threads)
     const int tid = threadIdx.x;
-    if (tid < 11) { s_lin[0][tid] = kLinR[tid]; s_lin[1][tid] = kLinL[tid]; }
     const bool dec = (flags & 8u) != 0, fix = (flags & 2u) != 0;
     const int nout = dec ? kTileOut / 2 : kTileOut;
-    auto X = [&](int i) -> cpx {                                                 // input sample i of the tile
-        cpx x = unpack(s_raw[(i / 28) * 32 + 4 + (i % 28)]);
-        if (fix) { x.re = w16(x.re << 2); x.im = w16(x.im << 2); }
-        return x;
-    };
     uint32_t tile = blockIdx.x;
     if (tile >= tiles) return;
+    // Which two input samples and which weights an output takes depends only on its index inside the tile: worked out once per thread (six outputs
+    // each), so that the per-tile work is two LDS reads, the sign fix as one packed shift, and the interpolation as two 16x16+16x16 dot products
+    // (v_dot2_i32_i16 wraps like the reference's pmaddwd; k = 0 is x * 128 >> 7 = x).
+    constexpr int PER = (kTileOut + 255) / 256;
+    int ia[PER], ib[PER]; uint32_t wrl[PER];
+#pragma unroll
+    for (int j = 0; j < PER; j++) {
+        const int m = tid + 256 * j, m1 = dec ? 2 * m : m;
+        const int p = m1 / 10, k = m1 - 10 * p;
+        const int a = 11 * p + k, b = k == 0 ? a : a + 1;
+        ia[j] = (a / 28) * 32 + 4 + (a % 28); ib[j] = (b / 28) * 32 + 4 + (b % 28);
+        const int R = k == 0 ? 128 : kLinR[k], L = k == 0 ? 0 : kLinL[k + 1];
+        wrl[j] = ((uint32_t)R & 0xFFFFu) | ((uint32_t)L << 16);
+        if (m >= nout) { ia[j] = ib[j] = 4; }
+    }
     const uint4* src = reinterpret_cast<const uint4*>(raw + (size_t)tile * kTileRaw);
     uint4 r0 = src[tid], r1 = tid + 256 < NQ ? src[tid + 256] : uint4{0, 0, 0, 0};
     for (;;) {
@@ -372,17 +380,15 @@ __global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__
             r0 = nsrc[tid]; if (tid + 256 < NQ) r1 = nsrc[tid + 256];
         }
         __syncthreads();
-        for (int m = tid; m < nout; m += 256) {
-            const int m1 = dec ? 2 * m : m;
-            const int p = m1 / 10, k = m1 - 10 * p;
-            cpx v;
-            if (k == 0) v = X(11 * p);
-            else {
-                const cpx a = X(11 * p + k), b = X(11 * p + k + 1);
-                const int R = s_lin[0][k], L = s_lin[1][k + 1];
-                v = mk(w16((a.re * R + b.re * L) >> 7), w16((a.im * R + b.im * L) >> 7));
-            }
-            s_out[m] = pack(v);
+#pragma unroll
+        for (int j = 0; j < PER; j++) {
+            const int m = tid + 256 * j;
+            pcx a = s_raw[ia[j]], b = s_raw[ib[j]];
+            if (fix) { a = __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, a) << (short)2)); b = __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, b) << (short)2)); }
+            const pcx re2 = (a & 0xFFFFu) | (b << 16), im2 = (a >> 16) | (b & 0xFFFF0000u);          // (a.re, b.re), (a.im, b.im)
+            const int vr = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, re2), __builtin_bit_cast(s16x2_t, wrl[j]), 0, false);
+            const int vi = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, im2), __builtin_bit_cast(s16x2_t, wrl[j]), 0, false);
+            if (m < nout) s_out[m] = (((uint32_t)vr >> 7) & 0xFFFFu) | (((uint32_t)vi << 9) & 0xFFFF0000u);
         }
         __syncthreads();
         uint4* dst = reinterpret_cast<uint4*>(out + (size_t)tile * nout);          // nout * 4 bytes is a multiple of 16
