@@ -34,7 +34,7 @@ def main():
            "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024 as reported",
            "kernels": {}}
     total = 0.0
-    rx_path = ("k_scan", "k_frame", "k_viterbi", "k_finish")                  # one receive call; other kernels (ingest, tx) are listed only
+    rx_path = ("k_scan", "k_frame", "k_viterbi", "k_decode", "k_finish")      # one receive call (split or fused chain); other kernels (k_pack, ingest, tx) are listed only
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
