@@ -22,7 +22,7 @@ namespace sora {
 // tap the oldest bit, so the decision-1 branch costs K - b0, K = 14 (7 on a punctured step).
 //
 // Decisions without a compare.  The reference marks the decision in the metric LSB; here the nine spare low bits of
-// the field do the same job: step k of an 8-step block adds 1 << k to the decision-1 candidate.  That bit breaks
+// the field do the same job: step k of an 8-step block adds 1 << k (frame A; 1 << (k + 1) in frame B's half, whose bit 0 is a carry guard) to the decision-1 candidate.  That bit breaks
 // ties exactly like the reference's LSB (a tie keeps branch 0), marks of earlier steps sit BELOW it and can never
 // decide a comparison, and after the minimum it IS the decision.  Because the marks travel with the metric through
 // the butterfly, after 8 steps the low byte of a lane is the decision history of the SURVIVOR PATH into the state
@@ -79,7 +79,8 @@ __device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-ha
 }
 
 constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
-constexpr unsigned kOne = 0x00010001u;                    // bit 0 of both halves
+constexpr unsigned kOne = 0x00020001u;                    // mark bit 0 of both frames: bit 0 (frame A), bit 17 (frame B; bit 16 is the carry guard, see acs_step)
+constexpr unsigned kGuard = 1u << 16;
 
 constexpr int kRingBlocks = 48;                           // 8-step blocks of survivor history kept in LDS per wave: a window walks <= 37 of them
 
@@ -113,10 +114,15 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     case 4: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0x4E, 0xF, 0xF, true); break;                   // L ^ 2: quad_perm [2,3,0,1]
     default: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, true); break;                  // L ^ 1: quad_perm [1,0,3,2]
     }
-    V.U = pk_min16(pk_add16(X, bm), pk_add16(Y, bo));
+    // The two sums are plain 32-bit adds (VOP2, and the cross-lane move of a DPP phase folds into its add: v_add_u32_dpp): the wrap of frame
+    // A's 7-bit metric carries into bit 16, which belongs to nobody -- frame B's marks start at bit 17.  The guard is the lowest bit of the high
+    // half, below the mark of the current step, which always differs between the two candidates: it can never decide the minimum; it is
+    // cleared after it.  (v_pk_add_u16 is VOP3P-encoded and issues at half the rate of a VOP2, profiles/r01_issue_probe_table.txt; the constants
+    // stay 32-bit literals: the same instructions with the constants pinned into SGPRs measured 1.5-10 % slower.)
+    V.U = pk_min16(X + bm, Y + bo) & ~kGuard;
     if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
         uint8_t* e = reinterpret_cast<uint8_t*>(V.ring + V.roff + V.sidx[t24 / 8]);
-        e[0] = (uint8_t)V.U; e[1] = (uint8_t)(V.U >> 16);                       // ds_write_b8 + ds_write_b8_d16_hi: frame A's block, frame B's block
+        e[0] = (uint8_t)V.U; e[1] = (uint8_t)(V.U >> 17);                       // frame A's block, frame B's block
         V.roff = V.roff + 64 == kRingBlocks * 64 ? 0u : V.roff + 64;
         V.U &= 0xFE00FE00u;
     }
@@ -146,7 +152,7 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     const unsigned stA = (kA >> 2) & 0x3F, stB = (kB >> 2) & 0x3F;
     const unsigned back = 6u - tr % 6u;                                         // label lane holding state s now: rol6(s, 6 - tr mod 6)
     const unsigned pA = (unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stA, back))) & 0xFFu;  // decisions of the unfinished block
-    const unsigned pB = ((unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stB, back))) >> 16) & 0xFFu;  // along the start state's path
+    const unsigned pB = ((unsigned)__builtin_amdgcn_readlane((int)U, (int)lane_map(rol6(stB, back))) >> 17) & 0xFFu;  // along the start state's path
     const int m_lo = (int)(ob >> 3);                                            // first output byte of the window
     const int j = (int)((tr - 1) >> 3);                                         // block holding the start column
     const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8

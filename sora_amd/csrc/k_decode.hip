@@ -237,7 +237,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     const uint32_t nsteps = max(A.nsteps, B.nsteps);
     uint32_t tr = 0, ob = 0;
 
-    auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };
+    auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // (no half borrows: a plain 32-bit subtraction)
     auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + 256u + 24u + 6u;
@@ -251,7 +251,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
             const int k = t24_last % 8;
             unsigned lastA, lastB;
             if (k == 7) { const unsigned w = ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
-            else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (16 + k)) & 1u; }
+            else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (17 + k)) & 1u; }
             const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
             const bool partial = tr >= ob + 256u + 24u + 6u;
             uint32_t cntA = 0, cntB = 0;

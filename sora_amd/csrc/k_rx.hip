@@ -209,7 +209,7 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     const uint32_t nsteps = max(A.nsteps, B.nsteps);
     uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
-    auto normalize = [&]() { V.U = pk_sub16(V.U, dpp_pkmin_wave(V.U)); };       // Normalize (viterbicore.h:444-465), both frames; marks are clear here
+    auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // Normalize (viterbicore.h:444-465), both frames; marks and guard are clear here and no half borrows (its minimum is subtracted): one 32-bit VOP2
     auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
@@ -223,7 +223,7 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
             const int k = t24_last % 8;                                         // the last decision: mark k of the field, or bit 7 of the block just banked
             unsigned lastA, lastB;
             if (k == 7) { const unsigned w = ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
-            else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (16 + k)) & 1u; }
+            else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (17 + k)) & 1u; }
             const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
             const bool partial = tr >= ob + (uint32_t)(WIN + LOOK + 6);
             uint32_t cntA = 0, cntB = 0;
