@@ -74,10 +74,15 @@ __device__ __forceinline__ unsigned wave_min(unsigned v)                // minim
     { const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false); v = min(r[0], r[1]); }
     return v;
 }
-__device__ __forceinline__ int scan_add(int v, int lane)               // inclusive prefix sum over the wave, wrapping
+__device__ __forceinline__ int scan_add(int v, int)                    // inclusive prefix sum over the wave, wrapping: six DPP adds, no LDS round trips
 {
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) { const int o = __shfl_up(v, d); if (lane >= d) v = (int)((unsigned)v + (unsigned)o); }
+    // inside each row of 16: row_shr:1, 2, 4, 8 (lanes shifted in read 0); then lane 15 of row r - 1 into rows 1 and 3, lane 31 into rows 2 and 3
+    v = (int)((unsigned)v + (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x111, 0xF, 0xF, true));
+    v = (int)((unsigned)v + (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x112, 0xF, 0xF, true));
+    v = (int)((unsigned)v + (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x114, 0xF, 0xF, true));
+    v = (int)((unsigned)v + (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x118, 0xF, 0xF, true));
+    v = (int)((unsigned)v + (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));   // row_bcast:15, rows 1 and 3
+    v = (int)((unsigned)v + (unsigned)__builtin_amdgcn_update_dpp(0, v, 0x143, 0xC, 0xF, false));   // row_bcast:31, rows 2 and 3
     return v;
 }
 }  // namespace
