@@ -210,7 +210,11 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
     auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // Normalize (viterbicore.h:444-465), both frames; marks and guard are clear here and no half borrows (its minimum is subtracted): one 32-bit VOP2
+#ifdef SORA_DBG_NO_TRACE                                                        // experiment (tools/ab_decode.sh): the forward pass alone -- results are wrong, only the duration means something
+    auto trace = [&](unsigned, unsigned, uint32_t, uint32_t) {};
+#else
     auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
+#endif
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
         if (!A.done) t = min(t, A.tr_end);

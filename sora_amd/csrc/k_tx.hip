@@ -40,13 +40,15 @@ __device__ __forceinline__ int qam_level(const uint8_t* bits, int M, int kmod)
 // 96..127 of a 128-point IFFT, >> 4, GI = last 32, first/last two samples halved, saturating 16 -> 8 bit pack.
 // s_bins: 128 words (zero outside the 64 bins), s_sym: 160 words; 32 lanes, e = lane of the group.
 template <typename SYNC>
-__device__ __forceinline__ void ifft_emit(uint32_t* s_bins, uint32_t* s_sym, int e, const Tables& T, int8_t* out8, SYNC sync)
+__device__ __forceinline__ void ifft_emit(uint32_t* s_bins, uint32_t* s_sym, int e, const Fft128Tw& tw, int8_t* out8, SYNC sync)
 {
     cpx x[4], y[4];
     sync();
 #pragma unroll
     for (int m = 0; m < 4; m++) x[m] = unpack(s_bins[e + 32 * m]);
-    fft128_group<true>(x, y, s_bins, e, T, sync);
+    fft128_core<true>(x, s_bins, e, tw, sync);
+#pragma unroll
+    for (int q = 0; q < 4; q++) y[q] = unpack(s_bins[__brev((unsigned)(e + 32 * q)) >> 25]);       // FFT128LUTMap = 7-bit bit reversal
 #pragma unroll
     for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pack(sra(y[q], 4));
     sync();
@@ -115,13 +117,15 @@ __device__ __forceinline__ unsigned coded_bit(BIT bit, int c, int code_rate)
 
 __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
 {
-    __shared__ uint8_t  s_data[2600];
+    __shared__ alignas(4) uint8_t s_data[2608];
+    __shared__ uint32_t s_ga[656], s_gb[656];                                    // generator outputs A (133) / B (171) of the whole data field, bit i of the stream = bit i & 31 of word i >> 5
     __shared__ uint32_t s_crc[256];
     __shared__ uint32_t s_z[6 * 8 * 16];
     __shared__ uint32_t s_bins[8][128];
     __shared__ uint32_t s_sym[8][160];
     __shared__ uint8_t  s_ib[8][288];
     __shared__ uint32_t s_fcs;
+    __shared__ uint16_t s_map[288 + 48];                                         // interleaver positions of the frame's modulation, then of the SIGNAL symbol (BPSK)
     const uint32_t f = blockIdx.x;
     const int tid = threadIdx.x, g = tid >> 5, e = tid & 31;
     const Tables& T = A.T;
@@ -144,7 +148,7 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
 
     s_crc[tid] = T.crc[tid];
     for (int i = tid; i < 6 * 8 * 16; i += 256) s_z[i] = T.crcz[i];
-    for (uint32_t i = tid; i < nbytes + 8; i += 256) s_data[i] = (i >= 2 && i < 2 + L) ? mp[i - 2] : (uint8_t)0;
+    for (uint32_t i = tid; i < nbytes + 8; i += 256) s_data[i] = (i >= 2 && i < 2 + L) ? mp[i - 2] : (uint8_t)0;       // (+ 8: the word-wise encoder reads up to 3 bytes past nbytes)
     __syncthreads();
     if (tid < 64) {                                                              // FCS of the MPDU (PHY_11a.hpp:87,160-170)
         uint32_t crc;
@@ -166,11 +170,30 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
     }
     for (int i = tid; i < 640; i += 256) reinterpret_cast<uint16_t*>(out)[i] = reinterpret_cast<const uint16_t*>(A.preamble)[i];
     __syncthreads();
+    // TConvEncode_* (conv_enc.hpp:6-14) 32 input bits at a time: A = x ^ x>>2 ^ x>>3 ^ x>>5 ^ x>>6, B = x ^ x>>1 ^ x>>2 ^ x>>3 ^ x>>6 over the bit
+    // stream (x>>k = the bit k positions EARLIER: shifted in from the previous word; the encoder starts from state 0)
+    {
+        const uint32_t* dw = reinterpret_cast<const uint32_t*>(s_data);
+        for (uint32_t w = tid; w < (nbytes + 3) / 4; w += 256) {
+            const uint32_t X = dw[w], P = w ? dw[w - 1] : 0u;
+            auto sh = [&](int k) { return (X << k) | (P >> (32 - k)); };
+            const uint32_t x2 = sh(2), x3 = sh(3), x6 = sh(6);
+            s_ga[w] = X ^ x2 ^ x3 ^ sh(5) ^ x6;
+            s_gb[w] = X ^ sh(1) ^ x2 ^ x3 ^ x6;
+        }
+    }
+    __syncthreads();
 
     // PLCP SIGNAL (ieee80211a_cmn.h:8-26): RATE, LENGTH, even parity
     uint32_t sig = (uint32_t)rc | ((L + 4) << 5);
     sig |= (uint32_t)(__popc(sig) & 1) << 17;
-    auto sync = []() { __syncthreads(); };
+    // From here on every LDS slice is private to a 32-lane group (half a wave): a wave-level barrier orders what the groups of a wave
+    // write and read, the waves of the block run free of each other (a block barrier per stage of every pass used to hold them together).
+    for (int i = tid; i < 48 * nb; i += 256) s_map[i] = T.deint[(nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288 + i];
+    if (tid < 48) s_map[288 + tid] = T.deint[tid];
+    const Fft128Tw tw = fft128_twiddles(T, e);
+    __syncthreads();
+    auto sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     const uint32_t total = 1 + nsym;                                             // SIGNAL + data symbols
     for (uint32_t s0 = 0; s0 < total; s0 += 8) {
         const uint32_t s = s0 + (uint32_t)g;
@@ -180,15 +203,23 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
         for (int i = e; i < 128; i += 32) s_bins[g][i] = 0;
         if (active) {
             // coded bits of the symbol, written at their interleaved positions
-            const uint16_t* map = T.deint + (snb == 1 ? 0 : snb == 2 ? 1 : snb == 4 ? 2 : 3) * 288;
+            const uint16_t* map = is_sig ? s_map + 288 : s_map;
             for (int k = e; k < N; k += 32) {
                 unsigned b;
                 if (is_sig) b = coded_bit([&](int i) -> unsigned { return i < 0 ? 0u : (sig >> i) & 1u; }, k, 0);
-                else b = coded_bit([&](int i) -> unsigned { return i < 0 ? 0u : (s_data[i >> 3] >> (i & 7)) & 1u; }, (int)(s - 1) * N + k, cr);
+                else {
+                    // punctured position c of the data field -> (input bit i, generator): 1/2 A B per bit, 2/3 A B A per 2 bits, 3/4 A1 B1 A2 B3 per 3 bits
+                    const int c = (int)(s - 1) * N + k;
+                    int i, which;
+                    if (cr == 0) { i = c >> 1; which = c & 1; }
+                    else if (cr == 1) { const int q = c / 3, r = c - 3 * q; i = 2 * q + (r == 2); which = r == 1; }
+                    else { const int q = c >> 2, r = c & 3; i = 3 * q + (r == 2 ? 1 : r == 3 ? 2 : 0); which = r & 1; }
+                    b = ((which ? s_gb : s_ga)[i >> 5] >> (i & 31)) & 1u;
+                }
                 s_ib[g][map[k]] = (uint8_t)b;
             }
         }
-        __syncthreads();
+        sync();
         if (active) {
             // TMap11a* + T11aAddPilot (mapper11a.hpp, pilot.hpp:76-118): carriers in the order -26..-1, +1..+26 without pilots
             const int kmod = kmod_of(snb);
@@ -207,8 +238,8 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
                 s_bins[g][bin < 32 ? bin : bin + 64] = pack(mk(e == 1 ? -p : p, 0));
             }
         }
-        ifft_emit(s_bins[g], s_sym[g], e, T, active ? out + 2 * (640 + 160 * (size_t)s) : (int8_t*)nullptr, sync);
-        __syncthreads();
+        ifft_emit(s_bins[g], s_sym[g], e, tw, active ? out + 2 * (640 + 160 * (size_t)s) : (int8_t*)nullptr, sync);
+        sync();
     }
 }
 
