@@ -89,6 +89,15 @@ python3 "$HERE/ref_flatten.py" "$TMP/flat_mt" mt
     -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" \
     -I"$TMP/flat_mt" "$HERE/ref_graph_mt_shim.cpp" -o "$OUT/libsora_refgraph_mt.so" &
 PID_MT=$!
+# ---- the LEGACY 802.11a receiver (kernel/bb/dot11a: the C path behind BB11ARxFrameDemod), the second cross-check oracle of SURVEY section 8 f4
+python3 "$HERE/ref_flatten.py" "$TMP/flat_legacy" legacy
+cp "$HERE/ref_legacy_rxstream.h" "$TMP/flat_legacy/ref_legacy_rxstream.h"
+"$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden -pthread \
+    -fms-extensions -fms-compatibility -fms-compatibility-version=19.00 -fdelayed-template-parsing -fno-operator-names \
+    -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -DSTATIC_LUT -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" -include "$HERE/ref_legacy_pre.h" \
+    -I"$TMP/flat_legacy" -I"$TMP/flat_legacy/bb" -I"$TMP/flat_legacy/inc" "$HERE/ref_legacy_shim.cpp" -o "$OUT/libsora_reflegacy.so" &
+PID_LEGACY=$!
 wait $PID_KERNELS; echo "build_ref.sh: built $OUT/libsora_ref.so"          # the three compiles run side by side; set -e stops on the first failure
 wait $PID_GRAPH;   echo "build_ref.sh: built $OUT/libsora_refgraph.so"
 wait $PID_MT;      echo "build_ref.sh: built $OUT/libsora_refgraph_mt.so"
+wait $PID_LEGACY;  echo "build_ref.sh: built $OUT/libsora_reflegacy.so"

@@ -13,6 +13,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(HERE, "_build", "libsora_oracle.so")
 REF_SO = os.path.join(HERE, "_ref", "libsora_ref.so")
 REFGRAPH_SO = os.path.join(HERE, "_ref", "libsora_refgraph.so")
+REFLEGACY_SO = os.path.join(HERE, "_ref", "libsora_reflegacy.so")
 
 E_SUCCESS = 0x0
 E_FRAME_OK = 0x1
@@ -55,9 +56,10 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE])
     ref_root = os.environ.get("SORA_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref_root, "kernel", "core", "inc")):
-        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_graph_mt_shim.cpp", "ref_flatten.py", "ref_compat.h", "build_ref.sh")]
+        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_graph_mt_shim.cpp", "ref_legacy_shim.cpp", "ref_legacy_pre.h", "ref_legacy_rxstream.h",
+                                                "ref_flatten.py", "ref_compat.h", "build_ref.sh")]
         if force or any(not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
-                        for so in (REF_SO, REFGRAPH_SO, os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_mt.so"))):
+                        for so in (REF_SO, REFGRAPH_SO, os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_mt.so"), REFLEGACY_SO)):
             subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
 
 
@@ -320,6 +322,42 @@ class Reference:
 
 class RefFrame(ctypes.Structure):
     _fields_ = [(n, ctypes.c_uint32) for n in ("error_code", "sample_index", "rate_kbps", "length", "crc32", "mpdu_offset")]
+
+
+class LegacyEvent(ctypes.Structure):
+    _fields_ = [("hr", ctypes.c_int32), ("rate_code", ctypes.c_uint32), ("length", ctypes.c_uint32), ("crc_ok", ctypes.c_uint32), ("block_pos", ctypes.c_uint64)]
+
+
+LEGACY_RATE_KBPS = {0xB: 6000, 0xF: 9000, 0xA: 12000, 0xE: 18000, 0x9: 24000, 0xD: 36000, 0x8: 48000, 0xC: 54000}     # bba.h: DOT11A_RATE_*
+BB11A_OK_FRAME, BB11A_E_CRC32 = 0x202, 0x80006004 - (1 << 32)
+
+
+class ReferenceLegacy:
+    """The reference's LEGACY 802.11a receiver (kernel/bb/dot11a: BB11ARxCarrierSense / BB11ARxFrameDemod + the Viterbi worker thread), compiled from its
+    sources into oracle/_ref/libsora_reflegacy.so: the second cross-check oracle of SURVEY section 8 f4.  One instance per process (static context)."""
+    def __init__(self):
+        if not os.path.exists(REFLEGACY_SO):
+            try:
+                build()
+            except Exception:
+                pass
+        self.L = ctypes.CDLL(REFLEGACY_SO) if os.path.exists(REFLEGACY_SO) else None
+
+    def available(self): return self.L is not None
+
+    def rx11a(self, iq40, max_frames=64):
+        """CsFrameDemod (demod11a.cpp:52-185) over int16 [n,2] @40 MHz -> list of dict: hr (BB11A_OK_FRAME 0x202 / error), rate_kbps, length (incl. FCS),
+        crc_ok, block (RX blocks of 28 samples consumed when the frame ended), mpdu (length bytes, for OK and CRC32 results)."""
+        a = np.ascontiguousarray(iq40, np.int16).reshape(-1, 2)
+        ev = (LegacyEvent * max_frames)(); fb = np.zeros(max_frames * 4096, np.uint8)
+        n = self.L.ref_legacy_rx11a(_P(a), len(a) // 28 * 28, ev, max_frames, _P(fb), fb.size)
+        out = []; used = 0
+        for e in ev[:n]:
+            d = {"hr": e.hr & 0xFFFFFFFF, "rate_kbps": LEGACY_RATE_KBPS.get(e.rate_code & 0xF, 0), "length": e.length, "crc_ok": bool(e.crc_ok), "block": e.block_pos, "mpdu": b""}
+            if d["hr"] in (0x202, 0x80006004) and e.length >= 4 and used + e.length <= fb.size:
+                d["mpdu"] = fb[used:used + e.length].tobytes(); used += e.length
+            out.append(d)
+        return out
 
 
 class ReferenceGraph:

@@ -16,6 +16,7 @@ import sys
 REF = os.environ.get("SORA_REFERENCE", "/root/reference") + "/kernel"
 OUT = sys.argv[1]
 KEEP_SEPARATOR_11A = len(sys.argv) > 2 and sys.argv[2] == "mt"     # libsora_refgraph_mt.so: the 11a graph with its real thread boundary
+LEGACY = len(sys.argv) > 2 and sys.argv[2] == "legacy"            # libsora_reflegacy.so: the legacy dot11a C receiver (kernel/bb/dot11a), SURVEY section 8 f4
 
 shutil.rmtree(OUT, ignore_errors=True)
 os.makedirs(OUT + "/bb")
@@ -24,6 +25,19 @@ for d in ("core/inc", "brick/inc", "bb/Brick11/src", "bb/demod11", "inc"):
         shutil.copy(f, OUT + "/" + os.path.basename(f))
 for f in glob.glob(f"{REF}/inc/bb/*.h"):
     shutil.copy(f, OUT + "/bb/" + os.path.basename(f))
+if LEGACY:
+    # kernel/bb/dot11a: the sources of the legacy receiver (dot11/*.c, mod/*.c), its headers (inc/bb/mod.h, inc/bb/mod/*.h, inc/lut.h) and the
+    # static look-up tables it links (lutst/*.c), laid out so that both spellings of its includes resolve ("bb/mod/x.h", "../inc/bb/mod.h")
+    D = REF + "/bb/dot11a"
+    for sub in ("bb/mod", "inc/bb/mod", "dot11", "lutst"):
+        os.makedirs(OUT + "/" + sub, exist_ok=True)
+    for f in glob.glob(D + "/inc/bb/mod/*.h"):
+        shutil.copy(f, OUT + "/bb/mod/" + os.path.basename(f)); shutil.copy(f, OUT + "/inc/bb/mod/" + os.path.basename(f))
+    shutil.copy(D + "/inc/bb/mod.h", OUT + "/bb/mod.h"); shutil.copy(D + "/inc/bb/mod.h", OUT + "/inc/bb/mod.h"); shutil.copy(D + "/inc/lut.h", OUT + "/lut.h")
+    for f in glob.glob(D + "/dot11/*.c") + glob.glob(D + "/dot11/*.h") + glob.glob(D + "/mod/*.c"):
+        shutil.copy(f, OUT + "/dot11/" + os.path.basename(f))
+    for f in glob.glob(D + "/lutst/*.c"):
+        shutil.copy(f, OUT + "/lutst/" + os.path.basename(f))
 
 
 # ---- the Windows integer model (LLP64): the keyword `long` is 32 bits for the compiler the reference was written for, 64 here.
@@ -133,3 +147,13 @@ edit("stdbrick.hpp", lambda s: s.replace("Next0()->Process(ipin.clone());", "{ a
 edit("brick.h", lambda s: s.replace("        const char *self = typeid(*this).name();",
      '        char self[2048]; { int st_; char* d_ = abi::__cxa_demangle(typeid(*this).name(), 0, 0, &st_);'
      ' snprintf(self, sizeof(self), "class %s", d_ ? d_ : ""); free(d_); }'))
+
+if LEGACY:
+    write("timing.h", "#pragma once\n")                                   # bba.h: "../timing.h" (the TIMINGINFO stop-watch: oracle/ref_legacy_shim.cpp)
+    for d in ("bb/mod", "inc/bb/mod"):
+        # a path that climbs out of the tree it was written in
+        edit(d + "/afreq.h", lambda s: s.replace('"../../../../../brick/inc/bb_debug.h"', '"bb_debug.h"')
+             # a temporary bound to a non-const reference (an MSVC extension)
+             .replace("vcs m2 = (vcs)mul_high((vs&)flip(a), sin_nsin);", "vcs fl_ = flip(a); vcs m2 = (vcs)mul_high((vs&)fl_, sin_nsin);"))
+        # SoraRadioReadRxStream (core/inc/rxstream.h:8-37) belongs to the radio manager; the offline harness's version of it is in the shim
+        edit(d + "/fetchdt.h", lambda s: s.replace('#include "44MTo40M.h"', '#include "44MTo40M.h"\n#include "ref_legacy_rxstream.h"'))
