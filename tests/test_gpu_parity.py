@@ -512,3 +512,33 @@ def test_fused_decode_kernel_full_batch_equals_the_reference_graph(sora, torch_c
         ok, why = bench.check_against_reference(rx.results(ticket=t), kind, want, range(nfr))
         assert ok, why
     rx.close()
+
+
+def test_gpu_mpdus_equal_the_legacy_receivers(sora, torch_cuda, oracle):
+    """The second cross-check oracle: the reference's LEGACY dot11a C receiver compiled from its sources
+    (oracle/_ref/libsora_reflegacy.so, tests/test_oracle_legacy.py).  An independent implementation: every frame it decodes with a good FCS the
+    GPU path decodes too, to the same bytes."""
+    from oracle.pyoracle import ReferenceLegacy
+    lg = ReferenceLegacy()
+    if not lg.available():
+        pytest.skip("oracle/_ref/libsora_reflegacy.so not present")
+    rng = np.random.default_rng(416)
+    caps, want = [], []
+    for i in range(48):
+        rate = RATES[i % 8]; ln = int(rng.integers(20, 1400))
+        mp = rng.integers(0, 256, ln).astype(np.uint8).tobytes()
+        cap = oracle.tx_capture(mp, rate, lead=int(rng.integers(300, 900)) // 28 * 28, tail=1400)
+        if i % 3:
+            cap = awgn(cap, [0, 150, 450][i % 3], i)
+        cap = cap[:len(cap) // 28 * 28]
+        ev = [e for e in lg.rx11a(cap) if e["hr"] == 0x202]
+        caps.append(cap); want.append(ev[0] if ev else None)
+    got = run_rx(sora, torch_cuda, caps, 40)
+    n = 0
+    for i, w in enumerate(want):
+        if w is None:
+            continue
+        rows = [r for r in got if r["capture_id"] == i and r["error_code"] == E_FRAME_OK]
+        assert len(rows) == 1 and rows[0]["mpdu"] == w["mpdu"] and rows[0]["rate_kbps"] == w["rate_kbps"] and rows[0]["length"] == w["length"], i
+        n += 1
+    assert n >= 40, n
