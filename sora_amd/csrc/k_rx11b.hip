@@ -40,13 +40,20 @@ __device__ __forceinline__ uint32_t dot_sign(int rre, int rim, int xre, int xim)
 { return ((uint32_t)(rre * xre) + (uint32_t)(rim * xim)) >> 31; }
 }  // namespace
 
-__global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
+// Two instantiations.  CCK = false is the kernel for what nearly every capture holds (Barker-spread 1 / 2 Mbps frames): without the CCK decoders it
+// fits 64 VGPRs and runs 8 waves per SIMD.  When a header announces 5.5 / 11 Mbps it abandons the capture and flags it; the CCK = true instantiation
+// (125 VGPRs, 4 waves per SIMD) then redoes the flagged captures from their first sample.  Both write the same rows: the result is what one kernel
+// with everything inlined gives (that single kernel cost every capture 7-13 % of its speed).
+template <bool CCK>
+__device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
 {
     __shared__ uint8_t s_out_all[4][kOutBuf];
     __shared__ int s_state_all[4][32];                                  // per wave: [0..19] TBarkerSync partial sums, [20..27] TEnergyDetect window
     const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));      // wave-uniform values are told to be so: state then lives in SGPRs
     const uint32_t cap_i = blockIdx.x * 4 + wave;
     if (cap_i >= A.ncaps) return;
+    if (CCK && uni((int)A.needs_cck[cap_i]) == 0) return;
+    int cck_abort = 0;
     uint8_t* s_out = s_out_all[wave];
     int* const p_re = s_state_all[wave]; int* const p_im = p_re + 10; uint32_t* const win = reinterpret_cast<uint32_t*>(p_re + 20);
     if (lane < 32) p_re[lane] = 0;
@@ -132,6 +139,7 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
         default:   rate_kbps = 0; len = 0;
         }
         frame_length = len; plcp_data = 1;
+        if (!CCK && uni(rxrate) > RATE_2M) { cck_abort = 1; error_code = E_NOT_SUPPORTED; }        // this capture goes to the CCK instantiation
     };
     // ---- TDesc741 (scramble.hpp:93-170) -> TBB11bPlcpSwitch (PHY_11b.hpp:459-519)
     auto byte_out = [&](uint32_t b) __attribute__((always_inline)) {
@@ -225,6 +233,7 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
     };
     // ---- TBB11bRxRateSel ports 3 / 4: chips k0 .. k0+n-1 of the block (lane k = chip k, packed) join the queue; a full burst is decoded
     auto cck_push = [&](uint32_t chips, int k0, int n) __attribute__((always_inline)) {
+        if constexpr (CCK) {
         const uint32_t moved = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane - cck_n + k0) & 63), (int)chips);
         if (lane >= cck_n && lane < cck_n + n) cbuf = moved;
         cck_n += n;
@@ -234,6 +243,7 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
             cbuf = (uint32_t)__builtin_amdgcn_ds_bpermute(4 * ((lane + need) & 63), (int)cbuf);
             cck_n -= need;
             byte_out(b);
+        }
         }
     };
     // ---- one despread symbol into the brick the rate selector's port leads to
@@ -445,6 +455,7 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
             }
         }
         // ---- MAC11b_Receive bookkeeping after the source call (fb11b_demod.cpp:31-70)
+        if (!CCK && uni(cck_abort)) { if (lane == 0) A.needs_cck[cap_i] = 1u; return; }
         if (error_code != 0) {
             const uint32_t err = error_code;
             if (err != E_CS_TIMEOUT) {
@@ -473,9 +484,11 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
                     sym_timing(padded); qoff = 0;
                 }
                 if (uni(rxrate) <= RATE_2M && chip_n > 0) { const int sre = acc_re, sim = acc_im; chip_n = 0; acc_re = acc_im = 0; symbol_out(uni(rxrate), sre, sim); }
+                if constexpr (CCK) {
                 if (uni(rxrate) > RATE_2M && cck_n > 0) {               // opin3/4().pad(): zero chips complete the burst, one more byte comes out
                     const uint32_t w = lane < cck_n ? cbuf : 0u; cck_n = 0;
                     byte_out(uni(rxrate) == RATE_5P5M ? cck5p5_decode(w) : cck11_decode(w));
+                }
                 }
             }
             graph_reset();
@@ -485,6 +498,9 @@ __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A)
     }
     if (lane == 0) A.nframes[cap_i] = nfr;
 }
+
+__global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A) { rx11b_capture<false>(A); }
+__global__ void __launch_bounds__(256, 4) k_rx11b_cck(Rx11bArgs A) { rx11b_capture<true>(A); }
 
 }  // namespace sora
 
@@ -498,7 +514,7 @@ using namespace sora;
 struct sora_rx11b {
     sora_rx_cfg cfg{};
     hipStream_t stream = nullptr;
-    CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr;
+    CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_needs_cck = nullptr;
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
     std::vector<sora_capture_desc> h_caps;
@@ -512,7 +528,7 @@ static void rx11b_free(sora_rx11b_t* rx)
 {
     if (!rx) return;
     if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
-    (void)hipFree(rx->d_caps); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_nframes); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_iq_own);
+    (void)hipFree(rx->d_caps); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_nframes); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_iq_own); (void)hipFree(rx->d_needs_cck);
     delete rx;
 }
 
@@ -535,6 +551,7 @@ int sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out)
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures);
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * rows);
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures);
+    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_needs_cck, 4 * (size_t)cfg->max_captures);
     if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, rows * 4096);
     if (e != hipSuccess) { rx11b_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11b_create: device allocation", (int)e); }
     *out = rx;
@@ -566,8 +583,10 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     HIPCHK11(hipMemcpyAsync(rx->d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, rx->stream));
     Rx11bArgs A;
     A.iq = reinterpret_cast<const uint32_t*>(d_iq); A.caps = rx->d_caps; A.ncaps = (uint32_t)ncaps; A.thr = rx->cfg.cca_pwr_threshold;
-    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.crc = rx->d_crc;
+    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.crc = rx->d_crc; A.needs_cck = rx->d_needs_cck;
+    HIPCHK11(hipMemsetAsync(rx->d_needs_cck, 0, 4 * ncaps, rx->stream));
     hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);
+    hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)
     HIPCHK11(hipGetLastError());
     return SORA_OK;
 }

@@ -87,8 +87,10 @@ struct Rx11bArgs {
     uint32_t*       nframes;    // [ncaps]
     uint8_t*        mpdu;       // [ncaps*max_frames][4096]
     const uint32_t* crc;        // CRC-32 table
+    uint32_t*       needs_cck;  // [ncaps]: set by the first pass for a capture in which a header announces 5.5 / 11 Mbps; such captures are redone by k_rx11b_cck
 };
 __global__ void k_rx11b(Rx11bArgs A);
+__global__ void k_rx11b_cck(Rx11bArgs A);
 
 }  // namespace sora
 
