@@ -363,6 +363,63 @@ __device__ __forceinline__ void fft128_core_pk(const pcx x[4], uint32_t* s, int 
     sync();
 }
 
+// ---- the inverse transform on packed values (IFFT<128>, core/inc/ifft_r4dif.h): conj_mul_shift negates the DATA's real part (neg16, wrapping: -32768
+// stays -32768), which on packed values is one v_pk_mul_lo_u16 by (0xFFFF, 1); the twiddles go in as they are
+__device__ __forceinline__ pcx pk_neg16_lo(pcx a)
+{
+    typedef unsigned short u16x2p_t __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(pcx, (u16x2p_t)(__builtin_bit_cast(u16x2p_t, a) * u16x2p_t{ (unsigned short)0xFFFFu, (unsigned short)1u }));
+}
+__device__ __forceinline__ pcx pk_conj_cmul15(pcx x, pcx w)              // conj_mul_shift15(x, w): ((x.re w.re + x.im w.im) >> 15, (x.im w.re + neg16(x.re) w.im) >> 15)
+{
+    const int v0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, x), __builtin_bit_cast(s16x2_t, w), 0, false);
+    const int v1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, pk_neg16_lo(x)), __builtin_bit_cast(s16x2_t, pk_swap(w)), 0, false);
+    return (((uint32_t)v0 >> 15) & 0xFFFFu) | (((uint32_t)v1 << 1) & 0xFFFF0000u);
+}
+__device__ __forceinline__ void pk_r4_inv(pcx x0, pcx x1, pcx x2, pcx x3, const uint32_t (&w)[3], pcx& y0, pcx& y1, pcx& y2, pcx& y3)
+{
+    const pcx a = pk_sra(x0, 2), b = pk_sra(x1, 2), c = pk_sra(x2, 2), d = pk_sra(x3, 2);
+    const pcx ac = pk_adds(a, c), bd = pk_adds(b, d), a_c = pk_subs(a, c), b_d = pk_subs(b, d);
+    const pcx jb = pk_mul_j(b_d);
+    y0 = pk_adds(ac, bd);
+    y1 = pk_conj_cmul15(pk_subs(ac, bd), w[1]);
+    y2 = pk_conj_cmul15(pk_adds(a_c, jb), w[0]);
+    y3 = pk_conj_cmul15(pk_subs(a_c, jb), w[2]);
+}
+// fft128_core<true> on packed values; the 8-point terminal stage shared by a lane pair as in fft128_core_pk
+template <typename SYNC>
+__device__ __forceinline__ void ifft128_core_pk(const pcx x[4], uint32_t* s, int e, const Fft128Tw& W, SYNC sync)
+{
+    sync();
+    pk_r4_inv(x[0], x[1], x[2], x[3], W.w128, s[e], s[e + 32], s[e + 64], s[e + 96]);
+    sync();
+    {
+        const int base = 32 * (e >> 3) + (e & 7);
+        pcx y0, y1, y2, y3;
+        pk_r4_inv(s[base], s[base + 8], s[base + 16], s[base + 24], W.w32, y0, y1, y2, y3);
+        s[base] = y0; s[base + 8] = y1; s[base + 16] = y2; s[base + 24] = y3;
+    }
+    sync();
+    {
+        const bool hi = e & 1;                                                    // difference half
+        uint32_t* p = s + 8 * (e >> 1);
+        const uint4 A = reinterpret_cast<const uint4*>(p)[0], B = reinterpret_cast<const uint4*>(p)[1];
+        pcx v[4];
+        const pcx a[4] = { pk_sra(A.x, 3), pk_sra(A.y, 3), pk_sra(A.z, 3), pk_sra(A.w, 3) }, b[4] = { pk_sra(B.x, 3), pk_sra(B.y, 3), pk_sra(B.z, 3), pk_sra(B.w, 3) };
+#pragma unroll
+        for (int q = 0; q < 4; q++) v[q] = hi ? pk_subs(a[q], b[q]) : pk_adds(a[q], b[q]);
+        if (hi) { v[2] = pk_mul_j(v[2]); v[3] = pk_mul_j(v[3]); }                 // ee[2], ee[3] = (~im, re): +j d
+        pcx g0 = pk_adds(v[0], v[2]), g1 = pk_adds(v[1], v[3]), g2 = pk_adds(~v[2], v[0]), g3 = pk_adds(~v[3], v[1]);
+        if (hi) { g0 = pk_conj_cmul15(g0, W.w8[0]); g1 = pk_conj_cmul15(g1, W.w8[1]); g2 = pk_conj_cmul15(g2, W.w8[2]); g3 = pk_conj_cmul15(g3, W.w8[3]); }
+        else g3 = pk_mul_j(g3);                                                   // B1r = (~B1.im, B1.re)
+        uint4 y;
+        y.x = pk_adds(g0, g1); y.y = pk_adds(~g1, g0); y.z = pk_adds(g2, g3); y.w = pk_adds(~g3, g2);
+        sync();
+        reinterpret_cast<uint4*>(p)[hi ? 1 : 0] = y;
+    }
+    sync();
+}
+
 // ---------------------------------------------------------------------------------------------
 // CRC-32 (reflected, init 0xFFFFFFFF, no final xor here) of n >= 4 bytes in LDS by one wave.  The register update is
 // linear over GF(2): CRC(init, M) = CRC(0, M') with the first four bytes complemented, and

@@ -42,15 +42,13 @@ __device__ __forceinline__ int qam_level(const uint8_t* bits, int M, int kmod)
 template <typename SYNC>
 __device__ __forceinline__ void ifft_emit(uint32_t* s_bins, uint32_t* s_sym, int e, const Fft128Tw& tw, int8_t* out8, SYNC sync)
 {
-    cpx x[4], y[4];
+    pcx x[4];
     sync();
 #pragma unroll
-    for (int m = 0; m < 4; m++) x[m] = unpack(s_bins[e + 32 * m]);
-    fft128_core<true>(x, s_bins, e, tw, sync);
+    for (int m = 0; m < 4; m++) x[m] = s_bins[e + 32 * m];
+    ifft128_core_pk(x, s_bins, e, tw, sync);                                     // IFFT<128> on packed COMPLEX16 (bit-exact with fft128_core<true>)
 #pragma unroll
-    for (int q = 0; q < 4; q++) y[q] = unpack(s_bins[__brev((unsigned)(e + 32 * q)) >> 25]);       // FFT128LUTMap = 7-bit bit reversal
-#pragma unroll
-    for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pack(sra(y[q], 4));
+    for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pk_sra(s_bins[__brev((unsigned)(e + 32 * q)) >> 25], 4);      // FFT128LUTMap = 7-bit bit reversal; >> 4
     sync();
     s_sym[e] = s_sym[128 + e];
     sync();
