@@ -354,16 +354,21 @@ def bench_11n(torch, sora_amd, dev, ncaps=8192, reps=5):
     torch.cuda.synchronize()
     rx.process_dev(f0, f1, descs); res = rx.results()
     ok = sum(r["error_code"] == 1 for r in res)
-    for _ in range(3):                                                       # (the first calls after a result read-back are slower: warm up, then time)
-        rx.process_dev(f0, f1, descs)
-    rx.synchronize()
-    reps = max(reps, 20)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps):
-        rx.process_dev(f0, f1, descs)
-    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    def timed(depth, reps=24):
+        rx.set_depth(depth)
+        for _ in range(depth + 2):                                           # (the first calls after a result read-back are slower: warm up, then time)
+            rx.process_dev(f0, f1, descs)
+        rx.synchronize()
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        tks = [rx.process_dev(f0, f1, descs) for _ in range(reps)]
+        rx.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, tks
+    ms1, _ = timed(1)
+    ms, tks = timed(3)                                                       # three calls in flight on the handle's pipelines, every call collectable by its ticket
+    in_flight_ok = [sum(r["error_code"] == 1 for r in rx.results(ticket=t)) for t in tks[-3:]]
     out = {"workload": "%d two-chain captures x one MCS 10 frame, %s (%d samples @40 MHz per chain each), 2x2 cross-talk, AWGN" % (ncaps, what, n),
-           "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
+           "ms": round(ms, 3), "ms_one_call_in_flight": round(ms1, 3), "calls_in_flight": 3, "frames_ok_last_calls_in_flight": in_flight_ok,
+           "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 8 * ncaps * n, "achieved": round(8.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
            "unit": "GB/s", "frac": round(8.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
     if g.available():

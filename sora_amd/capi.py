@@ -56,6 +56,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
+           "sora_rx11n_set_depth", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
            "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_process_dev", "sora_ht40_results",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results"]
@@ -164,6 +165,10 @@ def load(build_if_missing=True):
     L.sora_rx11n_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11n_stream.restype = ctypes.c_void_p
     L.sora_rx11n_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx11n_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
+    L.sora_rx11n_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx11n_ticket.argtypes = [ctypes.c_void_p]
+    L.sora_rx11n_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx11n_results_of.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx11n_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                      ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
@@ -449,12 +454,25 @@ class Rx11n:
             pass
 
     def synchronize(self):
-        _check(self._L.sora_hip_stream_synchronize(self._L.sora_rx11n_stream(self._h)))
+        """waits for every call in flight"""
+        t = self._L.sora_rx11n_ticket(self._h)
+        for k in range(max(1, t - 3), t + 1):
+            if self._L.sora_rx11n_wait(self._h, k) != SORA_OK:
+                pass                                                     # a ticket whose pipeline has been reused: that call finished long ago
+
+    def set_depth(self, depth=0):
+        r = self._L.sora_rx11n_set_depth(self._h, depth)
+        if r < 0: _check(r)
+        return r
+
+    def wait(self, ticket):
+        _check(self._L.sora_rx11n_wait(self._h, int(ticket)))
 
     def process_dev(self, d_iq0, d_iq1, captures):
         arr, ptr = Rx._caps(captures)
         self._keep = (d_iq0, d_iq1)
         _check(self._L.sora_rx11n_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), ptr, len(arr)))
+        return self._L.sora_rx11n_ticket(self._h)
 
     def process(self, h_iq0, h_iq1, captures):
         a = np.ascontiguousarray(h_iq0, np.int16).reshape(-1, 2); b = np.ascontiguousarray(h_iq1, np.int16).reshape(-1, 2)
@@ -462,12 +480,15 @@ class Rx11n:
         arr, ptr = Rx._caps(captures)
         _check(self._L.sora_rx11n_process(self._h, a.ctypes.data, b.ctypes.data, len(a), ptr, len(arr)))
 
-    def results(self):
+    def results(self, ticket=None):
         max_frames = self.cfg.max_captures * self.cfg.max_frames_per_capture
         res = (FrameResult * max(1, max_frames))()
         n = ctypes.c_size_t(0)
         mp = np.zeros(max_frames * 4096, np.uint8)
-        _check(self._L.sora_rx11n_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data, mp.size))
+        if ticket is None:
+            _check(self._L.sora_rx11n_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data, mp.size))
+        else:
+            _check(self._L.sora_rx11n_results_of(self._h, int(ticket), res, max_frames, ctypes.byref(n), mp.ctypes.data, mp.size))
         out = []
         for r in res[:n.value]:
             d = {f: getattr(r, f) for f, _ in FrameResult._fields_}

@@ -1066,29 +1066,67 @@ __global__ void __launch_bounds__(256) k_finish11n(Frame11nArgs A)
 using namespace sora;
 
 
-struct sora_rx11n {
-    sora_rx_cfg cfg{};
+struct Pipe11n {                         // one call in flight: a stream and every device array a call writes
     hipStream_t stream = nullptr;
     CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr;
+    N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
+    std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
+    uint32_t ncaps = 0; bool have_results = false; int ticket = 0;
+};
+struct sora_rx11n {
+    sora_rx_cfg cfg{};
     sora_complex16* d_iq_own[2] = { nullptr, nullptr };
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
-    std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
-    uint32_t ncaps = 0; bool have_results = false;
     // the staged chain (k_scan11n -> k_frame11n -> k_viterbi11n -> k_finish11n); SORA_HIP_11N_MONO=1 selects the one-kernel form instead
     bool mono = false;
-    N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
     uint64_t cap_slots = 0;
+    Pipe11n* pipes[4] = { nullptr, nullptr, nullptr, nullptr };
+    int depth = 1, cur = 0, next_ticket = 0; bool started = false;
 };
 
 #define HIPCHK11N(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
 
+static void pipe11n_free(Pipe11n* p)
+{
+    if (!p) return;
+    if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    (void)hipFree(p->d_caps); (void)hipFree(p->d_rows); (void)hipFree(p->d_nframes); (void)hipFree(p->d_mpdu);
+    (void)hipFree(p->d_frames); (void)hipFree(p->d_jobs); (void)hipFree(p->d_njobs); (void)hipFree(p->d_soft); (void)hipFree(p->d_vout);
+    delete p;
+}
 static void rx11n_free(sora_rx11n_t* rx)
 {
     if (!rx) return;
-    if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
-    (void)hipFree(rx->d_caps); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_nframes); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_iq_own[0]); (void)hipFree(rx->d_iq_own[1]);
-    (void)hipFree(rx->d_frames); (void)hipFree(rx->d_jobs); (void)hipFree(rx->d_njobs); (void)hipFree(rx->d_soft); (void)hipFree(rx->d_vout);
+    for (Pipe11n* p : rx->pipes) pipe11n_free(p);
+    (void)hipFree(rx->d_iq_own[0]); (void)hipFree(rx->d_iq_own[1]);
     delete rx;
+}
+static hipError_t pipe11n_create(sora_rx11n_t* rx, Pipe11n** out)
+{
+    const sora_rx_cfg* cfg = &rx->cfg;
+    const size_t rows = (size_t)cfg->max_captures * cfg->max_frames_per_capture;
+    Pipe11n* p = new Pipe11n();
+    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_caps, sizeof(CapDesc) * cfg->max_captures);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_rows, sizeof(Rx11bRow) * rows);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_nframes, 4 * (size_t)cfg->max_captures);
+    if (e == hipSuccess) e = hipMalloc((void**)&p->d_mpdu, rows * 4096);
+    if (!rx->mono) {
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_frames, 3 * sizeof(N11Frame) * rows);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_jobs, 3 * sizeof(VitJob) * rows);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_njobs, 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_soft, (size_t)rx->cap_slots * kSoftPerSlot * 2 + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_vout, (size_t)rx->cap_slots * kOutPerSlot + 256);
+        // every array starts out defined: the decoder reads its soft stream in 12-step chunks (the tail of a frame's last chunk is read, never used)
+        if (e == hipSuccess) {
+            (void)hipMemsetAsync(p->d_frames, 0, 3 * sizeof(N11Frame) * rows, p->stream); (void)hipMemsetAsync(p->d_jobs, 0, 3 * sizeof(VitJob) * rows, p->stream);
+            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot * 2 + 256, p->stream); (void)hipMemsetAsync(p->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
+        }
+    }
+    if (e == hipSuccess) { (void)hipMemsetAsync(p->d_rows, 0, sizeof(Rx11bRow) * rows, p->stream); (void)hipMemsetAsync(p->d_nframes, 0, 4 * (size_t)cfg->max_captures, p->stream); }
+    if (e != hipSuccess) { pipe11n_free(p); return e; }
+    *out = p;
+    return hipSuccess;
 }
 
 int sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out)
@@ -1102,46 +1140,61 @@ int sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out)
     HIPCHK11N(hipSetDevice(cfg->device));
     sora_rx11n_t* rx = new sora_rx11n();
     rx->cfg = *cfg;
-    const size_t rows = (size_t)cfg->max_captures * cfg->max_frames_per_capture;
-    hipError_t e = (sora_internal_tables(cfg->device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK) ? hipSuccess : hipErrorUnknown;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * rows);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, rows * 4096);
+    if (!(sora_internal_tables(cfg->device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: tables", 0); }
     { const char* m = getenv("SORA_HIP_11N_MONO"); rx->mono = m && m[0] == '1'; }
     if (!rx->mono) {
         // symbol slots: 80 samples at 20 MHz each, + 4 per capture (the decoder's padded last burst and its chunked reads may reach past the last symbol)
         rx->cap_slots = cfg->max_total_samples / 2 / 80 + 4 * (uint64_t)cfg->max_captures + 4;
         if (rx->cap_slots * (uint64_t)kSoftPerSlot * 2 >= (1ull << 32)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_create: max_total_samples exceeds the 32-bit slot geometry of one handle (split the batch over several handles)", 0); }
-        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_frames, 3 * sizeof(N11Frame) * rows);
-        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rows);
-        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_njobs, 16);
-        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_soft, (size_t)rx->cap_slots * kSoftPerSlot * 2 + 256);
-        if (e == hipSuccess) e = hipMalloc((void**)&rx->d_vout, (size_t)rx->cap_slots * kOutPerSlot + 256);
     }
-    if (e != hipSuccess) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: device allocation / tables", (int)e); }
-    // every array starts out defined: the decoder reads its soft stream in 12-step chunks (the tail of a frame's last chunk is read, never used)
-    if (!rx->mono) {
-        (void)hipMemsetAsync(rx->d_frames, 0, 3 * sizeof(N11Frame) * rows, rx->stream); (void)hipMemsetAsync(rx->d_jobs, 0, 3 * sizeof(VitJob) * rows, rx->stream);
-        (void)hipMemsetAsync(rx->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot * 2 + 256, rx->stream); (void)hipMemsetAsync(rx->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, rx->stream);
-    }
-    (void)hipMemsetAsync(rx->d_rows, 0, sizeof(Rx11bRow) * rows, rx->stream); (void)hipMemsetAsync(rx->d_nframes, 0, 4 * (size_t)cfg->max_captures, rx->stream);
+    const hipError_t e = pipe11n_create(rx, &rx->pipes[0]);
+    if (e != hipSuccess) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: device allocation", (int)e); }
     *out = rx;
     return SORA_OK;
 }
 
-void* sora_rx11n_stream(sora_rx11n_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+void* sora_rx11n_stream(sora_rx11n_t* rx) { return rx ? (void*)rx->pipes[rx->cur]->stream : nullptr; }
 void sora_rx11n_destroy(sora_rx11n_t* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); rx11n_free(rx); } }
+
+int sora_rx11n_set_depth(sora_rx11n_t* rx, int depth)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_depth: null handle", 0);
+    const int prev = rx->depth;
+    if (depth <= 0) return prev;
+    if (depth > 4) depth = 4;
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
+    for (int i = 0; i < depth; i++)
+        if (!rx->pipes[i]) { const hipError_t e = pipe11n_create(rx, &rx->pipes[i]); if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_set_depth: device allocation", (int)e); }
+    rx->depth = depth;
+    if (rx->cur >= depth) rx->cur = 0;
+    return prev;
+}
+
+static Pipe11n* pipe11n_of(sora_rx11n_t* rx, int ticket)
+{
+    if (!rx || ticket <= 0) return nullptr;
+    for (int i = 0; i < rx->depth; i++) if (rx->pipes[i] && rx->pipes[i]->ticket == ticket) return rx->pipes[i];
+    return nullptr;
+}
+int sora_rx11n_ticket(sora_rx11n_t* rx) { return rx && rx->started ? rx->pipes[rx->cur]->ticket : 0; }
+int sora_rx11n_wait(sora_rx11n_t* rx, int ticket)
+{
+    Pipe11n* p = pipe11n_of(rx, ticket);
+    if (!p) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_wait: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    HIPCHK11N(hipStreamSynchronize(p->stream));
+    return SORA_OK;
+}
 
 int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_process_dev: null argument", 0);
     if (ncaps > rx->cfg.max_captures) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more captures than max_captures", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
-    std::vector<CapDesc>& h = rx->h_desc;
-    HIPCHK11N(hipStreamSynchronize(rx->stream));
-    h.resize(ncaps);
+    const int idx = rx->started ? (rx->cur + 1) % rx->depth : 0;                   // consecutive calls rotate over the pipelines
+    Pipe11n* P = rx->pipes[idx];
+    std::vector<CapDesc> h(ncaps);                                               // validated first: a refused call leaves the handle's calls intact
     uint64_t total = 0, slots = 0;
     for (size_t i = 0; i < ncaps; i++) {
         if (caps[i].nsamples % 28 != 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture length must be a whole number of 28-sample source bursts", 0);
@@ -1150,29 +1203,32 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
         slots += h[i].nslots; total += caps[i].nsamples;
     }
     if (total > rx->cfg.max_total_samples || (!rx->mono && slots > rx->cap_slots)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more samples than max_total_samples", 0);
-    rx->h_caps.assign(caps, caps + ncaps); rx->ncaps = (uint32_t)ncaps; rx->have_results = true;
+    HIPCHK11N(hipStreamSynchronize(P->stream));                                  // the call that used this pipeline `depth` calls ago has finished
+    P->h_desc.swap(h);
+    P->h_caps.assign(caps, caps + ncaps); P->ncaps = (uint32_t)ncaps; P->have_results = true; P->ticket = ++rx->next_ticket;
+    rx->cur = idx; rx->started = true;
     if (ncaps == 0) return SORA_OK;
-    HIPCHK11N(hipMemcpyAsync(rx->d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, rx->stream));
+    HIPCHK11N(hipMemcpyAsync(P->d_caps, P->h_desc.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, P->stream));
     Rx11nArgs A;
-    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.caps = rx->d_caps; A.ncaps = (uint32_t)ncaps;
-    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan;
+    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.caps = P->d_caps; A.ncaps = (uint32_t)ncaps;
+    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = P->d_rows; A.nframes = P->d_nframes; A.mpdu = P->d_mpdu; A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan;
     if (rx->mono) {
-        hipLaunchKernelGGL(k_rx11n_mono, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);
+        hipLaunchKernelGGL(k_rx11n_mono, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, P->stream, A);
         HIPCHK11N(hipGetLastError());
         return SORA_OK;
     }
     const uint32_t nrows = (uint32_t)ncaps * rx->cfg.max_frames_per_capture;
-    HIPCHK11N(hipMemsetAsync(rx->d_njobs, 0, 16, rx->stream));
+    HIPCHK11N(hipMemsetAsync(P->d_njobs, 0, 16, P->stream));
     Scan11nArgs S;
-    S.iq0 = A.iq0; S.iq1 = A.iq1; S.caps = rx->d_caps; S.ncaps = (uint32_t)ncaps; S.max_frames = A.max_frames; S.rows = rx->d_rows; S.nframes = rx->d_nframes;
-    S.T = rx->T; S.sincos = rx->sincos; S.atan = rx->atan; S.frames = rx->d_frames; S.jobs = rx->d_jobs; S.njobs = rx->d_njobs; S.nrows = nrows;
-    hipLaunchKernelGGL(k_scan11n, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, S);
+    S.iq0 = A.iq0; S.iq1 = A.iq1; S.caps = P->d_caps; S.ncaps = (uint32_t)ncaps; S.max_frames = A.max_frames; S.rows = P->d_rows; S.nframes = P->d_nframes;
+    S.T = rx->T; S.sincos = rx->sincos; S.atan = rx->atan; S.frames = P->d_frames; S.jobs = P->d_jobs; S.njobs = P->d_njobs; S.nrows = nrows;
+    hipLaunchKernelGGL(k_scan11n, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, P->stream, S);
     Frame11nArgs F;
-    F.iq0 = A.iq0; F.iq1 = A.iq1; F.caps = rx->d_caps; F.frames = rx->d_frames; F.njobs = rx->d_njobs; F.nrows = nrows; F.T = rx->T; F.sincos = rx->sincos; F.atan = rx->atan;
-    F.soft = rx->d_soft; F.vout = rx->d_vout; F.rows = rx->d_rows; F.mpdu = rx->d_mpdu;
-    hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, rx->stream, F);
-    hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, rx->stream, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
-    hipLaunchKernelGGL(k_finish11n, dim3((nrows + 3) / 4), dim3(256), 0, rx->stream, F);
+    F.iq0 = A.iq0; F.iq1 = A.iq1; F.caps = P->d_caps; F.frames = P->d_frames; F.njobs = P->d_njobs; F.nrows = nrows; F.T = rx->T; F.sincos = rx->sincos; F.atan = rx->atan;
+    F.soft = P->d_soft; F.vout = P->d_vout; F.rows = P->d_rows; F.mpdu = P->d_mpdu;
+    hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
+    hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint8_t*)P->d_soft, P->d_vout);
+    hipLaunchKernelGGL(k_finish11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
     HIPCHK11N(hipGetLastError());
     return SORA_OK;
 }
@@ -1184,53 +1240,67 @@ int sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const sora
     for (size_t i = 0; i < ncaps; i++)                                               // the buffer's size is known here: no descriptor may reach past it
         if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
+    for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));   // the handle's own sample buffers are shared by its pipelines: calls in flight read them
     const sora_complex16* src[2] = { h_iq0, h_iq1 };
     for (int k = 0; k < 2; k++) {
         if (!rx->d_iq_own[k]) HIPCHK11N(hipMalloc((void**)&rx->d_iq_own[k], sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
-        HIPCHK11N(hipMemcpyAsync(rx->d_iq_own[k], src[k], sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice, rx->stream));
+        HIPCHK11N(hipMemcpy(rx->d_iq_own[k], src[k], sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice));
     }
     return sora_rx11n_process_dev(rx, rx->d_iq_own[0], rx->d_iq_own[1], caps, ncaps);
 }
 
-int sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+static int pipe11n_results(sora_rx11n_t* rx, Pipe11n* P, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
 {
-    if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results: null argument", 0);
     *nout = 0;
-    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
-    if (rx->ncaps == 0) return SORA_OK;
+    if (!P->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
+    if (P->ncaps == 0) return SORA_OK;
     HIPCHK11N(hipSetDevice(rx->cfg.device));
-    HIPCHK11N(hipStreamSynchronize(rx->stream));
+    HIPCHK11N(hipStreamSynchronize(P->stream));
     const uint32_t mf = rx->cfg.max_frames_per_capture;
-    std::vector<Rx11bRow> rows((size_t)rx->ncaps * mf); std::vector<uint32_t> nfr(rx->ncaps);
-    HIPCHK11N(hipMemcpy(rows.data(), rx->d_rows, sizeof(Rx11bRow) * rows.size(), hipMemcpyDeviceToHost));
-    HIPCHK11N(hipMemcpy(nfr.data(), rx->d_nframes, 4 * (size_t)rx->ncaps, hipMemcpyDeviceToHost));
+    std::vector<Rx11bRow> rows((size_t)P->ncaps * mf); std::vector<uint32_t> nfr(P->ncaps);
+    HIPCHK11N(hipMemcpy(rows.data(), P->d_rows, sizeof(Rx11bRow) * rows.size(), hipMemcpyDeviceToHost));
+    HIPCHK11N(hipMemcpy(nfr.data(), P->d_nframes, 4 * (size_t)P->ncaps, hipMemcpyDeviceToHost));
     size_t used_rows = 0;
-    for (uint32_t c = 0; c < rx->ncaps; c++) used_rows += nfr[c] < mf ? nfr[c] : mf;
+    for (uint32_t c = 0; c < P->ncaps; c++) used_rows += nfr[c] < mf ? nfr[c] : mf;
     std::vector<uint8_t> bulk;
-    const size_t slots = (size_t)rx->ncaps * mf;
+    const size_t slots = (size_t)P->ncaps * mf;
     if (h_mpdu && used_rows > 16 && slots * 4096 <= ((size_t)1 << 30)) {
         bulk.resize(slots * 4096);
-        HIPCHK11N(hipMemcpy(bulk.data(), rx->d_mpdu, bulk.size(), hipMemcpyDeviceToHost));
+        HIPCHK11N(hipMemcpy(bulk.data(), P->d_mpdu, bulk.size(), hipMemcpyDeviceToHost));
     }
     size_t n = 0, moff = 0; int rc = SORA_OK;
-    for (uint32_t c = 0; c < rx->ncaps; c++)
+    for (uint32_t c = 0; c < P->ncaps; c++)
         for (uint32_t i = 0; i < nfr[c] && i < mf; i++) {
             const Rx11bRow& r = rows[(size_t)c * mf + i];
             if (n >= max_out) { rc = SORA_ERR_CAPACITY; continue; }
             sora_frame_result& o = out[n++];
             memset(&o, 0, sizeof(o));
-            o.capture_id = rx->h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
+            o.capture_id = P->h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
             o.length = (uint16_t)r.length; o.crc32 = r.crc32; o.mpdu_offset = (uint32_t)moff;
             if (i + 1 == mf && nfr[c] > mf) o.flags = SORA_ROW_TRUNCATED;             // more frames were found than the capture has rows
             if (h_mpdu && (r.error_code == 1u || r.error_code == 0x80000006u)) {
                 const size_t len = r.length < 4096 ? r.length : 4096;
                 if (moff + len > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
                 if (!bulk.empty()) memcpy(h_mpdu + moff, bulk.data() + ((size_t)c * mf + i) * 4096, len);
-                else HIPCHK11N(hipMemcpy(h_mpdu + moff, rx->d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
+                else HIPCHK11N(hipMemcpy(h_mpdu + moff, P->d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
                 moff += len;
             }
         }
     *nout = n;
     if (rc != SORA_OK) return sora_internal_fail(rc, "sora_rx11n_results: output buffer too small", 0);
     return SORA_OK;
+}
+
+int sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results: null argument", 0);
+    return pipe11n_results(rx, rx->pipes[rx->cur], out, max_out, nout, h_mpdu, mpdu_cap);
+}
+
+int sora_rx11n_results_of(sora_rx11n_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results_of: null argument", 0);
+    Pipe11n* P = pipe11n_of(rx, ticket);
+    if (!P) { *nout = 0; return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results_of: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0); }
+    return pipe11n_results(rx, P, out, max_out, nout, h_mpdu, mpdu_cap);
 }

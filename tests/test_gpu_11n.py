@@ -164,3 +164,40 @@ def test_staged_chain_equals_the_one_kernel_form(monkeypatch):
     assert sum(len(x) for x in staged) > 300
     for i in range(len(caps)):
         assert [key(e) for e in staged[i]] == [key(e) for e in mono[i]], i
+
+
+@pytest.mark.parametrize("depth", [1, 2, 3])
+def test_11n_calls_in_flight_are_collectable_by_ticket(depth):
+    """sora_rx11n_set_depth: consecutive calls on different batches rotate over the handle's pipelines; each call's rows and MPDUs are read back by its
+    ticket while later calls are in flight, and equal the oracle's; a ticket whose pipeline has been reused is refused."""
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    o = Oracle()
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rng = np.random.default_rng(500 + depth)
+    batches = []
+    for b in range(depth + 2):
+        caps = [capture_11n(rng, [frames[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 3)))], sigma=float(rng.choice([5, 60, 400]))) for _ in range(12)]
+        iq0 = np.concatenate([a for a, _ in caps]); iq1 = np.concatenate([c for _, c in caps])
+        descs = []; off = 0
+        for i, (a, _) in enumerate(caps):
+            descs.append((off, len(a), i)); off += len(a)
+        batches.append((caps, torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), descs))
+    n_max = max(len(b[1]) for b in batches)
+    rx = sora_amd.Rx11n(12, n_max, max_frames_per_capture=8)
+    assert rx.set_depth(depth) == 1
+    tickets = [rx.process_dev(b[1], b[2], b[3]) for b in batches]
+    assert tickets == list(range(1, len(batches) + 1))
+    for t, b in list(zip(tickets, batches))[-depth:]:                         # the calls still held by a pipeline
+        per = [[] for _ in b[0]]
+        for r in rx.results(ticket=t):
+            per[r["capture_id"]].append(r)
+        for i, (a, c) in enumerate(b[0]):
+            ok, why = same_events_11n(per[i], o.rx11n_capture(a, c))
+            assert ok, (t, i, why)
+    with pytest.raises(Exception):
+        rx.results(ticket=tickets[0])                                           # depth + 2 calls were made: the first call's pipeline has been reused
+    rx.close()
