@@ -49,6 +49,13 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
 {
     __shared__ uint8_t s_out_all[4][kOutBuf];
     __shared__ int s_state_all[4][32];                                  // per wave: [0..19] TBarkerSync partial sums, [20..27] TEnergyDetect window
+    __shared__ uint32_t s_crc_all[8][256];                              // CRC-32 tables: [0] the byte table, [k] = the same after k more zero bytes ("slicing"), built below
+    uint32_t* const s_crc = s_crc_all[0];
+    __shared__ int s_sym_all[4][2][64];                                 // per wave: despread sums of the symbols of one bulk pass (re, im)
+    s_crc[threadIdx.x] = A.crc[threadIdx.x];
+    __syncthreads();
+    { uint32_t t = s_crc[threadIdx.x]; for (int k = 1; k < 8; k++) { t = s_crc[t & 0xFF] ^ (t >> 8); s_crc_all[k][threadIdx.x] = t; } }
+    __syncthreads();
     const int lane = threadIdx.x & 63, wave = uni((int)(threadIdx.x >> 6));      // wave-uniform values are told to be so: state then lives in SGPRs
     const uint32_t cap_i = blockIdx.x * 4 + wave;
     if (cap_i >= A.ncaps) return;
@@ -105,7 +112,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         if (byte_count < (uint32_t)((int)frame_length - 4)) {
             if (lane == 0 && byte_count < kOutBuf) s_out[byte_count] = (uint8_t)b;
             byte_count++;
-            crc32 = (uint32_t)uni((int)A.crc[(crc32 ^ b) & 0xFF]) ^ (crc32 >> 8);
+            crc32 = (uint32_t)uni((int)s_crc[(crc32 ^ b) & 0xFF]) ^ (crc32 >> 8);
         } else if (byte_count < frame_length) {
             if (lane == 0 && byte_count < kOutBuf) s_out[byte_count] = (uint8_t)b;
             byte_count++;
@@ -378,6 +385,164 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         m_index += di + carry; m_frag = carry > 0 ? -3 : (carry < 0 ? 3 : mf);
     };
 
+
+    // ---- The payload in bulk.  Inside a frame's data field -- Barker aligned, rate and length known, whole source calls following one another -- the
+    // only serial dependence is the early-late timing loop, and that loop looks at nothing but the four phase energies of each 28-sample call.  So K
+    // calls are taken in one pass, one call per LANE: every lane computes its call's phase energies (v_dot2 on packed samples); a scalar loop of K
+    // short iterations runs the timing recurrence (TSymTiming::AdjustTiming, symtiming.hpp:118-170) and leaves each call its sampling phase; then the
+    // lanes pull their 6..8 chips, despread them into the (at most two) symbols they belong to -- every step of QuickBarkerDespread is a wrapping
+    // int16 add, so partial sums from different calls simply add up (LDS atomics) -- the symbols are demapped one per lane against their left
+    // neighbour, the bits are gathered with a ballot, and the bytes go through the same TDesc741 / TBB11bFrameSink code as ever.  K is chosen so that
+    // the frame's last bytes (the FCS event) are left to the call-by-call path below, which also handles every other phase.
+    int* const sy_re = s_sym_all[wave][0]; int* const sy_im = s_sym_all[wave][1];
+    auto writelane_u = [&](uint32_t& vec, uint32_t val, uint32_t ln) __attribute__((always_inline)) {
+        vec = (uint32_t)lane == ln ? val : vec;
+    };
+    typedef short bs16x2_t __attribute__((ext_vector_type(2)));
+    auto pk_sub = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) - __builtin_bit_cast(bs16x2_t, b))); };
+    auto pk_add = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) + __builtin_bit_cast(bs16x2_t, b))); };
+    auto pk_sra = [](uint32_t a, int n) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) >> (short)n)); };
+    auto payload_pass = [&](uint32_t& pos_, uint32_t& remain_, uint32_t& c_start_, uint32_t& c_stale_, uint32_t& p_start_, uint32_t& p_stale_, int qoff_) __attribute__((always_inline)) -> bool {
+        const int port = uni(rxrate);
+        const int spb = port == RATE_1M ? 8 : 4;                       // symbols per byte
+        if (byte_count + 1 >= frame_length) return false;
+        const int R = (int)(frame_length - 1 - byte_count);            // bytes still to complete before the FCS event
+        const int chips_to_event = 11 * (R * spb - sym_n) - chip_n;
+        int K = min(port == RATE_1M ? 64 : 32, min((int)(remain_ / 28u), (chips_to_event - 1) / 8 - 1));
+        if (K < 8) return false;
+        const uint32_t base0 = pos_ - (uint32_t)qoff_;
+        // ---- A. one call per lane: 28 samples, DC removed (TDCRemove: the estimate is frozen while demodulating), phase energies
+        const bool act = lane < K;
+        const uint32_t dcp = ((uint32_t)dc_re & 0xFFFFu) | ((uint32_t)dc_im << 16);
+        uint32_t xs[28];
+        {
+            const uint4* src = reinterpret_cast<const uint4*>(x + base0 + 28u * (uint32_t)(act ? lane : 0));
+#pragma unroll
+            for (int q = 0; q < 7; q++) { const uint4 v = src[q]; xs[4 * q] = pk_sub(v.x, dcp); xs[4 * q + 1] = pk_sub(v.y, dcp); xs[4 * q + 2] = pk_sub(v.z, dcp); xs[4 * q + 3] = pk_sub(v.w, dcp); }
+        }
+        int e0 = 0, e1 = 0, e2 = 0, e3 = 0;                            // sums over the block of |x >> 3|^2 per sampling phase, wrapping
+#pragma unroll
+        for (int q = 0; q < 7; q++) {
+            const bs16x2_t a0 = __builtin_bit_cast(bs16x2_t, pk_sra(xs[4 * q], 3)), a1 = __builtin_bit_cast(bs16x2_t, pk_sra(xs[4 * q + 1], 3));
+            const bs16x2_t a2 = __builtin_bit_cast(bs16x2_t, pk_sra(xs[4 * q + 2], 3)), a3 = __builtin_bit_cast(bs16x2_t, pk_sra(xs[4 * q + 3], 3));
+            e0 = __builtin_amdgcn_sdot2(a0, a0, e0, false); e1 = __builtin_amdgcn_sdot2(a1, a1, e1, false);
+            e2 = __builtin_amdgcn_sdot2(a2, a2, e2, false); e3 = __builtin_amdgcn_sdot2(a3, a3, e3, false);
+        }
+        // ---- B. the timing recurrence.  Every lane first works out what AdjustTiming would decide for its call at each of the four sampling
+        // phases (two 2-bit fields per phase: index step + 1, fraction step + 1); the serial part that is left is a scalar loop of a dozen
+        // instructions per call: pick the field of the current phase, move (m_index, m_frag) on, leave lane k + 1 its decimation phase.
+        uint32_t codes = 0;
+#pragma unroll
+        for (int mx = 0; mx < 4; mx++) {
+            const int sm = mx == 0 ? e0 : mx == 1 ? e1 : mx == 2 ? e2 : e3;
+            const int se = mx == 0 ? e3 : mx == 1 ? e0 : mx == 2 ? e1 : e2;
+            const int sl = mx == 0 ? e1 : mx == 1 ? e2 : mx == 2 ? e3 : e0;
+            const bool late_better = se < sl, a = sm < se, b = sm < sl;
+            const int di = late_better ? (a ? 1 : 0) : (b ? -1 : 0);
+            const int df = late_better ? (!a && b ? 1 : 0) : (!b && a ? -1 : 0);
+            codes |= (uint32_t)((di + 1) | ((df + 1) << 2)) << (4 * mx);
+        }
+        uint32_t miv = (uint32_t)m_index;                               // lane k: m_index as call k finds it (-1 .. 4)
+        {
+            int mi = m_index, mf = m_frag;
+            for (int k = 0; k < K; k++) {
+                const uint32_t c = ((uint32_t)lane_of((int)codes, k) >> (4 * (mi & 3))) & 15u;   // Decimation leaves m_index & 3: -1 -> 3 (idx < 0 moves on by 4), 4 -> 0
+                const int di = (int)(c & 3u) - 1, df = (int)(c >> 2) - 1;
+                const int f = di != 0 ? 0 : mf + df;                    // a step of the index clears the fraction
+                const int carry = f >= 4 ? 1 : (f <= -4 ? -1 : 0);
+                mi = (mi & 3) + di + carry; mf = carry > 0 ? -3 : (carry < 0 ? 3 : f);
+                miv = lane == k + 1 ? (uint32_t)mi : miv;
+            }
+            m_index = mi; m_frag = mf;
+        }
+        // ---- C. chips of this lane's call and their partial despread sums
+        const int mi = (int)miv;
+        const int cnt = act ? (mi < 0 ? 8 : (28 - mi + 3) >> 2) : 0;
+        int incl = cnt;                                                // inclusive prefix sum of the chip counts (DPP, as scan_add in k_rx11n.hip)
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, true); incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, true); incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, true);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false); incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
+        const int total = lane_of(incl, K - 1);
+        const int g0 = chip_n + incl - cnt;                            // chips before this call's first, counted from the start of the symbol in progress
+        const int sid0 = (int)(((uint32_t)g0 * 5958u) >> 16);          // g0 / 11 for g0 < 2^13
+        int c = g0 - 11 * sid0;
+        uint32_t partA = 0, partB = 0; bool crossed = false;
+        const bool m0 = mi == 0, m1 = mi == 1, m2 = mi == 2, m3 = mi == 3, m4 = mi >= 4;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            // the sample at offset max(mi + 4 j, 0) of the block (mi = -1 .. 4)
+            uint32_t v = xs[4 * j == 0 ? 0 : 4 * j - 1];
+            v = m0 ? xs[4 * j] : v; v = m1 ? xs[min(4 * j + 1, 27)] : v; v = m2 ? xs[min(4 * j + 2, 27)] : v; v = m3 ? xs[min(4 * j + 3, 27)] : v; v = m4 ? xs[min(4 * j + 4, 27)] : v;
+            uint32_t t;
+            if (c == 1 || c == 4) t = pk_sra(pk_sub(0u, v), 4);        // chips 1 and 4 are negated BEFORE the >> 4 (neg16, wrapping)
+            else { t = pk_sra(v, 4); if (c >= 8) t = pk_sub(0u, t); }   // chips 8..10 are subtracted after it
+            if (j < cnt) { if (crossed) partB = pk_add(partB, t); else partA = pk_add(partA, t); }
+            if (j < cnt) { c++; if (c == 11) { c = 0; crossed = true; } }
+        }
+        // ---- D. symbols: the carried partial sum, then every lane's parts (wrapping int16 sums: accumulated wide, wrapped when read)
+        lds_order();
+        sy_re[lane] = lane == 0 ? acc_re : 0; sy_im[lane] = lane == 0 ? acc_im : 0;
+        lds_order();
+        if (cnt > 0) {
+            atomicAdd(&sy_re[sid0], (int)(short)(partA & 0xFFFFu)); atomicAdd(&sy_im[sid0], (int)partA >> 16);
+            if (crossed && sid0 + 1 < 64) { atomicAdd(&sy_re[sid0 + 1], (int)(short)(partB & 0xFFFFu)); atomicAdd(&sy_im[sid0 + 1], (int)partB >> 16); }
+        }
+        lds_order();
+        const int T = chip_n + total;
+        const int nsym = (int)(((uint32_t)T * 5958u) >> 16);           // symbols completed in this pass
+        const int sre = w16(sy_re[lane]), sim = w16(sy_im[lane]);      // lane s: symbol s
+        const int pre_i = lane > 0 ? lane - 1 : 0;
+        int qre = w16(sy_re[pre_i]), qim = w16(sy_im[pre_i]);          // its left neighbour = the differential reference
+        const int cin_re = sym_n == 0 ? last_re : ref_re, cin_im = sym_n == 0 ? last_im : ref_im;
+        if (lane == 0) { qre = cin_re; qim = cin_im; }
+        // ---- E. bits (TDBPSKDemap / TDQPSKDemap, barkerspread.hpp:312-454) and bytes
+        unsigned long long W; int nbits;
+        if (port == RATE_1M) {
+            const unsigned long long b0 = __ballot(lane < nsym && dot_sign(qre, qim, sre, sim));
+            W = (unsigned long long)sym_byte | (b0 << sym_n); nbits = sym_n + nsym;
+        } else {
+            const int re = (int)((uint32_t)(qre * sre) + (uint32_t)(qim * sim)), im = (int)((uint32_t)(qre * sim) - (uint32_t)(qim * sre));
+            unsigned long long b0 = __ballot(lane < nsym && ((((uint32_t)re + (uint32_t)im) >> 31) != 0));
+            unsigned long long b1 = __ballot(lane < nsym && ((((uint32_t)re - (uint32_t)im) >> 31) != 0));
+            auto spread = [](unsigned long long v) { v &= 0xFFFFFFFFull; v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+                                                     v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full; v = (v | (v << 2)) & 0x3333333333333333ull; v = (v | (v << 1)) & 0x5555555555555555ull; return v; };
+            W = (unsigned long long)sym_byte | ((spread(b0) | (spread(b1) << 1)) << (2 * sym_n)); nbits = 2 * (sym_n + nsym);
+        }
+        const int nbytes = nbits >> 3;
+        // TDesc741 is self-synchronising -- out[n] = in[n] ^ in[n-4] ^ in[n-7] -- so the whole bit string is descrambled with two shifts
+        const unsigned long long S = (W << 7) | (unsigned long long)(byte_reg & 0x7Fu);
+        const unsigned long long O = (S >> 7) ^ (S >> 3) ^ S;
+        const uint32_t ob = (uint32_t)(O >> (8 * (lane & 7))) & 0xFFu;  // lane i: the i-th byte for TBB11bFrameSink (at most 6 complete in a pass)
+        if (nbytes > 0) {
+            byte_reg = (uint32_t)(W >> (8 * nbytes - 7)) & 0x7Fu;
+            const uint32_t idx = byte_count + (uint32_t)lane;
+            if (lane < nbytes && idx < kOutBuf) s_out[idx] = (uint8_t)ob;
+            // CRC-32 of the bytes in front of the FCS, all at once: byte i of n goes through the table that also carries it over the n - 1 - i
+            // bytes behind it; the register's four bytes enter with the first four message bytes
+            const uint32_t lim = (uint32_t)((int)frame_length - 4);
+            const int n = byte_count >= lim ? 0 : (int)min((uint32_t)nbytes, lim - byte_count);
+            uint32_t v = 0;
+            if (lane < n) v = s_crc_all[n - 1 - lane][(ob ^ (lane < 4 ? crc32 >> (8 * lane) : 0u)) & 0xFFu];
+            v ^= (uint32_t)dpp<0xB1>((int)v); v ^= (uint32_t)dpp<0x4E>((int)v); v ^= (uint32_t)dpp<0x141>((int)v);      // xor over lanes 0..7
+            crc32 = (uint32_t)lane_of((int)v, 0) ^ (n < 4 ? crc32 >> (8 * n) : 0u);
+            byte_count += (uint32_t)nbytes;
+        }
+        // ---- F. what the pass leaves behind
+        const int symtot = sym_n + nsym;
+        if (nsym > 0) {
+            ref_re = lane_of(sre, nsym - 1); ref_im = lane_of(sim, nsym - 1);
+            if (nbytes > 0) { const int ls = nbytes * spb - sym_n - 1; last_re = lane_of(sre, ls); last_im = lane_of(sim, ls); }
+        }
+        sym_n = symtot - nbytes * spb; sym_byte = (uint32_t)(W >> (8 * nbytes)) & 0xFFu;
+        chip_n = T - 11 * nsym;
+        acc_re = w16(lane_of(sre, nsym)); acc_im = w16(lane_of(sim, nsym));
+        const uint32_t adv = 28u * (uint32_t)K;
+        const uint32_t s0_ = c_start_;
+        pos_ += adv; remain_ -= adv;
+        c_start_ = s0_ + adv; c_stale_ = s0_ + adv - 28u; p_start_ = s0_ + adv - 28u; p_stale_ = s0_ + adv - 56u;
+        return true;
+    };
+
     uint32_t pos = 0, remain = cap_n;
     // TMemSamples appends 28 entries per call to its output queue; a call that finds fewer than 28 samples left (possible
     // after the Seek that follows a frame) leaves the tail of the previous call's burst in place (memsource.hpp:99-107).
@@ -447,6 +612,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 // calls are taken right here.  Same semantics as going round the outer loop -- MAC11b_Receive only looks at
                 // error_code after a call -- but in a loop of its own the compiler keeps just this phase's state in registers.
                 while (error_code == 0 && sync_flag == BARKER_SYNCED && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
+                    if (uni(plcp_data) && uni(rxrate) >= RATE_1M && uni(rxrate) <= RATE_2M && qoff % 4 == 0 && payload_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28; pf_ok = false; continue; }
                     p_start = c_start; p_take = 28; p_stale = c_stale;
                     c_stale = c_start; c_start = pos; pos += 28; remain -= 28;
                     const uint32_t base = c_start - (uint32_t)qoff;
@@ -499,7 +665,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     if (lane == 0) A.nframes[cap_i] = nfr;
 }
 
-__global__ void __launch_bounds__(256, 8) k_rx11b(Rx11bArgs A) { rx11b_capture<false>(A); }
+__global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A) { rx11b_capture<false>(A); }
 __global__ void __launch_bounds__(256, 4) k_rx11b_cck(Rx11bArgs A) { rx11b_capture<true>(A); }
 
 }  // namespace sora
