@@ -408,7 +408,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         if (byte_count + 1 >= frame_length) return false;
         const int R = (int)(frame_length - 1 - byte_count);            // bytes still to complete before the FCS event
         const int chips_to_event = 11 * (R * spb - sym_n) - chip_n;
-        int K = min(port == RATE_1M ? 64 : 32, min((int)(remain_ / 28u), (chips_to_event - 1) / 8 - 1));
+        const int K = min(port == RATE_1M ? 64 : 32, min((int)(remain_ / 28u), (chips_to_event - 1) / 8 - 1)) & ~7;   // (whole rounds of eight calls)
         if (K < 8) return false;
         const uint32_t base0 = pos_ - (uint32_t)qoff_;
         // ---- A. one call per lane: 28 samples, DC removed (TDCRemove: the estimate is frozen while demodulating), phase energies
@@ -442,19 +442,35 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             const int df = late_better ? (!a && b ? 1 : 0) : (!b && a ? -1 : 0);
             codes |= (uint32_t)((di + 1) | ((df + 1) << 2)) << (4 * mx);
         }
-        uint32_t miv = (uint32_t)m_index;                               // lane k: m_index as call k finds it (-1 .. 4)
+        // State: mx = m_index & 3 (what Decimation leaves: -1 -> 3 after its "idx < 0" step, 4 -> 0), M = m_frag + 3.  F = M + (df + 1) is the
+        // new fraction + 4 (4 after an index step); the 64-bit constant maps F = 0..8 to the wrapped fraction and the carry + 1 (5 bits each).
+        // Eight calls per round: their new m_index + 2 are packed into one word and left with lanes 8 ch .. 8 ch + 7.
+        const unsigned long long kFrac = 0x6ull | (0x8ull << 5) | (0x9ull << 10) | (0xAull << 15) | (0xBull << 20) | (0xCull << 25) | (0xDull << 30) | (0xEull << 35) | (0x10ull << 40);
+        uint32_t recw = 0;
         {
-            int mi = m_index, mf = m_frag;
-            for (int k = 0; k < K; k++) {
-                const uint32_t c = ((uint32_t)lane_of((int)codes, k) >> (4 * (mi & 3))) & 15u;   // Decimation leaves m_index & 3: -1 -> 3 (idx < 0 moves on by 4), 4 -> 0
-                const int di = (int)(c & 3u) - 1, df = (int)(c >> 2) - 1;
-                const int f = di != 0 ? 0 : mf + df;                    // a step of the index clears the fraction
-                const int carry = f >= 4 ? 1 : (f <= -4 ? -1 : 0);
-                mi = (mi & 3) + di + carry; mf = carry > 0 ? -3 : (carry < 0 ? 3 : f);
-                miv = lane == k + 1 ? (uint32_t)mi : miv;
+            uint32_t mx = (uint32_t)m_index & 3u, M = (uint32_t)(m_frag + 3), mraw = (uint32_t)(m_index + 2);
+            for (int ch = 0; ch < K / 8; ch++) {
+                uint32_t word = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t c = (uint32_t)lane_of((int)codes, 8 * ch + i) >> (4 * mx);
+                    const uint32_t d = c & 3u, e = (c >> 2) & 3u;
+                    const uint32_t F = d == 1u ? M + e : 4u;             // a step of the index clears the fraction
+                    const uint32_t t = (uint32_t)(kFrac >> (5 * F));
+                    M = t & 7u;
+                    mraw = mx + d + ((t >> 3) & 3u);                    // m_index + 2 = mx + (di + 1) + (carry + 1)
+                    word |= mraw << (4 * i);
+                    mx = (mraw + 2u) & 3u;
+                }
+                recw = (lane >> 3) == ch ? word : recw;
             }
-            m_index = mi; m_frag = mf;
+            m_frag = (int)M - 3;
+            const int m_prev = m_index; m_index = (int)mraw - 2;
+            // lane k: m_index as call k finds it = what call k - 1 left (lane 0: what the pass started with)
+            const uint32_t wprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)recw, 0x138, 0xF, 0xF, false);      // wave_shr:1
+            recw = lane == 0 ? (uint32_t)(m_prev + 2) : (wprev >> (4 * ((lane - 1) & 7))) & 15u;
         }
+        const uint32_t miv = recw - 2u;
         // ---- C. chips of this lane's call and their partial despread sums
         const int mi = (int)miv;
         const int cnt = act ? (mi < 0 ? 8 : (28 - mi + 3) >> 2) : 0;
@@ -465,19 +481,35 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         const int total = lane_of(incl, K - 1);
         const int g0 = chip_n + incl - cnt;                            // chips before this call's first, counted from the start of the symbol in progress
         const int sid0 = (int)(((uint32_t)g0 * 5958u) >> 16);          // g0 / 11 for g0 < 2^13
-        int c = g0 - 11 * sid0;
-        uint32_t partA = 0, partB = 0; bool crossed = false;
-        const bool m0 = mi == 0, m1 = mi == 1, m2 = mi == 2, m3 = mi == 3, m4 = mi >= 4;
+        const int c0 = g0 - 11 * sid0;                                  // the first chip's place in the Barker code
+        // chip j = the sample at offset max(mi + 4 j, 0): column mi & 3 of the block seen as 7 rows of 4, one row up for mi = 4, one row down
+        // (and sample 0 first) for mi = -1.  (Selects spelled out on lane masks: left to itself the optimiser turns the choice into a computed
+        // index and a 28-way select per chip.)
+        auto vsel = [](unsigned long long m, uint32_t a, uint32_t b) __attribute__((always_inline)) { uint32_t d; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m)); return d; };
+        const unsigned long long r0m = __ballot((mi & 1) != 0), r1m = __ballot((mi & 2) != 0), dnm = __ballot(mi < 0), upm = __ballot(mi == 4);
+        uint32_t col[7], y[8];
+#pragma unroll
+        for (int q = 0; q < 7; q++) col[q] = vsel(r1m, vsel(r0m, xs[4 * q + 3], xs[4 * q + 2]), vsel(r0m, xs[4 * q + 1], xs[4 * q]));
 #pragma unroll
         for (int j = 0; j < 8; j++) {
-            // the sample at offset max(mi + 4 j, 0) of the block (mi = -1 .. 4)
-            uint32_t v = xs[4 * j == 0 ? 0 : 4 * j - 1];
-            v = m0 ? xs[4 * j] : v; v = m1 ? xs[min(4 * j + 1, 27)] : v; v = m2 ? xs[min(4 * j + 2, 27)] : v; v = m3 ? xs[min(4 * j + 3, 27)] : v; v = m4 ? xs[min(4 * j + 4, 27)] : v;
-            uint32_t t;
-            if (c == 1 || c == 4) t = pk_sra(pk_sub(0u, v), 4);        // chips 1 and 4 are negated BEFORE the >> 4 (neg16, wrapping)
-            else { t = pk_sra(v, 4); if (c >= 8) t = pk_sub(0u, t); }   // chips 8..10 are subtracted after it
-            if (j < cnt) { if (crossed) partB = pk_add(partB, t); else partA = pk_add(partA, t); }
-            if (j < cnt) { c++; if (c == 11) { c = 0; crossed = true; } }
+            uint32_t v = col[min(j, 6)];
+            v = vsel(dnm, j == 0 ? xs[0] : col[j - 1], v);
+            if (j < 6) v = vsel(upm, col[j + 1], v);
+            y[j] = v;
+        }
+        // QuickBarkerDespread's signs as bit strings over j: chips 1 and 4 negated before the >> 4, chips 8..10 after it; the chips in front of
+        // the symbol boundary go to partA, the others to partB
+        const uint32_t preB = 0x9012u >> c0, postB = 0x380700u >> c0, crossB = 0x3FF800u >> c0, validB = (1u << cnt) - 1u;
+        const uint32_t aB = validB & ~crossB, bB = validB & crossB;
+        const bool crossed = bB != 0;
+        uint32_t partA = 0, partB = 0;
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const uint32_t m1 = (uint32_t)((int)(preB << (31 - j)) >> 31), m2 = (uint32_t)((int)(postB << (31 - j)) >> 31);
+            const uint32_t ma = (uint32_t)((int)(aB << (31 - j)) >> 31), mb = (uint32_t)((int)(bB << (31 - j)) >> 31);
+            uint32_t t = pk_sra(pk_sub(y[j] ^ m1, m1), 4);             // (v ^ -1) - (-1) = -v in each half, wrapping
+            t = pk_sub(t ^ m2, m2);
+            partA = pk_add(partA, t & ma); partB = pk_add(partB, t & mb);
         }
         // ---- D. symbols: the carried partial sum, then every lane's parts (wrapping int16 sums: accumulated wide, wrapped when read)
         lds_order();
