@@ -279,7 +279,7 @@ def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
 
 
-def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
+def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True):
     """Row f4 (802.11b receive graph): `ncaps` 44 MHz captures of one 1 Mbps DBPSK frame each (the modulator output recorded
     in tests/golden/refgraph_11b.npz, or a 500-byte frame from the compiled reference modulator when that library is
     here), noise added on the device.  A streaming integer path: 4 B per sample against the HBM roofline; the reference's
@@ -304,6 +304,9 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
     torch.cuda.synchronize()                                            # the handle's stream does not follow torch's
     rx.process_dev(flat, descs); res = rx.results()
     ok = sum(r["error_code"] == 1 for r in res)
+    for _ in range(3):                                                  # (the first calls after a read-back of results run slow: not the kernel's doing)
+        rx.process_dev(flat, descs)
+    rx.synchronize(); reps = max(reps, 20)
     torch.cuda.synchronize(); t0 = time.perf_counter()
     for _ in range(reps):
         rx.process_dev(flat, descs)
@@ -312,7 +315,7 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5):
            "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
            "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
-    if g.available():                                                   # the reference's 11b graph on this box's host cores, side by side
+    if cpu and g.available():                                           # the reference's 11b graph on this box's host cores, side by side
         import multiprocessing as mp
         import tempfile
         cores = host_cores()

@@ -442,35 +442,43 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             const int df = late_better ? (!a && b ? 1 : 0) : (!b && a ? -1 : 0);
             codes |= (uint32_t)((di + 1) | ((df + 1) << 2)) << (4 * mx);
         }
-        // State: mx = m_index & 3 (what Decimation leaves: -1 -> 3 after its "idx < 0" step, 4 -> 0), M = m_frag + 3.  F = M + (df + 1) is the
-        // new fraction + 4 (4 after an index step); the 64-bit constant maps F = 0..8 to the wrapped fraction and the carry + 1 (5 bits each).
-        // Eight calls per round: their new m_index + 2 are packed into one word and left with lanes 8 ch .. 8 ch + 7.
+        // State: mx = m_index & 3 (what Decimation leaves: -1 -> 3 after its "idx < 0" step, 4 -> 0), M = m_frag + 3.  As long as the index
+        // stays where it is every call just moves the fraction by its df, so a whole run of calls is settled by a prefix sum over the lanes:
+        // the run ends at the first call that steps the index (its own decision, or the fraction reaching +-4).  That one call is done exactly
+        // (F = M + (df + 1) is the new fraction + 4, or 4 after an index step; the 64-bit constant maps F = 0..8 to the wrapped fraction and
+        // the carry + 1, 5 bits each), and the next run starts behind it.
         const unsigned long long kFrac = 0x6ull | (0x8ull << 5) | (0x9ull << 10) | (0xAull << 15) | (0xBull << 20) | (0xCull << 25) | (0xDull << 30) | (0xEull << 35) | (0x10ull << 40);
-        uint32_t recw = 0;
+        const unsigned long long actm = K == 64 ? ~0ull : (1ull << K) - 1ull;
+        uint32_t miv2;                                                  // lane k: m_index + 2 as call k finds it
         {
             uint32_t mx = (uint32_t)m_index & 3u, M = (uint32_t)(m_frag + 3), mraw = (uint32_t)(m_index + 2);
-            for (int ch = 0; ch < K / 8; ch++) {
-                uint32_t word = 0;
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t c = (uint32_t)lane_of((int)codes, 8 * ch + i) >> (4 * mx);
-                    const uint32_t d = c & 3u, e = (c >> 2) & 3u;
-                    const uint32_t F = d == 1u ? M + e : 4u;             // a step of the index clears the fraction
-                    const uint32_t t = (uint32_t)(kFrac >> (5 * F));
-                    M = t & 7u;
-                    mraw = mx + d + ((t >> 3) & 3u);                    // m_index + 2 = mx + (di + 1) + (carry + 1)
-                    word |= mraw << (4 * i);
-                    mx = (mraw + 2u) & 3u;
-                }
-                recw = (lane >> 3) == ch ? word : recw;
+            int k0 = 0;
+            miv2 = mraw;
+            while (k0 < K) {
+                miv2 = lane == k0 ? mraw : (lane > k0 ? mx + 2u : miv2);
+                const uint32_t c = codes >> (4 * mx);
+                const bool jump = (c & 3u) != 1u;
+                const int step = lane >= k0 && !jump ? (int)((c >> 2) & 3u) - 1 : 0;
+                int P = step;                                           // inclusive prefix sum (DPP, as scan_add in k_rx11n.hip)
+                P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xF, 0xF, true); P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xF, 0xF, true);
+                P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xF, 0xF, true); P += __builtin_amdgcn_update_dpp(0, P, 0x118, 0xF, 0xF, true);
+                P += __builtin_amdgcn_update_dpp(0, P, 0x142, 0xA, 0xF, false); P += __builtin_amdgcn_update_dpp(0, P, 0x143, 0xC, 0xF, false);
+                const unsigned long long evm = __ballot(lane >= k0 && (jump || (uint32_t)((int)M + P) > 6u)) & actm;
+                if (evm == 0) { M = (uint32_t)((int)M + lane_of(P, K - 1)); mraw = mx + 2u; break; }
+                const int ks = __builtin_ctzll(evm);
+                const uint32_t ck = (uint32_t)lane_of((int)c, ks);
+                const uint32_t d = ck & 3u, e = (ck >> 2) & 3u;
+                const uint32_t Mb = (uint32_t)((int)M + lane_of(P, ks)) - (d == 1u ? e - 1u : 0u);      // the fraction call ks finds
+                const uint32_t F = d == 1u ? Mb + e : 4u;
+                const uint32_t t = (uint32_t)(kFrac >> (5 * F));
+                M = t & 7u;
+                mraw = mx + d + ((t >> 3) & 3u);                        // m_index + 2 = mx + (di + 1) + (carry + 1)
+                mx = (mraw + 2u) & 3u;
+                k0 = ks + 1;
             }
-            m_frag = (int)M - 3;
-            const int m_prev = m_index; m_index = (int)mraw - 2;
-            // lane k: m_index as call k finds it = what call k - 1 left (lane 0: what the pass started with)
-            const uint32_t wprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)recw, 0x138, 0xF, 0xF, false);      // wave_shr:1
-            recw = lane == 0 ? (uint32_t)(m_prev + 2) : (wprev >> (4 * ((lane - 1) & 7))) & 15u;
+            m_frag = (int)M - 3; m_index = (int)mraw - 2;
         }
-        const uint32_t miv = recw - 2u;
+        const uint32_t miv = miv2 - 2u;
         // ---- C. chips of this lane's call and their partial despread sums
         const int mi = (int)miv;
         const int cnt = act ? (mi < 0 ? 8 : (28 - mi + 3) >> 2) : 0;
