@@ -386,14 +386,16 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     };
 
 
-    // ---- The payload in bulk.  Inside a frame's data field -- Barker aligned, rate and length known, whole source calls following one another -- the
-    // only serial dependence is the early-late timing loop, and that loop looks at nothing but the four phase energies of each 28-sample call.  So K
-    // calls are taken in one pass, one call per LANE: every lane computes its call's phase energies (v_dot2 on packed samples); a scalar loop of K
-    // short iterations runs the timing recurrence (TSymTiming::AdjustTiming, symtiming.hpp:118-170) and leaves each call its sampling phase; then the
-    // lanes pull their 6..8 chips, despread them into the (at most two) symbols they belong to -- every step of QuickBarkerDespread is a wrapping
-    // int16 add, so partial sums from different calls simply add up (LDS atomics) -- the symbols are demapped one per lane against their left
-    // neighbour, the bits are gathered with a ballot, and the bytes go through the same TDesc741 / TBB11bFrameSink code as ever.  K is chosen so that
-    // the frame's last bytes (the FCS event) are left to the call-by-call path below, which also handles every other phase.
+    // ---- Runs of source calls in bulk.  Once the receiver is aligned to the Barker code -- SFD search, PLCP header, 1 / 2 Mbps payload; whole
+    // source calls following one another -- the only serial dependence from call to call is the early-late timing loop, and that loop looks at
+    // nothing but the four phase energies of each 28-sample call.  So up to 64 calls are taken in one pass, one call per LANE: every lane computes
+    // its call's phase energies (v_dot2 on packed samples) and what AdjustTiming (symtiming.hpp:118-170) would decide at each sampling phase; the
+    // recurrence over the calls is settled in runs by prefix sums; then the lanes pull their 6..8 chips and despread them into the (at most two)
+    // symbols they belong to -- every step of QuickBarkerDespread is a wrapping int16 add, so partial sums from different calls simply add up
+    // (LDS atomics) -- and the symbols are demapped one per lane against their left neighbours, the bits gathered with a ballot, descrambled with
+    // two shifts and handed on as whole bytes.  A pass never contains an EVENT (SFD found or given up, the header's sixth byte, the FCS): header
+    // and payload passes are sized to stop short of it, an SFD pass is cut back to the calls in front of the one the event falls into; that call,
+    // like every other phase, goes through the call-by-call code.
     int* const sy_re = s_sym_all[wave][0]; int* const sy_im = s_sym_all[wave][1];
     auto writelane_u = [&](uint32_t& vec, uint32_t val, uint32_t ln) __attribute__((always_inline)) {
         vec = (uint32_t)lane == ln ? val : vec;
@@ -402,14 +404,20 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     auto pk_sub = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) - __builtin_bit_cast(bs16x2_t, b))); };
     auto pk_add = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) + __builtin_bit_cast(bs16x2_t, b))); };
     auto pk_sra = [](uint32_t a, int n) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) >> (short)n)); };
-    auto payload_pass = [&](uint32_t& pos_, uint32_t& remain_, uint32_t& c_start_, uint32_t& c_stale_, uint32_t& p_start_, uint32_t& p_stale_, int qoff_) __attribute__((always_inline)) -> bool {
+    auto bulk_pass = [&](uint32_t& pos_, uint32_t& remain_, uint32_t& c_start_, uint32_t& c_stale_, uint32_t& p_start_, uint32_t& p_stale_, int qoff_) __attribute__((always_inline)) -> bool {
         const int port = uni(rxrate);
-        const int spb = port == RATE_1M ? 8 : 4;                       // symbols per byte
-        if (byte_count + 1 >= frame_length) return false;
-        const int R = (int)(frame_length - 1 - byte_count);            // bytes still to complete before the FCS event
-        const int chips_to_event = 11 * (R * spb - sym_n) - chip_n;
-        const int K = min(port == RATE_1M ? 64 : 32, min((int)(remain_ / 28u), (chips_to_event - 1) / 8 - 1)) & ~7;   // (whole rounds of eight calls)
-        if (K < 8) return false;
+        const int mode = port == RATE_SYNC ? 0 : (uni(plcp_data) ? 2 : 1);          // 0: TSFDSync, 1: the PLCP header's bytes, 2: the payload's
+        if (mode == 1 && port != RATE_1M) return false;
+        const int spb = port == RATE_2M ? 4 : 8;                        // symbols per byte
+        int K = min(64, (int)(remain_ / 28u));
+        if (mode != 0) {
+            if (mode == 2 && byte_count + 1 >= frame_length) return false;
+            const int R = mode == 2 ? (int)(frame_length - 1 - byte_count) : 6 - hdr_n;     // bytes up to and including the one that raises the event
+            const int chips_to_event = 11 * (R * spb - sym_n) - chip_n;
+            K = min(port == RATE_2M ? 32 : K, min(K, (chips_to_event - 1) / 8 - 1));        // (2 Mbps: 32 calls fill the 64-bit bit string)
+        }
+        if (K < 6) return false;
+        const int m_index0 = m_index, m_frag0 = m_frag;
         const uint32_t base0 = pos_ - (uint32_t)qoff_;
         // ---- A. one call per lane: 28 samples, DC removed (TDCRemove: the estimate is frozen while demodulating), phase energies
         const bool act = lane < K;
@@ -449,11 +457,11 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         // the carry + 1, 5 bits each), and the next run starts behind it.
         const unsigned long long kFrac = 0x6ull | (0x8ull << 5) | (0x9ull << 10) | (0xAull << 15) | (0xBull << 20) | (0xCull << 25) | (0xDull << 30) | (0xEull << 35) | (0x10ull << 40);
         const unsigned long long actm = K == 64 ? ~0ull : (1ull << K) - 1ull;
-        uint32_t miv2;                                                  // lane k: m_index + 2 as call k finds it
+        uint32_t miv2, Mv;                                              // lane k: m_index + 2 and m_frag + 3 as call k finds them
         {
             uint32_t mx = (uint32_t)m_index & 3u, M = (uint32_t)(m_frag + 3), mraw = (uint32_t)(m_index + 2);
             int k0 = 0;
-            miv2 = mraw;
+            miv2 = mraw; Mv = M;
             while (k0 < K) {
                 miv2 = lane == k0 ? mraw : (lane > k0 ? mx + 2u : miv2);
                 const uint32_t c = codes >> (4 * mx);
@@ -463,6 +471,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 P += __builtin_amdgcn_update_dpp(0, P, 0x111, 0xF, 0xF, true); P += __builtin_amdgcn_update_dpp(0, P, 0x112, 0xF, 0xF, true);
                 P += __builtin_amdgcn_update_dpp(0, P, 0x114, 0xF, 0xF, true); P += __builtin_amdgcn_update_dpp(0, P, 0x118, 0xF, 0xF, true);
                 P += __builtin_amdgcn_update_dpp(0, P, 0x142, 0xA, 0xF, false); P += __builtin_amdgcn_update_dpp(0, P, 0x143, 0xC, 0xF, false);
+                Mv = lane >= k0 ? (uint32_t)((int)M + P - step) : Mv;
                 const unsigned long long evm = __ballot(lane >= k0 && (jump || (uint32_t)((int)M + P) > 6u)) & actm;
                 if (evm == 0) { M = (uint32_t)((int)M + lane_of(P, K - 1)); mraw = mx + 2u; break; }
                 const int ks = __builtin_ctzll(evm);
@@ -520,66 +529,113 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             partA = pk_add(partA, t & ma); partB = pk_add(partB, t & mb);
         }
         // ---- D. symbols: the carried partial sum, then every lane's parts (wrapping int16 sums: accumulated wide, wrapped when read)
-        lds_order();
-        sy_re[lane] = lane == 0 ? acc_re : 0; sy_im[lane] = lane == 0 ? acc_im : 0;
-        lds_order();
-        if (cnt > 0) {
-            atomicAdd(&sy_re[sid0], (int)(short)(partA & 0xFFFFu)); atomicAdd(&sy_im[sid0], (int)partA >> 16);
-            if (crossed && sid0 + 1 < 64) { atomicAdd(&sy_re[sid0 + 1], (int)(short)(partB & 0xFFFFu)); atomicAdd(&sy_im[sid0 + 1], (int)partB >> 16); }
-        }
-        lds_order();
-        const int T = chip_n + total;
-        const int nsym = (int)(((uint32_t)T * 5958u) >> 16);           // symbols completed in this pass
-        const int sre = w16(sy_re[lane]), sim = w16(sy_im[lane]);      // lane s: symbol s
+        auto despread_sum = [&](int kc) __attribute__((always_inline)) {
+            lds_order();
+            sy_re[lane] = lane == 0 ? acc_re : 0; sy_im[lane] = lane == 0 ? acc_im : 0;
+            lds_order();
+            if (cnt > 0 && lane < kc) {
+                atomicAdd(&sy_re[sid0], (int)(short)(partA & 0xFFFFu)); atomicAdd(&sy_im[sid0], (int)partA >> 16);
+                if (crossed && sid0 + 1 < 64) { atomicAdd(&sy_re[sid0 + 1], (int)(short)(partB & 0xFFFFu)); atomicAdd(&sy_im[sid0 + 1], (int)partB >> 16); }
+            }
+            lds_order();
+        };
+        despread_sum(K);
+        int Kc = K;                                                     // calls this pass commits
+        int T = chip_n + total;
+        int nsym = (int)(((uint32_t)T * 5958u) >> 16);                  // symbols completed in this pass
+        int sre = w16(sy_re[lane]), sim = w16(sy_im[lane]);             // lane s: symbol s
         const int pre_i = lane > 0 ? lane - 1 : 0;
         int qre = w16(sy_re[pre_i]), qim = w16(sy_im[pre_i]);          // its left neighbour = the differential reference
-        const int cin_re = sym_n == 0 ? last_re : ref_re, cin_im = sym_n == 0 ? last_im : ref_im;
-        if (lane == 0) { qre = cin_re; qim = cin_im; }
-        // ---- E. bits (TDBPSKDemap / TDQPSKDemap, barkerspread.hpp:312-454) and bytes
-        unsigned long long W; int nbits;
-        if (port == RATE_1M) {
-            const unsigned long long b0 = __ballot(lane < nsym && dot_sign(qre, qim, sre, sim));
-            W = (unsigned long long)sym_byte | (b0 << sym_n); nbits = sym_n + nsym;
+        const unsigned long long below = (1ull << lane) - 1ull;
+        if (mode == 0) {
+            // ---- E0. TSFDSync (sfd_sync.hpp:76-126), a symbol per lane: DBPSK bit against the previous symbol, descrambled, the 16-bit window
+            // compared with all-ones and with the SFD; "ones seen before" and the error count are prefix counts over lane masks
+            if (lane == 0) { qre = last_re; qim = last_im; }
+            const bool in = lane < nsym;
+            const unsigned long long bits = __ballot(in && dot_sign(qre, qim, sre, sim));
+            const unsigned long long S = (bits << 7) | (unsigned long long)(byte_reg & 0x7Fu);
+            const unsigned long long O = (S >> 7) ^ (S >> 3) ^ S;
+            const unsigned long long Bw = (unsigned long long)(word & 0xFFFFu) | (O << 16);      // word after symbol n = bits n + 1 .. n + 16
+            const uint32_t wn = (uint32_t)(Bw >> (lane + 1)) & 0xFFFFu;
+            const bool ones = wn == 0xFFFFu, sfd = wn == 0xF3A0u;
+            const unsigned long long onesm = __ballot(in && ones);
+            const bool found = bit_one_found != 0 || (onesm & below) != 0;
+            const bool err = found && !sfd && !ones;
+            const unsigned long long errm = __ballot(in && err);
+            const bool fail = err && bit_err_cnt + (int)__popcll(errm & below) > 32;
+            const bool late = sync_cnt + (uint32_t)lane + 1u > 128u + 16u;
+            const unsigned long long evs = __ballot(in && ((found && sfd) || fail || late));
+            if (evs != 0) {                                             // cut back to the calls in front of the one that completes the event's symbol
+                const int gt = 11 * (__builtin_ctzll(evs) + 1) - 1;
+                Kc = __builtin_ctzll(__ballot(act && g0 <= gt && gt < g0 + cnt));
+                if (Kc == 0) { m_index = m_index0; m_frag = m_frag0; return false; }
+                despread_sum(Kc);
+                sre = w16(sy_re[lane]); sim = w16(sy_im[lane]);
+                T = chip_n + lane_of(incl, Kc - 1); nsym = (int)(((uint32_t)T * 5958u) >> 16);
+                m_index = (int)lane_of((int)miv2, Kc) - 2; m_frag = (int)lane_of((int)Mv, Kc) - 3;
+            }
+            const unsigned long long done = (1ull << nsym) - 1ull;      // (nsym <= 47)
+            if (nsym > 0) { last_re = lane_of(sre, nsym - 1); last_im = lane_of(sim, nsym - 1); }
+            byte_reg = (uint32_t)(S >> nsym) & 0x7Fu; word = (uint32_t)(Bw >> nsym) & 0xFFFFu;
+            sync_cnt += (uint32_t)nsym;
+            bit_one_found |= (onesm & done) != 0 ? 1 : 0;
+            bit_err_cnt += (int)__popcll(errm & done);
         } else {
-            const int re = (int)((uint32_t)(qre * sre) + (uint32_t)(qim * sim)), im = (int)((uint32_t)(qre * sim) - (uint32_t)(qim * sre));
-            unsigned long long b0 = __ballot(lane < nsym && ((((uint32_t)re + (uint32_t)im) >> 31) != 0));
-            unsigned long long b1 = __ballot(lane < nsym && ((((uint32_t)re - (uint32_t)im) >> 31) != 0));
-            auto spread = [](unsigned long long v) { v &= 0xFFFFFFFFull; v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-                                                     v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full; v = (v | (v << 2)) & 0x3333333333333333ull; v = (v | (v << 1)) & 0x5555555555555555ull; return v; };
-            W = (unsigned long long)sym_byte | ((spread(b0) | (spread(b1) << 1)) << (2 * sym_n)); nbits = 2 * (sym_n + nsym);
-        }
-        const int nbytes = nbits >> 3;
-        // TDesc741 is self-synchronising -- out[n] = in[n] ^ in[n-4] ^ in[n-7] -- so the whole bit string is descrambled with two shifts
-        const unsigned long long S = (W << 7) | (unsigned long long)(byte_reg & 0x7Fu);
-        const unsigned long long O = (S >> 7) ^ (S >> 3) ^ S;
-        const uint32_t ob = (uint32_t)(O >> (8 * (lane & 7))) & 0xFFu;  // lane i: the i-th byte for TBB11bFrameSink (at most 6 complete in a pass)
-        if (nbytes > 0) {
-            byte_reg = (uint32_t)(W >> (8 * nbytes - 7)) & 0x7Fu;
-            const uint32_t idx = byte_count + (uint32_t)lane;
-            if (lane < nbytes && idx < kOutBuf) s_out[idx] = (uint8_t)ob;
-            // CRC-32 of the bytes in front of the FCS, all at once: byte i of n goes through the table that also carries it over the n - 1 - i
-            // bytes behind it; the register's four bytes enter with the first four message bytes
-            const uint32_t lim = (uint32_t)((int)frame_length - 4);
-            const int n = byte_count >= lim ? 0 : (int)min((uint32_t)nbytes, lim - byte_count);
-            uint32_t v = 0;
-            if (lane < n) v = s_crc_all[n - 1 - lane][(ob ^ (lane < 4 ? crc32 >> (8 * lane) : 0u)) & 0xFFu];
-            v ^= (uint32_t)dpp<0xB1>((int)v); v ^= (uint32_t)dpp<0x4E>((int)v); v ^= (uint32_t)dpp<0x141>((int)v);      // xor over lanes 0..7
-            crc32 = (uint32_t)lane_of((int)v, 0) ^ (n < 4 ? crc32 >> (8 * n) : 0u);
-            byte_count += (uint32_t)nbytes;
+            // ---- E. bits (TDBPSKDemap / TDQPSKDemap, barkerspread.hpp:312-454) and bytes
+            const int cin_re = sym_n == 0 ? last_re : ref_re, cin_im = sym_n == 0 ? last_im : ref_im;
+            if (lane == 0) { qre = cin_re; qim = cin_im; }
+            unsigned long long W; int nbits;
+            if (port == RATE_1M) {
+                const unsigned long long b0 = __ballot(lane < nsym && dot_sign(qre, qim, sre, sim));
+                W = (unsigned long long)sym_byte | (b0 << sym_n); nbits = sym_n + nsym;
+            } else {
+                const int re = (int)((uint32_t)(qre * sre) + (uint32_t)(qim * sim)), im = (int)((uint32_t)(qre * sim) - (uint32_t)(qim * sre));
+                unsigned long long b0 = __ballot(lane < nsym && ((((uint32_t)re + (uint32_t)im) >> 31) != 0));
+                unsigned long long b1 = __ballot(lane < nsym && ((((uint32_t)re - (uint32_t)im) >> 31) != 0));
+                auto spread = [](unsigned long long v) { v &= 0xFFFFFFFFull; v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
+                                                         v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full; v = (v | (v << 2)) & 0x3333333333333333ull; v = (v | (v << 1)) & 0x5555555555555555ull; return v; };
+                W = (unsigned long long)sym_byte | ((spread(b0) | (spread(b1) << 1)) << (2 * sym_n)); nbits = 2 * (sym_n + nsym);
+            }
+            const int nbytes = nbits >> 3;
+            // TDesc741 is self-synchronising -- out[n] = in[n] ^ in[n-4] ^ in[n-7] -- so the whole bit string is descrambled with two shifts
+            const unsigned long long S = (W << 7) | (unsigned long long)(byte_reg & 0x7Fu);
+            const unsigned long long O = (S >> 7) ^ (S >> 3) ^ S;
+            if (nbytes > 0) {
+                byte_reg = (uint32_t)(W >> (8 * nbytes - 7)) & 0x7Fu;
+                if (mode == 1) {                                        // TBB11bPlcpSwitch -> TBB11bPlcpParser's burst (at most five bytes: the sixth is the event)
+                    for (int i = 0; i < nbytes; i++) {
+                        const uint32_t sh = ((uint32_t)(O >> (8 * i)) & 0xFFu) << (8 * (hdr_n & 3));
+                        hdr_lo |= hdr_n < 4 ? sh : 0u; hdr_hi |= hdr_n < 4 ? 0u : sh;
+                        hdr_n++;
+                    }
+                } else {
+                    const uint32_t ob = (uint32_t)(O >> (8 * (lane & 7))) & 0xFFu;  // lane i: the i-th byte for TBB11bFrameSink (at most 6 complete in a pass)
+                    const uint32_t idx = byte_count + (uint32_t)lane;
+                    if (lane < nbytes && idx < kOutBuf) s_out[idx] = (uint8_t)ob;
+                    // CRC-32 of the bytes in front of the FCS, all at once: byte i of n goes through the table that also carries it over the
+                    // n - 1 - i bytes behind it; the register's four bytes enter with the first four message bytes
+                    const uint32_t lim = (uint32_t)((int)frame_length - 4);
+                    const int n = byte_count >= lim ? 0 : (int)min((uint32_t)nbytes, lim - byte_count);
+                    uint32_t v = 0;
+                    if (lane < n) v = s_crc_all[n - 1 - lane][(ob ^ (lane < 4 ? crc32 >> (8 * lane) : 0u)) & 0xFFu];
+                    v ^= (uint32_t)dpp<0xB1>((int)v); v ^= (uint32_t)dpp<0x4E>((int)v); v ^= (uint32_t)dpp<0x141>((int)v);      // xor over lanes 0..7
+                    crc32 = (uint32_t)lane_of((int)v, 0) ^ (n < 4 ? crc32 >> (8 * n) : 0u);
+                    byte_count += (uint32_t)nbytes;
+                }
+            }
+            if (nsym > 0) {
+                ref_re = lane_of(sre, nsym - 1); ref_im = lane_of(sim, nsym - 1);
+                if (nbytes > 0) { const int ls = nbytes * spb - sym_n - 1; last_re = lane_of(sre, ls); last_im = lane_of(sim, ls); }
+            }
+            sym_n = sym_n + nsym - nbytes * spb; sym_byte = (uint32_t)(W >> (8 * nbytes)) & 0xFFu;
         }
         // ---- F. what the pass leaves behind
-        const int symtot = sym_n + nsym;
-        if (nsym > 0) {
-            ref_re = lane_of(sre, nsym - 1); ref_im = lane_of(sim, nsym - 1);
-            if (nbytes > 0) { const int ls = nbytes * spb - sym_n - 1; last_re = lane_of(sre, ls); last_im = lane_of(sim, ls); }
-        }
-        sym_n = symtot - nbytes * spb; sym_byte = (uint32_t)(W >> (8 * nbytes)) & 0xFFu;
         chip_n = T - 11 * nsym;
         acc_re = w16(lane_of(sre, nsym)); acc_im = w16(lane_of(sim, nsym));
-        const uint32_t adv = 28u * (uint32_t)K;
-        const uint32_t s0_ = c_start_;
+        const uint32_t adv = 28u * (uint32_t)Kc;
+        const uint32_t s0_ = c_start_, st0_ = c_stale_;
         pos_ += adv; remain_ -= adv;
-        c_start_ = s0_ + adv; c_stale_ = s0_ + adv - 28u; p_start_ = s0_ + adv - 28u; p_stale_ = s0_ + adv - 56u;
+        c_start_ = s0_ + adv; c_stale_ = s0_ + adv - 28u; p_start_ = s0_ + adv - 28u; p_stale_ = Kc >= 2 ? s0_ + adv - 56u : st0_;
         return true;
     };
 
@@ -652,7 +708,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 // calls are taken right here.  Same semantics as going round the outer loop -- MAC11b_Receive only looks at
                 // error_code after a call -- but in a loop of its own the compiler keeps just this phase's state in registers.
                 while (error_code == 0 && sync_flag == BARKER_SYNCED && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
-                    if (uni(plcp_data) && uni(rxrate) >= RATE_1M && uni(rxrate) <= RATE_2M && qoff % 4 == 0 && payload_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28; pf_ok = false; continue; }
+                    if (uni(rxrate) <= RATE_2M && bulk_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28; pf_ok = false; continue; }
                     p_start = c_start; p_take = 28; p_stale = c_stale;
                     c_stale = c_start; c_start = pos; pos += 28; remain -= 28;
                     const uint32_t base = c_start - (uint32_t)qoff;
