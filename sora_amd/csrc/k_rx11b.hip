@@ -672,33 +672,57 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             c_stale = c_start; c_start = pos; c_take = remain > 28 ? 28u : remain;
             pos += c_take; remain -= c_take;
             if (!power) {
+                // TDCRemove -> TBB11bRxSwitch -> TEnergyDetect -> TDCEstimator on the call's seven bursts (of four samples) at once: lane = sample.
+                // The only thing that moves inside a call is the DC estimate, once at most (every 8th burst, after burst j0 = update_cnt): the
+                // bursts are evaluated with the old and with the new estimate and each takes its own; window average, counter and threshold are
+                // prefix sums over the bursts; what lies behind the burst that raises power (or gives up) is not committed.
                 const cpx r = unpack(fetch28(c_start, c_take == 28, entry(c_start, c_take, c_stale, lane)));
-                int first_queued = 7;                                   // first burst (of 7) of this call that goes to TSymTiming
-                for (int i = 0; i < 7; i++) {                          // TDCRemove -> TBB11bRxSwitch -> TEnergyDetect -> TDCEstimator, burst by burst
-                    const int vre = w16(r.re - dc_re), vim = w16(r.im - dc_im);
-                    uint32_t en = (uint32_t)(((int)((uint32_t)(vre * vre) + (uint32_t)(vim * vim))) >> 5);
-                    en = (uint32_t)quad_sum((int)en);
-                    const uint32_t ave = (uint32_t)lane_of((int)en, 4 * i);
-                    {                                                   // the 8-entry window as a FIFO in LDS (same order as the circular buffer)
-                        const uint32_t w = lane < 8 ? win[lane] : 0u;
-                        avg_energy = avg_energy - (uint32_t)lane_of((int)w, 0) + ave;
-                        lds_order();
-                        const uint32_t nxt = (uint32_t)__shfl_down((int)w, 1);
-                        if (lane < 8) win[lane] = lane < 7 ? nxt : ave;
-                        lds_order();
-                    }
-                    ecount++;
-                    if (ecount >= 32) {
-                        if (ecount >= 100) { error_code = E_CS_TIMEOUT; break; }
-                        if (avg_energy >= thr) power = 1;
-                    }
-                    if (power) { first_queued = i + 1; break; }         // energy gating: this burst reaches neither estimator nor demodulator
-                    int hr = vre >> 5, hi = vim >> 5;                   // TDCEstimator: hadd(shift_right(pi, 5)) in wrapping int16
-                    hr = quad_sum(hr); hi = quad_sum(hi);
-                    sdc_re = w16(sdc_re + w16(lane_of(hr, 4 * i))); sdc_im = w16(sdc_im + w16(lane_of(hi, 4 * i)));
-                    if (update_cnt == 0) { dc_re = w16(dc_re + (sdc_re >> 2)); dc_im = w16(dc_im + (sdc_im >> 2)); update_cnt = 8; sdc_re = sdc_im = 0; }
-                    update_cnt--;
+                const int bq = lane >> 2;                               // this lane's burst
+                auto burst_prefix = [&](int v) __attribute__((always_inline)) {        // inclusive prefix over bursts of a per-burst value (same in a quad's lanes)
+                    v = (int)((uint32_t)v + (uint32_t)dpp<0x114>(v)); v = (int)((uint32_t)v + (uint32_t)dpp<0x118>(v));     // row_shr:4, row_shr:8
+                    return (int)((uint32_t)v + (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));        // + row 0's total (its lane 15) in row 1
+                };
+                const int j0 = (int)update_cnt;
+                const int v1re = w16(r.re - dc_re), v1im = w16(r.im - dc_im);
+                const int h1re = w16(quad_sum(v1re >> 5)), h1im = w16(quad_sum(v1im >> 5));      // TDCEstimator: hadd(shift_right(pi, 5)) in wrapping int16
+                const int p1re = burst_prefix(h1re), p1im = burst_prefix(h1im);
+                const int j0c = min(j0, 6);
+                const int dcn_re = w16(dc_re + (w16(sdc_re + lane_of(p1re, 4 * j0c)) >> 2)), dcn_im = w16(dc_im + (w16(sdc_im + lane_of(p1im, 4 * j0c)) >> 2));
+                const bool nw = bq > j0;                                // bursts behind the update see the new estimate
+                const int vre = nw ? w16(r.re - dcn_re) : v1re, vim = nw ? w16(r.im - dcn_im) : v1im;
+                const int q2re = w16(quad_sum(vre >> 5)), q2im = w16(quad_sum(vim >> 5));
+                const int h2re = nw ? q2re : 0, h2im = nw ? q2im : 0;
+                const int p2re = burst_prefix(h2re), p2im = burst_prefix(h2im);
+                const uint32_t ave = (uint32_t)quad_sum((int)(uint32_t)(((int)((uint32_t)(vre * vre) + (uint32_t)(vim * vim))) >> 5));
+                const uint32_t wold = lane < 8 ? win[lane] : 0u;        // the 8-entry window, oldest first
+                const uint32_t wout = (uint32_t)__shfl((int)wold, bq);  // the entry burst bq pushes out (7 bursts never reach a new one)
+                const uint32_t avg = avg_energy + (uint32_t)burst_prefix((int)(ave - wout));
+                const uint32_t ecn = ecount + (uint32_t)bq + 1u;
+                const unsigned long long evb = __ballot(lane < 28 && (lane & 3) == 0 && ecn >= 32u && (ecn >= 100u || avg >= thr));
+                const int js = evb != 0 ? __builtin_ctzll(evb) >> 2 : 7; // the burst that ends carrier sensing, if any
+                const int np = min(js + 1, 7), nd = min(js, 7);         // bursts through TEnergyDetect / through TDCEstimator
+                avg_energy = (uint32_t)lane_of((int)avg, 4 * (np - 1));
+                {                                                       // the window moves on by np entries
+                    const uint32_t av8 = (uint32_t)__shfl((int)ave, 4 * (lane - 8));     // (a statement of its own: inside the select's arm it would run with
+                    const uint32_t comb = lane < 8 ? wold : av8;                           //  lanes 0..7 switched off, and a permute reads 0 from such lanes)
+                    const uint32_t wnew = (uint32_t)__shfl((int)comb, lane + np);
+                    lds_order();
+                    if (lane < 8) win[lane] = wnew;
+                    lds_order();
                 }
+                if (js < 7) { if (ecount + (uint32_t)js + 1u >= 100u) error_code = E_CS_TIMEOUT; else power = 1; }
+                ecount += (uint32_t)np;
+                if (nd > 0) {
+                    if (j0 < nd) {                                      // the estimate was renewed after burst j0; bursts j0 + 1 .. nd - 1 went into the new sum
+                        dc_re = dcn_re; dc_im = dcn_im;
+                        sdc_re = w16(lane_of(p2re, 4 * (nd - 1))); sdc_im = w16(lane_of(p2im, 4 * (nd - 1)));
+                        update_cnt = (uint32_t)(8 - (nd - j0));
+                    } else {
+                        sdc_re = w16(sdc_re + lane_of(p1re, 4 * (nd - 1))); sdc_im = w16(sdc_im + lane_of(p1im, 4 * (nd - 1)));
+                        update_cnt -= (uint32_t)nd;
+                    }
+                }
+                const int first_queued = js + 1;
                 if (power) qoff = 4 * (7 - first_queued);               // the tail of the call in which power came up is queued
             } else {                                                    // a whole call: the queue hands TSymTiming one block of 28
                 const uint32_t at = lane < qoff ? entry(p_start, p_take, p_stale, 28 - qoff + lane) : entry(c_start, c_take, c_stale, lane - qoff);
