@@ -4,14 +4,22 @@
     python tools/summarize_pmc.py <FETCH_SIZE counter_collection.csv> <WRITE_SIZE counter_collection.csv> <frames per launch> [<SQ_INSTS counter_collection.csv>] > profiles/rNN_traffic.json
 
 FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (they come from the L2's memory-side request counters).
-Corrections applied as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950: FETCH_SIZE is doubled
-(128-byte requests tallied at 64 bytes); WRITE_SIZE is taken as reported (uncalibrated).  The two counters cannot share
-a pass, so each file comes from its own run of the same command.
+Corrections as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950 -- FETCH_SIZE reports half the bytes
+of a coalesced vector read; "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known byte count in your
+own access pattern" -- with the calibration done: tools/calib/fetch_calib moves 1 GiB in each access shape the kernels use
+(profiles/r02_k_calibration.json): vector loads, 16 B or 4 B per lane: reported / moved = 0.5; SCALAR loads (s_load_dwordx8,
+the way k_viterbi / k_viterbi11n read their soft values): 1.0; stores of 16 B, 4 B and 1 B per lane: 1.0.  So FETCH_SIZE is
+doubled for every kernel except the scalar-fed ones, WRITE_SIZE is taken as reported.  (Before this calibration the doubling
+was applied to all kernels, which counted k_viterbi's input twice: profiles up to r02_i.)  The two counters cannot share a
+pass, so each file comes from its own run of the same command.
 """
 import csv
 import json
 import sys
 from collections import defaultdict
+
+
+SCALAR_FED = ("k_viterbi", "k_viterbi11n")          # bulk input through s_load (dev_viterbi.h): FETCH_SIZE counts those requests in full
 
 
 def per_kernel(path, counter):
@@ -31,14 +39,14 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     out = {"unit": "bytes per launch", "frames_per_launch": frames,
-           "corrections": "FETCH_SIZE KiB x1024 x2 (gfx950: 128-B requests tallied at 64 B); WRITE_SIZE KiB x1024 as reported",
+           "corrections": "FETCH_SIZE KiB x1024, x2 for kernels fed by vector loads, x1 for kernels fed by scalar loads (k_viterbi, k_viterbi11n); WRITE_SIZE KiB x1024 as reported; factors measured by tools/calib/fetch_calib (profiles/r02_k_calibration.json)",
            "kernels": {}}
     total = 0.0
     rx_path = ("k_scan", "k_frame", "k_viterbi", "k_decode", "k_finish")      # one receive call (split or fused chain); other kernels (k_pack, ingest, tx) are listed only
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
-        fb = fetch.get(k, (0.0, 0))[0] * 1024 * 2
+        fb = fetch.get(k, (0.0, 0))[0] * 1024 * (1 if k in SCALAR_FED else 2)
         wb = write.get(k, (0.0, 0))[0] * 1024
         out["kernels"][k] = {"fetch_bytes": round(fb), "write_bytes": round(wb), "hbm_bytes": round(fb + wb),
                              "launches_sampled": fetch.get(k, (0.0, 0))[1]}
