@@ -158,12 +158,16 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8
     const int nblk = j - m_lo;                                                  // blocks below j on the walk
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    uint32_t W[kMaxWalk];                                                       // W[i] = block j - i, all 64 ring entries (one per lane)
-    const int sl0 = (j % kRingBlocks) * 64;
+    // W[i] = block j - i, all 64 ring entries (one per lane).  Read as LDS (a generic pointer would make these flat loads with 64-bit address
+    // arithmetic each); the ring slot steps down with a borrow-select (s_sub_u32 + s_cselect), the address is one v_lshl_or.
+    typedef const uint16_t __attribute__((address_space(3))) lds_u16;
+    lds_u16* lring = (lds_u16*)(uint32_t)(uintptr_t)ring;                       // the low half of a flat LDS address is the LDS offset
+    uint32_t W[kMaxWalk];
+    unsigned slot = uni((unsigned)j % (unsigned)kRingBlocks);
 #pragma unroll
     for (int i = 0; i < kMaxWalk; i++) {
-        const int sl = sl0 - 64 * i;
-        W[i] = ring[(sl < 0 ? sl + kRingBlocks * 64 : sl) + (int)lane];
+        W[i] = lring[(slot << 6) | lane];
+        asm("s_sub_u32 %0, %0, 1\n\ts_cselect_b32 %0, %1, %0" : "+s"(slot) : "n"(kRingBlocks - 1) : "scc");       // slot = slot ? slot - 1 : kRingBlocks - 1
     }
     unsigned HA, HB;
     if (n == 8) {
@@ -171,20 +175,26 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
         HB = ((unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stB)) >> 8) & 0xFFu;
     } else { HA = pA & ((1u << n) - 1u); HB = pB & ((1u << n) - 1u); }
     unsigned qA = rev6(((stA >> n) | rev6(HA & 0x3Fu)) & 0x3Fu), qB = rev6(((stB >> n) | rev6(HB & 0x3Fu)) & 0x3Fu);   // ring index at column 8j
-    unsigned hvA = 0, hvB = 0;                                                  // lane i <- decisions of block m_lo + i
-    writelane(hvA, HA, (unsigned)nblk); writelane(hvB, HB, (unsigned)nblk);
+    // The walk, top down: lane i <- the word of block j - i along frame A's path (tA) and along frame B's (tB).  It always runs its full
+    // length (blocks below the window are read and never used; a window shorter than the longest happens once per frame).  Per block and
+    // frame one v_readlane -- its lane select only looks at the low six bits, so the word just read IS the next ring index (frame A's as
+    // it stands, frame B's after a shift) -- and one v_writelane with a constant lane.  (s_nop 1: a VALU that reads an SGPR written by
+    // the VALU two instructions earlier; the assembler block is not seen by the compiler's hazard pass.)
+    unsigned tA = 0, tB = 0;
+    asm("s_nop 1\n\tv_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(tA), "+v"(tB) : "s"(HA), "s"(HB << 8));
 #pragma unroll
     for (int i = 1; i < kMaxWalk; i++) {
-        if (i <= nblk) {
-            HA = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qA) & 0xFFu;          qA = HA & 0x3Fu;
-            HB = ((unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB) >> 8) & 0xFFu;   qB = HB & 0x3Fu;
-            writelane(hvA, HA, (unsigned)(nblk - i)); writelane(hvB, HB, (unsigned)(nblk - i));
-        }
+        const unsigned rA = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qA);
+        const unsigned rB = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB);
+        qA = rA; qB = rB >> 8;
+        asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(tA), "+v"(tB) : "s"(rA), "s"(rB), "n"(i));
     }
-    // decoded byte m = (block m >> 6) | (block m+1 & 0x3F) << 2, lane i <-> byte m_lo + i
-    const unsigned upA = (unsigned)__shfl_down((int)hvA, 1), upB = (unsigned)__shfl_down((int)hvB, 1);
-    if (lane < (cntA >> 3)) outA[m_lo + (int)lane] = (uint8_t)((hvA >> 6) | ((upA & 0x3Fu) << 2));
-    if (lane < (cntB >> 3)) outB[m_lo + (int)lane] = (uint8_t)((hvB >> 6) | ((upB & 0x3Fu) << 2));
+    // decoded byte m = (block m >> 6) | (block m+1 & 0x3F) << 2; lane L <-> byte m_lo + L <-> blocks at walk positions nblk - L and nblk - L - 1
+    const int at = (nblk - (int)lane) << 2;
+    const unsigned loA = (unsigned)__builtin_amdgcn_ds_bpermute(at, (int)tA) & 0xFFu, upA = (unsigned)__builtin_amdgcn_ds_bpermute(at - 4, (int)tA) & 0xFFu;
+    const unsigned loB = ((unsigned)__builtin_amdgcn_ds_bpermute(at, (int)tB) >> 8) & 0xFFu, upB = ((unsigned)__builtin_amdgcn_ds_bpermute(at - 4, (int)tB) >> 8) & 0xFFu;
+    if (lane < (cntA >> 3)) outA[m_lo + (int)lane] = (uint8_t)((loA >> 6) | ((upA & 0x3Fu) << 2));
+    if (lane < (cntB >> 3)) outB[m_lo + (int)lane] = (uint8_t)((loB >> 6) | ((upB & 0x3Fu) << 2));
 }
 
 }  // namespace sora
