@@ -158,17 +158,18 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8
     const int nblk = j - m_lo;                                                  // blocks below j on the walk
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // W[i] = block j - i, all 64 ring entries (one per lane).  Read as LDS (a generic pointer would make these flat loads with 64-bit address
-    // arithmetic each); the ring slot steps down with a borrow-select (s_sub_u32 + s_cselect), the address is one v_lshl_or.
-    typedef const uint16_t __attribute__((address_space(3))) lds_u16;
-    lds_u16* lring = (lds_u16*)(uint32_t)(uintptr_t)ring;                       // the low half of a flat LDS address is the LDS offset
+    // W[i] = block j - i, all 64 ring entries (one per lane).  Read as LDS (through the generic pointer these were flat loads with 64-bit
+    // address arithmetic each); the ring slot steps down with a borrow-select (s_sub_u32 + s_cselect), the address is one v_lshl_add.
+    const unsigned ring_off = (unsigned)(uintptr_t)ring;                        // the low half of a flat LDS address is the LDS offset
     uint32_t W[kMaxWalk];
     unsigned slot = uni((unsigned)j % (unsigned)kRingBlocks);
 #pragma unroll
     for (int i = 0; i < kMaxWalk; i++) {
-        W[i] = lring[(slot << 6) | lane];
+        const unsigned addr = ring_off + (((slot << 6) | lane) << 1);
+        asm volatile("ds_read_u16 %0, %1" : "=v"(W[i]) : "v"(addr) : "memory");                                      // (zero-extends: no masking afterwards)
         asm("s_sub_u32 %0, %0, 1\n\ts_cselect_b32 %0, %1, %0" : "+s"(slot) : "n"(kRingBlocks - 1) : "scc");       // slot = slot ? slot - 1 : kRingBlocks - 1
     }
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]) : : "memory");             // (W[1..] are only used by the assembler blocks below, which stay behind this one)
     unsigned HA, HB;
     if (n == 8) {
         HA = (unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stA)) & 0xFFu;
@@ -178,16 +179,21 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     // The walk, top down: lane i <- the word of block j - i along frame A's path (tA) and along frame B's (tB).  It always runs its full
     // length (blocks below the window are read and never used; a window shorter than the longest happens once per frame).  Per block and
     // frame one v_readlane -- its lane select only looks at the low six bits, so the word just read IS the next ring index (frame A's as
-    // it stands, frame B's after a shift) -- and one v_writelane with a constant lane.  (s_nop 1: a VALU that reads an SGPR written by
-    // the VALU two instructions earlier; the assembler block is not seen by the compiler's hazard pass.)
+    // it stands, frame B's after a shift) -- and one v_writelane with a constant lane.  (Assembler blocks are not seen by the compiler's
+    // hazard pass, so the spacing is built in.)
     unsigned tA = 0, tB = 0;
-    asm("s_nop 1\n\tv_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(tA), "+v"(tB) : "s"(HA), "s"(HB << 8));
+    asm volatile("s_nop 1\n\tv_writelane_b32 %0, %2, 0\n\tv_writelane_b32 %1, %3, 0" : "+v"(tA), "+v"(tB) : "s"(HA), "s"(HB << 8));
+    // One block = five instructions in a fixed order, which is what keeps them clear of the two hazards involved without a single s_nop:
+    // an SGPR written by v_readlane is read as DATA by a VALU two instructions later at the earliest, and as a LANE SELECT four later.
 #pragma unroll
     for (int i = 1; i < kMaxWalk; i++) {
-        const unsigned rA = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qA);
-        const unsigned rB = (unsigned)__builtin_amdgcn_readlane((int)W[i], (int)qB);
-        qA = rA; qB = rB >> 8;
-        asm("s_nop 1\n\tv_writelane_b32 %0, %2, %4\n\tv_writelane_b32 %1, %3, %4" : "+v"(tA), "+v"(tB) : "s"(rA), "s"(rB), "n"(i));
+        unsigned t;
+        asm volatile("v_readlane_b32 %[a], %[w], %[a]\n\t"
+                     "v_readlane_b32 %[t], %[w], %[b]\n\t"
+                     "s_lshr_b32 %[b], %[t], 8\n\t"
+                     "v_writelane_b32 %[ta], %[a], %[i]\n\t"
+                     "v_writelane_b32 %[tb], %[t], %[i]"
+                     : [a] "+s"(qA), [b] "+s"(qB), [t] "=&s"(t), [ta] "+v"(tA), [tb] "+v"(tB) : [w] "v"(W[i]), [i] "n"(i));
     }
     // decoded byte m = (block m >> 6) | (block m+1 & 0x3F) << 2; lane L <-> byte m_lo + L <-> blocks at walk positions nblk - L and nblk - L - 1
     const int at = (nblk - (int)lane) << 2;
