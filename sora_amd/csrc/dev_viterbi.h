@@ -115,11 +115,13 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     default: X = V.U; Y = (unsigned)__builtin_amdgcn_update_dpp(0, u, 0xB1, 0xF, 0xF, true); break;                  // L ^ 1: quad_perm [1,0,3,2]
     }
     // The two sums are plain 32-bit adds (VOP2, and the cross-lane move of a DPP phase folds into its add: v_add_u32_dpp): the wrap of frame
-    // A's 7-bit metric carries into bit 16, which belongs to nobody -- frame B's marks start at bit 17.  The guard is the lowest bit of the high
-    // half, below the mark of the current step, which always differs between the two candidates: it can never decide the minimum; it is
-    // cleared after it.  (v_pk_add_u16 is VOP3P-encoded and issues at half the rate of a VOP2, profiles/r01_issue_probe_table.txt; the constants
-    // stay 32-bit literals: the same instructions with the constants pinned into SGPRs measured 1.5-10 % slower.)
-    V.U = pk_min16(X + bm, Y + bo) & ~kGuard;
+    // A's 7-bit metric carries into bit 16, which belongs to nobody -- frame B's marks start at bit 17.  That guard bit is the lowest bit of the
+    // high half, below the mark of the current step, which always differs between the two candidates: it can never decide the minimum.  It is
+    // cleared with the marks at the end of every 8-step block, and that is often enough: a path's metric grows by at most 14 per step, 112 per
+    // block, so it passes a multiple of 128 at most once per block and the bit never has to absorb a second carry.  (v_pk_add_u16 is
+    // VOP3P-encoded and issues at half the rate of a VOP2, profiles/r01_issue_probe_table.txt; the constants stay 32-bit literals: the same
+    // instructions with the constants pinned into SGPRs measured 1.5-10 % slower.)
+    V.U = pk_min16(X + bm, Y + bo);
     if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
         uint8_t* e = reinterpret_cast<uint8_t*>(V.ring + V.roff + V.sidx[t24 / 8]);
         e[0] = (uint8_t)V.U; e[1] = (uint8_t)(V.U >> 17);                       // frame A's block, frame B's block
