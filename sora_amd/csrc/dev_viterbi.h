@@ -137,10 +137,10 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
 // block just read.  All blocks the walk can touch (<= 38) are first fetched into registers, lane = ring index, with
 // independent LDS reads; the walk itself is then v_readlane + two scalar ops per block and frame, no memory latency.
 // Kept out of line: it is reached from every puncture group of the slow path.
+template <int kMaxWalk>                                                         // blocks a window's walk can touch: (WIN + LOOK + 7) / 8 + 2
 __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uint32_t tr_, uint32_t ob_, unsigned mA, unsigned mB,
                                            uint32_t cntA_, uint32_t cntB_, uint8_t* outA, uint8_t* outB)
 {
-    constexpr int kMaxWalk = 38;
     const unsigned lane = threadIdx.x & 63;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // arguments arrive in VGPRs; these are wave-uniform
     const uint32_t tr = uni(tr_), ob = uni(ob_), cntA = uni(cntA_), cntB = uni(cntB_);

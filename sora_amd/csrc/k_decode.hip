@@ -238,7 +238,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     uint32_t tr = 0, ob = 0;
 
     auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // (no half borrows: a plain 32-bit subtraction)
-    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace<38>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + 256u + 24u + 6u;
         if (!A.done) t = min(t, A.tr_end);

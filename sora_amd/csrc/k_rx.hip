@@ -213,7 +213,7 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 #ifdef SORA_DBG_NO_TRACE                                                        // experiment (tools/ab_decode.sh): the forward pass alone -- results are wrong, only the duration means something
     auto trace = [&](unsigned, unsigned, uint32_t, uint32_t) {};
 #else
-    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace<(WIN + LOOK + 7) / 8 + 2>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
 #endif
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
