@@ -40,7 +40,7 @@ FRAME_SAMPLES = 4880       # 160 STS + 160 LTS + 80 SIGNAL + 56*80 data @20 MHz
 CAPTURE_SAMPLES = 5040     # + 160 silence; 360 source bursts of 14
 ALG_BYTES_PER_SAMPLE = 4.0 + 216 / 8.0 / 80.0     # 4.3375
 HBM_PEAK = 8.0e12
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_k_traffic.json")     # rocprofv3 --pmc summary (tools/collect_profiles.sh)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_m_traffic.json")     # rocprofv3 --pmc summary (tools/collect_profiles.sh)
 
 
 def measured_traffic(kernel):
@@ -193,7 +193,7 @@ def cpu_baseline(iq, nframes, budget_s=10.0):
 
 def valu_roofline(nframes, ms_step):
     """What actually bounds this path: vector-ALU issue.  Wave-level VALU instructions of one receive call (rocprofv3
-    SQ_INSTS_VALU, profiles/r02_k_traffic.json) over the measured step time, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
+    SQ_INSTS_VALU, profiles/r02_m_traffic.json) over the measured step time, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
     per wave64 instruction (MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles)."""
     n = measured_valu() if nframes == FRAMES_PER_GPU else None
     if not n:
