@@ -279,7 +279,7 @@ def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
 
 
-def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True):
+def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True, rate_kbps=1000):
     """Row f4 (802.11b receive graph): `ncaps` 44 MHz captures of one 1 Mbps DBPSK frame each (the modulator output recorded
     in tests/golden/refgraph_11b.npz, or a 500-byte frame from the compiled reference modulator when that library is
     here), noise added on the device.  A streaming integer path: 4 B per sample against the HBM roofline; the reference's
@@ -287,7 +287,9 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True):
     from oracle.pyoracle import ReferenceGraph
     g = ReferenceGraph()
     if g.available():
-        s8 = g.tx11b(np.random.default_rng(11).integers(0, 256, 500).astype(np.uint8).tobytes(), 1000); what = "500-byte MPDU"
+        s8 = g.tx11b(np.random.default_rng(11).integers(0, 256, 500 if rate_kbps == 1000 else 1500).astype(np.uint8).tobytes(), rate_kbps); what = "500-byte MPDU" if rate_kbps == 1000 else "1500-byte MPDU"
+    elif rate_kbps != 1000:
+        return {"skipped": "needs oracle/_ref/libsora_refgraph.so (the capture comes from the reference's modulator)"}
     else:
         s8 = np.load(os.path.join(ROOT, "tests", "golden", "refgraph_11b.npz"))["tx_2"]; what = "40-byte MPDU (recorded modulator output)"
     n = (len(s8) + 1200 + 2800 + 27) // 28 * 28
@@ -311,7 +313,7 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True):
     for _ in range(reps):
         rx.process_dev(flat, descs)
     rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
-    out = {"workload": "%d captures x one 1 Mbps DBPSK frame, %s, long preamble (%d samples @44 MHz each), AWGN" % (ncaps, what, n),
+    out = {"workload": "%d captures x one %s frame, %s, long preamble (%d samples @44 MHz each), AWGN" % (ncaps, "1 Mbps DBPSK" if rate_kbps == 1000 else "%g Mbps CCK" % (rate_kbps / 1000.0), what, n),
            "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
            "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
@@ -508,7 +510,7 @@ def main():
     ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
-    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11n, rx11n_40) and print its object: for profiling that section alone")
+    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11b_cck, rx11n, rx11n_40) and print its object: for profiling that section alone")
     args = ap.parse_args()
 
     import torch
@@ -527,7 +529,8 @@ def main():
 
     if args.only:
         sections = {"stages": lambda: bench_stages(torch, sora_amd, dev), "ingest": lambda: bench_ingest(torch, sora_amd, dev), "tx": lambda: bench_tx(torch, sora_amd),
-                    "rx11b": lambda: bench_11b(torch, sora_amd, dev), "rx11n": lambda: bench_11n(torch, sora_amd, dev),
+                    "rx11b": lambda: bench_11b(torch, sora_amd, dev), "rx11b_cck": lambda: bench_11b(torch, sora_amd, dev, cpu=False, rate_kbps=11000),
+                    "rx11n": lambda: bench_11n(torch, sora_amd, dev),
                     "rx11n_40": lambda: bench_ht40(torch, sora_amd, dev)}
         print(json.dumps({args.only: sections[args.only]()}))
         return
@@ -728,6 +731,7 @@ def main():
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
             out["tx"] = bench_tx(torch, sora_amd)
             out["rx11b"] = bench_11b(torch, sora_amd, dev)
+            out["rx11b_cck"] = bench_11b(torch, sora_amd, dev, cpu=False, rate_kbps=11000)
             out["rx11n"] = bench_11n(torch, sora_amd, dev)
             out["rx11n_40"] = bench_ht40(torch, sora_amd, dev)
         if world == 1 and not args.no_cpu_baseline:

@@ -52,6 +52,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     __shared__ uint32_t s_crc_all[8][256];                              // CRC-32 tables: [0] the byte table, [k] = the same after k more zero bytes ("slicing"), built below
     uint32_t* const s_crc = s_crc_all[0];
     __shared__ int s_sym_all[4][2][64];                                 // per wave: despread sums of the symbols of one bulk pass (re, im)
+    __shared__ __attribute__((aligned(16))) uint32_t s_chip_all[CCK ? 4 : 1][CCK ? 544 : 4];         // per wave: the chips of one bulk pass over a CCK payload (queued ones first)
     s_crc[threadIdx.x] = A.crc[threadIdx.x];
     __syncthreads();
     { uint32_t t = s_crc[threadIdx.x]; for (int k = 1; k < 8; k++) { t = s_crc[t & 0xFF] ^ (t >> 8); s_crc_all[k][threadIdx.x] = t; } }
@@ -406,11 +407,17 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     auto pk_sra = [](uint32_t a, int n) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) >> (short)n)); };
     auto bulk_pass = [&](uint32_t& pos_, uint32_t& remain_, uint32_t& c_start_, uint32_t& c_stale_, uint32_t& p_start_, uint32_t& p_stale_, int qoff_) __attribute__((always_inline)) -> bool {
         const int port = uni(rxrate);
-        const int mode = port == RATE_SYNC ? 0 : (uni(plcp_data) ? 2 : 1);          // 0: TSFDSync, 1: the PLCP header's bytes, 2: the payload's
+        const int mode = port == RATE_SYNC ? 0 : (!uni(plcp_data) ? 1 : port <= RATE_2M ? 2 : 3);   // 0: TSFDSync, 1: the PLCP header's bytes, 2: a Barker payload's, 3: a CCK payload's
         if (mode == 1 && port != RATE_1M) return false;
+        if (mode == 3 && !CCK) return false;
         const int spb = port == RATE_2M ? 4 : 8;                        // symbols per byte
-        int K = min(64, (int)(remain_ / 28u));
-        if (mode != 0) {
+        const int need = port == RATE_5P5M ? 16 : 8;                    // CCK: chips per byte
+        int K = min(mode == 3 ? 62 : 64, (int)(remain_ / 28u));         // (62 calls: at most 63 code words with the queued chips)
+        if (mode == 3) {
+            if (byte_count + 1 >= frame_length) return false;
+            const int chips_to_event = (int)(frame_length - 1 - byte_count) * need - cck_n;
+            K = min(K, (chips_to_event - 1) / 8 - 1);
+        } else if (mode != 0) {
             if (mode == 2 && byte_count + 1 >= frame_length) return false;
             const int R = mode == 2 ? (int)(frame_length - 1 - byte_count) : 6 - hdr_n;     // bytes up to and including the one that raises the event
             const int chips_to_event = 11 * (R * spb - sym_n) - chip_n;
@@ -527,6 +534,123 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             uint32_t t = pk_sra(pk_sub(y[j] ^ m1, m1), 4);             // (v ^ -1) - (-1) = -v in each half, wrapping
             t = pk_sub(t ^ m2, m2);
             partA = pk_add(partA, t & ma); partB = pk_add(partB, t & mb);
+        }
+        if constexpr (CCK) {
+        if (mode == 3) {
+            // ---- C3..F3. a CCK payload: the chips go to a buffer in LDS behind the queued ones, a code word (8 chips) per lane is decoded with the
+            // reference's own sequence of comparisons (CCK11_DECODER cck.hpp:255-763: four phi2 hypotheses x four phi3 hypotheses, phi4 from
+            // the larger component's sign; TCCK5P5Decoder cck.hpp:26-206: two hypotheses), the DQPSK pair against the previous word's last
+            // chip, the odd-symbol rotation by lane parity, the descrambler a byte per lane against its left neighbour, and the frame sink's
+            // CRC-32 folded eight bytes at a time.
+            uint32_t* const chipbuf = s_chip_all[wave];
+            lds_order();
+            if (lane < cck_n) chipbuf[lane] = cbuf;
+            const int gq = cck_n + incl - cnt;                          // this call's first chip in the buffer
+#pragma unroll
+            for (int j = 0; j < 8; j++) if (j < cnt) chipbuf[gq + j] = y[j];
+            lds_order();
+            const int T = cck_n + total, nw = T >> 3;                   // chips in the buffer, complete words
+            const bool inw = lane < nw;
+            int pre[8], pim[8];
+            {
+                const uint4 c0 = *reinterpret_cast<const uint4*>(chipbuf + 8 * (inw ? lane : 0)), c1 = *reinterpret_cast<const uint4*>(chipbuf + 8 * (inw ? lane : 0) + 4);
+                const uint32_t cw[8] = { c0.x, c0.y, c0.z, c0.w, c1.x, c1.y, c1.z, c1.w };
+#pragma unroll
+                for (int i = 0; i < 8; i++) { pre[i] = (int)(short)(cw[i] & 0xFFFFu); pim[i] = (int)cw[i] >> 16; }
+            }
+            auto rotc = [](int re, int im, int kk, int& ore, int& oim) __attribute__((always_inline)) {  // (re + j im) * j^kk, kk a constant
+                const int xr = (kk & 1) ? im : re, xi = (kk & 1) ? re : im;
+                ore = ((kk + 1) & 2) ? -xr : xr; oim = (kk & 2) ? -xi : xi;
+            };
+            // A1..A4 of hypothesis phi2 = m pi/2 (r = (-j)^m = j^k, k = (4 - m) & 3), then Bx, By and L of hypothesis phi3 = s-th of 0, pi/2, pi, 3pi/2
+            auto corr = [&](int m, int sq, int& lre, int& lim, int& l5) __attribute__((always_inline)) {
+                const int k = (4 - m) & 3;
+                int t_re, t_im;
+                rotc(pre[0], pim[0], k, t_re, t_im); const int a1r = pre[1] + t_re, a1i = pim[1] + t_im;
+                rotc(pre[2], pim[2], k, t_re, t_im); const int a2r = t_re - pre[3], a2i = t_im - pim[3];
+                rotc(pre[4], pim[4], k, t_re, t_im); const int a3r = pre[5] + t_re, a3i = pim[5] + t_im;
+                rotc(pre[6], pim[6], k, t_re, t_im); const int a4r = pre[7] - t_re, a4i = pim[7] - t_im;
+                rotc(a1r, a1i, sq, t_re, t_im); const int bxr0 = a2r + t_re, bxi0 = a2i + t_im;
+                rotc(a3r, a3i, sq, t_re, t_im); const int byr0 = a4r + t_re, byi0 = a4i + t_im;
+                const int bxr = bxr0 >> 2, bxi = bxi0 >> 2, byr = byr0 >> 2, byi = byi0 >> 2;
+                lre = (int)((uint32_t)(bxr * byr) + (uint32_t)(bxi * byi));
+                lim = (int)((uint32_t)(bxr * byi) - (uint32_t)(bxi * byr));
+                l5  = (int)((uint32_t)(bxr * byr) - (uint32_t)(((-bxi0) >> 2) * byi));
+            };
+            const uint32_t p7 = (uint32_t)(pre[7] & 0xFFFF) | ((uint32_t)pim[7] << 16);
+            const uint32_t p7prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p7, 0x138, 0xF, 0xF, false);       // wave_shr:1: the previous word's last chip
+            const int qre = lane == 0 ? last_re : (int)(short)(p7prev & 0xFFFFu), qim = lane == 0 ? last_im : (int)p7prev >> 16;
+            const int dre = (int)((uint32_t)(qre * pre[7]) + (uint32_t)(qim * pim[7])) >> 1, dim = (int)((uint32_t)(qre * pim[7]) - (uint32_t)(qim * pre[7])) >> 1;
+            const uint32_t dq = (((uint32_t)dre + (uint32_t)dim) >> 31) | ((((uint32_t)dre - (uint32_t)dim) >> 31) << 1);   // demap_dqpsk_bits (soradsp.h:190-198)
+            uint32_t raw; int nbytes;                                   // lane i: the i-th byte in front of the descrambler
+            if (port == RATE_11M) {
+                int Mm[4]; uint32_t Vm[4];
+#pragma unroll
+                for (int m = 0; m < 4; m++) {
+                    int Ms[4]; uint32_t Vs[4];
+#pragma unroll
+                    for (int sq = 0; sq < 4; sq++) {
+                        int lre, lim, l5; corr(m, sq, lre, lim, l5);
+                        const int a1 = lre < 0 ? -lre : lre, a2 = lim < 0 ? -lim : lim;
+                        const uint32_t base = sq == 0 ? 0x00u : sq == 1 ? 0x30u : sq == 2 ? 0x10u : 0x20u;
+                        const bool first = a1 > a2;
+                        Ms[sq] = first ? (lre > 0 ? lre : -lre) : (lim > 0 ? lim : -lim);
+                        Vs[sq] = base | (first ? (lre > 0 ? 0x00u : 0x40u) : (lim > 0 ? 0xC0u : 0x80u));
+                    }
+                    const bool k01 = Ms[0] > Ms[1], k23 = Ms[2] > Ms[3];                              // "if (Max1 > Max2) 1 else 2", "if (Max3 > Max4) 3 else 4"
+                    const int M01 = k01 ? Ms[0] : Ms[1], M23 = k23 ? Ms[2] : Ms[3];
+                    const uint32_t V01 = k01 ? Vs[0] : Vs[1], V23 = k23 ? Vs[2] : Vs[3];
+                    const bool up = M23 > M01;                                                          // "if (Max34 > Module) Module = Max34"
+                    Mm[m] = up ? M23 : M01; Vm[m] = (up ? V23 : V01) | (m == 0 ? 0x00u : m == 1 ? 0x08u : m == 2 ? 0x04u : 0x0Cu);
+                }
+                uint32_t out = Mm[0] > Mm[1] ? (Mm[0] > Mm[3] ? Vm[0] : Vm[3]) : (Mm[1] > Mm[2] ? Vm[1] : Vm[2]);   // "lable4"
+                out |= dq;
+                out ^= ((cck_even ^ (uint32_t)lane) & 1u) ? 3u : 0u;   // the extra pi of every other symbol
+                raw = out & 0xFFu; nbytes = nw;
+            } else {
+                int lre, lim, l1, l2;
+                corr(1, 0, lre, lim, l1); corr(3, 0, lre, lim, l2);     // phi2 = pi/2 and 3pi/2, phi3 = 0
+                const int max1 = l1 > 0 ? l1 : -l1, max2 = l2 > 0 ? l2 : -l2;
+                const uint32_t half = (max1 > max2 ? (l1 > 0 ? 0x0u : 0x8u) : (l2 > 0 ? 0x4u : 0xCu)) | dq;
+                const uint32_t h0 = (uint32_t)__shfl((int)half, 2 * lane), h1 = (uint32_t)__shfl((int)half, 2 * lane + 1);
+                raw = ((h0 | (h1 << 4)) ^ 0x30u) & 0xFFu; nbytes = nw >> 1;
+            }
+            // TDesc741 a byte per lane: the seven bits in front of it are the top of the byte to the left (byte_reg for the first)
+            const uint32_t rprev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)raw, 0x138, 0xF, 0xF, false);
+            const uint32_t S15 = (raw << 7) | (lane == 0 ? (byte_reg & 0x7Fu) : (rprev >> 1));
+            const uint32_t ob = ((S15 >> 7) ^ (S15 >> 3) ^ S15) & 0xFFu;
+            if (nbytes > 0) {
+                byte_reg = (uint32_t)lane_of((int)raw, nbytes - 1) >> 1;
+                const uint32_t idx = byte_count + (uint32_t)lane;
+                if (lane < nbytes && idx < kOutBuf) s_out[idx] = (uint8_t)ob;
+                const uint32_t lim = (uint32_t)((int)frame_length - 4);
+                const int n = byte_count >= lim ? 0 : (int)min((uint32_t)nbytes, lim - byte_count);     // bytes in front of the FCS
+                // CRC-32 eight bytes at a time: every group's own contribution at once (byte i of a group of g through the table that carries it
+                // over the g - 1 - i bytes behind it), then the register is carried over one group after the other
+                const int glen = min(8, n - 8 * (lane >> 3));
+                uint32_t v = lane < n ? s_crc_all[glen - 1 - (lane & 7)][ob] : 0u;
+                v ^= (uint32_t)dpp<0xB1>((int)v); v ^= (uint32_t)dpp<0x4E>((int)v); v ^= (uint32_t)dpp<0x141>((int)v);
+                for (int g = 0; 8 * g < n; g++) {
+                    const int gl = min(8, n - 8 * g);
+                    uint32_t z = lane < min(gl, 4) ? s_crc_all[gl - 1 - lane][(crc32 >> (8 * lane)) & 0xFFu] : 0u;
+                    z ^= (uint32_t)dpp<0xB1>((int)z); z ^= (uint32_t)dpp<0x4E>((int)z);
+                    crc32 = (uint32_t)lane_of((int)z, 0) ^ (gl < 4 ? crc32 >> (8 * gl) : 0u) ^ (uint32_t)lane_of((int)v, 8 * g);
+                }
+                byte_count += (uint32_t)nbytes;
+                const int lw = nbytes * (need >> 3) - 1;                // the last word decoded
+                last_re = lane_of(pre[7], lw); last_im = lane_of(pim[7], lw);
+                if (port == RATE_11M) cck_even ^= (uint32_t)nbytes & 1u;
+            }
+            const int used = nbytes * need;
+            lds_order();
+            cbuf = lane < T - used ? chipbuf[used + lane] : 0u;
+            cck_n = T - used;
+            const uint32_t adv = 28u * (uint32_t)K;
+            const uint32_t s0_ = c_start_;
+            pos_ += adv; remain_ -= adv;
+            c_start_ = s0_ + adv; c_stale_ = s0_ + adv - 28u; p_start_ = s0_ + adv - 28u; p_stale_ = s0_ + adv - 56u;
+            return true;
+        }
         }
         // ---- D. symbols: the carried partial sum, then every lane's parts (wrapping int16 sums: accumulated wide, wrapped when read)
         auto despread_sum = [&](int kc) __attribute__((always_inline)) {
@@ -732,7 +856,7 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 // calls are taken right here.  Same semantics as going round the outer loop -- MAC11b_Receive only looks at
                 // error_code after a call -- but in a loop of its own the compiler keeps just this phase's state in registers.
                 while (error_code == 0 && sync_flag == BARKER_SYNCED && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
-                    if (uni(rxrate) <= RATE_2M && bulk_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28; pf_ok = false; continue; }
+                    if ((uni(rxrate) <= RATE_2M || (CCK && uni(plcp_data))) && bulk_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28; pf_ok = false; continue; }
                     p_start = c_start; p_take = 28; p_stale = c_stale;
                     c_stale = c_start; c_start = pos; pos += 28; remain -= 28;
                     const uint32_t base = c_start - (uint32_t)qoff;
