@@ -75,6 +75,36 @@ def test_gpu_11b_equals_reference_graph_and_oracle_on_random_captures(sora, orac
     assert nev > 1000 and nok > 300 and ncck > 100                      # all four rates decode, the CCK ones included
 
 
+def test_gpu_11b_long_frames_of_every_rate(sora, oracle):
+    """Frames long enough for many bulk passes (k_rx11b.hip: up to 64 source calls a pass; a CCK pass decodes ~57 code words), with a DC
+    offset and two frames of different rates in one capture: every event as the reference graph and the C restatement report it."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present (the captures come from the reference's modulator)")
+    rng = np.random.default_rng(1212)
+    caps = []
+    for rates, ln in (((1000, 11000), 700), ((2000, 5500), 1100), ((11000, 11000), 1500), ((5500, 2000), 1501), ((11000, 1000), 2000)):
+        parts = [np.zeros((1400, 2), np.float64)]
+        for r in rates:
+            s8 = g.tx11b(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), r)
+            parts += [s8.astype(np.float64) * 256.0, np.zeros((int(rng.integers(60, 120)) * 28, 2), np.float64)]
+        x = np.concatenate(parts)
+        x = x[:len(x) // 28 * 28] + rng.uniform(-400, 400, size=(1, 2)) + rng.normal(0, 60, (len(x) // 28 * 28, 2))
+        caps.append(np.clip(np.rint(x), -32768, 32767).astype(np.int16))
+    got = run_11b(sora, caps, max_frames=16)
+    nok = 0
+    for i, c in enumerate(caps):
+        rows = [r for r in got if r["capture_id"] == i]
+        ev = g.rx11b(c, max_frames=16)
+        ok, why = same_as_reference_11b(rows, ev)
+        assert ok, "capture %d vs the reference graph: %s" % (i, why)
+        ok, why = same_as_reference_11b(rows, oracle_rows(oracle, c))
+        assert ok, "capture %d vs oracle/so_rx11b.c: %s" % (i, why)
+        nok += sum(e["error_code"] == 1 for e in ev)
+    assert nok == 10                                                    # both frames of every capture decode
+
+
 def test_11b_capacity_and_argument_errors(sora):
     import torch
     with pytest.raises(Exception):
