@@ -324,7 +324,9 @@ typedef struct sora_ht40 sora_ht40_t;
 uint32_t sora_ht40_symbols(uint32_t length0, uint32_t length1, uint32_t n_bpsc, uint32_t code_rate);   /* data symbols of such a frame (0: bad arguments) */
 int   sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out);  /* max_soft_values >= sum over frames of 2 x nsym x 108 n_bpsc (+ 64 per frame) */
 void  sora_ht40_destroy(sora_ht40_t* rx);
-void* sora_ht40_stream(sora_ht40_t* rx);
+void* sora_ht40_stream(sora_ht40_t* rx);                                                               /* the stream of the most recent process call */
+int   sora_ht40_synchronize(sora_ht40_t* rx);                                                          /* every call issued so far has finished (a handle keeps three calls in flight:
+                                                                                                        * process_dev waits only for the call three calls back; results reports the most recent one) */
 int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);
 int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 

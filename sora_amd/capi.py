@@ -57,7 +57,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
            "sora_rx11n_set_depth", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
-           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_process_dev", "sora_ht40_results",
+           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_process_dev", "sora_ht40_results",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results"]
 
@@ -122,6 +122,7 @@ def load(build_if_missing=True):
     L.sora_ht40_create.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
     L.sora_ht40_destroy.argtypes = [ctypes.c_void_p]; L.sora_ht40_destroy.restype = None
     L.sora_ht40_stream.argtypes = [ctypes.c_void_p]; L.sora_ht40_stream.restype = ctypes.c_void_p
+    L.sora_ht40_synchronize.argtypes = [ctypes.c_void_p]
     L.sora_ht40_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(Ht40Frame), ctypes.c_size_t, ctypes.c_void_p]
     L.sora_ht40_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t]
     L.sora_shard_unique_id.argtypes = [ctypes.c_void_p]
@@ -517,7 +518,7 @@ class RxHt40:
             pass
 
     def synchronize(self):
-        _check(self._L.sora_hip_stream_synchronize(self._L.sora_ht40_stream(self._h)))
+        _check(self._L.sora_ht40_synchronize(self._h))
 
     @staticmethod
     def frames(descs):

@@ -261,13 +261,20 @@ __global__ void __launch_bounds__(256) k_ht40_finish(Ht40FinishArgs A)
 // ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
 using namespace sora;
 
+// A handle owns kHt40Slots independent slots (stream + every intermediate), used round-robin: a call waits only for the call that used its
+// slot three calls ago, so the host's part of call n + 1 (job tables, four small copies) and the tail of call n's kernels overlap call n + 1's
+// kernels.  sora_ht40_results reports the most recent call.
+static constexpr int kHt40Slots = 3;
+struct Ht40Slot {
+    hipStream_t stream = nullptr;
+    Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
+    uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
+    std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0;
+};
 struct sora_ht40 {
     int device = 0; uint32_t max_frames = 0; uint64_t max_soft = 0;
-    hipStream_t stream = nullptr;
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
-    Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
-    uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_w = nullptr;
-    std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0; bool have_results = false;
+    Ht40Slot slot[kHt40Slots]; int next = 0, last = 0; bool have_results = false;
 };
 
 #define HIPCHK40(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -276,9 +283,11 @@ static constexpr uint32_t kVoutStride = 4352;
 static void ht40_free(sora_ht40_t* rx)
 {
     if (!rx) return;
-    if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
-    (void)hipFree(rx->d_frames); (void)hipFree(rx->d_jobs); (void)hipFree(rx->d_njobs); (void)hipFree(rx->d_fjobs); (void)hipFree(rx->d_soft);
-    (void)hipFree(rx->d_vout); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_w);
+    for (Ht40Slot& S : rx->slot) {
+        if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
+        (void)hipFree(S.d_frames); (void)hipFree(S.d_jobs); (void)hipFree(S.d_njobs); (void)hipFree(S.d_fjobs); (void)hipFree(S.d_soft);
+        (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
+    }
     delete rx;
 }
 
@@ -303,31 +312,41 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
     rx->device = device; rx->max_frames = max_frames; rx->max_soft = max_soft_values;
     const size_t nj = 2 * (size_t)max_frames;
     hipError_t e = (sora_internal_tables(device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK) ? hipSuccess : hipErrorUnknown;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_frames, sizeof(Ht40Frame) * max_frames);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * nj);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_njobs, 16);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_fjobs, sizeof(Ht40Job) * nj);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_soft, max_soft_values * 2 + 1024);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_vout, nj * kVoutStride + 256);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, nj * 4096);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * nj);
-    if (e == hipSuccess) e = hipMemset(rx->d_soft, 0, max_soft_values * 2 + 1024);
-    if (e == hipSuccess) e = hipMemset(rx->d_vout, 0, nj * kVoutStride + 256);
+    for (Ht40Slot& S : rx->slot) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_frames, sizeof(Ht40Frame) * max_frames);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_jobs, 3 * sizeof(VitJob) * nj);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_njobs, 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_fjobs, sizeof(Ht40Job) * nj);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_soft, max_soft_values * 2 + 1024);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_vout, nj * kVoutStride + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, nj * 4096);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * nj);
+        if (e == hipSuccess) e = hipMemset(S.d_soft, 0, max_soft_values * 2 + 1024);
+        if (e == hipSuccess) e = hipMemset(S.d_vout, 0, nj * kVoutStride + 256);
+    }
     if (e != hipSuccess) { ht40_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_create: device allocation / tables", (int)e); }
     *out = rx;
     return SORA_OK;
 }
 
 void  sora_ht40_destroy(sora_ht40_t* rx) { if (rx) { (void)hipSetDevice(rx->device); ht40_free(rx); } }
-void* sora_ht40_stream(sora_ht40_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+void* sora_ht40_stream(sora_ht40_t* rx) { return rx ? (void*)rx->slot[rx->last].stream : nullptr; }         // the stream of the most recent call
+int sora_ht40_synchronize(sora_ht40_t* rx)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_synchronize: null handle", 0);
+    HIPCHK40(hipSetDevice(rx->device));
+    for (Ht40Slot& S : rx->slot) HIPCHK40(hipStreamSynchronize(S.stream));
+    return SORA_OK;
+}
 
 int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
 {
     if (!rx || (nframes && (!d_iq0 || !d_iq1 || !frames))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: null argument", 0);
     if (nframes > rx->max_frames) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more frames than max_frames", 0);
     HIPCHK40(hipSetDevice(rx->device));
-    HIPCHK40(hipStreamSynchronize(rx->stream));
+    Ht40Slot& S = rx->slot[rx->next];
+    HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
     std::vector<Ht40Frame> hf(nframes); std::vector<VitJob> hj(3 * 2 * (size_t)rx->max_frames); std::vector<Ht40Job> fj(2 * nframes);
     uint32_t nj[4] = { 0, 0, 0, 0 };
     uint64_t soft = 0;
@@ -349,20 +368,22 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
         F.pad[0] = F.pad[1] = F.pad[2] = 0;
     }
     if (soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
-    rx->h_frames.assign(frames, frames + nframes); rx->nframes = (uint32_t)nframes; rx->have_results = true;
+    S.h_frames.assign(frames, frames + nframes); S.nframes = (uint32_t)nframes; rx->have_results = true;
+    rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
     if (nframes == 0) return SORA_OK;
-    HIPCHK40(hipMemcpy(rx->d_frames, hf.data(), sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice));
-    HIPCHK40(hipMemcpy(rx->d_jobs, hj.data(), sizeof(VitJob) * hj.size(), hipMemcpyHostToDevice));
-    HIPCHK40(hipMemcpy(rx->d_njobs, nj, 16, hipMemcpyHostToDevice));
-    HIPCHK40(hipMemcpy(rx->d_fjobs, fj.data(), sizeof(Ht40Job) * fj.size(), hipMemcpyHostToDevice));
+    HIPCHK40(hipMemcpy(S.d_frames, hf.data(), sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice));
+    for (int r = 0; r < 3; r++)                                                   // (only the filled part of each code-rate list)
+        if (nj[r]) HIPCHK40(hipMemcpy(S.d_jobs + r * stride, hj.data() + r * stride, sizeof(VitJob) * nj[r], hipMemcpyHostToDevice));
+    HIPCHK40(hipMemcpy(S.d_njobs, nj, 16, hipMemcpyHostToDevice));
+    HIPCHK40(hipMemcpy(S.d_fjobs, fj.data(), sizeof(Ht40Job) * fj.size(), hipMemcpyHostToDevice));
     Ht40Args A;
-    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = rx->d_frames; A.nframes = (uint32_t)nframes;
-    A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = rx->d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights);
-    hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, rx->stream, A);
+    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = S.d_frames; A.nframes = (uint32_t)nframes;
+    A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights);
+    hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, S.stream, A);
     const uint32_t njobs = 2 * (uint32_t)nframes;
-    hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, rx->stream, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, (uint32_t)stride, (const uint8_t*)rx->d_soft, rx->d_vout);
-    Ht40FinishArgs Fi; Fi.jobs = rx->d_fjobs; Fi.njobs = njobs; Fi.vout = rx->d_vout; Fi.mpdu = rx->d_mpdu; Fi.rows = rx->d_rows; Fi.T = rx->T;
-    hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, rx->stream, Fi);
+    hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+    Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T;
+    hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());
     return SORA_OK;
 }
@@ -372,22 +393,23 @@ int sora_ht40_results(sora_ht40_t* rx, sora_frame_result* out, size_t max_out, s
     if (!rx || !nout || !out) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_results: null argument", 0);
     *nout = 0;
     if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
-    if (rx->nframes == 0) return SORA_OK;
+    Ht40Slot& S = rx->slot[rx->last];
+    if (S.nframes == 0) return SORA_OK;
     HIPCHK40(hipSetDevice(rx->device));
-    HIPCHK40(hipStreamSynchronize(rx->stream));
-    const size_t nj = 2 * (size_t)rx->nframes;
+    HIPCHK40(hipStreamSynchronize(S.stream));
+    const size_t nj = 2 * (size_t)S.nframes;
     if (nj > max_out) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: two rows per frame are reported", 0);
     std::vector<Rx11bRow> rows(nj);
-    HIPCHK40(hipMemcpy(rows.data(), rx->d_rows, sizeof(Rx11bRow) * nj, hipMemcpyDeviceToHost));
+    HIPCHK40(hipMemcpy(rows.data(), S.d_rows, sizeof(Rx11bRow) * nj, hipMemcpyDeviceToHost));
     std::vector<uint8_t> bulk;
-    if (h_mpdu) { bulk.resize(nj * 4096); HIPCHK40(hipMemcpy(bulk.data(), rx->d_mpdu, bulk.size(), hipMemcpyDeviceToHost)); }
+    if (h_mpdu) { bulk.resize(nj * 4096); HIPCHK40(hipMemcpy(bulk.data(), S.d_mpdu, bulk.size(), hipMemcpyDeviceToHost)); }
     size_t moff = 0;
     for (size_t j = 0; j < nj; j++) {
         sora_frame_result& o = out[j];
         memset(&o, 0, sizeof(o));
-        o.capture_id = rx->h_frames[j / 2].frame_id; o.start_sample = (uint32_t)(j & 1);                  // start_sample carries the spatial stream
-        o.error_code = rows[j].error_code; o.length = (uint16_t)rows[j].length; o.crc32 = rows[j].crc32; o.rate_kbps = rx->h_frames[j / 2].n_bpsc * 10 + rx->h_frames[j / 2].code_rate;
-        o.nsym = (uint16_t)sora_ht40_symbols(rx->h_frames[j / 2].length[0], rx->h_frames[j / 2].length[1], rx->h_frames[j / 2].n_bpsc, rx->h_frames[j / 2].code_rate);
+        o.capture_id = S.h_frames[j / 2].frame_id; o.start_sample = (uint32_t)(j & 1);                  // start_sample carries the spatial stream
+        o.error_code = rows[j].error_code; o.length = (uint16_t)rows[j].length; o.crc32 = rows[j].crc32; o.rate_kbps = S.h_frames[j / 2].n_bpsc * 10 + S.h_frames[j / 2].code_rate;
+        o.nsym = (uint16_t)sora_ht40_symbols(S.h_frames[j / 2].length[0], S.h_frames[j / 2].length[1], S.h_frames[j / 2].n_bpsc, S.h_frames[j / 2].code_rate);
         o.mpdu_offset = (uint32_t)moff;
         if (h_mpdu) {
             if (moff + rows[j].length > mpdu_cap) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: MPDU buffer too small", 0);

@@ -75,6 +75,33 @@ def test_loopback_with_carrier_offset_and_mixed_batch(env):
     assert ok == 2 * len(specs), ok
 
 
+def test_calls_in_flight_keep_their_results_apart(env):
+    """A handle keeps three calls in flight (own stream and intermediates each): five different batches issued back to back, then the same
+    five with the results read after every call -- the rows of the last call, and of every call read in turn, are the batch's own."""
+    torch, sora = env
+    rng = np.random.default_rng(77)
+    batches = []
+    for b in range(5):
+        specs = [(int(rng.choice([2, 4, 6])), int(rng.choice([0, 2])), int(rng.integers(60, 900)), int(rng.integers(60, 900))) for _ in range(12)]
+        iq, descs, psdus = make_frames(rng, specs, sigma=5.0)
+        batches.append((torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda(), descs, psdus))
+    nsoft = max(sum(2 * (sora.ht40_symbols(d[3], d[4], d[1], d[2]) * 108 * d[1] + 64) for d in descs) for _, _, descs, _ in batches)
+    rx = sora.RxHt40(12, nsoft)
+
+    def check(res, psdus):
+        assert len(res) == 24
+        for r in res:
+            assert r["error_code"] == 1 and r["mpdu"] == psdus[r["capture_id"]][r["stream"]], (r["capture_id"], r["stream"], hex(r["error_code"]))
+
+    for f0, f1, descs, _ in batches:                                    # no read-back in between
+        rx.process_dev(f0, f1, descs)
+    check(rx.results(), batches[-1][3])
+    for f0, f1, descs, psdus in batches:                                # and one by one
+        rx.process_dev(f0, f1, descs)
+        check(rx.results(), psdus)
+    rx.synchronize(); rx.close()
+
+
 def test_noise_decides_and_mmse_is_not_worse_than_zf(env):
     """Over noise levels around the point where 64-QAM 3/4 begins to fail, the MMSE weights lose no more PSDUs than zero forcing (same captures)."""
     good = {"zf": 0, "mmse": 0}; total = 0
