@@ -377,7 +377,10 @@ int  sora_shard_gather_results(sora_shard_t* sh, sora_rx_t* rx, int ticket, size
 typedef struct sora_rx11b sora_rx11b_t;
 int  sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out);
 void sora_rx11b_destroy(sora_rx11b_t* rx);
-void* sora_rx11b_stream(sora_rx11b_t* rx);            /* the handle's HIP stream (sora_hip_stream_synchronize waits for a call) */
+void* sora_rx11b_stream(sora_rx11b_t* rx);            /* the HIP stream of the most recent process call */
+int   sora_rx11b_synchronize(sora_rx11b_t* rx);       /* every call issued so far has finished.  A handle keeps two calls in flight (own stream and result
+                                                       * buffers each): process_dev waits only for the call before the previous one -- the caller's d_iq must
+                                                       * stay untouched until then --, results reports the most recent call */
 int  sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps);
 int  sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsamples, const sora_capture_desc* caps, size_t ncaps);
 int  sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);

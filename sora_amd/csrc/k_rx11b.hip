@@ -926,15 +926,23 @@ __global__ void __launch_bounds__(256, 4) k_rx11b_cck(Rx11bArgs A) { rx11b_captu
 
 using namespace sora;
 
-struct sora_rx11b {
-    sora_rx_cfg cfg{};
+// A handle owns two slots (stream + result buffers), used in turn: process_dev waits only for the call before the previous one, so the last
+// waves of call n and the first of call n + 1 share the chip (one wave per capture: a batch rarely fills the resident waves evenly).
+// sora_rx11b_results reports the most recent call.
+static constexpr int kSlots11b = 2;
+struct Slot11b {
     hipStream_t stream = nullptr;
     CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_needs_cck = nullptr;
+    std::vector<sora_capture_desc> h_caps;
+    std::vector<CapDesc> h_desc;                 // staging for the descriptor upload (kept until the slot's next call)
+    uint32_t ncaps = 0;
+};
+struct sora_rx11b {
+    sora_rx_cfg cfg{};
+    Slot11b slot[kSlots11b]; int next = 0, last = 0;
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
-    std::vector<sora_capture_desc> h_caps;
-    std::vector<CapDesc> h_desc;                 // staging for the descriptor upload (kept until the next call)
-    uint32_t ncaps = 0; bool have_results = false;
+    bool have_results = false;
 };
 
 #define HIPCHK11(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -942,8 +950,11 @@ struct sora_rx11b {
 static void rx11b_free(sora_rx11b_t* rx)
 {
     if (!rx) return;
-    if (rx->stream) { (void)hipStreamSynchronize(rx->stream); (void)hipStreamDestroy(rx->stream); }
-    (void)hipFree(rx->d_caps); (void)hipFree(rx->d_rows); (void)hipFree(rx->d_nframes); (void)hipFree(rx->d_mpdu); (void)hipFree(rx->d_iq_own); (void)hipFree(rx->d_needs_cck);
+    for (Slot11b& S : rx->slot) {
+        if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
+        (void)hipFree(S.d_caps); (void)hipFree(S.d_rows); (void)hipFree(S.d_nframes); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_needs_cck);
+    }
+    (void)hipFree(rx->d_iq_own);
     delete rx;
 }
 
@@ -962,18 +973,27 @@ int sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out)
     rx->d_crc = sora_internal_crc_table(cfg->device);
     const size_t rows = (size_t)cfg->max_captures * cfg->max_frames_per_capture;
     hipError_t e = rx->d_crc ? hipSuccess : hipErrorUnknown;
-    if (e == hipSuccess) e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_rows, sizeof(Rx11bRow) * rows);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_needs_cck, 4 * (size_t)cfg->max_captures);
-    if (e == hipSuccess) e = hipMalloc((void**)&rx->d_mpdu, rows * 4096);
+    for (Slot11b& S : rx->slot) {
+        if (e == hipSuccess) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_caps, sizeof(CapDesc) * cfg->max_captures);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * rows);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_nframes, 4 * (size_t)cfg->max_captures);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_needs_cck, 4 * (size_t)cfg->max_captures);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, rows * 4096);
+    }
     if (e != hipSuccess) { rx11b_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11b_create: device allocation", (int)e); }
     *out = rx;
     return SORA_OK;
 }
 
-void* sora_rx11b_stream(sora_rx11b_t* rx) { return rx ? (void*)rx->stream : nullptr; }
+void* sora_rx11b_stream(sora_rx11b_t* rx) { return rx ? (void*)rx->slot[rx->last].stream : nullptr; }       // the stream of the most recent call
+int sora_rx11b_synchronize(sora_rx11b_t* rx)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_synchronize: null handle", 0);
+    HIPCHK11(hipSetDevice(rx->cfg.device));
+    for (Slot11b& S : rx->slot) HIPCHK11(hipStreamSynchronize(S.stream));
+    return SORA_OK;
+}
 
 void sora_rx11b_destroy(sora_rx11b_t* rx) { if (rx) { (void)hipSetDevice(rx->cfg.device); rx11b_free(rx); } }
 
@@ -982,8 +1002,9 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     if (!rx || (ncaps && (!d_iq || !caps))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_process_dev: null argument", 0);
     if (ncaps > rx->cfg.max_captures) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process_dev: more captures than max_captures", 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
-    std::vector<CapDesc>& h = rx->h_desc;
-    HIPCHK11(hipStreamSynchronize(rx->stream));                                       // the previous call may still be reading d_caps / writing results
+    Slot11b& S = rx->slot[rx->next];
+    std::vector<CapDesc>& h = S.h_desc;
+    HIPCHK11(hipStreamSynchronize(S.stream));                                         // the slot's previous call may still be reading d_caps / writing results
     h.resize(ncaps);
     uint64_t total = 0;
     for (size_t i = 0; i < ncaps; i++) {
@@ -993,16 +1014,17 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
         total += caps[i].nsamples;
     }
     if (total > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process_dev: more samples than max_total_samples", 0);
-    rx->h_caps.assign(caps, caps + ncaps); rx->ncaps = (uint32_t)ncaps; rx->have_results = true;
+    S.h_caps.assign(caps, caps + ncaps); S.ncaps = (uint32_t)ncaps; rx->have_results = true;
+    rx->last = rx->next; rx->next = (rx->next + 1) % kSlots11b;
     if (ncaps == 0) return SORA_OK;
-    HIPCHK11(hipMemcpyAsync(rx->d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, rx->stream));
+    HIPCHK11(hipMemcpyAsync(S.d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
     Rx11bArgs A;
-    A.iq = reinterpret_cast<const uint32_t*>(d_iq); A.caps = rx->d_caps; A.ncaps = (uint32_t)ncaps; A.thr = rx->cfg.cca_pwr_threshold;
-    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = rx->d_rows; A.nframes = rx->d_nframes; A.mpdu = rx->d_mpdu; A.crc = rx->d_crc; A.needs_cck = rx->d_needs_cck;
+    A.iq = reinterpret_cast<const uint32_t*>(d_iq); A.caps = S.d_caps; A.ncaps = (uint32_t)ncaps; A.thr = rx->cfg.cca_pwr_threshold;
+    A.max_frames = rx->cfg.max_frames_per_capture; A.rows = S.d_rows; A.nframes = S.d_nframes; A.mpdu = S.d_mpdu; A.crc = rx->d_crc; A.needs_cck = S.d_needs_cck;
     static const bool one_kernel = []() { const char* e = getenv("SORA_HIP_11B_ONE_KERNEL"); return e && atoi(e) != 0; }();    // experiment: every capture through the CCK instantiation
-    HIPCHK11(hipMemsetAsync(rx->d_needs_cck, one_kernel ? 1 : 0, 4 * ncaps, rx->stream));
-    if (!one_kernel) hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);
-    hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, rx->stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)
+    HIPCHK11(hipMemsetAsync(S.d_needs_cck, one_kernel ? 1 : 0, 4 * ncaps, S.stream));
+    if (!one_kernel) hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);
+    hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)
     HIPCHK11(hipGetLastError());
     return SORA_OK;
 }
@@ -1015,7 +1037,8 @@ int sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsam
         if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer", 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
     if (!rx->d_iq_own) HIPCHK11(hipMalloc((void**)&rx->d_iq_own, sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
-    HIPCHK11(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice, rx->stream));
+    for (Slot11b& S : rx->slot) HIPCHK11(hipStreamSynchronize(S.stream));             // one upload buffer: no call may still be reading it
+    HIPCHK11(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice, rx->slot[rx->next].stream));
     return sora_rx11b_process_dev(rx, rx->d_iq_own, caps, ncaps);
 }
 
@@ -1024,37 +1047,38 @@ int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out,
     if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_results: null argument", 0);
     *nout = 0;
     if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
-    if (rx->ncaps == 0) return SORA_OK;
+    Slot11b& S = rx->slot[rx->last];
+    if (S.ncaps == 0) return SORA_OK;
     HIPCHK11(hipSetDevice(rx->cfg.device));
-    HIPCHK11(hipStreamSynchronize(rx->stream));
+    HIPCHK11(hipStreamSynchronize(S.stream));
     const uint32_t mf = rx->cfg.max_frames_per_capture;
-    std::vector<Rx11bRow> rows((size_t)rx->ncaps * mf); std::vector<uint32_t> nfr(rx->ncaps);
-    HIPCHK11(hipMemcpy(rows.data(), rx->d_rows, sizeof(Rx11bRow) * rows.size(), hipMemcpyDeviceToHost));
-    HIPCHK11(hipMemcpy(nfr.data(), rx->d_nframes, 4 * (size_t)rx->ncaps, hipMemcpyDeviceToHost));
+    std::vector<Rx11bRow> rows((size_t)S.ncaps * mf); std::vector<uint32_t> nfr(S.ncaps);
+    HIPCHK11(hipMemcpy(rows.data(), S.d_rows, sizeof(Rx11bRow) * rows.size(), hipMemcpyDeviceToHost));
+    HIPCHK11(hipMemcpy(nfr.data(), S.d_nframes, 4 * (size_t)S.ncaps, hipMemcpyDeviceToHost));
     // MPDU bytes: one bulk copy of the per-frame slots that are in use when that is cheap, else frame by frame
     size_t used_rows = 0;
-    for (uint32_t c = 0; c < rx->ncaps; c++) used_rows += nfr[c] < mf ? nfr[c] : mf;
+    for (uint32_t c = 0; c < S.ncaps; c++) used_rows += nfr[c] < mf ? nfr[c] : mf;
     std::vector<uint8_t> bulk;
-    const size_t slots = (size_t)rx->ncaps * mf;
+    const size_t slots = (size_t)S.ncaps * mf;
     if (h_mpdu && used_rows > 16 && slots * 4096 <= ((size_t)1 << 30)) {
         bulk.resize(slots * 4096);
-        HIPCHK11(hipMemcpy(bulk.data(), rx->d_mpdu, bulk.size(), hipMemcpyDeviceToHost));
+        HIPCHK11(hipMemcpy(bulk.data(), S.d_mpdu, bulk.size(), hipMemcpyDeviceToHost));
     }
     size_t n = 0, moff = 0; int rc = SORA_OK;
-    for (uint32_t c = 0; c < rx->ncaps; c++)
+    for (uint32_t c = 0; c < S.ncaps; c++)
         for (uint32_t i = 0; i < nfr[c] && i < mf; i++) {
             const Rx11bRow& r = rows[(size_t)c * mf + i];
             if (n >= max_out) { rc = SORA_ERR_CAPACITY; continue; }
             sora_frame_result& o = out[n++];
             memset(&o, 0, sizeof(o));
-            o.capture_id = rx->h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
+            o.capture_id = S.h_caps[c].capture_id; o.end_sample = r.end_sample; o.error_code = r.error_code; o.rate_kbps = r.rate_kbps;
             o.length = (uint16_t)r.length; o.crc32 = r.crc32; o.mpdu_offset = (uint32_t)moff;
             if (i + 1 == mf && nfr[c] > mf) o.flags = SORA_ROW_TRUNCATED;             // more frames were found than the capture has rows
             if (h_mpdu && (r.error_code == 1u || r.error_code == 0x80000006u)) {
                 const size_t len = r.length < 4096 ? r.length : 4096;
                 if (moff + len > mpdu_cap) { rc = SORA_ERR_CAPACITY; continue; }
                 if (!bulk.empty()) memcpy(h_mpdu + moff, bulk.data() + ((size_t)c * mf + i) * 4096, len);
-                else HIPCHK11(hipMemcpy(h_mpdu + moff, rx->d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
+                else HIPCHK11(hipMemcpy(h_mpdu + moff, S.d_mpdu + ((size_t)c * mf + i) * 4096, len, hipMemcpyDeviceToHost));
                 moff += len;
             }
         }

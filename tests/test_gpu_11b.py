@@ -105,6 +105,38 @@ def test_gpu_11b_long_frames_of_every_rate(sora, oracle):
     assert nok == 10                                                    # both frames of every capture decode
 
 
+def test_11b_calls_in_flight_keep_their_results_apart(sora, oracle):
+    """A handle keeps two calls in flight (own stream and result buffers each): four different batches issued back to back report the last
+    batch's rows; issued one by one with a read-back after each, every batch reports its own (checked against the C restatement)."""
+    import torch
+    rng = np.random.default_rng(2323)
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present (the captures come from the reference's modulator)")
+    batches = []
+    for b in range(4):
+        caps = [random_capture_11b(g, rng) for _ in range(24)]
+        descs, pos = [], 0
+        for i, c in enumerate(caps):
+            descs.append((pos, len(c), i)); pos += len(c)
+        batches.append((torch.from_numpy(np.concatenate(caps)).cuda(), descs, caps))
+    rx = sora.Rx11b(24, max(int(d.shape[0]) for d, _, _ in batches), max_frames_per_capture=64)
+
+    def check(res, caps):
+        for i, c in enumerate(caps):
+            ok, why = same_as_reference_11b([r for r in res if r["capture_id"] == i], oracle_rows(oracle, c))
+            assert ok, "capture %d: %s" % (i, why)
+
+    for d, descs, _ in batches:
+        rx.process_dev(d, descs)
+    check(rx.results(), batches[-1][2])
+    for d, descs, caps in batches:
+        rx.process_dev(d, descs)
+        check(rx.results(), caps)
+    rx.synchronize(); rx.close()
+
+
 def test_11b_capacity_and_argument_errors(sora):
     import torch
     with pytest.raises(Exception):
