@@ -314,7 +314,7 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True, rate_kbps=1000
         rx.process_dev(flat, descs)
     rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
     out = {"workload": "%d captures x one %s frame, %s, long preamble (%d samples @44 MHz each), AWGN" % (ncaps, "1 Mbps DBPSK" if rate_kbps == 1000 else "%g Mbps CCK" % (rate_kbps / 1000.0), what, n),
-           "ms": round(ms, 3), "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
+           "ms": round(ms, 3), "calls_in_flight": 2, "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
            "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
     if cpu and g.available():                                           # the reference's 11b graph on this box's host cores, side by side
@@ -492,7 +492,7 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
     alg = 8.0 * samples + 2.0 * 1500 * nframes                               # both chains read once + the decoded PSDUs
     return {"workload": "%d frames x 2 spatial streams, 64-QAM 3/4, 1500-byte PSDU per stream (%d data symbols, %d samples @40 MHz per chain each), 2x2 cross-talk, AWGN; unbiased MMSE" % (nframes, nsym, (2 + nsym) * 160),
             "parity": "unpinned: the reference has no 40 MHz / MMSE / per-stream-decoder receiver; loop-back against oracle/py_ht40.py, the reference's own bricks inside are pinned (tests/test_gpu_ht40.py)",
-            "ms": round(ms, 3), "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
+            "ms": round(ms, 3), "calls_in_flight": 3, "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
             "psdus_ok": ok, "psdus": 2 * nframes, "bound": "hbm", "algorithmic_bytes": int(alg), "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
 
