@@ -193,6 +193,16 @@ int sora_hip_deinterleave11a(const uint8_t* d_in, uint8_t* d_out, int n_bpsc, si
 int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const uint32_t* d_nsoft,
                         const uint16_t* d_frame_len, int code_rate, uint8_t* d_out, const uint32_t* d_out_off,
                         size_t n, void* stream);
+/* The same brick for a caller that streams bursts through it (a BRICK adapter calls once per burst): no allocation, no host
+ * wait, everything in stream order.  soft_span_bytes = the extent of the caller's soft buffer that the n jobs address
+ * (max over i of soft_off[i] + nsoft[i]; the jobs' ranges must not overlap); d_workspace = 16-byte aligned device memory of
+ * at least sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n), owned by the caller and free for reuse once the call's
+ * work on `stream` has completed.  (sora_hip_viterbi11a is this entry point over a grow-only workspace the library caches
+ * per device; it reads the extent back from the device and waits for the stream before it returns.) */
+size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n);
+int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const uint32_t* d_soft_off, const uint32_t* d_nsoft,
+                           const uint16_t* d_frame_len, int code_rate, uint8_t* d_out, const uint32_t* d_out_off,
+                           size_t n, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* Capture ingest in front of the receive graph, one streaming pass on the device:
  *   SORA_INGEST_RXBLOCK    the input is a Sora dump: 128-byte RX_BLOCKs = 16-byte descriptor + 28 COMPLEX16

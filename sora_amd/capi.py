@@ -52,7 +52,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
-           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
+           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
@@ -144,6 +144,9 @@ def load(build_if_missing=True):
     L.sora_hip_deinterleave11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_viterbi11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+    L.sora_hip_viterbi11a_workspace_bytes.argtypes = [ctypes.c_size_t, ctypes.c_size_t]; L.sora_hip_viterbi11a_workspace_bytes.restype = ctypes.c_size_t
+    L.sora_hip_viterbi11a_ws.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_stream_synchronize.argtypes = [ctypes.c_void_p]
     L.sora_hip_tx11a_samples.argtypes = [ctypes.c_uint32, ctypes.c_uint32]; L.sora_hip_tx11a_samples.restype = ctypes.c_size_t
     L.sora_hip_tx11a.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -725,6 +728,23 @@ def viterbi11a(soft, soft_off, nsoft, frame_len, code_rate, out_stride=2560, str
     out_off = (torch.arange(n, device=soft.device, dtype=torch.int32) * out_stride).contiguous()
     _check(load().sora_hip_viterbi11a(_dev_ptr(soft), _dev_ptr(soft_off), _dev_ptr(nsoft), _dev_ptr(frame_len), code_rate,
                                       _dev_ptr(out), _dev_ptr(out_off), n, _stream_ptr(stream)))
+    return out
+
+
+def viterbi11a_workspace_bytes(soft_span_bytes, n):
+    return int(load().sora_hip_viterbi11a_workspace_bytes(int(soft_span_bytes), int(n)))
+
+
+def viterbi11a_ws(soft, soft_off, nsoft, frame_len, code_rate, workspace, out=None, out_off=None, out_stride=2560, stream=None):
+    """The Viterbi brick out of a caller-owned workspace (uint8 CUDA tensor of >= viterbi11a_workspace_bytes(soft.numel(), n)):
+    no allocation and no host wait inside the call; the caller synchronises the stream before reading `out`."""
+    import torch
+    n = soft_off.shape[0]
+    if out is None:
+        out = torch.zeros((n, out_stride), dtype=torch.uint8, device=soft.device)
+        out_off = (torch.arange(n, device=soft.device, dtype=torch.int32) * out_stride).contiguous()
+    _check(load().sora_hip_viterbi11a_ws(_dev_ptr(soft), soft.numel(), _dev_ptr(soft_off), _dev_ptr(nsoft), _dev_ptr(frame_len), code_rate,
+                                         _dev_ptr(out), _dev_ptr(out_off), n, _dev_ptr(workspace), workspace.numel(), _stream_ptr(stream)))
     return out
 
 

@@ -82,19 +82,29 @@ constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in bot
 constexpr unsigned kOne = 0x00020001u;                    // mark bit 0 of both frames: bit 0 (frame A), bit 17 (frame B; bit 16 is the carry guard, see acs_step)
 constexpr unsigned kGuard = 1u << 16;
 
-constexpr int kRingBlocks = 48;                           // 8-step blocks of survivor history kept in LDS per wave: a window walks <= 37 of them
+// Survivor history in LDS, per wave: 8-step blocks of 64 16-bit entries {frame A's byte, frame B's byte}.  A window's walk touches
+// kMaxWalk = (WIN + LOOK + 7) / 8 + 2 consecutive blocks ending at the newest one.  The ring has a PERIOD of P blocks and 2 P positions:
+// block b is written twice, at b % P and at b % P + P, so the walk's blocks top, top - 1, ... (top = b % P + P) are always contiguous
+// and the trace-back reads them with ONE address register and compile-time offsets (the single-copy ring needed a borrow-select and an
+// address computation per block).  P is a multiple of 3: a 24-step row is three blocks, rows start at multiples of three blocks, so a
+// row never straddles the wrap and the position is advanced once per row.
+template <int WIN, int LOOK> struct RingGeom {
+    static constexpr int kMaxWalk = (WIN + LOOK + 7) / 8 + 2;                   // 37 for 256 / 24 (802.11a graph), 31 for 192 / 36 (802.11n graph)
+    static constexpr int P = (kMaxWalk + 2) / 3 * 3;                            // 39 / 33
+    static constexpr int kEntries = 2 * P * 64;                                 // 16-bit entries per wave: 9984 B / 8448 B
+};
 
 struct VitLane {
     unsigned U;              // (field B << 16) | field A; field = u << 9 | marks of the current 8-step block
     unsigned MX[24];         // soft mask (+ mark, + complement for own-is-candidate-1 lanes) of the mark-carrying operand, per t mod 24
     unsigned MY[6];          // soft mask of the second operand of a two-input step, per t mod 6
-    uint16_t* ring;          // LDS: [kRingBlocks][64] {frame A's block, frame B's block} (one byte each) at the block's end, indexed by rev6(state)
-    unsigned roff;           // slot of the block being filled, in words: (block index % kRingBlocks) * 64   (wave-uniform)
-    unsigned sidx[3];        // ring index of the state this lane holds at the end of block j, by j % 3: rev6(rol6^(8j+8)(lane))
+    uint16_t* ring;          // LDS: [2 P][64] {frame A's block, frame B's block} (one byte each) at the block's end, indexed by rev6(state)
+    unsigned rowpos;         // ring position (block index % P) of the first block of the current 24-step row, times 64   (wave-uniform)
+    unsigned sidx[3];        // ring index of the state this lane holds at the end of block j of a row: rev6(rol6^(8j+8)(lane))
 };
 
 // WHICH 0: (A,B) two soft values, 1: A only, 2: B only.  t24 = trellis step index mod 24 (a constant after unrolling).
-template <int WHICH>
+template <int WHICH, int P>
 __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsigned b)
 {
     const int ph = t24 % 6, k = t24 % 8;
@@ -123,9 +133,9 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     // instructions with the constants pinned into SGPRs measured 1.5-10 % slower.)
     V.U = pk_min16(X + bm, Y + bo);
     if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
-        uint8_t* e = reinterpret_cast<uint8_t*>(V.ring + V.roff + V.sidx[t24 / 8]);
-        e[0] = (uint8_t)V.U; e[1] = (uint8_t)(V.U >> 17);                       // frame A's block, frame B's block
-        V.roff = V.roff + 64 == kRingBlocks * 64 ? 0u : V.roff + 64;
+        uint16_t* e = V.ring + V.rowpos + (t24 / 8) * 64 + V.sidx[t24 / 8];
+        const uint16_t w = (uint16_t)((V.U & 0xFFu) | ((V.U >> 9) & 0xFF00u));  // frame A's block, frame B's block
+        e[0] = w; e[P * 64] = w;                                                // both copies (same address register, two immediates)
         V.U &= 0xFE00FE00u;
     }
 }
@@ -139,11 +149,11 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
 // Kept out of line: it is reached from every puncture group of the slow path.
 template <int kMaxWalk>                                                         // blocks a window's walk can touch: (WIN + LOOK + 7) / 8 + 2
 __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uint32_t tr_, uint32_t ob_, unsigned mA, unsigned mB,
-                                           uint32_t cntA_, uint32_t cntB_, uint8_t* outA, uint8_t* outB)
-{
+                                           uint32_t cntA_, uint32_t cntB_, uint8_t* outA, uint8_t* outB, uint32_t top_)
+{                                                                               // top: upper-copy ring position (P .. 2 P - 1) of block j = (tr - 1) >> 3
     const unsigned lane = threadIdx.x & 63;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // arguments arrive in VGPRs; these are wave-uniform
-    const uint32_t tr = uni(tr_), ob = uni(ob_), cntA = uni(cntA_), cntB = uni(cntB_);
+    const uint32_t tr = uni(tr_), ob = uni(ob_), cntA = uni(cntA_), cntB = uni(cntB_), top = uni(top_);
     auto rev6 = [](unsigned x) { return __brev(x) >> 26; };
     auto writelane = [](unsigned& vec, unsigned val, unsigned ln) {             // vec[lane ln] = val (one SGPR operand per VALU op: the lane select goes through M0)
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(ln) : "m0");
@@ -160,17 +170,13 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     const unsigned n = tr - 8u * (unsigned)j;                                   // its decisions known now: 1..8
     const int nblk = j - m_lo;                                                  // blocks below j on the walk
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // W[i] = block j - i, all 64 ring entries (one per lane).  Read as LDS (through the generic pointer these were flat loads with 64-bit
-    // address arithmetic each); the ring slot steps down with a borrow-select (s_sub_u32 + s_cselect), the address is one v_lshl_add.
-    const unsigned ring_off = (unsigned)(uintptr_t)ring;                        // the low half of a flat LDS address is the LDS offset
+    // W[i] = block j - i, all 64 ring entries (one per lane): ring positions top - i, contiguous thanks to the second copy of every block
+    // (RingGeom), so ONE address register and compile-time offsets.  (Read as LDS: the low half of a flat LDS address is the LDS offset.)
+    const unsigned low = (unsigned)(uintptr_t)ring + ((((top - (unsigned)(kMaxWalk - 1)) << 6) | lane) << 1);
     uint32_t W[kMaxWalk];
-    unsigned slot = uni((unsigned)j % (unsigned)kRingBlocks);
 #pragma unroll
-    for (int i = 0; i < kMaxWalk; i++) {
-        const unsigned addr = ring_off + (((slot << 6) | lane) << 1);
-        asm volatile("ds_read_u16 %0, %1" : "=v"(W[i]) : "v"(addr) : "memory");                                      // (zero-extends: no masking afterwards)
-        asm("s_sub_u32 %0, %0, 1\n\ts_cselect_b32 %0, %1, %0" : "+s"(slot) : "n"(kRingBlocks - 1) : "scc");       // slot = slot ? slot - 1 : kRingBlocks - 1
-    }
+    for (int i = 0; i < kMaxWalk; i++)
+        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(W[i]) : "v"(low), "n"((kMaxWalk - 1 - i) * 128) : "memory");   // (zero-extends: no masking afterwards)
     asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]) : : "memory");             // (W[1..] are only used by the assembler blocks below, which stay behind this one)
     unsigned HA, HB;
     if (n == 8) {

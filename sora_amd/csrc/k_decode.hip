@@ -34,7 +34,7 @@ constexpr int kSoftRing = 2304;                            // operands per trell
 
 struct DecodeLds {
     uint32_t ring[2][kSoftRing];                           // [pair] soft operands
-    uint16_t surv[2][kRingBlocks * 64];                    // [pair] survivor history of the trellis wave (dev_viterbi.h)
+    uint16_t surv[2][RingGeom<256, 24>::kEntries];         // [pair] survivor history of the trellis wave (dev_viterbi.h: two copies of every block)
     uint32_t eq[2][4][64];                                 // [pair][symbol of the pass] FFT staging, then the equalised bins
     uint8_t  soft[2][4][288];                              // [pair][symbol of the pass] soft values in carrier order
     uint16_t map[2][2][288];                               // [pair][frame] de-interleaver source index of the frame's modulation
@@ -222,7 +222,8 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     VitLane V;
     const unsigned vl = lane_map(lane);                                         // label lane: holds state rol6^t(vl) after t steps
     V.U = vl == 0 ? 0u : 0x18u * kFld;                                         // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
-    V.ring = ring; V.roff = 0;
+    V.ring = ring; V.rowpos = 0;
+    constexpr int P = RingGeom<256, 24>::P;
     V.sidx[0] = __brev(rol6(vl, 2)) >> 26; V.sidx[1] = __brev(rol6(vl, 4)) >> 26; V.sidx[2] = __brev(vl) >> 26;
 #pragma unroll
     for (int t = 0; t < 24; t++) {
@@ -238,7 +239,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     uint32_t tr = 0, ob = 0;
 
     auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // (no half borrows: a plain 32-bit subtraction)
-    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace<38>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RingGeom<256, 24>::kMaxWalk>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out, top); };
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + 256u + 24u + 6u;
         if (!A.done) t = min(t, A.tr_end);
@@ -249,8 +250,9 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     auto check = [&](int t24_last) {                                            // trace-back schedule (viterbi.hpp:196-214), per frame
         if (tr >= next_thr) {
             const int k = t24_last % 8;
+            const uint32_t pos = V.rowpos + (uint32_t)(t24_last / 8) * 64u;     // ring position (x 64) of block (tr - 1) >> 3
             unsigned lastA, lastB;
-            if (k == 7) { const unsigned w = ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
+            if (k == 7) { const unsigned w = ring[pos + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
             else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (17 + k)) & 1u; }
             const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
             const bool partial = tr >= ob + 256u + 24u + 6u;
@@ -263,7 +265,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
                 if (tr >= B.tr_end) { cntB = B.tr_end - ob - 6; B.done = true; }
                 else if (partial) cntB = 256;
             }
-            if (cntA | cntB) trace(mA, mB, cntA, cntB);
+            if (cntA | cntB) trace(mA, mB, cntA, cntB, (pos >> 6) + (uint32_t)P);
             if (partial) ob += 256;
             next_thr = next_event();
         }
@@ -289,11 +291,12 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     auto release = [&](uint32_t c) { lds_release(&S.consumed[pi], c * (uint32_t)VC); };   // everything below chunk c has been read
     auto group = [&](const Chunk& K, int h, int i0) {                           // one puncture group = GS steps; i0 = step inside the chunk, h = half of the 24-step row
         const int k0 = i0 / GS * GBv, t24 = 12 * h + i0;
-        acs_step<0>(V, t24, K.v[k0], K.v[k0 + 1]);                              // ACS(A,B)
-        if (CR != 0) acs_step<1>(V, t24 + 1, K.v[k0 + 2], 0);                   // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
-        if (CR == 2) acs_step<2>(V, t24 + 2, 0, K.v[k0 + 3]);                   // ACS(B)     3/4
+        acs_step<0, P>(V, t24, K.v[k0], K.v[k0 + 1]);                              // ACS(A,B)
+        if (CR != 0) acs_step<1, P>(V, t24 + 1, K.v[k0 + 2], 0);                   // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
+        if (CR == 2) acs_step<2, P>(V, t24 + 2, 0, K.v[k0 + 3]);                   // ACS(B)     3/4
         if ((t24 + GS) % 8 == 0) normalize();
     };
+    auto end_row = [&]() { V.rowpos = V.rowpos + 3 * 64 == (unsigned)P * 64 ? 0u : V.rowpos + 3 * 64; };
     auto fast_chunk = [&](const Chunk& K, int h) {
 #ifndef SORA_DBG_NO_TRELLIS                                                     // experiment: the symbol side alone (operands consumed, no ACS)
 #pragma unroll
@@ -325,6 +328,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
             cur = load_chunk(c + 2);
             fast_chunk(nxt, 1);
             c += 2;
+            end_row();
             release(c);
         }
         if (!(tr < nsteps)) break;
@@ -334,6 +338,7 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
         cur = load_chunk(c + 2);
         chunk(nxt, 1);
         c += 2;
+        end_row();
         release(c);
     }
     lds_release(&S.consumed[pi], 0x40000000u);                                  // nothing more will be read: the symbol wave never waits again

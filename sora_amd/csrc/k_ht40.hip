@@ -30,13 +30,13 @@ struct Ht40Frame {
     uint32_t length[2];
     int32_t  cfo;               // phase per 40 MHz sample, 65536 = 2 pi (TFreqComp_11n's vfo_step convention)
     float    noise_var;         // per carrier, in LSB^2 of the FFT output; 0 = zero forcing
-    uint32_t soft_off[2];       // bytes from the soft base, per stream
-    uint32_t pad[3];
+    uint32_t soft_off;          // dwords from the soft base: the frame's PAIR STREAM (k_rx.hip viterbi_forward), stream 0 << 9 | stream 1 << 25
+    uint32_t pad[4];
 };
 struct Ht40Args {
     const uint32_t* iq0; const uint32_t* iq1; const Ht40Frame* frames; uint32_t nframes;
     Tables T; const uint32_t* sincos; const short* atan;
-    uint8_t* soft;
+    uint32_t* soft;
     uint32_t* w_out;            // optional [nframes][4][128]: the detection weights (tests)
 };
 struct Ht40Job { uint32_t out_off, length, row, pad; };
@@ -168,7 +168,7 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
     }
     wsync40();
     // ---- data symbols, in order (the pilot phase of symbol d rotates symbol d + 1)
-    uint32_t* dst[2] = { reinterpret_cast<uint32_t*>(A.soft + F.soft_off[0]), reinterpret_cast<uint32_t*>(A.soft + F.soft_off[1]) };
+    uint32_t* dst = A.soft + F.soft_off;
     for (uint32_t d = 0; d < F.nsym; d++) {
         symbol_fft(320 + 160 * d, 0);
 #pragma unroll
@@ -211,11 +211,10 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
             }
         }
         wsync40();
-        // de-interleave per stream into its own decoder's soft stream: 16-bit fields v << 9, two per word
-#pragma unroll
-        for (int s = 0; s < 2; s++)
-            for (int w = lane; w < ncb / 2; w += 64)
-                dst[s][(size_t)d * (ncb / 2) + w] = ((uint32_t)W.soft[s][W.dtab[s][2 * w]] << 9) | ((uint32_t)W.soft[s][W.dtab[s][2 * w + 1]] << 25);
+        // de-interleave both streams into the frame's pair stream: one decoder wave takes stream 0 in its low halves and stream 1 in its
+        // high halves, so operand g = soft value g of stream 0 << 9 | soft value g of stream 1 << 25 (whole-dword coalesced stores)
+        for (int g = lane; g < ncb; g += 64)
+            dst[(size_t)d * ncb + g] = ((uint32_t)W.soft[0][W.dtab[0][g]] << 9) | ((uint32_t)W.soft[1][W.dtab[1][g]] << 25);
         wsync40();
     }
 }
@@ -268,7 +267,7 @@ static constexpr int kHt40Slots = 3;
 struct Ht40Slot {
     hipStream_t stream = nullptr;
     Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
-    uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
+    uint32_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
     std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0;
 };
 struct sora_ht40 {
@@ -358,16 +357,16 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
         Ht40Frame& F = hf[i];
         F.offset = s.offset; F.nsym = nsym; F.nb = s.n_bpsc; F.code_rate = s.code_rate; F.length[0] = s.length[0]; F.length[1] = s.length[1]; F.cfo = s.cfo; F.noise_var = s.noise_var;
         const uint64_t per = (uint64_t)nsym * 108 * s.n_bpsc;                       // soft values per stream
+        F.soft_off = (uint32_t)soft;
         for (int k = 0; k < 2; k++) {
-            F.soft_off[k] = (uint32_t)(soft * 2);
             VitJob& J = hj[s.code_rate * stride + nj[s.code_rate]++];                // the two streams of a frame are neighbours in their list: one wave decodes both
-            J.soft_off = F.soft_off[k]; J.nsoft = (uint32_t)per; J.length = s.length[k]; J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate; J.pad = 0;
+            J.soft_off = F.soft_off; J.nsoft = (uint32_t)per; J.length = s.length[k]; J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate; J.pad = 0;
             fj[2 * i + k] = Ht40Job{ J.out_off, s.length[k], (uint32_t)(2 * i + k), 0 };
-            soft += (per + 31) / 32 * 32;
         }
-        F.pad[0] = F.pad[1] = F.pad[2] = 0;
+        soft += (per + 31) / 32 * 32;                                               // dwords: one operand per soft value of a stream
+        F.pad[0] = F.pad[1] = F.pad[2] = F.pad[3] = 0;
     }
-    if (soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
+    if (2 * soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
     S.h_frames.assign(frames, frames + nframes); S.nframes = (uint32_t)nframes; rx->have_results = true;
     rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
     if (nframes == 0) return SORA_OK;
@@ -381,7 +380,7 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
     A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights);
     hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, S.stream, A);
     const uint32_t njobs = 2 * (uint32_t)nframes;
-    hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+    hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint32_t*)S.d_soft, S.d_vout);
     Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T;
     hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());

@@ -27,7 +27,7 @@ __device__ __constant__ uint8_t kPilotSgn[128] = {        // pilot.hpp:10-28: 1 
 // the pass's four symbols in order, pilot k in lane k, the loop state in scalar registers.  The equalised symbol never
 // leaves LDS; the small tables (demap steps, de-interleaver map) live in LDS, the FFT twiddles in registers; the next
 // pass's samples are requested before the tracking loop so that their latency hides behind it.
-//   algorithmic bytes per data symbol: 256 read (64 of the 80 samples) + 2 N_CBPS written (16-bit soft fields)
+//   algorithmic bytes per data symbol: 256 read (64 of the 80 samples) + 2 N_CBPS written (16-bit operand fields of the pair stream)
 __global__ void __launch_bounds__(256) k_frame(RxArgs A)
 {
     __shared__ uint32_t s_eq[4][4][64];                                          // [wave][symbol of the pass]: FFT staging, then the equalised bins
@@ -43,9 +43,21 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     const uint32_t j = jr.list * A.nrows + jr.idx;                               // slot of the job in jobs[] / joblist[]
     const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
+    // The pair stream (viterbi_forward): jobs 2p and 2p+1 of a code-rate list are decoded by one wave from one operand stream, this frame's
+    // soft values in the 16-bit half `half`.  The stream lives in the slot region of the pair's frame with more soft values (a tie: the even
+    // job), 4 bytes per operand; this wave zero-fills its half from its own end to the pair's.
+    const uint32_t half = jr.idx & 1u;
+    const bool has_mate = (jr.idx ^ 1u) < A.njobs[jr.list];
+    uint32_t my_nsoft = (uint32_t)r.nsym * 48u * r.nbpsc, pair_nsoft = my_nsoft, host_slot0 = r.slot0;
+    if (has_mate) {
+        const FrameRow& m = A.frames[A.joblist[jr.list * A.nrows + (jr.idx ^ 1u)]];
+        const uint32_t mate_nsoft = (uint32_t)m.nsym * 48u * m.nbpsc;
+        if (mate_nsoft > my_nsoft || (mate_nsoft == my_nsoft && half == 1u)) host_slot0 = m.slot0;
+        pair_nsoft = max(my_nsoft, mate_nsoft);
+    }
     if (lane == 0) {
         VitJob J; J.pad = 0;
-        J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftPerSlot * 2u; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+        J.valid = 1; J.soft_off = host_slot0 * (uint32_t)kSoftPerSlot; J.nsoft = my_nsoft; J.length = r.length;
         J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
         A.jobs[j] = J;
     }
@@ -61,7 +73,7 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
         const uint16_t* map = T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
         for (int i = lane; i < ncbps; i += 64) s_map[w][i] = map[i];
     }
-    uint32_t* dst = reinterpret_cast<uint32_t*>(A.soft + (size_t)r.slot0 * kSoftPerSlot * 2);
+    uint16_t* dst = reinterpret_cast<uint16_t*>(A.soft + (size_t)host_slot0 * kSoftPerSlot) + half;     // operand i of the pair: dst[2 i]
     // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
     const int pk = lane & 3;
     const int pbin = pk == 0 ? 43 : pk == 1 ? 57 : pk == 2 ? 7 : 21, pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
@@ -144,27 +156,32 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
             }
         }
         wsync();
-        // ---- T11aDeinterleave*: out[k] = in[j(k)]; the pass's symbols are contiguous in the frame's soft stream (16-bit fields v << 9)
+        // ---- T11aDeinterleave*: out[k] = in[j(k)]; the pass's symbols are contiguous in the frame's half of the pair stream (16-bit fields v << 9)
         {
-            const int nact = min(4, nsym - s0 + 1), wps = ncbps / 2;
-            uint32_t* d = dst + (size_t)(s0 - 1) * wps;
-            for (int i = lane; i < nact * wps; i += 64) {
-                const int gs = i / wps, k2 = i - gs * wps;
-                d[i] = ((uint32_t)s_soft[w][gs][s_map[w][2 * k2]] << 9) | ((uint32_t)s_soft[w][gs][s_map[w][2 * k2 + 1]] << 25);
+            const int nact = min(4, nsym - s0 + 1);
+            uint16_t* d = dst + 2 * (size_t)(s0 - 1) * ncbps;
+            for (int i = lane; i < nact * ncbps; i += 64) {
+                const int gs = i / ncbps, k = i - gs * ncbps;
+                d[2 * i] = (uint16_t)((uint32_t)s_soft[w][gs][s_map[w][k]] << 9);
             }
         }
         wsync();
     }
+    for (uint32_t i = my_nsoft + lane; i < pair_nsoft; i += 64) dst[2 * (size_t)i] = 0;   // the shorter frame of a pair: zero operands up to the pair's end
 }
 
 // (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
 struct VitSide {            // wave-uniform per-frame bookkeeping
-    const uint32_t* soft; uint8_t* out; uint32_t nsteps, last_chunk, tr_end; bool done;
+    uint8_t* out; uint32_t nsteps, tr_end; bool done;
 };
 
-// Soft input: 16 bits per soft value, v << 9 (what k_frame / k_soft_widen write), so a packed branch-metric operand is
-// one s_pack_ll/hh_b32_b16 of a word of frame A and a word of frame B.  The words arrive through the scalar cache
-// (s_load_dwordx8 per 12-step chunk per frame, prefetched one chunk ahead): no VALU work.
+// Soft input: the PAIR STREAM.  The two frames a wave decodes (consecutive jobs of one code-rate list) share one stream of ready-made
+// branch-metric operands: dword i = (soft value i of frame A) << 9 | (soft value i of frame B) << 25 -- exactly what acs_step xors with the
+// lane's mask.  The producers (k_frame, k_frame11n, k_ht40_frame, k_soft_widen) write each frame's 16-bit half; the stream lives in the
+// slot region of the frame with more soft values and the shorter frame's half is zero-filled up to the pair's length (its trellis half keeps
+// stepping on well-formed operands: a half fed garbage could carry twice into the guard bit within one block).  One s_load_dwordx16 (+x8 /
+// +x2) per 12-step chunk through the scalar cache, prefetched one chunk ahead; no scalar packing (the split streams of round 2 cost one
+// s_pack_ll/hh_b32_b16 per soft value and two address computations per chunk: a third of the kernel's issue slots).
 //
 // Trace-back (TViterbiCore::Traceback, viterbicore.h:468-555) runs in the same wave, out of LDS, whenever the window
 // schedule of T11aViterbi<..,256,24>::Process (viterbi.hpp:196-214) fires: the ring holds, per 8-column block j
@@ -176,24 +193,26 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
 // WIN / LOOK: the window schedule of T11aViterbi<.., N_INPUT, TRELLIS_DEPTH = WIN, TRELLIS_LOOKAHEAD = LOOK> -- 256 / 24 in the 802.11a graph
 // (fb11ademod_config.hpp:199), 192 / 36 in the 802.11n graph (fb11ndemod_config.hpp:199); a walk touches at most (WIN + LOOK + 7) / 8 + 2 <= 38 blocks.
 template <int CR, int WIN, int LOOK>
-__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring)
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint32_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring)
 {
+    using RG = RingGeom<WIN, LOOK>;
+    constexpr int P = RG::P;
     constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
     constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
-    constexpr int CW = 12 / GS * GB / 2;                                        // 32-bit soft words per 12-step chunk: 12 / 9 / 8
+    constexpr int CW = 12 / GS * GB;                                            // operands (dwords) per 12-step chunk: 24 / 18 / 16
     const unsigned lane = threadIdx.x & 63;
     VitSide A, B;
-    A.soft = reinterpret_cast<const uint32_t*>(soft_base + JA.soft_off); A.out = out_base + JA.out_off;
-    A.nsteps = JA.nsoft / GB * GS; A.last_chunk = (A.nsteps - 1) / 12; A.tr_end = JA.length * 8u + 16u + 6u; A.done = false;
-    const VitJob& JBx = hasB ? JB : JA;
-    B.soft = reinterpret_cast<const uint32_t*>(soft_base + JBx.soft_off); B.out = out_base + JBx.out_off;
-    B.nsteps = hasB ? JBx.nsoft / GB * GS : 0u; B.last_chunk = (JBx.nsoft / GB * GS - 1) / 12; B.tr_end = hasB ? JBx.length * 8u + 16u + 6u : 0u; B.done = !hasB;
+    A.out = out_base + JA.out_off; A.nsteps = JA.nsoft / GB * GS; A.tr_end = JA.length * 8u + 16u + 6u; A.done = false;
+    B.out = out_base + JB.out_off; B.nsteps = hasB ? JB.nsoft / GB * GS : 0u; B.tr_end = hasB ? JB.length * 8u + 16u + 6u : 0u; B.done = !hasB;
+    const uint32_t nsteps = max(A.nsteps, B.nsteps);
+    const uint32_t* sp = soft_base + JA.soft_off;                               // the pair stream (JA.soft_off == JB.soft_off, in dwords)
+    const uint32_t last_chunk = (nsteps - 1) / 12;
 
     auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };   // step kinds of a puncture group (viterbi.hpp:167-187)
     VitLane V;
     const unsigned vl = lane_map(lane);                                         // label lane: holds state rol6^t(vl) after t steps
     V.U = vl == 0 ? 0u : 0x18u * kFld;                                         // ALL_INIT0 / ALL_INIT = 0x00 / 0x30 (viterbilut.h:22-30)
-    V.ring = ring; V.roff = 0;
+    V.ring = ring; V.rowpos = 0;
     V.sidx[0] = __brev(rol6(vl, 2)) >> 26; V.sidx[1] = __brev(rol6(vl, 4)) >> 26; V.sidx[2] = __brev(vl) >> 26;   // rev6 of the state: (8j + 8) mod 6 = 2, 4, 0
 #pragma unroll
     for (int t = 0; t < 24; t++) {
@@ -206,14 +225,13 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         if (t < 6) V.MY[t] = own1 ? (mb ^ (7u * kFld)) : mb;
     }
 
-    const uint32_t nsteps = max(A.nsteps, B.nsteps);
     uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
     auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // Normalize (viterbicore.h:444-465), both frames; marks and guard are clear here and no half borrows (its minimum is subtracted): one 32-bit VOP2
 #ifdef SORA_DBG_NO_TRACE                                                        // experiment (tools/ab_decode.sh): the forward pass alone -- results are wrong, only the duration means something
-    auto trace = [&](unsigned, unsigned, uint32_t, uint32_t) {};
+    auto trace = [&](unsigned, unsigned, uint32_t, uint32_t, uint32_t) {};
 #else
-    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB) { viterbi_trace<(WIN + LOOK + 7) / 8 + 2>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out); };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RG::kMaxWalk>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out, top); };
 #endif
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
@@ -225,8 +243,9 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     auto check = [&](int t24_last) {                                            // trace-back schedule (viterbi.hpp:196-214), per frame
         if (tr >= next_thr) {
             const int k = t24_last % 8;                                         // the last decision: mark k of the field, or bit 7 of the block just banked
+            const uint32_t pos = V.rowpos + (uint32_t)(t24_last / 8) * 64u;     // ring position (x 64) of block (tr - 1) >> 3
             unsigned lastA, lastB;
-            if (k == 7) { const unsigned w = ring[(V.roff == 0 ? (kRingBlocks - 1) * 64u : V.roff - 64u) + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
+            if (k == 7) { const unsigned w = ring[pos + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
             else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (17 + k)) & 1u; }
             const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
             const bool partial = tr >= ob + (uint32_t)(WIN + LOOK + 6);
@@ -239,39 +258,34 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
                 if (tr >= B.tr_end) { cntB = B.tr_end - ob - 6; B.done = true; }
                 else if (partial) cntB = WIN;
             }
-            if (cntA | cntB) trace(mA, mB, cntA, cntB);
+            if (cntA | cntB) trace(mA, mB, cntA, cntB, (pos >> 6) + (uint32_t)P);
             if (partial) ob += WIN;
             next_thr = next_event();
         }
     };
-    struct Chunk { uint32_t a[CW], b[CW]; };
-    auto load_chunk = [&](uint32_t c, uint32_t zero) -> Chunk {                 // chunk c of both frames; past a frame's end: its last chunk again
-        Chunk K;                                                                //   (that frame is done by then; the frame's spare slot covers a ragged tail)
-        const uint32_t* pa = A.soft + min(c, A.last_chunk) * CW + zero;
-        const uint32_t* pb = B.soft + min(c, B.last_chunk) * CW + zero;
+    struct Chunk { uint32_t v[CW]; };
+    auto load_chunk = [&](uint32_t c, uint32_t zero) -> Chunk {                 // chunk c of the pair stream; past the pair's end: its last chunk again
+        Chunk K;                                                                //   (both frames are done by then)
+        const uint32_t* p = sp + min(c, last_chunk) * CW + zero;
 #ifdef SORA_DBG_NO_SMEM                                                          // experiment (tools/ab_decode.sh): no soft values from memory -- results are wrong, only the duration means something
 #pragma unroll
-        for (int i = 0; i < CW; i++) { K.a[i] = ((c + zero) * 0x9E3779B1u + (uint32_t)i * 0x85EBCA6Bu) & 0x0E000E00u; K.b[i] = ((c + zero) * 0xC2B2AE35u + (uint32_t)i * 0x27D4EB2Fu) & 0x0E000E00u; }
-        (void)pa; (void)pb;
+        for (int i = 0; i < CW; i++) K.v[i] = ((c + zero) * 0x9E3779B1u + (uint32_t)i * 0x85EBCA6Bu) & 0x0E000E00u;
+        (void)p;
 #else
 #pragma unroll
-        for (int i = 0; i < CW; i++) { K.a[i] = pa[i]; K.b[i] = pb[i]; }
+        for (int i = 0; i < CW; i++) K.v[i] = p[i];
 #endif
         return K;
-    };
-    auto sv = [](const Chunk& K, int k) -> unsigned {                           // soft value k of the chunk, frames A | B: s_pack_ll/hh_b32_b16
-        const uint32_t a = K.a[k >> 1], b = K.b[k >> 1];
-        const u16x2_t v = (k & 1) ? u16x2_t{(unsigned short)(a >> 16), (unsigned short)(b >> 16)} : u16x2_t{(unsigned short)a, (unsigned short)b};
-        return __builtin_bit_cast(unsigned, v);
     };
     // one puncture group = GS steps; i0 = step index inside the 12-step chunk, h = which half of the 24-step row
     auto group = [&](const Chunk& K, int h, int i0) {
         const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
-        acs_step<0>(V, t24, sv(K, k0), sv(K, k0 + 1));                          // ACS(A,B)
-        if (CR != 0) acs_step<1>(V, t24 + 1, sv(K, k0 + 2), 0);                 // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
-        if (CR == 2) acs_step<2>(V, t24 + 2, 0, sv(K, k0 + 3));                 // ACS(B)     3/4
+        acs_step<0, P>(V, t24, K.v[k0], K.v[k0 + 1]);                           // ACS(A,B)
+        if (CR != 0) acs_step<1, P>(V, t24 + 1, K.v[k0 + 2], 0);                // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
+        if (CR == 2) acs_step<2, P>(V, t24 + 2, 0, K.v[k0 + 3]);                // ACS(B)     3/4
         if ((t24 + GS) % 8 == 0) normalize();                                   // (trellis index & 7) == 0 after a group
     };
+    auto end_row = [&]() { V.rowpos = V.rowpos + 3 * 64 == (unsigned)P * 64 ? 0u : V.rowpos + 3 * 64; };   // P is a multiple of 3: the wrap falls between rows
     auto fast_chunk = [&](const Chunk& K, int h) {                              // 12 steps, no trace-back due inside: straight-line code
 #pragma unroll
         for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
@@ -294,26 +308,28 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     // Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0), and the compiler puts it at the
     // first use of the loaded registers.  The prefetch of chunk c+1 must therefore be ISSUED after the first use of chunk c
     // (or that wait would cover the prefetch too) and is then covered by a whole chunk of ACS work.  The order is pinned by
-    // data flow: the prefetch address takes a bit of chunk c that is always zero (soft fields are v << 9).
+    // data flow: the prefetch address takes a bit of chunk c that is always zero (operand fields are v << 9).
     uint32_t c = 0;
     Chunk cur = load_chunk(0, 0);
     while (tr < nsteps && !(A.done && B.done)) {
         // rows (2 chunks) that certainly need no look at the schedule: run them back to back, 9 rows out of 10
         const uint32_t lim = min(nsteps, next_thr - 1);
         for (uint32_t rows = lim > tr ? (lim - tr) / 24 : 0; rows > 0; rows--) {
-            Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
+            Chunk nxt = load_chunk(c + 1, cur.v[0] & 1u);
             fast_chunk(cur, 0);
-            cur = load_chunk(c + 2, (nxt.a[0] | nxt.b[0]) & 1u);
+            cur = load_chunk(c + 2, nxt.v[0] & 1u);
             fast_chunk(nxt, 1);
             c += 2;
+            end_row();
         }
         if (!(tr < nsteps)) break;
-        Chunk nxt = load_chunk(c + 1, (cur.a[0] | cur.b[0]) & 1u);
+        Chunk nxt = load_chunk(c + 1, cur.v[0] & 1u);
         chunk(cur, 0);
         if (!(tr < nsteps && !(A.done && B.done))) break;
-        cur = load_chunk(c + 2, (nxt.a[0] | nxt.b[0]) & 1u);
+        cur = load_chunk(c + 2, nxt.v[0] & 1u);
         chunk(nxt, 1);
         c += 2;
+        end_row();
     }
 }
 
@@ -322,9 +338,9 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 // Frames are queued per code rate (k_scan), so the two frames of a wave always share the puncture pattern; the last
 // frame of an odd list runs alone in the low half.  (Jobs given through sora_hip_viterbi11a are one list of one rate.)
 template <int WIN, int LOOK>
-__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
-    __shared__ uint16_t s_ring[4][kRingBlocks * 64];                             // 24 KB: survivor history of the last 384 columns, per wave
+    __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];                // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
     // wave -> (code-rate list, pair): list r has ceil(n_r / 2) pairs (njobs3 == nullptr: one list of njobs_single jobs)
     uint32_t n[3] = { njobs_single, 0, 0 };
@@ -344,24 +360,17 @@ __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ j
         return J;
     };
     const VitJob JA = load_job(fa);
-    VitJob JB = JA;
-    bool hasB = fb < njobs;
-    if (hasB) { JB = load_job(fb); hasB = JB.valid != 0; }
-    const bool pair = JA.valid && hasB && JA.code_rate == JB.code_rate;
-    for (int pass = 0; pass < (pair ? 1 : 2); pass++) {                         // unpaired: A alone, then B alone (one call site per code rate)
-        const bool second = pass == 1;
-        if (second ? !hasB : !JA.valid) continue;
-        const VitJob X = second ? JB : JA;
-        if (X.code_rate == 0)      viterbi_forward<0, WIN, LOOK>(X, JB, pair, soft, out, ring);
-        else if (X.code_rate == 1) viterbi_forward<1, WIN, LOOK>(X, JB, pair, soft, out, ring);
-        else                       viterbi_forward<2, WIN, LOOK>(X, JB, pair, soft, out, ring);
-    }
+    const bool hasB = fb < njobs;
+    const VitJob JB = hasB ? load_job(fb) : JA;
+    if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK>(JA, JB, hasB, soft, out, ring);
+    else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK>(JA, JB, hasB, soft, out, ring);
+    else                        viterbi_forward<2, WIN, LOOK>(JA, JB, hasB, soft, out, ring);
 }
 
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi_kernel_body<256, 24>(jobs, njobs3, njobs_single, stride, soft, out); }
 // the 802.11n graph's decoder: T11aViterbi<5000*8, 312, 192, 36> (fb11ndemod_config.hpp:199)
-__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi_kernel_body<192, 36>(jobs, njobs3, njobs_single, stride, soft, out); }
 
 // ------------------------------------------------------------------------------------------------
@@ -467,24 +476,30 @@ __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uin
 // stand-alone stage kernels (per-stage C entry points)
 // (k_fft64_batch, k_demap_batch, k_deint_batch: k_stage.hip)
 
-// sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits);
-// the trellis kernel reads 16-bit fields v << 9.
-__global__ void __launch_bounds__(256) k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16)
+// sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits); the trellis kernel reads the
+// pair stream (viterbi_forward).  Block j widens job j into its half of the stream it shares with job j ^ 1 -- hosted at 4 x the byte
+// offset of the pair's longer job, which keeps the hosted ranges disjoint because the caller's are -- zero-fills its half up to the
+// pair's length, and writes its job record.
+__global__ void __launch_bounds__(256) k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
+                                                    int code_rate, uint32_t n, uint32_t span, uint32_t* pair, VitJob* jobs)
 {
-    const uint32_t j = blockIdx.x;
+    const uint32_t j = blockIdx.x, mate = j ^ 1u, half = j & 1u;
+    const uint32_t mine = nsoft[j];
+    uint32_t host = off8[j], total = mine;
+    if (mate < n) {
+        const uint32_t theirs = nsoft[mate];
+        if (theirs > mine || (theirs == mine && half == 1u)) host = off8[mate];
+        total = max(mine, theirs);
+    }
     const uint8_t* in = soft8 + off8[j];
-    uint16_t* out = reinterpret_cast<uint16_t*>(soft16 + off16[j]);
-    for (uint32_t k = threadIdx.x; k < nsoft[j]; k += blockDim.x) out[k] = (uint16_t)((in[k] & 7u) << 9);
-}
-
-__global__ void __launch_bounds__(64) k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
-                                                      const uint32_t* out_off, int code_rate, uint32_t n)
-{
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    VitJob J; J.soft_off = soft_off[i]; J.nsoft = nsoft[i]; J.length = flen[i]; J.dec_off = 0; J.out_off = out_off[i];
-    J.valid = 1; J.code_rate = (uint32_t)code_rate; J.pad = 0;
-    jobs[i] = J;
+    uint16_t* out = reinterpret_cast<uint16_t*>(pair + host) + half;
+    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) out[2 * (size_t)k] = k < mine ? (uint16_t)((in[k] & 7u) << 9) : (uint16_t)0;
+    if (threadIdx.x == 0) {
+        VitJob J; J.soft_off = host; J.nsoft = mine; J.length = flen[j]; J.dec_off = 0; J.out_off = out_off[j];
+        J.valid = 1; J.code_rate = (uint32_t)code_rate; J.pad = 0;
+        jobs[j] = J;
+    }
+    (void)span;
 }
 
 }  // namespace sora

@@ -33,7 +33,7 @@ struct RxArgs {
     Tables          T;
     FrameRow*       frames;
     const FrameCtx* fctx;
-    uint8_t*        soft;           // [slots*288] 16-bit fields (v << 9); unused by the fused decode kernel
+    uint32_t*       soft;           // [slots*288] pair-stream operands (soft A << 9 | soft B << 25, k_rx.hip); unused by the fused decode kernel
     uint8_t*        vout;           // [slots*32]
     uint8_t*        mpdu;           // [slots*32]
     VitJob*         jobs;           // [3][nrows] (indexed by job); unused by the fused decode kernel
@@ -44,8 +44,8 @@ struct RxArgs {
 __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
 __global__ void k_decode(RxArgs A);
-__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
-__global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
+__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* soft, uint8_t* out);
+__global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* soft, uint8_t* out);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);
@@ -71,9 +71,8 @@ __global__ void k_tx_preamble(int8_t* out8, Tables T);
 __global__ void k_tx11a(TxArgs A);
 __global__ void k_ingest(const uint8_t* raw, uint32_t* out, uint64_t m0, uint64_t n_out, unsigned flags);
 __global__ void k_ingest_tile(const uint8_t* raw, uint32_t* out, unsigned flags, uint32_t tiles);
-__global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint32_t* off16, uint8_t* soft16);
-__global__ void k_make_vitjobs(VitJob* jobs, const uint32_t* soft_off, const uint32_t* nsoft, const uint16_t* flen,
-                               const uint32_t* out_off, int code_rate, uint32_t n);
+__global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
+                             int code_rate, uint32_t n, uint32_t span, uint32_t* pair, VitJob* jobs);
 
 // ---- 802.11b receive graph (k_rx11b.hip)
 struct Rx11bRow { uint32_t end_sample, error_code, rate_kbps, length, crc32; };

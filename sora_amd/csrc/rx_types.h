@@ -5,7 +5,8 @@
 //   caps[]        per capture {offset, nsamples, id, slot_base}
 //   frames[]      frame table, max_frames_per_capture rows per capture, filled by k_scan in time order
 //   fctx[]        per frame: FreqCoeffs[64] + ChannelCoeffs[64] (CF_FreqCompensate / CF_Channel_11a)
-//   soft[]        per frame: de-interleaved soft values, 16-bit fields v << 9, contiguous (frame base = slot0*576 bytes)
+//   soft[]        per PAIR of frames (the two a trellis wave decodes): de-interleaved soft values as ready operands, dword i =
+//                 soft A << 9 | soft B << 25 (base = slot0 of the pair's longer frame * 288 dwords)
 //   vout[]        per frame: Viterbi output bytes (length+2), base = slot0*32
 //   mpdu[]        per frame: descrambled MPDU, base = slot0*32 (same geometry as vout)
 //   rows[]        compacted sora_frame_result rows + counter
@@ -45,7 +46,7 @@ struct FrameCtx {           // 512 bytes
 };
 
 struct VitJob {             // one Viterbi decode: a frame of the RX path or one job of sora_hip_viterbi11a
-    uint32_t soft_off;      // bytes from the soft base (4-byte aligned)
+    uint32_t soft_off;      // dwords from the soft base: the pair stream this job shares with its neighbour (jobs 2p, 2p+1 of a list)
     uint32_t nsoft;
     uint32_t length;        // frame_length (decoded bytes = length+2)
     uint32_t dec_off;       // unused (decisions live in LDS)

@@ -265,7 +265,7 @@ struct RxPipe {
     uint32_t cap_slots = 0, cap_rows = 0;
     // device arrays
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
-    uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
+    uint32_t* d_soft = nullptr; VitJob* d_jobs = nullptr;       // split decode path only (allocated on its first use)
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
@@ -367,7 +367,7 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     // Symbol slots, frame rows and the byte offsets derived from them are 32-bit on the device: a configuration that would
     // wrap them is refused here instead of decoding garbage later.
     const uint64_t want_slots = n20 / 80 + cfg->max_captures + 16, want_rows = (uint64_t)cfg->max_captures * cfg->max_frames_per_capture;
-    if (want_slots * (2ull * kSoftPerSlot) >= (1ull << 32) || want_rows >= (1ull << 31) / 3 || cfg->max_total_samples >= (1ull << 32)) {
+    if (want_slots * (1ull * kSoftPerSlot) >= (1ull << 32) || want_rows >= (1ull << 31) / 3 || cfg->max_total_samples >= (1ull << 32)) {
         rx_free(rx);
         return fail(SORA_ERR_CAPACITY, "sora_rx_create: max_total_samples / max_captures x max_frames_per_capture exceed the 32-bit slot geometry of one handle (split the batch over several handles)");
     }
@@ -431,7 +431,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
     if (!rx->fused && !rx->d_soft) {                                             // the 16-bit soft stream and the job table exist only for the split path
-        HIPCHK(hipMalloc((void**)&rx->d_soft, 2 * (size_t)kSoftPerSlot * rx->cap_slots + 64));
+        HIPCHK(hipMalloc((void**)&rx->d_soft, 4 * (size_t)kSoftPerSlot * rx->cap_slots + 256));   // pair-stream operands: 4 bytes per soft value of the pair's longer frame
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
     hipStream_t st = rx->stream;
@@ -474,7 +474,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             R.soft = rx->d_soft; R.jobs = rx->d_jobs;
             hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
-            hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
+            hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint32_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
         }
         hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
@@ -990,6 +990,38 @@ int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_co
     return SORA_OK;
 }
 
+// The stage works out of a caller-owned workspace (no allocation, no host wait): the pair stream of jobs 2p / 2p+1 is hosted at
+// 4 x the byte offset of the pair's longer job (the caller's soft ranges are disjoint, so the hosted ranges are), followed by the job
+// table.  sora_hip_viterbi11a keeps the original signature on top of a grow-only workspace cached per device.
+size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n)
+{
+    return ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255) + sizeof(VitJob) * n;
+}
+
+int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const uint32_t* d_soft_off, const uint32_t* d_nsoft, const uint16_t* d_frame_len,
+                           int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* d_workspace, size_t workspace_bytes, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: bad argument");
+    if (n == 0) return SORA_OK;
+    if (!d_workspace || ((uintptr_t)d_workspace & 15)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a_ws: the workspace must be a 16-byte aligned device buffer");
+    if (workspace_bytes < sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a_ws: workspace smaller than sora_hip_viterbi11a_workspace_bytes()");
+    if (soft_span_bytes >= (1ull << 32) || n >= (1ull << 31)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
+    hipStream_t st = (hipStream_t)stream;
+    uint32_t* pair = (uint32_t*)d_workspace;
+    VitJob* jobs = (VitJob*)((uint8_t*)d_workspace + ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255));
+    hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, d_frame_len, d_out_off, code_rate, (uint32_t)n, (uint32_t)soft_span_bytes, pair, jobs);
+    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint32_t*)pair, d_out);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+
+namespace {
+struct VitWs { void* p = nullptr; size_t bytes = 0; };
+std::mutex g_vitws_mutex;
+VitWs g_vitws[64];
+}
+
 int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const uint32_t* d_nsoft, const uint16_t* d_frame_len,
                         int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* stream)
 {
@@ -997,28 +1029,30 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
     if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: bad argument");
     if (n == 0) return SORA_OK;
     hipStream_t st = (hipStream_t)stream;
-    // scratch: the 16-bit soft stream and the job table
-    std::vector<uint32_t> h_nsoft(n), h_s16_off(n);
+    // This signature does not say how far the soft buffer reaches: read the extent back once (the _ws entry point takes it as an argument).
+    std::vector<uint32_t> h_off(n), h_nsoft(n);
+    HIPCHK(hipMemcpyAsync(h_off.data(), d_soft_off, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipMemcpyAsync(h_nsoft.data(), d_nsoft, 4 * n, hipMemcpyDeviceToHost, st));
     HIPCHK(hipStreamSynchronize(st));
-    uint64_t s16 = 0;
+    uint64_t span = 0;
     for (size_t i = 0; i < n; i++) {
         if (h_nsoft[i] < 24) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: a job needs at least one OFDM symbol of soft values");
-        h_s16_off[i] = (uint32_t)s16; s16 += ((uint64_t)h_nsoft[i] * 2 + 64 + 3) & ~3ull;      // + slack for the last 12-step chunk
+        span = std::max<uint64_t>(span, (uint64_t)h_off[i] + h_nsoft[i]);
     }
-    if (s16 >> 32) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
-    // scratch (the 16-bit soft stream, its offsets, the job table) in one allocation, released on every path
-    struct Scratch { void* p = nullptr; ~Scratch() { if (p) (void)hipFree(p); } } scratch;
-    const size_t soft_bytes = (s16 + 64 + 255) & ~(size_t)255, off_bytes = (4 * n + 255) & ~(size_t)255;
-    HIPCHK(hipMalloc(&scratch.p, soft_bytes + off_bytes + sizeof(VitJob) * n));
-    uint8_t* soft16 = (uint8_t*)scratch.p; uint32_t* s16off = (uint32_t*)(soft16 + soft_bytes); VitJob* jobs = (VitJob*)(soft16 + soft_bytes + off_bytes);
-    HIPCHK(hipMemsetAsync(soft16, 0, s16 + 64, st));
-    HIPCHK(hipMemcpyAsync(s16off, h_s16_off.data(), 4 * n, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, (const uint32_t*)s16off, soft16);
-    hipLaunchKernelGGL(k_make_vitjobs, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, jobs, (const uint32_t*)s16off, d_nsoft, d_frame_len, d_out_off, code_rate, (uint32_t)n);
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)soft16, d_out);
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipStreamSynchronize(st));                                             // the scratch is released when this function returns
+    if (span >> 32) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
+    int dev = 0; HIPCHK(hipGetDevice(&dev));
+    if (dev < 0 || dev >= 64) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: device ordinal out of range");
+    const size_t need = sora_hip_viterbi11a_workspace_bytes((size_t)span, n);
+    std::lock_guard<std::mutex> lock(g_vitws_mutex);                             // one cached workspace per device: calls through this signature are serialised
+    VitWs& W = g_vitws[dev];
+    if (W.bytes < need) {
+        if (W.p) { HIPCHK(hipDeviceSynchronize()); (void)hipFree(W.p); W.p = nullptr; W.bytes = 0; }
+        HIPCHK(hipMalloc(&W.p, need + need / 4));
+        W.bytes = need + need / 4;
+    }
+    const int rc = sora_hip_viterbi11a_ws(d_soft, (size_t)span, d_soft_off, d_nsoft, d_frame_len, code_rate, d_out, d_out_off, n, W.p, W.bytes, stream);
+    if (rc != SORA_OK) return rc;
+    HIPCHK(hipStreamSynchronize(st));                                             // the cached workspace is free for the next call when this one returns
     return SORA_OK;
 }
 

@@ -93,6 +93,18 @@ def test_viterbi_bit_exact_on_noise(sora, torch_cuda, oracle, cr):
         want = oracle.viterbi_frame(softs[i], cr, L)
         assert len(want) == L + 2
         assert np.array_equal(out[i, :L + 2], want), (cr, L)
+    # the same jobs out of a caller-owned workspace (no allocation, no host wait inside the call), twice in a row on one stream, and with an
+    # odd job count (the last job has no pair mate)
+    d_buf = torch.from_numpy(buf).cuda()
+    ws = torch.empty(sora.viterbi11a_workspace_bytes(d_buf.numel(), len(lens)), dtype=torch.uint8, device="cuda")
+    for n in (len(lens), len(lens) - 1):
+        args = (torch.tensor(offs[:n], dtype=torch.int32).cuda(), torch.tensor(ns[:n], dtype=torch.int32).cuda(), torch.tensor(lens[:n], dtype=torch.int16).cuda())
+        for _ in range(2):
+            o2 = sora.viterbi11a_ws(d_buf, *args, cr, ws)
+        torch.cuda.synchronize()
+        o2 = o2.cpu().numpy()
+        for i, L in enumerate(lens[:n]):
+            assert np.array_equal(o2[i, :L + 2], out[i, :L + 2]), ("workspace", cr, L, n)
 
 
 # ------------------------------------------------------------------ whole path
