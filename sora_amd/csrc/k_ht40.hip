@@ -305,7 +305,7 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
     if (device < 0 || device >= ndev) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "device ordinal out of range", 0);
-    if (max_soft_values * 2 + 1024 >= (1ull << 32)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_create: max_soft_values exceeds the 32-bit offsets of one handle", 0);
+    if (max_soft_values * 2 + 4096 + 1024 >= (1ull << 32)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_create: max_soft_values exceeds the 32-bit offsets of one handle", 0);
     HIPCHK40(hipSetDevice(device));
     sora_ht40_t* rx = new sora_ht40();
     rx->device = device; rx->max_frames = max_frames; rx->max_soft = max_soft_values;
@@ -317,11 +317,11 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_jobs, 3 * sizeof(VitJob) * nj);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_njobs, 16);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_fjobs, sizeof(Ht40Job) * nj);
-        if (e == hipSuccess) e = hipMalloc((void**)&S.d_soft, max_soft_values * 2 + 1024);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_soft, max_soft_values * 2 + 4096 + 1024);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_vout, nj * kVoutStride + 256);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, nj * 4096);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * nj);
-        if (e == hipSuccess) e = hipMemset(S.d_soft, 0, max_soft_values * 2 + 1024);
+        if (e == hipSuccess) e = hipMemset(S.d_soft, 0, max_soft_values * 2 + 4096 + 1024);
         if (e == hipSuccess) e = hipMemset(S.d_vout, 0, nj * kVoutStride + 256);
     }
     if (e != hipSuccess) { ht40_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_create: device allocation / tables", (int)e); }

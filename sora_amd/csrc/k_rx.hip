@@ -171,6 +171,13 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
 }
 
 // (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
+#ifndef SORA_VIT_PF_AHEAD
+#define SORA_VIT_PF_AHEAD 6
+#endif
+constexpr int kVitPfAhead = SORA_VIT_PF_AHEAD;              // chunks of look-ahead of the pair stream's L2 prefetch (0: none); build variants measure others
+typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
+typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 struct VitSide {            // wave-uniform per-frame bookkeeping
     uint8_t* out; uint32_t nsteps, tr_end; bool done;
 };
@@ -193,7 +200,7 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
 // WIN / LOOK: the window schedule of T11aViterbi<.., N_INPUT, TRELLIS_DEPTH = WIN, TRELLIS_LOOKAHEAD = LOOK> -- 256 / 24 in the 802.11a graph
 // (fb11ademod_config.hpp:199), 192 / 36 in the 802.11n graph (fb11ndemod_config.hpp:199); a walk touches at most (WIN + LOOK + 7) / 8 + 2 <= 38 blocks.
 template <int CR, int WIN, int LOOK>
-__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint32_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring)
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint32_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring, uint32_t* pf_dump)
 {
     using RG = RingGeom<WIN, LOOK>;
     constexpr int P = RG::P;
@@ -263,26 +270,41 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
             next_thr = next_event();
         }
     };
-    struct Chunk { uint32_t v[CW]; };
-    auto load_chunk = [&](uint32_t c, uint32_t zero) -> Chunk {                 // chunk c of the pair stream; past the pair's end: its last chunk again
+    // The chunk loads are written out as s_load_dwordx16 (+x8 / +x2): the look-ahead load below is inline assembly, and next to inline
+    // assembly that may touch memory the compiler no longer proves the stream unclobbered and would fetch it with VECTOR loads (8 x
+    // global_load_dwordx4 per row).  `off` is a byte offset from the pair stream's base.  The destination registers are defined by the
+    // load statement but hold the data only after lgkmcnt(0): wait_chunk() is that wait and the data dependence every use hangs on.
+    struct Chunk { u32x16_t lo; u32x8_t hi8; u32x2_t hi2; };
+    auto load_chunk = [&](uint32_t c) -> Chunk {                                // chunk c of the pair stream; past the pair's end: its last chunk again
         Chunk K;                                                                //   (both frames are done by then)
-        const uint32_t* p = sp + min(c, last_chunk) * CW + zero;
+        const uint32_t off = min(c, last_chunk) * (uint32_t)(CW * 4);
 #ifdef SORA_DBG_NO_SMEM                                                          // experiment (tools/ab_decode.sh): no soft values from memory -- results are wrong, only the duration means something
 #pragma unroll
-        for (int i = 0; i < CW; i++) K.v[i] = ((c + zero) * 0x9E3779B1u + (uint32_t)i * 0x85EBCA6Bu) & 0x0E000E00u;
-        (void)p;
+        for (int i = 0; i < 16; i++) K.lo[i] = (c * 0x9E3779B1u + (uint32_t)i * 0x85EBCA6Bu) & 0x0E000E00u;
+        K.hi8 = K.lo.lo; K.hi2 = K.lo.lo.lo.lo;
 #else
-#pragma unroll
-        for (int i = 0; i < CW; i++) K.v[i] = p[i];
+        // ("+v"(V.U): the statement sits in the metrics' dependence chain, so the scheduler cannot sink it below the ACS work that is meant
+        //  to cover its latency -- it had moved the load to within 16 instructions of its wait)
+        asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(K.lo), "+v"(V.U) : "s"(sp), "s"(off));
+        if (CW == 24) asm volatile("s_load_dwordx8 %0, %1, %2 offset:64" : "=s"(K.hi8) : "s"(sp), "s"(off));
+        if (CW == 18) asm volatile("s_load_dwordx2 %0, %1, %2 offset:64" : "=s"(K.hi2) : "s"(sp), "s"(off));
 #endif
         return K;
     };
+    auto wait_chunk = [&](Chunk& K) {
+#ifndef SORA_DBG_NO_SMEM
+        if (CW == 24)      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(K.lo), "+s"(K.hi8));
+        else if (CW == 18) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(K.lo), "+s"(K.hi2));
+        else               asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(K.lo));
+#endif
+    };
+    auto op = [](const Chunk& K, int i) -> uint32_t { return i < 16 ? K.lo[i] : CW == 24 ? K.hi8[i - 16] : K.hi2[i - 16]; };
     // one puncture group = GS steps; i0 = step index inside the 12-step chunk, h = which half of the 24-step row
     auto group = [&](const Chunk& K, int h, int i0) {
         const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
-        acs_step<0, P>(V, t24, K.v[k0], K.v[k0 + 1]);                           // ACS(A,B)
-        if (CR != 0) acs_step<1, P>(V, t24 + 1, K.v[k0 + 2], 0);                // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
-        if (CR == 2) acs_step<2, P>(V, t24 + 2, 0, K.v[k0 + 3]);                // ACS(B)     3/4
+        acs_step<0, P>(V, t24, op(K, k0), op(K, k0 + 1));                       // ACS(A,B)
+        if (CR != 0) acs_step<1, P>(V, t24 + 1, op(K, k0 + 2), 0);              // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
+        if (CR == 2) acs_step<2, P>(V, t24 + 2, 0, op(K, k0 + 3));              // ACS(B)     3/4
         if ((t24 + GS) % 8 == 0) normalize();                                   // (trellis index & 7) == 0 after a group
     };
     auto end_row = [&]() { V.rowpos = V.rowpos + 3 * 64 == (unsigned)P * 64 ? 0u : V.rowpos + 3 * 64; };   // P is a multiple of 3: the wrap falls between rows
@@ -305,32 +327,56 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         if (tr + 12 <= nsteps && next_thr > tr + 12) fast_chunk(K, h); else slow_chunk(K, h);
     };
 
-    // Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0), and the compiler puts it at the
-    // first use of the loaded registers.  The prefetch of chunk c+1 must therefore be ISSUED after the first use of chunk c
-    // (or that wait would cover the prefetch too) and is then covered by a whole chunk of ACS work.  The order is pinned by
-    // data flow: the prefetch address takes a bit of chunk c that is always zero (operand fields are v << 9).
+    // A chunk is 64 / 72 / 96 bytes the wave reads exactly once: every scalar load is a miss all the way to HBM (or the Infinity
+    // Cache, where k_frame's stores went), ~0.6 us against the ~0.25 us one chunk of ACS work covers.  (The split streams of round 2 read
+    // 32 bytes per frame and chunk, so every other load hit the line its predecessor had fetched.)  A second scalar load in flight would
+    // not help -- lgkmcnt(0) waits for the youngest too -- but the vector memory path has its own counter: one never-waited-for load per
+    // 128-byte line, kVitPfAhead chunks ahead, pulls the line into the L2 the scalar cache misses into.  It is an LDS-DMA load
+    // (global_load_lds_dword: all lanes read the same dword, the 256 bytes land in a per-wave dump area nobody reads), because a load into
+    // a VGPR would write that register whenever it returns -- long after the allocator has handed it to something else.  The stream's
+    // owner allocates 4 KB of slack behind the last pair stream, so the look-ahead of the last pair stays inside the buffer.
+    constexpr int kPfPerRow = (2 * CW * 4) % 128 == 0 ? 1 : 2;                  // 3/4: a row is exactly one line; 1/2, 2/3: one per chunk touches every line
+    unsigned pf_off = (unsigned)kVitPfAhead * CW * 4u;
+    const unsigned pf_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)pf_dump);                        // LDS offset of the dump area (the low half of a flat LDS address)
+    auto prefetch_row = [&]() {
+        if (kVitPfAhead > 0) {
+#pragma unroll
+            for (int i = 0; i < kPfPerRow; i++)
+                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%3" : : "s"(pf_m0), "v"(pf_off), "s"(sp), "n"(i * CW * 4) : "m0");
+            pf_off += 2u * CW * 4u;
+        }
+    };
+    // Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0).  The load of chunk c+1 is therefore ISSUED
+    // right after the wait for chunk c (statement order: the assembly statements are volatile) and is covered by a whole chunk of ACS work.
     uint32_t c = 0;
-    Chunk cur = load_chunk(0, 0);
+    Chunk cur = load_chunk(0);
     while (tr < nsteps && !(A.done && B.done)) {
         // rows (2 chunks) that certainly need no look at the schedule: run them back to back, 9 rows out of 10
         const uint32_t lim = min(nsteps, next_thr - 1);
         for (uint32_t rows = lim > tr ? (lim - tr) / 24 : 0; rows > 0; rows--) {
-            Chunk nxt = load_chunk(c + 1, cur.v[0] & 1u);
+            prefetch_row();
+            wait_chunk(cur);
+            Chunk nxt = load_chunk(c + 1);
             fast_chunk(cur, 0);
-            cur = load_chunk(c + 2, nxt.v[0] & 1u);
+            wait_chunk(nxt);
+            cur = load_chunk(c + 2);
             fast_chunk(nxt, 1);
             c += 2;
             end_row();
         }
         if (!(tr < nsteps)) break;
-        Chunk nxt = load_chunk(c + 1, cur.v[0] & 1u);
+        prefetch_row();                                                         // (the slow rows keep the look-ahead in step)
+        wait_chunk(cur);
+        Chunk nxt = load_chunk(c + 1);
         chunk(cur, 0);
+        wait_chunk(nxt);                                                        // (also when the row ends early: no load is left in flight behind the loop)
         if (!(tr < nsteps && !(A.done && B.done))) break;
-        cur = load_chunk(c + 2, nxt.v[0] & 1u);
+        cur = load_chunk(c + 2);
         chunk(nxt, 1);
         c += 2;
         end_row();
     }
+    wait_chunk(cur);
 }
 
 // Four waves per 256-thread workgroup, two frames per wave (no cross-wave traffic).  One-wave workgroups were kept to
@@ -341,6 +387,7 @@ template <int WIN, int LOOK>
 __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
     __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];                // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
+    __shared__ uint32_t s_pfdump[4][64];                                         // where the look-ahead loads of the pair stream land (viterbi_forward); with it 40 KB: four workgroups per CU
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
     // wave -> (code-rate list, pair): list r has ceil(n_r / 2) pairs (njobs3 == nullptr: one list of njobs_single jobs)
     uint32_t n[3] = { njobs_single, 0, 0 };
@@ -362,9 +409,9 @@ __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ j
     const VitJob JA = load_job(fa);
     const bool hasB = fb < njobs;
     const VitJob JB = hasB ? load_job(fb) : JA;
-    if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK>(JA, JB, hasB, soft, out, ring);
-    else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK>(JA, JB, hasB, soft, out, ring);
-    else                        viterbi_forward<2, WIN, LOOK>(JA, JB, hasB, soft, out, ring);
+    if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK>(JA, JB, hasB, soft, out, ring, s_pfdump[threadIdx.x >> 6]);
+    else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK>(JA, JB, hasB, soft, out, ring, s_pfdump[threadIdx.x >> 6]);
+    else                        viterbi_forward<2, WIN, LOOK>(JA, JB, hasB, soft, out, ring, s_pfdump[threadIdx.x >> 6]);
 }
 
 __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)

@@ -1123,12 +1123,12 @@ static hipError_t pipe11n_create(sora_rx11n_t* rx, Pipe11n** out)
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_frames, 3 * sizeof(N11Frame) * rows);
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_jobs, 3 * sizeof(VitJob) * rows);
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_njobs, 16);
-        if (e == hipSuccess) e = hipMalloc((void**)&p->d_soft, (size_t)rx->cap_slots * kSoftPerSlot * 4 + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_soft, (size_t)rx->cap_slots * kSoftPerSlot * 4 + 4096 + 256);
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_vout, (size_t)rx->cap_slots * kOutPerSlot + 256);
         // every array starts out defined: the decoder reads its soft stream in 12-step chunks (the tail of a frame's last chunk is read, never used)
         if (e == hipSuccess) {
             (void)hipMemsetAsync(p->d_frames, 0, 3 * sizeof(N11Frame) * rows, p->stream); (void)hipMemsetAsync(p->d_jobs, 0, 3 * sizeof(VitJob) * rows, p->stream);
-            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot * 4 + 256, p->stream); (void)hipMemsetAsync(p->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
+            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot * 4 + 4096 + 256, p->stream); (void)hipMemsetAsync(p->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
         }
     }
     if (e == hipSuccess) { (void)hipMemsetAsync(p->d_rows, 0, sizeof(Rx11bRow) * rows, p->stream); (void)hipMemsetAsync(p->d_nframes, 0, 4 * (size_t)cfg->max_captures, p->stream); }

@@ -431,7 +431,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
     if (!rx->fused && !rx->d_soft) {                                             // the 16-bit soft stream and the job table exist only for the split path
-        HIPCHK(hipMalloc((void**)&rx->d_soft, 4 * (size_t)kSoftPerSlot * rx->cap_slots + 256));   // pair-stream operands: 4 bytes per soft value of the pair's longer frame
+        HIPCHK(hipMalloc((void**)&rx->d_soft, 4 * (size_t)kSoftPerSlot * rx->cap_slots + 4096 + 256));   // pair-stream operands: 4 bytes per soft value of the pair's longer frame; 4 KB of slack for the trellis kernel's look-ahead
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
     hipStream_t st = rx->stream;
@@ -995,7 +995,7 @@ int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_co
 // table.  sora_hip_viterbi11a keeps the original signature on top of a grow-only workspace cached per device.
 size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n)
 {
-    return ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255) + sizeof(VitJob) * n;
+    return ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255) + sizeof(VitJob) * n + 4096;   // (+ slack for the trellis kernel's look-ahead loads)
 }
 
 int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const uint32_t* d_soft_off, const uint32_t* d_nsoft, const uint16_t* d_frame_len,

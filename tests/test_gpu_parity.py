@@ -434,7 +434,7 @@ def test_frames_beyond_the_row_limit_are_counted_and_flagged(sora, torch_cuda, o
 def test_oversized_configuration_is_refused(sora):
     """A handle whose symbol-slot geometry would overflow the 32-bit offsets of the device tables is refused at creation."""
     with pytest.raises(sora.SoraError) as e:
-        sora.Rx(max_captures=16, max_total_samples=700_000_000, sample_rate_mhz=20)
+        sora.Rx(max_captures=16, max_total_samples=1_300_000_000, sample_rate_mhz=20)
     assert e.value.code == -6
 
 

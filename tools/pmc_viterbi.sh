@@ -8,7 +8,8 @@ ARGS="--no-cpu-baseline --no-extras --check 64 --steps 3 --warmup 1 --depth 1 --
 i=0
 for SET in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY" \
            "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_MISC SQ_INST_CYCLES_SALU SQ_THREAD_CYCLES_VALU" \
-           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_IFETCH SQ_WAIT_INST_LDS"; do
+           "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_IFETCH SQ_WAIT_INST_LDS" \
+           "GRBM_GUI_ACTIVE GRBM_COUNT"; do
   i=$((i+1))
   timeout 200 rocprofv3 --pmc $SET --output-format csv -d $OUT/${TAG}_sq$i -o p -- python $R/bench.py $ARGS > /dev/null 2> $OUT/${TAG}_sq$i.err
 done
@@ -23,4 +24,4 @@ out = {k: {c: round(sum(v) / len(v)) for c, v in d.items()} for k, d in acc.item
 json.dump(out, open("$OUT/${TAG}_sq_counters.json", "w"), indent=1)
 print(json.dumps(out.get("k_viterbi", {}), indent=1))
 PY
-rm -rf $OUT/${TAG}_sq1 $OUT/${TAG}_sq2 $OUT/${TAG}_sq3
+rm -rf $OUT/${TAG}_sq1 $OUT/${TAG}_sq2 $OUT/${TAG}_sq3 $OUT/${TAG}_sq4
