@@ -27,6 +27,11 @@ import os
 import sys
 import time
 
+# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): with the
+# default only three of the handle's pipelines run side by side whatever sora_rx_set_depth says (profiles/r03_e_timeline_*.txt).
+# An application setting, made before the runtime starts; the library itself reads no environment variable.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -507,6 +512,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the stage / ingest / tx / 11b / 11n sections")
     ap.add_argument("--depth", type=int, default=0, help="process calls in flight on the handle's internal pipelines (0 = library default)")
+    ap.add_argument("--trellis", type=int, default=-1, help="trellis kernel: 64 = k_viterbi, 16 = k_viterbi16, 0 = the library's choice from the depth (default: leave the handle as created)")
     ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
@@ -545,6 +551,10 @@ def main():
     if args.depth:
         rx.set_depth(args.depth)
     depth = rx.set_depth(0)
+    if args.trellis >= 0:
+        rx.set_trellis(args.trellis)
+    torch.cuda.synchronize()
+    rx.wait_for_producer = False                  # the inputs are resident in HBM from here on: no per-call wait for torch's stream
 
     def barrier():
         if world > 1:
@@ -571,22 +581,29 @@ def main():
     exp_bytes = exp_rows.tobytes()
     host_rows_ok = exp_n == len(res) and all(int(exp_rows[k]["crc32"]) == res[k]["crc32"] and int(exp_rows[k]["error_code"]) == res[k]["error_code"] for k in range(exp_n)) \
         and all(bytes(exp_mpdu[int(r["mpdu_offset"]):int(r["mpdu_offset"]) + int(r["length"])]) == res[k]["mpdu"] for k, r in enumerate(exp_rows) if int(r["error_code"]) == 1)
-    stats = {"delivered": 0, "bad": 0}
+    stats = {"delivered": 0, "bad": 0, "t_submit": 0.0, "t_wait": 0.0, "t_check": 0.0}
 
     def consume(tk):
+        ta = time.perf_counter()
         rx.wait(tk)
+        tb = time.perf_counter()
+        stats["t_wait"] += tb - ta
         b = bufs[tk % depth]
         stats["delivered"] += 1
         if int(b.nrows[0]) != exp_n or b.rows[:exp_n].tobytes() != exp_bytes:
             stats["bad"] += 1
+        stats["t_check"] += time.perf_counter() - tb
 
     def run_block(k, deliver, dep=None):
         dep = dep or depth                                          # calls in flight on the handle right now (<= len(bufs))
         first = None
         for _ in range(k):
+            ta = time.perf_counter()
             tk = rx.process_dev(d_iq, descs)
             if deliver:
                 rx.deliver_async(tk, bufs[tk % depth])
+            stats["t_submit"] += time.perf_counter() - ta
+            if deliver:
                 if first is None:
                     first = tk
                 if tk - first >= dep - 1:
@@ -606,12 +623,15 @@ def main():
     if world > 1:                                  # every rank runs the same number of blocks
         r_t = torch.tensor([repeats], device=dev, dtype=torch.int64); dist.all_reduce(r_t, op=dist.ReduceOp.MAX); repeats = int(r_t.item())
     barrier()
+    for k_ in ("t_submit", "t_wait", "t_check"):
+        stats[k_] = 0.0
     t0 = time.perf_counter()
     for _ in range(repeats):
         run_block(args.steps, deliver)
     rx.flush()
     barrier()
     t1 = time.perf_counter()
+    host_ms = {k_[2:]: round(1e3 * stats[k_] / (args.steps * repeats), 4) for k_ in ("t_submit", "t_wait", "t_check")}
     timed_steps = args.steps * repeats
     mpdu_ok = bool(deliver) and all((b.mpdu == exp_mpdu).all() for b in bufs)     # the last `depth` calls' MPDU arrays, byte for byte
     # the same K steps once more with HIP events around every kernel launch (on the streams the kernels run on): the
@@ -709,6 +729,7 @@ def main():
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
             "parity": {"against": kind, "captures_checked": len(idx), "ok": parity_ok, "host_rows_ok": host_rows_ok},
+            "host_ms_per_step": host_ms,
             "delivery": {"enabled": deliver, "calls_delivered_and_compared": tot_delivered, "calls_with_wrong_rows": tot_bad, "rows_per_call": exp_n,
                          "row_bytes_per_call": 36 * nfr * MAXF, "mpdu_bytes_per_call": int(exp_mpdu.size), "last_calls_mpdu_ok": mpdu_ok},
             # the reference's own figure of merit (MACStopwatch.h:84-128): cost / required time, < 1 = faster than real time

@@ -139,12 +139,25 @@ const char* sora_rx_kernel_name(size_t index);
 
 /* Consecutive process calls rotate over `depth` internal pipelines (own stream, own intermediate arrays), so the
  * latency-bound front end of one call overlaps the trellis kernel of the call before it -- what the reference gets from
- * running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120).  Default 3 (environment SORA_HIP_DEPTH), 1 = strictly
- * one call at a time, at most 4.  Returns the previous value; depth <= 0 only queries.  sora_rx_results / _results_dev /
+ * running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120).  Default 6, 1 = strictly
+ * one call at a time, at most 8.  (The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, one of them
+ * the null stream's: a host that wants more than three calls to actually run side by side sets that variable, as bench.py does.)  Returns the previous value; depth <= 0 only queries.  sora_rx_results / _results_dev /
  * _stream refer to the MOST RECENT process call, the *_of forms to the call whose ticket is given; sora_rx_flush waits for
  * every call in flight; an input buffer must stay untouched until the call that reads it has finished (as with any
  * asynchronous call). */
 int  sora_rx_set_depth(sora_rx_t* rx, int depth);
+
+/* Two trellis kernels decode the soft stream of the split data-field path, bit for bit the same T11aViterbi (viterbi.hpp:103-237):
+ *   64  k_viterbi    the 64 states of a frame pair in the 64 lanes of a wave: two frames per wave, the most waves -- the faster
+ *                    one while few frames are in flight (one 4096-frame call: 2048 waves for 1024 SIMDs);
+ *   16  k_viterbi16  a frame pair in 16 lanes x 4 registers, eight frames per wave: half the vector instructions per frame and
+ *                    no cross-row exchanges, but a quarter of the waves -- the faster one once several calls are in flight.
+ *   0   (default)    chosen by the library from the handle's depth.
+ * Returns the previous setting; a negative argument only queries. */
+int  sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair);
+/* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
+ * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
+int  sora_rx_set_graph(sora_rx_t* rx, int enable);
 
 /* Two implementations of the data field (T11aDataSymbol .. T11aViterbi) with identical results:
  *   0 (default)  k_frame (symbol chain, soft values to HBM as 16-bit fields) then k_viterbi (two frames per wave);
@@ -152,7 +165,7 @@ int  sora_rx_set_depth(sora_rx_t* rx, int depth);
  *                reference's RxThread feeds its ViterbiThread through TThreadSeparator (stdbrick.hpp:89-248) -- a quarter of
  *                the HBM traffic, the better choice for one call at a time; with several calls in flight the split form is
  *                faster because its kernels leave room for each other on the CUs.
- * Returns the previous value; enable < 0 only queries.  Environment SORA_HIP_FUSED sets the default of new handles.
+ * Returns the previous value; enable < 0 only queries.
  * sora_rx_kernel_name_fused(i) names the kernels of the fused chain for sora_rx_kernel_times ("" = slot not used). */
 int  sora_rx_set_fused(sora_rx_t* rx, int enable);
 const char* sora_rx_kernel_name_fused(size_t index);
@@ -202,7 +215,9 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
 size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n);
 int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const uint32_t* d_soft_off, const uint32_t* d_nsoft,
                            const uint16_t* d_frame_len, int code_rate, uint8_t* d_out, const uint32_t* d_out_off,
-                           size_t n, void* d_workspace, size_t workspace_bytes, void* stream);
+                           size_t n, void* d_workspace, size_t workspace_bytes, int lanes_per_pair, void* stream);
+/* lanes_per_pair: which of the two trellis kernels decodes (identical results): 64 (or 0) = k_viterbi, 16 = k_viterbi16 (see
+ * sora_rx_set_trellis). */
 
 /* Capture ingest in front of the receive graph, one streaming pass on the device:
  *   SORA_INGEST_RXBLOCK    the input is a Sora dump: 128-byte RX_BLOCKs = 16-byte descriptor + 28 COMPLEX16
@@ -304,6 +319,7 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
  * further calls have been made); an input buffer must stay untouched until the call that reads it has finished.  sora_rx11n_set_depth returns the
  * previous value (depth <= 0 only queries) and waits for the calls in flight; sora_rx11n_process (host buffers) also does. */
 int   sora_rx11n_set_depth(sora_rx11n_t* rx, int depth);
+int   sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair);                                     /* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
 int   sora_rx11n_ticket(sora_rx11n_t* rx);
 int   sora_rx11n_wait(sora_rx11n_t* rx, int ticket);
 int   sora_rx11n_results_of(sora_rx11n_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
@@ -335,6 +351,7 @@ uint32_t sora_ht40_symbols(uint32_t length0, uint32_t length1, uint32_t n_bpsc, 
 int   sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out);  /* max_soft_values >= sum over frames of 2 x nsym x 108 n_bpsc (+ 64 per frame) */
 void  sora_ht40_destroy(sora_ht40_t* rx);
 void* sora_ht40_stream(sora_ht40_t* rx);                                                               /* the stream of the most recent process call */
+int   sora_ht40_set_trellis(sora_ht40_t* rx, int lanes_per_pair);                                       /* 64 (default) / 16: as sora_rx_set_trellis (the two streams of a frame are one pair) */
 int   sora_ht40_synchronize(sora_ht40_t* rx);                                                          /* every call issued so far has finished (a handle keeps three calls in flight:
                                                                                                         * process_dev waits only for the call three calls back; results reports the most recent one) */
 int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);

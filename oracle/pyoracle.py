@@ -129,6 +129,11 @@ class Oracle:
         a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(frame_length + 64, np.uint8)
         n = self.L.so_viterbi_frame(_P(a), len(a), code_rate, frame_length, _P(o)); return o[:n]
 
+    def viterbi_frame_ex(self, soft, code_rate, frame_length, depth, lookahead):
+        """T11aViterbi with another window schedule (the 802.11n graph's 192 / 36)."""
+        a = np.ascontiguousarray(soft, np.uint8); o = np.zeros(frame_length + 64, np.uint8)
+        n = self.L.so_viterbi_frame_ex(_P(a), len(a), code_rate, frame_length, _P(o), depth, lookahead); return o[:n]
+
     def desc_sink(self, dec, frame_length):
         a = np.ascontiguousarray(dec, np.uint8); o = np.zeros(frame_length, np.uint8); crc = ctypes.c_uint32(0)
         e = self.L.so_desc_sink(_P(a), frame_length, _P(o), ctypes.byref(crc)); return e, o, crc.value

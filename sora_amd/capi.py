@@ -52,12 +52,12 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
-           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
+           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
-           "sora_rx11n_set_depth", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
-           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_process_dev", "sora_ht40_results",
+           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
+           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_results",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results"]
 
@@ -117,6 +117,10 @@ def load(build_if_missing=True):
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
     L.sora_rx_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_set_fused.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_set_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx11n_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_ht40_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_kernel_name_fused.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name_fused.restype = ctypes.c_char_p
     L.sora_ht40_symbols.argtypes = [ctypes.c_uint32] * 4; L.sora_ht40_symbols.restype = ctypes.c_uint32
     L.sora_ht40_create.argtypes = [ctypes.c_int, ctypes.c_uint32, ctypes.c_uint64, ctypes.POINTER(ctypes.c_void_p)]
@@ -146,7 +150,7 @@ def load(build_if_missing=True):
                                       ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_viterbi11a_workspace_bytes.argtypes = [ctypes.c_size_t, ctypes.c_size_t]; L.sora_hip_viterbi11a_workspace_bytes.restype = ctypes.c_size_t
     L.sora_hip_viterbi11a_ws.argtypes = [ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int,
-                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
+                                         ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
     L.sora_hip_stream_synchronize.argtypes = [ctypes.c_void_p]
     L.sora_hip_tx11a_samples.argtypes = [ctypes.c_uint32, ctypes.c_uint32]; L.sora_hip_tx11a_samples.restype = ctypes.c_size_t
     L.sora_hip_tx11a.argtypes = [ctypes.c_void_p] * 5 + [ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
@@ -220,6 +224,12 @@ class Rx:
         h = ctypes.c_void_p()
         _check(L.sora_rx_create(ctypes.byref(cfg), ctypes.byref(h)))
         self._h = h; self._L = L; self.cfg = cfg; self._keep = None
+        self.wait_for_producer = True      # process_dev first waits for torch's current stream (bench.py turns it off: its inputs are resident)
+        # harness-side overrides (the library itself reads no environment variable): A/B runs of the tools and tests
+        if os.environ.get("SORA_HIP_DEPTH"): self.set_depth(int(os.environ["SORA_HIP_DEPTH"]))
+        if os.environ.get("SORA_HIP_FUSED"): self.set_fused(int(os.environ["SORA_HIP_FUSED"]))
+        if os.environ.get("SORA_HIP_GRAPH"): self.set_graph(int(os.environ["SORA_HIP_GRAPH"]))
+        if os.environ.get("SORA_HIP_TRELLIS"): self.set_trellis(int(os.environ["SORA_HIP_TRELLIS"]))
 
     def close(self):
         if self._h:
@@ -260,7 +270,7 @@ class Rx:
     def process_dev(self, d_iq, captures):
         """d_iq: int16 torch CUDA tensor [N,2] (resident in HBM); captures: [(offset, nsamples[, id])]."""
         arr, ptr = self._caps(captures)
-        self._keep = d_iq
+        _hold(self, d_iq)
         _check(self._L.sora_rx_process_dev(self._h, _dev_ptr(d_iq), ptr, len(arr)))
         return self._L.sora_rx_ticket(self._h)
 
@@ -309,8 +319,17 @@ class Rx:
         _check(self._L.sora_rx_set_profiling(self._h, 1 if enable else 0))
 
     def set_depth(self, depth=0):
-        """number of process calls kept in flight on internal pipelines (1..4); returns the previous value"""
+        """number of process calls kept in flight on internal pipelines (1..8); returns the previous value"""
         return int(self._L.sora_rx_set_depth(self._h, int(depth)))
+
+    def set_trellis(self, lanes_per_pair=-1):
+        """64: k_viterbi, 16: k_viterbi16, 0: the library chooses from the depth; returns the previous setting"""
+        r = int(self._L.sora_rx_set_trellis(self._h, int(lanes_per_pair)))
+        if r < 0: _check(r)
+        return r
+
+    def set_graph(self, enable=-1):
+        return int(self._L.sora_rx_set_graph(self._h, int(enable)))
 
     def set_fused(self, enable=-1):
         """1: decode the data field with the fused kernel (k_decode), 0: k_frame + k_viterbi; returns the previous setting"""
@@ -416,7 +435,7 @@ class Rx11b:
 
     def process_dev(self, d_iq, captures):
         arr, ptr = Rx._caps(captures)
-        self._keep = d_iq
+        _hold(self, d_iq)
         _check(self._L.sora_rx11b_process_dev(self._h, _dev_ptr(d_iq), ptr, len(arr)))
 
     def process(self, h_iq, captures):
@@ -470,12 +489,17 @@ class Rx11n:
         if r < 0: _check(r)
         return r
 
+    def set_trellis(self, lanes_per_pair=-1):
+        r = int(self._L.sora_rx11n_set_trellis(self._h, int(lanes_per_pair)))
+        if r < 0: _check(r)
+        return r
+
     def wait(self, ticket):
         _check(self._L.sora_rx11n_wait(self._h, int(ticket)))
 
     def process_dev(self, d_iq0, d_iq1, captures):
         arr, ptr = Rx._caps(captures)
-        self._keep = (d_iq0, d_iq1)
+        _hold(self, (d_iq0, d_iq1))
         _check(self._L.sora_rx11n_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), ptr, len(arr)))
         return self._L.sora_rx11n_ticket(self._h)
 
@@ -536,9 +560,14 @@ class RxHt40:
         arr._n = len(descs)
         return arr
 
+    def set_trellis(self, lanes_per_pair=-1):
+        r = int(self._L.sora_ht40_set_trellis(self._h, int(lanes_per_pair)))
+        if r < 0: _check(r)
+        return r
+
     def process_dev(self, d_iq0, d_iq1, descs, d_weights=None):
         arr = self.frames(descs); n = getattr(arr, "_n", len(arr))
-        self._keep = (d_iq0, d_iq1, d_weights); self._n = n
+        _hold(self, (d_iq0, d_iq1, d_weights)); self._n = n
         _check(self._L.sora_ht40_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), arr, n, _dev_ptr(d_weights) if d_weights is not None else None))
 
     def results(self, with_mpdu=True):
@@ -561,6 +590,19 @@ def ht40_symbols(length0, length1, n_bpsc, code_rate):
 
 
 # ---- per-stage entry points on torch CUDA tensors ---------------------------------------------------
+def _hold(obj, item, sync=True):
+    """The handles keep several calls in flight on their own non-blocking streams: (i) the inputs of the last 8 calls stay referenced
+    (torch's caching allocator must not hand a block to the next tensor while a kernel still reads it), (ii) whatever produced the
+    tensors on torch's current stream has finished before the library's stream reads them."""
+    import collections
+    if getattr(obj, "_keep", None) is None:
+        obj._keep = collections.deque(maxlen=8)
+    obj._keep.append(item)
+    if sync and getattr(obj, "wait_for_producer", True):
+        import torch
+        torch.cuda.current_stream().synchronize()
+
+
 def _stream_ptr(stream):
     if stream is None:
         import torch
@@ -735,7 +777,7 @@ def viterbi11a_workspace_bytes(soft_span_bytes, n):
     return int(load().sora_hip_viterbi11a_workspace_bytes(int(soft_span_bytes), int(n)))
 
 
-def viterbi11a_ws(soft, soft_off, nsoft, frame_len, code_rate, workspace, out=None, out_off=None, out_stride=2560, stream=None):
+def viterbi11a_ws(soft, soft_off, nsoft, frame_len, code_rate, workspace, out=None, out_off=None, out_stride=2560, lanes_per_pair=0, stream=None):
     """The Viterbi brick out of a caller-owned workspace (uint8 CUDA tensor of >= viterbi11a_workspace_bytes(soft.numel(), n)):
     no allocation and no host wait inside the call; the caller synchronises the stream before reading `out`."""
     import torch
@@ -744,7 +786,7 @@ def viterbi11a_ws(soft, soft_off, nsoft, frame_len, code_rate, workspace, out=No
         out = torch.zeros((n, out_stride), dtype=torch.uint8, device=soft.device)
         out_off = (torch.arange(n, device=soft.device, dtype=torch.int32) * out_stride).contiguous()
     _check(load().sora_hip_viterbi11a_ws(_dev_ptr(soft), soft.numel(), _dev_ptr(soft_off), _dev_ptr(nsoft), _dev_ptr(frame_len), code_rate,
-                                         _dev_ptr(out), _dev_ptr(out_off), n, _dev_ptr(workspace), workspace.numel(), _stream_ptr(stream)))
+                                         _dev_ptr(out), _dev_ptr(out_off), n, _dev_ptr(workspace), workspace.numel(), int(lanes_per_pair), _stream_ptr(stream)))
     return out
 
 

@@ -274,6 +274,7 @@ struct sora_ht40 {
     int device = 0; uint32_t max_frames = 0; uint64_t max_soft = 0;
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
     Ht40Slot slot[kHt40Slots]; int next = 0, last = 0; bool have_results = false;
+    int lanes16 = 0;            // trellis kernel: 0 = k_viterbi11n (64 lanes per stream pair), 1 = k_viterbi16_11n (sora_ht40_set_trellis)
 };
 
 #define HIPCHK40(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -331,6 +332,15 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
 
 void  sora_ht40_destroy(sora_ht40_t* rx) { if (rx) { (void)hipSetDevice(rx->device); ht40_free(rx); } }
 void* sora_ht40_stream(sora_ht40_t* rx) { return rx ? (void*)rx->slot[rx->last].stream : nullptr; }         // the stream of the most recent call
+int sora_ht40_set_trellis(sora_ht40_t* rx, int lanes_per_pair)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_set_trellis: null handle", 0);
+    const int old = rx->lanes16 ? 16 : 64;
+    if (lanes_per_pair == 16 || lanes_per_pair == 64) rx->lanes16 = lanes_per_pair == 16;
+    else if (lanes_per_pair >= 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_set_trellis: 16 or 64 lanes per stream pair", 0);
+    return old;
+}
+
 int sora_ht40_synchronize(sora_ht40_t* rx)
 {
     if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_synchronize: null handle", 0);
@@ -380,7 +390,10 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
     A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights);
     hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, S.stream, A);
     const uint32_t njobs = 2 * (uint32_t)nframes;
-    hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint32_t*)S.d_soft, S.d_vout);
+    if (rx->lanes16)
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((njobs + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint32_t*)S.d_soft, S.d_vout);
+    else
+        hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint32_t*)S.d_soft, S.d_vout);
     Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T;
     hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());

@@ -1021,7 +1021,11 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     Rx11bArgs A;
     A.iq = reinterpret_cast<const uint32_t*>(d_iq); A.caps = S.d_caps; A.ncaps = (uint32_t)ncaps; A.thr = rx->cfg.cca_pwr_threshold;
     A.max_frames = rx->cfg.max_frames_per_capture; A.rows = S.d_rows; A.nframes = S.d_nframes; A.mpdu = S.d_mpdu; A.crc = rx->d_crc; A.needs_cck = S.d_needs_cck;
-    static const bool one_kernel = []() { const char* e = getenv("SORA_HIP_11B_ONE_KERNEL"); return e && atoi(e) != 0; }();    // experiment: every capture through the CCK instantiation
+#ifdef SORA_VARIANT_11B_ONE_KERNEL                                             // build variant (sora_amd.build.build_variant): every capture through the CCK instantiation
+    constexpr bool one_kernel = true;
+#else
+    constexpr bool one_kernel = false;
+#endif
     HIPCHK11(hipMemsetAsync(S.d_needs_cck, one_kernel ? 1 : 0, 4 * ncaps, S.stream));
     if (!one_kernel) hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);
     hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)

@@ -87,6 +87,7 @@ __device__ __forceinline__ int scan_add(int v, int)                    // inclus
 }
 }  // namespace
 
+#ifdef SORA_VARIANT_11N_MONO            // build variant only (sora_amd.build.build_variant("mono11n", ["SORA_VARIANT_11N_MONO"])): the round-1 one-kernel form, an A/B partner
 __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
 {
     __shared__ WaveLds s_w[4];
@@ -569,6 +570,7 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
     }
     if (lane == 0) A.nframes[cap] = nfr;
 }
+#endif
 
 
 // ================================================================================================================================
@@ -1085,8 +1087,13 @@ struct sora_rx11n {
     sora_rx_cfg cfg{};
     sora_complex16* d_iq_own[2] = { nullptr, nullptr };
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
-    // the staged chain (k_scan11n -> k_frame11n -> k_viterbi11n -> k_finish11n); SORA_HIP_11N_MONO=1 selects the one-kernel form instead
-    bool mono = false;
+    // the staged chain (k_scan11n -> k_frame11n -> k_viterbi11n -> k_finish11n); the build variant SORA_VARIANT_11N_MONO runs the one-kernel form instead
+#ifdef SORA_VARIANT_11N_MONO
+    static constexpr bool mono = true;
+#else
+    static constexpr bool mono = false;
+#endif
+    int lanes16 = 0;             // trellis kernel: 0 = k_viterbi11n (64 lanes per frame pair), 1 = k_viterbi16_11n (sora_rx11n_set_trellis)
     uint64_t cap_slots = 0;
     Pipe11n* pipes[4] = { nullptr, nullptr, nullptr, nullptr };
     int depth = 1, cur = 0, next_ticket = 0; bool started = false;
@@ -1149,7 +1156,6 @@ int sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out)
     sora_rx11n_t* rx = new sora_rx11n();
     rx->cfg = *cfg;
     if (!(sora_internal_tables(cfg->device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: tables", 0); }
-    { const char* m = getenv("SORA_HIP_11N_MONO"); rx->mono = m && m[0] == '1'; }
     if (!rx->mono) {
         // symbol slots: 80 samples at 20 MHz each, + 4 per capture (the decoder's padded last burst and its chunked reads may reach past the last symbol)
         rx->cap_slots = cfg->max_total_samples / 2 / 80 + 4 * (uint64_t)cfg->max_captures + 4;
@@ -1174,9 +1180,20 @@ int sora_rx11n_set_depth(sora_rx11n_t* rx, int depth)
     for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
     for (int i = 0; i < depth; i++)
         if (!rx->pipes[i]) { const hipError_t e = pipe11n_create(rx, &rx->pipes[i]); if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_set_depth: device allocation", (int)e); }
+    // a shrink keeps the most recent call addressable: its pipeline moves into the surviving range (the tickets of the pipelines that
+    // fall outside it become stale, as the header says)
+    if (rx->cur >= depth) { std::swap(rx->pipes[0], rx->pipes[rx->cur]); rx->cur = 0; }
     rx->depth = depth;
-    if (rx->cur >= depth) rx->cur = 0;
     return prev;
+}
+
+int sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_trellis: null handle", 0);
+    const int old = rx->lanes16 ? 16 : 64;
+    if (lanes_per_pair == 16 || lanes_per_pair == 64) rx->lanes16 = lanes_per_pair == 16;
+    else if (lanes_per_pair >= 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_trellis: 16 or 64 lanes per frame pair", 0);
+    return old;
 }
 
 static Pipe11n* pipe11n_of(sora_rx11n_t* rx, int ticket)
@@ -1220,11 +1237,11 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     Rx11nArgs A;
     A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.caps = P->d_caps; A.ncaps = (uint32_t)ncaps;
     A.max_frames = rx->cfg.max_frames_per_capture; A.rows = P->d_rows; A.nframes = P->d_nframes; A.mpdu = P->d_mpdu; A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan;
-    if (rx->mono) {
-        hipLaunchKernelGGL(k_rx11n_mono, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, P->stream, A);
-        HIPCHK11N(hipGetLastError());
-        return SORA_OK;
-    }
+#ifdef SORA_VARIANT_11N_MONO
+    hipLaunchKernelGGL(k_rx11n_mono, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, P->stream, A);
+    HIPCHK11N(hipGetLastError());
+    return SORA_OK;
+#endif
     const uint32_t nrows = (uint32_t)ncaps * rx->cfg.max_frames_per_capture;
     HIPCHK11N(hipMemsetAsync(P->d_njobs, 0, 16, P->stream));
     Scan11nArgs S;
@@ -1235,7 +1252,10 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     F.iq0 = A.iq0; F.iq1 = A.iq1; F.caps = P->d_caps; F.frames = P->d_frames; F.njobs = P->d_njobs; F.nrows = nrows; F.T = rx->T; F.sincos = rx->sincos; F.atan = rx->atan;
     F.soft = P->d_soft; F.jobs = P->d_jobs; F.vout = P->d_vout; F.rows = P->d_rows; F.mpdu = P->d_mpdu;
     hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
-    hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint32_t*)P->d_soft, P->d_vout);
+    if (rx->lanes16)
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((nrows + 7) / 8 + 2), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint32_t*)P->d_soft, P->d_vout);
+    else
+        hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint32_t*)P->d_soft, P->d_vout);
     hipLaunchKernelGGL(k_finish11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
     HIPCHK11N(hipGetLastError());
     return SORA_OK;

@@ -267,6 +267,7 @@ struct RxPipe {
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
     uint32_t* d_soft = nullptr; VitJob* d_jobs = nullptr;       // split decode path only (allocated on its first use)
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
+    int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip)
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
@@ -361,8 +362,6 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     e = hipHostMalloc((void**)&rx->h_caps_pinned, sizeof(CapDesc) * cfg->max_captures, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&rx->ev_caps, hipEventDisableTiming);
     if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "pinned descriptor buffer", e); }
-    if (const char* g = getenv("SORA_HIP_GRAPH")) rx->use_graph = atoi(g) != 0;
-    if (const char* g = getenv("SORA_HIP_FUSED")) rx->fused = atoi(g) != 0;
     const uint64_t n20 = cfg->max_total_samples / rx->str;
     // Symbol slots, frame rows and the byte offsets derived from them are 32-bit on the device: a configuration that would
     // wrap them is refused here instead of decoding garbage later.
@@ -474,7 +473,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             R.soft = rx->d_soft; R.jobs = rx->d_jobs;
             hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
-            hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint32_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
+            if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
+                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint32_t*)rx->d_soft, rx->d_vout);
+            else
+                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint32_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
         }
         hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
@@ -617,10 +619,13 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
 // front end of one call (k_scan) overlaps the issue-bound decode kernel of the call before it -- the overlap
 // the reference gets from running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120, TThreadSeparator
 // stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
+constexpr int kAutoLanes16Depth = 4;                            // depth from which the automatic choice is k_viterbi16 (profiles/r03_d_ab_trellis.txt: it wins from four calls in flight)
 struct sora_rx {
-    static constexpr int kMaxDepth = 4;
+    static constexpr int kMaxDepth = 8;
     sora_rx_cfg cfg{};
-    int depth = 3;
+    int depth = 6;
+    int trellis = 0;             // sora_rx_set_trellis: 0 = chosen from the depth, 64 / 16 = lanes per frame pair
+    bool use_graph = false;
     int cur = 0;                 // pipeline of the most recent process call
     bool started = false;
     bool profiling = false;
@@ -640,7 +645,7 @@ static RxPipe* pipe_at(sora_rx* rx, int i)
 {
     if (!rx->pipes[i]) {
         if (pipe_create(&rx->cfg, &rx->pipes[i]) != SORA_OK) return nullptr;
-        rx->pipes[i]->fused = rx->fused;
+        rx->pipes[i]->fused = rx->fused; rx->pipes[i]->use_graph = rx->use_graph;
         if (rx->profiling) (void)pipe_set_profiling(rx->pipes[i], 1);
     }
     return rx->pipes[i];
@@ -656,7 +661,6 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     if (rc != SORA_OK) return rc;
     sora_rx* rx = new sora_rx();
     rx->cfg = *cfg; rx->pipes[0] = p0; rx->fused = p0->fused;
-    if (const char* env = getenv("SORA_HIP_DEPTH")) rx->depth = std::max(1, std::min((int)sora_rx::kMaxDepth, atoi(env)));
     *out = rx;
     return SORA_OK;
 }
@@ -676,6 +680,29 @@ int sora_rx_set_fused(sora_rx_t* rx, int enable)
         rx->fused = enable != 0;
         for (RxPipe* p : rx->pipes) if (p) { p->fused = rx->fused; p->last_valid = false; }      // (a recorded hipGraph holds the other kernel chain)
     }
+    return old;
+}
+
+// Which trellis kernel a call uses: k_viterbi16 pays off once enough frames are in flight to give every SIMD a wave of it (it packs
+// eight frames into a wave, k_viterbi two); see DESIGN.md section 3.1.
+static int lanes16_for(const sora_rx* rx) { return rx->trellis == 16 ? 1 : rx->trellis == 64 ? 0 : (rx->depth >= kAutoLanes16Depth ? 1 : 0); }
+
+int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->trellis;
+    if (lanes_per_pair == 0 || lanes_per_pair == 16 || lanes_per_pair == 64) {
+        rx->trellis = lanes_per_pair;
+        for (RxPipe* p : rx->pipes) if (p) p->last_valid = false;               // (a recorded hipGraph holds the other kernel)
+    } else if (lanes_per_pair > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_trellis: 0 (automatic), 16 or 64 lanes per frame pair");
+    return old;
+}
+
+int sora_rx_set_graph(sora_rx_t* rx, int enable)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->use_graph ? 1 : 0;
+    if (enable >= 0) { rx->use_graph = enable != 0; for (RxPipe* p : rx->pipes) if (p) { p->use_graph = rx->use_graph; p->last_valid = false; } }
     return old;
 }
 
@@ -709,6 +736,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
+    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -720,6 +748,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
+    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -999,11 +1028,12 @@ size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n)
 }
 
 int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const uint32_t* d_soft_off, const uint32_t* d_nsoft, const uint16_t* d_frame_len,
-                           int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* d_workspace, size_t workspace_bytes, void* stream)
+                           int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* d_workspace, size_t workspace_bytes, int lanes_per_pair, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
     if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: bad argument");
     if (n == 0) return SORA_OK;
+    if (lanes_per_pair != 0 && lanes_per_pair != 16 && lanes_per_pair != 64) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a_ws: lanes_per_pair is 0 (default: 64), 16 or 64");
     if (!d_workspace || ((uintptr_t)d_workspace & 15)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a_ws: the workspace must be a 16-byte aligned device buffer");
     if (workspace_bytes < sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a_ws: workspace smaller than sora_hip_viterbi11a_workspace_bytes()");
     if (soft_span_bytes >= (1ull << 32) || n >= (1ull << 31)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
@@ -1011,7 +1041,10 @@ int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const 
     uint32_t* pair = (uint32_t*)d_workspace;
     VitJob* jobs = (VitJob*)((uint8_t*)d_workspace + ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255));
     hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, d_frame_len, d_out_off, code_rate, (uint32_t)n, (uint32_t)soft_span_bytes, pair, jobs);
-    hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint32_t*)pair, d_out);
+    if (lanes_per_pair == 16)
+        hipLaunchKernelGGL(k_viterbi16, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint32_t*)pair, d_out);
+    else
+        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint32_t*)pair, d_out);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
@@ -1050,7 +1083,7 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
         HIPCHK(hipMalloc(&W.p, need + need / 4));
         W.bytes = need + need / 4;
     }
-    const int rc = sora_hip_viterbi11a_ws(d_soft, (size_t)span, d_soft_off, d_nsoft, d_frame_len, code_rate, d_out, d_out_off, n, W.p, W.bytes, stream);
+    const int rc = sora_hip_viterbi11a_ws(d_soft, (size_t)span, d_soft_off, d_nsoft, d_frame_len, code_rate, d_out, d_out_off, n, W.p, W.bytes, 0, stream);
     if (rc != SORA_OK) return rc;
     HIPCHK(hipStreamSynchronize(st));                                             // the cached workspace is free for the next call when this one returns
     return SORA_OK;

@@ -10,7 +10,7 @@ from test_oracle_11n_graph import golden_captures
 pytestmark = pytest.mark.gpu
 
 
-def run_batch(caps, max_frames=8):
+def run_batch(caps, max_frames=8, trellis=None):
     import torch
     import sora_amd
     n = sum(len(a) for a, _ in caps)
@@ -19,6 +19,8 @@ def run_batch(caps, max_frames=8):
     for i, (a, _) in enumerate(caps):
         descs.append((off, len(a), i)); off += len(a)
     rx = sora_amd.Rx11n(len(caps), n, max_frames_per_capture=max_frames)
+    if trellis is not None:
+        rx.set_trellis(trellis)
     rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), descs)
     per = [[] for _ in caps]
     for r in rx.results():
@@ -144,10 +146,12 @@ def test_gpu_equals_the_live_reference_graph():
     assert nev > 320 and kinds.get(1, 0) > 100 and kinds.get(0x80000005, 0) > 50, kinds
 
 
-def test_staged_chain_equals_the_one_kernel_form(monkeypatch):
-    """The default chain (k_scan11n -> k_frame11n -> k_viterbi11n -> k_finish11n) and the one-wave-per-capture kernel of round 1
-    (SORA_HIP_11N_MONO=1, kept for A/B runs) report the same rows and MPDUs, frames cut by the end of the capture included."""
+def test_both_trellis_kernels_decode_the_11n_graph_alike():
+    """sora_rx11n_set_trellis: k_viterbi11n (64 lanes per frame pair) and k_viterbi16_11n (16 lanes per pair, eight frames per wave), both
+    with the 192 / 36 window of T11aViterbi<5000*8, 312, 192, 36>, report the same rows and MPDUs -- frames cut by the end of the capture
+    (zero-padded decoder input) included -- and those are the oracle's."""
     import sora_amd
+    from oracle.pyoracle import Oracle
     if sora_amd.device_count() <= 0:
         pytest.skip("no HIP device")
     z = np.load(__import__("test_oracle_11n_graph").GOLD)
@@ -157,13 +161,15 @@ def test_staged_chain_equals_the_one_kernel_form(monkeypatch):
     for t in range(300):
         fr = [frames[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 5)))]
         caps.append(capture_11n(rng, fr, sigma=float(rng.choice([5, 60, 600, 1500])), cut=float(rng.uniform(0.05, 1.0)) if t % 2 else None))
-    staged = run_batch(caps)
-    monkeypatch.setenv("SORA_HIP_11N_MONO", "1")
-    mono = run_batch(caps)
+    a = run_batch(caps, trellis=64)
+    b = run_batch(caps, trellis=16)
     key = lambda e: (e["error_code"], e["end_sample"], e["rate_kbps"], e["length"], e["crc32"], e["mpdu"])
-    assert sum(len(x) for x in staged) > 300
+    assert sum(len(x) for x in a) > 300
+    o = Oracle()
     for i in range(len(caps)):
-        assert [key(e) for e in staged[i]] == [key(e) for e in mono[i]], i
+        assert [key(e) for e in a[i]] == [key(e) for e in b[i]], i
+        if i % 10 == 0:
+            assert [key(e) for e in b[i]] == [key(e) for e in o.rx11n_capture(*caps[i])], i
 
 
 @pytest.mark.parametrize("depth", [1, 2, 3])

@@ -43,10 +43,12 @@ def comp0(x):
     return ((x.astype(np.int64) * 32767) >> 15).astype(np.int16)
 
 
-def run(env, iq, descs, want_w=False):
+def run(env, iq, descs, want_w=False, trellis=None):
     torch, sora = env
     nsoft = sum(2 * (sora.ht40_symbols(d[3], d[4], d[1], d[2]) * 108 * d[1] + 64) for d in descs)
     rx = sora.RxHt40(len(descs), nsoft)
+    if trellis is not None:
+        rx.set_trellis(trellis)
     w = torch.zeros((len(descs), 4, 128, 2), dtype=torch.int16, device="cuda") if want_w else None
     rx.process_dev(torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda(), descs, w)
     res = rx.results(); rx.close()
@@ -73,6 +75,19 @@ def test_loopback_with_carrier_offset_and_mixed_batch(env):
     res, _ = run(env, iq, descs)
     ok = sum(r["error_code"] == 1 and r["mpdu"] == psdus[r["capture_id"]][r["stream"]] for r in res)
     assert ok == 2 * len(specs), ok
+
+
+def test_both_trellis_kernels_decode_the_streams_alike(env):
+    """sora_ht40_set_trellis(16): the two streams of a frame as one pair in 16 lanes x 4 registers (k_viterbi16_11n), four frames per wave --
+    same rows and PSDUs as the 64-lane kernel, on a mixed batch that includes frames too noisy to decode."""
+    rng = np.random.default_rng(8)
+    specs = [(int(rng.choice([1, 2, 4, 6])), int(rng.choice([0, 1, 2])), int(rng.integers(20, 900)), int(rng.integers(20, 900))) for _ in range(37)]
+    iq, descs, psdus = make_frames(rng, specs, sigma=14.0, cfo_step=-21.0)
+    a, _ = run(env, iq, descs, trellis=64)
+    b, _ = run(env, iq, descs, trellis=16)
+    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["length"], r["crc32"], r["mpdu"])
+    assert [key(r) for r in a] == [key(r) for r in b]
+    assert sum(r["error_code"] == 1 for r in a) > len(specs)
 
 
 def test_calls_in_flight_keep_their_results_apart(env):

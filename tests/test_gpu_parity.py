@@ -27,12 +27,14 @@ def sora():
     return sora_amd
 
 
-def run_rx(sora, torch, caps, rate_mhz, max_frames=4, fused=None):
+def run_rx(sora, torch, caps, rate_mhz, max_frames=4, fused=None, trellis=None):
     iq, descs = batch(caps)
     rx = sora.Rx(max_captures=max(1, len(caps)), max_total_samples=max(64, len(iq)), sample_rate_mhz=rate_mhz,
                  max_frames_per_capture=max_frames)
     if fused is not None:
         rx.set_fused(fused)
+    if trellis is not None:
+        rx.set_trellis(trellis)
     d = torch.from_numpy(iq).cuda()
     rx.process_dev(d, descs)
     res = rx.results()
@@ -105,6 +107,13 @@ def test_viterbi_bit_exact_on_noise(sora, torch_cuda, oracle, cr):
         o2 = o2.cpu().numpy()
         for i, L in enumerate(lens[:n]):
             assert np.array_equal(o2[i, :L + 2], out[i, :L + 2]), ("workspace", cr, L, n)
+        # ... and through the other trellis kernel (k_viterbi16: a frame pair in 16 lanes x 4 registers, eight frames per wave): job counts
+        # that leave rows of its last wave empty or half-filled
+        o3 = sora.viterbi11a_ws(d_buf, *args, cr, ws, lanes_per_pair=16)
+        torch.cuda.synchronize()
+        o3 = o3.cpu().numpy()
+        for i, L in enumerate(lens[:n]):
+            assert np.array_equal(o3[i, :L + 2], out[i, :L + 2]), ("16 lanes per pair", cr, L, n)
 
 
 # ------------------------------------------------------------------ whole path
@@ -519,6 +528,57 @@ def test_fused_decode_kernel_full_batch_equals_the_reference_graph(sora, torch_c
     assert rx.set_fused(1) == 0 and rx.set_fused(-1) == 1
     d = torch_cuda.from_numpy(iq).cuda(); dd = sora.Rx.captures(descs)
     tickets = [rx.process_dev(d, dd) for _ in range(3)]              # three calls in flight on the fused path
+    kind, want = bench.reference_rows(iq, nfr, oracle)
+    for t in tickets:
+        ok, why = bench.check_against_reference(rx.results(ticket=t), kind, want, range(nfr))
+        assert ok, why
+    rx.close()
+
+
+# ------------------------------------------------------------------ the 16-lanes-per-pair trellis kernel (k_viterbi16)
+def test_trellis16_equals_the_oracle_on_random_captures(sora, torch_cuda, oracle):
+    """sora_rx_set_trellis(16): eight frames per wave, the coset layout of k_vit16.hip.  Same rows as the oracle on random captures:
+    all rates (frames of different modulation and length share a wave), noise up to failure, several frames per capture, truncation."""
+    from gpu_util import random_capture
+    rng = np.random.default_rng(20261003)
+    for mhz in (20, 40):
+        caps = [random_capture(oracle, rng, mhz) for _ in range(200)]
+        want = oracle_results(oracle, caps, mhz)
+        ok, why = same_results(run_rx(sora, torch_cuda, caps, mhz, max_frames=8, trellis=16), want)
+        assert ok, (mhz, why)
+
+
+def test_trellis16_on_lengths_rates_and_partly_filled_waves(sora, torch_cuda, oracle):
+    """Every rate at lengths around the window schedule's corners; list sizes 1..9 per code rate (rows of the last wave empty, a
+    pair without its second frame), frames of very different length sharing a wave."""
+    caps = []
+    for i, rate in enumerate(RATES):
+        for j, ln in enumerate((1, 5, 29, 30, 31, 33, 100, 257, 1024, 1500, 2304)[: 3 + (i % 5) * 2]):
+            caps.append(make_capture(oracle, rate, ln, seed=3100 + 20 * i + j, rate_mhz=20, sigma=60 + 15 * j, tail=160)[0])
+    want = oracle_results(oracle, caps, 20)
+    ok, why = same_results(run_rx(sora, torch_cuda, caps, 20, max_frames=2, trellis=16), want)
+    assert ok, why
+    for n in (1, 2, 3, 7, 8, 9):
+        ok, why = same_results(run_rx(sora, torch_cuda, caps[:n], 20, max_frames=2, trellis=16), oracle_results(oracle, caps[:n], 20))
+        assert ok, (n, why)
+
+
+def test_trellis16_full_batch_equals_the_reference_graph(sora, torch_cuda, oracle):
+    """The bench workload (BASELINE configs[2], 4096 x 1500 B at 54 Mbps) through k_viterbi16 with four calls in flight, every capture of
+    every call against the compiled reference graph."""
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+    import bench
+    from oracle.pyoracle import ReferenceGraph
+    if not ReferenceGraph().available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    nfr = bench.FRAMES_PER_GPU
+    iq, descs, _ = bench.make_workload(oracle, nfr, seed0=0)
+    rx = sora.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+    rx.set_depth(4)
+    assert rx.set_trellis(16) == 0 and rx.set_trellis(-1) == 16
+    d = torch_cuda.from_numpy(iq).cuda(); dd = sora.Rx.captures(descs)
+    tickets = [rx.process_dev(d, dd) for _ in range(4)]
     kind, want = bench.reference_rows(iq, nfr, oracle)
     for t in tickets:
         ok, why = bench.check_against_reference(rx.results(ticket=t), kind, want, range(nfr))
