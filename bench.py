@@ -646,15 +646,25 @@ def main():
     t3 = time.perf_counter()
     ktimes = rx.kernel_times()
     rx.set_profiling(False)
-    # and with ONE call in flight: each kernel alone on the chip (the per-kernel roofline without the CU sharing of overlapped calls)
-    rx.set_depth(1); rx.flush()
-    rx.set_profiling(True)
-    for _ in range(max(10, args.steps // 2)):
-        rx.process_dev(d_iq, descs)
-    rx.flush()
-    ktimes1 = rx.kernel_times()
-    rx.set_profiling(False)
-    rx.set_depth(depth)
+    # and with ONE call in flight: each kernel alone on the chip (the per-kernel roofline without the CU sharing of overlapped calls).
+    # The trellis kernel is pinned to the one the timed region used (left to itself the library picks k_viterbi for a single call in
+    # flight and k_viterbi16 from depth 4); the other one is measured alone as well, for the record.
+    lanes = rx.trellis(); trellis_setting = rx.set_trellis(-1)
+    tname = {64: "k_viterbi", 16: "k_viterbi16"}
+
+    def alone(l):
+        rx.set_trellis(l); rx.set_depth(1); rx.flush()
+        rx.set_profiling(True)
+        for _ in range(max(10, args.steps // 2)):
+            rx.process_dev(d_iq, descs)
+        rx.flush()
+        kt = rx.kernel_times()
+        rx.set_profiling(False)
+        return {(tname[l] if k == "k_viterbi" else k): v for k, v in kt.items()}
+    ktimes1 = alone(lanes)
+    ktimes1_other = alone(80 - lanes)
+    ktimes = {(tname[lanes] if k == "k_viterbi" else k): v for k, v in ktimes.items()}
+    rx.set_trellis(trellis_setting); rx.set_depth(depth)
 
     # ---- the other implementation of the data field: k_decode (symbol and trellis waves in one kernel, soft values in LDS)
     fused = None
@@ -722,7 +732,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_profiled": round((t3 - t2) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 IQ / u8 path metrics", "data": "synthetic",
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
-                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth,
+                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth, "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
                        "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait/compare of the oldest call in flight" % (repeats, args.steps)
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
@@ -740,6 +750,9 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes1[dom], 4),
                          "kernel_ms_note": "mean launch duration with ONE call in flight (the kernel alone on the chip); with %d calls overlapped the same launch lasts %.4f ms (frac %.5f) because it shares the CUs" % (depth, ktimes[dom], ach / HBM_PEAK),
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
+                         "other_trellis_kernel": {"kernel": tname[80 - lanes], "kernel_ms": round(ktimes1_other[tname[80 - lanes]], 4),
+                                                  "frac": round(launch_bytes / (ktimes1_other[tname[80 - lanes]] * 1e-3) / HBM_PEAK, 5),
+                                                  "note": "sora_rx_set_trellis: k_viterbi = two frames per wave (the faster one for a call alone on the chip), k_viterbi16 = eight per wave (the faster one from four calls in flight; the automatic choice follows the depth)"},
                          "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},

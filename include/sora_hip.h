@@ -155,6 +155,7 @@ int  sora_rx_set_depth(sora_rx_t* rx, int depth);
  *   0   (default)    chosen by the library from the handle's depth.
  * Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair);
+int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process call will use: 64 or 16 (resolves the automatic choice: 16 from depth 4) */
 /* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);

@@ -595,20 +595,21 @@ static int pipe_results_dev(RxPipe* rx, const sora_frame_result** d_rows, const 
 }
 
 // Result delivery without a host wait: pack, then copy rows / count / MPDU array behind the call's kernels on its own stream.
+// (Measured and dropped in round 3: ONE kernel writing the three ranges into the mapped host buffers itself instead of three copies --
+// no blit launches, no ~50 us of queue idle time between them -- made the step 19 % slower, 0.53 -> 0.63 ms: waves stalled on PCIe
+// writes hold CU slots the other calls' kernels need.  profiles/r03_j_deliver_kernel.txt.)
 static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_nrows, uint8_t* h_mpdu, size_t mpdu_bytes)
 {
     if (!rx || !h_rows || !h_nrows) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_deliver_async: null argument");
     if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
+    const size_t need = (size_t)kOutPerSlot * rx->total_slots;
+    if (h_mpdu && mpdu_bytes < need) return fail(SORA_ERR_CAPACITY, "sora_rx_deliver_async: h_mpdu is smaller than sora_rx_mpdu_bytes()");   // (checked before anything is enqueued)
     HIPCHK(hipSetDevice(rx->cfg.device));
     { const int rc = pipe_pack(rx); if (rc) return rc; }
     const size_t nr = std::min<size_t>(max_rows, (size_t)rx->ncaps * rx->cfg.max_frames_per_capture);
     HIPCHK(hipMemcpyAsync(h_nrows, rx->d_nrows, 4, hipMemcpyDeviceToHost, rx->stream));
     if (nr) HIPCHK(hipMemcpyAsync(h_rows, rx->d_rows, sizeof(sora_frame_result) * nr, hipMemcpyDeviceToHost, rx->stream));
-    if (h_mpdu) {
-        const size_t need = (size_t)kOutPerSlot * rx->total_slots;
-        if (mpdu_bytes < need) return fail(SORA_ERR_CAPACITY, "sora_rx_deliver_async: h_mpdu is smaller than sora_rx_mpdu_bytes()");
-        if (need) HIPCHK(hipMemcpyAsync(h_mpdu, rx->d_mpdu, need, hipMemcpyDeviceToHost, rx->stream));
-    }
+    if (h_mpdu && need) HIPCHK(hipMemcpyAsync(h_mpdu, rx->d_mpdu, need, hipMemcpyDeviceToHost, rx->stream));
     return SORA_OK;
 }
 
@@ -697,6 +698,8 @@ int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
     } else if (lanes_per_pair > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_trellis: 0 (automatic), 16 or 64 lanes per frame pair");
     return old;
 }
+
+int sora_rx_trellis(sora_rx_t* rx) { return rx ? (lanes16_for(rx) ? 16 : 64) : SORA_ERR_INVALID_PARAM; }
 
 int sora_rx_set_graph(sora_rx_t* rx, int enable)
 {

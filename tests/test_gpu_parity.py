@@ -242,7 +242,8 @@ def test_calls_in_flight(sora, torch_cuda, oracle, depth):
         iq, d = batch(caps)
         sets.append((torch_cuda.from_numpy(iq).cuda(), d, oracle_results(oracle, caps, 20)))
     rx = sora.Rx(max_captures=8, max_total_samples=max(len(t) for t, _, _ in sets), sample_rate_mhz=20, max_frames_per_capture=2)
-    assert rx.set_depth(depth) == 3 and rx.set_depth(0) == depth
+    assert rx.set_depth(depth) == 6 and rx.set_depth(0) == depth
+    assert rx.trellis() == (16 if depth >= 4 else 64)                 # the automatic choice of the trellis kernel follows the depth
     for k in range(9):
         t, d, want = sets[k % 3]
         rx.process_dev(t, d)
@@ -576,7 +577,8 @@ def test_trellis16_full_batch_equals_the_reference_graph(sora, torch_cuda, oracl
     iq, descs, _ = bench.make_workload(oracle, nfr, seed0=0)
     rx = sora.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
     rx.set_depth(4)
-    assert rx.set_trellis(16) == 0 and rx.set_trellis(-1) == 16
+    rx.set_trellis(16)
+    assert rx.set_trellis(-1) == 16 and rx.trellis() == 16
     d = torch_cuda.from_numpy(iq).cuda(); dd = sora.Rx.captures(descs)
     tickets = [rx.process_dev(d, dd) for _ in range(4)]
     kind, want = bench.reference_rows(iq, nfr, oracle)
