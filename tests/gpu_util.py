@@ -34,7 +34,28 @@ def make_capture(oracle, rate_kbps, length, seed, rate_mhz=40, sigma=0.0, lead=0
 _RATES = (6000, 9000, 12000, 18000, 24000, 36000, 48000, 54000)
 
 
-def random_capture(o, rng, mhz):
+def multipath(x, rng, deep=False, rate_mhz=40):
+    """A frequency-selective channel (SURVEY section 8d iv): 2-4 taps, the echoes 1-8 samples @20 MHz behind the direct path, 3-12 dB
+    down, random phase; deep=True: one echo as strong as the direct path (within 1 dB) -- spectral nulls in which the truncating
+    per-carrier division of T11aLTS::_channel_estimation meets divisors near (and at) zero (channel_11a.hpp:125-178).
+    x: [n,2] at rate_mhz -> float64 [n,2] (not yet rounded)."""
+    z = np.asarray(x, np.float64); z = z[:, 0] + 1j * z[:, 1]
+    step = 2 if rate_mhz == 40 else 1
+    y = z.copy()
+    ntap = int(rng.integers(1, 4))
+    for k in range(ntap):
+        d = int(rng.integers(1, 9)) * step
+        if deep and k == 0:
+            g = 10 ** (-rng.uniform(0, 1) / 20)
+        else:
+            g = 10 ** (-rng.uniform(3, 12) / 20)
+        y[d:] += g * np.exp(2j * np.pi * rng.random()) * z[:-d]
+    y *= 1.0 / np.sqrt(1 + 0.3 * ntap)                                       # keep the level about where it was
+    return np.stack([y.real, y.imag], 1)
+
+
+def random_capture(o, rng, mhz, multipath_p=0.0):
+    """multipath_p: probability of a frequency-selective channel (0 keeps the random stream the recorded fixtures were made with)"""
     kind = rng.integers(0, 10)
     parts = []
     if kind == 0:                                                        # noise only, sometimes loud enough to trip carrier sense
@@ -54,12 +75,35 @@ def random_capture(o, rng, mhz):
         z = (x[:, 0].astype(np.float64) + 1j * x[:, 1]) * np.exp(2j * np.pi * f * np.arange(len(x)) / 40e6)
         x = np.stack([np.rint(z.real), np.rint(z.imag)], 1)
     x = x.astype(np.float64)
+    if multipath_p and rng.random() < multipath_p:                        # frequency-selective channel, one in four with a deep null
+        x = multipath(x, rng, deep=rng.random() < 0.25)
     if rng.random() < 0.3:                                               # DC offset (TDCRemoveEx / TDCEstimator path)
         x += rng.uniform(-600, 600, size=(1, 2))
     if rng.random() < 0.2:                                               # gain
         x *= rng.uniform(0.25, 1.6)
     x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
     sigma = float(rng.choice([0, 0, 60, 150, 400, 900, 2000]))
+    if sigma:
+        x = awgn(x, sigma, int(rng.integers(1 << 30)))
+    if mhz == 20:
+        x = x[::2].copy()
+    return pad_capture(x, mhz)
+
+
+def multipath_capture(o, rng, mhz, deep=None):
+    """One or two frames through a multipath channel (always), then CFO / noise as in random_capture."""
+    parts = []
+    for _ in range(int(rng.choice([1, 1, 2]))):
+        rate = int(rng.choice(_RATES)); L = int(rng.choice([20, 60, 150, 400, 900, 1500]))
+        mp = rng.integers(0, 256, L).astype(np.uint8).tobytes()
+        parts.append(o.tx_capture(mp, rate, seed=int(rng.integers(1, 128)), lead=int(rng.integers(0, 120)), tail=int(rng.choice([160, 200, 400]))))
+    x = multipath(np.concatenate(parts), rng, deep=(rng.random() < 0.4) if deep is None else deep)
+    if rng.random() < 0.3:
+        f = rng.uniform(-60e3, 60e3)
+        z = (x[:, 0] + 1j * x[:, 1]) * np.exp(2j * np.pi * f * np.arange(len(x)) / 40e6)
+        x = np.stack([z.real, z.imag], 1)
+    x = np.clip(np.rint(x), -32768, 32767).astype(np.int16)
+    sigma = float(rng.choice([0, 30, 60, 150, 400]))
     if sigma:
         x = awgn(x, sigma, int(rng.integers(1 << 30)))
     if mhz == 20:
@@ -144,7 +188,7 @@ def same_as_reference_graph(rows, ref_events, position=None):
     return True, ""
 
 
-def random_capture_11b(graph, rng):
+def random_capture_11b(graph, rng, multipath_p=0.0):
     """A random 44 MHz capture for the 802.11b receive graph: 1-3 frames of the REFERENCE's own modulator (1, 2, 5.5 or 11 Mbps,
     long preamble; graph = oracle.pyoracle.ReferenceGraph) with gaps, gain, DC offset, a small carrier offset, noise,
     sometimes truncated, sometimes noise only."""
@@ -163,6 +207,8 @@ def random_capture_11b(graph, rng):
     x = np.concatenate(parts).astype(np.float64)
     if kind == 1:
         x = x[:int(len(x) * rng.uniform(0.3, 0.95))]
+    if multipath_p and rng.random() < multipath_p:                           # echoes up to two chips behind the direct path (8 samples @44 MHz)
+        x = multipath(x, rng, deep=rng.random() < 0.25, rate_mhz=44)
     if rng.random() < 0.3:
         f = rng.uniform(-20e3, 20e3)
         z = (x[:, 0] + 1j * x[:, 1]) * np.exp(2j * np.pi * f * np.arange(len(x)) / 44e6)
@@ -240,7 +286,7 @@ def htsig_cases(seed, n):
     return np.stack(out)
 
 
-def capture_11n(rng, frames, sigma=20.0, cut=None):
+def capture_11n(rng, frames, sigma=20.0, cut=None, multipath_p=0.0):
     """Two-chain 40 MHz capture (int16 [n,2] each, n a multiple of 28) from `frames` = [(s0, s1)] transmit waveforms of the two TX
     chains: per frame a random gap, gain, per-chain phase, cross-talk and CFO; white noise on top; `cut` (0..1) truncates the last frame."""
     segs0, segs1 = [], []
@@ -248,7 +294,16 @@ def capture_11n(rng, frames, sigma=20.0, cut=None):
         gap = int(rng.integers(200, 1500)); x = float(rng.choice([0.0, 0.1, 0.3])); gain = float(rng.choice([0.3, 1.0, 2.0]))
         ph = np.exp(1j * rng.uniform(0, 2 * np.pi, 2)); cfo = rng.uniform(-3e-4, 3e-4)
         c0 = s0[:, 0] + 1j * s0[:, 1]; c1 = s1[:, 0] + 1j * s1[:, 1]; k = np.arange(len(c0))
-        r0 = gain * (ph[0] * c0 + x * c1) * np.exp(1j * cfo * k); r1 = gain * (ph[1] * c1 + x * c0) * np.exp(1j * cfo * k)
+        if multipath_p and rng.random() < multipath_p:                       # a 2x2 matrix of frequency-selective channels: every TX -> RX path its own echoes
+            def path(c, direct):
+                y = direct * c
+                for _ in range(int(rng.integers(1, 4))):
+                    d = int(rng.integers(1, 9)) * 2; g = 10 ** (-rng.uniform(3, 14) / 20) * abs(direct if direct else 0.3)
+                    y[d:] += g * np.exp(2j * np.pi * rng.random()) * c[:-d]
+                return y
+            r0 = gain * (path(c0, ph[0]) + path(c1, x)) * np.exp(1j * cfo * k); r1 = gain * (path(c1, ph[1]) + path(c0, x)) * np.exp(1j * cfo * k)
+        else:
+            r0 = gain * (ph[0] * c0 + x * c1) * np.exp(1j * cfo * k); r1 = gain * (ph[1] * c1 + x * c0) * np.exp(1j * cfo * k)
         if cut is not None and i == len(frames) - 1:
             r0 = r0[:int(len(r0) * cut)]; r1 = r1[:len(r0)]
         segs0 += [np.zeros(gap, complex), r0]; segs1 += [np.zeros(gap, complex), r1]

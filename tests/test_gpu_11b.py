@@ -55,6 +55,25 @@ def test_gpu_11b_equals_recorded_reference_events(sora, oracle, fixture):
     assert k == len(z["ev_error"])
 
 
+def test_gpu_11b_equals_the_reference_graph_under_multipath(sora, oracle):
+    """Echoes up to two chips behind the direct path on every capture (a quarter with an echo within 1 dB of it): 500 captures, every
+    event of the compiled reference graph against the GPU graph (1 / 2 / 5.5 / 11 Mbps)."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present (the captures come from the reference's modulator)")
+    rng = np.random.default_rng(1212)
+    caps = [random_capture_11b(g, rng, multipath_p=1.0) for _ in range(500)]
+    got = run_11b(sora, caps, max_frames=64)
+    nev = nok = 0
+    for i, c in enumerate(caps):
+        ev = g.rx11b(c, max_frames=64)
+        ok, why = same_as_reference_11b([r for r in got if r["capture_id"] == i], ev)
+        assert ok, "capture %d vs the reference graph: %s" % (i, why)
+        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev)
+    assert nev > 800 and nok > 150, (nev, nok)
+
+
 def test_gpu_11b_equals_reference_graph_and_oracle_on_random_captures(sora, oracle):
     from oracle.pyoracle import ReferenceGraph
     g = ReferenceGraph()

@@ -146,6 +146,33 @@ def test_gpu_equals_the_live_reference_graph():
     assert nev > 320 and kinds.get(1, 0) > 100 and kinds.get(0x80000005, 0) > 50, kinds
 
 
+def test_gpu_11n_equals_the_oracle_under_a_2x2_multipath_channel():
+    """500 two-chain captures through a 2x2 matrix of frequency-selective channels (every TX -> RX path its own echoes): TMimoChannelEst's
+    float per-carrier inverse on unequal and ill-conditioned carriers (channel_11n.hpp:423-433), the pilot tracker behind it.  Rows and
+    MPDUs equal the oracle's (which tests/test_oracle_11n_graph.py pins to the compiled reference graph on the same kind of captures)."""
+    import sora_amd
+    from oracle.pyoracle import Oracle
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    o = Oracle()
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rng = np.random.default_rng(79)
+    caps = []
+    for t in range(500):
+        fr = [frames[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 3)))]
+        caps.append(capture_11n(rng, fr, sigma=float(rng.choice([5, 20, 60, 200])), multipath_p=1.0))
+    got = run_batch(caps)
+    nev = nok = 0
+    for i, (a, b) in enumerate(caps):
+        want = o.rx11n_capture(a, b)
+        ok, why = same_events_11n(got[i], want)
+        assert ok, (i, why)
+        assert [e["end_sample"] for e in got[i]] == [e["end_sample"] for e in want], i
+        nev += len(want); nok += sum(e["error_code"] == 1 for e in want)
+    assert nev > 500 and nok > 150, (nev, nok)
+
+
 def test_both_trellis_kernels_decode_the_11n_graph_alike():
     """sora_rx11n_set_trellis: k_viterbi11n (64 lanes per frame pair) and k_viterbi16_11n (16 lanes per pair, eight frames per wave), both
     with the 192 / 36 window of T11aViterbi<5000*8, 312, 192, 36>, report the same rows and MPDUs -- frames cut by the end of the capture

@@ -306,7 +306,7 @@ def test_randomised_captures_match_the_oracle(sora, torch_cuda, oracle):
     from gpu_util import random_capture
     rng = np.random.default_rng(20260925)
     for mhz in (20, 40):
-        caps = [random_capture(oracle, rng, mhz) for _ in range(150)]
+        caps = [random_capture(oracle, rng, mhz, multipath_p=0.3) for _ in range(150)]
         got = run_rx(sora, torch_cuda, caps, mhz, max_frames=8)
         ok, why = same_results(got, oracle_results(oracle, caps, mhz))
         assert ok, (mhz, why)
@@ -333,6 +333,37 @@ def test_gpu_equals_the_reference_graph(sora, torch_cuda, oracle):
         assert ok, "capture %d: %s" % (i, why)
         nev += len(ev)
     assert nev > 300
+
+
+@pytest.mark.parametrize("trellis", [64, 16])
+def test_multipath_captures_equal_the_reference_graph(sora, torch_cuda, oracle, trellis):
+    """frequency-selective channels on the headline path.  600 captures through 2-4 tap channels (echoes 1-8
+    samples @20 MHz behind the direct path, 3-12 dB down, random phase), two in five with an echo within 1 dB of the direct path: deep
+    nulls, where T11aLTS::_channel_estimation's truncating division by |Y_k|^2 >> 8 meets small divisors and, at zero, writes a zero
+    coefficient (channel_11a.hpp:144-151) -- k_scan does the same.  Every event against the compiled reference graph; both trellis kernels."""
+    from gpu_util import multipath_capture, same_as_reference_graph
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present")
+    rng = np.random.default_rng(20261005 + trellis)
+    caps = [multipath_capture(oracle, rng, 40) for _ in range(600)]
+    got = run_rx(sora, torch_cuda, caps, 40, max_frames=8, trellis=trellis)
+    per = [[] for _ in caps]
+    for r in got:
+        per[r["capture_id"]].append(r)
+    kinds = {}
+    for i, c in enumerate(caps):
+        ev = g.rx11a(c)
+        ok, why = same_as_reference_graph(per[i], ev)
+        assert ok, "capture %d: %s" % (i, why)
+        for e in ev:
+            kinds[e["error_code"]] = kinds.get(e["error_code"], 0) + 1
+    assert kinds.get(0x1, 0) > 200 and kinds.get(0x80000006, 0) > 30, kinds    # decoded frames and frames the channel broke
+    # the same captures as 20 MHz input (the even samples): what the oracle reports on them
+    caps20 = [pad_capture(c[::2].copy(), 20) for c in caps[:200]]
+    ok, why = same_results(run_rx(sora, torch_cuda, caps20, 20, max_frames=8, trellis=trellis), oracle_results(oracle, caps20, 20))
+    assert ok, why
 
 
 def test_20mhz_mode_equals_the_reference_graph_on_the_40mhz_stream(sora, torch_cuda, oracle):

@@ -44,6 +44,23 @@ def test_oracle_11b_equals_reference_graph_on_random_captures(o, seed):
     assert nev > 1000 and nok > 300 and ncck > 100
 
 
+def test_oracle_11b_equals_reference_graph_under_multipath(o):
+    """Echoes up to two chips behind the direct path (a quarter of them within 1 dB of it) on every capture: Barker despreading, the
+    timing recurrence and the CCK correlators on smeared chips.  Every event against the compiled reference graph."""
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not built (needs the reference tree)")
+    rng = np.random.default_rng(23)
+    nev = nok = 0
+    for i in range(300):
+        c = random_capture_11b(g, rng, multipath_p=1.0)
+        ev = g.rx11b(c)
+        ok, why = same_as_reference_11b(o.rx11b_capture(c), ev)
+        assert ok, "capture %d: %s" % (i, why)
+        nev += len(ev); nok += sum(e["error_code"] == 1 for e in ev)
+    assert nev > 500 and nok > 100
+
+
 @pytest.mark.parametrize("fixture", ["refgraph_11b.npz", "refgraph_11b_cck.npz"])
 def test_oracle_11b_equals_recorded_reference_events(o, fixture):
     z = np.load(os.path.join(GOLD, fixture))

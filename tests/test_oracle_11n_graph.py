@@ -65,3 +65,26 @@ def test_oracle_equals_reference_graph_live(o):
         n4 = len(a) // 2 // 4 * 4; skip = int(rng.integers(0, 500))
         assert o.cca11n(a[::2][:n4], b[::2][:n4], skip) == g.cca11n(a[::2][:n4], b[::2][:n4], skip)
     assert nev > 40
+
+
+def test_oracle_equals_reference_graph_under_multipath(o):
+    """A 2x2 matrix of frequency-selective channels (every TX -> RX path its own 1-3 echoes, 1-8 samples @20 MHz behind its direct tap):
+    the per-carrier 2x2 inverse of TMimoChannelEst (channel_11n.hpp:423-433: float, determinant / 65536 as the divisor) on unequal,
+    partly ill-conditioned carriers.  Every event of the compiled reference graph against the restatement."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not built (needs the reference tree)")
+    rng = np.random.default_rng(31)
+    nev = nok = 0
+    for t in range(60):
+        frames = []
+        for _ in range(int(rng.integers(1, 3))):
+            mcs = int(rng.choice([8, 9, 10, 10, 9, 8])); ln = int(rng.integers(1, 400))
+            frames.append(g.tx11n(rng.integers(0, 256, ln).astype(np.uint8).tobytes(), mcs))
+        a, b = capture_11n(rng, frames, sigma=float(rng.choice([5, 20, 60])), multipath_p=1.0)
+        want = g.rx11n(a, b); got = o.rx11n_capture(a, b)
+        ok, why = same_events_11n(got, want, position="sample_index")
+        assert ok, (t, why)
+        nev += len(want); nok += sum(e["error_code"] == 1 for e in want)
+    assert nev > 60 and nok > 20, (nev, nok)

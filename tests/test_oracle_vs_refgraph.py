@@ -11,7 +11,7 @@ import os
 import numpy as np
 import pytest
 
-from gpu_util import random_capture, same_as_reference_graph, source_position, source_position_44, upsample_40_to_44
+from gpu_util import multipath_capture, random_capture, same_as_reference_graph, source_position, source_position_44, upsample_40_to_44
 from oracle.pyoracle import Oracle, ReferenceGraph
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
@@ -46,12 +46,30 @@ def test_oracle_equals_reference_graph_on_random_captures(o, graph, seed):
     rng = np.random.default_rng(seed)
     nframes = 0
     for i in range(250):
-        cap = random_capture(o, rng, 40)
+        cap = random_capture(o, rng, 40, multipath_p=0.3)
         ev = graph.rx11a(cap)
         ok, why = same_as_reference_graph(o.rx_capture(cap, 40), ev)
         assert ok, "seed %d capture %d: %s" % (seed, i, why)
         nframes += len(ev)
     assert nframes > 150
+
+
+def test_oracle_equals_reference_graph_under_multipath(o, graph):
+    """frequency-selective channels -- 2-4 taps, echoes 1-8 samples behind the direct path, a deep-null case in
+    two of five (an echo within 1 dB of the direct path).  T11aLTS::_channel_estimation divides per carrier by |Y_k|^2 >> 8 with C
+    truncation and writes a ZERO coefficient where that divisor is zero (channel_11a.hpp:144-151: `if (e[j] != 0) ... else 0`); the
+    restatement does the same (so_rx11a.c), and so does k_scan.  600 captures, every event compared."""
+    rng = np.random.default_rng(20261005)
+    nev = 0; kinds = {}
+    for i in range(600):
+        cap = multipath_capture(o, rng, 40)
+        ev = graph.rx11a(cap)
+        ok, why = same_as_reference_graph(o.rx_capture(cap, 40), ev)
+        assert ok, "capture %d: %s" % (i, why)
+        nev += len(ev)
+        for e in ev:
+            kinds[e["error_code"]] = kinds.get(e["error_code"], 0) + 1
+    assert nev > 600 and kinds.get(0x1, 0) > 200 and kinds.get(0x80000006, 0) > 30, kinds     # decoded frames AND frames the channel broke
 
 
 def test_the_two_thread_harness_reports_the_same_events(o, graph):
