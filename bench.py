@@ -70,6 +70,43 @@ def measured_valu(kernel=None):
         return None
 
 
+def workload_payload(seed0, i, nframes, distinct=512):
+    """MPDU (without FCS) of capture i of make_workload(.., nframes, seed0): what any rank can recompute about any other rank's batch"""
+    rng = np.random.default_rng(0x5EED0000 + seed0 + i % min(distinct, nframes))
+    return rng.integers(0, 256, MPDU_LEN - 4).astype(np.uint8).tobytes()
+
+
+def exchange_results(torch, rx, d_iq, descs, dev, nfr, maxf):
+    """The multi-GPU path's one exchange step, on an initialised process group: one more call, then RCCL all-gathers of
+    {rows, MPDU bytes} per rank, the device-packed result rows and the dense MPDU blocks (sora_amd.shard.gather_mpdus) -- every MPDU of
+    every rank reaches every host (fb11a_demod.cpp:64-70 for a sharded batch) -- and a check of every gathered MPDU against the payload
+    its rank transmitted (rank r's batch comes from seed0 = r * 100003, so any rank can recompute it)."""
+    from sora_amd.shard import gather_mpdus
+    rx.process_dev(d_iq, descs)
+    rows, nrows, mpdu_ptr = rx.results_dev()
+    rx.flush()
+
+    class _Arr:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2}
+    mpdu_dev = torch.as_tensor(_Arr(mpdu_ptr, rx.mpdu_bytes(rx.ticket())), device=dev)
+    tg0 = time.perf_counter()
+    allrows, allmp, per_rank = gather_mpdus(rows, int(nrows.item()), mpdu_dev, max_rows_per_rank=nfr * maxf, max_bytes_per_rank=nfr * maxf * MPDU_LEN)
+    torch.cuda.synchronize()
+    tg1 = time.perf_counter()
+    ar = allrows.cpu().numpy().view(np.uint32); am = allmp.cpu().numpy()
+    okm = 0; k = 0
+    for rr, cnt in enumerate(per_rank):                                  # rank rr's rows: its captures were made from seed0 = rr * 100003
+        for w in ar[k:k + cnt]:
+            if int(w[3]) == 1:
+                o_, ln = int(w[8]), int(w[5] & 0xFFFF)
+                okm += bytes(am[o_:o_ + ln - 4]) == workload_payload(rr * 100003, int(w[0]), nfr)
+        k += cnt
+    return {"rows": int(allrows.shape[0]), "rows_per_rank": per_rank, "mpdu_bytes": int(am.size), "mpdus_equal_to_the_transmitted_payloads": int(okm),
+            "exchange_ms": round((tg1 - tg0) * 1e3, 3),
+            "bytes_per_rank": {"counts": 8, "rows": 36 * nfr * maxf, "mpdu_block": nfr * maxf * MPDU_LEN}}
+
+
 def make_workload(oracle, nframes, seed0, distinct=512):
     """-> (iq int16 [nframes*CAPTURE_SAMPLES, 2], descs, payloads)"""
     from gpu_util import pad_capture
@@ -704,15 +741,13 @@ def main():
         elapsed = float(t.item())
 
     counters = torch.tensor([len(res), n_ok, n_payload_ok, stats["delivered"], stats["bad"]], device=dev, dtype=torch.int64)
-    gathered_rows = None
+    gathered_rows = None; gathered = None
     if world > 1:
-        # the path's one exchange step: RCCL all-gather of the device-packed result rows + all-reduce of counters
-        from sora_amd.shard import gather_rows
-        rx.process_dev(d_iq, descs)
-        rows, nrows, _ = rx.results_dev()
-        rx.flush()
-        allrows, per_rank = gather_rows(rows, int(nrows.item()), max_rows_per_rank=nfr * 2)
-        gathered_rows = int(allrows.shape[0])
+        # the path's one exchange step: RCCL all-gathers of the device-packed result rows AND the MPDUs (every MPDU
+        # reaches the one host buffer, fb11a_demod.cpp:64-70) + all-reduce of counters.  Per rank and exchange: 8 bytes of counts,
+        # 36 bytes x 2 x captures of rows, MPDU_LEN x captures of MPDU bytes.
+        gathered = exchange_results(torch, rx, d_iq, descs, dev, nfr, MAXF)
+        gathered_rows = gathered["rows"]
         dist.all_reduce(counters)
     tot_frames, tot_ok, tot_payload_ok, tot_delivered, tot_bad = [int(v) for v in counters.tolist()]
 
@@ -737,7 +772,7 @@ def main():
                        "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait/compare of the oldest call in flight" % (repeats, args.steps)
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
-            "frames": tot_frames, "gathered_rows": gathered_rows, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
+            "frames": tot_frames, "gathered_rows": gathered_rows, "gathered": gathered, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
             "parity": {"against": kind, "captures_checked": len(idx), "ok": parity_ok, "host_rows_ok": host_rows_ok},
             "host_ms_per_step": host_ms,
             "delivery": {"enabled": deliver, "calls_delivered_and_compared": tot_delivered, "calls_with_wrong_rows": tot_bad, "rows_per_call": exp_n,

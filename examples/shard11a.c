@@ -1,8 +1,8 @@
 /* shard11a.c -- a plain-C multi-GPU host for libsora_hip.so: BASELINE config 5 ("N concurrent 20/40 MHz captures sharded across the
  * GPUs of one node") without Python.  One process per GPU; every process loads the same dump, takes its block of the `--captures N`
  * copies of it (sora_shard_partition: captures are the shard, fb11ademod_config.hpp:68-95 -- no state crosses captures), runs the
- * receive path on its own GPU and joins the others in ONE exchange, the gather of the result rows (sora_shard_gather_results =
- * ncclAllGather over RCCL/xGMI).  Rank 0 creates the RCCL id and leaves it in --id-file; the others wait for the file.
+ * receive path on its own GPU and joins the others in ONE exchange, the gather of the result rows and MPDUs
+ * (sora_shard_gather_results_mpdu = three ncclAllGather over RCCL/xGMI: counts, rows, dense MPDU blocks).  Rank 0 creates the RCCL id and leaves it in --id-file; the others wait for the file.
  * Build: gcc -std=c11 -Iinclude examples/shard11a.c -Lsora_amd/lib -lsora_hip -Wl,-rpath,$PWD/sora_amd/lib -o shard11a
  * Usage: for r in 0..W-1:  shard11a <file.dmp> [--raw14] [--rate 40|20] --captures N --world W --rank r --id-file /tmp/sora.id &
  *        (device = rank; one node)
@@ -94,20 +94,28 @@ int main(int argc, char** argv)
     const size_t per_rank = ((ncap_total + (size_t)world - 1) / (size_t)world) * max_frames;
     sora_frame_result* all = (sora_frame_result*)calloc(per_rank * (size_t)world, sizeof(*all));
     uint32_t* counts = (uint32_t*)calloc((size_t)world, sizeof(uint32_t));
-    size_t total = 0;
-    if (sora_shard_gather_results(sh, rx, 0, per_rank, all, counts, &total) != SORA_OK) DIE("sora_shard_gather_results");
+    size_t total = 0, mpdu_total = 0;
+    const size_t mpdu_per_rank = per_rank * 2504;                                      /* rows x the longest MPDU the 802.11a graph accepts */
+    uint8_t* mpdus = (uint8_t*)malloc(mpdu_per_rank * (size_t)world);
+    if (!mpdus) DIE("host memory");
+    if (sora_shard_gather_results_mpdu(sh, rx, 0, per_rank, all, counts, &total, mpdu_per_rank, mpdus, &mpdu_total) != SORA_OK) DIE("sora_shard_gather_results_mpdu");
     if (rank == 0) {
         size_t good = 0;
-        for (size_t i = 0; i < total; i++) good += all[i].error_code == SORA_E_FRAME_OK;
+        uint32_t fnv = 2166136261u;                                                     /* over every gathered MPDU byte, in row order */
+        for (size_t i = 0; i < total; i++) {
+            good += all[i].error_code == SORA_E_FRAME_OK;
+            if (all[i].error_code == SORA_E_FRAME_OK || all[i].error_code == SORA_E_CRC32_FAIL)
+                for (uint32_t k = 0; k < all[i].length; k++) fnv = (fnv ^ mpdus[all[i].mpdu_offset + k]) * 16777619u;
+        }
         printf("world %d: %zu captures, %zu frames gathered (", world, ncap_total, total);
         for (int r = 0; r < world; r++) printf("%s%u", r ? " + " : "", counts[r]);
-        printf("), good %zu / bad %zu; first: capture %u %u kbps length %u FCS %08x, last: capture %u\n", good, total - good,
+        printf("), good %zu / bad %zu; first: capture %u %u kbps length %u FCS %08x, last: capture %u; %zu MPDU bytes gathered, fnv1a %08x\n", good, total - good,
                total ? all[0].capture_id : 0, total ? all[0].rate_kbps : 0, total ? all[0].length : 0, total ? all[0].crc32 : 0,
-               total ? all[total - 1].capture_id : 0);
+               total ? all[total - 1].capture_id : 0, mpdu_total, fnv);
     }
     sora_rx_destroy(rx); sora_shard_destroy(sh);
     sora_hip_free(d_file); sora_hip_free(d_iq);
-    free(all); free(counts); free(caps); free(file);
+    free(all); free(counts); free(caps); free(file); free(mpdus);
     if (rank == 0) remove(idfile);
     return 0;
 }

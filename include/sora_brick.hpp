@@ -333,7 +333,7 @@ public:
         return true;
     }
     void Reset() {}                                      // every call starts from the graph's initial state
-    void Flush() {}
+    void Flush() { if (rx_) (void)sora_rx11b_synchronize(rx_); }   // the handle keeps two calls in flight: Flush() = all of them have finished
     sora_rx11b_t* handle() { return rx_; }
 private:
     CF_Error& ctx_; sora_rx11b_t* rx_;
@@ -357,7 +357,7 @@ public:
         return true;
     }
     void Reset() {}                                      // every call starts from the graph's initial state
-    void Flush() {}
+    void Flush() { if (rx_) (void)sora_rx11n_synchronize(rx_); }   // (sora_rx11n_set_depth calls in flight)
     sora_rx11n_t* handle() { return rx_; }
 private:
     CF_Error& ctx_; sora_rx11n_t* rx_;

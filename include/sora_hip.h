@@ -322,8 +322,10 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
 int   sora_rx11n_set_depth(sora_rx11n_t* rx, int depth);
 int   sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair);                                     /* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
 int   sora_rx11n_ticket(sora_rx11n_t* rx);
+int   sora_rx11n_synchronize(sora_rx11n_t* rx);                                                       /* every call issued so far has finished */
 int   sora_rx11n_wait(sora_rx11n_t* rx, int ticket);
 int   sora_rx11n_results_of(sora_rx11n_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+int   sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);   /* as sora_rx11b_deliver_async */
 
 /* ------------------------------------------------------------------------------------------------
  * The data field of an HT-mixed 40 MHz, two-stream frame (BASELINE.json configs[3]: 128-point FFT, MMSE MIMO detection, one decoder per
@@ -357,6 +359,15 @@ int   sora_ht40_synchronize(sora_ht40_t* rx);                                   
                                                                                                         * process_dev waits only for the call three calls back; results reports the most recent one) */
 int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);
 int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+/* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_ht40_calls_in_flight() (3) further calls have reused its
+ * slot -- so back-to-back calls are all collectable, each by its own ticket, while later ones run.  The INPUT buffers of a call must stay
+ * untouched until sora_ht40_wait(its ticket) (or _results_of, or _synchronize) has returned. */
+int   sora_ht40_ticket(sora_ht40_t* rx);                       /* ticket of the most recent process call (0: none) */
+int   sora_ht40_calls_in_flight(sora_ht40_t* rx);              /* how many calls the handle keeps addressable */
+int   sora_ht40_wait(sora_ht40_t* rx, int ticket);
+void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket);
+int   sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+int   sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);    /* as sora_rx11b_deliver_async: two rows per frame */
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU sharding for a C host.  Captures are independent -- the reference resets its context per
@@ -384,6 +395,12 @@ int  sora_shard_gather_rows(sora_shard_t* sh, const sora_frame_result* d_rows, c
 int  sora_shard_reduce_counters(sora_shard_t* sh, uint64_t* d_counters, size_t n, void* stream);
 int  sora_shard_gather_results(sora_shard_t* sh, sora_rx_t* rx, int ticket, size_t max_rows_per_rank,
                                sora_frame_result* h_all_rows, uint32_t* h_counts, size_t* n_total);
+/* The same with the MPDUs (what fb11a_demod.cpp:64-70 hands to the MAC): every rank's MPDU bytes, densely packed in row order, gathered
+ * with one more ncclAllGather of max_mpdu_bytes_per_rank bytes per rank; the gathered rows' mpdu_offset indexes h_all_mpdu
+ * (world x max_mpdu_bytes_per_rank bytes of room), *mpdu_total = bytes used.  h_all_mpdu = NULL: rows only.
+ * Every rank must make the call (three collectives); a rank whose own part fails still takes part and every rank then returns an error. */
+int  sora_shard_gather_results_mpdu(sora_shard_t* sh, sora_rx_t* rx, int ticket, size_t max_rows_per_rank, sora_frame_result* h_all_rows,
+                                    uint32_t* h_counts, size_t* n_total, size_t max_mpdu_bytes_per_rank, uint8_t* h_all_mpdu, size_t* mpdu_total);
 
 /* ------------------------------------------------------------------------------------------------
  * 802.11b receive graph = CreateDemodGraph (kernel/bb/demod11/fb11bdemod_config.hpp:122-172) driven by
@@ -395,8 +412,8 @@ int  sora_shard_gather_results(sora_shard_t* sh, sora_rx_t* rx, int ticket, size
  * FCS bytes and one stale buffer byte, PHY_11b.hpp:725-731); start_sample, nsym and cfo_est are 0.  Long preamble; 1 Mbps
  * DBPSK, 2 Mbps DQPSK, 5.5 and 11 Mbps CCK payloads (all four rates of the reference graph).
  * Two kernels per call: the first has no CCK decoders in it (more resident waves) and hands a capture over when a header announces
- * 5.5 / 11 Mbps; the second redoes the handed-over captures.  Environment SORA_HIP_11B_ONE_KERNEL=1 sends every capture through the second
- * one only: 1 / 2 Mbps traffic 3-6 % slower, CCK traffic 28 % faster (same rows either way).
+ * 5.5 / 11 Mbps; the second redoes the handed-over captures.  (A build variant, SORA_VARIANT_11B_ONE_KERNEL, sends every capture through the
+ * second one only: 1 / 2 Mbps traffic 3-6 % slower, CCK traffic 28 % faster, same rows either way.)
  * ------------------------------------------------------------------------------------------------ */
 #define SORA_E_NOT_SUPPORTED     ((int)0x80000003)
 #define SORA_E_SFD_FAIL          ((int)0x80000004)
@@ -412,6 +429,19 @@ int   sora_rx11b_synchronize(sora_rx11b_t* rx);       /* every call issued so fa
 int  sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps);
 int  sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsamples, const sora_capture_desc* caps, size_t ncaps);
 int  sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+/* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_rx11b_calls_in_flight() (2) further calls have reused its
+ * slot -- back-to-back calls are all collectable, each by its own ticket, while the next one runs (what fb11b_demod.cpp does per frame,
+ * per call).  The INPUT buffer of a call must stay untouched until sora_rx11b_wait(its ticket) (or _results_of, or _synchronize) has returned. */
+int   sora_rx11b_ticket(sora_rx11b_t* rx);                     /* ticket of the most recent process call (0: none) */
+int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls the handle keeps addressable */
+int   sora_rx11b_wait(sora_rx11b_t* rx, int ticket);
+void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket);
+int   sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+/* Result delivery without a host wait (as sora_rx_deliver_async): behind the call's kernels, on its stream, the dense rows in (capture, time)
+ * order -- h_rows must have room for captures x max_frames_per_capture of them --, h_counts[0] = rows, h_counts[1] = MPDU bytes, and the MPDUs
+ * densely packed in row order (the rows' mpdu_offset indexes h_mpdu; an MPDU that would reach past mpdu_cap is left out and h_counts[1] says
+ * so).  Page-locked buffers (sora_hip_host_alloc); valid once sora_rx11b_wait(ticket) has returned.  h_mpdu may be NULL. */
+int   sora_rx11b_deliver_async(sora_rx11b_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Small device-memory helpers so a pure-C host needs no HIP headers.

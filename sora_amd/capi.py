@@ -54,12 +54,12 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
            "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results",
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_wait", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
-           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
-           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_results",
+           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
+           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_stream_of", "sora_ht40_results_of",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
-           "sora_shard_reduce_counters", "sora_shard_gather_results"]
+           "sora_shard_reduce_counters", "sora_shard_gather_results", "sora_shard_gather_results_mpdu"]
 
 _lib = None
 
@@ -140,6 +140,8 @@ def load(build_if_missing=True):
     L.sora_shard_reduce_counters.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_shard_gather_results.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(FrameResult),
                                             ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_size_t)]
+    L.sora_shard_gather_results_mpdu.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int, ctypes.c_size_t, ctypes.POINTER(FrameResult),
+                                                 ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_size_t), ctypes.c_size_t, ctypes.POINTER(ctypes.c_uint8), ctypes.POINTER(ctypes.c_size_t)]
     L.sora_hip_fft64.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_fft128.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     L.sora_hip_lts11a.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
@@ -400,7 +402,19 @@ class HostResults:
             arrs.append(np.ctypeslib.as_array((ctypes.c_uint8 * nbytes).from_address(p)))
         self.rows = arrs[0].view(ROW_DTYPE)
         self.nrows = arrs[1][:4].view(np.uint32)
+        self.counts = arrs[1][:8].view(np.uint32)       # the 11b / 11n / HT40 handles deliver {rows, MPDU bytes}
         self.mpdu = arrs[2]
+
+    def results(self):
+        """the delivered table as the list of dicts Rx*.results() returns (after wait(ticket)): dense MPDUs, mpdu_offset indexes self.mpdu"""
+        out = []
+        for r in self.rows[:int(self.counts[0])]:
+            d = {k: int(r[k]) for k in ROW_DTYPE.names}
+            has = d["error_code"] in (E_FRAME_OK, E_CRC32_FAIL) and self.mpdu is not None
+            d["mpdu"] = self.mpdu[d["mpdu_offset"]:d["mpdu_offset"] + min(d["length"], 4096)].tobytes() if has else b""
+            d["stream"] = d["start_sample"]
+            out.append(d)
+        return out
 
     def close(self):
         for p in self._ptrs:
@@ -442,22 +456,40 @@ class Rx11b:
         arr, ptr = Rx._caps(captures)
         _hold(self, d_iq)
         _check(self._L.sora_rx11b_process_dev(self._h, _dev_ptr(d_iq), ptr, len(arr)))
+        return self._L.sora_rx11b_ticket(self._h)
+
+    def ticket(self):
+        return self._L.sora_rx11b_ticket(self._h)
+
+    def calls_in_flight(self):
+        return int(self._L.sora_rx11b_calls_in_flight(self._h))
+
+    def wait(self, ticket):
+        _check(self._L.sora_rx11b_wait(self._h, int(ticket)))
+
+    def deliver_async(self, ticket, buf):
+        """rows + dense MPDUs of the call into the page-locked HostResults `buf`, behind the call's kernels; valid after wait(ticket)"""
+        _check(self._L.sora_rx11b_deliver_async(self._h, int(ticket), buf.rows.ctypes.data, len(buf.rows), buf.counts.ctypes.data,
+                          buf.mpdu.ctypes.data if buf.mpdu is not None else None, buf.mpdu.size if buf.mpdu is not None else 0))
 
     def process(self, h_iq, captures):
         a = np.ascontiguousarray(h_iq, np.int16).reshape(-1, 2)
         arr, ptr = Rx._caps(captures)
         _check(self._L.sora_rx11b_process(self._h, a.ctypes.data, len(a), ptr, len(arr)))
 
-    def results(self):
+    def results(self, ticket=None, with_mpdu=True):
         max_frames = self.cfg.max_captures * self.cfg.max_frames_per_capture
         res = (FrameResult * max(1, max_frames))()
         n = ctypes.c_size_t(0)
-        mp = np.zeros(max_frames * 4096, np.uint8)
-        _check(self._L.sora_rx11b_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data, mp.size))
+        mp = np.zeros(max_frames * 4096 if with_mpdu else 1, np.uint8)
+        if ticket is None:
+            _check(self._L.sora_rx11b_results(self._h, res, max_frames, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        else:
+            _check(self._L.sora_rx11b_results_of(self._h, int(ticket), res, max_frames, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
         out = []
         for r in res[:n.value]:
             d = {f: getattr(r, f) for f, _ in FrameResult._fields_}
-            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + min(r.length, 4096)].tobytes() if r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
+            d["mpdu"] = mp[r.mpdu_offset:r.mpdu_offset + min(r.length, 4096)].tobytes() if with_mpdu and r.error_code in (E_FRAME_OK, E_CRC32_FAIL) else b""
             out.append(d)
         return out
 
@@ -501,6 +533,11 @@ class Rx11n:
 
     def wait(self, ticket):
         _check(self._L.sora_rx11n_wait(self._h, int(ticket)))
+
+    def deliver_async(self, ticket, buf):
+        """rows + dense MPDUs of the call into the page-locked HostResults `buf`, behind the call's kernels; valid after wait(ticket)"""
+        _check(self._L.sora_rx11n_deliver_async(self._h, int(ticket), buf.rows.ctypes.data, len(buf.rows), buf.counts.ctypes.data,
+                          buf.mpdu.ctypes.data if buf.mpdu is not None else None, buf.mpdu.size if buf.mpdu is not None else 0))
 
     def process_dev(self, d_iq0, d_iq1, captures):
         arr, ptr = Rx._caps(captures)
@@ -574,12 +611,34 @@ class RxHt40:
         arr = self.frames(descs); n = getattr(arr, "_n", len(arr))
         _hold(self, (d_iq0, d_iq1, d_weights)); self._n = n
         _check(self._L.sora_ht40_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), arr, n, _dev_ptr(d_weights) if d_weights is not None else None))
+        t = self._L.sora_ht40_ticket(self._h)
+        self._nof = getattr(self, "_nof", {}); self._nof[t] = n
+        for old in [k for k in self._nof if k <= t - 8]:
+            del self._nof[old]
+        return t
 
-    def results(self, with_mpdu=True):
-        n2 = 2 * self._n
+    def ticket(self):
+        return self._L.sora_ht40_ticket(self._h)
+
+    def calls_in_flight(self):
+        return int(self._L.sora_ht40_calls_in_flight(self._h))
+
+    def wait(self, ticket):
+        _check(self._L.sora_ht40_wait(self._h, int(ticket)))
+
+    def deliver_async(self, ticket, buf):
+        """rows + dense MPDUs of the call into the page-locked HostResults `buf`, behind the call's kernels; valid after wait(ticket)"""
+        _check(self._L.sora_ht40_deliver_async(self._h, int(ticket), buf.rows.ctypes.data, len(buf.rows), buf.counts.ctypes.data,
+                          buf.mpdu.ctypes.data if buf.mpdu is not None else None, buf.mpdu.size if buf.mpdu is not None else 0))
+
+    def results(self, with_mpdu=True, ticket=None):
+        n2 = 2 * (self._n if ticket is None else self._nof[int(ticket)])
         res = (FrameResult * max(1, n2))(); n = ctypes.c_size_t(0)
         mp = np.zeros(n2 * 4096 if with_mpdu else 1, np.uint8)
-        _check(self._L.sora_ht40_results(self._h, res, n2, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        if ticket is None:
+            _check(self._L.sora_ht40_results(self._h, res, n2, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
+        else:
+            _check(self._L.sora_ht40_results_of(self._h, int(ticket), res, n2, ctypes.byref(n), mp.ctypes.data if with_mpdu else None, mp.size))
         out = []
         for r in res[:n.value]:
             d = {f: getattr(r, f) for f, _ in FrameResult._fields_}

@@ -317,14 +317,17 @@ int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_
 
 // ---- dsp_math tables (dsp_math.h:215-245): generated once per device with the C library, as the reference generates them at start-up
 #include <cmath>
+#include <mutex>
 #include <vector>
 namespace {
 struct DspTables { uint32_t* sincos = nullptr; short* atan = nullptr; };
+std::mutex g_dsp_mutex;
 const DspTables* dsp_tables()
 {
     static DspTables tabs[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    std::lock_guard<std::mutex> lock(g_dsp_mutex);                              // handles may be created from different threads: built once per device, published whole
     DspTables& T = tabs[dev];
     if (!T.sincos) {
         std::vector<uint32_t> sc(65536); std::vector<short> at(4097);
@@ -335,9 +338,12 @@ const DspTables* dsp_tables()
         }
         for (int i = 0; i <= 4096; i++) at[i] = (short)(atan((double)i / 4096.0) / (M_PI / 4.0) * 8192);
         uint32_t* d_sc = nullptr; short* d_at = nullptr;
-        if (hipMalloc((void**)&d_sc, sc.size() * 4) != hipSuccess || hipMalloc((void**)&d_at, at.size() * 2) != hipSuccess) return nullptr;
-        if (hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_at, at.data(), at.size() * 2, hipMemcpyHostToDevice) != hipSuccess) return nullptr;
-        T.sincos = d_sc; T.atan = d_at;
+        if (hipMalloc((void**)&d_sc, sc.size() * 4) != hipSuccess || hipMalloc((void**)&d_at, at.size() * 2) != hipSuccess ||
+            hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_at, at.data(), at.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {
+            (void)hipFree(d_sc); (void)hipFree(d_at);
+            return nullptr;
+        }
+        T.atan = d_at; T.sincos = d_sc;                                         // (sincos last: it is what marks the entry as built)
     }
     return &T;
 }

@@ -269,11 +269,14 @@ struct Ht40Slot {
     Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
     uint32_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
     std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0;
+    int ticket = 0;             // of the call this slot holds (0: none)
+    DenseStage dense;           // sora_ht40_deliver_async
+    std::vector<sora_frame_result> h_tmpl;                                      // what the rows of this call carry besides the decoder's verdict
 };
 struct sora_ht40 {
     int device = 0; uint32_t max_frames = 0; uint64_t max_soft = 0;
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
-    Ht40Slot slot[kHt40Slots]; int next = 0, last = 0; bool have_results = false;
+    Ht40Slot slot[kHt40Slots]; int next = 0, last = 0, seq = 0; bool have_results = false;
     int lanes16 = 0;            // trellis kernel: 0 = k_viterbi11n (64 lanes per stream pair), 1 = k_viterbi16_11n (sora_ht40_set_trellis)
 };
 
@@ -287,6 +290,7 @@ static void ht40_free(sora_ht40_t* rx)
         if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
         (void)hipFree(S.d_frames); (void)hipFree(S.d_jobs); (void)hipFree(S.d_njobs); (void)hipFree(S.d_fjobs); (void)hipFree(S.d_soft);
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
+        sora_internal_dense_free(&S.dense);
     }
     delete rx;
 }
@@ -379,6 +383,7 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
     if (2 * soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
     S.h_frames.assign(frames, frames + nframes); S.nframes = (uint32_t)nframes; rx->have_results = true;
     rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
+    S.ticket = ++rx->seq;
     if (nframes == 0) return SORA_OK;
     HIPCHK40(hipMemcpy(S.d_frames, hf.data(), sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice));
     for (int r = 0; r < 3; r++)                                                   // (only the filled part of each code-rate list)
@@ -400,12 +405,8 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
     return SORA_OK;
 }
 
-int sora_ht40_results(sora_ht40_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+static int ht40_slot_results(sora_ht40_t* rx, Ht40Slot& S, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
 {
-    if (!rx || !nout || !out) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_results: null argument", 0);
-    *nout = 0;
-    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
-    Ht40Slot& S = rx->slot[rx->last];
     if (S.nframes == 0) return SORA_OK;
     HIPCHK40(hipSetDevice(rx->device));
     HIPCHK40(hipStreamSynchronize(S.stream));
@@ -430,4 +431,58 @@ int sora_ht40_results(sora_ht40_t* rx, sora_frame_result* out, size_t max_out, s
     }
     *nout = nj;
     return SORA_OK;
+}
+
+int sora_ht40_results(sora_ht40_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout || !out) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_results: null argument", 0);
+    *nout = 0;
+    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
+    return ht40_slot_results(rx, rx->slot[rx->last], out, max_out, nout, h_mpdu, mpdu_cap);
+}
+
+// Tickets (as sora_rx_ticket / _wait / _results_of): every process call is addressable until kHt40Slots further calls have reused its slot.
+static Ht40Slot* ht40_slot_of(sora_ht40_t* rx, int ticket)
+{
+    if (!rx || ticket <= 0) return nullptr;
+    for (Ht40Slot& S : rx->slot) if (S.ticket == ticket) return &S;
+    return nullptr;
+}
+static const char* const kStaleHt40 = "stale ticket: its slot has been reused by a later process call (or the ticket was never issued)";
+int sora_ht40_ticket(sora_ht40_t* rx) { return rx && rx->have_results ? rx->slot[rx->last].ticket : 0; }
+int sora_ht40_calls_in_flight(sora_ht40_t* rx) { (void)rx; return kHt40Slots; }
+int sora_ht40_wait(sora_ht40_t* rx, int ticket)
+{
+    Ht40Slot* S = ht40_slot_of(rx, ticket);
+    if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
+    HIPCHK40(hipSetDevice(rx->device));
+    HIPCHK40(hipStreamSynchronize(S->stream));
+    return SORA_OK;
+}
+void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket) { Ht40Slot* S = ht40_slot_of(rx, ticket); return S ? (void*)S->stream : nullptr; }
+int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    Ht40Slot* S = ht40_slot_of(rx, ticket);
+    if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
+    HIPCHK40(hipSetDevice(rx->device));
+    S->h_tmpl.resize(2 * (size_t)S->nframes);
+    for (size_t j = 0; j < S->h_tmpl.size(); j++) {                             // (the same fields sora_ht40_results fills in on the host)
+        sora_frame_result& o = S->h_tmpl[j]; const sora_ht40_frame& f = S->h_frames[j / 2];
+        memset(&o, 0, sizeof(o));
+        o.capture_id = f.frame_id; o.start_sample = (uint32_t)(j & 1); o.rate_kbps = f.n_bpsc * 10 + f.code_rate;
+        o.nsym = (uint16_t)sora_ht40_symbols(f.length[0], f.length[1], f.n_bpsc, f.code_rate);
+    }
+    // two rows per frame, always: "captures" = frames, max_frames_per_capture = 2, no per-capture counts.  (The template is read by an
+    // asynchronous copy: it lives in the slot until the slot's next call.)
+    return sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, S->h_tmpl.data(), S->nframes, 2, S->d_mpdu, S->stream,
+                                       h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+}
+
+int sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!nout || !out) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_results_of: null argument", 0);
+    *nout = 0;
+    Ht40Slot* S = ht40_slot_of(rx, ticket);
+    if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
+    return ht40_slot_results(rx, *S, out, max_out, nout, h_mpdu, mpdu_cap);
 }

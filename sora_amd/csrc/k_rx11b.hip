@@ -934,12 +934,14 @@ struct Slot11b {
     hipStream_t stream = nullptr;
     CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_needs_cck = nullptr;
     std::vector<sora_capture_desc> h_caps;
+    int ticket = 0;              // of the call this slot holds (0: none)
+    DenseStage dense;            // sora_rx11b_deliver_async
     std::vector<CapDesc> h_desc;                 // staging for the descriptor upload (kept until the slot's next call)
     uint32_t ncaps = 0;
 };
 struct sora_rx11b {
     sora_rx_cfg cfg{};
-    Slot11b slot[kSlots11b]; int next = 0, last = 0;
+    Slot11b slot[kSlots11b]; int next = 0, last = 0, seq = 0;
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
     bool have_results = false;
@@ -953,6 +955,7 @@ static void rx11b_free(sora_rx11b_t* rx)
     for (Slot11b& S : rx->slot) {
         if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
         (void)hipFree(S.d_caps); (void)hipFree(S.d_rows); (void)hipFree(S.d_nframes); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_needs_cck);
+        sora_internal_dense_free(&S.dense);
     }
     (void)hipFree(rx->d_iq_own);
     delete rx;
@@ -1016,6 +1019,7 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     if (total > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process_dev: more samples than max_total_samples", 0);
     S.h_caps.assign(caps, caps + ncaps); S.ncaps = (uint32_t)ncaps; rx->have_results = true;
     rx->last = rx->next; rx->next = (rx->next + 1) % kSlots11b;
+    S.ticket = ++rx->seq;
     if (ncaps == 0) return SORA_OK;
     HIPCHK11(hipMemcpyAsync(S.d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
     Rx11bArgs A;
@@ -1046,12 +1050,8 @@ int sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsam
     return sora_rx11b_process_dev(rx, rx->d_iq_own, caps, ncaps);
 }
 
-int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+static int slot11b_results(sora_rx11b_t* rx, Slot11b& S, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
 {
-    if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_results: null argument", 0);
-    *nout = 0;
-    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
-    Slot11b& S = rx->slot[rx->last];
     if (S.ncaps == 0) return SORA_OK;
     HIPCHK11(hipSetDevice(rx->cfg.device));
     HIPCHK11(hipStreamSynchronize(S.stream));
@@ -1089,4 +1089,49 @@ int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out,
     *nout = n;
     if (rc != SORA_OK) return sora_internal_fail(rc, "sora_rx11b_results: output buffer too small", 0);
     return SORA_OK;
+}
+
+int sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_results: null argument", 0);
+    *nout = 0;
+    if (!rx->have_results) return sora_internal_fail(SORA_ERR_FAILED, "no process call to report", 0);
+    return slot11b_results(rx, rx->slot[rx->last], out, max_out, nout, h_mpdu, mpdu_cap);
+}
+
+// Tickets (as sora_rx_ticket / _wait / _results_of): every process call is addressable until kSlots11b further calls have reused its slot.
+static Slot11b* slot11b_of(sora_rx11b_t* rx, int ticket)
+{
+    if (!rx || ticket <= 0) return nullptr;
+    for (Slot11b& S : rx->slot) if (S.ticket == ticket) return &S;
+    return nullptr;
+}
+static const char* const kStale11b = "stale ticket: its slot has been reused by a later process call (or the ticket was never issued)";
+int sora_rx11b_ticket(sora_rx11b_t* rx) { return rx && rx->have_results ? rx->slot[rx->last].ticket : 0; }
+int sora_rx11b_calls_in_flight(sora_rx11b_t* rx) { (void)rx; return kSlots11b; }
+int sora_rx11b_wait(sora_rx11b_t* rx, int ticket)
+{
+    Slot11b* S = slot11b_of(rx, ticket);
+    if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStale11b, 0);
+    HIPCHK11(hipSetDevice(rx->cfg.device));
+    HIPCHK11(hipStreamSynchronize(S->stream));
+    return SORA_OK;
+}
+void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket) { Slot11b* S = slot11b_of(rx, ticket); return S ? (void*)S->stream : nullptr; }
+int sora_rx11b_deliver_async(sora_rx11b_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    Slot11b* S = slot11b_of(rx, ticket);
+    if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStale11b, 0);
+    HIPCHK11(hipSetDevice(rx->cfg.device));
+    return sora_internal_dense_deliver(&S->dense, S->d_rows, S->d_nframes, S->d_caps, nullptr, S->ncaps, rx->cfg.max_frames_per_capture, S->d_mpdu, S->stream,
+                                       h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+}
+
+int sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    if (!nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_results_of: null argument", 0);
+    *nout = 0;
+    Slot11b* S = slot11b_of(rx, ticket);
+    if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStale11b, 0);
+    return slot11b_results(rx, *S, out, max_out, nout, h_mpdu, mpdu_cap);
 }

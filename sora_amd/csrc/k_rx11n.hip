@@ -1082,6 +1082,7 @@ struct Pipe11n {                         // one call in flight: a stream and eve
     N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
     std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
     uint32_t ncaps = 0; bool have_results = false; int ticket = 0;
+    DenseStage dense;                       // sora_rx11n_deliver_async
 };
 struct sora_rx11n {
     sora_rx_cfg cfg{};
@@ -1107,6 +1108,7 @@ static void pipe11n_free(Pipe11n* p)
     if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
     (void)hipFree(p->d_caps); (void)hipFree(p->d_rows); (void)hipFree(p->d_nframes); (void)hipFree(p->d_mpdu);
     (void)hipFree(p->d_frames); (void)hipFree(p->d_jobs); (void)hipFree(p->d_njobs); (void)hipFree(p->d_soft); (void)hipFree(p->d_vout);
+    sora_internal_dense_free(&p->dense);
     delete p;
 }
 static void rx11n_free(sora_rx11n_t* rx)
@@ -1194,6 +1196,24 @@ int sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair)
     if (lanes_per_pair == 16 || lanes_per_pair == 64) rx->lanes16 = lanes_per_pair == 16;
     else if (lanes_per_pair >= 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_trellis: 16 or 64 lanes per frame pair", 0);
     return old;
+}
+
+static Pipe11n* pipe11n_of(sora_rx11n_t* rx, int ticket);
+int sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
+{
+    Pipe11n* P = pipe11n_of(rx, ticket);
+    if (!P || !P->have_results) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_deliver_async: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    return sora_internal_dense_deliver(&P->dense, P->d_rows, P->d_nframes, P->d_caps, nullptr, P->ncaps, rx->cfg.max_frames_per_capture, P->d_mpdu, P->stream,
+                                       h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+}
+
+int sora_rx11n_synchronize(sora_rx11n_t* rx)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_synchronize: null handle", 0);
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
+    return SORA_OK;
 }
 
 static Pipe11n* pipe11n_of(sora_rx11n_t* rx, int ticket)

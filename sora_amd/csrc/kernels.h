@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include "dev_arith.h"
 #include "rx_types.h"
+#include "../../include/sora_hip.h"
 
 namespace sora {
 
@@ -95,8 +96,23 @@ __global__ void k_rx11b_cck(Rx11bArgs A);
 
 }  // namespace sora
 
+// k_deliver.hip: dense rows + MPDUs of a call of the Rx11bRow-table handles into page-locked host memory, behind the call's kernels
+struct DenseStage {                  // per slot / pipeline (grow-only device staging)
+    sora_frame_result* d_rows = nullptr; size_t rows_bytes = 0;
+    uint32_t* d_src = nullptr; size_t src_bytes = 0;
+    uint8_t* d_mpdu = nullptr; size_t mpdu_bytes = 0;
+    uint32_t* d_meta = nullptr; size_t meta_bytes = 0;
+    sora_frame_result* d_tmpl = nullptr; size_t tmpl_bytes = 0;
+};
+void sora_internal_dense_free(DenseStage* D);
+int sora_internal_dense_deliver(DenseStage* D, const sora::Rx11bRow* d_rows, const uint32_t* d_nframes, const sora::CapDesc* d_caps, const sora_frame_result* h_tmpl,
+                                uint32_t ncaps, uint32_t mf, const uint8_t* d_slots, hipStream_t st,
+                                sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap);
+
 // sora_hip.cpp: records the message sora_hip_last_error() returns; hip_error = 0 for none
 int sora_internal_fail(int code, const char* what, int hip_error);
 const uint32_t* sora_internal_crc_table(int device);
+struct sora_rx;
+extern "C" int sora_internal_rx_device(sora_rx* rx);                           // device ordinal of a receive handle (sora_shard.cpp)
 int sora_internal_tables(int device, sora::Tables* out);                  // the per-device tables of the stage entry points (uploaded on first use)
 int sora_internal_dsp_tables(const uint32_t** sincos, const short** atan);  // dsp_math tables of the current device (k_11n.hip)   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr

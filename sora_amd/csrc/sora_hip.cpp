@@ -699,6 +699,8 @@ int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
     return old;
 }
 
+int sora_internal_rx_device(sora_rx_t* rx) { return rx ? rx->cfg.device : -1; }
+
 int sora_rx_trellis(sora_rx_t* rx) { return rx ? (lanes16_for(rx) ? 16 : 64) : SORA_ERR_INVALID_PARAM; }
 
 int sora_rx_set_graph(sora_rx_t* rx, int enable)

@@ -58,6 +58,56 @@ def gather_rows(rows, nrows, max_rows_per_rank, group=None):
     return torch.cat(parts) if parts else allrows[:0], cl
 
 
+def pack_mpdus(rows, nrows, mpdu, max_bytes):
+    """This rank's MPDUs, densely packed in row order (the exchange unit of gather_mpdus).  rows: int32 tensor [>=nrows, 9] whose
+    mpdu_offset (word 8) indexes the uint8 tensor `mpdu`; rows that carry an MPDU are FRAME_OK / CRC32_FAIL.  Returns (uint8 tensor
+    [max_bytes] on rows' device, bytes used, int32 tensor [nrows] of the rows' dense offsets).  Runs on the rows' device (torch ops)."""
+    import torch
+    dev = rows.device
+    r = rows[:nrows].to(torch.int64)
+    err = r[:, 3] & 0xFFFFFFFF
+    has = (err == 0x00000001) | (err == 0x80000006)
+    ln = torch.where(has, r[:, 5] & 0xFFFF, torch.zeros_like(r[:, 5]))
+    dense = torch.cumsum(ln, 0) - ln
+    used = int(ln.sum().item()) if nrows else 0
+    if used > max_bytes:
+        raise ValueError("pack_mpdus: %d MPDU bytes exceed max_bytes %d" % (used, max_bytes))
+    out = torch.zeros(max_bytes, dtype=torch.uint8, device=dev)
+    if used:
+        row_of = torch.repeat_interleave(torch.arange(nrows, device=dev), ln)                  # for every dense byte: its row ...
+        within = torch.arange(used, device=dev) - dense[row_of]                                 # ... and its index inside the MPDU
+        out[:used] = mpdu[(r[:, 8] & 0xFFFFFFFF)[row_of] + within]
+    return out, used, dense.to(torch.int32)
+
+
+def gather_mpdus(rows, nrows, mpdu, max_rows_per_rank, max_bytes_per_rank, group=None):
+    """Rows AND MPDUs of every rank on every rank (what fb11a_demod.cpp:64-70 hands to the MAC, for a sharded batch): three all-gathers
+    -- {rows, bytes} per rank, the padded row blocks, the dense MPDU blocks.  Returns (int32 tensor [total, 9] whose mpdu_offset indexes
+    the second result, uint8 tensor [total bytes], per-rank row counts)."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    dev = rows.device
+    block, used, dense = pack_mpdus(rows, nrows, mpdu, max_bytes_per_rank)
+    pad = torch.zeros((max_rows_per_rank, ROW_WORDS), dtype=torch.int32, device=dev)
+    pad[:nrows] = rows[:nrows]
+    pad[:nrows, 8] = dense
+    pairs = torch.zeros((world, 2), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(pairs, torch.tensor([[nrows, used]], dtype=torch.int32, device=dev), group=group)
+    allrows = torch.zeros((world * max_rows_per_rank, ROW_WORDS), dtype=torch.int32, device=dev)
+    dist.all_gather_into_tensor(allrows, pad, group=group)
+    allmp = torch.zeros(world * max_bytes_per_rank, dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(allmp, block, group=group)
+    pl = pairs.tolist()
+    rparts, mparts, moff = [], [], 0
+    for r in range(world):
+        c, b = int(pl[r][0]), int(pl[r][1])
+        blk = allrows[r * max_rows_per_rank: r * max_rows_per_rank + c].clone()
+        blk[:, 8] += moff
+        rparts.append(blk); mparts.append(allmp[r * max_bytes_per_rank: r * max_bytes_per_rank + b]); moff += b
+    return (torch.cat(rparts) if rparts else allrows[:0]), (torch.cat(mparts) if mparts else allmp[:0]), [int(p[0]) for p in pl]
+
+
 def reduce_counters(values, group=None, device=None):
     """Sum small integer counters (frames, CRC-ok, samples, bits) over the ranks."""
     import torch

@@ -153,6 +153,42 @@ def test_11b_calls_in_flight_keep_their_results_apart(sora, oracle):
     for d, descs, caps in batches:
         rx.process_dev(d, descs)
         check(rx.results(), caps)
+    # tickets: with calls issued back to back, every call in flight is collectable by its own ticket while the next ones run
+    # (sora_rx11b_ticket / _wait / _results_of: the contract of sora_rx_*); a ticket whose slot has been reused is refused
+    depth = rx.calls_in_flight()
+    assert depth == 2
+    tickets = []
+    for k in range(7):
+        d, descs, caps = batches[k % 4]
+        tickets.append((rx.process_dev(d, descs), caps))
+        if len(tickets) >= depth:
+            t, c = tickets[-depth]
+            rx.wait(t)
+            check(rx.results(ticket=t), c)                               # the OLDER call, read while the newer one is in flight
+    check(rx.results(ticket=tickets[-1][0]), tickets[-1][1])
+    assert rx.ticket() == tickets[-1][0]
+    # delivery without a host wait (sora_rx11b_deliver_async): rows + densely packed MPDUs into page-locked memory behind each call's
+    # kernels, two calls in flight; the delivered table is the one results() reports
+    key = lambda r: (r["capture_id"], r["end_sample"], r["error_code"], r["rate_kbps"], r["length"], r["crc32"], r["mpdu"])
+    bufs = [sora.HostResults(24 * 64, 1 << 20) for _ in range(depth)]
+    pend = []
+    for k in range(5):
+        d, descs, caps = batches[k % 4]
+        t = rx.process_dev(d, descs)
+        rx.deliver_async(t, bufs[k % depth])
+        pend.append((t, bufs[k % depth]))
+        if len(pend) >= depth:
+            t0, b0 = pend.pop(0)
+            rx.wait(t0)
+            got = b0.results()
+            assert [key(r) for r in got] == [key(r) for r in rx.results(ticket=t0)] and len(got) > 10
+            assert int(b0.counts[1]) == sum(len(r["mpdu"]) for r in got)
+    for b in bufs:
+        b.close()
+    with pytest.raises(sora.SoraError):
+        rx.results(ticket=tickets[0][0])                                 # long reused
+    with pytest.raises(sora.SoraError):
+        rx.wait(10 ** 6)                                                 # never issued
     rx.synchronize(); rx.close()
 
 

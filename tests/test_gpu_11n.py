@@ -233,4 +233,19 @@ def test_11n_calls_in_flight_are_collectable_by_ticket(depth):
             assert ok, (t, i, why)
     with pytest.raises(Exception):
         rx.results(ticket=tickets[0])                                           # depth + 2 calls were made: the first call's pipeline has been reused
+    # delivery without a host wait (sora_rx11n_deliver_async): rows + densely packed MPDUs behind each call's kernels, `depth` calls in flight
+    key = lambda r: (r["capture_id"], r["end_sample"], r["error_code"], r["rate_kbps"], r["length"], r["crc32"], r["mpdu"])
+    bufs = [sora_amd.HostResults(12 * 8, 1 << 18) for _ in range(depth)]
+    pend = []
+    for k in range(depth + 3):
+        b = batches[k % len(batches)]
+        t = rx.process_dev(b[1], b[2], b[3])
+        rx.deliver_async(t, bufs[k % depth]); pend.append((t, bufs[k % depth]))
+        if len(pend) >= depth:
+            t0, b0 = pend.pop(0)
+            rx.wait(t0)
+            got = b0.results()
+            assert [key(r) for r in got] == [key(r) for r in rx.results(ticket=t0)] and len(got) >= 12
+    for bb in bufs:
+        bb.close()
     rx.close()

@@ -4,6 +4,7 @@ libsora_hip.so like any user would (gcc / g++, -lsora_hip) and run as separate p
 import hashlib
 import os
 import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -129,6 +130,14 @@ def test_c_host_shards_captures_and_gathers_over_rccl(tmp_path, golden_dir):
     dump = tmp_path / "fsample6.dmp"; dump.write_bytes(make_dump(iq, raw14=True))
     out = run([exe, str(dump), "--raw14", "--rate", "40", "--captures", "5", "--world", "1", "--rank", "0", "--id-file", str(tmp_path / "sora.id")])
     assert "world 1: 5 captures, 5 frames gathered (5), good 5 / bad 0" in out and "6000 kbps length 1392 FCS 80ef9b11, last: capture 4" in out, out
+    # the gathered MPDUs: five copies of the fixture's MPDU (sha256 pinned in SURVEY.md 8c), byte for byte -- the host prints their FNV-1a
+    from oracle.pyoracle import Oracle
+    mp = Oracle().rx_capture(iq[:len(iq) // 28 * 28], 40)[0]["mpdu"]
+    assert hashlib.sha256(mp).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+    h = 2166136261
+    for b in mp * 5:
+        h = ((h ^ b) * 16777619) & 0xFFFFFFFF
+    assert "%d MPDU bytes gathered, fnv1a %08x" % (5 * len(mp), h) in out, out
 
 
 def test_shard_api_from_python_matches_results(golden_dir):
@@ -151,8 +160,42 @@ def test_shard_api_from_python_matches_results(golden_dir):
     assert total.value == len(want) == 3 and counts[0] == 3
     for r, w in zip(rows, want):
         assert (r.capture_id, r.end_sample, r.error_code, r.rate_kbps, r.length, r.crc32) == (w["capture_id"], w["end_sample"], w["error_code"], w["rate_kbps"], w["length"], w["crc32"])
+    # ... and with the MPDUs: dense, in row order, mpdu_offset pointing into the gathered buffer
+    full = rx.results()
+    rows2 = (FrameResult * 12)(); mp = (ctypes.c_uint8 * (12 * 2504))(); mtot = ctypes.c_size_t(0)
+    assert L.sora_shard_gather_results_mpdu(sh, rx._h, 0, 12, rows2, counts, ctypes.byref(total), 12 * 2504, mp, ctypes.byref(mtot)) == 0, L.sora_hip_last_error()
+    assert total.value == 3 and mtot.value == sum(len(w["mpdu"]) for w in full)
+    for r, w in zip(rows2, full):
+        assert bytes(mp[r.mpdu_offset:r.mpdu_offset + r.length]) == w["mpdu"]
+    # a buffer too small for this rank's MPDUs is refused (after the exchange, on every rank)
+    assert L.sora_shard_gather_results_mpdu(sh, rx._h, 0, 12, rows2, counts, ctypes.byref(total), 64, mp, ctypes.byref(mtot)) != 0
     first = ctypes.c_size_t(); cnt = ctypes.c_size_t(); got = []
     for r in range(3):
         L.sora_shard_partition(256, 3, r, ctypes.byref(first), ctypes.byref(cnt)); got.append((first.value, cnt.value))
     assert got == [(0, 86), (86, 85), (171, 85)]
     L.sora_shard_destroy(sh); rx.close()
+
+
+def test_bench_result_exchange_over_rccl_with_a_world_of_one(oracle):
+    """bench.py --gpus N (BASELINE configs[4]: 256 captures over 8 GPUs = 32 per rank) ends with ONE exchange: RCCL all-gathers of the
+    device-packed rows and the dense MPDU blocks of every rank.  The 8-GPU run is the driver's; this runs the very same function on the
+    one GPU of the test box, over an initialised `nccl` process group of one rank, with the per-rank batch of configs[4]."""
+    import torch
+    import torch.distributed as dist
+    import sora_amd
+    sys.path.insert(0, ROOT)
+    import bench
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", str(29400 + os.getpid() % 500))
+    dist.init_process_group("nccl", rank=0, world_size=1)
+    try:
+        nfr = 32
+        iq, descs, payloads = bench.make_workload(oracle, nfr, seed0=0)
+        dev = torch.device("cuda", 0)
+        d_iq = torch.from_numpy(iq).to(dev)
+        rx = sora_amd.Rx(max_captures=nfr, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+        g = bench.exchange_results(torch, rx, d_iq, sora_amd.Rx.captures(descs), dev, nfr, 2)
+        assert g["rows"] == nfr and g["rows_per_rank"] == [nfr], g
+        assert g["mpdus_equal_to_the_transmitted_payloads"] >= nfr - 2 and g["mpdu_bytes"] == bench.MPDU_LEN * nfr, g
+        rx.close()
+    finally:
+        dist.destroy_process_group()

@@ -114,6 +114,39 @@ def test_calls_in_flight_keep_their_results_apart(env):
     for f0, f1, descs, psdus in batches:                                # and one by one
         rx.process_dev(f0, f1, descs)
         check(rx.results(), psdus)
+    # tickets: every call in flight is collectable by its own ticket while later ones run (sora_ht40_ticket / _wait / _results_of);
+    # a ticket whose slot has been reused is refused
+    depth = rx.calls_in_flight()
+    assert depth == 3
+    tickets = []
+    for k in range(9):
+        f0, f1, descs, psdus = batches[k % 5]
+        tickets.append((rx.process_dev(f0, f1, descs), psdus))
+        if len(tickets) >= depth:
+            t, ps = tickets[-depth]
+            rx.wait(t)
+            check(rx.results(ticket=t), ps)                              # the oldest call in flight, read while two newer ones run
+    for t, ps in tickets[-depth:]:
+        check(rx.results(ticket=t), ps)
+    assert rx.ticket() == tickets[-1][0]
+    with pytest.raises(sora.SoraError):
+        rx.results(ticket=tickets[0][0])
+    # delivery without a host wait (sora_ht40_deliver_async): two rows per frame and the PSDUs, densely packed, behind each call's kernels
+    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["rate_kbps"], r["length"], r["nsym"], r["crc32"], r["mpdu"])
+    bufs = [sora.HostResults(24, 24 * 1024) for _ in range(depth)]
+    pend = []
+    for k in range(7):
+        f0, f1, descs, psdus = batches[k % 5]
+        t = rx.process_dev(f0, f1, descs)
+        rx.deliver_async(t, bufs[k % depth]); pend.append((t, bufs[k % depth], psdus))
+        if len(pend) >= depth:
+            t0, b0, ps = pend.pop(0)
+            rx.wait(t0)
+            got = b0.results()
+            check(got, ps)
+            assert [key(r) for r in got] == [key(r) for r in rx.results(ticket=t0)]
+    for b in bufs:
+        b.close()
     rx.synchronize(); rx.close()
 
 

@@ -134,3 +134,58 @@ def test_two_rank_gloo_gather_11n():
         assert sum(counts) == len(want) and len(counts) == 2 and min(counts) > 0
         assert tot == [len(want), sum(1 for w in want if w[5] == 1)]
         assert got == want
+
+
+def _worker_mpdu(rank, world, port, q):
+    """rows + MPDUs: every rank's MPDU bytes reach every rank (sora_amd.shard.gather_mpdus: dense pack, three all-gathers), with the rows'
+    mpdu_offset pointing into the gathered buffer -- the logic sora_shard_gather_results_mpdu runs over RCCL."""
+    sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import torch
+    import torch.distributed as dist
+    from gpu_util import make_capture
+    from oracle.pyoracle import Oracle, RATES
+    from sora_amd.shard import gather_mpdus, partition, results_from_rows, rows_from_results
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    ncaps = 9
+    caps = [make_capture(o, RATES[i % 8], 40 + 31 * i, seed=40 + i, rate_mhz=20, sigma=100 if i != 4 else 6000)[0] for i in range(ncaps)]
+    first, count = partition(ncaps, world, rank)
+    local = []; sparse = np.zeros(1 << 16, np.uint8); pos = 7                  # a sparse MPDU array as the library's (slot-addressed) one
+    for i in range(first, first + count):
+        for r in o.rx_capture(caps[i], 20):
+            r = dict(r); r["capture_id"] = i
+            if r["error_code"] in (1, 0x80000006):
+                sparse[pos:pos + r["length"]] = np.frombuffer(r["mpdu"], np.uint8); r["mpdu_offset"] = pos; pos += r["length"] + 13
+            local.append(r)
+    rows = torch.from_numpy(rows_from_results(local).copy())
+    allrows, allmp, counts = gather_mpdus(rows, len(local), torch.from_numpy(sparse), max_rows_per_rank=16, max_bytes_per_rank=8192)
+    got = results_from_rows(allrows.numpy()); mp = allmp.numpy()
+    q.put((rank, counts, [(g["capture_id"], g["error_code"], g["length"], bytes(mp[g["mpdu_offset"]:g["mpdu_offset"] + g["length"]]) if g["error_code"] in (1, 0x80000006) else b"") for g in got]))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_two_rank_gloo_gather_mpdus():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 33500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_mpdu, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = [q.get(timeout=180) for _ in ps]
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import make_capture
+    from oracle.pyoracle import Oracle, RATES
+    o = Oracle(); want = []
+    for i in range(9):
+        c = make_capture(o, RATES[i % 8], 40 + 31 * i, seed=40 + i, rate_mhz=20, sigma=100 if i != 4 else 6000)[0]
+        for r in o.rx_capture(c, 20):
+            want.append((i, r["error_code"], r["length"], r["mpdu"] if r["error_code"] in (1, 0x80000006) else b""))
+    assert len(want) >= 8 and sum(1 for w in want if w[1] == 1) >= 6
+    for rank, counts, got in outs:
+        assert sum(counts) == len(want)
+        assert got == want
