@@ -188,6 +188,17 @@ def load(build_if_missing=True):
     L.sora_rx11b_synchronize.argtypes = [ctypes.c_void_p]
     L.sora_rx11b_process_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx11b_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
+    _res_of = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t]
+    _deliver = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    for pre in ("sora_rx11b", "sora_ht40"):
+        getattr(L, pre + "_ticket").argtypes = [ctypes.c_void_p]
+        getattr(L, pre + "_calls_in_flight").argtypes = [ctypes.c_void_p]
+        getattr(L, pre + "_wait").argtypes = [ctypes.c_void_p, ctypes.c_int]
+        getattr(L, pre + "_stream_of").argtypes = [ctypes.c_void_p, ctypes.c_int]; getattr(L, pre + "_stream_of").restype = ctypes.c_void_p
+        getattr(L, pre + "_results_of").argtypes = _res_of
+        getattr(L, pre + "_deliver_async").argtypes = _deliver
+    L.sora_rx11n_deliver_async.argtypes = _deliver
+    L.sora_rx11n_synchronize.argtypes = [ctypes.c_void_p]
     L.sora_rx11b_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                      ctypes.c_void_p, ctypes.c_size_t]
     _lib = L
@@ -632,7 +643,7 @@ class RxHt40:
                           buf.mpdu.ctypes.data if buf.mpdu is not None else None, buf.mpdu.size if buf.mpdu is not None else 0))
 
     def results(self, with_mpdu=True, ticket=None):
-        n2 = 2 * (self._n if ticket is None else self._nof[int(ticket)])
+        n2 = 2 * (self._n if ticket is None else self._nof.get(int(ticket), self.max_frames))
         res = (FrameResult * max(1, n2))(); n = ctypes.c_size_t(0)
         mp = np.zeros(n2 * 4096 if with_mpdu else 1, np.uint8)
         if ticket is None:

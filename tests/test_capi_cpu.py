@@ -135,3 +135,13 @@ int build_graph(sora_complex16* d_in, sora_complex16* d_fft, uint8_t* d_soft, ui
         r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), os.path.join(ROOT, "tests", "cxx", chain)],
                            capture_output=True, text=True)
         assert r.returncode == 0, r.stderr
+
+
+def test_every_bound_function_declares_its_argument_types():
+    """ctypes passes undeclared pointer arguments as C ints (truncated to 32 bits): every export the binding lists has argtypes."""
+    import sora_amd
+    from sora_amd import capi
+    L = sora_amd.load(build_if_missing=False)
+    no_args = {"sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count"}
+    missing = [n for n in capi.EXPORTS if n not in no_args and getattr(L, n).argtypes is None]
+    assert missing == ["sora_hip_memcpy_d2d"] or missing == [], missing      # (sora_hip_memcpy_d2d is for C hosts; the binding never calls it)
