@@ -321,6 +321,58 @@ def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
 
 
+def timed_with_delivery(sora_amd, rx, submit, depth, reps, rows_cap, mpdu_cap):
+    """The timed region of the widened rows, the headline's protocol: every step = one process call (submit() -> ticket) + deliver_async of
+    its dense rows and MPDUs into page-locked host memory behind its kernels + wait for the OLDEST call in flight and comparison of the
+    table it delivered (row bytes, MPDU bytes) with the first call's.  -> (ms per step, delivery object, the first call's result dicts)"""
+    bufs = [sora_amd.HostResults(rows_cap, mpdu_cap) for _ in range(depth)]
+    t = submit(); rx.deliver_async(t, bufs[0]); rx.wait(t)
+    first = bufs[0].results()
+    n, m = int(bufs[0].counts[0]), int(bufs[0].counts[1])
+    exp_rows = bufs[0].rows[:n].tobytes(); exp_mpdu = bufs[0].mpdu[:m].copy()
+    stat = {"delivered": 0, "bad": 0}
+
+    def consume(tk, b):
+        rx.wait(tk)
+        stat["delivered"] += 1
+        if int(b.counts[0]) != n or int(b.counts[1]) != m or b.rows[:n].tobytes() != exp_rows or not (b.mpdu[:m] == exp_mpdu).all():
+            stat["bad"] += 1
+
+    def block(k):
+        pend = []
+        for i in range(k):
+            tk = submit(); b = bufs[i % depth]
+            rx.deliver_async(tk, b); pend.append((tk, b))
+            if len(pend) >= depth:
+                consume(*pend.pop(0))
+        for tk, b in pend:
+            consume(tk, b)
+    block(depth + 2)                                                        # warm-up
+    t0 = time.perf_counter()
+    block(reps)
+    ms = (time.perf_counter() - t0) / reps * 1e3
+    out = {"enabled": True, "calls_delivered_and_compared": stat["delivered"], "calls_with_wrong_tables": stat["bad"], "rows_per_call": n, "mpdu_bytes_per_call": m,
+           "protocol": "every step = process call + deliver_async (dense rows + MPDUs to pinned host memory) + wait/compare of the oldest of %d calls in flight" % depth}
+    for b in bufs:
+        b.close()
+    return ms, out, first
+
+
+def reference_gate(first, ncaps, ref_events, same):
+    """Every capture of the batch against the compiled reference graph (ref_events(i) -> its events for capture i).  -> parity object"""
+    per = [[] for _ in range(ncaps)]
+    for r in first:
+        per[r["capture_id"]].append(r)
+    bad = 0; why0 = ""
+    for i in range(ncaps):
+        ok, why = same(per[i], ref_events(i))
+        if not ok:
+            bad += 1; why0 = why0 or "capture %d: %s" % (i, why)
+    if bad:
+        print("PARITY MISMATCH vs the reference graph: %d captures, first: %s" % (bad, why0), file=sys.stderr)
+    return {"against": "reference", "captures_checked": ncaps, "ok": bad == 0, "captures_with_differences": bad}
+
+
 def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True, rate_kbps=1000):
     """Row f4 (802.11b receive graph): `ncaps` 44 MHz captures of one 1 Mbps DBPSK frame each (the modulator output recorded
     in tests/golden/refgraph_11b.npz, or a 500-byte frame from the compiled reference modulator when that library is
@@ -346,19 +398,27 @@ def bench_11b(torch, sora_amd, dev, ncaps=8192, reps=5, cpu=True, rate_kbps=1000
     rx = sora_amd.Rx11b(ncaps, ncaps * n, max_frames_per_capture=4)
     flat = iq.view(-1, 2)
     torch.cuda.synchronize()                                            # the handle's stream does not follow torch's
-    rx.process_dev(flat, descs); res = rx.results()
-    ok = sum(r["error_code"] == 1 for r in res)
-    for _ in range(3):                                                  # (the first calls after a read-back of results run slow: not the kernel's doing)
-        rx.process_dev(flat, descs)
-    rx.synchronize(); reps = max(reps, 20)
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps):
-        rx.process_dev(flat, descs)
-    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    rx.wait_for_producer = False
+    depth = rx.calls_in_flight()
+    mlen = 500 if rate_kbps == 1000 else 1500
+    ms, delivery, first = timed_with_delivery(sora_amd, rx, lambda: rx.process_dev(flat, descs), depth, max(reps, 20), ncaps * 4, ncaps * (mlen + 4) + 4096)
+    ok = sum(r["error_code"] == 1 for r in first)
+    rx.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(10):                                                 # one call at a time, for the record
+        rx.wait(rx.process_dev(flat, descs))
+    ms1 = (time.perf_counter() - t0) / 10 * 1e3
     out = {"workload": "%d captures x one %s frame, %s, long preamble (%d samples @44 MHz each), AWGN" % (ncaps, "1 Mbps DBPSK" if rate_kbps == 1000 else "%g Mbps CCK" % (rate_kbps / 1000.0), what, n),
-           "ms": round(ms, 3), "calls_in_flight": 2, "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
+           "ms": round(ms, 3), "ms_one_call_in_flight": round(ms1, 3), "calls_in_flight": depth, "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 4 * ncaps * n, "achieved": round(4.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
-           "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
+           "unit": "GB/s", "frac": round(4.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4), "delivery": delivery}
+    if g.available():                                                   # the whole batch against the compiled reference graph, capture by capture
+        from gpu_util import same_as_reference_11b
+        host = iq.cpu().numpy()
+        out["parity"] = reference_gate(first, ncaps, lambda i: g.rx11b(host[i], max_frames=4), same_as_reference_11b)
+        del host
+    else:
+        out["parity"] = {"against": None, "captures_checked": 0, "ok": None, "note": "oracle/_ref/libsora_refgraph.so is not here"}
     if cpu and g.available():                                           # the reference's 11b graph on this box's host cores, side by side
         import multiprocessing as mp
         import tempfile
@@ -399,25 +459,35 @@ def bench_11n(torch, sora_amd, dev, ncaps=8192, reps=5):
     rx = sora_amd.Rx11n(ncaps, ncaps * n, max_frames_per_capture=4)
     f0 = iq[0].view(-1, 2); f1 = iq[1].view(-1, 2)
     torch.cuda.synchronize()
-    rx.process_dev(f0, f1, descs); res = rx.results()
-    ok = sum(r["error_code"] == 1 for r in res)
-    def timed(depth, reps=24):
-        rx.set_depth(depth)
-        for _ in range(depth + 2):                                           # (the first calls after a result read-back are slower: warm up, then time)
-            rx.process_dev(f0, f1, descs)
-        rx.synchronize()
-        torch.cuda.synchronize(); t0 = time.perf_counter()
-        tks = [rx.process_dev(f0, f1, descs) for _ in range(reps)]
-        rx.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3, tks
-    ms1, _ = timed(1)
-    ms, tks = timed(3)                                                       # three calls in flight on the handle's pipelines, every call collectable by its ticket
-    in_flight_ok = [sum(r["error_code"] == 1 for r in rx.results(ticket=t)) for t in tks[-3:]]
+    rx.wait_for_producer = False
+    mlen = 1000 if g.available() else 150
+    res = {}
+    for lanes in (64, 16):                                                   # both trellis kernels (sora_rx11n_set_trellis), three calls in flight
+        rx.set_trellis(lanes); rx.set_depth(3)
+        ms_, delivery_, first_ = timed_with_delivery(sora_amd, rx, lambda: rx.process_dev(f0, f1, descs), 3, max(reps, 24), ncaps * 4, ncaps * (mlen + 4) + 4096)
+        res[lanes] = (ms_, delivery_, first_)
+    best = min(res, key=lambda l: res[l][0])
+    ms, delivery, first = res[best]
+    ok = sum(r["error_code"] == 1 for r in first)
+    rx.set_trellis(best); rx.set_depth(1)
+    t0 = time.perf_counter()
+    for _ in range(10):
+        rx.wait(rx.process_dev(f0, f1, descs))
+    ms1 = (time.perf_counter() - t0) / 10 * 1e3
     out = {"workload": "%d two-chain captures x one MCS 10 frame, %s (%d samples @40 MHz per chain each), 2x2 cross-talk, AWGN" % (ncaps, what, n),
-           "ms": round(ms, 3), "ms_one_call_in_flight": round(ms1, 3), "calls_in_flight": 3, "frames_ok_last_calls_in_flight": in_flight_ok,
+           "ms": round(ms, 3), "ms_one_call_in_flight": round(ms1, 3), "calls_in_flight": 3, "trellis_kernel": {64: "k_viterbi11n", 16: "k_viterbi16_11n"}[best],
+           "ms_by_trellis_kernel": {"k_viterbi11n": round(res[64][0], 3), "k_viterbi16_11n": round(res[16][0], 3)},
            "msamples_per_s": round(ncaps * n / ms / 1e3, 1), "frames_ok": ok, "frames": ncaps,
            "bound": "hbm", "algorithmic_bytes": 8 * ncaps * n, "achieved": round(8.0 * ncaps * n / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
-           "unit": "GB/s", "frac": round(8.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4)}
+           "unit": "GB/s", "frac": round(8.0 * ncaps * n / (ms * 1e-3) / HBM_PEAK, 4), "delivery": delivery}
+    if g.available():                                                        # the whole batch against the compiled reference graph, capture by capture
+        from gpu_util import same_events_11n
+        h0 = iq[0].cpu().numpy(); h1 = iq[1].cpu().numpy()
+        out["parity"] = reference_gate(first, ncaps, lambda i: g.rx11n(h0[i], h1[i]), lambda got, want: same_events_11n(got, want, position="sample_index"))
+        out["parity"]["both_trellis_kernels_same_table"] = [(r["capture_id"], r["error_code"], r["crc32"], r["mpdu"]) for r in res[64][2]] == [(r["capture_id"], r["error_code"], r["crc32"], r["mpdu"]) for r in res[16][2]]
+        del h0, h1
+    else:
+        out["parity"] = {"against": None, "captures_checked": 0, "ok": None, "note": "oracle/_ref/libsora_refgraph.so is not here"}
     if g.available():
         import multiprocessing as mp
         import tempfile
@@ -520,22 +590,24 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
     descs = sora_amd.RxHt40.frames([(i * n, 6, 2, 1500, 1500, 0, 2 * sigma * sigma / 128.0, i) for i in range(nframes)])
     rx = sora_amd.RxHt40(nframes, nframes * 2 * (nsym * 648 + 64))
     f0 = iq[0].view(-1, 2); f1 = iq[1].view(-1, 2)
-    rx.process_dev(f0, f1, descs); res = rx.results()
-    ok = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] for r in res)
-    for _ in range(3):
-        rx.process_dev(f0, f1, descs)
-    rx.synchronize()
-    reps = 20
-    torch.cuda.synchronize(); t0 = time.perf_counter()
-    for _ in range(reps):
-        rx.process_dev(f0, f1, descs)
-    rx.synchronize(); ms = (time.perf_counter() - t0) / reps * 1e3
+    torch.cuda.synchronize()
+    rx.wait_for_producer = False
+    depth = rx.calls_in_flight()
+    res = {}
+    for lanes in (64, 16):
+        rx.set_trellis(lanes)
+        res[lanes] = timed_with_delivery(sora_amd, rx, lambda: rx.process_dev(f0, f1, descs), depth, 20, 2 * nframes, 2 * nframes * 1500 + 4096)
+    best = min(res, key=lambda l: res[l][0])
+    ms, delivery, first = res[best]
+    ok = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] for r in first)
     samples = nframes * (2 + nsym) * 160                                     # per chain, 40 MHz
     alg = 8.0 * samples + 2.0 * 1500 * nframes                               # both chains read once + the decoded PSDUs
     return {"workload": "%d frames x 2 spatial streams, 64-QAM 3/4, 1500-byte PSDU per stream (%d data symbols, %d samples @40 MHz per chain each), 2x2 cross-talk, AWGN; unbiased MMSE" % (nframes, nsym, (2 + nsym) * 160),
             "parity": "unpinned: the reference has no 40 MHz / MMSE / per-stream-decoder receiver; loop-back against oracle/py_ht40.py, the reference's own bricks inside are pinned (tests/test_gpu_ht40.py)",
-            "ms": round(ms, 3), "calls_in_flight": 3, "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
-            "psdus_ok": ok, "psdus": 2 * nframes, "bound": "hbm", "algorithmic_bytes": int(alg), "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+            "ms": round(ms, 3), "calls_in_flight": depth, "trellis_kernel": {64: "k_viterbi11n", 16: "k_viterbi16_11n"}[best],
+            "ms_by_trellis_kernel": {"k_viterbi11n": round(res[64][0], 3), "k_viterbi16_11n": round(res[16][0], 3)},
+            "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
+            "psdus_ok": ok, "psdus": 2 * nframes, "delivery": delivery, "bound": "hbm", "algorithmic_bytes": int(alg), "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
 
 
