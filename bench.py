@@ -45,7 +45,7 @@ FRAME_SAMPLES = 4880       # 160 STS + 160 LTS + 80 SIGNAL + 56*80 data @20 MHz
 CAPTURE_SAMPLES = 5040     # + 160 silence; 360 source bursts of 14
 ALG_BYTES_PER_SAMPLE = 4.0 + 216 / 8.0 / 80.0     # 4.3375
 HBM_PEAK = 8.0e12
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_m_traffic.json")     # rocprofv3 --pmc summary (tools/collect_profiles.sh)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_n_traffic.json")     # rocprofv3 --pmc summary (tools/collect_profiles.sh)
 
 
 def measured_traffic(kernel):
@@ -243,7 +243,7 @@ def valu_roofline(nframes, ms_step):
     peak = 256 * 4 * 2.4e9 / 2
     ach = n / (ms_step * 1e-3)
     return {"insts_per_call": n, "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-            "frac": round(ach / peak, 4), "dominant_kernel_insts": measured_valu("k_viterbi")}
+            "frac": round(ach / peak, 4), "dominant_kernel_insts": measured_valu("k_viterbi16") or measured_valu("k_viterbi")}
 
 
 def bench_stages(torch, sora_amd, dev, nsym=1 << 20, reps=10):

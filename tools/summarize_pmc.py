@@ -19,7 +19,9 @@ import sys
 from collections import defaultdict
 
 
-SCALAR_FED = ("k_viterbi", "k_viterbi11n")          # bulk input through s_load (dev_viterbi.h): FETCH_SIZE counts those requests in full
+SCALAR_FED = ()          # round 2: k_viterbi read 32-byte pieces with s_load_dwordx8 and FETCH_SIZE counted them in full.  Round 3: it reads whole 64-byte
+                         # lines (s_load_dwordx16 of the pair stream) and its raw FETCH_SIZE equals k_viterbi16's, which reads the SAME 132 MB with
+                         # vector loads (profiles/r03_n_traffic.json: 66.7 vs 66.1 MB raw) -- the half-tally applies to both, so both are doubled.
 
 
 def per_kernel(path, counter):
@@ -39,10 +41,11 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     out = {"unit": "bytes per launch", "frames_per_launch": frames,
-           "corrections": "FETCH_SIZE KiB x1024, x2 for kernels fed by vector loads, x1 for kernels fed by scalar loads (k_viterbi, k_viterbi11n); WRITE_SIZE KiB x1024 as reported; factors measured by tools/calib/fetch_calib (profiles/r02_k_calibration.json)",
+           "corrections": "FETCH_SIZE KiB x1024 x2 (the guide's gfx950 correction; round 3: also for k_viterbi, whose 64-byte scalar loads are tallied like vector loads -- its raw count equals k_viterbi16's for the same 132 MB stream); WRITE_SIZE KiB x1024 as reported; factors measured by tools/calib/fetch_calib (profiles/r02_k_calibration.json)",
            "kernels": {}}
     total = 0.0
-    rx_path = ("k_scan", "k_frame", "k_viterbi", "k_decode", "k_finish")      # one receive call (split or fused chain); other kernels (k_pack, ingest, tx) are listed only
+    trellis = sys.argv[5] if len(sys.argv) > 5 else "k_viterbi16"             # the trellis kernel of the call being summed (the run also holds a few launches of the other one)
+    rx_path = ("k_scan", "k_frame", trellis, "k_decode", "k_finish")           # one receive call (split or fused chain); other kernels (k_pack, ingest, tx) are listed only
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
@@ -60,6 +63,7 @@ def main():
             if k in rx_path:
                 tv += valu.get(k, (0.0, 0))[0]
         out["total_valu_insts_per_call"] = round(tv)
+    out["receive_call_sums"] = list(rx_path)
     out["total_hbm_bytes_per_call"] = round(total)
     out["algorithmic_bytes_per_call"] = round(frames * 4880 * 4.3375)
     json.dump(out, sys.stdout, indent=1)
