@@ -359,6 +359,20 @@ int   sora_ht40_synchronize(sora_ht40_t* rx);                                   
                                                                                                         * process_dev waits only for the call three calls back; results reports the most recent one) */
 int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);
 int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
+/* The same receiver on RAW CAPTURES, as every other handle takes its input: two-chain 40 MHz captures (whole 28-sample source bursts,
+ * offsets a multiple of 4) in, the front end finds the frames.  The legacy preamble and HT-SIG of an HT-mixed 40 MHz frame are the 20 MHz
+ * waveforms sent on both halves of the channel (the upper one rotated by 90 degrees), so the even samples of x[n] j^n are (1 + j) times
+ * the 20 MHz legacy waveform and the reference's own bricks apply unchanged: TCCA11n (cca_11n.hpp:5-171), the L-LTF frequency offset
+ * (freqoffset_11n.hpp:86-280), TSisoChannelEst / Comp, T11nSigDemap, the SIG decoder and T11nSigParser (PHY_11n.hpp:400-514) with one
+ * gate relaxed -- MCS 8..14 at CBW 40 and LENGTH <= 4000 are accepted where PHY_11n.hpp:497-505 accepts MCS 8..10 and 1500.  Own
+ * definitions (parity unpinned): each spatial stream carries its own PSDU of HT-SIG's LENGTH through its own encoder (configs[3]'s
+ * "dual Viterbi"), the CFO handed to the data field is the L-LTF estimate, the noise variance the MMSE detector uses is estimated from
+ * the difference of the two L-LTF symbols.  Rows: per event in (capture, time) order; a recorded frame reports two rows (start_sample =
+ * spatial stream, rate_kbps = MCS, end_sample = 40 MHz source position of the event, FRAME_OK / CRC32_FAIL), a header that fails one row
+ * (SORA_E_PLCP_HEADER_FAIL); a frame the capture cuts off raises no event.  Tickets / results_of / deliver_async as above.  One host
+ * wait per call, between the front end and the data field. */
+int   sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* h_caps, size_t ncaps,
+                                     uint32_t max_frames_per_capture);
 /* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_ht40_calls_in_flight() (3) further calls have reused its
  * slot -- so back-to-back calls are all collectable, each by its own ticket, while later ones run.  The INPUT buffers of a call must stay
  * untouched until sora_ht40_wait(its ticket) (or _results_of, or _synchronize) has returned. */

@@ -174,3 +174,102 @@ def mmse_weights(Y, noise_var):
         Wb = np.linalg.solve(G, H.conj().T)
         W[b] = Wb / np.real(np.diag(Wb @ H))[:, None]                                                # unbiased MMSE
     return W
+
+
+# ------------------------------------------------------------------------------------------------ the preamble (HT-mixed format, 40 MHz)
+# IEEE 802.11n-2009 20.3.9: L-STF, L-LTF, L-SIG and HT-SIG are the 20 MHz legacy waveforms sent on BOTH halves of the 40 MHz channel,
+# the upper half rotated by +90 degrees; then HT-STF (4 us), the HT-LTFs and the data field at the full width.  Both TX chains send the
+# same legacy part (no cyclic shifts in this model).  What a receiver gets from this: a 20 MHz front end that reads the even samples of
+# y[n] = x[n] j^n (a shift by +10 MHz: the lower copy lands on DC, the upper copy aliases onto it) sees (1 + j) times the 20 MHz legacy
+# waveform through the channel H_lower + j H_upper -- so the reference's own 802.11n front end (carrier sense, L-LTF, the SIG decoder and
+# T11nSigParser, kernel/bb/Brick11/src/PHY_11n.hpp:400-514) finds and parses it unchanged; oracle-side that is how this part is PINNED
+# (tests/test_ht40_preamble_model.py runs the restated reference receiver on it).
+_STF = np.zeros(53, complex)
+for _k, _v in zip(range(-24, 25, 4), [1, -1, 1, -1, -1, 1, 0, -1, -1, 1, 1, 1, 1]):
+    _STF[_k + 26] = _v * (1 + 1j) * np.sqrt(13.0 / 6.0) * np.sqrt(0.5)
+_LTF = np.array([1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 0,
+                 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1], float)
+_LEG_DATA = [k for k in range(-26, 27) if k not in (-21, -7, 0, 7, 21)]
+# two-stream MCS 8..14 -> (N_BPSC, code rate index); MCS 15 (5/6) has no decoder here
+MCS2 = {8: (1, 0), 9: (2, 0), 10: (2, 2), 11: (4, 0), 12: (4, 2), 13: (6, 1), 14: (6, 2)}
+
+
+def _dup40(sym20):
+    """53 legacy carriers (-26..26) -> 128-bin spectrum of the 40 MHz channel: lower copy at -32 + k, upper copy at +32 + k times j"""
+    X = np.zeros(128, complex)
+    for i, k in enumerate(range(-26, 27)):
+        X[(k - 32) % 128] = sym20[i]
+        X[(k + 32) % 128] = 1j * sym20[i]
+    return X
+
+
+def _leg_symbol(coded48, qbpsk, amp):
+    il = np.zeros(48)
+    k = np.arange(48)
+    il[3 * (k % 16) + k // 16] = coded48                                     # the 11a BPSK interleaver (N_CBPS 48): receiver side k <- 3 (k & 15) + (k >> 4)
+    s = np.zeros(53, complex)
+    for c, kk in enumerate(_LEG_DATA):
+        v = (2.0 * il[c] - 1.0) * amp
+        s[kk + 26] = 1j * v if qbpsk else v
+    for kk, p in zip((-21, -7, 7, 21), (1, 1, 1, -1)):
+        s[kk + 26] = p * amp
+    return s
+
+
+def ht_sig_bits(mcs, length, cbw40=1):
+    b = np.zeros(48, np.uint8)
+    for i in range(7): b[i] = (mcs >> i) & 1
+    b[7] = cbw40
+    for i in range(16): b[8 + i] = (length >> i) & 1
+    b[24] = 1; b[25] = 1; b[26] = 1                                          # smoothing, not sounding, reserved
+    crc = 0xFF                                                               # CRC-8 over bits 0..33 exactly as T11nSigParser recomputes it (PHY_11n.hpp:486-492)
+    for i in range(34):
+        crc ^= int(b[i])
+        crc = (crc >> 1) ^ 0xE0 if crc & 1 else crc >> 1
+    c = (~crc) & 0xFF
+    for i in range(8): b[34 + i] = (c >> i) & 1
+    return b
+
+
+def l_sig_bits(l_length):
+    b = np.zeros(24, np.uint8)
+    b[0], b[1], b[2], b[3] = 1, 1, 0, 1                                      # RATE = 6 Mbps
+    for i in range(12): b[5 + i] = (l_length >> i) & 1
+    b[17] = int(b[:17].sum() & 1)
+    return b
+
+
+def tx_frame(psdus, mcs, seeds=(0x5D, 0x2B), sig_amp=1.0):
+    """A whole HT-mixed 40 MHz two-stream frame: L-STF, L-LTF, L-SIG, HT-SIG, HT-STF, 2 x HT-LTF, data.  psdus: two byte strings WITH FCS
+    and of EQUAL length (the HT-SIG LENGTH field is one number; each spatial stream carries its own PSDU of that length through its own
+    encoder -- BASELINE.json configs[3]'s 'dual Viterbi').  -> (complex128 [2, n] @40 MHz, nsym, first sample of HT-LTF 1)."""
+    assert len(psdus[0]) == len(psdus[1]) and mcs in MCS2
+    nb, cr = MCS2[mcs]
+    data, nsym = tx(psdus, nb, cr, seeds)
+    dur_us = 36 + 4 * nsym                                                   # L-STF 8, L-LTF 8, L-SIG 4, HT-SIG 8, HT-STF 4, HT-LTFs 8 -> 40; the legacy part announces what follows L-SIG
+    l_length = max(1, -(-(dur_us + 4 - 20) // 4) * 3 - 3)
+    parts = []
+    stf = np.fft.ifft(_dup40(_STF)) * 128.0
+    parts.append(np.tile(stf, 3)[:320])                                      # 8 us: the 0.8 us pattern repeats (period 32 samples @40 MHz)
+    ltf = np.fft.ifft(_dup40(_LTF)) * 128.0
+    parts.append(np.concatenate([ltf[-64:], ltf, ltf]))                      # GI2 + two long symbols
+    a, b = encode(np.concatenate([l_sig_bits(l_length)]))
+    sym = np.fft.ifft(_dup40(_leg_symbol(np.stack([a, b], 1).reshape(-1), False, sig_amp))) * 128.0
+    parts.append(np.concatenate([sym[-32:], sym]))
+    a, b = encode(ht_sig_bits(mcs, len(psdus[0])))
+    coded = np.stack([a, b], 1).reshape(-1)
+    for h in range(2):
+        sym = np.fft.ifft(_dup40(_leg_symbol(coded[48 * h:48 * h + 48], True, sig_amp))) * 128.0
+        parts.append(np.concatenate([sym[-32:], sym]))
+    parts.append(np.tile(stf, 2)[:160])                                      # HT-STF (the duplicated short symbol: the receiver only needs its place)
+    pre = np.concatenate(parts)
+    x = np.concatenate([np.stack([pre, pre]), data], axis=1)
+    return x, nsym, len(pre)
+
+
+def front_end_view(iq):
+    """What the reused 20 MHz front end reads: the even samples of x[n] j^n = (-1)^m x[2m], as a 40 MHz-rate capture whose even samples
+    carry it (the reference's TDownSample2 keeps the even samples).  iq: int16 [n, 2] -> int16 [n, 2]"""
+    z = np.asarray(iq, np.int32).copy()
+    z[2::4] = np.clip(-z[2::4], -32768, 32767)                                # m odd <-> n = 2m = 2 mod 4
+    return z.astype(np.int16)

@@ -57,7 +57,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_wait", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
            "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
-           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_stream_of", "sora_ht40_results_of",
+           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_process_captures_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_stream_of", "sora_ht40_results_of",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results", "sora_shard_gather_results_mpdu"]
 
@@ -190,6 +190,7 @@ def load(build_if_missing=True):
     L.sora_rx11b_process.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     _res_of = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t), ctypes.c_void_p, ctypes.c_size_t]
     _deliver = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t]
+    L.sora_ht40_process_captures_dev.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint32]
     for pre in ("sora_rx11b", "sora_ht40"):
         getattr(L, pre + "_ticket").argtypes = [ctypes.c_void_p]
         getattr(L, pre + "_calls_in_flight").argtypes = [ctypes.c_void_p]
@@ -626,6 +627,16 @@ class RxHt40:
         self._nof = getattr(self, "_nof", {}); self._nof[t] = n
         for old in [k for k in self._nof if k <= t - 8]:
             del self._nof[old]
+        return t
+
+    def process_captures_dev(self, d_iq0, d_iq1, captures, max_frames_per_capture=4):
+        """raw two-chain 40 MHz captures [(offset, nsamples[, id])]: the front end finds, parses and measures the frames"""
+        arr, ptr = Rx._caps(captures)
+        _hold(self, (d_iq0, d_iq1))
+        _check(self._L.sora_ht40_process_captures_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), ptr, len(arr), int(max_frames_per_capture)))
+        t = self._L.sora_ht40_ticket(self._h)
+        self._n = len(arr) * int(max_frames_per_capture)
+        self._nof = getattr(self, "_nof", {}); self._nof[t] = self._n
         return t
 
     def ticket(self):

@@ -264,12 +264,17 @@ using namespace sora;
 // slot three calls ago, so the host's part of call n + 1 (job tables, four small copies) and the tail of call n's kernels overlap call n + 1's
 // kernels.  sora_ht40_results reports the most recent call.
 static constexpr int kHt40Slots = 3;
+struct Ht40Event { uint32_t capture_id, end_sample, error_code, mcs, length, nsym; int frame; bool truncated; };   // frame: index into the call's described frames, -1 = header failed
 struct Ht40Slot {
     hipStream_t stream = nullptr;
     Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
     uint32_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
     std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0;
     int ticket = 0;             // of the call this slot holds (0: none)
+    // sora_ht40_process_captures_dev: the front end's arrays (grow-only) and what it found in this slot's call
+    CapDesc* d_caps = nullptr; size_t caps_bytes = 0; Rx11bRow* d_scanrows = nullptr; size_t scanrows_bytes = 0;
+    uint32_t* d_nfr = nullptr; size_t nfr_bytes = 0; Ht40Found* d_found = nullptr; size_t found_bytes = 0;
+    bool capture_mode = false; uint32_t capture_mf = 0; std::vector<Ht40Event> events;
     DenseStage dense;           // sora_ht40_deliver_async
     std::vector<sora_frame_result> h_tmpl;                                      // what the rows of this call carry besides the decoder's verdict
 };
@@ -291,6 +296,7 @@ static void ht40_free(sora_ht40_t* rx)
         (void)hipFree(S.d_frames); (void)hipFree(S.d_jobs); (void)hipFree(S.d_njobs); (void)hipFree(S.d_fjobs); (void)hipFree(S.d_soft);
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
         sora_internal_dense_free(&S.dense);
+        (void)hipFree(S.d_caps); (void)hipFree(S.d_scanrows); (void)hipFree(S.d_nfr); (void)hipFree(S.d_found);
     }
     delete rx;
 }
@@ -353,13 +359,10 @@ int sora_ht40_synchronize(sora_ht40_t* rx)
     return SORA_OK;
 }
 
-int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
+// the data field of `nframes` described frames on slot S (its stream is idle): descriptors -> device, k_ht40_frame, the trellis kernel, k_ht40_finish
+static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
 {
-    if (!rx || (nframes && (!d_iq0 || !d_iq1 || !frames))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: null argument", 0);
     if (nframes > rx->max_frames) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more frames than max_frames", 0);
-    HIPCHK40(hipSetDevice(rx->device));
-    Ht40Slot& S = rx->slot[rx->next];
-    HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
     std::vector<Ht40Frame> hf(nframes); std::vector<VitJob> hj(3 * 2 * (size_t)rx->max_frames); std::vector<Ht40Job> fj(2 * nframes);
     uint32_t nj[4] = { 0, 0, 0, 0 };
     uint64_t soft = 0;
@@ -405,8 +408,104 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
     return SORA_OK;
 }
 
+int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
+{
+    if (!rx || (nframes && (!d_iq0 || !d_iq1 || !frames))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: null argument", 0);
+    HIPCHK40(hipSetDevice(rx->device));
+    Ht40Slot& S = rx->slot[rx->next];
+    HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
+    S.events.clear(); S.capture_mode = false;
+    return ht40_submit(rx, S, d_iq0, d_iq1, frames, nframes, d_weights);
+}
+
+// ---- the same receiver on RAW CAPTURES (BASELINE configs[3] as every other handle takes its input): two-chain 40 MHz captures in, the
+// front end (k_scan_ht40 in k_rx11n.hip: the reference's 20 MHz carrier sense / L-LTF / SIG bricks on the duplicated legacy preamble)
+// finds the frames, parses HT-SIG and estimates CFO and noise variance; the frame records come back to the host, which describes the data
+// fields to the kernels above.  One host wait per call, between the scan and the data field (the data field of call k still overlaps
+// the scan of call k + 1).  Rows: per event in (capture, time) order -- a recorded frame reports two rows (start_sample = spatial stream
+// 0 / 1, rate_kbps = MCS, end_sample = the 40 MHz source position of the event), a header that fails one row with SORA_E_PLCP_HEADER_FAIL.
+int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps, uint32_t max_frames_per_capture)
+{
+    if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps)) || max_frames_per_capture == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_captures_dev: bad argument", 0);
+    if ((uint64_t)ncaps * max_frames_per_capture >= (1ull << 31)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: too many rows", 0);
+    HIPCHK40(hipSetDevice(rx->device));
+    Ht40Slot& S = rx->slot[rx->next];
+    HIPCHK40(hipStreamSynchronize(S.stream));
+    const uint32_t mf = max_frames_per_capture;
+    const size_t nrows = ncaps * (size_t)mf;
+    std::vector<CapDesc> hc(ncaps);
+    for (size_t i = 0; i < ncaps; i++) {
+        if (caps[i].offset & 3) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture offset must be a multiple of 4 samples", 0);
+        if (caps[i].nsamples % 28) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture length must be a whole number of 28-sample source bursts", 0);
+        hc[i].offset = caps[i].offset; hc[i].nsamples = caps[i].nsamples; hc[i].capture_id = caps[i].capture_id; hc[i].slot_base = 0; hc[i].nslots = 0;
+    }
+    S.events.clear(); S.capture_mode = true; S.capture_mf = mf;
+    if (ncaps == 0) return ht40_submit(rx, S, d_iq0, d_iq1, nullptr, 0, nullptr);
+    auto grow = [](void** p, size_t* have, size_t need) -> bool { if (*have >= need) return true; if (*p) (void)hipFree(*p); *p = nullptr; *have = 0; if (hipMalloc(p, need) != hipSuccess) return false; *have = need; return true; };
+    if (!grow((void**)&S.d_caps, &S.caps_bytes, sizeof(CapDesc) * ncaps) || !grow((void**)&S.d_scanrows, &S.scanrows_bytes, sizeof(Rx11bRow) * nrows) ||
+        !grow((void**)&S.d_nfr, &S.nfr_bytes, 4 * ncaps) || !grow((void**)&S.d_found, &S.found_bytes, sizeof(Ht40Found) * nrows))
+        return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_process_captures_dev: device allocation", 0);
+    HIPCHK40(hipMemcpyAsync(S.d_caps, hc.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
+    HIPCHK40(hipMemsetAsync(S.d_nfr, 0, 4 * ncaps, S.stream));
+    { const int rc = sora_internal_scan_ht40(reinterpret_cast<const uint32_t*>(d_iq0), reinterpret_cast<const uint32_t*>(d_iq1), S.d_caps, (uint32_t)ncaps, mf, S.d_scanrows, S.d_nfr, S.d_found,
+                                             rx->T, rx->sincos, rx->atan, S.stream); if (rc) return rc; }
+    std::vector<uint32_t> nfr(ncaps); std::vector<Ht40Found> found(nrows);
+    HIPCHK40(hipMemcpyAsync(nfr.data(), S.d_nfr, 4 * ncaps, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK40(hipMemcpyAsync(found.data(), S.d_found, sizeof(Ht40Found) * nrows, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK40(hipStreamSynchronize(S.stream));                                      // (the stream just copied hc / found: they may go out of scope)
+    std::vector<sora_ht40_frame> fr;
+    for (size_t c = 0; c < ncaps; c++) {
+        const uint32_t n = std::min(nfr[c], mf);
+        for (uint32_t i = 0; i < n; i++) {
+            const Ht40Found& F = found[c * mf + i];
+            Ht40Event E; E.capture_id = caps[c].capture_id; E.end_sample = F.end_sample; E.error_code = F.error_code; E.mcs = F.mcs; E.length = F.ht_len; E.nsym = F.nsym; E.frame = -1;
+            E.truncated = (i + 1 == mf && nfr[c] > mf);
+            if (F.error_code == 0) {
+                sora_ht40_frame f; memset(&f, 0, sizeof(f));
+                f.offset = caps[c].offset + 2ull * F.a20 + 160;                  // HT-STF is 4 us = 160 samples @40 MHz; HT-LTF 1 follows
+                f.n_bpsc = F.mcs == 8 ? 1u : F.mcs <= 10 ? 2u : F.mcs <= 12 ? 4u : 6u;
+                f.code_rate = (F.mcs == 10 || F.mcs == 12 || F.mcs == 14) ? 2u : F.mcs == 13 ? 1u : 0u;
+                f.length[0] = f.length[1] = F.ht_len;                            // one HT-SIG LENGTH: each stream carries its own PSDU of that length (oracle/py_ht40.py tx_frame)
+                f.cfo = F.cfo / 2;                                               // per 20 MHz sample -> per 40 MHz sample
+                f.noise_var = F.noise_var; f.frame_id = (uint32_t)S.events.size();
+                E.frame = (int)fr.size(); fr.push_back(f);
+            }
+            S.events.push_back(E);
+        }
+    }
+    return ht40_submit(rx, S, d_iq0, d_iq1, fr.data(), fr.size(), nullptr);
+}
+
 static int ht40_slot_results(sora_ht40_t* rx, Ht40Slot& S, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
 {
+    if (S.capture_mode) {                                                        // rows per event of the front end, in (capture, time) order
+        HIPCHK40(hipSetDevice(rx->device));
+        HIPCHK40(hipStreamSynchronize(S.stream));
+        const size_t nj = 2 * (size_t)S.nframes;
+        std::vector<Rx11bRow> rows(nj);
+        if (nj) HIPCHK40(hipMemcpy(rows.data(), S.d_rows, sizeof(Rx11bRow) * nj, hipMemcpyDeviceToHost));
+        std::vector<uint8_t> bulk;
+        if (h_mpdu && nj) { bulk.resize(nj * 4096); HIPCHK40(hipMemcpy(bulk.data(), S.d_mpdu, bulk.size(), hipMemcpyDeviceToHost)); }
+        size_t n = 0, moff = 0;
+        for (const Ht40Event& E : S.events) {
+            for (int k = 0; k < (E.frame >= 0 ? 2 : 1); k++) {
+                if (n >= max_out) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: output buffer too small", 0);
+                sora_frame_result& o = out[n++];
+                memset(&o, 0, sizeof(o));
+                o.capture_id = E.capture_id; o.end_sample = E.end_sample; o.error_code = E.error_code; o.flags = E.truncated ? SORA_ROW_TRUNCATED : 0; o.mpdu_offset = (uint32_t)moff;
+                if (E.frame >= 0) {
+                    const Rx11bRow& r = rows[2 * (size_t)E.frame + k];
+                    o.start_sample = (uint32_t)k; o.rate_kbps = E.mcs; o.nsym = (uint16_t)E.nsym; o.error_code = r.error_code; o.length = (uint16_t)r.length; o.crc32 = r.crc32;
+                    if (h_mpdu) {
+                        if (moff + r.length > mpdu_cap) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: MPDU buffer too small", 0);
+                        memcpy(h_mpdu + moff, bulk.data() + (2 * (size_t)E.frame + k) * 4096, r.length); moff += r.length;
+                    }
+                }
+            }
+        }
+        *nout = n;
+        return SORA_OK;
+    }
     if (S.nframes == 0) return SORA_OK;
     HIPCHK40(hipSetDevice(rx->device));
     HIPCHK40(hipStreamSynchronize(S.stream));
@@ -471,6 +570,10 @@ int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_ro
         memset(&o, 0, sizeof(o));
         o.capture_id = f.frame_id; o.start_sample = (uint32_t)(j & 1); o.rate_kbps = f.n_bpsc * 10 + f.code_rate;
         o.nsym = (uint16_t)sora_ht40_symbols(f.length[0], f.length[1], f.n_bpsc, f.code_rate);
+        if (S->capture_mode) {                                                  // (raw captures: the decoded frames' rows as sora_ht40_results reports them; failed headers have no MPDU and are not delivered)
+            const Ht40Event& E = S->events[f.frame_id];
+            o.capture_id = E.capture_id; o.end_sample = E.end_sample; o.rate_kbps = E.mcs;
+        }
     }
     // two rows per frame, always: "captures" = frames, max_frames_per_capture = 2, no per-capture counts.  (The template is read by an
     // asynchronous copy: it lives in the slot until the slot's next call.)

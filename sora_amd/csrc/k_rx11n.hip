@@ -640,7 +640,16 @@ struct FrameLds {
 };
 }  // namespace
 
-__global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
+// HT40 = false: the reference's 20 MHz graph (k_scan11n).  HT40 = true: the same front end on the legacy part of an HT-mixed 40 MHz frame
+// (k_scan_ht40): the legacy preamble and HT-SIG are the 20 MHz waveforms sent on both halves of the channel, the upper one rotated by
+// 90 degrees, so the even samples of x[n] j^n -- (-1)^m x[2m]: a sign per sample -- are (1 + j) times the 20 MHz legacy waveform and
+// every brick up to T11nSigParser applies unchanged (oracle/py_ht40.py tx_frame / front_end_view; tests/test_ht40_preamble_model.py
+// runs the restated reference receiver on it).  What differs behind the parser: MCS 8..14 at CBW 40 and lengths up to 4000 are
+// accepted (PHY_11n.hpp:497 accepts 8..10 at 1500), and instead of queueing a 20 MHz data field the frame is recorded for the 40 MHz
+// data-field kernels (k_ht40.hip) with what they need from here: position, CFO (per 40 MHz sample) and the noise variance, estimated
+// from the difference of the two L-LTF symbols.  That part is this library's own definition: parity unpinned.
+template <bool HT40>
+__device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* found)
 {
     __shared__ ScanLds s_w[4];
     __shared__ uint8_t s_lut[6][256];
@@ -653,7 +662,12 @@ __global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
     const CapDesc cd = A.caps[cap];
     const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
     const uint32_t n20 = cd.nsamples / 2;
-    auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t { return i < n20 ? iq[r][2 * (size_t)i] : 0u; };
+    auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t {
+        if (i >= n20) return 0u;
+        const uint32_t v = iq[r][2 * (size_t)i];
+        if (HT40 && (i & 1u)) { const cpx c = unpack(v); return pack(mk(sat16(-c.re), sat16(-c.im))); }     // x[2m] (-1)^m
+        return v;
+    };
     const Fft64Tw tw = fft64_twiddles(A.T, lane & 15);
     auto nosync = []() __attribute__((always_inline)) { wsync(); };
 
@@ -771,6 +785,21 @@ __global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
             for (int q = 0; q < 4; q++) W.y[g >> 1][64 * (g & 1) + e + 16 * q] = pack(yy[q]);
         }
         wsync();
+        float noise_var = 0.0f;
+        if (HT40) {                                                          // the two L-LTF symbols differ by noise only: E|Y1 - Y2|^2 = 2 var(FFT<64> bin); an FFT<128> bin of the
+            float acc = 0.0f;                                                // 40 MHz stream carries half that (same noise per sample, twice the 1/N), so noise_var = sum / (4 x 104 bins)
+            if (lane != 0 && (lane < 27 || lane >= 38)) {
+#pragma unroll
+                for (int r = 0; r < 2; r++) {
+                    const cpx p = unpack(W.y[r][lane]), q = unpack(W.y[r][64 + lane]);
+                    const float dr = (float)(p.re - q.re), di = (float)(p.im - q.im);
+                    acc += dr * dr + di * di;
+                }
+            }
+#pragma unroll
+            for (int d = 32; d >= 1; d >>= 1) acc += __shfl_xor(acc, d);
+            noise_var = acc * (1.0f / 416.0f);
+        }
 #pragma unroll
         for (int r = 0; r < 2; r++) {
             uint32_t o = 0;
@@ -848,10 +877,15 @@ __global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
                 for (int b = 0; b < 34; b++) { crc ^= (uint32_t)(ht >> b) & 1; crc = (crc & 1) ? (crc >> 1) ^ 0xE0 : crc >> 1; }
                 if (((~crc) & 0xFF) != (uint32_t)((ht >> 34) & 0x3FFF)) break;
                 const uint32_t mc = (uint32_t)ht & 0x7F;
-                if (mc < 8 || mc >= 11) break;
                 const uint32_t hl = (uint32_t)(ht >> 8) & 0xFFFF;
-                if (hl > 1500) break;
-                mcs = mc; ht_len = hl; code_rate = mc == 10 ? 2u : 0u;
+                if (HT40) {
+                    if (mc < 8 || mc > 14 || !((ht >> 7) & 1) || hl > 4000 || hl < 4) break;     // two streams, 40 MHz, a rate this library has a decoder for
+                    mcs = mc; ht_len = hl; code_rate = (mc == 10 || mc == 12 || mc == 14) ? 2u : mc == 13 ? 1u : 0u;
+                } else {
+                    if (mc < 8 || mc >= 11) break;
+                    if (hl > 1500) break;
+                    mcs = mc; ht_len = hl; code_rate = mc == 10 ? 2u : 0u;
+                }
                 sig_ok = true;
             } while (0);
             if (!sig_ok) err = E_PLCP;
@@ -861,6 +895,15 @@ __global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
         bool event = false, queue = false;
         uint32_t nproc = 0, nsoft = 0;
         if (decoded && err != 0) { event = true; last_burst_end = at_end ? n_pad : min(a, n_pad); }
+        else if (HT40 && decoded && !at_end) {
+            // HT-STF at a, HT-LTF 1 / 2 at a + 80 / a + 160, data symbol d at a + 240 + 80 d (20 MHz indices; 4 us symbols).  The frame is
+            // recorded when all of it lies inside the capture; a frame the capture cuts off raises no event (as the 20 MHz graph behaves).
+            const uint32_t nb = mcs == 8 ? 1u : mcs <= 10 ? 2u : mcs <= 12 ? 4u : 6u;
+            const uint32_t ndbps = 108u * nb * (code_rate == 0 ? 1u : code_rate == 1 ? 2u : 3u) / (code_rate == 0 ? 2u : code_rate == 1 ? 3u : 4u);
+            const uint32_t nsym = (16u + 8u * ht_len + 6u + ndbps - 1u) / ndbps;
+            nproc = nsym;
+            if (a + 240 + 80 * nsym <= n_real) { event = true; queue = true; last_burst_end = a + 240 + 80 * nsym; }
+        }
         else if (decoded && !at_end) {
             // HT-STF at a, HT-LTF at a + 80 / a + 160, data symbol d at a + 240 + 80 d; a symbol is processed when it starts inside the
             // padded capture (its missing samples read as zero: the flush of the partly filled queues)
@@ -887,7 +930,11 @@ __global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
             if (lane == 0) {
                 Rx11bRow r; r.end_sample = 2 * next; r.error_code = queue ? 0u : err; r.rate_kbps = queue ? mcs : 0u; r.length = queue ? ht_len : 0u; r.crc32 = 0u;
                 rows[nfr] = r;
-                if (queue) {
+                if (HT40) {
+                    Ht40Found F; F.a20 = origin + a; F.mcs = queue ? mcs : 0u; F.ht_len = queue ? ht_len : 0u; F.cfo = cfo; F.noise_var = noise_var;
+                    F.end_sample = 2 * next; F.error_code = queue ? 0u : err; F.nsym = queue ? nproc : 0u;
+                    found[row] = F;
+                } else if (queue) {
                     const uint32_t list = code_rate;
                     const uint32_t idx = atomicAdd(&A.njobs[list], 1u);
                     N11Frame F; F.cap = cap; F.row = row; F.l0 = origin + l0; F.cfo = cfo; F.mcs = mcs; F.ht_len = ht_len; F.code_rate = code_rate;
@@ -905,6 +952,25 @@ __global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A)
     }
     if (lane == 0) A.nframes[cap] = nfr;
 }
+
+__global__ void __launch_bounds__(256) k_scan11n(Scan11nArgs A) { scan11n_body<false>(A, nullptr); }
+// The front end of the 40 MHz HT receiver (sora_ht40_process_captures_dev, k_ht40.hip): carrier sense, L-LTF, L-SIG / HT-SIG on the
+// duplicated legacy preamble -> one Ht40Found record per event.
+__global__ void __launch_bounds__(256) k_scan_ht40(Scan11nArgs A, Ht40Found* found) { scan11n_body<true>(A, found); }
+
+}  // namespace sora
+int sora_internal_scan_ht40(const uint32_t* iq0, const uint32_t* iq1, const sora::CapDesc* d_caps, uint32_t ncaps, uint32_t max_frames, sora::Rx11bRow* d_rows, uint32_t* d_nframes,
+                            sora::Ht40Found* d_found, const sora::Tables& T, const uint32_t* sincos, const short* atan, hipStream_t st)
+{
+    using namespace sora;
+    Scan11nArgs S{};
+    S.iq0 = iq0; S.iq1 = iq1; S.caps = d_caps; S.ncaps = ncaps; S.max_frames = max_frames; S.rows = d_rows; S.nframes = d_nframes; S.T = T; S.sincos = sincos; S.atan = atan;
+    S.frames = nullptr; S.jobs = nullptr; S.njobs = nullptr; S.nrows = ncaps * max_frames;
+    hipLaunchKernelGGL(k_scan_ht40, dim3((ncaps + 3) / 4), dim3(256), 0, st, S, d_found);
+    const hipError_t e = hipGetLastError();
+    return e == hipSuccess ? SORA_OK : sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "k_scan_ht40", (int)e);
+}
+namespace sora {
 
 __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
 {

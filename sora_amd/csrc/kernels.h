@@ -94,7 +94,20 @@ struct Rx11bArgs {
 __global__ void k_rx11b(Rx11bArgs A);
 __global__ void k_rx11b_cck(Rx11bArgs A);
 
+// one event of the 40 MHz HT front end (k_scan_ht40 in k_rx11n.hip), row cap * max_frames + i
+struct Ht40Found {
+    uint32_t a20;                  // 20 MHz index (in the capture) of the first HT-STF sample: HT-LTF 1 starts 2 * a20 + 160 samples @40 MHz into the capture
+    uint32_t mcs, ht_len, nsym;    // 0 unless the frame was recorded
+    int32_t  cfo;                  // phase step per 20 MHz sample, 65536 = 2 pi (TFreqOffsetEst_11n's convention)
+    float    noise_var;            // per carrier of the FFT<128> of the 40 MHz stream, LSB^2 (from the L-LTF pair)
+    uint32_t end_sample;           // 40 MHz source position at which the event is seen
+    uint32_t error_code;           // 0: recorded (the data field decides), else E_PLCP
+};
+
 }  // namespace sora
+
+int sora_internal_scan_ht40(const uint32_t* iq0, const uint32_t* iq1, const sora::CapDesc* d_caps, uint32_t ncaps, uint32_t max_frames, sora::Rx11bRow* d_rows, uint32_t* d_nframes,
+                            sora::Ht40Found* d_found, const sora::Tables& T, const uint32_t* sincos, const short* atan, hipStream_t st);
 
 // k_deliver.hip: dense rows + MPDUs of a call of the Rx11bRow-table handles into page-locked host memory, behind the call's kernels
 struct DenseStage {                  // per slot / pipeline (grow-only device staging)

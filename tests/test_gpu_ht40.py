@@ -235,3 +235,90 @@ def test_mmse_weights_against_float64(env):
                 continue
             worst = max(worst, float(np.abs(w[f, :, b].astype(float) - want).max()))
     assert worst <= 1.0, worst
+
+
+# ------------------------------------------------------------------ raw captures: the front end (sora_ht40_process_captures_dev)
+def _raw_captures(rng, specs, sigma=8.0, cfo=0.0):
+    """specs: per capture a list of (mcs, length) frames (or a callable that spoils the waveform).  -> (iq [2, n, 2], descs, truth per capture)"""
+    parts, descs, truth, pos = [], [], [], 0
+    for ci, frames in enumerate(specs):
+        segs = []; want = []
+        for fi, (mcs, ln, spoil) in enumerate(frames):
+            ps = [m.add_fcs(rng.integers(0, 256, ln - 4, dtype=np.uint8).tobytes()) for _ in range(2)]
+            x, nsym, pre = m.tx_frame(ps, mcs)
+            if spoil == "sig":                                           # garbage where L-SIG / HT-SIG should be: the header must fail
+                x[:, 640:1120] = x[:, 640:1120][:, ::-1] * 1j
+            ph = rng.uniform(0, 2 * np.pi, 4)
+            H = np.array([[1.0 * np.exp(1j * ph[0]), 0.3 * np.exp(1j * ph[1])], [0.25 * np.exp(1j * ph[2]), 0.9 * np.exp(1j * ph[3])]])
+            y = m.channel(x, H, 0.0, rng, cfo_step=cfo, lead=int(rng.integers(300, 900)))
+            segs.append(y); want.append((mcs, ps, spoil))
+        y = np.concatenate(segs + [np.zeros((2, 800, 2), np.int16)], axis=1).astype(np.float64)
+        y += rng.normal(0, sigma, y.shape)
+        y = np.clip(np.rint(y), -32768, 32767).astype(np.int16)
+        n = y.shape[1] // 28 * 28
+        parts.append(y[:, :n]); descs.append((pos, n, 100 + ci)); truth.append(want); pos += n
+    return np.concatenate(parts, axis=1), descs, truth
+
+
+def test_raw_captures_front_end_finds_parses_and_decodes(env):
+    """BASELINE configs[3] on raw two-chain 40 MHz captures: carrier sense, L-LTF, L-SIG / HT-SIG (the reference's 20 MHz bricks on the
+    duplicated legacy preamble), CFO and noise variance estimated, then the 40 MHz data field (FFT<128>, unbiased MMSE, a decoder per
+    stream).  Loop-back against the numpy model (parity unpinned for the 40 MHz extension): every MCS 8..14, several frames per capture,
+    a carrier offset, a frame whose SIG field is spoiled (one PLCP row), captures of pure noise."""
+    torch, sora = env
+    rng = np.random.default_rng(4040)
+    specs = [[(8 + k % 7, int(rng.integers(40, 900)), None)] for k in range(14)]
+    specs += [[(9, 120, None), (13, 700, None), (11, 64, None)], [(14, 1500, None), (10, 300, "sig"), (12, 333, None)], []]
+    for cfo in (0.0, 21.0):
+        iq, descs, truth = _raw_captures(rng, specs, sigma=8.0, cfo=cfo)
+        nsoft = 2 * sum(2 * (m.nsym_for([ln, ln], *m.MCS2[mcs]) * 108 * m.MCS2[mcs][0] + 64) for fr in specs for mcs, ln, _ in fr)
+        rx = sora.RxHt40(64, nsoft)
+        t = rx.process_captures_dev(torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda(), descs, max_frames_per_capture=4)
+        res = rx.results(ticket=t)
+        per = {}
+        for r in res:
+            per.setdefault(r["capture_id"], []).append(r)
+        for ci, want in enumerate(truth):
+            got = per.get(100 + ci, [])
+            exp = []
+            for mcs, ps, spoil in want:
+                exp += [("plcp",)] if spoil else [(mcs, 0, ps[0]), (mcs, 1, ps[1])]
+            assert len(got) == len(exp), (cfo, ci, [(hex(r["error_code"]), r["rate_kbps"], r["stream"]) for r in got])
+            ends = [r["end_sample"] for r in got]
+            assert ends == sorted(ends)
+            for r, e in zip(got, exp):
+                if e[0] == "plcp":
+                    assert r["error_code"] == 0x80000005, (cfo, ci, hex(r["error_code"]))
+                else:
+                    assert (r["error_code"], r["rate_kbps"], r["stream"], r["mpdu"]) == (1, e[0], e[1], e[2]), (cfo, ci, hex(r["error_code"]), r["rate_kbps"], r["stream"])
+        rx.close()
+
+
+def test_raw_capture_calls_in_flight_and_delivery(env):
+    """tickets and sora_ht40_deliver_async with raw captures: three different batches in flight, every call collected by its ticket, the
+    delivered tables equal to results_of (decoded frames; a failed header has no MPDU and is not delivered)."""
+    torch, sora = env
+    rng = np.random.default_rng(4141)
+    batches = []
+    for b in range(4):
+        specs = [[(8 + int(rng.integers(0, 7)), int(rng.integers(40, 600)), None)] for _ in range(10)]
+        iq, descs, truth = _raw_captures(rng, specs, sigma=6.0)
+        batches.append((torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda(), descs, truth))
+    rx = sora.RxHt40(16, 1 << 22)
+    depth = rx.calls_in_flight()
+    bufs = [sora.HostResults(16 * 2 * 2, 1 << 16) for _ in range(depth)]
+    pend = []
+    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["rate_kbps"], r["end_sample"], r["length"], r["crc32"], r["mpdu"])
+    for k in range(7):
+        f0, f1, descs, truth = batches[k % 4]
+        t = rx.process_captures_dev(f0, f1, descs, max_frames_per_capture=2)
+        rx.deliver_async(t, bufs[k % depth]); pend.append((t, bufs[k % depth], truth))
+        if len(pend) >= depth:
+            t0, b0, tr = pend.pop(0)
+            rx.wait(t0)
+            got = b0.results(); ref = rx.results(ticket=t0)
+            assert [key(r) for r in got] == [key(r) for r in ref if r["error_code"] in (1, 0x80000006)]
+            assert sum(r["error_code"] == 1 for r in got) == 20 and {r["mpdu"] for r in got} == {p for fr in tr for _, ps, _ in fr for p in ps}
+    for b in bufs:
+        b.close()
+    rx.synchronize(); rx.close()
