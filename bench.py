@@ -567,18 +567,21 @@ def check_against_reference(res, kind, want, idx):
 
 
 def bench_ht40(torch, sora_amd, dev, nframes=4096):
-    """BASELINE configs[3] (802.11n 2x2 40 MHz HT: 128-point FFT, MMSE detection, one decoder per spatial stream) -- PARITY UNPINNED, the
-    reference has no such receiver.  `nframes` frames of 64-QAM 3/4 on both streams (MCS 15's modulation), a 1500-byte
-    PSDU per stream, from the independent numpy model of the format (oracle/py_ht40.py) through a 2x2 channel with cross-talk; noise added on
-    the device.  Input = the data field as the 20 MHz front end would hand it over (two HT-LTF symbols + data symbols, both chains, HBM resident)."""
+    """BASELINE configs[3] (802.11n 2x2 40 MHz HT: 128-point FFT, MMSE detection, one decoder per spatial stream) on RAW CAPTURES -- parity
+    unpinned for the 40 MHz extension, the reference has no such receiver; its own 20 MHz front-end bricks find
+    and parse the frames.  `nframes` two-chain 40 MHz captures of one HT-mixed frame each: legacy preamble + HT-SIG + HT-STF + 2 HT-LTF +
+    data, MCS 14 (64-QAM 3/4 on both streams), a 1500-byte PSDU per stream, from the numpy model of the format (oracle/py_ht40.py tx_frame;
+    its preamble is pinned through the restated reference receiver) through a 2x2 channel with cross-talk; noise added on the device.
+    sora_ht40_process_captures_dev: carrier sense, L-LTF, L-SIG / HT-SIG, CFO and noise variance, then the data field."""
     from oracle import py_ht40 as m
     rng = np.random.default_rng(40)
     ps = [m.add_fcs(rng.integers(0, 256, 1496, dtype=np.uint8).tobytes()) for _ in range(2)]
-    x, nsym = m.tx(ps, 6, 2)
+    x, nsym, pre = m.tx_frame(ps, 14)
     H = np.array([[1.0, 0.3j], [0.25, 0.9 * np.exp(0.7j)]])
     y = (H @ x) * 250.0
-    n = (y.shape[1] + 63) // 64 * 64
-    base = np.zeros((2, n, 2), np.float32); base[:, :y.shape[1], 0] = y.real; base[:, :y.shape[1], 1] = y.imag
+    lead = 400
+    n = (lead + y.shape[1] + 600 + 27) // 28 * 28
+    base = np.zeros((2, n, 2), np.float32); base[:, lead:lead + y.shape[1], 0] = y.real; base[:, lead:lead + y.shape[1], 1] = y.imag
     b = torch.from_numpy(base).to(dev)
     gen = torch.Generator(device=dev); gen.manual_seed(4040)
     iq = torch.empty((2, nframes, n, 2), dtype=torch.int16, device=dev)
@@ -587,7 +590,7 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
         k = min(64, nframes - i)
         for c in range(2):
             iq[c, i:i + k] = (b[c][None] + sigma * torch.randn((k, n, 2), generator=gen, device=dev)).round().clamp(-32768, 32767).to(torch.int16)
-    descs = sora_amd.RxHt40.frames([(i * n, 6, 2, 1500, 1500, 0, 2 * sigma * sigma / 128.0, i) for i in range(nframes)])
+    caps = sora_amd.Rx.captures([(i * n, n, i) for i in range(nframes)])
     rx = sora_amd.RxHt40(nframes, nframes * 2 * (nsym * 648 + 64))
     f0 = iq[0].view(-1, 2); f1 = iq[1].view(-1, 2)
     torch.cuda.synchronize()
@@ -596,16 +599,22 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
     res = {}
     for lanes in (64, 16):
         rx.set_trellis(lanes)
-        res[lanes] = timed_with_delivery(sora_amd, rx, lambda: rx.process_dev(f0, f1, descs), depth, 20, 2 * nframes, 2 * nframes * 1500 + 4096)
+        res[lanes] = timed_with_delivery(sora_amd, rx, lambda: rx.process_captures_dev(f0, f1, caps, max_frames_per_capture=2), depth, 20, 2 * nframes, 2 * nframes * 1500 + 4096)
     best = min(res, key=lambda l: res[l][0])
     ms, delivery, first = res[best]
-    ok = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] for r in first)
-    samples = nframes * (2 + nsym) * 160                                     # per chain, 40 MHz
+    ok = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] and r["rate_kbps"] == 14 for r in first)
+    # the data field alone (the caller supplies what the front end would find): sora_ht40_process_dev
+    descs = sora_amd.RxHt40.frames([(i * n + lead + pre, 6, 2, 1500, 1500, 0, 2 * sigma * sigma / 128.0, i) for i in range(nframes)])
+    rx.set_trellis(best)
+    ms_df, _, first_df = timed_with_delivery(sora_amd, rx, lambda: rx.process_dev(f0, f1, descs), depth, 20, 2 * nframes, 2 * nframes * 1500 + 4096)
+    ok_df = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] for r in first_df)
+    samples = nframes * n                                                    # per chain, 40 MHz: the whole capture is input now
     alg = 8.0 * samples + 2.0 * 1500 * nframes                               # both chains read once + the decoded PSDUs
-    return {"workload": "%d frames x 2 spatial streams, 64-QAM 3/4, 1500-byte PSDU per stream (%d data symbols, %d samples @40 MHz per chain each), 2x2 cross-talk, AWGN; unbiased MMSE" % (nframes, nsym, (2 + nsym) * 160),
-            "parity": "unpinned: the reference has no 40 MHz / MMSE / per-stream-decoder receiver; loop-back against oracle/py_ht40.py, the reference's own bricks inside are pinned (tests/test_gpu_ht40.py)",
+    return {"workload": "%d two-chain 40 MHz captures x one HT-mixed frame, MCS 14 (64-QAM 3/4 on both streams), 1500-byte PSDU per stream (%d data symbols; %d samples per chain and capture), 2x2 cross-talk, AWGN; front end + unbiased MMSE on the estimated noise variance" % (nframes, nsym, n),
+            "parity": "unpinned for the 40 MHz extension (the reference has no 40 MHz / MMSE / per-stream-decoder receiver): loop-back against oracle/py_ht40.py; the front end is the reference's 20 MHz bricks (pinned), the model's preamble is pinned through the restated reference receiver (tests/test_ht40_preamble_model.py)",
             "ms": round(ms, 3), "calls_in_flight": depth, "trellis_kernel": {64: "k_viterbi11n", 16: "k_viterbi16_11n"}[best],
             "ms_by_trellis_kernel": {"k_viterbi11n": round(res[64][0], 3), "k_viterbi16_11n": round(res[16][0], 3)},
+            "ms_data_field_only": round(ms_df, 3), "psdus_ok_data_field_only": ok_df,
             "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
             "psdus_ok": ok, "psdus": 2 * nframes, "delivery": delivery, "bound": "hbm", "algorithmic_bytes": int(alg), "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
             "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
