@@ -321,38 +321,82 @@ def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
 
 
+class TableChecker:
+    """Byte-for-byte comparison of delivered tables with the verified first call's, off the submitting thread: comparing 6-12 MB of MPDUs
+    takes a host core 1-2 ms -- longer than the GPU takes to decode them -- so a small pool of threads does it (numpy and memcmp release the
+    GIL) while the main thread submits the next call.  A buffer is handed out again only after its comparison has finished."""
+    EXTRA = 4                                                               # buffers beyond the calls in flight: the ones being compared
+
+    def __init__(self, exp_rows_bytes, exp_mpdu):
+        from concurrent.futures import ThreadPoolExecutor
+        self.pool = ThreadPoolExecutor(self.EXTRA)
+        self.rows = exp_rows_bytes
+        m8 = exp_mpdu.size // 8 * 8
+        self.m8 = m8; self.m = exp_mpdu.size
+        self.head = np.frombuffer(exp_mpdu[:m8].tobytes(), np.uint64); self.tail = exp_mpdu[m8:].copy()
+        self.pending = {}; self.compared = 0; self.bad = 0
+
+    def _same(self, rows_view, mpdu_view):
+        return (rows_view.tobytes() == self.rows and bool((mpdu_view[:self.m8].view(np.uint64) == self.head).all())
+                and bool((mpdu_view[self.m8:self.m] == self.tail).all()))
+
+    def check(self, key, counts_ok, rows_view, mpdu_view):
+        """Queue buffer `key`'s comparison (its call has completed)."""
+        self.pending[key] = self.pool.submit(self._same, rows_view, mpdu_view) if counts_ok else None
+
+    def release(self, key):
+        """Before buffer `key` is written again: its comparison must be over."""
+        if key in self.pending:
+            f = self.pending.pop(key)
+            self.compared += 1
+            if f is None or not f.result():
+                self.bad += 1
+
+    def drain(self):
+        for key in list(self.pending):
+            self.release(key)
+
+    def finish(self):
+        self.drain()
+        self.pool.shutdown()
+
+
 def timed_with_delivery(sora_amd, rx, submit, depth, reps, rows_cap, mpdu_cap):
     """The timed region of the widened rows, the headline's protocol: every step = one process call (submit() -> ticket) + deliver_async of
     its dense rows and MPDUs into page-locked host memory behind its kernels + wait for the OLDEST call in flight and comparison of the
     table it delivered (row bytes, MPDU bytes) with the first call's.  -> (ms per step, delivery object, the first call's result dicts)"""
-    bufs = [sora_amd.HostResults(rows_cap, mpdu_cap) for _ in range(depth)]
+    nb = depth + TableChecker.EXTRA
+    bufs = [sora_amd.HostResults(rows_cap, mpdu_cap) for _ in range(nb)]
     t = submit(); rx.deliver_async(t, bufs[0]); rx.wait(t)
     first = bufs[0].results()
     n, m = int(bufs[0].counts[0]), int(bufs[0].counts[1])
-    exp_rows = bufs[0].rows[:n].tobytes(); exp_mpdu = bufs[0].mpdu[:m].copy()
-    stat = {"delivered": 0, "bad": 0}
+    chk = TableChecker(bufs[0].rows[:n].tobytes(), bufs[0].mpdu[:m].copy())
+    seq = [0]
 
-    def consume(tk, b):
+    def consume(tk, i):
         rx.wait(tk)
-        stat["delivered"] += 1
-        if int(b.counts[0]) != n or int(b.counts[1]) != m or b.rows[:n].tobytes() != exp_rows or not (b.mpdu[:m] == exp_mpdu).all():
-            stat["bad"] += 1
+        b = bufs[i]
+        chk.check(i, int(b.counts[0]) == n and int(b.counts[1]) == m, b.rows[:n], b.mpdu[:m])
 
     def block(k):
         pend = []
-        for i in range(k):
-            tk = submit(); b = bufs[i % depth]
-            rx.deliver_async(tk, b); pend.append((tk, b))
+        for _ in range(k):
+            i = seq[0] % nb; seq[0] += 1
+            chk.release(i)
+            tk = submit()
+            rx.deliver_async(tk, bufs[i]); pend.append((tk, i))
             if len(pend) >= depth:
                 consume(*pend.pop(0))
-        for tk, b in pend:
-            consume(tk, b)
+        for tk, i in pend:
+            consume(tk, i)
     block(depth + 2)                                                        # warm-up
     t0 = time.perf_counter()
     block(reps)
+    chk.finish()
     ms = (time.perf_counter() - t0) / reps * 1e3
-    out = {"enabled": True, "calls_delivered_and_compared": stat["delivered"], "calls_with_wrong_tables": stat["bad"], "rows_per_call": n, "mpdu_bytes_per_call": m,
-           "protocol": "every step = process call + deliver_async (dense rows + MPDUs to pinned host memory) + wait/compare of the oldest of %d calls in flight" % depth}
+    out = {"enabled": True, "calls_delivered_and_compared": chk.compared, "calls_with_wrong_tables": chk.bad, "rows_per_call": n, "mpdu_bytes_per_call": m,
+           "protocol": "every step = process call + deliver_async (dense rows + MPDUs to pinned host memory) + wait for the oldest of %d calls in flight, whose rows and MPDU bytes "
+                       "are compared with the verified first call's by a pool of %d host threads (inside the timed region)" % (depth, TableChecker.EXTRA)}
     for b in bufs:
         b.close()
     return ms, out, first
@@ -693,23 +737,23 @@ def main():
     # ---- result delivery inside the timed region: after every process call its dense rows and its MPDU array are copied
     # to page-locked host memory behind the kernels (sora_rx_deliver_async), and the oldest call in flight is waited for
     # and its rows compared with the verified ones -- what RxThread does per frame (fb11a_demod.cpp:37-71), per call.
-    bufs = [sora_amd.HostResults(nfr * MAXF, rx.mpdu_bytes(t)) for _ in range(depth)]
+    nb = depth + TableChecker.EXTRA
+    bufs = [sora_amd.HostResults(nfr * MAXF, rx.mpdu_bytes(t)) for _ in range(nb)]
     rx.deliver_async(t, bufs[0]); rx.wait(t)
     exp_n = int(bufs[0].nrows[0]); exp_rows = bufs[0].rows[:exp_n].copy(); exp_mpdu = bufs[0].mpdu.copy()
     exp_bytes = exp_rows.tobytes()
     host_rows_ok = exp_n == len(res) and all(int(exp_rows[k]["crc32"]) == res[k]["crc32"] and int(exp_rows[k]["error_code"]) == res[k]["error_code"] for k in range(exp_n)) \
         and all(bytes(exp_mpdu[int(r["mpdu_offset"]):int(r["mpdu_offset"]) + int(r["length"])]) == res[k]["mpdu"] for k, r in enumerate(exp_rows) if int(r["error_code"]) == 1)
-    stats = {"delivered": 0, "bad": 0, "t_submit": 0.0, "t_wait": 0.0, "t_check": 0.0}
+    stats = {"t_submit": 0.0, "t_wait": 0.0, "t_check": 0.0}
+    chk = TableChecker(exp_bytes, exp_mpdu)                         # rows AND MPDU bytes of every delivered call, compared by a few host threads
 
     def consume(tk):
         ta = time.perf_counter()
         rx.wait(tk)
         tb = time.perf_counter()
         stats["t_wait"] += tb - ta
-        b = bufs[tk % depth]
-        stats["delivered"] += 1
-        if int(b.nrows[0]) != exp_n or b.rows[:exp_n].tobytes() != exp_bytes:
-            stats["bad"] += 1
+        b = bufs[tk % nb]
+        chk.check(tk % nb, int(b.nrows[0]) == exp_n, b.rows[:exp_n], b.mpdu)
         stats["t_check"] += time.perf_counter() - tb
 
     def run_block(k, deliver, dep=None):
@@ -717,9 +761,11 @@ def main():
         first = None
         for _ in range(k):
             ta = time.perf_counter()
+            if deliver:
+                chk.release((rx.ticket() + 1) % nb)                 # the buffer the next call will be delivered into: its comparison must be over
             tk = rx.process_dev(d_iq, descs)
             if deliver:
-                rx.deliver_async(tk, bufs[tk % depth])
+                rx.deliver_async(tk, bufs[tk % nb])
             stats["t_submit"] += time.perf_counter() - ta
             if deliver:
                 if first is None:
@@ -740,6 +786,7 @@ def main():
     repeats = max(1, int(np.ceil(args.min_seconds / max(probe, 1e-6))))
     if world > 1:                                  # every rank runs the same number of blocks
         r_t = torch.tensor([repeats], device=dev, dtype=torch.int64); dist.all_reduce(r_t, op=dist.ReduceOp.MAX); repeats = int(r_t.item())
+    chk.drain(); chk.compared = chk.bad = 0
     barrier()
     for k_ in ("t_submit", "t_wait", "t_check"):
         stats[k_] = 0.0
@@ -747,11 +794,13 @@ def main():
     for _ in range(repeats):
         run_block(args.steps, deliver)
     rx.flush()
+    chk.drain()                                                     # every delivered table has been compared when the clock stops
     barrier()
     t1 = time.perf_counter()
     host_ms = {k_[2:]: round(1e3 * stats[k_] / (args.steps * repeats), 4) for k_ in ("t_submit", "t_wait", "t_check")}
     timed_steps = args.steps * repeats
-    mpdu_ok = bool(deliver) and all((b.mpdu == exp_mpdu).all() for b in bufs)     # the last `depth` calls' MPDU arrays, byte for byte
+    stats["delivered"], stats["bad"] = chk.compared, chk.bad
+    mpdu_ok = bool(deliver) and all((b.mpdu == exp_mpdu).all() for b in bufs)     # the last calls' MPDU arrays once more, byte for byte
     # the same K steps once more with HIP events around every kernel launch (on the streams the kernels run on): the
     # roofline's launch durations are means over this region; `value` comes from the un-instrumented region above
     # (recording 6 events per call costs a few percent, reported as ms_per_step_profiled)
@@ -792,15 +841,15 @@ def main():
         for dname, dval in (("one_call_in_flight", 1), ("calls_in_flight_%d" % depth, depth)):
             rx.set_depth(dval); rx.flush()
             run_block(args.warmup, deliver, dval); rx.flush()
-            stats_before = dict(stats)
+            chk.drain(); bad_before = chk.bad
             tf0 = time.perf_counter()
             nblk = max(1, repeats // 4)
             for _ in range(nblk):
                 run_block(args.steps, deliver, dval)
-            rx.flush()
+            rx.flush(); chk.drain()
             tf1 = time.perf_counter()
             fused[dname] = {"ms_per_step": round((tf1 - tf0) / (nblk * args.steps) * 1e3, 4), "steps": nblk * args.steps,
-                            "calls_with_wrong_rows": stats["bad"] - stats_before["bad"]}
+                            "calls_with_wrong_rows": chk.bad - bad_before}
         rx.set_depth(1); rx.flush(); rx.set_profiling(True)
         for _ in range(max(10, args.steps // 2)):
             rx.process_dev(d_iq, descs)
@@ -850,7 +899,7 @@ def main():
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth, "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
-                       "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait/compare of the oldest call in flight" % (repeats, args.steps)
+                       "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads" % (repeats, args.steps, TableChecker.EXTRA)
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "gathered": gathered, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
