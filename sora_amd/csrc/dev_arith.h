@@ -56,6 +56,7 @@ __device__ __forceinline__ int sqnorm(cpx a) { return (int)((unsigned)(a.re * a.
 struct Tables {
     const short*    usin;        // [65536]  core/inc/intalglut.h usin_lut
     const short*    ucos;        // [65536]
+    const uint32_t* rot;         // [65536]  {ucos, -usin} packed: the rotation coefficient of an FP_RAD angle in one read
     const short*    uatan2;      // [256*256]
     const uint8_t*  demap;       // [4][256]  bpsk, qam16_2, qam64_2, qam64_3 (demapper.h:55-130)
     const uint32_t* tw64;        // [3][16] packed W64^{k j}, k=1,2,3   (fft_lut_twiddle.h:61433-61504)
@@ -83,8 +84,7 @@ __device__ __forceinline__ int uatan2(const Tables& T, int y, int x)
 }
 __device__ __forceinline__ cpx rot_coeff(const Tables& T, int th)        // (ucos(th), -usin(th)) with FP_RAD th
 {
-    unsigned i = (unsigned)th & 0xFFFFu;
-    return mk((int)T.ucos[i], w16(-(int)T.usin[i]));
+    return unpack(T.rot[(unsigned)th & 0xFFFFu]);
 }
 
 // data carrier k (0..47) -> FFT bin, in demap order -26..-1, +1..+26 without the pilots (demapper11a.hpp:20-37)

@@ -33,7 +33,6 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     __shared__ uint32_t s_eq[4][4][64];                                          // [wave][symbol of the pass]: FFT staging, then the equalised bins
     __shared__ uint8_t  s_soft[4][4][288];                                       // [wave][symbol of the pass]: soft values in carrier order
     __shared__ uint8_t  s_demap[1024];                                           // DemapperCore step tables
-    __shared__ uint16_t s_map[4][288];                                           // [wave] de-interleaver source index of the frame's modulation
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
     const Tables& T = A.T;
     reinterpret_cast<uint32_t*>(s_demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(T.demap)[threadIdx.x];
@@ -68,10 +67,12 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     PkTw fq[4], ch[4];                                                           // FreqCoeffs / ChannelCoeffs as the operand pairs of the packed complex product
 #pragma unroll
     for (int m = 0; m < 4; m++) { fq[m] = pk_tw_mul(fx->freq[e + 16 * m]); ch[m] = pk_tw_mul(fx->chan[e + 16 * m]); }
-    const int nb = r.nbpsc, ncbps = 48 * nb, nsym = r.nsym;
+    const int nb = __builtin_amdgcn_readfirstlane((int)r.nbpsc), ncbps = 48 * nb, nsym = __builtin_amdgcn_readfirstlane((int)r.nsym);   // (wave-uniform: scalar branches on the modulation)
+    uint32_t mp[5];                                                              // de-interleaver source index of output positions lane + 64 t (past N_CBPS: none)
     {
         const uint16_t* map = T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
-        for (int i = lane; i < ncbps; i += 64) s_map[w][i] = map[i];
+#pragma unroll
+        for (int t = 0; t < 5; t++) mp[t] = lane + 64 * t < ncbps ? (uint32_t)map[lane + 64 * t] : 0xFFFFFFFFu;
     }
     uint16_t* dst = reinterpret_cast<uint16_t*>(A.soft + (size_t)host_slot0 * kSoftPerSlot) + half;     // operand i of the pair: dst[2 i]
     // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
@@ -159,10 +160,12 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
         // ---- T11aDeinterleave*: out[k] = in[j(k)]; the pass's symbols are contiguous in the frame's half of the pair stream (16-bit fields v << 9)
         {
             const int nact = min(4, nsym - s0 + 1);
-            uint16_t* d = dst + 2 * (size_t)(s0 - 1) * ncbps;
-            for (int i = lane; i < nact * ncbps; i += 64) {
-                const int gs = i / ncbps, k = i - gs * ncbps;
-                d[2 * i] = (uint16_t)((uint32_t)s_soft[w][gs][s_map[w][k]] << 9);
+            uint16_t* d = dst + 2 * ((size_t)(s0 - 1) * ncbps + lane);
+            for (int gs = 0; gs < nact; gs++, d += 2 * ncbps) {                 // (symbol by symbol: no index arithmetic per value)
+                const uint8_t* src = s_soft[w][gs];
+#pragma unroll
+                for (int t = 0; t < 5; t++)
+                    if (mp[t] != 0xFFFFFFFFu) d[128 * t] = (uint16_t)((uint32_t)src[mp[t]] << 9);
             }
         }
         wsync();

@@ -35,7 +35,7 @@ static int fail(int code, const char* what, hipError_t e = hipSuccess)
 struct HostTables {
     std::vector<int16_t> usin, ucos, uatan2;
     std::vector<uint8_t> demap;
-    std::vector<uint32_t> tw64, tw16, sts, crc, tw128, tw32, tw8;
+    std::vector<uint32_t> tw64, tw16, sts, crc, tw128, tw32, tw8, rot;
     std::vector<uint16_t> deint;
     std::vector<uint8_t> scr, scr_seq, scr_phase;
     std::vector<uint32_t> crcz;
@@ -91,6 +91,8 @@ static void build_tables(HostTables& H)
         H.usin[i] = (int16_t)std::floor(32767.0 * std::sin(x) + 0.5);
         H.ucos[i] = (int16_t)std::floor(32767.0 * std::cos(x) + 0.5);
     }
+    H.rot.resize(65536);
+    for (int i = 0; i < 65536; i++) H.rot[i] = pk(H.ucos[i], -(int)H.usin[i]);
     for (int yi = 0; yi < 256; yi++)                     // core/inc/intalglut.h:7332
         for (int xi = 0; xi < 256; xi++) {
             int t = (int)(std::atan2((double)(int8_t)yi, (double)(int8_t)xi) * 32768.0 / GEN_PI);
@@ -204,6 +206,7 @@ static int make_dev_tables(DevTables& D)
     int rc;
     if ((rc = upload(D, H.usin, (const void**)&D.T.usin))) return rc;
     if ((rc = upload(D, H.ucos, (const void**)&D.T.ucos))) return rc;
+    if ((rc = upload(D, H.rot, (const void**)&D.T.rot))) return rc;
     if ((rc = upload(D, H.uatan2, (const void**)&D.T.uatan2))) return rc;
     if ((rc = upload(D, H.demap, (const void**)&D.T.demap))) return rc;
     if ((rc = upload(D, H.tw64, (const void**)&D.T.tw64))) return rc;
