@@ -19,12 +19,22 @@
 namespace sora {
 
 #ifdef SORA_SCAN_PROBE
-__device__ unsigned long long g_scan_probe[16];
+__device__ unsigned long long g_scan_probe[16];              // [0..7] ticks per region, [8..15] how often (capture 0 only; tools/probe_scan.py)
+#define PROBE_DECL() long long _pa[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned _pn[8] = {0, 0, 0, 0, 0, 0, 0, 0}
 #define PROBE_T0() const long long _t0 = clock64()
-#define PROBE_ADD(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) g_scan_probe[i] += (unsigned long long)(clock64() - _t0); } while (0)
+#define PROBE_ADD(i) do { _pa[i] += clock64() - _t0; _pn[i]++; } while (0)
+#define PROBE_T(n) const long long n = clock64()
+#define PROBE_A(n, i) do { _pa[i] += clock64() - n; _pn[i]++; } while (0)
+#define PROBE_TK() const long long _tk = clock64()
+#define PROBE_ADDK(i) do { _pa[i] += clock64() - _tk; _pn[i]++; if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 0; q < 8; q++) { g_scan_probe[q] += (unsigned long long)_pa[q]; g_scan_probe[8 + q] += _pn[q]; } } while (0)
 #else
+#define PROBE_DECL()
 #define PROBE_T0()
 #define PROBE_ADD(i)
+#define PROBE_T(n)
+#define PROBE_A(n, i)
+#define PROBE_TK()
+#define PROBE_ADDK(i)
 #endif
 
 struct Acc4 { int e0, e1, e2, e3; int reg; };            // CMovingWindow<int,4> + CAccumulator (dspalg.hpp:5-98), oldest first
@@ -55,7 +65,173 @@ __device__ __forceinline__ int carrier_bin(int k)
     int b = 1 + (k - 24); if (b >= 7) b++; if (b >= 21) b++; return b;
 }
 
-__global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
+// ---- T11aLTS on the 144 samples at lts_start (channel_11a.hpp:206-330): CFO estimate, frequency shift, FFT<64>, channel inverse -> *fx.
+// Out of line (once per frame): its temporaries and table pointers stay out of the carrier-sense loop's register allocation.  Returns the CFO.
+__device__ __noinline__ int lts_section(const Tables& T, const uint32_t* iq, uint32_t lts_start, uint32_t STR, FrameCtx* fx)
+{
+    __shared__ uint32_t s_fft[64];
+    __shared__ uint32_t s_x[144];
+    const int lane = threadIdx.x;
+    auto sync = []() { __syncthreads(); };
+                        // stage the 144 samples (20 MHz rate) in LDS
+                        for (int i = lane; i < 144; i += 64) s_x[i] = iq[lts_start + (uint32_t)i * STR];
+                        sync();
+                        // x[n] = s_x[8+n]; first 64 are >>1 (rep_shift_right<16>, :216)
+                        cpx x1 = sra(unpack(s_x[8 + lane]), 1);
+                        cpx x2 = unpack(s_x[8 + 64 + lane]);
+                        int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
+                        const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
+                        const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
+                        const int cfo = arg >> 6;                   // size_t divisor: unsigned division = floor (dspalg.hpp:242)
+                        // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
+                        const cpx fc = rot_coeff(T, w16(lane * cfo));
+                        fx->freq[lane] = pack(fc);
+                        cpx xs = mul_q15(x1, fc);                                     // FrequencyShift (:120)
+                        sync();
+                        s_x[lane] = pack(xs);
+                        sync();
+                        // FFT<64> on lanes 0..15
+                        cpx Y[4];
+                        {
+                            const int e = lane & 15;
+                            cpx xin[4];
+    #pragma unroll
+                            for (int m = 0; m < 4; m++) xin[m] = unpack(s_x[e + 16 * m]);
+                            fft64_group(xin, Y, s_fft, e, T, sync);                    // all lanes call (barriers); results identical per 16-lane group
+                        }
+                        // lane L (0..63) takes bin L: Y of group lane (L&15), register (L>>4)
+                        {
+                            cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
+                            uint32_t coef = 0;
+                            if (!(lane >= 28 && lane < 36)) {                          // _channel_estimation (:125-178)
+                                const int e = sqnorm(Yb) >> 8;
+                                const cpx L = mk(kLtsSeq[lane] ? 1600 : -1600, 0);
+                                int cre, cim; conj_mul32(L, Yb, cre, cim);
+                                int rre = 0, rim = 0;
+                                if (e != 0) { rre = cre / e; rim = cim / e; }
+                                coef = pack(mk(w16(rre), w16(rim)));
+                            }
+                            fx->chan[lane] = coef;
+                        }
+                        __threadfence_block();
+                        sync();
+    return cfo;
+}
+
+// ---- the SIGNAL symbol at sym_start: T11aDataSymbol .. T11aViterbiSig .. T11aPLCPParser (PHY_11a.hpp:389-580), lane-parallel; out of line
+// like lts_section.  Every field of the result is wave-uniform.
+struct SigOut { uint32_t ok, kbps, len, nsym, cr, nb; int cfo_comp, sfo_comp, cfo_tr, sfo_tr; };
+__device__ __noinline__ SigOut signal_section(const Tables& T, const uint32_t* iq, uint32_t sym_start, uint32_t STR, const FrameCtx* fx)
+{
+    __shared__ uint32_t s_fft[64];
+    __shared__ uint8_t  s_soft[48];
+    __shared__ uint64_t s_dec[25];                   // Viterbi_sig11 decision words (wave-uniform ballots)
+    const int lane = threadIdx.x;
+    auto sync = []() { __syncthreads(); };
+                            // ---- the SIGNAL symbol: full header chain, lane-parallel
+                            const int e = lane & 15;
+                            cpx xin[4], Y[4];
+    #pragma unroll
+                            for (int m = 0; m < 4; m++) {                              // skip CP 8, >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+                                const int n = e + 16 * m;
+                                cpx x = sra(unpack(iq[sym_start + (uint32_t)(8 + n) * STR]), 1);
+                                xin[m] = mul_q15(x, unpack(fx->freq[n]));
+                            }
+                            fft64_group(xin, Y, s_fft, e, T, sync);
+                            cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
+                            cpx eq = mk(0, 0);
+                            if (!(lane >= 28 && lane < 36)) {                          // TChannelEqualization (channel_11a.hpp:548-574)
+                                int re, im; mul32(Yb, unpack(fx->chan[lane]), re, im);
+                                eq = mk(w16(re >> 8), w16(im >> 8));
+                            }
+                            // TPhaseCompensate with the reset CompCoeffs (0x7fff, 0) (ieee80211facade.hpp:198-206)
+                            cpx pc = mul_q15(eq, mk(0x7fff, 0));
+                            sync();
+                            s_fft[lane] = pack(pc);
+                            sync();
+                            // _pilot_track (pilot.hpp:166-233), symbol_count = 127 -> PilotSgn[127] = 0
+                            cpx p43 = unpack(s_fft[43]), p57 = unpack(s_fft[57]), p7 = unpack(s_fft[7]), p21 = unpack(s_fft[21]);
+                            const int th1 = __builtin_amdgcn_readfirstlane(uatan2(T, p43.im, p43.re)), th2 = __builtin_amdgcn_readfirstlane(uatan2(T, p57.im, p57.re));
+                            const int th3 = __builtin_amdgcn_readfirstlane(uatan2(T, p7.im, p7.re)),   th4 = __builtin_amdgcn_readfirstlane(uatan2(T, -p21.im, -p21.re));
+                            const int avg = w16((th1 + th2 + th3 + th4) / 4);
+                            const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+                            const int cfo_tracker = w16(avg >> 2), sfo_tracker = w16(del >> 2);
+                            const int cfo_comp = w16(avg + cfo_tracker), sfo_comp = w16(del + sfo_tracker);
+                            // T11aDemapBPSK on the rotated carriers -> T11aDeinterleaveBPSK
+                            if (lane < 48) {
+                                const int bin = carrier_bin(lane);
+                                const int cidx = bin < 32 ? bin : bin - 64;            // signed carrier number
+                                cpx r = mul_q15(unpack(s_fft[bin]), rot_coeff(T, w16(avg + cidx * del)));
+                                int v = r.re >> 4; v = min(max(v, -128), 127);         // demap_limit (demapper.h:141-151)
+                                s_soft[lane] = T.demap[(unsigned)v & 0xFF];
+                            }
+                            sync();
+                            uint8_t sa = 0, sb = 0;                                     // de-interleaved soft pair of trellis step t = lane (t < 24)
+                            if (lane < 24) { sa = s_soft[T.deint[2 * lane]]; sb = s_soft[T.deint[2 * lane + 1]]; }
+                            // ---- Viterbi_sig11 (viterbicore.h:35-261): lane = state
+                            const int n = lane;
+                            const int r0 = n, r1 = 64 | n;
+                            const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
+                            const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
+                            unsigned m = (n == 0) ? 0u : 0x30u;
+                            if (lane == 0) s_dec[0] = 0;
+    #pragma unroll
+                            for (int t = 1; t <= 24; t++) {
+                                const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
+                                const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
+                                const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
+                                const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
+                                const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
+                                m = min(c0, c1);
+                                { const uint64_t d = __ballot(m & 1); if (lane == 0) s_dec[t] = d; }
+                                if ((t & 7) == 0) {
+                                    unsigned mn = m;
+    #pragma unroll
+                                    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
+                                    m = (m - (mn & 0xFE)) & 0xFF;
+                                }
+                            }
+                            // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
+                            unsigned key = (m << 8) | ((unsigned)n << 2), kmin = key;
+    #pragma unroll
+                            for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
+                            kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
+                            int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+                            sync();                                                     // s_dec complete
+                            uint32_t sig = 0;
+    #pragma unroll
+                            for (int b = 0; b < 24; b++) {
+                                // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
+                                sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
+                                pos = (pos >> 1) & 0x3F;
+                                pos |= (int)((s_dec[23 - b] >> pos) & 1) << 6;
+                            }
+                            sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;     // viterbi.hpp:39 (wave-uniform)
+                            // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
+                            bool ok = true;
+                            sig &= 0xFFFFFF;
+                            if (sig & 0xFC0010) ok = false;
+                            uint32_t par = (sig >> 16) ^ sig; par = (par >> 8) ^ par; par = (par >> 4) ^ par; par = (par >> 2) ^ par; par = (par >> 1) ^ par;
+                            if (par & 1) ok = false;
+                            uint32_t kbps = 0; int nd = 0, nb = 0, cr = 0;
+                            switch (sig & 0xF) {                                        // ieee80211a_cmn.h:97-107, :65-94, :114-149
+                            case 0x8: kbps = 48000; nd = 192; nb = 6; cr = 1; break;  case 0x9: kbps = 24000; nd = 96;  nb = 4; cr = 0; break;
+                            case 0xA: kbps = 12000; nd = 48;  nb = 2; cr = 0; break;  case 0xB: kbps = 6000;  nd = 24;  nb = 1; cr = 0; break;
+                            case 0xC: kbps = 54000; nd = 216; nb = 6; cr = 2; break;  case 0xD: kbps = 36000; nd = 144; nb = 4; cr = 2; break;
+                            case 0xE: kbps = 18000; nd = 72;  nb = 2; cr = 2; break;  case 0xF: kbps = 9000;  nd = 36;  nb = 1; cr = 2; break;
+                            default: ok = false; break;
+                            }
+                            const uint32_t len = (sig >> 5) & 0xFFF;
+                            if (len > 2500) ok = false;
+                            SigOut O;
+                            O.ok = ok ? 1u : 0u; O.kbps = kbps; O.len = len; O.cr = (uint32_t)cr; O.nb = (uint32_t)nb;
+                            O.nsym = ok ? (len * 8 + 16 + 6 + (uint32_t)nd - 1) / (uint32_t)nd : 0u;                  // B11aGetSymbolCount
+                            O.cfo_comp = cfo_comp; O.sfo_comp = sfo_comp; O.cfo_tr = cfo_tracker; O.sfo_tr = sfo_tracker;
+                            sync();
+    return O;
+}
+
+__global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
 {
     const uint32_t cap_i = blockIdx.x;
     if (cap_i >= A.ncaps) return;
@@ -65,10 +241,6 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
     const uint32_t STR = A.str, APP = 28 / (2 / STR), BUR = 8 / (2 / STR);
     const uint32_t nunits = (cd.nsamples / APP) * APP;
     const Tables& T = A.T;
-    __shared__ uint32_t s_fft[64];
-    __shared__ uint32_t s_x[144];
-    __shared__ uint8_t  s_soft[48];
-    __shared__ uint64_t s_dec[25];                   // Viterbi_sig11 decision words (wave-uniform ballots)
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
     uint32_t Hv = 0;                         // sample_his in TIME ORDER, one packed sample per lane (lane & 15, oldest = 0): 4 bursts of 4, already >>2
@@ -238,6 +410,8 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
     };
 
     const uint32_t nchunks = nunits / APP;
+    PROBE_DECL();
+    PROBE_TK();
     // Every frame of the capture is found and counted, as RxThread reports every frame; those past the row limit get no row and
     // no decode job (their per-frame context goes to the capture's spare FrameCtx), and the host flags the capture's last row.
     auto ctx_of = [&](uint32_t k) { return A.fctx + (k < A.max_frames ? (size_t)cap_i * A.max_frames + k : (size_t)A.nrows + cap_i); };
@@ -248,13 +422,19 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                 // bursts until the carrier-sense time-out is raised; if that is near, stay inside this source call
                 const uint32_t to_timeout = sense_count >= 84 ? 0u : (84u - sense_count + 3u) / 4u;
                 const uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
-                if (fast_idle(min(min(room, dc_cnt + 1u), 8u))) continue;
+                PROBE_T0();
+                const uint32_t took = fast_idle(min(min(room, dc_cnt + 1u), 8u));
+                PROBE_ADD(3);
+                if (took) continue;
             }
             if (!cca_detected && sync_high) {
+                PROBE_T0();
                 fast_sync(min((avail_end - vpos) / BUR, 4u - high_count % 4u));
+                PROBE_ADD(4);
                 continue;
             }
             const uint32_t pos20 = vpos / STR;
+            PROBE_T(_tb);
             if (!cca_detected) {
                 PROBE_T0();
                 // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
@@ -315,173 +495,51 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                 PROBE_ADD(0);
             } else if (!symbol_is_data) {
                 // ================= T11aLTS: IPORT COMPLEX16 x 144 (channel_11a.hpp:206-229)
-                if (lts_n == 0) lts_start = vpos;
+                if (lts_n == 0) {
+                    // Nothing observable happens while the brick collects its 144 samples (no carrier sense, no error source): go straight
+                    // to the burst that completes them instead of counting 35 bursts.
+                    lts_start = vpos;
+                    const uint32_t last_v = vpos + 35u * BUR;
+                    if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }       // the capture ends inside the LTS: nothing more to report
+                    lts_n = 140; vpos = last_v;
+                    c = (vpos + BUR + APP - 1) / APP - 2;                                   // the for-loop increment lands on the chunk that delivers that burst
+                    break;
+                }
                 lts_n += 4;
                 if (lts_n == 144) {
                     PROBE_T0();
                     lts_n = 0; symbol_is_data = 1;
-                    // stage the 144 samples (20 MHz rate) in LDS
-                    for (int i = lane; i < 144; i += 64) s_x[i] = iq[lts_start + (uint32_t)i * STR];
-                    sync();
-                    // x[n] = s_x[8+n]; first 64 are >>1 (rep_shift_right<16>, :216)
-                    cpx x1 = sra(unpack(s_x[8 + lane]), 1);
-                    cpx x2 = unpack(s_x[8 + 64 + lane]);
-                    int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
-                    const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
-                    const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
-                    const int cfo = arg >> 6;                   // size_t divisor: unsigned division = floor (dspalg.hpp:242)
-                    // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
-                    const cpx fc = rot_coeff(T, w16(lane * cfo));
-                    FrameCtx* fx = ctx_of(nfr);
-                    fx->freq[lane] = pack(fc);
-                    cpx xs = mul_q15(x1, fc);                                     // FrequencyShift (:120)
-                    sync();
-                    s_x[lane] = pack(xs);
-                    sync();
-                    // FFT<64> on lanes 0..15
-                    cpx Y[4];
-                    {
-                        const int e = lane & 15;
-                        cpx xin[4];
-#pragma unroll
-                        for (int m = 0; m < 4; m++) xin[m] = unpack(s_x[e + 16 * m]);
-                        fft64_group(xin, Y, s_fft, e, T, sync);                    // all lanes call (barriers); results identical per 16-lane group
-                    }
-                    // lane L (0..63) takes bin L: Y of group lane (L&15), register (L>>4)
-                    {
-                        cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
-                        uint32_t coef = 0;
-                        if (!(lane >= 28 && lane < 36)) {                          // _channel_estimation (:125-178)
-                            const int e = sqnorm(Yb) >> 8;
-                            const cpx L = mk(kLtsSeq[lane] ? 1600 : -1600, 0);
-                            int cre, cim; conj_mul32(L, Yb, cre, cim);
-                            int rre = 0, rim = 0;
-                            if (e != 0) { rre = cre / e; rim = cim / e; }
-                            coef = pack(mk(w16(rre), w16(rim)));
-                        }
-                        fx->chan[lane] = coef;
-                    }
-                    r_cfo = cfo;
-                    __threadfence_block();
-                    sync();
+                    r_cfo = __builtin_amdgcn_readfirstlane(lts_section(T, iq, lts_start, STR, ctx_of(nfr)));
                     PROBE_ADD(1);
                 }
             } else {
                 // ================= T11aDataSymbol: IPORT COMPLEX16 x 80 (PHY_11a.hpp:389-428)
                 if (sym_n == 0) sym_start = vpos;
+                if (sym_n == 0 && error_code == 0) {                                        // likewise: to the symbol's 20th burst (not once an event is pending: the rest of that source call still counts bursts)
+                    const uint32_t last_v = vpos + 19u * BUR;
+                    if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }
+                    sym_n = 76; vpos = last_v;
+                    c = (vpos + BUR + APP - 1) / APP - 2;
+                    break;
+                }
                 sym_n += 4;
                 if (sym_n == 80) {
                     sym_n = 0;
                     if (sym_idx == 0) {
                         PROBE_T0();
-                        // ---- the SIGNAL symbol: full header chain, lane-parallel
-                        FrameCtx* fx = ctx_of(nfr);
-                        const int e = lane & 15;
-                        cpx xin[4], Y[4];
-#pragma unroll
-                        for (int m = 0; m < 4; m++) {                              // skip CP 8, >>1, x FreqCoeffs (channel_11a.hpp:643-644)
-                            const int n = e + 16 * m;
-                            cpx x = sra(unpack(iq[sym_start + (uint32_t)(8 + n) * STR]), 1);
-                            xin[m] = mul_q15(x, unpack(fx->freq[n]));
-                        }
-                        fft64_group(xin, Y, s_fft, e, T, sync);
-                        cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
-                        cpx eq = mk(0, 0);
-                        if (!(lane >= 28 && lane < 36)) {                          // TChannelEqualization (channel_11a.hpp:548-574)
-                            int re, im; mul32(Yb, unpack(fx->chan[lane]), re, im);
-                            eq = mk(w16(re >> 8), w16(im >> 8));
-                        }
-                        const uint32_t slot0 = cd.slot_base + (sym_start / STR) / 80;
-                        // TPhaseCompensate with the reset CompCoeffs (0x7fff, 0) (ieee80211facade.hpp:198-206)
-                        cpx pc = mul_q15(eq, mk(0x7fff, 0));
-                        sync();
-                        s_fft[lane] = pack(pc);
-                        sync();
-                        // _pilot_track (pilot.hpp:166-233), symbol_count = 127 -> PilotSgn[127] = 0
-                        cpx p43 = unpack(s_fft[43]), p57 = unpack(s_fft[57]), p7 = unpack(s_fft[7]), p21 = unpack(s_fft[21]);
-                        const int th1 = __builtin_amdgcn_readfirstlane(uatan2(T, p43.im, p43.re)), th2 = __builtin_amdgcn_readfirstlane(uatan2(T, p57.im, p57.re));
-                        const int th3 = __builtin_amdgcn_readfirstlane(uatan2(T, p7.im, p7.re)),   th4 = __builtin_amdgcn_readfirstlane(uatan2(T, -p21.im, -p21.re));
-                        const int avg = w16((th1 + th2 + th3 + th4) / 4);
-                        const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
-                        const int cfo_tracker = w16(avg >> 2), sfo_tracker = w16(del >> 2);
-                        const int cfo_comp = w16(avg + cfo_tracker), sfo_comp = w16(del + sfo_tracker);
-                        // T11aDemapBPSK on the rotated carriers -> T11aDeinterleaveBPSK
-                        if (lane < 48) {
-                            const int bin = carrier_bin(lane);
-                            const int cidx = bin < 32 ? bin : bin - 64;            // signed carrier number
-                            cpx r = mul_q15(unpack(s_fft[bin]), rot_coeff(T, w16(avg + cidx * del)));
-                            int v = r.re >> 4; v = min(max(v, -128), 127);         // demap_limit (demapper.h:141-151)
-                            s_soft[lane] = T.demap[(unsigned)v & 0xFF];
-                        }
-                        sync();
-                        uint8_t sa = 0, sb = 0;                                     // de-interleaved soft pair of trellis step t = lane (t < 24)
-                        if (lane < 24) { sa = s_soft[T.deint[2 * lane]]; sb = s_soft[T.deint[2 * lane + 1]]; }
-                        // ---- Viterbi_sig11 (viterbicore.h:35-261): lane = state
-                        const int n = lane;
-                        const int r0 = n, r1 = 64 | n;
-                        const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
-                        const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
-                        unsigned m = (n == 0) ? 0u : 0x30u;
-                        if (lane == 0) s_dec[0] = 0;
-#pragma unroll
-                        for (int t = 1; t <= 24; t++) {
-                            const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
-                            const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
-                            const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
-                            const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
-                            const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
-                            m = min(c0, c1);
-                            { const uint64_t d = __ballot(m & 1); if (lane == 0) s_dec[t] = d; }
-                            if ((t & 7) == 0) {
-                                unsigned mn = m;
-#pragma unroll
-                                for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
-                                m = (m - (mn & 0xFE)) & 0xFF;
-                            }
-                        }
-                        // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
-                        unsigned key = (m << 8) | ((unsigned)n << 2), kmin = key;
-#pragma unroll
-                        for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
-                        kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
-                        int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
-                        sync();                                                     // s_dec complete
-                        uint32_t sig = 0;
-#pragma unroll
-                        for (int b = 0; b < 24; b++) {
-                            // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
-                            sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
-                            pos = (pos >> 1) & 0x3F;
-                            pos |= (int)((s_dec[23 - b] >> pos) & 1) << 6;
-                        }
-                        sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;     // viterbi.hpp:39 (wave-uniform)
-                        // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
-                        bool ok = true;
-                        sig &= 0xFFFFFF;
-                        if (sig & 0xFC0010) ok = false;
-                        uint32_t par = (sig >> 16) ^ sig; par = (par >> 8) ^ par; par = (par >> 4) ^ par; par = (par >> 2) ^ par; par = (par >> 1) ^ par;
-                        if (par & 1) ok = false;
-                        uint32_t kbps = 0; int nd = 0, nb = 0, cr = 0;
-                        switch (sig & 0xF) {                                        // ieee80211a_cmn.h:97-107, :65-94, :114-149
-                        case 0x8: kbps = 48000; nd = 192; nb = 6; cr = 1; break;  case 0x9: kbps = 24000; nd = 96;  nb = 4; cr = 0; break;
-                        case 0xA: kbps = 12000; nd = 48;  nb = 2; cr = 0; break;  case 0xB: kbps = 6000;  nd = 24;  nb = 1; cr = 0; break;
-                        case 0xC: kbps = 54000; nd = 216; nb = 6; cr = 2; break;  case 0xD: kbps = 36000; nd = 144; nb = 4; cr = 2; break;
-                        case 0xE: kbps = 18000; nd = 72;  nb = 2; cr = 2; break;  case 0xF: kbps = 9000;  nd = 36;  nb = 1; cr = 2; break;
-                        default: ok = false; break;
-                        }
-                        const uint32_t len = (sig >> 5) & 0xFFF;
-                        if (len > 2500) ok = false;
-                        r_start = frame_start; r_slot0 = slot0; r_data_start = sym_start / STR;
-                        r_cfo_comp = cfo_comp; r_sfo_comp = sfo_comp; r_cfo_tr = cfo_tracker; r_sfo_tr = sfo_tracker;
-                        if (ok) {
-                            const uint32_t ns = (len * 8 + 16 + 6 + (uint32_t)nd - 1) / (uint32_t)nd;   // B11aGetSymbolCount
-                            r_rate = kbps; r_len = len; r_nsym = ns; r_cr = (uint32_t)cr; r_nb = (uint32_t)nb;
-                            remain_symbols = ns + 1; plcp_is_data = 1;
+                        // ---- the SIGNAL symbol: full header chain, lane-parallel (signal_section, out of line)
+                        const SigOut so = signal_section(T, iq, sym_start, STR, ctx_of(nfr));
+                        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+                        r_start = frame_start; r_slot0 = cd.slot_base + (sym_start / STR) / 80; r_data_start = sym_start / STR;
+                        r_cfo_comp = uni(so.cfo_comp); r_sfo_comp = uni(so.sfo_comp); r_cfo_tr = uni(so.cfo_tr); r_sfo_tr = uni(so.sfo_tr);
+                        if (uni((int)so.ok)) {
+                            r_rate = (uint32_t)uni((int)so.kbps); r_len = (uint32_t)uni((int)so.len); r_nsym = (uint32_t)uni((int)so.nsym);
+                            r_cr = (uint32_t)uni((int)so.cr); r_nb = (uint32_t)uni((int)so.nb);
+                            remain_symbols = r_nsym + 1; plcp_is_data = 1;
                         } else {
                             r_rate = 0; r_len = 0; r_nsym = 0; r_cr = 0; r_nb = 0;
                             error_code = E_PLCP_HEADER_FAIL;
                         }
-                        sync();
                         PROBE_ADD(2);
                     }
                     sym_idx++;
@@ -504,8 +562,10 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                 }
             }
             vpos += BUR;
+            PROBE_A(_tb, 6);
         }
         // ---- RxThread bookkeeping after each source call (fb11a_demod.cpp:37-71)
+        PROBE_T(_tc);
         if (error_code != 0) {
             if (error_code == E_CS_TIMEOUT) {
                 error_code = 0; cca_detected = 0; cs_reset();
@@ -533,8 +593,10 @@ __global__ void __launch_bounds__(64, 3) k_scan(ScanArgs A)
                 frame_reset();
             }
         }
+        PROBE_A(_tc, 7);
     }
     if (lane == 0) A.nframes[cap_i] = nfr;
+    PROBE_ADDK(5);
 }
 
 }  // namespace sora

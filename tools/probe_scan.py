@@ -1,30 +1,34 @@
-"""Developer probe: where does k_scan spend its cycles? (build with -DSORA_SCAN_PROBE)"""
-import ctypes, os, subprocess, sys, time
+"""Developer probe: where does k_scan spend its cycles?  Builds the library with -DSORA_SCAN_PROBE (clock64 around the regions of k_scan,
+block 0 only) and runs it on the bench workload (one 54 Mbps 1500-byte frame per capture at sample 0, 160 samples of silence behind it)."""
+import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-so = "/tmp/libsora_probe.so"
-src = [os.path.join(ROOT, "sora_amd", "csrc", f) for f in ("k_scan.hip", "k_rx.hip", "k_stage.hip", "sora_hip.cpp")]
-subprocess.check_call(["hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip", "-DSORA_SCAN_PROBE"] + src + ["-o", so])
-import torch
 from sora_amd import build as b
-b.LIB = so
+so = os.path.join(ROOT, "sora_amd", "lib", "variants", "scan_probe.so")
+if not os.path.exists(so) or "--rebuild" in sys.argv:                     # (build it where there is no GPU to pay for: python tools/probe_scan.py --build-only)
+    so = b.build_variant("scan_probe", ["SORA_SCAN_PROBE"])
+if "--build-only" in sys.argv:
+    sys.exit(0)
+os.environ["SORA_HIP_LIB"] = so
+import torch
 import sora_amd
 from oracle.pyoracle import Oracle
-from gpu_util import make_capture, batch
+import bench
 o = Oracle()
-caps = [make_capture(o, 54000, 1496, seed=i, rate_mhz=20, sigma=300, tail=320)[0] for i in range(64)]
-iq, descs = batch(caps)
-rx = sora_amd.Rx(len(caps), len(iq), sample_rate_mhz=20)
+n = 4096
+iq, descs, _ = bench.make_workload(o, n, 0, distinct=64)
+rx = sora_amd.Rx(n, len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+rx.set_depth(1)
 d = torch.from_numpy(iq).cuda()
 for _ in range(3):
     rx.process_dev(d, descs); rx.flush()
-rx.set_profiling(True); rx.process_dev(d, descs); rx.flush(); print(rx.kernel_times())
+rx.set_profiling(True); rx.process_dev(d, descs); rx.flush(); print(rx.kernel_times()); rx.set_profiling(False)
 L = ctypes.CDLL(so)
 buf = (ctypes.c_ulonglong * 16)()
 L.sora_debug_scan_probe(buf, 1)
 rx.process_dev(d, descs); rx.flush()
 L.sora_debug_scan_probe(buf, 0)
-names = ["carrier sense (all bursts)", "T11aLTS", "SIGNAL chain"]
-for i, n in enumerate(names):
-    print("%-28s %9d cycles" % (n, buf[i]))
+names = ["carrier sense, burst by burst", "T11aLTS", "SIGNAL chain", "fast_idle passes", "fast_sync passes", "whole kernel (capture 0)", "burst-by-burst iterations (incl. the first three rows)", "bookkeeping after a source call"]
+for i, nme in enumerate(names):
+    print("%-32s %9d ticks  %5d times" % (nme, buf[i], buf[8 + i]))
