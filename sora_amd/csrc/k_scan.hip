@@ -65,10 +65,30 @@ __device__ __forceinline__ int carrier_bin(int k)
     int b = 1 + (k - 24); if (b >= 7) b++; if (b >= 21) b++; return b;
 }
 
+// The tables the two out-of-line sections use, handed over BY VALUE: a reference to the kernel's argument block would force that block
+// into private memory, and everything read from it (thresholds, strides) would count as lane-varying -- the whole carrier-sense state machine
+// would then run in vector registers under exec masks.
+struct ScanTabs { const short* uatan2; const uint32_t* rot; const uint8_t* demap; const uint16_t* deint; const uint32_t* tw64; const uint32_t* tw16; };
+template <typename P> __device__ __forceinline__ P* uni_ptr(P* p)
+{
+    const uint64_t v = (uint64_t)(uintptr_t)p;
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v), hi = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32));
+    return (P*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ Tables tables_of(const ScanTabs& b)
+{
+    Tables T = {};
+    T.uatan2 = uni_ptr(b.uatan2); T.rot = uni_ptr(b.rot); T.demap = uni_ptr(b.demap); T.deint = uni_ptr(b.deint); T.tw64 = uni_ptr(b.tw64); T.tw16 = uni_ptr(b.tw16);
+    return T;
+}
+
 // ---- T11aLTS on the 144 samples at lts_start (channel_11a.hpp:206-330): CFO estimate, frequency shift, FFT<64>, channel inverse -> *fx.
 // Out of line (once per frame): its temporaries and table pointers stay out of the carrier-sense loop's register allocation.  Returns the CFO.
-__device__ __noinline__ int lts_section(const Tables& T, const uint32_t* iq, uint32_t lts_start, uint32_t STR, FrameCtx* fx)
+__device__ __noinline__ int lts_section(ScanTabs tabs, const uint32_t* iq_, uint32_t lts_start_, uint32_t STR_, FrameCtx* fx_)
 {
+    const Tables T = tables_of(tabs);
+    const uint32_t* iq = uni_ptr(iq_); FrameCtx* fx = uni_ptr(fx_);
+    const uint32_t lts_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)lts_start_), STR = (uint32_t)__builtin_amdgcn_readfirstlane((int)STR_);
     __shared__ uint32_t s_fft[64];
     __shared__ uint32_t s_x[144];
     const int lane = threadIdx.x;
@@ -121,8 +141,11 @@ __device__ __noinline__ int lts_section(const Tables& T, const uint32_t* iq, uin
 // ---- the SIGNAL symbol at sym_start: T11aDataSymbol .. T11aViterbiSig .. T11aPLCPParser (PHY_11a.hpp:389-580), lane-parallel; out of line
 // like lts_section.  Every field of the result is wave-uniform.
 struct SigOut { uint32_t ok, kbps, len, nsym, cr, nb; int cfo_comp, sfo_comp, cfo_tr, sfo_tr; };
-__device__ __noinline__ SigOut signal_section(const Tables& T, const uint32_t* iq, uint32_t sym_start, uint32_t STR, const FrameCtx* fx)
+__device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_, uint32_t sym_start_, uint32_t STR_, const FrameCtx* fx_)
 {
+    const Tables T = tables_of(tabs);
+    const uint32_t* iq = uni_ptr(iq_); const FrameCtx* fx = uni_ptr(fx_);
+    const uint32_t sym_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym_start_), STR = (uint32_t)__builtin_amdgcn_readfirstlane((int)STR_);
     __shared__ uint32_t s_fft[64];
     __shared__ uint8_t  s_soft[48];
     __shared__ uint64_t s_dec[25];                   // Viterbi_sig11 decision words (wave-uniform ballots)
@@ -241,6 +264,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     const uint32_t STR = A.str, APP = 28 / (2 / STR), BUR = 8 / (2 / STR);
     const uint32_t nunits = (cd.nsamples / APP) * APP;
     const Tables& T = A.T;
+    const ScanTabs tabs = { T.uatan2, T.rot, T.demap, T.deint, T.tw64, T.tw16 };
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
     uint32_t Hv = 0;                         // sample_his in TIME ORDER, one packed sample per lane (lane & 15, oldest = 0): 4 bursts of 4, already >>2
@@ -509,7 +533,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                 if (lts_n == 144) {
                     PROBE_T0();
                     lts_n = 0; symbol_is_data = 1;
-                    r_cfo = __builtin_amdgcn_readfirstlane(lts_section(T, iq, lts_start, STR, ctx_of(nfr)));
+                    r_cfo = __builtin_amdgcn_readfirstlane(lts_section(tabs, iq, lts_start, STR, ctx_of(nfr)));
                     PROBE_ADD(1);
                 }
             } else {
@@ -528,7 +552,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                     if (sym_idx == 0) {
                         PROBE_T0();
                         // ---- the SIGNAL symbol: full header chain, lane-parallel (signal_section, out of line)
-                        const SigOut so = signal_section(T, iq, sym_start, STR, ctx_of(nfr));
+                        const SigOut so = signal_section(tabs, iq, sym_start, STR, ctx_of(nfr));
                         auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
                         r_start = frame_start; r_slot0 = cd.slot_base + (sym_start / STR) / 80; r_data_start = sym_start / STR;
                         r_cfo_comp = uni(so.cfo_comp); r_sfo_comp = uni(so.sfo_comp); r_cfo_tr = uni(so.cfo_tr); r_sfo_tr = uni(so.sfo_tr);
