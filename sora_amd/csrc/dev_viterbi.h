@@ -78,6 +78,50 @@ __device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-ha
     return pk_min16(r32[0], r32[1]);
 }
 
+// ------------------------------------------------------------------------------------------------
+// The soft stream (rx_types.h).  Producers pack eight values (three bits each, value j in bits 3 j ..) into three bytes; a trellis lane
+// fetches the 16 bits that contain value i of its frame -- at any byte address: gfx950 serves unaligned 16-bit loads
+// (tools/calib/unaligned_probe.hip) -- and shifts.
+__device__ __forceinline__ uint32_t soft3_pack8(const uint32_t v[8])
+{
+    return v[0] | (v[1] << 3) | (v[2] << 6) | (v[3] << 9) | (v[4] << 12) | (v[5] << 15) | (v[6] << 18) | (v[7] << 21);
+}
+__device__ __forceinline__ void soft3_store8(uint8_t* stream, uint32_t group, uint32_t bits24)     // values 8 group .. 8 group + 7
+{
+    uint8_t* p = stream + 3u * group;
+    p[0] = (uint8_t)bits24; p[1] = (uint8_t)(bits24 >> 8); p[2] = (uint8_t)(bits24 >> 16);
+}
+struct SoftRaw { uint32_t w, sh; };                        // a fetched value before the shift
+// One lane's view of one frame's stream: value k of every CW-value chunk.  BITS is a property of the kernel (3 for the 802.11a graph's
+// producers, 8 for the 802.11n / 40 MHz ones).  When a chunk is a whole number of bytes (every case but three-bit values at rate 2/3) the
+// value's bit offset inside its byte never changes: a fetch is an add, a clamp and a load, the field a shift and a mask.  Past the frame's
+// end the fetch address stays on the frame's last value (some well-formed value: nobody uses it).
+template <int BITS, int CW> struct SoftCursor {
+    static constexpr int ADV = BITS * CW;
+    static constexpr bool kConst = ADV % 8 == 0;
+    uint32_t off;            // kConst: byte offset (from the soft base) of the value in chunk 0; else: of the stream
+    uint32_t pos;            // else: bit offset of the value in chunk 0 inside the stream
+    uint32_t lim;            // kConst: byte offset of the frame's last value; else: its bit offset inside the stream
+    uint32_t lsh;            // kConst: 9 - (bit offset & 7): the shift that puts the value at bits 9..11
+    __device__ __forceinline__ void init(uint32_t stream_off, uint32_t k, uint32_t last)
+    {
+        const uint32_t t0 = (uint32_t)BITS * min(k, last), tl = (uint32_t)BITS * last;
+        if (kConst) { off = stream_off + (t0 >> 3); pos = 0; lim = stream_off + (tl >> 3); lsh = 9u - (t0 & 7u); }
+        else { off = stream_off; pos = t0; lim = tl; lsh = 0; }
+    }
+    __device__ __forceinline__ SoftRaw fetch(const uint8_t* __restrict__ base, uint32_t c) const
+    {
+        SoftRaw r;
+        if (kConst) { r.sh = 0; r.w = *reinterpret_cast<const uint16_t*>(base + min(off + c * (uint32_t)(ADV / 8), lim)); }
+        else { const uint32_t t = min(pos + c * (uint32_t)ADV, lim); r.sh = t & 7u; r.w = *reinterpret_cast<const uint16_t*>(base + (off + (t >> 3))); }
+        return r;
+    }
+    __device__ __forceinline__ uint32_t field(const SoftRaw& r) const                                   // the value as a 16-bit metric field (u << 9)
+    {
+        return kConst ? (r.w << lsh) & 0x0E00u : ((r.w >> r.sh) & 7u) << 9;
+    }
+};
+
 constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
 constexpr unsigned kOne = 0x00020001u;                    // mark bit 0 of both frames: bit 0 (frame A), bit 17 (frame B; bit 16 is the carry guard, see acs_step)
 constexpr unsigned kGuard = 1u << 16;

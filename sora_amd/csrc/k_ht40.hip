@@ -30,13 +30,13 @@ struct Ht40Frame {
     uint32_t length[2];
     int32_t  cfo;               // phase per 40 MHz sample, 65536 = 2 pi (TFreqComp_11n's vfo_step convention)
     float    noise_var;         // per carrier, in LSB^2 of the FFT output; 0 = zero forcing
-    uint32_t soft_off;          // dwords from the soft base: the frame's PAIR STREAM (k_rx.hip viterbi_forward), stream 0 << 9 | stream 1 << 25
+    uint32_t soft_off;          // bytes from the soft base: stream 0's soft values, one byte each (VitJob::soft_bits = 8); stream 1's follow at + round_up(values per stream, 32)
     uint32_t pad[4];
 };
 struct Ht40Args {
     const uint32_t* iq0; const uint32_t* iq1; const Ht40Frame* frames; uint32_t nframes;
     Tables T; const uint32_t* sincos; const short* atan;
-    uint32_t* soft;
+    uint8_t* soft;
     uint32_t* w_out;            // optional [nframes][4][128]: the detection weights (tests)
 };
 struct Ht40Job { uint32_t out_off, length, row, pad; };
@@ -168,7 +168,8 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
     }
     wsync40();
     // ---- data symbols, in order (the pilot phase of symbol d rotates symbol d + 1)
-    uint32_t* dst = A.soft + F.soft_off;
+    uint8_t* dst = A.soft + F.soft_off;
+    const uint32_t per_pad = (F.nsym * 108u * F.nb + 31u) / 32u * 32u;         // stream 1 starts here (ht40_submit lays the job records out the same way)
     for (uint32_t d = 0; d < F.nsym; d++) {
         symbol_fft(320 + 160 * d, 0);
 #pragma unroll
@@ -211,10 +212,11 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
             }
         }
         wsync40();
-        // de-interleave both streams into the frame's pair stream: one decoder wave takes stream 0 in its low halves and stream 1 in its
-        // high halves, so operand g = soft value g of stream 0 << 9 | soft value g of stream 1 << 25 (whole-dword coalesced stores)
-        for (int g = lane; g < ncb; g += 64)
-            dst[(size_t)d * ncb + g] = ((uint32_t)W.soft[0][W.dtab[0][g]] << 9) | ((uint32_t)W.soft[1][W.dtab[1][g]] << 25);
+        // de-interleave both streams, each into its own byte stream (one decoder wave takes stream 0 in its low halves and stream 1 in its high halves)
+        for (int g = lane; g < ncb; g += 64) {
+            dst[(size_t)d * ncb + g] = W.soft[0][W.dtab[0][g]];
+            dst[per_pad + (size_t)d * ncb + g] = W.soft[1][W.dtab[1][g]];
+        }
         wsync40();
     }
 }
@@ -268,7 +270,7 @@ struct Ht40Event { uint32_t capture_id, end_sample, error_code, mcs, length, nsy
 struct Ht40Slot {
     hipStream_t stream = nullptr;
     Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
-    uint32_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
+    uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
     std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0;
     int ticket = 0;             // of the call this slot holds (0: none)
     // sora_ht40_process_captures_dev: the front end's arrays (grow-only) and what it found in this slot's call
@@ -377,13 +379,13 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
         F.soft_off = (uint32_t)soft;
         for (int k = 0; k < 2; k++) {
             VitJob& J = hj[s.code_rate * stride + nj[s.code_rate]++];                // the two streams of a frame are neighbours in their list: one wave decodes both
-            J.soft_off = F.soft_off; J.nsoft = (uint32_t)per; J.length = s.length[k]; J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate; J.pad = 0;
+            J.soft_off = F.soft_off + (uint32_t)k * (uint32_t)((per + 31) / 32 * 32); J.soft_bits = 8; J.nsoft = (uint32_t)per; J.length = s.length[k]; J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate;
             fj[2 * i + k] = Ht40Job{ J.out_off, s.length[k], (uint32_t)(2 * i + k), 0 };
         }
-        soft += (per + 31) / 32 * 32;                                               // dwords: one operand per soft value of a stream
+        soft += 2 * ((per + 31) / 32 * 32);                                         // bytes: one per soft value, both streams
         F.pad[0] = F.pad[1] = F.pad[2] = F.pad[3] = 0;
     }
-    if (2 * soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
+    if (soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
     S.h_frames.assign(frames, frames + nframes); S.nframes = (uint32_t)nframes; rx->have_results = true;
     rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
     S.ticket = ++rx->seq;
@@ -399,9 +401,9 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
     hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, S.stream, A);
     const uint32_t njobs = 2 * (uint32_t)nframes;
     if (rx->lanes16)
-        hipLaunchKernelGGL(k_viterbi16_11n, dim3((njobs + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint32_t*)S.d_soft, S.d_vout);
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((njobs + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     else
-        hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint32_t*)S.d_soft, S.d_vout);
+        hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T;
     hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());

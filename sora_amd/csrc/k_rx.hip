@@ -27,7 +27,7 @@ __device__ __constant__ uint8_t kPilotSgn[128] = {        // pilot.hpp:10-28: 1 
 // the pass's four symbols in order, pilot k in lane k, the loop state in scalar registers.  The equalised symbol never
 // leaves LDS; the small tables (demap steps, de-interleaver map) live in LDS, the FFT twiddles in registers; the next
 // pass's samples are requested before the tracking loop so that their latency hides behind it.
-//   algorithmic bytes per data symbol: 256 read (64 of the 80 samples) + 2 N_CBPS written (16-bit operand fields of the pair stream)
+//   algorithmic bytes per data symbol: 256 read (64 of the 80 samples) + 3 N_CBPS / 8 written (the packed soft stream, rx_types.h)
 __global__ void __launch_bounds__(256) k_frame(RxArgs A)
 {
     __shared__ uint32_t s_eq[4][4][64];                                          // [wave][symbol of the pass]: FFT staging, then the equalised bins
@@ -42,22 +42,11 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     const uint32_t j = jr.list * A.nrows + jr.idx;                               // slot of the job in jobs[] / joblist[]
     const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
-    // The pair stream (viterbi_forward): jobs 2p and 2p+1 of a code-rate list are decoded by one wave from one operand stream, this frame's
-    // soft values in the 16-bit half `half`.  The stream lives in the slot region of the pair's frame with more soft values (a tie: the even
-    // job), 4 bytes per operand; this wave zero-fills its half from its own end to the pair's.
-    const uint32_t half = jr.idx & 1u;
-    const bool has_mate = (jr.idx ^ 1u) < A.njobs[jr.list];
-    uint32_t my_nsoft = (uint32_t)r.nsym * 48u * r.nbpsc, pair_nsoft = my_nsoft, host_slot0 = r.slot0;
-    if (has_mate) {
-        const FrameRow& m = A.frames[A.joblist[jr.list * A.nrows + (jr.idx ^ 1u)]];
-        const uint32_t mate_nsoft = (uint32_t)m.nsym * 48u * m.nbpsc;
-        if (mate_nsoft > my_nsoft || (mate_nsoft == my_nsoft && half == 1u)) host_slot0 = m.slot0;
-        pair_nsoft = max(my_nsoft, mate_nsoft);
-    }
+    const uint32_t my_nsoft = (uint32_t)r.nsym * 48u * r.nbpsc;
     if (lane == 0) {
-        VitJob J; J.pad = 0;
-        J.valid = 1; J.soft_off = host_slot0 * (uint32_t)kSoftPerSlot; J.nsoft = my_nsoft; J.length = r.length;
-        J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate;
+        VitJob J;
+        J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = my_nsoft; J.length = r.length;
+        J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
         A.jobs[j] = J;
     }
     const FrameCtx* fx = A.fctx + f;
@@ -68,13 +57,15 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
 #pragma unroll
     for (int m = 0; m < 4; m++) { fq[m] = pk_tw_mul(fx->freq[e + 16 * m]); ch[m] = pk_tw_mul(fx->chan[e + 16 * m]); }
     const int nb = __builtin_amdgcn_readfirstlane((int)r.nbpsc), ncbps = 48 * nb, nsym = __builtin_amdgcn_readfirstlane((int)r.nsym);   // (wave-uniform: scalar branches on the modulation)
-    uint32_t mp[5];                                                              // de-interleaver source index of output positions lane + 64 t (past N_CBPS: none)
+    // de-interleaver source indices of output positions 8 lane .. 8 lane + 7 (lane < N_CBPS / 8: one three-byte group of the packed stream), two per register
+    uint32_t mp[4];
+    const bool packs = 8 * lane < ncbps;
     {
         const uint16_t* map = T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
 #pragma unroll
-        for (int t = 0; t < 5; t++) mp[t] = lane + 64 * t < ncbps ? (uint32_t)map[lane + 64 * t] : 0xFFFFFFFFu;
+        for (int t = 0; t < 4; t++) mp[t] = packs ? (uint32_t)map[8 * lane + 2 * t] | ((uint32_t)map[8 * lane + 2 * t + 1] << 16) : 0u;
     }
-    uint16_t* dst = reinterpret_cast<uint16_t*>(A.soft + (size_t)host_slot0 * kSoftPerSlot) + half;     // operand i of the pair: dst[2 i]
+    uint8_t* dst = A.soft + (size_t)r.slot0 * kSoftBytesPerSlot;                  // the frame's packed soft stream: symbol s (1-based) at 3 N_CBPS / 8 * (s - 1) bytes
     // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
     const int pk = lane & 3;
     const int pbin = pk == 0 ? 43 : pk == 1 ? 57 : pk == 2 ? 7 : 21, pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
@@ -157,41 +148,37 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
             }
         }
         wsync();
-        // ---- T11aDeinterleave*: out[k] = in[j(k)]; the pass's symbols are contiguous in the frame's half of the pair stream (16-bit fields v << 9)
+        // ---- T11aDeinterleave*: out[k] = in[j(k)], eight values -> three bytes of the frame's stream (soft3_store8), symbol by symbol
         {
             const int nact = min(4, nsym - s0 + 1);
-            uint16_t* d = dst + 2 * ((size_t)(s0 - 1) * ncbps + lane);
-            for (int gs = 0; gs < nact; gs++, d += 2 * ncbps) {                 // (symbol by symbol: no index arithmetic per value)
-                const uint8_t* src = s_soft[w][gs];
+            const uint32_t sym_bytes = 3u * (uint32_t)ncbps / 8u;
+            uint8_t* d = dst + (size_t)(s0 - 1) * sym_bytes;
+            for (int gs = 0; gs < nact; gs++, d += sym_bytes) {
+                if (packs) {
+                    const uint8_t* src = s_soft[w][gs];
+                    uint32_t v[8];
 #pragma unroll
-                for (int t = 0; t < 5; t++)
-                    if (mp[t] != 0xFFFFFFFFu) d[128 * t] = (uint16_t)((uint32_t)src[mp[t]] << 9);
+                    for (int t = 0; t < 4; t++) { v[2 * t] = src[mp[t] & 0xFFFFu]; v[2 * t + 1] = src[mp[t] >> 16]; }
+                    soft3_store8(d, (uint32_t)lane, soft3_pack8(v));
+                }
             }
         }
         wsync();
     }
-    for (uint32_t i = my_nsoft + lane; i < pair_nsoft; i += 64) dst[2 * (size_t)i] = 0;   // the shorter frame of a pair: zero operands up to the pair's end
 }
 
 // (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
-#ifndef SORA_VIT_PF_AHEAD
-#define SORA_VIT_PF_AHEAD 6
-#endif
-constexpr int kVitPfAhead = SORA_VIT_PF_AHEAD;              // chunks of look-ahead of the pair stream's L2 prefetch (0: none); build variants measure others
-typedef uint32_t u32x16_t __attribute__((ext_vector_type(16)));
-typedef uint32_t u32x8_t __attribute__((ext_vector_type(8)));
-typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 struct VitSide {            // wave-uniform per-frame bookkeeping
     uint8_t* out; uint32_t nsteps, tr_end; bool done;
 };
 
-// Soft input: the PAIR STREAM.  The two frames a wave decodes (consecutive jobs of one code-rate list) share one stream of ready-made
-// branch-metric operands: dword i = (soft value i of frame A) << 9 | (soft value i of frame B) << 25 -- exactly what acs_step xors with the
-// lane's mask.  The producers (k_frame, k_frame11n, k_ht40_frame, k_soft_widen) write each frame's 16-bit half; the stream lives in the
-// slot region of the frame with more soft values and the shorter frame's half is zero-filled up to the pair's length (its trellis half keeps
-// stepping on well-formed operands: a half fed garbage could carry twice into the guard bit within one block).  One s_load_dwordx16 (+x8 /
-// +x2) per 12-step chunk through the scalar cache, prefetched one chunk ahead; no scalar packing (the split streams of round 2 cost one
-// s_pack_ll/hh_b32_b16 per soft value and two address computations per chunk: a third of the kernel's issue slots).
+// Soft input: the two frames a wave decodes (consecutive jobs of one code-rate list) each have their own packed stream (rx_types.h: three
+// bits per value, or a byte).  Per 12-step chunk, lane k < 32 fetches value k of frame A, lane 32 + k value k of frame B (one 16-bit load
+// each, two chunks ahead), shifts it into a 16-bit metric field and writes it to the wave's operand table in LDS; five or six broadcast
+// ds_read_b128 then give every lane the chunk's operands, dword i = field A | field B << 16 -- exactly what acs_step xors with the lane's
+// mask.  (Round 3 first kept such operand dwords in HBM -- 264 MB per call written and read, fetched through the scalar cache; round 2 a
+// 16-bit stream per frame that cost one s_pack per value.)  Past a frame's end its last value is repeated: its trellis half keeps stepping
+// on well-formed operands (a half fed garbage could carry twice into the guard bit within one block).
 //
 // Trace-back (TViterbiCore::Traceback, viterbicore.h:468-555) runs in the same wave, out of LDS, whenever the window
 // schedule of T11aViterbi<..,256,24>::Process (viterbi.hpp:196-214) fires: the ring holds, per 8-column block j
@@ -202,8 +189,8 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
 // & 0x3F) << 2.
 // WIN / LOOK: the window schedule of T11aViterbi<.., N_INPUT, TRELLIS_DEPTH = WIN, TRELLIS_LOOKAHEAD = LOOK> -- 256 / 24 in the 802.11a graph
 // (fb11ademod_config.hpp:199), 192 / 36 in the 802.11n graph (fb11ndemod_config.hpp:199); a walk touches at most (WIN + LOOK + 7) / 8 + 2 <= 38 blocks.
-template <int CR, int WIN, int LOOK>
-__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint32_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring, uint32_t* pf_dump)
+template <int CR, int WIN, int LOOK, int BITS>
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring, uint16_t* ops)
 {
     using RG = RingGeom<WIN, LOOK>;
     constexpr int P = RG::P;
@@ -215,8 +202,10 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     A.out = out_base + JA.out_off; A.nsteps = JA.nsoft / GB * GS; A.tr_end = JA.length * 8u + 16u + 6u; A.done = false;
     B.out = out_base + JB.out_off; B.nsteps = hasB ? JB.nsoft / GB * GS : 0u; B.tr_end = hasB ? JB.length * 8u + 16u + 6u : 0u; B.done = !hasB;
     const uint32_t nsteps = max(A.nsteps, B.nsteps);
-    const uint32_t* sp = soft_base + JA.soft_off;                               // the pair stream (JA.soft_off == JB.soft_off, in dwords)
-    const uint32_t last_chunk = (nsteps - 1) / 12;
+    // this lane's part in fetching a chunk: value (lane & 31) of frame lane >> 5
+    const bool mineB = lane >= 32u && hasB;
+    const uint32_t my_soft_off = mineB ? JB.soft_off : JA.soft_off;
+    const uint32_t my_last = max(mineB ? JB.nsoft : JA.nsoft, 1u) - 1u, my_k = lane & 31u;
 
     auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };   // step kinds of a puncture group (viterbi.hpp:167-187)
     VitLane V;
@@ -273,35 +262,25 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
             next_thr = next_event();
         }
     };
-    // The chunk loads are written out as s_load_dwordx16 (+x8 / +x2): the look-ahead load below is inline assembly, and next to inline
-    // assembly that may touch memory the compiler no longer proves the stream unclobbered and would fetch it with VECTOR loads (8 x
-    // global_load_dwordx4 per row).  `off` is a byte offset from the pair stream's base.  The destination registers are defined by the
-    // load statement but hold the data only after lgkmcnt(0): wait_chunk() is that wait and the data dependence every use hangs on.
-    struct Chunk { u32x16_t lo; u32x8_t hi8; u32x2_t hi2; };
-    auto load_chunk = [&](uint32_t c) -> Chunk {                                // chunk c of the pair stream; past the pair's end: its last chunk again
-        Chunk K;                                                                //   (both frames are done by then)
-        const uint32_t off = min(c, last_chunk) * (uint32_t)(CW * 4);
-#ifdef SORA_DBG_NO_SMEM                                                          // experiment (tools/ab_decode.sh): no soft values from memory -- results are wrong, only the duration means something
+    struct Chunk { uint32_t v[(CW + 3) / 4 * 4]; };
+    SoftCursor<BITS, CW> cur;
+    cur.init(my_soft_off, my_k, my_last);
+    auto fetch = [&](uint32_t c) -> SoftRaw { return cur.fetch(soft_base, c); };
+    uint16_t* my_op = ops + 2u * my_k + (lane >> 5);                           // operand k, frame's half (k up to 31: the table has 32 operands, those past CW are never read)
+    auto lds_order = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    auto unpack = [&](const SoftRaw& R) -> Chunk {
+        *my_op = (uint16_t)cur.field(R);
+        lds_order();
+        Chunk K;
 #pragma unroll
-        for (int i = 0; i < 16; i++) K.lo[i] = (c * 0x9E3779B1u + (uint32_t)i * 0x85EBCA6Bu) & 0x0E000E00u;
-        K.hi8 = K.lo.lo; K.hi2 = K.lo.lo.lo.lo;
-#else
-        // ("+v"(V.U): the statement sits in the metrics' dependence chain, so the scheduler cannot sink it below the ACS work that is meant
-        //  to cover its latency -- it had moved the load to within 16 instructions of its wait)
-        asm volatile("s_load_dwordx16 %0, %2, %3" : "=s"(K.lo), "+v"(V.U) : "s"(sp), "s"(off));
-        if (CW == 24) asm volatile("s_load_dwordx8 %0, %1, %2 offset:64" : "=s"(K.hi8) : "s"(sp), "s"(off));
-        if (CW == 18) asm volatile("s_load_dwordx2 %0, %1, %2 offset:64" : "=s"(K.hi2) : "s"(sp), "s"(off));
-#endif
+        for (int i = 0; i < (CW + 3) / 4; i++) {
+            const uint4 x = reinterpret_cast<const uint4*>(ops)[i];
+            K.v[4 * i] = x.x; K.v[4 * i + 1] = x.y; K.v[4 * i + 2] = x.z; K.v[4 * i + 3] = x.w;
+        }
+        lds_order();
         return K;
     };
-    auto wait_chunk = [&](Chunk& K) {
-#ifndef SORA_DBG_NO_SMEM
-        if (CW == 24)      asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(K.lo), "+s"(K.hi8));
-        else if (CW == 18) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(K.lo), "+s"(K.hi2));
-        else               asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(K.lo));
-#endif
-    };
-    auto op = [](const Chunk& K, int i) -> uint32_t { return i < 16 ? K.lo[i] : CW == 24 ? K.hi8[i - 16] : K.hi2[i - 16]; };
+    auto op = [](const Chunk& K, int i) -> uint32_t { return K.v[i]; };
     // one puncture group = GS steps; i0 = step index inside the 12-step chunk, h = which half of the 24-step row
     auto group = [&](const Chunk& K, int h, int i0) {
         const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
@@ -330,67 +309,40 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         if (tr + 12 <= nsteps && next_thr > tr + 12) fast_chunk(K, h); else slow_chunk(K, h);
     };
 
-    // A chunk is 64 / 72 / 96 bytes the wave reads exactly once: every scalar load is a miss all the way to HBM (or the Infinity
-    // Cache, where k_frame's stores went), ~0.6 us against the ~0.25 us one chunk of ACS work covers.  (The split streams of round 2 read
-    // 32 bytes per frame and chunk, so every other load hit the line its predecessor had fetched.)  A second scalar load in flight would
-    // not help -- lgkmcnt(0) waits for the youngest too -- but the vector memory path has its own counter: one never-waited-for load per
-    // 128-byte line, kVitPfAhead chunks ahead, pulls the line into the L2 the scalar cache misses into.  It is an LDS-DMA load
-    // (global_load_lds_dword: all lanes read the same dword, the 256 bytes land in a per-wave dump area nobody reads), because a load into
-    // a VGPR would write that register whenever it returns -- long after the allocator has handed it to something else.  The stream's
-    // owner allocates 4 KB of slack behind the last pair stream, so the look-ahead of the last pair stays inside the buffer.
-    constexpr int kPfPerRow = (2 * CW * 4) % 128 == 0 ? 1 : 2;                  // 3/4: a row is exactly one line; 1/2, 2/3: one per chunk touches every line
-    unsigned pf_off = (unsigned)kVitPfAhead * CW * 4u;
-    const unsigned pf_m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(uintptr_t)pf_dump);                        // LDS offset of the dump area (the low half of a flat LDS address)
-    auto prefetch_row = [&]() {
-        if (kVitPfAhead > 0) {
-#pragma unroll
-            for (int i = 0; i < kPfPerRow; i++)
-                asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, %2 offset:%3" : : "s"(pf_m0), "v"(pf_off), "s"(sp), "n"(i * CW * 4) : "m0");
-            pf_off += 2u * CW * 4u;
-        }
-    };
-    // Scalar loads return out of order, so the only wait the hardware offers is lgkmcnt(0).  The load of chunk c+1 is therefore ISSUED
-    // right after the wait for chunk c (statement order: the assembly statements are volatile) and is covered by a whole chunk of ACS work.
+    // Vector loads return in order: chunk c + 2 is requested before chunk c is stepped through (the compiler's vmcnt waits follow from that).
     uint32_t c = 0;
-    Chunk cur = load_chunk(0);
+    SoftRaw r0 = fetch(0), r1 = fetch(1);
     while (tr < nsteps && !(A.done && B.done)) {
         // rows (2 chunks) that certainly need no look at the schedule: run them back to back, 9 rows out of 10
         const uint32_t lim = min(nsteps, next_thr - 1);
         for (uint32_t rows = lim > tr ? (lim - tr) / 24 : 0; rows > 0; rows--) {
-            prefetch_row();
-            wait_chunk(cur);
-            Chunk nxt = load_chunk(c + 1);
-            fast_chunk(cur, 0);
-            wait_chunk(nxt);
-            cur = load_chunk(c + 2);
-            fast_chunk(nxt, 1);
+            const Chunk K0 = unpack(r0); r0 = fetch(c + 2);
+            fast_chunk(K0, 0);
+            const Chunk K1 = unpack(r1); r1 = fetch(c + 3);
+            fast_chunk(K1, 1);
             c += 2;
             end_row();
         }
         if (!(tr < nsteps)) break;
-        prefetch_row();                                                         // (the slow rows keep the look-ahead in step)
-        wait_chunk(cur);
-        Chunk nxt = load_chunk(c + 1);
-        chunk(cur, 0);
-        wait_chunk(nxt);                                                        // (also when the row ends early: no load is left in flight behind the loop)
+        const Chunk K0 = unpack(r0); r0 = fetch(c + 2);
+        chunk(K0, 0);
         if (!(tr < nsteps && !(A.done && B.done))) break;
-        cur = load_chunk(c + 2);
-        chunk(nxt, 1);
+        const Chunk K1 = unpack(r1); r1 = fetch(c + 3);
+        chunk(K1, 1);
         c += 2;
         end_row();
     }
-    wait_chunk(cur);
 }
 
 // Four waves per 256-thread workgroup, two frames per wave (no cross-wave traffic).  One-wave workgroups were kept to
 // 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.
 // Frames are queued per code rate (k_scan), so the two frames of a wave always share the puncture pattern; the last
 // frame of an odd list runs alone in the low half.  (Jobs given through sora_hip_viterbi11a are one list of one rate.)
-template <int WIN, int LOOK>
-__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
+template <int WIN, int LOOK, int BITS>
+__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
     __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];                // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
-    __shared__ uint32_t s_pfdump[4][64];                                         // where the look-ahead loads of the pair stream land (viterbi_forward); with it 40 KB: four workgroups per CU
+    __shared__ uint16_t s_ops[4][64];                                            // [wave][operand of the chunk][frame]: the soft values as metric fields (viterbi_forward); with it under 40 KB: four workgroups per CU
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
     // wave -> (code-rate list, pair): list r has ceil(n_r / 2) pairs (njobs3 == nullptr: one list of njobs_single jobs)
     uint32_t n[3] = { njobs_single, 0, 0 };
@@ -406,22 +358,22 @@ __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ j
         const VitJob& G = jobs[f];
         VitJob J;
         J.soft_off = uni(G.soft_off); J.nsoft = uni(G.nsoft); J.length = uni(G.length); J.dec_off = uni(G.dec_off);
-        J.out_off = uni(G.out_off); J.valid = uni(G.valid); J.code_rate = uni(G.code_rate); J.pad = 0;
+        J.out_off = uni(G.out_off); J.valid = uni(G.valid); J.code_rate = uni(G.code_rate); J.soft_bits = uni(G.soft_bits);
         return J;
     };
     const VitJob JA = load_job(fa);
     const bool hasB = fb < njobs;
     const VitJob JB = hasB ? load_job(fb) : JA;
-    if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK>(JA, JB, hasB, soft, out, ring, s_pfdump[threadIdx.x >> 6]);
-    else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK>(JA, JB, hasB, soft, out, ring, s_pfdump[threadIdx.x >> 6]);
-    else                        viterbi_forward<2, WIN, LOOK>(JA, JB, hasB, soft, out, ring, s_pfdump[threadIdx.x >> 6]);
+    if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
+    else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
+    else                        viterbi_forward<2, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
 }
 
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
-{ viterbi_kernel_body<256, 24>(jobs, njobs3, njobs_single, stride, soft, out); }
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+{ viterbi_kernel_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out); }
 // the 802.11n graph's decoder: T11aViterbi<5000*8, 312, 192, 36> (fb11ndemod_config.hpp:199)
-__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
-{ viterbi_kernel_body<192, 36>(jobs, njobs3, njobs_single, stride, soft, out); }
+__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+{ viterbi_kernel_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }
 
 // ------------------------------------------------------------------------------------------------
 // k_finish: T11aDesc (scramble.hpp:267-353) + TBB11aFrameSink (PHY_11a.hpp:607-702).  One wave per frame.
@@ -526,30 +478,26 @@ __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uin
 // stand-alone stage kernels (per-stage C entry points)
 // (k_fft64_batch, k_demap_batch, k_deint_batch: k_stage.hip)
 
-// sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits); the trellis kernel reads the
-// pair stream (viterbi_forward).  Block j widens job j into its half of the stream it shares with job j ^ 1 -- hosted at 4 x the byte
-// offset of the pair's longer job, which keeps the hosted ranges disjoint because the caller's are -- zero-fills its half up to the
-// pair's length, and writes its job record.
-__global__ void __launch_bounds__(256) k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
-                                                    int code_rate, uint32_t n, uint32_t span, uint32_t* pair, VitJob* jobs)
+// sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits); the trellis kernels read packed
+// streams out of buffers that have slack behind them (their 16-bit fetches reach one byte past a stream's end).  Block j packs job j's
+// values (a multiple of 8: the port burst is 48) into the workspace at byte 3 ceil(off8[j] / 8) -- disjoint because the caller's ranges
+// are -- and writes its job record.
+__global__ void __launch_bounds__(256) k_soft_pack3(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
+                                                    int code_rate, uint8_t* packed, VitJob* jobs)
 {
-    const uint32_t j = blockIdx.x, mate = j ^ 1u, half = j & 1u;
-    const uint32_t mine = nsoft[j];
-    uint32_t host = off8[j], total = mine;
-    if (mate < n) {
-        const uint32_t theirs = nsoft[mate];
-        if (theirs > mine || (theirs == mine && half == 1u)) host = off8[mate];
-        total = max(mine, theirs);
-    }
+    const uint32_t j = blockIdx.x, mine = nsoft[j], at = (off8[j] + 7u) / 8u * 3u;
     const uint8_t* in = soft8 + off8[j];
-    uint16_t* out = reinterpret_cast<uint16_t*>(pair + host) + half;
-    for (uint32_t k = threadIdx.x; k < total; k += blockDim.x) out[2 * (size_t)k] = k < mine ? (uint16_t)((in[k] & 7u) << 9) : (uint16_t)0;
+    for (uint32_t g = threadIdx.x; g < (mine + 7u) / 8u; g += blockDim.x) {
+        uint32_t v[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) v[k] = 8u * g + k < mine ? in[8u * g + k] & 7u : 0u;
+        soft3_store8(packed + at, g, soft3_pack8(v));
+    }
     if (threadIdx.x == 0) {
-        VitJob J; J.soft_off = host; J.nsoft = mine; J.length = flen[j]; J.dec_off = 0; J.out_off = out_off[j];
-        J.valid = 1; J.code_rate = (uint32_t)code_rate; J.pad = 0;
+        VitJob J; J.soft_off = at; J.nsoft = mine; J.length = flen[j]; J.dec_off = 0; J.out_off = out_off[j];
+        J.valid = 1; J.code_rate = (uint32_t)code_rate; J.soft_bits = 3;
         jobs[j] = J;
     }
-    (void)span;
 }
 
 }  // namespace sora

@@ -609,7 +609,7 @@ struct Frame11nArgs {
     const uint32_t* iq0; const uint32_t* iq1; const CapDesc* caps;
     const N11Frame* frames; const uint32_t* njobs; uint32_t nrows;
     Tables T; const uint32_t* sincos; const short* atan;
-    uint32_t* soft;                // [slots * 288] pair-stream operands (k_rx.hip viterbi_forward): soft A << 9 | soft B << 25
+    uint8_t* soft;                 // [slots * 288] the frames' soft streams, one byte per value (VitJob::soft_bits = 8)
     VitJob*   jobs;                // [3][nrows]: k_frame11n fills in the pair stream's offset (the mate is known only after the scan)
     const uint8_t* vout;           // [slots * 32]
     Rx11bRow* rows; uint8_t* mpdu;
@@ -941,8 +941,8 @@ __device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* fo
                     F.nproc = nproc; F.nsoft = nsoft; F.slot0 = cd.slot_base + (origin + a + 240) / 80;
                     for (int k = 0; k < 6; k++) F.pad[k] = 0;
                     A.frames[(size_t)list * A.nrows + idx] = F;
-                    VitJob J; J.soft_off = 0u /* the pair stream: set by k_frame11n */; J.nsoft = nsoft; J.length = ht_len; J.dec_off = 0; J.out_off = F.slot0 * (uint32_t)kOutPerSlot;
-                    J.valid = 1; J.code_rate = code_rate; J.pad = 0;
+                    VitJob J; J.soft_off = F.slot0 * (uint32_t)kSoftPerSlot; J.soft_bits = 8; J.nsoft = nsoft; J.length = ht_len; J.dec_off = 0; J.out_off = F.slot0 * (uint32_t)kOutPerSlot;
+                    J.valid = 1; J.code_rate = code_rate;
                     A.jobs[(size_t)list * A.nrows + idx] = J;
                 }
             }
@@ -982,16 +982,6 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
     const JobRef jr = locate_job(blockIdx.x * 4 + wv, A.njobs);
     if (!jr.ok) return;
     const N11Frame F = A.frames[(size_t)jr.list * A.nrows + jr.idx];
-    // the pair stream (k_rx.hip viterbi_forward): jobs 2p / 2p+1 of a list share one operand stream, this frame's soft values in 16-bit half
-    // `half`, hosted in the slot region of the pair's frame with more soft values; the shorter one zero-fills its half up to the pair's end
-    const uint32_t half = jr.idx & 1u;
-    uint32_t host_slot0 = F.slot0, pair_nsoft = F.nsoft;
-    if ((jr.idx ^ 1u) < A.njobs[jr.list]) {
-        const N11Frame& M = A.frames[(size_t)jr.list * A.nrows + (jr.idx ^ 1u)];
-        if (M.nsoft > F.nsoft || (M.nsoft == F.nsoft && half == 1u)) host_slot0 = M.slot0;
-        pair_nsoft = max(F.nsoft, M.nsoft);
-    }
-    if (lane == 0) A.jobs[(size_t)jr.list * A.nrows + jr.idx].soft_off = host_slot0 * (uint32_t)kSoftPerSlot;
     FrameLds& W = s_w[wv];
     const CapDesc cd = A.caps[F.cap];
     const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
@@ -1054,7 +1044,7 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
     // ---- the data symbols, in order
     const uint32_t a_data = a_ltf + 160;
     const uint32_t S = 104u * (uint32_t)nb;
-    uint16_t* dst = reinterpret_cast<uint16_t*>(A.soft + (size_t)host_slot0 * kSoftPerSlot) + half;   // operand i of the pair: dst[2 i]
+    uint8_t* dst = A.soft + (size_t)F.slot0 * kSoftPerSlot;                  // the frame's soft stream, one byte per value (VitJob::soft_bits = 8), in its own symbol slots
     uint32_t nx0 = fetch(0, a_data + 16 + lane), nx1 = fetch(1, a_data + 16 + lane);     // the next symbol's samples are requested one symbol ahead
     for (uint32_t d = 0; d < nproc; d++) {
         const uint32_t pos = a_data + 80 * d;
@@ -1088,11 +1078,11 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
             }
         }
         wsync();
-        // joined position g (stream g & 1) <- soft[g & 1][dtab[g]], as this frame's 16-bit field v << 9 of the pair's operand
-        for (uint32_t g = lane; g < S; g += 64) dst[2 * ((size_t)d * S + g)] = (uint16_t)((uint32_t)W.soft[g & 1][W.dtab[g]] << 9);
+        // joined position g (stream g & 1) <- soft[g & 1][dtab[g]]
+        for (uint32_t g = lane; g < S; g += 64) dst[(size_t)d * S + g] = W.soft[g & 1][W.dtab[g]];
         wsync();
     }
-    for (uint32_t g = nproc * S + lane; g < pair_nsoft; g += 64) dst[2 * (size_t)g] = 0;      // the zero soft values of a flush at the end of the capture; the shorter frame of a pair
+    for (uint32_t g = nproc * S + lane; g < F.nsoft; g += 64) dst[g] = 0;                     // the zero soft values of a flush at the end of the capture
 }
 
 // T11aDesc + TBB11aFrameSink (scramble.hpp:319-349, PHY_11a.hpp:660-692) on the decoded bytes of a queued frame -> MPDU slot, error code, FCS
@@ -1145,7 +1135,7 @@ using namespace sora;
 struct Pipe11n {                         // one call in flight: a stream and every device array a call writes
     hipStream_t stream = nullptr;
     CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr;
-    N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
+    N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
     std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
     uint32_t ncaps = 0; bool have_results = false; int ticket = 0;
     DenseStage dense;                       // sora_rx11n_deliver_async
@@ -1198,12 +1188,12 @@ static hipError_t pipe11n_create(sora_rx11n_t* rx, Pipe11n** out)
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_frames, 3 * sizeof(N11Frame) * rows);
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_jobs, 3 * sizeof(VitJob) * rows);
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_njobs, 16);
-        if (e == hipSuccess) e = hipMalloc((void**)&p->d_soft, (size_t)rx->cap_slots * kSoftPerSlot * 4 + 4096 + 256);
+        if (e == hipSuccess) e = hipMalloc((void**)&p->d_soft, (size_t)rx->cap_slots * kSoftPerSlot + kSoftSlack);
         if (e == hipSuccess) e = hipMalloc((void**)&p->d_vout, (size_t)rx->cap_slots * kOutPerSlot + 256);
         // every array starts out defined: the decoder reads its soft stream in 12-step chunks (the tail of a frame's last chunk is read, never used)
         if (e == hipSuccess) {
             (void)hipMemsetAsync(p->d_frames, 0, 3 * sizeof(N11Frame) * rows, p->stream); (void)hipMemsetAsync(p->d_jobs, 0, 3 * sizeof(VitJob) * rows, p->stream);
-            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot * 4 + 4096 + 256, p->stream); (void)hipMemsetAsync(p->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
+            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot + kSoftSlack, p->stream); (void)hipMemsetAsync(p->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
         }
     }
     if (e == hipSuccess) { (void)hipMemsetAsync(p->d_rows, 0, sizeof(Rx11bRow) * rows, p->stream); (void)hipMemsetAsync(p->d_nframes, 0, 4 * (size_t)cfg->max_captures, p->stream); }
@@ -1339,9 +1329,9 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     F.soft = P->d_soft; F.jobs = P->d_jobs; F.vout = P->d_vout; F.rows = P->d_rows; F.mpdu = P->d_mpdu;
     hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
     if (rx->lanes16)
-        hipLaunchKernelGGL(k_viterbi16_11n, dim3((nrows + 7) / 8 + 2), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint32_t*)P->d_soft, P->d_vout);
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((nrows + 7) / 8 + 2), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint8_t*)P->d_soft, P->d_vout);
     else
-        hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint32_t*)P->d_soft, P->d_vout);
+        hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint8_t*)P->d_soft, P->d_vout);
     hipLaunchKernelGGL(k_finish11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
     HIPCHK11N(hipGetLastError());
     return SORA_OK;

@@ -23,9 +23,12 @@
 // lane's masks exactly as in k_viterbi.  Per step and wave: 2 operand instructions + 4 x (add, add_dpp, pk_min) for EIGHT
 // frames (k_viterbi: 5 to 8 for two).
 //
-// Operands.  The four rows decode different pairs, so the operands are per-lane values: each lane loads its pair's stream
-// (the pair stream of k_rx.hip, 16 lanes reading the same address) with global_load_dwordx4, two chunks ahead -- vector
-// loads return in order, so the look-ahead is just a deeper vmcnt.
+// Operands.  The four rows decode different pairs, so the operands are per-lane values.  Lane (row, 2 j + f) fetches soft
+// values j, j + 8 (, j + 16) of the chunk from frame f's packed stream (rx_types.h: three bits per value; 16-bit loads, two
+// chunks ahead -- vector loads return in order, so the look-ahead is just a deeper vmcnt), shifts them into 16-bit metric
+// fields and writes them to the row's operand table in LDS; four to six broadcast ds_read_b128 then hand every lane the
+// chunk's operands (field A | field B << 16).  Round 3 first read ready-made operand dwords from HBM (264 MB per call
+// written and read; now 50).
 //
 // Trace-back.  The survivor ring is indexed by rev6(state) as in k_viterbi (the next index is the low six bits of the byte
 // read), one 128-byte table per row and block.  The walk is lane-parallel instead of readlane-serial: every lane walks the
@@ -51,8 +54,9 @@ template <int WIN, int LOOK> struct Geom16 {
 template <int WIN, int LOOK> struct Lds16 {
     uint16_t ring[Geom16<WIN, LOOK>::P][4][64];                                 // [block % P][row][rev6(state)] {frame A's byte, frame B's byte}: 18944 / 15872 B
     uint32_t udump[4][64];                                                      // the metrics registers at a trace-back (the start state's unfinished block)
+    uint16_t ops[4][24][2];                                                     // [row][operand of the chunk][frame]: the soft values as metric fields
     uint8_t  path[8][Geom16<WIN, LOOK>::kPathBytes];                             // [row * 2 + frame][walk position]: the bytes along the traced path
-};                                                                              // 20288 / 17216 bytes: eight one-wave workgroups per CU
+};                                                                              // 20672 / 17600 bytes: seven one-wave workgroups per CU
 
 constexpr unsigned kW[4] = { 0u, 21u, 42u, 63u };
 
@@ -205,8 +209,9 @@ __device__ __noinline__ void trace16(unsigned lds_off, unsigned U0, unsigned U1,
     lds_fence();
 }
 
-template <int CR, int WIN, int LOOK>
-__device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint32_t* __restrict__ sp, uint32_t nstepsA, uint32_t nstepsB, uint32_t my_tr_end, bool my_valid, uint8_t* my_out)
+template <int CR, int WIN, int LOOK, int BITS>
+__device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __restrict__ soft, uint32_t my_soft_off, uint32_t my_nsoft,
+                                          uint32_t nstepsA, uint32_t nstepsB, uint32_t my_tr_end, bool my_valid, uint8_t* my_out)
 {
     using G = Geom16<WIN, LOOK>;
     constexpr int P = G::P;
@@ -217,7 +222,7 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint32_t* _
     const unsigned v0 = v_of_lane(l16);
     const uint32_t row_steps = max(nstepsA, nstepsB);
     const uint32_t nsteps = wave_max_u32(row_steps);
-    const uint32_t my_last_chunk = (max(row_steps, 1u) - 1) / 12;               // of this lane's pair stream
+    const uint32_t my_last = max(my_nsoft, 1u) - 1u;                            // the last soft value of this lane's frame (fetches past it repeat it: well-formed operands nobody uses)
 
     auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };
     Vit16 V;
@@ -275,16 +280,32 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint32_t* _
     };
 
     struct Chunk { uint32_t v[CW]; };
-    auto load_chunk = [&](uint32_t c) -> Chunk {                                // chunk c of this lane's pair stream; past its end: its last chunk again
+    constexpr int NV = (CW + 7) / 8;                                            // soft values a lane fetches per chunk: operands j, j + 8 (, j + 16) of its frame
+    struct Raw { SoftRaw r[NV]; };
+    const uint32_t my_j = l16 >> 1;
+    SoftCursor<BITS, CW> cur[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) cur[v].init(my_soft_off, my_j + 8u * v, my_last);
+    auto fetch = [&](uint32_t c) -> Raw {                                       // chunk c: the loads only
+        Raw R;
+#pragma unroll
+        for (int v = 0; v < NV; v++) R.r[v] = cur[v].fetch(soft, c);
+        return R;
+    };
+    uint16_t* my_ops = &S.ops[row][my_j][half];
+    const uint4* row_ops = reinterpret_cast<const uint4*>(&S.ops[row][0][0]);
+    auto unpack = [&](const Raw& R) -> Chunk {                                  // ... their values -> the row's operand table -> every lane's registers
+#pragma unroll
+        for (int v = 0; v < NV; v++) my_ops[16 * v] = (uint16_t)cur[v].field(R.r[v]);      // (operand j + 8 v; slots up to 23 exist, those past CW are never read)
+        lds_fence();
         Chunk K;
-        const uint32_t* p = sp + min(c, my_last_chunk) * (uint32_t)CW;
-        if (CW % 4 == 0) {
 #pragma unroll
-            for (int i = 0; i < CW / 4; i++) { const uint4 x = reinterpret_cast<const uint4*>(p)[i]; K.v[4 * i] = x.x; K.v[4 * i + 1] = x.y; K.v[4 * i + 2] = x.z; K.v[4 * i + 3] = x.w; }
-        } else {
-#pragma unroll
-            for (int i = 0; i < CW / 2; i++) { const uint2 x = reinterpret_cast<const uint2*>(p)[i]; K.v[2 * i] = x.x; K.v[2 * i + 1] = x.y; }
+        for (int i = 0; i < (CW + 3) / 4; i++) {
+            const uint4 x = row_ops[i];
+            K.v[4 * i] = x.x; K.v[4 * i + 1] = x.y;
+            if (4 * i + 2 < CW) { K.v[4 * i + 2] = x.z; K.v[4 * i + 3] = x.w; }
         }
+        lds_fence();
         return K;
     };
     unsigned pos512[3];
@@ -318,28 +339,28 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint32_t* _
     };
     auto chunk = [&](const Chunk& K, int h) { if (tr + 12 <= nsteps && next_thr > tr + 12) fast_chunk(K, h); else slow_chunk(K, h); };
 
-    // Vector loads return in order: chunk c + 2 is requested before chunk c is stepped through.  Four chunk buffers in fixed roles, two rows
-    // per turn of the fast loop, so that no buffer is ever copied (a rotating pair of buffers cost 64 register moves per row).
+    // Vector loads return in order: chunk c + 2 is requested before chunk c is stepped through.  Four fetch buffers in fixed roles, two rows
+    // per turn of the fast loop, so that no buffer is ever copied.
     uint32_t c = 0;
-    Chunk b0 = load_chunk(0), b1 = load_chunk(1), b2, b3;
+    Raw b0 = fetch(0), b1 = fetch(1), b2, b3;
     while (tr < nsteps && !all_done) {
         const uint32_t lim = min(nsteps, next_thr - 1);
         uint32_t rows = lim > tr ? (lim - tr) / 24 : 0;                         // rows that certainly need no look at the schedule
         for (; rows >= 2; rows -= 2) {
-            b2 = load_chunk(c + 2); fast_chunk(b0, 0);
-            b3 = load_chunk(c + 3); fast_chunk(b1, 1);
+            b2 = fetch(c + 2); fast_chunk(unpack(b0), 0);
+            b3 = fetch(c + 3); fast_chunk(unpack(b1), 1);
             end_row();
-            b0 = load_chunk(c + 4); fast_chunk(b2, 0);
-            b1 = load_chunk(c + 5); fast_chunk(b3, 1);
+            b0 = fetch(c + 4); fast_chunk(unpack(b2), 0);
+            b1 = fetch(c + 5); fast_chunk(unpack(b3), 1);
             end_row();
             c += 4;
         }
         if (!(tr < nsteps)) break;
-        b2 = load_chunk(c + 2);
-        if (rows) fast_chunk(b0, 0); else chunk(b0, 0);
+        b2 = fetch(c + 2);
+        if (rows) fast_chunk(unpack(b0), 0); else chunk(unpack(b0), 0);
         if (!(tr < nsteps && !all_done)) break;
-        b3 = load_chunk(c + 3);
-        if (rows) fast_chunk(b1, 1); else chunk(b1, 1);
+        b3 = fetch(c + 3);
+        if (rows) fast_chunk(unpack(b1), 1); else chunk(unpack(b1), 1);
         end_row();
         b0 = b2; b1 = b3;
         c += 2;
@@ -347,9 +368,9 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint32_t* _
 }
 
 // One wave per workgroup: wave w of code-rate list r decodes pairs 4w .. 4w+3 of the list (jobs 8w .. 8w+7), one pair per 16-lane row.
-template <int WIN, int LOOK>
+template <int WIN, int LOOK, int BITS>
 __device__ __forceinline__ void viterbi16_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride,
-                                               const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
+                                               const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
     __shared__ Lds16<WIN, LOOK> S;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -368,21 +389,20 @@ __device__ __forceinline__ void viterbi16_body(const VitJob* __restrict__ jobs, 
     const uint32_t code_rate = uni(jobs[8u * w].code_rate);
     const uint32_t gsd = code_rate == 0 ? 2u : code_rate == 2 ? 4u : 3u, gss = code_rate == 0 ? 1u : code_rate == 2 ? 3u : 2u;
     const uint32_t nstepsA = hasA ? GA.nsoft / gsd * gss : 0u, nstepsB = hasB ? GBj.nsoft / gsd * gss : 0u;
-    const uint32_t* sp = soft + GA.soft_off;
     const VitJob& Mine = half ? GBj : GA;
     const bool my_valid = half ? hasB : hasA;
     const uint32_t my_tr_end = Mine.length * 8u + 16u + 6u;
     uint8_t* my_out = out + Mine.out_off;
-    if (code_rate == 0)      forward16<0, WIN, LOOK>(S, sp, nstepsA, nstepsB, my_tr_end, my_valid, my_out);
-    else if (code_rate == 1) forward16<1, WIN, LOOK>(S, sp, nstepsA, nstepsB, my_tr_end, my_valid, my_out);
-    else                     forward16<2, WIN, LOOK>(S, sp, nstepsA, nstepsB, my_tr_end, my_valid, my_out);
+    if (code_rate == 0)      forward16<0, WIN, LOOK, BITS>(S, soft, Mine.soft_off, Mine.nsoft, nstepsA, nstepsB, my_tr_end, my_valid, my_out);
+    else if (code_rate == 1) forward16<1, WIN, LOOK, BITS>(S, soft, Mine.soft_off, Mine.nsoft, nstepsA, nstepsB, my_tr_end, my_valid, my_out);
+    else                     forward16<2, WIN, LOOK, BITS>(S, soft, Mine.soft_off, Mine.nsoft, nstepsA, nstepsB, my_tr_end, my_valid, my_out);
 }
 
 }  // namespace
 
-__global__ void __launch_bounds__(64) k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
-{ viterbi16_body<256, 24>(jobs, njobs3, njobs_single, stride, soft, out); }
-__global__ void __launch_bounds__(64) k_viterbi16_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* __restrict__ soft, uint8_t* __restrict__ out)
-{ viterbi16_body<192, 36>(jobs, njobs3, njobs_single, stride, soft, out); }
+__global__ void __launch_bounds__(64) k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+{ viterbi16_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out); }
+__global__ void __launch_bounds__(64) k_viterbi16_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+{ viterbi16_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }
 
 }  // namespace sora

@@ -34,7 +34,7 @@ struct RxArgs {
     Tables          T;
     FrameRow*       frames;
     const FrameCtx* fctx;
-    uint32_t*       soft;           // [slots*288] pair-stream operands (soft A << 9 | soft B << 25, k_rx.hip); unused by the fused decode kernel
+    uint8_t*        soft;           // [slots*108] the frames' packed soft streams (three bits per value, rx_types.h); unused by the fused decode kernel
     uint8_t*        vout;           // [slots*32]
     uint8_t*        mpdu;           // [slots*32]
     VitJob*         jobs;           // [3][nrows] (indexed by job); unused by the fused decode kernel
@@ -45,10 +45,10 @@ struct RxArgs {
 __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
 __global__ void k_decode(RxArgs A);
-__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* soft, uint8_t* out);
-__global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* soft, uint8_t* out);
-__global__ void k_viterbi16(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* soft, uint8_t* out);       // k_vit16.hip
-__global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint32_t* soft, uint8_t* out);
+__global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
+__global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
+__global__ void k_viterbi16(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);       // k_vit16.hip
+__global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);
@@ -74,8 +74,8 @@ __global__ void k_tx_preamble(int8_t* out8, Tables T);
 __global__ void k_tx11a(TxArgs A);
 __global__ void k_ingest(const uint8_t* raw, uint32_t* out, uint64_t m0, uint64_t n_out, unsigned flags);
 __global__ void k_ingest_tile(const uint8_t* raw, uint32_t* out, unsigned flags, uint32_t tiles);
-__global__ void k_soft_widen(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
-                             int code_rate, uint32_t n, uint32_t span, uint32_t* pair, VitJob* jobs);
+__global__ void k_soft_pack3(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
+                             int code_rate, uint8_t* packed, VitJob* jobs);
 
 // ---- 802.11b receive graph (k_rx11b.hip)
 struct Rx11bRow { uint32_t end_sample, error_code, rate_kbps, length, crc32; };

@@ -5,8 +5,11 @@
 //   caps[]        per capture {offset, nsamples, id, slot_base}
 //   frames[]      frame table, max_frames_per_capture rows per capture, filled by k_scan in time order
 //   fctx[]        per frame: FreqCoeffs[64] + ChannelCoeffs[64] (CF_FreqCompensate / CF_Channel_11a)
-//   soft[]        per PAIR of frames (the two a trellis wave decodes): de-interleaved soft values as ready operands, dword i =
-//                 soft A << 9 | soft B << 25 (base = slot0 of the pair's longer frame * 288 dwords)
+//   soft[]        per frame: its de-interleaved soft values (0..7) as a packed bit stream, THREE BITS per value, value i in bits
+//                 3 i .. 3 i + 2 (little-endian), base = slot0 * 108 bytes (a 64-QAM symbol's 288 values are exactly 108 bytes, so a
+//                 frame's stream never leaves its own symbol slots).  VitJob::soft_bits = 3: what k_viterbi / k_viterbi16 read.  (The 802.11n and
+//                 40 MHz producers write one BYTE per value, soft_bits = 8, read by k_viterbi11n / k_viterbi16_11n: the format is a
+//                 property of the kernel.)  Readers fetch 16 bits at byte (bits * i) >> 3 and take three of them.
 //   vout[]        per frame: Viterbi output bytes (length+2), base = slot0*32
 //   mpdu[]        per frame: descrambled MPDU, base = slot0*32 (same geometry as vout)
 //   rows[]        compacted sora_frame_result rows + counter
@@ -46,14 +49,14 @@ struct FrameCtx {           // 512 bytes
 };
 
 struct VitJob {             // one Viterbi decode: a frame of the RX path or one job of sora_hip_viterbi11a
-    uint32_t soft_off;      // dwords from the soft base: the pair stream this job shares with its neighbour (jobs 2p, 2p+1 of a list)
+    uint32_t soft_off;      // BYTES from the soft base: this frame's soft stream
     uint32_t nsoft;
     uint32_t length;        // frame_length (decoded bytes = length+2)
     uint32_t dec_off;       // unused (decisions live in LDS)
     uint32_t out_off;       // bytes from the output base
     uint32_t valid;
     uint32_t code_rate;
-    uint32_t pad;
+    uint32_t soft_bits;     // 3: packed three bits per soft value; 8: one byte per soft value (its low three bits) -- informative: the trellis kernel's template parameter decides
 };
 
 struct TrackRec {           // per data-symbol slot
@@ -77,6 +80,8 @@ __host__ __device__ inline JobRef locate_job(uint32_t g, const uint32_t* njobs)
 }
 
 constexpr int kSoftPerSlot = 288;      // N_CBPS max
+constexpr int kSoftBytesPerSlot = 108; // ... at three bits each
+constexpr int kSoftSlack = 64;         // bytes behind the last stream that a reader's 16-bit fetch / a producer's padded last group may touch
 constexpr int kOutPerSlot  = 32;       // decoded bytes per symbol max 27 -> 32
 
 constexpr uint32_t E_FRAME_OK = 0x00000001u, E_PLCP_HEADER_FAIL = 0x80000005u, E_CRC32_FAIL = 0x80000006u,

@@ -268,7 +268,7 @@ struct RxPipe {
     uint32_t cap_slots = 0, cap_rows = 0;
     // device arrays
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
-    uint32_t* d_soft = nullptr; VitJob* d_jobs = nullptr;       // split decode path only (allocated on its first use)
+    uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip)
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
@@ -432,8 +432,8 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     rx->h_caps.swap(hc);
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
-    if (!rx->fused && !rx->d_soft) {                                             // the 16-bit soft stream and the job table exist only for the split path
-        HIPCHK(hipMalloc((void**)&rx->d_soft, 4 * (size_t)kSoftPerSlot * rx->cap_slots + 4096 + 256));   // pair-stream operands: 4 bytes per soft value of the pair's longer frame; 4 KB of slack for the trellis kernel's look-ahead
+    if (!rx->fused && !rx->d_soft) {                                             // the packed soft streams and the job table exist only for the split path
+        HIPCHK(hipMalloc((void**)&rx->d_soft, (size_t)kSoftBytesPerSlot * rx->cap_slots + kSoftSlack));   // three bits per soft value (rx_types.h)
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
     hipStream_t st = rx->stream;
@@ -477,9 +477,9 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
             if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
-                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint32_t*)rx->d_soft, rx->d_vout);
+                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
             else
-                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint32_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
+                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
         }
         hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
@@ -1027,12 +1027,13 @@ int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_co
     return SORA_OK;
 }
 
-// The stage works out of a caller-owned workspace (no allocation, no host wait): the pair stream of jobs 2p / 2p+1 is hosted at
-// 4 x the byte offset of the pair's longer job (the caller's soft ranges are disjoint, so the hosted ranges are), followed by the job
-// table.  sora_hip_viterbi11a keeps the original signature on top of a grow-only workspace cached per device.
+// The stage works out of a caller-owned workspace (no allocation, no host wait): every job's soft values packed to three bits each
+// (k_soft_pack3: at byte 3 ceil(off / 8), disjoint because the caller's ranges are), followed by the job table.  sora_hip_viterbi11a keeps
+// the original signature on top of a grow-only workspace cached per device.
+static size_t vit_ws_packed_bytes(size_t soft_span_bytes) { return ((soft_span_bytes / 8 + 2) * 3 + kSoftSlack + 255) & ~(size_t)255; }
 size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n)
 {
-    return ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255) + sizeof(VitJob) * n + 4096;   // (+ slack for the trellis kernel's look-ahead loads)
+    return vit_ws_packed_bytes(soft_span_bytes) + sizeof(VitJob) * n;
 }
 
 int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const uint32_t* d_soft_off, const uint32_t* d_nsoft, const uint16_t* d_frame_len,
@@ -1046,13 +1047,13 @@ int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const 
     if (workspace_bytes < sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a_ws: workspace smaller than sora_hip_viterbi11a_workspace_bytes()");
     if (soft_span_bytes >= (1ull << 32) || n >= (1ull << 31)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
     hipStream_t st = (hipStream_t)stream;
-    uint32_t* pair = (uint32_t*)d_workspace;
-    VitJob* jobs = (VitJob*)((uint8_t*)d_workspace + ((4 * soft_span_bytes + 256 + 255) & ~(size_t)255));
-    hipLaunchKernelGGL(k_soft_widen, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, d_frame_len, d_out_off, code_rate, (uint32_t)n, (uint32_t)soft_span_bytes, pair, jobs);
+    uint8_t* packed = (uint8_t*)d_workspace;
+    VitJob* jobs = (VitJob*)((uint8_t*)d_workspace + vit_ws_packed_bytes(soft_span_bytes));
+    hipLaunchKernelGGL(k_soft_pack3, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, d_frame_len, d_out_off, code_rate, packed, jobs);
     if (lanes_per_pair == 16)
-        hipLaunchKernelGGL(k_viterbi16, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint32_t*)pair, d_out);
+        hipLaunchKernelGGL(k_viterbi16, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)packed, d_out);
     else
-        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint32_t*)pair, d_out);
+        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)packed, d_out);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
