@@ -28,9 +28,10 @@ import sys
 import time
 
 # The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): with the
-# default only three of the handle's pipelines run side by side whatever sora_rx_set_depth says (profiles/r03_e_timeline_*.txt).
+# default only three of the handle's pipelines run side by side whatever sora_rx_set_depth says (profiles/r03_e_timeline_*.txt);
+# eight calls in flight want at least twelve (profiles/r03_y_depth_and_queues.txt).
 # An application setting, made before the runtime starts; the library itself reads no environment variable.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 import numpy as np
 

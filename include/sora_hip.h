@@ -139,9 +139,10 @@ const char* sora_rx_kernel_name(size_t index);
 
 /* Consecutive process calls rotate over `depth` internal pipelines (own stream, own intermediate arrays), so the
  * latency-bound front end of one call overlaps the trellis kernel of the call before it -- what the reference gets from
- * running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120).  Default 6, 1 = strictly
- * one call at a time, at most 8.  (The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, one of them
- * the null stream's: a host that wants more than three calls to actually run side by side sets that variable, as bench.py does.)  Returns the previous value; depth <= 0 only queries.  sora_rx_results / _results_dev /
+ * running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120).  Default 8, 1 = strictly
+ * one call at a time, at most 16.  (The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues, 4 by default, one of them
+ * the null stream's: a host that wants more than three calls to actually run side by side sets that variable, as bench.py does -- 16; measured:
+ * the step time of the benchmark batch stops improving at eight calls in flight on twelve or more queues.)  Returns the previous value; depth <= 0 only queries.  sora_rx_results / _results_dev /
  * _stream refer to the MOST RECENT process call, the *_of forms to the call whose ticket is given; sora_rx_flush waits for
  * every call in flight; an input buffer must stay untouched until the call that reads it has finished (as with any
  * asynchronous call). */

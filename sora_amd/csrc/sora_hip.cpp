@@ -625,9 +625,9 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
 // stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
 constexpr int kAutoLanes16Depth = 4;                            // depth from which the automatic choice is k_viterbi16 (profiles/r03_d_ab_trellis.txt: it wins from four calls in flight)
 struct sora_rx {
-    static constexpr int kMaxDepth = 8;
+    static constexpr int kMaxDepth = 16;
     sora_rx_cfg cfg{};
-    int depth = 6;
+    int depth = 8;
     int trellis = 0;             // sora_rx_set_trellis: 0 = chosen from the depth, 64 / 16 = lanes per frame pair
     bool use_graph = false;
     int cur = 0;                 // pipeline of the most recent process call

@@ -242,7 +242,7 @@ def test_calls_in_flight(sora, torch_cuda, oracle, depth):
         iq, d = batch(caps)
         sets.append((torch_cuda.from_numpy(iq).cuda(), d, oracle_results(oracle, caps, 20)))
     rx = sora.Rx(max_captures=8, max_total_samples=max(len(t) for t, _, _ in sets), sample_rate_mhz=20, max_frames_per_capture=2)
-    assert rx.set_depth(depth) == 6 and rx.set_depth(0) == depth
+    assert rx.set_depth(depth) == 8 and rx.set_depth(0) == depth
     assert rx.trellis() == (16 if depth >= 4 else 64)                 # the automatic choice of the trellis kernel follows the depth
     for k in range(9):
         t, d, want = sets[k % 3]
