@@ -315,7 +315,7 @@ void* sora_rx11n_stream(sora_rx11n_t* rx);
 int   sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps);
 int   sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const sora_complex16* h_iq1, size_t nsamples_per_chain, const sora_capture_desc* caps, size_t ncaps);
 int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
-/* Calls in flight, as for sora_rx_t: consecutive process calls rotate over `depth` pipelines (own stream and result arrays; default 1, at most 4), so
+/* Calls in flight, as for sora_rx_t: consecutive process calls rotate over `depth` pipelines (own stream and result arrays; default 1, at most 8), so
  * the latency-bound scan / symbol kernels of one call overlap the issue-bound trellis kernel of the call before it.  Every call has a ticket;
  * sora_rx11n_results / _stream refer to the most recent call, sora_rx11n_wait / _results_of to the call whose ticket is given (valid until `depth`
  * further calls have been made); an input buffer must stay untouched until the call that reads it has finished.  sora_rx11n_set_depth returns the

@@ -138,6 +138,10 @@ template <int WIN, int LOOK> struct RingGeom {
     static constexpr int kEntries = 2 * P * 64;                                 // 16-bit entries per wave: 9984 B / 8448 B
 };
 
+// The two frames' decision bytes of a finished block as one 16-bit word: frame A's marks are byte 0 of the register, frame B's (bits 17..24,
+// above the guard bit) byte 2 of the register shifted right by one: a shift and a byte permute.
+__device__ __forceinline__ unsigned bank_word(unsigned U) { return __builtin_amdgcn_perm(U >> 1, U, 0x0C0C0600u); }
+
 struct VitLane {
     unsigned U;              // (field B << 16) | field A; field = u << 9 | marks of the current 8-step block
     unsigned MX[24];         // soft mask (+ mark, + complement for own-is-candidate-1 lanes) of the mark-carrying operand, per t mod 24
@@ -178,7 +182,7 @@ __device__ __forceinline__ void acs_step(VitLane& V, int t24, unsigned a, unsign
     V.U = pk_min16(X + bm, Y + bo);
     if (k == 7) {                                                               // end of an 8-step block: bank the path histories, clear the marks
         uint16_t* e = V.ring + V.rowpos + (t24 / 8) * 64 + V.sidx[t24 / 8];
-        const uint16_t w = (uint16_t)((V.U & 0xFFu) | ((V.U >> 9) & 0xFF00u));  // frame A's block, frame B's block
+        const uint16_t w = (uint16_t)bank_word(V.U);                            // frame A's block, frame B's block
         e[0] = w; e[P * 64] = w;                                                // both copies (same address register, two immediates)
         V.U &= 0xFE00FE00u;
     }

@@ -1152,7 +1152,8 @@ struct sora_rx11n {
 #endif
     int lanes16 = 0;             // trellis kernel: 0 = k_viterbi11n (64 lanes per frame pair), 1 = k_viterbi16_11n (sora_rx11n_set_trellis)
     uint64_t cap_slots = 0;
-    Pipe11n* pipes[4] = { nullptr, nullptr, nullptr, nullptr };
+    static constexpr int kMaxDepth = 8;
+    Pipe11n* pipes[kMaxDepth] = {};
     int depth = 1, cur = 0, next_ticket = 0; bool started = false;
 };
 
@@ -1233,7 +1234,7 @@ int sora_rx11n_set_depth(sora_rx11n_t* rx, int depth)
     if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_depth: null handle", 0);
     const int prev = rx->depth;
     if (depth <= 0) return prev;
-    if (depth > 4) depth = 4;
+    if (depth > sora_rx11n::kMaxDepth) depth = sora_rx11n::kMaxDepth;
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
     for (int i = 0; i < depth; i++)

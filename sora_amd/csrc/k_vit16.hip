@@ -121,7 +121,7 @@ __device__ __forceinline__ void acs16(Vit16& V, int t24, unsigned a, unsigned b,
         const int jb = t24 / 8;
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            const unsigned w = (V.U[i] & 0xFFu) | ((V.U[i] >> 9) & 0xFF00u);
+            const unsigned w = bank_word(V.U[i]);
             const unsigned addr = V.sadr[jb][i] + pos512[jb];
             asm volatile("ds_write_b16 %0, %1" : : "v"(addr), "v"(w) : "memory");
             V.U[i] &= 0xFE00FE00u;
