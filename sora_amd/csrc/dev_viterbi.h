@@ -1,5 +1,6 @@
-// dev_viterbi.h -- the 64-state trellis machinery shared by k_viterbi (k_rx.hip: soft values from HBM through the scalar cache)
-// and k_decode (k_decode.hip: soft values out of an LDS ring filled by the symbol waves of the same workgroup).
+// dev_viterbi.h -- the 64-state trellis machinery shared by k_viterbi (k_rx.hip: soft values from the frames' packed streams in HBM, handed
+// round through an operand table in LDS), k_viterbi16 (k_vit16.hip: the same in the 16-lanes-per-pair layout) and k_decode (k_decode.hip:
+// operands out of an LDS ring filled by the symbol waves of the same workgroup).
 #pragma once
 #include <hip/hip_runtime.h>
 #include "rx_types.h"
