@@ -37,12 +37,24 @@ __device__ unsigned long long g_scan_probe[16];              // [0..7] ticks per
 #define PROBE_ADDK(i)
 #endif
 
-struct Acc4 { int e0, e1, e2, e3; int reg; };            // CMovingWindow<int,4> + CAccumulator (dspalg.hpp:5-98), oldest first
-__device__ __forceinline__ void acc_clear(Acc4& a) { a.e0 = a.e1 = a.e2 = a.e3 = 0; a.reg = 0; }
-__device__ __forceinline__ void acc_push(Acc4& a, int d)
+// CMovingWindow<int,4> + CAccumulator (dspalg.hpp:5-98).  The sum is a wave-uniform scalar; the window lives in a vector register, element g
+// (oldest first) in lanes 4 g .. 4 g + 3 of every 16-lane row, so that the idle fast path can run eight bursts' sliding sums as one prefix sum.
+struct Acc4 { int reg; uint32_t Z; };
+__device__ __forceinline__ void acc_clear(Acc4& a) { a.reg = 0; a.Z = 0; }
+__device__ __forceinline__ void acc_push(Acc4& a, int d)                    // d wave-uniform
 {
-    a.reg = (int)((unsigned)a.reg + (unsigned)d - (unsigned)a.e0);
-    a.e0 = a.e1; a.e1 = a.e2; a.e2 = a.e3; a.e3 = d;
+    const int e0 = __builtin_amdgcn_readfirstlane((int)a.Z);
+    a.reg = (int)((unsigned)a.reg + (unsigned)d - (unsigned)e0);
+    const uint32_t sh = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.Z, 0x104, 0xF, 0xF, true);     // row_shl:4: element g <- element g + 1
+    a.Z = (threadIdx.x & 12u) == 12u ? (uint32_t)d : sh;
+}
+// inclusive prefix sum over the eight 4-lane groups of lanes 0..31 (lanes 32..63 mirror them): row_shr:4, row_shr:8, row_bcast:15 into rows 1 / 3
+__device__ __forceinline__ uint32_t group_scan(uint32_t t)
+{
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, false);
+    return t;
 }
 
 __device__ __forceinline__ int wave_sum(int v)
@@ -356,28 +368,39 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         dr += (unsigned)__shfl_xor((int)dr, 1); di += (unsigned)__shfl_xor((int)di, 1);
         vr += (unsigned)__shfl_xor((int)vr, 2); vi += (unsigned)__shfl_xor((int)vi, 2); ve += (unsigned)__shfl_xor((int)ve, 2);
         dr += (unsigned)__shfl_xor((int)dr, 2); di += (unsigned)__shfl_xor((int)di, 2);
-        uint32_t done = 0;
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            if ((uint32_t)b < K && done == (uint32_t)b) {
-                const int sr = __builtin_amdgcn_readlane((int)vr, 4 * b), si = __builtin_amdgcn_readlane((int)vi, 4 * b), se = __builtin_amdgcn_readlane((int)ve, 4 * b);
-                Acc4 tr_ = ac_re, ti_ = ac_im, te_ = energy;
-                acc_push(tr_, sr); acc_push(ti_, si); acc_push(te_, se);
-                const int iAuto = abs(tr_.reg) + abs(ti_.reg), iEnergy = te_.reg;
-                if (!(iEnergy > (int)A.thr && iAuto >= iEnergy - (iEnergy >> 3))) {
-                    ac_re = tr_; ac_im = ti_; energy = te_;
-                    auto_count = 0; sense_count += 4;
-                    sum_dc_re = w16(sum_dc_re + w16(__builtin_amdgcn_readlane((int)dr, 4 * b)));
-                    sum_dc_im = w16(sum_dc_im + w16(__builtin_amdgcn_readlane((int)di, 4 * b)));
-                    if (dc_cnt == 0) {
-                        dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
-                        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
-                    }
-                    dc_cnt--;
-                    if (sense_count >= 84) error_code = E_CS_TIMEOUT;           // cca.hpp:433-437
-                    done++;
-                }
+        // ---- the K bursts' sliding sums at once.  After burst b the accumulator holds reg + sum_{i<=b} (d_i - z_i), z = the value that leaves the
+        // 4-element window: the old elements for b < 4, d_{b-4} after that.  One prefix sum per stream over the burst groups, the reference's test
+        // (cca.hpp:386-437) in every group, and the first burst whose test is true ends the pass.
+        const bool second_row = (l & 16u) != 0u;
+        const uint32_t m16 = hi | ((l - 16u) & 31u);
+        const uint32_t pr = (uint32_t)__shfl((int)vr, (int)m16), pim = (uint32_t)__shfl((int)vi, (int)m16), pe = (uint32_t)__shfl((int)ve, (int)m16);   // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
+        const uint32_t zr = second_row ? pr : ac_re.Z, zi = second_row ? pim : ac_im.Z, ze = second_row ? pe : energy.Z;
+        const uint32_t Rr = (uint32_t)ac_re.reg + group_scan(vr - zr), Ri = (uint32_t)ac_im.reg + group_scan(vi - zi), Re = (uint32_t)energy.reg + group_scan(ve - ze);
+        const int iAuto_v = abs((int)Rr) + abs((int)Ri), iEnergy_v = (int)Re;
+        const bool carrier = iEnergy_v > (int)A.thr && iAuto_v >= iEnergy_v - (iEnergy_v >> 3);
+        const uint32_t hits = (uint32_t)__ballot(carrier) & 0x11111111u & (K >= 8u ? 0xFFFFFFFFu : ((1u << (4u * K)) - 1u));
+        const uint32_t done = hits ? (uint32_t)__builtin_ctz(hits) >> 2 : K;
+        if (done) {
+            const int last = (int)(4u * (done - 1u));
+            ac_re.reg = __builtin_amdgcn_readlane((int)Rr, last); ac_im.reg = __builtin_amdgcn_readlane((int)Ri, last); energy.reg = __builtin_amdgcn_readlane((int)Re, last);
+            {   // the windows <- the last four of {old window, d_0 .. d_{done-1}} (element g in lanes 4 g .. 4 g + 3 of every row)
+                const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;
+                const int from_old = (int)(((uint32_t)lane & 48u) | (src & 15u)), from_new = (int)(hi | ((src - 16u) & 31u));
+                const bool old = src < 16u;
+                const uint32_t kr = (uint32_t)__shfl((int)ac_re.Z, from_old), fr = (uint32_t)__shfl((int)vr, from_new);
+                const uint32_t ki = (uint32_t)__shfl((int)ac_im.Z, from_old), fi = (uint32_t)__shfl((int)vi, from_new);
+                const uint32_t ke = (uint32_t)__shfl((int)energy.Z, from_old), fe = (uint32_t)__shfl((int)ve, from_new);
+                ac_re.Z = old ? kr : fr; ac_im.Z = old ? ki : fi; energy.Z = old ? ke : fe;
             }
+            auto_count = 0; sense_count += 4u * done;
+            // TDCEstimator (dc.hpp:92-166): 16-bit running sums of the bursts taken; the estimate moves at most at the pass's last burst (K <= dc_cnt + 1)
+            sum_dc_re = w16(sum_dc_re + __builtin_amdgcn_readlane((int)group_scan(dr), last));
+            sum_dc_im = w16(sum_dc_im + __builtin_amdgcn_readlane((int)group_scan(di), last));
+            if (done == dc_cnt + 1u) {
+                dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
+                dc_cnt = 7; sum_dc_re = sum_dc_im = 0;
+            } else dc_cnt -= done;
+            if (sense_count >= 84) error_code = E_CS_TIMEOUT;                   // cca.hpp:433-437
         }
         if (done) {                                                             // history <- its last 16 samples
             const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;   // index in {old history 0..15, new samples 16..47}

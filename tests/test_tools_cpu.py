@@ -15,15 +15,15 @@ def _csv(path, rows):
 
 
 def test_summarize_pmc_applies_the_calibrated_factors(tmp_path):
-    """FETCH_SIZE (KiB) is doubled for kernels fed by vector loads and taken as reported for the scalar-fed trellis kernels;
-    WRITE_SIZE is taken as reported (profiles/r02_k_calibration.json)."""
+    """FETCH_SIZE (KiB) is doubled for every kernel (all of them are fed by vector loads since round 3: the trellis kernels fetch the packed soft
+    stream with 16-bit vector loads); WRITE_SIZE is taken as reported (profiles/r02_k_calibration.json)."""
     f, w = str(tmp_path / "f.csv"), str(tmp_path / "w.csv")
     _csv(f, [("sora::k_frame(sora::RxArgs)", "FETCH_SIZE", 1000), ("sora::k_viterbi(sora::VitJob const*)", "FETCH_SIZE", 2000), ("other_kernel()", "FETCH_SIZE", 5)])
     _csv(w, [("sora::k_frame(sora::RxArgs)", "WRITE_SIZE", 300), ("sora::k_viterbi(sora::VitJob const*)", "WRITE_SIZE", 10)])
-    out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), f, w, "4096"]))
+    out = json.loads(subprocess.check_output([sys.executable, os.path.join(ROOT, "tools", "summarize_pmc.py"), f, w, "4096", "", "k_viterbi"]))   # (the trellis kernel of the call being summed)
     k = out["kernels"]
     assert k["k_frame"]["fetch_bytes"] == 1000 * 1024 * 2 and k["k_frame"]["write_bytes"] == 300 * 1024
-    assert k["k_viterbi"]["fetch_bytes"] == 2000 * 1024 and k["k_viterbi"]["write_bytes"] == 10 * 1024
+    assert k["k_viterbi"]["fetch_bytes"] == 2000 * 1024 * 2 and k["k_viterbi"]["write_bytes"] == 10 * 1024
     assert "other_kernel" not in k
     assert out["total_hbm_bytes_per_call"] == k["k_frame"]["hbm_bytes"] + k["k_viterbi"]["hbm_bytes"]
     assert out["algorithmic_bytes_per_call"] == round(4096 * 4880 * 4.3375)

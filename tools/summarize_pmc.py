@@ -7,11 +7,11 @@ FETCH_SIZE / WRITE_SIZE are reported in KiB per dispatch (they come from the L2'
 Corrections as /opt/skills/guides/MI355X_MICROARCH.md (section HBM) prescribes for gfx950 -- FETCH_SIZE reports half the bytes
 of a coalesced vector read; "other access widths and WRITE_SIZE are uncalibrated: calibrate on a known byte count in your
 own access pattern" -- with the calibration done: tools/calib/fetch_calib moves 1 GiB in each access shape the kernels use
-(profiles/r02_k_calibration.json): vector loads, 16 B or 4 B per lane: reported / moved = 0.5; SCALAR loads (s_load_dwordx8,
-the way k_viterbi / k_viterbi11n read their soft values): 1.0; stores of 16 B, 4 B and 1 B per lane: 1.0.  So FETCH_SIZE is
-doubled for every kernel except the scalar-fed ones, WRITE_SIZE is taken as reported.  (Before this calibration the doubling
-was applied to all kernels, which counted k_viterbi's input twice: profiles up to r02_i.)  The two counters cannot share a
-pass, so each file comes from its own run of the same command.
+(profiles/r02_k_calibration.json): vector loads, 16 B or 4 B per lane: reported / moved = 0.5; scalar loads of 32 bytes
+(s_load_dwordx8, the way round 2's k_viterbi read its soft values): 1.0; stores of 16 B, 4 B and 1 B per lane: 1.0.  Every kernel
+of round 3 is fed by vector loads (the trellis kernels fetch the packed soft stream with 16-bit vector loads), so FETCH_SIZE is
+doubled for all of them; WRITE_SIZE is taken as reported.  The two counters cannot share a pass, so each file comes from its own
+run of the same command.
 """
 import csv
 import json
@@ -19,9 +19,7 @@ import sys
 from collections import defaultdict
 
 
-SCALAR_FED = ()          # round 2: k_viterbi read 32-byte pieces with s_load_dwordx8 and FETCH_SIZE counted them in full.  Round 3: it reads whole 64-byte
-                         # lines (s_load_dwordx16 of the pair stream) and its raw FETCH_SIZE equals k_viterbi16's, which reads the SAME 132 MB with
-                         # vector loads (profiles/r03_n_traffic.json: 66.7 vs 66.1 MB raw) -- the half-tally applies to both, so both are doubled.
+SCALAR_FED = ()          # (round 2: k_viterbi, fed by 32-byte scalar loads that FETCH_SIZE counted in full)
 
 
 def per_kernel(path, counter):
@@ -41,7 +39,7 @@ def main():
     write = per_kernel(sys.argv[2], "WRITE_SIZE")
     frames = int(sys.argv[3]) if len(sys.argv) > 3 else 4096
     out = {"unit": "bytes per launch", "frames_per_launch": frames,
-           "corrections": "FETCH_SIZE KiB x1024 x2 (the guide's gfx950 correction; round 3: also for k_viterbi, whose 64-byte scalar loads are tallied like vector loads -- its raw count equals k_viterbi16's for the same 132 MB stream); WRITE_SIZE KiB x1024 as reported; factors measured by tools/calib/fetch_calib (profiles/r02_k_calibration.json)",
+           "corrections": "FETCH_SIZE KiB x1024 x2 (the guide's gfx950 correction; every kernel is fed by vector loads); WRITE_SIZE KiB x1024 as reported; factors measured by tools/calib/fetch_calib (profiles/r02_k_calibration.json)",
            "kernels": {}}
     total = 0.0
     trellis = sys.argv[5] if len(sys.argv) > 5 else "k_viterbi16"             # the trellis kernel of the call being summed (the run also holds a few launches of the other one)
@@ -55,7 +53,7 @@ def main():
                              "launches_sampled": fetch.get(k, (0.0, 0))[1]}
         if k in rx_path:
             total += fb + wb
-    if len(sys.argv) > 4:                                                     # third pass: SQ_INSTS_VALU / SQ_INSTS_SALU per dispatch
+    if len(sys.argv) > 4 and sys.argv[4]:                                     # third pass: SQ_INSTS_VALU / SQ_INSTS_SALU per dispatch
         valu = per_kernel(sys.argv[4], "SQ_INSTS_VALU"); salu = per_kernel(sys.argv[4], "SQ_INSTS_SALU")
         tv = 0.0
         for k in out["kernels"]:
