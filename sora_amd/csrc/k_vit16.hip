@@ -53,10 +53,12 @@ template <int WIN, int LOOK> struct Geom16 {
 
 template <int WIN, int LOOK> struct Lds16 {
     uint16_t ring[Geom16<WIN, LOOK>::P][4][64];                                 // [block % P][row][rev6(state)] {frame A's byte, frame B's byte}: 18944 / 15872 B
-    uint32_t udump[4][64];                                                      // the metrics registers at a trace-back (the start state's unfinished block)
-    uint16_t ops[4][24][2];                                                     // [row][operand of the chunk][frame]: the soft values as metric fields
+    union {
+        uint32_t udump[4][64];                                                  // the metrics registers at a trace-back (the start state's unfinished block)
+        uint16_t ops[4][24][2];                                                 // [row][operand of the chunk][frame]: the soft values as metric fields -- live only inside
+    };                                                                          //   forward16's unpack(), never across a trace-back: the two share their bytes
     uint8_t  path[8][Geom16<WIN, LOOK>::kPathBytes];                             // [row * 2 + frame][walk position]: the bytes along the traced path
-};                                                                              // 20672 / 17600 bytes: seven one-wave workgroups per CU
+};                                                                              // 20288 / 17216 bytes: eight one-wave workgroups per CU (20480 each)
 
 constexpr unsigned kW[4] = { 0u, 21u, 42u, 63u };
 
