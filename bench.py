@@ -46,7 +46,7 @@ FRAME_SAMPLES = 4880       # 160 STS + 160 LTS + 80 SIGNAL + 56*80 data @20 MHz
 CAPTURE_SAMPLES = 5040     # + 160 silence; 360 source bursts of 14
 ALG_BYTES_PER_SAMPLE = 4.0 + 216 / 8.0 / 80.0     # 4.3375
 HBM_PEAK = 8.0e12
-TRAFFIC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_x_traffic.json")
+TRAFFIC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final_traffic.json")
 
 
 def measured_traffic(kernel):
