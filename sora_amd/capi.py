@@ -677,12 +677,12 @@ def ht40_symbols(length0, length1, n_bpsc, code_rate):
 
 # ---- per-stage entry points on torch CUDA tensors ---------------------------------------------------
 def _hold(obj, item, sync=True):
-    """The handles keep several calls in flight on their own non-blocking streams: (i) the inputs of the last 8 calls stay referenced
+    """The handles keep several calls in flight on their own non-blocking streams (up to 16: sora_rx_set_depth): (i) the inputs of the last 17 calls stay referenced
     (torch's caching allocator must not hand a block to the next tensor while a kernel still reads it), (ii) whatever produced the
     tensors on torch's current stream has finished before the library's stream reads them."""
     import collections
     if getattr(obj, "_keep", None) is None:
-        obj._keep = collections.deque(maxlen=8)
+        obj._keep = collections.deque(maxlen=17)
     obj._keep.append(item)
     if sync and getattr(obj, "wait_for_producer", True):
         import torch
