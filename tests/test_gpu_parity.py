@@ -114,6 +114,23 @@ def test_viterbi_bit_exact_on_noise(sora, torch_cuda, oracle, cr):
         o3 = o3.cpu().numpy()
         for i, L in enumerate(lens[:n]):
             assert np.array_equal(o3[i, :L + 2], out[i, :L + 2]), ("16 lanes per pair", cr, L, n)
+    # the stage packs the caller's bytes to three bits per value (k_soft_pack3): jobs at ODD byte offsets, with junk in the upper five bits of
+    # every byte (only the low three are soft values), decode to the same bytes
+    offs2, o = [], 1
+    for nsoft in ns:
+        offs2.append(o); o += nsoft + 3
+    buf2 = rng.integers(0, 32, size=o + 64).astype(np.uint8) << 3
+    for s_, o_ in zip(softs, offs2):
+        buf2[o_:o_ + len(s_)] |= s_
+    d_buf2 = torch.from_numpy(buf2).cuda()
+    ws2 = torch.empty(sora.viterbi11a_workspace_bytes(d_buf2.numel(), len(lens)), dtype=torch.uint8, device="cuda")
+    args2 = (torch.tensor(offs2, dtype=torch.int32).cuda(), torch.tensor(ns, dtype=torch.int32).cuda(), torch.tensor(lens, dtype=torch.int16).cuda())
+    for lanes in (64, 16):
+        o4 = sora.viterbi11a_ws(d_buf2, *args2, cr, ws2, lanes_per_pair=lanes)
+        torch.cuda.synchronize()
+        o4 = o4.cpu().numpy()
+        for i, L in enumerate(lens):
+            assert np.array_equal(o4[i, :L + 2], out[i, :L + 2]), ("odd offsets", lanes, cr, L)
 
 
 # ------------------------------------------------------------------ whole path
