@@ -162,11 +162,11 @@ int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process c
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);
 
 /* Two implementations of the data field (T11aDataSymbol .. T11aViterbi) with identical results:
- *   0 (default)  k_frame (symbol chain, soft values to HBM as 16-bit fields) then k_viterbi (two frames per wave);
+ *   0 (default)  k_frame (symbol chain, soft values to HBM packed three bits each) then k_viterbi16 / k_viterbi (sora_rx_set_trellis);
  *   1            k_decode: both in one kernel, symbol waves feeding trellis waves through a ring in LDS the way the
- *                reference's RxThread feeds its ViterbiThread through TThreadSeparator (stdbrick.hpp:89-248) -- a quarter of
- *                the HBM traffic, the better choice for one call at a time; with several calls in flight the split form is
- *                faster because its kernels leave room for each other on the CUs.
+ *                reference's RxThread feeds its ViterbiThread through TThreadSeparator (stdbrick.hpp:89-248).  Since round 3
+ *                the split form is the faster one at any depth and moves little more HBM (its soft stream is 25 MB per 4096
+ *                frames); the fused kernel remains as an independent second implementation.
  * Returns the previous value; enable < 0 only queries.
  * sora_rx_kernel_name_fused(i) names the kernels of the fused chain for sora_rx_kernel_times ("" = slot not used). */
 int  sora_rx_set_fused(sora_rx_t* rx, int enable);
