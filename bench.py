@@ -507,8 +507,8 @@ def bench_11n(torch, sora_amd, dev, ncaps=8192, reps=5):
     rx.wait_for_producer = False
     mlen = 1000 if g.available() else 150
     res = {}
-    D11N = 6
-    for lanes in (64, 16):                                                   # both trellis kernels (sora_rx11n_set_trellis), six calls in flight
+    D11N = 8
+    for lanes in (64, 16):                                                   # both trellis kernels (sora_rx11n_set_trellis), eight calls in flight
         rx.set_trellis(lanes); rx.set_depth(D11N)
         ms_, delivery_, first_ = timed_with_delivery(sora_amd, rx, lambda: rx.process_dev(f0, f1, descs), D11N, max(reps, 36), ncaps * 4, ncaps * (mlen + 4) + 4096)
         res[lanes] = (ms_, delivery_, first_)
