@@ -250,7 +250,7 @@ def test_repeated_calls_replay_graph(sora, torch_cuda, oracle, graph, monkeypatc
     rx.close()
 
 
-@pytest.mark.parametrize("depth", [1, 2, 4])
+@pytest.mark.parametrize("depth", [1, 2, 4, 8, 16])
 def test_calls_in_flight(sora, torch_cuda, oracle, depth):
     """Consecutive calls rotate over internal pipelines; results() always reports the most recent call."""
     sets = []
@@ -261,13 +261,17 @@ def test_calls_in_flight(sora, torch_cuda, oracle, depth):
     rx = sora.Rx(max_captures=8, max_total_samples=max(len(t) for t, _, _ in sets), sample_rate_mhz=20, max_frames_per_capture=2)
     assert rx.set_depth(depth) == 8 and rx.set_depth(0) == depth
     assert rx.trellis() == (16 if depth >= 4 else 64)                 # the automatic choice of the trellis kernel follows the depth
-    for k in range(9):
+    ncalls = max(9, 2 * depth + 1)                  # (every pipeline is used at least twice)
+    tickets = []
+    for k in range(ncalls):
         t, d, want = sets[k % 3]
-        rx.process_dev(t, d)
+        tickets.append(rx.process_dev(t, d))
         if k % 2:                                   # sometimes let several calls pile up before looking
             ok, why = same_results(rx.results(), want); assert ok, (k, why)
+    for k in range(max(0, ncalls - depth), ncalls):  # every call still in flight is addressable by its ticket
+        ok, why = same_results(rx.results(ticket=tickets[k]), sets[k % 3][2]); assert ok, ("ticket", k, why)
     rx.flush()
-    ok, why = same_results(rx.results(), sets[8 % 3][2]); assert ok, why
+    ok, why = same_results(rx.results(), sets[(ncalls - 1) % 3][2]); assert ok, why
     rx.reset()
     with pytest.raises(Exception):
         rx.results()
