@@ -117,7 +117,17 @@ __device__ __forceinline__ int dsp_atan16(const short* tab, int x, int y)      /
     const int tsum = absx + absy, d = absx - absy;
     const int tmax = (tsum + ((d ^ (d >> 31)) - (d >> 31))) >> 1, tmin = tsum - tmax;
     if (tmax == 0) return 0;
-    const int idx = (int)(((unsigned)tmin << 16) + (unsigned)(tmax >> 1)) / tmax;
+    int idx;
+    if (tmin >= 0 && tmin <= tmax && tmax < 32768) {
+        // The usual case (everything but an input of -32768): numerator < 2^31 + 2^14, divisor < 2^15, quotient <= 65536.  One reciprocal and a
+        // correction in each direction instead of the 30-instruction integer division: the float estimate is off by less than 0.02.
+        const unsigned num = ((unsigned)tmin << 16) + ((unsigned)tmax >> 1);
+        unsigned q = (unsigned)((float)num * __builtin_amdgcn_rcpf((float)tmax));
+        int r = (int)(num - __umul24(q, (unsigned)tmax));
+        if (r < 0) { q--; r += tmax; }
+        if (r >= tmax) q++;
+        idx = (int)q;
+    } else idx = (int)(((unsigned)tmin << 16) + (unsigned)(tmax >> 1)) / tmax;
     return atan_tail(tab, idx >> 4, tsign, sign);
 }
 __device__ __forceinline__ int dsp_atan32(const short* tab, int x, int y)      // dsp_math::atan(int, int), for |x| + |y| < 2^31

@@ -987,12 +987,15 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
     const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
     const uint32_t n20 = cd.nsamples / 2;
     auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t { return i < n20 ? iq[r][2 * (size_t)i] : 0u; };
-    const Fft64Tw tw = fft64_twiddles(A.T, lane & 15);
+    const Fft64TwPk tw = fft64_twiddles_pk(A.T, lane & 15);                     // the packed-arithmetic FFT<64> of k_frame (dev_arith.h): half the instructions of the unpacked one
     auto nosync = []() __attribute__((always_inline)) { wsync(); };
     const int cfo = uni(F.cfo);
     const uint32_t l0 = (uint32_t)uni((int)F.l0), mcs = (uint32_t)uni((int)F.mcs), nproc = (uint32_t)uni((int)F.nproc);
     const int nb = mcs == 8 ? 1 : 2;
-    for (int g = lane; g < 104 * nb; g += 64) W.dtab[g] = (uint8_t)deint11n_index(nb, g & 1, g >> 1);
+    // joined position g = lane + 64 t (stream g & 1 = lane & 1) <- soft[lane & 1][dt[t]]: the lane's four de-interleaver entries stay in registers
+    uint32_t dt[4];
+#pragma unroll
+    for (int t = 0; t < 4; t++) { const int g = lane + 64 * t; dt[t] = g < 104 * nb ? (uint32_t)deint11n_index(nb, g & 1, g >> 1) : 0xFFFFFFFFu; }
     int theta = 0;
     // one symbol at 20 MHz index `pos` (its CP included): TFreqComp_11n (running phase n * CFO - theta, n counted from the L-LTF), two FFTs -> W.y[.][64 * half ..]
     auto symbol_fft = [&](uint32_t pos, uint32_t x0, uint32_t x1, int half) __attribute__((always_inline)) {
@@ -1002,13 +1005,13 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
         mul32(unpack(x0), cof, re, im); W.buf[0][lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
         mul32(unpack(x1), cof, re, im); W.buf[1][lane] = pack(mk(sat16(re >> 15), sat16(im >> 15)));
         wsync();
-        const int g = lane >> 4, e = lane & 15; cpx x[4], yy[4];
+        const int g = lane >> 4, e = lane & 15; pcx x[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) x[q] = unpack(W.buf[g & 1][e + 16 * q]);
-        fft64_group(x, yy, W.fft[g], e, tw, nosync);
+        for (int q = 0; q < 4; q++) x[q] = W.buf[g & 1][e + 16 * q];
+        fft64_core_pk(x, W.fft[g], e, tw, nosync);                               // bin j at slot bitrev6(j) of W.fft[g]
         if (g < 2) {
 #pragma unroll
-            for (int q = 0; q < 4; q++) W.y[g][64 * half + e + 16 * q] = pack(yy[q]);
+            for (int q = 0; q < 4; q++) W.y[g][64 * half + e + 16 * q] = W.fft[g][__brev((unsigned)(e + 16 * q)) >> 26];
         }
         wsync();
     };
@@ -1078,8 +1081,12 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
             }
         }
         wsync();
-        // joined position g (stream g & 1) <- soft[g & 1][dtab[g]]
-        for (uint32_t g = lane; g < S; g += 64) dst[(size_t)d * S + g] = W.soft[g & 1][W.dtab[g]];
+        {
+            const uint8_t* mine = W.soft[lane & 1];
+            uint8_t* o = dst + (size_t)d * S + lane;
+#pragma unroll
+            for (int t = 0; t < 4; t++) if (dt[t] != 0xFFFFFFFFu) o[64 * t] = mine[dt[t]];
+        }
         wsync();
     }
     for (uint32_t g = nproc * S + lane; g < F.nsoft; g += 64) dst[g] = 0;                     // the zero soft values of a flush at the end of the capture
