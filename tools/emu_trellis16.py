@@ -15,7 +15,9 @@ span(e0..e3); the butterfly partner of state s at step t is s ^ e_j, j = 5 - t m
     e0, e2, e4 = e0 ^ e2 ^ 21     ->  lane ^ 1, lane ^ 2, lane ^ 3 (and register ^ 1)      all quad_perm
     e1, e3, e5 = e1 ^ e3 ^ 42     ->  lane ^ 8, lane ^ 7, lane ^ 15 (and register ^ 2)     row_ror:8, row_half_mirror, row_mirror
 so every exchange is ONE row-local DPP move and a register renaming: no v_permlane swaps, no in-register special case,
-and the two branch-metric operands of a step (P and K - P + mark) serve all four registers.
+and the two branch-metric operands of a step (P and K - P + mark) serve all four registers.  (The model starts from the pair's soft values
+as operand fields; how the kernel gets them -- 16-bit loads from the frames' packed three-bit streams, an operand table in LDS -- is the
+format checked by tests/test_soft3_format.py.)
 """
 import numpy as np
 
