@@ -355,9 +355,9 @@ uint32_t sora_ht40_symbols(uint32_t length0, uint32_t length1, uint32_t n_bpsc, 
 int   sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out);  /* max_soft_values >= sum over frames of 2 x nsym x 108 n_bpsc (+ 64 per frame) */
 void  sora_ht40_destroy(sora_ht40_t* rx);
 void* sora_ht40_stream(sora_ht40_t* rx);                                                               /* the stream of the most recent process call */
-int   sora_ht40_set_trellis(sora_ht40_t* rx, int lanes_per_pair);                                       /* 64 (default) / 16: as sora_rx_set_trellis (the two streams of a frame are one pair) */
-int   sora_ht40_synchronize(sora_ht40_t* rx);                                                          /* every call issued so far has finished (a handle keeps three calls in flight:
-                                                                                                        * process_dev waits only for the call three calls back; results reports the most recent one) */
+int   sora_ht40_set_trellis(sora_ht40_t* rx, int lanes_per_pair);                                       /* 16 (default: the handle keeps eight calls in flight) / 64: as sora_rx_set_trellis (the two streams of a frame are one pair) */
+int   sora_ht40_synchronize(sora_ht40_t* rx);                                                          /* every call issued so far has finished (a handle keeps eight calls in flight:
+                                                                                                        * process_dev waits only for the call eight calls back; results reports the most recent one) */
 int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);
 int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* The same receiver on RAW CAPTURES, as every other handle takes its input: two-chain 40 MHz captures (whole 28-sample source bursts,
@@ -370,11 +370,12 @@ int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_ou
  * "dual Viterbi"), the CFO handed to the data field is the L-LTF estimate, the noise variance the MMSE detector uses is estimated from
  * the difference of the two L-LTF symbols.  Rows: per event in (capture, time) order; a recorded frame reports two rows (start_sample =
  * spatial stream, rate_kbps = MCS, end_sample = 40 MHz source position of the event, FRAME_OK / CRC32_FAIL), a header that fails one row
- * (SORA_E_PLCP_HEADER_FAIL); a frame the capture cuts off raises no event.  Tickets / results_of / deliver_async as above.  One host
- * wait per call, between the front end and the data field. */
+ * (SORA_E_PLCP_HEADER_FAIL); a frame the capture cuts off raises no event.  Tickets / results_of / deliver_async as above.  The call is one
+ * chain of kernels (the front end's records become the data field's tables on the device, k_ht40_plan): no host wait inside it; captures that
+ * hold more frames / soft values than the handle was created for are reported by sora_ht40_wait / _results_of (SORA_ERR_CAPACITY). */
 int   sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* h_caps, size_t ncaps,
                                      uint32_t max_frames_per_capture);
-/* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_ht40_calls_in_flight() (3) further calls have reused its
+/* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_ht40_calls_in_flight() (8) further calls have reused its
  * slot -- so back-to-back calls are all collectable, each by its own ticket, while later ones run.  The INPUT buffers of a call must stay
  * untouched until sora_ht40_wait(its ticket) (or _results_of, or _synchronize) has returned. */
 int   sora_ht40_ticket(sora_ht40_t* rx);                       /* ticket of the most recent process call (0: none) */

@@ -16,9 +16,11 @@
 namespace sora {
 
 __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict__ rows, const uint32_t* __restrict__ nframes, const CapDesc* __restrict__ caps,
-                                                     const sora_frame_result* __restrict__ tmpl, uint32_t ncaps, uint32_t mf,
-                                                     sora_frame_result* __restrict__ out, uint32_t* __restrict__ src_slot, uint32_t* __restrict__ meta, uint32_t mpdu_cap)
+                                                     const sora_frame_result* __restrict__ tmpl, uint32_t ncaps_bound, uint32_t mf,
+                                                     sora_frame_result* __restrict__ out, uint32_t* __restrict__ src_slot, uint32_t* __restrict__ meta, uint32_t mpdu_cap,
+                                                     const uint32_t* __restrict__ ncaps_dev)
 {
+    const uint32_t ncaps = ncaps_dev ? min(ncaps_bound, *ncaps_dev) : ncaps_bound;     // (the 40 MHz handle plans its frames on the device: the host knows only a bound)
     __shared__ uint32_t s_a[1024], s_b[1024];
     __shared__ uint32_t s_base[2];
     const uint32_t t = threadIdx.x;
@@ -97,7 +99,8 @@ void sora_internal_dense_free(DenseStage* D)
 
 int sora_internal_dense_deliver(DenseStage* D, const Rx11bRow* d_rows, const uint32_t* d_nframes, const CapDesc* d_caps, const sora_frame_result* h_tmpl,
                                 uint32_t ncaps, uint32_t mf, const uint8_t* d_slots, hipStream_t st,
-                                sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap)
+                                sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap,
+                                const sora_frame_result* d_tmpl, const uint32_t* d_ncaps)
 {
     if (!D || !h_rows || !h_meta || (h_mpdu && mpdu_cap == 0)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "deliver_async: null argument", 0);
     const size_t cap_rows = (size_t)ncaps * mf;
@@ -112,8 +115,8 @@ int sora_internal_dense_deliver(DenseStage* D, const Rx11bRow* d_rows, const uin
     hipError_t e = hipSuccess;
     if (h_tmpl) e = hipMemcpyAsync(D->d_tmpl, h_tmpl, sizeof(sora_frame_result) * cap_rows, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "deliver_async: row templates", (int)e);
-    hipLaunchKernelGGL(k_dense_rows, dim3(1), dim3(1024), 0, st, d_rows, d_nframes, d_caps, (const sora_frame_result*)(h_tmpl ? D->d_tmpl : nullptr), ncaps, mf,
-                       D->d_rows, D->d_src, D->d_meta, (uint32_t)(h_mpdu ? mpdu_cap : 0));
+    hipLaunchKernelGGL(k_dense_rows, dim3(1), dim3(1024), 0, st, d_rows, d_nframes, d_caps, (const sora_frame_result*)(d_tmpl ? d_tmpl : h_tmpl ? D->d_tmpl : nullptr), ncaps, mf,
+                       D->d_rows, D->d_src, D->d_meta, (uint32_t)(h_mpdu ? mpdu_cap : 0), d_ncaps);
     if (h_mpdu) hipLaunchKernelGGL(k_dense_mpdu, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, (const sora_frame_result*)D->d_rows, (const uint32_t*)D->d_src,
                                    (const uint32_t*)D->d_meta, d_slots, D->d_mpdu);
     e = hipMemcpyAsync(h_meta, D->d_meta, 8, hipMemcpyDeviceToHost, st);

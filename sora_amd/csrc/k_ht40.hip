@@ -38,9 +38,10 @@ struct Ht40Args {
     Tables T; const uint32_t* sincos; const short* atan;
     uint8_t* soft;
     uint32_t* w_out;            // optional [nframes][4][128]: the detection weights (tests)
+    const uint32_t* plan;       // raw-capture calls: {frames, events, soft bytes, error} written by k_ht40_plan (nframes above is then only a bound)
 };
 struct Ht40Job { uint32_t out_off, length, row, pad; };
-struct Ht40FinishArgs { const Ht40Job* jobs; uint32_t njobs; const uint8_t* vout; uint8_t* mpdu; Rx11bRow* rows; Tables T; };
+struct Ht40FinishArgs { const Ht40Job* jobs; uint32_t njobs; const uint8_t* vout; uint8_t* mpdu; Rx11bRow* rows; Tables T; const uint32_t* plan; };
 
 namespace {
 static __constant__ int8_t kHtLtf40[117] = {    // carriers -58..58 (IEEE 802.11n-2009 eq. 20-24)
@@ -82,7 +83,7 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
     const uint32_t f = blockIdx.x * 4 + wv;
-    if (f >= A.nframes) return;
+    if (f >= (A.plan ? min(A.nframes, A.plan[0]) : A.nframes)) return;
     Ht40Lds& W = s_w[wv];
     const Ht40Frame F = A.frames[f];
     const uint32_t* iq[2] = { A.iq0 + F.offset, A.iq1 + F.offset };
@@ -231,7 +232,7 @@ __global__ void __launch_bounds__(256) k_ht40_finish(Ht40FinishArgs A)
     __syncthreads();
     const int lane = threadIdx.x & 63, wv = (int)(threadIdx.x >> 6);
     const uint32_t j = blockIdx.x * 4 + wv;
-    if (j >= A.njobs) return;
+    if (j >= (A.plan ? min(A.njobs, 2u * A.plan[0]) : A.njobs)) return;
     const Ht40Job J = A.jobs[j];
     const uint8_t* dec = A.vout + J.out_off;
     uint8_t* mp = A.mpdu + (size_t)J.row * 4096;
@@ -257,15 +258,108 @@ __global__ void __launch_bounds__(256) k_ht40_finish(Ht40FinishArgs A)
     }
 }
 
+// ---- raw-capture calls: what the front end found (k_scan_ht40: per capture a count and up to `mf` Ht40Found records in time order) -> the data
+// field's tables, on the device, so that the call is one uninterrupted chain of kernels (the first version read the records back and built the
+// tables on the host: one host wait per call).  One block: per capture the number of recorded frames, their soft bytes and their number per
+// code rate; five exclusive prefix sums over the captures; then every capture writes its frames' descriptors, the two decoder jobs of each
+// (neighbours in their code-rate list: one wave decodes both streams), the finish jobs and the rows' templates, in (capture, time) order.
+__device__ __forceinline__ uint32_t ht40_ndbps_dev(uint32_t nb, uint32_t cr) { return 108u * nb * (cr == 0 ? 1u : cr == 1 ? 2u : 3u) / (cr == 0 ? 2u : cr == 1 ? 3u : 4u); }
+struct Ht40Geom { uint32_t nb, cr, nsym, per, per_pad; };
+__device__ __forceinline__ Ht40Geom ht40_geom(const Ht40Found& F)
+{
+    Ht40Geom G;
+    G.nb = F.mcs == 8 ? 1u : F.mcs <= 10 ? 2u : F.mcs <= 12 ? 4u : 6u;
+    G.cr = (F.mcs == 10 || F.mcs == 12 || F.mcs == 14) ? 2u : F.mcs == 13 ? 1u : 0u;
+    const uint32_t nd = ht40_ndbps_dev(G.nb, G.cr);
+    G.nsym = (16u + 8u * F.ht_len + 6u + nd - 1u) / nd;                          // sora_ht40_symbols(len, len, nb, cr)
+    G.per = G.nsym * 108u * G.nb; G.per_pad = (G.per + 31u) / 32u * 32u;
+    return G;
+}
+__global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ caps, uint32_t ncaps, uint32_t mf, const uint32_t* __restrict__ nfr, const Ht40Found* __restrict__ found,
+                                                    uint32_t max_frames, uint64_t max_soft, uint32_t vout_stride,
+                                                    Ht40Frame* __restrict__ frames, VitJob* __restrict__ jobs, uint32_t stride, uint32_t* __restrict__ njobs, Ht40Job* __restrict__ fjobs,
+                                                    sora_frame_result* __restrict__ tmpl, uint32_t* __restrict__ plan)
+{
+    __shared__ uint32_t s_v[5][1024];
+    __shared__ uint32_t s_base[5];
+    __shared__ uint32_t s_err;
+    const uint32_t t = threadIdx.x;
+    if (t < 5) s_base[t] = 0;
+    if (t == 0) s_err = 0;
+    __syncthreads();
+    for (uint32_t c0 = 0; c0 < ncaps; c0 += 1024) {
+        const uint32_t c = c0 + t;
+        const uint32_t n = c < ncaps ? min(nfr[c], mf) : 0u;
+        uint32_t mine[5] = { 0, 0, 0, 0, 0 };                                    // frames, soft bytes, frames of code rate 0 / 1 / 2
+        for (uint32_t i = 0; i < n; i++) {
+            const Ht40Found& F = found[(size_t)c * mf + i];
+            if (F.error_code != 0) continue;
+            const Ht40Geom G = ht40_geom(F);
+            mine[0]++; mine[1] += 2u * G.per_pad; mine[2 + G.cr]++;
+        }
+#pragma unroll
+        for (int k = 0; k < 5; k++) s_v[k][t] = mine[k];
+        __syncthreads();
+        for (uint32_t o = 1; o < 1024; o <<= 1) {                                // Hillis-Steele inclusive scans of the five counters
+            uint32_t add[5];
+#pragma unroll
+            for (int k = 0; k < 5; k++) add[k] = t >= o ? s_v[k][t - o] : 0u;
+            __syncthreads();
+#pragma unroll
+            for (int k = 0; k < 5; k++) s_v[k][t] += add[k];
+            __syncthreads();
+        }
+        uint32_t at[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) at[k] = s_base[k] + s_v[k][t] - mine[k];
+        for (uint32_t i = 0; i < n; i++) {
+            const Ht40Found& F = found[(size_t)c * mf + i];
+            if (F.error_code != 0) continue;
+            const Ht40Geom G = ht40_geom(F);
+            const uint32_t fi = at[0], soft_off = at[1], pos = 2u * at[2 + G.cr];
+            at[0]++; at[1] += 2u * G.per_pad; at[2 + G.cr]++;
+            if (fi >= max_frames || (uint64_t)soft_off + 2u * G.per_pad > max_soft || !(F.noise_var >= 0.0f)) { s_err = 1u; continue; }   // (reported by wait / results: SORA_ERR_CAPACITY)
+            Ht40Frame H;
+            H.offset = caps[c].offset + 2ull * F.a20 + 160ull;                   // HT-STF is 4 us = 160 samples @40 MHz; HT-LTF 1 follows
+            H.nsym = G.nsym; H.nb = G.nb; H.code_rate = G.cr; H.length[0] = H.length[1] = F.ht_len;   // one HT-SIG LENGTH: each stream carries its own PSDU of that length
+            H.cfo = F.cfo / 2;                                                   // per 20 MHz sample -> per 40 MHz sample
+            H.noise_var = F.noise_var; H.soft_off = soft_off; H.pad[0] = H.pad[1] = H.pad[2] = H.pad[3] = 0;
+            frames[fi] = H;
+#pragma unroll
+            for (uint32_t k = 0; k < 2; k++) {
+                VitJob J;
+                J.soft_off = soft_off + k * G.per_pad; J.soft_bits = 8; J.nsoft = G.per; J.length = F.ht_len; J.dec_off = 0; J.out_off = (2u * fi + k) * vout_stride; J.valid = 1; J.code_rate = G.cr;
+                jobs[(size_t)G.cr * stride + pos + k] = J;
+                fjobs[2u * fi + k] = Ht40Job{ J.out_off, F.ht_len, 2u * fi + k, 0u };
+                sora_frame_result o;
+                o.capture_id = caps[c].capture_id; o.start_sample = k; o.end_sample = F.end_sample; o.error_code = 0; o.rate_kbps = F.mcs;
+                o.length = 0; o.nsym = (uint16_t)G.nsym; o.crc32 = 0; o.cfo_est = 0; o.flags = 0; o.mpdu_offset = 0;
+                tmpl[2u * fi + k] = o;
+            }
+        }
+        __syncthreads();
+        if (t == 1023) {
+#pragma unroll
+            for (int k = 0; k < 5; k++) s_base[k] += s_v[k][1023];
+        }
+        __syncthreads();
+    }
+    if (t == 0) {                                                                // (a batch that does not fit is not decoded at all: the job lists would have holes)
+        const bool bad = s_err != 0;
+        plan[0] = bad ? 0u : s_base[0]; plan[1] = s_base[0]; plan[2] = s_base[1]; plan[3] = s_err;
+        njobs[0] = bad ? 0u : 2u * s_base[2]; njobs[1] = bad ? 0u : 2u * s_base[3]; njobs[2] = bad ? 0u : 2u * s_base[4]; njobs[3] = 0;
+    }
+}
+
 }  // namespace sora
 
 // ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
 using namespace sora;
 
 // A handle owns kHt40Slots independent slots (stream + every intermediate), used round-robin: a call waits only for the call that used its
-// slot three calls ago, so the host's part of call n + 1 (job tables, four small copies) and the tail of call n's kernels overlap call n + 1's
+// slot kHt40Slots calls ago, so the host's part of call n + 1 (job tables, four small copies) and the tail of call n's kernels overlap call n + 1's
 // kernels.  sora_ht40_results reports the most recent call.
-static constexpr int kHt40Slots = 3;
+static constexpr int kHt40Slots = 8;
 struct Ht40Event { uint32_t capture_id, end_sample, error_code, mcs, length, nsym; int frame; bool truncated; };   // frame: index into the call's described frames, -1 = header failed
 struct Ht40Slot {
     hipStream_t stream = nullptr;
@@ -277,6 +371,11 @@ struct Ht40Slot {
     CapDesc* d_caps = nullptr; size_t caps_bytes = 0; Rx11bRow* d_scanrows = nullptr; size_t scanrows_bytes = 0;
     uint32_t* d_nfr = nullptr; size_t nfr_bytes = 0; Ht40Found* d_found = nullptr; size_t found_bytes = 0;
     bool capture_mode = false; uint32_t capture_mf = 0; std::vector<Ht40Event> events;
+    // ... planned on the device (k_ht40_plan): the records come back asynchronously into page-locked memory and are turned into `events` when the call is collected
+    uint32_t* d_plan = nullptr; sora_frame_result* d_tmpl = nullptr;
+    void* h_pin = nullptr; size_t pin_bytes = 0;                                // {plan[4], CapDesc[ncaps] (upload), nfr[ncaps], Ht40Found[ncaps * mf]}
+    uint32_t* h_plan = nullptr; CapDesc* h_capsup = nullptr; uint32_t* h_nfr = nullptr; Ht40Found* h_found = nullptr;
+    std::vector<sora_capture_desc> h_caps; bool events_pending = false; uint32_t bound_frames = 0; bool plan_error = false;
     DenseStage dense;           // sora_ht40_deliver_async
     std::vector<sora_frame_result> h_tmpl;                                      // what the rows of this call carry besides the decoder's verdict
 };
@@ -284,7 +383,7 @@ struct sora_ht40 {
     int device = 0; uint32_t max_frames = 0; uint64_t max_soft = 0;
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
     Ht40Slot slot[kHt40Slots]; int next = 0, last = 0, seq = 0; bool have_results = false;
-    int lanes16 = 0;            // trellis kernel: 0 = k_viterbi11n (64 lanes per stream pair), 1 = k_viterbi16_11n (sora_ht40_set_trellis)
+    int lanes16 = 1;            // trellis kernel: 1 = k_viterbi16_11n (default: the handle keeps eight calls in flight), 0 = k_viterbi11n (64 lanes per stream pair; the faster one for a call alone) -- sora_ht40_set_trellis
 };
 
 #define HIPCHK40(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -299,6 +398,7 @@ static void ht40_free(sora_ht40_t* rx)
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
         sora_internal_dense_free(&S.dense);
         (void)hipFree(S.d_caps); (void)hipFree(S.d_scanrows); (void)hipFree(S.d_nfr); (void)hipFree(S.d_found);
+        (void)hipFree(S.d_plan); (void)hipFree(S.d_tmpl); if (S.h_pin) (void)hipHostFree(S.h_pin);
     }
     delete rx;
 }
@@ -334,6 +434,8 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_vout, nj * kVoutStride + 256);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, nj * 4096);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * nj);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_plan, 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_tmpl, sizeof(sora_frame_result) * nj);
         if (e == hipSuccess) e = hipMemset(S.d_soft, 0, max_soft_values * 2 + 4096 + 1024);
         if (e == hipSuccess) e = hipMemset(S.d_vout, 0, nj * kVoutStride + 256);
     }
@@ -397,14 +499,14 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
     HIPCHK40(hipMemcpy(S.d_fjobs, fj.data(), sizeof(Ht40Job) * fj.size(), hipMemcpyHostToDevice));
     Ht40Args A;
     A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = S.d_frames; A.nframes = (uint32_t)nframes;
-    A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights);
+    A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights); A.plan = nullptr;
     hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, S.stream, A);
     const uint32_t njobs = 2 * (uint32_t)nframes;
     if (rx->lanes16)
         hipLaunchKernelGGL(k_viterbi16_11n, dim3((njobs + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     else
         hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
-    Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T;
+    Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T; Fi.plan = nullptr;
     hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());
     return SORA_OK;
@@ -416,66 +518,97 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
     HIPCHK40(hipSetDevice(rx->device));
     Ht40Slot& S = rx->slot[rx->next];
     HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
-    S.events.clear(); S.capture_mode = false;
+    S.events.clear(); S.capture_mode = false; S.events_pending = false; S.plan_error = false;
     return ht40_submit(rx, S, d_iq0, d_iq1, frames, nframes, d_weights);
 }
 
 // ---- the same receiver on RAW CAPTURES (BASELINE configs[3] as every other handle takes its input): two-chain 40 MHz captures in, the
 // front end (k_scan_ht40 in k_rx11n.hip: the reference's 20 MHz carrier sense / L-LTF / SIG bricks on the duplicated legacy preamble)
-// finds the frames, parses HT-SIG and estimates CFO and noise variance; the frame records come back to the host, which describes the data
-// fields to the kernels above.  One host wait per call, between the scan and the data field (the data field of call k still overlaps
-// the scan of call k + 1).  Rows: per event in (capture, time) order -- a recorded frame reports two rows (start_sample = spatial stream
-// 0 / 1, rate_kbps = MCS, end_sample = the 40 MHz source position of the event), a header that fails one row with SORA_E_PLCP_HEADER_FAIL.
+// finds the frames, parses HT-SIG and estimates CFO and noise variance; k_ht40_plan turns its records into the data field's tables on the
+// device, and the data-field kernels follow in the same stream: no host wait inside a call (the first version read the records back and
+// planned on the host).  The records travel to page-locked host memory behind the kernels and become the call's events when it is
+// collected.  Rows: per event in (capture, time) order -- a recorded frame reports two rows (start_sample = spatial stream 0 / 1,
+// rate_kbps = MCS, end_sample = the 40 MHz source position of the event), a header that fails one row with SORA_E_PLCP_HEADER_FAIL.
 int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps, uint32_t max_frames_per_capture)
 {
     if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps)) || max_frames_per_capture == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_captures_dev: bad argument", 0);
     if ((uint64_t)ncaps * max_frames_per_capture >= (1ull << 31)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: too many rows", 0);
     HIPCHK40(hipSetDevice(rx->device));
     Ht40Slot& S = rx->slot[rx->next];
-    HIPCHK40(hipStreamSynchronize(S.stream));
+    HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
     const uint32_t mf = max_frames_per_capture;
     const size_t nrows = ncaps * (size_t)mf;
-    std::vector<CapDesc> hc(ncaps);
     for (size_t i = 0; i < ncaps; i++) {
         if (caps[i].offset & 3) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture offset must be a multiple of 4 samples", 0);
         if (caps[i].nsamples % 28) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture length must be a whole number of 28-sample source bursts", 0);
-        hc[i].offset = caps[i].offset; hc[i].nsamples = caps[i].nsamples; hc[i].capture_id = caps[i].capture_id; hc[i].slot_base = 0; hc[i].nslots = 0;
     }
-    S.events.clear(); S.capture_mode = true; S.capture_mf = mf;
-    if (ncaps == 0) return ht40_submit(rx, S, d_iq0, d_iq1, nullptr, 0, nullptr);
     auto grow = [](void** p, size_t* have, size_t need) -> bool { if (*have >= need) return true; if (*p) (void)hipFree(*p); *p = nullptr; *have = 0; if (hipMalloc(p, need) != hipSuccess) return false; *have = need; return true; };
-    if (!grow((void**)&S.d_caps, &S.caps_bytes, sizeof(CapDesc) * ncaps) || !grow((void**)&S.d_scanrows, &S.scanrows_bytes, sizeof(Rx11bRow) * nrows) ||
-        !grow((void**)&S.d_nfr, &S.nfr_bytes, 4 * ncaps) || !grow((void**)&S.d_found, &S.found_bytes, sizeof(Ht40Found) * nrows))
+    if (ncaps && (!grow((void**)&S.d_caps, &S.caps_bytes, sizeof(CapDesc) * ncaps) || !grow((void**)&S.d_scanrows, &S.scanrows_bytes, sizeof(Rx11bRow) * nrows) ||
+                  !grow((void**)&S.d_nfr, &S.nfr_bytes, 4 * ncaps) || !grow((void**)&S.d_found, &S.found_bytes, sizeof(Ht40Found) * nrows)))
         return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_process_captures_dev: device allocation", 0);
-    HIPCHK40(hipMemcpyAsync(S.d_caps, hc.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
+    const size_t o_caps = 64, o_nfr = o_caps + ((sizeof(CapDesc) * ncaps + 63) & ~(size_t)63), o_found = o_nfr + ((4 * ncaps + 63) & ~(size_t)63), need = o_found + sizeof(Ht40Found) * nrows + 64;
+    if (S.pin_bytes < need) {
+        if (S.h_pin) { (void)hipHostFree(S.h_pin); S.h_pin = nullptr; S.pin_bytes = 0; }
+        if (hipHostMalloc(&S.h_pin, need, hipHostMallocDefault) != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_process_captures_dev: page-locked host memory", 0);
+        S.pin_bytes = need;
+    }
+    S.h_plan = reinterpret_cast<uint32_t*>(S.h_pin); S.h_capsup = reinterpret_cast<CapDesc*>((uint8_t*)S.h_pin + o_caps);
+    S.h_nfr = reinterpret_cast<uint32_t*>((uint8_t*)S.h_pin + o_nfr); S.h_found = reinterpret_cast<Ht40Found*>((uint8_t*)S.h_pin + o_found);
+    for (size_t i = 0; i < ncaps; i++) { CapDesc& h = S.h_capsup[i]; h.offset = caps[i].offset; h.nsamples = caps[i].nsamples; h.capture_id = caps[i].capture_id; h.slot_base = 0; h.nslots = 0; }
+    S.h_caps.assign(caps, caps + ncaps);
+    S.events.clear(); S.capture_mode = true; S.capture_mf = mf; S.events_pending = true; S.plan_error = false; S.nframes = 0;
+    S.bound_frames = (uint32_t)std::min<uint64_t>(nrows, rx->max_frames);
+    rx->have_results = true; rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
+    S.ticket = ++rx->seq;
+    S.h_plan[0] = S.h_plan[1] = S.h_plan[2] = S.h_plan[3] = 0;
+    if (ncaps == 0) { S.events_pending = false; return SORA_OK; }
+    HIPCHK40(hipMemcpyAsync(S.d_caps, S.h_capsup, sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
     HIPCHK40(hipMemsetAsync(S.d_nfr, 0, 4 * ncaps, S.stream));
     { const int rc = sora_internal_scan_ht40(reinterpret_cast<const uint32_t*>(d_iq0), reinterpret_cast<const uint32_t*>(d_iq1), S.d_caps, (uint32_t)ncaps, mf, S.d_scanrows, S.d_nfr, S.d_found,
                                              rx->T, rx->sincos, rx->atan, S.stream); if (rc) return rc; }
-    std::vector<uint32_t> nfr(ncaps); std::vector<Ht40Found> found(nrows);
-    HIPCHK40(hipMemcpyAsync(nfr.data(), S.d_nfr, 4 * ncaps, hipMemcpyDeviceToHost, S.stream));
-    HIPCHK40(hipMemcpyAsync(found.data(), S.d_found, sizeof(Ht40Found) * nrows, hipMemcpyDeviceToHost, S.stream));
-    HIPCHK40(hipStreamSynchronize(S.stream));                                      // (the stream just copied hc / found: they may go out of scope)
-    std::vector<sora_ht40_frame> fr;
-    for (size_t c = 0; c < ncaps; c++) {
-        const uint32_t n = std::min(nfr[c], mf);
+    const size_t stride = 2 * (size_t)rx->max_frames;
+    hipLaunchKernelGGL(k_ht40_plan, dim3(1), dim3(1024), 0, S.stream, (const CapDesc*)S.d_caps, (uint32_t)ncaps, mf, (const uint32_t*)S.d_nfr, (const Ht40Found*)S.d_found,
+                       rx->max_frames, (uint64_t)rx->max_soft, kVoutStride, S.d_frames, S.d_jobs, (uint32_t)stride, S.d_njobs, S.d_fjobs, S.d_tmpl, S.d_plan);
+    HIPCHK40(hipMemcpyAsync(S.h_nfr, S.d_nfr, 4 * ncaps, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK40(hipMemcpyAsync(S.h_found, S.d_found, sizeof(Ht40Found) * nrows, hipMemcpyDeviceToHost, S.stream));
+    HIPCHK40(hipMemcpyAsync(S.h_plan, S.d_plan, 16, hipMemcpyDeviceToHost, S.stream));
+    const uint32_t bf = S.bound_frames, bj = 2 * bf;                           // the kernels are launched for the most frames there can be and stop at the planned count
+    Ht40Args A;
+    A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = S.d_frames; A.nframes = bf;
+    A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = nullptr; A.plan = S.d_plan;
+    hipLaunchKernelGGL(k_ht40_frame, dim3((bf + 3) / 4), dim3(256), 0, S.stream, A);
+    if (rx->lanes16)
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((bj + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+    else
+        hipLaunchKernelGGL(k_viterbi11n, dim3((bj / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+    Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = bj; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T; Fi.plan = S.d_plan;
+    hipLaunchKernelGGL(k_ht40_finish, dim3((bj + 3) / 4), dim3(256), 0, S.stream, Fi);
+    HIPCHK40(hipGetLastError());
+    return SORA_OK;
+}
+
+// a raw-capture call whose stream has been waited for: the front end's records (in page-locked memory by now) -> the call's events
+static int ht40_collect_events(Ht40Slot& S)
+{
+    if (!S.events_pending) return S.plan_error ? sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: the captures hold more frames / soft values than the handle was created for (max_frames, max_soft_values)", 0) : SORA_OK;
+    S.events_pending = false;
+    S.plan_error = S.h_plan[3] != 0;
+    S.events.clear();
+    const uint32_t mf = S.capture_mf;
+    uint32_t nf = 0;
+    for (size_t c = 0; c < S.h_caps.size(); c++) {
+        const uint32_t n = std::min(S.h_nfr[c], mf);
         for (uint32_t i = 0; i < n; i++) {
-            const Ht40Found& F = found[c * mf + i];
-            Ht40Event E; E.capture_id = caps[c].capture_id; E.end_sample = F.end_sample; E.error_code = F.error_code; E.mcs = F.mcs; E.length = F.ht_len; E.nsym = F.nsym; E.frame = -1;
-            E.truncated = (i + 1 == mf && nfr[c] > mf);
-            if (F.error_code == 0) {
-                sora_ht40_frame f; memset(&f, 0, sizeof(f));
-                f.offset = caps[c].offset + 2ull * F.a20 + 160;                  // HT-STF is 4 us = 160 samples @40 MHz; HT-LTF 1 follows
-                f.n_bpsc = F.mcs == 8 ? 1u : F.mcs <= 10 ? 2u : F.mcs <= 12 ? 4u : 6u;
-                f.code_rate = (F.mcs == 10 || F.mcs == 12 || F.mcs == 14) ? 2u : F.mcs == 13 ? 1u : 0u;
-                f.length[0] = f.length[1] = F.ht_len;                            // one HT-SIG LENGTH: each stream carries its own PSDU of that length (oracle/py_ht40.py tx_frame)
-                f.cfo = F.cfo / 2;                                               // per 20 MHz sample -> per 40 MHz sample
-                f.noise_var = F.noise_var; f.frame_id = (uint32_t)S.events.size();
-                E.frame = (int)fr.size(); fr.push_back(f);
-            }
+            const Ht40Found& F = S.h_found[c * mf + i];
+            Ht40Event E; E.capture_id = S.h_caps[c].capture_id; E.end_sample = F.end_sample; E.error_code = F.error_code; E.mcs = F.mcs; E.length = F.ht_len; E.nsym = F.nsym; E.frame = -1;
+            E.truncated = (i + 1 == mf && S.h_nfr[c] > mf);
+            if (F.error_code == 0) E.frame = (int)nf++;                            // (the order k_ht40_plan numbers the frames in)
             S.events.push_back(E);
         }
     }
-    return ht40_submit(rx, S, d_iq0, d_iq1, fr.data(), fr.size(), nullptr);
+    S.nframes = S.h_plan[0];
+    if (S.plan_error || nf != S.h_plan[1]) { S.plan_error = true; S.nframes = 0; return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: the captures hold more frames / soft values than the handle was created for (max_frames, max_soft_values)", 0); }
+    return SORA_OK;
 }
 
 static int ht40_slot_results(sora_ht40_t* rx, Ht40Slot& S, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
@@ -483,6 +616,7 @@ static int ht40_slot_results(sora_ht40_t* rx, Ht40Slot& S, sora_frame_result* ou
     if (S.capture_mode) {                                                        // rows per event of the front end, in (capture, time) order
         HIPCHK40(hipSetDevice(rx->device));
         HIPCHK40(hipStreamSynchronize(S.stream));
+        { const int rc = ht40_collect_events(S); if (rc) return rc; }
         const size_t nj = 2 * (size_t)S.nframes;
         std::vector<Rx11bRow> rows(nj);
         if (nj) HIPCHK40(hipMemcpy(rows.data(), S.d_rows, sizeof(Rx11bRow) * nj, hipMemcpyDeviceToHost));
@@ -558,7 +692,7 @@ int sora_ht40_wait(sora_ht40_t* rx, int ticket)
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
     HIPCHK40(hipSetDevice(rx->device));
     HIPCHK40(hipStreamSynchronize(S->stream));
-    return SORA_OK;
+    return S->capture_mode ? ht40_collect_events(*S) : SORA_OK;                  // (a raw-capture call that outgrew the handle's capacity says so here)
 }
 void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket) { Ht40Slot* S = ht40_slot_of(rx, ticket); return S ? (void*)S->stream : nullptr; }
 int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
@@ -566,16 +700,15 @@ int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_ro
     Ht40Slot* S = ht40_slot_of(rx, ticket);
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
     HIPCHK40(hipSetDevice(rx->device));
+    if (S->capture_mode)                                                        // raw captures: template rows and frame count were written by k_ht40_plan; the host knows only the bound
+        return sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, nullptr, S->bound_frames, 2, S->d_mpdu, S->stream,
+                                           h_rows, max_rows, h_counts, h_mpdu, mpdu_cap, S->d_tmpl, S->d_plan);
     S->h_tmpl.resize(2 * (size_t)S->nframes);
     for (size_t j = 0; j < S->h_tmpl.size(); j++) {                             // (the same fields sora_ht40_results fills in on the host)
         sora_frame_result& o = S->h_tmpl[j]; const sora_ht40_frame& f = S->h_frames[j / 2];
         memset(&o, 0, sizeof(o));
         o.capture_id = f.frame_id; o.start_sample = (uint32_t)(j & 1); o.rate_kbps = f.n_bpsc * 10 + f.code_rate;
         o.nsym = (uint16_t)sora_ht40_symbols(f.length[0], f.length[1], f.n_bpsc, f.code_rate);
-        if (S->capture_mode) {                                                  // (raw captures: the decoded frames' rows as sora_ht40_results reports them; failed headers have no MPDU and are not delivered)
-            const Ht40Event& E = S->events[f.frame_id];
-            o.capture_id = E.capture_id; o.end_sample = E.end_sample; o.rate_kbps = E.mcs;
-        }
     }
     // two rows per frame, always: "captures" = frames, max_frames_per_capture = 2, no per-capture counts.  (The template is read by an
     // asynchronous copy: it lives in the slot until the slot's next call.)

@@ -120,7 +120,8 @@ struct DenseStage {                  // per slot / pipeline (grow-only device st
 void sora_internal_dense_free(DenseStage* D);
 int sora_internal_dense_deliver(DenseStage* D, const sora::Rx11bRow* d_rows, const uint32_t* d_nframes, const sora::CapDesc* d_caps, const sora_frame_result* h_tmpl,
                                 uint32_t ncaps, uint32_t mf, const uint8_t* d_slots, hipStream_t st,
-                                sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap);
+                                sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap,
+                                const sora_frame_result* d_tmpl = nullptr, const uint32_t* d_ncaps = nullptr);   // (a template already on the device; the real number of "captures" where the host only knows a bound)
 
 // sora_hip.cpp: records the message sora_hip_last_error() returns; hip_error = 0 for none
 int sora_internal_fail(int code, const char* what, int hip_error);
