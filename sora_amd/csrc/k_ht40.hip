@@ -373,6 +373,7 @@ struct Ht40Slot {
     bool capture_mode = false; uint32_t capture_mf = 0; std::vector<Ht40Event> events;
     // ... planned on the device (k_ht40_plan): the records come back asynchronously into page-locked memory and are turned into `events` when the call is collected
     uint32_t* d_plan = nullptr; sora_frame_result* d_tmpl = nullptr;
+    void* h_stage = nullptr;                                                    // descriptor calls: page-locked staging of {frames, job lists, finish jobs, counts} for asynchronous uploads
     void* h_pin = nullptr; size_t pin_bytes = 0;                                // {plan[4], CapDesc[ncaps] (upload), nfr[ncaps], Ht40Found[ncaps * mf]}
     uint32_t* h_plan = nullptr; CapDesc* h_capsup = nullptr; uint32_t* h_nfr = nullptr; Ht40Found* h_found = nullptr;
     std::vector<sora_capture_desc> h_caps; bool events_pending = false; uint32_t bound_frames = 0; bool plan_error = false;
@@ -398,7 +399,7 @@ static void ht40_free(sora_ht40_t* rx)
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
         sora_internal_dense_free(&S.dense);
         (void)hipFree(S.d_caps); (void)hipFree(S.d_scanrows); (void)hipFree(S.d_nfr); (void)hipFree(S.d_found);
-        (void)hipFree(S.d_plan); (void)hipFree(S.d_tmpl); if (S.h_pin) (void)hipHostFree(S.h_pin);
+        (void)hipFree(S.d_plan); (void)hipFree(S.d_tmpl); if (S.h_pin) (void)hipHostFree(S.h_pin); if (S.h_stage) (void)hipHostFree(S.h_stage);
     }
     delete rx;
 }
@@ -435,6 +436,7 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, nj * 4096);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * nj);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_plan, 16);
+        if (e == hipSuccess) e = hipHostMalloc(&S.h_stage, sizeof(Ht40Frame) * max_frames + 3 * sizeof(VitJob) * nj + sizeof(Ht40Job) * nj + 64, hipHostMallocDefault);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_tmpl, sizeof(sora_frame_result) * nj);
         if (e == hipSuccess) e = hipMemset(S.d_soft, 0, max_soft_values * 2 + 4096 + 1024);
         if (e == hipSuccess) e = hipMemset(S.d_vout, 0, nj * kVoutStride + 256);
@@ -467,7 +469,11 @@ int sora_ht40_synchronize(sora_ht40_t* rx)
 static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
 {
     if (nframes > rx->max_frames) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more frames than max_frames", 0);
-    std::vector<Ht40Frame> hf(nframes); std::vector<VitJob> hj(3 * 2 * (size_t)rx->max_frames); std::vector<Ht40Job> fj(2 * nframes);
+    // (the tables are built in the slot's page-locked staging area -- the slot's previous call has finished -- and uploaded asynchronously)
+    Ht40Frame* hf = reinterpret_cast<Ht40Frame*>(S.h_stage);
+    VitJob* hj = reinterpret_cast<VitJob*>(hf + rx->max_frames);
+    Ht40Job* fj = reinterpret_cast<Ht40Job*>(hj + 3 * 2 * (size_t)rx->max_frames);
+    uint32_t* nj_stage = reinterpret_cast<uint32_t*>(fj + 2 * (size_t)rx->max_frames);
     uint32_t nj[4] = { 0, 0, 0, 0 };
     uint64_t soft = 0;
     const size_t stride = 2 * (size_t)rx->max_frames;
@@ -492,11 +498,12 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
     rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
     S.ticket = ++rx->seq;
     if (nframes == 0) return SORA_OK;
-    HIPCHK40(hipMemcpy(S.d_frames, hf.data(), sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice));
+    for (int r = 0; r < 4; r++) nj_stage[r] = nj[r];
+    HIPCHK40(hipMemcpyAsync(S.d_frames, hf, sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice, S.stream));
     for (int r = 0; r < 3; r++)                                                   // (only the filled part of each code-rate list)
-        if (nj[r]) HIPCHK40(hipMemcpy(S.d_jobs + r * stride, hj.data() + r * stride, sizeof(VitJob) * nj[r], hipMemcpyHostToDevice));
-    HIPCHK40(hipMemcpy(S.d_njobs, nj, 16, hipMemcpyHostToDevice));
-    HIPCHK40(hipMemcpy(S.d_fjobs, fj.data(), sizeof(Ht40Job) * fj.size(), hipMemcpyHostToDevice));
+        if (nj[r]) HIPCHK40(hipMemcpyAsync(S.d_jobs + r * stride, hj + r * stride, sizeof(VitJob) * nj[r], hipMemcpyHostToDevice, S.stream));
+    HIPCHK40(hipMemcpyAsync(S.d_njobs, nj_stage, 16, hipMemcpyHostToDevice, S.stream));
+    HIPCHK40(hipMemcpyAsync(S.d_fjobs, fj, sizeof(Ht40Job) * 2 * nframes, hipMemcpyHostToDevice, S.stream));
     Ht40Args A;
     A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = S.d_frames; A.nframes = (uint32_t)nframes;
     A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = reinterpret_cast<uint32_t*>(d_weights); A.plan = nullptr;
