@@ -714,11 +714,26 @@ __device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* fo
             int det = -1;
             const unsigned long long lmask = lim >= 64 ? ~0ull : ((1ull << lim) - 1);
             if (!pf && (bA & lmask) == 0) {
-                for (int i = 3; i < lim; i += 4) {
-                    sense += 4;
-                    if (sense >= 84) timeout = true;
-                    const uint32_t s4 = base + (uint32_t)i - 3;
-                    if (timeout && (s4 + 3) / 14 != (s4 + 7) / 14) { timeout = false; sense = 0; }
+                // idle block: per 4-sample burst j  sense += 4; sense >= 84 raises the time-out; a raised time-out is cleared, with the counter, by
+                // the first burst that ends a 14-sample source call.  In closed form over the block's bursts (sense needs 21 bursts to reach 84:
+                // at most one time-out is raised inside a block): lane j says whether burst j ends a source call, two find-first-bits do the rest.
+                const int nbst = lim >> 2;
+                const uint32_t X = (uint32_t)__ballot(((base + 4u * (uint32_t)lane + 3u) % 14u) >= 10u) & (nbst >= 32 ? 0xFFFFFFFFu : ((1u << nbst) - 1u));
+                int j = 0;
+                bool counted = false;
+                if (timeout) {
+                    if (X == 0u) { sense += 4 * nbst; counted = true; }
+                    else { j = __builtin_ctz(X) + 1; sense = 0; timeout = false; }
+                }
+                if (!counted) {
+                    const int r = nbst - j, k = max((84 - sense + 3) >> 2, 1);          // bursts left in the block; bursts until the counter reaches 84
+                    if (k > r) sense += 4 * r;
+                    else {
+                        const int jt = j + k - 1;                                       // the burst that raises the time-out (it may clear it itself)
+                        const uint32_t m = jt >= 32 ? 0u : (X >> jt) << jt;
+                        if (m == 0u) { sense += 4 * r; timeout = true; }
+                        else { sense = 4 * (nbst - 1 - __builtin_ctz(m)); timeout = false; }
+                    }
                 }
                 pc = 0;
             } else if (pf && !timeout && (bB & lmask) == 0 && pc + lim <= 160) {
