@@ -450,6 +450,10 @@ int  sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out
  * per call).  The INPUT buffer of a call must stay untouched until sora_rx11b_wait(its ticket) (or _results_of, or _synchronize) has returned. */
 int   sora_rx11b_ticket(sora_rx11b_t* rx);                     /* ticket of the most recent process call (0: none) */
 int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls the handle keeps addressable */
+/* The graph runs as two kernels: the Barker-rate instantiation decodes every capture and hands those whose PLCP header announces 5.5 / 11 Mbps to the
+ * CCK-capable one, which redoes them from their first sample.  enable = 1: every capture goes straight through the CCK-capable instantiation (all
+ * four rates, identical rows) -- the better choice when most frames are CCK; 0 (default): two passes; negative: query.  Returns the previous setting. */
+int   sora_rx11b_set_single_pass(sora_rx11b_t* rx, int enable);
 int   sora_rx11b_wait(sora_rx11b_t* rx, int ticket);
 void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket);
 int   sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);

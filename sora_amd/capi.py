@@ -54,7 +54,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
            "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_wait", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_set_single_pass", "sora_rx11b_wait", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
            "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_results_of",
            "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_process_captures_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_stream_of", "sora_ht40_results_of",
@@ -183,6 +183,7 @@ def load(build_if_missing=True):
     L.sora_rx11n_results.argtypes = [ctypes.c_void_p, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                      ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx11b_create.argtypes = [ctypes.POINTER(RxCfg), ctypes.POINTER(ctypes.c_void_p)]
+    L.sora_rx11b_set_single_pass.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx11b_destroy.argtypes = [ctypes.c_void_p]; L.sora_rx11b_destroy.restype = None
     L.sora_rx11b_stream.argtypes = [ctypes.c_void_p]; L.sora_rx11b_stream.restype = ctypes.c_void_p
     L.sora_rx11b_synchronize.argtypes = [ctypes.c_void_p]
@@ -475,6 +476,10 @@ class Rx11b:
 
     def calls_in_flight(self):
         return int(self._L.sora_rx11b_calls_in_flight(self._h))
+
+    def set_single_pass(self, enable=-1):
+        """1: every capture straight through the CCK-capable kernel (mostly-CCK traffic); 0: two passes (default); returns the previous setting"""
+        return int(self._L.sora_rx11b_set_single_pass(self._h, int(enable)))
 
     def wait(self, ticket):
         _check(self._L.sora_rx11b_wait(self._h, int(ticket)))

@@ -945,6 +945,7 @@ struct sora_rx11b {
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
     bool have_results = false;
+    bool single_pass = false;       // sora_rx11b_set_single_pass: every capture straight through the CCK-capable instantiation
 };
 
 #define HIPCHK11(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -1030,8 +1031,9 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
 #else
     constexpr bool one_kernel = false;
 #endif
-    HIPCHK11(hipMemsetAsync(S.d_needs_cck, one_kernel ? 1 : 0, 4 * ncaps, S.stream));
-    if (!one_kernel) hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);
+    const bool single = one_kernel || rx->single_pass;
+    HIPCHK11(hipMemsetAsync(S.d_needs_cck, single ? 1 : 0, 4 * ncaps, S.stream));
+    if (!single) hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);
     hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)
     HIPCHK11(hipGetLastError());
     return SORA_OK;
@@ -1109,6 +1111,16 @@ static Slot11b* slot11b_of(sora_rx11b_t* rx, int ticket)
 static const char* const kStale11b = "stale ticket: its slot has been reused by a later process call (or the ticket was never issued)";
 int sora_rx11b_ticket(sora_rx11b_t* rx) { return rx && rx->have_results ? rx->slot[rx->last].ticket : 0; }
 int sora_rx11b_calls_in_flight(sora_rx11b_t* rx) { (void)rx; return kSlots11b; }
+// Two passes (default): k_rx11b (90 VGPRs, the Barker rates) decodes every capture and hands the ones whose PLCP header announces 5.5 / 11 Mbps
+// to k_rx11b_cck (128 VGPRs), which redoes them from their first sample.  A host that expects mostly CCK traffic skips the first pass:
+// every capture goes straight through the CCK-capable instantiation (it decodes all four rates; identical rows).  Returns the previous setting.
+int sora_rx11b_set_single_pass(sora_rx11b_t* rx, int enable)
+{
+    if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_set_single_pass: null handle", 0);
+    const int old = rx->single_pass ? 1 : 0;
+    if (enable >= 0) rx->single_pass = enable != 0;
+    return old;
+}
 int sora_rx11b_wait(sora_rx11b_t* rx, int ticket)
 {
     Slot11b* S = slot11b_of(rx, ticket);

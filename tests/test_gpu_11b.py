@@ -19,13 +19,15 @@ def sora():
     return sora_amd
 
 
-def run_11b(sora, caps, max_frames=16):
+def run_11b(sora, caps, max_frames=16, single_pass=False):
     import torch
     parts, descs, pos = [], [], 0
     for i, c in enumerate(caps):
         descs.append((pos, len(c), i)); parts.append(c); pos += len(c)
     iq = np.concatenate(parts) if parts else np.zeros((0, 2), np.int16)
     rx = sora.Rx11b(max(1, len(caps)), max(28, len(iq)), max_frames_per_capture=max_frames)
+    if single_pass:
+        assert rx.set_single_pass(1) == 0 and rx.set_single_pass(-1) == 1
     rx.process_dev(torch.from_numpy(iq).cuda(), descs)
     res = rx.results(); rx.close()
     return res
@@ -112,6 +114,8 @@ def test_gpu_11b_long_frames_of_every_rate(sora, oracle):
         x = x[:len(x) // 28 * 28] + rng.uniform(-400, 400, size=(1, 2)) + rng.normal(0, 60, (len(x) // 28 * 28, 2))
         caps.append(np.clip(np.rint(x), -32768, 32767).astype(np.int16))
     got = run_11b(sora, caps, max_frames=16)
+    # sora_rx11b_set_single_pass: every capture straight through the CCK-capable kernel instead of two passes -- the same rows, MPDUs included
+    assert run_11b(sora, caps, max_frames=16, single_pass=True) == got
     nok = 0
     for i, c in enumerate(caps):
         rows = [r for r in got if r["capture_id"] == i]
