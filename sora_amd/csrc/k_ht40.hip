@@ -92,6 +92,7 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
     for (int k = lane; k < ncb; k += 64) { W.dtab[0][k] = (uint16_t)deint40_index(nb, 0, k); W.dtab[1][k] = (uint16_t)deint40_index(nb, 1, k); }
     int theta = 0;
     auto nosync = []() __attribute__((always_inline)) { wsync40(); };
+    const Fft128TwPk twpk = fft128_twiddles_pk(A.T, lane & 31);
     // one 160-sample symbol starting at sample `pos` of the frame: TFreqComp_11n, cyclic prefix dropped, FFT<128> per chain (32 lanes each) -> W.y[slot]
     auto symbol_fft = [&](uint32_t pos, int slot) __attribute__((always_inline)) {
 #pragma unroll
@@ -105,12 +106,12 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
             }
         }
         wsync40();
-        const int r = lane >> 5, e = lane & 31; cpx x[4], yy[4];
+        const int r = lane >> 5, e = lane & 31; pcx x[4];
 #pragma unroll
-        for (int m = 0; m < 4; m++) x[m] = unpack(W.buf[r][e + 32 * m]);
-        fft128_group<false>(x, yy, W.fft[r], e, A.T, nosync);
+        for (int m = 0; m < 4; m++) x[m] = W.buf[r][e + 32 * m];
+        fft128_core_pk(x, W.fft[r], e, twpk, nosync);                            // the packed-arithmetic FFT<128> of k_fft128_batch (dev_arith.h): point j at slot bitrev7(j)
 #pragma unroll
-        for (int q = 0; q < 4; q++) W.y[slot][r][e + 32 * q] = pack(yy[q]);
+        for (int q = 0; q < 4; q++) W.y[slot][r][e + 32 * q] = W.fft[r][__brev((unsigned)(e + 32 * q)) >> 25];
         wsync40();
     };
     symbol_fft(0, 0);
