@@ -31,7 +31,22 @@ import time
 # default only three of the handle's pipelines run side by side whatever sora_rx_set_depth says (profiles/r03_e_timeline_*.txt);
 # eight calls in flight want at least twelve (profiles/r03_y_depth_and_queues.txt).
 # An application setting, made before the runtime starts; the library itself reads no environment variable.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+def _early_hw_queues(argv):
+    """--hw-queues N, read before the HIP runtime starts: N > 0 sets GPU_MAX_HW_QUEUES (unless the environment already does),
+    0 leaves the runtime's default alone (`config.hw_queues` is then null)."""
+    for i, a in enumerate(argv):
+        if a == "--hw-queues" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--hw-queues="):
+            return int(a.split("=", 1)[1])
+    return None
+
+
+_HWQ = _early_hw_queues(sys.argv)
+if _HWQ is None:
+    _HWQ = 16
+if _HWQ > 0:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", str(_HWQ))
 
 import numpy as np
 
@@ -695,6 +710,7 @@ def main():
     ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
+    ap.add_argument("--hw-queues", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (read before HIP starts); 0 = leave the runtime default")
     ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11b_cck, rx11n, rx11n_40) and print its object: for profiling that section alone")
     args = ap.parse_args()
 
@@ -853,37 +869,6 @@ def main():
     ktimes = {(tname[lanes] if k == "k_viterbi" else k): v for k, v in ktimes.items()}
     rx.set_trellis(trellis_setting); rx.set_depth(depth)
 
-    # ---- the other implementation of the data field: k_decode (symbol and trellis waves in one kernel, soft values in LDS)
-    fused = None
-    if world == 1 and not args.no_extras:
-        fused = {}
-        rx.flush(); rx.set_fused(1)
-        for dname, dval in (("one_call_in_flight", 1), ("calls_in_flight_%d" % depth, depth)):
-            rx.set_depth(dval); rx.flush()
-            run_block(args.warmup, deliver, dval); rx.flush()
-            chk.drain(); bad_before = chk.bad
-            tf0 = time.perf_counter()
-            nblk = max(1, repeats // 4)
-            for _ in range(nblk):
-                run_block(args.steps, deliver, dval)
-            rx.flush(); chk.drain()
-            tf1 = time.perf_counter()
-            fused[dname] = {"ms_per_step": round((tf1 - tf0) / (nblk * args.steps) * 1e3, 4), "steps": nblk * args.steps,
-                            "calls_with_wrong_rows": chk.bad - bad_before}
-        rx.set_depth(1); rx.flush(); rx.set_profiling(True)
-        for _ in range(max(10, args.steps // 2)):
-            rx.process_dev(d_iq, descs)
-        rx.flush()
-        fused["kernel_ms_one_call_in_flight"] = {k: round(v, 4) for k, v in rx.kernel_times().items()}
-        rx.set_profiling(False)
-        tk = rx.process_dev(d_iq, descs)
-        fres = rx.results(ticket=tk)
-        okf, whyf = check_against_reference(fres, kind, want, idx)
-        fused["parity"] = {"against": kind, "captures_checked": len(idx), "ok": okf}
-        if not okf:
-            print("PARITY MISMATCH (fused path) vs %s: %s" % (kind, whyf), file=sys.stderr)
-        rx.set_fused(0); rx.set_depth(depth); rx.flush()
-
     elapsed = t1 - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -942,9 +927,6 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
-        if fused is not None:
-            fused["note"] = "sora_rx_set_fused(1): the same workload and timed-region protocol with the data field decoded by k_decode"
-            out["fused_decode"] = fused
         if world == 1 and not args.no_extras:
             out["stages"] = bench_stages(torch, sora_amd, dev)
             out["ingest"] = bench_ingest(torch, sora_amd, dev)

@@ -104,6 +104,13 @@ void* sora_rx_stream(sora_rx_t* rx);
 int  sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* h_caps, size_t ncaps);
 /* Same with a host buffer (copied to HBM first; the PCIe time is then part of the call). */
 int  sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* h_caps, size_t ncaps);
+/* LoadSoraDumpFile -> graph -> MPDU buffer as ONE stream-ordered path (brickutil.h:20-58 in front of fb11a_demod.cpp:88-120): the raw dump
+ * bytes in host memory (page-locked for a copy that overlaps the other calls in flight: sora_hip_host_alloc) go up to the call's
+ * pipeline, sora_hip_ingest (flags SORA_INGEST_*: RX_BLOCK de-framing, 14 -> 16 bit, 44 -> 40 MHz, TDownSample2) runs on the device and
+ * the receive chain decodes the result; no host wait anywhere.  The capture descriptors address the INGESTED sample stream (its length is
+ * sora_hip_ingest_count(dump_bytes, flags), at the handle's sample_rate_mhz).  The host buffer must stay untouched until the call has
+ * completed (sora_rx_wait).  Ticket, results and delivery as for sora_rx_process_dev. */
+int  sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, unsigned ingest_flags, const sora_capture_desc* h_caps, size_t ncaps);
 /* TBB11aFrameSink's frame buffer + CF_Error per frame: copies results of the last process call to the host.
  * h_mpdu may be NULL (descriptors only).  *nout = rows written. Frames appear in (capture, time) order. */
 int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
@@ -161,14 +168,13 @@ int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process c
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);
 
-/* Two implementations of the data field (T11aDataSymbol .. T11aViterbi) with identical results:
- *   0 (default)  k_frame (symbol chain, soft values to HBM packed three bits each) then k_viterbi16 / k_viterbi (sora_rx_set_trellis);
- *   1            k_decode: both in one kernel, symbol waves feeding trellis waves through a ring in LDS the way the
- *                reference's RxThread feeds its ViterbiThread through TThreadSeparator (stdbrick.hpp:89-248).  Since round 3
- *                the split form is the faster one at any depth and moves little more HBM (its soft stream is 25 MB per 4096
- *                frames); the fused kernel remains as an independent second implementation.
- * Returns the previous value; enable < 0 only queries.
- * sora_rx_kernel_name_fused(i) names the kernels of the fused chain for sora_rx_kernel_times ("" = slot not used). */
+/* The data field (T11aDataSymbol .. T11aViterbi) is decoded by k_frame (symbol chain, soft values to HBM packed three bits each)
+ * followed by k_viterbi16 / k_viterbi (sora_rx_set_trellis).  Rounds 2-3 also shipped k_decode -- both in one kernel, symbol waves
+ * feeding trellis waves through a ring in LDS the way the reference's RxThread feeds its ViterbiThread through TThreadSeparator
+ * (stdbrick.hpp:89-248) -- which lost to the split form at every depth (0.80 against 0.46 ms per step, BENCH_r03) and is a BUILD
+ * VARIANT since round 4 (sora_amd.build.build_variant("fused", ["SORA_WITH_K_DECODE"])): in the default library
+ * sora_rx_set_fused(rx, 1) returns SORA_E_NOT_SUPPORTED and changes nothing; enable = 0 and the query (enable < 0) still work and
+ * return the previous value.  sora_rx_kernel_name_fused(i) names the kernels of the fused chain ("" = slot not used). */
 int  sora_rx_set_fused(sora_rx_t* rx, int enable);
 const char* sora_rx_kernel_name_fused(size_t index);
 
@@ -210,7 +216,8 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
                         size_t n, void* stream);
 /* The same brick for a caller that streams bursts through it (a BRICK adapter calls once per burst): no allocation, no host
  * wait, everything in stream order.  soft_span_bytes = the extent of the caller's soft buffer that the n jobs address
- * (max over i of soft_off[i] + nsoft[i]; the jobs' ranges must not overlap); d_workspace = 16-byte aligned device memory of
+ * (max over i of soft_off[i] + nsoft[i]; the jobs' ranges must not overlap -- any offsets, any order, any nsoft >= 24: a
+ * job with less than one OFDM symbol of soft values is not a frame); d_workspace = 16-byte aligned device memory of
  * at least sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n), owned by the caller and free for reuse once the call's
  * work on `stream` has completed.  (sora_hip_viterbi11a is this entry point over a grow-only workspace the library caches
  * per device; it reads the extent back from the device and waits for the stream before it returns.) */

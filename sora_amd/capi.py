@@ -5,6 +5,7 @@ The wrapper mirrors the reference harness: `Rx.process(...)` = RxThread over a b
 `Rx.results()` = the frames TBB11aFrameSink reported.  Nothing here falls back to a CPU implementation:
 if the library or a GPU is missing, calls raise.
 """
+import collections
 import ctypes
 import os
 
@@ -50,7 +51,7 @@ class Ht40Frame(ctypes.Structure):
 
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
-           "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process", "sora_rx_results",
+           "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process_dump", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
            "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
@@ -116,6 +117,7 @@ def load(build_if_missing=True):
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
     L.sora_rx_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_process_dump.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx_set_fused.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_set_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -296,6 +298,20 @@ class Rx:
         _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), ptr, len(arr)))
         return self._L.sora_rx_ticket(self._h)
 
+    def process_dump(self, h_dump, flags, captures):
+        """h_dump: the raw dump bytes in host memory -- a numpy uint8 array or a (pinned) torch CPU uint8 tensor, untouched until the call has
+        completed; flags: INGEST_*; captures address the ingested stream.  Copy, ingest and the receive chain run on the call's own stream."""
+        arr, ptr = self._caps(captures)
+        if hasattr(h_dump, "data_ptr"):
+            addr, nbytes = h_dump.data_ptr(), h_dump.numel() * h_dump.element_size()
+        else:
+            a = np.ascontiguousarray(h_dump).view(np.uint8).reshape(-1); addr, nbytes = a.ctypes.data, a.size; h_dump = a
+        if self._keep is None:
+            self._keep = collections.deque(maxlen=17)
+        self._keep.append(h_dump)
+        _check(self._L.sora_rx_process_dump(self._h, ctypes.c_void_p(addr), nbytes, int(flags), ptr, len(arr)))
+        return self._L.sora_rx_ticket(self._h)
+
     def ticket(self):
         """ticket of the most recent process call (0: none)"""
         return self._L.sora_rx_ticket(self._h)
@@ -352,8 +368,12 @@ class Rx:
         return int(self._L.sora_rx_set_graph(self._h, int(enable)))
 
     def set_fused(self, enable=-1):
-        """1: decode the data field with the fused kernel (k_decode), 0: k_frame + k_viterbi; returns the previous setting"""
-        return int(self._L.sora_rx_set_fused(self._h, int(enable)))
+        """1: decode the data field with the fused kernel (k_decode -- a build variant since round 4: SoraError SORA_E_NOT_SUPPORTED in the
+        default library), 0: k_frame + k_viterbi; returns the previous setting"""
+        r = int(self._L.sora_rx_set_fused(self._h, int(enable)))
+        if r not in (0, 1):
+            raise SoraError(r, (self._L.sora_hip_last_error() or b"").decode())
+        return r
 
     def kernel_times(self):
         """{kernel name: ms} of the profiled process calls (HIP events on the handle's streams)."""

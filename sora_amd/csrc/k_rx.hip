@@ -480,18 +480,23 @@ __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uin
 
 // sora_hip_viterbi11a takes the reference's soft format (one byte per soft value, 3 significant bits); the trellis kernels read packed
 // streams out of buffers that have slack behind them (their 16-bit fetches reach one byte past a stream's end).  Block j packs job j's
-// values (a multiple of 8: the port burst is 48) into the workspace at byte 3 ceil(off8[j] / 8) -- disjoint because the caller's ranges
-// are -- and writes its job record.
+// values into the workspace at byte ceil(off8[j] / 2) -- FOUR bits of room per value of the caller's range for three bits of stream, so
+// that the streams of jobs whose ranges are disjoint stay disjoint for ANY offsets and ANY nsoft >= 11, in any job order: the stream
+// of n values takes ceil(3 n / 8) bytes (the last, partial group of eight is written byte by byte, not padded to three bytes), and
+// ceil(off / 2) + ceil(3 n / 8) <= floor((off + n) / 2) from n = 11 on.  (Round 3 placed a job at byte 3 ceil(off / 8) and padded its last
+// group: disjoint only for nsoft % 8 == 0.)
 __global__ void __launch_bounds__(256) k_soft_pack3(const uint8_t* soft8, const uint32_t* off8, const uint32_t* nsoft, const uint16_t* flen, const uint32_t* out_off,
                                                     int code_rate, uint8_t* packed, VitJob* jobs)
 {
-    const uint32_t j = blockIdx.x, mine = nsoft[j], at = (off8[j] + 7u) / 8u * 3u;
+    const uint32_t j = blockIdx.x, mine = nsoft[j], at = (off8[j] + 1u) / 2u;
     const uint8_t* in = soft8 + off8[j];
     for (uint32_t g = threadIdx.x; g < (mine + 7u) / 8u; g += blockDim.x) {
         uint32_t v[8];
 #pragma unroll
         for (int k = 0; k < 8; k++) v[k] = 8u * g + k < mine ? in[8u * g + k] & 7u : 0u;
-        soft3_store8(packed + at, g, soft3_pack8(v));
+        const uint32_t bits24 = soft3_pack8(v), left = mine - 8u * g;
+        if (left >= 8u) soft3_store8(packed + at, g, bits24);
+        else for (uint32_t b = 0; b < (3u * left + 7u) / 8u; b++) packed[at + 3u * g + b] = (uint8_t)(bits24 >> (8u * b));
     }
     if (threadIdx.x == 0) {
         VitJob J; J.soft_off = at; J.nsoft = mine; J.length = flen[j]; J.dec_off = 0; J.out_off = out_off[j];

@@ -52,7 +52,11 @@ template <int WIN, int LOOK> struct Geom16 {
 };
 
 template <int WIN, int LOOK> struct Lds16 {
+#ifdef SORA_EXP_NORING                                                           // experiment (tools/r04_exp_noring.sh): no survivor ring, no trace-back -- results are wrong, only the duration means something
+    uint16_t ring[1][4][64];
+#else
     uint16_t ring[Geom16<WIN, LOOK>::P][4][64];                                 // [block % P][row][rev6(state)] {frame A's byte, frame B's byte}: 18944 / 15872 B
+#endif
     union {
         uint32_t udump[4][64];                                                  // the metrics registers at a trace-back (the start state's unfinished block)
         uint16_t ops[4][24][2];                                                 // [row][operand of the chunk][frame]: the soft values as metric fields -- live only inside
@@ -258,7 +262,9 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     auto pos_of = [&](uint32_t p, int jb) -> uint32_t { const uint32_t q = p + (uint32_t)jb; return q >= (uint32_t)P ? q - (uint32_t)P : q; };
 
     auto trace = [&](uint32_t my_cnt, int t24_last) {
+#ifndef SORA_EXP_NORING
         trace16<WIN, LOOK>((unsigned)(uintptr_t)&S, V.U[0], V.U[1], V.U[2], V.U[3], tr, ob, pos_of(pos, t24_last / 8), (uint32_t)(t24_last % 8), my_cnt, my_out);
+#endif
     };
     auto next_event = [&]() -> uint32_t {
         const uint32_t mine = my_done ? 0xFFFFFFFFu : my_tr_end;
@@ -313,7 +319,11 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     unsigned pos512[3];
     auto set_row_pos = [&]() {
 #pragma unroll
+#ifdef SORA_EXP_NORING
+        for (int jb = 0; jb < 3; jb++) pos512[jb] = 0u;
+#else
         for (int jb = 0; jb < 3; jb++) pos512[jb] = pos_of(pos, jb) * 512u;
+#endif
     };
     auto end_row = [&]() { pos = pos_of(pos, 3); set_row_pos(); };
     set_row_pos();
@@ -402,7 +412,12 @@ __device__ __forceinline__ void viterbi16_body(const VitJob* __restrict__ jobs, 
 
 }  // namespace
 
-__global__ void __launch_bounds__(64) k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+#ifdef SORA_EXP_LB
+#define SORA_VIT16_BOUNDS __launch_bounds__(64, SORA_EXP_LB)
+#else
+#define SORA_VIT16_BOUNDS __launch_bounds__(64)
+#endif
+__global__ void SORA_VIT16_BOUNDS k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi16_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out); }
 __global__ void __launch_bounds__(64) k_viterbi16_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi16_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }

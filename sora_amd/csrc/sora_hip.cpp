@@ -273,6 +273,7 @@ struct RxPipe {
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip)
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
+    uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
     sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
     // last call.  Descriptors go up through a pinned staging buffer (a pageable source would make the "async" copy wait for
     // the stream to drain and expose every launch latency of the call) and only when they differ from the resident set.
@@ -312,7 +313,7 @@ static void rx_free(RxPipe* rx)
 {
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes,
-                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist };
+                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -467,12 +468,15 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
         R.frames = rx->d_frames; R.fctx = rx->d_fctx;
         R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
+#ifdef SORA_WITH_K_DECODE
         if (rx->fused) {
             // the data field of every frame, samples -> decoded bytes, in one kernel: two frames per trellis wave, two pairs per
             // workgroup (at most ceil(n / 2) + 2 pairs over the three code-rate lists; surplus workgroups return at once)
             hipLaunchKernelGGL(k_decode, dim3(((nrows + 1) / 2 + 2 + 1) / 2), dim3(256), 0, st, R);
             mark(); mark();
-        } else {
+        } else
+#endif
+        {
             R.soft = rx->d_soft; R.jobs = rx->d_jobs;
             hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
@@ -526,6 +530,36 @@ static int pipe_process(RxPipe* rx, const sora_complex16* h_iq, size_t total_sam
     }
     HIPCHK(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * total_samples, hipMemcpyHostToDevice, rx->stream));
     return pipe_process_dev(rx, rx->d_iq_own, caps, ncaps, total_samples);
+}
+
+// LoadSoraDumpFile -> graph as ONE stream-ordered path (brickutil.h:20-58 in front of fb11a_demod.cpp:88-120): the dump bytes go up from
+// (preferably page-locked) host memory, sora_hip_ingest de-frames / sign-fixes / resamples / decimates them on the device, and the receive
+// chain runs on the result -- all on this pipeline's stream, no host wait.  The capture descriptors address the INGESTED stream.
+static int pipe_process_dump(RxPipe* rx, const void* h_dump, size_t dump_bytes, unsigned flags, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx || !h_dump || dump_bytes == 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dump: null argument");
+    if ((flags & ~15u) || (dump_bytes & 3)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dump: unknown ingest flag, or a dump that is not a whole number of 4-byte samples");
+    const size_t n = sora_hip_ingest_count(dump_bytes, flags);
+    if (n > rx->cfg.max_total_samples) return fail(SORA_ERR_CAPACITY, "sora_rx_process_dump: the dump holds more samples than sora_rx_cfg.max_total_samples");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    if (rx->dump_cap < dump_bytes || rx->iq_own_samples < n) HIPCHK(hipStreamSynchronize(rx->stream));   // (growing: the previous call of this pipeline may still read them)
+    if (rx->dump_cap < dump_bytes) {
+        if (rx->d_dump) (void)hipFree(rx->d_dump);
+        rx->d_dump = nullptr; rx->dump_cap = 0;
+        HIPCHK(hipMalloc((void**)&rx->d_dump, dump_bytes + 256));
+        rx->dump_cap = dump_bytes;
+    }
+    if (rx->iq_own_samples < n) {
+        if (rx->d_iq_own) (void)hipFree(rx->d_iq_own);
+        rx->d_iq_own = nullptr; rx->iq_own_samples = 0;
+        HIPCHK(hipMalloc((void**)&rx->d_iq_own, sizeof(sora_complex16) * (n + 64)));
+        rx->iq_own_samples = n;
+    }
+    HIPCHK(hipMemcpyAsync(rx->d_dump, h_dump, dump_bytes, hipMemcpyHostToDevice, rx->stream));
+    size_t got = 0;
+    const int rc = sora_hip_ingest(rx->d_dump, dump_bytes, flags, rx->d_iq_own, rx->iq_own_samples, &got, (void*)rx->stream);
+    if (rc != SORA_OK) return rc;
+    return pipe_process_dev(rx, rx->d_iq_own, caps, ncaps, got);
 }
 
 static int pipe_pack(RxPipe* rx)                                                // dense rows of the pipeline's call -> d_rows / d_nrows, in stream order
@@ -680,6 +714,9 @@ int sora_rx_set_fused(sora_rx_t* rx, int enable)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     const int old = rx->fused ? 1 : 0;
+#ifndef SORA_WITH_K_DECODE
+    if (enable > 0) return fail(SORA_E_NOT_SUPPORTED, "sora_rx_set_fused: k_decode is not part of this build of the library (a build variant since round 4: sora_amd.build.build_variant(\"fused\", [\"SORA_WITH_K_DECODE\"]))");
+#endif
     if (enable >= 0) {
         rx->fused = enable != 0;
         for (RxPipe* p : rx->pipes) if (p) { p->fused = rx->fused; p->last_valid = false; }      // (a recorded hipGraph holds the other kernel chain)
@@ -758,6 +795,18 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
+    return rc;
+}
+
+int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, unsigned ingest_flags, const sora_capture_desc* caps, size_t ncaps)
+{
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dump: null argument");
+    const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
+    RxPipe* p = pipe_at(rx, next);
+    if (!p) return SORA_ERR_HARDWARE_FAILED;
+    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
+    const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
 }
@@ -1028,9 +1077,9 @@ int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_co
 }
 
 // The stage works out of a caller-owned workspace (no allocation, no host wait): every job's soft values packed to three bits each
-// (k_soft_pack3: at byte 3 ceil(off / 8), disjoint because the caller's ranges are), followed by the job table.  sora_hip_viterbi11a keeps
+// (k_soft_pack3: at byte ceil(off / 2), disjoint for any offsets and lengths because the caller's ranges are), followed by the job table.  sora_hip_viterbi11a keeps
 // the original signature on top of a grow-only workspace cached per device.
-static size_t vit_ws_packed_bytes(size_t soft_span_bytes) { return ((soft_span_bytes / 8 + 2) * 3 + kSoftSlack + 255) & ~(size_t)255; }
+static size_t vit_ws_packed_bytes(size_t soft_span_bytes) { return (soft_span_bytes / 2 + 4 + kSoftSlack + 255) & ~(size_t)255; }
 size_t sora_hip_viterbi11a_workspace_bytes(size_t soft_span_bytes, size_t n)
 {
     return vit_ws_packed_bytes(soft_span_bytes) + sizeof(VitJob) * n;

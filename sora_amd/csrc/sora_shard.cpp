@@ -243,11 +243,11 @@ int sora_shard_gather_results_mpdu(sora_shard_t* sh, sora_rx_t* rx, int ticket, 
         if (e == hipSuccess && mpdu_block && mine[0]) {
             // dense MPDU block of this rank: row i's bytes at the running sum of the lengths of the rows before it; the rows' mpdu_offset is rewritten to it
             hipLaunchKernelGGL(sora::k_shard_mpdu_offsets, dim3(1), dim3(1024), 0, st, sh->d_mine, mine[0], sh->d_off, sh->d_pair + 2 * W);
-            hipLaunchKernelGGL(sora::k_shard_mpdu_pack, dim3((mine[0] + 3) / 4), dim3(256), 0, st, sh->d_mine, mine[0], (const uint32_t*)sh->d_off, d_mpdu, sh->d_mpdu_mine, (uint32_t)mpdu_block);
+            hipLaunchKernelGGL(sora::k_shard_mpdu_pack, dim3((mine[0] + 3) / 4), dim3(256), 0, st, sh->d_mine, mine[0], (const uint32_t*)sh->d_off, d_mpdu, sh->d_mpdu_mine, (uint32_t)max_mpdu_bytes_per_rank);   // the CALLER's limit: the 16-byte rounding is only the staging / AllGather granule
             if (e == hipSuccess) e = hipMemcpyAsync(&mine[1], sh->d_pair + 2 * W, 4, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess && mine[1] > mpdu_block) { lrc = SORA_ERR_CAPACITY; lwhat = "sora_shard_gather_results: this rank's MPDUs exceed max_mpdu_bytes_per_rank"; }
+            if (e == hipSuccess && mine[1] > max_mpdu_bytes_per_rank) { lrc = SORA_ERR_CAPACITY; lwhat = "sora_shard_gather_results: this rank's MPDUs exceed max_mpdu_bytes_per_rank"; }
         }
         if (e != hipSuccess) { lrc = SORA_ERR_HARDWARE_FAILED; lwhat = "sora_shard_gather_results: staging this rank's rows"; }
     }

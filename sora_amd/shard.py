@@ -88,10 +88,20 @@ def gather_mpdus(rows, nrows, mpdu, max_rows_per_rank, max_bytes_per_rank, group
     import torch.distributed as dist
     world = dist.get_world_size(group)
     dev = rows.device
-    block, used, dense = pack_mpdus(rows, nrows, mpdu, max_bytes_per_rank)
+    # A rank whose local tables do not fit still enters all three collectives (contributing the count -1 and no bytes) and every rank
+    # raises afterwards -- the others would otherwise wait forever in a collective the failed rank never enters (the C path,
+    # sora_shard_gather_results_mpdu, does the same with the sentinel 0xFFFFFFFF).
+    failure = None
     pad = torch.zeros((max_rows_per_rank, ROW_WORDS), dtype=torch.int32, device=dev)
-    pad[:nrows] = rows[:nrows]
-    pad[:nrows, 8] = dense
+    try:
+        if nrows > max_rows_per_rank:
+            raise ValueError("gather_mpdus: %d rows exceed max_rows_per_rank %d" % (nrows, max_rows_per_rank))
+        block, used, dense = pack_mpdus(rows, nrows, mpdu, max_bytes_per_rank)
+        pad[:nrows] = rows[:nrows]
+        pad[:nrows, 8] = dense
+    except ValueError as e:
+        failure = e
+        block, used, nrows = torch.zeros(max_bytes_per_rank, dtype=torch.uint8, device=dev), 0, -1
     pairs = torch.zeros((world, 2), dtype=torch.int32, device=dev)
     dist.all_gather_into_tensor(pairs, torch.tensor([[nrows, used]], dtype=torch.int32, device=dev), group=group)
     allrows = torch.zeros((world * max_rows_per_rank, ROW_WORDS), dtype=torch.int32, device=dev)
@@ -99,6 +109,11 @@ def gather_mpdus(rows, nrows, mpdu, max_rows_per_rank, max_bytes_per_rank, group
     allmp = torch.zeros(world * max_bytes_per_rank, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(allmp, block, group=group)
     pl = pairs.tolist()
+    if failure is not None:
+        raise failure
+    bad = [r for r in range(world) if int(pl[r][0]) < 0]
+    if bad:
+        raise RuntimeError("gather_mpdus: rank(s) %s reported that their tables do not fit (nothing was gathered)" % bad)
     rparts, mparts, moff = [], [], 0
     for r in range(world):
         c, b = int(pl[r][0]), int(pl[r][1])

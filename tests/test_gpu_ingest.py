@@ -106,3 +106,32 @@ def test_44mhz_graph_on_the_gpu_equals_the_reference_44m_graph(sora, oracle):
         assert ok, "capture %d: %s" % (i, why)
         nev += len(ev)
     assert nev > 120
+
+
+def test_dump_bytes_in_host_memory_to_mpdus_in_one_call(sora, oracle, golden_dir):
+    """sora_rx_process_dump: LoadSoraDumpFile -> graph -> MPDU buffer as one stream-ordered path (brickutil.h:20-58 in front of
+    fb11a_demod.cpp:88-120).  The fixture dump from pinned host memory, three calls in flight on the handle's pipelines (their own
+    staging buffers), 40 MHz graph and decimate-on-ingest 20 MHz graph; a dump that holds more samples than the handle is refused."""
+    import torch
+    g = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))
+    iq = g["iq_i8"].astype(np.int16) << 8
+    raw = make_dump(iq, raw14=True)
+    pinned = torch.from_numpy(raw).pin_memory()
+    want = "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+    for mhz, flags in ((40, sora.INGEST_RXBLOCK | sora.INGEST_RAW14), (20, sora.INGEST_RXBLOCK | sora.INGEST_RAW14 | sora.INGEST_DECIMATE2)):
+        n = sora.ingest_count(raw.size, flags)
+        burst = 28 if mhz == 40 else 14
+        rx = sora.Rx(1, n, sample_rate_mhz=mhz)
+        rx.set_depth(3)
+        tickets = [rx.process_dump(pinned, flags, [(0, n // burst * burst, 7)]) for _ in range(4)]
+        for t in tickets[1:]:                                             # (the first ticket's pipeline has been reused by the fourth call)
+            res = rx.results(ticket=t)
+            assert len(res) == 1 and res[0]["error_code"] == sora.E_FRAME_OK and res[0]["capture_id"] == 7, (mhz, res)
+            assert hashlib.sha256(res[0]["mpdu"]).hexdigest() == want
+        t = rx.process_dump(raw, flags, [(0, n // burst * burst, 0)])     # pageable host memory works too (the copy is then synchronous)
+        assert hashlib.sha256(rx.results(ticket=t)[0]["mpdu"]).hexdigest() == want
+        rx.close()
+    small = sora.Rx(1, 1024, sample_rate_mhz=40)
+    with pytest.raises(sora.SoraError):
+        small.process_dump(pinned, sora.INGEST_RXBLOCK | sora.INGEST_RAW14, [(0, 1008, 0)])
+    small.close()

@@ -131,6 +131,27 @@ def test_viterbi_bit_exact_on_noise(sora, torch_cuda, oracle, cr):
         o4 = o4.cpu().numpy()
         for i, L in enumerate(lens):
             assert np.array_equal(o4[i, :L + 2], out[i, :L + 2]), ("odd offsets", lanes, cr, L)
+    # jobs whose nsoft is NOT a multiple of 8, laid back to back (no gap between a job's last value and the next job's first)
+    # and listed in reverse order of their offsets -- round 3's placement (byte 3 ceil(off / 8), last group padded) let neighbours overwrite
+    # each other's packed bytes here (off = 4, nsoft = 28 wrote bytes 3..14, the job at off = 32 starts at byte 12)
+    ns3 = [n_ - 4 for n_ in ns]
+    offs3, o = [], 4
+    for nsoft in ns3:
+        offs3.append(o); o += nsoft
+    buf3 = rng.integers(0, 32, size=o + 64).astype(np.uint8) << 3
+    for s_, o_, n_ in zip(softs, offs3, ns3):
+        buf3[o_:o_ + n_] |= s_[:n_]
+    order = list(range(len(lens)))[::-1]
+    d_buf3 = torch.from_numpy(buf3).cuda()
+    ws3 = torch.empty(sora.viterbi11a_workspace_bytes(d_buf3.numel(), len(lens)), dtype=torch.uint8, device="cuda")
+    args3 = (torch.tensor([offs3[i] for i in order], dtype=torch.int32).cuda(), torch.tensor([ns3[i] for i in order], dtype=torch.int32).cuda(),
+             torch.tensor([lens[i] for i in order], dtype=torch.int16).cuda())
+    for lanes in (64, 16):
+        o5 = sora.viterbi11a_ws(d_buf3, *args3, cr, ws3, lanes_per_pair=lanes)
+        torch.cuda.synchronize()
+        o5 = o5.cpu().numpy()
+        for k, i in enumerate(order):
+            assert np.array_equal(o5[k, :lens[i] + 2], out[i, :lens[i] + 2]), ("back to back, nsoft % 8 = 4", lanes, cr, lens[i])
 
 
 # ------------------------------------------------------------------ whole path
@@ -536,10 +557,34 @@ def test_config3_full_batch_equals_the_reference_graph(sora, torch_cuda, oracle)
 
 
 # ------------------------------------------------------------------ the fused decode kernel (k_decode)
+# A build variant since round 4: these three tests run only when the loaded library was built with SORA_WITH_K_DECODE
+# (sora_amd.build.build_variant("fused", ["SORA_WITH_K_DECODE"]); SORA_HIP_LIB=sora_amd/lib/variants/fused.so); the default library
+# answers sora_rx_set_fused(1) with SORA_E_NOT_SUPPORTED, which test_fused_mode_is_a_build_variant checks.
+def _need_fused(sora):
+    rx = sora.Rx(max_captures=1, max_total_samples=1024, sample_rate_mhz=20)
+    try:
+        rx.set_fused(1)
+    except sora.SoraError:
+        pytest.skip("k_decode is not part of this build of libsora_hip.so (build variant 'fused')")
+    finally:
+        rx.close()
+
+
+def test_fused_mode_is_a_build_variant(sora, torch_cuda):
+    rx = sora.Rx(max_captures=1, max_total_samples=1024, sample_rate_mhz=20)
+    assert rx.set_fused(-1) == 0 and rx.set_fused(0) == 0
+    try:
+        assert rx.set_fused(1) == 0 and rx.set_fused(-1) == 1           # a variant build: the switch works
+    except sora.SoraError as e:
+        assert e.code & 0xFFFFFFFF == 0x80000003 and rx.set_fused(-1) == 0   # the default build: SORA_E_NOT_SUPPORTED, nothing changed
+    rx.close()
+
+
 def test_fused_decode_kernel_equals_the_oracle_on_random_captures(sora, torch_cuda, oracle):
     """sora_rx_set_fused(1): symbol waves feeding trellis waves through an LDS ring inside one kernel.  Same rows as the oracle,
     and as the split path, on random captures: all rates (so frames of different modulation share a trellis wave), lengths,
     noise up to failure, several frames per capture, truncation, pure noise."""
+    _need_fused(sora)
     from gpu_util import random_capture
     rng = np.random.default_rng(20261001)
     for mhz in (20, 40):
@@ -555,6 +600,7 @@ def test_fused_decode_kernel_equals_the_oracle_on_random_captures(sora, torch_cu
 def test_fused_decode_kernel_on_lengths_rates_and_odd_lists(sora, torch_cuda, oracle):
     """Every rate at lengths around the window schedule's corners, list sizes 1..5 per code rate (the last frame of an odd list
     runs alone in its trellis wave), frames of very different length sharing a wave."""
+    _need_fused(sora)
     caps = []
     for i, rate in enumerate(RATES):
         for j, ln in enumerate((1, 5, 29, 30, 31, 33, 100, 257, 1024, 1500, 2304)[: 3 + (i % 5) * 2]):
@@ -569,6 +615,7 @@ def test_fused_decode_kernel_on_lengths_rates_and_odd_lists(sora, torch_cuda, or
 
 def test_fused_decode_kernel_full_batch_equals_the_reference_graph(sora, torch_cuda, oracle):
     """The bench workload (BASELINE configs[2], 4096 x 1500 B at 54 Mbps) through k_decode, every capture against the compiled reference graph."""
+    _need_fused(sora)
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
     import bench
