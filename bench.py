@@ -61,7 +61,11 @@ FRAME_SAMPLES = 4880       # 160 STS + 160 LTS + 80 SIGNAL + 56*80 data @20 MHz
 CAPTURE_SAMPLES = 5040     # + 160 silence; 360 source bursts of 14
 ALG_BYTES_PER_SAMPLE = 4.0 + 216 / 8.0 / 80.0     # 4.3375
 HBM_PEAK = 8.0e12
-TRAFFIC_JSON = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r03_final_traffic.json")
+PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+TRAFFIC_JSON = os.path.join(PROFILES, "r04_final_traffic.json")          # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh): replayed, not measured by this run
+if not os.path.exists(TRAFFIC_JSON):
+    TRAFFIC_JSON = os.path.join(PROFILES, "r03_final_traffic.json")
+VALU_PEAK_JSON = os.path.join(PROFILES, "r04_valu_peak.json")          # tools/calib/valu_peak.hip on one MI355X: what the chip sustains per instruction kind
 
 
 def measured_traffic(kernel):
@@ -250,91 +254,260 @@ def cpu_baseline(iq, nframes, budget_s=10.0):
 
 
 def valu_roofline(nframes, ms_step):
-    """What actually bounds this path: vector-ALU issue.  Wave-level VALU instructions of one receive call (rocprofv3
-    SQ_INSTS_VALU, profiles/r02_m_traffic.json) over the measured step time, against 256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles
-    per wave64 instruction (MI355X_MICROARCH.md: a wave64 VALU op issues over 2 cycles)."""
+    """What actually bounds this path: vector-ALU issue.  Wave-level VALU instructions of one receive call (rocprofv3 SQ_INSTS_VALU in separate
+    --pmc passes -- replayed from the committed summary, counters need rocprof) over the measured step time, against what the chip SUSTAINS for
+    this path's instruction mix: tools/calib/valu_peak.hip runs long unrolled streams of one instruction kind on every CU and reports wave-
+    instructions per second of wall time (so the clock the chip holds under that load is in the number): v_add_u32 1166 G/s (2 cycles per
+    wave64 instruction at ~2.28 GHz), v_pk_min_u16 / v_add_u32_dpp / any VOP3 ~580 G/s (half rate), and the trellis step's own mix -- four
+    add, four add_dpp, four pk_min, xor, sub, each minimum depending on the two sums before it -- 607 G/s at ANY occupancy from one to eight
+    waves per SIMD.  That last figure is `peak`: the ceiling for code made of add-compare-select steps."""
     n = measured_valu() if nframes == FRAMES_PER_GPU else None
     if not n:
         return None
-    peak = 256 * 4 * 2.4e9 / 2
+    try:
+        with open(VALU_PEAK_JSON) as f:
+            pk = json.load(f)
+        peak = pk["trellis_step_mix"]["g_per_s"]["4"] * 1e9; vop2 = pk["v_add_u32"]["g_per_s"]["4"]; half = pk["v_pk_min_u16"]["g_per_s"]["4"]
+        src = "profiles/r04_valu_peak.json (tools/calib/valu_peak.hip, measured on one MI355X; not re-measured by this run)"
+    except (OSError, KeyError, ValueError):
+        peak = 256 * 4 * 2.4e9 / 2; vop2 = peak / 1e9; half = vop2 / 2; src = "256 CUs x 4 SIMDs x 2.4 GHz / 2 cycles per wave64 instruction (no probe file)"
     ach = n / (ms_step * 1e-3)
-    return {"insts_per_call": n, "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "unit": "G wave-instr/s",
-            "frac": round(ach / peak, 4), "dominant_kernel_insts": measured_valu("k_viterbi16") or measured_valu("k_viterbi")}
+    return {"insts_per_call": n, "insts_source": "profiles/%s (rocprofv3 --pmc SQ_INSTS_VALU; replayed)" % os.path.basename(TRAFFIC_JSON),
+            "achieved": round(ach / 1e9, 1), "peak": round(peak / 1e9, 1), "peak_source": src, "unit": "G wave-instr/s", "frac": round(ach / peak, 4),
+            "vop2_only_rate": vop2, "half_rate_instruction_rate": half,
+            "dominant_kernel_insts": measured_valu("k_viterbi16") or measured_valu("k_viterbi")}
 
 
-def bench_stages(torch, sora_amd, dev, nsym=1 << 20, reps=10):
+def bench_stages(torch, sora_amd, dev, nsym=1 << 20, reps=12, nsets=3):
     """The per-stage entry points (what the BRICK adapters call), each over `nsym` OFDM symbols resident in HBM, against the
     HBM roofline with SURVEY.md section 8(d)'s algorithmic bytes per symbol: FFT 256 in + 256 out; symbol front end
     (T11aDataSymbol..TChannelEqualization) 320 in + 256 out; demap (64-QAM) 256 in + 288 out; de-interleave 288 + 288;
-    Viterbi (54 Mbps frames of 56 symbols) 288 soft bytes in + 27 decoded bytes out; FFT<128> 512 + 512."""
+    Viterbi (54 Mbps frames of 56 symbols) 288 soft bytes in + 27 decoded bytes out; FFT<128> 512 + 512.
+    Round 4: every stage cycles through `nsets` DISTINCT input / output buffer sets, so consecutive launches share no
+    line and the bytes in play (1.6-1.8 GB) are far past the 256 MiB Infinity Cache -- round 3's single 537-604 MB set only just exceeded it."""
     from sora_amd import capi
     L = capi.load()
     out = {}
     g = torch.Generator(device=dev); g.manual_seed(7)
 
-    def timed(fn, nbytes, label, n=nsym):
-        for _ in range(2):
-            fn()
+    def timed(fns, nbytes, label, n=nsym):
+        for f in fns:
+            f()
         e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
-        for _ in range(reps):
-            fn()
+        for i in range(reps):
+            fns[i % len(fns)]()
         e1.record(); torch.cuda.synchronize()
         ms = e0.elapsed_time(e1) / reps
         out[label] = {"symbols": n, "ms": round(ms, 4), "algorithmic_bytes": int(nbytes), "achieved": round(nbytes / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
-                      "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "gsymbols_per_s": round(n / ms / 1e6, 3)}
+                      "unit": "GB/s", "frac": round(nbytes / (ms * 1e-3) / HBM_PEAK, 4), "gsymbols_per_s": round(n / ms / 1e6, 3),
+                      "buffer_sets": len(fns), "bytes_in_play": int(nbytes) * len(fns)}
 
     st = capi._stream_ptr(None)
-    x = torch.randint(-6000, 6000, (nsym, 64, 2), dtype=torch.int16, device=dev, generator=g)
-    y = torch.empty_like(x)
-    timed(lambda: L.sora_hip_fft64(capi._dev_ptr(x), capi._dev_ptr(y), nsym, st), nsym * 512, "fft64")
-    soft = torch.empty((nsym, 288), dtype=torch.uint8, device=dev)
-    timed(lambda: L.sora_hip_demap11a(capi._dev_ptr(x), capi._dev_ptr(soft), 6, nsym, st), nsym * (256 + 288), "demap11a_qam64")
-    de = torch.empty_like(soft)
-    timed(lambda: L.sora_hip_deinterleave11a(capi._dev_ptr(soft), capi._dev_ptr(de), 6, nsym, st), nsym * 576, "deinterleave11a_qam64")
-    del y
-    x80 = torch.randint(-6000, 6000, (nsym, 80, 2), dtype=torch.int16, device=dev, generator=g)
+    P = capi._dev_ptr
+    xs = [torch.randint(-6000, 6000, (nsym, 64, 2), dtype=torch.int16, device=dev, generator=g) for _ in range(nsets)]
+    ys = [torch.empty_like(xs[0]) for _ in range(nsets)]
+    timed([(lambda x=x, y=y: L.sora_hip_fft64(P(x), P(y), nsym, st)) for x, y in zip(xs, ys)], nsym * 512, "fft64")
+    del ys
+    softs = [torch.empty((nsym, 288), dtype=torch.uint8, device=dev) for _ in range(nsets)]
+    timed([(lambda x=x, o=o: L.sora_hip_demap11a(P(x), P(o), 6, nsym, st)) for x, o in zip(xs, softs)], nsym * (256 + 288), "demap11a_qam64")
+    des = [torch.empty_like(softs[0]) for _ in range(nsets)]
+    timed([(lambda i=i, o=o: L.sora_hip_deinterleave11a(P(i), P(o), 6, nsym, st)) for i, o in zip(softs, des)], nsym * 576, "deinterleave11a_qam64")
+    del des, softs
+    n128 = nsym // 2
+    x128 = [x.view(n128, 128, 2) for x in xs]; y128 = [torch.empty_like(x128[0]) for _ in range(nsets)]
+    timed([(lambda x=x, y=y: L.sora_hip_fft128(P(x), P(y), n128, st)) for x, y in zip(x128, y128)], n128 * 1024, "fft128", n128)
+    del y128, x128, xs
+    x80 = [torch.randint(-6000, 6000, (nsym, 80, 2), dtype=torch.int16, device=dev, generator=g) for _ in range(nsets)]
     nctx = 4096
     lts_in = torch.randint(-6000, 6000, (nctx, 144, 2), dtype=torch.int16, device=dev, generator=g)
     ctx = sora_amd.lts11a(lts_in)
     idx = (torch.arange(nsym, device=dev, dtype=torch.int32) // 256) % nctx
-    eq = torch.empty((nsym, 64, 2), dtype=torch.int16, device=dev)
-    timed(lambda: L.sora_hip_symfront11a(capi._dev_ptr(x80), capi._dev_ptr(ctx), capi._dev_ptr(idx), capi._dev_ptr(eq), nsym, st), nsym * 576, "symfront11a")
-    del x80, eq, idx
-    n128 = nsym // 2
-    x128 = x.view(n128, 128, 2); y128 = torch.empty_like(x128)
-    timed(lambda: L.sora_hip_fft128(capi._dev_ptr(x128), capi._dev_ptr(y128), n128, st), n128 * 1024, "fft128", n128)
-    del y128, x128, x
+    eqs = [torch.empty((nsym, 64, 2), dtype=torch.int16, device=dev) for _ in range(nsets)]
+    timed([(lambda x=x, e=e: L.sora_hip_symfront11a(P(x), P(ctx), P(idx), P(e), nsym, st)) for x, e in zip(x80, eqs)], nsym * 576, "symfront11a")
+    del x80, eqs, idx
     # Viterbi: frames of 56 symbols x 216 soft values (the bench frame), random soft values 0..7
     nfr = 8192; nso = 56 * 288
     sv = torch.randint(0, 8, (nfr * nso,), dtype=torch.uint8, device=dev, generator=g)
     so = (torch.arange(nfr, device=dev, dtype=torch.int32) * nso).contiguous(); ns = torch.full((nfr,), nso, dtype=torch.int32, device=dev)
     fl = torch.full((nfr,), MPDU_LEN, dtype=torch.int16, device=dev)
     vo = torch.zeros((nfr, 1536), dtype=torch.uint8, device=dev); oo = (torch.arange(nfr, device=dev, dtype=torch.int32) * 1536).contiguous()
-    timed(lambda: L.sora_hip_viterbi11a(capi._dev_ptr(sv), capi._dev_ptr(so), capi._dev_ptr(ns), capi._dev_ptr(fl), 2, capi._dev_ptr(vo), capi._dev_ptr(oo), nfr, st),
+    timed([lambda: L.sora_hip_viterbi11a(P(sv), P(so), P(ns), P(fl), 2, P(vo), P(oo), nfr, st)],
           nfr * 56 * (288 + 27), "viterbi11a_r34", nfr * 56)
     return out
 
 
-def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20):
+def bench_ingest(torch, sora_amd, dev, nbytes=256 << 20, reps=20, nsets=3):
     """Row f3 (capture ingest): a 44 MHz RX_BLOCK dump resident in HBM -> de-framed, sign-fixed, resampled 40 MHz stream.
-    A pure streaming kernel: algorithmic bytes = dump bytes read + samples written, against the HBM roofline."""
+    A pure streaming kernel: algorithmic bytes = dump bytes read + samples written, against the HBM roofline.  `nsets` distinct dumps in turn
+    (round 4: 0.8 GB of input in play instead of one 256 MiB buffer that is exactly the size of the Infinity Cache)."""
     flags = sora_amd.INGEST_RXBLOCK | sora_amd.INGEST_RAW14 | sora_amd.INGEST_44TO40
-    raw = torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev)
+    raws = [torch.randint(0, 256, (nbytes,), dtype=torch.uint8, device=dev) for _ in range(nsets)]
     n_out = sora_amd.ingest_count(nbytes, flags)
-    for _ in range(3):
-        out = sora_amd.ingest(raw, flags, sync=False)
+    for r in raws:
+        out = sora_amd.ingest(r, flags, sync=False)
     e0 = torch.cuda.Event(enable_timing=True); e1 = torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize(); e0.record()
-    for _ in range(reps):
-        out = sora_amd.ingest(raw, flags, sync=False)
+    for i in range(reps):
+        out = sora_amd.ingest(raws[i % nsets], flags, sync=False)
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / reps
     alg = nbytes + 4 * n_out
-    del raw, out
-    return {"workload": "%d MiB Sora RX_BLOCK dump @44 MHz -> de-frame + 14->16 bit + 44->40 MHz (%d samples out)" % (nbytes >> 20, n_out),
+    del raws, out
+    return {"workload": "%d MiB Sora RX_BLOCK dump @44 MHz -> de-frame + 14->16 bit + 44->40 MHz (%d samples out), %d distinct dumps in turn" % (nbytes >> 20, n_out, nsets),
             "bound": "hbm", "ms": round(ms, 4), "algorithmic_bytes": alg, "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9,
             "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4), "msamples_per_s_in": round(nbytes / 128 * 28 / ms / 1e3, 1)}
+
+
+
+def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
+    """The reference harness's own figure of merit (MACStopwatch.h:84-128,130-164): per frame, cost (time spent demodulating it) over required
+    time (its samples / 40 MHz), with mean / max / std and the shares >= 0.8 and >= 1.0.
+    (a) BASELINE configs[1]: kernel/test-data/fsample-6.dmp as ONE capture (tests/golden/fsample6_40mhz_i8.npz: the dump after the 14 -> 16 bit
+        fix, 75,320 samples @40 MHz = 1.883 ms of air time, one 6 Mbps frame of 465 symbols): wall time of process -> wait with one call in
+        flight, and the compiled reference graph on one host core beside it.
+    (b) the 4096-frame batch, one call in flight (process -> deliver -> wait): every frame of a call costs that call's latency (they complete
+        together), required = 9760 samples / 40 MHz = 244 us; the distribution is over the frames of `reps` calls.  The amortised cost
+        (step time / frames) is what `realtime.factor` reports."""
+    import hashlib
+    from oracle.pyoracle import ReferenceGraph
+    out = {}
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fsample6_40mhz_i8.npz"))
+    iq40 = g["iq_i8"].astype(np.int16) << 8
+    n = len(iq40) // 28 * 28
+    d = torch.from_numpy(np.ascontiguousarray(iq40[:n])).to(dev)
+    rx = sora_amd.Rx(1, n, sample_rate_mhz=40, max_frames_per_capture=2)
+    rx.set_depth(1)
+    one = [(0, n, 0)]
+    t = rx.process_dev(d, one); res = rx.results(ticket=t)
+    rx.wait_for_producer = False
+    ok = len(res) == 1 and res[0]["error_code"] == sora_amd.E_FRAME_OK and hashlib.sha256(res[0]["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+    per = {}
+    for lanes in (64, 16):
+        rx.set_trellis(lanes); rx.flush()
+        for _ in range(5):
+            rx.wait(rx.process_dev(d, one))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); rx.wait(rx.process_dev(d, one)); ts.append(time.perf_counter() - t0)
+        per[lanes] = float(np.median(ts)) * 1e3
+    rx.set_trellis(64); rx.set_profiling(True)
+    for _ in range(10):
+        rx.wait(rx.process_dev(d, one))
+    rx.flush(); kt = rx.kernel_times(); rx.set_profiling(False); rx.close()
+    air_ms = n / 40e3
+    best = min(per.values())
+    out["fsample6_single_capture"] = {
+        "workload": "kernel/test-data/fsample-6.dmp after the 14->16 bit fix: one 6 Mbps frame, 1392 bytes, 465 data symbols, %d samples @40 MHz" % n,
+        "air_time_ms": round(air_ms, 4), "decode_ms": round(best, 4), "decode_ms_by_trellis_kernel": {"k_viterbi": round(per[64], 4), "k_viterbi16": round(per[16], 4)},
+        "realtime_factor": round(best / air_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kt.items()}, "mpdu_sha256_ok": bool(ok),
+        "protocol": "sora_rx_process_dev + sora_rx_wait, one call in flight, samples resident in HBM; median of %d calls (host wall clock)" % reps}
+    ref = ReferenceGraph()
+    if ref.available():
+        caps = np.ascontiguousarray(iq40[None, :n])
+        ref.rx11a_bench(caps)
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 1.0:
+            ref.rx11a_bench(caps, 4); k += 4
+        cpu_ms = (time.perf_counter() - t0) / k * 1e3
+        out["fsample6_single_capture"]["cpu_reference_decode_ms_one_core"] = round(cpu_ms, 4)
+        out["fsample6_single_capture"]["cpu_reference_realtime_factor_one_core"] = round(cpu_ms / air_ms, 4)
+    # (b) the batch, one call in flight
+    old_depth = rx_batch.set_depth(1); old_tr = rx_batch.set_trellis(-1); rx_batch.flush()
+    req_us = 2 * FRAME_SAMPLES / 40.0
+    dist = {}
+    for lanes in (64, 16):
+        rx_batch.set_trellis(lanes); rx_batch.flush()
+        buf = sora_amd.HostResults(nfr * 2, rx_batch.mpdu_bytes(rx_batch.process_dev(d_iq, descs))); rx_batch.flush()
+        lat = []
+        for i in range(reps + 3):
+            t0 = time.perf_counter()
+            tk = rx_batch.process_dev(d_iq, descs); rx_batch.deliver_async(tk, buf); rx_batch.wait(tk)
+            if i >= 3:
+                lat.append((time.perf_counter() - t0) * 1e6)
+        buf.close()
+        r = np.asarray(lat) / req_us                                         # every frame of call i has ratio r[i]
+        dist[{64: "k_viterbi", 16: "k_viterbi16"}[lanes]] = {
+            "call_latency_ms": round(float(np.mean(lat)) / 1e3, 4), "frames": int(nfr * len(lat)), "required_us_per_frame": req_us,
+            "ratio_mean": round(float(r.mean()), 3), "ratio_max": round(float(r.max()), 3), "ratio_std": round(float(r.std()), 3),
+            "share_ge_0.8": round(float((r >= 0.8).mean()), 3), "share_ge_1.0": round(float((r >= 1.0).mean()), 3)}
+    rx_batch.set_trellis(old_tr); rx_batch.set_depth(old_depth); rx_batch.flush()
+    out["batch_per_frame"] = {"definition": "MACStopwatch's per-frame ratio cost / required with cost = the latency of the call the frame is in (process -> deliver -> wait, one call in flight: "
+                                            "all %d frames of a call complete together) and required = %d samples / 40 MHz; >= 1.0 means a frame's result arrives later than its own air time, although "
+                                            "the batch as a whole is decoded far faster than real time (realtime.factor, the amortised cost)" % (nfr, 2 * FRAME_SAMPLES),
+                              "by_trellis_kernel": dist}
+    return out
+
+
+def bench_e2e(torch, sora_amd, dev, rx, iq, nfr, exp_rows, exp_mpdu, steps=24, nbatches=4):
+    """Dump bytes in page-locked host memory -> sora_rx_process_dump (H2D copy + sora_hip_ingest + the receive chain on one stream, no host wait) ->
+    rows and MPDUs delivered to the host: LoadSoraDumpFile -> graph -> MPDU buffer (brickutil.h:20-58, fb11a_demod.cpp:88-120) as one path.
+    The workload's captures as a 40 MHz RX_BLOCK dump (every 20 MHz sample doubled -- TDownSample2, done by the ingest, drops the copies --
+    128-byte blocks of a 16-byte descriptor + 28 samples): `nbatches` DIFFERENT dumps (the captures rotated by a quarter of the batch each)
+    are submitted in turn, about 190 MB each, so the inputs of consecutive calls share nothing and their total is past the 256 MiB Infinity Cache."""
+    from test_oracle_ingest import make_dump
+    flags = sora_amd.INGEST_RXBLOCK | sora_amd.INGEST_DECIMATE2
+    caps20 = iq.reshape(nfr, CAPTURE_SAMPLES, 2)
+    blocks_per_cap = 2 * CAPTURE_SAMPLES // 28
+    base = np.empty((nfr, blocks_per_cap * 128), np.uint8)
+    for i in range(0, nfr, 256):
+        c40 = np.repeat(caps20[i:i + 256], 2, axis=1).reshape(-1, 2)
+        base[i:i + 256] = make_dump(c40, raw14=False, seed=i).reshape(-1, blocks_per_cap * 128)
+    dumps, ids = [], []
+    for k in range(nbatches):
+        sh = (k * nfr) // nbatches
+        perm = (np.arange(nfr) + sh) % nfr                                    # position i of dump k holds capture perm[i]
+        t = torch.empty(base.size, dtype=torch.uint8).pin_memory()
+        t.numpy().reshape(base.shape)[:] = base[perm]
+        dumps.append(t); ids.append(perm)
+    del base
+    descs = [sora_amd.Rx.captures([(i * CAPTURE_SAMPLES, CAPTURE_SAMPLES, int(ids[k][i])) for i in range(nfr)]) for k in range(nbatches)]
+    # what every call must deliver: per capture id {error_code, length, crc32} of the verified table (rows come in position order)
+    order = np.argsort(exp_rows["capture_id"], kind="stable")
+    want = {f: exp_rows[f][order] for f in ("capture_id", "error_code", "length", "crc32")}
+    depth = 4
+    old_depth = rx.set_depth(depth); rx.flush()
+    nb = depth + 2
+    bufs = [sora_amd.HostResults(nfr * 2, rx.mpdu_bytes(rx.ticket())) for _ in range(nb)]
+    bad = [0]; checked = [0]; mp_checked = [0]
+
+    def consume(tk, k):
+        rx.wait(tk)
+        b = bufs[tk % nb]
+        n = int(b.nrows[0]); rows = b.rows[:n]
+        o = np.argsort(rows["capture_id"], kind="stable")
+        same = n == len(want["capture_id"]) and all(np.array_equal(rows[f][o], want[f]) for f in want)
+        if same and k == 0:                                                   # the unrotated dump: the MPDU array byte for byte as well
+            same = bool((b.mpdu == exp_mpdu).all()); mp_checked[0] += 1
+        checked[0] += 1; bad[0] += 0 if same else 1
+
+    def block(nsteps):
+        pend = []
+        for i in range(nsteps):
+            k = i % nbatches
+            tk = rx.process_dump(dumps[k], flags, descs[k])
+            rx.deliver_async(tk, bufs[tk % nb]); pend.append((tk, k))
+            if len(pend) >= depth:
+                consume(*pend.pop(0))
+        for tk, k in pend:
+            consume(tk, k)
+    block(nbatches + depth)                                                   # warm-up: every pipeline's staging buffers exist
+    bad[0] = checked[0] = mp_checked[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    block(steps)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    rx.set_depth(old_depth); rx.flush()
+    for b in bufs:
+        b.close()
+    dump_bytes = int(dumps[0].numel())
+    return {"workload": "%d dumps of %.1f MB (the batch's captures as a 40 MHz RX_BLOCK dump, rotated) in page-locked host memory, submitted in turn: sora_rx_process_dump = H2D copy + "
+                        "sora_hip_ingest (de-frame, TDownSample2) + receive chain on the call's stream, then deliver_async of rows + MPDUs; %d calls in flight" % (nbatches, dump_bytes / 1e6, depth),
+            "ms_per_step": round(ms, 4), "dump_bytes_per_step": dump_bytes, "distinct_input_bytes": dump_bytes * nbatches,
+            "pcie_gb_per_s_host_to_device": round(dump_bytes / ms / 1e6, 2), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms / 1e3, 1),
+            "decoded_mbit_per_s": round(nfr * MPDU_LEN * 8 / ms / 1e3, 1),
+            "calls_delivered_and_checked": checked[0], "calls_with_wrong_rows": bad[0], "calls_with_mpdu_bytes_compared": mp_checked[0],
+            "note": "bound by the host link: the 40 MHz dump is 9.4 bytes of PCIe traffic per 20 MHz sample decoded (RX_BLOCK framing, both 40 MHz samples of a pair)"}
 
 
 class TableChecker:
@@ -343,9 +516,16 @@ class TableChecker:
     GIL) while the main thread submits the next call.  A buffer is handed out again only after its comparison has finished."""
     EXTRA = 4                                                               # buffers beyond the calls in flight: the ones being compared
 
-    def __init__(self, exp_rows_bytes, exp_mpdu):
+    def __init__(self, exp_rows_bytes, exp_mpdu, cores=None):
         from concurrent.futures import ThreadPoolExecutor
-        self.pool = ThreadPoolExecutor(self.EXTRA)
+
+        def pin():                                                          # a checker thread never runs on the submit thread's core
+            if cores and hasattr(os, "sched_setaffinity"):
+                try:
+                    os.sched_setaffinity(0, set(cores))
+                except OSError:
+                    pass
+        self.pool = ThreadPoolExecutor(self.EXTRA, initializer=pin)
         self.rows = exp_rows_bytes
         m8 = exp_mpdu.size // 8 * 8
         self.m8 = m8; self.m = exp_mpdu.size
@@ -380,6 +560,23 @@ class TableChecker:
     def finish(self):
         self.drain()
         self.pool.shutdown()
+
+
+def pin_rank_threads(local_rank, world):
+    """Several ranks share one host: rank r takes the r-th slice of the usable cores, pins the calling (submit) thread to the slice's first core
+    and returns the slice (the checker threads take the rest).  With one rank, or fewer than two cores per rank, nothing is pinned."""
+    if not hasattr(os, "sched_getaffinity"):
+        return []
+    cores = sorted(os.sched_getaffinity(0))
+    per = len(cores) // max(1, world)
+    if world <= 1 or per < 2:
+        return []
+    mine = cores[local_rank * per:(local_rank + 1) * per]
+    try:
+        os.sched_setaffinity(0, {mine[0]})
+    except OSError:
+        return []
+    return mine
 
 
 def timed_with_delivery(sora_amd, rx, submit, depth, reps, rows_cap, mpdu_cap):
@@ -778,7 +975,8 @@ def main():
     host_rows_ok = exp_n == len(res) and all(int(exp_rows[k]["crc32"]) == res[k]["crc32"] and int(exp_rows[k]["error_code"]) == res[k]["error_code"] for k in range(exp_n)) \
         and all(bytes(exp_mpdu[int(r["mpdu_offset"]):int(r["mpdu_offset"]) + int(r["length"])]) == res[k]["mpdu"] for k, r in enumerate(exp_rows) if int(r["error_code"]) == 1)
     stats = {"t_submit": 0.0, "t_wait": 0.0, "t_check": 0.0}
-    chk = TableChecker(exp_bytes, exp_mpdu)                         # rows AND MPDU bytes of every delivered call, compared by a few host threads
+    share = pin_rank_threads(local_rank, world)                     # this rank's cores: the submit thread on the first, the checker's threads on the others
+    chk = TableChecker(exp_bytes, exp_mpdu, cores=share[1:] if len(share) > 1 else None)   # rows AND MPDU bytes of every delivered call, compared by a few host threads
 
     def consume(tk):
         ta = time.perf_counter()
@@ -786,9 +984,9 @@ def main():
         tb = time.perf_counter()
         stats["t_wait"] += tb - ta
         b = bufs[tk % nb]
-        # (several ranks share one host: the byte-for-byte comparison of the 8 MB MPDU array -- 20 GB/s of host reads per rank at this step rate --
-        #  is then done for every world-th call of a rank, the row table for every call; with one rank every call's MPDUs are compared)
-        chk.check(tk % nb, int(b.nrows[0]) == exp_n, b.rows[:exp_n], b.mpdu if tk % world == 0 else None)
+        # every call's rows AND MPDU bytes, whatever the number of ranks: the comparison runs on the checker's threads, which (like the submit
+        # thread) are pinned to this rank's own share of the host's cores (pin_rank_threads) -- round 3 sampled every world-th call instead
+        chk.check(tk % nb, int(b.nrows[0]) == exp_n, b.rows[:exp_n], b.mpdu)
         stats["t_check"] += time.perf_counter() - tb
 
     def run_block(k, deliver, dep=None):
@@ -867,7 +1065,33 @@ def main():
     ktimes1 = alone(lanes)
     ktimes1_other = alone(80 - lanes)
     ktimes = {(tname[lanes] if k == "k_viterbi" else k): v for k, v in ktimes.items()}
-    rx.set_trellis(trellis_setting); rx.set_depth(depth)
+
+    # ---- what a plain host gets: process -> deliver -> wait with ONE or TWO calls in flight, i.e. at most two of the
+    # handle's streams in use -- fewer than the runtime's default four hardware queues, so GPU_MAX_HW_QUEUES plays no part -- same timed-region
+    # protocol (delivery + comparison inside), each trellis kernel pinned in turn.
+    plain = {}
+    if world == 1:
+        for dval in (1, 2):
+            for l in (64, 16):
+                rx.set_trellis(l); rx.set_depth(dval); rx.flush()
+                run_block(args.warmup, deliver, dval); rx.flush(); chk.drain(); bad0 = chk.bad
+                nblk = max(1, repeats // 6)
+                tp0 = time.perf_counter()
+                for _ in range(nblk):
+                    run_block(args.steps, deliver, dval)
+                rx.flush(); chk.drain()
+                ms_p = (time.perf_counter() - tp0) / (nblk * args.steps) * 1e3
+                plain["calls_in_flight_%d_%s" % (dval, tname[l])] = {"ms_per_step": round(ms_p, 4), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms_p / 1e3, 1),
+                                                                      "calls_with_wrong_rows": chk.bad - bad0}
+        best2 = min((k for k in plain if k.startswith("calls_in_flight_2")), key=lambda k: plain[k]["ms_per_step"])
+        plain["best_with_at_most_two_calls_in_flight"] = dict(plain[best2], config=best2)
+        plain["note"] = ("the headline keeps %d calls in flight%s; with at most two, the chip holds at most 8192 frames = 1024 waves of k_viterbi16 (one per SIMD, each bound by its own "
+                         "issue rate) or 4096 of k_viterbi (1.7x the instructions): DESIGN.md section 3.6, profiles/r04_a_depth_table.txt" % (depth, " on %s hardware queues" % os.environ["GPU_MAX_HW_QUEUES"] if os.environ.get("GPU_MAX_HW_QUEUES") else ""))
+    rx.set_trellis(trellis_setting); rx.set_depth(depth); rx.flush()
+    latency = e2e = None
+    if world == 1 and not args.no_extras:
+        latency = bench_latency(torch, sora_amd, dev, rx, d_iq, descs, nfr)
+        e2e = bench_e2e(torch, sora_amd, dev, rx, iq, nfr, exp_rows, exp_mpdu)
 
     elapsed = t1 - t0
     if world > 1:
@@ -904,7 +1128,7 @@ def main():
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth, "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
-                       "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, TableChecker.EXTRA, "" if world == 1 else " (MPDU bytes: every %d-th call of a rank, the ranks share one host)" % world)
+                       "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "gathered": gathered, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
@@ -917,6 +1141,7 @@ def main():
                          "call_latency_ms_one_in_flight": round(sum(v for k, v in ktimes1.items()), 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach1 / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(ach1 / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
+                         "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as tools/summarize_pmc.py documents; replayed, not measured by this run)" % os.path.basename(TRAFFIC_JSON),
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes1[dom], 4),
                          "kernel_ms_note": "mean launch duration with ONE call in flight (the kernel alone on the chip); with %d calls overlapped the same launch lasts %.4f ms (frac %.5f) because it shares the CUs" % (depth, ktimes[dom], ach / HBM_PEAK),
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
@@ -927,6 +1152,12 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
+        if plain:
+            out["plain_host"] = plain
+        if latency is not None:
+            out["latency"] = latency
+        if e2e is not None:
+            out["e2e"] = e2e
         if world == 1 and not args.no_extras:
             out["stages"] = bench_stages(torch, sora_amd, dev)
             out["ingest"] = bench_ingest(torch, sora_amd, dev)

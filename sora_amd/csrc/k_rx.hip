@@ -167,6 +167,333 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Round 4: the data field's symbol chain as THREE kernels (VERDICT r3 #3c) instead of one wave per frame.
+//
+// What a symbol needs from its predecessor is four numbers (CFO_comp, SFO_comp and the two trackers of TPilotTrack,
+// pilot.hpp:213-232 -> freqoffset.hpp:28); everything else -- TFreqCompensation, TFFT64, TChannelEqualization in front of
+// the tracker, the rotation by CompCoeffs and by the pilots' mean phase / slope, T11aDemap and T11aDeinterleave behind
+// it -- is per-symbol work.  k_frame ran the tracker's chain (two dependent LUT gathers, ~50 vector + ~40 scalar
+// instructions per symbol) on a whole wave for the four lanes that hold a symbol's pilots: 36 % of its vector
+// instructions, and a frame's symbols one pass after the other (fsample-6's 465 symbols: 117 passes, 0.30 ms for one wave).
+//   k_sym_front  per SYMBOL SLOT (rx_types.h): samples -> equalised bins eq[slot][64] in HBM      (16 lanes per symbol)
+//   k_track      per FRAME, four lanes (= the four pilots) each, sixteen frames per wave: the chain over the frame's
+//                symbols in order, reading 16 bytes per symbol, writing the rotation parameters track[slot] (TrackRec)
+//   k_sym_back   per SYMBOL SLOT: eq[slot] x CompCoeffs x rotation -> demap -> de-interleave -> packed soft stream
+// The symbol kernels find a slot's frame through slot_row[] (written by k_scan for the data symbols of every frame it
+// queues).  HBM is the idle resource of this path (4.6 % of the roofline in round 3): the equalised symbols cost
+// 256 B written + ~210 B read per symbol (59 + 48 MB per 4096-frame call) and buy the tracker's instructions back.
+struct SlotOwner { uint32_t row; bool ok; };
+
+// pilot.hpp:10-28 as a bit string (bit i of word i >> 5 = polarity -1 of symbol count i)
+__device__ __forceinline__ unsigned pilot_sgn(unsigned count)
+{
+    const unsigned w = count < 32 ? 0x2049a7b8u : count < 64 ? 0x9836ba32u : count < 96 ? 0xaa16f395u : 0x3f8ec52fu;
+    return (w >> (count & 31u)) & 1u;
+}
+
+constexpr int kSlotIters = 4;                                                    // quads of slots per wave: 16 consecutive slots
+
+// One quad of slots through TFreqCompensation, TFFT64 and TChannelEqualization: group g's symbol from raw[] (its 64 samples behind the cyclic
+// prefix, sample e + 16 m) with the frame's FreqCoeffs / ChannelCoeffs already in their packed-product form; bins 4e .. 4e+3 out.
+template <typename SYNC>
+__device__ __forceinline__ void sym_front_quad(const uint32_t raw[4], const PkTw fq[4], const PkTw ch[4], uint32_t* sl, int e, const Fft64TwPk& W, SYNC wsync, uint32_t o[4])
+{
+    pcx x[4];
+#pragma unroll
+    for (int m = 0; m < 4; m++) x[m] = pk_cmul<15>(pk_sra(raw[m], 1), fq[m]);   // >>1, x FreqCoeffs (channel_11a.hpp:643-644)
+    fft64_core_pk(x, sl, e, W, wsync);
+    const unsigned rv = __brev((unsigned)e) >> 28;                               // bin 4e+q sits at slot bitrev6(4e+q) = bitrev4(e) + 16 bitrev2(q)
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const int bin = 4 * e + q;
+        o[q] = (bin >= 28 && bin < 36) ? 0u : pk_cmul<8>(sl[rv + 16u * ((q & 1) * 2 + (q >> 1))], ch[q]);   // channel_11a.hpp:548-574
+    }
+    wsync();
+}
+
+__global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
+{
+    __shared__ uint32_t s_eq[4][4][64];                                          // [wave][group]: FFT staging
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
+    const Tables& T = A.T;
+    const uint32_t slot_first = (blockIdx.x * 4u + (uint32_t)w) * (4u * kSlotIters);
+    if (slot_first >= A.total_slots) return;
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    // the owners of the wave's 16 slots: lane l < 16 asks for slot slot_first + l, the groups pick theirs up by cross-lane reads
+    const uint32_t my_slot = slot_first + (uint32_t)(lane & 15);
+    const uint32_t my_own = (lane < 16 && my_slot < A.total_slots) ? A.slot_row[my_slot] : 0xFFFFFFFFu;
+    const unsigned long long owned = __ballot(my_own != 0xFFFFFFFFu);
+    if (owned == 0) return;                                                      // preamble / silence only
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)my_own, __builtin_ctzll(owned));
+    const bool one_frame = __ballot(lane < 16 && my_own != 0xFFFFFFFFu && my_own != row0) == 0;   // the usual case: every owned slot of the wave belongs to ONE frame
+    uint32_t own[kSlotIters];
+#pragma unroll
+    for (int it = 0; it < kSlotIters; it++) own[it] = (uint32_t)__shfl((int)my_own, 4 * it + g);
+    const Fft64TwPk W = fft64_twiddles_pk(T, e);
+    uint32_t* sl = s_eq[w][g];
+    uint4* eq4 = reinterpret_cast<uint4*>(A.eq);
+    auto store = [&](uint32_t slot, const uint32_t o[4]) {
+        eq4[(size_t)slot * 16u + (uint32_t)e] = uint4{ o[0], o[1], o[2], o[3] };
+        // the four pilot bins once more, densely (16 bytes per slot: k_track reads nothing else): bins 43, 57, 7, 21 = (e, q) (10,3), (14,1), (1,3), (5,1)
+        if (e == 10) A.pil[(size_t)slot * 4u + 0u] = o[3];
+        if (e == 14) A.pil[(size_t)slot * 4u + 1u] = o[1];
+        if (e == 1)  A.pil[(size_t)slot * 4u + 2u] = o[3];
+        if (e == 5)  A.pil[(size_t)slot * 4u + 3u] = o[1];
+    };
+    if (one_frame) {
+        // ---- one frame: its row and its coefficients once per wave, every sample load in flight before the first butterfly
+        const FrameRow& r = A.frames[row0];
+        const uint32_t* iq = A.iq + A.caps[r.capture].offset;
+        const uint32_t ds = r.data_start, s0 = r.slot0, str = A.str;
+        const FrameCtx* fx = A.fctx + row0;
+        uint32_t raw[kSlotIters][4];
+#pragma unroll
+        for (int it = 0; it < kSlotIters; it++) {
+            const uint32_t p0 = ds + 80u * (slot_first + 4u * it + (uint32_t)g - s0) + 8u;   // skip_cp = 8 (PHY_11a.hpp:365,394)
+#pragma unroll
+            for (int m = 0; m < 4; m++) raw[it][m] = own[it] != 0xFFFFFFFFu ? iq[(size_t)(p0 + (uint32_t)(e + 16 * m)) * str] : 0u;
+        }
+        PkTw fq[4], ch[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) { fq[m] = pk_tw_mul(fx->freq[e + 16 * m]); ch[m] = pk_tw_mul(fx->chan[4 * e + m]); }
+#pragma unroll
+        for (int it = 0; it < kSlotIters; it++) {
+            if (((owned >> (4 * it)) & 0xFull) == 0) continue;                   // (wave-uniform)
+            uint32_t o[4];
+            sym_front_quad(raw[it], fq, ch, sl, e, W, wsync, o);
+            if (own[it] != 0xFFFFFFFFu) store(slot_first + 4u * it + (uint32_t)g, o);
+        }
+        return;
+    }
+    // ---- several frames meet in these 16 slots (the end of one and the start of the next, captures of a few symbols): per group and quad
+#pragma unroll 1
+    for (int it = 0; it < kSlotIters; it++) {
+        if (((owned >> (4 * it)) & 0xFull) == 0) continue;
+        const uint32_t ow = (uint32_t)__shfl((int)my_own, 4 * it + g);
+        const bool mine = ow != 0xFFFFFFFFu;
+        const uint32_t slot = slot_first + 4u * it + (uint32_t)g;
+        uint32_t raw[4] = { 0u, 0u, 0u, 0u };
+        PkTw fq[4], ch[4];
+        const FrameCtx* fx = A.fctx + (mine ? ow : 0u);
+        if (mine) {
+            const FrameRow& r = A.frames[ow];
+            const uint32_t* iq = A.iq + A.caps[r.capture].offset;
+            const uint32_t p0 = r.data_start + 80u * (slot - r.slot0) + 8u;
+#pragma unroll
+            for (int m = 0; m < 4; m++) raw[m] = iq[(size_t)(p0 + (uint32_t)(e + 16 * m)) * A.str];
+        }
+#pragma unroll
+        for (int m = 0; m < 4; m++) { fq[m] = pk_tw_mul(mine ? fx->freq[e + 16 * m] : 0u); ch[m] = pk_tw_mul(mine ? fx->chan[4 * e + m] : 0u); }
+        uint32_t o[4];
+        sym_front_quad(raw, fq, ch, sl, e, W, wsync, o);
+        if (mine) store(slot, o);
+    }
+}
+
+// The loop-carried part (freqoffset.hpp:28-30, pilot.hpp:166-233): pilot k of a frame in lane 4 f + k, sixteen frames per wave, every
+// frame stepping through its own symbols; the four angles of a frame meet through quad broadcasts.
+__global__ void __launch_bounds__(256) k_track(RxArgs A)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, pk = lane & 3;
+    const Tables& T = A.T;
+    const JobRef jr = locate_job((blockIdx.x * 4u + (uint32_t)w) * 16u + (uint32_t)(lane >> 2), A.njobs);
+    const uint32_t j = jr.ok ? jr.list * A.nrows + jr.idx : 0u;
+    const uint32_t f = jr.ok ? A.joblist[j] : 0u;
+    FrameRow r = A.frames[f];
+    const int nsym = jr.ok ? (int)r.nsym : 0;
+    if (jr.ok && pk == 0) {
+        VitJob J;
+        J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+        J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
+        A.jobs[j] = J;
+    }
+    // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
+    const int pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
+    int cfo_comp = r.cfo_comp, sfo_comp = r.sfo_comp, cfo_tr = r.cfo_tracker, sfo_tr = r.sfo_tracker;
+    unsigned symbol_count = 0;                                                   // 127 -> 0 after the SIGNAL symbol
+    int nmax = nsym;
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    const uint32_t* pp = A.pil + (size_t)(r.slot0 + 1u) * 4u + (uint32_t)pk;    // pilot k of data symbol s at pp[4 (s - 1)]: 16 bytes per symbol and frame (k_sym_front)
+    TrackRec* trk = A.track + r.slot0 + 1u;
+    constexpr int kAhead = 4;                                                    // symbols requested ahead of the one in the chain (each step is two dependent table reads long)
+    uint32_t q[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; i++) q[i] = i < nsym ? pp[4 * i] : 0u;
+    for (int s = 1; s <= nmax; s++) {
+        const uint32_t cur = q[0];
+#pragma unroll
+        for (int i = 0; i + 1 < kAhead; i++) q[i] = q[i + 1];
+        q[kAhead - 1] = s + kAhead <= nsym ? pp[4 * (s + kAhead - 1)] : 0u;
+        if (s <= nsym) {                                                         // (uniform inside a quad: the cross-lane reads below see their whole quad)
+            const cpx p = mul_q15(unpack(cur), rot_coeff(T, w16(cfo_comp + pc * sfo_comp)));
+            int th = pk == 3 ? uatan2(T, -p.im, -p.re) : uatan2(T, p.im, p.re);
+            if (pilot_sgn(symbol_count)) th = w16(th + 0x8000);
+            symbol_count++; if (symbol_count >= 127) symbol_count = 0;
+            // The four angles of the quad, in every lane.  Written as assembler on purpose: with __builtin_amdgcn_update_dpp the compiler folds two of
+            // the broadcasts into the arithmetic that follows (v_add_u32_dpp / v_subrev_u32_dpp writing the register it reads through the DPP
+            // selector) and `del` comes out a few LSB off -- reproduced in round 4 (tools/dbg_arrays.py), the same fault round 3 noted in k_frame.
+            // (s_nop 1: a VALU write of th followed by a DPP read needs two wait states, and the hazard pass does not look into assembler.)
+            int th1, th2, th3, th4;
+            asm volatile("s_nop 1\n\t"
+                         "v_mov_b32_dpp %0, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %2, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                         : "=&v"(th1), "=&v"(th2), "=&v"(th3), "=&v"(th4) : "v"(th));
+            const int avg = w16((th1 + th2 + th3 + th4) / 4);
+            const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+#ifdef SORA_DBG_TRACK_TH
+            if (pk == 0) { TrackRec t; t.cfo_comp = (int16_t)th1; t.sfo_comp = (int16_t)th2; t.avg = (int16_t)th3; t.del = (int16_t)th4; trk[s - 1] = t; }
+#else
+            if (pk == 0) { TrackRec t; t.cfo_comp = (int16_t)cfo_comp; t.sfo_comp = (int16_t)sfo_comp; t.avg = (int16_t)avg; t.del = (int16_t)del; trk[s - 1] = t; }
+#endif
+            cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
+            cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
+        }
+    }
+}
+
+// TPhaseCompensate + TPilotTrack::_rotate + T11aDemap for one group's symbol (3 data carriers per lane, 16 lanes per symbol): the three bins v3
+// (carriers e, e + 16, e + 32 in demap order) x CompCoeffs(cfo, sfo) x rotation(avg, del) -> soft values in carrier order at `dst`.
+__device__ __forceinline__ void sym_back_demap(const Tables& T, const uint8_t* s_demap, const uint32_t v3[3], TrackRec tr, int nb, int e, uint8_t* dst)
+{
+    cpx c1[3], c2[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) {                                                // all six coefficient reads in flight together
+        const int bin = carrier_bin48(e + 16 * m);
+        const int c = bin < 32 ? bin : bin - 64;
+        c1[m] = rot_coeff(T, w16((int)tr.cfo_comp + c * (int)tr.sfo_comp));
+        c2[m] = rot_coeff(T, w16((int)tr.avg + c * (int)tr.del));
+    }
+#pragma unroll
+    for (int m = 0; m < 3; m++) {
+        const int k = e + 16 * m;
+        cpx v = mul_q15(unpack(v3[m]), c1[m]);
+        v = mul_q15(v, c2[m]);
+        int re = v.re >> 4, im = v.im >> 4;                                       // demap_limit<64> (demapper.h:141-151)
+        re = min(max(re, -128), 127); im = min(max(im, -128), 127);
+        const unsigned ur = (unsigned)re & 0xFF, ui = (unsigned)im & 0xFF;
+        uint8_t* o = dst + k * nb;                                                // DemapperCore::Demap<N_BPSC> (demapper.h:16-45)
+        if (nb == 1) { o[0] = s_demap[ur]; }
+        else if (nb == 2) { o[0] = s_demap[ur]; o[1] = s_demap[ui]; }
+        else if (nb == 4) { o[0] = s_demap[ur]; o[1] = s_demap[256 + ur]; o[2] = s_demap[ui]; o[3] = s_demap[256 + ui]; }
+        else { o[0] = s_demap[ur]; o[1] = s_demap[512 + ur]; o[2] = s_demap[768 + ur];
+               o[3] = s_demap[ui]; o[4] = s_demap[512 + ui]; o[5] = s_demap[768 + ui]; }
+    }
+}
+
+// ... then T11aDeinterleave + the packed three-bit stream, a symbol at a time across the wave (eight values -> three bytes per lane).
+__global__ void __launch_bounds__(256) k_sym_back(RxArgs A)
+{
+    __shared__ uint8_t s_soft[4][4][288];                                        // [wave][group]: soft values in carrier order
+    __shared__ uint8_t s_demap[1024];                                            // DemapperCore step tables
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
+    const Tables& T = A.T;
+    reinterpret_cast<uint32_t*>(s_demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(T.demap)[threadIdx.x];
+    __syncthreads();                                                             // the only block barrier: the waves are independent from here on
+    const uint32_t slot_first = (blockIdx.x * 4u + (uint32_t)w) * (4u * kSlotIters);
+    if (slot_first >= A.total_slots) return;
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    const uint32_t my_slot = slot_first + (uint32_t)(lane & 15);
+    const uint32_t my_own = (lane < 16 && my_slot < A.total_slots) ? A.slot_row[my_slot] : 0xFFFFFFFFu;
+    const unsigned long long owned = __ballot(my_own != 0xFFFFFFFFu);
+    if (owned == 0) return;
+    const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)my_own, __builtin_ctzll(owned));
+    const bool one_frame = __ballot(lane < 16 && my_own != 0xFFFFFFFFu && my_own != row0) == 0;
+    int bins[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) bins[m] = carrier_bin48(e + 16 * m);
+    if (one_frame) {
+        // ---- one frame: modulation, stream position and de-interleaver entries once per wave; the loads of all four quads up front
+        const FrameRow& r = A.frames[row0];
+        const int nb = __builtin_amdgcn_readfirstlane((int)r.nbpsc), ncbps = 48 * nb;
+        const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)r.slot0), sym_bytes = 3u * (uint32_t)ncbps / 8u;
+        uint8_t* stream = A.soft + (size_t)slot0 * kSoftBytesPerSlot;
+        const bool packs = 8 * lane < ncbps;
+        uint32_t mp[4];
+        {
+            const uint16_t* map = T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
+#pragma unroll
+            for (int t = 0; t < 4; t++) mp[t] = packs ? (uint32_t)map[8 * lane + 2 * t] | ((uint32_t)map[8 * lane + 2 * t + 1] << 16) : 0u;
+        }
+        TrackRec tr[kSlotIters]; uint32_t v3[kSlotIters][3];
+#pragma unroll
+        for (int it = 0; it < kSlotIters; it++) {
+            const uint32_t slot = slot_first + 4u * it + (uint32_t)g;
+            const bool mine = (owned >> (4 * it + g)) & 1ull;
+            tr[it] = mine ? A.track[slot] : TrackRec{ 0, 0, 0, 0 };
+#pragma unroll
+            for (int m = 0; m < 3; m++) v3[it][m] = mine ? A.eq[(size_t)slot * 64u + (uint32_t)bins[m]] : 0u;
+        }
+#pragma unroll
+        for (int it = 0; it < kSlotIters; it++) {
+            const unsigned quad = (unsigned)(owned >> (4 * it)) & 0xFu;
+            if (quad == 0) continue;                                             // (wave-uniform)
+            if ((quad >> g) & 1u) sym_back_demap(T, s_demap, v3[it], tr[it], nb, e, s_soft[w][g]);
+            wsync();
+#pragma unroll
+            for (int gs = 0; gs < 4; gs++) {
+                if (!((quad >> gs) & 1u) || !packs) continue;
+                const uint32_t sg = slot_first + 4u * it + (uint32_t)gs;         // data symbol sg - slot0 of the frame
+                const uint8_t* src = s_soft[w][gs];
+                uint32_t v[8];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { v[2 * t] = src[mp[t] & 0xFFFFu]; v[2 * t + 1] = src[mp[t] >> 16]; }
+                soft3_store8(stream + (size_t)(sg - slot0 - 1u) * sym_bytes, (uint32_t)lane, soft3_pack8(v));
+            }
+            wsync();
+        }
+        return;
+    }
+    // ---- several frames meet in these 16 slots: per group and quad
+    int cur_nb = 0; uint32_t mp[4] = { 0, 0, 0, 0 };                             // de-interleaver entries of output positions 8 lane .. 8 lane + 7 for modulation cur_nb
+#pragma unroll 1
+    for (int it = 0; it < kSlotIters; it++) {
+        const unsigned quad = (unsigned)(owned >> (4 * it)) & 0xFu;
+        if (quad == 0) continue;
+        const uint32_t ow = (uint32_t)__shfl((int)my_own, 4 * it + g);
+        const bool mine = ow != 0xFFFFFFFFu;
+        const uint32_t slot = slot_first + 4u * it + (uint32_t)g;
+        int nb = 0; uint32_t slot0 = 0;
+        if (mine) {
+            const FrameRow& r = A.frames[ow];
+            nb = r.nbpsc; slot0 = r.slot0;
+            uint32_t v3[3];
+#pragma unroll
+            for (int m = 0; m < 3; m++) v3[m] = A.eq[(size_t)slot * 64u + (uint32_t)bins[m]];
+            sym_back_demap(T, s_demap, v3, A.track[slot], nb, e, s_soft[w][g]);
+        }
+        wsync();
+#pragma unroll 1
+        for (int gs = 0; gs < 4; gs++) {
+            if (!((quad >> gs) & 1u)) continue;
+            const int nbg = __shfl(nb, 16 * gs);
+            const uint32_t slot0g = (uint32_t)__shfl((int)slot0, 16 * gs);
+            const int ncbps = 48 * nbg;
+            if (nbg != cur_nb) {
+                cur_nb = nbg;
+                const uint16_t* map = T.deint + (nbg == 1 ? 0 : nbg == 2 ? 1 : nbg == 4 ? 2 : 3) * 288;
+                const bool packs = 8 * lane < ncbps;
+#pragma unroll
+                for (int t = 0; t < 4; t++) mp[t] = packs ? (uint32_t)map[8 * lane + 2 * t] | ((uint32_t)map[8 * lane + 2 * t + 1] << 16) : 0u;
+            }
+            if (8 * lane < ncbps) {
+                const uint32_t sg = slot_first + 4u * it + (uint32_t)gs;
+                uint8_t* d = A.soft + (size_t)slot0g * kSoftBytesPerSlot + (size_t)(sg - slot0g - 1u) * (3u * (uint32_t)ncbps / 8u);
+                const uint8_t* src = s_soft[w][gs];
+                uint32_t v[8];
+#pragma unroll
+                for (int t = 0; t < 4; t++) { v[2 * t] = src[mp[t] & 0xFFFFu]; v[2 * t + 1] = src[mp[t] >> 16]; }
+                soft3_store8(d, (uint32_t)lane, soft3_pack8(v));
+            }
+        }
+        wsync();
+    }
+}
+
 // (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
 struct VitSide {            // wave-uniform per-frame bookkeeping
     uint8_t* out; uint32_t nsteps, tr_end; bool done;

@@ -23,6 +23,7 @@ struct ScanArgs {
     uint32_t*       joblist;    // [3][nrows] their frame-table rows, compacted: consecutive workgroups of the per-frame
                                 //            kernels then carry live work (workgroup b runs on XCD b % 8)
     uint32_t        nrows;      // list stride = ncaps * max_frames
+    uint32_t*       slot_row;   // [total slots] frame-table row that owns a symbol slot (the data symbols of every queued frame); the host presets 0xFFFFFFFF
 };
 
 struct RxArgs {
@@ -40,10 +41,17 @@ struct RxArgs {
     VitJob*         jobs;           // [3][nrows] (indexed by job); unused by the fused decode kernel
     const uint32_t* njobs;
     const uint32_t* joblist;
+    const uint32_t* slot_row;       // [total_slots] owner row of a symbol slot, 0xFFFFFFFF = none (k_scan)
+    uint32_t*       eq;             // [total_slots][64] equalised bins, packed COMPLEX16 (k_sym_front -> k_track, k_sym_back)
+    TrackRec*       track;          // [total_slots] rotation parameters of a data symbol (k_track -> k_sym_back)
+    uint32_t*       pil;            // [total_slots][4] the four pilot bins (43, 57, 7, 21) of eq[] once more, densely: all k_track reads
 };
 
 __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
+__global__ void k_sym_front(RxArgs A);
+__global__ void k_track(RxArgs A);
+__global__ void k_sym_back(RxArgs A);
 __global__ void k_decode(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);

@@ -269,6 +269,7 @@ struct RxPipe {
     // device arrays
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
     uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
+    uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;   // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip)
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
@@ -313,7 +314,7 @@ static void rx_free(RxPipe* rx)
 {
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes,
-                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump };
+                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -437,6 +438,14 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMalloc((void**)&rx->d_soft, (size_t)kSoftBytesPerSlot * rx->cap_slots + kSoftSlack));   // three bits per soft value (rx_types.h)
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
+    if (!rx->d_slot_row) {
+        HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
+#ifdef SORA_FRAME_SPLIT3
+        HIPCHK(hipMalloc((void**)&rx->d_eq, 256 * ((size_t)rx->cap_slots + 64)));
+        HIPCHK(hipMalloc((void**)&rx->d_track, sizeof(TrackRec) * ((size_t)rx->cap_slots + 64)));
+        HIPCHK(hipMalloc((void**)&rx->d_pil, 16 * ((size_t)rx->cap_slots + 64)));
+#endif
+    }
     hipStream_t st = rx->stream;
     const bool prof = rx->profiling;
     if (prof) { const int rc = fold_profile(rx); if (rc) return rc; }
@@ -457,10 +466,11 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
         HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
         HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 12, st));
+        HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));        // no symbol slot has an owner yet
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows;
+        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = rx->d_slot_row;
         mark();
         hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
@@ -477,8 +487,16 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         } else
 #endif
         {
-            R.soft = rx->d_soft; R.jobs = rx->d_jobs;
+            R.soft = rx->d_soft; R.jobs = rx->d_jobs; R.slot_row = rx->d_slot_row; R.eq = rx->d_eq; R.track = rx->d_track; R.pil = rx->d_pil;
+#ifdef SORA_FRAME_SPLIT3                                                         // build variant (A/B, round 4): the symbol chain as three kernels (k_rx.hip) -- per symbol slot in front of and behind
+            // the tracker, per frame (four lanes each) for the tracker.  Measured and NOT adopted (profiles/r04_h_*): 10 M fewer instructions per call, but the equalised
+            // symbols' round trip through HBM makes the two symbol kernels as long as k_frame, and a lone call pays three launches instead of one.
+            hipLaunchKernelGGL(k_sym_front, dim3((slots + 63) / 64), dim3(256), 0, st, R);
+            hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
+            hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
+#else
             hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+#endif
             mark();
             if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
                 hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
@@ -809,6 +827,19 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
+}
+
+// Test / tool hook (not part of the ABI in include/sora_hip.h): the device arrays between the kernels of the most recent call, for
+// stage-by-stage comparisons (tools/dbg_arrays.py).  out[] = { frames, slot_row, eq, track, soft, jobs, joblist, njobs }; *slots = symbol slots of the call.
+int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, uint32_t* nrows)
+{
+    if (!rx || !out) return SORA_ERR_INVALID_PARAM;
+    RxPipe* p = rx->pipes[rx->cur];
+    if (!p) return SORA_ERR_FAILED;
+    out[0] = p->d_frames; out[1] = p->d_slot_row; out[2] = p->d_eq; out[3] = p->d_track; out[4] = p->d_soft; out[5] = p->d_jobs; out[6] = p->d_joblist; out[7] = p->d_njobs;
+    if (slots) *slots = p->total_slots;
+    if (nrows) *nrows = p->ncaps * p->cfg.max_frames_per_capture;
+    return SORA_OK;
 }
 
 int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
