@@ -390,7 +390,12 @@ int   sora_ht40_calls_in_flight(sora_ht40_t* rx);              /* how many calls
 int   sora_ht40_wait(sora_ht40_t* rx, int ticket);
 void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket);
 int   sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
-int   sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);    /* as sora_rx11b_deliver_async: two rows per frame */
+/* As sora_rx11b_deliver_async, two rows per RECORDED frame (one per spatial stream).  Unlike sora_ht40_results_of -- and unlike the 802.11b /
+ * 802.11n handles' delivery -- a raw-capture call delivers ONLY the decoded frames this way: an event that ended in the front end (an HT-SIG
+ * whose CRC-8 fails, an unsupported MCS: E_ERROR_PLCP_HEADER_FAIL, no PSDU) has no row in the delivered table, and the SORA_ROW_TRUNCATED flag
+ * of a capture with more frames than max_frames_per_capture is not carried.  A host that needs those collects the call with
+ * sora_ht40_results_of(ticket), which reports one row per event in (capture, time) order. */
+int   sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------
  * Multi-GPU sharding for a C host.  Captures are independent -- the reference resets its context per
@@ -467,7 +472,10 @@ int   sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out
 /* Result delivery without a host wait (as sora_rx_deliver_async): behind the call's kernels, on its stream, the dense rows in (capture, time)
  * order -- h_rows must have room for captures x max_frames_per_capture of them --, h_counts[0] = rows, h_counts[1] = MPDU bytes, and the MPDUs
  * densely packed in row order (the rows' mpdu_offset indexes h_mpdu; an MPDU that would reach past mpdu_cap is left out and h_counts[1] says
- * so).  Page-locked buffers (sora_hip_host_alloc); valid once sora_rx11b_wait(ticket) has returned.  h_mpdu may be NULL. */
+ * so).  Page-locked buffers (sora_hip_host_alloc); valid once sora_rx11b_wait(ticket) has returned.  h_mpdu may be NULL.
+ * The copies are enqueued before the call's sizes are known to the host, so they move the WHOLE of what the caller offers -- max
+ * captures x frames rows and all mpdu_cap bytes, every call: give mpdu_cap the size the traffic needs (frames x MTU), not a worst case
+ * (rows x 4096 costs tens of MB over the host link per call and delivers stale bytes behind h_counts[1]). */
 int   sora_rx11b_deliver_async(sora_rx11b_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------

@@ -662,6 +662,8 @@ class RxHt40:
         t = self._L.sora_ht40_ticket(self._h)
         self._n = len(arr) * int(max_frames_per_capture)
         self._nof = getattr(self, "_nof", {}); self._nof[t] = self._n
+        for old in [k for k in self._nof if k <= t - 8]:                        # (tickets older than the handle's eight slots are gone: process_dev prunes the same way)
+            del self._nof[old]
         return t
 
     def ticket(self):
