@@ -111,6 +111,24 @@ int  sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_sam
  * sora_hip_ingest_count(dump_bytes, flags), at the handle's sample_rate_mhz).  The host buffer must stay untouched until the call has
  * completed (sora_rx_wait).  Ticket, results and delivery as for sora_rx_process_dev. */
 int  sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, unsigned ingest_flags, const sora_capture_desc* h_caps, size_t ncaps);
+/* Stream continuation (the live-source case: TRxStream hands the graph an endless stream, brick/inc/rxstream.hpp:34-66, and the graph's
+ * state -- the DC estimate, which integrates for ever (dc.hpp:92-166), the carrier-sense windows and counters (cca.hpp:126-158) -- carries
+ * over from one read to the next).  With sora_rx_set_stream_mode(rx, 1) capture k of a process call CONTINUES capture k of the call before it:
+ *   - after a call, sora_rx_stream_consumed(rx, ticket, h, n) gives, per capture, the RESUME POINT: the number of input-rate samples of that
+ *     capture that are final (a position where a burst boundary of the graph falls on a source-call boundary while it is in plain carrier
+ *     sense; 0 if the capture holds none).  Every frame the call reported ends in front of it; a frame that was still running when the
+ *     capture ended lies behind it and has NOT been reported;
+ *   - the host builds the next call's capture k from the stream FROM THAT POINT on: the unconsumed tail of what it submitted plus whatever
+ *     has arrived since (each capture still a whole number of 28-sample source bursts; 14 at 20 MHz).  The library starts it with the state
+ *     the graph had at the resume point, so the rows of all the calls together (positions are relative to their own capture: add the
+ *     stream position of its first sample) are exactly the events the graph reports on the uncut stream -- tests/test_gpu_stream.py holds a
+ *     40 MHz stream cut at arbitrary 28-sample boundaries to the compiled reference graph's events on the whole;
+ *   - calls of a handle in stream mode run one after the other (a process call first waits for the one before it: it needs its records);
+ *     throughput comes from many streams (captures) per call.  sora_rx_reset, and switching the mode, start every stream afresh.  Not
+ *     available for sample_rate_mhz = 44 (SORA_E_NOT_SUPPORTED).  Returns the previous mode; a negative argument only queries. */
+int  sora_rx_set_stream_mode(sora_rx_t* rx, int enable);
+int  sora_rx_stream_consumed(sora_rx_t* rx, int ticket, uint32_t* h_consumed, size_t ncaps);
+
 /* TBB11aFrameSink's frame buffer + CF_Error per frame: copies results of the last process call to the host.
  * h_mpdu may be NULL (descriptors only).  *nout = rows written. Frames appear in (capture, time) order. */
 int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);

@@ -51,7 +51,7 @@ class Ht40Frame(ctypes.Structure):
 
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
-           "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process_dump", "sora_rx_process", "sora_rx_results",
+           "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process_dump", "sora_rx_set_stream_mode", "sora_rx_stream_consumed", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
            "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
@@ -117,6 +117,8 @@ def load(build_if_missing=True):
     L.sora_rx_kernel_times.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_float), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx_kernel_name.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name.restype = ctypes.c_char_p
     L.sora_rx_set_depth.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_set_stream_mode.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_stream_consumed.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx_process_dump.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_uint, ctypes.POINTER(CaptureDesc), ctypes.c_size_t]
     L.sora_rx_set_fused.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
@@ -297,6 +299,19 @@ class Rx:
         arr, ptr = self._caps(captures)
         _check(self._L.sora_rx_process(self._h, a.ctypes.data, len(a), ptr, len(arr)))
         return self._L.sora_rx_ticket(self._h)
+
+    def set_stream_mode(self, enable=-1):
+        """1: capture k of a call continues capture k of the call before it (sora_hip.h: stream continuation); returns the previous mode"""
+        r = int(self._L.sora_rx_set_stream_mode(self._h, int(enable)))
+        if r not in (0, 1):
+            raise SoraError(r, (self._L.sora_hip_last_error() or b"").decode())
+        return r
+
+    def stream_consumed(self, ticket, ncaps):
+        """per capture of the most recent call: input-rate samples that are final = where the next call's capture must start in the stream"""
+        out = np.zeros(ncaps, np.uint32)
+        _check(self._L.sora_rx_stream_consumed(self._h, int(ticket), out.ctypes.data, int(ncaps)))
+        return out
 
     def process_dump(self, h_dump, flags, captures):
         """h_dump: the raw dump bytes in host memory -- a numpy uint8 array or a (pinned) torch CPU uint8 tensor, untouched until the call has

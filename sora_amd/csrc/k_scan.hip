@@ -307,6 +307,39 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     cs_reset();
     auto sync = []() { __syncthreads(); };
 
+    // ---- stream continuation (sora_rx_set_stream_mode; TRxStream hands the graph an endless stream, rxstream.hpp:34-66: the DC estimate of
+    // dc.hpp:92-166 integrates for ever, the carrier-sense windows and counters carry over from read to read).  A RESUME POINT is a position
+    // where a burst boundary falls on a source-call boundary while the graph is in plain carrier sense (no detection under way, no event
+    // pending): everything the graph knows there is the record below.  The capture's last resume point is published (A.consumed) and its
+    // record kept; the next call's capture k starts AT that point of the stream and the record is its initial state -- so what the graph
+    // reports from there on is what it reports on the uncut stream, and a frame cut by the end of a capture is simply found again.
+    uint32_t* const crec = A.cont ? A.cont + (size_t)cap_i * kContWords : nullptr;
+    constexpr uint32_t kContMagic = 0x534F5241u;
+    auto elem = [&](uint32_t Z, int l) { return (uint32_t)__shfl((int)Z, 4 * (l & 3)); };   // window element (l & 3) sits in lanes 4 (l & 3) ..
+    auto cont_save = [&](uint32_t at) {
+        const int l = lane;
+        const uint32_t zr = elem(ac_re.Z, l), zi = elem(ac_im.Z, l), ze = elem(energy.Z, l), hv = (uint32_t)__shfl((int)Hv, l & 15);
+        uint32_t v = l < 16 ? hv : l < 20 ? zr : l < 24 ? zi : l < 28 ? ze : 0u;
+        const uint32_t sc[16] = { (uint32_t)ac_re.reg, (uint32_t)ac_im.reg, (uint32_t)energy.reg, sense_count, high_count, (uint32_t)peak_corr, (uint32_t)peak_index, dc_cnt,
+                                  (uint32_t)sum_dc_re, (uint32_t)sum_dc_im, (uint32_t)dc_re, (uint32_t)dc_im, at, kContMagic, 0u, 0u };
+#pragma unroll
+        for (int k = 0; k < 16; k++) if (l == 28 + k) v = sc[k];
+        crec[l] = v;
+        if (l == 0) A.consumed[cap_i] = at;
+    };
+    if (crec) {
+        if (lane == 0) A.consumed[cap_i] = 0;
+        const uint32_t v = crec[lane];
+        if ((uint32_t)__builtin_amdgcn_readlane((int)v, 41) == kContMagic) {       // a record exists: this capture continues a stream
+            auto sc = [&](int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 28 + k); };
+            Hv = (uint32_t)__shfl((int)v, lane & 15);
+            ac_re.Z = (uint32_t)__shfl((int)v, 16 + ((lane & 15) >> 2)); ac_im.Z = (uint32_t)__shfl((int)v, 20 + ((lane & 15) >> 2)); energy.Z = (uint32_t)__shfl((int)v, 24 + ((lane & 15) >> 2));
+            ac_re.reg = (int)sc(0); ac_im.reg = (int)sc(1); energy.reg = (int)sc(2); sense_count = sc(3); high_count = sc(4); peak_corr = (int)sc(5); peak_index = (int)sc(6);
+            dc_cnt = sc(7); sum_dc_re = (int)sc(8); sum_dc_im = (int)sc(9); dc_re = (int)sc(10); dc_im = (int)sc(11);
+        }
+    }
+    uint32_t last_saved = 0xFFFFFFFFu;
+
     // GetCrossCorrelation (cca.hpp:202-218) for pattern p: the reference starts at the oldest burst, i.e. h[0]
     auto cross_corr = [&](int p) -> int {
         int sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
@@ -465,10 +498,16 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     for (uint32_t c = 0; c < nchunks; c++) {
         const uint32_t avail_end = (c + 1) * APP;
         while (vpos + BUR <= avail_end) {
+            if (crec && !cca_detected && !sync_high && auto_count == 0 && error_code == 0 && vpos % APP == 0 && vpos != last_saved) { cont_save(vpos); last_saved = vpos; }
             if (!cca_detected && !sync_high && auto_count == 0) {
                 // bursts until the carrier-sense time-out is raised; if that is near, stay inside this source call
                 const uint32_t to_timeout = sense_count >= 84 ? 0u : (84u - sense_count + 3u) / 4u;
-                const uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
+                uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
+                if (crec) {                                                     // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen
+                    uint32_t j = 1;
+                    while ((vpos + j * BUR) % APP != 0) j++;
+                    room = min(room, j);
+                }
                 PROBE_T0();
                 const uint32_t took = fast_idle(min(min(room, dc_cnt + 1u), 8u));
                 PROBE_ADD(3);
@@ -643,6 +682,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         }
         PROBE_A(_tc, 7);
     }
+    if (crec && !cca_detected && !sync_high && auto_count == 0 && error_code == 0 && vpos % APP == 0 && vpos <= nunits && vpos != last_saved) cont_save(vpos);   // the capture ends in plain carrier sense: all of it is final
     if (lane == 0) A.nframes[cap_i] = nfr;
     PROBE_ADDK(5);
 }

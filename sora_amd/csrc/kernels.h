@@ -24,7 +24,11 @@ struct ScanArgs {
                                 //            kernels then carry live work (workgroup b runs on XCD b % 8)
     uint32_t        nrows;      // list stride = ncaps * max_frames
     uint32_t*       slot_row;   // [total slots] frame-table row that owns a symbol slot (the data symbols of every queued frame); the host presets 0xFFFFFFFF
+    // stream continuation (sora_rx_set_stream_mode): capture k of this call continues capture k of the call before it
+    uint32_t*       cont;       // [ncaps][kContWords] the carrier-sense state at the capture's last resume point (read at entry when valid, rewritten at every later one); null = off
+    uint32_t*       consumed;   // [ncaps] input-rate samples of this capture that are final: the host submits the stream from there on next time
 };
+constexpr int kContWords = 64;
 
 struct RxArgs {
     const uint32_t* iq;

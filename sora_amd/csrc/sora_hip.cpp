@@ -275,6 +275,7 @@ struct RxPipe {
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
+    uint32_t* cont = nullptr; uint32_t* consumed = nullptr;     // stream mode: the HANDLE's continuation records / resume points (not owned by the pipeline)
     sora_frame_result* d_rows = nullptr; uint32_t* d_nrows = nullptr;
     // last call.  Descriptors go up through a pinned staging buffer (a pageable source would make the "async" copy wait for
     // the stream to drain and expose every launch latency of the call) and only when they differ from the resident set.
@@ -470,7 +471,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = rx->d_slot_row;
+        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = rx->d_slot_row; S.cont = rx->cont; S.consumed = rx->consumed;
         mark();
         hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
@@ -688,6 +689,9 @@ struct sora_rx {
     bool fused = false;
     int seq = 0;                 // ticket of the most recent process call
     RxPipe* pipes[kMaxDepth] = {};
+    // stream mode (sora_rx_set_stream_mode): capture k of a call continues capture k of the call before it
+    bool stream_mode = false;
+    uint32_t* d_cont = nullptr; uint32_t* d_consumed = nullptr;
 };
 
 static RxPipe* pipe_of(sora_rx* rx, int ticket)
@@ -725,6 +729,8 @@ void sora_rx_destroy(sora_rx_t* rx)
 {
     if (!rx) return;
     for (RxPipe* p : rx->pipes) if (p) pipe_destroy(p);
+    if (rx->d_cont) (void)hipFree(rx->d_cont);
+    if (rx->d_consumed) (void)hipFree(rx->d_consumed);
     delete rx;
 }
 
@@ -781,6 +787,10 @@ int sora_rx_reset(sora_rx_t* rx)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     for (RxPipe* p : rx->pipes) if (p) { const int rc = pipe_reset(p); if (rc) return rc; }
+    if (rx->d_cont) {                                                            // ISource::Reset: every stream starts afresh
+        HIPCHK(hipMemset(rx->d_cont, 0, 4 * (size_t)kContWords * rx->cfg.max_captures));
+        HIPCHK(hipMemset(rx->d_consumed, 0, 4 * (size_t)rx->cfg.max_captures));
+    }
     return SORA_OK;
 }
 
@@ -793,12 +803,57 @@ int sora_rx_flush(sora_rx_t* rx)
 
 void* sora_rx_stream(sora_rx_t* rx) { return rx ? pipe_stream(rx->pipes[rx->cur]) : nullptr; }
 
+// Stream mode: a call continues the one before it, so that one must have finished with the records (its scan) before this one's scan reads
+// them -- the calls of a handle in stream mode run one after the other (the host needs the resume points of call n to assemble call n + 1 anyway).
+static int stream_prologue(sora_rx* rx, RxPipe* p)
+{
+    p->cont = nullptr; p->consumed = nullptr;
+    if (!rx->stream_mode) return SORA_OK;
+    for (RxPipe* q : rx->pipes) if (q) { const int rc = pipe_flush(q); if (rc) return rc; }
+    p->cont = rx->d_cont; p->consumed = rx->d_consumed; p->last_valid = false;
+    return SORA_OK;
+}
+
+int sora_rx_set_stream_mode(sora_rx_t* rx, int enable)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->stream_mode ? 1 : 0;
+    if (enable < 0) return old;
+    if (enable && rx->cfg.sample_rate_mhz == 44) return fail(SORA_E_NOT_SUPPORTED, "sora_rx_set_stream_mode: not for the 44 MHz graph (its resampler's queue is not part of the continuation record)");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    for (RxPipe* q : rx->pipes) if (q) { const int rc = pipe_flush(q); if (rc) return rc; }
+    if (enable && !rx->d_cont) {
+        HIPCHK(hipMalloc((void**)&rx->d_cont, 4 * (size_t)kContWords * rx->cfg.max_captures));
+        HIPCHK(hipMalloc((void**)&rx->d_consumed, 4 * (size_t)rx->cfg.max_captures));
+    }
+    if (rx->d_cont) {                                                            // switching either way starts every stream afresh
+        HIPCHK(hipMemset(rx->d_cont, 0, 4 * (size_t)kContWords * rx->cfg.max_captures));
+        HIPCHK(hipMemset(rx->d_consumed, 0, 4 * (size_t)rx->cfg.max_captures));
+    }
+    rx->stream_mode = enable != 0;
+    return old;
+}
+
+int sora_rx_stream_consumed(sora_rx_t* rx, int ticket, uint32_t* h_consumed, size_t ncaps)
+{
+    if (!rx || !h_consumed) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_stream_consumed: null argument");
+    if (!rx->stream_mode) return fail(SORA_ERR_FAILED, "sora_rx_stream_consumed: the handle is not in stream mode");
+    RxPipe* p = pipe_of(rx, ticket);
+    if (!p || ticket != rx->seq) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_stream_consumed: only the most recent call's resume points exist");
+    if (ncaps > p->ncaps) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_stream_consumed: more captures than the call had");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    HIPCHK(hipStreamSynchronize(p->stream));
+    if (ncaps) HIPCHK(hipMemcpy(h_consumed, rx->d_consumed, 4 * ncaps, hipMemcpyDeviceToHost));
+    return SORA_OK;
+}
+
 int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
     const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
+    { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
@@ -811,6 +866,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
+    { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
@@ -823,6 +879,7 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
+    { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
