@@ -27,10 +27,10 @@ import os
 import sys
 import time
 
-# The HIP runtime multiplexes streams onto GPU_MAX_HW_QUEUES hardware queues (default 4, one of them the null stream's): with the
-# default only three of the handle's pipelines run side by side whatever sora_rx_set_depth says (profiles/r03_e_timeline_*.txt);
-# eight calls in flight want at least twelve (profiles/r03_y_depth_and_queues.txt).
-# An application setting, made before the runtime starts; the library itself reads no environment variable.
+# The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues per stream-priority level (default 4).  Round 3's bench
+# set GPU_MAX_HW_QUEUES=16 before HIP started, because eight pipelines of one priority ran three at a time; since round 4 the library spreads a
+# handle's pipelines over the three priority levels (sora_internal_stream_create) and gets a hardware queue per pipeline by itself: the default
+# run sets NO environment variable (config.hw_queues = null; profiles/r04_m_stream_priorities.txt).  --hw-queues N still sets it, for A/B runs.
 def _early_hw_queues(argv):
     """--hw-queues N, read before the HIP runtime starts: N > 0 sets GPU_MAX_HW_QUEUES (unless the environment already does),
     0 leaves the runtime's default alone (`config.hw_queues` is then null)."""
@@ -44,7 +44,7 @@ def _early_hw_queues(argv):
 
 _HWQ = _early_hw_queues(sys.argv)
 if _HWQ is None:
-    _HWQ = 16
+    _HWQ = 0
 if _HWQ > 0:
     os.environ.setdefault("GPU_MAX_HW_QUEUES", str(_HWQ))
 
@@ -907,7 +907,7 @@ def main():
     ap.add_argument("--check", type=int, default=0, help="captures compared with the reference after the timed region (0 = all)")
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
-    ap.add_argument("--hw-queues", type=int, default=16, help="GPU_MAX_HW_QUEUES for this process (read before HIP starts); 0 = leave the runtime default")
+    ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (read before HIP starts); 0 = leave the runtime default")
     ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11b_cck, rx11n, rx11n_40) and print its object: for profiling that section alone")
     args = ap.parse_args()
 
@@ -1025,9 +1025,8 @@ def main():
     for k_ in ("t_submit", "t_wait", "t_check"):
         stats[k_] = 0.0
     t0 = time.perf_counter()
-    for _ in range(repeats):
-        run_block(args.steps, deliver)
-    rx.flush()
+    run_block(args.steps * repeats, deliver)                        # ONE continuous run of K x repeats steps: the calls in flight are collected at its end only
+    rx.flush()                                                      # (round 3 drained the handle after every K steps: with K = 20 and eight calls in flight a fifth of the region was fill and drain)
     chk.drain()                                                     # every delivered table has been compared when the clock stops
     barrier()
     t1 = time.perf_counter()
@@ -1077,8 +1076,7 @@ def main():
                 run_block(args.warmup, deliver, dval); rx.flush(); chk.drain(); bad0 = chk.bad
                 nblk = max(1, repeats // 6)
                 tp0 = time.perf_counter()
-                for _ in range(nblk):
-                    run_block(args.steps, deliver, dval)
+                run_block(args.steps * nblk, deliver, dval)
                 rx.flush(); chk.drain()
                 ms_p = (time.perf_counter() - tp0) / (nblk * args.steps) * 1e3
                 plain["calls_in_flight_%d_%s" % (dval, tname[l])] = {"ms_per_step": round(ms_p, 4), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms_p / 1e3, 1),
@@ -1128,7 +1126,7 @@ def main():
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "calls_in_flight": depth, "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
-                       "timed_region": "%d x %d steps; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
+                       "timed_region": "%d x %d steps in one continuous run; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "gathered": gathered, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,

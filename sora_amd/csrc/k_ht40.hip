@@ -427,7 +427,7 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
     const size_t nj = 2 * (size_t)max_frames;
     hipError_t e = (sora_internal_tables(device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK) ? hipSuccess : hipErrorUnknown;
     for (Ht40Slot& S : rx->slot) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = sora_internal_stream_create(&S.stream, (int)(&S - &rx->slot[0]));
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_frames, sizeof(Ht40Frame) * max_frames);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_jobs, 3 * sizeof(VitJob) * nj);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_njobs, 16);

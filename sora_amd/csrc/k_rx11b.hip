@@ -978,7 +978,7 @@ int sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out)
     const size_t rows = (size_t)cfg->max_captures * cfg->max_frames_per_capture;
     hipError_t e = rx->d_crc ? hipSuccess : hipErrorUnknown;
     for (Slot11b& S : rx->slot) {
-        if (e == hipSuccess) e = hipStreamCreateWithFlags(&S.stream, hipStreamNonBlocking);
+        if (e == hipSuccess) e = sora_internal_stream_create(&S.stream, (int)(&S - &rx->slot[0]));
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_caps, sizeof(CapDesc) * cfg->max_captures);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * rows);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_nframes, 4 * (size_t)cfg->max_captures);

@@ -1197,12 +1197,12 @@ static void rx11n_free(sora_rx11n_t* rx)
     (void)hipFree(rx->d_iq_own[0]); (void)hipFree(rx->d_iq_own[1]);
     delete rx;
 }
-static hipError_t pipe11n_create(sora_rx11n_t* rx, Pipe11n** out)
+static hipError_t pipe11n_create(sora_rx11n_t* rx, Pipe11n** out, int index = 0)
 {
     const sora_rx_cfg* cfg = &rx->cfg;
     const size_t rows = (size_t)cfg->max_captures * cfg->max_frames_per_capture;
     Pipe11n* p = new Pipe11n();
-    hipError_t e = hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking);
+    hipError_t e = sora_internal_stream_create(&p->stream, index);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_caps, sizeof(CapDesc) * cfg->max_captures);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_rows, sizeof(Rx11bRow) * rows);
     if (e == hipSuccess) e = hipMalloc((void**)&p->d_nframes, 4 * (size_t)cfg->max_captures);
@@ -1260,7 +1260,7 @@ int sora_rx11n_set_depth(sora_rx11n_t* rx, int depth)
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
     for (int i = 0; i < depth; i++)
-        if (!rx->pipes[i]) { const hipError_t e = pipe11n_create(rx, &rx->pipes[i]); if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_set_depth: device allocation", (int)e); }
+        if (!rx->pipes[i]) { const hipError_t e = pipe11n_create(rx, &rx->pipes[i], i); if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_set_depth: device allocation", (int)e); }
     // a shrink keeps the most recent call addressable: its pipeline moves into the surviving range (the tickets of the pipelines that
     // fall outside it become stale, as the header says)
     if (rx->cur >= depth) { std::swap(rx->pipes[0], rx->pipes[rx->cur]); rx->cur = 0; }

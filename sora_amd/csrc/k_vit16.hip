@@ -60,7 +60,8 @@ template <int WIN, int LOOK> struct Lds16 {
     union {
         uint32_t udump[4][64];                                                  // the metrics registers at a trace-back (the start state's unfinished block)
         uint16_t ops[4][24][2];                                                 // [row][operand of the chunk][frame]: the soft values as metric fields -- live only inside
-    };                                                                          //   forward16's unpack(), never across a trace-back: the two share their bytes
+        uint16_t ops2[2][4][24][2];                                             //   forward16's unpack() / the fast loop's two alternating tables, never across a trace-back:
+    };                                                                          //   they share their bytes with the trace-back's register dump
     uint8_t  path[8][Geom16<WIN, LOOK>::kPathBytes];                             // [row * 2 + frame][walk position]: the bytes along the traced path
 };                                                                              // 20288 / 17216 bytes: eight one-wave workgroups per CU (20480 each)
 
@@ -339,6 +340,35 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
         for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
         tr += 12;
     };
+    // The fast loop's operand hand-over, off the critical path (round 4).  unpack() writes a chunk's fields, reads the row's table back and uses the
+    // operands at once: one LDS round trip per 12 steps sits in a lone wave's dependence chain (SQ_WAIT_ANY 21 % of its cycles,
+    // profiles/r04_a_sq_counters_alone.json).  Here chunk c + 1's fields are written at the START of chunk c into the other of two tables and read
+    // back in the MIDDLE of chunk c: by the time chunk c + 1 begins its operands have long been in registers.
+    uint16_t* my_ops2[2] = { &S.ops2[0][row][my_j][half], &S.ops2[1][row][my_j][half] };
+    const uint4* row_ops2[2] = { reinterpret_cast<const uint4*>(&S.ops2[0][row][0][0]), reinterpret_cast<const uint4*>(&S.ops2[1][row][0][0]) };
+    auto stage = [&](const Raw& R, int t) {
+#pragma unroll
+        for (int v = 0; v < NV; v++) my_ops2[t][16 * v] = (uint16_t)cur[v].field(R.r[v]);
+    };
+    auto collect = [&](int t) -> Chunk {
+        lds_fence();
+        Chunk K;
+#pragma unroll
+        for (int i = 0; i < (CW + 3) / 4; i++) {
+            const uint4 x = row_ops2[t][i];
+            K.v[4 * i] = x.x; K.v[4 * i + 1] = x.y;
+            if (4 * i + 2 < CW) { K.v[4 * i + 2] = x.z; K.v[4 * i + 3] = x.w; }
+        }
+        return K;
+    };
+    auto fast_chunk_mid = [&](const Chunk& K, int h, Chunk& Knext, int tnext) {
+#pragma unroll
+        for (int g = 0; g < 12 / GS; g++) {
+            if (g == (12 / GS) / 2) Knext = collect(tnext);
+            group(K, h, g * GS);
+        }
+        tr += 12;
+    };
     auto slow_chunk = [&](const Chunk& K, int h) {
 #pragma unroll
         for (int g = 0; g < 12 / GS; g++) {
@@ -358,14 +388,22 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     while (tr < nsteps && !all_done) {
         const uint32_t lim = min(nsteps, next_thr - 1);
         uint32_t rows = lim > tr ? (lim - tr) / 24 : 0;                         // rows that certainly need no look at the schedule
-        for (; rows >= 2; rows -= 2) {
-            b2 = fetch(c + 2); fast_chunk(unpack(b0), 0);
-            b3 = fetch(c + 3); fast_chunk(unpack(b1), 1);
-            end_row();
-            b0 = fetch(c + 4); fast_chunk(unpack(b2), 0);
-            b1 = fetch(c + 5); fast_chunk(unpack(b3), 1);
-            end_row();
-            c += 4;
+        if (rows >= 2) {
+            // invariant at the top of a turn: Ka = chunk c's operands (in registers), b1 / b2 = the raw values of chunks c + 1 / c + 2 (requested)
+            Chunk Ka, Kb;
+            b2 = fetch(c + 2);
+            stage(b0, 0); Ka = collect(0); lds_fence();
+            for (; rows >= 2; rows -= 2) {
+                b3 = fetch(c + 3); stage(b1, 1); fast_chunk_mid(Ka, 0, Kb, 1);
+                b0 = fetch(c + 4); stage(b2, 0); fast_chunk_mid(Kb, 1, Ka, 0);
+                end_row();
+                b1 = fetch(c + 5); stage(b3, 1); fast_chunk_mid(Ka, 0, Kb, 1);
+                b2 = fetch(c + 6); stage(b0, 0); fast_chunk_mid(Kb, 1, Ka, 0);
+                end_row();
+                c += 4;
+            }
+            lds_fence();                                                        // (the tables share their bytes with unpack()'s and the trace-back's: nothing of them is pending past here)
+            // b0 holds chunk c's raw values, b1 / b2 those of c + 1 / c + 2: what the code below expects of b0, b1
         }
         if (!(tr < nsteps)) break;
         b2 = fetch(c + 2);

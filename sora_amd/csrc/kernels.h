@@ -135,6 +135,9 @@ int sora_internal_dense_deliver(DenseStage* D, const sora::Rx11bRow* d_rows, con
                                 sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap,
                                 const sora_frame_result* d_tmpl = nullptr, const uint32_t* d_ncaps = nullptr);   // (a template already on the device; the real number of "captures" where the host only knows a bound)
 
+// sora_hip.cpp: the i-th stream of a handle (its i-th pipeline / slot), non-blocking, on priority level i % 3: the runtime keeps GPU_MAX_HW_QUEUES
+// hardware queues per level, so a handle's streams get a hardware queue each without the application setting an environment variable
+hipError_t sora_internal_stream_create(hipStream_t* out, int index);
 // sora_hip.cpp: records the message sora_hip_last_error() returns; hip_error = 0 for none
 int sora_internal_fail(int code, const char* what, int hip_error);
 const uint32_t* sora_internal_crc_table(int device);

@@ -18,6 +18,19 @@
 using namespace sora;
 
 static thread_local std::string g_last_error;
+hipError_t sora_internal_stream_create(hipStream_t* out, int index)
+{
+#ifndef SORA_ONE_STREAM_PRIORITY
+    int least = 0, greatest = 0;
+    (void)hipDeviceGetStreamPriorityRange(&least, &greatest);
+    const int level = index % 3, prio = level == 0 ? 0 : level == 1 ? greatest : least;
+    if (least != greatest) return hipStreamCreateWithPriority(out, hipStreamNonBlocking, prio);
+#else
+    (void)index;
+#endif
+    return hipStreamCreateWithFlags(out, hipStreamNonBlocking);
+}
+
 static int fail(int code, const char* what, hipError_t e = hipSuccess)
 {
     char buf[256];
@@ -347,7 +360,7 @@ int   sora_hip_memcpy_d2d(void* dd, const void* ds, size_t n, void* stream) { HI
 void* sora_hip_host_alloc(size_t bytes) { void* p = nullptr; if (hipHostMalloc(&p, bytes, hipHostMallocDefault) != hipSuccess) return nullptr; return p; }
 void  sora_hip_host_free(void* p) { if (p) (void)hipHostFree(p); }
 
-static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
+static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out, int index = 0)
 {
     if (!cfg || !out || cfg->struct_size != sizeof(sora_rx_cfg)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_create: bad cfg");
     if (cfg->sample_rate_mhz != 20 && cfg->sample_rate_mhz != 40 && cfg->sample_rate_mhz != 44) return fail(SORA_ERR_INVALID_PARAM, "sample_rate_mhz must be 20, 40 or 44");
@@ -363,7 +376,12 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out)
     rx->tabs.device = cfg->device;
     int rc = make_dev_tables(rx->tabs);
     if (rc) { rx_free(rx); return rc; }
-    hipError_t e = hipStreamCreateWithFlags(&rx->stream, hipStreamNonBlocking);
+    // The HIP runtime multiplexes a process's streams onto GPU_MAX_HW_QUEUES hardware queues PER PRIORITY LEVEL (default 4, one of the normal
+    // level's is the null stream's): eight pipelines of one priority run three at a time (profiles/r03_e_timeline_*.txt).  Spreading the
+    // handle's pipelines over the three levels gives every one of them a hardware queue of its own WITHOUT the application having to set an
+    // environment variable before HIP starts.  The levels only order dispatch among kernels that are ready at the same
+    // moment; every pipeline's chain is sequential, so none of them starves (profiles/r04_m_stream_priorities.txt).
+    hipError_t e = sora_internal_stream_create(&rx->stream, index);
     if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "hipStreamCreate", e); }
     e = hipHostMalloc((void**)&rx->h_caps_pinned, sizeof(CapDesc) * cfg->max_captures, hipHostMallocDefault);
     if (e == hipSuccess) e = hipEventCreateWithFlags(&rx->ev_caps, hipEventDisableTiming);
@@ -704,7 +722,7 @@ static RxPipe* pipe_of(sora_rx* rx, int ticket)
 static RxPipe* pipe_at(sora_rx* rx, int i)
 {
     if (!rx->pipes[i]) {
-        if (pipe_create(&rx->cfg, &rx->pipes[i]) != SORA_OK) return nullptr;
+        if (pipe_create(&rx->cfg, &rx->pipes[i], i) != SORA_OK) return nullptr;
         rx->pipes[i]->fused = rx->fused; rx->pipes[i]->use_graph = rx->use_graph;
         if (rx->profiling) (void)pipe_set_profiling(rx->pipes[i], 1);
     }
