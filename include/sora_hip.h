@@ -482,7 +482,10 @@ int   sora_rx11b_ticket(sora_rx11b_t* rx);                     /* ticket of the 
 int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls the handle keeps addressable */
 /* The graph runs as two kernels: the Barker-rate instantiation decodes every capture and hands those whose PLCP header announces 5.5 / 11 Mbps to the
  * CCK-capable one, which redoes them from their first sample.  enable = 1: every capture goes straight through the CCK-capable instantiation (all
- * four rates, identical rows) -- the better choice when most frames are CCK; 0 (default): two passes; negative: query.  Returns the previous setting. */
+ * four rates, identical rows) -- the better choice when most frames are CCK; 0: always two passes; 2 (DEFAULT since round 4): automatic -- a
+ * two-pass call counts on the device how many captures its first pass handed over, and once such a count has come back (the handle never waits for
+ * it) and says "more than half", the following calls take the single pass, except every 16th, which measures again; negative: query.  Returns the
+ * previous setting (0, 1 or 2). */
 int   sora_rx11b_set_single_pass(sora_rx11b_t* rx, int enable);
 int   sora_rx11b_wait(sora_rx11b_t* rx, int ticket);
 void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket);

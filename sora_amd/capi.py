@@ -513,7 +513,7 @@ class Rx11b:
         return int(self._L.sora_rx11b_calls_in_flight(self._h))
 
     def set_single_pass(self, enable=-1):
-        """1: every capture straight through the CCK-capable kernel (mostly-CCK traffic); 0: two passes (default); returns the previous setting"""
+        """the pass plan: 2 automatic (default), 1 every capture straight through the CCK-capable kernel, 0 always two passes; returns the previous plan"""
         return int(self._L.sora_rx11b_set_single_pass(self._h, int(enable)))
 
     def wait(self, ticket):

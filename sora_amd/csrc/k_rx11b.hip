@@ -917,6 +917,19 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
 __global__ void __launch_bounds__(256, 4) k_rx11b(Rx11bArgs A) { rx11b_capture<false>(A); }
 __global__ void __launch_bounds__(256, 4) k_rx11b_cck(Rx11bArgs A) { rx11b_capture<true>(A); }
 
+// how many captures the first pass handed over (the automatic pass plan's measurement): one block
+__global__ void __launch_bounds__(1024) k_rx11b_count_flagged(const uint32_t* __restrict__ needs_cck, uint32_t ncaps, uint32_t* __restrict__ out)
+{
+    __shared__ uint32_t s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    uint32_t n = 0;
+    for (uint32_t i = threadIdx.x; i < ncaps; i += 1024) n += needs_cck[i] ? 1u : 0u;
+    if (n) atomicAdd(&s_n, n);
+    __syncthreads();
+    if (threadIdx.x == 0) out[0] = s_n;
+}
+
 }  // namespace sora
 
 // ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
@@ -938,6 +951,9 @@ struct Slot11b {
     DenseStage dense;            // sora_rx11b_deliver_async
     std::vector<CapDesc> h_desc;                 // staging for the descriptor upload (kept until the slot's next call)
     uint32_t ncaps = 0;
+    // automatic pass plan: how many captures the first pass handed to the CCK instantiation, counted on the device behind a two-pass call and
+    // copied to page-locked memory (h_flagged[0] = count, valid once ev_flagged has completed)
+    uint32_t* d_flagged = nullptr; uint32_t* h_flagged = nullptr; hipEvent_t ev_flagged = nullptr; bool flagged_pending = false;
 };
 struct sora_rx11b {
     sora_rx_cfg cfg{};
@@ -945,7 +961,9 @@ struct sora_rx11b {
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
     bool have_results = false;
-    bool single_pass = false;       // sora_rx11b_set_single_pass: every capture straight through the CCK-capable instantiation
+    int  pass_plan = 2;             // sora_rx11b_set_single_pass: 0 = two passes, 1 = every capture straight through the CCK-capable instantiation, 2 (default) = automatic
+    bool auto_single = false;       // automatic plan: what the most recent measurement said (more than half of a call's captures carried CCK frames)
+    uint32_t auto_calls = 0;        // ... and every 16th call of a single-pass run is a two-pass call again, to measure
 };
 
 #define HIPCHK11(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -956,6 +974,7 @@ static void rx11b_free(sora_rx11b_t* rx)
     for (Slot11b& S : rx->slot) {
         if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
         (void)hipFree(S.d_caps); (void)hipFree(S.d_rows); (void)hipFree(S.d_nframes); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_needs_cck);
+        (void)hipFree(S.d_flagged); if (S.h_flagged) (void)hipHostFree(S.h_flagged); if (S.ev_flagged) (void)hipEventDestroy(S.ev_flagged);
         sora_internal_dense_free(&S.dense);
     }
     (void)hipFree(rx->d_iq_own);
@@ -983,6 +1002,9 @@ int sora_rx11b_create(const sora_rx_cfg* cfg, sora_rx11b_t** out)
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * rows);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_nframes, 4 * (size_t)cfg->max_captures);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_needs_cck, 4 * (size_t)cfg->max_captures);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_flagged, 16);
+        if (e == hipSuccess) e = hipHostMalloc((void**)&S.h_flagged, 16, hipHostMallocDefault);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S.ev_flagged, hipEventDisableTiming);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, rows * 4096);
     }
     if (e != hipSuccess) { rx11b_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11b_create: device allocation", (int)e); }
@@ -1031,9 +1053,22 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
 #else
     constexpr bool one_kernel = false;
 #endif
-    const bool single = one_kernel || rx->single_pass;
+    // The pass plan.  Automatic (default): a two-pass call also counts, on the device, how many captures its first pass handed over; once such a
+    // count has come back (no waiting: the event is only queried) and says "more than half", the following calls go straight through the CCK
+    // instantiation -- which decodes all four rates with identical rows -- except every 16th, which is a two-pass call again and measures.
+    for (Slot11b& Q : rx->slot)
+        if (Q.flagged_pending && hipEventQuery(Q.ev_flagged) == hipSuccess) { Q.flagged_pending = false; rx->auto_single = 2u * Q.h_flagged[0] > Q.h_flagged[1]; }
+    bool single = one_kernel || rx->pass_plan == 1;
+    if (rx->pass_plan == 2 && rx->auto_single && (++rx->auto_calls & 15u) != 0u) single = true;
     HIPCHK11(hipMemsetAsync(S.d_needs_cck, single ? 1 : 0, 4 * ncaps, S.stream));
     if (!single) hipLaunchKernelGGL(k_rx11b, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);
+    if (!single && rx->pass_plan == 2 && !S.flagged_pending) {
+        hipLaunchKernelGGL(k_rx11b_count_flagged, dim3(1), dim3(1024), 0, S.stream, (const uint32_t*)S.d_needs_cck, (uint32_t)ncaps, S.d_flagged);
+        S.h_flagged[1] = (uint32_t)ncaps;
+        HIPCHK11(hipMemcpyAsync(S.h_flagged, S.d_flagged, 4, hipMemcpyDeviceToHost, S.stream));
+        HIPCHK11(hipEventRecord(S.ev_flagged, S.stream));
+        S.flagged_pending = true;
+    }
     hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)
     HIPCHK11(hipGetLastError());
     return SORA_OK;
@@ -1117,8 +1152,8 @@ int sora_rx11b_calls_in_flight(sora_rx11b_t* rx) { (void)rx; return kSlots11b; }
 int sora_rx11b_set_single_pass(sora_rx11b_t* rx, int enable)
 {
     if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_set_single_pass: null handle", 0);
-    const int old = rx->single_pass ? 1 : 0;
-    if (enable >= 0) rx->single_pass = enable != 0;
+    const int old = rx->pass_plan;
+    if (enable >= 0) { rx->pass_plan = enable > 2 ? 2 : enable; rx->auto_single = false; rx->auto_calls = 0; }
     return old;
 }
 int sora_rx11b_wait(sora_rx11b_t* rx, int ticket)

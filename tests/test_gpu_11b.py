@@ -26,8 +26,9 @@ def run_11b(sora, caps, max_frames=16, single_pass=False):
         descs.append((pos, len(c), i)); parts.append(c); pos += len(c)
     iq = np.concatenate(parts) if parts else np.zeros((0, 2), np.int16)
     rx = sora.Rx11b(max(1, len(caps)), max(28, len(iq)), max_frames_per_capture=max_frames)
+    assert rx.set_single_pass(-1) == 2                                   # the default pass plan is automatic
     if single_pass:
-        assert rx.set_single_pass(1) == 0 and rx.set_single_pass(-1) == 1
+        assert rx.set_single_pass(1) == 2 and rx.set_single_pass(-1) == 1
     rx.process_dev(torch.from_numpy(iq).cuda(), descs)
     res = rx.results(); rx.close()
     return res
@@ -206,3 +207,53 @@ def test_11b_capacity_and_argument_errors(sora):
     with pytest.raises(Exception):
         rx.process_dev(torch.zeros((560, 2), dtype=torch.int16).cuda(), [(0, 560, 0)])    # more than max_total_samples
     rx.close()
+
+
+def test_the_automatic_pass_plan_changes_nothing_but_the_time(sora, oracle):
+    """sora_rx11b_set_single_pass(2), the default: after a call whose first pass handed most captures to the CCK instantiation the handle takes
+    the single pass by itself (and a two-pass call every 16th, to measure again).  Thirty-six calls of CCK-heavy traffic followed by Barker-only
+    traffic: every call's rows equal the fixed two-pass plan's."""
+    import torch
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        pytest.skip("oracle/_ref/libsora_refgraph.so not present (the captures come from the reference's modulator)")
+    rng = np.random.default_rng(515)
+
+    def batch(rates):
+        caps = []
+        for r in rates:
+            s8 = g.tx11b(rng.integers(0, 256, int(rng.integers(20, 300))).astype(np.uint8).tobytes(), r)
+            x = np.concatenate([np.zeros((28 * 40, 2)), s8.astype(np.float64) * 256.0, np.zeros((28 * 60, 2))])
+            x = x[:len(x) // 28 * 28] + rng.normal(0, 50, (len(x) // 28 * 28, 2))
+            caps.append(np.clip(np.rint(x), -32768, 32767).astype(np.int16))
+        return caps
+    cck = batch([11000, 5500, 11000, 2000, 11000, 5500, 11000, 11000])
+    barker = batch([1000, 2000, 1000, 2000, 1000, 1000, 2000, 1000])
+    want_cck = run_11b_fixed(sora, cck); want_barker = run_11b_fixed(sora, barker)
+    n = max(sum(len(c) for c in cck), sum(len(c) for c in barker))
+    rx = sora.Rx11b(8, n, max_frames_per_capture=16)
+
+    def call(caps):
+        descs, pos = [], 0
+        for i, c in enumerate(caps):
+            descs.append((pos, len(c), i)); pos += len(c)
+        t = rx.process_dev(torch.from_numpy(np.concatenate(caps)).cuda(), descs)
+        return rx.results(ticket=t)
+    for k in range(20):
+        assert call(cck) == want_cck, k
+    for k in range(16):
+        assert call(barker) == want_barker, k
+    rx.close()
+
+
+def run_11b_fixed(sora, caps):
+    import torch
+    descs, pos = [], 0
+    for i, c in enumerate(caps):
+        descs.append((pos, len(c), i)); pos += len(c)
+    rx = sora.Rx11b(len(caps), pos, max_frames_per_capture=16)
+    rx.set_single_pass(0)
+    rx.process_dev(torch.from_numpy(np.concatenate(caps)).cuda(), descs)
+    res = rx.results(); rx.close()
+    return res
