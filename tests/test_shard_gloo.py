@@ -189,3 +189,40 @@ def test_two_rank_gloo_gather_mpdus():
     for rank, counts, got in outs:
         assert sum(counts) == len(want)
         assert got == want
+
+
+def _worker_overflow(rank, world, port, q):
+    """a rank whose MPDUs do not fit its block must still enter all three collectives (the others would wait for ever) and EVERY rank raises."""
+    sys.path.insert(0, ROOT)
+    import torch
+    import torch.distributed as dist
+    from sora_amd.shard import gather_mpdus
+    os.environ["MASTER_ADDR"] = "127.0.0.1"; os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rows = torch.zeros((2, 9), dtype=torch.int32)
+    rows[:, 3] = 1; rows[0, 5] = 100; rows[1, 5] = 300 if rank == 1 else 50; rows[1, 8] = 100      # rank 1 holds 400 bytes of MPDUs, rank 0 150
+    mpdu = torch.arange(1024, dtype=torch.int32).to(torch.uint8)
+    try:
+        gather_mpdus(rows, 2, mpdu, max_rows_per_rank=4, max_bytes_per_rank=256)
+        q.put((rank, "no error"))
+    except ValueError as e:
+        q.put((rank, "local: %s" % e))
+    except RuntimeError as e:
+        q.put((rank, "remote: %s" % e))
+    dist.barrier(); dist.destroy_process_group()
+
+
+def test_a_rank_that_overflows_takes_every_rank_down_instead_of_hanging_them():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 35500 + (os.getpid() % 2000)
+    ps = [ctx.Process(target=_worker_overflow, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    outs = dict(q.get(timeout=120) for _ in ps)
+    for p in ps:
+        p.join(60)
+        assert p.exitcode == 0
+    assert outs[1].startswith("local:") and "exceed" in outs[1], outs
+    assert outs[0].startswith("remote:") and "[1]" in outs[0], outs
