@@ -439,6 +439,69 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
     return out
 
 
+def bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, maxf, exp_rows, exp_mpdu, seconds, cores):
+    """What a plain host gets when it hands over MORE PER CALL instead of keeping more calls in flight: the rotated device copies of the batch
+    as ONE call of len(d_iqs) x nfr captures, at most TWO such calls in flight, every call delivered (rows + MPDU bytes) and compared.  The first
+    call is verified against the already verified nfr-capture table, quarter by quarter (capture_id and mpdu_offset shifted, everything else and
+    every MPDU byte equal).  Reported per nfr captures, so that it reads beside ms_per_step."""
+    g_n = len(d_iqs); n_iq = d_iqs[0].shape[0]
+    big = torch.cat(d_iqs)
+    descs = sora_amd.Rx.captures([(g * n_iq + i * CAPTURE_SAMPLES, CAPTURE_SAMPLES, g * nfr + i) for g in range(g_n) for i in range(nfr)])
+    rx = sora_amd.Rx(max_captures=g_n * nfr, max_total_samples=g_n * n_iq, sample_rate_mhz=20, device=local_rank, max_frames_per_capture=maxf)
+    dep = 2
+    rx.set_depth(dep)
+    torch.cuda.synchronize()
+    rx.wait_for_producer = False
+    t = rx.process_dev(big, descs)
+    nb = dep + TableChecker.EXTRA
+    bufs = [sora_amd.HostResults(g_n * nfr * maxf, rx.mpdu_bytes(t)) for _ in range(nb)]
+    rx.deliver_async(t, bufs[0]); rx.wait(t)
+    n = int(bufs[0].nrows[0]); rows = bufs[0].rows[:n].copy(); mp = bufs[0].mpdu.copy()
+    exp_n = len(exp_rows)
+    ok = n == g_n * exp_n
+    if ok:
+        for g in range(g_n):
+            q = rows[g * exp_n:(g + 1) * exp_n]
+            ok = ok and all((q[f] == exp_rows[f]).all() for f in q.dtype.names if f not in ("capture_id", "mpdu_offset")) \
+                and bool((q["capture_id"] == exp_rows["capture_id"] + g * nfr).all())
+            good = np.nonzero(exp_rows["error_code"] == 1)[0]
+            for k in good:
+                a, b, ln = int(q["mpdu_offset"][k]), int(exp_rows["mpdu_offset"][k]), int(exp_rows["length"][k])
+                if mp[a:a + ln].tobytes() != exp_mpdu[b:b + ln].tobytes():
+                    ok = False
+                    break
+    chk = TableChecker(rows.tobytes(), mp, cores=cores)
+
+    def block(k):
+        first = None
+        for _ in range(k):
+            chk.release((rx.ticket() + 1) % nb)
+            tk = rx.process_dev(big, descs)
+            rx.deliver_async(tk, bufs[tk % nb])
+            if first is None:
+                first = tk
+            if tk - first >= dep - 1:
+                rx.wait(tk - (dep - 1)); b = bufs[(tk - (dep - 1)) % nb]
+                chk.check((tk - (dep - 1)) % nb, int(b.nrows[0]) == n, b.rows[:n], b.mpdu)
+        for old in range(max(first, tk - (dep - 1) + 1), tk + 1):
+            rx.wait(old); b = bufs[old % nb]
+            chk.check(old % nb, int(b.nrows[0]) == n, b.rows[:n], b.mpdu)
+        rx.flush(); chk.drain()
+    block(4)
+    t0 = time.perf_counter(); block(8); probe = (time.perf_counter() - t0) / 8
+    ncalls = max(16, int(seconds / max(probe, 1e-6)))
+    chk.compared = chk.bad = 0
+    t0 = time.perf_counter(); block(ncalls); dt = time.perf_counter() - t0
+    out = {"captures_per_call": g_n * nfr, "calls_in_flight": dep, "trellis": {64: "k_viterbi", 16: "k_viterbi16"}[rx.trellis()], "calls_timed": ncalls,
+           "ms_per_call": round(1e3 * dt / ncalls, 4), "ms_per_%d_captures" % nfr: round(1e3 * dt / ncalls / g_n, 4),
+           "msamples_per_s": round(g_n * nfr * FRAME_SAMPLES * ncalls / dt / 1e6, 1), "first_call_equals_the_verified_table": bool(ok),
+           "calls_compared": chk.compared, "calls_with_wrong_rows": chk.bad, "input_bytes_per_call": int(big.numel() * 2),
+           "note": "the same step protocol (process_dev -> deliver_async -> wait -> compare, no environment variable) with %d captures per call and two calls in flight" % (g_n * nfr)}
+    chk.finish(); rx.close()
+    del big
+    return out
+
+
 def bench_e2e(torch, sora_amd, dev, rx, iq, nfr, exp_rows, exp_mpdu, steps=24, nbatches=4):
     """Dump bytes in page-locked host memory -> sora_rx_process_dump (H2D copy + sora_hip_ingest + the receive chain on one stream, no host wait) ->
     rows and MPDUs delivered to the host: LoadSoraDumpFile -> graph -> MPDU buffer (brickutil.h:20-58, fb11a_demod.cpp:88-120) as one path.
@@ -901,6 +964,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)
     ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--headline-only", action="store_true", help="stop after the timed region and print its step time only (kernel-trace runs: tools/trace_timeline.sh)")
+    ap.add_argument("--wait-oldest", action="store_true", help="the host waits for its OLDEST ticket (round-3 loop) instead of taking completions as they come (sora_rx_wait_any)")
+    ap.add_argument("--no-plain", action="store_true", help="skip the plain_host section (experiments)")
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="captures per GPU (default: the BASELINE config; "
                     "--gpus 8 --frames 32 is BASELINE configs[4] literally: 256 captures over 8 GPUs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -986,36 +1052,44 @@ def main():
     share = pin_rank_threads(local_rank, world)                     # this rank's cores: the submit thread on the first, the checker's threads on the others
     chk = TableChecker(exp_bytes, exp_mpdu, cores=share[1:] if len(share) > 1 else None)   # rows AND MPDU bytes of every delivered call, compared by a few host threads
 
-    def consume(tk):
+    # Completion order (round 4): calls in flight overtake one another (their streams sit on different dispatch priorities and share the chip), so
+    # the loop takes whichever delivered call has finished (sora_rx_wait_any) and the next process call reuses THAT pipeline; --wait-oldest is the
+    # round-3 loop (always wait for the oldest ticket), reported beside the headline as in_order_host.
+    import collections
+    inflight = {}                                                   # ticket -> index of the buffer it is delivered into
+    free = collections.deque(range(nb))
+    order = {"any": not args.wait_oldest}
+
+    def consume_one():
         ta = time.perf_counter()
-        rx.wait(tk)
+        if order["any"]:
+            tk = rx.wait_any()
+        else:
+            tk = min(inflight); rx.wait(tk)
         tb = time.perf_counter()
         stats["t_wait"] += tb - ta
-        b = bufs[tk % nb]
+        bi = inflight.pop(tk); b = bufs[bi]
         # every call's rows AND MPDU bytes, whatever the number of ranks: the comparison runs on the checker's threads, which (like the submit
         # thread) are pinned to this rank's own share of the host's cores (pin_rank_threads) -- round 3 sampled every world-th call instead
-        chk.check(tk % nb, int(b.nrows[0]) == exp_n, b.rows[:exp_n], b.mpdu)
+        chk.check(bi, int(b.nrows[0]) == exp_n, b.rows[:exp_n], b.mpdu)
+        free.append(bi)
         stats["t_check"] += time.perf_counter() - tb
 
     def run_block(k, deliver, dep=None):
-        dep = dep or depth                                          # calls in flight on the handle right now (<= len(bufs))
-        first = None
+        dep = dep or depth                                          # calls in flight on the handle right now (<= len(bufs) - EXTRA)
         for _ in range(k):
             ta = time.perf_counter()
             if deliver:
-                chk.release((rx.ticket() + 1) % nb)                 # the buffer the next call will be delivered into: its comparison must be over
+                bi = free.popleft()
+                chk.release(bi)                                     # the buffer the next call will be delivered into: its comparison must be over
             tk = rx.process_dev(d_iqs[(rx.ticket() + 1) % NCOPIES], descs)
             if deliver:
-                rx.deliver_async(tk, bufs[tk % nb])
+                rx.deliver_async(tk, bufs[bi]); inflight[tk] = bi
             stats["t_submit"] += time.perf_counter() - ta
-            if deliver:
-                if first is None:
-                    first = tk
-                if tk - first >= dep - 1:
-                    consume(tk - (dep - 1))
-        if deliver and first is not None:
-            for old in range(max(first, tk - (dep - 1) + 1), tk + 1):
-                consume(old)
+            if deliver and len(inflight) >= dep:
+                consume_one()
+        while inflight:
+            consume_one()
 
     deliver = not args.no_deliver
     run_block(args.warmup, deliver)
@@ -1039,6 +1113,11 @@ def main():
     barrier()
     t1 = time.perf_counter()
     host_ms = {k_[2:]: round(1e3 * stats[k_] / (args.steps * repeats), 4) for k_ in ("t_submit", "t_wait", "t_check")}
+    if args.headline_only:
+        if rank == 0:
+            print(json.dumps({"ms_per_step": round(1e3 * (t1 - t0) / (args.steps * repeats), 4), "steps": args.steps * repeats, "calls_in_flight": depth, "captures_per_call": nfr,
+                              "calls_with_wrong_rows": chk.bad, "host_ms_per_step": host_ms}))
+        return
     timed_steps = args.steps * repeats
     stats["delivered"], stats["bad"] = chk.compared, chk.bad
     mpdu_ok = bool(deliver) and all((b.mpdu == exp_mpdu).all() for b in bufs)     # the last calls' MPDU arrays once more, byte for byte
@@ -1077,7 +1156,18 @@ def main():
     # handle's streams in use -- fewer than the runtime's default four hardware queues, so GPU_MAX_HW_QUEUES plays no part -- same timed-region
     # protocol (delivery + comparison inside), each trellis kernel pinned in turn.
     plain = {}
-    if world == 1:
+    if world == 1 and not args.no_plain:
+        if order["any"] and deliver:                                 # the headline's calls in flight with the round-3 loop: always wait for the OLDEST ticket
+            rx.set_trellis(lanes); rx.set_depth(depth); rx.flush(); order["any"] = False
+            run_block(args.warmup, deliver); rx.flush(); chk.drain(); bad0 = chk.bad
+            nblk = max(1, repeats // 4)
+            tp0 = time.perf_counter()
+            run_block(args.steps * nblk, deliver)
+            rx.flush(); chk.drain()
+            ms_p = (time.perf_counter() - tp0) / (nblk * args.steps) * 1e3
+            plain["calls_in_flight_%d_waiting_for_the_oldest_ticket" % depth] = {"ms_per_step": round(ms_p, 4), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms_p / 1e3, 1),
+                                                                                 "calls_with_wrong_rows": chk.bad - bad0}
+            order["any"] = True
         for dval in (1, 2):
             for l in (64, 16):
                 rx.set_trellis(l); rx.set_depth(dval); rx.flush()
@@ -1091,6 +1181,11 @@ def main():
                                                                       "calls_with_wrong_rows": chk.bad - bad0}
         best2 = min((k for k in plain if k.startswith("calls_in_flight_2")), key=lambda k: plain[k]["ms_per_step"])
         plain["best_with_at_most_two_calls_in_flight"] = dict(plain[best2], config=best2)
+        try:
+            plain["two_calls_in_flight_of_%d_captures" % (NCOPIES * nfr)] = bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, MAXF, exp_rows, exp_mpdu, args.min_seconds,
+                                                                                           share[1:] if len(share) > 1 else None)
+        except Exception as e:                                      # (a second 320 MB input and its workspace: report, do not lose the line)
+            plain["two_calls_in_flight_of_%d_captures" % (NCOPIES * nfr)] = {"error": repr(e)}
         plain["note"] = ("the headline keeps %d calls in flight%s; with at most two, the chip holds at most 8192 frames = 1024 waves of k_viterbi16 (one per SIMD, each bound by its own "
                          "issue rate) or 4096 of k_viterbi (1.7x the instructions): DESIGN.md section 3.6, profiles/r04_a_depth_table.txt" % (depth, " on %s hardware queues" % os.environ["GPU_MAX_HW_QUEUES"] if os.environ.get("GPU_MAX_HW_QUEUES") else ""))
     rx.set_trellis(trellis_setting); rx.set_depth(depth); rx.flush()
@@ -1132,7 +1227,7 @@ def main():
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_profiled": round((t3 - t2) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 IQ / u8 path metrics", "data": "synthetic",
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
-                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "input_copies_rotated": NCOPIES, "input_bytes_in_play": int(NCOPIES * iq.nbytes), "calls_in_flight": depth, "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "input_copies_rotated": NCOPIES, "input_bytes_in_play": int(NCOPIES * iq.nbytes), "calls_in_flight": depth, "completions": "as they happen (sora_rx_wait_any)" if order["any"] else "oldest ticket first (sora_rx_wait)", "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
                        "timed_region": "%d x %d steps in one continuous run; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},

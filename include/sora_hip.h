@@ -134,7 +134,9 @@ int  sora_rx_stream_consumed(sora_rx_t* rx, int ticket, uint32_t* h_consumed, si
 int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* Tickets.  With several calls in flight (sora_rx_set_depth) every process call has a TICKET, a positive number that
- * identifies the call until `depth` further process calls have been made on the handle (its pipeline is then reused).
+ * identifies the call until its pipeline is reused: by the `depth`-th process call after it, or earlier once the call is
+ * RELEASED -- its delivery was enqueued (sora_rx_deliver_async) and it has been waited for (sora_rx_wait / sora_rx_wait_any),
+ * so that everything it produced is in the caller's memory.
  * What fb11a_demod.cpp:37-71 does per frame -- look at the result, hand the MPDU to the MAC -- is done per call with these:
  *   sora_rx_ticket          ticket of the most recent process call (0: none yet)
  *   sora_rx_wait            block until that call has finished (its kernels and any sora_rx_deliver_async copies)
@@ -146,9 +148,17 @@ int  sora_rx_results(sora_rx_t* rx, sora_frame_result* h_out, size_t max_out, si
  *                           number, and -- h_mpdu != NULL -- the MPDU array (row.mpdu_offset indexes it; mpdu_bytes must be
  *                           at least sora_rx_mpdu_bytes(rx, ticket)).  The buffers should be page-locked
  *                           (sora_hip_host_alloc) so that the copies overlap later calls; they are valid after sora_rx_wait.
+ *   sora_rx_wait_any        block until SOME call whose delivery has been enqueued has finished, and return its ticket (the oldest
+ *                           one if several have).  Calls in flight overtake one another (their streams sit on different dispatch
+ *                           priorities and share the chip); a host that always waits for its oldest ticket leaves the pipelines of the
+ *                           calls that finished first idle until the slowest one is through (measured: a third of every pipeline's
+ *                           time, profiles/r04_t_own_timeline.txt).  RxThread's loop (fb11a_demod.cpp:37-71) with this call:
+ *                               process_dev -> deliver_async -> [depth calls in flight?] wait_any -> hand that call's MPDUs to the MAC.
+ *                           The next process call reuses a released pipeline first.  SORA_ERR_FAILED if no such call is in flight.
  * A stale ticket gives SORA_ERR_INVALID_PARAM. */
 int    sora_rx_ticket(sora_rx_t* rx);
 int    sora_rx_wait(sora_rx_t* rx, int ticket);
+int    sora_rx_wait_any(sora_rx_t* rx, int* ticket);
 int    sora_rx_results_of(sora_rx_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 void*  sora_rx_stream_of(sora_rx_t* rx, int ticket);
 size_t sora_rx_mpdu_bytes(sora_rx_t* rx, int ticket);
@@ -178,10 +188,11 @@ int  sora_rx_set_depth(sora_rx_t* rx, int depth);
  *                    one while few frames are in flight (one 4096-frame call: 2048 waves for 1024 SIMDs);
  *   16  k_viterbi16  a frame pair in 16 lanes x 4 registers, eight frames per wave: half the vector instructions per frame and
  *                    no cross-row exchanges, but a quarter of the waves -- the faster one once several calls are in flight.
- *   0   (default)    chosen by the library from the handle's depth.
+ *   0   (default)    chosen by the library from the handle's capacity in flight: k_viterbi16 when depth x max_captures >= 16384
+ *                    (four 4096-capture calls, two 16384-capture calls), k_viterbi below that.
  * Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair);
-int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process call will use: 64 or 16 (resolves the automatic choice: 16 from depth 4) */
+int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process call will use: 64 or 16 (resolves the automatic choice) */
 /* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);

@@ -52,7 +52,7 @@ class Ht40Frame(ctypes.Structure):
 EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count", "sora_hip_malloc", "sora_hip_free",
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process_dump", "sora_rx_set_stream_mode", "sora_rx_stream_consumed", "sora_rx_process", "sora_rx_results",
-           "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
+           "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_wait_any", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
            "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_set_single_pass", "sora_rx11b_wait", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
@@ -105,6 +105,7 @@ def load(build_if_missing=True):
     L.sora_rx_results_dev.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
     L.sora_rx_ticket.argtypes = [ctypes.c_void_p]
     L.sora_rx_wait.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx_wait_any.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_int)]
     L.sora_rx_results_of.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(FrameResult), ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t),
                                      ctypes.c_void_p, ctypes.c_size_t]
     L.sora_rx_results_dev_of.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_void_p)]
@@ -333,6 +334,13 @@ class Rx:
 
     def wait(self, ticket):
         _check(self._L.sora_rx_wait(self._h, int(ticket)))
+
+    def wait_any(self):
+        """Block until some call with an enqueued delivery (deliver_async) has finished -> its ticket (the oldest finished one).  The call is then
+        released: the next process call may reuse its pipeline ahead of older calls still in flight."""
+        t = ctypes.c_int(0)
+        _check(self._L.sora_rx_wait_any(self._h, ctypes.byref(t)))
+        return t.value
 
     def mpdu_bytes(self, ticket):
         return int(self._L.sora_rx_mpdu_bytes(self._h, int(ticket)))

@@ -266,6 +266,25 @@ __device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_
     return O;
 }
 
+// Stream continuation: the record of a resume point (see k_scan).  Out of line, everything by value: its selects and shuffles stay out of the
+// carrier-sense loop's register allocation (inlined at its two call sites it cost the loop 56 more SGPR spills and 48 bytes of scratch).
+constexpr uint32_t kContMagic = 0x534F5241u;
+__device__ __noinline__ void cont_store(uint32_t* crec, uint32_t* consumed, uint32_t Hv, uint32_t Zr, uint32_t Zi, uint32_t Ze, int rr, int ri, int re,
+                                        uint32_t sense_count, uint32_t high_count, int peak_corr, int peak_index, uint32_t dc_cnt, int sum_dc_re, int sum_dc_im,
+                                        int dc_re, int dc_im, uint32_t at)
+{
+    const int l = threadIdx.x;
+    const uint32_t zr = (uint32_t)__shfl((int)Zr, 4 * (l & 3)), zi = (uint32_t)__shfl((int)Zi, 4 * (l & 3)), ze = (uint32_t)__shfl((int)Ze, 4 * (l & 3));   // window element (l & 3) sits in lanes 4 (l & 3) ..
+    const uint32_t hv = (uint32_t)__shfl((int)Hv, l & 15);
+    uint32_t v = l < 16 ? hv : l < 20 ? zr : l < 24 ? zi : l < 28 ? ze : 0u;
+    const uint32_t sc[16] = { (uint32_t)rr, (uint32_t)ri, (uint32_t)re, sense_count, high_count, (uint32_t)peak_corr, (uint32_t)peak_index, dc_cnt,
+                              (uint32_t)sum_dc_re, (uint32_t)sum_dc_im, (uint32_t)dc_re, (uint32_t)dc_im, at, kContMagic, 0u, 0u };
+#pragma unroll
+    for (int k = 0; k < 16; k++) if (l == 28 + k) v = sc[k];
+    crec[l] = v;
+    if (l == 0) *consumed = at;
+}
+
 __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
 {
     const uint32_t cap_i = blockIdx.x;
@@ -313,23 +332,14 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     // pending): everything the graph knows there is the record below.  The capture's last resume point is published (A.consumed) and its
     // record kept; the next call's capture k starts AT that point of the stream and the record is its initial state -- so what the graph
     // reports from there on is what it reports on the uncut stream, and a frame cut by the end of a capture is simply found again.
-    uint32_t* const crec = A.cont ? A.cont + (size_t)cap_i * kContWords : nullptr;
-    constexpr uint32_t kContMagic = 0x534F5241u;
-    auto elem = [&](uint32_t Z, int l) { return (uint32_t)__shfl((int)Z, 4 * (l & 3)); };   // window element (l & 3) sits in lanes 4 (l & 3) ..
+    const bool streaming = A.cont != nullptr;                                   // (one flag lives through the loop; the pointers are re-derived where they are used)
     auto cont_save = [&](uint32_t at) {
-        const int l = lane;
-        const uint32_t zr = elem(ac_re.Z, l), zi = elem(ac_im.Z, l), ze = elem(energy.Z, l), hv = (uint32_t)__shfl((int)Hv, l & 15);
-        uint32_t v = l < 16 ? hv : l < 20 ? zr : l < 24 ? zi : l < 28 ? ze : 0u;
-        const uint32_t sc[16] = { (uint32_t)ac_re.reg, (uint32_t)ac_im.reg, (uint32_t)energy.reg, sense_count, high_count, (uint32_t)peak_corr, (uint32_t)peak_index, dc_cnt,
-                                  (uint32_t)sum_dc_re, (uint32_t)sum_dc_im, (uint32_t)dc_re, (uint32_t)dc_im, at, kContMagic, 0u, 0u };
-#pragma unroll
-        for (int k = 0; k < 16; k++) if (l == 28 + k) v = sc[k];
-        crec[l] = v;
-        if (l == 0) A.consumed[cap_i] = at;
+        cont_store(A.cont + (size_t)cap_i * kContWords, A.consumed + cap_i, Hv, ac_re.Z, ac_im.Z, energy.Z, ac_re.reg, ac_im.reg, energy.reg, sense_count, high_count, peak_corr, peak_index,
+                   dc_cnt, sum_dc_re, sum_dc_im, dc_re, dc_im, at);
     };
-    if (crec) {
+    if (streaming) {
         if (lane == 0) A.consumed[cap_i] = 0;
-        const uint32_t v = crec[lane];
+        const uint32_t v = A.cont[(size_t)cap_i * kContWords + lane];
         if ((uint32_t)__builtin_amdgcn_readlane((int)v, 41) == kContMagic) {       // a record exists: this capture continues a stream
             auto sc = [&](int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 28 + k); };
             Hv = (uint32_t)__shfl((int)v, lane & 15);
@@ -338,7 +348,6 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
             dc_cnt = sc(7); sum_dc_re = (int)sc(8); sum_dc_im = (int)sc(9); dc_re = (int)sc(10); dc_im = (int)sc(11);
         }
     }
-    uint32_t last_saved = 0xFFFFFFFFu;
 
     // GetCrossCorrelation (cca.hpp:202-218) for pattern p: the reference starts at the oldest burst, i.e. h[0]
     auto cross_corr = [&](int p) -> int {
@@ -364,13 +373,12 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
 
     // Carrier sense reads the stream 4 samples at a time, wave-uniformly: stage 64 consecutive units per
     // coalesced 256-byte load (one per lane) and hand them out with v_readlane instead of paying one global
-    // round trip per burst.
+    // round trip per burst.  (Keeping the following 64 units in flight in a second register was measured in round 4: the kernel
+    // alone stays at 0.102-0.108 ms -- the loads are L2 hits behind the staging kernel, not what the wave waits for -- so it is not done.)
     uint32_t win_base = 0xFFFFFFFFu, win = 0;
+    auto stage = [&](uint32_t u) { win_base = u; win = (u + (uint32_t)lane < nunits) ? iq[u + (uint32_t)lane] : 0u; };
     auto sample = [&](uint32_t u) -> uint32_t {
-        if (u - win_base >= 64u) {
-            win_base = u;
-            win = (u + (uint32_t)lane < nunits) ? iq[u + (uint32_t)lane] : 0u;
-        }
+        if (u - win_base >= 64u) stage(u);
         return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(u - win_base));
     };
 
@@ -383,10 +391,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     // carrier-sense time-out will fire in it (error_code is examined, and the brick reset, at the end of that call), and
     // stops in front of the first burst whose test is true -- that burst goes through the full path below.
     auto fast_idle = [&](uint32_t K) -> uint32_t {
-        if (vpos - win_base + K * BUR > 64u || win_base == 0xFFFFFFFFu) {       // stage the next 64 units (one coalesced load)
-            win_base = vpos;
-            win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
-        }
+        if (vpos - win_base + K * BUR > 64u || win_base == 0xFFFFFFFFu) stage(vpos);
         const uint32_t l = (uint32_t)lane & 31u, hi = (uint32_t)lane & 32u;    // lanes 32..63 mirror lanes 0..31
         const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
         const cpx x = unpack(raw);
@@ -449,10 +454,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     // cca.hpp:245-265): a burst only enters the history; every fourth one the history is correlated with the winning
     // STS pattern.  Up to 4 bursts per pass, one sample per lane; the correlation runs one tap per lane.
     auto fast_sync = [&](uint32_t K) {                                          // K = bursts taken (1..4), at most up to the next check
-        if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) {
-            win_base = vpos;
-            win = (vpos + (uint32_t)lane < nunits) ? iq[vpos + (uint32_t)lane] : 0u;
-        }
+        if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) stage(vpos);
         const uint32_t l = (uint32_t)lane & 15u;
         const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
         const cpx x = unpack(raw);
@@ -498,15 +500,16 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     for (uint32_t c = 0; c < nchunks; c++) {
         const uint32_t avail_end = (c + 1) * APP;
         while (vpos + BUR <= avail_end) {
-            if (crec && !cca_detected && !sync_high && auto_count == 0 && error_code == 0 && vpos % APP == 0 && vpos != last_saved) { cont_save(vpos); last_saved = vpos; }
+            if (streaming && vpos == avail_end - APP && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);   // (inside this loop the only multiple of APP vpos can be is the chunk's start)
             if (!cca_detected && !sync_high && auto_count == 0) {
                 // bursts until the carrier-sense time-out is raised; if that is near, stay inside this source call
                 const uint32_t to_timeout = sense_count >= 84 ? 0u : (84u - sense_count + 3u) / 4u;
                 uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
-                if (crec) {                                                     // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen
-                    uint32_t j = 1;
-                    while ((vpos + j * BUR) % APP != 0) j++;
-                    room = min(room, j);
+                if (streaming) {                                                   // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen:
+                    // in units of half a burst vpos sits m past the chunk's start and a source call is 7; j bursts further it is m + 2 j: j = -m / 2 = 3 m (mod 7), 0 -> 7
+                    const uint32_t m7 = (((vpos + APP - (avail_end - APP)) / (BUR / 2u)) % 7u);
+                    const uint32_t j = (3u * m7) % 7u;
+                    room = min(room, j ? j : 7u);
                 }
                 PROBE_T0();
                 const uint32_t took = fast_idle(min(min(room, dc_cnt + 1u), 8u));
@@ -682,7 +685,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         }
         PROBE_A(_tc, 7);
     }
-    if (crec && !cca_detected && !sync_high && auto_count == 0 && error_code == 0 && vpos % APP == 0 && vpos <= nunits && vpos != last_saved) cont_save(vpos);   // the capture ends in plain carrier sense: all of it is final
+    if (streaming && vpos == nunits && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);   // the capture ends in plain carrier sense: all of it is final
     if (lane == 0) A.nframes[cap_i] = nfr;
     PROBE_ADDK(5);
 }

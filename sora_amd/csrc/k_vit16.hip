@@ -456,7 +456,12 @@ __device__ __forceinline__ void viterbi16_body(const VitJob* __restrict__ jobs, 
 #define SORA_VIT16_BOUNDS __launch_bounds__(64)
 #endif
 __global__ void SORA_VIT16_BOUNDS k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
-{ viterbi16_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out); }
+{
+#ifdef SORA_EXP_VIT_PRIO
+    __builtin_amdgcn_s_setprio(SORA_EXP_VIT_PRIO);              // experiment (round 4): the issue-bound trellis waves ahead of the latency-bound front-end waves on their SIMD
+#endif
+    viterbi16_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out);
+}
 __global__ void __launch_bounds__(64) k_viterbi16_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi16_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }
 

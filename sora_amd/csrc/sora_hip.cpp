@@ -12,6 +12,7 @@
 #include <mutex>
 #include <string>
 #include <vector>
+#include <thread>
 #include "../../include/sora_hip.h"
 #include "kernels.h"
 
@@ -297,6 +298,9 @@ struct RxPipe {
     uint32_t ncaps = 0, total_slots = 0;
     bool have_results = false;
     int ticket = 0;              // the process call this pipeline holds (sora_rx_ticket); 0 = none
+    // completion order (sora_rx_wait_any): a call whose delivery has been enqueued (ev_done follows its last copy) and waited for is RELEASED --
+    // everything it produced is in the caller's memory -- and its pipeline may be reused ahead of older calls still in flight
+    hipEvent_t ev_done = nullptr; bool delivered = false, released = false;
     // Opt-in (SORA_HIP_GRAPH=1): a call that repeats the previous one's geometry (same IQ buffer, same capture set) replays
     // the kernel chain as one hipGraph launch.  Off by default: on this path the GPU time per call dwarfs the six enqueues,
     // and instantiating the graph on the second identical call costs more than it saves for short runs.
@@ -308,6 +312,8 @@ struct RxPipe {
     hipEvent_t ev[9] = {};
     bool ev_valid = false;       // ev[] hold a call whose durations have not been folded into t_sum yet
     double t_sum[8] = {}; uint64_t t_calls = 0;   // per-kernel durations (ms) summed over the profiled calls of this pipeline
+    // tool hook (sora_internal_rx_timeline): when set, every profiled call also leaves its kernel boundaries as ms since *tl_base
+    std::vector<float>* tl = nullptr; hipEvent_t* tl_base = nullptr; int index = 0;
 };
 
 static constexpr size_t kNumTimed = 5;
@@ -320,6 +326,10 @@ static int fold_profile(RxPipe* rx)
     if (!rx->ev_valid) return SORA_OK;
     HIPCHK(hipEventSynchronize(rx->ev[kNumTimed]));
     for (size_t i = 0; i < kNumTimed; i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, rx->ev[i], rx->ev[i + 1])); rx->t_sum[i] += t; }
+    if (rx->tl && rx->tl_base && *rx->tl_base && rx->tl->size() < (size_t)(1u << 22)) {
+        rx->tl->push_back((float)rx->index);
+        for (size_t i = 0; i <= kNumTimed; i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, *rx->tl_base, rx->ev[i])); rx->tl->push_back(t); }
+    }
     rx->t_calls++; rx->ev_valid = false;
     return SORA_OK;
 }
@@ -334,6 +344,7 @@ static void rx_free(RxPipe* rx)
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
     if (rx->graph) (void)hipGraphDestroy(rx->graph);
     if (rx->ev_caps) (void)hipEventDestroy(rx->ev_caps);
+    if (rx->ev_done) (void)hipEventDestroy(rx->ev_done);
     if (rx->h_caps_pinned) (void)hipHostFree(rx->h_caps_pinned);
     free_dev_tables(rx->tabs);
     if (rx->stream) (void)hipStreamDestroy(rx->stream);
@@ -418,7 +429,7 @@ static int pipe_reset(RxPipe* rx)
     if (!rx) return SORA_ERR_INVALID_PARAM;
     HIPCHK(hipSetDevice(rx->cfg.device));
     HIPCHK(hipStreamSynchronize(rx->stream));
-    rx->ncaps = 0; rx->total_slots = 0; rx->have_results = false; rx->h_caps.clear(); rx->ticket = 0;
+    rx->ncaps = 0; rx->total_slots = 0; rx->have_results = false; rx->h_caps.clear(); rx->ticket = 0; rx->delivered = rx->released = false;
     return SORA_OK;
 }
 
@@ -451,7 +462,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     if (total > rx->cfg.max_total_samples || slots64 > rx->cap_slots) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
     const uint32_t slots = (uint32_t)slots64;
     rx->h_caps.swap(hc);
-    rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false;
+    rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false; rx->delivered = rx->released = false;
     if (ncaps == 0) { rx->have_results = true; return SORA_OK; }
     if (!rx->fused && !rx->d_soft) {                                             // the packed soft streams and the job table exist only for the split path
         HIPCHK(hipMalloc((void**)&rx->d_soft, (size_t)kSoftBytesPerSlot * rx->cap_slots + kSoftSlack));   // three bits per soft value (rx_types.h)
@@ -684,6 +695,9 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
     HIPCHK(hipMemcpyAsync(h_nrows, rx->d_nrows, 4, hipMemcpyDeviceToHost, rx->stream));
     if (nr) HIPCHK(hipMemcpyAsync(h_rows, rx->d_rows, sizeof(sora_frame_result) * nr, hipMemcpyDeviceToHost, rx->stream));
     if (h_mpdu && need) HIPCHK(hipMemcpyAsync(h_mpdu, rx->d_mpdu, need, hipMemcpyDeviceToHost, rx->stream));
+    if (!rx->ev_done) HIPCHK(hipEventCreateWithFlags(&rx->ev_done, hipEventDisableTiming));
+    HIPCHK(hipEventRecord(rx->ev_done, rx->stream));
+    rx->delivered = true;
     return SORA_OK;
 }
 
@@ -694,7 +708,8 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
 // front end of one call (k_scan) overlaps the issue-bound decode kernel of the call before it -- the overlap
 // the reference gets from running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120, TThreadSeparator
 // stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
-constexpr int kAutoLanes16Depth = 4;                            // depth from which the automatic choice is k_viterbi16 (profiles/r03_d_ab_trellis.txt: it wins from four calls in flight)
+constexpr long long kAutoLanes16Captures = 16384;               // captures in flight (depth x the handle's max_captures) from which the automatic choice is k_viterbi16: it wins from four
+                                                                // 4096-capture calls in flight (profiles/r03_d_ab_trellis.txt) and equally from two 16384-capture calls (profiles/r04_q_large_calls.txt)
 struct sora_rx {
     static constexpr int kMaxDepth = 16;
     sora_rx_cfg cfg{};
@@ -710,6 +725,8 @@ struct sora_rx {
     // stream mode (sora_rx_set_stream_mode): capture k of a call continues capture k of the call before it
     bool stream_mode = false;
     uint32_t* d_cont = nullptr; uint32_t* d_consumed = nullptr;
+    // tool hook (sora_internal_rx_timeline)
+    std::vector<float> tl; hipEvent_t tl_base = nullptr;
 };
 
 static RxPipe* pipe_of(sora_rx* rx, int ticket)
@@ -719,12 +736,30 @@ static RxPipe* pipe_of(sora_rx* rx, int ticket)
     return nullptr;
 }
 
+// The pipeline the next process call uses: an unused one; else the RELEASED call with the oldest ticket (delivered and waited for: nothing of it is
+// left to read on the device); else the oldest call -- plain rotation, the call then waits for that pipeline's stream as it always did.  A host that only
+// ever waits for its oldest ticket sees exactly the round-robin of before; one that takes completions as they come (sora_rx_wait_any) keeps every
+// pipeline busy although calls overtake one another (their streams sit on different dispatch priorities).
+static int next_pipe(const sora_rx* rx)
+{
+    if (!rx->started) return 0;
+    int best = -1, best_rel = -1;
+    for (int i = 0; i < rx->depth; i++) {
+        const RxPipe* p = rx->pipes[i];
+        if (!p || p->ticket == 0) return i;
+        if (p->released && (best_rel < 0 || p->ticket < rx->pipes[best_rel]->ticket)) best_rel = i;
+        if (best < 0 || p->ticket < rx->pipes[best]->ticket) best = i;
+    }
+    return best_rel >= 0 ? best_rel : best;
+}
+
 static RxPipe* pipe_at(sora_rx* rx, int i)
 {
     if (!rx->pipes[i]) {
         if (pipe_create(&rx->cfg, &rx->pipes[i], i) != SORA_OK) return nullptr;
         rx->pipes[i]->fused = rx->fused; rx->pipes[i]->use_graph = rx->use_graph;
         if (rx->profiling) (void)pipe_set_profiling(rx->pipes[i], 1);
+        rx->pipes[i]->tl = &rx->tl; rx->pipes[i]->tl_base = &rx->tl_base; rx->pipes[i]->index = i;
     }
     return rx->pipes[i];
 }
@@ -749,6 +784,7 @@ void sora_rx_destroy(sora_rx_t* rx)
     for (RxPipe* p : rx->pipes) if (p) pipe_destroy(p);
     if (rx->d_cont) (void)hipFree(rx->d_cont);
     if (rx->d_consumed) (void)hipFree(rx->d_consumed);
+    if (rx->tl_base) (void)hipEventDestroy(rx->tl_base);
     delete rx;
 }
 
@@ -767,8 +803,13 @@ int sora_rx_set_fused(sora_rx_t* rx, int enable)
 }
 
 // Which trellis kernel a call uses: k_viterbi16 pays off once enough frames are in flight to give every SIMD a wave of it (it packs
-// eight frames into a wave, k_viterbi two); see DESIGN.md section 3.1.
-static int lanes16_for(const sora_rx* rx) { return rx->trellis == 16 ? 1 : rx->trellis == 64 ? 0 : (rx->depth >= kAutoLanes16Depth ? 1 : 0); }
+// eight frames into a wave, k_viterbi two); see DESIGN.md section 3.1.  What counts is the handle's capacity in flight, not the number
+// of tickets: two calls of 16384 captures fill the chip like eight of 4096, and eight calls of 64 captures do not.
+static int lanes16_for(const sora_rx* rx)
+{
+    if (rx->trellis) return rx->trellis == 16;
+    return (long long)rx->depth * (long long)rx->cfg.max_captures >= kAutoLanes16Captures;
+}
 
 int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
 {
@@ -868,7 +909,7 @@ int sora_rx_stream_consumed(sora_rx_t* rx, int ticket, uint32_t* h_consumed, siz
 int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
-    const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
+    const int next = next_pipe(rx);
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
@@ -881,7 +922,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
 int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samples, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process: null argument");
-    const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
+    const int next = next_pipe(rx);
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
@@ -894,7 +935,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
 int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, unsigned ingest_flags, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dump: null argument");
-    const int next = rx->started ? (rx->cur + 1) % rx->depth : 0;
+    const int next = next_pipe(rx);
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
@@ -914,6 +955,29 @@ int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, ui
     out[0] = p->d_frames; out[1] = p->d_slot_row; out[2] = p->d_eq; out[3] = p->d_track; out[4] = p->d_soft; out[5] = p->d_jobs; out[6] = p->d_joblist; out[7] = p->d_njobs;
     if (slots) *slots = p->total_slots;
     if (nrows) *nrows = p->ncaps * p->cfg.max_frames_per_capture;
+    return SORA_OK;
+}
+
+// Test / tool hook (not part of the ABI in include/sora_hip.h): a timeline of the profiled calls without a profiler attached.  start = 1 records the
+// time base (on the first pipeline's stream) and clears the log; every call processed under sora_rx_set_profiling(1) then leaves 1 + 6 floats:
+// its pipeline and the boundaries of memset+caps | k_scan | k_frame | trellis | k_finish in ms since the base.  start = 0 copies the log out.
+int sora_internal_rx_timeline(sora_rx_t* rx, int start, float* out, size_t cap, size_t* nout)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    if (start) {
+        RxPipe* p0 = pipe_at(rx, 0); if (!p0) return SORA_ERR_FAILED;
+        if (!rx->tl_base) HIPCHK(hipEventCreate(&rx->tl_base));
+        rx->tl.clear();
+        for (int i = 0; i < sora_rx::kMaxDepth; i++) if (rx->pipes[i]) { rx->pipes[i]->tl = &rx->tl; rx->pipes[i]->tl_base = &rx->tl_base; rx->pipes[i]->index = i; }
+        HIPCHK(hipEventRecord(rx->tl_base, p0->stream));
+        HIPCHK(hipEventSynchronize(rx->tl_base));
+        return SORA_OK;
+    }
+    if (!out || !nout) return SORA_ERR_INVALID_PARAM;
+    for (RxPipe* p : rx->pipes) if (p) { const int rc = fold_profile(p); if (rc) return rc; }
+    *nout = rx->tl.size() < cap ? rx->tl.size() : cap;
+    memcpy(out, rx->tl.data(), *nout * sizeof(float));
     return SORA_OK;
 }
 
@@ -937,7 +1001,36 @@ int sora_rx_wait(sora_rx_t* rx, int ticket)
 {
     RxPipe* p = pipe_of(rx, ticket);
     if (!p) return fail(SORA_ERR_INVALID_PARAM, kStale);
-    return pipe_flush(p);
+    const int rc = pipe_flush(p);
+    if (rc == SORA_OK && p->delivered) p->released = true;
+    return rc;
+}
+
+int sora_rx_wait_any(sora_rx_t* rx, int* ticket)
+{
+    if (!rx || !ticket) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_wait_any: null argument");
+    *ticket = 0;
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    for (unsigned spin = 0;; spin++) {
+        RxPipe* done = nullptr; bool pending = false;
+        for (int i = 0; i < sora_rx::kMaxDepth; i++) {
+            RxPipe* p = rx->pipes[i];
+            if (!p || p->ticket == 0 || !p->delivered || p->released) continue;
+            pending = true;
+            const hipError_t q = hipEventQuery(p->ev_done);
+            if (q == hipSuccess) { if (!done || p->ticket < done->ticket) done = p; }
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); return fail(SORA_ERR_HARDWARE_FAILED, "sora_rx_wait_any: hipEventQuery failed"); }
+        }
+        if (done) {
+            const int rc = pipe_flush(done);                                    // (its stream is idle: returns at once)
+            if (rc) return rc;
+            done->released = true; *ticket = done->ticket;
+            return SORA_OK;
+        }
+        if (!pending) return fail(SORA_ERR_FAILED, "sora_rx_wait_any: no call with an enqueued delivery (sora_rx_deliver_async) is in flight");
+        (void)hipGetLastError();                                                // (hipErrorNotReady is sticky for hipGetLastError)
+        if (spin > 64) std::this_thread::yield();
+    }
 }
 
 void* sora_rx_stream_of(sora_rx_t* rx, int ticket) { RxPipe* p = pipe_of(rx, ticket); return p ? pipe_stream(p) : nullptr; }

@@ -281,7 +281,11 @@ def test_calls_in_flight(sora, torch_cuda, oracle, depth):
         sets.append((torch_cuda.from_numpy(iq).cuda(), d, oracle_results(oracle, caps, 20)))
     rx = sora.Rx(max_captures=8, max_total_samples=max(len(t) for t, _, _ in sets), sample_rate_mhz=20, max_frames_per_capture=2)
     assert rx.set_depth(depth) == 8 and rx.set_depth(0) == depth
-    assert rx.trellis() == (16 if depth >= 4 else 64)                 # the automatic choice of the trellis kernel follows the depth
+    assert rx.trellis() == 64                                         # the automatic choice of the trellis kernel follows the capacity in flight (depth x max_captures)
+    big = sora.Rx(max_captures=4096, max_total_samples=4096 * 64, sample_rate_mhz=20, max_frames_per_capture=1)
+    big.set_depth(depth); assert big.trellis() == (16 if depth * 4096 >= 16384 else 64)
+    big.close()
+    rx.set_trellis(16 if depth >= 4 else 64)                          # (the deeper rotations run the eight-frames-per-wave kernel, as they do at full size)
     ncalls = max(9, 2 * depth + 1)                  # (every pipeline is used at least twice)
     tickets = []
     for k in range(ncalls):
@@ -492,6 +496,63 @@ def test_results_are_delivered_to_pinned_host_memory_behind_the_kernels(sora, to
     small = sora.HostResults(16, 64)
     with pytest.raises(sora.SoraError):                               # an MPDU buffer that is too small is refused, not overrun
         rx.deliver_async(rx.ticket(), small)
+    rx.close()
+
+
+def test_completions_are_taken_in_the_order_they_happen(sora, torch_cuda, oracle):
+    """sora_rx_wait_any: the host takes whichever delivered call has finished (calls in flight overtake one another) and the next process call reuses
+    THAT pipeline; every ticket comes back exactly once with its own results, older tickets stay addressable while a younger released one is recycled,
+    and with nothing in flight the call fails instead of blocking."""
+    sets = []
+    for s in range(3):
+        caps = [make_capture(oracle, [54000, 6000, 24000][s], 90 + 400 * (s == 1) + 11 * i, seed=1200 + 10 * s + i, rate_mhz=20, sigma=90, tail=160)[0] for i in range(2 + 2 * s)]
+        iq, d = batch(caps)
+        sets.append((torch_cuda.from_numpy(iq).cuda(), d, oracle_results(oracle, caps, 20)))
+    n = max(len(t) for t, _, _ in sets)
+    rx = sora.Rx(max_captures=8, max_total_samples=n, sample_rate_mhz=20, max_frames_per_capture=2)
+    depth = 4
+    rx.set_depth(depth)
+    with pytest.raises(sora.SoraError):
+        rx.wait_any()                                                # nothing in flight
+    bufs = {}; free = [sora.HostResults(16, (n // 80 + 8 + 16) * 32) for _ in range(depth)]
+    which = {}; seen = []
+
+    def submit(k):
+        t, d, _ = sets[k % 3]
+        tk = rx.process_dev(t, d)
+        bufs[tk] = free.pop(); which[tk] = k % 3
+        rx.deliver_async(tk, bufs[tk])
+        return tk
+
+    def check(tk):
+        want = sets[which[tk]][2]; b = bufs.pop(tk)
+        assert int(b.nrows[0]) == len(want)
+        for row, w in zip(b.rows[:len(want)], want):
+            for f in ("capture_id", "start_sample", "end_sample", "error_code", "rate_kbps", "length", "nsym", "crc32", "cfo_est"):
+                assert int(row[f]) == w[f], (tk, f, int(row[f]), w[f])
+            if w["error_code"] == 0x1:
+                assert bytes(b.mpdu[int(row["mpdu_offset"]):int(row["mpdu_offset"]) + w["length"]]) == w["mpdu"]
+        free.append(b)
+    k = 0
+    for _ in range(depth):
+        submit(k); k += 1
+    for _ in range(40):
+        tk = rx.wait_any(); seen.append(tk); check(tk)
+        submit(k); k += 1
+    while bufs:
+        tk = rx.wait_any(); seen.append(tk); check(tk)
+    assert sorted(seen) == list(range(1, k + 1))                     # every call exactly once
+    with pytest.raises(sora.SoraError):
+        rx.wait_any()
+    # a released younger call is recycled ahead of older calls still held
+    rx.flush()
+    a = submit(k); b_ = submit(k + 1); c = submit(k + 2); d_ = submit(k + 3)
+    rx.wait(c); check(c)                                              # c is released (delivered and waited for)
+    e = submit(k + 4)                                                 # takes c's pipeline: a, b, d stay addressable
+    for tk in (a, b_, d_, e):
+        ok, why = same_results(rx.results(ticket=tk), sets[which[tk]][2]); assert ok, (tk, why)
+    with pytest.raises(sora.SoraError):
+        rx.results(ticket=c)
     rx.close()
 
 

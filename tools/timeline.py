@@ -32,6 +32,18 @@ for t, d in pts:
 hist[cur] += t1 - last
 tot = sum(hist.values())
 print("  kernels running at once:", {k: "%.1f %%" % (100.0 * v / tot) for k, v in sorted(hist.items())})
+# the same per kernel: how many launches of THAT kernel were running at once (time-weighted), and the mean
+for name in sorted(per):
+    p2 = []
+    for s, e, n, q in steady:
+        if n == name:
+            p2.append((s, 1)); p2.append((e, -1))
+    p2.sort(); cur = 0; last = t0; h = collections.Counter()
+    for t, d in p2:
+        h[cur] += t - last; last = t; cur += d
+    h[cur] += t1 - last
+    tt = sum(h.values())
+    print("  %-28s at once: mean %.2f  %s" % (name[:28], sum(k * v for k, v in h.items()) / tt, {k: "%.0f %%" % (100.0 * v / tt) for k, v in sorted(h.items())}))
 qs = collections.defaultdict(int)
 for s, e, n, q in steady:
     qs[q] += e - s
