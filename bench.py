@@ -441,11 +441,12 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
 
 def bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, maxf, exp_rows, exp_mpdu, seconds, cores):
     """What a plain host gets when it hands over MORE PER CALL instead of keeping more calls in flight: the rotated device copies of the batch
-    as ONE call of len(d_iqs) x nfr captures, at most TWO such calls in flight, every call delivered (rows + MPDU bytes) and compared.  The first
+    as ONE call of 8 x nfr captures, at most TWO such calls in flight, every call delivered (rows + MPDU bytes) and compared.  The first
     call is verified against the already verified nfr-capture table, quarter by quarter (capture_id and mpdu_offset shifted, everything else and
     every MPDU byte equal).  Reported per nfr captures, so that it reads beside ms_per_step."""
-    g_n = len(d_iqs); n_iq = d_iqs[0].shape[0]
-    big = torch.cat(d_iqs)
+    copies = list(d_iqs) * max(1, 8 // len(d_iqs))                   # 8 x nfr captures per call: its trellis launch is two rounds of the chip's trellis slots
+    g_n = len(copies); n_iq = d_iqs[0].shape[0]                     # (at 4 x nfr it is exactly ONE round, and the step is bimodal, 0.39-0.53 ms: profiles/r04_r_call_size.txt)
+    big = torch.cat(copies)
     descs = sora_amd.Rx.captures([(g * n_iq + i * CAPTURE_SAMPLES, CAPTURE_SAMPLES, g * nfr + i) for g in range(g_n) for i in range(nfr)])
     rx = sora_amd.Rx(max_captures=g_n * nfr, max_total_samples=g_n * n_iq, sample_rate_mhz=20, device=local_rank, max_frames_per_capture=maxf)
     dep = 2
@@ -644,7 +645,7 @@ def pin_rank_threads(local_rank, world):
 
 def timed_with_delivery(sora_amd, rx, submit, depth, reps, rows_cap, mpdu_cap):
     """The timed region of the widened rows, the headline's protocol: every step = one process call (submit() -> ticket) + deliver_async of
-    its dense rows and MPDUs into page-locked host memory behind its kernels + wait for the OLDEST call in flight and comparison of the
+    its dense rows and MPDUs into page-locked host memory behind its kernels + wait for a call in flight (see anyorder) and comparison of the
     table it delivered (row bytes, MPDU bytes) with the first call's.  -> (ms per step, delivery object, the first call's result dicts)"""
     nb = depth + TableChecker.EXTRA
     bufs = [sora_amd.HostResults(rows_cap, mpdu_cap) for _ in range(nb)]
@@ -654,30 +655,38 @@ def timed_with_delivery(sora_amd, rx, submit, depth, reps, rows_cap, mpdu_cap):
     chk = TableChecker(bufs[0].rows[:n].tobytes(), bufs[0].mpdu[:m].copy())
     seq = [0]
 
-    def consume(tk, i):
-        rx.wait(tk)
-        b = bufs[i]
+    # handles with sora_*_wait_any take completions as they happen (and their next call reuses that pipeline); the two-slot handles wait for the older call
+    anyorder = hasattr(rx, "wait_any")
+    import collections
+    free = collections.deque(range(nb)); pend = {}
+
+    def consume_one():
+        if anyorder:
+            tk = rx.wait_any()
+        else:
+            tk = min(pend); rx.wait(tk)
+        i = pend.pop(tk); b = bufs[i]
         chk.check(i, int(b.counts[0]) == n and int(b.counts[1]) == m, b.rows[:n], b.mpdu[:m])
+        free.append(i)
 
     def block(k):
-        pend = []
         for _ in range(k):
-            i = seq[0] % nb; seq[0] += 1
+            i = free.popleft()
             chk.release(i)
             tk = submit()
-            rx.deliver_async(tk, bufs[i]); pend.append((tk, i))
+            rx.deliver_async(tk, bufs[i]); pend[tk] = i
             if len(pend) >= depth:
-                consume(*pend.pop(0))
-        for tk, i in pend:
-            consume(tk, i)
+                consume_one()
+        while pend:
+            consume_one()
     block(depth + 2)                                                        # warm-up
     t0 = time.perf_counter()
     block(reps)
     chk.finish()
     ms = (time.perf_counter() - t0) / reps * 1e3
     out = {"enabled": True, "calls_delivered_and_compared": chk.compared, "calls_with_wrong_tables": chk.bad, "rows_per_call": n, "mpdu_bytes_per_call": m,
-           "protocol": "every step = process call + deliver_async (dense rows + MPDUs to pinned host memory) + wait for the oldest of %d calls in flight, whose rows and MPDU bytes "
-                       "are compared with the verified first call's by a pool of %d host threads (inside the timed region)" % (depth, TableChecker.EXTRA)}
+           "protocol": "every step = process call + deliver_async (dense rows + MPDUs to pinned host memory) + wait for %s of %d calls in flight, whose rows and MPDU bytes "
+                       "are compared with the verified first call's by a pool of %d host threads (inside the timed region)" % ("whichever finishes first" if anyorder else "the oldest", depth, TableChecker.EXTRA)}
     for b in bufs:
         b.close()
     return ms, out, first
@@ -1120,6 +1129,7 @@ def main():
         return
     timed_steps = args.steps * repeats
     stats["delivered"], stats["bad"] = chk.compared, chk.bad
+    stats["mpdu_compared_timed"] = getattr(chk, "mpdu_compared", 0)
     mpdu_ok = bool(deliver) and all((b.mpdu == exp_mpdu).all() for b in bufs)     # the last calls' MPDU arrays once more, byte for byte
     # the same K steps once more with HIP events around every kernel launch (on the streams the kernels run on): the
     # roofline's launch durations are means over this region; `value` comes from the un-instrumented region above
@@ -1182,10 +1192,10 @@ def main():
         best2 = min((k for k in plain if k.startswith("calls_in_flight_2")), key=lambda k: plain[k]["ms_per_step"])
         plain["best_with_at_most_two_calls_in_flight"] = dict(plain[best2], config=best2)
         try:
-            plain["two_calls_in_flight_of_%d_captures" % (NCOPIES * nfr)] = bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, MAXF, exp_rows, exp_mpdu, args.min_seconds,
+            plain["two_calls_in_flight_of_%d_captures" % (8 * nfr)] = bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, MAXF, exp_rows, exp_mpdu, args.min_seconds,
                                                                                            share[1:] if len(share) > 1 else None)
         except Exception as e:                                      # (a second 320 MB input and its workspace: report, do not lose the line)
-            plain["two_calls_in_flight_of_%d_captures" % (NCOPIES * nfr)] = {"error": repr(e)}
+            plain["two_calls_in_flight_of_%d_captures" % (8 * nfr)] = {"error": repr(e)}
         plain["note"] = ("the headline keeps %d calls in flight%s; with at most two, the chip holds at most 8192 frames = 1024 waves of k_viterbi16 (one per SIMD, each bound by its own "
                          "issue rate) or 4096 of k_viterbi (1.7x the instructions): DESIGN.md section 3.6, profiles/r04_a_depth_table.txt" % (depth, " on %s hardware queues" % os.environ["GPU_MAX_HW_QUEUES"] if os.environ.get("GPU_MAX_HW_QUEUES") else ""))
     rx.set_trellis(trellis_setting); rx.set_depth(depth); rx.flush()
@@ -1229,14 +1239,14 @@ def main():
             "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
                        "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "input_copies_rotated": NCOPIES, "input_bytes_in_play": int(NCOPIES * iq.nbytes), "calls_in_flight": depth, "completions": "as they happen (sora_rx_wait_any)" if order["any"] else "oldest ticket first (sora_rx_wait)", "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
-                       "timed_region": "%d x %d steps in one continuous run; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for the oldest call in flight, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
+                       "timed_region": "%d x %d steps in one continuous run; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for %s, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, "whichever call in flight finishes first (sora_rx_wait_any)" if order["any"] else "the oldest call in flight", TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
             "decoded_mbit_per_s": round(msps * (MPDU_LEN * 8.0 / FRAME_SAMPLES), 2),
             "frames": tot_frames, "gathered_rows": gathered_rows, "gathered": gathered, "frames_crc_ok": tot_ok, "frames_payload_ok": tot_payload_ok,
             "parity": {"against": kind, "captures_checked": len(idx), "ok": parity_ok, "host_rows_ok": host_rows_ok},
             "host_ms_per_step": host_ms,
             "delivery": {"enabled": deliver, "calls_delivered_and_compared": tot_delivered, "calls_with_wrong_rows": tot_bad, "rows_per_call": exp_n,
-                         "row_bytes_per_call": 36 * nfr * MAXF, "mpdu_bytes_per_call": int(exp_mpdu.size), "last_calls_mpdu_ok": mpdu_ok, "calls_with_mpdu_bytes_compared": getattr(chk, "mpdu_compared", 0)},
+                         "row_bytes_per_call": 36 * nfr * MAXF, "mpdu_bytes_per_call": int(exp_mpdu.size), "last_calls_mpdu_ok": mpdu_ok, "calls_with_mpdu_bytes_compared": stats.get("mpdu_compared_timed", 0)},
             # the reference's own figure of merit (MACStopwatch.h:84-128): cost / required time, < 1 = faster than real time
             "realtime": {"factor": round(ms_per_step * 1e-3 / air_s, 7), "channels_20mhz_in_real_time": round(air_s / (ms_per_step * 1e-3), 1),
                          "call_latency_ms_one_in_flight": round(sum(v for k, v in ktimes1.items()), 4)},
@@ -1248,7 +1258,7 @@ def main():
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
                          "other_trellis_kernel": {"kernel": tname[80 - lanes], "kernel_ms": round(ktimes1_other[tname[80 - lanes]], 4),
                                                   "frac": round(launch_bytes / (ktimes1_other[tname[80 - lanes]] * 1e-3) / HBM_PEAK, 5),
-                                                  "note": "sora_rx_set_trellis: k_viterbi = two frames per wave (the faster one for a call alone on the chip), k_viterbi16 = eight per wave (the faster one from four calls in flight; the automatic choice follows the depth)"},
+                                                  "note": "sora_rx_set_trellis: k_viterbi = two frames per wave (the faster one for a call alone on the chip), k_viterbi16 = eight per wave (the faster one from 16384 captures in flight; the automatic choice follows depth x max_captures)"},
                          "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},

@@ -354,13 +354,14 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
 /* Calls in flight, as for sora_rx_t: consecutive process calls rotate over `depth` pipelines (own stream and result arrays; default 1, at most 8), so
  * the latency-bound scan / symbol kernels of one call overlap the issue-bound trellis kernel of the call before it.  Every call has a ticket;
  * sora_rx11n_results / _stream refer to the most recent call, sora_rx11n_wait / _results_of to the call whose ticket is given (valid until `depth`
- * further calls have been made); an input buffer must stay untouched until the call that reads it has finished.  sora_rx11n_set_depth returns the
+ * further calls have been made, or until the call is released: delivered and waited for, see sora_rx_wait_any); an input buffer must stay untouched until the call that reads it has finished.  sora_rx11n_set_depth returns the
  * previous value (depth <= 0 only queries) and waits for the calls in flight; sora_rx11n_process (host buffers) also does. */
 int   sora_rx11n_set_depth(sora_rx11n_t* rx, int depth);
 int   sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair);                                     /* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
 int   sora_rx11n_ticket(sora_rx11n_t* rx);
 int   sora_rx11n_synchronize(sora_rx11n_t* rx);                                                       /* every call issued so far has finished */
 int   sora_rx11n_wait(sora_rx11n_t* rx, int ticket);
+int   sora_rx11n_wait_any(sora_rx11n_t* rx, int* ticket);                                             /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is then released and its pipeline reused first */
 int   sora_rx11n_results_of(sora_rx11n_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 int   sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);   /* as sora_rx11b_deliver_async */
 

@@ -1149,6 +1149,7 @@ __global__ void __launch_bounds__(256) k_finish11n(Frame11nArgs A)
 
 // ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
 #include <vector>
+#include <thread>
 #include <string.h>
 #include <stdlib.h>
 using namespace sora;
@@ -1161,6 +1162,7 @@ struct Pipe11n {                         // one call in flight: a stream and eve
     std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
     uint32_t ncaps = 0; bool have_results = false; int ticket = 0;
     DenseStage dense;                       // sora_rx11n_deliver_async
+    hipEvent_t ev_done = nullptr; bool delivered = false, released = false;     // sora_rx11n_wait_any (the rules of sora_rx_wait_any, include/sora_hip.h)
 };
 struct sora_rx11n {
     sora_rx_cfg cfg{};
@@ -1185,6 +1187,7 @@ static void pipe11n_free(Pipe11n* p)
 {
     if (!p) return;
     if (p->stream) { (void)hipStreamSynchronize(p->stream); (void)hipStreamDestroy(p->stream); }
+    if (p->ev_done) (void)hipEventDestroy(p->ev_done);
     (void)hipFree(p->d_caps); (void)hipFree(p->d_rows); (void)hipFree(p->d_nframes); (void)hipFree(p->d_mpdu);
     (void)hipFree(p->d_frames); (void)hipFree(p->d_jobs); (void)hipFree(p->d_njobs); (void)hipFree(p->d_soft); (void)hipFree(p->d_vout);
     sora_internal_dense_free(&p->dense);
@@ -1283,8 +1286,13 @@ int sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_
     Pipe11n* P = pipe11n_of(rx, ticket);
     if (!P || !P->have_results) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_deliver_async: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
-    return sora_internal_dense_deliver(&P->dense, P->d_rows, P->d_nframes, P->d_caps, nullptr, P->ncaps, rx->cfg.max_frames_per_capture, P->d_mpdu, P->stream,
-                                       h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+    const int rc = sora_internal_dense_deliver(&P->dense, P->d_rows, P->d_nframes, P->d_caps, nullptr, P->ncaps, rx->cfg.max_frames_per_capture, P->d_mpdu, P->stream,
+                                               h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+    if (rc != SORA_OK) return rc;
+    if (!P->ev_done) HIPCHK11N(hipEventCreateWithFlags(&P->ev_done, hipEventDisableTiming));
+    HIPCHK11N(hipEventRecord(P->ev_done, P->stream));
+    P->delivered = true;
+    return SORA_OK;
 }
 
 int sora_rx11n_synchronize(sora_rx11n_t* rx)
@@ -1308,7 +1316,45 @@ int sora_rx11n_wait(sora_rx11n_t* rx, int ticket)
     if (!p) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_wait: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     HIPCHK11N(hipStreamSynchronize(p->stream));
+    if (p->delivered) p->released = true;
     return SORA_OK;
+}
+
+int sora_rx11n_wait_any(sora_rx11n_t* rx, int* ticket)
+{
+    if (!rx || !ticket) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_wait_any: null argument", 0);
+    *ticket = 0;
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    for (unsigned spin = 0;; spin++) {
+        Pipe11n* done = nullptr; bool pending = false;
+        for (int i = 0; i < rx->depth; i++) {
+            Pipe11n* p = rx->pipes[i];
+            if (!p || p->ticket == 0 || !p->delivered || p->released) continue;
+            pending = true;
+            const hipError_t q = hipEventQuery(p->ev_done);
+            if (q == hipSuccess) { if (!done || p->ticket < done->ticket) done = p; }
+            else if (q != hipErrorNotReady) { (void)hipGetLastError(); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_wait_any: hipEventQuery", (int)q); }
+        }
+        if (done) { HIPCHK11N(hipStreamSynchronize(done->stream)); done->released = true; *ticket = done->ticket; return SORA_OK; }
+        if (!pending) return sora_internal_fail(SORA_ERR_FAILED, "sora_rx11n_wait_any: no call with an enqueued delivery (sora_rx11n_deliver_async) is in flight", 0);
+        (void)hipGetLastError();
+        if (spin > 64) std::this_thread::yield();
+    }
+}
+
+// The pipeline of the next call: an unused one, else the released call with the oldest ticket, else the oldest call (plain rotation) -- sora_hip.cpp next_pipe()
+static int next_pipe11n(const sora_rx11n_t* rx)
+{
+    if (!rx->started) return 0;
+    int best = -1, best_rel = -1;
+    for (int i = 0; i < rx->depth; i++) {
+        const Pipe11n* p = rx->pipes[i];
+        if (!p) continue;
+        if (p->ticket == 0) return i;
+        if (p->released && (best_rel < 0 || p->ticket < rx->pipes[best_rel]->ticket)) best_rel = i;
+        if (best < 0 || p->ticket < rx->pipes[best]->ticket) best = i;
+    }
+    return best_rel >= 0 ? best_rel : best;
 }
 
 int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps)
@@ -1316,7 +1362,7 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_process_dev: null argument", 0);
     if (ncaps > rx->cfg.max_captures) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more captures than max_captures", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
-    const int idx = rx->started ? (rx->cur + 1) % rx->depth : 0;                   // consecutive calls rotate over the pipelines
+    const int idx = next_pipe11n(rx);                                            // consecutive calls rotate over the pipelines; a released one first
     Pipe11n* P = rx->pipes[idx];
     std::vector<CapDesc> h(ncaps);                                               // validated first: a refused call leaves the handle's calls intact
     uint64_t total = 0, slots = 0;
@@ -1329,7 +1375,7 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     if (total > rx->cfg.max_total_samples || (!rx->mono && slots > rx->cap_slots)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more samples than max_total_samples", 0);
     HIPCHK11N(hipStreamSynchronize(P->stream));                                  // the call that used this pipeline `depth` calls ago has finished
     P->h_desc.swap(h);
-    P->h_caps.assign(caps, caps + ncaps); P->ncaps = (uint32_t)ncaps; P->have_results = true; P->ticket = ++rx->next_ticket;
+    P->h_caps.assign(caps, caps + ncaps); P->ncaps = (uint32_t)ncaps; P->have_results = true; P->ticket = ++rx->next_ticket; P->delivered = P->released = false;
     rx->cur = idx; rx->started = true;
     if (ncaps == 0) return SORA_OK;
     HIPCHK11N(hipMemcpyAsync(P->d_caps, P->h_desc.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, P->stream));

@@ -249,3 +249,56 @@ def test_11n_calls_in_flight_are_collectable_by_ticket(depth):
     for bb in bufs:
         bb.close()
     rx.close()
+
+
+def test_11n_completions_are_taken_as_they_happen():
+    """sora_rx11n_wait_any: every delivered call comes back exactly once, with its own table; the released pipeline is the one reused."""
+    import torch
+    import sora_amd
+    if sora_amd.device_count() <= 0:
+        pytest.skip("no HIP device")
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rng = np.random.default_rng(777)
+    batches = []
+    for b in range(3):
+        caps = [capture_11n(rng, [frames[int(i)] for i in rng.integers(0, 4, size=1 + b)], sigma=float(rng.choice([5, 60]))) for _ in range(4 + 4 * b)]
+        iq0 = np.concatenate([a for a, _ in caps]); iq1 = np.concatenate([c for _, c in caps])
+        descs = []; off = 0
+        for i, (a, _) in enumerate(caps):
+            descs.append((off, len(a), i)); off += len(a)
+        batches.append((torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), descs))
+    rx = sora_amd.Rx11n(12, max(len(b[0]) for b in batches), max_frames_per_capture=8)
+    depth = 4
+    rx.set_depth(depth)
+    key = lambda r: (r["capture_id"], r["end_sample"], r["error_code"], r["rate_kbps"], r["length"], r["crc32"], r["mpdu"])
+    want = []
+    for b in batches:                                                          # the tables to expect, one call at a time
+        t = rx.process_dev(*b); want.append([key(r) for r in rx.results(ticket=t)])
+    rx.synchronize()
+    with pytest.raises(Exception):
+        rx.wait_any()                                                         # no delivery is pending
+    free = [sora_amd.HostResults(12 * 8, 1 << 18) for _ in range(depth)]
+    held = {}; seen = []; k = 0
+
+    def submit():
+        nonlocal k
+        t = rx.process_dev(*batches[k % 3]); held[t] = (free.pop(), k % 3); k += 1
+        rx.deliver_async(t, held[t][0])
+
+    def take():
+        t = rx.wait_any(); seen.append(t)
+        buf, which = held.pop(t)
+        assert [key(r) for r in buf.results()] == want[which], t
+        free.append(buf)
+    first = t + 1
+    for _ in range(depth):
+        submit()
+    for _ in range(24):
+        take(); submit()
+    while held:
+        take()
+    assert sorted(seen) == list(range(first, first + k))
+    for bb in free:
+        bb.close()
+    rx.close()
