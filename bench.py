@@ -1263,6 +1263,11 @@ def main():
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
+        try:                                                        # where the library this run loaded came from
+            from sora_amd import build as _b
+            out["build"] = dict(_b.build_info(), loaded=os.environ.get("SORA_HIP_LIB") or "sora_amd/lib/libsora_hip.so")
+        except Exception as e:
+            out["build"] = {"error": repr(e)}
         if plain:
             out["plain_host"] = plain
         if latency is not None:

@@ -47,6 +47,53 @@ def needs_build():
     return any(os.path.getmtime(os.path.join(CSRC, f)) > t for f in SOURCES + HEADERS)
 
 
+INFO = os.path.join(HERE, "lib", "libsora_hip.buildinfo.json")
+
+
+def sources_sha256():
+    """One hash over every source and header the library is built from (what a build stamp is compared with)."""
+    import hashlib
+    h = hashlib.sha256()
+    for f in sorted(SOURCES) + sorted(HEADERS):
+        with open(os.path.join(CSRC, f), "rb") as fh:
+            h.update(f.encode()); h.update(fh.read())
+    return h.hexdigest()
+
+
+def build_info():
+    """Where the library that is loaded came from (the .so is a git-ignored artefact that travels with the snapshot):
+    the stamp build() wrote beside it, whether its source hash is the tree's, and whether it was built on this host."""
+    import json, socket, hashlib
+    out = {"library": os.path.relpath(LIB, os.path.dirname(HERE)), "exists": os.path.exists(LIB)}
+    if out["exists"]:
+        with open(LIB, "rb") as fh:
+            out["library_sha256"] = hashlib.sha256(fh.read()).hexdigest()
+    try:
+        with open(INFO) as fh:
+            st = json.load(fh)
+    except Exception:
+        st = None
+    now = sources_sha256()
+    out["stamp"] = st
+    out["sources_sha256_now"] = now
+    out["built_from_this_tree"] = bool(st) and st.get("sources_sha256") == now and st.get("library_sha256") == out.get("library_sha256")
+    out["built_on_this_host"] = bool(st) and st.get("host") == socket.gethostname()
+    return out
+
+
+def _write_info(ncompiled):
+    import json, socket, hashlib, time
+    try:
+        ver = subprocess.run([hipcc(), "--version"], capture_output=True, text=True).stdout.splitlines()[0]
+    except Exception:
+        ver = None
+    with open(LIB, "rb") as fh:
+        lib_sha = hashlib.sha256(fh.read()).hexdigest()
+    with open(INFO, "w") as fh:
+        json.dump({"sources_sha256": sources_sha256(), "library_sha256": lib_sha, "host": socket.gethostname(), "built_at_unix": int(time.time()), "hipcc": ver,
+                   "flags": FLAGS, "objects_compiled_in_this_build": ncompiled}, fh, indent=1)
+
+
 def build_variant(name, defines):
     """An experimental build of the whole library with extra -D flags -> sora_amd/lib/variants/<name>.so (A/B measurements:
     run any entry point with SORA_HIP_LIB=<that file>)."""
@@ -80,6 +127,7 @@ def build(force=False, verbose=False):
     if verbose:
         print(" ".join(cmd))
     subprocess.check_call(cmd)
+    _write_info(len(todo))
     return LIB
 
 

@@ -314,6 +314,7 @@ struct RxPipe {
     double t_sum[8] = {}; uint64_t t_calls = 0;   // per-kernel durations (ms) summed over the profiled calls of this pipeline
     // tool hook (sora_internal_rx_timeline): when set, every profiled call also leaves its kernel boundaries as ms since *tl_base
     std::vector<float>* tl = nullptr; hipEvent_t* tl_base = nullptr; int index = 0;
+    unsigned only = 0xF;         // tool hook (sora_internal_rx_only): which kernels of the chain a call launches (1 scan, 2 frame, 4 trellis, 8 finish)
 };
 
 static constexpr size_t kNumTimed = 5;
@@ -494,15 +495,17 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
 
     auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
+        if (rx->only & 1u) {
         HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
         HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 12, st));
         HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));        // no symbol slot has an owner yet
+        }
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
         S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = rx->d_slot_row; S.cont = rx->cont; S.consumed = rx->consumed;
         mark();
-        hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
+        if (rx->only & 1u) hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
         RxArgs R{};
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
@@ -525,16 +528,17 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
             hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
 #else
-            hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+            if (rx->only & 2u) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
 #endif
             mark();
-            if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
+            if (!(rx->only & 4u)) {}
+            else if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
                 hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
             else
                 hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
         }
-        hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+        if (rx->only & 8u) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
         mark();
         return SORA_OK;
     };
@@ -955,6 +959,15 @@ int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, ui
     out[0] = p->d_frames; out[1] = p->d_slot_row; out[2] = p->d_eq; out[3] = p->d_track; out[4] = p->d_soft; out[5] = p->d_jobs; out[6] = p->d_joblist; out[7] = p->d_njobs;
     if (slots) *slots = p->total_slots;
     if (nrows) *nrows = p->ncaps * p->cfg.max_frames_per_capture;
+    return SORA_OK;
+}
+
+// Test / tool hook (not part of the ABI in include/sora_hip.h): the next calls launch only the kernels in `mask` (1 k_scan + its memsets, 2 k_frame, 4 the trellis
+// kernel, 8 k_finish) and leave the other stages' arrays as the last full call wrote them -- to time one kernel against another (tools/r04_corun.py).
+int sora_internal_rx_only(sora_rx_t* rx, unsigned mask)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    for (int i = 0; i < sora_rx::kMaxDepth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->only = mask & 0xFu; p->last_valid = false; } if (i + 1 >= rx->depth) break; }
     return SORA_OK;
 }
 

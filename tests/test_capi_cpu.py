@@ -145,3 +145,13 @@ def test_every_bound_function_declares_its_argument_types():
     no_args = {"sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count"}
     missing = [n for n in capi.EXPORTS if n not in no_args and getattr(L, n).argtypes is None]
     assert missing == ["sora_hip_memcpy_d2d"] or missing == [], missing      # (sora_hip_memcpy_d2d is for C hosts; the binding never calls it)
+
+
+def test_the_library_on_disk_is_built_from_the_sources_in_the_tree():
+    """The .so is a git-ignored artefact that travels with the snapshot: build() stamps it with a hash of every source and header, and build_info()
+    (reported in bench.py's `build` object) says whether the file that gets loaded was built from the tree as it is now."""
+    from sora_amd import build
+    build.build()
+    info = build.build_info()
+    assert info["exists"] and info["stamp"] and info["built_from_this_tree"], info
+    assert info["stamp"]["sources_sha256"] == build.sources_sha256()
