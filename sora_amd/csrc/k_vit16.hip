@@ -457,6 +457,12 @@ __device__ __forceinline__ void viterbi16_body(const VitJob* __restrict__ jobs, 
 #endif
 __global__ void SORA_VIT16_BOUNDS k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
+#ifdef SORA_EXP_STAGGER                                         // experiment (round 4): waves of one launch start up to SORA_EXP_STAGGER x 16 x 1.75 us apart (a hash of the workgroup), so that the
+    {                                                           // two waves of a SIMD are not in the add-compare-select stretch and in the trace-back at the same time
+        const uint32_t d = ((blockIdx.x * 2654435761u) >> 28) * SORA_EXP_STAGGER;
+        for (uint32_t i = 0; i < d; i++) __builtin_amdgcn_s_sleep(63);
+    }
+#endif
 #ifdef SORA_EXP_VIT_PRIO
     __builtin_amdgcn_s_setprio(SORA_EXP_VIT_PRIO);              // experiment (round 4): the issue-bound trellis waves ahead of the latency-bound front-end waves on their SIMD
 #endif
