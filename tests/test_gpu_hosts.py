@@ -61,6 +61,19 @@ def test_plain_c_host_decodes_the_recorded_dump(tmp_path, golden_dir):
     assert hashlib.sha256(mp.read_bytes()).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
 
 
+def test_plain_c_host_keeps_calls_in_flight_and_takes_completions_as_they_happen(tmp_path, golden_dir):
+    """examples/rxthread11a.c: RxThread's loop per call -- process_dev -> deliver_async into page-locked buffers -> (depth calls in flight) wait_any -> compare -- compiled
+    with gcc -std=c11 -Wall -Werror against include/sora_hip.h only.  30 calls of fsample-6 with 5 in flight: every delivered table equals the first call's, whose frame is the
+    recorded one; with nothing left in flight sora_rx_wait_any refuses instead of blocking."""
+    exe = build("gcc", "-std=c11", os.path.join(ROOT, "examples", "rxthread11a.c"), "rxthread11a")
+    iq = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8
+    dump = tmp_path / "fsample6.dmp"; dump.write_bytes(make_dump(iq, raw14=True))
+    for depth, calls in ((5, 30), (1, 3), (16, 40)):
+        out = run([exe, str(dump), "--raw14", "--calls", str(calls), "--depth", str(depth)])
+        assert "6000 kbps" in out and "length 1392" in out and "FCS 80ef9b11" in out and "FRAME_OK" in out, out
+        assert "calls %d, in flight %d, collected %d, tables differing from the first call's 0, idle wait_any refused" % (calls, depth, calls) in out, out
+
+
 def test_plain_c_hosts_of_the_11b_and_11n_graphs_run(tmp_path, golden_dir, oracle):
     """examples/demod11b.c / demod11n.c on recorded modulator output (tests/golden): every frame the oracle reports."""
     from test_oracle_11b import channel_11b
