@@ -196,14 +196,20 @@ __device__ __noinline__ void trace16(unsigned lds_off, unsigned U0, unsigned U1,
     unsigned q = rev6u(((st >> nn) | rev6u(H & 0x3Fu)) & 0x3Fu);                 // ring index at column 8j
     __attribute__((address_space(3))) uint8_t* pth = S.path[row * 2u + half];
     pth[0] = (uint8_t)H;
-    uint32_t p = pj;
-#pragma unroll 4
+    // The walk, unrolled in full: the ring position of step i is pj - i (mod P), a scalar -- its row's byte offset is one v_lshl_add off the dependence chain --
+    // so that a block costs four vector instructions (shift, field, two address adds) and the chain ds_read -> bfe -> lshl_add -> ds_read (round 4: it was seven,
+    // with the position counted down in a vector register).
+    typedef __attribute__((address_space(3))) const uint16_t lds_u16;
+    const unsigned rowbase = (unsigned)(uintptr_t)&S.ring[0][row][0], sh = 8u * half;
+#pragma unroll
     for (int i = 1; i < G::kMaxWalk; i++) {                                     // always the full length: blocks below the window are read and never used
-        p = p == 0 ? (uint32_t)P - 1u : p - 1u;
-        unsigned w = S.ring[p][row][q];
-        w = (w >> (8u * half)) & 0xFFu;
-        pth[i] = (uint8_t)w;
-        q = w & 0x3Fu;
+        const int d = (int)pj - i;
+        const uint32_t p = (uint32_t)(d < 0 ? d + P : d);
+        unsigned base = rowbase + p * 512u;
+        asm volatile("" : "+v"(base));                                          // (one register: the chain's add is then v_lshl_add, not a three-input add behind a shift)
+        const unsigned raw = *(lds_u16*)(uintptr_t)(base + (q << 1));
+        pth[i] = (uint8_t)(raw >> sh);                                          // (this frame's byte of the pair)
+        q = __builtin_amdgcn_ubfe(raw, sh, 6u);
     }
     lds_fence();
     // decoded byte m = (block m >> 6) | (block m + 1 & 0x3F) << 2; block m sits at walk position j - m.  Lane (l16 >> 1) of the row's
