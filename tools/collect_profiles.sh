@@ -1,6 +1,6 @@
 #!/bin/bash
-# collect_profiles.sh <tag> -- run on the GPU box (gpurun): kernel-trace stats of the bench command (default: three calls
-# in flight; and once more with ONE call in flight, so that every kernel's duration is the kernel alone on the chip) + the
+# collect_profiles.sh <tag> -- run on the GPU box (gpurun): kernel-trace stats of the headline loop (the handle's default calls in flight -- under the
+# tracer the host is the bottleneck there -- and once more with ONE call in flight, so that every kernel's duration is the kernel alone on the chip) + the
 # PMC passes (their own runs, one call in flight so that every dispatch is attributed cleanly).
 # Outputs land in gpurun_out/<tag>_*; copy the summaries to profiles/ afterwards (see DESIGN.md, section "Measurement").
 set -u
@@ -9,9 +9,9 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-QUICK="--no-cpu-baseline --no-extras --check 64"
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o p -- python $R/bench.py --no-cpu-baseline > $OUT/${TAG}_ks_bench.json 2> $OUT/${TAG}_ks.err
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks1 -o p -- python $R/bench.py $QUICK --depth 1 --trellis 16 > $OUT/${TAG}_ks1_bench.json 2> $OUT/${TAG}_ks1.err
+QUICK="--no-cpu-baseline --no-extras --no-plain --check 64"   # (--no-plain: the plain_host section launches 32768-capture calls, which do not belong in per-launch means of the 4096-capture call)
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o p -- python $R/bench.py $QUICK --headline-only --min-seconds 2 > $OUT/${TAG}_ks_bench.json 2> $OUT/${TAG}_ks.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks1 -o p -- python $R/bench.py $QUICK --headline-only --min-seconds 2 --depth 1 --trellis 16 > $OUT/${TAG}_ks1_bench.json 2> $OUT/${TAG}_ks1.err
 # the PMC passes, once per trellis kernel (sora_rx_set_trellis: 16 = k_viterbi16, what the default bench uses; 64 = k_viterbi)
 for T in 16 64; do
   PMC="$QUICK --steps 3 --warmup 1 --depth 1 --trellis $T --min-seconds 0 --no-deliver"
