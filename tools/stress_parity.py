@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--captures", type=int, default=600)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=100)
+    ap.add_argument("--trellis", type=int, default=0, help="0: the library's choice (k_viterbi for batches this small), 16: k_viterbi16, 64: k_viterbi")
     args = ap.parse_args()
     import torch
     import sora_amd
@@ -32,6 +33,8 @@ def main():
         caps = [random_capture(o, rng, mhz) for _ in range(min(args.batch, args.captures - b0))]
         iq, descs = batch(caps)
         rx = sora_amd.Rx(len(caps), len(iq), sample_rate_mhz=mhz, max_frames_per_capture=8)
+        if args.trellis:
+            rx.set_trellis(args.trellis)
         rx.process_dev(torch.from_numpy(iq).cuda(), descs)
         got = rx.results(); rx.close()
         want = []
