@@ -418,6 +418,7 @@ int   sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq
 int   sora_ht40_ticket(sora_ht40_t* rx);                       /* ticket of the most recent process call (0: none) */
 int   sora_ht40_calls_in_flight(sora_ht40_t* rx);              /* how many calls the handle keeps addressable */
 int   sora_ht40_wait(sora_ht40_t* rx, int ticket);
+int   sora_ht40_wait_any(sora_ht40_t* rx, int* ticket);                                               /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
 void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket);
 int   sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* As sora_rx11b_deliver_async, two rows per RECORDED frame (one per spatial stream).  Unlike sora_ht40_results_of -- and unlike the 802.11b /
@@ -500,6 +501,7 @@ int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls
  * previous setting (0, 1 or 2). */
 int   sora_rx11b_set_single_pass(sora_rx11b_t* rx, int enable);
 int   sora_rx11b_wait(sora_rx11b_t* rx, int ticket);
+int   sora_rx11b_wait_any(sora_rx11b_t* rx, int* ticket);                                             /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
 void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket);
 int   sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* Result delivery without a host wait (as sora_rx_deliver_async): behind the call's kernels, on its stream, the dense rows in (capture, time)

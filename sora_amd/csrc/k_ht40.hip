@@ -16,6 +16,7 @@
 // W = diag((W' H)_ss)^-1 W', W' = (H^H H + s2 I)^-1 H^H (unbiased MMSE) in single precision (documented tolerance: +-1 LSB of the int16 weight against a float64 evaluation,
 // tests/test_gpu_ht40.py).  The model the tests generate captures with is oracle/py_ht40.py.
 #include <vector>
+#include <thread>
 #include <algorithm>
 #include <string.h>
 #include "kernels.h"
@@ -368,6 +369,7 @@ struct Ht40Slot {
     uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; Rx11bRow* d_rows = nullptr;
     std::vector<sora_ht40_frame> h_frames; uint32_t nframes = 0;
     int ticket = 0;             // of the call this slot holds (0: none)
+    hipEvent_t ev_done = nullptr; bool delivered = false, released = false;     // sora_ht40_wait_any (kernels.h: slots_next / slots_poll)
     // sora_ht40_process_captures_dev: the front end's arrays (grow-only) and what it found in this slot's call
     CapDesc* d_caps = nullptr; size_t caps_bytes = 0; Rx11bRow* d_scanrows = nullptr; size_t scanrows_bytes = 0;
     uint32_t* d_nfr = nullptr; size_t nfr_bytes = 0; Ht40Found* d_found = nullptr; size_t found_bytes = 0;
@@ -396,6 +398,7 @@ static void ht40_free(sora_ht40_t* rx)
     if (!rx) return;
     for (Ht40Slot& S : rx->slot) {
         if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
+        if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         (void)hipFree(S.d_frames); (void)hipFree(S.d_jobs); (void)hipFree(S.d_njobs); (void)hipFree(S.d_fjobs); (void)hipFree(S.d_soft);
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
         sora_internal_dense_free(&S.dense);
@@ -496,8 +499,8 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
     }
     if (soft > rx->max_soft) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more soft values than max_soft_values", 0);
     S.h_frames.assign(frames, frames + nframes); S.nframes = (uint32_t)nframes; rx->have_results = true;
-    rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
-    S.ticket = ++rx->seq;
+    rx->last = rx->next;
+    S.ticket = ++rx->seq; S.delivered = S.released = false;
     if (nframes == 0) return SORA_OK;
     for (int r = 0; r < 4; r++) nj_stage[r] = nj[r];
     HIPCHK40(hipMemcpyAsync(S.d_frames, hf, sizeof(Ht40Frame) * nframes, hipMemcpyHostToDevice, S.stream));
@@ -524,6 +527,7 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
 {
     if (!rx || (nframes && (!d_iq0 || !d_iq1 || !frames))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: null argument", 0);
     HIPCHK40(hipSetDevice(rx->device));
+    rx->next = slots_next(rx->slot, kHt40Slots);                                  // an unused slot, else a released call's, else the oldest call's
     Ht40Slot& S = rx->slot[rx->next];
     HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
     S.events.clear(); S.capture_mode = false; S.events_pending = false; S.plan_error = false;
@@ -542,6 +546,7 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps)) || max_frames_per_capture == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_captures_dev: bad argument", 0);
     if ((uint64_t)ncaps * max_frames_per_capture >= (1ull << 31)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: too many rows", 0);
     HIPCHK40(hipSetDevice(rx->device));
+    rx->next = slots_next(rx->slot, kHt40Slots);                                  // an unused slot, else a released call's, else the oldest call's
     Ht40Slot& S = rx->slot[rx->next];
     HIPCHK40(hipStreamSynchronize(S.stream));                                     // the call that used this slot kHt40Slots calls ago
     const uint32_t mf = max_frames_per_capture;
@@ -566,8 +571,8 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     S.h_caps.assign(caps, caps + ncaps);
     S.events.clear(); S.capture_mode = true; S.capture_mf = mf; S.events_pending = true; S.plan_error = false; S.nframes = 0;
     S.bound_frames = (uint32_t)std::min<uint64_t>(nrows, rx->max_frames);
-    rx->have_results = true; rx->last = rx->next; rx->next = (rx->next + 1) % kHt40Slots;
-    S.ticket = ++rx->seq;
+    rx->have_results = true; rx->last = rx->next;
+    S.ticket = ++rx->seq; S.delivered = S.released = false;
     S.h_plan[0] = S.h_plan[1] = S.h_plan[2] = S.h_plan[3] = 0;
     if (ncaps == 0) { S.events_pending = false; return SORA_OK; }
     HIPCHK40(hipMemcpyAsync(S.d_caps, S.h_capsup, sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
@@ -700,7 +705,22 @@ int sora_ht40_wait(sora_ht40_t* rx, int ticket)
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
     HIPCHK40(hipSetDevice(rx->device));
     HIPCHK40(hipStreamSynchronize(S->stream));
+    if (S->delivered) S->released = true;
     return S->capture_mode ? ht40_collect_events(*S) : SORA_OK;                  // (a raw-capture call that outgrew the handle's capacity says so here)
+}
+int sora_ht40_wait_any(sora_ht40_t* rx, int* ticket)
+{
+    if (!rx || !ticket) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_wait_any: null argument", 0);
+    *ticket = 0;
+    HIPCHK40(hipSetDevice(rx->device));
+    for (unsigned spin = 0;; spin++) {
+        bool pending; hipError_t err;
+        Ht40Slot* S = slots_poll(rx->slot, kHt40Slots, &pending, &err);
+        if (err != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_wait_any: hipEventQuery", (int)err);
+        if (S) { const int t = S->ticket; const int rc = sora_ht40_wait(rx, t); *ticket = t; return rc; }   // (the ticket is reported even when its call outgrew the handle's capacity)
+        if (!pending) return sora_internal_fail(SORA_ERR_FAILED, "sora_ht40_wait_any: no call with an enqueued delivery (sora_ht40_deliver_async) is in flight", 0);
+        if (spin > 64) std::this_thread::yield();
+    }
 }
 void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket) { Ht40Slot* S = ht40_slot_of(rx, ticket); return S ? (void*)S->stream : nullptr; }
 int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
@@ -708,9 +728,13 @@ int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_ro
     Ht40Slot* S = ht40_slot_of(rx, ticket);
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
     HIPCHK40(hipSetDevice(rx->device));
-    if (S->capture_mode)                                                        // raw captures: template rows and frame count were written by k_ht40_plan; the host knows only the bound
-        return sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, nullptr, S->bound_frames, 2, S->d_mpdu, S->stream,
-                                           h_rows, max_rows, h_counts, h_mpdu, mpdu_cap, S->d_tmpl, S->d_plan);
+    if (S->capture_mode) {                                                      // raw captures: template rows and frame count were written by k_ht40_plan; the host knows only the bound
+        const int rc = sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, nullptr, S->bound_frames, 2, S->d_mpdu, S->stream,
+                                                   h_rows, max_rows, h_counts, h_mpdu, mpdu_cap, S->d_tmpl, S->d_plan);
+        if (rc != SORA_OK) return rc;
+        HIPCHK40(slots_mark_delivered(*S));
+        return SORA_OK;
+    }
     S->h_tmpl.resize(2 * (size_t)S->nframes);
     for (size_t j = 0; j < S->h_tmpl.size(); j++) {                             // (the same fields sora_ht40_results fills in on the host)
         sora_frame_result& o = S->h_tmpl[j]; const sora_ht40_frame& f = S->h_frames[j / 2];
@@ -720,8 +744,11 @@ int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_ro
     }
     // two rows per frame, always: "captures" = frames, max_frames_per_capture = 2, no per-capture counts.  (The template is read by an
     // asynchronous copy: it lives in the slot until the slot's next call.)
-    return sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, S->h_tmpl.data(), S->nframes, 2, S->d_mpdu, S->stream,
-                                       h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+    const int rc = sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, S->h_tmpl.data(), S->nframes, 2, S->d_mpdu, S->stream,
+                                               h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+    if (rc != SORA_OK) return rc;
+    HIPCHK40(slots_mark_delivered(*S));
+    return SORA_OK;
 }
 
 int sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)

@@ -934,6 +934,7 @@ __global__ void __launch_bounds__(1024) k_rx11b_count_flagged(const uint32_t* __
 
 // ------------------------------------------------------------------------------------------------ host side (C ABI, include/sora_hip.h)
 #include <vector>
+#include <thread>
 #include <string.h>
 #include "../../include/sora_hip.h"
 
@@ -948,6 +949,7 @@ struct Slot11b {
     CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_needs_cck = nullptr;
     std::vector<sora_capture_desc> h_caps;
     int ticket = 0;              // of the call this slot holds (0: none)
+    hipEvent_t ev_done = nullptr; bool delivered = false, released = false;      // sora_rx11b_wait_any (kernels.h: slots_next / slots_poll)
     DenseStage dense;            // sora_rx11b_deliver_async
     std::vector<CapDesc> h_desc;                 // staging for the descriptor upload (kept until the slot's next call)
     uint32_t ncaps = 0;
@@ -974,7 +976,7 @@ static void rx11b_free(sora_rx11b_t* rx)
     for (Slot11b& S : rx->slot) {
         if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
         (void)hipFree(S.d_caps); (void)hipFree(S.d_rows); (void)hipFree(S.d_nframes); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_needs_cck);
-        (void)hipFree(S.d_flagged); if (S.h_flagged) (void)hipHostFree(S.h_flagged); if (S.ev_flagged) (void)hipEventDestroy(S.ev_flagged);
+        (void)hipFree(S.d_flagged); if (S.h_flagged) (void)hipHostFree(S.h_flagged); if (S.ev_flagged) (void)hipEventDestroy(S.ev_flagged); if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         sora_internal_dense_free(&S.dense);
     }
     (void)hipFree(rx->d_iq_own);
@@ -1028,6 +1030,7 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     if (!rx || (ncaps && (!d_iq || !caps))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_process_dev: null argument", 0);
     if (ncaps > rx->cfg.max_captures) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process_dev: more captures than max_captures", 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
+    rx->next = slots_next(rx->slot, kSlots11b);                                       // an unused slot, else a released call's, else the oldest call's
     Slot11b& S = rx->slot[rx->next];
     std::vector<CapDesc>& h = S.h_desc;
     HIPCHK11(hipStreamSynchronize(S.stream));                                         // the slot's previous call may still be reading d_caps / writing results
@@ -1041,8 +1044,8 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     }
     if (total > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process_dev: more samples than max_total_samples", 0);
     S.h_caps.assign(caps, caps + ncaps); S.ncaps = (uint32_t)ncaps; rx->have_results = true;
-    rx->last = rx->next; rx->next = (rx->next + 1) % kSlots11b;
-    S.ticket = ++rx->seq;
+    rx->last = rx->next;
+    S.ticket = ++rx->seq; S.delivered = S.released = false;
     if (ncaps == 0) return SORA_OK;
     HIPCHK11(hipMemcpyAsync(S.d_caps, h.data(), sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
     Rx11bArgs A;
@@ -1083,6 +1086,7 @@ int sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsam
     HIPCHK11(hipSetDevice(rx->cfg.device));
     if (!rx->d_iq_own) HIPCHK11(hipMalloc((void**)&rx->d_iq_own, sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
     for (Slot11b& S : rx->slot) HIPCHK11(hipStreamSynchronize(S.stream));             // one upload buffer: no call may still be reading it
+    rx->next = slots_next(rx->slot, kSlots11b);                                       // (the slot process_dev is about to pick: nothing changes in between)
     HIPCHK11(hipMemcpyAsync(rx->d_iq_own, h_iq, sizeof(sora_complex16) * nsamples, hipMemcpyHostToDevice, rx->slot[rx->next].stream));
     return sora_rx11b_process_dev(rx, rx->d_iq_own, caps, ncaps);
 }
@@ -1162,7 +1166,22 @@ int sora_rx11b_wait(sora_rx11b_t* rx, int ticket)
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStale11b, 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
     HIPCHK11(hipStreamSynchronize(S->stream));
+    if (S->delivered) S->released = true;
     return SORA_OK;
+}
+int sora_rx11b_wait_any(sora_rx11b_t* rx, int* ticket)
+{
+    if (!rx || !ticket) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_wait_any: null argument", 0);
+    *ticket = 0;
+    HIPCHK11(hipSetDevice(rx->cfg.device));
+    for (unsigned spin = 0;; spin++) {
+        bool pending; hipError_t err;
+        Slot11b* S = slots_poll(rx->slot, kSlots11b, &pending, &err);
+        if (err != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11b_wait_any: hipEventQuery", (int)err);
+        if (S) { const int t = S->ticket; const int rc = sora_rx11b_wait(rx, t); if (rc == SORA_OK) *ticket = t; return rc; }
+        if (!pending) return sora_internal_fail(SORA_ERR_FAILED, "sora_rx11b_wait_any: no call with an enqueued delivery (sora_rx11b_deliver_async) is in flight", 0);
+        if (spin > 64) std::this_thread::yield();
+    }
 }
 void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket) { Slot11b* S = slot11b_of(rx, ticket); return S ? (void*)S->stream : nullptr; }
 int sora_rx11b_deliver_async(sora_rx11b_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
@@ -1170,8 +1189,11 @@ int sora_rx11b_deliver_async(sora_rx11b_t* rx, int ticket, sora_frame_result* h_
     Slot11b* S = slot11b_of(rx, ticket);
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStale11b, 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
-    return sora_internal_dense_deliver(&S->dense, S->d_rows, S->d_nframes, S->d_caps, nullptr, S->ncaps, rx->cfg.max_frames_per_capture, S->d_mpdu, S->stream,
-                                       h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+    const int rc = sora_internal_dense_deliver(&S->dense, S->d_rows, S->d_nframes, S->d_caps, nullptr, S->ncaps, rx->cfg.max_frames_per_capture, S->d_mpdu, S->stream,
+                                               h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
+    if (rc != SORA_OK) return rc;
+    HIPCHK11(slots_mark_delivered(*S));
+    return SORA_OK;
 }
 
 int sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)

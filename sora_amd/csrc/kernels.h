@@ -116,6 +116,41 @@ struct Ht40Found {
     uint32_t error_code;           // 0: recorded (the data field decides), else E_PLCP
 };
 
+
+// ---- completion order for the handles whose calls sit in a small array of slots (sora_rx11b_*, sora_ht40_*): the rules of sora_rx_wait_any
+// (include/sora_hip.h).  A slot type has { hipStream_t stream; int ticket; hipEvent_t ev_done; bool delivered, released; }.
+template <typename Slot> inline int slots_next(const Slot* s, int n)           // the slot of the next call: unused, else the released call with the oldest ticket, else the oldest call
+{
+    int best = 0, best_rel = -1;
+    for (int i = 0; i < n; i++) {
+        if (s[i].ticket == 0) return i;
+        if (s[i].released && (best_rel < 0 || s[i].ticket < s[best_rel].ticket)) best_rel = i;
+        if (s[i].ticket < s[best].ticket) best = i;
+    }
+    return best_rel >= 0 ? best_rel : best;
+}
+template <typename Slot> inline hipError_t slots_mark_delivered(Slot& s)       // behind the last copy of a delivery
+{
+    if (!s.ev_done) { const hipError_t e = hipEventCreateWithFlags(&s.ev_done, hipEventDisableTiming); if (e != hipSuccess) return e; }
+    const hipError_t e = hipEventRecord(s.ev_done, s.stream);
+    if (e == hipSuccess) s.delivered = true;
+    return e;
+}
+// -> the finished delivered slot with the oldest ticket (nullptr: none yet); *pending = some delivered call has not been released
+template <typename Slot> inline Slot* slots_poll(Slot* s, int n, bool* pending, hipError_t* err)
+{
+    Slot* done = nullptr; *pending = false; *err = hipSuccess;
+    for (int i = 0; i < n; i++) {
+        if (s[i].ticket == 0 || !s[i].delivered || s[i].released) continue;
+        *pending = true;
+        const hipError_t q = hipEventQuery(s[i].ev_done);
+        if (q == hipSuccess) { if (!done || s[i].ticket < done->ticket) done = &s[i]; }
+        else if (q != hipErrorNotReady) { (void)hipGetLastError(); *err = q; return nullptr; }
+    }
+    if (!done) (void)hipGetLastError();                                         // (hipErrorNotReady is sticky for hipGetLastError)
+    return done;
+}
+
 }  // namespace sora
 
 int sora_internal_scan_ht40(const uint32_t* iq0, const uint32_t* iq1, const sora::CapDesc* d_caps, uint32_t ncaps, uint32_t max_frames, sora::Rx11bRow* d_rows, uint32_t* d_nframes,

@@ -257,3 +257,51 @@ def run_11b_fixed(sora, caps):
     rx.process_dev(torch.from_numpy(np.concatenate(caps)).cuda(), descs)
     res = rx.results(); rx.close()
     return res
+
+
+@pytest.mark.gpu
+def test_11b_completions_are_taken_as_they_happen(sora, oracle):
+    """sora_rx11b_wait_any: every delivered call comes back exactly once with its own table; nothing pending -> refused."""
+    import torch
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "refgraph_11b.npz"))
+    from test_oracle_11b import channel_11b
+    batches = []
+    for b in range(3):
+        caps = [channel_11b(z["tx_%d" % ((i + b) % 4)], 300 + 17 * b + i) for i in range(3 + b)]
+        n = max(len(c) for c in caps) // 28 * 28
+        iq = np.concatenate([c[:n] if len(c) >= n else np.concatenate([c, np.zeros((n - len(c), 2), np.int16)]) for c in caps])
+        descs = [(i * n, n, i) for i in range(len(caps))]
+        batches.append((torch.from_numpy(np.ascontiguousarray(iq)).cuda(), descs))
+    rx = sora.Rx11b(8, max(len(b[0]) for b in batches), max_frames_per_capture=8)
+    key = lambda r: (r["capture_id"], r["end_sample"], r["error_code"], r["rate_kbps"], r["length"], r["crc32"], r["mpdu"])
+    want = []
+    for d, descs in batches:
+        t = rx.process_dev(d, descs); want.append([key(r) for r in rx.results(ticket=t)])
+    rx.synchronize()
+    with pytest.raises(sora.SoraError):
+        rx.wait_any()
+    depth = rx.calls_in_flight()
+    free = [sora.HostResults(8 * 8, 1 << 18) for _ in range(depth)]
+    held = {}; seen = []; k = 0; first = t + 1
+
+    def submit():
+        nonlocal k
+        d, descs = batches[k % 3]
+        tk = rx.process_dev(d, descs); held[tk] = (free.pop(), k % 3); k += 1
+        rx.deliver_async(tk, held[tk][0])
+
+    def take():
+        tk = rx.wait_any(); seen.append(tk)
+        buf, which = held.pop(tk)
+        assert [key(r) for r in buf.results()] == want[which] and len(want[which]) >= 1, tk
+        free.append(buf)
+    for _ in range(depth):
+        submit()
+    for _ in range(12):
+        take(); submit()
+    while held:
+        take()
+    assert sorted(seen) == list(range(first, first + k))
+    for b in free:
+        b.close()
+    rx.synchronize(); rx.close()

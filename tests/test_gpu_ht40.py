@@ -406,3 +406,48 @@ def test_gpu_psdus_equal_the_independent_float64_receiver(env):
     assert nframes >= 500, (nframes, missed_by_gpu, missed_by_f64)
     assert missed_by_gpu <= 0.04 * 540 and missed_by_f64 <= 0.02 * 540, (missed_by_gpu, missed_by_f64)
     assert both >= 2 * nframes * 0.95 and only_f64 <= 2 * nframes * 0.04, (nframes, both, only_f64, only_gpu)
+
+
+@pytest.mark.gpu
+def test_raw_capture_completions_are_taken_as_they_happen(env):
+    """sora_ht40_wait_any: eight raw-capture calls in flight, taken in the order they finish; every ticket exactly once, its delivered table equal to
+    results_of, the released slot reused by the next call; nothing pending -> refused."""
+    torch, sora = env
+    rng = np.random.default_rng(5151)
+    batches = []
+    for b in range(3):
+        specs = [[(8 + int(rng.integers(0, 7)), int(rng.integers(40, 400)), None)] for _ in range(6 + 2 * b)]
+        iq, descs, truth = _raw_captures(rng, specs, sigma=10.0)
+        batches.append((torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda(), descs))
+    rx = sora.RxHt40(16, 1 << 22)
+    with pytest.raises(sora.SoraError):
+        rx.wait_any()
+    depth = rx.calls_in_flight()
+    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["rate_kbps"], r["end_sample"], r["length"], r["crc32"], r["mpdu"])
+    free = [sora.HostResults(16 * 2 * 2, 1 << 16) for _ in range(depth)]
+    held = {}; seen = []; k = 0
+
+    def submit():
+        nonlocal k
+        f0, f1, descs = batches[k % 3]
+        t = rx.process_captures_dev(f0, f1, descs, max_frames_per_capture=2); held[t] = free.pop(); k += 1
+        rx.deliver_async(t, held[t])
+
+    def take():
+        t = rx.wait_any(); seen.append(t)
+        buf = held.pop(t)
+        got = buf.results(); ref = rx.results(ticket=t)                  # (the slot is released, but nothing has reused it yet)
+        assert [key(r) for r in got] == [key(r) for r in ref if r["error_code"] in (1, 0x80000006)] and len(got) >= 10, t
+        free.append(buf)
+    for _ in range(depth):
+        submit()
+    for _ in range(20):
+        take(); submit()
+    while held:
+        take()
+    assert sorted(seen) == list(range(1, k + 1))
+    with pytest.raises(sora.SoraError):
+        rx.wait_any()
+    for b in free:
+        b.close()
+    rx.synchronize(); rx.close()
