@@ -947,7 +947,7 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
     res = {}
     for lanes in (64, 16):
         rx.set_trellis(lanes)
-        res[lanes] = timed_with_delivery(sora_amd, rx, lambda: rx.process_captures_dev(f0, f1, caps, max_frames_per_capture=2), depth, 20, 2 * nframes, 2 * nframes * 1500 + 4096)
+        res[lanes] = timed_with_delivery(sora_amd, rx, lambda: rx.process_captures_dev(f0, f1, caps, max_frames_per_capture=2), depth, 20, 4 * nframes, 2 * nframes * 1500 + 4096)   # (room for two rows per event the captures could hold)
     best = min(res, key=lambda l: res[l][0])
     ms, delivery, first = res[best]
     ok = sum(r["error_code"] == 1 and r["mpdu"] == ps[r["stream"]] and r["rate_kbps"] == 14 for r in first)

@@ -421,11 +421,10 @@ int   sora_ht40_wait(sora_ht40_t* rx, int ticket);
 int   sora_ht40_wait_any(sora_ht40_t* rx, int* ticket);                                               /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
 void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket);
 int   sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
-/* As sora_rx11b_deliver_async, two rows per RECORDED frame (one per spatial stream).  Unlike sora_ht40_results_of -- and unlike the 802.11b /
- * 802.11n handles' delivery -- a raw-capture call delivers ONLY the decoded frames this way: an event that ended in the front end (an HT-SIG
- * whose CRC-8 fails, an unsupported MCS: E_ERROR_PLCP_HEADER_FAIL, no PSDU) has no row in the delivered table, and the SORA_ROW_TRUNCATED flag
- * of a capture with more frames than max_frames_per_capture is not carried.  A host that needs those collects the call with
- * sora_ht40_results_of(ticket), which reports one row per event in (capture, time) order. */
+/* As sora_rx11b_deliver_async.  The delivered table is the one sora_ht40_results_of reports, in (capture, time) order: two rows per RECORDED frame
+ * (one per spatial stream, start_sample = the stream) and -- raw-capture calls -- one row per event that ended in the front end (an HT-SIG whose CRC-8
+ * fails, an unsupported MCS: E_ERROR_PLCP_HEADER_FAIL, no PSDU); the rows of the last event a full capture could hold carry SORA_ROW_TRUNCATED.
+ * max_rows: at least 2 x the call's frames (descriptor calls) / 2 x ncaps x max_frames_per_capture (raw-capture calls: the host knows only that bound). */
 int   sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------

@@ -18,8 +18,10 @@ namespace sora {
 __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict__ rows, const uint32_t* __restrict__ nframes, const CapDesc* __restrict__ caps,
                                                      const sora_frame_result* __restrict__ tmpl, uint32_t ncaps_bound, uint32_t mf,
                                                      sora_frame_result* __restrict__ out, uint32_t* __restrict__ src_slot, uint32_t* __restrict__ meta, uint32_t mpdu_cap,
-                                                     const uint32_t* __restrict__ ncaps_dev)
+                                                     const uint32_t* __restrict__ ncaps_dev, const uint32_t* __restrict__ evbase)
 {
+    // evbase (the 40 MHz handle's raw-capture calls): "capture" c is an EVENT of the front end; evbase[c] = the row of rows[] its first row comes from, or 0xFFFFFFFF for
+    // an event without a decoded frame (a PLCP header that failed): its one row is the template row as it stands (error code, position; no MPDU)
     const uint32_t ncaps = ncaps_dev ? min(ncaps_bound, *ncaps_dev) : ncaps_bound;     // (the 40 MHz handle plans its frames on the device: the host knows only a bound)
     __shared__ uint32_t s_a[1024], s_b[1024];
     __shared__ uint32_t s_base[2];
@@ -30,9 +32,10 @@ __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict_
         const uint32_t c = c0 + t;
         const uint32_t found = c < ncaps ? (nframes ? nframes[c] : mf) : 0u;
         const uint32_t n = min(found, mf);
+        const uint32_t base = c < ncaps ? (evbase ? evbase[c] : c * mf) : 0u;
         uint32_t bytes = 0;
-        for (uint32_t i = 0; i < n; i++) {
-            const Rx11bRow& r = rows[(size_t)c * mf + i];
+        for (uint32_t i = 0; i < n && base != 0xFFFFFFFFu; i++) {
+            const Rx11bRow& r = rows[(size_t)base + i];
             if (r.error_code == E_FRAME_OK || r.error_code == E_CRC32_FAIL) bytes += min(r.length, 4096u);
         }
         s_a[t] = n; s_b[t] = bytes;
@@ -45,17 +48,23 @@ __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict_
         }
         uint32_t row = s_base[0] + s_a[t] - n, off = s_base[1] + s_b[t] - bytes;
         for (uint32_t i = 0; i < n; i++, row++) {
-            const Rx11bRow& r = rows[(size_t)c * mf + i];
             sora_frame_result o;
-            if (tmpl) o = tmpl[(size_t)c * mf + i];                              // (40 MHz HT: capture_id = frame id, start_sample = spatial stream, rate, symbols)
+            if (base == 0xFFFFFFFFu) {                                           // an event without a frame: the template row is the row
+                o = tmpl[(size_t)c * mf + i]; o.length = 0; o.crc32 = 0; o.mpdu_offset = off;
+                out[row] = o; src_slot[row] = 0xFFFFFFFFu;
+                continue;
+            }
+            const Rx11bRow& r = rows[(size_t)base + i];
+            uint16_t tflags = 0;
+            if (tmpl) { o = tmpl[(size_t)c * mf + i]; tflags = o.flags; }         // (40 MHz HT: capture_id = frame id, start_sample = spatial stream, rate, symbols; a raw-capture call's truncation flag)
             else { o.capture_id = caps[c].capture_id; o.start_sample = 0; o.nsym = 0; o.cfo_est = 0; o.rate_kbps = r.rate_kbps; o.end_sample = r.end_sample; }
             o.error_code = r.error_code; o.length = (uint16_t)r.length; o.crc32 = r.crc32;
-            o.flags = (uint16_t)((i + 1 == mf && found > mf) ? SORA_ROW_TRUNCATED : 0);
+            o.flags = (uint16_t)(tflags | ((i + 1 == mf && found > mf) ? SORA_ROW_TRUNCATED : 0));
             const bool has = r.error_code == E_FRAME_OK || r.error_code == E_CRC32_FAIL;
             const uint32_t len = has ? min(r.length, 4096u) : 0u;
             o.mpdu_offset = off;
             out[row] = o;
-            src_slot[row] = (has && off + len <= mpdu_cap) ? (uint32_t)((size_t)c * mf + i) : 0xFFFFFFFFu;    // (an MPDU that does not fit is not copied; the host sees it from the total)
+            src_slot[row] = (has && off + len <= mpdu_cap) ? (uint32_t)((size_t)base + i) : 0xFFFFFFFFu;    // (an MPDU that does not fit is not copied; the host sees it from the total)
             off += len;
         }
         __syncthreads();
@@ -100,7 +109,7 @@ void sora_internal_dense_free(DenseStage* D)
 int sora_internal_dense_deliver(DenseStage* D, const Rx11bRow* d_rows, const uint32_t* d_nframes, const CapDesc* d_caps, const sora_frame_result* h_tmpl,
                                 uint32_t ncaps, uint32_t mf, const uint8_t* d_slots, hipStream_t st,
                                 sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap,
-                                const sora_frame_result* d_tmpl, const uint32_t* d_ncaps)
+                                const sora_frame_result* d_tmpl, const uint32_t* d_ncaps, const uint32_t* d_evbase)
 {
     if (!D || !h_rows || !h_meta || (h_mpdu && mpdu_cap == 0)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "deliver_async: null argument", 0);
     const size_t cap_rows = (size_t)ncaps * mf;
@@ -116,7 +125,7 @@ int sora_internal_dense_deliver(DenseStage* D, const Rx11bRow* d_rows, const uin
     if (h_tmpl) e = hipMemcpyAsync(D->d_tmpl, h_tmpl, sizeof(sora_frame_result) * cap_rows, hipMemcpyHostToDevice, st);
     if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "deliver_async: row templates", (int)e);
     hipLaunchKernelGGL(k_dense_rows, dim3(1), dim3(1024), 0, st, d_rows, d_nframes, d_caps, (const sora_frame_result*)(d_tmpl ? d_tmpl : h_tmpl ? D->d_tmpl : nullptr), ncaps, mf,
-                       D->d_rows, D->d_src, D->d_meta, (uint32_t)(h_mpdu ? mpdu_cap : 0), d_ncaps);
+                       D->d_rows, D->d_src, D->d_meta, (uint32_t)(h_mpdu ? mpdu_cap : 0), d_ncaps, d_evbase);
     if (h_mpdu) hipLaunchKernelGGL(k_dense_mpdu, dim3((unsigned)((cap_rows + 3) / 4)), dim3(256), 0, st, (const sora_frame_result*)D->d_rows, (const uint32_t*)D->d_src,
                                    (const uint32_t*)D->d_meta, d_slots, D->d_mpdu);
     e = hipMemcpyAsync(h_meta, D->d_meta, 8, hipMemcpyDeviceToHost, st);

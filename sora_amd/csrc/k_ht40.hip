@@ -280,19 +280,21 @@ __device__ __forceinline__ Ht40Geom ht40_geom(const Ht40Found& F)
 __global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ caps, uint32_t ncaps, uint32_t mf, const uint32_t* __restrict__ nfr, const Ht40Found* __restrict__ found,
                                                     uint32_t max_frames, uint64_t max_soft, uint32_t vout_stride,
                                                     Ht40Frame* __restrict__ frames, VitJob* __restrict__ jobs, uint32_t stride, uint32_t* __restrict__ njobs, Ht40Job* __restrict__ fjobs,
-                                                    sora_frame_result* __restrict__ tmpl, uint32_t* __restrict__ plan)
+                                                    sora_frame_result* __restrict__ tmpl, uint32_t* __restrict__ plan, uint32_t* __restrict__ evbase, uint32_t* __restrict__ evn)
 {
-    __shared__ uint32_t s_v[5][1024];
-    __shared__ uint32_t s_base[5];
+    // Besides the data field's tables: the call's EVENT table for sora_ht40_deliver_async, in (capture, time) order like sora_ht40_results_of -- event e has evn[e] rows (two for a
+    // recorded frame, one for a header that failed), template rows tmpl[2 e + k], and evbase[e] = the row of the decoder's row table its rows start at (0xFFFFFFFF: no frame).
+    __shared__ uint32_t s_v[6][1024];
+    __shared__ uint32_t s_base[6];
     __shared__ uint32_t s_err;
     const uint32_t t = threadIdx.x;
-    if (t < 5) s_base[t] = 0;
+    if (t < 6) s_base[t] = 0;
     if (t == 0) s_err = 0;
     __syncthreads();
     for (uint32_t c0 = 0; c0 < ncaps; c0 += 1024) {
         const uint32_t c = c0 + t;
         const uint32_t n = c < ncaps ? min(nfr[c], mf) : 0u;
-        uint32_t mine[5] = { 0, 0, 0, 0, 0 };                                    // frames, soft bytes, frames of code rate 0 / 1 / 2
+        uint32_t mine[6] = { 0, 0, 0, 0, 0, n };                                 // frames, soft bytes, frames of code rate 0 / 1 / 2, events
         for (uint32_t i = 0; i < n; i++) {
             const Ht40Found& F = found[(size_t)c * mf + i];
             if (F.error_code != 0) continue;
@@ -300,27 +302,36 @@ __global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ 
             mine[0]++; mine[1] += 2u * G.per_pad; mine[2 + G.cr]++;
         }
 #pragma unroll
-        for (int k = 0; k < 5; k++) s_v[k][t] = mine[k];
+        for (int k = 0; k < 6; k++) s_v[k][t] = mine[k];
         __syncthreads();
-        for (uint32_t o = 1; o < 1024; o <<= 1) {                                // Hillis-Steele inclusive scans of the five counters
-            uint32_t add[5];
+        for (uint32_t o = 1; o < 1024; o <<= 1) {                                // Hillis-Steele inclusive scans of the six counters
+            uint32_t add[6];
 #pragma unroll
-            for (int k = 0; k < 5; k++) add[k] = t >= o ? s_v[k][t - o] : 0u;
+            for (int k = 0; k < 6; k++) add[k] = t >= o ? s_v[k][t - o] : 0u;
             __syncthreads();
 #pragma unroll
-            for (int k = 0; k < 5; k++) s_v[k][t] += add[k];
+            for (int k = 0; k < 6; k++) s_v[k][t] += add[k];
             __syncthreads();
         }
-        uint32_t at[5];
+        uint32_t at[6];
 #pragma unroll
-        for (int k = 0; k < 5; k++) at[k] = s_base[k] + s_v[k][t] - mine[k];
+        for (int k = 0; k < 6; k++) at[k] = s_base[k] + s_v[k][t] - mine[k];
         for (uint32_t i = 0; i < n; i++) {
             const Ht40Found& F = found[(size_t)c * mf + i];
-            if (F.error_code != 0) continue;
+            const uint32_t e = at[5]++;                                          // the event's index in the call
+            const uint16_t tflag = (uint16_t)((i + 1 == mf && nfr[c] > mf) ? SORA_ROW_TRUNCATED : 0);
+            if (F.error_code != 0) {                                             // a header that failed: one row, no frame (what sora_ht40_results_of reports for it)
+                sora_frame_result o;
+                o.capture_id = caps[c].capture_id; o.start_sample = 0; o.end_sample = F.end_sample; o.error_code = F.error_code; o.rate_kbps = 0;
+                o.length = 0; o.nsym = 0; o.crc32 = 0; o.cfo_est = 0; o.flags = tflag; o.mpdu_offset = 0;
+                tmpl[2u * e] = o; evbase[e] = 0xFFFFFFFFu; evn[e] = 1u;
+                continue;
+            }
             const Ht40Geom G = ht40_geom(F);
             const uint32_t fi = at[0], soft_off = at[1], pos = 2u * at[2 + G.cr];
             at[0]++; at[1] += 2u * G.per_pad; at[2 + G.cr]++;
-            if (fi >= max_frames || (uint64_t)soft_off + 2u * G.per_pad > max_soft || !(F.noise_var >= 0.0f)) { s_err = 1u; continue; }   // (reported by wait / results: SORA_ERR_CAPACITY)
+            evbase[e] = 2u * fi; evn[e] = 2u;
+            if (fi >= max_frames || (uint64_t)soft_off + 2u * G.per_pad > max_soft || !(F.noise_var >= 0.0f)) { s_err = 1u; evn[e] = 0u; continue; }   // (reported by wait / results: SORA_ERR_CAPACITY)
             Ht40Frame H;
             H.offset = caps[c].offset + 2ull * F.a20 + 160ull;                   // HT-STF is 4 us = 160 samples @40 MHz; HT-LTF 1 follows
             H.nsym = G.nsym; H.nb = G.nb; H.code_rate = G.cr; H.length[0] = H.length[1] = F.ht_len;   // one HT-SIG LENGTH: each stream carries its own PSDU of that length
@@ -335,20 +346,20 @@ __global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ 
                 fjobs[2u * fi + k] = Ht40Job{ J.out_off, F.ht_len, 2u * fi + k, 0u };
                 sora_frame_result o;
                 o.capture_id = caps[c].capture_id; o.start_sample = k; o.end_sample = F.end_sample; o.error_code = 0; o.rate_kbps = F.mcs;
-                o.length = 0; o.nsym = (uint16_t)G.nsym; o.crc32 = 0; o.cfo_est = 0; o.flags = 0; o.mpdu_offset = 0;
-                tmpl[2u * fi + k] = o;
+                o.length = 0; o.nsym = (uint16_t)G.nsym; o.crc32 = 0; o.cfo_est = 0; o.flags = tflag; o.mpdu_offset = 0;
+                tmpl[2u * e + k] = o;
             }
         }
         __syncthreads();
         if (t == 1023) {
 #pragma unroll
-            for (int k = 0; k < 5; k++) s_base[k] += s_v[k][1023];
+            for (int k = 0; k < 6; k++) s_base[k] += s_v[k][1023];
         }
         __syncthreads();
     }
     if (t == 0) {                                                                // (a batch that does not fit is not decoded at all: the job lists would have holes)
         const bool bad = s_err != 0;
-        plan[0] = bad ? 0u : s_base[0]; plan[1] = s_base[0]; plan[2] = s_base[1]; plan[3] = s_err;
+        plan[0] = bad ? 0u : s_base[0]; plan[1] = s_base[0]; plan[2] = s_base[1]; plan[3] = s_err; plan[4] = bad ? 0u : s_base[5];
         njobs[0] = bad ? 0u : 2u * s_base[2]; njobs[1] = bad ? 0u : 2u * s_base[3]; njobs[2] = bad ? 0u : 2u * s_base[4]; njobs[3] = 0;
     }
 }
@@ -375,7 +386,9 @@ struct Ht40Slot {
     uint32_t* d_nfr = nullptr; size_t nfr_bytes = 0; Ht40Found* d_found = nullptr; size_t found_bytes = 0;
     bool capture_mode = false; uint32_t capture_mf = 0; std::vector<Ht40Event> events;
     // ... planned on the device (k_ht40_plan): the records come back asynchronously into page-locked memory and are turned into `events` when the call is collected
-    uint32_t* d_plan = nullptr; sora_frame_result* d_tmpl = nullptr;
+    uint32_t* d_plan = nullptr;
+    uint32_t* d_evbase = nullptr; size_t evbase_bytes = 0; uint32_t* d_evn = nullptr; size_t evn_bytes = 0;   // the call's event table (k_ht40_plan -> sora_ht40_deliver_async)
+    sora_frame_result* d_evtmpl = nullptr; size_t evtmpl_bytes = 0; uint32_t bound_events = 0;
     void* h_stage = nullptr;                                                    // descriptor calls: page-locked staging of {frames, job lists, finish jobs, counts} for asynchronous uploads
     void* h_pin = nullptr; size_t pin_bytes = 0;                                // {plan[4], CapDesc[ncaps] (upload), nfr[ncaps], Ht40Found[ncaps * mf]}
     uint32_t* h_plan = nullptr; CapDesc* h_capsup = nullptr; uint32_t* h_nfr = nullptr; Ht40Found* h_found = nullptr;
@@ -403,7 +416,7 @@ static void ht40_free(sora_ht40_t* rx)
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
         sora_internal_dense_free(&S.dense);
         (void)hipFree(S.d_caps); (void)hipFree(S.d_scanrows); (void)hipFree(S.d_nfr); (void)hipFree(S.d_found);
-        (void)hipFree(S.d_plan); (void)hipFree(S.d_tmpl); if (S.h_pin) (void)hipHostFree(S.h_pin); if (S.h_stage) (void)hipHostFree(S.h_stage);
+        (void)hipFree(S.d_plan); (void)hipFree(S.d_evbase); (void)hipFree(S.d_evn); (void)hipFree(S.d_evtmpl); if (S.h_pin) (void)hipHostFree(S.h_pin); if (S.h_stage) (void)hipHostFree(S.h_stage);
     }
     delete rx;
 }
@@ -439,9 +452,8 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_vout, nj * kVoutStride + 256);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_mpdu, nj * 4096);
         if (e == hipSuccess) e = hipMalloc((void**)&S.d_rows, sizeof(Rx11bRow) * nj);
-        if (e == hipSuccess) e = hipMalloc((void**)&S.d_plan, 16);
+        if (e == hipSuccess) e = hipMalloc((void**)&S.d_plan, 32);
         if (e == hipSuccess) e = hipHostMalloc(&S.h_stage, sizeof(Ht40Frame) * max_frames + 3 * sizeof(VitJob) * nj + sizeof(Ht40Job) * nj + 64, hipHostMallocDefault);
-        if (e == hipSuccess) e = hipMalloc((void**)&S.d_tmpl, sizeof(sora_frame_result) * nj);
         if (e == hipSuccess) e = hipMemset(S.d_soft, 0, max_soft_values * 2 + 4096 + 1024);
         if (e == hipSuccess) e = hipMemset(S.d_vout, 0, nj * kVoutStride + 256);
     }
@@ -557,7 +569,9 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     }
     auto grow = [](void** p, size_t* have, size_t need) -> bool { if (*have >= need) return true; if (*p) (void)hipFree(*p); *p = nullptr; *have = 0; if (hipMalloc(p, need) != hipSuccess) return false; *have = need; return true; };
     if (ncaps && (!grow((void**)&S.d_caps, &S.caps_bytes, sizeof(CapDesc) * ncaps) || !grow((void**)&S.d_scanrows, &S.scanrows_bytes, sizeof(Rx11bRow) * nrows) ||
-                  !grow((void**)&S.d_nfr, &S.nfr_bytes, 4 * ncaps) || !grow((void**)&S.d_found, &S.found_bytes, sizeof(Ht40Found) * nrows)))
+                  !grow((void**)&S.d_nfr, &S.nfr_bytes, 4 * ncaps) || !grow((void**)&S.d_found, &S.found_bytes, sizeof(Ht40Found) * nrows) ||
+                  !grow((void**)&S.d_evbase, &S.evbase_bytes, 4 * nrows) || !grow((void**)&S.d_evn, &S.evn_bytes, 4 * nrows) ||
+                  !grow((void**)&S.d_evtmpl, &S.evtmpl_bytes, sizeof(sora_frame_result) * 2 * nrows)))
         return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_process_captures_dev: device allocation", 0);
     const size_t o_caps = 64, o_nfr = o_caps + ((sizeof(CapDesc) * ncaps + 63) & ~(size_t)63), o_found = o_nfr + ((4 * ncaps + 63) & ~(size_t)63), need = o_found + sizeof(Ht40Found) * nrows + 64;
     if (S.pin_bytes < need) {
@@ -570,7 +584,7 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     for (size_t i = 0; i < ncaps; i++) { CapDesc& h = S.h_capsup[i]; h.offset = caps[i].offset; h.nsamples = caps[i].nsamples; h.capture_id = caps[i].capture_id; h.slot_base = 0; h.nslots = 0; }
     S.h_caps.assign(caps, caps + ncaps);
     S.events.clear(); S.capture_mode = true; S.capture_mf = mf; S.events_pending = true; S.plan_error = false; S.nframes = 0;
-    S.bound_frames = (uint32_t)std::min<uint64_t>(nrows, rx->max_frames);
+    S.bound_frames = (uint32_t)std::min<uint64_t>(nrows, rx->max_frames); S.bound_events = (uint32_t)nrows;
     rx->have_results = true; rx->last = rx->next;
     S.ticket = ++rx->seq; S.delivered = S.released = false;
     S.h_plan[0] = S.h_plan[1] = S.h_plan[2] = S.h_plan[3] = 0;
@@ -581,7 +595,7 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
                                              rx->T, rx->sincos, rx->atan, S.stream); if (rc) return rc; }
     const size_t stride = 2 * (size_t)rx->max_frames;
     hipLaunchKernelGGL(k_ht40_plan, dim3(1), dim3(1024), 0, S.stream, (const CapDesc*)S.d_caps, (uint32_t)ncaps, mf, (const uint32_t*)S.d_nfr, (const Ht40Found*)S.d_found,
-                       rx->max_frames, (uint64_t)rx->max_soft, kVoutStride, S.d_frames, S.d_jobs, (uint32_t)stride, S.d_njobs, S.d_fjobs, S.d_tmpl, S.d_plan);
+                       rx->max_frames, (uint64_t)rx->max_soft, kVoutStride, S.d_frames, S.d_jobs, (uint32_t)stride, S.d_njobs, S.d_fjobs, S.d_evtmpl, S.d_plan, S.d_evbase, S.d_evn);
     HIPCHK40(hipMemcpyAsync(S.h_nfr, S.d_nfr, 4 * ncaps, hipMemcpyDeviceToHost, S.stream));
     HIPCHK40(hipMemcpyAsync(S.h_found, S.d_found, sizeof(Ht40Found) * nrows, hipMemcpyDeviceToHost, S.stream));
     HIPCHK40(hipMemcpyAsync(S.h_plan, S.d_plan, 16, hipMemcpyDeviceToHost, S.stream));
@@ -728,9 +742,11 @@ int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_ro
     Ht40Slot* S = ht40_slot_of(rx, ticket);
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
     HIPCHK40(hipSetDevice(rx->device));
-    if (S->capture_mode) {                                                      // raw captures: template rows and frame count were written by k_ht40_plan; the host knows only the bound
-        const int rc = sora_internal_dense_deliver(&S->dense, S->d_rows, nullptr, nullptr, nullptr, S->bound_frames, 2, S->d_mpdu, S->stream,
-                                                   h_rows, max_rows, h_counts, h_mpdu, mpdu_cap, S->d_tmpl, S->d_plan);
+    if (S->capture_mode) {                                                      // raw captures: the event table (rows per event, template rows, source rows) and the event count were written by
+        // k_ht40_plan; the host knows only the bound ncaps x max_frames_per_capture.  The table is the one sora_ht40_results_of reports: a header that failed is a row, the
+        // last row a full capture could hold carries SORA_ROW_TRUNCATED (round 4; before, only decoded frames were delivered).
+        const int rc = sora_internal_dense_deliver(&S->dense, S->d_rows, S->d_evn, nullptr, nullptr, S->bound_events, 2, S->d_mpdu, S->stream,
+                                                   h_rows, max_rows, h_counts, h_mpdu, mpdu_cap, S->d_evtmpl, S->d_plan + 4, S->d_evbase);
         if (rc != SORA_OK) return rc;
         HIPCHK40(slots_mark_delivered(*S));
         return SORA_OK;

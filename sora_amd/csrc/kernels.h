@@ -168,7 +168,7 @@ void sora_internal_dense_free(DenseStage* D);
 int sora_internal_dense_deliver(DenseStage* D, const sora::Rx11bRow* d_rows, const uint32_t* d_nframes, const sora::CapDesc* d_caps, const sora_frame_result* h_tmpl,
                                 uint32_t ncaps, uint32_t mf, const uint8_t* d_slots, hipStream_t st,
                                 sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap,
-                                const sora_frame_result* d_tmpl = nullptr, const uint32_t* d_ncaps = nullptr);   // (a template already on the device; the real number of "captures" where the host only knows a bound)
+                                const sora_frame_result* d_tmpl = nullptr, const uint32_t* d_ncaps = nullptr, const uint32_t* d_evbase = nullptr);   // (a template already on the device; the real number of "captures" where the host only knows a bound; per "capture" the row its rows start at, k_dense_rows)
 
 // sora_hip.cpp: the i-th stream of a handle (its i-th pipeline / slot), non-blocking, on priority level i % 3: the runtime keeps GPU_MAX_HW_QUEUES
 // hardware queues per level, so a handle's streams get a hardware queue each without the application setting an environment variable

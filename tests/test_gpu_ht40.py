@@ -318,7 +318,7 @@ def test_raw_captures_beyond_the_handles_capacity_are_reported(env):
 
 def test_raw_capture_calls_in_flight_and_delivery(env):
     """tickets and sora_ht40_deliver_async with raw captures: three different batches in flight, every call collected by its ticket, the
-    delivered tables equal to results_of (decoded frames; a failed header has no MPDU and is not delivered)."""
+    delivered tables equal to results_of row for row (decoded frames, headers that failed, the truncation flag)."""
     torch, sora = env
     rng = np.random.default_rng(4141)
     batches = []
@@ -330,13 +330,13 @@ def test_raw_capture_calls_in_flight_and_delivery(env):
     depth = rx.calls_in_flight()
     bufs = [sora.HostResults(16 * 2 * 2, 1 << 16) for _ in range(depth)]
     pend = []
-    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["rate_kbps"], r["end_sample"], r["length"], r["crc32"], r["mpdu"])
+    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["rate_kbps"], r["end_sample"], r["length"], r["crc32"], r["mpdu"], r.get("flags", 0))
     checked = [0]
 
     def collect(t0, b0, tr):
         rx.wait(t0)
         got = b0.results(); ref = rx.results(ticket=t0)
-        assert [key(r) for r in got] == [key(r) for r in ref if r["error_code"] in (1, 0x80000006)]
+        assert [key(r) for r in got] == [key(r) for r in ref]
         sent = {p for fr in tr for _, ps, _ in fr for p in ps}
         assert len(got) >= 18 and sum(r["error_code"] == 1 for r in got) >= 17 and all(r["mpdu"] in sent for r in got if r["error_code"] == 1)
         checked[0] += 1
@@ -437,7 +437,7 @@ def test_raw_capture_completions_are_taken_as_they_happen(env):
         t = rx.wait_any(); seen.append(t)
         buf = held.pop(t)
         got = buf.results(); ref = rx.results(ticket=t)                  # (the slot is released, but nothing has reused it yet)
-        assert [key(r) for r in got] == [key(r) for r in ref if r["error_code"] in (1, 0x80000006)] and len(got) >= 10, t
+        assert [key(r) for r in got] == [key(r) for r in ref] and len(got) >= 10, t
         free.append(buf)
     for _ in range(depth):
         submit()
@@ -451,3 +451,31 @@ def test_raw_capture_completions_are_taken_as_they_happen(env):
     for b in free:
         b.close()
     rx.synchronize(); rx.close()
+
+
+@pytest.mark.gpu
+def test_raw_capture_delivery_carries_failed_headers_and_truncation(env):
+    """sora_ht40_deliver_async of a raw-capture call delivers the table sora_ht40_results_of reports: a frame whose SIG field is spoiled is ONE row with
+    E_ERROR_PLCP_HEADER_FAIL between its neighbours' rows, and a capture with more frames than max_frames_per_capture ends in rows flagged SORA_ROW_TRUNCATED."""
+    torch, sora = env
+    rng = np.random.default_rng(6161)
+    specs = [[(9, 150, None), (10, 300, "sig"), (12, 333, None)], [(11, 80, None)], [(13, 200, None), (8, 90, None), (14, 400, None)], []]
+    iq, descs, truth = _raw_captures(rng, specs, sigma=8.0)
+    f0, f1 = torch.from_numpy(iq[0].copy()).cuda(), torch.from_numpy(iq[1].copy()).cuda()
+    key = lambda r: (r["capture_id"], r["stream"], r["error_code"], r["rate_kbps"], r["end_sample"], r["length"], r["crc32"], r["flags"], r["mpdu"])
+    for mf in (4, 2):
+        rx = sora.RxHt40(16, 1 << 21)
+        buf = sora.HostResults(len(specs) * mf * 2, 1 << 16)
+        t = rx.process_captures_dev(f0, f1, descs, max_frames_per_capture=mf)
+        rx.deliver_async(t, buf); rx.wait(t)
+        got = buf.results(); ref = rx.results(ticket=t)
+        assert [key(r) for r in got] == [key(r) for r in ref], mf
+        codes = [(r["capture_id"], r["error_code"]) for r in got]
+        if mf == 4:
+            assert codes.count((100, 0x80000005)) == 1 and sum(r["error_code"] == 1 for r in got) == 2 * 6 and all(r["flags"] == 0 for r in got)
+            i = codes.index((100, 0x80000005))
+            assert got[i - 1]["capture_id"] == 100 and got[i + 1]["capture_id"] == 100 and got[i]["mpdu"] == b""   # between its neighbours, in time order
+        else:
+            flagged = [r for r in got if r["flags"] & 1]
+            assert {r["capture_id"] for r in flagged} == {100, 102} and all(r["flags"] == 0 for r in got if r["capture_id"] == 101)
+        buf.close(); rx.close()
