@@ -413,7 +413,7 @@ int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_ou
 int   sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* h_caps, size_t ncaps,
                                      uint32_t max_frames_per_capture);
 /* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_ht40_calls_in_flight() (8) further calls have reused its
- * slot -- so back-to-back calls are all collectable, each by its own ticket, while later ones run.  The INPUT buffers of a call must stay
+ * slot (or, once the call is released -- delivered and waited for -- until the next call, which takes a released slot first) -- so back-to-back calls are all collectable, each by its own ticket, while later ones run.  The INPUT buffers of a call must stay
  * untouched until sora_ht40_wait(its ticket) (or _results_of, or _synchronize) has returned. */
 int   sora_ht40_ticket(sora_ht40_t* rx);                       /* ticket of the most recent process call (0: none) */
 int   sora_ht40_calls_in_flight(sora_ht40_t* rx);              /* how many calls the handle keeps addressable */
@@ -488,7 +488,7 @@ int  sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const 
 int  sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsamples, const sora_capture_desc* caps, size_t ncaps);
 int  sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_rx11b_calls_in_flight() (2) further calls have reused its
- * slot -- back-to-back calls are all collectable, each by its own ticket, while the next one runs (what fb11b_demod.cpp does per frame,
+ * slot (or, once the call is released -- delivered and waited for -- until the next call, which takes a released slot first) -- back-to-back calls are all collectable, each by its own ticket, while the next one runs (what fb11b_demod.cpp does per frame,
  * per call).  The INPUT buffer of a call must stay untouched until sora_rx11b_wait(its ticket) (or _results_of, or _synchronize) has returned. */
 int   sora_rx11b_ticket(sora_rx11b_t* rx);                     /* ticket of the most recent process call (0: none) */
 int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls the handle keeps addressable */
