@@ -321,6 +321,14 @@ static constexpr size_t kNumTimed = 5;
 static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_finish" };
 static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
 
+namespace sora {
+__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16)          // n16 16-byte words <- 0
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
+}
+}  // namespace sora
+
 // Adds the durations of the pipeline's last profiled call to its running sums (waits for that call).
 static int fold_profile(RxPipe* rx)
 {
@@ -338,7 +346,7 @@ static int fold_profile(RxPipe* rx)
 static void rx_free(RxPipe* rx)
 {
     if (!rx) return;
-    void* ptrs[] = { rx->d_caps, rx->d_frames, rx->d_fctx, rx->d_nframes,
+    void* ptrs[] = { rx->d_caps, rx->d_fctx, rx->d_nframes,
                      rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
@@ -409,16 +417,18 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out, int index = 0)
     rx->cap_slots = (uint32_t)want_slots;
     rx->cap_rows = (uint32_t)want_rows;
     struct { void** p; size_t bytes; } allocs[] = {
-        { (void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures }, { (void**)&rx->d_frames, sizeof(FrameRow) * rx->cap_rows },
+        { (void**)&rx->d_caps, sizeof(CapDesc) * cfg->max_captures },
         { (void**)&rx->d_fctx, sizeof(FrameCtx) * ((size_t)rx->cap_rows + cfg->max_captures) }, { (void**)&rx->d_nframes, 4 * (size_t)cfg->max_captures },
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
         { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
-        { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_njobs, 12 }, { (void**)&rx->d_joblist, 3 * 4 * (size_t)rx->cap_rows },
+        { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_joblist, 3 * 4 * (size_t)rx->cap_rows },
+        { (void**)&rx->d_njobs, 64 + sizeof(FrameRow) * rx->cap_rows },             // the three job counters AND, 64 bytes on, the frame table: one fill clears both at the start of a call
     };
     for (auto& a : allocs) {
         e = hipMalloc(a.p, a.bytes);
         if (e != hipSuccess) { rx_free(rx); return fail(SORA_ERR_HARDWARE_FAILED, "hipMalloc (receive-path arrays)", e); }
     }
+    rx->d_frames = reinterpret_cast<FrameRow*>(reinterpret_cast<uint8_t*>(rx->d_njobs) + 64);
     *out = rx;
     return SORA_OK;
 }
@@ -496,9 +506,15 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 
     auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
         if (rx->only & 1u) {
-        HIPCHK(hipMemsetAsync(rx->d_frames, 0, sizeof(FrameRow) * (size_t)nrows, st));
-        HIPCHK(hipMemsetAsync(rx->d_njobs, 0, 12, st));
-        HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));        // no symbol slot has an owner yet
+        // the job counters and the frame table behind them: ONE fill (every packet of a call costs the command processor a few microseconds, and a call is a dozen
+        // of them: DESIGN.md section 3.6) -- by a kernel of this library: a hipMemsetAsync of 64 + 64 n bytes recorded into a hipGraph faults on replay
+        {
+            const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16);
+            hipLaunchKernelGGL(k_clear16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16);
+        }
+#ifdef SORA_FRAME_SPLIT3
+        HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));        // no symbol slot has an owner yet (only the three-kernel symbol chain reads the owners)
+#endif
         }
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
