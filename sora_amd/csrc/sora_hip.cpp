@@ -314,6 +314,7 @@ struct RxPipe {
     double t_sum[8] = {}; uint64_t t_calls = 0;   // per-kernel durations (ms) summed over the profiled calls of this pipeline
     // tool hook (sora_internal_rx_timeline): when set, every profiled call also leaves its kernel boundaries as ms since *tl_base
     std::vector<float>* tl = nullptr; hipEvent_t* tl_base = nullptr; int index = 0;
+    unsigned extra = 0;          // tool hook (sora_internal_rx_extra): empty kernel launches appended to every call's chain (what does a packet cost?)
     unsigned only = 0xF;         // tool hook (sora_internal_rx_only): which kernels of the chain a call launches (1 scan, 2 frame, 4 trellis, 8 finish)
 };
 
@@ -555,6 +556,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             mark();
         }
         if (rx->only & 8u) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+        for (unsigned x = 0; x < rx->extra; x++) hipLaunchKernelGGL(k_clear16, dim3(1), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), 0u);
         mark();
         return SORA_OK;
     };
@@ -984,6 +986,14 @@ int sora_internal_rx_only(sora_rx_t* rx, unsigned mask)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     for (int i = 0; i < sora_rx::kMaxDepth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->only = mask & 0xFu; p->last_valid = false; } if (i + 1 >= rx->depth) break; }
+    return SORA_OK;
+}
+
+// Test / tool hook: `n` empty kernel launches behind every call's k_finish (tools/r04_packet_cost.sh).
+int sora_internal_rx_extra(sora_rx_t* rx, unsigned n)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    for (int i = 0; i < rx->depth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->extra = n; p->last_valid = false; } }
     return SORA_OK;
 }
 
