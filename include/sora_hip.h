@@ -188,11 +188,19 @@ int  sora_rx_set_depth(sora_rx_t* rx, int depth);
  *                    one while few frames are in flight (one 4096-frame call: 2048 waves for 1024 SIMDs);
  *   16  k_viterbi16  a frame pair in 16 lanes x 4 registers, eight frames per wave: half the vector instructions per frame and
  *                    no cross-row exchanges, but a quarter of the waves -- the faster one once several calls are in flight.
+ *   SORA_TRELLIS_WINDOWED (1)  k_viterbi16w (round 5): the frame's 256-bit trace-back windows (viterbi.hpp:196-214) decoded side by side, each run from
+ *                    all-equal metrics a warm-up ahead of its first window and PROVEN afterwards -- its metric vector at the preceding normalisation
+ *                    point must equal its predecessor's there (k_win_verify); a frame with a mismatch is decoded again by k_viterbi.  Bit-exact by
+ *                    construction; the kernel for few frames in flight (one capture, one lone call), where a frame per wave-slot leaves the chip idle.
  *   0   (default)    chosen by the library from the handle's capacity in flight: k_viterbi16 when depth x max_captures >= 16384
- *                    (four 4096-capture calls, two 16384-capture calls), k_viterbi below that.
+ *                    (four 4096-capture calls, two 16384-capture calls), the window-parallel form below that.
  * Returns the previous setting; a negative argument only queries. */
+#define SORA_TRELLIS_WINDOWED 1
 int  sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair);
-int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process call will use: 64 or 16 (resolves the automatic choice) */
+int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process call will use: 64, 16 or SORA_TRELLIS_WINDOWED (resolves the automatic choice) */
+/* The window-parallel trellis's proof record since the handle was created: out[0] unit boundaries compared, out[1] boundaries whose vectors differed,
+ * out[2] frames decoded again by the serial kernel because of that, out[3] units.  Waits for the handle's calls in flight. */
+int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
 /* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);

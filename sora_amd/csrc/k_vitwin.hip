@@ -1,0 +1,320 @@
+// k_vitwin.hip -- the K=7 trellis decoded WINDOW-PARALLEL with exact verification (round 5; gfx950).
+//
+//   k_viterbi16w   eight UNITS per wave in the 16-lanes-per-pair layout of k_vit16.hip (dev_vit16.h): a unit = windows k0 .. k1 - 1 of one frame
+//   k_win_verify   per frame: every unit's metric vector at its verify point against the vector its predecessor had there; a frame with a
+//                  mismatch is queued for the serial kernel (k_viterbi), which then overwrites what the units wrote
+//
+// Why.  T11aViterbi (viterbi.hpp:148-235) is one serial chain per frame: 8-bit wrapping metrics, the decision in the LSB, unsigned minimum --
+// no block decomposition of that arithmetic is exact by itself, so one frame was one wave-slot, a lone 4096-frame call
+// filled half the SIMDs (0.62 ms) and a single capture took 33 ns per trellis step (fsample-6: 0.37 ms).  But the chain FORGETS: the decoder's
+// whole state at a normalisation point (viterbicore.h:444-465) is the 64 seven-bit metrics relative to their minimum -- the LSBs are
+// overwritten by the next step -- and survivor paths merge within a few constraint lengths, after which that vector no longer depends on
+// where the decoder started.  The reference itself already cuts the frame into 256-bit trace-back windows (viterbi.hpp:196-214).
+//
+// How.  A unit starts kWinWarm steps before its VERIFY POINT b = floor24(256 k0) (a step at which every code rate normalises) from all-zero
+// metrics, steps through the same add-compare-select code as k_viterbi16 (the state <-> lane map is free at an all-equal start, so the unit
+// simply calls its first step "step 0": b - kWinWarm is a multiple of 24, which keeps puncture phase, normalisation points and 8-step decision
+// blocks aligned with the frame's), stores its vector when it reaches b, decodes its windows with the unchanged trace-back, and stores its
+// vector again at the next unit's verify point.  The frame's first unit starts at step 0 from the reference's initial metrics.  If
+// vector(unit u at b_u) == vector(unit u - 1 at b_u) for every u >= 1, then by induction every unit was on the reference decoder's own
+// trajectory from its verify point on -- the forward pass is a deterministic function of (vector at a normalisation point, soft values after
+// it) -- and every decision a window's walk reads (columns > 256 k0 >= b) is the reference's: bit-exact by construction, not by probability.
+// tools/winmodel measured how often the proof fails: never for a frame that passes its CRC (kWinWarm = 96, every rate, noise up to the
+// decoding threshold); frames that are noise fail and are decoded again serially, so the worst case costs the serial kernel on top.
+//
+// Cost: (kWinWarm + 30) extra steps per unit.  The planner (dev_winplan.h) cuts a call into about one chip's worth of units (16384): a lone
+// capture becomes units of one window, a 4096-frame call units of twelve.
+#include <hip/hip_runtime.h>
+#include "dev_vit16.h"
+
+namespace sora {
+
+namespace {
+
+constexpr uint32_t kNever = 0xFFFFFFFFu;
+
+// what a lane knows about one of the two units of its row
+struct UnitGeom {
+    uint32_t soft_off, last;     // the frame's stream, its last value
+    uint32_t i0;                 // soft value of the unit's first step
+    uint32_t nsteps;             // steps from the unit's first to the frame's last
+    uint32_t ob;                 // WIN k0 - s0: where, in the unit's own step count, its first window's bits begin
+    uint32_t tr_end;             // the frame's last trace-back, in the unit's step count
+    uint32_t vstep, estep;       // steps at which the unit's vector goes to vecs[..][0] / [..][1] (kNever: not)
+    uint32_t wleft;              // windows the unit decodes before it is done (the frame's end ends it anyway)
+    uint32_t vec;
+    uint8_t* out;                // the frame's output shifted by the unit's first step (bytes)
+    bool valid, first;
+};
+
+template <int CR, int WIN>
+__device__ __forceinline__ UnitGeom unit_geom(const VitJob* __restrict__ jobs, const WinUnit* __restrict__ units, uint32_t at, bool has, uint8_t* __restrict__ out)
+{
+    constexpr uint32_t GB = CR == 0 ? 2 : CR == 2 ? 4 : 3, GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;
+    UnitGeom g;
+    const WinUnit w = units[at];
+    const VitJob& J = jobs[w.job];
+    const uint32_t b = (uint32_t)WIN * w.k0 / 24u * 24u;
+    const uint32_t s0 = w.u == 0 ? 0u : b - (uint32_t)kWinWarm;
+    g.valid = has; g.first = w.u == 0;
+    g.soft_off = J.soft_off; g.last = max(J.nsoft, 1u) - 1u;
+    g.i0 = s0 / GS * GB;
+    g.nsteps = has ? J.nsoft / GB * GS - s0 : 0u;
+    g.ob = (uint32_t)WIN * w.k0 - s0;
+    g.tr_end = J.length * 8u + 16u + 6u - s0;
+    g.vstep = (has && w.u != 0) ? (uint32_t)kWinWarm : kNever;
+    g.estep = (has && w.k1 != 0xFFFFu) ? (uint32_t)WIN * w.k1 / 24u * 24u - s0 : kNever;
+    g.wleft = w.k1 == 0xFFFFu ? 0x10000u : (uint32_t)(w.k1 - w.k0);
+    g.vec = w.vec;
+    g.out = out + J.out_off + (s0 >> 3);
+    return g;
+}
+
+template <int CR, int WIN, int LOOK, int BITS>
+__device__ __forceinline__ void forward16w(Lds16<WIN, LOOK>& S, const uint8_t* __restrict__ soft, const UnitGeom& GA, const UnitGeom& GB_, uint16_t* __restrict__ vecs)
+{
+    using G = Geom16<WIN, LOOK>;
+    constexpr int P = G::P;
+    constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group
+    constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
+    constexpr int CW = 12 / GS * GB;                                            // operands per 12-step chunk: 24 / 18 / 16
+    constexpr uint32_t THR = WIN + LOOK + 6;
+    const unsigned lane = threadIdx.x & 63, row = lane >> 4, l16 = lane & 15, half = lane & 1u;
+    const unsigned v0 = v_of_lane(l16);
+    const UnitGeom& Mine = half ? GB_ : GA;
+    const uint32_t nsteps = wave_max_u32(max(GA.nsteps, GB_.nsteps));
+    const uint32_t my_last = Mine.last;
+
+    auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };
+    Vit16 V;
+    // the frame's first unit starts from ALL_INIT0 / ALL_INIT (viterbilut.h:22-30), every other one from all-equal metrics; each half of the registers is a unit of its own
+    {
+        const unsigned ia = GA.first ? 0x18u << 9 : 0u, ib = GB_.first ? 0x18u << 25 : 0u;
+#pragma unroll
+        for (int i = 0; i < 4; i++) V.U[i] = (v0 ^ kW[i]) == 0 ? 0u : (ia | ib);
+    }
+    const unsigned ring_base = (unsigned)(uintptr_t)&S.ring[0][0][0];
+#pragma unroll
+    for (int jb = 0; jb < 3; jb++)
+#pragma unroll
+        for (int i = 0; i < 4; i++) V.sadr[jb][i] = ring_base + ((row * 64u + rev6u(rol6(v0 ^ kW[i], jb == 0 ? 2 : jb == 1 ? 4 : 0))) << 1);
+#pragma unroll
+    for (int t = 0; t < 24; t++) {
+        const int ph = t % 6, k = t % 8;
+        const unsigned n = rol6(v0, ph + 1);
+        const bool vb = (v0 >> (5 - ph)) & 1u;
+        const unsigned ma = (__popc(n & 0155) & 1) ? 7u * kFld : 0u, mb = (__popc(n & 0117) & 1) ? 7u * kFld : 0u;
+        const unsigned mx = which_of(ph) == 2 ? mb : ma;
+        V.MX[t] = vb ? ((mx ^ (7u * kFld)) | (kOne << k)) : mx;
+        if (t < 6) V.MY[t] = vb ? (mb ^ (7u * kFld)) : mb;
+    }
+
+    uint32_t tr = 0;                                                            // steps taken, in every unit's own count (wave-uniform)
+    uint32_t pos = 0;
+    uint32_t my_ob = Mine.ob, my_wleft = Mine.wleft;
+    const uint32_t my_tr_end = Mine.tr_end;
+    bool my_done = !Mine.valid;
+    uint32_t vstepA = GA.vstep, vstepB = GB_.vstep, estepA = GA.estep, estepB = GB_.estep;   // (row-uniform: every lane holds a coset of BOTH units' metrics)
+
+    auto normalize = [&]() {
+        const unsigned m = row_pkmin(pk_min16(pk_min16(V.U[0], V.U[1]), pk_min16(V.U[2], V.U[3])));
+#pragma unroll
+        for (int i = 0; i < 4; i++) V.U[i] -= m;
+    };
+    auto pos_of = [&](uint32_t p, int jb) -> uint32_t { const uint32_t q = p + (uint32_t)jb; return q >= (uint32_t)P ? q - (uint32_t)P : q; };
+    auto trace = [&](uint32_t my_cnt, int t24_last) {
+        trace16<WIN, LOOK, true>((unsigned)(uintptr_t)&S, V.U[0], V.U[1], V.U[2], V.U[3], tr, my_ob, pos_of(pos, t24_last / 8), (uint32_t)(t24_last % 8), my_cnt, Mine.out);
+    };
+    auto next_event = [&]() -> uint32_t {
+        uint32_t mine = my_done ? kNever : min(my_ob + THR, my_tr_end);
+        mine = min(min(mine, min(vstepA, vstepB)), min(estepA, estepB));
+        return wave_min_u32(mine);
+    };
+    uint32_t next_thr = next_event();
+    bool all_done = wave_min_u32(my_done ? 1u : 0u) != 0u;
+    // a vector: register i of row-lane l16 at [16 i + l16], the unit's half of the register -- the same order at both ends of a comparison (both are taken at a
+    // multiple of 24 of the unit's own steps, where the state <-> lane map is the identity)
+    auto save = [&](uint32_t vec, int which, bool hi) {
+        uint16_t* d = vecs + ((size_t)vec * 2u + (uint32_t)which) * 64u + l16;
+#pragma unroll
+        for (int i = 0; i < 4; i++) d[16 * i] = (uint16_t)(hi ? V.U[i] >> 16 : V.U[i]);
+    };
+    auto check = [&](int t24_last) {
+        if (tr >= next_thr) {
+            // verification vectors: due only at multiples of 24 steps, i.e. straight after a normalisation, marks and carry guard cleared
+            if (tr == vstepA) { save(GA.vec, 0, false); vstepA = kNever; }
+            if (tr == vstepB) { save(GB_.vec, 0, true); vstepB = kNever; }
+            if (tr == estepA) { save(GA.vec, 1, false); estepA = kNever; }
+            if (tr == estepB) { save(GB_.vec, 1, true); estepB = kNever; }
+            // trace-back schedule (viterbi.hpp:196-214), per unit
+            uint32_t cnt = 0; bool partial = false;
+            if (!my_done) {
+                if (tr >= my_tr_end) { cnt = my_tr_end - my_ob - 6; my_done = true; }
+                else if (tr >= my_ob + THR) { cnt = WIN; partial = true; }
+            }
+            if (wave_max_u32(cnt) != 0u) trace(cnt, t24_last);
+            if (partial) { my_ob += WIN; if (--my_wleft == 0) my_done = true; }
+            next_thr = next_event();
+            all_done = wave_min_u32(my_done ? 1u : 0u) != 0u;
+        }
+    };
+
+    struct Chunk { uint32_t v[CW]; };
+    constexpr int NV = (CW + 7) / 8;
+    struct Raw { SoftRaw r[NV]; };
+    const uint32_t my_j = l16 >> 1;
+    SoftCursor<BITS, CW> cur[NV];
+#pragma unroll
+    for (int v = 0; v < NV; v++) cur[v].init(Mine.soft_off, Mine.i0 + my_j + 8u * v, my_last);
+    auto fetch = [&](uint32_t c) -> Raw {
+        Raw R;
+#pragma unroll
+        for (int v = 0; v < NV; v++) R.r[v] = cur[v].fetch(soft, c);
+        return R;
+    };
+    uint16_t* my_ops = &S.ops[row][my_j][half];
+    const uint4* row_ops = reinterpret_cast<const uint4*>(&S.ops[row][0][0]);
+    auto unpack = [&](const Raw& R) -> Chunk {
+#pragma unroll
+        for (int v = 0; v < NV; v++) my_ops[16 * v] = (uint16_t)cur[v].field(R.r[v]);
+        lds_fence();
+        Chunk K;
+#pragma unroll
+        for (int i = 0; i < (CW + 3) / 4; i++) {
+            const uint4 x = row_ops[i];
+            K.v[4 * i] = x.x; K.v[4 * i + 1] = x.y;
+            if (4 * i + 2 < CW) { K.v[4 * i + 2] = x.z; K.v[4 * i + 3] = x.w; }
+        }
+        lds_fence();
+        return K;
+    };
+    unsigned pos512[3];
+    auto set_row_pos = [&]() {
+#pragma unroll
+        for (int jb = 0; jb < 3; jb++) pos512[jb] = pos_of(pos, jb) * 512u;
+    };
+    auto end_row = [&]() { pos = pos_of(pos, 3); set_row_pos(); };
+    set_row_pos();
+    auto group = [&](const Chunk& K, int h, int i0) {
+        const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
+        acs16<0, P>(V, t24, K.v[k0], K.v[k0 + 1], pos512);
+        if (CR != 0) acs16<1, P>(V, t24 + 1, K.v[k0 + 2], 0, pos512);
+        if (CR == 2) acs16<2, P>(V, t24 + 2, 0, K.v[k0 + 3], pos512);
+        if ((t24 + GS) % 8 == 0) normalize();
+    };
+    auto fast_chunk = [&](const Chunk& K, int h) {
+#pragma unroll
+        for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
+        tr += 12;
+    };
+    auto slow_chunk = [&](const Chunk& K, int h) {
+#pragma unroll
+        for (int g = 0; g < 12 / GS; g++) {
+            if (tr < nsteps && !all_done) {
+                group(K, h, g * GS);
+                tr += GS;
+                check(12 * h + g * GS + GS - 1);
+            }
+        }
+    };
+    auto chunk = [&](const Chunk& K, int h) { if (tr + 12 <= nsteps && next_thr > tr + 12) fast_chunk(K, h); else slow_chunk(K, h); };
+
+    // A unit is a few hundred to a few thousand steps: the plain loop of k_viterbi16 (operands unpacked at the head of every chunk), without its
+    // two-table hand-over -- half the code, and what that hand-over buys (2 % for a wave alone on its SIMD) a unit gives back many times over.
+    uint32_t c = 0;
+    Raw b0 = fetch(0), b1 = fetch(1), b2, b3;
+    while (tr < nsteps && !all_done) {
+        const uint32_t lim = min(nsteps, next_thr - 1);
+        uint32_t rows = lim > tr ? (lim - tr) / 24 : 0;                         // rows that certainly need no look at the schedule
+        for (; rows > 0; rows--) {
+            b2 = fetch(c + 2);
+            fast_chunk(unpack(b0), 0);
+            b3 = fetch(c + 3);
+            fast_chunk(unpack(b1), 1);
+            end_row();
+            b0 = b2; b1 = b3;
+            c += 2;
+        }
+        if (!(tr < nsteps)) break;
+        b2 = fetch(c + 2);
+        chunk(unpack(b0), 0);
+        if (!(tr < nsteps && !all_done)) break;
+        b3 = fetch(c + 3);
+        chunk(unpack(b1), 1);
+        end_row();
+        b0 = b2; b1 = b3;
+        c += 2;
+    }
+}
+
+// One wave per workgroup: wave w of code-rate list r decodes units 8w .. 8w+7 of the list, one pair of units per 16-lane row.
+template <int WIN, int LOOK, int BITS>
+__device__ __forceinline__ void viterbi16w_body(const VitJob* __restrict__ jobs, const WinUnit* __restrict__ units, const uint32_t* __restrict__ nunits3, uint32_t ustride,
+                                                const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
+{
+    __shared__ Lds16<WIN, LOOK> S;
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t n[3] = { nunits3[0], nunits3[1], nunits3[2] };
+    uint32_t w = uni(blockIdx.x), list = 0;
+    while (list < 3 && w >= (min(n[list], ustride) + 7) / 8) { w -= (min(n[list], ustride) + 7) / 8; list++; }
+    if (list >= 3) return;
+    const uint32_t nun = uni(min(n[list], ustride));
+    units += (size_t)list * ustride;
+    const unsigned lane = threadIdx.x & 63, row = lane >> 4;
+    const uint32_t fa = 8u * w + 2u * row, fb = fa + 1u;
+    const bool hasA = fa < nun, hasB = fb < nun;
+    const uint32_t atA = hasA ? fa : 8u * w, atB = hasB ? fb : atA;              // an empty slot reads a unit that exists (its operands are never used, it writes nothing)
+    const uint32_t code_rate = uni(jobs[units[8u * w].job].code_rate);           // (a list holds one code rate)
+    if (code_rate == 0) {
+        const UnitGeom A = unit_geom<0, WIN>(jobs, units, atA, hasA, out), B = unit_geom<0, WIN>(jobs, units, atB, hasB, out);
+        forward16w<0, WIN, LOOK, BITS>(S, soft, A, B, vecs);
+    } else if (code_rate == 1) {
+        const UnitGeom A = unit_geom<1, WIN>(jobs, units, atA, hasA, out), B = unit_geom<1, WIN>(jobs, units, atB, hasB, out);
+        forward16w<1, WIN, LOOK, BITS>(S, soft, A, B, vecs);
+    } else {
+        const UnitGeom A = unit_geom<2, WIN>(jobs, units, atA, hasA, out), B = unit_geom<2, WIN>(jobs, units, atB, hasB, out);
+        forward16w<2, WIN, LOOK, BITS>(S, soft, A, B, vecs);
+    }
+}
+
+}  // namespace
+
+__global__ void __launch_bounds__(64) k_viterbi16w(const VitJob* __restrict__ jobs, const WinUnit* __restrict__ units, const uint32_t* __restrict__ nunits3, uint32_t ustride,
+                                                   const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
+{ viterbi16w_body<256, 24, 3>(jobs, units, nunits3, ustride, soft, out, vecs); }
+
+// One wave per frame (job slot), four per workgroup: lane l compares boundary l + 1 (, l + 65, ...) of the frame -- unit u's vector at its verify point against
+// unit u - 1's vector at the same step, 128 bytes each.  Any mismatch: the frame's VitJob goes to the list the serial kernel decodes afterwards.
+// stats[0..3] += boundaries compared, boundaries that differed, frames queued again, units.
+__global__ void __launch_bounds__(256) k_win_verify(const VitJob* __restrict__ jobs, const WinFrame* __restrict__ wframes, uint32_t* __restrict__ hdr, uint32_t jstride,
+                                                    const uint16_t* __restrict__ vecs, VitJob* __restrict__ redo, unsigned long long* __restrict__ stats)
+{
+    const JobRef jr = locate_job(blockIdx.x * 4u + (threadIdx.x >> 6), hdr);
+    if (!jr.ok) return;
+    const unsigned lane = threadIdx.x & 63;
+    const uint32_t jslot = jr.list * jstride + jr.idx;
+    const WinFrame F = wframes[jslot];
+    uint32_t bad = 0;
+    for (uint32_t u = 1u + lane; u < F.nunits; u += 64u) {
+        const uint4* a = reinterpret_cast<const uint4*>(vecs + ((size_t)(F.vec0 + u) * 2u) * 64u);            // unit u, at its own verify point
+        const uint4* b = reinterpret_cast<const uint4*>(vecs + ((size_t)(F.vec0 + u - 1u) * 2u + 1u) * 64u);  // unit u - 1, at the same step
+        uint32_t d = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const uint4 x = a[i], y = b[i]; d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
+        bad += d != 0u;
+    }
+#pragma unroll
+    for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o);
+    if (lane == 0) {
+        if (bad) {
+            const uint32_t at = atomicAdd(&hdr[kHdrRedo + jr.list], 1u);
+            redo[(size_t)jr.list * jstride + at] = jobs[jslot];
+        }
+        if (stats) {
+            atomicAdd(&stats[0], (unsigned long long)(F.nunits - 1u)); atomicAdd(&stats[3], (unsigned long long)F.nunits);
+            if (bad) { atomicAdd(&stats[1], (unsigned long long)bad); atomicAdd(&stats[2], 1ull); }
+        }
+    }
+}
+
+}  // namespace sora

@@ -285,7 +285,9 @@ struct RxPipe {
     uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
     uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;   // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
-    int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip)
+    int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
+                                                                // 2 = k_viterbi16w + k_win_verify + k_viterbi on what failed its proof (window-parallel, k_vitwin.hip)
+    WinUnit* d_wunits = nullptr; WinFrame* d_wframes = nullptr; uint16_t* d_wvecs = nullptr; VitJob* d_rjobs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
@@ -318,6 +320,7 @@ struct RxPipe {
     unsigned only = 0xF;         // tool hook (sora_internal_rx_only): which kernels of the chain a call launches (1 scan, 2 frame, 4 trellis, 8 finish)
 };
 
+constexpr uint32_t kWinUnitsTarget = 16384;                     // units a call of the window-parallel trellis is cut into at least, frames permitting: one round of the chip's 2048 eight-unit trellis slots
 static constexpr size_t kNumTimed = 5;
 static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_finish" };
 static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
@@ -348,7 +351,8 @@ static void rx_free(RxPipe* rx)
 {
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_fctx, rx->d_nframes,
-                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil };
+                     rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil,
+                     rx->d_wunits, rx->d_wframes, rx->d_wvecs, rx->d_rjobs, rx->d_wstats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -480,6 +484,15 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMalloc((void**)&rx->d_soft, (size_t)kSoftBytesPerSlot * rx->cap_slots + kSoftSlack));   // three bits per soft value (rx_types.h)
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
+    if (rx->lanes16 == 2 && !rx->d_wunits) {                                     // the window-parallel trellis's tables, on its first use
+        rx->wstride = kWinUnitsTarget + rx->cap_rows;
+        HIPCHK(hipMalloc((void**)&rx->d_wunits, 3 * sizeof(WinUnit) * (size_t)rx->wstride));
+        HIPCHK(hipMalloc((void**)&rx->d_wframes, 3 * sizeof(WinFrame) * (size_t)rx->cap_rows));
+        HIPCHK(hipMalloc((void**)&rx->d_wvecs, (size_t)kWinVecBytes * rx->wstride));
+        HIPCHK(hipMalloc((void**)&rx->d_rjobs, 3 * sizeof(VitJob) * (size_t)rx->cap_rows));
+        HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(rx->d_wstats, 0, 4 * sizeof(unsigned long long)));
+    }
     if (!rx->d_slot_row) {
         HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
 #ifdef SORA_FRAME_SPLIT3
@@ -545,10 +558,21 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
             hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
 #else
+            if (rx->lanes16 == 2) { R.wunits = rx->d_wunits; R.wframes = rx->d_wframes; R.hdr = rx->d_njobs; R.wstride = rx->wstride; R.wtarget = kWinUnitsTarget; }
             if (rx->only & 2u) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
 #endif
             mark();
             if (!(rx->only & 4u)) {}
+            else if (rx->lanes16 == 2) {
+                // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), the proof, and
+                // the serial kernel over the frames whose proof failed (none, normally: its workgroups find empty lists and return)
+                const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);   // (a frame has at most 80 windows)
+                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const WinUnit*)rx->d_wunits,
+                                   (const uint32_t*)(rx->d_njobs + kHdrUnits), rx->wstride, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
+                hipLaunchKernelGGL(k_win_verify, dim3((nrows + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const WinFrame*)rx->d_wframes, rx->d_njobs, nrows,
+                                   (const uint16_t*)rx->d_wvecs, rx->d_rjobs, rx->d_wstats);
+                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_rjobs, (const uint32_t*)(rx->d_njobs + kHdrRedo), 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
+            }
             else if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
                 hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
             else
@@ -827,9 +851,9 @@ int sora_rx_set_fused(sora_rx_t* rx, int enable)
 // Which trellis kernel a call uses: k_viterbi16 pays off once enough frames are in flight to give every SIMD a wave of it (it packs
 // eight frames into a wave, k_viterbi two); see DESIGN.md section 3.1.  What counts is the handle's capacity in flight, not the number
 // of tickets: two calls of 16384 captures fill the chip like eight of 4096, and eight calls of 64 captures do not.
-static int lanes16_for(const sora_rx* rx)
+static int lanes16_for(const sora_rx* rx)                                       // -> RxPipe::lanes16: 0 k_viterbi, 1 k_viterbi16, 2 window-parallel
 {
-    if (rx->trellis) return rx->trellis == 16;
+    if (rx->trellis) return rx->trellis == 16 ? 1 : rx->trellis == 1 ? 2 : 0;
     return (long long)rx->depth * (long long)rx->cfg.max_captures >= kAutoLanes16Captures;
 }
 
@@ -837,16 +861,31 @@ int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     const int old = rx->trellis;
-    if (lanes_per_pair == 0 || lanes_per_pair == 16 || lanes_per_pair == 64) {
+    if (lanes_per_pair == 0 || lanes_per_pair == 16 || lanes_per_pair == 64 || lanes_per_pair == SORA_TRELLIS_WINDOWED) {
         rx->trellis = lanes_per_pair;
         for (RxPipe* p : rx->pipes) if (p) p->last_valid = false;               // (a recorded hipGraph holds the other kernel)
-    } else if (lanes_per_pair > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_trellis: 0 (automatic), 16 or 64 lanes per frame pair");
+    } else if (lanes_per_pair > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_trellis: 0 (automatic), 16 or 64 lanes per frame pair, or SORA_TRELLIS_WINDOWED");
     return old;
+}
+
+// boundaries compared, boundaries that differed, frames decoded again by the serial kernel, units -- summed over the handle's pipelines since its creation
+int sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4])
+{
+    if (!rx || !out) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_window_stats: null argument");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    for (RxPipe* p : rx->pipes) if (p && p->d_wstats) {
+        unsigned long long v[4];
+        HIPCHK(hipStreamSynchronize(p->stream));
+        HIPCHK(hipMemcpy(v, p->d_wstats, sizeof v, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 4; i++) out[i] += v[i];
+    }
+    return SORA_OK;
 }
 
 int sora_internal_rx_device(sora_rx_t* rx) { return rx ? rx->cfg.device : -1; }
 
-int sora_rx_trellis(sora_rx_t* rx) { return rx ? (lanes16_for(rx) ? 16 : 64) : SORA_ERR_INVALID_PARAM; }
+int sora_rx_trellis(sora_rx_t* rx) { return rx ? (lanes16_for(rx) == 2 ? SORA_TRELLIS_WINDOWED : lanes16_for(rx) ? 16 : 64) : SORA_ERR_INVALID_PARAM; }
 
 int sora_rx_set_graph(sora_rx_t* rx, int enable)
 {
