@@ -9,7 +9,6 @@
 #include <utility>
 #include "kernels.h"
 #include "dev_viterbi.h"
-#include "dev_winplan.h"
 
 namespace sora {
 
@@ -50,7 +49,6 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
         J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
         A.jobs[j] = J;
     }
-    win_plan_frame(A, jr.list, jr.idx, r.length, r.code_rate, (unsigned)lane, 64u, [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); });
     const FrameCtx* fx = A.fctx + f;
     const uint32_t* iq = A.iq + A.caps[r.capture].offset;
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
@@ -310,7 +308,6 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
         J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
         A.jobs[j] = J;
     }
-    if (jr.ok) win_plan_frame(A, jr.list, jr.idx, r.length, r.code_rate, (unsigned)pk, 4u, [&](uint32_t v) { return (uint32_t)__shfl((int)v, lane & ~3); });
     // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
     const int pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
     int cfo_comp = r.cfo_comp, sfo_comp = r.sfo_comp, cfo_tr = r.cfo_tracker, sfo_tr = r.sfo_tracker;

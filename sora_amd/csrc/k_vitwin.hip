@@ -22,10 +22,13 @@
 // tools/winmodel measured how often the proof fails: never for a frame that passes its CRC (kWinWarm = 96, every rate, noise up to the
 // decoding threshold); frames that are noise fail and are decoded again serially, so the worst case costs the serial kernel on top.
 //
-// Cost: (kWinWarm + 30) extra steps per unit.  The planner (dev_winplan.h) cuts a call into about one chip's worth of units (16384): a lone
-// capture becomes units of one window, a 4096-frame call units of twelve.
+// Cost: (kWinWarm + 30) extra steps per unit.  A call is cut into about one chip's worth of units (dev_winplan.h; 16384): a lone capture
+// becomes units of one window, a 4096-frame call units of twelve.  Unit u of frame idx sits at position u x frames + idx of its code rate's
+// list -- the eight units of a wave are the same piece of eight frames, so their trace-backs fall on the same steps.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include "dev_vit16.h"
+#include "dev_winplan.h"
 
 namespace sora {
 
@@ -47,25 +50,32 @@ struct UnitGeom {
     bool valid, first;
 };
 
-template <int CR, int WIN>
-__device__ __forceinline__ UnitGeom unit_geom(const VitJob* __restrict__ jobs, const WinUnit* __restrict__ units, uint32_t at, bool has, uint8_t* __restrict__ out)
+// position p of a code-rate list of n frames -> the unit it holds (if any)
+template <int CR, int WIN, int LOOK>
+__device__ __forceinline__ UnitGeom unit_geom(const VitJob* __restrict__ jobs, uint32_t n, uint32_t p, uint32_t q, uint32_t vbase, uint8_t* __restrict__ out)
 {
     constexpr uint32_t GB = CR == 0 ? 2 : CR == 2 ? 4 : 3, GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;
     UnitGeom g;
-    const WinUnit w = units[at];
-    const VitJob& J = jobs[w.job];
-    const uint32_t b = (uint32_t)WIN * w.k0 / 24u * 24u;
-    const uint32_t s0 = w.u == 0 ? 0u : b - (uint32_t)kWinWarm;
-    g.valid = has; g.first = w.u == 0;
+    const bool inside = p < n * q;
+    const uint32_t upos = inside ? p / n : 0u, idx = inside ? p - upos * n : 0u;
+    const VitJob& J = jobs[idx];
+    const uint32_t nev = win_events(J.length, CR, WIN, LOOK), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
+    const bool has = inside && upos < nun;
+    const uint32_t u = has ? (m == 1u ? win_unit_at(upos, nun) : upos) : 0u;
+    const uint32_t k0 = u * m, k1 = (u + 1u) * m;
+    const bool last = u + 1u >= nun;
+    const uint32_t b = (uint32_t)WIN * k0 / 24u * 24u;
+    const uint32_t s0 = u == 0 ? 0u : b - (uint32_t)kWinWarm;
+    g.valid = has; g.first = u == 0;
     g.soft_off = J.soft_off; g.last = max(J.nsoft, 1u) - 1u;
     g.i0 = s0 / GS * GB;
     g.nsteps = has ? J.nsoft / GB * GS - s0 : 0u;
-    g.ob = (uint32_t)WIN * w.k0 - s0;
+    g.ob = (uint32_t)WIN * k0 - s0;
     g.tr_end = J.length * 8u + 16u + 6u - s0;
-    g.vstep = (has && w.u != 0) ? (uint32_t)kWinWarm : kNever;
-    g.estep = (has && w.k1 != 0xFFFFu) ? (uint32_t)WIN * w.k1 / 24u * 24u - s0 : kNever;
-    g.wleft = w.k1 == 0xFFFFu ? 0x10000u : (uint32_t)(w.k1 - w.k0);
-    g.vec = w.vec;
+    g.vstep = (has && u != 0) ? (uint32_t)kWinWarm : kNever;
+    g.estep = (has && !last) ? (uint32_t)WIN * k1 / 24u * 24u - s0 : kNever;
+    g.wleft = last ? 0x10000u : m;
+    g.vec = vbase + idx * q + u;
     g.out = out + J.out_off + (s0 >> 3);
     return g;
 }
@@ -247,57 +257,60 @@ __device__ __forceinline__ void forward16w(Lds16<WIN, LOOK>& S, const uint8_t* _
     }
 }
 
-// One wave per workgroup: wave w of code-rate list r decodes units 8w .. 8w+7 of the list, one pair of units per 16-lane row.
+// One wave per workgroup: wave w of code-rate list r holds positions 8w .. 8w+7 of the list, one pair of units per 16-lane row.
 template <int WIN, int LOOK, int BITS>
-__device__ __forceinline__ void viterbi16w_body(const VitJob* __restrict__ jobs, const WinUnit* __restrict__ units, const uint32_t* __restrict__ nunits3, uint32_t ustride,
+__device__ __forceinline__ void viterbi16w_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
                                                 const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
 {
     __shared__ Lds16<WIN, LOOK> S;
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
-    const uint32_t n[3] = { nunits3[0], nunits3[1], nunits3[2] };
+    const uint32_t n[3] = { hdr[0], hdr[1], hdr[2] };
+    const uint32_t q = uni(win_units_per_frame(n[0] + n[1] + n[2], target));
     uint32_t w = uni(blockIdx.x), list = 0;
-    while (list < 3 && w >= (min(n[list], ustride) + 7) / 8) { w -= (min(n[list], ustride) + 7) / 8; list++; }
+    while (list < 3 && w >= (n[list] * q + 7) / 8) { w -= (n[list] * q + 7) / 8; list++; }
     if (list >= 3) return;
-    const uint32_t nun = uni(min(n[list], ustride));
-    units += (size_t)list * ustride;
+    const uint32_t nl = uni(n[list]);
+    jobs += (size_t)list * jstride;
     const unsigned lane = threadIdx.x & 63, row = lane >> 4;
-    const uint32_t fa = 8u * w + 2u * row, fb = fa + 1u;
-    const bool hasA = fa < nun, hasB = fb < nun;
-    const uint32_t atA = hasA ? fa : 8u * w, atB = hasB ? fb : atA;              // an empty slot reads a unit that exists (its operands are never used, it writes nothing)
-    const uint32_t code_rate = uni(jobs[units[8u * w].job].code_rate);           // (a list holds one code rate)
-    if (code_rate == 0) {
-        const UnitGeom A = unit_geom<0, WIN>(jobs, units, atA, hasA, out), B = unit_geom<0, WIN>(jobs, units, atB, hasB, out);
-        forward16w<0, WIN, LOOK, BITS>(S, soft, A, B, vecs);
-    } else if (code_rate == 1) {
-        const UnitGeom A = unit_geom<1, WIN>(jobs, units, atA, hasA, out), B = unit_geom<1, WIN>(jobs, units, atB, hasB, out);
-        forward16w<1, WIN, LOOK, BITS>(S, soft, A, B, vecs);
-    } else {
-        const UnitGeom A = unit_geom<2, WIN>(jobs, units, atA, hasA, out), B = unit_geom<2, WIN>(jobs, units, atB, hasB, out);
-        forward16w<2, WIN, LOOK, BITS>(S, soft, A, B, vecs);
-    }
+    const uint32_t pa = 8u * w + 2u * row, pb = pa + 1u, vbase = list * vstride;
+    const uint32_t code_rate = uni(jobs[0].code_rate);                           // (a list holds one code rate)
+    auto run = [&](auto cr) {
+        constexpr int CR = decltype(cr)::value;
+        UnitGeom A = unit_geom<CR, WIN, LOOK>(jobs, nl, pa, q, vbase, out), B = unit_geom<CR, WIN, LOOK>(jobs, nl, pb, q, vbase, out);
+        if (__ballot(A.valid || B.valid) == 0) return;                           // (frames shorter than the longest leave whole waves empty)
+        if (!B.valid) { const bool v = false; B = A; B.valid = v; B.vstep = B.estep = kNever; B.nsteps = 0; }   // an empty slot steps through a unit that exists: well-formed operands, nothing written
+        if (!A.valid) { const bool v = false; const UnitGeom T = B; A = T; A.valid = v; A.vstep = A.estep = kNever; A.nsteps = 0; }
+        forward16w<CR, WIN, LOOK, BITS>(S, soft, A, B, vecs);
+    };
+    if (code_rate == 0) run(std::integral_constant<int, 0>{});
+    else if (code_rate == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
 }
 
 }  // namespace
 
-__global__ void __launch_bounds__(64) k_viterbi16w(const VitJob* __restrict__ jobs, const WinUnit* __restrict__ units, const uint32_t* __restrict__ nunits3, uint32_t ustride,
+__global__ void __launch_bounds__(64) k_viterbi16w(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
                                                    const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
-{ viterbi16w_body<256, 24, 3>(jobs, units, nunits3, ustride, soft, out, vecs); }
+{ viterbi16w_body<256, 24, 3>(jobs, hdr, jstride, target, vstride, soft, out, vecs); }
 
 // One wave per frame (job slot), four per workgroup: lane l compares boundary l + 1 (, l + 65, ...) of the frame -- unit u's vector at its verify point against
 // unit u - 1's vector at the same step, 128 bytes each.  Any mismatch: the frame's VitJob goes to the list the serial kernel decodes afterwards.
 // stats[0..3] += boundaries compared, boundaries that differed, frames queued again, units.
-__global__ void __launch_bounds__(256) k_win_verify(const VitJob* __restrict__ jobs, const WinFrame* __restrict__ wframes, uint32_t* __restrict__ hdr, uint32_t jstride,
+__global__ void __launch_bounds__(256) k_win_verify(const VitJob* __restrict__ jobs, uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
                                                     const uint16_t* __restrict__ vecs, VitJob* __restrict__ redo, unsigned long long* __restrict__ stats)
 {
     const JobRef jr = locate_job(blockIdx.x * 4u + (threadIdx.x >> 6), hdr);
     if (!jr.ok) return;
     const unsigned lane = threadIdx.x & 63;
     const uint32_t jslot = jr.list * jstride + jr.idx;
-    const WinFrame F = wframes[jslot];
+    const VitJob J = jobs[jslot];
+    const uint32_t q = win_units_per_frame(hdr[0] + hdr[1] + hdr[2], target);
+    const uint32_t nev = win_events(J.length, J.code_rate, 256u, 24u), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
+    const size_t vec0 = (size_t)jr.list * vstride + (size_t)jr.idx * q;
     uint32_t bad = 0;
-    for (uint32_t u = 1u + lane; u < F.nunits; u += 64u) {
-        const uint4* a = reinterpret_cast<const uint4*>(vecs + ((size_t)(F.vec0 + u) * 2u) * 64u);            // unit u, at its own verify point
-        const uint4* b = reinterpret_cast<const uint4*>(vecs + ((size_t)(F.vec0 + u - 1u) * 2u + 1u) * 64u);  // unit u - 1, at the same step
+    for (uint32_t u = 1u + lane; u < nun; u += 64u) {
+        const uint4* a = reinterpret_cast<const uint4*>(vecs + ((vec0 + u) * 2u) * 64u);              // unit u, at its own verify point
+        const uint4* b = reinterpret_cast<const uint4*>(vecs + ((vec0 + u - 1u) * 2u + 1u) * 64u);    // unit u - 1, at the same step
         uint32_t d = 0;
 #pragma unroll
         for (int i = 0; i < 8; i++) { const uint4 x = a[i], y = b[i]; d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
@@ -308,10 +321,10 @@ __global__ void __launch_bounds__(256) k_win_verify(const VitJob* __restrict__ j
     if (lane == 0) {
         if (bad) {
             const uint32_t at = atomicAdd(&hdr[kHdrRedo + jr.list], 1u);
-            redo[(size_t)jr.list * jstride + at] = jobs[jslot];
+            redo[(size_t)jr.list * jstride + at] = J;
         }
         if (stats) {
-            atomicAdd(&stats[0], (unsigned long long)(F.nunits - 1u)); atomicAdd(&stats[3], (unsigned long long)F.nunits);
+            atomicAdd(&stats[0], (unsigned long long)(nun - 1u)); atomicAdd(&stats[3], (unsigned long long)nun);
             if (bad) { atomicAdd(&stats[1], (unsigned long long)bad); atomicAdd(&stats[2], 1ull); }
         }
     }

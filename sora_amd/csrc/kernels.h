@@ -49,12 +49,6 @@ struct RxArgs {
     uint32_t*       eq;             // [total_slots][64] equalised bins, packed COMPLEX16 (k_sym_front -> k_track, k_sym_back)
     TrackRec*       track;          // [total_slots] rotation parameters of a data symbol (k_track -> k_sym_back)
     uint32_t*       pil;            // [total_slots][4] the four pilot bins (43, 57, 7, 21) of eq[] once more, densely: all k_track reads
-    // the window-parallel trellis (k_vitwin.hip): a frame's units are planned where its VitJob is published (dev_winplan.h); wunits == nullptr: off
-    WinUnit*        wunits;         // [3][wstride] per code rate, in the order the frames' ranges were handed out
-    WinFrame*       wframes;        // [3][nrows] per job slot
-    uint32_t*       hdr;            // the call's 64-byte counter block (rx_types.h: kHdrUnits, kHdrRedo, kHdrVecs); njobs points at its first three words
-    uint32_t        wstride;        // capacity of one list of units
-    uint32_t        wtarget;        // units the call should be cut into at least, frames permitting (a chip's worth of trellis slots)
 };
 
 __global__ void k_scan(ScanArgs A);
@@ -67,9 +61,10 @@ __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t n
 __global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_viterbi16(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);       // k_vit16.hip
 __global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
-// k_vitwin.hip: the window-parallel trellis.  units3 = the call's counter block + kHdrUnits; ustride = capacity of a list of units; jstride = that of a list of jobs
-__global__ void k_viterbi16w(const VitJob* jobs, const WinUnit* units, const uint32_t* nunits3, uint32_t ustride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
-__global__ void k_win_verify(const VitJob* jobs, const WinFrame* wframes, uint32_t* hdr, uint32_t jstride, const uint16_t* vecs, VitJob* redo, unsigned long long* stats);
+// k_vitwin.hip: the window-parallel trellis.  hdr = the call's counter block (njobs per code rate in its first three words); jstride = capacity of a list of jobs;
+// target = units the call is cut into at least, frames permitting; vstride = vectors per code-rate list
+__global__ void k_viterbi16w(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
+__global__ void k_win_verify(const VitJob* jobs, uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs, VitJob* redo, unsigned long long* stats);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);

@@ -62,18 +62,10 @@ struct VitJob {             // one Viterbi decode: a frame of the RX path or one
 // ---- the window-parallel trellis (k_vitwin.hip, round 5).  A frame's trace-back windows (256 decoded bits each, viterbi.hpp:196-214) are cut into UNITS of m
 // consecutive windows; a unit is decoded on its own -- from all-zero metrics kWinWarm steps before its verify point b = floor24(WIN k0) -- and proven afterwards:
 // its metric vector at b must equal the vector the unit before it had there (k_win_verify); a frame with any mismatch is decoded again by the serial kernel.
-struct WinUnit {            // 16 bytes
-    uint32_t job;           // slot of the frame's VitJob in jobs[] (list * stride + idx)
-    uint16_t k0, k1;        // first window, one past the last (0xFFFF: up to the frame's end)
-    uint32_t vec;           // index of the unit's two vectors {at its own verify point, at the next unit's} in the vector array; a frame's units are consecutive in k0 order
-    uint32_t u;             // the unit's index inside its frame (0: starts at step 0 from the reference's initial metrics)
-};
-struct WinFrame { uint32_t vec0, nunits; };   // per job slot: the frame's first vector index and its number of units
 constexpr int kWinWarm = 144;                 // warm-up steps in front of a verify point (a multiple of 24).  tools/winmodel: with 96 no frame that passes its CRC failed a verification at any rate; 144 leaves a margin
 constexpr int kWinVecBytes = 256;             // per unit: two vectors of 64 16-bit metric fields in the kernel's own lane order
-// words of the 64-byte block in front of the frame table (cleared at the start of every call): 0..2 njobs per code rate, 3..5 units per code rate, 6..8 frames to be
-// decoded again per code rate, 9 vectors handed out
-constexpr int kHdrUnits = 3, kHdrRedo = 6, kHdrVecs = 9;
+// words of the 64-byte block in front of the frame table (cleared at the start of every call): 0..2 njobs per code rate, 6..8 frames to be decoded again per code rate
+constexpr int kHdrRedo = 6;
 
 struct TrackRec {           // per data-symbol slot
     int16_t cfo_comp, sfo_comp;   // CompCoeffs of THIS symbol = build_coeff(cfo_comp, sfo_comp)

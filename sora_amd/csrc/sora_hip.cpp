@@ -287,7 +287,7 @@ struct RxPipe {
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
                                                                 // 2 = k_viterbi16w + k_win_verify + k_viterbi on what failed its proof (window-parallel, k_vitwin.hip)
-    WinUnit* d_wunits = nullptr; WinFrame* d_wframes = nullptr; uint16_t* d_wvecs = nullptr; VitJob* d_rjobs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;
+    uint16_t* d_wvecs = nullptr; VitJob* d_rjobs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;   // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
@@ -352,7 +352,7 @@ static void rx_free(RxPipe* rx)
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_fctx, rx->d_nframes,
                      rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil,
-                     rx->d_wunits, rx->d_wframes, rx->d_wvecs, rx->d_rjobs, rx->d_wstats };
+                     rx->d_wvecs, rx->d_rjobs, rx->d_wstats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -484,11 +484,9 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMalloc((void**)&rx->d_soft, (size_t)kSoftBytesPerSlot * rx->cap_slots + kSoftSlack));   // three bits per soft value (rx_types.h)
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
-    if (rx->lanes16 == 2 && !rx->d_wunits) {                                     // the window-parallel trellis's tables, on its first use
+    if (rx->lanes16 == 2 && !rx->d_wvecs) {                                      // the window-parallel trellis's arrays, on its first use
         rx->wstride = kWinUnitsTarget + rx->cap_rows;
-        HIPCHK(hipMalloc((void**)&rx->d_wunits, 3 * sizeof(WinUnit) * (size_t)rx->wstride));
-        HIPCHK(hipMalloc((void**)&rx->d_wframes, 3 * sizeof(WinFrame) * (size_t)rx->cap_rows));
-        HIPCHK(hipMalloc((void**)&rx->d_wvecs, (size_t)kWinVecBytes * rx->wstride));
+        HIPCHK(hipMalloc((void**)&rx->d_wvecs, 3 * (size_t)kWinVecBytes * rx->wstride));
         HIPCHK(hipMalloc((void**)&rx->d_rjobs, 3 * sizeof(VitJob) * (size_t)rx->cap_rows));
         HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * sizeof(unsigned long long)));
         HIPCHK(hipMemset(rx->d_wstats, 0, 4 * sizeof(unsigned long long)));
@@ -558,7 +556,6 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
             hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
 #else
-            if (rx->lanes16 == 2) { R.wunits = rx->d_wunits; R.wframes = rx->d_wframes; R.hdr = rx->d_njobs; R.wstride = rx->wstride; R.wtarget = kWinUnitsTarget; }
             if (rx->only & 2u) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
 #endif
             mark();
@@ -567,9 +564,9 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), the proof, and
                 // the serial kernel over the frames whose proof failed (none, normally: its workgroups find empty lists and return)
                 const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);   // (a frame has at most 80 windows)
-                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const WinUnit*)rx->d_wunits,
-                                   (const uint32_t*)(rx->d_njobs + kHdrUnits), rx->wstride, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
-                hipLaunchKernelGGL(k_win_verify, dim3((nrows + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const WinFrame*)rx->d_wframes, rx->d_njobs, nrows,
+                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                                   (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
+                hipLaunchKernelGGL(k_win_verify, dim3((nrows + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
                                    (const uint16_t*)rx->d_wvecs, rx->d_rjobs, rx->d_wstats);
                 hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_rjobs, (const uint32_t*)(rx->d_njobs + kHdrRedo), 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
             }

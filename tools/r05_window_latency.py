@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--profile-batch", type=int, default=0, help="only N lone window-parallel calls of the batch (for rocprofv3 --kernel-trace --stats)")
     a = ap.parse_args()
     import torch
     import sora_amd
@@ -29,6 +30,15 @@ def main():
     dev = "cuda:0"
     out = {}
     names = {64: "k_viterbi", 16: "k_viterbi16", 1: "k_viterbi16w"}
+    if a.profile_batch:
+        iq, descs, _ = bench.make_workload(o, a.frames, seed0=0)
+        d_iq = torch.from_numpy(iq).to(dev); dd = sora_amd.Rx.captures(descs)
+        rx = sora_amd.Rx(max_captures=a.frames, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+        rx.set_depth(1); rx.set_trellis(1)
+        for _ in range(a.profile_batch):
+            rx.wait(rx.process_dev(d_iq, dd))
+        print(json.dumps(rx.window_stats())); rx.close()
+        return
     # (a) one capture
     g = np.load(os.path.join(ROOT, "tests", "golden", "fsample6_40mhz_i8.npz"))
     iq40 = g["iq_i8"].astype(np.int16) << 8
