@@ -524,6 +524,17 @@ int   sora_rx11b_deliver_async(sora_rx11b_t* rx, int ticket, sora_frame_result* 
  * Small device-memory helpers so a pure-C host needs no HIP headers.
  * ------------------------------------------------------------------------------------------------ */
 int   sora_hip_device_count(void);
+
+/* The look-up tables (usin / ucos / uatan2 of core/inc/intalglut.h:4,3648,7332, the FFT twiddles of fft_lut_twiddle.h:61433-61600, the demapper's step tables of
+ * Brick11/src/demapper.h:55-130, dsp_math.h:215-245's sincos / atan, ...) are regenerated from closed forms when a process first needs them, with the host's libm.
+ * Each has a PINNED sha256 compiled into the library; a table that does not hash to its pin (another libm, -ffast-math) makes every create / stage call fail with
+ * SORA_ERR_FAILED instead of decoding differently.  sora_hip_table_digest needs no device; sora_hip_table_read copies the device-resident table of the current
+ * device back (h_out == NULL: only *bytes). */
+int   sora_hip_table_count(void);
+const char* sora_hip_table_name(int index);
+const char* sora_hip_table_pin(const char* name);                 /* the pinned sha256 (64 hex digits), NULL: no such table */
+int   sora_hip_table_digest(const char* name, char hex65[65]);    /* what this build on this host generates */
+int   sora_hip_table_read(const char* name, void* h_out, size_t cap, size_t* bytes);
 void* sora_hip_malloc(size_t bytes);
 void  sora_hip_free(void* d_ptr);
 int   sora_hip_memcpy_h2d(void* d_dst, const void* h_src, size_t bytes);

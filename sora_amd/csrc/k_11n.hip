@@ -319,6 +319,17 @@ int sora_hip_mimo_comp11n(const sora_complex16* d_hinv, const uint32_t* d_frame_
 #include <cmath>
 #include <mutex>
 #include <vector>
+// the two tables on the host (dsp_math.h:215-245)
+void sora_internal_dsp_host_tables(std::vector<uint32_t>& sc, std::vector<short>& at)
+{
+    sc.resize(65536); at.resize(4097);
+    for (unsigned i = 0; i < 65536; i++) {
+        const double r = (double)i * 2.0 * M_PI / 65535.0;
+        const short c = (short)(cos(r) * 32767.5), s = (short)(sin(r) * 32767.5);
+        sc[i] = ((uint32_t)(uint16_t)c) | ((uint32_t)(uint16_t)s << 16);
+    }
+    for (int i = 0; i <= 4096; i++) at[i] = (short)(atan((double)i / 4096.0) / (M_PI / 4.0) * 8192);
+}
 namespace {
 struct DspTables { uint32_t* sincos = nullptr; short* atan = nullptr; };
 std::mutex g_dsp_mutex;
@@ -330,13 +341,9 @@ const DspTables* dsp_tables()
     std::lock_guard<std::mutex> lock(g_dsp_mutex);                              // handles may be created from different threads: built once per device, published whole
     DspTables& T = tabs[dev];
     if (!T.sincos) {
-        std::vector<uint32_t> sc(65536); std::vector<short> at(4097);
-        for (unsigned i = 0; i < 65536; i++) {
-            const double r = (double)i * 2.0 * M_PI / 65535.0;
-            const short c = (short)(cos(r) * 32767.5), s = (short)(sin(r) * 32767.5);
-            sc[i] = ((uint32_t)(uint16_t)c) | ((uint32_t)(uint16_t)s << 16);
-        }
-        for (int i = 0; i <= 4096; i++) at[i] = (short)(atan((double)i / 4096.0) / (M_PI / 4.0) * 8192);
+        std::vector<uint32_t> sc; std::vector<short> at;
+        sora_internal_dsp_host_tables(sc, at);
+        if (sora_internal_pin_table("dsp_sincos", sc.data(), sc.size() * 4) != SORA_OK || sora_internal_pin_table("dsp_atan", at.data(), at.size() * 2) != SORA_OK) return nullptr;
         uint32_t* d_sc = nullptr; short* d_at = nullptr;
         if (hipMalloc((void**)&d_sc, sc.size() * 4) != hipSuccess || hipMalloc((void**)&d_at, at.size() * 2) != hipSuccess ||
             hipMemcpy(d_sc, sc.data(), sc.size() * 4, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(d_at, at.data(), at.size() * 2, hipMemcpyHostToDevice) != hipSuccess) {

@@ -323,9 +323,11 @@ __global__ void __launch_bounds__(256) k_win_verify(const VitJob* __restrict__ j
             const uint32_t at = atomicAdd(&hdr[kHdrRedo + jr.list], 1u);
             redo[(size_t)jr.list * jstride + at] = J;
         }
+        // the record: one bank of four counters per 16th of the workgroups (thousands of atomics on ONE address take a hundred microseconds: the first version of this kernel)
         if (stats) {
-            atomicAdd(&stats[0], (unsigned long long)(nun - 1u)); atomicAdd(&stats[3], (unsigned long long)nun);
-            if (bad) { atomicAdd(&stats[1], (unsigned long long)bad); atomicAdd(&stats[2], 1ull); }
+            unsigned long long* b = stats + 4u * (blockIdx.x & (kWinStatBanks - 1u));
+            atomicAdd(&b[0], (unsigned long long)(nun - 1u)); atomicAdd(&b[3], (unsigned long long)nun);
+            if (bad) { atomicAdd(&b[1], (unsigned long long)bad); atomicAdd(&b[2], 1ull); }
         }
     }
 }

@@ -1,6 +1,7 @@
 // kernels.h -- argument blocks and declarations of the receive-path kernels (shared by host and device code).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <vector>
 #include "dev_arith.h"
 #include "rx_types.h"
 #include "../../include/sora_hip.h"
@@ -183,4 +184,6 @@ const uint32_t* sora_internal_crc_table(int device);
 struct sora_rx;
 extern "C" int sora_internal_rx_device(sora_rx* rx);                           // device ordinal of a receive handle (sora_shard.cpp)
 int sora_internal_tables(int device, sora::Tables* out);                  // the per-device tables of the stage entry points (uploaded on first use)
+void sora_internal_dsp_host_tables(std::vector<uint32_t>& sincos, std::vector<short>& atan);   // k_11n.hip: the two dsp_math tables as the host generates them
+int sora_internal_pin_table(const char* name, const void* data, size_t bytes);   // sora_hip.cpp: SORA_OK iff the bytes are the pinned sha256 of table `name`
 int sora_internal_dsp_tables(const uint32_t** sincos, const short** atan);  // dsp_math tables of the current device (k_11n.hip)   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr

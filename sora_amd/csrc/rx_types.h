@@ -66,6 +66,7 @@ constexpr int kWinWarm = 144;                 // warm-up steps in front of a ver
 constexpr int kWinVecBytes = 256;             // per unit: two vectors of 64 16-bit metric fields in the kernel's own lane order
 // words of the 64-byte block in front of the frame table (cleared at the start of every call): 0..2 njobs per code rate, 6..8 frames to be decoded again per code rate
 constexpr int kHdrRedo = 6;
+constexpr unsigned kWinStatBanks = 64;        // k_win_verify spreads its record over this many banks of four counters (a power of two)
 
 struct TrackRec {           // per data-symbol slot
     int16_t cfo_comp, sfo_comp;   // CompCoeffs of THIS symbol = build_coeff(cfo_comp, sfo_comp)

@@ -195,6 +195,98 @@ static void build_tables(HostTables& H)
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The tables are PINNED: they are generated with this host's libm, and a libm that rounds one sine differently -- or a build with
+// -ffast-math -- would change decoded bits without any test in this library noticing.  Every table's sha256 is a constant below (taken from a build whose
+// tables were compared entry for entry with the reference headers: core/inc/intalglut.h:4,3648,7332, fft_lut_twiddle.h:61433-61600, Brick11/src/demapper.h:55-130,
+// dsp_math.h:215-245); the first use of the tables in a process computes the digests and refuses to go on if one differs.
+namespace {
+struct Sha256 {
+    uint32_t h[8] = { 0x6a09e667u, 0xbb67ae85u, 0x3c6ef372u, 0xa54ff53au, 0x510e527fu, 0x9b05688cu, 0x1f83d9abu, 0x5be0cd19u };
+    uint8_t buf[64]; size_t nbuf = 0; uint64_t total = 0;
+    static uint32_t ror(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+    void block(const uint8_t* p)
+    {
+        static const uint32_t K[64] = {
+            0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,0xd807aa98,0x12835b01,0x243185be,0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,
+            0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,0x5cb0a9dc,0x76f988da,0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,
+            0x27b70a85,0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,0xd192e819,0xd6990624,0xf40e3585,0x106aa070,
+            0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2 };
+        uint32_t w[64];
+        for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
+        for (int i = 16; i < 64; i++) { const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10); w[i] = w[i - 16] + s0 + w[i - 7] + s1; }
+        uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+        for (int i = 0; i < 64; i++) {
+            const uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+            const uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+            hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+        }
+        h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    }
+    void update(const void* data, size_t n)
+    {
+        const uint8_t* p = (const uint8_t*)data; total += n;
+        while (n) { const size_t k = std::min(n, 64 - nbuf); memcpy(buf + nbuf, p, k); nbuf += k; p += k; n -= k; if (nbuf == 64) { block(buf); nbuf = 0; } }
+    }
+    std::string hex()
+    {
+        const uint64_t bits = total * 8; const uint8_t one = 0x80, zero = 0;
+        update(&one, 1); while (nbuf != 56) update(&zero, 1);
+        uint8_t len[8]; for (int i = 0; i < 8; i++) len[i] = (uint8_t)(bits >> (56 - 8 * i));
+        update(len, 8);
+        char out[65]; for (int i = 0; i < 8; i++) snprintf(out + 8 * i, 9, "%08x", h[i]);
+        return std::string(out, 64);
+    }
+};
+struct TablePin { const char* name; const char* sha256; };
+const TablePin kTablePins[] = {
+    { "usin", "303884f4e7d2b574a47cfb1aa610b99aa0722bdd0303db2ebf5f27b0c4eea9b6" },
+    { "ucos", "92eca3a66ce9f1035e4b84374dd64f991c69da693e8124613505e953a84e184b" },
+    { "rot", "0266a6ff7410a9c4720c60965a2e28ca2f4ef2e17df46f89a9e16a27330fd523" },
+    { "uatan2", "7a6b394236967f6f6d0ad97e8cb14edb0ab4f6f50df17f54264f6f2abb3a6aeb" },
+    { "demap", "1028dd6bbe87a4ac8190f3bdb9628785714b7cb5f649c170574138c059675d99" },
+    { "tw64", "b9a69426c357baf5a4338bfd398e5b754922f997044a2b295ed6dc70068bd7bd" },
+    { "tw16", "fe8575adcefa7254bc7a07d5f9000b6c0f69d37f042a6b865fcf9c482ebf0ca9" },
+    { "sts", "45f304e6f7f2553d44618ef4b6c4afebc914c22e3a334ace20ef35c384ff7ce7" },
+    { "deint", "0178a68770023711d77bd5c4b897579856f846ca086f8a9efa8ffac20ba408a4" },
+    { "crc", "12f3e0576d447eb37b36d82ba0c1c5481b8f0d12fdc70347ce4a076b229d4c86" },
+    { "scr", "79b208c989740a73350771cd9db10902810c4b6b75cb4fd2578bc7adc6162507" },
+    { "scr_seq", "76f691c12b4e3d25b4e0606aa540677f02e5c31b3666188853e624e89bbe7452" },
+    { "scr_phase", "4945a6c487c65e6fcb57a858d925a69e3fb382dd397099a6e510a4a6f76e0177" },
+    { "tw128", "91cc9a797bfd3c35a1c0ce8d972452419000b0b1dab70cdd56b435f5d01ad834" },
+    { "tw32", "2a00eb47f9337b725bd5cfe52b6e7a6c696b141f4d4f10fe770fc403d7b3d703" },
+    { "tw8", "e54d5a6817c1f2a559297821786fc9d2e58aa55dc2699d64d289e26bea16e348" },
+    { "crcz", "035d5a8379b2b38f05c16cb38107a51e153fd87dc45d71909ef8c25db84897e7" },
+    { "dsp_sincos", "a85b7311f9347b68cb30ddf481a5670b78339f985ec327a1c6d4325dedf9800c" },
+    { "dsp_atan", "7b576ae30701be7ab527c540af4d02e23e5b1ae1cc97e3ee83ab6cd63aa6343d" },
+};
+}  // namespace
+
+static std::string table_digest(const void* data, size_t bytes) { Sha256 s; s.update(data, bytes); return s.hex(); }
+
+// SORA_OK when `name` is a pinned table and the bytes are the pinned ones; SORA_ERR_FAILED otherwise (message in sora_hip_last_error)
+int sora_internal_pin_table(const char* name, const void* data, size_t bytes)
+{
+    const std::string got = table_digest(data, bytes);
+    for (const TablePin& t : kTablePins) if (!strcmp(t.name, name)) {
+        if (got == t.sha256) return SORA_OK;
+        char msg[256]; snprintf(msg, sizeof msg, "look-up table '%s' does not have its pinned sha256 (this host's libm or the build's floating-point flags generate different tables): got %s", name, got.c_str());
+        return fail(SORA_ERR_FAILED, msg);
+    }
+    return fail(SORA_ERR_FAILED, "look-up table without a pinned digest");
+}
+
+template <typename V> static int pin(const char* name, const V& v) { return sora_internal_pin_table(name, v.data(), v.size() * sizeof(v[0])); }
+static int pin_host_tables(const HostTables& H)
+{
+    int rc;
+    if ((rc = pin("usin", H.usin)) || (rc = pin("ucos", H.ucos)) || (rc = pin("rot", H.rot)) || (rc = pin("uatan2", H.uatan2)) || (rc = pin("demap", H.demap)) ||
+        (rc = pin("tw64", H.tw64)) || (rc = pin("tw16", H.tw16)) || (rc = pin("sts", H.sts)) || (rc = pin("deint", H.deint)) || (rc = pin("crc", H.crc)) ||
+        (rc = pin("scr", H.scr)) || (rc = pin("scr_seq", H.scr_seq)) || (rc = pin("scr_phase", H.scr_phase)) || (rc = pin("tw128", H.tw128)) || (rc = pin("tw32", H.tw32)) ||
+        (rc = pin("tw8", H.tw8)) || (rc = pin("crcz", H.crcz))) return rc;
+    return SORA_OK;
+}
+
 struct DevTables {
     Tables T{};
     std::vector<void*> allocs;
@@ -218,6 +310,12 @@ static int make_dev_tables(DevTables& D)
 {
     HostTables H; build_tables(H);
     int rc;
+    {
+        static std::mutex m; static int pinned = -1;                             // once per process: the tables are a function of the build and the host's libm
+        std::lock_guard<std::mutex> lock(m);
+        if (pinned < 0) pinned = pin_host_tables(H);
+        if (pinned != SORA_OK) return pin_host_tables(H);                        // (again: the message belongs to this thread)
+    }
     if ((rc = upload(D, H.usin, (const void**)&D.T.usin))) return rc;
     if ((rc = upload(D, H.ucos, (const void**)&D.T.ucos))) return rc;
     if ((rc = upload(D, H.rot, (const void**)&D.T.rot))) return rc;
@@ -376,6 +474,54 @@ int sora_hip_device_count(void)
     if (hipGetDeviceCount(&n) != hipSuccess) return 0;
     return n;
 }
+// ---- the pinned look-up tables, by name (include/sora_hip.h)
+namespace { struct NamedTable { const char* name; const void* host; size_t bytes; const void* const* dev; }; }
+static std::vector<NamedTable> named_tables(const HostTables& H, const std::vector<uint32_t>& sc, const std::vector<short>& at, const Tables* T, const uint32_t* const* dsc, const short* const* dat)
+{
+#define NT(n, v, d) { n, (v).data(), (v).size() * sizeof((v)[0]), (const void* const*)(d) }
+    return { NT("usin", H.usin, T ? &T->usin : nullptr), NT("ucos", H.ucos, T ? &T->ucos : nullptr), NT("rot", H.rot, T ? &T->rot : nullptr), NT("uatan2", H.uatan2, T ? &T->uatan2 : nullptr),
+             NT("demap", H.demap, T ? &T->demap : nullptr), NT("tw64", H.tw64, T ? &T->tw64 : nullptr), NT("tw16", H.tw16, T ? &T->tw16 : nullptr), NT("sts", H.sts, T ? &T->sts : nullptr),
+             NT("deint", H.deint, T ? &T->deint : nullptr), NT("crc", H.crc, T ? &T->crc : nullptr), NT("scr", H.scr, T ? &T->scr : nullptr), NT("scr_seq", H.scr_seq, T ? &T->scr_seq : nullptr),
+             NT("scr_phase", H.scr_phase, T ? &T->scr_phase : nullptr), NT("tw128", H.tw128, T ? &T->tw128 : nullptr), NT("tw32", H.tw32, T ? &T->tw32 : nullptr), NT("tw8", H.tw8, T ? &T->tw8 : nullptr),
+             NT("crcz", H.crcz, T ? &T->crcz : nullptr), NT("dsp_sincos", sc, dsc), NT("dsp_atan", at, dat) };
+#undef NT
+}
+int sora_hip_table_count(void) { return (int)(sizeof(kTablePins) / sizeof(kTablePins[0])); }
+const char* sora_hip_table_name(int index) { return index >= 0 && index < sora_hip_table_count() ? kTablePins[index].name : nullptr; }
+const char* sora_hip_table_pin(const char* name) { for (const TablePin& t : kTablePins) if (name && !strcmp(t.name, name)) return t.sha256; return nullptr; }
+// the digest of table `name` as THIS build on THIS host generates it (no device needed): what make_dev_tables compares with the pin
+int sora_hip_table_digest(const char* name, char hex65[65])
+{
+    if (!name || !hex65) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_table_digest: null argument");
+    HostTables H; build_tables(H);
+    std::vector<uint32_t> sc; std::vector<short> at; sora_internal_dsp_host_tables(sc, at);
+    for (const NamedTable& t : named_tables(H, sc, at, nullptr, nullptr, nullptr)) if (!strcmp(t.name, name)) {
+        const std::string d = table_digest(t.host, t.bytes);
+        memcpy(hex65, d.c_str(), 65);
+        return SORA_OK;
+    }
+    return fail(SORA_ERR_INVALID_PARAM, "sora_hip_table_digest: no such table");
+}
+// the DEVICE-RESIDENT copy of table `name` on the current device (the stage entry points' tables; a handle's own copies come from the same generator), read back
+int sora_hip_table_read(const char* name, void* h_out, size_t cap, size_t* bytes)
+{
+    if (!name || !bytes) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_table_read: null argument");
+    DevTables* D = stage_tables();
+    if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_table_read: no tables on this device");
+    const uint32_t* dsc = nullptr; const short* dat = nullptr;
+    if (!strncmp(name, "dsp_", 4) && sora_internal_dsp_tables(&dsc, &dat) != SORA_OK) return fail(SORA_ERR_HARDWARE_FAILED, "sora_hip_table_read: dsp_math tables");
+    HostTables H; build_tables(H);
+    std::vector<uint32_t> sc; std::vector<short> at; sora_internal_dsp_host_tables(sc, at);
+    for (const NamedTable& t : named_tables(H, sc, at, &D->T, &dsc, &dat)) if (!strcmp(t.name, name)) {
+        *bytes = t.bytes;
+        if (!h_out) return SORA_OK;
+        if (cap < t.bytes) return fail(SORA_ERR_CAPACITY, "sora_hip_table_read: buffer too small");
+        HIPCHK(hipMemcpy(h_out, *t.dev, t.bytes, hipMemcpyDeviceToHost));
+        return SORA_OK;
+    }
+    return fail(SORA_ERR_INVALID_PARAM, "sora_hip_table_read: no such table");
+}
+
 void* sora_hip_malloc(size_t bytes) { void* p = nullptr; if (hipMalloc(&p, bytes) != hipSuccess) return nullptr; return p; }
 void  sora_hip_free(void* p) { if (p) (void)hipFree(p); }
 int   sora_hip_memcpy_h2d(void* d, const void* h, size_t n) { HIPCHK(hipMemcpy(d, h, n, hipMemcpyHostToDevice)); return SORA_OK; }
@@ -488,8 +634,8 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         rx->wstride = kWinUnitsTarget + rx->cap_rows;
         HIPCHK(hipMalloc((void**)&rx->d_wvecs, 3 * (size_t)kWinVecBytes * rx->wstride));
         HIPCHK(hipMalloc((void**)&rx->d_rjobs, 3 * sizeof(VitJob) * (size_t)rx->cap_rows));
-        HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(rx->d_wstats, 0, 4 * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * kWinStatBanks * sizeof(unsigned long long)));
+        HIPCHK(hipMemset(rx->d_wstats, 0, 4 * kWinStatBanks * sizeof(unsigned long long)));
     }
     if (!rx->d_slot_row) {
         HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
@@ -872,10 +1018,10 @@ int sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4])
     HIPCHK(hipSetDevice(rx->cfg.device));
     for (int i = 0; i < 4; i++) out[i] = 0;
     for (RxPipe* p : rx->pipes) if (p && p->d_wstats) {
-        unsigned long long v[4];
+        unsigned long long v[4 * kWinStatBanks];
         HIPCHK(hipStreamSynchronize(p->stream));
         HIPCHK(hipMemcpy(v, p->d_wstats, sizeof v, hipMemcpyDeviceToHost));
-        for (int i = 0; i < 4; i++) out[i] += v[i];
+        for (unsigned i = 0; i < 4 * kWinStatBanks; i++) out[i & 3u] += v[i];
     }
     return SORA_OK;
 }
