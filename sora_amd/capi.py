@@ -154,6 +154,7 @@ def load(build_if_missing=True):
     L.sora_rx_set_graph.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_trellis.argtypes = [ctypes.c_void_p]
     L.sora_rx_window_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
+    L.sora_hip_table_count.argtypes = []
     L.sora_hip_table_name.argtypes = [ctypes.c_int]; L.sora_hip_table_name.restype = ctypes.c_char_p
     L.sora_hip_table_pin.argtypes = [ctypes.c_char_p]; L.sora_hip_table_pin.restype = ctypes.c_char_p
     L.sora_hip_table_digest.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
