@@ -192,8 +192,8 @@ int  sora_rx_set_depth(sora_rx_t* rx, int depth);
  *                    all-equal metrics a warm-up ahead of its first window and PROVEN afterwards -- its metric vector at the preceding normalisation
  *                    point must equal its predecessor's there (k_win_verify); a frame with a mismatch is decoded again by k_viterbi.  Bit-exact by
  *                    construction; the kernel for few frames in flight (one capture, one lone call), where a frame per wave-slot leaves the chip idle.
- *   0   (default)    chosen by the library from the handle's capacity in flight: k_viterbi16 when depth x max_captures >= 16384
- *                    (four 4096-capture calls, two 16384-capture calls), the window-parallel form below that.
+ *   0   (default)    chosen by the library from the handle's capacity in flight: k_viterbi16 when depth x max_captures >= 32768
+ *                    (eight 4096-capture calls, two 16384-capture calls), the window-parallel form below that.
  * Returns the previous setting; a negative argument only queries. */
 #define SORA_TRELLIS_WINDOWED 1
 int  sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair);
@@ -201,6 +201,15 @@ int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process c
 /* The window-parallel trellis's proof record since the handle was created: out[0] unit boundaries compared, out[1] boundaries whose vectors differed,
  * out[2] frames decoded again by the serial kernel because of that, out[3] units.  Waits for the handle's calls in flight. */
 int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
+/* Two forms of the symbol chain T11aDataSymbol .. T11aDeinterleave (fb11ademod_config.hpp:200-222) write the same soft stream:
+ *   1   k_frame      one wave per frame, four symbols per pass, the pilot tracker's loop-carried chain in the same wave: the cheaper one when the chip is full of frames;
+ *   3   k_sym_front -> k_track_lds -> k_sym_back   per symbol slot in front of and behind the tracker (TFreqCompensation, TFFT64, TChannelEqualization | TPhaseCompensate's
+ *                    rotation, T11aDemap, T11aDeinterleave), and the tracker's chain (freqoffset.hpp:28-30, pilot.hpp:166-233) alone, four lanes per frame, with its
+ *                    three look-up tables folded into LDS: a frame's symbols spread over the chip -- the one for few, long frames (fsample-6: 465 symbols);
+ *   0   (default)    chosen by the library: 3 while depth x max_captures x max_frames_per_capture <= 512, else 1.
+ * Returns the previous setting; a negative argument only queries. */
+int  sora_rx_set_front(sora_rx_t* rx, int kernels);
+int  sora_rx_front(sora_rx_t* rx);              /* 1 or 3: what the next process call will use */
 /* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);

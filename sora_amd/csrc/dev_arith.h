@@ -71,7 +71,42 @@ struct Tables {
     const uint32_t* tw32;        // [3][8]  packed W32^{k j}
     const uint32_t* tw8;         // [4]     {W8^0, W8^1, W8^0, W8^3} (fft_lut_twiddle.h:61575-61581)
     const uint32_t* crcz;        // [6][8][16] CRC-32 register after 40 * 2^k zero bytes, per nibble of the start value (parallel CRC)
+    const uint32_t* trk;         // TrkTables (below): usin / ucos / uatan2 once more, folded to 113 KB so that a workgroup can hold them in LDS (k_track_lds)
 };
+
+// The three trigonometric tables of the pilot tracker's chain, small enough for one workgroup's LDS (round 5).  usin / ucos (65536 entries each) are a quarter
+// wave plus one bit per entry: the reference's generator used pi = 3.141593, so its tables are not exactly symmetric -- 481 / 474 entries differ by one from the
+// mirrored quarter wave, always in the direction their quadrant fixes -- and uatan2 (256 x 256) is odd in y for every y but -128: rows 0 .. 127 and the negated
+// row -128.  The host builds these from the full tables and checks that they reproduce every entry before it uploads them (sora_hip.cpp).
+struct TrkTables {
+    int16_t  q[16392];           // usin[0 .. 16384] (padded to a multiple of 16 bytes)
+    uint32_t exs[2048];          // bit i: usin[i] is one off the mirrored quarter wave: -1 in quadrants 1 and 2, +1 in quadrant 3 (none in quadrant 0)
+    uint32_t exc[2048];          // bit i: ucos[i] is one off sin(i + 16384) mirrored: -1 in quadrants 0 and 1, +1 in quadrants 2 and 3
+    int16_t  h[129 * 256];       // uatan2[y][x & 0xFF] for y = 0 .. 127; row 128 = -uatan2[-128][..]: uatan2(y < 0, x) = -h[-y][x & 0xFF]
+};
+// (index arithmetic shared by the host's check and the kernel)
+__host__ __device__ inline int trk_quarter_index(unsigned a) { const unsigned q = a & 0x3FFFu; return (int)(((a >> 14) & 1u) ? 16384u - q : q); }
+template <typename TBL> __host__ __device__ inline int trk_usin(const TBL& t, unsigned a)     // usin[a], a = FP_RAD angle & 0xFFFF
+{
+    const unsigned quad = a >> 14;
+    int v = t.q[trk_quarter_index(a)];
+    if (quad & 2u) v = -v;
+    if ((t.exs[a >> 5] >> (a & 31u)) & 1u) v += quad == 3u ? 1 : -1;
+    return v;
+}
+template <typename TBL> __host__ __device__ inline int trk_ucos(const TBL& t, unsigned a)     // ucos[a]
+{
+    const unsigned b = (a + 16384u) & 0xFFFFu, quad = a >> 14;
+    int v = t.q[trk_quarter_index(b)];
+    if ((b >> 14) & 2u) v = -v;
+    if ((t.exc[a >> 5] >> (a & 31u)) & 1u) v += quad >= 2u ? 1 : -1;
+    return v;
+}
+template <typename TBL> __host__ __device__ inline int trk_uatan2_entry(const TBL& t, int ys, int xs)   // uatan2_lut[(ys & 0xFF) * 256 + (xs & 0xFF)], ys in -128 .. 127
+{
+    const int r = ys < 0 ? -ys : ys, v = t.h[r * 256 + (xs & 0xFF)];
+    return ys < 0 ? -v : v;
+}
 
 // uatan2 (core/inc/intalg.h:100-113): highest set bit of |y|,|x| -> common shift -> 256x256 LUT
 __device__ __forceinline__ int bit_scope(int v) { unsigned a = (unsigned)(v > 0 ? v : -v); return a ? 31 - __clz(a) : 0; }

@@ -356,6 +356,77 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
     }
 }
 
+// Round 5: the same chain with its three tables in LDS -- the tracker for FEW frames in flight (a single capture: fsample-6's 465 symbols).
+// k_track's step is two dependent L2 gathers long (rot[] is 256 KB, uatan2[] 128 KB: 0.7 us per symbol); here a workgroup first copies the folded tables
+// (dev_arith.h TrkTables, 113 KB: quarter-wave sine + exception bits, uatan2 for y >= 0) into its LDS and the step is two LDS reads and ~25 dependent vector
+// instructions.  One workgroup serves up to 64 frames (four lanes each); the tables are exact by the host's exhaustive check (sora_hip.cpp: trk_tables_exact).
+__global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
+{
+    __shared__ TrkTables s_t;
+    {
+        const uint4* src = reinterpret_cast<const uint4*>(A.T.trk);
+        uint4* dst = reinterpret_cast<uint4*>(&s_t);
+        for (uint32_t i = threadIdx.x; i < sizeof(TrkTables) / 16; i += 256) dst[i] = src[i];
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, pk = lane & 3;
+    const JobRef jr = locate_job(blockIdx.x * 64u + (threadIdx.x >> 2), A.njobs);
+    const uint32_t j = jr.ok ? jr.list * A.nrows + jr.idx : 0u;
+    const uint32_t f = jr.ok ? A.joblist[j] : 0u;
+    const FrameRow r = A.frames[f];
+    const int nsym = jr.ok ? (int)r.nsym : 0;
+    if (jr.ok && pk == 0) {
+        VitJob J;
+        J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+        J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
+        A.jobs[j] = J;
+    }
+    const int pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;             // pilot k in lane k: carriers -21, -7, +7, +21 (pilot.hpp:138-164)
+    int cfo_comp = r.cfo_comp, sfo_comp = r.sfo_comp, cfo_tr = r.cfo_tracker, sfo_tr = r.sfo_tracker;
+    unsigned symbol_count = 0;                                                   // 127 -> 0 after the SIGNAL symbol
+    int nmax = nsym;
+#pragma unroll
+    for (int o = 32; o >= 4; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
+    nmax = __builtin_amdgcn_readfirstlane(nmax);
+    const uint32_t* pp = A.pil + (size_t)(r.slot0 + 1u) * 4u + (uint32_t)pk;    // pilot k of data symbol s at pp[4 (s - 1)] (k_sym_front)
+    TrackRec* trk = A.track + r.slot0 + 1u;
+    constexpr int kAhead = 8;                                                    // symbols requested ahead of the one in the chain (a step is ~0.1 us, an L2 miss ten times that)
+    uint32_t q[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; i++) q[i] = i < nsym ? pp[4 * i] : 0u;
+    for (int s0 = 1; s0 <= nmax; s0 += kAhead) {
+#pragma unroll
+        for (int u = 0; u < kAhead; u++) {                                       // (unrolled: the request ring's slots are registers)
+            const int s = s0 + u;
+            const uint32_t cur = q[u];
+            q[u] = s + kAhead <= nsym ? pp[4 * (s + kAhead - 1)] : 0u;
+            if (s <= nsym) {                                                     // (uniform inside a quad: the cross-lane reads below see their whole quad)
+                const unsigned a = (unsigned)(cfo_comp + pc * sfo_comp) & 0xFFFFu;
+                cpx c; c.re = trk_ucos(s_t, a); c.im = w16(-trk_usin(s_t, a));   // rot_coeff: (ucos, -usin)
+                const cpx p = mul_q15(unpack(cur), c);
+                int y = pk == 3 ? -p.im : p.im, x = pk == 3 ? -p.re : p.re;
+                const int shift = max(bit_scope(x), bit_scope(y)) - 6;           // uatan2 (intalg.h:100-113)
+                if (shift > 0) { y >>= shift; x >>= shift; }
+                int th = trk_uatan2_entry(s_t, (int)(signed char)(y & 0xFF), x);
+                if (pilot_sgn(symbol_count)) th = w16(th + 0x8000);
+                symbol_count++; if (symbol_count >= 127) symbol_count = 0;
+                int th1, th2, th3, th4;                                          // the four angles of the quad, in every lane (assembler: see k_track)
+                asm volatile("s_nop 1\n\t"
+                             "v_mov_b32_dpp %0, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_mov_b32_dpp %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_mov_b32_dpp %2, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                             "v_mov_b32_dpp %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                             : "=&v"(th1), "=&v"(th2), "=&v"(th3), "=&v"(th4) : "v"(th));
+                const int avg = w16((th1 + th2 + th3 + th4) / 4);
+                const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+                if (pk == 0) { TrackRec t; t.cfo_comp = (int16_t)cfo_comp; t.sfo_comp = (int16_t)sfo_comp; t.avg = (int16_t)avg; t.del = (int16_t)del; trk[s - 1] = t; }
+                cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
+                cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
+            }
+        }
+    }
+}
+
 // TPhaseCompensate + TPilotTrack::_rotate + T11aDemap for one group's symbol (3 data carriers per lane, 16 lanes per symbol): the three bins v3
 // (carriers e, e + 16, e + 32 in demap order) x CompCoeffs(cfo, sfo) x rotation(avg, del) -> soft values in carrier order at `dst`.
 __device__ __forceinline__ void sym_back_demap(const Tables& T, const uint8_t* s_demap, const uint32_t v3[3], TrackRec tr, int nb, int e, uint8_t* dst)

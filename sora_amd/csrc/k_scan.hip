@@ -665,7 +665,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                 else if (has_row) {
                     // queue the frame for the per-frame kernels
                     if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
-                    for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[r_slot0 + sy] = cap_i * A.max_frames + nfr;   // its data symbols' slots (k_sym_front / k_sym_back)
+                    if (A.slot_row) for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[r_slot0 + sy] = cap_i * A.max_frames + nfr;   // its data symbols' slots (k_sym_front / k_sym_back)
                 }
                 if (lane == 0 && has_row) {
                     FrameRow row;

@@ -56,6 +56,7 @@ __global__ void k_scan(ScanArgs A);
 __global__ void k_frame(RxArgs A);
 __global__ void k_sym_front(RxArgs A);
 __global__ void k_track(RxArgs A);
+__global__ void k_track_lds(RxArgs A);
 __global__ void k_sym_back(RxArgs A);
 __global__ void k_decode(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);

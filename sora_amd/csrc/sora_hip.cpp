@@ -53,6 +53,7 @@ struct HostTables {
     std::vector<uint16_t> deint;
     std::vector<uint8_t> scr, scr_seq, scr_phase;
     std::vector<uint32_t> crcz;
+    std::vector<uint32_t> trk;           // TrkTables as words
 };
 
 static inline uint32_t pk(int re, int im) { return ((uint32_t)re & 0xFFFFu) | ((uint32_t)im << 16); }
@@ -193,6 +194,28 @@ static void build_tables(HostTables& H)
         for (int q = 0; q < 127; q++) H.scr_seq[q] = H.scr[st[q]];
         for (int s7 = 1; s7 < 128; s7++) H.scr_phase[s7] = (uint8_t)pos_of[s7];
     }
+    // the tracker's tables folded for LDS (dev_arith.h: TrkTables)
+    {
+        static_assert(sizeof(TrkTables) % 16 == 0, "TrkTables is copied 16 bytes at a time");
+        H.trk.assign(sizeof(TrkTables) / 4, 0u);
+        TrkTables& t = *reinterpret_cast<TrkTables*>(H.trk.data());
+        for (int i = 0; i <= 16384; i++) t.q[i] = H.usin[i];
+        for (unsigned a = 0; a < 65536; a++) {
+            if (trk_usin(t, a) != H.usin[a]) t.exs[a >> 5] |= 1u << (a & 31u);
+            if (trk_ucos(t, a) != H.ucos[a]) t.exc[a >> 5] |= 1u << (a & 31u);
+        }
+        for (int y = 0; y < 128; y++) for (int x = 0; x < 256; x++) t.h[y * 256 + x] = H.uatan2[y * 256 + x];
+        for (int x = 0; x < 256; x++) t.h[128 * 256 + x] = (int16_t)-H.uatan2[128 * 256 + x];
+    }
+}
+
+// every entry of usin / ucos / uatan2 out of the folded tables: the proof that k_track_lds reads what the other kernels read
+static bool trk_tables_exact(const HostTables& H)
+{
+    const TrkTables& t = *reinterpret_cast<const TrkTables*>(H.trk.data());
+    for (unsigned a = 0; a < 65536; a++) if (trk_usin(t, a) != H.usin[a] || trk_ucos(t, a) != H.ucos[a]) return false;
+    for (int y = -128; y < 128; y++) for (int x = 0; x < 256; x++) if (trk_uatan2_entry(t, y, x) != H.uatan2[(y & 0xFF) * 256 + x]) return false;
+    return true;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -256,6 +279,7 @@ const TablePin kTablePins[] = {
     { "tw128", "91cc9a797bfd3c35a1c0ce8d972452419000b0b1dab70cdd56b435f5d01ad834" },
     { "tw32", "2a00eb47f9337b725bd5cfe52b6e7a6c696b141f4d4f10fe770fc403d7b3d703" },
     { "tw8", "e54d5a6817c1f2a559297821786fc9d2e58aa55dc2699d64d289e26bea16e348" },
+    { "trk", "df906ebcda760d39590c55e7f479d1e49f34ef3f8a87508afca083ecff664c3c" },
     { "crcz", "035d5a8379b2b38f05c16cb38107a51e153fd87dc45d71909ef8c25db84897e7" },
     { "dsp_sincos", "a85b7311f9347b68cb30ddf481a5670b78339f985ec327a1c6d4325dedf9800c" },
     { "dsp_atan", "7b576ae30701be7ab527c540af4d02e23e5b1ae1cc97e3ee83ab6cd63aa6343d" },
@@ -283,7 +307,8 @@ static int pin_host_tables(const HostTables& H)
     if ((rc = pin("usin", H.usin)) || (rc = pin("ucos", H.ucos)) || (rc = pin("rot", H.rot)) || (rc = pin("uatan2", H.uatan2)) || (rc = pin("demap", H.demap)) ||
         (rc = pin("tw64", H.tw64)) || (rc = pin("tw16", H.tw16)) || (rc = pin("sts", H.sts)) || (rc = pin("deint", H.deint)) || (rc = pin("crc", H.crc)) ||
         (rc = pin("scr", H.scr)) || (rc = pin("scr_seq", H.scr_seq)) || (rc = pin("scr_phase", H.scr_phase)) || (rc = pin("tw128", H.tw128)) || (rc = pin("tw32", H.tw32)) ||
-        (rc = pin("tw8", H.tw8)) || (rc = pin("crcz", H.crcz))) return rc;
+        (rc = pin("tw8", H.tw8)) || (rc = pin("crcz", H.crcz)) || (rc = pin("trk", H.trk))) return rc;
+    if (!trk_tables_exact(H)) return fail(SORA_ERR_FAILED, "the tracker's folded tables (TrkTables) do not reproduce usin / ucos / uatan2");
     return SORA_OK;
 }
 
@@ -333,6 +358,7 @@ static int make_dev_tables(DevTables& D)
     if ((rc = upload(D, H.tw32, (const void**)&D.T.tw32))) return rc;
     if ((rc = upload(D, H.tw8, (const void**)&D.T.tw8))) return rc;
     if ((rc = upload(D, H.crcz, (const void**)&D.T.crcz))) return rc;
+    if ((rc = upload(D, H.trk, (const void**)&D.T.trk))) return rc;
     return SORA_OK;
 }
 static void free_dev_tables(DevTables& D) { for (void* p : D.allocs) (void)hipFree(p); D.allocs.clear(); }
@@ -382,6 +408,7 @@ struct RxPipe {
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
     uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
     uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;   // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
+    bool split = false;                                         // symbol chain as k_sym_front -> k_track_lds -> k_sym_back (few frames in flight) instead of k_frame (one wave per frame)
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
                                                                 // 2 = k_viterbi16w + k_win_verify + k_viterbi on what failed its proof (window-parallel, k_vitwin.hip)
@@ -483,7 +510,7 @@ static std::vector<NamedTable> named_tables(const HostTables& H, const std::vect
              NT("demap", H.demap, T ? &T->demap : nullptr), NT("tw64", H.tw64, T ? &T->tw64 : nullptr), NT("tw16", H.tw16, T ? &T->tw16 : nullptr), NT("sts", H.sts, T ? &T->sts : nullptr),
              NT("deint", H.deint, T ? &T->deint : nullptr), NT("crc", H.crc, T ? &T->crc : nullptr), NT("scr", H.scr, T ? &T->scr : nullptr), NT("scr_seq", H.scr_seq, T ? &T->scr_seq : nullptr),
              NT("scr_phase", H.scr_phase, T ? &T->scr_phase : nullptr), NT("tw128", H.tw128, T ? &T->tw128 : nullptr), NT("tw32", H.tw32, T ? &T->tw32 : nullptr), NT("tw8", H.tw8, T ? &T->tw8 : nullptr),
-             NT("crcz", H.crcz, T ? &T->crcz : nullptr), NT("dsp_sincos", sc, dsc), NT("dsp_atan", at, dat) };
+             NT("crcz", H.crcz, T ? &T->crcz : nullptr), NT("trk", H.trk, T ? &T->trk : nullptr), NT("dsp_sincos", sc, dsc), NT("dsp_atan", at, dat) };
 #undef NT
 }
 int sora_hip_table_count(void) { return (int)(sizeof(kTablePins) / sizeof(kTablePins[0])); }
@@ -495,6 +522,7 @@ int sora_hip_table_digest(const char* name, char hex65[65])
     if (!name || !hex65) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_table_digest: null argument");
     HostTables H; build_tables(H);
     std::vector<uint32_t> sc; std::vector<short> at; sora_internal_dsp_host_tables(sc, at);
+    if (!strcmp(name, "trk") && !trk_tables_exact(H)) return fail(SORA_ERR_FAILED, "the tracker's folded tables (TrkTables) do not reproduce usin / ucos / uatan2");
     for (const NamedTable& t : named_tables(H, sc, at, nullptr, nullptr, nullptr)) if (!strcmp(t.name, name)) {
         const std::string d = table_digest(t.host, t.bytes);
         memcpy(hex65, d.c_str(), 65);
@@ -637,13 +665,16 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * kWinStatBanks * sizeof(unsigned long long)));
         HIPCHK(hipMemset(rx->d_wstats, 0, 4 * kWinStatBanks * sizeof(unsigned long long)));
     }
-    if (!rx->d_slot_row) {
-        HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
 #ifdef SORA_FRAME_SPLIT3
+    const bool split = true;
+#else
+    const bool split = rx->split && !rx->fused;
+#endif
+    if (split && !rx->d_slot_row) {                                              // the three-kernel symbol chain's arrays, on its first use: slot owners, equalised bins (256 B per slot), pilots, rotation parameters
+        HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
         HIPCHK(hipMalloc((void**)&rx->d_eq, 256 * ((size_t)rx->cap_slots + 64)));
         HIPCHK(hipMalloc((void**)&rx->d_track, sizeof(TrackRec) * ((size_t)rx->cap_slots + 64)));
         HIPCHK(hipMalloc((void**)&rx->d_pil, 16 * ((size_t)rx->cap_slots + 64)));
-#endif
     }
     hipStream_t st = rx->stream;
     const bool prof = rx->profiling;
@@ -670,14 +701,12 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16);
             hipLaunchKernelGGL(k_clear16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16);
         }
-#ifdef SORA_FRAME_SPLIT3
-        HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));        // no symbol slot has an owner yet (only the three-kernel symbol chain reads the owners)
-#endif
+        if (split) HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));   // no symbol slot has an owner yet (only the three-kernel symbol chain reads the owners)
         }
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = rx->d_slot_row; S.cont = rx->cont; S.consumed = rx->consumed;
+        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = split ? rx->d_slot_row : nullptr; S.cont = rx->cont; S.consumed = rx->consumed;
         mark();
         if (rx->only & 1u) hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
@@ -695,15 +724,20 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 #endif
         {
             R.soft = rx->d_soft; R.jobs = rx->d_jobs; R.slot_row = rx->d_slot_row; R.eq = rx->d_eq; R.track = rx->d_track; R.pil = rx->d_pil;
-#ifdef SORA_FRAME_SPLIT3                                                         // build variant (A/B, round 4): the symbol chain as three kernels (k_rx.hip) -- per symbol slot in front of and behind
-            // the tracker, per frame (four lanes each) for the tracker.  Measured and NOT adopted (profiles/r04_h_*): 10 M fewer instructions per call, but the equalised
-            // symbols' round trip through HBM makes the two symbol kernels as long as k_frame, and a lone call pays three launches instead of one.
-            hipLaunchKernelGGL(k_sym_front, dim3((slots + 63) / 64), dim3(256), 0, st, R);
-            hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
-            hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
+            if (split) {
+                // The symbol chain as three kernels (k_rx.hip): per symbol slot in front of and behind the tracker, per frame (four lanes each) for the tracker.  Round 4 built it
+                // (k_track, tables in L2) and did not adopt it: no faster than k_frame for a full batch (profiles/r04_h_*).  Round 5: the tracker with its tables in LDS
+                // (k_track_lds) makes it the chain for FEW frames in flight, where k_frame's one wave per frame is a 465-symbol serial loop (fsample-6).
+                if (rx->only & 2u) {
+                    hipLaunchKernelGGL(k_sym_front, dim3((slots + 63) / 64), dim3(256), 0, st, R);
+#ifdef SORA_FRAME_SPLIT3
+                    hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
 #else
-            if (rx->only & 2u) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+                    hipLaunchKernelGGL(k_track_lds, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
 #endif
+                    hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
+                }
+            } else if (rx->only & 2u) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
             if (!(rx->only & 4u)) {}
             else if (rx->lanes16 == 2) {
@@ -897,13 +931,15 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
 // front end of one call (k_scan) overlaps the issue-bound decode kernel of the call before it -- the overlap
 // the reference gets from running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120, TThreadSeparator
 // stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
-constexpr long long kAutoLanes16Captures = 16384;               // captures in flight (depth x the handle's max_captures) from which the automatic choice is k_viterbi16: it wins from four
-                                                                // 4096-capture calls in flight (profiles/r03_d_ab_trellis.txt) and equally from two 16384-capture calls (profiles/r04_q_large_calls.txt)
+constexpr long long kAutoLanes16Captures = 32768;               // captures in flight (depth x the handle's max_captures) from which the automatic choice is k_viterbi16: below that the
+                                                                // window-parallel form wins (gpurun r05: one to four 4096-capture calls in flight 0.60 / 0.51 / 0.48 / 0.46 ms per call against
+                                                                // 0.71 / 0.52 / 0.51 / 0.51 for the better of the two serial kernels; eight calls: k_viterbi16 0.40 against 0.42)
 struct sora_rx {
     static constexpr int kMaxDepth = 16;
     sora_rx_cfg cfg{};
     int depth = 8;
     int trellis = 0;             // sora_rx_set_trellis: 0 = chosen from the depth, 64 / 16 = lanes per frame pair
+    int front = 0;               // sora_rx_set_front: 0 = chosen from the capacity in flight, 1 = k_frame, 3 = the three-kernel symbol chain
     bool use_graph = false;
     int cur = 0;                 // pipeline of the most recent process call
     bool started = false;
@@ -996,9 +1032,29 @@ int sora_rx_set_fused(sora_rx_t* rx, int enable)
 // of tickets: two calls of 16384 captures fill the chip like eight of 4096, and eight calls of 64 captures do not.
 static int lanes16_for(const sora_rx* rx)                                       // -> RxPipe::lanes16: 0 k_viterbi, 1 k_viterbi16, 2 window-parallel
 {
-    if (rx->trellis) return rx->trellis == 16 ? 1 : rx->trellis == 1 ? 2 : 0;
-    return (long long)rx->depth * (long long)rx->cfg.max_captures >= kAutoLanes16Captures;
+    if (rx->trellis) return rx->trellis == 16 ? 1 : rx->trellis == SORA_TRELLIS_WINDOWED ? 2 : 0;
+    return (long long)rx->depth * (long long)rx->cfg.max_captures >= kAutoLanes16Captures ? 1 : 2;
 }
+
+// The symbol chain: one wave per frame (k_frame) is the cheaper one when the chip is full of frames; the three-kernel chain spreads a frame's symbols over the
+// chip and runs the tracker's chain out of LDS: the one for few, long frames.
+constexpr long long kAutoSplitRows = 512;                       // frame rows in flight (depth x max_captures x max_frames_per_capture) up to which the automatic choice is the three-kernel chain
+static bool split_for(const sora_rx* rx)
+{
+    if (rx->front) return rx->front == 3;
+    return (long long)rx->depth * (long long)rx->cfg.max_captures * (long long)rx->cfg.max_frames_per_capture <= kAutoSplitRows;
+}
+int sora_rx_set_front(sora_rx_t* rx, int kernels)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->front;
+    if (kernels == 0 || kernels == 1 || kernels == 3) {
+        rx->front = kernels;
+        for (RxPipe* p : rx->pipes) if (p) p->last_valid = false;               // (a recorded hipGraph holds the other kernels)
+    } else if (kernels > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_front: 0 (automatic), 1 (k_frame) or 3 (k_sym_front, k_track_lds, k_sym_back)");
+    return old;
+}
+int sora_rx_front(sora_rx_t* rx) { return rx ? (split_for(rx) ? 3 : 1) : SORA_ERR_INVALID_PARAM; }
 
 int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
 {
@@ -1118,6 +1174,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
+    if (p->split != split_for(rx)) { p->split = split_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1131,6 +1188,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
+    if (p->split != split_for(rx)) { p->split = split_for(rx); p->last_valid = false; }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1144,6 +1202,7 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
+    if (p->split != split_for(rx)) { p->split = split_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;

@@ -281,11 +281,11 @@ def test_calls_in_flight(sora, torch_cuda, oracle, depth):
         sets.append((torch_cuda.from_numpy(iq).cuda(), d, oracle_results(oracle, caps, 20)))
     rx = sora.Rx(max_captures=8, max_total_samples=max(len(t) for t, _, _ in sets), sample_rate_mhz=20, max_frames_per_capture=2)
     assert rx.set_depth(depth) == 8 and rx.set_depth(0) == depth
-    assert rx.trellis() == 64                                         # the automatic choice of the trellis kernel follows the capacity in flight (depth x max_captures)
+    assert rx.trellis() == sora.TRELLIS_WINDOWED                      # the automatic choice of the trellis kernel follows the capacity in flight (depth x max_captures): few frames -> cut into units
     big = sora.Rx(max_captures=4096, max_total_samples=4096 * 64, sample_rate_mhz=20, max_frames_per_capture=1)
-    big.set_depth(depth); assert big.trellis() == (16 if depth * 4096 >= 16384 else 64)
+    big.set_depth(depth); assert big.trellis() == (16 if depth * 4096 >= 32768 else sora.TRELLIS_WINDOWED)
     big.close()
-    rx.set_trellis(16 if depth >= 4 else 64)                          # (the deeper rotations run the eight-frames-per-wave kernel, as they do at full size)
+    rx.set_trellis(16 if depth >= 4 else 64 if depth >= 2 else 0)     # (the deeper rotations run the eight-frames-per-wave kernel, as they do at full size; one call in flight: the library's choice)
     ncalls = max(9, 2 * depth + 1)                  # (every pipeline is used at least twice)
     tickets = []
     for k in range(ncalls):

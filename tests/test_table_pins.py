@@ -18,7 +18,7 @@ def sora():
 
 def test_every_table_hashes_to_its_pin(sora):
     names = sora.table_names()
-    assert len(names) == 19 and {"usin", "ucos", "rot", "uatan2", "demap", "tw64", "tw16", "tw128", "tw32", "tw8", "dsp_sincos", "dsp_atan"} <= set(names)
+    assert len(names) == 20 and {"usin", "ucos", "rot", "uatan2", "demap", "tw64", "tw16", "tw128", "tw32", "tw8", "dsp_sincos", "dsp_atan"} <= set(names)
     for n in names:
         pin = sora.table_pin(n)
         assert pin and len(pin) == 64 and pin != "0" * 64, n
