@@ -26,7 +26,13 @@
 extern "C" {
 #endif
 
-#define SORA_HIP_ABI_VERSION 2
+/* 3 (round 5).  Against 2: (i) behaviour that round 4 changed under the old number: a call that has been delivered (sora_rx_deliver_async) AND waited for
+ * (sora_rx_wait / _wait_any; the same for the rx11b / rx11n / ht40 handles) is RELEASED -- its pipeline is the first to be reused, so its ticket is valid for `depth`
+ * further calls only if the host has not both delivered and waited for it; sora_rx_set_fused(1) answers SORA_E_NOT_SUPPORTED in the default build;
+ * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
+ * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
+ * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
+#define SORA_HIP_ABI_VERSION 3
 
 /* COMPLEX16: kernel/core/inc/complex.h */
 typedef struct { int16_t re, im; } sora_complex16;

@@ -739,9 +739,14 @@ class RxHt40:
         _check(self._L.sora_ht40_process_dev(self._h, _dev_ptr(d_iq0), _dev_ptr(d_iq1), arr, n, _dev_ptr(d_weights) if d_weights is not None else None))
         t = self._L.sora_ht40_ticket(self._h)
         self._nof = getattr(self, "_nof", {}); self._nof[t] = n
-        for old in [k for k in self._nof if k <= t - 8]:
-            del self._nof[old]
+        self._prune_nof()
         return t
+
+    def _prune_nof(self):
+        """forget the row bounds of tickets the LIBRARY no longer knows (a released slot is reused ahead of older calls still in flight, so ticket arithmetic
+        does not tell: ADVICE r4)"""
+        for old in [k for k in self._nof if not self._L.sora_ht40_stream_of(self._h, int(k))]:
+            del self._nof[old]
 
     def process_captures_dev(self, d_iq0, d_iq1, captures, max_frames_per_capture=4):
         """raw two-chain 40 MHz captures [(offset, nsamples[, id])]: the front end finds, parses and measures the frames"""
@@ -751,8 +756,7 @@ class RxHt40:
         t = self._L.sora_ht40_ticket(self._h)
         self._n = len(arr) * int(max_frames_per_capture)
         self._nof = getattr(self, "_nof", {}); self._nof[t] = self._n
-        for old in [k for k in self._nof if k <= t - 8]:                        # (tickets older than the handle's eight slots are gone: process_dev prunes the same way)
-            del self._nof[old]
+        self._prune_nof()
         return t
 
     def ticket(self):

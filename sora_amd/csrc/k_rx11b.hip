@@ -1059,8 +1059,12 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
     // The pass plan.  Automatic (default): a two-pass call also counts, on the device, how many captures its first pass handed over; once such a
     // count has come back (no waiting: the event is only queried) and says "more than half", the following calls go straight through the CCK
     // instantiation -- which decodes all four rates with identical rows -- except every 16th, which is a two-pass call again and measures.
-    for (Slot11b& Q : rx->slot)
-        if (Q.flagged_pending && hipEventQuery(Q.ev_flagged) == hipSuccess) { Q.flagged_pending = false; rx->auto_single = 2u * Q.h_flagged[0] > Q.h_flagged[1]; }
+    for (Slot11b& Q : rx->slot) {
+        if (!Q.flagged_pending) continue;
+        const hipError_t qe = hipEventQuery(Q.ev_flagged);
+        if (qe == hipSuccess) { Q.flagged_pending = false; rx->auto_single = 2u * Q.h_flagged[0] > Q.h_flagged[1]; }
+        else (void)hipGetLastError();                                           // (hipErrorNotReady is sticky for hipGetLastError: the check at the end of this call must not see it -- ADVICE r4)
+    }
     bool single = one_kernel || rx->pass_plan == 1;
     if (rx->pass_plan == 2 && rx->auto_single && (++rx->auto_calls & 15u) != 0u) single = true;
     HIPCHK11(hipMemsetAsync(S.d_needs_cck, single ? 1 : 0, 4 * ncaps, S.stream));

@@ -456,6 +456,11 @@ __global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
 }
+__global__ void __launch_bounds__(256) k_fill16(uint4* __restrict__ p, uint32_t n16, uint32_t v)   // n16 16-byte words <- v v v v
+{
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i < n16) p[i] = make_uint4(v, v, v, v);
+}
 }  // namespace sora
 
 // Adds the durations of the pipeline's last profiled call to its running sums (waits for that call).
@@ -701,7 +706,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16);
             hipLaunchKernelGGL(k_clear16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16);
         }
-        if (split) HIPCHK(hipMemsetAsync(rx->d_slot_row, 0xFF, 4 * (size_t)slots, st));   // no symbol slot has an owner yet (only the three-kernel symbol chain reads the owners)
+        if (split) {                                                             // no symbol slot has an owner yet (only the three-kernel symbol chain reads the owners); a kernel, not a memset: see above
+            const uint32_t n16 = (slots + 3) / 4;                                // (the array has 64 words of slack)
+            hipLaunchKernelGGL(k_fill16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_slot_row), n16, 0xFFFFFFFFu);
+        }
         }
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;

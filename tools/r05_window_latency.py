@@ -20,6 +20,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=4096)
     ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--profile-single", type=int, default=0, help="only N calls of fsample-6 as one capture with the library's automatic kernel choice (for rocprofv3 --kernel-trace --stats)")
     ap.add_argument("--profile-batch", type=int, default=0, help="only N lone window-parallel calls of the batch (for rocprofv3 --kernel-trace --stats)")
     a = ap.parse_args()
     import torch
@@ -30,6 +31,17 @@ def main():
     dev = "cuda:0"
     out = {}
     names = {64: "k_viterbi", 16: "k_viterbi16", 1: "k_viterbi16w"}
+    if a.profile_single:
+        g = np.load(os.path.join(ROOT, "tests", "golden", "fsample6_40mhz_i8.npz"))
+        iq40 = g["iq_i8"].astype(np.int16) << 8
+        n = len(iq40) // 28 * 28
+        d = torch.from_numpy(np.ascontiguousarray(iq40[:n])).to(dev)
+        rx = sora_amd.Rx(1, n, sample_rate_mhz=40, max_frames_per_capture=2)
+        rx.set_depth(1)
+        for _ in range(a.profile_single):
+            rx.wait(rx.process_dev(d, [(0, n, 0)]))
+        print(json.dumps({"front": rx.front(), "trellis": rx.trellis()})); rx.close()
+        return
     if a.profile_batch:
         iq, descs, _ = bench.make_workload(o, a.frames, seed0=0)
         d_iq = torch.from_numpy(iq).to(dev); dd = sora_amd.Rx.captures(descs)
