@@ -31,6 +31,9 @@ import time
 # set GPU_MAX_HW_QUEUES=16 before HIP started, because eight pipelines of one priority ran three at a time; since round 4 the library spreads a
 # handle's pipelines over the three priority levels (sora_internal_stream_create) and gets a hardware queue per pipeline by itself: the default
 # run sets NO environment variable (config.hw_queues = null; profiles/r04_m_stream_priorities.txt).  --hw-queues N still sets it, for A/B runs.
+TRELLIS_NAMES = {64: "k_viterbi", 16: "k_viterbi16", 1: "k_viterbi16w"}      # sora_rx_set_trellis: two frames per wave / eight per wave / window-parallel (round 5)
+
+
 def _early_hw_queues(argv):
     """--hw-queues N, read before the HIP runtime starts: N > 0 sets GPU_MAX_HW_QUEUES (unless the environment already does),
     0 leaves the runtime's default alone (`config.hw_queues` is then null)."""
@@ -325,7 +328,15 @@ def bench_stages(torch, sora_amd, dev, nsym=1 << 20, reps=12, nsets=3):
     idx = (torch.arange(nsym, device=dev, dtype=torch.int32) // 256) % nctx
     eqs = [torch.empty((nsym, 64, 2), dtype=torch.int16, device=dev) for _ in range(nsets)]
     timed([(lambda x=x, e=e: L.sora_hip_symfront11a(P(x), P(ctx), P(idx), P(e), nsym, st)) for x, e in zip(x80, eqs)], nsym * 576, "symfront11a")
-    del x80, eqs, idx
+    # the three one-multiply bricks alone: 256 in + 256 out per symbol, a frame's 256 bytes of coefficients shared by its 256 symbols
+    # (SURVEY section 8d counts a private coefficient read per symbol for the equaliser: 768)
+    del x80
+    x64 = [torch.randint(-6000, 6000, (nsym, 64, 2), dtype=torch.int16, device=dev, generator=g) for _ in range(nsets)]
+    stt = torch.randint(-32768, 32767, (nctx, 134), dtype=torch.int16, device=dev, generator=g)
+    timed([(lambda x=x, e=e: L.sora_hip_freq_comp11a(P(x), P(ctx), P(idx), P(e), nsym, st)) for x, e in zip(x64, eqs)], nsym * 512, "freq_comp11a")
+    timed([(lambda x=x, e=e: L.sora_hip_equalize11a(P(x), P(ctx), P(idx), P(e), nsym, st)) for x, e in zip(x64, eqs)], nsym * 512, "equalize11a")
+    timed([(lambda x=x, e=e: L.sora_hip_phase_comp11a(P(x), P(stt), P(idx), P(e), nsym, st)) for x, e in zip(x64, eqs)], nsym * 512, "phase_comp11a")
+    del x64, eqs, idx, stt
     # Viterbi: frames of 56 symbols x 216 soft values (the bench frame), random soft values 0..7
     nfr = 8192; nso = 56 * 288
     sv = torch.randint(0, 8, (nfr * nso,), dtype=torch.uint8, device=dev, generator=g)
@@ -383,24 +394,31 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
     rx.wait_for_producer = False
     ok = len(res) == 1 and res[0]["error_code"] == sora_amd.E_FRAME_OK and hashlib.sha256(res[0]["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
     per = {}
-    for lanes in (64, 16):
-        rx.set_trellis(lanes); rx.flush()
+    chains = {1: "k_frame", 3: "k_sym_front+k_track_lds+k_sym_back"}
+    for front, lanes in ((1, 64), (1, 16), (1, 1), (3, 64), (3, 1)):
+        rx.set_front(front); rx.set_trellis(lanes); rx.flush()
+        ok = ok and [r["mpdu"] for r in rx.results(ticket=rx.process_dev(d, one))] == [res[0]["mpdu"]]
         for _ in range(5):
             rx.wait(rx.process_dev(d, one))
         ts = []
         for _ in range(reps):
             t0 = time.perf_counter(); rx.wait(rx.process_dev(d, one)); ts.append(time.perf_counter() - t0)
-        per[lanes] = float(np.median(ts)) * 1e3
-    rx.set_trellis(64); rx.set_profiling(True)
+        per[chains[front] + " | " + TRELLIS_NAMES[lanes]] = float(np.median(ts)) * 1e3
+    rx.set_front(0); rx.set_trellis(0); rx.flush()                             # the library's own choice for a lone capture: the chains that spread ONE frame over the chip
+    auto = chains[rx.front()] + " | " + TRELLIS_NAMES[rx.trellis()]
+    rx.set_profiling(True)
     for _ in range(10):
         rx.wait(rx.process_dev(d, one))
-    rx.flush(); kt = rx.kernel_times(); rx.set_profiling(False); rx.close()
+    rx.flush(); kt = rx.kernel_times(); rx.set_profiling(False); wstats = rx.window_stats(); rx.close()
     air_ms = n / 40e3
     best = min(per.values())
     out["fsample6_single_capture"] = {
         "workload": "kernel/test-data/fsample-6.dmp after the 14->16 bit fix: one 6 Mbps frame, 1392 bytes, 465 data symbols, %d samples @40 MHz" % n,
-        "air_time_ms": round(air_ms, 4), "decode_ms": round(best, 4), "decode_ms_by_trellis_kernel": {"k_viterbi": round(per[64], 4), "k_viterbi16": round(per[16], 4)},
-        "realtime_factor": round(best / air_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kt.items()}, "mpdu_sha256_ok": bool(ok),
+        "air_time_ms": round(air_ms, 4), "decode_ms": round(per[auto], 4), "kernels": auto + " (the library's automatic choice)", "decode_ms_by_kernels": {k: round(v, 4) for k, v in per.items()},
+        "decode_ms_best": round(best, 4),
+        "realtime_factor": round(per[auto] / air_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+        "kernel_ms_note": "the library's five timed intervals of the automatic chain: 'k_frame' = k_sym_front + k_track_lds + k_sym_back, 'k_viterbi' = k_viterbi16w + k_win_verify + k_viterbi's empty second pass",
+        "window_trellis_record": wstats, "mpdu_sha256_ok": bool(ok),
         "protocol": "sora_rx_process_dev + sora_rx_wait, one call in flight, samples resident in HBM; median of %d calls (host wall clock)" % reps}
     ref = ReferenceGraph()
     if ref.available():
@@ -416,7 +434,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
     old_depth = rx_batch.set_depth(1); old_tr = rx_batch.set_trellis(-1); rx_batch.flush()
     req_us = 2 * FRAME_SAMPLES / 40.0
     dist = {}
-    for lanes in (64, 16):
+    for lanes in (64, 16, 1):
         rx_batch.set_trellis(lanes); rx_batch.flush()
         buf = sora_amd.HostResults(nfr * 2, rx_batch.mpdu_bytes(rx_batch.process_dev(d_iq, descs))); rx_batch.flush()
         lat = []
@@ -427,7 +445,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
                 lat.append((time.perf_counter() - t0) * 1e6)
         buf.close()
         r = np.asarray(lat) / req_us                                         # every frame of call i has ratio r[i]
-        dist[{64: "k_viterbi", 16: "k_viterbi16"}[lanes]] = {
+        dist[TRELLIS_NAMES[lanes]] = {
             "call_latency_ms": round(float(np.mean(lat)) / 1e3, 4), "frames": int(nfr * len(lat)), "required_us_per_frame": req_us,
             "ratio_mean": round(float(r.mean()), 3), "ratio_max": round(float(r.max()), 3), "ratio_std": round(float(r.std()), 3),
             "share_ge_0.8": round(float((r >= 0.8).mean()), 3), "share_ge_1.0": round(float((r >= 1.0).mean()), 3)}
@@ -493,7 +511,7 @@ def bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, maxf, exp_rows, ex
     ncalls = max(16, int(seconds / max(probe, 1e-6)))
     chk.compared = chk.bad = 0
     t0 = time.perf_counter(); block(ncalls); dt = time.perf_counter() - t0
-    out = {"captures_per_call": g_n * nfr, "calls_in_flight": dep, "trellis": {64: "k_viterbi", 16: "k_viterbi16"}[rx.trellis()], "calls_timed": ncalls,
+    out = {"captures_per_call": g_n * nfr, "calls_in_flight": dep, "trellis": TRELLIS_NAMES[rx.trellis()], "calls_timed": ncalls,
            "ms_per_call": round(1e3 * dt / ncalls, 4), "ms_per_%d_captures" % nfr: round(1e3 * dt / ncalls / g_n, 4),
            "msamples_per_s": round(g_n * nfr * FRAME_SAMPLES * ncalls / dt / 1e6, 1), "first_call_equals_the_verified_table": bool(ok),
            "calls_compared": chk.compared, "calls_with_wrong_rows": chk.bad, "input_bytes_per_call": int(big.numel() * 2),
@@ -1152,7 +1170,7 @@ def main():
     # The trellis kernel is pinned to the one the timed region used (left to itself the library picks k_viterbi for a single call in
     # flight and k_viterbi16 from depth 4); the other one is measured alone as well, for the record.
     lanes = rx.trellis(); trellis_setting = rx.set_trellis(-1)
-    tname = {64: "k_viterbi", 16: "k_viterbi16"}
+    tname = TRELLIS_NAMES
 
     def alone(l):
         rx.set_trellis(l); rx.set_depth(1); rx.flush()
@@ -1164,7 +1182,7 @@ def main():
         rx.set_profiling(False)
         return {(tname[l] if k == "k_viterbi" else k): v for k, v in kt.items()}
     ktimes1 = alone(lanes)
-    ktimes1_other = alone(80 - lanes)
+    ktimes1_others = {l: alone(l) for l in TRELLIS_NAMES if l != lanes}
     ktimes = {(tname[lanes] if k == "k_viterbi" else k): v for k, v in ktimes.items()}
 
     # ---- what a plain host gets: process -> deliver -> wait with ONE or TWO calls in flight, i.e. at most two of the
@@ -1184,7 +1202,7 @@ def main():
                                                                                  "calls_with_wrong_rows": chk.bad - bad0}
             order["any"] = True
         for dval in (1, 2):
-            for l in (64, 16):
+            for l in (64, 16, 1):
                 rx.set_trellis(l); rx.set_depth(dval); rx.flush()
                 run_block(args.warmup, deliver, dval); rx.flush(); chk.drain(); bad0 = chk.bad
                 nblk = max(1, repeats // 6)
@@ -1194,6 +1212,8 @@ def main():
                 ms_p = (time.perf_counter() - tp0) / (nblk * args.steps) * 1e3
                 plain["calls_in_flight_%d_%s" % (dval, tname[l])] = {"ms_per_step": round(ms_p, 4), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms_p / 1e3, 1),
                                                                       "calls_with_wrong_rows": chk.bad - bad0}
+        best1 = min((k for k in plain if k.startswith("calls_in_flight_1_")), key=lambda k: plain[k]["ms_per_step"])
+        plain["calls_in_flight_1"] = dict(plain[best1], config=best1)           # (the library's automatic choice for one lone call of this size is the window-parallel trellis)
         best2 = min((k for k in plain if k.startswith("calls_in_flight_2")), key=lambda k: plain[k]["ms_per_step"])
         plain["best_with_at_most_two_calls_in_flight"] = dict(plain[best2], config=best2)
         try:
@@ -1261,9 +1281,9 @@ def main():
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes1[dom], 4),
                          "kernel_ms_note": "mean launch duration with ONE call in flight (the kernel alone on the chip); with %d calls overlapped the same launch lasts %.4f ms (frac %.5f) because it shares the CUs" % (depth, ktimes[dom], ach / HBM_PEAK),
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
-                         "other_trellis_kernel": {"kernel": tname[80 - lanes], "kernel_ms": round(ktimes1_other[tname[80 - lanes]], 4),
-                                                  "frac": round(launch_bytes / (ktimes1_other[tname[80 - lanes]] * 1e-3) / HBM_PEAK, 5),
-                                                  "note": "sora_rx_set_trellis: k_viterbi = two frames per wave (the faster one for a call alone on the chip), k_viterbi16 = eight per wave (the faster one from 16384 captures in flight; the automatic choice follows depth x max_captures)"},
+                         "other_trellis_kernels": {tname[l]: {"kernel_ms": round(kt[tname[l]], 4), "frac": round(launch_bytes / (kt[tname[l]] * 1e-3) / HBM_PEAK, 5)} for l, kt in ktimes1_others.items()},
+                         "other_trellis_kernels_note": "sora_rx_set_trellis, each alone on the chip: k_viterbi = two frames per wave, k_viterbi16 = eight per wave (the one for 32768 and more captures in flight), k_viterbi16w = the frames' "
+                                                       "trace-back windows decoded side by side and proven afterwards, with k_win_verify and the serial kernel's (empty) second pass in its time (the one below that; the automatic choice follows depth x max_captures)",
                          "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},

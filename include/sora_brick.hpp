@@ -222,6 +222,29 @@ struct THip11aSymFront : THipStage<sora_complex16, 80 * N, sora_complex16, 64 * 
         : THipStage<sora_complex16, 80 * N, sora_complex16, 64 * N, CallSymFront11a, T_CTX, T_NEXT>(ctx, next, d_out, CallSymFront11a{ d_ctx, N }, stream) {}
 };
 
+// The three one-multiply bricks of the symbol chain, each where its SSE brick sits (IPORT COMPLEX16 x 64 -> OPORT COMPLEX16 x 64, N symbols per burst):
+//   THipFreqCompensation     TFreqCompensation     (channel_11a.hpp:614-653)   bound to the frame's T11aLTS record (CF_FreqCompensate::Coeffs)
+//   THipChannelEqualization  TChannelEqualization  (channel_11a.hpp:534-604)   bound to the same record (CF_Channel_11a::ChannelCoeffs)
+//   THipPhaseCompensate      TPhaseCompensate      (freqoffset.hpp:16-66)      bound to the tracker's state (CF_PhaseCompensate::CompCoeffs = sora_track11a_state::comp)
+struct CallFreqComp11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_freq_comp11a(in, d_ctx, nullptr, out, n, st); } };
+struct CallEqualize11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_equalize11a(in, d_ctx, nullptr, out, n, st); } };
+struct CallPhaseComp11a { const sora_track11a_state* d_state; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_phase_comp11a(in, d_state, nullptr, out, n, st); } };
+template <size_t N, class T_CTX, class T_NEXT>
+struct THipFreqCompensation : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallFreqComp11a, T_CTX, T_NEXT> {
+    THipFreqCompensation(T_CTX& ctx, T_NEXT* next, const sora_lts11a_ctx* d_ctx, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallFreqComp11a, T_CTX, T_NEXT>(ctx, next, d_out, CallFreqComp11a{ d_ctx, N }, stream) {}
+};
+template <size_t N, class T_CTX, class T_NEXT>
+struct THipChannelEqualization : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallEqualize11a, T_CTX, T_NEXT> {
+    THipChannelEqualization(T_CTX& ctx, T_NEXT* next, const sora_lts11a_ctx* d_ctx, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallEqualize11a, T_CTX, T_NEXT>(ctx, next, d_out, CallEqualize11a{ d_ctx, N }, stream) {}
+};
+template <size_t N, class T_CTX, class T_NEXT>
+struct THipPhaseCompensate : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallPhaseComp11a, T_CTX, T_NEXT> {
+    THipPhaseCompensate(T_CTX& ctx, T_NEXT* next, const sora_track11a_state* d_state, sora_complex16* d_out, void* stream = nullptr)
+        : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallPhaseComp11a, T_CTX, T_NEXT>(ctx, next, d_out, CallPhaseComp11a{ d_state, N }, stream) {}
+};
+
 // TPhaseCompensate -> TPilotTrack (freqoffset.hpp:14-66, pilot.hpp:121-269): IPORT COMPLEX16 x 64 -> OPORT COMPLEX16 x 64, N symbols of ONE
 // frame per burst; CF_PhaseCompensate / CF_PilotTrack live in `d_state` and carry over from burst to burst.  d_first / d_nsym: device words
 // holding 0 and N (the C entry point takes frame tables).

@@ -251,12 +251,21 @@ int sora_hip_lts11a(const sora_complex16* d_in, sora_lts11a_ctx* d_ctx, size_t n
 /* T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization (PHY_11a.hpp:361-430, channel_11a.hpp:532-653):
  * IPORT COMPLEX16 x 80 -> OPORT COMPLEX16 x 64; symbol i uses d_ctx[d_ctx_index[i]] (d_ctx_index NULL: d_ctx[0]) */
 int sora_hip_symfront11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_eq, size_t n, void* stream);
+/* The three one-multiply bricks of the symbol chain on their own (the receive path fuses them; here each can replace its SSE brick alone), IPORT COMPLEX16 x 64 ->
+ * OPORT COMPLEX16 x 64, symbol i with the coefficients of d_ctx[d_ctx_index[i]] (index NULL: d_ctx[0]):
+ *   TFreqCompensation     (channel_11a.hpp:614-653)  out = ((in >> 1) x CF_FreqCompensate::Coeffs) >> 15.  The brick also leaves in >> 1 in its input queue; the
+ *                                                   queue belongs to the caller here and is not written.
+ *   TChannelEqualization  (channel_11a.hpp:534-604)  out = (in x CF_Channel_11a::ChannelCoeffs) >> 8, bins 28 .. 35 zero
+ *   TPhaseCompensate      (freqoffset.hpp:16-66)     out = (in x CF_PhaseCompensate::CompCoeffs) >> 15 -- sora_track11a_state::comp of d_state[d_state_index[i]] */
+int sora_hip_freq_comp11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_out, size_t n, void* stream);
+int sora_hip_equalize11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_out, size_t n, void* stream);
 /* TPhaseCompensate + TPilotTrack (freqoffset.hpp:14-66, pilot.hpp:121-269) over the symbols of n frames, in order:
  * frame f owns symbols d_first[f] .. d_first[f]+d_nsym[f]-1 of d_eq; d_state[f] = CF_PhaseCompensate + CF_PilotTrack,
  * read at entry and written back.  Bins 0 and 27..37 of the output are not defined by the reference and are written 0. */
 typedef struct { int16_t cfo_comp, sfo_comp, cfo_tracker, sfo_tracker; uint32_t symbol_count; sora_complex16 comp[64]; } sora_track11a_state;
 int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state,
                             sora_complex16* d_out, size_t nframes, void* stream);
+int sora_hip_phase_comp11a(const sora_complex16* d_in, const sora_track11a_state* d_state, const uint32_t* d_state_index, sora_complex16* d_out, size_t n, void* stream);
 /* T11aDemap<N_BPSC>::Filter (demapper11a.hpp:10-79): IPORT COMPLEX16x64 -> OPORT uchar x 48*n_bpsc */
 int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream);
 /* T11aDeinterleave{BPSK,QPSK,QAM16,QAM64} (deinterleaver.hpp): IPORT uchar x N_CBPS -> OPORT uchar x N_CBPS */

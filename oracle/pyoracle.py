@@ -303,6 +303,12 @@ class Reference:
         a = np.ascontiguousarray(a, np.int16).reshape(4, 2); b = np.ascontiguousarray(b, np.int16).reshape(4, 2)
         o = np.zeros((4, 2), np.int16); getattr(self.L, fn)(_P(a), _P(b), *extra, _P(o)); return o
 
+    def brick64(self, which, x, coeffs):
+        """one symbol through the reference's own primitives in the order of TFreqCompensation ("freq_comp"), TChannelEqualization ("channel_equalize") or
+        TPhaseCompensate ("phase_comp") -- oracle/ref_shim.cpp"""
+        a = np.ascontiguousarray(x, np.int16).reshape(64, 2); c = np.ascontiguousarray(coeffs, np.int16).reshape(64, 2); o = np.zeros_like(a)
+        getattr(self.L, "ref_%s64" % which)(_P(a), _P(c), _P(o)); return o
+
     def demap(self, nbpsc, x):
         a = np.ascontiguousarray(x, np.int16).reshape(64, 2); lim = np.zeros_like(a); o = np.zeros(48 * nbpsc, np.uint8)
         self.L.ref_demap_limit64(_P(a), _P(lim)); self.L.ref_demap11a(_P(lim), nbpsc, _P(o)); return o

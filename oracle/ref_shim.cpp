@@ -47,6 +47,24 @@ EXPORT void ref_vcs_sqnorm(const int16_t* a, int32_t* r)
 EXPORT void ref_vcs_pack(const int32_t* re, const int32_t* im, int16_t* r)
 { A16 vi a, b; A16 vcs z; memcpy(&a, re, 16); memcpy(&b, im, 16); pack(z, a, b); memcpy(r, &z, 16); }
 
+// ---------------------------------------------------------------- three one-line bricks on one symbol (64 COMPLEX16), the reference's own primitives in the bricks' own order
+// TFreqCompensation::Process (channel_11a.hpp:642-644): rep_shift_right<16>(pi, pi, 1); FrequencyShift<16>(po, pi, FreqCoeffs) = rep_mul<16> (dspalg.hpp:219-224)
+EXPORT void ref_freq_comp64(const int16_t* in, const int16_t* coeffs, int16_t* out)
+{ A16 vcs x[16], c[16], o[16]; memcpy(x, in, 256); memcpy(c, coeffs, 256); rep_shift_right<16>(x, x, 1); rep_mul<16>(o, x, c); memcpy(out, o, 256); }
+// TChannelEqualization::_channel_equalize (channel_11a.hpp:548-574): mul -> >> norm_shift (8) -> pack, vcs 7 and 8 (bins 28..35) zero
+EXPORT void ref_channel_equalize64(const int16_t* in, const int16_t* coeffs, int16_t* out)
+{
+    A16 vcs x[16], c[16], o[16]; memcpy(x, in, 256); memcpy(c, coeffs, 256);
+    vi re, im;
+    set_zero(o[7]); set_zero(o[8]);
+    for (int i = 0; i < 7; i++)  { mul(re, im, x[i], c[i]); re = shift_right(re, 8); im = shift_right(im, 8); pack(o[i], re, im); }
+    for (int i = 9; i < 16; i++) { mul(re, im, x[i], c[i]); re = shift_right(re, 8); im = shift_right(im, 8); pack(o[i], re, im); }
+    memcpy(out, o, 256);
+}
+// TPhaseCompensate::_phase_compensate (freqoffset.hpp:28-30): rep_mul<16>(output, input, CompCoeffs)
+EXPORT void ref_phase_comp64(const int16_t* in, const int16_t* coeffs, int16_t* out)
+{ A16 vcs x[16], c[16], o[16]; memcpy(x, in, 256); memcpy(c, coeffs, 256); rep_mul<16>(o, x, c); memcpy(out, o, 256); }
+
 // ---------------------------------------------------------------- intalg.h
 EXPORT int16_t ref_usin(int16_t r) { return usin(r); }
 EXPORT int16_t ref_ucos(int16_t r) { return ucos(r); }

@@ -121,6 +121,45 @@ __global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* __restri
     }
 }
 
+// The three one-multiply bricks of the symbol chain on their own (in the receive path they are fused into k_frame / k_sym_front / k_sym_back):
+//   KIND 0  TFreqCompensation      out = ((in >> 1) x FreqCoeffs) >> 15, wrapping pack                  (channel_11a.hpp:642-644, dspalg.hpp:219-224)
+//   KIND 1  TChannelEqualization   out = (in x ChannelCoeffs) >> 8, wrapping pack; bins 28 .. 35 = 0     (channel_11a.hpp:548-574)
+//   KIND 2  TPhaseCompensate       out = (in x CompCoeffs) >> 15, wrapping pack                          (freqoffset.hpp:28-30)
+// Symbol i multiplies by the 64 coefficients at coef + cstride x cindex[i] + coff words (cindex == nullptr: set 0): a frame's coefficients serve all its symbols, so
+// a symbol is 256 bytes in and 256 out.  16 lanes per symbol, one 16-byte load and store per lane, every load of a thread's tiles in flight before the first product.
+template <int KIND>
+__global__ void __launch_bounds__(256) k_cmul64_batch(const uint32_t* __restrict__ in, const uint32_t* __restrict__ coef, uint32_t cstride, uint32_t coff, const uint32_t* __restrict__ cindex,
+                                                      uint32_t* __restrict__ out, uint32_t n)
+{
+    constexpr int kTiles = 8;
+    const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
+    uint4 v[kTiles]; uint32_t ci[kTiles];
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) {
+        const uint32_t i = (blockIdx.x * kTiles + t) * 16 + g;
+        v[t] = i < n ? reinterpret_cast<const uint4*>(in)[(size_t)i * 16 + e] : uint4{0, 0, 0, 0};
+        ci[t] = (i < n && cindex) ? cindex[i] : 0u;
+    }
+#pragma unroll
+    for (int t = 0; t < kTiles; t++) {
+        const uint32_t i = (blockIdx.x * kTiles + t) * 16 + g;
+        const uint32_t* c = coef + (size_t)ci[t] * cstride + coff + 4 * e;           // (a context's coefficient arrays start on a word, not on 16 bytes: four word loads, L2-resident)
+        const uint32_t x[4] = { v[t].x, v[t].y, v[t].z, v[t].w };
+        uint32_t o[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+            const PkTw w = pk_tw_mul(c[q]);
+            if (KIND == 0)      o[q] = pk_cmul<15>(pk_sra(x[q], 1), w);
+            else if (KIND == 1) o[q] = (4 * e + q >= 28 && 4 * e + q < 36) ? 0u : pk_cmul<8>(x[q], w);
+            else                o[q] = pk_cmul<15>(x[q], w);
+        }
+        if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 16 + e] = uint4{o[0], o[1], o[2], o[3]};
+    }
+}
+template __global__ void k_cmul64_batch<0>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+template __global__ void k_cmul64_batch<1>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+template __global__ void k_cmul64_batch<2>(const uint32_t*, const uint32_t*, uint32_t, uint32_t, const uint32_t*, uint32_t*, uint32_t);
+
 // TFFT64: the same shape without the context.
 __global__ void __launch_bounds__(256) k_fft64_batch(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, uint32_t n, Tables T)
 {

@@ -1422,6 +1422,37 @@ int sora_hip_symfront11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ct
     return SORA_OK;
 }
 
+// The symbol chain's three one-multiply bricks on their own (k_stage.hip: k_cmul64_batch)
+static int cmul64_stage(int kind, const char* who, const sora_complex16* d_in, const void* d_coef, uint32_t cstride_words, uint32_t coff_words, const uint32_t* d_index, sora_complex16* d_out, size_t n, void* stream)
+{
+    if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+    if (!d_in || !d_coef || !d_out) return fail(SORA_ERR_INVALID_PARAM, who);
+    if (n == 0) return SORA_OK;
+    if (n >= (1ull << 31)) return fail(SORA_ERR_CAPACITY, who);
+    if (((uintptr_t)d_in | (uintptr_t)d_out) & 15) return fail(SORA_ERR_INVALID_PARAM, "symbol buffers must be 16-byte aligned");
+    const dim3 grid((unsigned)((n + 127) / 128)); const hipStream_t st = (hipStream_t)stream;
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in); const uint32_t* cf = reinterpret_cast<const uint32_t*>(d_coef); uint32_t* out = reinterpret_cast<uint32_t*>(d_out);
+    if (kind == 0)      hipLaunchKernelGGL(k_cmul64_batch<0>, grid, dim3(256), 0, st, in, cf, cstride_words, coff_words, d_index, out, (uint32_t)n);
+    else if (kind == 1) hipLaunchKernelGGL(k_cmul64_batch<1>, grid, dim3(256), 0, st, in, cf, cstride_words, coff_words, d_index, out, (uint32_t)n);
+    else                hipLaunchKernelGGL(k_cmul64_batch<2>, grid, dim3(256), 0, st, in, cf, cstride_words, coff_words, d_index, out, (uint32_t)n);
+    HIPCHK(hipGetLastError());
+    return SORA_OK;
+}
+int sora_hip_freq_comp11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_out, size_t n, void* stream)
+{
+    static_assert(sizeof(sora_lts11a_ctx) == 516, "sora_lts11a_ctx layout");
+    return cmul64_stage(0, "sora_hip_freq_comp11a: null pointer", d_in, d_ctx, 129u, 1u, d_ctx_index, d_out, n, stream);
+}
+int sora_hip_equalize11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ctx, const uint32_t* d_ctx_index, sora_complex16* d_out, size_t n, void* stream)
+{
+    return cmul64_stage(1, "sora_hip_equalize11a: null pointer", d_in, d_ctx, 129u, 65u, d_ctx_index, d_out, n, stream);
+}
+int sora_hip_phase_comp11a(const sora_complex16* d_in, const sora_track11a_state* d_state, const uint32_t* d_state_index, sora_complex16* d_out, size_t n, void* stream)
+{
+    static_assert(sizeof(sora_track11a_state) == 268, "sora_track11a_state layout");
+    return cmul64_stage(2, "sora_hip_phase_comp11a: null pointer", d_in, d_state, 67u, 3u, d_state_index, d_out, n, stream);
+}
+
 int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out, size_t nframes, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");

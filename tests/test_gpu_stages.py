@@ -102,3 +102,51 @@ def test_fft128_matches_reference_vectors(env, golden_dir):
     assert np.array_equal(got, v["fft128_out"])
     got64 = sora.fft64(torch.from_numpy(v["fft64_in"]).cuda()).cpu().numpy()
     assert np.array_equal(got64, v["fft64_out"])
+
+
+def _mul32(a, b):
+    """vector128.h:1075-1081 on int64 arrays [...,2]: 32-bit wrapping parts of a x b with the im of b negated by _mm_sign_epi16 (wrapping)"""
+    w16 = lambda v: ((v + 32768) & 0xFFFF) - 32768          # noqa: E731
+    w32 = lambda v: ((v + (1 << 31)) & 0xFFFFFFFF) - (1 << 31)  # noqa: E731
+    re = w32(a[..., 0] * b[..., 0] + a[..., 1] * w16(-b[..., 1])); im = w32(a[..., 0] * b[..., 1] + a[..., 1] * b[..., 0])
+    return re, im, w16
+
+
+def test_freq_comp_equalize_phase_comp_alone(env, oracle):
+    """TFreqCompensation, TChannelEqualization and TPhaseCompensate as stand-alone stages (channel_11a.hpp:534-653, freqoffset.hpp:16-66): 4099 random
+    symbols with the corner values, several coefficient sets picked per symbol, against the vector128 arithmetic restated in numpy AND -- where oracle/_ref is
+    present -- against the reference's own primitives called in the bricks' order (oracle/ref_shim.cpp: ref_freq_comp64, ref_channel_equalize64, ref_phase_comp64)."""
+    from oracle.pyoracle import Reference
+    torch, sora = env
+    rng = np.random.default_rng(44)
+    n, m = 4099, 7
+    amps = np.array([32767, 20000, 8000, 500, 30])[np.arange(n) % 5]
+    x = (rng.integers(-32768, 32768, size=(n, 64, 2)) % (2 * amps[:, None, None] + 1) - amps[:, None, None]).astype(np.int16)
+    x[7, 3] = (-32768, 32767); x[8] = 0; x[9] = 32767; x[10] = -32768
+    ctx = rng.integers(-32768, 32768, size=(m, 258)).astype(np.int16)           # sora_lts11a_ctx: cfo_est, reserved, freq[64], chan[64]
+    ctx[0, 2:] = 32767; ctx[1, 2:] = -32768
+    st = rng.integers(-32768, 32768, size=(m, 134)).astype(np.int16)            # sora_track11a_state: 4 x int16, symbol_count, comp[64]
+    st[0, 6:] = -32768
+    idx = rng.integers(0, m, n).astype(np.int32); idx[:m] = np.arange(m)
+    xd = torch.from_numpy(x).cuda(); id_ = torch.from_numpy(idx).cuda()
+    got = {"freq_comp": sora.freq_comp11a(xd, torch.from_numpy(ctx).cuda(), id_).cpu().numpy(),
+           "channel_equalize": sora.equalize11a(xd, torch.from_numpy(ctx).cuda(), id_).cpu().numpy(),
+           "phase_comp": sora.phase_comp11a(xd, torch.from_numpy(st).cuda(), id_).cpu().numpy()}
+    coef = {"freq_comp": ctx[:, 2:130].reshape(m, 64, 2), "channel_equalize": ctx[:, 130:258].reshape(m, 64, 2), "phase_comp": st[:, 6:].reshape(m, 64, 2)}
+    X = x.astype(np.int64)
+    for which in got:
+        c = coef[which][idx].astype(np.int64)
+        a = X >> 1 if which == "freq_comp" else X
+        re, im, w16 = _mul32(a, c)
+        sh = 8 if which == "channel_equalize" else 15
+        want = np.stack([w16(re >> sh), w16(im >> sh)], -1).astype(np.int16)
+        if which == "channel_equalize":
+            want[:, 28:36] = 0
+        assert np.array_equal(got[which], want), which
+    # index NULL = set 0 for every symbol
+    assert np.array_equal(sora.equalize11a(xd[:100], torch.from_numpy(ctx).cuda()).cpu().numpy(), sora.equalize11a(xd[:100], torch.from_numpy(ctx).cuda(), torch.zeros(100, dtype=torch.int32).cuda()).cpu().numpy())
+    ref = Reference()
+    if ref.available() and hasattr(ref.L, "ref_freq_comp64"):
+        for i in list(range(12)) + list(range(n - 200, n)):
+            for which in got:
+                assert np.array_equal(got[which][i], ref.brick64(which, x[i], coef[which][idx[i]])), (which, i)

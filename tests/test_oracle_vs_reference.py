@@ -74,3 +74,27 @@ def test_crc32(oracle, reference):
     for n in (0, 1, 5, 100, 1500):
         b = rng.integers(0, 256, n).astype(np.uint8).tobytes()
         assert oracle.crc32(b) == reference.crc32(b)
+
+
+def test_one_multiply_bricks_in_numpy_equal_the_reference_primitives(reference):
+    """The numpy restatement tests/test_gpu_stages.py checks the stand-alone TFreqCompensation / TChannelEqualization / TPhaseCompensate stages with (on the GPU box)
+    against the reference's own primitives in the bricks' order (oracle/ref_shim.cpp, channel_11a.hpp:548-574,642-644, freqoffset.hpp:28-30), here, where the
+    reference library is freshly built: 300 random symbols and the corner values."""
+    import os
+    import importlib.util
+    if not hasattr(reference.L, "ref_freq_comp64"):
+        pytest.skip("oracle/_ref/libsora_ref.so predates the brick shims")
+    spec = importlib.util.spec_from_file_location("tgs", os.path.join(os.path.dirname(os.path.abspath(__file__)), "test_gpu_stages.py"))
+    tgs = importlib.util.module_from_spec(spec); spec.loader.exec_module(tgs)
+    rng = np.random.default_rng(1)
+    for it in range(300):
+        x = rng.integers(-32768, 32768, (64, 2)).astype(np.int16); c = rng.integers(-32768, 32768, (64, 2)).astype(np.int16)
+        if it == 0: x[:] = -32768; c[:] = -32768
+        if it == 1: x[:] = 32767; c[:] = -32768
+        for which in ("freq_comp", "channel_equalize", "phase_comp"):
+            a = x.astype(np.int64) >> 1 if which == "freq_comp" else x.astype(np.int64)
+            re, im, w16 = tgs._mul32(a, c.astype(np.int64)); sh = 8 if which == "channel_equalize" else 15
+            want = np.stack([w16(re >> sh), w16(im >> sh)], -1).astype(np.int16)
+            if which == "channel_equalize":
+                want[28:36] = 0
+            assert np.array_equal(reference.brick64(which, x, c), want), (which, it)
