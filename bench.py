@@ -167,6 +167,11 @@ def _cpu_worker(args):
         g = ReferenceGraph()
         caps = np.repeat(caps, 2, axis=1)                                 # input preparation, not timed
         run = lambda: g.rx11a_bench(caps)                                 # noqa: E731  (the loop over captures is inside the library)
+    elif kind == "reference_mt":                                          # the reference's native split: RxThread here, ViterbiThread behind TThreadSeparator on a second core (fb11a_demod.cpp:83-120)
+        import ctypes
+        mt = ctypes.CDLL(os.path.join(ROOT, "oracle", "_ref", "libsora_refgraph_mt.so")); mt.ref_rx11a_bench_mt.restype = ctypes.c_uint32
+        caps = np.ascontiguousarray(np.repeat(caps, 2, axis=1))
+        run = lambda: mt.ref_rx11a_bench_mt(caps.ctypes.data_as(ctypes.c_void_p), caps.shape[0], caps.shape[1], 1)  # noqa: E731
     else:
         from oracle.pyoracle import Oracle
         o = Oracle()
@@ -244,6 +249,25 @@ def cpu_baseline(iq, nframes, budget_s=10.0):
                 out[kind] = {"value": round(sum(r[0] * FRAME_SAMPLES / r[2] for r in res) / 1e6, 3),   # side by side: rates add
                              "single": round(one[0] * FRAME_SAMPLES / one[2] / 1e6, 4),
                              "n": sum(r[0] for r in res), "ok": sum(r[1] for r in res), "secs": secs}
+        if have_ref and os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libsora_refgraph_mt.so")) and cores >= 2:
+            # "single-thread and the native demod || Viterbi split" -- one instance of the two-thread harness (two cores), then cores // 2 of them side by
+            # side.  Each instance is a process of its own that leaves through os._exit: its ViterbiThread spins on the separator's queue for good, as the reference's does.
+            def mt_run(n_inst, secs):
+                import subprocess
+                ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-mt-worker", "%s,%d,%d,%d,%g" % (path, nframes, k, n_inst, secs)], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL)
+                      for k in range(n_inst)]
+                res = []
+                for q in ps:
+                    try:
+                        o_, _ = q.communicate(timeout=secs + 60)
+                        res.append(json.loads(o_.decode().strip().splitlines()[-1]))
+                    except Exception:
+                        q.kill()
+                return res
+            one = mt_run(1, 3.0); pairs = max(1, cores // 2); many = mt_run(pairs, 4.0)
+            if one and len(many) == pairs:
+                out["reference_mt"] = {"single": round(one[0][0] * FRAME_SAMPLES / one[0][2] / 1e6, 4), "value": round(sum(r[0] * FRAME_SAMPLES / r[2] for r in many) / 1e6, 3), "instances": pairs,
+                                       "ok": one[0][1], "n": one[0][0]}
     kind = "reference" if have_ref else "port"
     m = out[kind]
     what = ("the reference's brick graph compiled from its sources (oracle/_ref/libsora_refgraph.so, SSE)" if have_ref
@@ -253,6 +277,12 @@ def cpu_baseline(iq, nframes, budget_s=10.0):
          "frames_ok": m["ok"], "frames_run": m["n"]}
     if have_ref:
         r["port_value"] = out["port"]["value"]; r["port_single_core_value"] = out["port"]["single"]
+    if "reference_mt" in out:
+        mt = out["reference_mt"]
+        r["two_thread_value"] = mt["single"]
+        r["two_thread"] = {"value_one_instance_two_cores": mt["single"], "value_all_cores": mt["value"], "instances": mt["instances"], "frames_ok": mt["ok"], "frames_run": mt["n"],
+                           "what": "the reference's own harness shape: RxThread on one core, ViterbiThread behind TThreadSeparator on a second (fb11a_demod.cpp:83-120, stdbrick.hpp:89-248; "
+                                   "oracle/_ref/libsora_refgraph_mt.so, graph and thread kept across captures); the single-thread build above replaces the separator by TNoInline"}
     return r
 
 
@@ -987,6 +1017,10 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
 
 
 def main():
+    if len(sys.argv) == 3 and sys.argv[1] == "--cpu-mt-worker":                 # one instance of the reference's two-thread harness (cpu_baseline.two_thread): never returns normally
+        p_, nf, first, stride, secs = sys.argv[2].split(",")
+        print(json.dumps(list(_cpu_worker((p_, int(nf), int(first), int(stride), float(secs), "reference_mt")))), flush=True)
+        os._exit(0)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=60)

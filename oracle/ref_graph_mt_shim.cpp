@@ -71,3 +71,43 @@ EXPORT int ref_rx11a_capture_mt(const int16_t* iq, uint32_t nsamples40, ref_fram
     IReferenceCounting::Release(src);
     return n;
 }
+
+// The two-thread harness as bench.py times it (cpu_baseline.two_thread_value): the graph and the ViterbiThread are created ONCE -- as Test11A_FB_Demod creates them
+// once per dump (fb11a_demod.cpp:88-120) -- and `ncap` equal-sized captures laid end to end go through the RxThread loop `reps` times; only the number of
+// frames with a good FCS comes back.  Two host cores are busy: RxThread here, ViterbiThread spinning on the separator's queue as the reference's does.
+EXPORT uint32_t ref_rx11a_bench_mt(const int16_t* iq, uint32_t ncap, uint32_t nsamples40, uint32_t reps)
+{
+    static ISource* src; static ISource* vit; static IControlPoint* cs; static VitThread vt; static pthread_t viterbi; static int started;
+    if (g_cap < nsamples40 + 64) { free(g_buf); g_cap = nsamples40 + 64; g_buf = (COMPLEX16*)aligned_alloc(16, ((size_t)g_cap * 4 + 15) & ~(size_t)15); }
+    uint32_t ok = 0;
+    for (uint32_t r = 0; r < reps; r++)
+        for (uint32_t c = 0; c < ncap; c++) {
+            memcpy(g_buf, iq + (size_t)c * nsamples40 * 2, (size_t)nsamples40 * 4);
+            BB11aDemodCtx.Init(g_buf, nsamples40 * sizeof(COMPLEX16), g_out, sizeof(g_out));
+            if (!src) {
+                CreateDemodGraph11a_40M(src, vit, cs);
+                if (!vit) return 0xFFFFFFFFu;
+                vt.vit = vit; vt.stop = 0;
+                if (pthread_create(&viterbi, NULL, viterbi_thread, &vt) != 0) return 0xFFFFFFFEu;
+                started = 1;
+            } else src->Seek(ISource::START_POS);
+            src->Flush(); BB11aDemodCtx.Reset(); src->Reset();
+            uint nWaitCounter = 12;
+            for (;;) {
+                bool rc = src->Process();
+                ulong err = BB11aDemodCtx.CF_Error::error_code();
+                if (err != E_ERROR_SUCCESS) {
+                    if (err == E_ERROR_CS_TIMEOUT) {
+                        BB11aDemodCtx.ResetCarrierSense(); cs->Reset();
+                        if (nWaitCounter > 0) { nWaitCounter--; continue; }
+                        nWaitCounter = 12; continue;
+                    }
+                    ok += err == E_ERROR_FRAME_OK;
+                    src->Flush(); BB11aDemodCtx.Reset(); src->Reset();
+                }
+                if (!rc) break;
+            }
+        }
+    (void)started;
+    return ok;
+}
