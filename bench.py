@@ -460,6 +460,8 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
         cpu_ms = (time.perf_counter() - t0) / k * 1e3
         out["fsample6_single_capture"]["cpu_reference_decode_ms_one_core"] = round(cpu_ms, 4)
         out["fsample6_single_capture"]["cpu_reference_realtime_factor_one_core"] = round(cpu_ms / air_ms, 4)
+    if rx_batch is None:
+        return out
     # (b) the batch, one call in flight
     old_depth = rx_batch.set_depth(1); old_tr = rx_batch.set_trellis(-1); rx_batch.flush()
     req_us = 2 * FRAME_SAMPLES / 40.0
@@ -929,6 +931,75 @@ def bench_tx(torch, sora_amd, nframes=4096, reps=10):
             "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": round(alg / (ms * 1e-3) / HBM_PEAK, 4)}
 
 
+def bench_shard_shape(torch, sora_amd, dev, oracle, ncaps=32, nframes=16, reps=60):
+    """SURVEY section 8(d) config 5's per-GPU share (BASELINE configs[4]): 32 captures of 16 frames each (1500 bytes at 54 Mbps, the headline's frames back to back,
+    160 samples of silence between them) -- 512 frames per call, far too few to fill the chip with a frame per wave, and k_scan walks each capture's sixteen frames
+    one after the other.  One call in flight and eight, every call's rows checked against the compiled reference graph over the WHOLE capture (event for event,
+    MPDU bytes included); kernel times of a lone call; the HBM roofline with the headline's bytes per sample."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from gpu_util import same_as_reference_graph, same_results
+    from oracle.pyoracle import ReferenceGraph
+    iq, _, _ = make_workload(oracle, ncaps * nframes, seed0=5151)
+    caps = iq.reshape(ncaps, nframes * CAPTURE_SAMPLES, 2)
+    g = ReferenceGraph(); have_ref = g.available()
+    d_iq = torch.from_numpy(iq).to(dev)
+    descs = sora_amd.Rx.captures([(i * nframes * CAPTURE_SAMPLES, nframes * CAPTURE_SAMPLES, i) for i in range(ncaps)])
+    rx = sora_amd.Rx(max_captures=ncaps, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=nframes + 2)
+    out = {"workload": "%d captures x %d frames of %d bytes at 54 Mbps, %d samples @20 MHz per capture" % (ncaps, nframes, MPDU_LEN, nframes * CAPTURE_SAMPLES),
+           "frames_per_call": ncaps * nframes}
+    # parity gate: every capture, whole table
+    rx.set_depth(1)
+    res = rx.results(ticket=rx.process_dev(d_iq, descs))
+    ok = len(res) == ncaps * nframes; why = ""
+    for i in range(ncaps):
+        rows = [r for r in res if r["capture_id"] == i]
+        if have_ref:
+            o_, w_ = same_as_reference_graph(rows, g.rx11a(np.repeat(caps[i], 2, axis=0), max_frames=nframes + 4))
+        else:
+            want = [dict(r, capture_id=i) for r in oracle.rx_capture(caps[i], 20)]
+            o_, w_ = same_results(rows, want)
+        if not o_:
+            ok = False; why = why or "capture %d: %s" % (i, w_)
+    out["parity"] = {"against": "reference" if have_ref else "port", "captures_checked": ncaps, "frames": len(res), "frames_ok": sum(r["error_code"] == 1 for r in res), "ok": bool(ok), "why": why}
+    samples = ncaps * nframes * FRAME_SAMPLES
+    by = {}
+    for depth in (1, 8):
+        rx.set_depth(depth); rx.flush()
+        chains = "%s | %s" % ({1: "k_frame", 3: "k_sym_front+k_track_lds+k_sym_back"}[rx.front()], TRELLIS_NAMES[rx.trellis()])
+        for _ in range(depth + 2):
+            rx.process_dev(d_iq, descs)
+        rx.flush()
+        n = reps * depth
+        torch.cuda.synchronize(); t0 = time.perf_counter(); tickets = []
+        for _ in range(n):
+            tickets.append(rx.process_dev(d_iq, descs))
+            if len(tickets) >= depth:
+                rx.wait(tickets.pop(0))
+        for t in tickets:
+            rx.wait(t)
+        ms = (time.perf_counter() - t0) / n * 1e3
+        by["calls_in_flight_%d" % depth] = {"ms_per_call": round(ms, 4), "msamples_per_s": round(samples / ms / 1e3, 1), "kernels": chains + " (the library's choice)",
+                                            "hbm_frac": round(samples * ALG_BYTES_PER_SAMPLE / (ms * 1e-3) / HBM_PEAK, 5)}
+    rx.set_depth(1); rx.flush(); rx.set_profiling(True)
+    for _ in range(10):
+        rx.wait(rx.process_dev(d_iq, descs))
+    rx.flush(); out["kernel_ms_one_call_in_flight"] = {k: round(v, 4) for k, v in rx.kernel_times().items()}; rx.set_profiling(False)
+    # the round-4 kernels on the same shape, one call in flight, for the record
+    rx.set_front(1); rx.set_trellis(64); rx.flush()
+    for _ in range(3):
+        rx.wait(rx.process_dev(d_iq, descs))
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        rx.wait(rx.process_dev(d_iq, descs))
+    out["one_call_in_flight_round4_kernels_ms"] = round((time.perf_counter() - t0) / reps * 1e3, 4)
+    out["window_trellis_record"] = rx.window_stats()
+    rx.close()
+    out.update(by)
+    out["roofline"] = {"bound": "hbm", "algorithmic_bytes_per_call": int(samples * ALG_BYTES_PER_SAMPLE), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
+                       "achieved": round(samples * ALG_BYTES_PER_SAMPLE / (by["calls_in_flight_8"]["ms_per_call"] * 1e-3) / 1e9, 2), "frac": by["calls_in_flight_8"]["hbm_frac"]}
+    return out
+
+
 def reference_rows(iq, nfr, oracle):
     """What the reference reports for every capture of the workload: the compiled reference graph (oracle/_ref, fresh
     graph state per capture is not needed: a capture ends in silence and the graph resets after every frame) where it is
@@ -1039,7 +1110,7 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (read before HIP starts); 0 = leave the runtime default")
-    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11b_cck, rx11n, rx11n_40) and print its object: for profiling that section alone")
+    ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11b_cck, rx11n, rx11n_40, shard_32x16, latency) and print its object: for profiling that section alone")
     args = ap.parse_args()
 
     import torch
@@ -1060,7 +1131,8 @@ def main():
         sections = {"stages": lambda: bench_stages(torch, sora_amd, dev), "ingest": lambda: bench_ingest(torch, sora_amd, dev), "tx": lambda: bench_tx(torch, sora_amd),
                     "rx11b": lambda: bench_11b(torch, sora_amd, dev), "rx11b_cck": lambda: bench_11b(torch, sora_amd, dev, cpu=False, rate_kbps=11000),
                     "rx11n": lambda: bench_11n(torch, sora_amd, dev),
-                    "rx11n_40": lambda: bench_ht40(torch, sora_amd, dev)}
+                    "rx11n_40": lambda: bench_ht40(torch, sora_amd, dev), "shard_32x16": lambda: bench_shard_shape(torch, sora_amd, dev, Oracle()),
+                    "latency": lambda: bench_latency(torch, sora_amd, dev, None, None, None, 0)}
         print(json.dumps({args.only: sections[args.only]()}))
         return
     oracle = Oracle()
@@ -1341,6 +1413,7 @@ def main():
             out["rx11b_cck"] = bench_11b(torch, sora_amd, dev, cpu=False, rate_kbps=11000)
             out["rx11n"] = bench_11n(torch, sora_amd, dev)
             out["rx11n_40"] = bench_ht40(torch, sora_amd, dev)
+            out["shard_32x16"] = bench_shard_shape(torch, sora_amd, dev, oracle)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(iq, nfr)
             out["realtime"]["cpu_reference_factor_one_core"] = round(20.0 / out["cpu_baseline"]["single_core_value"], 4) if out["cpu_baseline"].get("single_core_value") else None
