@@ -97,7 +97,17 @@ cp "$HERE/ref_legacy_rxstream.h" "$TMP/flat_legacy/ref_legacy_rxstream.h"
     -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -DSTATIC_LUT -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" -include "$HERE/ref_legacy_pre.h" \
     -I"$TMP/flat_legacy" -I"$TMP/flat_legacy/bb" -I"$TMP/flat_legacy/inc" "$HERE/ref_legacy_shim.cpp" -o "$OUT/libsora_reflegacy.so" &
 PID_LEGACY=$!
+# ---- the 11a receive graph with HIP bricks plugged into it through the reference's own CREATE_BRICK_FILTER (oracle/ref_graph_hip_shim.cpp; the product's entry points
+#      are bound at run time, nothing of it is linked); the generated substitution list is kept beside the library for INTEGRATION.md / the test to quote
+python3 "$HERE/ref_flatten.py" "$TMP/flat_hip" hip
+"$CXX" -std=c++14 -O2 -U__OPTIMIZE__ -fPIC -shared -fvisibility=hidden \
+    -fms-extensions -fms-compatibility -fms-compatibility-version=19.00 -fdelayed-template-parsing -fno-operator-names \
+    -msse4.1 -mssse3 -Wno-everything -DUSER_MODE -D__XSAVEINTRIN_H -include "$HERE/ref_compat.h" \
+    -I"$TMP/flat_hip" -I"$HERE" "$HERE/ref_graph_hip_shim.cpp" -o "$OUT/libsora_refgraph_hip.so" &
+PID_HIP=$!
+cp "$TMP/flat_hip/fb11ademod_config_hip.diff" "$OUT/fb11ademod_config_hip.diff"
 wait $PID_KERNELS; echo "build_ref.sh: built $OUT/libsora_ref.so"          # the three compiles run side by side; set -e stops on the first failure
 wait $PID_GRAPH;   echo "build_ref.sh: built $OUT/libsora_refgraph.so"
 wait $PID_MT;      echo "build_ref.sh: built $OUT/libsora_refgraph_mt.so"
 wait $PID_LEGACY;  echo "build_ref.sh: built $OUT/libsora_reflegacy.so"
+wait $PID_HIP;     echo "build_ref.sh: built $OUT/libsora_refgraph_hip.so"

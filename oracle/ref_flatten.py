@@ -17,6 +17,7 @@ REF = os.environ.get("SORA_REFERENCE", "/root/reference") + "/kernel"
 OUT = sys.argv[1]
 KEEP_SEPARATOR_11A = len(sys.argv) > 2 and sys.argv[2] == "mt"     # libsora_refgraph_mt.so: the 11a graph with its real thread boundary
 LEGACY = len(sys.argv) > 2 and sys.argv[2] == "legacy"            # libsora_reflegacy.so: the legacy dot11a C receiver (kernel/bb/dot11a), SURVEY section 8 f4
+HIPBRICKS = len(sys.argv) > 2 and sys.argv[2] == "hip"            # libsora_refgraph_hip.so: the reference's 11a receive graph with HIP bricks plugged into it (oracle/ref_graph_hip_shim.cpp)
 
 shutil.rmtree(OUT, ignore_errors=True)
 os.makedirs(OUT + "/bb")
@@ -126,6 +127,34 @@ edit("pinqueue.h", lambda s: s.replace("[nstream][qsize]", "[NSTREAM][lcm<N,M>::
 #      infinitely fast ViterbiThread -- which is also what oracle/so_rx11a.c and the GPU path implement.
 if not KEEP_SEPARATOR_11A:
     edit("fb11ademod_config.hpp", lambda s: s.replace("TThreadSeparator<>::Filter", "TNoInline").replace("srcViterbi = vit0;", "srcViterbi = NULL;"))
+if HIPBRICKS:
+    # The drop-in, as a maintainer would make it: copies of the reference's own CreateDemodGraph11a_40M in which only the brick NAMES on
+    # three kinds of CREATE_BRICK_FILTER lines change.  Generated here from the reference's text -- nothing of it is kept in this repository.
+    cfg = open(OUT + "/fb11ademod_config.hpp", encoding="latin-1").read()
+    m = re.search(r"static inline\s*\nvoid CreateDemodGraph11a_40M \(.*?\n\}\n", cfg, flags=re.S)
+    if not m:
+        raise SystemExit("ref_flatten.py: CreateDemodGraph11a_40M not found (reference layout changed?)")
+    body = m.group(0)
+    def variant(name, subs):
+        t = body.replace("CreateDemodGraph11a_40M", name)
+        for a, b in subs:
+            if a not in t:
+                raise SystemExit("ref_flatten.py: '%s' not in CreateDemodGraph11a_40M (reference layout changed?)" % a)
+            t = t.replace(a, b)
+        return t
+    fft = [("TFFT64, BB11aDemodCtx", "THipFFT64, BB11aDemodCtx")]
+    dmd = [("T11aDemapBPSK::Filter", "THip11aDemap<1>::Filter"), ("T11aDemapQPSK::Filter", "THip11aDemap<2>::Filter"), ("T11aDemapQAM16::Filter", "THip11aDemap<4>::Filter"),
+           ("T11aDemapQAM64::Filter", "THip11aDemap<6>::Filter"),
+           ("T11aDeinterleaveBPSK, BB11aDemodCtx", "THip11aDeinterleave<1>::Filter, BB11aDemodCtx"), ("T11aDeinterleaveQPSK, BB11aDemodCtx", "THip11aDeinterleave<2>::Filter, BB11aDemodCtx"),
+           ("T11aDeinterleaveQAM16, BB11aDemodCtx", "THip11aDeinterleave<4>::Filter, BB11aDemodCtx"), ("T11aDeinterleaveQAM64, BB11aDemodCtx", "THip11aDeinterleave<6>::Filter, BB11aDemodCtx")]
+    write("fb11ademod_config_hip.hpp", "#pragma once\n" + variant("CreateDemodGraph11a_40M_HipFFT", fft) + "\n" + variant("CreateDemodGraph11a_40M_HipFFTDemapDeint", fft + dmd))
+    diff = ["--- kernel/bb/demod11/fb11ademod_config.hpp (CreateDemodGraph11a_40M)", "+++ the same with HIP bricks"]
+    for a, b in fft + dmd:
+        for line in body.split("\n"):
+            if a in line:
+                diff += ["-" + line.strip(), "+" + line.strip().replace(a, b)]
+    write("fb11ademod_config_hip.diff", "\n".join(diff) + "\n")
+
 # ---- mapper11a.hpp: an array bound that this clang's declaration/expression disambiguation trips over (same value)
 edit("mapper11a.hpp", lambda s: s.replace("(&lut)[intpow<2, LUT_BITS>::value][LUT_BITS/M/2]", "(&lut)[(1 << LUT_BITS)][LUT_BITS/M/2]"))
 

@@ -10,6 +10,9 @@
 #include "fb11ademod_config.hpp"
 
 #define EXPORT extern "C" __attribute__((visibility("default")))
+#ifndef REF_CREATE_40M                                // (oracle/ref_graph_hip_shim.cpp includes this file with its own graph builder)
+#define REF_CREATE_40M CreateDemodGraph11a_40M
+#endif
 
 struct ref_frame { uint32_t error_code, sample_index, rate_kbps, length, crc32, mpdu_offset; };
 
@@ -27,7 +30,7 @@ static int rx11a_run(int mhz, const int16_t* iq, uint32_t nsamples40, ref_frame*
     if (g_cap < nsamples40 + 64) { free(g_buf); g_cap = nsamples40 + 64; g_buf = (COMPLEX16*)aligned_alloc(16, ((size_t)g_cap * 4 + 15) & ~(size_t)15); }
     memcpy(g_buf, iq, (size_t)nsamples40 * 4);
     BB11aDemodCtx.Init(g_buf, nsamples40 * sizeof(COMPLEX16), g_out, sizeof(g_out));
-    if (!g_src) { if (mhz == 44) CreateDemodGraph11a_44M(g_src, g_vit, g_cs); else CreateDemodGraph11a_40M(g_src, g_vit, g_cs); }
+    if (!g_src) { if (mhz == 44) CreateDemodGraph11a_44M(g_src, g_vit, g_cs); else REF_CREATE_40M(g_src, g_vit, g_cs); }
     else g_src->Seek(ISource::START_POS);             // the graph is built once; rewind the memory source
     g_src->Flush(); BB11aDemodCtx.Reset(); g_src->Reset();
     int n = 0; uint32_t used = 0; uint nWaitCounter = 12;
