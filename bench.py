@@ -1098,7 +1098,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--headline-only", action="store_true", help="stop after the timed region and print its step time only (kernel-trace runs: tools/trace_timeline.sh)")
     ap.add_argument("--wait-oldest", action="store_true", help="the host waits for its OLDEST ticket (round-3 loop) instead of taking completions as they come (sora_rx_wait_any)")
-    ap.add_argument("--extra-launches", type=int, default=0, help="experiment: empty kernel launches appended to every call (tool hook sora_internal_rx_extra)")
+    ap.add_argument("--extra-launches", type=int, default=0, help="experiment: empty kernel launches appended to every call (tool hook sora_internal_rx_extra: needs the TOOLS variant of the library, SORA_HIP_LIB=sora_amd/lib/variants/tools.so from sora_amd.build.build_variant('tools', ['SORA_TOOLS']))")
     ap.add_argument("--no-plain", action="store_true", help="skip the plain_host section (experiments)")
     ap.add_argument("--frames", type=int, default=FRAMES_PER_GPU, help="captures per GPU (default: the BASELINE config; "
                     "--gpus 8 --frames 32 is BASELINE configs[4] literally: 256 captures over 8 GPUs)")

@@ -25,6 +25,9 @@
 #ifdef __cplusplus
 extern "C" {
 #endif
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility push(default)     /* libsora_hip.so is built with -fvisibility=hidden: what this header declares is what it exports */
+#endif
 
 /* 3 (round 5).  Against 2: (i) behaviour that round 4 changed under the old number: a call that has been delivered (sora_rx_deliver_async) AND waited for
  * (sora_rx_wait / _wait_any; the same for the rx11b / rx11n / ht40 handles) is RELEASED -- its pipeline is the first to be reused, so its ticket is valid for `depth`
@@ -572,6 +575,9 @@ int   sora_hip_stream_synchronize(void* stream);
 int   sora_hip_abi_version(void);
 const char* sora_hip_last_error(void);
 
+#if defined(__GNUC__) || defined(__clang__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

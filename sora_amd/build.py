@@ -17,7 +17,7 @@ SOURCES = ["k_scan.hip", "k_rx.hip", "k_vit16.hip", "k_vitwin.hip", "k_stage.hip
 # compiles it in (the entry point answers SORA_E_NOT_SUPPORTED otherwise).
 VARIANT_SOURCES = {"SORA_WITH_K_DECODE": ["k_decode.hip"]}
 HEADERS = ["dev_arith.h", "dev_viterbi.h", "dev_vit16.h", "dev_winplan.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-x", "hip"]
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip"]   # hidden: the library exports what include/sora_hip.h declares, nothing else
 
 
 def hipcc():
@@ -99,6 +99,8 @@ def build_variant(name, defines):
     run any entry point with SORA_HIP_LIB=<that file>)."""
     out_dir = os.path.join(HERE, "lib", "variants"); os.makedirs(out_dir, exist_ok=True)
     out = os.path.join(out_dir, name + ".so")
+    if any(d.startswith(("SORA_EXP_", "SORA_DBG_", "SORA_SCAN_PROBE")) for d in defines) and "SORA_TOOLS" not in defines:
+        defines = list(defines) + ["SORA_TOOLS"]                                  # every experiment / probe switch lives in the tools variant only (kernels.h refuses otherwise)
     extra = [f for d in defines for f in VARIANT_SOURCES.get(d.split("=")[0], [])]
     cmd = [hipcc()] + FLAGS + ["-shared", "-w"] + ["-D" + d for d in defines] + [os.path.join(CSRC, f) for f in SOURCES + extra] + ["-ldl", "-o", out]
     subprocess.check_call(cmd)

@@ -446,6 +446,15 @@ struct RxPipe {
 };
 
 constexpr uint32_t kWinUnitsTarget = 16384;                     // units a call of the window-parallel trellis is cut into at least, frames permitting: one round of the chip's 2048 eight-unit trellis slots
+// Probe hooks (which kernels of the chain a call launches, empty launches appended to a call, the calls' kernel boundaries on one time base, the device arrays between the
+// kernels) exist in the TOOLS variant of the library only -- sora_amd.build.build_variant("tools", ["SORA_TOOLS"]), loaded by the scripts under tools/ through SORA_HIP_LIB.
+// The product build has neither the entry points nor the branches they steer.
+#ifdef SORA_TOOLS
+#define RX_ONLY(rx, bit) (((rx)->only & (bit)) != 0u)
+#define SORA_TOOL_HOOK __attribute__((visibility("default")))
+#else
+#define RX_ONLY(rx, bit) true
+#endif
 static constexpr size_t kNumTimed = 5;
 static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k_frame", "k_viterbi", "k_finish" };
 static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
@@ -469,10 +478,12 @@ static int fold_profile(RxPipe* rx)
     if (!rx->ev_valid) return SORA_OK;
     HIPCHK(hipEventSynchronize(rx->ev[kNumTimed]));
     for (size_t i = 0; i < kNumTimed; i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, rx->ev[i], rx->ev[i + 1])); rx->t_sum[i] += t; }
+#ifdef SORA_TOOLS
     if (rx->tl && rx->tl_base && *rx->tl_base && rx->tl->size() < (size_t)(1u << 22)) {
         rx->tl->push_back((float)rx->index);
         for (size_t i = 0; i <= kNumTimed; i++) { float t = 0.f; HIPCHK(hipEventElapsedTime(&t, *rx->tl_base, rx->ev[i])); rx->tl->push_back(t); }
     }
+#endif
     rx->t_calls++; rx->ev_valid = false;
     return SORA_OK;
 }
@@ -699,7 +710,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
 
     auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
-        if (rx->only & 1u) {
+        if (RX_ONLY(rx, 1u)) {
         // the job counters and the frame table behind them: ONE fill (every packet of a call costs the command processor a few microseconds, and a call is a dozen
         // of them: DESIGN.md section 3.6) -- by a kernel of this library: a hipMemsetAsync of 64 + 64 n bytes recorded into a hipGraph faults on replay
         {
@@ -716,7 +727,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
         S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = split ? rx->d_slot_row : nullptr; S.cont = rx->cont; S.consumed = rx->consumed;
         mark();
-        if (rx->only & 1u) hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
+        if (RX_ONLY(rx, 1u)) hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
         RxArgs R{};
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
@@ -736,7 +747,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                 // The symbol chain as three kernels (k_rx.hip): per symbol slot in front of and behind the tracker, per frame (four lanes each) for the tracker.  Round 4 built it
                 // (k_track, tables in L2) and did not adopt it: no faster than k_frame for a full batch (profiles/r04_h_*).  Round 5: the tracker with its tables in LDS
                 // (k_track_lds) makes it the chain for FEW frames in flight, where k_frame's one wave per frame is a 465-symbol serial loop (fsample-6).
-                if (rx->only & 2u) {
+                if (RX_ONLY(rx, 2u)) {
                     hipLaunchKernelGGL(k_sym_front, dim3((slots + 63) / 64), dim3(256), 0, st, R);
 #ifdef SORA_FRAME_SPLIT3
                     hipLaunchKernelGGL(k_track, dim3((nrows + 63) / 64), dim3(256), 0, st, R);
@@ -745,9 +756,9 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 #endif
                     hipLaunchKernelGGL(k_sym_back, dim3((slots + 63) / 64), dim3(256), 0, st, R);
                 }
-            } else if (rx->only & 2u) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+            } else if (RX_ONLY(rx, 2u)) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
-            if (!(rx->only & 4u)) {}
+            if (!RX_ONLY(rx, 4u)) {}
             else if (rx->lanes16 == 2) {
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), the proof, and
                 // the serial kernel over the frames whose proof failed (none, normally: its workgroups find empty lists and return)
@@ -764,8 +775,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                 hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
         }
-        if (rx->only & 8u) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+        if (RX_ONLY(rx, 8u)) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+#ifdef SORA_TOOLS
         for (unsigned x = 0; x < rx->extra; x++) hipLaunchKernelGGL(k_clear16, dim3(1), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), 0u);
+#endif
         mark();
         return SORA_OK;
     };
@@ -1216,9 +1229,10 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     return rc;
 }
 
+#ifdef SORA_TOOLS
 // Test / tool hook (not part of the ABI in include/sora_hip.h): the device arrays between the kernels of the most recent call, for
 // stage-by-stage comparisons (tools/dbg_arrays.py).  out[] = { frames, slot_row, eq, track, soft, jobs, joblist, njobs }; *slots = symbol slots of the call.
-int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, uint32_t* nrows)
+SORA_TOOL_HOOK int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, uint32_t* nrows)
 {
     if (!rx || !out) return SORA_ERR_INVALID_PARAM;
     RxPipe* p = rx->pipes[rx->cur];
@@ -1231,7 +1245,7 @@ int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, ui
 
 // Test / tool hook (not part of the ABI in include/sora_hip.h): the next calls launch only the kernels in `mask` (1 k_scan + its memsets, 2 k_frame, 4 the trellis
 // kernel, 8 k_finish) and leave the other stages' arrays as the last full call wrote them -- to time one kernel against another (tools/r04_corun.py).
-int sora_internal_rx_only(sora_rx_t* rx, unsigned mask)
+SORA_TOOL_HOOK int sora_internal_rx_only(sora_rx_t* rx, unsigned mask)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     for (int i = 0; i < sora_rx::kMaxDepth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->only = mask & 0xFu; p->last_valid = false; } if (i + 1 >= rx->depth) break; }
@@ -1239,7 +1253,7 @@ int sora_internal_rx_only(sora_rx_t* rx, unsigned mask)
 }
 
 // Test / tool hook: `n` empty kernel launches behind every call's k_finish (tools/r04_packet_cost.sh).
-int sora_internal_rx_extra(sora_rx_t* rx, unsigned n)
+SORA_TOOL_HOOK int sora_internal_rx_extra(sora_rx_t* rx, unsigned n)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     for (int i = 0; i < rx->depth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->extra = n; p->last_valid = false; } }
@@ -1249,7 +1263,7 @@ int sora_internal_rx_extra(sora_rx_t* rx, unsigned n)
 // Test / tool hook (not part of the ABI in include/sora_hip.h): a timeline of the profiled calls without a profiler attached.  start = 1 records the
 // time base (on the first pipeline's stream) and clears the log; every call processed under sora_rx_set_profiling(1) then leaves 1 + 6 floats:
 // its pipeline and the boundaries of memset+caps | k_scan | k_frame | trellis | k_finish in ms since the base.  start = 0 copies the log out.
-int sora_internal_rx_timeline(sora_rx_t* rx, int start, float* out, size_t cap, size_t* nout)
+SORA_TOOL_HOOK int sora_internal_rx_timeline(sora_rx_t* rx, int start, float* out, size_t cap, size_t* nout)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     HIPCHK(hipSetDevice(rx->cfg.device));
@@ -1268,6 +1282,8 @@ int sora_internal_rx_timeline(sora_rx_t* rx, int start, float* out, size_t cap, 
     memcpy(out, rx->tl.data(), *nout * sizeof(float));
     return SORA_OK;
 }
+
+#endif  // SORA_TOOLS
 
 int sora_rx_results(sora_rx_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap)
 {

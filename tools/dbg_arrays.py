@@ -1,5 +1,14 @@
 """dbg_arrays.py [out.npz] -- on the GPU box: run fsample-6 through the library named by SORA_HIP_LIB (or the default) and dump the arrays
 between the kernels of the call (sora_internal_rx_arrays).  Run once per build variant and compare the files (tools/dbg_compare.py)."""
+
+# (round 5) the probe hooks live in the TOOLS variant of the library only: build it once and load it
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+if not _os.environ.get("SORA_HIP_LIB"):
+    from sora_amd import build as _b
+    _v = _os.path.join(_os.path.dirname(_b.LIB), "variants", "tools.so")
+    _os.environ["SORA_HIP_LIB"] = _v if _os.path.exists(_v) else _b.build_variant("tools", ["SORA_TOOLS"])
+
 import ctypes, os, sys
 import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -1,5 +1,14 @@
 #!/usr/bin/env python3
-"""r04_corun.py -- on the GPU box: how much does each front-end kernel slow the trellis kernel down when both are on the chip?  Two handles of 16384 captures
+"""
+
+# (round 5) the probe hooks live in the TOOLS variant of the library only: build it once and load it
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+if not _os.environ.get("SORA_HIP_LIB"):
+    from sora_amd import build as _b
+    _v = _os.path.join(_os.path.dirname(_b.LIB), "variants", "tools.so")
+    _os.environ["SORA_HIP_LIB"] = _v if _os.path.exists(_v) else _b.build_variant("tools", ["SORA_TOOLS"])
+r04_corun.py -- on the GPU box: how much does each front-end kernel slow the trellis kernel down when both are on the chip?  Two handles of 16384 captures
 each, one call in flight each, two host threads: handle T launches ONLY the trellis kernel (the chip's trellis slots full: 2048 waves), handle F launches only
 k_scan, only k_frame or only k_finish, back to back (tool hook sora_internal_rx_only; the skipped stages' arrays stay as a full call left them).
 Prints the mean duration of T's launches alone and beside each F, and F's beside T."""

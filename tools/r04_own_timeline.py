@@ -1,5 +1,14 @@
 #!/usr/bin/env python3
-"""r04_own_timeline.py [--frames F] [--depth D] [--calls N] -- on the GPU box: the headline loop's kernel timeline WITHOUT a profiler attached
+"""
+
+# (round 5) the probe hooks live in the TOOLS variant of the library only: build it once and load it
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+if not _os.environ.get("SORA_HIP_LIB"):
+    from sora_amd import build as _b
+    _v = _os.path.join(_os.path.dirname(_b.LIB), "variants", "tools.so")
+    _os.environ["SORA_HIP_LIB"] = _v if _os.path.exists(_v) else _b.build_variant("tools", ["SORA_TOOLS"])
+r04_own_timeline.py [--frames F] [--depth D] [--calls N] -- on the GPU box: the headline loop's kernel timeline WITHOUT a profiler attached
 (rocprofv3's kernel trace makes the host the bottleneck at eight calls in flight: 0.62 instead of 0.40 ms per step).  The library's own HIP events
 (sora_rx_set_profiling) are read against one time base (tool hook sora_internal_rx_timeline).  Prints, for the steady state: the step period, how many
 launches of each kernel run at once (time-weighted), the share of time no trellis / no front-end kernel is running, and the gaps inside a pipeline."""

@@ -1,5 +1,14 @@
 #!/usr/bin/env python3
-"""r04_trellis_only.py -- on the GPU box: the trellis kernel's own throughput by launch size and by launches in flight.  One handle, calls that launch ONLY
+"""
+
+# (round 5) the probe hooks live in the TOOLS variant of the library only: build it once and load it
+import os as _os, sys as _sys
+_sys.path.insert(0, _os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))))
+if not _os.environ.get("SORA_HIP_LIB"):
+    from sora_amd import build as _b
+    _v = _os.path.join(_os.path.dirname(_b.LIB), "variants", "tools.so")
+    _os.environ["SORA_HIP_LIB"] = _v if _os.path.exists(_v) else _b.build_variant("tools", ["SORA_TOOLS"])
+r04_trellis_only.py -- on the GPU box: the trellis kernel's own throughput by launch size and by launches in flight.  One handle, calls that launch ONLY
 k_viterbi16 (tool hook sora_internal_rx_only; the earlier stages' arrays are those of one full call), `depth` calls in flight on the handle's pipelines.
 Prints ms per 4096 captures.  (profiles/r04_w_corun.txt: two launches of 1024 waves side by side finish sooner than one of 2048.)"""
 import ctypes, os, sys, time
