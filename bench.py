@@ -65,31 +65,45 @@ CAPTURE_SAMPLES = 5040     # + 160 silence; 360 source bursts of 14
 ALG_BYTES_PER_SAMPLE = 4.0 + 216 / 8.0 / 80.0     # 4.3375
 HBM_PEAK = 8.0e12
 PROFILES = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-TRAFFIC_JSON = os.path.join(PROFILES, "r04_final_traffic.json")          # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh): replayed, not measured by this run
-if not os.path.exists(TRAFFIC_JSON):
-    TRAFFIC_JSON = os.path.join(PROFILES, "r03_final_traffic.json")
+TRAFFIC_JSON = os.path.join(PROFILES, "r05_final_traffic.json")          # rocprofv3 --pmc passes of this command (tools/collect_profiles.sh): replayed, not measured by this run
 VALU_PEAK_JSON = os.path.join(PROFILES, "r04_valu_peak.json")          # tools/calib/valu_peak.hip on one MI355X: what the chip sustains per instruction kind
+
+
+def _traffic_profile():
+    """The committed PMC summary, or (None, why).  It is replayed into the bench line only while it belongs to THIS tree: tools/summarize_pmc.py stamps it with the
+    hash of every source and header the library is built from (sora_amd.build.sources_sha256), and a summary whose stamp is missing or differs is refused."""
+    try:
+        with open(TRAFFIC_JSON) as f:
+            t = json.load(f)
+    except (OSError, ValueError) as e:
+        return None, "no PMC summary (%s)" % e.__class__.__name__
+    try:
+        from sora_amd import build as _b
+        now = _b.sources_sha256()
+    except Exception as e:
+        return None, "sources hash unavailable (%r)" % e
+    if t.get("sources_sha256") != now:
+        return None, "stale: %s was collected for sources %s, this tree is %s" % (os.path.basename(TRAFFIC_JSON), str(t.get("sources_sha256"))[:16], now[:16])
+    if t.get("frames_per_launch") != FRAMES_PER_GPU:
+        return None, "collected for %s frames per launch" % t.get("frames_per_launch")
+    return t, "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE / SQ_INSTS in separate passes, corrected as tools/summarize_pmc.py documents; replayed, not measured by this run; sources stamp matches)" % os.path.basename(TRAFFIC_JSON)
 
 
 def measured_traffic(kernel):
     """HBM bytes per launch of `kernel` from the committed PMC summary (FETCH_SIZE x2 + WRITE_SIZE, see the file), or None."""
+    t, _ = _traffic_profile()
     try:
-        with open(TRAFFIC_JSON) as f:
-            t = json.load(f)
-        return t["kernels"][kernel]["hbm_bytes"] if t.get("frames_per_launch") == FRAMES_PER_GPU else None
-    except (OSError, KeyError, ValueError):
+        return t["kernels"][kernel]["hbm_bytes"] if t else None
+    except KeyError:
         return None
 
 
 def measured_valu(kernel=None):
     """Wave-level VALU instructions per launch (SQ_INSTS_VALU, same PMC summary): of `kernel`, or of the whole call."""
+    t, _ = _traffic_profile()
     try:
-        with open(TRAFFIC_JSON) as f:
-            t = json.load(f)
-        if t.get("frames_per_launch") != FRAMES_PER_GPU:
-            return None
-        return t["kernels"][kernel]["valu_insts"] if kernel else t["total_valu_insts_per_call"]
-    except (OSError, KeyError, ValueError):
+        return None if not t else t["kernels"][kernel]["valu_insts"] if kernel else t["total_valu_insts_per_call"]
+    except KeyError:
         return None
 
 
@@ -1383,7 +1397,7 @@ def main():
                          "call_latency_ms_one_in_flight": round(sum(v for k, v in ktimes1.items()), 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach1 / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
                          "frac": round(ach1 / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
-                         "traffic_source": "profiles/%s (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, corrected as tools/summarize_pmc.py documents; replayed, not measured by this run)" % os.path.basename(TRAFFIC_JSON),
+                         "traffic_source": _traffic_profile()[1],
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes1[dom], 4),
                          "kernel_ms_note": "mean launch duration with ONE call in flight (the kernel alone on the chip); with %d calls overlapped the same launch lasts %.4f ms (frac %.5f) because it shares the CUs" % (depth, ktimes[dom], ach / HBM_PEAK),
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),

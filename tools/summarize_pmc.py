@@ -61,6 +61,13 @@ def main():
             if k in rx_path:
                 tv += valu.get(k, (0.0, 0))[0]
         out["total_valu_insts_per_call"] = round(tv)
+    try:                                                                      # the tree these counters belong to: bench.py refuses to replay them beside other sources
+        import os
+        sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+        from sora_amd import build as _b
+        out["sources_sha256"] = _b.sources_sha256()
+    except Exception as e:
+        out["sources_sha256"] = None; out["sources_sha256_error"] = repr(e)
     out["receive_call_sums"] = list(rx_path)
     out["total_hbm_bytes_per_call"] = round(total)
     out["algorithmic_bytes_per_call"] = round(frames * 4880 * 4.3375)
