@@ -75,37 +75,32 @@ struct Tables {
 };
 
 // The three trigonometric tables of the pilot tracker's chain, small enough for one workgroup's LDS (round 5).  usin / ucos (65536 entries each) are a quarter
-// wave plus one bit per entry: the reference's generator used pi = 3.141593, so its tables are not exactly symmetric -- 481 / 474 entries differ by one from the
-// mirrored quarter wave, always in the direction their quadrant fixes -- and uatan2 (256 x 256) is odd in y for every y but -128: rows 0 .. 127 and the negated
-// row -128.  The host builds these from the full tables and checks that they reproduce every entry before it uploads them (sora_hip.cpp).
+// wave plus a two-bit signed correction per entry: the reference's generator used pi = 3.141593, so its tables are not exactly symmetric -- 481 / 474 entries differ
+// by one from the mirrored quarter wave -- and uatan2 (256 x 256) is odd in y for every y but -128: rows 0 .. 127 and the negated row -128.  The host builds these
+// from the full tables and checks that they reproduce EVERY entry before it uploads them (sora_hip.cpp: trk_tables_exact).
 struct TrkTables {
     int16_t  q[16392];           // usin[0 .. 16384] (padded to a multiple of 16 bytes)
-    uint32_t exs[2048];          // bit i: usin[i] is one off the mirrored quarter wave: -1 in quadrants 1 and 2, +1 in quadrant 3 (none in quadrant 0)
-    uint32_t exc[2048];          // bit i: ucos[i] is one off sin(i + 16384) mirrored: -1 in quadrants 0 and 1, +1 in quadrants 2 and 3
+    uint32_t e2s[4096];          // two bits per angle a, at bit 2 (a & 15) of word a >> 4: usin[a] minus the mirrored quarter wave, as a signed two-bit number (0, +1, -1)
+    uint32_t e2c[4096];          // the same for ucos[a] against the quarter wave mirrored for a + 16384
     int16_t  h[129 * 256];       // uatan2[y][x & 0xFF] for y = 0 .. 127; row 128 = -uatan2[-128][..]: uatan2(y < 0, x) = -h[-y][x & 0xFF]
 };
-// (index arithmetic shared by the host's check and the kernel)
-__host__ __device__ inline int trk_quarter_index(unsigned a) { const unsigned q = a & 0x3FFFu; return (int)(((a >> 14) & 1u) ? 16384u - q : q); }
+// (index arithmetic shared by the host's check and the kernel) the quarter-wave index of angle a: q in even quadrants, 16384 - q in odd ones, q = a & 0x3FFF
+__host__ __device__ inline int trk_quarter_index(unsigned a) { const int m = -(int)((a >> 14) & 1u); return (int)((((int)a ^ m) & 0x3FFF) - m); }
+__host__ __device__ inline int trk_sext2(uint32_t word, unsigned a) { return ((int)(word << (30u - 2u * (a & 15u)))) >> 30; }
 template <typename TBL> __host__ __device__ inline int trk_usin(const TBL& t, unsigned a)     // usin[a], a = FP_RAD angle & 0xFFFF
 {
-    const unsigned quad = a >> 14;
-    int v = t.q[trk_quarter_index(a)];
-    if (quad & 2u) v = -v;
-    if ((t.exs[a >> 5] >> (a & 31u)) & 1u) v += quad == 3u ? 1 : -1;
-    return v;
+    const int ms = -(int)((a >> 15) & 1u);
+    return ((t.q[trk_quarter_index(a)] ^ ms) - ms) + trk_sext2(t.e2s[a >> 4], a);
 }
 template <typename TBL> __host__ __device__ inline int trk_ucos(const TBL& t, unsigned a)     // ucos[a]
 {
-    const unsigned b = (a + 16384u) & 0xFFFFu, quad = a >> 14;
-    int v = t.q[trk_quarter_index(b)];
-    if ((b >> 14) & 2u) v = -v;
-    if ((t.exc[a >> 5] >> (a & 31u)) & 1u) v += quad >= 2u ? 1 : -1;
-    return v;
+    const int mc = -(int)(((a >> 15) ^ (a >> 14)) & 1u);
+    return ((t.q[16384 - trk_quarter_index(a)] ^ mc) - mc) + trk_sext2(t.e2c[a >> 4], a);
 }
 template <typename TBL> __host__ __device__ inline int trk_uatan2_entry(const TBL& t, int ys, int xs)   // uatan2_lut[(ys & 0xFF) * 256 + (xs & 0xFF)], ys in -128 .. 127
 {
-    const int r = ys < 0 ? -ys : ys, v = t.h[r * 256 + (xs & 0xFF)];
-    return ys < 0 ? -v : v;
+    const int sy = ys >> 31, r = (ys ^ sy) - sy, v = t.h[r * 256 + (xs & 0xFF)];
+    return (v ^ sy) - sy;
 }
 
 // uatan2 (core/inc/intalg.h:100-113): highest set bit of |y|,|x| -> common shift -> 256x256 LUT

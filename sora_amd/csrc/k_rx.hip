@@ -358,15 +358,26 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
 
 // Round 5: the same chain with its three tables in LDS -- the tracker for FEW frames in flight (a single capture: fsample-6's 465 symbols).
 // k_track's step is two dependent L2 gathers long (rot[] is 256 KB, uatan2[] 128 KB: 0.7 us per symbol); here a workgroup first copies the folded tables
-// (dev_arith.h TrkTables, 113 KB: quarter-wave sine + exception bits, uatan2 for y >= 0) into its LDS and the step is two LDS reads and ~25 dependent vector
-// instructions.  One workgroup serves up to 64 frames (four lanes each); the tables are exact by the host's exhaustive check (sora_hip.cpp: trk_tables_exact).
+// (dev_arith.h TrkTables, 129 KB: quarter-wave sine + two-bit corrections, uatan2 for y >= 0) into its LDS, and the step is three LDS reads deep.  One wave is
+// alone on its SIMD, so the step costs what its instructions cost to ISSUE (~5 cycles each): the loop is written for few instructions, not for few dependent ones --
+// no exec-mask juggling (frames shorter than the wave's longest keep stepping on clamped reads and write nothing), the pilot polarity a scalar, the state wrapped
+// only where a product needs it, the two divisions by 28 as float products (exact for every difference of two 16-bit angles: tests/test_track_division.py).
+// One workgroup serves up to 64 frames (four lanes each); the tables are exact by the host's exhaustive check (sora_hip.cpp: trk_tables_exact).
 __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
 {
     __shared__ TrkTables s_t;
     {
+        // 129 KB from L2 / HBM: eleven 16-byte loads per thread in flight at a time (a loop that waits for every load costs a memory latency per 4 KB: 33 of them)
         const uint4* src = reinterpret_cast<const uint4*>(A.T.trk);
         uint4* dst = reinterpret_cast<uint4*>(&s_t);
-        for (uint32_t i = threadIdx.x; i < sizeof(TrkTables) / 16; i += 256) dst[i] = src[i];
+        constexpr uint32_t kWords = sizeof(TrkTables) / 16, kBatch = 11;
+        for (uint32_t i0 = threadIdx.x; i0 < kWords; i0 += 256u * kBatch) {
+            uint4 v[kBatch];
+#pragma unroll
+            for (uint32_t b = 0; b < kBatch; b++) v[b] = src[min(i0 + 256u * b, kWords - 1u)];
+#pragma unroll
+            for (uint32_t b = 0; b < kBatch; b++) if (i0 + 256u * b < kWords) dst[i0 + 256u * b] = v[b];
+        }
     }
     __syncthreads();
     const int lane = threadIdx.x & 63, pk = lane & 3;
@@ -382,47 +393,57 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
         A.jobs[j] = J;
     }
     const int pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;             // pilot k in lane k: carriers -21, -7, +7, +21 (pilot.hpp:138-164)
-    int cfo_comp = r.cfo_comp, sfo_comp = r.sfo_comp, cfo_tr = r.cfo_tracker, sfo_tr = r.sfo_tracker;
-    unsigned symbol_count = 0;                                                   // 127 -> 0 after the SIGNAL symbol
+    const int m3 = pk == 3 ? -1 : 0;                                             // the fourth pilot's angle is taken of -p (pilot.hpp:166-233)
+    int cfo = r.cfo_comp, sfo = r.sfo_comp, ctr = r.cfo_tracker, str = r.sfo_tracker;   // cfo / sfo wrapped to 16 bits after every step; the trackers run free (they are only ever added)
     int nmax = nsym;
 #pragma unroll
     for (int o = 32; o >= 4; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
-    const uint32_t* pp = A.pil + (size_t)(r.slot0 + 1u) * 4u + (uint32_t)pk;    // pilot k of data symbol s at pp[4 (s - 1)] (k_sym_front)
+    const uint32_t* pp = (jr.ok ? A.pil + (size_t)(r.slot0 + 1u) * 4u : A.pil) + (uint32_t)pk;   // pilot k of data symbol s at pp[4 (s - 1)] (k_sym_front)
     TrackRec* trk = A.track + r.slot0 + 1u;
+    const unsigned last = (unsigned)max(nsym, 1) - 1u;
     constexpr int kAhead = 8;                                                    // symbols requested ahead of the one in the chain (a step is ~0.1 us, an L2 miss ten times that)
     uint32_t q[kAhead];
 #pragma unroll
-    for (int i = 0; i < kAhead; i++) q[i] = i < nsym ? pp[4 * i] : 0u;
+    for (int i = 0; i < kAhead; i++) q[i] = pp[4u * min((unsigned)i, last)];
+    unsigned cnt = 0;                                                            // symbol_count: 127 -> 0 after the SIGNAL symbol; the same in every frame of the wave
+    constexpr float kInv28 = 0.0357142873108387f;                                // 0x3D124925: trunc((float)d * kInv28) == d / 28 (C division) for every |d| <= 65535
     for (int s0 = 1; s0 <= nmax; s0 += kAhead) {
 #pragma unroll
         for (int u = 0; u < kAhead; u++) {                                       // (unrolled: the request ring's slots are registers)
             const int s = s0 + u;
             const uint32_t cur = q[u];
-            q[u] = s + kAhead <= nsym ? pp[4 * (s + kAhead - 1)] : 0u;
-            if (s <= nsym) {                                                     // (uniform inside a quad: the cross-lane reads below see their whole quad)
-                const unsigned a = (unsigned)(cfo_comp + pc * sfo_comp) & 0xFFFFu;
-                cpx c; c.re = trk_ucos(s_t, a); c.im = w16(-trk_usin(s_t, a));   // rot_coeff: (ucos, -usin)
-                const cpx p = mul_q15(unpack(cur), c);
-                int y = pk == 3 ? -p.im : p.im, x = pk == 3 ? -p.re : p.re;
-                const int shift = max(bit_scope(x), bit_scope(y)) - 6;           // uatan2 (intalg.h:100-113)
-                if (shift > 0) { y >>= shift; x >>= shift; }
-                int th = trk_uatan2_entry(s_t, (int)(signed char)(y & 0xFF), x);
-                if (pilot_sgn(symbol_count)) th = w16(th + 0x8000);
-                symbol_count++; if (symbol_count >= 127) symbol_count = 0;
-                int th1, th2, th3, th4;                                          // the four angles of the quad, in every lane (assembler: see k_track)
-                asm volatile("s_nop 1\n\t"
-                             "v_mov_b32_dpp %0, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                             "v_mov_b32_dpp %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                             "v_mov_b32_dpp %2, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                             "v_mov_b32_dpp %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                             : "=&v"(th1), "=&v"(th2), "=&v"(th3), "=&v"(th4) : "v"(th));
-                const int avg = w16((th1 + th2 + th3 + th4) / 4);
-                const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
-                if (pk == 0) { TrackRec t; t.cfo_comp = (int16_t)cfo_comp; t.sfo_comp = (int16_t)sfo_comp; t.avg = (int16_t)avg; t.del = (int16_t)del; trk[s - 1] = t; }
-                cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
-                cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
-            }
+            q[u] = pp[4u * min((unsigned)(s + kAhead - 1), last)];
+            const int flip = pilot_sgn(cnt) ? 0x8000 : 0;                        // (scalar: pilot.hpp:10-28)
+            cnt = cnt + 1u >= 127u ? 0u : cnt + 1u;
+            // rot_coeff(cfo + pc sfo) = (ucos, -usin) out of the quarter wave
+            const unsigned a = (unsigned)(cfo + pc * sfo) & 0xFFFFu;
+            const int qi = trk_quarter_index(a);
+            const int sraw = s_t.q[qi], craw = s_t.q[16384 - qi];
+            const uint32_t ws = s_t.e2s[a >> 4], wc = s_t.e2c[a >> 4];
+            const int ms = __builtin_amdgcn_sbfe((int)a, 15, 1), mc = __builtin_amdgcn_sbfe((int)(a ^ (a << 1)), 15, 1);
+            const int sn = ((sraw ^ ms) - ms) + trk_sext2(ws, a), cs = ((craw ^ mc) - mc) + trk_sext2(wc, a);
+            // p = pilot x (cs, -sn), Q15 with a wrapping pack (vector128.h:1201-1211)
+            const int pr = (int)(short)cur, pi = (int)cur >> 16;
+            const int re = __builtin_amdgcn_sbfe(pr * cs + pi * sn, 15, 16), im = __builtin_amdgcn_sbfe(pi * cs - pr * sn, 15, 16);
+            const int x = (re ^ m3) - m3, y = (im ^ m3) - m3;
+            // uatan2 (intalg.h:100-113): the larger magnitude's top bit to bit 6, then the table
+            const int sh = max(25 - (int)__clz((unsigned)(max(x, -x) | max(y, -y))), 0);
+            int th = trk_uatan2_entry(s_t, y >> sh, x >> sh);
+            th = __builtin_amdgcn_sbfe(th ^ flip, 0, 16);                        // + 0x8000 mod 2^16 for a pilot of polarity -1
+            int th1, th2, th3, th4;                                              // the four angles of the quad, in every lane (assembler: see k_track)
+            asm volatile("s_nop 1\n\t"
+                         "v_mov_b32_dpp %0, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %2, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                         "v_mov_b32_dpp %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                         : "=&v"(th1), "=&v"(th2), "=&v"(th3), "=&v"(th4) : "v"(th));
+            const int sum = th1 + th2 + th3 + th4;
+            const int avg = (sum + ((sum >> 31) & 3)) >> 2;                      // (th1 + th2 + th3 + th4) / 4, towards zero: within 16 bits
+            const int del = ((int)((float)(th3 - th1) * kInv28) + (int)((float)(th4 - th2) * kInv28)) >> 1;
+            if (pk == 0 && s <= nsym) { TrackRec t; t.cfo_comp = (int16_t)cfo; t.sfo_comp = (int16_t)sfo; t.avg = (int16_t)avg; t.del = (int16_t)del; trk[s - 1] = t; }
+            ctr += avg >> 2; str += del >> 2;
+            cfo = __builtin_amdgcn_sbfe(cfo + avg + ctr, 0, 16); sfo = __builtin_amdgcn_sbfe(sfo + del + str, 0, 16);
         }
     }
 }

@@ -200,9 +200,10 @@ static void build_tables(HostTables& H)
         H.trk.assign(sizeof(TrkTables) / 4, 0u);
         TrkTables& t = *reinterpret_cast<TrkTables*>(H.trk.data());
         for (int i = 0; i <= 16384; i++) t.q[i] = H.usin[i];
-        for (unsigned a = 0; a < 65536; a++) {
-            if (trk_usin(t, a) != H.usin[a]) t.exs[a >> 5] |= 1u << (a & 31u);
-            if (trk_ucos(t, a) != H.ucos[a]) t.exc[a >> 5] |= 1u << (a & 31u);
+        for (unsigned a = 0; a < 65536; a++) {                                    // (the corrections start at zero: trk_usin / trk_ucos return the mirrored quarter wave)
+            const int ds = H.usin[a] - trk_usin(t, a), dc = H.ucos[a] - trk_ucos(t, a);
+            t.e2s[a >> 4] |= ((uint32_t)ds & 3u) << (2u * (a & 15u));            // (a difference beyond +-1 does not fit: trk_tables_exact fails the load)
+            t.e2c[a >> 4] |= ((uint32_t)dc & 3u) << (2u * (a & 15u));
         }
         for (int y = 0; y < 128; y++) for (int x = 0; x < 256; x++) t.h[y * 256 + x] = H.uatan2[y * 256 + x];
         for (int x = 0; x < 256; x++) t.h[128 * 256 + x] = (int16_t)-H.uatan2[128 * 256 + x];
@@ -279,7 +280,7 @@ const TablePin kTablePins[] = {
     { "tw128", "91cc9a797bfd3c35a1c0ce8d972452419000b0b1dab70cdd56b435f5d01ad834" },
     { "tw32", "2a00eb47f9337b725bd5cfe52b6e7a6c696b141f4d4f10fe770fc403d7b3d703" },
     { "tw8", "e54d5a6817c1f2a559297821786fc9d2e58aa55dc2699d64d289e26bea16e348" },
-    { "trk", "df906ebcda760d39590c55e7f479d1e49f34ef3f8a87508afca083ecff664c3c" },
+    { "trk", "3be082dbd671d4ac431fd688fa67f4967ae1b48f48612595e68701e30e83a30e" },
     { "crcz", "035d5a8379b2b38f05c16cb38107a51e153fd87dc45d71909ef8c25db84897e7" },
     { "dsp_sincos", "a85b7311f9347b68cb30ddf481a5670b78339f985ec327a1c6d4325dedf9800c" },
     { "dsp_atan", "7b576ae30701be7ab527c540af4d02e23e5b1ae1cc97e3ee83ab6cd63aa6343d" },
