@@ -461,7 +461,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
         "air_time_ms": round(air_ms, 4), "decode_ms": round(per[auto], 4), "kernels": auto + " (the library's automatic choice)", "decode_ms_by_kernels": {k: round(v, 4) for k, v in per.items()},
         "decode_ms_best": round(best, 4),
         "realtime_factor": round(per[auto] / air_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
-        "kernel_ms_note": "the library's five timed intervals of the automatic chain: 'k_frame' = k_sym_front + k_track_lds + k_sym_back, 'k_viterbi' = k_viterbi16w + k_win_verify + k_viterbi's empty second pass",
+        "kernel_ms_note": "the library's five timed intervals of the automatic chain: 'k_frame' = k_sym_front + k_track_lds + k_sym_back, 'k_viterbi' = k_viterbi16w + k_win_redo",
         "window_trellis_record": wstats, "mpdu_sha256_ok": bool(ok),
         "protocol": "sora_rx_process_dev + sora_rx_wait, one call in flight, samples resident in HBM; median of %d calls (host wall clock)" % reps}
     ref = ReferenceGraph()
@@ -1438,7 +1438,7 @@ def main():
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
                          "other_trellis_kernels": {tname[l]: {"kernel_ms": round(kt[tname[l]], 4), "frac": round(launch_bytes / (kt[tname[l]] * 1e-3) / HBM_PEAK, 5)} for l, kt in ktimes1_others.items()},
                          "other_trellis_kernels_note": "sora_rx_set_trellis, each alone on the chip: k_viterbi = two frames per wave, k_viterbi16 = eight per wave (the one for 32768 and more captures in flight), k_viterbi16w = the frames' "
-                                                       "trace-back windows decoded side by side and proven afterwards, with k_win_verify and the serial kernel's (empty) second pass in its time (the one below that; the automatic choice follows depth x max_captures)",
+                                                       "trace-back windows decoded side by side and proven afterwards, with k_win_redo (the proof) in its time (the one below that; the automatic choice follows depth x max_captures)",
                          "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},

@@ -199,7 +199,7 @@ int  sora_rx_set_depth(sora_rx_t* rx, int depth);
  *                    no cross-row exchanges, but a quarter of the waves -- the faster one once several calls are in flight.
  *   SORA_TRELLIS_WINDOWED (1)  k_viterbi16w (round 5): the frame's 256-bit trace-back windows (viterbi.hpp:196-214) decoded side by side, each run from
  *                    all-equal metrics a warm-up ahead of its first window and PROVEN afterwards -- its metric vector at the preceding normalisation
- *                    point must equal its predecessor's there (k_win_verify); a frame with a mismatch is decoded again by k_viterbi.  Bit-exact by
+ *                    point must equal its predecessor's there (k_win_redo); a frame with a mismatch is decoded again serially by the same kernel.  Bit-exact by
  *                    construction; the kernel for few frames in flight (one capture, one lone call), where a frame per wave-slot leaves the chip idle.
  *   0   (default)    chosen by the library from the handle's capacity in flight: k_viterbi16 when depth x max_captures >= 32768
  *                    (eight 4096-capture calls, two 16384-capture calls), the window-parallel form below that.

@@ -1,6 +1,6 @@
 // dev_winplan.h -- how a call's frames are cut into the units of the window-parallel trellis (k_vitwin.hip).  Nothing is planned ahead and no table is kept:
 // a frame's cut follows from its length and code rate, the number of frames of the call and the call's unit target, and both kernels (k_viterbi16w,
-// k_win_verify) work it out where they need it.
+// k_win_redo) work it out where they need it.
 #pragma once
 #include "rx_types.h"
 

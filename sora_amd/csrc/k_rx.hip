@@ -9,6 +9,7 @@
 #include <utility>
 #include "kernels.h"
 #include "dev_viterbi.h"
+#include "dev_winplan.h"
 
 namespace sora {
 
@@ -757,8 +758,10 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 // 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.
 // Frames are queued per code rate (k_scan), so the two frames of a wave always share the puncture pattern; the last
 // frame of an odd list runs alone in the low half.  (Jobs given through sora_hip_viterbi11a are one list of one rate.)
-template <int WIN, int LOOK, int BITS>
-__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+struct DecodeEveryPair { __device__ __forceinline__ bool operator()(uint32_t, uint32_t, uint32_t, bool) const { return true; } };
+template <int WIN, int LOOK, int BITS, typename GATE = DecodeEveryPair>
+__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out,
+                                                    GATE gate = GATE())
 {
     __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];                // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
     __shared__ uint16_t s_ops[4][64];                                            // [wave][operand of the chunk][frame]: the soft values as metric fields (viterbi_forward); with it under 40 KB: four workgroups per CU
@@ -772,6 +775,7 @@ __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ j
     const uint32_t njobs = uni(n[list]);
     jobs += (size_t)list * stride;
     const uint32_t fa = pw * 2, fb = fa + 1;
+    if (!gate(list, fa, fb, fb < njobs)) return;                                 // (k_win_redo: the pair's proofs hold, nothing to decode again)
     uint16_t* ring = s_ring[threadIdx.x >> 6];
     auto load_job = [&](uint32_t f) {
         const VitJob& G = jobs[f];
@@ -793,6 +797,46 @@ __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs
 // the 802.11n graph's decoder: T11aViterbi<5000*8, 312, 192, 36> (fb11ndemod_config.hpp:199)
 __global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi_kernel_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }
+
+// The window-parallel trellis's proof AND the serial decode of what failed it, in one launch (k_vitwin.hip describes the proof; a verify kernel + k_viterbi as two
+// launches cost a lone capture a kernel and a queue gap).  A wave owns a PAIR of frames of one code-rate list, as in k_viterbi: its lower half compares the unit
+// boundaries of frame A (unit u's vector at its verify point against unit u - 1's vector at the same step), its upper half those of frame B; if every boundary of both
+// holds the wave is done -- what k_viterbi16w wrote is the reference's decode -- else it decodes the pair serially, overwriting it.
+struct WinProofGate {
+    const VitJob* jobs; const uint32_t* hdr; uint32_t jstride, target, vstride; const uint16_t* vecs; unsigned long long* stats;
+    __device__ __forceinline__ bool operator()(uint32_t list, uint32_t fa, uint32_t fb, bool hasB) const
+    {
+        const unsigned lane = threadIdx.x & 63, side = lane >> 5, l32 = lane & 31u;
+        const uint32_t q = win_units_per_frame(hdr[0] + hdr[1] + hdr[2], target);
+        const uint32_t idx = side ? fb : fa;
+        const bool have = side ? hasB : true;
+        const VitJob& J = jobs[(size_t)list * jstride + (have ? idx : fa)];
+        const uint32_t nev = win_events(J.length, J.code_rate, 256u, 24u), m = win_per_unit(nev, q), nun = have ? (nev + m - 1u) / m : 1u;
+        const size_t vec0 = (size_t)list * vstride + (size_t)idx * q;
+        uint32_t bad = 0;
+        for (uint32_t u = 1u + l32; u < nun; u += 32u) {
+            const uint4* a = reinterpret_cast<const uint4*>(vecs + ((vec0 + u) * 2u) * 64u);
+            const uint4* b = reinterpret_cast<const uint4*>(vecs + ((vec0 + u - 1u) * 2u + 1u) * 64u);
+            uint32_t d = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) { const uint4 x = a[i], y = b[i]; d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
+            bad += d != 0u;
+        }
+        const unsigned long long ba = __ballot(bad != 0u);
+        uint32_t nbad = bad;
+#pragma unroll
+        for (int o = 16; o >= 1; o >>= 1) nbad += __shfl_xor(nbad, o);             // per side
+        if (stats && l32 == 0 && have) {                                          // the record, banked (rx_types.h kWinStatBanks)
+            unsigned long long* bk = stats + 4u * ((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kWinStatBanks - 1u));
+            atomicAdd(&bk[0], (unsigned long long)(nun - 1u)); atomicAdd(&bk[3], (unsigned long long)nun);
+            if (nbad) { atomicAdd(&bk[1], (unsigned long long)nbad); atomicAdd(&bk[2], 1ull); }
+        }
+        return ba != 0ull;
+    }
+};
+__global__ void __launch_bounds__(256) k_win_redo(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* __restrict__ vecs,
+                                                  const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, unsigned long long* __restrict__ stats)
+{ viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, WinProofGate{ jobs, hdr, jstride, target, vstride, vecs, stats }); }
 
 // ------------------------------------------------------------------------------------------------
 // k_finish: T11aDesc (scramble.hpp:267-353) + TBB11aFrameSink (PHY_11a.hpp:607-702).  One wave per frame.

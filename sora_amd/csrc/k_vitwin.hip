@@ -1,8 +1,8 @@
 // k_vitwin.hip -- the K=7 trellis decoded WINDOW-PARALLEL with exact verification (round 5; gfx950).
 //
 //   k_viterbi16w   eight UNITS per wave in the 16-lanes-per-pair layout of k_vit16.hip (dev_vit16.h): a unit = windows k0 .. k1 - 1 of one frame
-//   k_win_verify   per frame: every unit's metric vector at its verify point against the vector its predecessor had there; a frame with a
-//                  mismatch is queued for the serial kernel (k_viterbi), which then overwrites what the units wrote
+//   k_win_redo     (k_rx.hip) per pair of frames: every unit's metric vector at its verify point against the vector its predecessor had there; a pair with a
+//                  mismatch is decoded again, serially, by the same wave (k_viterbi's body), which overwrites what the units wrote
 //
 // Why.  T11aViterbi (viterbi.hpp:148-235) is one serial chain per frame: 8-bit wrapping metrics, the decision in the LSB, unsigned minimum --
 // no block decomposition of that arithmetic is exact by itself, so one frame was one wave-slot, a lone 4096-frame call
@@ -293,43 +293,7 @@ __global__ void __launch_bounds__(64) k_viterbi16w(const VitJob* __restrict__ jo
                                                    const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
 { viterbi16w_body<256, 24, 3>(jobs, hdr, jstride, target, vstride, soft, out, vecs); }
 
-// One wave per frame (job slot), four per workgroup: lane l compares boundary l + 1 (, l + 65, ...) of the frame -- unit u's vector at its verify point against
-// unit u - 1's vector at the same step, 128 bytes each.  Any mismatch: the frame's VitJob goes to the list the serial kernel decodes afterwards.
-// stats[0..3] += boundaries compared, boundaries that differed, frames queued again, units.
-__global__ void __launch_bounds__(256) k_win_verify(const VitJob* __restrict__ jobs, uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
-                                                    const uint16_t* __restrict__ vecs, VitJob* __restrict__ redo, unsigned long long* __restrict__ stats)
-{
-    const JobRef jr = locate_job(blockIdx.x * 4u + (threadIdx.x >> 6), hdr);
-    if (!jr.ok) return;
-    const unsigned lane = threadIdx.x & 63;
-    const uint32_t jslot = jr.list * jstride + jr.idx;
-    const VitJob J = jobs[jslot];
-    const uint32_t q = win_units_per_frame(hdr[0] + hdr[1] + hdr[2], target);
-    const uint32_t nev = win_events(J.length, J.code_rate, 256u, 24u), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
-    const size_t vec0 = (size_t)jr.list * vstride + (size_t)jr.idx * q;
-    uint32_t bad = 0;
-    for (uint32_t u = 1u + lane; u < nun; u += 64u) {
-        const uint4* a = reinterpret_cast<const uint4*>(vecs + ((vec0 + u) * 2u) * 64u);              // unit u, at its own verify point
-        const uint4* b = reinterpret_cast<const uint4*>(vecs + ((vec0 + u - 1u) * 2u + 1u) * 64u);    // unit u - 1, at the same step
-        uint32_t d = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) { const uint4 x = a[i], y = b[i]; d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
-        bad += d != 0u;
-    }
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) bad += __shfl_xor(bad, o);
-    if (lane == 0) {
-        if (bad) {
-            const uint32_t at = atomicAdd(&hdr[kHdrRedo + jr.list], 1u);
-            redo[(size_t)jr.list * jstride + at] = J;
-        }
-        // the record: one bank of four counters per 16th of the workgroups (thousands of atomics on ONE address take a hundred microseconds: the first version of this kernel)
-        if (stats) {
-            unsigned long long* b = stats + 4u * (blockIdx.x & (kWinStatBanks - 1u));
-            atomicAdd(&b[0], (unsigned long long)(nun - 1u)); atomicAdd(&b[3], (unsigned long long)nun);
-            if (bad) { atomicAdd(&b[1], (unsigned long long)bad); atomicAdd(&b[2], 1ull); }
-        }
-    }
-}
+// (the proof itself -- every unit's vector at its verify point against its predecessor's at the same step -- and the serial decode of what fails it are ONE kernel, k_win_redo in
+// k_rx.hip, beside the serial trellis it shares its body with)
 
 }  // namespace sora

@@ -61,12 +61,10 @@ struct VitJob {             // one Viterbi decode: a frame of the RX path or one
 
 // ---- the window-parallel trellis (k_vitwin.hip, round 5).  A frame's trace-back windows (256 decoded bits each, viterbi.hpp:196-214) are cut into UNITS of m
 // consecutive windows; a unit is decoded on its own -- from all-zero metrics kWinWarm steps before its verify point b = floor24(WIN k0) -- and proven afterwards:
-// its metric vector at b must equal the vector the unit before it had there (k_win_verify); a frame with any mismatch is decoded again by the serial kernel.
+// its metric vector at b must equal the vector the unit before it had there; a frame with any mismatch is decoded again serially (k_win_redo does both).
 constexpr int kWinWarm = 144;                 // warm-up steps in front of a verify point (a multiple of 24).  tools/winmodel: with 96 no frame that passes its CRC failed a verification at any rate; 144 leaves a margin
 constexpr int kWinVecBytes = 256;             // per unit: two vectors of 64 16-bit metric fields in the kernel's own lane order
-// words of the 64-byte block in front of the frame table (cleared at the start of every call): 0..2 njobs per code rate, 6..8 frames to be decoded again per code rate
-constexpr int kHdrRedo = 6;
-constexpr unsigned kWinStatBanks = 64;        // k_win_verify spreads its record over this many banks of four counters (a power of two)
+constexpr unsigned kWinStatBanks = 64;        // k_win_redo spreads its record over this many banks of four counters (a power of two)
 
 struct TrackRec {           // per data-symbol slot
     int16_t cfo_comp, sfo_comp;   // CompCoeffs of THIS symbol = build_coeff(cfo_comp, sfo_comp)

@@ -412,8 +412,8 @@ struct RxPipe {
     bool split = false;                                         // symbol chain as k_sym_front -> k_track_lds -> k_sym_back (few frames in flight) instead of k_frame (one wave per frame)
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
-                                                                // 2 = k_viterbi16w + k_win_verify + k_viterbi on what failed its proof (window-parallel, k_vitwin.hip)
-    uint16_t* d_wvecs = nullptr; VitJob* d_rjobs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;   // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
+                                                                // 2 = k_viterbi16w + k_win_redo (the proof, and the serial decode of what fails it) (window-parallel, k_vitwin.hip)
+    uint16_t* d_wvecs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;   // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
@@ -461,15 +461,11 @@ static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k
 static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
 
 namespace sora {
-__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16)          // n16 16-byte words <- 0
+__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16, uint4* __restrict__ ones = nullptr, uint32_t m16 = 0)   // n16 16-byte words <- 0, then m16 of `ones` <- all ones
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
-}
-__global__ void __launch_bounds__(256) k_fill16(uint4* __restrict__ p, uint32_t n16, uint32_t v)   // n16 16-byte words <- v v v v
-{
-    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
-    if (i < n16) p[i] = make_uint4(v, v, v, v);
+    else if (i - n16 < m16) ones[i - n16] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
 }
 }  // namespace sora
 
@@ -494,7 +490,7 @@ static void rx_free(RxPipe* rx)
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_fctx, rx->d_nframes,
                      rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil,
-                     rx->d_wvecs, rx->d_rjobs, rx->d_wstats };
+                     rx->d_wvecs, rx->d_wstats };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -678,7 +674,6 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     if (rx->lanes16 == 2 && !rx->d_wvecs) {                                      // the window-parallel trellis's arrays, on its first use
         rx->wstride = kWinUnitsTarget + rx->cap_rows;
         HIPCHK(hipMalloc((void**)&rx->d_wvecs, 3 * (size_t)kWinVecBytes * rx->wstride));
-        HIPCHK(hipMalloc((void**)&rx->d_rjobs, 3 * sizeof(VitJob) * (size_t)rx->cap_rows));
         HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * kWinStatBanks * sizeof(unsigned long long)));
         HIPCHK(hipMemset(rx->d_wstats, 0, 4 * kWinStatBanks * sizeof(unsigned long long)));
     }
@@ -715,12 +710,9 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         // the job counters and the frame table behind them: ONE fill (every packet of a call costs the command processor a few microseconds, and a call is a dozen
         // of them: DESIGN.md section 3.6) -- by a kernel of this library: a hipMemsetAsync of 64 + 64 n bytes recorded into a hipGraph faults on replay
         {
-            const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16);
-            hipLaunchKernelGGL(k_clear16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16);
-        }
-        if (split) {                                                             // no symbol slot has an owner yet (only the three-kernel symbol chain reads the owners); a kernel, not a memset: see above
-            const uint32_t n16 = (slots + 3) / 4;                                // (the array has 64 words of slack)
-            hipLaunchKernelGGL(k_fill16, dim3((n16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_slot_row), n16, 0xFFFFFFFFu);
+            // ... and, for the three-kernel symbol chain, the slot owners (no symbol slot has an owner yet; only that chain reads them): the same launch
+            const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16), m16 = split ? (slots + 3) / 4 : 0u;   // (the owners' array has 64 words of slack)
+            hipLaunchKernelGGL(k_clear16, dim3((n16 + m16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16, reinterpret_cast<uint4*>(rx->d_slot_row), m16);
         }
         }
         ScanArgs S{};
@@ -761,14 +753,13 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             mark();
             if (!RX_ONLY(rx, 4u)) {}
             else if (rx->lanes16 == 2) {
-                // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), the proof, and
-                // the serial kernel over the frames whose proof failed (none, normally: its workgroups find empty lists and return)
+                // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), then the proof
+                // and the serial decode of the pairs of frames that fail it (none, normally: k_win_redo's waves check and return)
                 const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);   // (a frame has at most 80 windows)
                 hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
                                    (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
-                hipLaunchKernelGGL(k_win_verify, dim3((nrows + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
-                                   (const uint16_t*)rx->d_wvecs, rx->d_rjobs, rx->d_wstats);
-                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_rjobs, (const uint32_t*)(rx->d_njobs + kHdrRedo), 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
+                hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                                   (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
             }
             else if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
                 hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);

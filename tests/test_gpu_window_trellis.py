@@ -1,4 +1,4 @@
-"""The window-parallel trellis (sora_rx_set_trellis(SORA_TRELLIS_WINDOWED): k_viterbi16w + k_win_verify + k_viterbi on what failed its proof,
+"""The window-parallel trellis (sora_rx_set_trellis(SORA_TRELLIS_WINDOWED): k_viterbi16w + k_win_redo (the proof, and the serial decode of what fails it),
 sora_amd/csrc/k_vitwin.hip) against the oracle and the compiled reference graph: the same rows and the same MPDU bytes as the serial kernels,
 whether a frame's units all pass their verification (every decodable frame) or not (frames that are noise behind a good SIGNAL symbol: the
 serial kernel decodes them again).  T11aViterbi: /root/reference/kernel/bb/Brick11/src/viterbi.hpp:103-237, viterbicore.h:293-555."""
@@ -74,8 +74,8 @@ def test_random_captures_equal_the_oracle(sora, torch_cuda, oracle):
 
 
 def test_noise_behind_a_good_header_is_decoded_again(sora, torch_cuda, oracle):
-    """Frames whose SIGNAL symbol is intact and whose data field is noise: the units' vectors do not meet, k_win_verify queues the frame for
-    the serial kernel, and the bytes (FCS failure and all) are the oracle's.  The proof's record says so."""
+    """Frames whose SIGNAL symbol is intact and whose data field is noise: the units' vectors do not meet, k_win_redo decodes the frame
+    again serially, and the bytes (FCS failure and all) are the oracle's.  The proof's record says so."""
     rng = np.random.default_rng(77)
     caps = []
     for i, rate in enumerate(RATES):
