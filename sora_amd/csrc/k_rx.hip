@@ -367,6 +367,13 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
 __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
 {
     __shared__ TrkTables s_t;
+    __shared__ uint32_t s_pol[128];                                              // the pilot polarities (pilot.hpp:10-28, period 127) of the eight symbols from count c on, one bit each
+    if (threadIdx.x < 127) {
+        unsigned b = 0;
+#pragma unroll
+        for (unsigned u = 0; u < 8; u++) b |= pilot_sgn((threadIdx.x + u) % 127u) << u;
+        s_pol[threadIdx.x] = b;
+    }
     {
         // 129 KB from L2 / HBM: eleven 16-byte loads per thread in flight at a time (a loop that waits for every load costs a memory latency per 4 KB: 33 of them)
         const uint4* src = reinterpret_cast<const uint4*>(A.T.trk);
@@ -400,23 +407,29 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
 #pragma unroll
     for (int o = 32; o >= 4; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
-    const uint32_t* pp = (jr.ok ? A.pil + (size_t)(r.slot0 + 1u) * 4u : A.pil) + (uint32_t)pk;   // pilot k of data symbol s at pp[4 (s - 1)] (k_sym_front)
-    TrackRec* trk = A.track + r.slot0 + 1u;
-    const unsigned last = (unsigned)max(nsym, 1) - 1u;
+    // pilot k of data symbol s is word 4 (slot0 + s) + k of pil[] (k_sym_front); a record goes to track[slot0 + s].  32-bit word offsets from the arrays' bases, so that a
+    // request is a minimum, a shift-add and the load.  Symbols past the frame's last re-read its last pilots and their records land on the slot behind the frame --
+    // preamble or silence of whatever follows, a slot no frame owns and k_sym_back never reads.
+    const uint32_t w0 = (jr.ok ? (r.slot0 + 1u) * 4u + (uint32_t)pk : (uint32_t)pk) * 4u;   // BYTE offsets: a uniform base plus a 32-bit lane offset is one address operand pair
+    const uint32_t t0 = (jr.ok ? r.slot0 + 1u : A.total_slots + 1u) * 8u;        // (no job: a slot in the arrays' slack)
+    const char* __restrict__ pil = reinterpret_cast<const char*>(A.pil);
+    char* __restrict__ trk2 = reinterpret_cast<char*>(A.track);
+    const unsigned last = (unsigned)max(nsym, 1) - 1u, nrec = (unsigned)nsym;
     constexpr int kAhead = 8;                                                    // symbols requested ahead of the one in the chain (a step is ~0.1 us, an L2 miss ten times that)
     uint32_t q[kAhead];
 #pragma unroll
-    for (int i = 0; i < kAhead; i++) q[i] = pp[4u * min((unsigned)i, last)];
+    for (int i = 0; i < kAhead; i++) q[i] = *reinterpret_cast<const uint32_t*>(pil + (w0 + 16u * min((unsigned)i, last)));
     unsigned cnt = 0;                                                            // symbol_count: 127 -> 0 after the SIGNAL symbol; the same in every frame of the wave
     constexpr float kInv28 = 0.0357142873108387f;                                // 0x3D124925: trunc((float)d * kInv28) == d / 28 (C division) for every |d| <= 65535
     for (int s0 = 1; s0 <= nmax; s0 += kAhead) {
+        const unsigned pol = (unsigned)__builtin_amdgcn_readfirstlane((int)s_pol[cnt]);   // the polarities of the block's eight symbols, one scalar byte
+        cnt = cnt + (unsigned)kAhead >= 127u ? cnt + (unsigned)kAhead - 127u : cnt + (unsigned)kAhead;
 #pragma unroll
         for (int u = 0; u < kAhead; u++) {                                       // (unrolled: the request ring's slots are registers)
             const int s = s0 + u;
             const uint32_t cur = q[u];
-            q[u] = pp[4u * min((unsigned)(s + kAhead - 1), last)];
-            const int flip = pilot_sgn(cnt) ? 0x8000 : 0;                        // (scalar: pilot.hpp:10-28)
-            cnt = cnt + 1u >= 127u ? 0u : cnt + 1u;
+            q[u] = *reinterpret_cast<const uint32_t*>(pil + (w0 + 16u * min((unsigned)(s + kAhead - 1), last)));
+            const int flip = (int)((pol << (15 - u)) & 0x8000u);
             // rot_coeff(cfo + pc sfo) = (ucos, -usin) out of the quarter wave
             const unsigned a = (unsigned)(cfo + pc * sfo) & 0xFFFFu;
             const int qi = trk_quarter_index(a);
@@ -429,7 +442,7 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
             const int re = __builtin_amdgcn_sbfe(pr * cs + pi * sn, 15, 16), im = __builtin_amdgcn_sbfe(pi * cs - pr * sn, 15, 16);
             const int x = (re ^ m3) - m3, y = (im ^ m3) - m3;
             // uatan2 (intalg.h:100-113): the larger magnitude's top bit to bit 6, then the table
-            const int sh = max(25 - (int)__clz((unsigned)(max(x, -x) | max(y, -y))), 0);
+            const int sh = max(25 - __builtin_clz((unsigned)(max(x, -x) | max(y, -y)) | 1u), 0);
             int th = trk_uatan2_entry(s_t, y >> sh, x >> sh);
             th = __builtin_amdgcn_sbfe(th ^ flip, 0, 16);                        // + 0x8000 mod 2^16 for a pilot of polarity -1
             int th1, th2, th3, th4;                                              // the four angles of the quad, in every lane (assembler: see k_track)
@@ -442,7 +455,8 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
             const int sum = th1 + th2 + th3 + th4;
             const int avg = (sum + ((sum >> 31) & 3)) >> 2;                      // (th1 + th2 + th3 + th4) / 4, towards zero: within 16 bits
             const int del = ((int)((float)(th3 - th1) * kInv28) + (int)((float)(th4 - th2) * kInv28)) >> 1;
-            if (pk == 0 && s <= nsym) { TrackRec t; t.cfo_comp = (int16_t)cfo; t.sfo_comp = (int16_t)sfo; t.avg = (int16_t)avg; t.del = (int16_t)del; trk[s - 1] = t; }
+            // TrackRec { cfo_comp, sfo_comp, avg, del } of THIS symbol: the quad's four lanes store the same eight bytes (no exec juggling)
+            *reinterpret_cast<uint2*>(trk2 + (t0 + 8u * min((unsigned)(s - 1), nrec))) = uint2{ ((uint32_t)cfo & 0xFFFFu) | ((uint32_t)sfo << 16), ((uint32_t)avg & 0xFFFFu) | ((uint32_t)del << 16) };
             ctr += avg >> 2; str += del >> 2;
             cfo = __builtin_amdgcn_sbfe(cfo + avg + ctr, 0, 16); sfo = __builtin_amdgcn_sbfe(sfo + del + str, 0, 16);
         }
