@@ -1,0 +1,268 @@
+"""benchlib.latency -- the under-filled and host-fed cases: one capture, one lone call, large calls, the host-fed loop."""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+from benchlib.common import *  # noqa: F401,F403
+from benchlib.common import _traffic_profile  # noqa: F401
+
+
+def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
+    """The reference harness's own figure of merit (MACStopwatch.h:84-128,130-164): per frame, cost (time spent demodulating it) over required
+    time (its samples / 40 MHz), with mean / max / std and the shares >= 0.8 and >= 1.0.
+    (a) BASELINE configs[1]: kernel/test-data/fsample-6.dmp as ONE capture (tests/golden/fsample6_40mhz_i8.npz: the dump after the 14 -> 16 bit
+        fix, 75,320 samples @40 MHz = 1.883 ms of air time, one 6 Mbps frame of 465 symbols): wall time of process -> wait with one call in
+        flight, and the compiled reference graph on one host core beside it.
+    (b) the 4096-frame batch, one call in flight (process -> deliver -> wait): every frame of a call costs that call's latency (they complete
+        together), required = 9760 samples / 40 MHz = 244 us; the distribution is over the frames of `reps` calls.  The amortised cost
+        (step time / frames) is what `realtime.factor` reports."""
+    import hashlib
+    from oracle.pyoracle import ReferenceGraph
+    out = {}
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fsample6_40mhz_i8.npz"))
+    iq40 = g["iq_i8"].astype(np.int16) << 8
+    n = len(iq40) // 28 * 28
+    d = torch.from_numpy(np.ascontiguousarray(iq40[:n])).to(dev)
+    rx = sora_amd.Rx(1, n, sample_rate_mhz=40, max_frames_per_capture=2)
+    rx.set_depth(1)
+    one = [(0, n, 0)]
+    t = rx.process_dev(d, one); res = rx.results(ticket=t)
+    rx.wait_for_producer = False
+    ok = len(res) == 1 and res[0]["error_code"] == sora_amd.E_FRAME_OK and hashlib.sha256(res[0]["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+    per = {}
+    chains = {1: "k_frame", 3: "k_sym_front+k_track_lds+k_sym_back"}
+    for front, lanes in ((1, 64), (1, 16), (1, 1), (3, 64), (3, 1)):
+        rx.set_front(front); rx.set_trellis(lanes); rx.flush()
+        ok = ok and [r["mpdu"] for r in rx.results(ticket=rx.process_dev(d, one))] == [res[0]["mpdu"]]
+        for _ in range(5):
+            rx.wait(rx.process_dev(d, one))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); rx.wait(rx.process_dev(d, one)); ts.append(time.perf_counter() - t0)
+        per[chains[front] + " | " + TRELLIS_NAMES[lanes]] = float(np.median(ts)) * 1e3
+    rx.set_front(0); rx.set_trellis(0); rx.flush()                             # the library's own choice for a lone capture: the chains that spread ONE frame over the chip
+    auto = chains[rx.front()] + " | " + TRELLIS_NAMES[rx.trellis()]
+    rx.set_profiling(True)
+    for _ in range(10):
+        rx.wait(rx.process_dev(d, one))
+    rx.flush(); kt = rx.kernel_times(); rx.set_profiling(False); wstats = rx.window_stats(); rx.close()
+    air_ms = n / 40e3
+    best = min(per.values())
+    out["fsample6_single_capture"] = {
+        "workload": "kernel/test-data/fsample-6.dmp after the 14->16 bit fix: one 6 Mbps frame, 1392 bytes, 465 data symbols, %d samples @40 MHz" % n,
+        "air_time_ms": round(air_ms, 4), "decode_ms": round(per[auto], 4), "kernels": auto + " (the library's automatic choice)", "decode_ms_by_kernels": {k: round(v, 4) for k, v in per.items()},
+        "decode_ms_best": round(best, 4),
+        "realtime_factor": round(per[auto] / air_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
+        "kernel_ms_note": "the library's five timed intervals of the automatic chain: 'k_frame' = k_sym_front + k_track_lds + k_sym_back, 'k_viterbi' = k_viterbi16w + k_win_redo",
+        "window_trellis_record": wstats, "mpdu_sha256_ok": bool(ok),
+        "protocol": "sora_rx_process_dev + sora_rx_wait, one call in flight, samples resident in HBM; median of %d calls (host wall clock)" % reps}
+    ref = ReferenceGraph()
+    if ref.available():
+        caps = np.ascontiguousarray(iq40[None, :n])
+        ref.rx11a_bench(caps)
+        t0 = time.perf_counter(); k = 0
+        while time.perf_counter() - t0 < 1.0:
+            ref.rx11a_bench(caps, 4); k += 4
+        cpu_ms = (time.perf_counter() - t0) / k * 1e3
+        out["fsample6_single_capture"]["cpu_reference_decode_ms_one_core"] = round(cpu_ms, 4)
+        out["fsample6_single_capture"]["cpu_reference_realtime_factor_one_core"] = round(cpu_ms / air_ms, 4)
+    if rx_batch is None:
+        return out
+    # (b) the batch, one call in flight
+    old_depth = rx_batch.set_depth(1); old_tr = rx_batch.set_trellis(-1); rx_batch.flush()
+    req_us = 2 * FRAME_SAMPLES / 40.0
+    dist = {}
+    for lanes in (64, 16, 1):
+        rx_batch.set_trellis(lanes); rx_batch.flush()
+        buf = sora_amd.HostResults(nfr * 2, rx_batch.mpdu_bytes(rx_batch.process_dev(d_iq, descs))); rx_batch.flush()
+        lat = []
+        for i in range(reps + 3):
+            t0 = time.perf_counter()
+            tk = rx_batch.process_dev(d_iq, descs); rx_batch.deliver_async(tk, buf); rx_batch.wait(tk)
+            if i >= 3:
+                lat.append((time.perf_counter() - t0) * 1e6)
+        buf.close()
+        r = np.asarray(lat) / req_us                                         # every frame of call i has ratio r[i]
+        dist[TRELLIS_NAMES[lanes]] = {
+            "call_latency_ms": round(float(np.mean(lat)) / 1e3, 4), "frames": int(nfr * len(lat)), "required_us_per_frame": req_us,
+            "ratio_mean": round(float(r.mean()), 3), "ratio_max": round(float(r.max()), 3), "ratio_std": round(float(r.std()), 3),
+            "share_ge_0.8": round(float((r >= 0.8).mean()), 3), "share_ge_1.0": round(float((r >= 1.0).mean()), 3)}
+    rx_batch.set_trellis(old_tr); rx_batch.set_depth(old_depth); rx_batch.flush()
+    out["batch_per_frame"] = {"definition": "MACStopwatch's per-frame ratio cost / required with cost = the latency of the call the frame is in (process -> deliver -> wait, one call in flight: "
+                                            "all %d frames of a call complete together) and required = %d samples / 40 MHz; >= 1.0 means a frame's result arrives later than its own air time, although "
+                                            "the batch as a whole is decoded far faster than real time (realtime.factor, the amortised cost)" % (nfr, 2 * FRAME_SAMPLES),
+                              "by_trellis_kernel": dist}
+    return out
+
+
+def bench_large_call(torch, sora_amd, local_rank, d_iqs, nfr, maxf, exp_rows, exp_mpdu, seconds, cores):
+    """What a plain host gets when it hands over MORE PER CALL instead of keeping more calls in flight: the rotated device copies of the batch
+    as ONE call of 8 x nfr captures, at most TWO such calls in flight, every call delivered (rows + MPDU bytes) and compared.  The first
+    call is verified against the already verified nfr-capture table, quarter by quarter (capture_id and mpdu_offset shifted, everything else and
+    every MPDU byte equal).  Reported per nfr captures, so that it reads beside ms_per_step."""
+    copies = list(d_iqs) * max(1, 8 // len(d_iqs))                   # 8 x nfr captures per call: its trellis launch is two rounds of the chip's trellis slots
+    g_n = len(copies); n_iq = d_iqs[0].shape[0]                     # (at 4 x nfr it is exactly ONE round, and the step is bimodal, 0.39-0.53 ms: profiles/r04_r_call_size.txt)
+    big = torch.cat(copies)
+    descs = sora_amd.Rx.captures([(g * n_iq + i * CAPTURE_SAMPLES, CAPTURE_SAMPLES, g * nfr + i) for g in range(g_n) for i in range(nfr)])
+    rx = sora_amd.Rx(max_captures=g_n * nfr, max_total_samples=g_n * n_iq, sample_rate_mhz=20, device=local_rank, max_frames_per_capture=maxf)
+    dep = 2
+    rx.set_depth(dep)
+    torch.cuda.synchronize()
+    rx.wait_for_producer = False
+    t = rx.process_dev(big, descs)
+    nb = dep + TableChecker.EXTRA
+    bufs = [sora_amd.HostResults(g_n * nfr * maxf, rx.mpdu_bytes(t)) for _ in range(nb)]
+    rx.deliver_async(t, bufs[0]); rx.wait(t)
+    n = int(bufs[0].nrows[0]); rows = bufs[0].rows[:n].copy(); mp = bufs[0].mpdu.copy()
+    exp_n = len(exp_rows)
+    ok = n == g_n * exp_n
+    if ok:
+        for g in range(g_n):
+            q = rows[g * exp_n:(g + 1) * exp_n]
+            ok = ok and all((q[f] == exp_rows[f]).all() for f in q.dtype.names if f not in ("capture_id", "mpdu_offset")) \
+                and bool((q["capture_id"] == exp_rows["capture_id"] + g * nfr).all())
+            good = np.nonzero(exp_rows["error_code"] == 1)[0]
+            for k in good:
+                a, b, ln = int(q["mpdu_offset"][k]), int(exp_rows["mpdu_offset"][k]), int(exp_rows["length"][k])
+                if mp[a:a + ln].tobytes() != exp_mpdu[b:b + ln].tobytes():
+                    ok = False
+                    break
+    chk = TableChecker(rows.tobytes(), mp, cores=cores)
+
+    def block(k):
+        first = None
+        for _ in range(k):
+            chk.release((rx.ticket() + 1) % nb)
+            tk = rx.process_dev(big, descs)
+            rx.deliver_async(tk, bufs[tk % nb])
+            if first is None:
+                first = tk
+            if tk - first >= dep - 1:
+                rx.wait(tk - (dep - 1)); b = bufs[(tk - (dep - 1)) % nb]
+                chk.check((tk - (dep - 1)) % nb, int(b.nrows[0]) == n, b.rows[:n], b.mpdu)
+        for old in range(max(first, tk - (dep - 1) + 1), tk + 1):
+            rx.wait(old); b = bufs[old % nb]
+            chk.check(old % nb, int(b.nrows[0]) == n, b.rows[:n], b.mpdu)
+        rx.flush(); chk.drain()
+    block(4)
+    t0 = time.perf_counter(); block(8); probe = (time.perf_counter() - t0) / 8
+    ncalls = max(16, int(seconds / max(probe, 1e-6)))
+    chk.compared = chk.bad = 0
+    t0 = time.perf_counter(); block(ncalls); dt = time.perf_counter() - t0
+    out = {"captures_per_call": g_n * nfr, "calls_in_flight": dep, "trellis": TRELLIS_NAMES[rx.trellis()], "calls_timed": ncalls,
+           "ms_per_call": round(1e3 * dt / ncalls, 4), "ms_per_%d_captures" % nfr: round(1e3 * dt / ncalls / g_n, 4),
+           "msamples_per_s": round(g_n * nfr * FRAME_SAMPLES * ncalls / dt / 1e6, 1), "first_call_equals_the_verified_table": bool(ok),
+           "calls_compared": chk.compared, "calls_with_wrong_rows": chk.bad, "input_bytes_per_call": int(big.numel() * 2),
+           "note": "the same step protocol (process_dev -> deliver_async -> wait -> compare, no environment variable) with %d captures per call and two calls in flight" % (g_n * nfr)}
+    chk.finish(); rx.close()
+    del big
+    return out
+
+
+def bench_e2e(torch, sora_amd, dev, rx, iq, nfr, exp_rows, exp_mpdu, steps=24, nbatches=4):
+    """Dump bytes in page-locked host memory -> sora_rx_process_dump (H2D copy + sora_hip_ingest + the receive chain on one stream, no host wait) ->
+    rows and MPDUs delivered to the host: LoadSoraDumpFile -> graph -> MPDU buffer (brickutil.h:20-58, fb11a_demod.cpp:88-120) as one path.
+    The workload's captures as a 40 MHz RX_BLOCK dump (every 20 MHz sample doubled -- TDownSample2, done by the ingest, drops the copies --
+    128-byte blocks of a 16-byte descriptor + 28 samples): `nbatches` DIFFERENT dumps (the captures rotated by a quarter of the batch each)
+    are submitted in turn, about 190 MB each, so the inputs of consecutive calls share nothing and their total is past the 256 MiB Infinity Cache."""
+    from test_oracle_ingest import make_dump
+    flags = sora_amd.INGEST_RXBLOCK | sora_amd.INGEST_DECIMATE2
+    caps20 = iq.reshape(nfr, CAPTURE_SAMPLES, 2)
+    blocks_per_cap = 2 * CAPTURE_SAMPLES // 28
+    base = np.empty((nfr, blocks_per_cap * 128), np.uint8)
+    for i in range(0, nfr, 256):
+        c40 = np.repeat(caps20[i:i + 256], 2, axis=1).reshape(-1, 2)
+        base[i:i + 256] = make_dump(c40, raw14=False, seed=i).reshape(-1, blocks_per_cap * 128)
+    dumps, ids = [], []
+    for k in range(nbatches):
+        sh = (k * nfr) // nbatches
+        perm = (np.arange(nfr) + sh) % nfr                                    # position i of dump k holds capture perm[i]
+        t = torch.empty(base.size, dtype=torch.uint8).pin_memory()
+        t.numpy().reshape(base.shape)[:] = base[perm]
+        dumps.append(t); ids.append(perm)
+    del base
+    descs = [sora_amd.Rx.captures([(i * CAPTURE_SAMPLES, CAPTURE_SAMPLES, int(ids[k][i])) for i in range(nfr)]) for k in range(nbatches)]
+    # what every call must deliver: per capture id {error_code, length, crc32} of the verified table (rows come in position order)
+    order = np.argsort(exp_rows["capture_id"], kind="stable")
+    want = {f: exp_rows[f][order] for f in ("capture_id", "error_code", "length", "crc32")}
+    depth = 4
+    old_depth = rx.set_depth(depth); rx.flush()
+    nb = depth + 2
+    bufs = [sora_amd.HostResults(nfr * 2, rx.mpdu_bytes(rx.ticket())) for _ in range(nb)]
+    bad = [0]; checked = [0]; mp_checked = [0]
+
+    def consume(tk, k):
+        rx.wait(tk)
+        b = bufs[tk % nb]
+        n = int(b.nrows[0]); rows = b.rows[:n]
+        o = np.argsort(rows["capture_id"], kind="stable")
+        same = n == len(want["capture_id"]) and all(np.array_equal(rows[f][o], want[f]) for f in want)
+        if same and k == 0:                                                   # the unrotated dump: the MPDU array byte for byte as well
+            same = bool((b.mpdu == exp_mpdu).all()); mp_checked[0] += 1
+        checked[0] += 1; bad[0] += 0 if same else 1
+
+    def block(nsteps):
+        pend = []
+        for i in range(nsteps):
+            k = i % nbatches
+            tk = rx.process_dump(dumps[k], flags, descs[k])
+            rx.deliver_async(tk, bufs[tk % nb]); pend.append((tk, k))
+            if len(pend) >= depth:
+                consume(*pend.pop(0))
+        for tk, k in pend:
+            consume(tk, k)
+    block(nbatches + depth)                                                   # warm-up: every pipeline's staging buffers exist
+    bad[0] = checked[0] = mp_checked[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    block(steps)
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    dump_bytes = int(dumps[0].numel())
+    dump_row = {"workload": "%d dumps of %.1f MB (the batch's captures as a 40 MHz RX_BLOCK dump, rotated) in page-locked host memory, submitted in turn: sora_rx_process_dump = H2D copy + "
+                            "sora_hip_ingest (de-frame, TDownSample2) + receive chain on the call's stream, then deliver_async of rows + MPDUs; %d calls in flight" % (nbatches, dump_bytes / 1e6, depth),
+                "ms_per_step": round(ms, 4), "bytes_per_step": dump_bytes, "distinct_input_bytes": dump_bytes * nbatches,
+                "pcie_gb_per_s_host_to_device": round(dump_bytes / ms / 1e6, 2), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms / 1e3, 1),
+                "decoded_mbit_per_s": round(nfr * MPDU_LEN * 8 / ms / 1e3, 1),
+                "calls_delivered_and_checked": checked[0], "calls_with_wrong_rows": bad[0], "calls_with_mpdu_bytes_compared": mp_checked[0],
+                "note": "bound by the host link: the 40 MHz dump is 9.4 bytes of PCIe traffic per 20 MHz sample decoded (RX_BLOCK framing, both 40 MHz samples of a pair)"}
+    # the same host-fed loop with the stream the graph actually consumes -- descriptors stripped, TDownSample2 already applied (what brickutil.h:20-58 +
+    # samples.hpp:36-39 leave: 4 bytes per 20 MHz sample), handed to the 20 MHz handle's sora_rx_process: H2D copy + receive chain + delivery, same comparison.
+    del dumps
+    streams = []
+    for k in range(nbatches):
+        t = torch.empty((nfr * CAPTURE_SAMPLES, 2), dtype=torch.int16).pin_memory()
+        t.numpy().reshape(nfr, CAPTURE_SAMPLES, 2)[:] = caps20[ids[k]]
+        streams.append(t)
+
+    def block2(nsteps):
+        pend = []
+        for i in range(nsteps):
+            k = i % nbatches
+            tk = rx.process(streams[k].numpy(), descs[k])
+            rx.deliver_async(tk, bufs[tk % nb]); pend.append((tk, k))
+            if len(pend) >= depth:
+                consume(*pend.pop(0))
+        for tk, k in pend:
+            consume(tk, k)
+    block2(nbatches + depth)
+    bad[0] = checked[0] = mp_checked[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    block2(steps)
+    ms2 = (time.perf_counter() - t0) / steps * 1e3
+    sbytes = int(streams[0].numel()) * 2
+    stream_row = {"workload": "%d streams of %.1f MB (the same captures as the 20 MHz COMPLEX16 stream the graph consumes: descriptors stripped, even samples only) in page-locked host memory: "
+                              "sora_rx_process = H2D copy + receive chain, then deliver_async of rows + MPDUs; %d calls in flight" % (nbatches, sbytes / 1e6, depth),
+                  "ms_per_step": round(ms2, 4), "bytes_per_step": sbytes, "pcie_gb_per_s_host_to_device": round(sbytes / ms2 / 1e6, 2), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms2 / 1e3, 1),
+                  "decoded_mbit_per_s": round(nfr * MPDU_LEN * 8 / ms2 / 1e3, 1),
+                  "calls_delivered_and_checked": checked[0], "calls_with_wrong_rows": bad[0], "calls_with_mpdu_bytes_compared": mp_checked[0],
+                  "note": "4.1 bytes of PCIe traffic per 20 MHz sample decoded: who strips the RX_BLOCK framing and drops the odd samples before the link (the capture front end, or a host pass) halves the link's load"}
+    rx.set_depth(old_depth); rx.flush()
+    for b in bufs:
+        b.close()
+    best = max((dump_row, stream_row), key=lambda r: r["msamples_per_s"])
+    return {"msamples_per_s": best["msamples_per_s"], "ms_per_step": best["ms_per_step"], "path": "stripped_stream_20mhz" if best is stream_row else "rx_block_dump_40mhz",
+            "rx_block_dump_40mhz": dump_row, "stripped_stream_20mhz": stream_row}
