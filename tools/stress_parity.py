@@ -21,22 +21,34 @@ def main():
     ap.add_argument("--captures", type=int, default=600)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=100)
-    ap.add_argument("--trellis", type=int, default=0, help="0: the library's choice (k_viterbi for batches this small), 16: k_viterbi16, 64: k_viterbi")
+    ap.add_argument("--trellis", type=int, default=0, help="0: the library's choice (the window-parallel kernel for batches this small), 1: k_viterbi16w, 16: k_viterbi16, 64: k_viterbi")
+    ap.add_argument("--front", type=int, default=0, help="0: the library's choice, 1: k_frame, 3: k_sym_front -> k_track_lds -> k_sym_back")
+    ap.add_argument("--noise-frames", type=float, default=0.0, help="share of captures whose data field is replaced by noise behind an intact SIGNAL symbol (the window-parallel trellis's proof fails: the serial path)")
     args = ap.parse_args()
     import torch
     import sora_amd
     o = Oracle()
     rng = np.random.default_rng(args.seed)
     t0 = time.time(); nfr = 0; nok = 0
+    rec = {"boundaries": 0, "boundaries_failed": 0, "frames_decoded_again": 0, "units": 0}
     for b0 in range(0, args.captures, args.batch):
         mhz = int(rng.choice([20, 40]))
         caps = [random_capture(o, rng, mhz) for _ in range(min(args.batch, args.captures - b0))]
+        for i in range(len(caps)):
+            if rng.random() < args.noise_frames and len(caps[i]) > 3000:
+                c = caps[i].astype(np.int32); a = (700 if mhz == 20 else 1400); c[a:len(c) - 200] = np.rint(rng.normal(0, 2500, (len(c) - 200 - a, 2)))
+                caps[i] = np.clip(c, -32768, 32767).astype(np.int16)
         iq, descs = batch(caps)
         rx = sora_amd.Rx(len(caps), len(iq), sample_rate_mhz=mhz, max_frames_per_capture=8)
         if args.trellis:
             rx.set_trellis(args.trellis)
+        if args.front:
+            rx.set_front(args.front)
         rx.process_dev(torch.from_numpy(iq).cuda(), descs)
-        got = rx.results(); rx.close()
+        got = rx.results()
+        for k, v in rx.window_stats().items():
+            rec[k] += v
+        rx.close()
         want = []
         for i, c in enumerate(caps):
             for r in o.rx_capture(c, mhz):
@@ -54,7 +66,7 @@ def main():
             print("FAILED:", why)
             return 1
         nfr += len(want); nok += sum(r["error_code"] == 1 for r in want)
-    print("stress parity OK: %d captures, %d frames (%d FRAME_OK) identical, %.1f s" % (args.captures, nfr, nok, time.time() - t0))
+    print("stress parity OK: %d captures, %d frames (%d FRAME_OK) identical, %.1f s; window-parallel trellis: %s" % (args.captures, nfr, nok, time.time() - t0, rec))
     return 0
 
 
