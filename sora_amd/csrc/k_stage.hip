@@ -145,12 +145,13 @@ __global__ void __launch_bounds__(256) k_cmul64_batch(const uint32_t* __restrict
         const uint32_t i = (blockIdx.x * kTiles + t) * 16 + g;
         const uint32_t* c = coef + (size_t)ci[t] * cstride + coff + 4 * e;           // (a context's coefficient arrays start on a word, not on 16 bytes: four word loads, L2-resident)
         const uint32_t x[4] = { v[t].x, v[t].y, v[t].z, v[t].w };
+        const uint32_t keep = (e == 7 || e == 8) ? 0u : 0xFFFFFFFFu;                 // bins 28 .. 35 = lanes 7 and 8 of the symbol: zero (channel_11a.hpp:545-546)
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const PkTw w = pk_tw_mul(c[q]);
             if (KIND == 0)      o[q] = pk_cmul<15>(pk_sra(x[q], 1), w);
-            else if (KIND == 1) o[q] = (4 * e + q >= 28 && 4 * e + q < 36) ? 0u : pk_cmul<8>(x[q], w);
+            else if (KIND == 1) o[q] = pk_cmul<8>(x[q], w) & keep;                  // (a mask, not a branch: the select on 4e + q made the compiler fetch every coefficient under its own exec mask)
             else                o[q] = pk_cmul<15>(x[q], w);
         }
         if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 16 + e] = uint4{o[0], o[1], o[2], o[3]};
