@@ -4,7 +4,7 @@
 # PMC passes (their own runs, one call in flight so that every dispatch is attributed cleanly).
 # Outputs land in gpurun_out/<tag>_*; copy the summaries to profiles/ afterwards (see DESIGN.md, section "Measurement").
 set -u
-TAG=${1:-r03}
+TAG=${1:-r05}
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out
 mkdir -p $OUT
