@@ -12,8 +12,8 @@ cd /tmp && export TMPDIR=/tmp
 QUICK="--no-cpu-baseline --no-extras --no-plain --check 64"   # (--no-plain: the plain_host section launches 32768-capture calls, which do not belong in per-launch means of the 4096-capture call)
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks -o p -- python $R/bench.py $QUICK --headline-only --min-seconds 2 > $OUT/${TAG}_ks_bench.json 2> $OUT/${TAG}_ks.err
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_ks1 -o p -- python $R/bench.py $QUICK --headline-only --min-seconds 2 --depth 1 --trellis 16 > $OUT/${TAG}_ks1_bench.json 2> $OUT/${TAG}_ks1.err
-# the PMC passes, once per trellis kernel (sora_rx_set_trellis: 16 = k_viterbi16, what the default bench uses; 64 = k_viterbi)
-for T in 16 64; do
+# the PMC passes, once per trellis kernel (sora_rx_set_trellis: 16 = k_viterbi16, what the default bench uses; 64 = k_viterbi; 1 = the window-parallel k_viterbi16w)
+for T in ${TRELLISES:-16 64 1}; do
   PMC="$QUICK --steps 3 --warmup 1 --depth 1 --trellis $T --min-seconds 0 --no-deliver"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_fetch -o p -- python $R/bench.py $PMC > /dev/null 2> $OUT/${TAG}_fetch.err
   rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_write -o p -- python $R/bench.py $PMC > /dev/null 2> $OUT/${TAG}_write.err
@@ -21,7 +21,9 @@ for T in 16 64; do
   I=$(find $OUT/${TAG}_insts -name "*counter_collection.csv" | head -1)
   F=$(find $OUT/${TAG}_fetch -name "*counter_collection.csv" | head -1)
   W=$(find $OUT/${TAG}_write -name "*counter_collection.csv" | head -1)
-  if [ $T = 16 ]; then python $R/tools/summarize_pmc.py "$F" "$W" 4096 "$I" k_viterbi16 > $OUT/${TAG}_traffic.json; else python $R/tools/summarize_pmc.py "$F" "$W" 4096 "$I" k_viterbi > $OUT/${TAG}_traffic_trellis64.json; fi
+  if [ $T = 16 ]; then python $R/tools/summarize_pmc.py "$F" "$W" 4096 "$I" k_viterbi16 > $OUT/${TAG}_traffic.json;
+  elif [ $T = 64 ]; then python $R/tools/summarize_pmc.py "$F" "$W" 4096 "$I" k_viterbi > $OUT/${TAG}_traffic_trellis64.json;
+  else python $R/tools/summarize_pmc.py "$F" "$W" 4096 "$I" k_viterbi16w > $OUT/${TAG}_traffic_windowed.json; fi     # (the window-parallel form: k_viterbi16w + k_win_redo)
   rm -rf $OUT/${TAG}_fetch $OUT/${TAG}_write $OUT/${TAG}_insts
 done
 K=$(find $OUT/${TAG}_ks -name "*kernel_stats.csv" | head -1)
