@@ -46,6 +46,7 @@ typedef struct { int16_t re, im; } sora_complex16;
 #define SORA_E_PARAMETER         ((int)0x80000001)
 #define SORA_E_PLCP_HEADER_FAIL  ((int)0x80000005)
 #define SORA_E_CRC32_FAIL        ((int)0x80000006)
+#define SORA_E_INTERNAL_TIMEOUT  ((int)0x8000F001) /* not a code of the reference: a bounded wait inside k_pipe expired (sora_rx_set_front) -- no result for the frame */
 #define SORA_ERR_FAILED          ((int)0x8000FFFF)  /* BK_ERROR_FAILED */
 #define SORA_ERR_HARDWARE_FAILED ((int)0x8000FFFE)  /* BK_ERROR_HARDWARE_FAILED: a HIP call failed */
 #define SORA_ERR_INVALID_PARAM   (-1)               /* BK_ERROR_INVALID_PARAM */
@@ -210,15 +211,19 @@ int  sora_rx_trellis(sora_rx_t* rx);            /* the kernel the next process c
 /* The window-parallel trellis's proof record since the handle was created: out[0] unit boundaries compared, out[1] boundaries whose vectors differed,
  * out[2] frames decoded again by the serial kernel because of that, out[3] units.  Waits for the handle's calls in flight. */
 int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
-/* Two forms of the symbol chain T11aDataSymbol .. T11aDeinterleave (fb11ademod_config.hpp:200-222) write the same soft stream:
+/* Three forms of the symbol chain T11aDataSymbol .. T11aDeinterleave (fb11ademod_config.hpp:200-222) write the same soft stream:
  *   1   k_frame      one wave per frame, four symbols per pass, the pilot tracker's loop-carried chain in the same wave: the cheaper one when the chip is full of frames;
  *   3   k_sym_front -> k_track_lds -> k_sym_back   per symbol slot in front of and behind the tracker (TFreqCompensation, TFFT64, TChannelEqualization | TPhaseCompensate's
  *                    rotation, T11aDemap, T11aDeinterleave), and the tracker's chain (freqoffset.hpp:28-30, pilot.hpp:166-233) alone, four lanes per frame, with its
  *                    three look-up tables folded into LDS: a frame's symbols spread over the chip -- the one for few, long frames (fsample-6: 465 symbols);
- *   0   (default)    chosen by the library: 3 while depth x max_captures x max_frames_per_capture <= 512, else 1.
+ *   4   k_pipe       form 3 AND the window-parallel trellis as ONE launch whose workgroups hand symbols on as the tracker passes them (the reference's demod || Viterbi
+ *                    overlap, fb11a_demod.cpp:109-112, inside a frame): the one for a handful of frames (a single capture).  Used only with the window-parallel trellis and
+ *                    where every workgroup of the handle's calls in flight is resident at once (at most 192 of them); otherwise a request for 4 runs as 3.  Its hand-offs
+ *                    are bounded waits: should one ever expire, the call's frames are reported with error_code SORA_E_INTERNAL_TIMEOUT instead of a result;
+ *   0   (default)    chosen by the library: 4 while depth x max_captures x max_frames_per_capture <= 16 (and it fits), 3 up to 512, else 1.
  * Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_front(sora_rx_t* rx, int kernels);
-int  sora_rx_front(sora_rx_t* rx);              /* 1 or 3: what the next process call will use */
+int  sora_rx_front(sora_rx_t* rx);              /* 1, 3 or 4: what the next process call will use */
 /* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);

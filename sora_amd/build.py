@@ -16,7 +16,7 @@ SOURCES = ["k_scan.hip", "k_rx.hip", "k_vit16.hip", "k_vitwin.hip", "k_stage.hip
 # k_decode.hip (the data field in one kernel, sora_rx_set_fused) left the default library in round 4: build_variant("fused", ["SORA_WITH_K_DECODE"])
 # compiles it in (the entry point answers SORA_E_NOT_SUPPORTED otherwise).
 VARIANT_SOURCES = {"SORA_WITH_K_DECODE": ["k_decode.hip"]}
-HEADERS = ["dev_arith.h", "dev_viterbi.h", "dev_vit16.h", "dev_winplan.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
+HEADERS = ["dev_arith.h", "dev_viterbi.h", "dev_vit16.h", "dev_winplan.h", "dev_vitwin.h", "dev_11n.h", "rx_types.h", "kernels.h", os.path.join("..", "..", "include", "sora_hip.h")]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fvisibility=hidden", "-x", "hip"]   # hidden: the library exports what include/sora_hip.h declares, nothing else
 
 

@@ -425,7 +425,8 @@ class Rx:
         return r
 
     def set_front(self, kernels=-1):
-        """1: k_frame (one wave per frame), 3: k_sym_front -> k_track_lds -> k_sym_back, 0: the library chooses; returns the previous setting"""
+        """1: k_frame (one wave per frame), 3: k_sym_front -> k_track_lds -> k_sym_back, 4: k_pipe (those and the window-parallel trellis as one launch),
+        0: the library chooses; returns the previous setting"""
         r = int(self._L.sora_rx_set_front(self._h, int(kernels)))
         if r < 0: _check(r)
         return r

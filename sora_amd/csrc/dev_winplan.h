@@ -36,5 +36,21 @@ __host__ __device__ inline uint32_t win_unit_at(uint32_t p, uint32_t nun)
     const uint32_t c0 = (nun + 2u) / 3u, c1 = (nun + 1u) / 3u;
     return p < c0 ? 3u * p : p < c0 + c1 ? 3u * (p - c0) + 1u : 3u * (p - c0 - c1) + 2u;
 }
+// A list of ONE frame cut into single windows (a lone capture) lays them out so that no wave mixes trace-back steps: the three classes u mod 3 each start a wave of
+// their own, and the frame's last unit -- whose only trace-back is the frame's end, earlier than its class's -- sits alone behind them.  (A wave steps until its slowest
+// unit is done and pays every distinct trace-back step with a walk of its own: the wave that holds the frame's end is the launch's last one, and it should be a short one.)
+// The layout needs up to 21 + 8 slots more than the frame has units: a list of one frame gets win_slots() of them.
+constexpr uint32_t kWinLonePad = 32;
+constexpr uint32_t kWinNone = 0xFFFFFFFFu;
+__host__ __device__ inline uint32_t win_slots(uint32_t nframes, uint32_t q) { return nframes == 1u ? q + kWinLonePad : nframes * q; }
+__host__ __device__ inline uint32_t win_unit_lone(uint32_t p, uint32_t nun)
+{
+    const uint32_t N = nun - 1u, c0 = (N + 2u) / 3u, c1 = (N + 1u) / 3u, c2 = N / 3u;
+    const uint32_t a1 = (c0 + 7u) & ~7u, a2 = a1 + ((c1 + 7u) & ~7u), a3 = a2 + ((c2 + 7u) & ~7u);
+    if (p < a1) return p < c0 ? 3u * p : kWinNone;
+    if (p < a2) return p - a1 < c1 ? 3u * (p - a1) + 1u : kWinNone;
+    if (p < a3) return p - a2 < c2 ? 3u * (p - a2) + 2u : kWinNone;
+    return p == a3 ? N : kWinNone;
+}
 
 }  // namespace sora

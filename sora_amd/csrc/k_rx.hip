@@ -10,6 +10,7 @@
 #include "kernels.h"
 #include "dev_viterbi.h"
 #include "dev_winplan.h"
+#include "dev_vitwin.h"
 
 namespace sora {
 
@@ -213,12 +214,23 @@ __device__ __forceinline__ void sym_front_quad(const uint32_t raw[4], const PkTw
     wsync();
 }
 
-__global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
+// Stores another workgroup of the SAME launch reads (k_pipe): written through to memory (sc1), so that the publishing flag needs no write-back of the XCD's L2 behind it
+// (cdna_hip_programming.md, guideline 16, form R1: sc1 payload, every storing wave drains, one relaxed agent-scope flag).
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void store16_through(uint4* p, uint4 v)
 {
-    __shared__ uint32_t s_eq[4][4][64];                                          // [wave][group]: FFT staging
+    const u32x4_t x = { v.x, v.y, v.z, v.w };
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" : : "v"(p), "v"(x) : "memory");
+}
+__device__ __forceinline__ void store4_through(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+// The slots of workgroup `bid` (64 of them, 16 per wave) through TFreqCompensation, TFFT64 and TChannelEqualization.  THROUGH: the results are for workgroups of this launch.
+template <bool THROUGH>
+__device__ __forceinline__ void sym_front_block(const RxArgs& A, uint32_t bid, uint32_t (*s_eq)[4][64])
+{
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
     const Tables& T = A.T;
-    const uint32_t slot_first = (blockIdx.x * 4u + (uint32_t)w) * (4u * kSlotIters);
+    const uint32_t slot_first = (bid * 4u + (uint32_t)w) * (4u * kSlotIters);
     if (slot_first >= A.total_slots) return;
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     // the owners of the wave's 16 slots: lane l < 16 asks for slot slot_first + l, the groups pick theirs up by cross-lane reads
@@ -235,12 +247,14 @@ __global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
     uint32_t* sl = s_eq[w][g];
     uint4* eq4 = reinterpret_cast<uint4*>(A.eq);
     auto store = [&](uint32_t slot, const uint32_t o[4]) {
-        eq4[(size_t)slot * 16u + (uint32_t)e] = uint4{ o[0], o[1], o[2], o[3] };
+        if (THROUGH) store16_through(eq4 + ((size_t)slot * 16u + (uint32_t)e), uint4{ o[0], o[1], o[2], o[3] });
+        else eq4[(size_t)slot * 16u + (uint32_t)e] = uint4{ o[0], o[1], o[2], o[3] };
         // the four pilot bins once more, densely (16 bytes per slot: k_track reads nothing else): bins 43, 57, 7, 21 = (e, q) (10,3), (14,1), (1,3), (5,1)
-        if (e == 10) A.pil[(size_t)slot * 4u + 0u] = o[3];
-        if (e == 14) A.pil[(size_t)slot * 4u + 1u] = o[1];
-        if (e == 1)  A.pil[(size_t)slot * 4u + 2u] = o[3];
-        if (e == 5)  A.pil[(size_t)slot * 4u + 3u] = o[1];
+        auto pilot = [&](uint32_t k, uint32_t v) { if (THROUGH) store4_through(A.pil + ((size_t)slot * 4u + k), v); else A.pil[(size_t)slot * 4u + k] = v; };
+        if (e == 10) pilot(0u, o[3]);
+        if (e == 14) pilot(1u, o[1]);
+        if (e == 1)  pilot(2u, o[3]);
+        if (e == 5)  pilot(3u, o[1]);
     };
     if (one_frame) {
         // ---- one frame: its row and its coefficients once per wave, every sample load in flight before the first butterfly
@@ -290,6 +304,12 @@ __global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
         sym_front_quad(raw, fq, ch, sl, e, W, wsync, o);
         if (mine) store(slot, o);
     }
+}
+
+__global__ void __launch_bounds__(256) k_sym_front(RxArgs A)
+{
+    __shared__ uint32_t s_eq[4][4][64];                                          // [wave][group]: FFT staging
+    sym_front_block<false>(A, blockIdx.x, s_eq);
 }
 
 // The loop-carried part (freqoffset.hpp:28-30, pilot.hpp:166-233): pilot k of a frame in lane 4 f + k, sixteen frames per wave, every
@@ -357,6 +377,66 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
     }
 }
 
+// One symbol of the chain out of the folded tables in LDS (freqoffset.hpp:28-30, pilot.hpp:166-233): pilot k of the frame in lane k of a quad, `cur` its equalised bin, `flip`
+// 0x8000 for a symbol of pilot polarity -1.  Advances the state and returns the symbol's TrackRec { cfo_comp, sfo_comp, avg, del } as two words.
+__device__ __forceinline__ uint2 track_step(const TrkTables& s_t, uint32_t cur, int flip, int pc, int m3, int& cfo, int& sfo, int& ctr, int& str)
+{
+    constexpr float kInv28 = 0.0357142873108387f;                                // 0x3D124925: trunc((float)d * kInv28) == d / 28 (C division) for every |d| <= 65535
+    // rot_coeff(cfo + pc sfo) = (ucos, -usin) out of the quarter wave
+    const unsigned a = (unsigned)(cfo + pc * sfo) & 0xFFFFu;
+    const int qi = trk_quarter_index(a);
+    const int sraw = s_t.q[qi], craw = s_t.q[16384 - qi];
+    const uint32_t ws = s_t.e2s[a >> 4], wc = s_t.e2c[a >> 4];
+    const int ms = __builtin_amdgcn_sbfe((int)a, 15, 1), mc = __builtin_amdgcn_sbfe((int)(a ^ (a << 1)), 15, 1);
+    const int sn = ((sraw ^ ms) - ms) + trk_sext2(ws, a), cs = ((craw ^ mc) - mc) + trk_sext2(wc, a);
+    // p = pilot x (cs, -sn), Q15 with a wrapping pack (vector128.h:1201-1211)
+    const int pr = (int)(short)cur, pi = (int)cur >> 16;
+    const int re = __builtin_amdgcn_sbfe(pr * cs + pi * sn, 15, 16), im = __builtin_amdgcn_sbfe(pi * cs - pr * sn, 15, 16);
+    const int x = (re ^ m3) - m3, y = (im ^ m3) - m3;
+    // uatan2 (intalg.h:100-113): the larger magnitude's top bit to bit 6, then the table
+    const int sh = max(25 - __builtin_clz((unsigned)(max(x, -x) | max(y, -y)) | 1u), 0);
+    int th = trk_uatan2_entry(s_t, y >> sh, x >> sh);
+    th = __builtin_amdgcn_sbfe(th ^ flip, 0, 16);                                // + 0x8000 mod 2^16 for a pilot of polarity -1
+    int th1, th2, th3, th4;                                                      // the four angles of the quad, in every lane (assembler: see k_track)
+    asm volatile("s_nop 1\n\t"
+                 "v_mov_b32_dpp %0, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %2, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
+                 "v_mov_b32_dpp %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
+                 : "=&v"(th1), "=&v"(th2), "=&v"(th3), "=&v"(th4) : "v"(th));
+    const int sum = th1 + th2 + th3 + th4;
+    const int avg = (sum + ((sum >> 31) & 3)) >> 2;                              // (th1 + th2 + th3 + th4) / 4, towards zero: within 16 bits
+    const int del = ((int)((float)(th3 - th1) * kInv28) + (int)((float)(th4 - th2) * kInv28)) >> 1;
+    // the record's halves by one byte permute each (low half of the second operand | low half of the first << 16)
+    const uint2 rec = uint2{ __builtin_amdgcn_perm((uint32_t)sfo, (uint32_t)cfo, 0x05040100u), __builtin_amdgcn_perm((uint32_t)del, (uint32_t)avg, 0x05040100u) };
+    ctr += avg >> 2; str += del >> 2;
+    // cfo runs free like the trackers (it is only ever added, and read modulo 2^16: unsigned, so that the wrap of 32 bits is defined); sfo is a factor of the 24-bit product above
+    cfo = (int)((unsigned)cfo + (unsigned)avg + (unsigned)ctr); sfo = __builtin_amdgcn_sbfe(sfo + del + str, 0, 16);
+    return rec;
+}
+
+// The tracker's tables into a workgroup's LDS (256 threads; the caller's barrier follows).
+__device__ __forceinline__ void track_tables_to_lds(const uint32_t* __restrict__ trk, TrkTables& s_t, uint32_t* s_pol)
+{
+    if (threadIdx.x < 127) {
+        unsigned b = 0;
+#pragma unroll
+        for (unsigned u = 0; u < 8; u++) b |= pilot_sgn((threadIdx.x + u) % 127u) << u;
+        s_pol[threadIdx.x] = b;
+    }
+    // 129 KB from L2 / HBM: eleven 16-byte loads per thread in flight at a time (a loop that waits for every load costs a memory latency per 4 KB: 33 of them)
+    const uint4* src = reinterpret_cast<const uint4*>(trk);
+    uint4* dst = reinterpret_cast<uint4*>(&s_t);
+    constexpr uint32_t kWords = sizeof(TrkTables) / 16, kBatch = 11;
+    for (uint32_t i0 = threadIdx.x; i0 < kWords; i0 += 256u * kBatch) {
+        uint4 v[kBatch];
+#pragma unroll
+        for (uint32_t b = 0; b < kBatch; b++) v[b] = src[min(i0 + 256u * b, kWords - 1u)];
+#pragma unroll
+        for (uint32_t b = 0; b < kBatch; b++) if (i0 + 256u * b < kWords) dst[i0 + 256u * b] = v[b];
+    }
+}
+
 // Round 5: the same chain with its three tables in LDS -- the tracker for FEW frames in flight (a single capture: fsample-6's 465 symbols).
 // k_track's step is two dependent L2 gathers long (rot[] is 256 KB, uatan2[] 128 KB: 0.7 us per symbol); here a workgroup first copies the folded tables
 // (dev_arith.h TrkTables, 129 KB: quarter-wave sine + two-bit corrections, uatan2 for y >= 0) into its LDS, and the step is three LDS reads deep.  One wave is
@@ -368,25 +448,7 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
 {
     __shared__ TrkTables s_t;
     __shared__ uint32_t s_pol[128];                                              // the pilot polarities (pilot.hpp:10-28, period 127) of the eight symbols from count c on, one bit each
-    if (threadIdx.x < 127) {
-        unsigned b = 0;
-#pragma unroll
-        for (unsigned u = 0; u < 8; u++) b |= pilot_sgn((threadIdx.x + u) % 127u) << u;
-        s_pol[threadIdx.x] = b;
-    }
-    {
-        // 129 KB from L2 / HBM: eleven 16-byte loads per thread in flight at a time (a loop that waits for every load costs a memory latency per 4 KB: 33 of them)
-        const uint4* src = reinterpret_cast<const uint4*>(A.T.trk);
-        uint4* dst = reinterpret_cast<uint4*>(&s_t);
-        constexpr uint32_t kWords = sizeof(TrkTables) / 16, kBatch = 11;
-        for (uint32_t i0 = threadIdx.x; i0 < kWords; i0 += 256u * kBatch) {
-            uint4 v[kBatch];
-#pragma unroll
-            for (uint32_t b = 0; b < kBatch; b++) v[b] = src[min(i0 + 256u * b, kWords - 1u)];
-#pragma unroll
-            for (uint32_t b = 0; b < kBatch; b++) if (i0 + 256u * b < kWords) dst[i0 + 256u * b] = v[b];
-        }
-    }
+    track_tables_to_lds(A.T.trk, s_t, s_pol);
     __syncthreads();
     const int lane = threadIdx.x & 63, pk = lane & 3;
     const JobRef jr = locate_job(blockIdx.x * 64u + (threadIdx.x >> 2), A.njobs);
@@ -420,7 +482,6 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
 #pragma unroll
     for (int i = 0; i < kAhead; i++) q[i] = *reinterpret_cast<const uint32_t*>(pil + (w0 + 16u * min((unsigned)i, last)));
     unsigned cnt = 0;                                                            // symbol_count: 127 -> 0 after the SIGNAL symbol; the same in every frame of the wave
-    constexpr float kInv28 = 0.0357142873108387f;                                // 0x3D124925: trunc((float)d * kInv28) == d / 28 (C division) for every |d| <= 65535
     for (int s0 = 1; s0 <= nmax; s0 += kAhead) {
         const unsigned pol = (unsigned)__builtin_amdgcn_readfirstlane((int)s_pol[cnt]);   // the polarities of the block's eight symbols, one scalar byte
         cnt = cnt + (unsigned)kAhead >= 127u ? cnt + (unsigned)kAhead - 127u : cnt + (unsigned)kAhead;
@@ -430,35 +491,8 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
             const uint32_t cur = q[u];
             q[u] = *reinterpret_cast<const uint32_t*>(pil + (w0 + 16u * min((unsigned)(s + kAhead - 1), last)));
             const int flip = (int)((pol << (15 - u)) & 0x8000u);
-            // rot_coeff(cfo + pc sfo) = (ucos, -usin) out of the quarter wave
-            const unsigned a = (unsigned)(cfo + pc * sfo) & 0xFFFFu;
-            const int qi = trk_quarter_index(a);
-            const int sraw = s_t.q[qi], craw = s_t.q[16384 - qi];
-            const uint32_t ws = s_t.e2s[a >> 4], wc = s_t.e2c[a >> 4];
-            const int ms = __builtin_amdgcn_sbfe((int)a, 15, 1), mc = __builtin_amdgcn_sbfe((int)(a ^ (a << 1)), 15, 1);
-            const int sn = ((sraw ^ ms) - ms) + trk_sext2(ws, a), cs = ((craw ^ mc) - mc) + trk_sext2(wc, a);
-            // p = pilot x (cs, -sn), Q15 with a wrapping pack (vector128.h:1201-1211)
-            const int pr = (int)(short)cur, pi = (int)cur >> 16;
-            const int re = __builtin_amdgcn_sbfe(pr * cs + pi * sn, 15, 16), im = __builtin_amdgcn_sbfe(pi * cs - pr * sn, 15, 16);
-            const int x = (re ^ m3) - m3, y = (im ^ m3) - m3;
-            // uatan2 (intalg.h:100-113): the larger magnitude's top bit to bit 6, then the table
-            const int sh = max(25 - __builtin_clz((unsigned)(max(x, -x) | max(y, -y)) | 1u), 0);
-            int th = trk_uatan2_entry(s_t, y >> sh, x >> sh);
-            th = __builtin_amdgcn_sbfe(th ^ flip, 0, 16);                        // + 0x8000 mod 2^16 for a pilot of polarity -1
-            int th1, th2, th3, th4;                                              // the four angles of the quad, in every lane (assembler: see k_track)
-            asm volatile("s_nop 1\n\t"
-                         "v_mov_b32_dpp %0, %4 quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                         "v_mov_b32_dpp %1, %4 quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                         "v_mov_b32_dpp %2, %4 quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf bound_ctrl:1\n\t"
-                         "v_mov_b32_dpp %3, %4 quad_perm:[3,3,3,3] row_mask:0xf bank_mask:0xf bound_ctrl:1"
-                         : "=&v"(th1), "=&v"(th2), "=&v"(th3), "=&v"(th4) : "v"(th));
-            const int sum = th1 + th2 + th3 + th4;
-            const int avg = (sum + ((sum >> 31) & 3)) >> 2;                      // (th1 + th2 + th3 + th4) / 4, towards zero: within 16 bits
-            const int del = ((int)((float)(th3 - th1) * kInv28) + (int)((float)(th4 - th2) * kInv28)) >> 1;
             // TrackRec { cfo_comp, sfo_comp, avg, del } of THIS symbol: the quad's four lanes store the same eight bytes (no exec juggling)
-            *reinterpret_cast<uint2*>(trk2 + (t0 + 8u * min((unsigned)(s - 1), nrec))) = uint2{ ((uint32_t)cfo & 0xFFFFu) | ((uint32_t)sfo << 16), ((uint32_t)avg & 0xFFFFu) | ((uint32_t)del << 16) };
-            ctr += avg >> 2; str += del >> 2;
-            cfo = __builtin_amdgcn_sbfe(cfo + avg + ctr, 0, 16); sfo = __builtin_amdgcn_sbfe(sfo + del + str, 0, 16);
+            *reinterpret_cast<uint2*>(trk2 + (t0 + 8u * min((unsigned)(s - 1), nrec))) = track_step(s_t, cur, flip, pc, m3, cfo, sfo, ctr, str);
         }
     }
 }
@@ -599,6 +633,238 @@ __global__ void __launch_bounds__(256) k_sym_back(RxArgs A)
         }
         wsync();
     }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Round 5: the data field of a HANDFUL of frames (a single capture: BASELINE configs[1]) as ONE launch -- k_pipe.
+//
+// Behind one another, k_sym_front -> k_track_lds -> k_sym_back -> k_viterbi16w cost fsample-6 9 + 112 + 10 + 34 us plus three kernel boundaries, and all but the
+// tracker's 112 us (a serial chain: DESIGN.md section 3.8) is work that could run BESIDE it: a symbol's soft values can be made as soon as the chain has passed
+// it, a trace-back window's unit can be decoded as soon as its soft values exist.  k_pipe is those four kernels' code in one grid whose workgroups take ROLES
+// by their index and hand their results on INSIDE the launch:
+//   [0, nfront)                 sym_front_block: 64 symbol slots each; eq[] / pil[] written through (sc1), then ONE flag per workgroup
+//   [nfront, nfront + ntrack)   one frame each.  Wave 0 runs the chain (the frame's pilots and the records it produces are in LDS: no address arithmetic, no
+//                               memory latency in the loop); waves 1-3 follow it through an LDS counter, four symbols at a time in turn: rotate, demap,
+//                               de-interleave, pack, write the quad's soft bytes through (sc1 dwords) and publish a count per wave
+//   the rest                    four waves each, a wave = eight units of the window-parallel trellis (dev_vitwin.h) -- it works out its units, waits until the
+//                               three counters of its frames say that every soft value it will read has been written, acquires, and decodes
+// Waiting only ever looks at a workgroup of a LOWER role, the launch is small enough for every workgroup to be resident at once (sora_hip.cpp: pipe_fits -- 160 KB
+// of LDS each, one per CU, at most ~190 of the 256), and every wait is bounded: a wait that expires sets flags[0] and gives up, k_finish then reports every frame
+// of the call as SORA_E_INTERNAL_TIMEOUT instead of a result (never seen; the bound is one second).  Hand-offs follow cdna_hip_programming.md guideline 16.
+// The proof of the units and the serial decode of what fails it stay a kernel of their own behind this one (k_win_redo), then k_finish.
+constexpr uint32_t kPipeMaxSym = 1376;                                           // pilots kept in LDS: 1366 data symbols (4095 bytes at 6 Mbps) + the chain's overshoot to a multiple of eight
+constexpr uint32_t kPipeRing = 512;                                              // records kept in LDS (a ring: the helpers are a few symbols behind the chain)
+struct PipeTrackLds {
+    TrkTables t;
+    uint32_t pol[128];
+    uint32_t pil[kPipeMaxSym][4];
+    uint2 rec[kPipeRing];
+    uint8_t demap[1024];
+    uint8_t soft[3][4][288];                                                     // [helper][symbol of the quad]: soft values in carrier order, then the quad's packed bytes on their way out
+    uint32_t done;                                                               // symbols the chain has passed
+    uint32_t next_quad[3];                                                       // the quad each helper works on (all below the smallest are finished)
+    uint32_t give_up;
+    uint32_t pad[11];
+};
+constexpr uint32_t kPipeLdsBytes = sizeof(PipeTrackLds);
+static_assert(kPipeLdsBytes <= 160 * 1024 && sizeof(TrkTables) % 16 == 0, "k_pipe: a tracker workgroup's LDS");
+static_assert(4 * sizeof(Lds16<256, 24>) <= kPipeLdsBytes, "k_pipe: four trellis waves' LDS");
+
+#ifdef SORA_DBG_PIPE_TIMELINE                                                    // tools/pipe_timeline.py: 10 ns stamps of the launch's hand-offs, behind the hand-off words
+#define PIPE_STAMP(P, i) do { if ((threadIdx.x & 63) == 0) (P).flags[(P).stamp_base + (i)] = (uint32_t)wall_clock64(); } while (0)
+#else
+#define PIPE_STAMP(P, i) do {} while (0)
+#endif
+__device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ bool pipe_expired(long long t0) { return wall_clock64() - t0 > 100000000ll; }   // one second of the 100 MHz counter
+
+// ---- role 2: one frame's chain and everything behind it up to the soft stream
+__device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs& P, uint32_t t, PipeTrackLds& L)
+{
+    const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const JobRef jr = locate_job(t, A.njobs);
+    if (!jr.ok) return;                                                          // (the whole workgroup)
+    track_tables_to_lds(A.T.trk, L.t, L.pol);                                    // (its loads are in flight while wave 0 waits for the front workgroups)
+    reinterpret_cast<uint32_t*>(L.demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.T.demap)[threadIdx.x];
+    const uint32_t j = jr.list * A.nrows + jr.idx, f = A.joblist[j];
+    const FrameRow r = A.frames[f];
+    const uint32_t nsym = min((uint32_t)r.nsym, kPipeMaxSym - 8u), slot0 = r.slot0;
+    if (threadIdx.x == 0) {
+        VitJob J;
+        J.valid = 1; J.soft_off = slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+        J.dec_off = 0; J.out_off = slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
+        A.jobs[j] = J;                                                           // (for the kernels behind this launch; the trellis waves of this one work it out themselves)
+        L.done = 0; L.give_up = 0; L.next_quad[0] = 0; L.next_quad[1] = 1; L.next_quad[2] = 2;
+    }
+    if (w == 0) {
+        // the front workgroups that hold this frame's slots: one flag per lane (a frame is at most 22 of them)
+        const uint32_t b0 = (slot0 + 1u) >> 6, b1 = (slot0 + max(nsym, 1u)) >> 6;
+        const uint32_t* fl = P.flags + 4u + 4u * A.nrows + b0 + (uint32_t)lane;
+        const bool mine = b0 + (uint32_t)lane <= b1;
+        const long long t0 = wall_clock64();
+        bool gave_up = false;
+        while (!__all(!mine || flag_load(fl) != 0u)) {
+            if (pipe_expired(t0)) { gave_up = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+        }
+        if (gave_up && lane == 0) { L.give_up = 1; atomicOr(P.flags, 1u); }
+        PIPE_STAMP(P, 1);
+    }
+    __syncthreads();
+    if (L.give_up) return;
+    {   // the frame's pilots (16 bytes per symbol: k_sym_front's dense copy) -> LDS, by loads that pass this CU's L1 (sc1: the acquire that plain loads would need is ~1.7 us
+        // in front of the chain; the helpers, who read eq[] with plain loads, make theirs beside it); the overshoot reads zeros
+        const unsigned long long* src = reinterpret_cast<const unsigned long long*>(A.pil) + 2u * (size_t)(slot0 + 1u);
+        unsigned long long* dst = reinterpret_cast<unsigned long long*>(&L.pil[0][0]);
+        for (uint32_t i = threadIdx.x; i < 2u * (nsym + 8u); i += 256u) dst[i] = i < 2u * nsym ? __hip_atomic_load(src + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+    }
+    __syncthreads();
+    if (w == 0) {
+        // ---- the chain (k_track_lds's step), lanes 0-3
+        __builtin_amdgcn_s_setprio(3);
+        PIPE_STAMP(P, 2);
+        if (lane < 4) {
+            const int pk = lane & 3;
+            const int pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21, m3 = pk == 3 ? -1 : 0;
+            int cfo = r.cfo_comp, sfo = r.sfo_comp, ctr = r.cfo_tracker, str = r.sfo_tracker;
+            unsigned cnt = 0;
+            volatile uint32_t* done = &L.done; volatile uint32_t* nq = L.next_quad;
+            for (uint32_t s0 = 1; s0 <= nsym; s0 += 8u) {
+                if (s0 + 7u > kPipeRing) {                                       // the records about to be overwritten must have been used (frames of more than 512 symbols only)
+                    while (4u * min(min(nq[0], nq[1]), nq[2]) + kPipeRing < s0 + 7u) __builtin_amdgcn_s_sleep(1);
+                }
+                const unsigned pol = (unsigned)__builtin_amdgcn_readfirstlane((int)L.pol[cnt]);
+                cnt = cnt + 8u >= 127u ? cnt + 8u - 127u : cnt + 8u;
+                uint32_t q[8];
+#pragma unroll
+                for (int u = 0; u < 8; u++) q[u] = L.pil[s0 - 1u + (uint32_t)u][pk];
+                const uint32_t ring = (s0 - 1u) & (kPipeRing - 1u);
+#pragma unroll
+                for (int u = 0; u < 8; u++) L.rec[ring + (uint32_t)u] = track_step(L.t, q[u], (int)((pol << (15 - u)) & 0x8000u), pc, m3, cfo, sfo, ctr, str);
+                asm volatile("" ::: "memory");                                   // (the records before the count: a wave's LDS accesses are served in order)
+                if (lane == 0) *done = min(s0 + 7u, nsym);
+            }
+        }
+        PIPE_STAMP(P, 3);
+        return;
+    }
+    // ---- the helpers: TPhaseCompensate + the pilots' rotation + T11aDemap + T11aDeinterleave + the packed stream, quad by quad behind the chain
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                           // (eq[] was written by the front workgroups of this launch)
+    const int h = w - 1, g = lane >> 4, e = lane & 15;
+    auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    const int nb = __builtin_amdgcn_readfirstlane((int)r.nbpsc), ncbps = 48 * nb;
+    const uint32_t sym_bytes = 3u * (uint32_t)ncbps / 8u;
+    uint8_t* stream = A.soft + (size_t)slot0 * kSoftBytesPerSlot;
+    const bool packs = 8 * lane < ncbps;
+    uint32_t mp[4];
+    {
+        const uint16_t* map = A.T.deint + (nb == 1 ? 0 : nb == 2 ? 1 : nb == 4 ? 2 : 3) * 288;
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++) mp[tt] = packs ? (uint32_t)map[8 * lane + 2 * tt] | ((uint32_t)map[8 * lane + 2 * tt + 1] << 16) : 0u;
+    }
+    int bins[3];
+#pragma unroll
+    for (int m = 0; m < 3; m++) bins[m] = carrier_bin48(e + 16 * m);
+    volatile uint32_t* done = &L.done; volatile uint32_t* nq = L.next_quad;
+    uint32_t* my_count = P.flags + 4u + 4u * f + (uint32_t)h;
+    uint32_t quads = 0;
+    uint8_t* bytes = &L.soft[h][0][0];                                           // (the quad's packed bytes reuse the helper's soft values' place once those are gathered)
+    for (uint32_t k = (uint32_t)h; 4u * k < nsym; k += 3u) {
+        const uint32_t nact = min(4u, nsym - 4u * k), s = 4u * k + 1u + (uint32_t)g;   // group g's symbol (1-based)
+        const bool mine = (uint32_t)g < nact;
+        uint32_t v3[3];
+#pragma unroll
+        for (int m = 0; m < 3; m++) v3[m] = mine ? A.eq[(size_t)(slot0 + s) * 64u + (uint32_t)bins[m]] : 0u;   // (in flight while the chain gets there)
+        while (*done < 4u * k + nact) __builtin_amdgcn_s_sleep(1);
+        asm volatile("" ::: "memory");
+        const uint2 rw = L.rec[(s - 1u) & (kPipeRing - 1u)];
+        TrackRec tr;
+        tr.cfo_comp = (int16_t)rw.x; tr.sfo_comp = (int16_t)(rw.x >> 16); tr.avg = (int16_t)rw.y; tr.del = (int16_t)(rw.y >> 16);
+        if (mine) sym_back_demap(A.T, L.demap, v3, tr, nb, e, L.soft[h][g]);
+        wsync();
+        uint32_t b24[4];
+#pragma unroll
+        for (int gs = 0; gs < 4; gs++) {
+            const uint8_t* src = L.soft[h][gs];
+            uint32_t v[8];
+#pragma unroll
+            for (int tt = 0; tt < 4; tt++) { v[2 * tt] = src[mp[tt] & 0xFFFFu]; v[2 * tt + 1] = src[mp[tt] >> 16]; }
+            b24[gs] = soft3_pack8(v);
+        }
+        wsync();
+        if (packs) {
+#pragma unroll
+            for (int gs = 0; gs < 4; gs++) soft3_store8(bytes + (uint32_t)gs * sym_bytes, (uint32_t)lane, b24[gs]);
+        }
+        wsync();
+        // the quad's bytes (a multiple of eight from a multiple-of-four address: 72 N_BPSC per quad; a last, shorter quad is rounded up into the frame's own spare slot)
+        const uint32_t ndw = (nact * sym_bytes + 3u) / 4u;
+        uint32_t* out32 = reinterpret_cast<uint32_t*>(stream + (size_t)(4u * k) * sym_bytes);
+        for (uint32_t i = (uint32_t)lane; i < ndw; i += 64u) store4_through(out32 + i, reinterpret_cast<const uint32_t*>(bytes)[i]);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        wsync();
+        quads++;
+        if (lane == 0) { store4_through(my_count, quads); nq[h] = k + 3u; }
+    }
+    if (lane == 0) nq[h] = 0x3FFFFFFFu;
+    PIPE_STAMP(P, 4 + h);
+}
+
+// ---- role 3: a wave of the window-parallel trellis
+__device__ __forceinline__ void pipe_trellis_wave(const RxArgs& A, const PipeArgs& P, uint32_t wave_index, Lds16<256, 24>& S)
+{
+    auto jobs_of = [&](uint32_t list) {
+        const uint32_t* jl = A.joblist + (size_t)list * A.nrows; const FrameRow* fr = A.frames;
+        return [jl, fr](uint32_t idx) {
+            const FrameRow& r = fr[jl[idx]];
+            VitJob J;
+            J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+            J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
+            return J;
+        };
+    };
+    auto ready = [&](const UnitGeom& GA, const UnitGeom& GB_, uint32_t list) -> bool {
+        const unsigned lane = threadIdx.x & 63, l16 = lane & 15;
+        const UnitGeom& M = (lane & 1u) ? GB_ : GA;
+        const bool polls = l16 < 2u && M.valid;                                  // one lane per unit
+        const uint32_t f = A.joblist[(size_t)list * A.nrows + M.idx];
+        const uint32_t ncbps = 48u * A.frames[f].nbpsc;
+        const uint32_t quads = polls ? ((M.need + ncbps - 1u) / ncbps + 3u) / 4u : 0u;   // quads of symbols that hold the unit's soft values
+        const uint32_t* c = P.flags + 4u + 4u * f;
+        const long long t0 = wall_clock64();
+        for (;;) {
+            bool ok = true;
+#pragma unroll
+            for (uint32_t h = 0; h < 3; h++) ok = ok && flag_load(c + h) >= (quads + 2u - h) / 3u;   // helper h has the quads = h (mod 3)
+            if (__all(ok)) break;
+            if (pipe_expired(t0)) { if (lane == 0) atomicOr(P.flags, 1u); return false; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        PIPE_STAMP(P, 16 + 2 * wave_index);
+        return true;
+    };
+    viterbi16w_wave<256, 24, 3>(S, wave_index, jobs_of, ready, A.njobs, P.target, P.vstride, (const uint8_t*)A.soft, A.vout, P.vecs);
+    PIPE_STAMP(P, 17 + 2 * wave_index);
+}
+
+__global__ void __launch_bounds__(256) k_pipe(RxArgs A, PipeArgs P)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kPipeLdsBytes];
+    uint32_t b = blockIdx.x;
+    if (b == 0) PIPE_STAMP(P, 0);
+    if (b < P.nfront) {
+        sym_front_block<true>(A, b, reinterpret_cast<uint32_t (*)[4][64]>(lds));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every storing wave drains, then ONE flag
+        __syncthreads();
+        if (threadIdx.x == 0) store4_through(P.flags + 4u + 4u * A.nrows + b, 1u);
+        if (b == 0) PIPE_STAMP(P, 8);
+        return;
+    }
+    b -= P.nfront;
+    if (b < P.ntrack) { pipe_track_block(A, P, b, *reinterpret_cast<PipeTrackLds*>(lds)); return; }
+    b -= P.ntrack;
+    pipe_trellis_wave(A, P, b * 4u + (threadIdx.x >> 6), reinterpret_cast<Lds16<256, 24>*>(lds)[threadIdx.x >> 6]);
 }
 
 // (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
@@ -773,9 +1039,11 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 // Frames are queued per code rate (k_scan), so the two frames of a wave always share the puncture pattern; the last
 // frame of an odd list runs alone in the low half.  (Jobs given through sora_hip_viterbi11a are one list of one rate.)
 struct DecodeEveryPair { __device__ __forceinline__ bool operator()(uint32_t, uint32_t, uint32_t, bool) const { return true; } };
-template <int WIN, int LOOK, int BITS, typename GATE = DecodeEveryPair>
+struct NothingAfter { __device__ __forceinline__ void operator()(uint32_t, uint32_t, uint32_t, bool) const {} };
+// (gate(list, fa, fb, hasB): decode this pair at all?  after(...): what the wave does with its pair once the pair's bytes are final -- k_win_redo_finish's T11aDesc / frame sink)
+template <int WIN, int LOOK, int BITS, typename GATE = DecodeEveryPair, typename AFTER = NothingAfter>
 __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out,
-                                                    GATE gate = GATE())
+                                                    GATE gate = GATE(), AFTER after = AFTER())
 {
     __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];                // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
     __shared__ uint16_t s_ops[4][64];                                            // [wave][operand of the chunk][frame]: the soft values as metric fields (viterbi_forward); with it under 40 KB: four workgroups per CU
@@ -789,21 +1057,24 @@ __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ j
     const uint32_t njobs = uni(n[list]);
     jobs += (size_t)list * stride;
     const uint32_t fa = pw * 2, fb = fa + 1;
-    if (!gate(list, fa, fb, fb < njobs)) return;                                 // (k_win_redo: the pair's proofs hold, nothing to decode again)
-    uint16_t* ring = s_ring[threadIdx.x >> 6];
-    auto load_job = [&](uint32_t f) {
-        const VitJob& G = jobs[f];
-        VitJob J;
-        J.soft_off = uni(G.soft_off); J.nsoft = uni(G.nsoft); J.length = uni(G.length); J.dec_off = uni(G.dec_off);
-        J.out_off = uni(G.out_off); J.valid = uni(G.valid); J.code_rate = uni(G.code_rate); J.soft_bits = uni(G.soft_bits);
-        return J;
-    };
-    const VitJob JA = load_job(fa);
-    const bool hasB = fb < njobs;
-    const VitJob JB = hasB ? load_job(fb) : JA;
-    if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
-    else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
-    else                        viterbi_forward<2, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
+    if (gate(list, fa, fb, fb < njobs)) {                                        // (k_win_redo: false = the pair's proofs hold, nothing to decode again)
+        uint16_t* ring = s_ring[threadIdx.x >> 6];
+        auto load_job = [&](uint32_t f) {
+            const VitJob& G = jobs[f];
+            VitJob J;
+            J.soft_off = uni(G.soft_off); J.nsoft = uni(G.nsoft); J.length = uni(G.length); J.dec_off = uni(G.dec_off);
+            J.out_off = uni(G.out_off); J.valid = uni(G.valid); J.code_rate = uni(G.code_rate); J.soft_bits = uni(G.soft_bits);
+            return J;
+        };
+        const VitJob JA = load_job(fa);
+        const bool hasB = fb < njobs;
+        const VitJob JB = hasB ? load_job(fb) : JA;
+        if (JA.code_rate == 0)      viterbi_forward<0, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
+        else if (JA.code_rate == 1) viterbi_forward<1, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
+        else                        viterbi_forward<2, WIN, LOOK, BITS>(JA, JB, hasB, soft, out, ring, s_ops[threadIdx.x >> 6]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");                   // (after() reads the bytes this wave has just written)
+    }
+    after(list, fa, fb, fb < njobs);
 }
 
 __global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
@@ -862,33 +1133,58 @@ __global__ void __launch_bounds__(256) k_win_redo(const VitJob* __restrict__ job
 //     the 40 bytes that END 40 l bytes before the end of the message (table-driven, bytes out of LDS), then six tree
 //     levels fold lane l + 2^k into lane l through Z_(40 * 2^k) (8 nibble look-ups each).  ~450 instructions per frame
 //     instead of a 4500-instruction byte-serial chain on one lane.
-__global__ void __launch_bounds__(256) k_finish(RxArgs A)
+struct FinishLds {
+    uint32_t crc[256]; uint32_t z[6 * 8 * 16]; uint32_t bufs[4][2504 / 4 + 2];
+    uint32_t seq4[128];          // the scrambler sequence's bytes at phases p, p + 8, p + 16, p + 24 (mod 127) as one word: what four consecutive MPDU bytes are xored with
+    uint8_t  phase[128];         // T.scr_phase
+};
+__device__ __forceinline__ void finish_tables_to_lds(const RxArgs& A, FinishLds& L)      // (256 threads; the caller's barrier follows)
 {
-    __shared__ uint32_t s_crc[256];
-    __shared__ uint32_t s_z[6 * 8 * 16];
-    __shared__ uint32_t s_bufs[4][2504 / 4 + 2];
-    s_crc[threadIdx.x] = A.T.crc[threadIdx.x];
-    for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) s_z[i] = A.T.crcz[i];
-    __syncthreads();
-    const JobRef jr = locate_job(blockIdx.x * 4 + (threadIdx.x >> 6), A.njobs);
-    if (!jr.ok) return;
-    const uint32_t f = A.joblist[jr.list * A.nrows + jr.idx];
+    L.crc[threadIdx.x] = A.T.crc[threadIdx.x];
+    for (int i = threadIdx.x; i < 6 * 8 * 16; i += 256) L.z[i] = A.T.crcz[i];
+    if (threadIdx.x < 127) {
+        const uint8_t* q = A.T.scr_seq; const uint32_t p = threadIdx.x;
+        L.seq4[p] = (uint32_t)q[p] | ((uint32_t)q[(p + 8u) % 127u] << 8) | ((uint32_t)q[(p + 16u) % 127u] << 16) | ((uint32_t)q[(p + 24u) % 127u] << 24);
+    }
+    if (threadIdx.x >= 128) L.phase[threadIdx.x - 128] = A.T.scr_phase[threadIdx.x - 128];
+}
+// one wave, frame row f
+__device__ __forceinline__ void finish_frame(const RxArgs& A, uint32_t f, FinishLds& lds)
+{
+    const uint32_t* s_crc = lds.crc; const uint32_t* s_z = lds.z; uint32_t (*s_bufs)[2504 / 4 + 2] = lds.bufs;
     FrameRow& r = A.frames[f];
     if (!r.valid || r.error_code != 0) return;
     const int lane = threadIdx.x & 63;
-    const Tables& T = A.T;
+    if (A.pipe_flags && A.pipe_flags[0] != 0u) {                                 // a hand-off inside k_pipe ran into its one-second bound: no result is better than a wrong one
+        if (lane == 0) r.error_code = E_INTERNAL_TIMEOUT;
+        return;
+    }
     uint32_t* s_buf = s_bufs[threadIdx.x >> 6];
-    const uint8_t* dec = A.vout + (size_t)r.slot0 * kOutPerSlot;
-    uint8_t* mp = A.mpdu + (size_t)r.slot0 * kOutPerSlot;
-    const uint32_t L = r.length;
-    const unsigned seed = dec[1] >> 1;                                           // byte 0 dropped, byte 1 >> 1 seeds the register
-    const unsigned phase = T.scr_phase[seed & 0x7F];                             // 255: seed 0 (sequence stays 0)
+    const uint32_t* dec32 = reinterpret_cast<const uint32_t*>(A.vout + (size_t)r.slot0 * kOutPerSlot);   // (32-byte aligned; the MPDU starts at its byte 2)
+    uint32_t* mp32 = reinterpret_cast<uint32_t*>(A.mpdu + (size_t)r.slot0 * kOutPerSlot);
+    const uint32_t L = min((uint32_t)r.length, 2500u), nwords = (L + 3u) / 4u;   // (k_scan queues nothing longer)
+    // Four bytes per lane and pass, every load of the frame in flight before the first is used (a byte per lane and pass with the store behind it was a memory round
+    // trip per 64 bytes: 22 of them in a row for fsample-6, most of what this kernel cost a lone capture).  Word w of the MPDU = bytes 2 + 4w .. 5 + 4w of the decoder's
+    // output: two aligned words and a byte shift.  The words past the frame's last byte carry garbage into the LDS copy and the MPDU array's slack; nothing reads them.
+    constexpr int kPasses = (2500 / 4 + 63) / 64;                                // 10
+    uint32_t lo[kPasses], hi[kPasses];
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) {
+        const uint32_t w = (uint32_t)lane + 64u * (uint32_t)k, wc = min(w, nwords);
+        lo[k] = dec32[wc]; hi[k] = dec32[wc + 1u];
+    }
+    const unsigned seed = (unsigned)__builtin_amdgcn_readfirstlane((int)lo[0]) >> 9;   // byte 0 dropped, byte 1 >> 1 seeds the register (lane 0 holds word 0)
+    const unsigned phase = lds.phase[seed & 0x7F];                               // 255: seed 0 (sequence stays 0)
     uint8_t* bytes = reinterpret_cast<uint8_t*>(s_buf);
-    for (uint32_t i = lane; i < L; i += 64) {
-        const unsigned sb = phase == 255 ? 0u : T.scr_seq[(phase + 8u * i) % 127u];
-        const unsigned o = dec[2 + i] ^ sb;
-        bytes[i] = (uint8_t)o;
-        mp[i] = (uint8_t)o;
+#pragma unroll
+    for (int k = 0; k < kPasses; k++) {
+        const uint32_t w = (uint32_t)lane + 64u * (uint32_t)k;
+        if (w < nwords) {
+            const uint32_t sb = phase == 255 ? 0u : lds.seq4[(phase + 32u * w) % 127u];   // scrambler byte j = seqbyte[(phase + 8 j) mod 127]
+            const uint32_t o = __builtin_amdgcn_alignbyte(hi[k], lo[k], 2u) ^ sb;
+            s_buf[w] = o;
+            mp32[w] = o;
+        }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();                                             // the LDS buffer is private to this wave
@@ -907,6 +1203,31 @@ __global__ void __launch_bounds__(256) k_finish(RxArgs A)
         r.crc32 = fcs;
         r.error_code = ((~crc) == fcs) ? E_FRAME_OK : E_CRC32_FAIL;              // PHY_11a.hpp:688-692
     }
+}
+
+__global__ void __launch_bounds__(256) k_finish(RxArgs A)
+{
+    __shared__ FinishLds L;
+    finish_tables_to_lds(A, L);
+    __syncthreads();
+    const JobRef jr = locate_job(blockIdx.x * 4 + (threadIdx.x >> 6), A.njobs);
+    if (!jr.ok) return;
+    finish_frame(A, A.joblist[jr.list * A.nrows + jr.idx], L);
+}
+
+// Behind the window-parallel trellis: k_win_redo AND k_finish as one launch -- the wave that holds a pair's proof (and decodes the pair again if it fails) descrambles and
+// checks its two frames itself.  A kernel boundary less for a lone capture (1.5 us of packet + the next kernel's ramp); the same work for a batch.
+__global__ void __launch_bounds__(256) k_win_redo_finish(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
+                                                         const uint16_t* __restrict__ vecs, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, unsigned long long* __restrict__ stats, RxArgs A)
+{
+    __shared__ FinishLds L;
+    finish_tables_to_lds(A, L);
+    __syncthreads();
+    auto after = [&](uint32_t list, uint32_t fa, uint32_t fb, bool hasB) {
+        finish_frame(A, A.joblist[list * A.nrows + fa], L);
+        if (hasB) finish_frame(A, A.joblist[list * A.nrows + fb], L);
+    };
+    viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, WinProofGate{ jobs, hdr, jstride, target, vstride, vecs, stats }, after);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -693,7 +693,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
 }  // namespace sora
 
 #ifdef SORA_SCAN_PROBE
-extern "C" int sora_debug_scan_probe(unsigned long long* out, int reset)
+extern "C" __attribute__((visibility("default"))) int sora_debug_scan_probe(unsigned long long* out, int reset)
 {
     if (hipMemcpyFromSymbol(out, HIP_SYMBOL(sora::g_scan_probe), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
     if (reset) { unsigned long long z[16] = {0}; (void)hipMemcpyToSymbol(HIP_SYMBOL(sora::g_scan_probe), z, sizeof(z)); }

@@ -57,6 +57,18 @@ struct RxArgs {
     uint32_t*       eq;             // [total_slots][64] equalised bins, packed COMPLEX16 (k_sym_front -> k_track, k_sym_back)
     TrackRec*       track;          // [total_slots] rotation parameters of a data symbol (k_track -> k_sym_back)
     uint32_t*       pil;            // [total_slots][4] the four pilot bins (43, 57, 7, 21) of eq[] once more, densely: all k_track reads
+    const uint32_t* pipe_flags;     // k_finish behind k_pipe: word 0 != 0 = a hand-off inside that launch gave up (else null)
+};
+
+// k_pipe (k_rx.hip): the data field of a handful of frames as ONE launch.  Workgroups [0, nfront) are k_sym_front's, [nfront, nfront + ntrack) one frame's tracker and
+// everything behind it each, the rest four waves of the window-parallel trellis.  flags (zeroed before every call): [0] a wait gave up; [4 + 4 f + h] quads of symbols
+// published by helper wave h of frame row f; [4 + 4 nrows + b] front workgroup b is done.
+struct PipeArgs {
+    uint32_t  nfront, ntrack;
+    uint32_t* flags;
+    uint32_t  target, vstride;     // the window-parallel trellis's unit target and its vectors' stride per code-rate list
+    uint16_t* vecs;
+    uint32_t  stamp_base;          // (tools variant, SORA_DBG_PIPE_TIMELINE: where the launch's time stamps go, in words from flags)
 };
 
 __global__ void k_scan(ScanArgs A);
@@ -65,6 +77,7 @@ __global__ void k_sym_front(RxArgs A);
 __global__ void k_track(RxArgs A);
 __global__ void k_track_lds(RxArgs A);
 __global__ void k_sym_back(RxArgs A);
+__global__ void k_pipe(RxArgs A, PipeArgs P);
 __global__ void k_decode(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
@@ -73,7 +86,9 @@ __global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint
 // k_vitwin.hip: the window-parallel trellis.  hdr = the call's counter block (njobs per code rate in its first three words); jstride = capacity of a list of jobs;
 // target = units the call is cut into at least, frames permitting; vstride = vectors per code-rate list
 __global__ void k_viterbi16w(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
-__global__ void k_win_redo(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats);   // k_rx.hip
+__global__ void k_win_redo(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats);
+__global__ void k_win_redo_finish(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats,
+                                  RxArgs A);   // ... and k_finish behind it, in the same waves   // k_rx.hip
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);

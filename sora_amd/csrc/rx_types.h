@@ -92,6 +92,7 @@ constexpr int kSoftSlack = 64;         // bytes behind the last stream that a re
 constexpr int kOutPerSlot  = 32;       // decoded bytes per symbol max 27 -> 32
 
 constexpr uint32_t E_FRAME_OK = 0x00000001u, E_PLCP_HEADER_FAIL = 0x80000005u, E_CRC32_FAIL = 0x80000006u,
-                   E_CS_TIMEOUT = 0x80000007u;
+                   E_CS_TIMEOUT = 0x80000007u,
+                   E_INTERNAL_TIMEOUT = 0x8000F001u;   // (SORA_E_INTERNAL_TIMEOUT, sora_hip.h: not one of the reference's codes)
 
 }  // namespace sora

@@ -15,6 +15,7 @@
 #include <thread>
 #include "../../include/sora_hip.h"
 #include "kernels.h"
+#include "dev_winplan.h"
 
 using namespace sora;
 
@@ -409,7 +410,9 @@ struct RxPipe {
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
     uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
     uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;   // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
-    bool split = false;                                         // symbol chain as k_sym_front -> k_track_lds -> k_sym_back (few frames in flight) instead of k_frame (one wave per frame)
+    int  front = 1;                                             // symbol chain: 1 = k_frame (one wave per frame), 3 = k_sym_front -> k_track_lds -> k_sym_back (few frames in flight),
+                                                                // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
+    uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed by every call's clear
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
                                                                 // 2 = k_viterbi16w + k_win_redo (the proof, and the serial decode of what fails it) (window-parallel, k_vitwin.hip)
@@ -446,6 +449,7 @@ struct RxPipe {
     unsigned only = 0xF;         // tool hook (sora_internal_rx_only): which kernels of the chain a call launches (1 scan, 2 frame, 4 trellis, 8 finish)
 };
 
+constexpr uint32_t kWinLoneWaves = 3 * sora::kWinLonePad / 8;   // waves a call may need on top of its units' eight per wave: a code-rate list of ONE frame is laid out with gaps (dev_winplan.h)
 constexpr uint32_t kWinUnitsTarget = 16384;                     // units a call of the window-parallel trellis is cut into at least, frames permitting: one round of the chip's 2048 eight-unit trellis slots
 // Probe hooks (which kernels of the chain a call launches, empty launches appended to a call, the calls' kernel boundaries on one time base, the device arrays between the
 // kernels) exist in the TOOLS variant of the library only -- sora_amd.build.build_variant("tools", ["SORA_TOOLS"]), loaded by the scripts under tools/ through SORA_HIP_LIB.
@@ -461,11 +465,13 @@ static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k
 static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
 
 namespace sora {
-__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16, uint4* __restrict__ ones = nullptr, uint32_t m16 = 0)   // n16 16-byte words <- 0, then m16 of `ones` <- all ones
+__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16, uint4* __restrict__ ones = nullptr, uint32_t m16 = 0,   // n16 16-byte words <- 0, then m16 of `ones` <- all ones,
+                                                 uint4* __restrict__ z2 = nullptr, uint32_t k16 = 0)                                             // then k16 of `z2` <- 0
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
     else if (i - n16 < m16) ones[i - n16] = make_uint4(0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu);
+    else if (i - n16 - m16 < k16) z2[i - n16 - m16] = make_uint4(0u, 0u, 0u, 0u);
 }
 }  // namespace sora
 
@@ -490,7 +496,7 @@ static void rx_free(RxPipe* rx)
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_fctx, rx->d_nframes,
                      rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil,
-                     rx->d_wvecs, rx->d_wstats };
+                     rx->d_wvecs, rx->d_wstats, rx->d_pflags };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -680,8 +686,13 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 #ifdef SORA_FRAME_SPLIT3
     const bool split = true;
 #else
-    const bool split = rx->split && !rx->fused;
+    const bool split = rx->front >= 3 && !rx->fused;
 #endif
+    const bool pipe = split && rx->front == 4 && rx->lanes16 == 2;               // (the handle only asks for k_pipe where its workgroups are all resident at once: pipe_fits)
+    if (pipe && !rx->d_pflags) {
+        rx->pflag_words = (4u + 4u * rx->cap_rows + (rx->cap_slots + 63u) / 64u + 4u + 3u) / 4u * 4u;
+        HIPCHK(hipMalloc((void**)&rx->d_pflags, 4 * ((size_t)rx->pflag_words + 1024)));   // (+ the tools variant's time stamps)
+    }
     if (split && !rx->d_slot_row) {                                              // the three-kernel symbol chain's arrays, on its first use: slot owners, equalised bins (256 B per slot), pilots, rotation parameters
         HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
         HIPCHK(hipMalloc((void**)&rx->d_eq, 256 * ((size_t)rx->cap_slots + 64)));
@@ -712,7 +723,9 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         {
             // ... and, for the three-kernel symbol chain, the slot owners (no symbol slot has an owner yet; only that chain reads them): the same launch
             const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16), m16 = split ? (slots + 3) / 4 : 0u;   // (the owners' array has 64 words of slack)
-            hipLaunchKernelGGL(k_clear16, dim3((n16 + m16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16, reinterpret_cast<uint4*>(rx->d_slot_row), m16);
+            const uint32_t k16 = pipe ? (4u + 4u * nrows + (slots + 63u) / 64u + 3u) / 4u : 0u;                                    // ... and k_pipe's hand-off words
+            hipLaunchKernelGGL(k_clear16, dim3((n16 + m16 + k16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16, reinterpret_cast<uint4*>(rx->d_slot_row), m16,
+                               reinterpret_cast<uint4*>(rx->d_pflags), k16);
         }
         }
         ScanArgs S{};
@@ -723,6 +736,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         if (RX_ONLY(rx, 1u)) hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
         RxArgs R{};
+        bool redo_finish = false;
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
         R.frames = rx->d_frames; R.fctx = rx->d_fctx;
         R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
@@ -736,6 +750,22 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 #endif
         {
             R.soft = rx->d_soft; R.jobs = rx->d_jobs; R.slot_row = rx->d_slot_row; R.eq = rx->d_eq; R.track = rx->d_track; R.pil = rx->d_pil;
+            redo_finish = rx->lanes16 == 2 && RX_ONLY(rx, 4u) && RX_ONLY(rx, 8u);
+            const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);   // the window-parallel trellis: a frame has at most 80 windows
+            if (pipe) {
+                R.pipe_flags = rx->d_pflags;
+                // a handful of frames: the symbol chain AND the window-parallel trellis as one launch (k_rx.hip: k_pipe), the proof behind it
+                if (RX_ONLY(rx, 2u)) {
+                    PipeArgs P{};
+                    P.nfront = (slots + 63) / 64; P.ntrack = nrows; P.flags = rx->d_pflags; P.target = kWinUnitsTarget; P.vstride = rx->wstride; P.vecs = rx->d_wvecs; P.stamp_base = rx->pflag_words;
+                    hipLaunchKernelGGL(k_pipe, dim3(P.nfront + P.ntrack + ((units_max + 7) / 8 + 3 + kWinLoneWaves + 3) / 4), dim3(256), 0, st, R, P);
+                }
+                mark();
+                if (RX_ONLY(rx, 4u) && !redo_finish)
+                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                                       (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
+                mark();
+            } else {
             if (split) {
                 // The symbol chain as three kernels (k_rx.hip): per symbol slot in front of and behind the tracker, per frame (four lanes each) for the tracker.  Round 4 built it
                 // (k_track, tables in L2) and did not adopt it: no faster than k_frame for a full batch (profiles/r04_h_*).  Round 5: the tracker with its tables in LDS
@@ -755,19 +785,24 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             else if (rx->lanes16 == 2) {
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), then the proof
                 // and the serial decode of the pairs of frames that fail it (none, normally: k_win_redo's waves check and return)
-                const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);   // (a frame has at most 80 windows)
-                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
                                    (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
-                hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
-                                   (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
+                if (!redo_finish)
+                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                                       (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
             }
             else if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
                 hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
             else
                 hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
+            }
         }
-        if (RX_ONLY(rx, 8u)) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
+        // (behind the window-parallel trellis the proof, the decode of what fails it and T11aDesc / the frame sink are ONE launch: the wave that holds a pair of frames finishes them)
+        if (redo_finish)
+            hipLaunchKernelGGL(k_win_redo_finish, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                               (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats, R);
+        else if (RX_ONLY(rx, 8u)) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
 #ifdef SORA_TOOLS
         for (unsigned x = 0; x < rx->extra; x++) hipLaunchKernelGGL(k_clear16, dim3(1), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), 0u);
 #endif
@@ -1052,22 +1087,36 @@ static int lanes16_for(const sora_rx* rx)                                       
 // The symbol chain: one wave per frame (k_frame) is the cheaper one when the chip is full of frames; the three-kernel chain spreads a frame's symbols over the
 // chip and runs the tracker's chain out of LDS: the one for few, long frames.
 constexpr long long kAutoSplitRows = 512;                       // frame rows in flight (depth x max_captures x max_frames_per_capture) up to which the automatic choice is the three-kernel chain
-static bool split_for(const sora_rx* rx)
+constexpr long long kAutoPipeRows = 16;                         // ... and up to which it is k_pipe (the chain and the window-parallel trellis as one launch), if that launch fits
+// k_pipe's workgroups wait for one another inside the launch: it is only used where ALL workgroups of ALL the handle's calls in flight are resident at once -- one per CU
+// (160 KB of LDS each), and a good part of the chip left to whatever else runs
+static bool pipe_fits(const sora_rx* rx)
 {
-    if (rx->front) return rx->front == 3;
-    return (long long)rx->depth * (long long)rx->cfg.max_captures * (long long)rx->cfg.max_frames_per_capture <= kAutoSplitRows;
+    const uint64_t str = rx->cfg.sample_rate_mhz == 20 ? 1 : 2, rows = (uint64_t)rx->cfg.max_captures * rx->cfg.max_frames_per_capture;
+    const uint64_t slots = rx->cfg.max_total_samples / str / 80 + rx->cfg.max_captures + 16;
+    const uint64_t units = std::min<uint64_t>(std::max<uint64_t>(kWinUnitsTarget, rows), 80ull * rows);
+    const uint64_t groups = (slots + 63) / 64 + rows + ((units + 7) / 8 + 3 + kWinLoneWaves + 3) / 4;
+    return groups * (uint64_t)rx->depth <= 192;
+}
+static int front_for(const sora_rx* rx)                                        // -> RxPipe::front
+{
+    if (rx->front == 1 || rx->front == 3) return rx->front;
+    const bool can_pipe = lanes16_for(rx) == 2 && pipe_fits(rx);
+    if (rx->front == 4) return can_pipe ? 4 : 3;
+    const long long rows = (long long)rx->depth * (long long)rx->cfg.max_captures * (long long)rx->cfg.max_frames_per_capture;
+    return rows <= kAutoPipeRows && can_pipe ? 4 : rows <= kAutoSplitRows ? 3 : 1;
 }
 int sora_rx_set_front(sora_rx_t* rx, int kernels)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     const int old = rx->front;
-    if (kernels == 0 || kernels == 1 || kernels == 3) {
+    if (kernels == 0 || kernels == 1 || kernels == 3 || kernels == 4) {
         rx->front = kernels;
         for (RxPipe* p : rx->pipes) if (p) p->last_valid = false;               // (a recorded hipGraph holds the other kernels)
-    } else if (kernels > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_front: 0 (automatic), 1 (k_frame) or 3 (k_sym_front, k_track_lds, k_sym_back)");
+    } else if (kernels > 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_set_front: 0 (automatic), 1 (k_frame), 3 (k_sym_front, k_track_lds, k_sym_back) or 4 (k_pipe)");
     return old;
 }
-int sora_rx_front(sora_rx_t* rx) { return rx ? (split_for(rx) ? 3 : 1) : SORA_ERR_INVALID_PARAM; }
+int sora_rx_front(sora_rx_t* rx) { return rx ? front_for(rx) : SORA_ERR_INVALID_PARAM; }
 
 int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
 {
@@ -1187,7 +1236,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    if (p->split != split_for(rx)) { p->split = split_for(rx); p->last_valid = false; }
+    if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1201,7 +1250,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    if (p->split != split_for(rx)) { p->split = split_for(rx); p->last_valid = false; }
+    if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1215,7 +1264,7 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    if (p->split != split_for(rx)) { p->split = split_for(rx); p->last_valid = false; }
+    if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1223,13 +1272,14 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
 
 #ifdef SORA_TOOLS
 // Test / tool hook (not part of the ABI in include/sora_hip.h): the device arrays between the kernels of the most recent call, for
-// stage-by-stage comparisons (tools/dbg_arrays.py).  out[] = { frames, slot_row, eq, track, soft, jobs, joblist, njobs }; *slots = symbol slots of the call.
+// stage-by-stage comparisons (tools/dbg_arrays.py).  out[] = { frames, slot_row, eq, track, soft, jobs, joblist, njobs, k_pipe's stamps }; *slots = symbol slots of the call.
 SORA_TOOL_HOOK int sora_internal_rx_arrays(sora_rx_t* rx, const void** out, uint32_t* slots, uint32_t* nrows)
 {
     if (!rx || !out) return SORA_ERR_INVALID_PARAM;
     RxPipe* p = rx->pipes[rx->cur];
     if (!p) return SORA_ERR_FAILED;
     out[0] = p->d_frames; out[1] = p->d_slot_row; out[2] = p->d_eq; out[3] = p->d_track; out[4] = p->d_soft; out[5] = p->d_jobs; out[6] = p->d_joblist; out[7] = p->d_njobs;
+    out[8] = p->d_pflags ? p->d_pflags + p->pflag_words : nullptr;               // k_pipe's time stamps (SORA_DBG_PIPE_TIMELINE)
     if (slots) *slots = p->total_slots;
     if (nrows) *nrows = p->ncaps * p->cfg.max_frames_per_capture;
     return SORA_OK;

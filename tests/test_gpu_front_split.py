@@ -73,7 +73,7 @@ def test_fsample6_and_the_automatic_choice(sora, torch_cuda, golden_dir):
     cap = pad_capture(iq, 40)
     rx = sora.Rx(max_captures=1, max_total_samples=len(cap), sample_rate_mhz=40, max_frames_per_capture=2)
     rx.set_depth(1)
-    assert rx.front() == 3 and rx.trellis() == sora.TRELLIS_WINDOWED             # a single capture: the chains that spread ONE frame over the chip
+    assert rx.front() == 4 and rx.trellis() == sora.TRELLIS_WINDOWED             # a single capture: the chain and the trellis spread over the chip as one launch (k_pipe; tests/test_gpu_pipe.py)
     rx.process_dev(torch_cuda.from_numpy(cap).cuda(), [(0, len(cap), 0)])
     got = rx.results()
     assert len(got) == 1 and got[0]["error_code"] == 1 and hashlib.sha256(got[0]["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"

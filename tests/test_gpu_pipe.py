@@ -1,0 +1,116 @@
+"""k_pipe (sora_rx_set_front(4), sora_amd/csrc/k_rx.hip): the symbol chain AND the window-parallel trellis of a handful of frames as ONE launch whose workgroups
+hand symbols on inside it -- front workgroups -> a frame's tracker (chain in wave 0, soft values made by waves 1-3 behind it) -> trellis waves that wait for the soft
+values they read.  Same rows and MPDU bytes as the oracle: random captures at both sample rates, frames of one to 835 symbols at every rate (the records' LDS ring wraps
+from 512 on), several frames per capture, frames that are noise behind an intact SIGNAL symbol (the units' proof fails: k_win_redo decodes them again), repeated and
+graph-replayed calls (every hand-off word is cleared by the call), several calls in flight; no frame is ever reported as SORA_E_INTERNAL_TIMEOUT."""
+import hashlib
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+from gpu_util import batch, make_capture, oracle_results, pad_capture, random_capture, same_results  # noqa: E402
+from oracle.pyoracle import RATES  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+E_INTERNAL_TIMEOUT = 0x8000F001
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def sora():
+    import sora_amd
+    sora_amd.load()
+    assert sora_amd.device_count() > 0
+    return sora_amd
+
+
+def run_pipe(sora, torch, caps, mhz, max_frames=4, depth=1):
+    iq, descs = batch(caps)
+    rx = sora.Rx(max_captures=max(1, len(caps)), max_total_samples=max(64, len(iq)), sample_rate_mhz=mhz, max_frames_per_capture=max_frames)
+    rx.set_depth(depth)
+    rx.set_front(4)
+    assert rx.front() == 4 and rx.trellis() == sora.TRELLIS_WINDOWED, (rx.front(), rx.trellis())
+    rx.process_dev(torch.from_numpy(iq).cuda(), descs)
+    res = rx.results()
+    rx.close()
+    assert all(r["error_code"] != E_INTERNAL_TIMEOUT for r in res)
+    return res
+
+
+def test_random_captures_equal_the_oracle(sora, torch_cuda, oracle):
+    rng = np.random.default_rng(20260928)
+    for mhz, n, reps in ((20, 1, 12), (40, 1, 12), (20, 3, 6), (40, 2, 6)):
+        for _ in range(reps):
+            caps = [random_capture(oracle, rng, mhz, multipath_p=0.2) for _ in range(n)]
+            ok, why = same_results(run_pipe(sora, torch_cuda, caps, mhz), oracle_results(oracle, caps, mhz))
+            assert ok, (mhz, n, why)
+
+
+def test_every_rate_one_symbol_to_835(sora, torch_cuda, oracle):
+    k = 0
+    for i, rate in enumerate(RATES):
+        for j, ln in enumerate((1, 7, 24, 47, 100, 511, 1500, 2500)):
+            if (i + j) % 2:
+                continue
+            cap = make_capture(oracle, rate, ln, seed=9000 + 16 * i + j, rate_mhz=20, sigma=(30, 200, 700, 1500)[(i + j) % 4], tail=160, cfo_hz=(-70e3, 0, 35e3)[j % 3])[0]
+            ok, why = same_results(run_pipe(sora, torch_cuda, [cap], 20, max_frames=2), oracle_results(oracle, [cap], 20))
+            assert ok, (rate, ln, why)
+            k += 1
+    assert k >= 30
+
+
+def test_frames_of_noise_are_decoded_again(sora, torch_cuda, oracle):
+    rng = np.random.default_rng(5)
+    caps = []
+    for i in range(4):
+        c = make_capture(oracle, (54000, 6000, 24000, 36000)[i], 1500, seed=100 + i, rate_mhz=20, sigma=50, tail=160)[0].astype(np.int32)
+        c[700:len(c) - 200] = np.rint(rng.normal(0, 2500, (len(c) - 900, 2)))   # the data field replaced by noise: SIGNAL stays intact
+        caps.append(np.clip(c, -32768, 32767).astype(np.int16))
+    iq, descs = batch(caps)
+    rx = sora.Rx(max_captures=4, max_total_samples=len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+    rx.set_depth(1); rx.set_front(4)
+    assert rx.front() == 4
+    rx.process_dev(torch_cuda.from_numpy(iq).cuda(), descs)
+    got = rx.results()
+    st = rx.window_stats()
+    rx.close()
+    ok, why = same_results(got, oracle_results(oracle, caps, 20))
+    assert ok, why
+    assert st["frames_decoded_again"] >= 1 and st["boundaries_failed"] >= 1, st
+
+
+def test_repeated_calls_graph_replay_and_calls_in_flight(sora, torch_cuda, oracle, golden_dir):
+    iq = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8
+    cap = pad_capture(iq, 40)
+    want = "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+    d = torch_cuda.from_numpy(cap).cuda()
+    one = [(0, len(cap), 0)]
+    rx = sora.Rx(max_captures=1, max_total_samples=len(cap), sample_rate_mhz=40, max_frames_per_capture=2)
+    assert rx.front() == 4 and rx.trellis() == sora.TRELLIS_WINDOWED             # a single capture, default depth: the automatic choice
+    for graph in (0, 1):
+        rx.set_graph(graph)
+        for _ in range(6):
+            res = rx.results(ticket=rx.process_dev(d, one))
+            assert len(res) == 1 and res[0]["error_code"] == 1 and hashlib.sha256(res[0]["mpdu"]).hexdigest() == want
+    rx.set_graph(0)
+    tickets = [rx.process_dev(d, one) for _ in range(8)]                         # eight calls in flight, every one k_pipe on its own stream
+    for t in tickets:
+        res = rx.results(ticket=t)
+        assert len(res) == 1 and res[0]["error_code"] == 1 and hashlib.sha256(res[0]["mpdu"]).hexdigest() == want
+    st = rx.window_stats()
+    assert st["boundaries_failed"] == 0 and st["frames_decoded_again"] == 0, st
+    rx.close()
+    # what does not fit runs as the three-kernel chain
+    big = sora.Rx(max_captures=256, max_total_samples=1 << 22, sample_rate_mhz=20, max_frames_per_capture=2)
+    big.set_depth(1); big.set_front(4)
+    assert big.front() == 3
+    big.close()

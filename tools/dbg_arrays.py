@@ -26,7 +26,7 @@ rx.process_dev(d, [(0, n, 0)])
 res = rx.results()
 print([(r["error_code"], r["rate_kbps"], r["length"], r["nsym"]) for r in res])
 L = capi.load()
-ptrs = (ctypes.c_void_p * 8)(); slots = ctypes.c_uint32(0); nrows = ctypes.c_uint32(0)
+ptrs = (ctypes.c_void_p * 9)(); slots = ctypes.c_uint32(0); nrows = ctypes.c_uint32(0)
 L.sora_internal_rx_arrays.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_void_p), ctypes.POINTER(ctypes.c_uint32), ctypes.POINTER(ctypes.c_uint32)]
 assert L.sora_internal_rx_arrays(rx._h, ptrs, ctypes.byref(slots), ctypes.byref(nrows)) == 0
 S = slots.value

@@ -16,9 +16,15 @@ import sora_amd
 from oracle.pyoracle import Oracle
 import bench
 o = Oracle()
-n = 4096
-iq, descs, _ = bench.make_workload(o, n, 0, distinct=64)
-rx = sora_amd.Rx(n, len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
+if "--fsample6" in sys.argv:                                               # the single capture of BASELINE configs[1] instead (40 MHz, one 6 Mbps frame of 465 symbols)
+    g = np.load(os.path.join(ROOT, "tests", "golden", "fsample6_40mhz_i8.npz"))
+    iq = g["iq_i8"].astype(np.int16) << 8
+    iq = np.ascontiguousarray(iq[:len(iq) // 28 * 28]); n = 1; descs = [(0, len(iq), 0)]
+    rx = sora_amd.Rx(1, len(iq), sample_rate_mhz=40, max_frames_per_capture=2)
+else:
+    n = 4096
+    iq, descs, _ = bench.make_workload(o, n, 0, distinct=64)
+    rx = sora_amd.Rx(n, len(iq), sample_rate_mhz=20, max_frames_per_capture=2)
 rx.set_depth(1)
 d = torch.from_numpy(iq).cuda()
 for _ in range(3):

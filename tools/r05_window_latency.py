@@ -60,7 +60,7 @@ def main():
     rx.set_depth(1)
     one = [(0, n, 0)]
     single = {}
-    for front, lanes in ((1, 64), (1, 16), (1, 1), (3, 64), (3, 1)):
+    for front, lanes in ((1, 64), (1, 16), (1, 1), (3, 64), (3, 1), (4, 1)):
         rx.set_front(front); rx.set_trellis(lanes); rx.flush()
         t = rx.process_dev(d, one); res = rx.results(ticket=t)
         ok = len(res) == 1 and res[0]["error_code"] == 1 and hashlib.sha256(res[0]["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
@@ -80,7 +80,8 @@ def main():
         for _ in range(10):
             rx.wait(rx.process_dev(d, one))
         rx.flush(); kt = rx.kernel_times(); rx.set_profiling(False)
-        single[("k_frame" if front == 1 else "k_sym_front+k_track_lds+k_sym_back") + " | " + names[lanes]] = {
+        assert rx.front() == front, (rx.front(), front)
+        single[("k_pipe (k_sym_front, k_track_lds, k_sym_back, k_viterbi16w in one launch)" if front == 4 else ("k_frame" if front == 1 else "k_sym_front+k_track_lds+k_sym_back") + " | " + names[lanes])] = {
             "decode_ms": round(float(np.median(ts)) * 1e3, 4), "min_ms": round(float(np.min(ts)) * 1e3, 4), "decode_ms_as_one_graph_launch": round(float(np.median(tg)) * 1e3, 4),
             "mpdu_sha256_ok": bool(ok), "kernel_ms": {k: round(v, 4) for k, v in kt.items()}}
     single["window_stats"] = rx.window_stats()
