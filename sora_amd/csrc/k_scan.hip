@@ -296,6 +296,12 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     const uint32_t nunits = (cd.nsamples / APP) * APP;
     const Tables& T = A.T;
     const ScanTabs tabs = { T.uatan2, T.rot, T.demap, T.deint, T.tw64, T.tw16 };
+    // the fills a call used to get from a kernel of their own in front of this one (kernels.h ScanArgs): nobody reads any of these words before this kernel has ended
+    if (A.own_slots && A.slot_row) for (uint32_t i = (uint32_t)lane; i < cd.nslots; i += 64u) A.slot_row[cd.slot_base + i] = 0xFFFFFFFFu;
+    if (cap_i == 0) {
+        if (A.zero_a) for (uint32_t i = (uint32_t)lane; i < A.nzero_a; i += 64u) A.zero_a[i] = 0u;
+        if (A.zero_b) for (uint32_t i = (uint32_t)lane; i < A.nzero_b; i += 64u) A.zero_b[i] = 0u;
+    }
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
     uint32_t Hv = 0;                         // sample_his in TIME ORDER, one packed sample per lane (lane & 15, oldest = 0): 4 bursts of 4, already >>2

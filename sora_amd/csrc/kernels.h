@@ -35,6 +35,11 @@ struct ScanArgs {
     // stream continuation (sora_rx_set_stream_mode): capture k of this call continues capture k of the call before it
     uint32_t*       cont;       // [ncaps][kContWords] the carrier-sense state at the capture's last resume point (read at entry when valid, rewritten at every later one); null = off
     uint32_t*       consumed;   // [ncaps] input-rate samples of this capture that are final: the host submits the stream from there on next time
+    // what the NEXT call needs cleared, done here instead of by a fill kernel in front of every call (sora_hip.cpp: a pipeline's calls alternate between two sets of
+    // job counters; workgroup 0 zeroes the set this call does not use, and k_pipe's hand-off words): null = the host's fill has done it
+    uint32_t*       zero_a; uint32_t nzero_a;
+    uint32_t*       zero_b; uint32_t nzero_b;
+    uint32_t        own_slots;  // 1: every capture's workgroup presets its own symbol slots' owners (0xFFFFFFFF) itself
 };
 constexpr int kContWords = 64;
 

@@ -412,7 +412,11 @@ struct RxPipe {
     uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;   // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
     int  front = 1;                                             // symbol chain: 1 = k_frame (one wave per frame), 3 = k_sym_front -> k_track_lds -> k_sym_back (few frames in flight),
                                                                 // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
-    uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed by every call's clear
+    uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed for every call
+    // A call needs its job counters zero, k_pipe's words zero and (three-kernel chain) no symbol slot owned: the call BEFORE it on this pipeline arranges that inside its k_scan
+    // (the pipeline's calls alternate between two sets of counters, words 0-3 and 8-11 of the 64-byte block in front of the frame table) -- no fill kernel in front of a call
+    // unless counters_ready says that nothing has: the first call, a call recorded into a hipGraph (its arguments are frozen: it always uses set 0 behind its own fill)
+    uint32_t parity = 0; bool counters_ready = false;
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
     int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
                                                                 // 2 = k_viterbi16w + k_win_redo (the proof, and the serial decode of what fails it) (window-parallel, k_vitwin.hip)
@@ -716,22 +720,33 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     }
     const uint32_t nrows = rx->ncaps * rx->cfg.max_frames_per_capture;
 
-    auto enqueue = [&]() -> int {                                                // the kernel chain of one call, in stream order
-        if (RX_ONLY(rx, 1u)) {
-        // the job counters and the frame table behind them: ONE fill (every packet of a call costs the command processor a few microseconds, and a call is a dozen
-        // of them: DESIGN.md section 3.6) -- by a kernel of this library: a hipMemsetAsync of 64 + 64 n bytes recorded into a hipGraph faults on replay
-        {
-            // ... and, for the three-kernel symbol chain, the slot owners (no symbol slot has an owner yet; only that chain reads them): the same launch
+    auto enqueue = [&](bool recording) -> int {                                  // the kernel chain of one call, in stream order (recording: into a hipGraph)
+#ifdef SORA_TOOLS
+        const bool self_clean = false;                                           // (the tools variant's partial chains and array dumps want the plain protocol: a fill in front of every call)
+#else
+        const bool self_clean = !recording && !rx->fused;
+#endif
+        const bool fill = !self_clean || !rx->counters_ready;
+        const uint32_t par = fill ? 0u : rx->parity;
+        uint32_t* const counters = rx->d_njobs + 8u * par;
+        const uint32_t pipe_words = pipe ? 4u + 4u * nrows + (slots + 63u) / 64u : 0u;
+        if (fill && RX_ONLY(rx, 1u)) {
+            // the job counters and the frame table behind them, the slot owners (no symbol slot has an owner yet; only the three-kernel chain reads them) and k_pipe's hand-off
+            // words: ONE fill (every packet of a call costs the command processor a few microseconds: DESIGN.md section 3.6) -- by a kernel of this library: a hipMemsetAsync
+            // of 64 + 64 n bytes recorded into a hipGraph faults on replay
             const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16), m16 = split ? (slots + 3) / 4 : 0u;   // (the owners' array has 64 words of slack)
-            const uint32_t k16 = pipe ? (4u + 4u * nrows + (slots + 63u) / 64u + 3u) / 4u : 0u;                                    // ... and k_pipe's hand-off words
+            const uint32_t k16 = (pipe_words + 3u) / 4u;
             hipLaunchKernelGGL(k_clear16, dim3((n16 + m16 + k16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16, reinterpret_cast<uint4*>(rx->d_slot_row), m16,
                                reinterpret_cast<uint4*>(rx->d_pflags), k16);
-        }
         }
         ScanArgs S{};
         S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
-        S.njobs = rx->d_njobs; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = split ? rx->d_slot_row : nullptr; S.cont = rx->cont; S.consumed = rx->consumed;
+        S.njobs = counters; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = split ? rx->d_slot_row : nullptr; S.cont = rx->cont; S.consumed = rx->consumed;
+        if (self_clean) {                                                        // this call's k_scan prepares the next one's (and its own slot owners and hand-off words)
+            S.zero_a = rx->d_njobs + 8u * (1u - par); S.nzero_a = 4; S.zero_b = pipe ? rx->d_pflags : nullptr; S.nzero_b = pipe_words; S.own_slots = 1;
+        }
+        rx->parity = self_clean ? 1u - par : 0u; rx->counters_ready = self_clean;
         mark();
         if (RX_ONLY(rx, 1u)) hipLaunchKernelGGL(k_scan, dim3(rx->ncaps), dim3(64), 0, st, S);
         mark();
@@ -739,7 +754,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         bool redo_finish = false;
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
         R.frames = rx->d_frames; R.fctx = rx->d_fctx;
-        R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = rx->d_njobs; R.joblist = rx->d_joblist;
+        R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = counters; R.joblist = rx->d_joblist;
 #ifdef SORA_WITH_K_DECODE
         if (rx->fused) {
             // the data field of every frame, samples -> decoded bytes, in one kernel: two frames per trellis wave, two pairs per
@@ -762,7 +777,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                 }
                 mark();
                 if (RX_ONLY(rx, 4u) && !redo_finish)
-                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
                                        (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
                 mark();
             } else {
@@ -785,22 +800,22 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             else if (rx->lanes16 == 2) {
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), then the proof
                 // and the serial decode of the pairs of frames that fail it (none, normally: k_win_redo's waves check and return)
-                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
                                    (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
                 if (!redo_finish)
-                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
                                        (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
             }
             else if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
-                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
+                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
             else
-                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
+                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
             mark();
             }
         }
         // (behind the window-parallel trellis the proof, the decode of what fails it and T11aDesc / the frame sink are ONE launch: the wave that holds a pair of frames finishes them)
         if (redo_finish)
-            hipLaunchKernelGGL(k_win_redo_finish, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)rx->d_njobs, nrows, kWinUnitsTarget, rx->wstride,
+            hipLaunchKernelGGL(k_win_redo_finish, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
                                (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats, R);
         else if (RX_ONLY(rx, 8u)) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
 #ifdef SORA_TOOLS
@@ -820,7 +835,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     if (rx->use_graph && !prof && repeat) {
         if (!rx->graph_exec) {                                                   // second identical call: record the chain
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                const int rc = enqueue();
+                const int rc = enqueue(true);
                 hipGraph_t g = nullptr;
                 const hipError_t e2 = hipStreamEndCapture(st, &g);
                 if (rc == SORA_OK && e2 == hipSuccess && g && hipGraphInstantiate(&rx->graph_exec, g, nullptr, nullptr, 0) == hipSuccess) rx->graph = g;
@@ -829,7 +844,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         }
         if (rx->graph_exec) { HIPCHK(hipGraphLaunch(rx->graph_exec, st)); launched = true; }
     }
-    if (!launched) { const int rc = enqueue(); if (rc) return rc; }
+    if (!launched) { const int rc = enqueue(false); if (rc) return rc; }
     HIPCHK(hipGetLastError());
     rx->ev_valid = prof;
     rx->have_results = true;
