@@ -367,7 +367,7 @@ def main():
                          "whole_path_frac": round(msps * 1e6 / world * ALG_BYTES_PER_SAMPLE / HBM_PEAK, 5),
                          "other_trellis_kernels": {tname[l]: {"kernel_ms": round(kt[tname[l]], 4), "frac": round(launch_bytes / (kt[tname[l]] * 1e-3) / HBM_PEAK, 5)} for l, kt in ktimes1_others.items()},
                          "other_trellis_kernels_note": "sora_rx_set_trellis, each alone on the chip: k_viterbi = two frames per wave, k_viterbi16 = eight per wave (the one for 32768 and more captures in flight), k_viterbi16w = the frames' "
-                                                       "trace-back windows decoded side by side and proven afterwards, with k_win_redo (the proof) in its time (the one below that; the automatic choice follows depth x max_captures)",
+                                                       "trace-back windows decoded side by side and proven afterwards (the one below that; the automatic choice follows depth x max_captures; the proof runs in the waves of the finishing kernel, k_win_redo_finish)",
                          "valu": valu_roofline(nfr, ms_per_step)},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},

@@ -33,9 +33,10 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
     rx.wait_for_producer = False
     ok = len(res) == 1 and res[0]["error_code"] == sora_amd.E_FRAME_OK and hashlib.sha256(res[0]["mpdu"]).hexdigest() == "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
     per = {}
-    chains = {1: "k_frame", 3: "k_sym_front+k_track_lds+k_sym_back"}
-    for front, lanes in ((1, 64), (1, 16), (1, 1), (3, 64), (3, 1)):
+    chains = {1: "k_frame", 3: "k_sym_front+k_track_lds+k_sym_back", 4: "k_pipe (k_sym_front, k_track_lds, k_sym_back and the trellis as one launch)"}
+    for front, lanes in ((1, 64), (1, 16), (1, 1), (3, 64), (3, 1), (4, 1)):
         rx.set_front(front); rx.set_trellis(lanes); rx.flush()
+        assert rx.front() == front, (rx.front(), front)
         ok = ok and [r["mpdu"] for r in rx.results(ticket=rx.process_dev(d, one))] == [res[0]["mpdu"]]
         for _ in range(5):
             rx.wait(rx.process_dev(d, one))
@@ -43,7 +44,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
         for _ in range(reps):
             t0 = time.perf_counter(); rx.wait(rx.process_dev(d, one)); ts.append(time.perf_counter() - t0)
         per[chains[front] + " | " + TRELLIS_NAMES[lanes]] = float(np.median(ts)) * 1e3
-    rx.set_front(0); rx.set_trellis(0); rx.flush()                             # the library's own choice for a lone capture: the chains that spread ONE frame over the chip
+    rx.set_front(0); rx.set_trellis(0); rx.flush()                             # the library's own choice for a lone capture: the chain and the trellis spread over the chip as ONE launch
     auto = chains[rx.front()] + " | " + TRELLIS_NAMES[rx.trellis()]
     rx.set_profiling(True)
     for _ in range(10):
@@ -56,7 +57,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
         "air_time_ms": round(air_ms, 4), "decode_ms": round(per[auto], 4), "kernels": auto + " (the library's automatic choice)", "decode_ms_by_kernels": {k: round(v, 4) for k, v in per.items()},
         "decode_ms_best": round(best, 4),
         "realtime_factor": round(per[auto] / air_ms, 4), "kernel_ms": {k: round(v, 4) for k, v in kt.items()},
-        "kernel_ms_note": "the library's five timed intervals of the automatic chain: 'k_frame' = k_sym_front + k_track_lds + k_sym_back, 'k_viterbi' = k_viterbi16w + k_win_redo",
+        "kernel_ms_note": "the library's five timed intervals of the automatic chain: 'memset+caps' = nothing but the first packet's way to the GPU (the fill kernel is gone), 'k_frame' = k_pipe (symbol chain + window-parallel trellis), 'k_viterbi' = nothing, 'k_finish' = k_win_redo_finish (the units' proof, T11aDesc, the frame sink)",
         "window_trellis_record": wstats, "mpdu_sha256_ok": bool(ok),
         "protocol": "sora_rx_process_dev + sora_rx_wait, one call in flight, samples resident in HBM; median of %d calls (host wall clock)" % reps}
     ref = ReferenceGraph()

@@ -22,7 +22,9 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--batch", type=int, default=100)
     ap.add_argument("--trellis", type=int, default=0, help="0: the library's choice (the window-parallel kernel for batches this small), 1: k_viterbi16w, 16: k_viterbi16, 64: k_viterbi")
-    ap.add_argument("--front", type=int, default=0, help="0: the library's choice, 1: k_frame, 3: k_sym_front -> k_track_lds -> k_sym_back")
+    ap.add_argument("--front", type=int, default=0, help="0: the library's choice, 1: k_frame, 3: k_sym_front -> k_track_lds -> k_sym_back, 4: k_pipe (needs few rows in flight: --batch 1 or 2, --depth 1)")
+    ap.add_argument("--depth", type=int, default=0, help="calls in flight the handle is sized for (0: its default)")
+    ap.add_argument("--max-frames", type=int, default=8)
     ap.add_argument("--noise-frames", type=float, default=0.0, help="share of captures whose data field is replaced by noise behind an intact SIGNAL symbol (the window-parallel trellis's proof fails: the serial path)")
     args = ap.parse_args()
     import torch
@@ -39,11 +41,14 @@ def main():
                 c = caps[i].astype(np.int32); a = (700 if mhz == 20 else 1400); c[a:len(c) - 200] = np.rint(rng.normal(0, 2500, (len(c) - 200 - a, 2)))
                 caps[i] = np.clip(c, -32768, 32767).astype(np.int16)
         iq, descs = batch(caps)
-        rx = sora_amd.Rx(len(caps), len(iq), sample_rate_mhz=mhz, max_frames_per_capture=8)
+        rx = sora_amd.Rx(len(caps), len(iq), sample_rate_mhz=mhz, max_frames_per_capture=args.max_frames)
+        if args.depth:
+            rx.set_depth(args.depth)
         if args.trellis:
             rx.set_trellis(args.trellis)
         if args.front:
             rx.set_front(args.front)
+            assert rx.front() == args.front, "the handle does not run front %d in this shape (it would run %d)" % (args.front, rx.front())
         rx.process_dev(torch.from_numpy(iq).cuda(), descs)
         got = rx.results()
         for k, v in rx.window_stats().items():

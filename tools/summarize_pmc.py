@@ -43,7 +43,7 @@ def main():
            "kernels": {}}
     total = 0.0
     trellis = sys.argv[5] if len(sys.argv) > 5 else "k_viterbi16"             # the trellis kernel of the call being summed (the run also holds a few launches of the other one)
-    rx_path = ("k_scan", "k_frame", trellis, "k_decode", "k_finish") + (("k_win_redo",) if trellis == "k_viterbi16w" else ())           # one receive call (split or fused chain); other kernels (k_pack, ingest, tx) are listed only
+    rx_path = ("k_scan", "k_frame", trellis, "k_decode", "k_finish") + (("k_win_redo", "k_win_redo_finish") if trellis == "k_viterbi16w" else ())           # one receive call (split or fused chain); other kernels (k_pack, ingest, tx) are listed only
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("k_"):
             continue
