@@ -215,7 +215,8 @@ private:
 
 // T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization (PHY_11a.hpp:361-430, channel_11a.hpp:532-653) as one brick:
 // IPORT COMPLEX16 x 80 -> OPORT COMPLEX16 x 64, N symbols per burst, bound to the frame's T11aLTS record.
-struct CallSymFront11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_symfront11a(in, d_ctx, nullptr, out, n, st); } };
+struct CallSymFront11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out,
+        void* st) const { return sora_hip_symfront11a(in, d_ctx, nullptr, out, n, st); } };
 template <size_t N, class T_CTX, class T_NEXT>
 struct THip11aSymFront : THipStage<sora_complex16, 80 * N, sora_complex16, 64 * N, CallSymFront11a, T_CTX, T_NEXT> {
     THip11aSymFront(T_CTX& ctx, T_NEXT* next, const sora_lts11a_ctx* d_ctx, sora_complex16* d_out, void* stream = nullptr)
@@ -226,9 +227,12 @@ struct THip11aSymFront : THipStage<sora_complex16, 80 * N, sora_complex16, 64 * 
 //   THipFreqCompensation     TFreqCompensation     (channel_11a.hpp:614-653)   bound to the frame's T11aLTS record (CF_FreqCompensate::Coeffs)
 //   THipChannelEqualization  TChannelEqualization  (channel_11a.hpp:534-604)   bound to the same record (CF_Channel_11a::ChannelCoeffs)
 //   THipPhaseCompensate      TPhaseCompensate      (freqoffset.hpp:16-66)      bound to the tracker's state (CF_PhaseCompensate::CompCoeffs = sora_track11a_state::comp)
-struct CallFreqComp11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_freq_comp11a(in, d_ctx, nullptr, out, n, st); } };
-struct CallEqualize11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_equalize11a(in, d_ctx, nullptr, out, n, st); } };
-struct CallPhaseComp11a { const sora_track11a_state* d_state; size_t n; int operator()(const sora_complex16* in, sora_complex16* out, void* st) const { return sora_hip_phase_comp11a(in, d_state, nullptr, out, n, st); } };
+struct CallFreqComp11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out,
+        void* st) const { return sora_hip_freq_comp11a(in, d_ctx, nullptr, out, n, st); } };
+struct CallEqualize11a { const sora_lts11a_ctx* d_ctx; size_t n; int operator()(const sora_complex16* in, sora_complex16* out,
+        void* st) const { return sora_hip_equalize11a(in, d_ctx, nullptr, out, n, st); } };
+struct CallPhaseComp11a { const sora_track11a_state* d_state; size_t n; int operator()(const sora_complex16* in, sora_complex16* out,
+        void* st) const { return sora_hip_phase_comp11a(in, d_state, nullptr, out, n, st); } };
 template <size_t N, class T_CTX, class T_NEXT>
 struct THipFreqCompensation : THipStage<sora_complex16, 64 * N, sora_complex16, 64 * N, CallFreqComp11a, T_CTX, T_NEXT> {
     THipFreqCompensation(T_CTX& ctx, T_NEXT* next, const sora_lts11a_ctx* d_ctx, sora_complex16* d_out, void* stream = nullptr)
@@ -272,7 +276,8 @@ public:
     template <class T_IPIN> bool Process(T_IPIN& ipin)
     {
         while (ipin.check_read()) {
-            if (got_ < nsym_ && sora_hip_memcpy_d2d(d_soft_ + (size_t)got_ * 48 * N_BPSC, ipin.peek(), 48 * N_BPSC, this->stream_) != SORA_OK) return this->raise(SORA_ERR_HARDWARE_FAILED);
+            if (got_ < nsym_ && sora_hip_memcpy_d2d(d_soft_ + (size_t)got_ * 48 * N_BPSC, ipin.peek(), 48 * N_BPSC,
+                    this->stream_) != SORA_OK) return this->raise(SORA_ERR_HARDWARE_FAILED);
             ipin.pop();
             if (++got_ == nsym_) {
                 const uint32_t tab[4] = { 0u, nsym_ * 48u * (uint32_t)N_BPSC, (uint32_t)len_, 0u };   // soft_off, nsoft, frame_len (uint16), out_off
@@ -371,7 +376,8 @@ public:
     ~THipRx11nSource() { if (rx_) sora_rx11n_destroy(rx_); }
     THipRx11nSource(const THipRx11nSource&) = delete;
     THipRx11nSource& operator=(const THipRx11nSource&) = delete;
-    void Bind(const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps) { d_iq_[0] = d_iq0; d_iq_[1] = d_iq1; caps_ = caps; ncaps_ = ncaps; }
+    void Bind(const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps) { d_iq_[0] = d_iq0; d_iq_[1] = d_iq1;
+        caps_ = caps; ncaps_ = ncaps; }
     bool Process()
     {
         if (!rx_) return false;

@@ -397,13 +397,16 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
  * further calls have been made, or until the call is released: delivered and waited for, see sora_rx_wait_any); an input buffer must stay untouched until the call that reads it has finished.  sora_rx11n_set_depth returns the
  * previous value (depth <= 0 only queries) and waits for the calls in flight; sora_rx11n_process (host buffers) also does. */
 int   sora_rx11n_set_depth(sora_rx11n_t* rx, int depth);
-int   sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair);                                     /* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
+/* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
+int   sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair);
 int   sora_rx11n_ticket(sora_rx11n_t* rx);
 int   sora_rx11n_synchronize(sora_rx11n_t* rx);                                                       /* every call issued so far has finished */
 int   sora_rx11n_wait(sora_rx11n_t* rx, int ticket);
-int   sora_rx11n_wait_any(sora_rx11n_t* rx, int* ticket);                                             /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is then released and its pipeline reused first */
+/* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is then released and its pipeline reused first */
+int   sora_rx11n_wait_any(sora_rx11n_t* rx, int* ticket);
 int   sora_rx11n_results_of(sora_rx11n_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
-int   sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);   /* as sora_rx11b_deliver_async */
+/* as sora_rx11b_deliver_async */
+int   sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap);
 
 /* ------------------------------------------------------------------------------------------------
  * The data field of an HT-mixed 40 MHz, two-stream frame (BASELINE.json configs[3]: 128-point FFT, MMSE MIMO detection, one decoder per
@@ -429,10 +432,12 @@ typedef struct {
 } sora_ht40_frame;
 typedef struct sora_ht40 sora_ht40_t;
 uint32_t sora_ht40_symbols(uint32_t length0, uint32_t length1, uint32_t n_bpsc, uint32_t code_rate);   /* data symbols of such a frame (0: bad arguments) */
-int   sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out);  /* max_soft_values >= sum over frames of 2 x nsym x 108 n_bpsc (+ 64 per frame) */
+/* max_soft_values >= sum over frames of 2 x nsym x 108 n_bpsc (+ 64 per frame) */
+int   sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, sora_ht40_t** out);
 void  sora_ht40_destroy(sora_ht40_t* rx);
 void* sora_ht40_stream(sora_ht40_t* rx);                                                               /* the stream of the most recent process call */
-int   sora_ht40_set_trellis(sora_ht40_t* rx, int lanes_per_pair);                                       /* 16 (default: the handle keeps eight calls in flight) / 64: as sora_rx_set_trellis (the two streams of a frame are one pair) */
+/* 16 (default: the handle keeps eight calls in flight) / 64: as sora_rx_set_trellis (the two streams of a frame are one pair) */
+int   sora_ht40_set_trellis(sora_ht40_t* rx, int lanes_per_pair);
 int   sora_ht40_synchronize(sora_ht40_t* rx);                                                          /* every call issued so far has finished (a handle keeps eight calls in flight:
                                                                                                         * process_dev waits only for the call eight calls back; results reports the most recent one) */
 int   sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* h_frames, size_t nframes, sora_complex16* d_weights);
@@ -458,7 +463,8 @@ int   sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq
 int   sora_ht40_ticket(sora_ht40_t* rx);                       /* ticket of the most recent process call (0: none) */
 int   sora_ht40_calls_in_flight(sora_ht40_t* rx);              /* how many calls the handle keeps addressable */
 int   sora_ht40_wait(sora_ht40_t* rx, int ticket);
-int   sora_ht40_wait_any(sora_ht40_t* rx, int* ticket);                                               /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
+/* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
+int   sora_ht40_wait_any(sora_ht40_t* rx, int* ticket);
 void* sora_ht40_stream_of(sora_ht40_t* rx, int ticket);
 int   sora_ht40_results_of(sora_ht40_t* rx, int ticket, sora_frame_result* h_out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* As sora_rx11b_deliver_async.  The delivered table is the one sora_ht40_results_of reports, in (capture, time) order: two rows per RECORDED frame
@@ -540,7 +546,8 @@ int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls
  * previous setting (0, 1 or 2). */
 int   sora_rx11b_set_single_pass(sora_rx11b_t* rx, int enable);
 int   sora_rx11b_wait(sora_rx11b_t* rx, int ticket);
-int   sora_rx11b_wait_any(sora_rx11b_t* rx, int* ticket);                                             /* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
+/* as sora_rx_wait_any: the oldest FINISHED call with an enqueued delivery; it is released and its slot reused first */
+int   sora_rx11b_wait_any(sora_rx11b_t* rx, int* ticket);
 void* sora_rx11b_stream_of(sora_rx11b_t* rx, int ticket);
 int   sora_rx11b_results_of(sora_rx11b_t* rx, int ticket, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* Result delivery without a host wait (as sora_rx_deliver_async): behind the call's kernels, on its stream, the dense rows in (capture, time)

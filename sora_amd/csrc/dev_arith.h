@@ -80,7 +80,8 @@ struct Tables {
 // from the full tables and checks that they reproduce EVERY entry before it uploads them (sora_hip.cpp: trk_tables_exact).
 struct TrkTables {
     int16_t  q[16392];           // usin[0 .. 16384] (padded to a multiple of 16 bytes)
-    uint32_t e2s[4096];          // two bits per angle a, at bit 2 (a & 15) of word a >> 4: usin[a] minus the mirrored quarter wave, as a signed two-bit number (0, +1, -1)
+    // two bits per angle a, at bit 2 (a & 15) of word a >> 4: usin[a] minus the mirrored quarter wave, as a signed two-bit number (0, +1, -1)
+    uint32_t e2s[4096];
     uint32_t e2c[4096];          // the same for ucos[a] against the quarter wave mirrored for a + 16384
     int16_t  h[129 * 256];       // uatan2[y][x & 0xFF] for y = 0 .. 127; row 128 = -uatan2[-128][..]: uatan2(y < 0, x) = -h[-y][x & 0xFF]
 };
@@ -97,7 +98,8 @@ template <typename TBL> __host__ __device__ inline int trk_ucos(const TBL& t, un
     const int mc = -(int)(((a >> 15) ^ (a >> 14)) & 1u);
     return ((t.q[16384 - trk_quarter_index(a)] ^ mc) - mc) + trk_sext2(t.e2c[a >> 4], a);
 }
-template <typename TBL> __host__ __device__ inline int trk_uatan2_entry(const TBL& t, int ys, int xs)   // uatan2_lut[(ys & 0xFF) * 256 + (xs & 0xFF)], ys in -128 .. 127
+// uatan2_lut[(ys & 0xFF) * 256 + (xs & 0xFF)], ys in -128 .. 127
+template <typename TBL> __host__ __device__ inline int trk_uatan2_entry(const TBL& t, int ys, int xs)
 {
     const int sy = ys >> 31, r = (ys ^ sy) - sy, v = t.h[r * 256 + (xs & 0xFF)];
     return (v ^ sy) - sy;
@@ -229,7 +231,8 @@ __device__ __forceinline__ Fft128Tw fft128_twiddles(const Tables& T, int e)
     return Fft128Tw{ { T.tw128[e], T.tw128[32 + e], T.tw128[64 + e] }, { T.tw32[j], T.tw32[8 + j], T.tw32[16 + j] }, { T.tw8[0], T.tw8[1], T.tw8[2], T.tw8[3] } };
 }
 template <bool INV, typename SYNC>
-__device__ __forceinline__ void fft128_core(const cpx x[4], uint32_t* s, int e, const Fft128Tw& T, SYNC sync)   // result left in s[]: point j at slot bitrev7(j)
+// result left in s[]: point j at slot bitrev7(j)
+__device__ __forceinline__ void fft128_core(const cpx x[4], uint32_t* s, int e, const Fft128Tw& T, SYNC sync)
 {
     sync();
     {   // stage N=128: butterfly e on points e, e+32, e+64, e+96
@@ -285,8 +288,10 @@ __device__ __forceinline__ void fft128_group(const cpx x[4], cpx y[4], uint32_t*
 typedef short s16x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t pcx;                                          // packed COMPLEX16
 __device__ __forceinline__ pcx pk_sra(pcx a, int n) { return __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, a) >> (short)n)); }
-__device__ __forceinline__ pcx pk_adds(pcx a, pcx b) { return __builtin_bit_cast(pcx, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b))); }
-__device__ __forceinline__ pcx pk_subs(pcx a, pcx b) { return __builtin_bit_cast(pcx, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, a), __builtin_bit_cast(s16x2_t, b))); }
+__device__ __forceinline__ pcx pk_adds(pcx a, pcx b) { return __builtin_bit_cast(pcx, __builtin_elementwise_add_sat(__builtin_bit_cast(s16x2_t, a),
+        __builtin_bit_cast(s16x2_t, b))); }
+__device__ __forceinline__ pcx pk_subs(pcx a, pcx b) { return __builtin_bit_cast(pcx, __builtin_elementwise_sub_sat(__builtin_bit_cast(s16x2_t, a),
+        __builtin_bit_cast(s16x2_t, b))); }
 __device__ __forceinline__ pcx pk_swap(pcx a) { return (a >> 16) | (a << 16); }
 __device__ __forceinline__ pcx pk_mul_j(pcx a) { return pk_swap(a) ^ 0x0000FFFFu; }           // (~im, re)   mul_j
 __device__ __forceinline__ pcx pk_neg_j(pcx a) { return pk_swap(a) ^ 0xFFFF0000u; }           // (im, ~re)   the 4-point terminal stage's -j
@@ -400,7 +405,8 @@ __device__ __forceinline__ pcx pk_neg16_lo(pcx a)
     typedef unsigned short u16x2p_t __attribute__((ext_vector_type(2)));
     return __builtin_bit_cast(pcx, (u16x2p_t)(__builtin_bit_cast(u16x2p_t, a) * u16x2p_t{ (unsigned short)0xFFFFu, (unsigned short)1u }));
 }
-__device__ __forceinline__ pcx pk_conj_cmul15(pcx x, pcx w)              // conj_mul_shift15(x, w): ((x.re w.re + x.im w.im) >> 15, (x.im w.re + neg16(x.re) w.im) >> 15)
+// conj_mul_shift15(x, w): ((x.re w.re + x.im w.im) >> 15, (x.im w.re + neg16(x.re) w.im) >> 15)
+__device__ __forceinline__ pcx pk_conj_cmul15(pcx x, pcx w)
 {
     const int v0 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, x), __builtin_bit_cast(s16x2_t, w), 0, false);
     const int v1 = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, pk_neg16_lo(x)), __builtin_bit_cast(s16x2_t, pk_swap(w)), 0, false);

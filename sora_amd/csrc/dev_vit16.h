@@ -19,12 +19,15 @@ template <int WIN, int LOOK> struct Lds16 {
 #ifdef SORA_EXP_NORING                                                           // experiment (tools/r04_exp_noring.sh): no survivor ring, no trace-back -- results are wrong, only the duration means something
     uint16_t ring[1][4][64];
 #else
-    uint16_t ring[Geom16<WIN, LOOK>::P][4][64];                                 // [block % P][row][rev6(state)] {frame A's byte, frame B's byte}: 18944 / 15872 B
+    // [block % P][row][rev6(state)] {frame A's byte, frame B's byte}: 18944 / 15872 B
+    uint16_t ring[Geom16<WIN, LOOK>::P][4][64];
 #endif
     union {
         uint32_t udump[4][64];                                                  // the metrics registers at a trace-back (the start state's unfinished block)
-        uint16_t ops[4][24][2];                                                 // [row][operand of the chunk][frame]: the soft values as metric fields -- live only inside
-        uint16_t ops2[2][4][24][2];                                             //   forward16's unpack() / the fast loop's two alternating tables, never across a trace-back:
+        // [row][operand of the chunk][frame]: the soft values as metric fields -- live only inside
+        uint16_t ops[4][24][2];
+        //   forward16's unpack() / the fast loop's two alternating tables, never across a trace-back:
+        uint16_t ops2[2][4][24][2];
     };                                                                          //   they share their bytes with the trace-back's register dump
     uint8_t  path[8][Geom16<WIN, LOOK>::kPathBytes];                             // [row * 2 + frame][walk position]: the bytes along the traced path
 };                                                                              // 20288 / 17216 bytes: eight one-wave workgroups per CU (20480 each)
@@ -112,7 +115,8 @@ __device__ __forceinline__ unsigned row_pkmin(unsigned v)
 }
 __device__ __forceinline__ unsigned wave_min_u32(unsigned v) { return (unsigned)__builtin_amdgcn_readfirstlane((int)dpp_min_u32_wave(v)); }
 __device__ __forceinline__ unsigned wave_max_u32(unsigned v) { return ~wave_min_u32(~v); }
-__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void lds_fence() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 // Trace-back of one window for every frame of the wave whose count is non-zero (my_cnt: this lane's frame = (row, lane & 1)); kept out of
 // line (it is reached from every puncture group of the slow path), so everything arrives by value and the LDS block by its offset.
@@ -171,7 +175,8 @@ __device__ __noinline__ void trace16(unsigned lds_off, unsigned U0, unsigned U1,
         const int d = (int)pj - i;
         const uint32_t p = (uint32_t)(d < 0 ? d + P : d);
         unsigned base = rowbase + p * 512u;
-        asm volatile("" : "+v"(base));                                          // (one register: the chain's add is then v_lshl_add, not a three-input add behind a shift)
+        // (one register: the chain's add is then v_lshl_add, not a three-input add behind a shift)
+        asm volatile("" : "+v"(base));
         const unsigned raw = *(lds_u16*)(uintptr_t)(base + (q << 1));
         pth[i] = (uint8_t)(raw >> sh);                                          // (this frame's byte of the pair)
         q = __builtin_amdgcn_ubfe(raw, sh, 6u);

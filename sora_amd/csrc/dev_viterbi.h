@@ -23,7 +23,8 @@ namespace sora {
 // tap the oldest bit, so the decision-1 branch costs K - b0, K = 14 (7 on a punctured step).
 //
 // Decisions without a compare.  The reference marks the decision in the metric LSB; here the nine spare low bits of
-// the field do the same job: step k of an 8-step block adds 1 << k (frame A; 1 << (k + 1) in frame B's half, whose bit 0 is a carry guard) to the decision-1 candidate.  That bit breaks
+// the field do the same job: step k of an 8-step block adds 1 << k (frame A; 1 << (k + 1) in
+// frame B's half, whose bit 0 is a carry guard) to the decision-1 candidate.  That bit breaks
 // ties exactly like the reference's LSB (a tie keeps branch 0), marks of earlier steps sit BELOW it and can never
 // decide a comparison, and after the minimum it IS the decision.  Because the marks travel with the metric through
 // the butterfly, after 8 steps the low byte of a lane is the decision history of the SURVIVOR PATH into the state
@@ -63,9 +64,12 @@ __device__ __forceinline__ unsigned dpp_min_u32_wave(unsigned v)      // wave-wi
 }
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) + __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t, a) - __builtin_bit_cast(u16x2_t, b))); }
-__device__ __forceinline__ unsigned pk_min16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ unsigned pk_add16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t,
+        a) + __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ unsigned pk_sub16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, (u16x2_t)(__builtin_bit_cast(u16x2_t,
+        a) - __builtin_bit_cast(u16x2_t, b))); }
+__device__ __forceinline__ unsigned pk_min16(unsigned a, unsigned b) { return __builtin_bit_cast(unsigned,
+        __builtin_elementwise_min(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b))); }
 
 __device__ __forceinline__ unsigned dpp_pkmin_wave(unsigned v)         // per-half wave-wide unsigned minimum, broadcast to all lanes
 {
@@ -124,7 +128,8 @@ template <int BITS, int CW> struct SoftCursor {
 };
 
 constexpr unsigned kFld = (1u << 9) | (1u << 25);        // one unit of u in both halves
-constexpr unsigned kOne = 0x00020001u;                    // mark bit 0 of both frames: bit 0 (frame A), bit 17 (frame B; bit 16 is the carry guard, see acs_step)
+// mark bit 0 of both frames: bit 0 (frame A), bit 17 (frame B; bit 16 is the carry guard, see acs_step)
+constexpr unsigned kOne = 0x00020001u;
 constexpr unsigned kGuard = 1u << 16;
 
 // Survivor history in LDS, per wave: 8-step blocks of 64 16-bit entries {frame A's byte, frame B's byte}.  A window's walk touches
@@ -204,7 +209,8 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // arguments arrive in VGPRs; these are wave-uniform
     const uint32_t tr = uni(tr_), ob = uni(ob_), cntA = uni(cntA_), cntB = uni(cntB_), top = uni(top_);
     auto rev6 = [](unsigned x) { return __brev(x) >> 26; };
-    auto writelane = [](unsigned& vec, unsigned val, unsigned ln) {             // vec[lane ln] = val (one SGPR operand per VALU op: the lane select goes through M0)
+    // vec[lane ln] = val (one SGPR operand per VALU op: the lane select goes through M0)
+    auto writelane = [](unsigned& vec, unsigned val, unsigned ln) {
         asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tv_writelane_b32 %0, %1, m0" : "+v"(vec) : "s"(val), "s"(ln) : "m0");
     };
     const unsigned lbl = rol6(lane_map(lane), tr) << 2;
@@ -225,8 +231,10 @@ __device__ __noinline__ void viterbi_trace(unsigned U, const uint16_t* ring, uin
     uint32_t W[kMaxWalk];
 #pragma unroll
     for (int i = 0; i < kMaxWalk; i++)
-        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(W[i]) : "v"(low), "n"((kMaxWalk - 1 - i) * 128) : "memory");   // (zero-extends: no masking afterwards)
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]) : : "memory");             // (W[1..] are only used by the assembler blocks below, which stay behind this one)
+        // (zero-extends: no masking afterwards)
+        asm volatile("ds_read_u16 %0, %1 offset:%2" : "=v"(W[i]) : "v"(low), "n"((kMaxWalk - 1 - i) * 128) : "memory");
+    // (W[1..] are only used by the assembler blocks below, which stay behind this one)
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(W[0]) : : "memory");
     unsigned HA, HB;
     if (n == 8) {
         HA = (unsigned)__builtin_amdgcn_readlane((int)W[0], (int)rev6(stA)) & 0xFFu;

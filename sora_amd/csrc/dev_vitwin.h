@@ -58,7 +58,8 @@ __device__ __forceinline__ UnitGeom unit_geom(JOBS job_at, uint32_t n, uint32_t 
     g.wleft = last ? 0x10000u : m;
     g.vec = vbase + idx * q + u;
     g.out = out + J.out_off + (s0 >> 3);
-    // the unit's last step: its last window's trace-back fires at the first schedule check at or past WIN k1 + LOOK + 6 (checks come every GS steps); the frame's last unit runs to the end
+    // the unit's last step: its last window's trace-back fires at the first schedule check at or
+    // past WIN k1 + LOOK + 6 (checks come every GS steps); the frame's last unit runs to the end
     g.need = last ? J.nsoft : min(J.nsoft, (((uint32_t)WIN * k1 + (uint32_t)LOOK + 6u + GS) / GS + 1u) * GB);
     g.idx = idx;
     return g;
@@ -246,7 +247,8 @@ __device__ __forceinline__ void forward16w(Lds16<WIN, LOOK>& S, const uint8_t* _
 // (S: the wave's own LDS block.  wave_index: which eighth-of-units of the call.  jobs_of(list): that list's job_at.  ready(A, B, list): called once the wave's units are
 // known, before the first soft value is read -- k_pipe waits there for the symbol chain; false = give up.)
 template <int WIN, int LOOK, int BITS, typename JOBSOF, typename READY>
-__device__ __forceinline__ void viterbi16w_wave(Lds16<WIN, LOOK>& S, uint32_t wave_index, JOBSOF jobs_of, READY ready, const uint32_t* __restrict__ hdr, uint32_t target, uint32_t vstride,
+__device__ __forceinline__ void viterbi16w_wave(Lds16<WIN, LOOK>& S, uint32_t wave_index, JOBSOF jobs_of, READY ready, const uint32_t* __restrict__ hdr,
+        uint32_t target, uint32_t vstride,
                                                 const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
 {
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
@@ -264,7 +266,8 @@ __device__ __forceinline__ void viterbi16w_wave(Lds16<WIN, LOOK>& S, uint32_t wa
         constexpr int CR = decltype(cr)::value;
         UnitGeom A = unit_geom<CR, WIN, LOOK>(job_at, nl, pa, q, vbase, out), B = unit_geom<CR, WIN, LOOK>(job_at, nl, pb, q, vbase, out);
         if (__ballot(A.valid || B.valid) == 0) return;                           // (frames shorter than the longest leave whole waves empty)
-        if (!B.valid) { const bool v = false; B = A; B.valid = v; B.vstep = B.estep = kNever; B.nsteps = 0; }   // an empty slot steps through a unit that exists: well-formed operands, nothing written
+        // an empty slot steps through a unit that exists: well-formed operands, nothing written
+        if (!B.valid) { const bool v = false; B = A; B.valid = v; B.vstep = B.estep = kNever; B.nsteps = 0; }
         if (!A.valid) { const bool v = false; const UnitGeom T = B; A = T; A.valid = v; A.vstep = A.estep = kNever; A.nsteps = 0; }
         forward16w<CR, WIN, LOOK, BITS>(S, soft, A, B, vecs, [&]() { return ready(A, B, list); });
     };

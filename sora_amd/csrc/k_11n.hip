@@ -251,7 +251,8 @@ __global__ void __launch_bounds__(256) k_pilot_track11n_batch(const uint32_t* x0
             for (int c = 0; c < 2; c++) {
                 const uint32_t* x = (c ? x1 : x0) + (size_t)(s0 + s) * 64;
                 const cpx a = unpack(x[64 - 21]), b = unpack(x[64 - 7]), d = unpack(x[7]), e = unpack(x[21]);
-                t[c] = (int)(short)((dsp_atan16(atan_tab, a.re, a.im) + dsp_atan16(atan_tab, b.re, b.im) + dsp_atan16(atan_tab, d.re, d.im) + dsp_atan16(atan_tab, e.re, e.im)) >> 2);
+                t[c] = (int)(short)((dsp_atan16(atan_tab, a.re, a.im) + dsp_atan16(atan_tab, b.re, b.im) + dsp_atan16(atan_tab, d.re,
+                        d.im) + dsp_atan16(atan_tab, e.re, e.im)) >> 2);
             }
             inc = (int)(short)((t[0] + t[1]) >> 1);
         }
@@ -338,7 +339,8 @@ const DspTables* dsp_tables()
     static DspTables tabs[64];
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
-    std::lock_guard<std::mutex> lock(g_dsp_mutex);                              // handles may be created from different threads: built once per device, published whole
+    // handles may be created from different threads: built once per device, published whole
+    std::lock_guard<std::mutex> lock(g_dsp_mutex);
     DspTables& T = tabs[dev];
     if (!T.sincos) {
         std::vector<uint32_t> sc; std::vector<short> at;
@@ -429,7 +431,8 @@ int sora_hip_sig_demap11n(const sora_complex16* d_sym, uint8_t* d_soft, size_t n
     if (sora_hip_device_count() <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
     if (!d_sym || !d_soft) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_hip_sig_demap11n: null argument", 0);
     if (nframes == 0) return SORA_OK;
-    hipLaunchKernelGGL(k_sig_demap11n_batch, dim3((unsigned)((nframes * 3 + 3) / 4)), dim3(256), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_sym), d_soft, (uint32_t)nframes);
+    hipLaunchKernelGGL(k_sig_demap11n_batch, dim3((unsigned)((nframes * 3 + 3) / 4)), dim3(256), 0, (hipStream_t)stream,
+            reinterpret_cast<const uint32_t*>(d_sym), d_soft, (uint32_t)nframes);
     return launch_result("k_sig_demap11n_batch");
 }
 

@@ -82,7 +82,8 @@ __device__ __forceinline__ void symbol_wave(const RxArgs& A, DecodeLds& S, int p
     fill_map(0, GA);
     if (hasB) fill_map(1, GB);
     wave_lds_sync();
-    const int pk = lane & 3;                                                     // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
+    // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
+    const int pk = lane & 3;
     const int pbin = pk == 0 ? 43 : pk == 1 ? 57 : pk == 2 ? 7 : 21, pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
     // per-frame loop state (wave-uniform): symbols done, values published, tracking loop (symbol_count: 127 -> 0 after SIGNAL)
     uint32_t s0[2] = { 1u, 1u }, wv[2] = { 0u, 0u }, symbol_count[2] = { 0u, 0u };
@@ -239,7 +240,8 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
     uint32_t tr = 0, ob = 0;
 
     auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // (no half borrows: a plain 32-bit subtraction)
-    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RingGeom<256, 24>::kMaxWalk>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out, top); };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RingGeom<256, 24>::kMaxWalk>(V.U, ring, tr, ob, mA,
+            mB, cntA, cntB, A.out, B.out, top); };
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + 256u + 24u + 6u;
         if (!A.done) t = min(t, A.tr_end);
@@ -281,7 +283,8 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
         const uint32_t* p = soft + (c * (uint32_t)VC) % (uint32_t)kSoftRing;
         if (VC % 4 == 0) {
 #pragma unroll
-            for (int i = 0; i < VC / 4; i++) { const uint4 q = reinterpret_cast<const uint4*>(p)[i]; K.v[4 * i] = q.x; K.v[4 * i + 1] = q.y; K.v[4 * i + 2] = q.z; K.v[4 * i + 3] = q.w; }
+            for (int i = 0; i < VC / 4; i++) { const uint4 q = reinterpret_cast<const uint4*>(p)[i]; K.v[4 * i] = q.x; K.v[4 * i + 1] = q.y;
+                K.v[4 * i + 2] = q.z; K.v[4 * i + 3] = q.w; }
         } else {
 #pragma unroll
             for (int i = 0; i < VC / 2; i++) { const uint2 q = reinterpret_cast<const uint2*>(p)[i]; K.v[2 * i] = q.x; K.v[2 * i + 1] = q.y; }
@@ -289,7 +292,8 @@ __device__ __forceinline__ void trellis_wave(DecodeLds& S, int pi, const FrameGe
         return K;
     };
     auto release = [&](uint32_t c) { lds_release(&S.consumed[pi], c * (uint32_t)VC); };   // everything below chunk c has been read
-    auto group = [&](const Chunk& K, int h, int i0) {                           // one puncture group = GS steps; i0 = step inside the chunk, h = half of the 24-step row
+    // one puncture group = GS steps; i0 = step inside the chunk, h = half of the 24-step row
+    auto group = [&](const Chunk& K, int h, int i0) {
         const int k0 = i0 / GS * GBv, t24 = 12 * h + i0;
         acs_step<0, P>(V, t24, K.v[k0], K.v[k0 + 1]);                              // ACS(A,B)
         if (CR != 0) acs_step<1, P>(V, t24 + 1, K.v[k0 + 2], 0);                   // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
@@ -352,7 +356,8 @@ __global__ void __launch_bounds__(256, 4) k_decode(RxArgs A)
     __shared__ DecodeLds S;
     const int tid = threadIdx.x, w = tid >> 6, pi = w & 1;
     reinterpret_cast<uint32_t*>(S.demap)[tid] = reinterpret_cast<const uint32_t*>(A.T.demap)[tid];
-    for (int i = tid; i < 2 * kSoftRing; i += 256) (&S.ring[0][0])[i] = 0;      // a half nobody writes (no frame B, a frame that has ended) must read as well-formed operands
+    // a half nobody writes (no frame B, a frame that has ended) must read as well-formed operands
+    for (int i = tid; i < 2 * kSoftRing; i += 256) (&S.ring[0][0])[i] = 0;
     if (tid < 4) S.produced[tid >> 1][tid & 1] = 0;
     if (tid < 2) S.consumed[tid] = 0;
     __syncthreads();                                                            // the only block barrier: the two pairs are independent from here on

@@ -22,7 +22,8 @@ __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict_
 {
     // evbase (the 40 MHz handle's raw-capture calls): "capture" c is an EVENT of the front end; evbase[c] = the row of rows[] its first row comes from, or 0xFFFFFFFF for
     // an event without a decoded frame (a PLCP header that failed): its one row is the template row as it stands (error code, position; no MPDU)
-    const uint32_t ncaps = ncaps_dev ? min(ncaps_bound, *ncaps_dev) : ncaps_bound;     // (the 40 MHz handle plans its frames on the device: the host knows only a bound)
+    // (the 40 MHz handle plans its frames on the device: the host knows only a bound)
+    const uint32_t ncaps = ncaps_dev ? min(ncaps_bound, *ncaps_dev) : ncaps_bound;
     __shared__ uint32_t s_a[1024], s_b[1024];
     __shared__ uint32_t s_base[2];
     const uint32_t t = threadIdx.x;
@@ -56,7 +57,8 @@ __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict_
             }
             const Rx11bRow& r = rows[(size_t)base + i];
             uint16_t tflags = 0;
-            if (tmpl) { o = tmpl[(size_t)c * mf + i]; tflags = o.flags; }         // (40 MHz HT: capture_id = frame id, start_sample = spatial stream, rate, symbols; a raw-capture call's truncation flag)
+            // (40 MHz HT: capture_id = frame id, start_sample = spatial stream, rate, symbols; a raw-capture call's truncation flag)
+            if (tmpl) { o = tmpl[(size_t)c * mf + i]; tflags = o.flags; }
             else { o.capture_id = caps[c].capture_id; o.start_sample = 0; o.nsym = 0; o.cfo_est = 0; o.rate_kbps = r.rate_kbps; o.end_sample = r.end_sample; }
             o.error_code = r.error_code; o.length = (uint16_t)r.length; o.crc32 = r.crc32;
             o.flags = (uint16_t)(tflags | ((i + 1 == mf && found > mf) ? SORA_ROW_TRUNCATED : 0));
@@ -64,7 +66,8 @@ __global__ void __launch_bounds__(1024) k_dense_rows(const Rx11bRow* __restrict_
             const uint32_t len = has ? min(r.length, 4096u) : 0u;
             o.mpdu_offset = off;
             out[row] = o;
-            src_slot[row] = (has && off + len <= mpdu_cap) ? (uint32_t)((size_t)base + i) : 0xFFFFFFFFu;    // (an MPDU that does not fit is not copied; the host sees it from the total)
+            // (an MPDU that does not fit is not copied; the host sees it from the total)
+            src_slot[row] = (has && off + len <= mpdu_cap) ? (uint32_t)((size_t)base + i) : 0xFFFFFFFFu;
             off += len;
         }
         __syncthreads();

@@ -31,7 +31,8 @@ struct Ht40Frame {
     uint32_t length[2];
     int32_t  cfo;               // phase per 40 MHz sample, 65536 = 2 pi (TFreqComp_11n's vfo_step convention)
     float    noise_var;         // per carrier, in LSB^2 of the FFT output; 0 = zero forcing
-    uint32_t soft_off;          // bytes from the soft base: stream 0's soft values, one byte each (VitJob::soft_bits = 8); stream 1's follow at + round_up(values per stream, 32)
+    // bytes from the soft base: stream 0's soft values, one byte each (VitJob::soft_bits = 8); stream 1's follow at + round_up(values per stream, 32)
+    uint32_t soft_off;
     uint32_t pad[4];
 };
 struct Ht40Args {
@@ -49,7 +50,8 @@ static __constant__ int8_t kHtLtf40[117] = {    // carriers -58..58 (IEEE 802.11
     1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1,
     -1, -1, -1, 1, 0, 0, 0, -1, 1, 1, -1,
     1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, 1, 1, 1, 1, 1, -1, -1, 1, 1, -1, 1, -1, 1, -1, -1, -1, -1, -1, 1, 1, -1, -1, 1, -1, 1, -1, 1, 1, 1, 1 };
-__device__ __forceinline__ void wsync40() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void wsync40() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 __device__ __forceinline__ int data_bin40(int c)          // data carrier c (0..107) -> FFT bin: -58..-2 then 2..58 without +-11, +-25, +-53
 {
     int k;
@@ -110,7 +112,8 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
         const int r = lane >> 5, e = lane & 31; pcx x[4];
 #pragma unroll
         for (int m = 0; m < 4; m++) x[m] = W.buf[r][e + 32 * m];
-        fft128_core_pk(x, W.fft[r], e, twpk, nosync);                            // the packed-arithmetic FFT<128> of k_fft128_batch (dev_arith.h): point j at slot bitrev7(j)
+        // the packed-arithmetic FFT<128> of k_fft128_batch (dev_arith.h): point j at slot bitrev7(j)
+        fft128_core_pk(x, W.fft[r], e, twpk, nosync);
 #pragma unroll
         for (int q = 0; q < 4; q++) W.y[slot][r][e + 32 * q] = W.fft[r][__brev((unsigned)(e + 32 * q)) >> 25];
         wsync40();
@@ -151,8 +154,10 @@ __global__ void __launch_bounds__(256) k_ht40_frame(Ht40Args A)
             const cf t0 = cf_mul(cj(a00), a01), t1 = cf_mul(cj(a10), a11);
             const cf g01 = { t0.re + t1.re, t0.im + t1.im };
             const float det = ((g00 * g11) - n2(g01)) / 65536.0f;
-            auto row0 = [&](cf hc0, cf hc1) { const cf u = cf_mul(g01, hc1); return cf{ ((g11 * hc0.re) - u.re) / det, ((g11 * hc0.im) - u.im) / det }; };   // g11 conj(h_r0) - g01 conj(h_r1)
-            auto row1 = [&](cf hc0, cf hc1) { const cf u = cf_mul(cj(g01), hc0); return cf{ ((g00 * hc1.re) - u.re) / det, ((g00 * hc1.im) - u.im) / det }; }; // g00 conj(h_r1) - g10 conj(h_r0)
+            // g11 conj(h_r0) - g01 conj(h_r1)
+            auto row0 = [&](cf hc0, cf hc1) { const cf u = cf_mul(g01, hc1); return cf{ ((g11 * hc0.re) - u.re) / det, ((g11 * hc0.im) - u.im) / det }; };
+            // g00 conj(h_r1) - g10 conj(h_r0)
+            auto row1 = [&](cf hc0, cf hc1) { const cf u = cf_mul(cj(g01), hc0); return cf{ ((g00 * hc1.re) - u.re) / det, ((g00 * hc1.im) - u.im) / det }; };
             w00 = row0(cj(a00), cj(a01)); w01 = row0(cj(a10), cj(a11));
             w10 = row1(cj(a00), cj(a01)); w11 = row1(cj(a10), cj(a11));
             // unbiased: row s is divided by (W H)_ss = the gain the stream's own symbol comes out with, so that the constellation sits where
@@ -277,7 +282,8 @@ __device__ __forceinline__ Ht40Geom ht40_geom(const Ht40Found& F)
     G.per = G.nsym * 108u * G.nb; G.per_pad = (G.per + 31u) / 32u * 32u;
     return G;
 }
-__global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ caps, uint32_t ncaps, uint32_t mf, const uint32_t* __restrict__ nfr, const Ht40Found* __restrict__ found,
+__global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ caps, uint32_t ncaps, uint32_t mf, const uint32_t* __restrict__ nfr,
+        const Ht40Found* __restrict__ found,
                                                     uint32_t max_frames, uint64_t max_soft, uint32_t vout_stride,
                                                     Ht40Frame* __restrict__ frames, VitJob* __restrict__ jobs, uint32_t stride, uint32_t* __restrict__ njobs, Ht40Job* __restrict__ fjobs,
                                                     sora_frame_result* __restrict__ tmpl, uint32_t* __restrict__ plan, uint32_t* __restrict__ evbase, uint32_t* __restrict__ evn)
@@ -320,7 +326,8 @@ __global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ 
             const Ht40Found& F = found[(size_t)c * mf + i];
             const uint32_t e = at[5]++;                                          // the event's index in the call
             const uint16_t tflag = (uint16_t)((i + 1 == mf && nfr[c] > mf) ? SORA_ROW_TRUNCATED : 0);
-            if (F.error_code != 0) {                                             // a header that failed: one row, no frame (what sora_ht40_results_of reports for it)
+            // a header that failed: one row, no frame (what sora_ht40_results_of reports for it)
+            if (F.error_code != 0) {
                 sora_frame_result o;
                 o.capture_id = caps[c].capture_id; o.start_sample = 0; o.end_sample = F.end_sample; o.error_code = F.error_code; o.rate_kbps = 0;
                 o.length = 0; o.nsym = 0; o.crc32 = 0; o.cfo_est = 0; o.flags = tflag; o.mpdu_offset = 0;
@@ -331,17 +338,20 @@ __global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ 
             const uint32_t fi = at[0], soft_off = at[1], pos = 2u * at[2 + G.cr];
             at[0]++; at[1] += 2u * G.per_pad; at[2 + G.cr]++;
             evbase[e] = 2u * fi; evn[e] = 2u;
-            if (fi >= max_frames || (uint64_t)soft_off + 2u * G.per_pad > max_soft || !(F.noise_var >= 0.0f)) { s_err = 1u; evn[e] = 0u; continue; }   // (reported by wait / results: SORA_ERR_CAPACITY)
+            // (reported by wait / results: SORA_ERR_CAPACITY)
+            if (fi >= max_frames || (uint64_t)soft_off + 2u * G.per_pad > max_soft || !(F.noise_var >= 0.0f)) { s_err = 1u; evn[e] = 0u; continue; }
             Ht40Frame H;
             H.offset = caps[c].offset + 2ull * F.a20 + 160ull;                   // HT-STF is 4 us = 160 samples @40 MHz; HT-LTF 1 follows
-            H.nsym = G.nsym; H.nb = G.nb; H.code_rate = G.cr; H.length[0] = H.length[1] = F.ht_len;   // one HT-SIG LENGTH: each stream carries its own PSDU of that length
+            // one HT-SIG LENGTH: each stream carries its own PSDU of that length
+            H.nsym = G.nsym; H.nb = G.nb; H.code_rate = G.cr; H.length[0] = H.length[1] = F.ht_len;
             H.cfo = F.cfo / 2;                                                   // per 20 MHz sample -> per 40 MHz sample
             H.noise_var = F.noise_var; H.soft_off = soft_off; H.pad[0] = H.pad[1] = H.pad[2] = H.pad[3] = 0;
             frames[fi] = H;
 #pragma unroll
             for (uint32_t k = 0; k < 2; k++) {
                 VitJob J;
-                J.soft_off = soft_off + k * G.per_pad; J.soft_bits = 8; J.nsoft = G.per; J.length = F.ht_len; J.dec_off = 0; J.out_off = (2u * fi + k) * vout_stride; J.valid = 1; J.code_rate = G.cr;
+                J.soft_off = soft_off + k * G.per_pad; J.soft_bits = 8; J.nsoft = G.per; J.length = F.ht_len; J.dec_off = 0;
+                    J.out_off = (2u * fi + k) * vout_stride; J.valid = 1; J.code_rate = G.cr;
                 jobs[(size_t)G.cr * stride + pos + k] = J;
                 fjobs[2u * fi + k] = Ht40Job{ J.out_off, F.ht_len, 2u * fi + k, 0u };
                 sora_frame_result o;
@@ -357,7 +367,8 @@ __global__ void __launch_bounds__(1024) k_ht40_plan(const CapDesc* __restrict__ 
         }
         __syncthreads();
     }
-    if (t == 0) {                                                                // (a batch that does not fit is not decoded at all: the job lists would have holes)
+    // (a batch that does not fit is not decoded at all: the job lists would have holes)
+    if (t == 0) {
         const bool bad = s_err != 0;
         plan[0] = bad ? 0u : s_base[0]; plan[1] = s_base[0]; plan[2] = s_base[1]; plan[3] = s_err; plan[4] = bad ? 0u : s_base[5];
         njobs[0] = bad ? 0u : 2u * s_base[2]; njobs[1] = bad ? 0u : 2u * s_base[3]; njobs[2] = bad ? 0u : 2u * s_base[4]; njobs[3] = 0;
@@ -373,7 +384,8 @@ using namespace sora;
 // slot kHt40Slots calls ago, so the host's part of call n + 1 (job tables, four small copies) and the tail of call n's kernels overlap call n + 1's
 // kernels.  sora_ht40_results reports the most recent call.
 static constexpr int kHt40Slots = 8;
-struct Ht40Event { uint32_t capture_id, end_sample, error_code, mcs, length, nsym; int frame; bool truncated; };   // frame: index into the call's described frames, -1 = header failed
+// frame: index into the call's described frames, -1 = header failed
+struct Ht40Event { uint32_t capture_id, end_sample, error_code, mcs, length, nsym; int frame; bool truncated; };
 struct Ht40Slot {
     hipStream_t stream = nullptr;
     Ht40Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; Ht40Job* d_fjobs = nullptr;
@@ -387,9 +399,11 @@ struct Ht40Slot {
     bool capture_mode = false; uint32_t capture_mf = 0; std::vector<Ht40Event> events;
     // ... planned on the device (k_ht40_plan): the records come back asynchronously into page-locked memory and are turned into `events` when the call is collected
     uint32_t* d_plan = nullptr;
-    uint32_t* d_evbase = nullptr; size_t evbase_bytes = 0; uint32_t* d_evn = nullptr; size_t evn_bytes = 0;   // the call's event table (k_ht40_plan -> sora_ht40_deliver_async)
+    // the call's event table (k_ht40_plan -> sora_ht40_deliver_async)
+    uint32_t* d_evbase = nullptr; size_t evbase_bytes = 0; uint32_t* d_evn = nullptr; size_t evn_bytes = 0;
     sora_frame_result* d_evtmpl = nullptr; size_t evtmpl_bytes = 0; uint32_t bound_events = 0;
-    void* h_stage = nullptr;                                                    // descriptor calls: page-locked staging of {frames, job lists, finish jobs, counts} for asynchronous uploads
+    // descriptor calls: page-locked staging of {frames, job lists, finish jobs, counts} for asynchronous uploads
+    void* h_stage = nullptr;
     void* h_pin = nullptr; size_t pin_bytes = 0;                                // {plan[4], CapDesc[ncaps] (upload), nfr[ncaps], Ht40Found[ncaps * mf]}
     uint32_t* h_plan = nullptr; CapDesc* h_capsup = nullptr; uint32_t* h_nfr = nullptr; Ht40Found* h_found = nullptr;
     std::vector<sora_capture_desc> h_caps; bool events_pending = false; uint32_t bound_frames = 0; bool plan_error = false;
@@ -400,7 +414,9 @@ struct sora_ht40 {
     int device = 0; uint32_t max_frames = 0; uint64_t max_soft = 0;
     Tables T{}; const uint32_t* sincos = nullptr; const short* atan = nullptr;
     Ht40Slot slot[kHt40Slots]; int next = 0, last = 0, seq = 0; bool have_results = false;
-    int lanes16 = 1;            // trellis kernel: 1 = k_viterbi16_11n (default: the handle keeps eight calls in flight), 0 = k_viterbi11n (64 lanes per stream pair; the faster one for a call alone) -- sora_ht40_set_trellis
+    // trellis kernel: 1 = k_viterbi16_11n (default: the handle keeps eight calls in flight), 0 =
+    // k_viterbi11n (64 lanes per stream pair; the faster one for a call alone) -- sora_ht40_set_trellis
+    int lanes16 = 1;
 };
 
 #define HIPCHK40(call) do { hipError_t _e = (call); if (_e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, #call, (int)_e); } while (0)
@@ -416,7 +432,8 @@ static void ht40_free(sora_ht40_t* rx)
         (void)hipFree(S.d_vout); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_rows);
         sora_internal_dense_free(&S.dense);
         (void)hipFree(S.d_caps); (void)hipFree(S.d_scanrows); (void)hipFree(S.d_nfr); (void)hipFree(S.d_found);
-        (void)hipFree(S.d_plan); (void)hipFree(S.d_evbase); (void)hipFree(S.d_evn); (void)hipFree(S.d_evtmpl); if (S.h_pin) (void)hipHostFree(S.h_pin); if (S.h_stage) (void)hipHostFree(S.h_stage);
+        (void)hipFree(S.d_plan); (void)hipFree(S.d_evbase); (void)hipFree(S.d_evn); (void)hipFree(S.d_evtmpl); if (S.h_pin) (void)hipHostFree(S.h_pin);
+            if (S.h_stage) (void)hipHostFree(S.h_stage);
     }
     delete rx;
 }
@@ -436,7 +453,8 @@ int sora_ht40_create(int device, uint32_t max_frames, uint64_t max_soft_values, 
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return sora_internal_fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path", 0);
     if (device < 0 || device >= ndev) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "device ordinal out of range", 0);
-    if (max_soft_values * 2 + 4096 + 1024 >= (1ull << 32)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_create: max_soft_values exceeds the 32-bit offsets of one handle", 0);
+    if (max_soft_values * 2 + 4096 + 1024 >= (1ull << 32)) return sora_internal_fail(SORA_ERR_CAPACITY,
+            "sora_ht40_create: max_soft_values exceeds the 32-bit offsets of one handle", 0);
     HIPCHK40(hipSetDevice(device));
     sora_ht40_t* rx = new sora_ht40();
     rx->device = device; rx->max_frames = max_frames; rx->max_soft = max_soft_values;
@@ -482,7 +500,8 @@ int sora_ht40_synchronize(sora_ht40_t* rx)
 }
 
 // the data field of `nframes` described frames on slot S (its stream is idle): descriptors -> device, k_ht40_frame, the trellis kernel, k_ht40_finish
-static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes, sora_complex16* d_weights)
+static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_ht40_frame* frames, size_t nframes,
+        sora_complex16* d_weights)
 {
     if (nframes > rx->max_frames) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_dev: more frames than max_frames", 0);
     // (the tables are built in the slot's page-locked staging area -- the slot's previous call has finished -- and uploaded asynchronously)
@@ -496,14 +515,18 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
     for (size_t i = 0; i < nframes; i++) {
         const sora_ht40_frame& s = frames[i];
         const uint32_t nsym = sora_ht40_symbols(s.length[0], s.length[1], s.n_bpsc, s.code_rate);
-        if (nsym == 0 || s.length[0] > 4000 || s.length[1] > 4000 || !(s.noise_var >= 0.0f)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_dev: bad frame descriptor (n_bpsc 1/2/4/6, code_rate 0..2, PSDU <= 4000 bytes, noise_var >= 0)", 0);
+        if (nsym == 0 || s.length[0] > 4000 || s.length[1] > 4000 || !(s.noise_var >= 0.0f)) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+                "sora_ht40_process_dev: bad frame descriptor (n_bpsc 1/2/4/6, code_rate 0..2, PSDU <= 4000 bytes, noise_var >= 0)", 0);
         Ht40Frame& F = hf[i];
-        F.offset = s.offset; F.nsym = nsym; F.nb = s.n_bpsc; F.code_rate = s.code_rate; F.length[0] = s.length[0]; F.length[1] = s.length[1]; F.cfo = s.cfo; F.noise_var = s.noise_var;
+        F.offset = s.offset; F.nsym = nsym; F.nb = s.n_bpsc; F.code_rate = s.code_rate; F.length[0] = s.length[0]; F.length[1] = s.length[1]; F.cfo = s.cfo;
+            F.noise_var = s.noise_var;
         const uint64_t per = (uint64_t)nsym * 108 * s.n_bpsc;                       // soft values per stream
         F.soft_off = (uint32_t)soft;
         for (int k = 0; k < 2; k++) {
-            VitJob& J = hj[s.code_rate * stride + nj[s.code_rate]++];                // the two streams of a frame are neighbours in their list: one wave decodes both
-            J.soft_off = F.soft_off + (uint32_t)k * (uint32_t)((per + 31) / 32 * 32); J.soft_bits = 8; J.nsoft = (uint32_t)per; J.length = s.length[k]; J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate;
+            // the two streams of a frame are neighbours in their list: one wave decodes both
+            VitJob& J = hj[s.code_rate * stride + nj[s.code_rate]++];
+            J.soft_off = F.soft_off + (uint32_t)k * (uint32_t)((per + 31) / 32 * 32); J.soft_bits = 8; J.nsoft = (uint32_t)per; J.length = s.length[k];
+                J.dec_off = 0; J.out_off = (uint32_t)((2 * i + k) * kVoutStride); J.valid = 1; J.code_rate = s.code_rate;
             fj[2 * i + k] = Ht40Job{ J.out_off, s.length[k], (uint32_t)(2 * i + k), 0 };
         }
         soft += 2 * ((per + 31) / 32 * 32);                                         // bytes: one per soft value, both streams
@@ -526,9 +549,11 @@ static int ht40_submit(sora_ht40_t* rx, Ht40Slot& S, const sora_complex16* d_iq0
     hipLaunchKernelGGL(k_ht40_frame, dim3((unsigned)((nframes + 3) / 4)), dim3(256), 0, S.stream, A);
     const uint32_t njobs = 2 * (uint32_t)nframes;
     if (rx->lanes16)
-        hipLaunchKernelGGL(k_viterbi16_11n, dim3((njobs + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((njobs + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u,
+                (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     else
-        hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+        hipLaunchKernelGGL(k_viterbi11n, dim3((njobs / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u,
+                (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = njobs; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T; Fi.plan = nullptr;
     hipLaunchKernelGGL(k_ht40_finish, dim3((njobs + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());
@@ -553,9 +578,11 @@ int sora_ht40_process_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const so
 // planned on the host).  The records travel to page-locked host memory behind the kernels and become the call's events when it is
 // collected.  Rows: per event in (capture, time) order -- a recorded frame reports two rows (start_sample = spatial stream 0 / 1,
 // rate_kbps = MCS, end_sample = the 40 MHz source position of the event), a header that fails one row with SORA_E_PLCP_HEADER_FAIL.
-int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps, uint32_t max_frames_per_capture)
+int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* caps, size_t ncaps,
+        uint32_t max_frames_per_capture)
 {
-    if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps)) || max_frames_per_capture == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_ht40_process_captures_dev: bad argument", 0);
+    if (!rx || (ncaps && (!d_iq0 || !d_iq1 || !caps)) || max_frames_per_capture == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+            "sora_ht40_process_captures_dev: bad argument", 0);
     if ((uint64_t)ncaps * max_frames_per_capture >= (1ull << 31)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: too many rows", 0);
     HIPCHK40(hipSetDevice(rx->device));
     rx->next = slots_next(rx->slot, kHt40Slots);                                  // an unused slot, else a released call's, else the oldest call's
@@ -567,7 +594,8 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
         if (caps[i].offset & 3) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture offset must be a multiple of 4 samples", 0);
         if (caps[i].nsamples % 28) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "capture length must be a whole number of 28-sample source bursts", 0);
     }
-    auto grow = [](void** p, size_t* have, size_t need) -> bool { if (*have >= need) return true; if (*p) (void)hipFree(*p); *p = nullptr; *have = 0; if (hipMalloc(p, need) != hipSuccess) return false; *have = need; return true; };
+    auto grow = [](void** p, size_t* have, size_t need) -> bool { if (*have >= need) return true; if (*p) (void)hipFree(*p); *p = nullptr; *have = 0;
+        if (hipMalloc(p, need) != hipSuccess) return false; *have = need; return true; };
     if (ncaps && (!grow((void**)&S.d_caps, &S.caps_bytes, sizeof(CapDesc) * ncaps) || !grow((void**)&S.d_scanrows, &S.scanrows_bytes, sizeof(Rx11bRow) * nrows) ||
                   !grow((void**)&S.d_nfr, &S.nfr_bytes, 4 * ncaps) || !grow((void**)&S.d_found, &S.found_bytes, sizeof(Ht40Found) * nrows) ||
                   !grow((void**)&S.d_evbase, &S.evbase_bytes, 4 * nrows) || !grow((void**)&S.d_evn, &S.evn_bytes, 4 * nrows) ||
@@ -576,12 +604,14 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     const size_t o_caps = 64, o_nfr = o_caps + ((sizeof(CapDesc) * ncaps + 63) & ~(size_t)63), o_found = o_nfr + ((4 * ncaps + 63) & ~(size_t)63), need = o_found + sizeof(Ht40Found) * nrows + 64;
     if (S.pin_bytes < need) {
         if (S.h_pin) { (void)hipHostFree(S.h_pin); S.h_pin = nullptr; S.pin_bytes = 0; }
-        if (hipHostMalloc(&S.h_pin, need, hipHostMallocDefault) != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_process_captures_dev: page-locked host memory", 0);
+        if (hipHostMalloc(&S.h_pin, need, hipHostMallocDefault) != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED,
+                "sora_ht40_process_captures_dev: page-locked host memory", 0);
         S.pin_bytes = need;
     }
     S.h_plan = reinterpret_cast<uint32_t*>(S.h_pin); S.h_capsup = reinterpret_cast<CapDesc*>((uint8_t*)S.h_pin + o_caps);
     S.h_nfr = reinterpret_cast<uint32_t*>((uint8_t*)S.h_pin + o_nfr); S.h_found = reinterpret_cast<Ht40Found*>((uint8_t*)S.h_pin + o_found);
-    for (size_t i = 0; i < ncaps; i++) { CapDesc& h = S.h_capsup[i]; h.offset = caps[i].offset; h.nsamples = caps[i].nsamples; h.capture_id = caps[i].capture_id; h.slot_base = 0; h.nslots = 0; }
+    for (size_t i = 0; i < ncaps; i++) { CapDesc& h = S.h_capsup[i]; h.offset = caps[i].offset; h.nsamples = caps[i].nsamples;
+        h.capture_id = caps[i].capture_id; h.slot_base = 0; h.nslots = 0; }
     S.h_caps.assign(caps, caps + ncaps);
     S.events.clear(); S.capture_mode = true; S.capture_mf = mf; S.events_pending = true; S.plan_error = false; S.nframes = 0;
     S.bound_frames = (uint32_t)std::min<uint64_t>(nrows, rx->max_frames); S.bound_events = (uint32_t)nrows;
@@ -591,7 +621,8 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     if (ncaps == 0) { S.events_pending = false; return SORA_OK; }
     HIPCHK40(hipMemcpyAsync(S.d_caps, S.h_capsup, sizeof(CapDesc) * ncaps, hipMemcpyHostToDevice, S.stream));
     HIPCHK40(hipMemsetAsync(S.d_nfr, 0, 4 * ncaps, S.stream));
-    { const int rc = sora_internal_scan_ht40(reinterpret_cast<const uint32_t*>(d_iq0), reinterpret_cast<const uint32_t*>(d_iq1), S.d_caps, (uint32_t)ncaps, mf, S.d_scanrows, S.d_nfr, S.d_found,
+    { const int rc = sora_internal_scan_ht40(reinterpret_cast<const uint32_t*>(d_iq0), reinterpret_cast<const uint32_t*>(d_iq1), S.d_caps, (uint32_t)ncaps, mf,
+            S.d_scanrows, S.d_nfr, S.d_found,
                                              rx->T, rx->sincos, rx->atan, S.stream); if (rc) return rc; }
     const size_t stride = 2 * (size_t)rx->max_frames;
     hipLaunchKernelGGL(k_ht40_plan, dim3(1), dim3(1024), 0, S.stream, (const CapDesc*)S.d_caps, (uint32_t)ncaps, mf, (const uint32_t*)S.d_nfr, (const Ht40Found*)S.d_found,
@@ -599,15 +630,18 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
     HIPCHK40(hipMemcpyAsync(S.h_nfr, S.d_nfr, 4 * ncaps, hipMemcpyDeviceToHost, S.stream));
     HIPCHK40(hipMemcpyAsync(S.h_found, S.d_found, sizeof(Ht40Found) * nrows, hipMemcpyDeviceToHost, S.stream));
     HIPCHK40(hipMemcpyAsync(S.h_plan, S.d_plan, 16, hipMemcpyDeviceToHost, S.stream));
-    const uint32_t bf = S.bound_frames, bj = 2 * bf;                           // the kernels are launched for the most frames there can be and stop at the planned count
+    // the kernels are launched for the most frames there can be and stop at the planned count
+    const uint32_t bf = S.bound_frames, bj = 2 * bf;
     Ht40Args A;
     A.iq0 = reinterpret_cast<const uint32_t*>(d_iq0); A.iq1 = reinterpret_cast<const uint32_t*>(d_iq1); A.frames = S.d_frames; A.nframes = bf;
     A.T = rx->T; A.sincos = rx->sincos; A.atan = rx->atan; A.soft = S.d_soft; A.w_out = nullptr; A.plan = S.d_plan;
     hipLaunchKernelGGL(k_ht40_frame, dim3((bf + 3) / 4), dim3(256), 0, S.stream, A);
     if (rx->lanes16)
-        hipLaunchKernelGGL(k_viterbi16_11n, dim3((bj + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((bj + 7) / 8 + 2), dim3(64), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u,
+                (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     else
-        hipLaunchKernelGGL(k_viterbi11n, dim3((bj / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u, (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
+        hipLaunchKernelGGL(k_viterbi11n, dim3((bj / 2 + 3 + 3) / 4), dim3(256), 0, S.stream, (const VitJob*)S.d_jobs, (const uint32_t*)S.d_njobs, 0u,
+                (uint32_t)stride, (const uint8_t*)S.d_soft, S.d_vout);
     Ht40FinishArgs Fi; Fi.jobs = S.d_fjobs; Fi.njobs = bj; Fi.vout = S.d_vout; Fi.mpdu = S.d_mpdu; Fi.rows = S.d_rows; Fi.T = rx->T; Fi.plan = S.d_plan;
     hipLaunchKernelGGL(k_ht40_finish, dim3((bj + 3) / 4), dim3(256), 0, S.stream, Fi);
     HIPCHK40(hipGetLastError());
@@ -627,14 +661,16 @@ static int ht40_collect_events(Ht40Slot& S)
         const uint32_t n = std::min(S.h_nfr[c], mf);
         for (uint32_t i = 0; i < n; i++) {
             const Ht40Found& F = S.h_found[c * mf + i];
-            Ht40Event E; E.capture_id = S.h_caps[c].capture_id; E.end_sample = F.end_sample; E.error_code = F.error_code; E.mcs = F.mcs; E.length = F.ht_len; E.nsym = F.nsym; E.frame = -1;
+            Ht40Event E; E.capture_id = S.h_caps[c].capture_id; E.end_sample = F.end_sample; E.error_code = F.error_code; E.mcs = F.mcs; E.length = F.ht_len;
+                E.nsym = F.nsym; E.frame = -1;
             E.truncated = (i + 1 == mf && S.h_nfr[c] > mf);
             if (F.error_code == 0) E.frame = (int)nf++;                            // (the order k_ht40_plan numbers the frames in)
             S.events.push_back(E);
         }
     }
     S.nframes = S.h_plan[0];
-    if (S.plan_error || nf != S.h_plan[1]) { S.plan_error = true; S.nframes = 0; return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: the captures hold more frames / soft values than the handle was created for (max_frames, max_soft_values)", 0); }
+    if (S.plan_error || nf != S.h_plan[1]) { S.plan_error = true; S.nframes = 0; return sora_internal_fail(SORA_ERR_CAPACITY,
+            "sora_ht40_process_captures_dev: the captures hold more frames / soft values than the handle was created for (max_frames, max_soft_values)", 0); }
     return SORA_OK;
 }
 
@@ -655,7 +691,8 @@ static int ht40_slot_results(sora_ht40_t* rx, Ht40Slot& S, sora_frame_result* ou
                 if (n >= max_out) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_results: output buffer too small", 0);
                 sora_frame_result& o = out[n++];
                 memset(&o, 0, sizeof(o));
-                o.capture_id = E.capture_id; o.end_sample = E.end_sample; o.error_code = E.error_code; o.flags = E.truncated ? SORA_ROW_TRUNCATED : 0; o.mpdu_offset = (uint32_t)moff;
+                o.capture_id = E.capture_id; o.end_sample = E.end_sample; o.error_code = E.error_code; o.flags = E.truncated ? SORA_ROW_TRUNCATED : 0;
+                    o.mpdu_offset = (uint32_t)moff;
                 if (E.frame >= 0) {
                     const Rx11bRow& r = rows[2 * (size_t)E.frame + k];
                     o.start_sample = (uint32_t)k; o.rate_kbps = E.mcs; o.nsym = (uint16_t)E.nsym; o.error_code = r.error_code; o.length = (uint16_t)r.length; o.crc32 = r.crc32;
@@ -731,7 +768,8 @@ int sora_ht40_wait_any(sora_ht40_t* rx, int* ticket)
         bool pending; hipError_t err;
         Ht40Slot* S = slots_poll(rx->slot, kHt40Slots, &pending, &err);
         if (err != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_ht40_wait_any: hipEventQuery", (int)err);
-        if (S) { const int t = S->ticket; const int rc = sora_ht40_wait(rx, t); *ticket = t; return rc; }   // (the ticket is reported even when its call outgrew the handle's capacity)
+        // (the ticket is reported even when its call outgrew the handle's capacity)
+        if (S) { const int t = S->ticket; const int rc = sora_ht40_wait(rx, t); *ticket = t; return rc; }
         if (!pending) return sora_internal_fail(SORA_ERR_FAILED, "sora_ht40_wait_any: no call with an enqueued delivery (sora_ht40_deliver_async) is in flight", 0);
         if (spin > 64) std::this_thread::yield();
     }
@@ -742,7 +780,8 @@ int sora_ht40_deliver_async(sora_ht40_t* rx, int ticket, sora_frame_result* h_ro
     Ht40Slot* S = ht40_slot_of(rx, ticket);
     if (!S) return sora_internal_fail(SORA_ERR_INVALID_PARAM, kStaleHt40, 0);
     HIPCHK40(hipSetDevice(rx->device));
-    if (S->capture_mode) {                                                      // raw captures: the event table (rows per event, template rows, source rows) and the event count were written by
+    // raw captures: the event table (rows per event, template rows, source rows) and the event count were written by
+    if (S->capture_mode) {
         // k_ht40_plan; the host knows only the bound ncaps x max_frames_per_capture.  The table is the one sora_ht40_results_of reports: a header that failed is a row, the
         // last row a full capture could hold carries SORA_ROW_TRUNCATED (round 4; before, only decoded frames were delivered).
         const int rc = sora_internal_dense_deliver(&S->dense, S->d_rows, S->d_evn, nullptr, nullptr, S->bound_events, 2, S->d_mpdu, S->stream,

@@ -55,10 +55,12 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     const uint32_t* iq = A.iq + A.caps[r.capture].offset;
     auto wsync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     const Fft64TwPk W = fft64_twiddles_pk(T, e);
-    PkTw fq[4], ch[4];                                                           // FreqCoeffs / ChannelCoeffs as the operand pairs of the packed complex product
+    // FreqCoeffs / ChannelCoeffs as the operand pairs of the packed complex product
+    PkTw fq[4], ch[4];
 #pragma unroll
     for (int m = 0; m < 4; m++) { fq[m] = pk_tw_mul(fx->freq[e + 16 * m]); ch[m] = pk_tw_mul(fx->chan[e + 16 * m]); }
-    const int nb = __builtin_amdgcn_readfirstlane((int)r.nbpsc), ncbps = 48 * nb, nsym = __builtin_amdgcn_readfirstlane((int)r.nsym);   // (wave-uniform: scalar branches on the modulation)
+    // (wave-uniform: scalar branches on the modulation)
+    const int nb = __builtin_amdgcn_readfirstlane((int)r.nbpsc), ncbps = 48 * nb, nsym = __builtin_amdgcn_readfirstlane((int)r.nsym);
     // de-interleaver source indices of output positions 8 lane .. 8 lane + 7 (lane < N_CBPS / 8: one three-byte group of the packed stream), two per register
     uint32_t mp[4];
     const bool packs = 8 * lane < ncbps;
@@ -67,7 +69,8 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
 #pragma unroll
         for (int t = 0; t < 4; t++) mp[t] = packs ? (uint32_t)map[8 * lane + 2 * t] | ((uint32_t)map[8 * lane + 2 * t + 1] << 16) : 0u;
     }
-    uint8_t* dst = A.soft + (size_t)r.slot0 * kSoftBytesPerSlot;                  // the frame's packed soft stream: symbol s (1-based) at 3 N_CBPS / 8 * (s - 1) bytes
+    // the frame's packed soft stream: symbol s (1-based) at 3 N_CBPS / 8 * (s - 1) bytes
+    uint8_t* dst = A.soft + (size_t)r.slot0 * kSoftBytesPerSlot;
     // pilot k in lane k: bins 43, 57, 7, 21 = carriers -21, -7, +7, +21 (pilot.hpp:138-164)
     const int pk = lane & 3;
     const int pbin = pk == 0 ? 43 : pk == 1 ? 57 : pk == 2 ? 7 : 21, pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;
@@ -239,7 +242,8 @@ __device__ __forceinline__ void sym_front_block(const RxArgs& A, uint32_t bid, u
     const unsigned long long owned = __ballot(my_own != 0xFFFFFFFFu);
     if (owned == 0) return;                                                      // preamble / silence only
     const uint32_t row0 = (uint32_t)__builtin_amdgcn_readlane((int)my_own, __builtin_ctzll(owned));
-    const bool one_frame = __ballot(lane < 16 && my_own != 0xFFFFFFFFu && my_own != row0) == 0;   // the usual case: every owned slot of the wave belongs to ONE frame
+    // the usual case: every owned slot of the wave belongs to ONE frame
+    const bool one_frame = __ballot(lane < 16 && my_own != 0xFFFFFFFFu && my_own != row0) == 0;
     uint32_t own[kSlotIters];
 #pragma unroll
     for (int it = 0; it < kSlotIters; it++) own[it] = (uint32_t)__shfl((int)my_own, 4 * it + g);
@@ -337,9 +341,11 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
 #pragma unroll
     for (int o = 32; o >= 4; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
     nmax = __builtin_amdgcn_readfirstlane(nmax);
-    const uint32_t* pp = A.pil + (size_t)(r.slot0 + 1u) * 4u + (uint32_t)pk;    // pilot k of data symbol s at pp[4 (s - 1)]: 16 bytes per symbol and frame (k_sym_front)
+    // pilot k of data symbol s at pp[4 (s - 1)]: 16 bytes per symbol and frame (k_sym_front)
+    const uint32_t* pp = A.pil + (size_t)(r.slot0 + 1u) * 4u + (uint32_t)pk;
     TrackRec* trk = A.track + r.slot0 + 1u;
-    constexpr int kAhead = 4;                                                    // symbols requested ahead of the one in the chain (each step is two dependent table reads long)
+    // symbols requested ahead of the one in the chain (each step is two dependent table reads long)
+    constexpr int kAhead = 4;
     uint32_t q[kAhead];
 #pragma unroll
     for (int i = 0; i < kAhead; i++) q[i] = i < nsym ? pp[4 * i] : 0u;
@@ -381,7 +387,8 @@ __global__ void __launch_bounds__(256) k_track(RxArgs A)
 // 0x8000 for a symbol of pilot polarity -1.  Advances the state and returns the symbol's TrackRec { cfo_comp, sfo_comp, avg, del } as two words.
 __device__ __forceinline__ uint2 track_step(const TrkTables& s_t, uint32_t cur, int flip, int pc, int m3, int& cfo, int& sfo, int& ctr, int& str)
 {
-    constexpr float kInv28 = 0.0357142873108387f;                                // 0x3D124925: trunc((float)d * kInv28) == d / 28 (C division) for every |d| <= 65535
+    // 0x3D124925: trunc((float)d * kInv28) == d / 28 (C division) for every |d| <= 65535
+    constexpr float kInv28 = 0.0357142873108387f;
     // rot_coeff(cfo + pc sfo) = (ucos, -usin) out of the quarter wave
     const unsigned a = (unsigned)(cfo + pc * sfo) & 0xFFFFu;
     const int qi = trk_quarter_index(a);
@@ -447,7 +454,8 @@ __device__ __forceinline__ void track_tables_to_lds(const uint32_t* __restrict__
 __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
 {
     __shared__ TrkTables s_t;
-    __shared__ uint32_t s_pol[128];                                              // the pilot polarities (pilot.hpp:10-28, period 127) of the eight symbols from count c on, one bit each
+    // the pilot polarities (pilot.hpp:10-28, period 127) of the eight symbols from count c on, one bit each
+    __shared__ uint32_t s_pol[128];
     track_tables_to_lds(A.T.trk, s_t, s_pol);
     __syncthreads();
     const int lane = threadIdx.x & 63, pk = lane & 3;
@@ -464,7 +472,8 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
     }
     const int pc = pk == 0 ? -21 : pk == 1 ? -7 : pk == 2 ? 7 : 21;             // pilot k in lane k: carriers -21, -7, +7, +21 (pilot.hpp:138-164)
     const int m3 = pk == 3 ? -1 : 0;                                             // the fourth pilot's angle is taken of -p (pilot.hpp:166-233)
-    int cfo = r.cfo_comp, sfo = r.sfo_comp, ctr = r.cfo_tracker, str = r.sfo_tracker;   // cfo / sfo wrapped to 16 bits after every step; the trackers run free (they are only ever added)
+    // cfo / sfo wrapped to 16 bits after every step; the trackers run free (they are only ever added)
+    int cfo = r.cfo_comp, sfo = r.sfo_comp, ctr = r.cfo_tracker, str = r.sfo_tracker;
     int nmax = nsym;
 #pragma unroll
     for (int o = 32; o >= 4; o >>= 1) nmax = max(nmax, __shfl_xor(nmax, o));
@@ -472,16 +481,19 @@ __global__ void __launch_bounds__(256) k_track_lds(RxArgs A)
     // pilot k of data symbol s is word 4 (slot0 + s) + k of pil[] (k_sym_front); a record goes to track[slot0 + s].  32-bit word offsets from the arrays' bases, so that a
     // request is a minimum, a shift-add and the load.  Symbols past the frame's last re-read its last pilots and their records land on the slot behind the frame --
     // preamble or silence of whatever follows, a slot no frame owns and k_sym_back never reads.
-    const uint32_t w0 = (jr.ok ? (r.slot0 + 1u) * 4u + (uint32_t)pk : (uint32_t)pk) * 4u;   // BYTE offsets: a uniform base plus a 32-bit lane offset is one address operand pair
+    // BYTE offsets: a uniform base plus a 32-bit lane offset is one address operand pair
+    const uint32_t w0 = (jr.ok ? (r.slot0 + 1u) * 4u + (uint32_t)pk : (uint32_t)pk) * 4u;
     const uint32_t t0 = (jr.ok ? r.slot0 + 1u : A.total_slots + 1u) * 8u;        // (no job: a slot in the arrays' slack)
     const char* __restrict__ pil = reinterpret_cast<const char*>(A.pil);
     char* __restrict__ trk2 = reinterpret_cast<char*>(A.track);
     const unsigned last = (unsigned)max(nsym, 1) - 1u, nrec = (unsigned)nsym;
-    constexpr int kAhead = 8;                                                    // symbols requested ahead of the one in the chain (a step is ~0.1 us, an L2 miss ten times that)
+    // symbols requested ahead of the one in the chain (a step is ~0.1 us, an L2 miss ten times that)
+    constexpr int kAhead = 8;
     uint32_t q[kAhead];
 #pragma unroll
     for (int i = 0; i < kAhead; i++) q[i] = *reinterpret_cast<const uint32_t*>(pil + (w0 + 16u * min((unsigned)i, last)));
-    unsigned cnt = 0;                                                            // symbol_count: 127 -> 0 after the SIGNAL symbol; the same in every frame of the wave
+    // symbol_count: 127 -> 0 after the SIGNAL symbol; the same in every frame of the wave
+    unsigned cnt = 0;
     for (int s0 = 1; s0 <= nmax; s0 += kAhead) {
         const unsigned pol = (unsigned)__builtin_amdgcn_readfirstlane((int)s_pol[cnt]);   // the polarities of the block's eight symbols, one scalar byte
         cnt = cnt + (unsigned)kAhead >= 127u ? cnt + (unsigned)kAhead - 127u : cnt + (unsigned)kAhead;
@@ -590,7 +602,8 @@ __global__ void __launch_bounds__(256) k_sym_back(RxArgs A)
         return;
     }
     // ---- several frames meet in these 16 slots: per group and quad
-    int cur_nb = 0; uint32_t mp[4] = { 0, 0, 0, 0 };                             // de-interleaver entries of output positions 8 lane .. 8 lane + 7 for modulation cur_nb
+    // de-interleaver entries of output positions 8 lane .. 8 lane + 7 for modulation cur_nb
+    int cur_nb = 0; uint32_t mp[4] = { 0, 0, 0, 0 };
 #pragma unroll 1
     for (int it = 0; it < kSlotIters; it++) {
         const unsigned quad = (unsigned)(owned >> (4 * it)) & 0xFu;
@@ -652,7 +665,8 @@ __global__ void __launch_bounds__(256) k_sym_back(RxArgs A)
 // of LDS each, one per CU, at most ~190 of the 256), and every wait is bounded: a wait that expires sets flags[0] and gives up, k_finish then reports every frame
 // of the call as SORA_E_INTERNAL_TIMEOUT instead of a result (never seen; the bound is one second).  Hand-offs follow cdna_hip_programming.md guideline 16.
 // The proof of the units and the serial decode of what fails it stay a kernel of their own behind this one (k_win_redo), then k_finish.
-constexpr uint32_t kPipeMaxSym = 1376;                                           // pilots kept in LDS: 1366 data symbols (4095 bytes at 6 Mbps) + the chain's overshoot to a multiple of eight
+// pilots kept in LDS: 1366 data symbols (4095 bytes at 6 Mbps) + the chain's overshoot to a multiple of eight
+constexpr uint32_t kPipeMaxSym = 1376;
 constexpr uint32_t kPipeRing = 512;                                              // records kept in LDS (a ring: the helpers are a few symbols behind the chain)
 struct PipeTrackLds {
     TrkTables t;
@@ -660,7 +674,8 @@ struct PipeTrackLds {
     uint32_t pil[kPipeMaxSym][4];
     uint2 rec[kPipeRing];
     uint8_t demap[1024];
-    uint8_t soft[3][4][288];                                                     // [helper][symbol of the quad]: soft values in carrier order, then the quad's packed bytes on their way out
+    // [helper][symbol of the quad]: soft values in carrier order, then the quad's packed bytes on their way out
+    uint8_t soft[3][4][288];
     uint32_t done;                                                               // symbols the chain has passed
     uint32_t next_quad[3];                                                       // the quad each helper works on (all below the smallest are finished)
     uint32_t give_up;
@@ -693,7 +708,8 @@ __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs
         VitJob J;
         J.valid = 1; J.soft_off = slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
         J.dec_off = 0; J.out_off = slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
-        A.jobs[j] = J;                                                           // (for the kernels behind this launch; the trellis waves of this one work it out themselves)
+        // (for the kernels behind this launch; the trellis waves of this one work it out themselves)
+        A.jobs[j] = J;
         L.done = 0; L.give_up = 0; L.next_quad[0] = 0; L.next_quad[1] = 1; L.next_quad[2] = 2;
     }
     if (w == 0) {
@@ -712,7 +728,9 @@ __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs
     }
     __syncthreads();
     if (L.give_up) return;
-    {   // the frame's pilots (16 bytes per symbol: k_sym_front's dense copy) -> LDS, by loads that pass this CU's L1 (sc1: the acquire that plain loads would need is ~1.7 us
+    // the frame's pilots (16 bytes per symbol: k_sym_front's dense copy) -> LDS, by loads
+    // that pass this CU's L1 (sc1: the acquire that plain loads would need is ~1.7 us
+    {
         // in front of the chain; the helpers, who read eq[] with plain loads, make theirs beside it); the overshoot reads zeros
         const unsigned long long* src = reinterpret_cast<const unsigned long long*>(A.pil) + 2u * (size_t)(slot0 + 1u);
         unsigned long long* dst = reinterpret_cast<unsigned long long*>(&L.pil[0][0]);
@@ -730,7 +748,8 @@ __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs
             unsigned cnt = 0;
             volatile uint32_t* done = &L.done; volatile uint32_t* nq = L.next_quad;
             for (uint32_t s0 = 1; s0 <= nsym; s0 += 8u) {
-                if (s0 + 7u > kPipeRing) {                                       // the records about to be overwritten must have been used (frames of more than 512 symbols only)
+                // the records about to be overwritten must have been used (frames of more than 512 symbols only)
+                if (s0 + 7u > kPipeRing) {
                     while (4u * min(min(nq[0], nq[1]), nq[2]) + kPipeRing < s0 + 7u) __builtin_amdgcn_s_sleep(1);
                 }
                 const unsigned pol = (unsigned)__builtin_amdgcn_readfirstlane((int)L.pol[cnt]);
@@ -768,7 +787,8 @@ __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs
     volatile uint32_t* done = &L.done; volatile uint32_t* nq = L.next_quad;
     uint32_t* my_count = P.flags + 4u + 4u * f + (uint32_t)h;
     uint32_t quads = 0;
-    uint8_t* bytes = &L.soft[h][0][0];                                           // (the quad's packed bytes reuse the helper's soft values' place once those are gathered)
+    // (the quad's packed bytes reuse the helper's soft values' place once those are gathered)
+    uint8_t* bytes = &L.soft[h][0][0];
     for (uint32_t k = (uint32_t)h; 4u * k < nsym; k += 3u) {
         const uint32_t nact = min(4u, nsym - 4u * k), s = 4u * k + 1u + (uint32_t)g;   // group g's symbol (1-based)
         const bool mine = (uint32_t)g < nact;
@@ -890,7 +910,8 @@ struct VitSide {            // wave-uniform per-frame bookkeeping
 // WIN / LOOK: the window schedule of T11aViterbi<.., N_INPUT, TRELLIS_DEPTH = WIN, TRELLIS_LOOKAHEAD = LOOK> -- 256 / 24 in the 802.11a graph
 // (fb11ademod_config.hpp:199), 192 / 36 in the 802.11n graph (fb11ndemod_config.hpp:199); a walk touches at most (WIN + LOOK + 7) / 8 + 2 <= 38 blocks.
 template <int CR, int WIN, int LOOK, int BITS>
-__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base, uint8_t* __restrict__ out_base, uint16_t* ring, uint16_t* ops)
+__device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& JB, bool hasB, const uint8_t* __restrict__ soft_base,
+        uint8_t* __restrict__ out_base, uint16_t* ring, uint16_t* ops)
 {
     using RG = RingGeom<WIN, LOOK>;
     constexpr int P = RG::P;
@@ -926,11 +947,13 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
 
     uint32_t tr = 0, ob = 0;                                                    // ob: bits handed out by the partial windows (same schedule for both frames)
 
-    auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };                // Normalize (viterbicore.h:444-465), both frames; marks and guard are clear here and no half borrows (its minimum is subtracted): one 32-bit VOP2
+    // Normalize (viterbicore.h:444-465), both frames; marks and guard are clear here and no half borrows (its minimum is subtracted): one 32-bit VOP2
+    auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };
 #ifdef SORA_DBG_NO_TRACE                                                        // experiment (tools/ab_decode.sh): the forward pass alone -- results are wrong, only the duration means something
     auto trace = [&](unsigned, unsigned, uint32_t, uint32_t, uint32_t) {};
 #else
-    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RG::kMaxWalk>(V.U, ring, tr, ob, mA, mB, cntA, cntB, A.out, B.out, top); };
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RG::kMaxWalk>(V.U, ring, tr, ob, mA, mB, cntA, cntB,
+            A.out, B.out, top); };
 #endif
     auto next_event = [&]() -> uint32_t {
         uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
@@ -966,7 +989,8 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
     SoftCursor<BITS, CW> cur;
     cur.init(my_soft_off, my_k, my_last);
     auto fetch = [&](uint32_t c) -> SoftRaw { return cur.fetch(soft_base, c); };
-    uint16_t* my_op = ops + 2u * my_k + (lane >> 5);                           // operand k, frame's half (k up to 31: the table has 32 operands, those past CW are never read)
+    // operand k, frame's half (k up to 31: the table has 32 operands, those past CW are never read)
+    uint16_t* my_op = ops + 2u * my_k + (lane >> 5);
     auto lds_order = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     auto unpack = [&](const SoftRaw& R) -> Chunk {
         *my_op = (uint16_t)cur.field(R);
@@ -1042,11 +1066,14 @@ struct DecodeEveryPair { __device__ __forceinline__ bool operator()(uint32_t, ui
 struct NothingAfter { __device__ __forceinline__ void operator()(uint32_t, uint32_t, uint32_t, bool) const {} };
 // (gate(list, fa, fb, hasB): decode this pair at all?  after(...): what the wave does with its pair once the pair's bytes are final -- k_win_redo_finish's T11aDesc / frame sink)
 template <int WIN, int LOOK, int BITS, typename GATE = DecodeEveryPair, typename AFTER = NothingAfter>
-__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out,
+__device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single,
+        uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out,
                                                     GATE gate = GATE(), AFTER after = AFTER())
 {
-    __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];                // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
-    __shared__ uint16_t s_ops[4][64];                                            // [wave][operand of the chunk][frame]: the soft values as metric fields (viterbi_forward); with it under 40 KB: four workgroups per CU
+    // 39 KB / 33 KB: survivor history, two copies of every block (RingGeom), per wave
+    __shared__ uint16_t s_ring[4][RingGeom<WIN, LOOK>::kEntries];
+    // [wave][operand of the chunk][frame]: the soft values as metric fields (viterbi_forward); with it under 40 KB: four workgroups per CU
+    __shared__ uint16_t s_ops[4][64];
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };   // everything below is per-wave uniform: keep it in SGPRs
     // wave -> (code-rate list, pair): list r has ceil(n_r / 2) pairs (njobs3 == nullptr: one list of njobs_single jobs)
     uint32_t n[3] = { njobs_single, 0, 0 };
@@ -1077,10 +1104,12 @@ __device__ __forceinline__ void viterbi_kernel_body(const VitJob* __restrict__ j
     after(list, fa, fb, fb < njobs);
 }
 
-__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(256) k_viterbi(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride,
+        const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi_kernel_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out); }
 // the 802.11n graph's decoder: T11aViterbi<5000*8, 312, 192, 36> (fb11ndemod_config.hpp:199)
-__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single,
+        uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi_kernel_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }
 
 // The window-parallel trellis's proof AND the serial decode of what failed it, in one launch (k_vitwin.hip describes the proof; a verify kernel + k_viterbi as two
@@ -1119,7 +1148,8 @@ struct WinProofGate {
         return ba != 0ull;
     }
 };
-__global__ void __launch_bounds__(256) k_win_redo(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* __restrict__ vecs,
+__global__ void __launch_bounds__(256) k_win_redo(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target,
+        uint32_t vstride, const uint16_t* __restrict__ vecs,
                                                   const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, unsigned long long* __restrict__ stats)
 { viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, WinProofGate{ jobs, hdr, jstride, target, vstride, vecs, stats }); }
 
@@ -1135,7 +1165,8 @@ __global__ void __launch_bounds__(256) k_win_redo(const VitJob* __restrict__ job
 //     instead of a 4500-instruction byte-serial chain on one lane.
 struct FinishLds {
     uint32_t crc[256]; uint32_t z[6 * 8 * 16]; uint32_t bufs[4][2504 / 4 + 2];
-    uint32_t seq4[128];          // the scrambler sequence's bytes at phases p, p + 8, p + 16, p + 24 (mod 127) as one word: what four consecutive MPDU bytes are xored with
+    // the scrambler sequence's bytes at phases p, p + 8, p + 16, p + 24 (mod 127) as one word: what four consecutive MPDU bytes are xored with
+    uint32_t seq4[128];
     uint8_t  phase[128];         // T.scr_phase
 };
 __device__ __forceinline__ void finish_tables_to_lds(const RxArgs& A, FinishLds& L)      // (256 threads; the caller's barrier follows)
@@ -1155,7 +1186,8 @@ __device__ __forceinline__ void finish_frame(const RxArgs& A, uint32_t f, Finish
     FrameRow& r = A.frames[f];
     if (!r.valid || r.error_code != 0) return;
     const int lane = threadIdx.x & 63;
-    if (A.pipe_flags && A.pipe_flags[0] != 0u) {                                 // a hand-off inside k_pipe ran into its one-second bound: no result is better than a wrong one
+    // a hand-off inside k_pipe ran into its one-second bound: no result is better than a wrong one
+    if (A.pipe_flags && A.pipe_flags[0] != 0u) {
         if (lane == 0) r.error_code = E_INTERNAL_TIMEOUT;
         return;
     }
@@ -1234,7 +1266,8 @@ __global__ void __launch_bounds__(256) k_win_redo_finish(const VitJob* __restric
 // k_pack: compacts the per-capture frame table into dense sora_frame_result rows in (capture, time) order, on the
 // device, so the rows can feed an RCCL all-gather without a host round trip.  mpdu_offset = slot0 * 32 indexes the
 // device MPDU array directly.  One 1024-thread block: captures are scanned in tiles of 1024.
-struct PackedRow { uint32_t capture_id, start_sample, end_sample, error_code, rate_kbps; uint16_t length, nsym; uint32_t crc32; int16_t cfo_est; uint16_t flags; uint32_t mpdu_offset; };
+struct PackedRow { uint32_t capture_id, start_sample, end_sample, error_code, rate_kbps; uint16_t length, nsym; uint32_t crc32; int16_t cfo_est;
+    uint16_t flags; uint32_t mpdu_offset; };
 __global__ void __launch_bounds__(1024) k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames,
                                                PackedRow* rows, uint32_t* nrows_out)
 {

@@ -30,15 +30,18 @@
 namespace sora {
 
 namespace {
-constexpr uint32_t E_NOT_SUPPORTED = 0x80000003u, E_SFD_FAIL = 0x80000004u, E_SFD_TIMEOUT = 0x80000008u, E_SYNC_TIMEOUT = 0x80000009u;   // the others: rx_types.h
+// the others: rx_types.h
+constexpr uint32_t E_NOT_SUPPORTED = 0x80000003u, E_SFD_FAIL = 0x80000004u, E_SFD_TIMEOUT = 0x80000008u, E_SYNC_TIMEOUT = 0x80000009u;
 enum { RATE_SYNC = 0, RATE_1M, RATE_2M, RATE_5P5M, RATE_11M };
 enum { NO_PEAK_FOUND = 0, PEAK_FOUND, PEAK_VALID, PEAK_VALIDED, BARKER_SYNCED };
 constexpr uint32_t kOutBuf = 4096;                                    // OUTPUTBUF_SIZE (fb11b_demod.cpp:21)
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }
 __device__ __forceinline__ int lane_of(int v, int l) { return __builtin_amdgcn_readlane(v, uni(l)); }
-template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }   // lanes without a source read 0
-__device__ __forceinline__ int quad_sum(int v) { v += dpp<0xB1>(v); return v + dpp<0x4E>(v); }                   // quad_perm [1,0,3,2], [2,3,0,1]: every lane of a quad gets its sum
+// lanes without a source read 0
+template <int CTRL> __device__ __forceinline__ int dpp(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+// quad_perm [1,0,3,2], [2,3,0,1]: every lane of a quad gets its sum
+__device__ __forceinline__ int quad_sum(int v) { v += dpp<0xB1>(v); return v + dpp<0x4E>(v); }
 __device__ __forceinline__ int sum8(int v) { v = quad_sum(v); return v + dpp<0x104>(v); }                        // + row_shl:4: lanes 0..3 hold lanes 0..7
 __device__ __forceinline__ void lds_order() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 __device__ __forceinline__ uint32_t dot_sign(int rre, int rim, int xre, int xim)          // (ulong)(ref.re*s.re + ref.im*s.im) >> 31
@@ -54,10 +57,12 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
 {
     __shared__ uint8_t s_out_all[4][kOutBuf];
     __shared__ int s_state_all[4][32];                                  // per wave: [0..19] TBarkerSync partial sums, [20..27] TEnergyDetect window
-    __shared__ uint32_t s_crc_all[8][256];                              // CRC-32 tables: [0] the byte table, [k] = the same after k more zero bytes ("slicing"), built below
+    // CRC-32 tables: [0] the byte table, [k] = the same after k more zero bytes ("slicing"), built below
+    __shared__ uint32_t s_crc_all[8][256];
     uint32_t* const s_crc = s_crc_all[0];
     __shared__ int s_sym_all[4][2][64];                                 // per wave: despread sums of the symbols of one bulk pass (re, im)
-    __shared__ __attribute__((aligned(16))) uint32_t s_chip_all[CCK ? 4 : 1][CCK ? 544 : 4];         // per wave: the chips of one bulk pass over a CCK payload (queued ones first)
+    // per wave: the chips of one bulk pass over a CCK payload (queued ones first)
+    __shared__ __attribute__((aligned(16))) uint32_t s_chip_all[CCK ? 4 : 1][CCK ? 544 : 4];
     s_crc[threadIdx.x] = A.crc[threadIdx.x];
     __syncthreads();
     { uint32_t t = s_crc[threadIdx.x]; for (int k = 1; k < 8; k++) { t = s_crc[t & 0xFF] ^ (t >> 8); s_crc_all[k][threadIdx.x] = t; } }
@@ -92,7 +97,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     int m_index = 2, m_frag = 0;                                                          // TSymTiming
     int sync_flag = NO_PEAK_FOUND, last_peak_cnt = -1, m_max = 0, search_count = 0;      // TBarkerSync
     int chip_n = 0, acc_re = 0, acc_im = 0;                                               // the current port's despreader
-    int cck_n = 0; uint32_t cck_even = 0; uint32_t cbuf = 0;                              // TCCK5P5Decoder / TCCK11Decoder: queued chips (lane j = j-th chip, packed), is_even
+    // TCCK5P5Decoder / TCCK11Decoder: queued chips (lane j = j-th chip, packed), is_even
+    int cck_n = 0; uint32_t cck_even = 0; uint32_t cbuf = 0;
     int bit_one_found = 0; uint32_t word = 0; int bit_err_cnt = 0; uint32_t sync_cnt = 0; // TSFDSync
     int sym_n = 0; uint32_t sym_byte = 0; int ref_re = 0, ref_im = 0;                     // TDBPSKDemap / TDQPSKDemap burst in progress
     int hdr_n = 0; uint32_t hdr_lo = 0, hdr_hi = 0;                                       // TBB11bPlcpParser's 6-byte burst
@@ -198,7 +204,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         o.l5  = (int)((uint32_t)(bxr * byr) - (uint32_t)(((-bxi0) >> 2) * byi));     // 5.5 Mbps: B[0].im is negated BEFORE the shift (cck.hpp:94-98)
         return o;
     };
-    auto cck_dqpsk = [&](int pos, int xre, int xim) __attribute__((always_inline)) {                   // demap_dqpsk_bits (core/inc/soradsp.h:190-198): halves first
+    // demap_dqpsk_bits (core/inc/soradsp.h:190-198): halves first
+    auto cck_dqpsk = [&](int pos, int xre, int xim) __attribute__((always_inline)) {
         const int re = (int)((uint32_t)(last_re * xre) + (uint32_t)(last_im * xim)) >> 1, im = (int)((uint32_t)(last_re * xim) - (uint32_t)(last_im * xre)) >> 1;
         return ((((uint32_t)re + (uint32_t)im) >> 31) << pos) | ((((uint32_t)re - (uint32_t)im) >> 31) << (pos + 1));
     };
@@ -221,15 +228,18 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             M = other ? oM : M; V = other ? oV : V;
         }
         const int m1 = lane_of(M, 0), m2 = lane_of(M, 4), m3 = lane_of(M, 8), m4 = lane_of(M, 12);
-        const uint32_t v1 = (uint32_t)lane_of((int)V, 0), v2 = (uint32_t)lane_of((int)V, 4) | 0x08u, v3 = (uint32_t)lane_of((int)V, 8) | 0x04u, v4 = (uint32_t)lane_of((int)V, 12) | 0x0Cu;
-        uint32_t out = m1 > m2 ? (m1 > m4 ? v1 : v4) : (m2 > m3 ? v2 : v3);                          // "lable4" tests 3pi/2 against module 1, else pi against module 2
+        const uint32_t v1 = (uint32_t)lane_of((int)V, 0), v2 = (uint32_t)lane_of((int)V, 4) | 0x08u, v3 = (uint32_t)lane_of((int)V,
+                8) | 0x04u, v4 = (uint32_t)lane_of((int)V, 12) | 0x0Cu;
+        // "lable4" tests 3pi/2 against module 1, else pi against module 2
+        uint32_t out = m1 > m2 ? (m1 > m4 ? v1 : v4) : (m2 > m3 ? v2 : v3);
         const int p7 = lane_of((int)w, 7); const int xre = (int)(short)p7, xim = p7 >> 16;
         out |= cck_dqpsk(0, xre, xim);
         out ^= (cck_even << 1) | cck_even; cck_even ^= 1u;
         last_re = xre; last_im = xim;
         return out & 0xFFu;
     };
-    auto cck5p5_decode = [&](uint32_t w) __attribute__((always_inline)) {                              // TCCK5P5Decoder: even + odd half byte (cck.hpp:26-46, 70-206)
+    // TCCK5P5Decoder: even + odd half byte (cck.hpp:26-46, 70-206)
+    auto cck5p5_decode = [&](uint32_t w) __attribute__((always_inline)) {
         uint32_t out = 0;
 #pragma unroll
         for (int half = 0; half < 2; half++) {
@@ -353,7 +363,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 const int port = uni(rxrate), sre = w16(acc_re + a_re), sim = w16(acc_im + a_im);
                 acc_re = w16(b_re); acc_im = w16(b_im); chip_n = chip_n + cnt - 11;
                 symbol_out(port, sre, sim);
-                if (uni(rxrate) > RATE_2M) {                            // the header has just announced a CCK rate: the chips after the symbol boundary are the first of the payload
+                // the header has just announced a CCK rate: the chips after the symbol boundary are the first of the payload
+                if (uni(rxrate) > RATE_2M) {
                     const int k0 = cnt - chip_n, n = chip_n;
                     chip_n = 0; acc_re = acc_im = 0;
                     cck_push(pack(mk(cre, cim)), k0, n);
@@ -407,12 +418,16 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         vec = (uint32_t)lane == ln ? val : vec;
     };
     typedef short bs16x2_t __attribute__((ext_vector_type(2)));
-    auto pk_sub = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) - __builtin_bit_cast(bs16x2_t, b))); };
-    auto pk_add = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) + __builtin_bit_cast(bs16x2_t, b))); };
+    auto pk_sub = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t,
+            a) - __builtin_bit_cast(bs16x2_t, b))); };
+    auto pk_add = [](uint32_t a, uint32_t b) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t,
+            a) + __builtin_bit_cast(bs16x2_t, b))); };
     auto pk_sra = [](uint32_t a, int n) __attribute__((always_inline)) { return __builtin_bit_cast(uint32_t, (bs16x2_t)(__builtin_bit_cast(bs16x2_t, a) >> (short)n)); };
-    auto bulk_pass = [&](uint32_t& pos_, uint32_t& remain_, uint32_t& c_start_, uint32_t& c_stale_, uint32_t& p_start_, uint32_t& p_stale_, int qoff_) __attribute__((always_inline)) -> bool {
+    auto bulk_pass = [&](uint32_t& pos_, uint32_t& remain_, uint32_t& c_start_, uint32_t& c_stale_, uint32_t& p_start_, uint32_t& p_stale_,
+            int qoff_) __attribute__((always_inline)) -> bool {
         const int port = uni(rxrate);
-        const int mode = port == RATE_SYNC ? 0 : (!uni(plcp_data) ? 1 : port <= RATE_2M ? 2 : 3);   // 0: TSFDSync, 1: the PLCP header's bytes, 2: a Barker payload's, 3: a CCK payload's
+        // 0: TSFDSync, 1: the PLCP header's bytes, 2: a Barker payload's, 3: a CCK payload's
+        const int mode = port == RATE_SYNC ? 0 : (!uni(plcp_data) ? 1 : port <= RATE_2M ? 2 : 3);
         if (mode == 1 && port != RATE_1M) return false;
         if (mode == 3 && !CCK) return false;
         const int spb = port == RATE_2M ? 4 : 8;                        // symbols per byte
@@ -438,7 +453,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         {
             const uint4* src = reinterpret_cast<const uint4*>(x + base0 + 28u * (uint32_t)(act ? lane : 0));
 #pragma unroll
-            for (int q = 0; q < 7; q++) { const uint4 v = src[q]; xs[4 * q] = pk_sub(v.x, dcp); xs[4 * q + 1] = pk_sub(v.y, dcp); xs[4 * q + 2] = pk_sub(v.z, dcp); xs[4 * q + 3] = pk_sub(v.w, dcp); }
+            for (int q = 0; q < 7; q++) { const uint4 v = src[q]; xs[4 * q] = pk_sub(v.x, dcp); xs[4 * q + 1] = pk_sub(v.y, dcp); xs[4 * q + 2] = pk_sub(v.z,
+                    dcp); xs[4 * q + 3] = pk_sub(v.w, dcp); }
         }
         int e0 = 0, e1 = 0, e2 = 0, e3 = 0;                            // sums over the block of |x >> 3|^2 per sampling phase, wrapping
 #pragma unroll
@@ -514,7 +530,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
         // chip j = the sample at offset max(mi + 4 j, 0): column mi & 3 of the block seen as 7 rows of 4, one row up for mi = 4, one row down
         // (and sample 0 first) for mi = -1.  (Selects spelled out on lane masks: left to itself the optimiser turns the choice into a computed
         // index and a 28-way select per chip.)
-        auto vsel = [](unsigned long long m, uint32_t a, uint32_t b) __attribute__((always_inline)) { uint32_t d; asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m)); return d; };
+        auto vsel = [](unsigned long long m, uint32_t a, uint32_t b) __attribute__((always_inline)) { uint32_t d;
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(d) : "v"(b), "v"(a), "s"(m)); return d; };
         const unsigned long long r0m = __ballot((mi & 1) != 0), r1m = __ballot((mi & 2) != 0), dnm = __ballot(mi < 0), upm = __ballot(mi == 4);
         uint32_t col[7], y[8];
 #pragma unroll
@@ -583,10 +600,12 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 l5  = (int)((uint32_t)(bxr * byr) - (uint32_t)(((-bxi0) >> 2) * byi));
             };
             const uint32_t p7 = (uint32_t)(pre[7] & 0xFFFF) | ((uint32_t)pim[7] << 16);
-            const uint32_t p7prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p7, 0x138, 0xF, 0xF, false);       // wave_shr:1: the previous word's last chip
+            // wave_shr:1: the previous word's last chip
+            const uint32_t p7prev = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)p7, 0x138, 0xF, 0xF, false);
             const int qre = lane == 0 ? last_re : (int)(short)(p7prev & 0xFFFFu), qim = lane == 0 ? last_im : (int)p7prev >> 16;
             const int dre = (int)((uint32_t)(qre * pre[7]) + (uint32_t)(qim * pim[7])) >> 1, dim = (int)((uint32_t)(qre * pim[7]) - (uint32_t)(qim * pre[7])) >> 1;
-            const uint32_t dq = (((uint32_t)dre + (uint32_t)dim) >> 31) | ((((uint32_t)dre - (uint32_t)dim) >> 31) << 1);   // demap_dqpsk_bits (soradsp.h:190-198)
+            // demap_dqpsk_bits (soradsp.h:190-198)
+            const uint32_t dq = (((uint32_t)dre + (uint32_t)dim) >> 31) | ((((uint32_t)dre - (uint32_t)dim) >> 31) << 1);
             uint32_t raw; int nbytes;                                   // lane i: the i-th byte in front of the descrambler
             if (port == RATE_11M) {
                 int Mm[4]; uint32_t Vm[4];
@@ -602,7 +621,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                         Ms[sq] = first ? (lre > 0 ? lre : -lre) : (lim > 0 ? lim : -lim);
                         Vs[sq] = base | (first ? (lre > 0 ? 0x00u : 0x40u) : (lim > 0 ? 0xC0u : 0x80u));
                     }
-                    const bool k01 = Ms[0] > Ms[1], k23 = Ms[2] > Ms[3];                              // "if (Max1 > Max2) 1 else 2", "if (Max3 > Max4) 3 else 4"
+                    // "if (Max1 > Max2) 1 else 2", "if (Max3 > Max4) 3 else 4"
+                    const bool k01 = Ms[0] > Ms[1], k23 = Ms[2] > Ms[3];
                     const int M01 = k01 ? Ms[0] : Ms[1], M23 = k23 ? Ms[2] : Ms[3];
                     const uint32_t V01 = k01 ? Vs[0] : Vs[1], V23 = k23 ? Vs[2] : Vs[3];
                     const bool up = M23 > M01;                                                          // "if (Max34 > Module) Module = Max34"
@@ -722,7 +742,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 unsigned long long b0 = __ballot(lane < nsym && ((((uint32_t)re + (uint32_t)im) >> 31) != 0));
                 unsigned long long b1 = __ballot(lane < nsym && ((((uint32_t)re - (uint32_t)im) >> 31) != 0));
                 auto spread = [](unsigned long long v) { v &= 0xFFFFFFFFull; v = (v | (v << 16)) & 0x0000FFFF0000FFFFull; v = (v | (v << 8)) & 0x00FF00FF00FF00FFull;
-                                                         v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full; v = (v | (v << 2)) & 0x3333333333333333ull; v = (v | (v << 1)) & 0x5555555555555555ull; return v; };
+                                                         v = (v | (v << 4)) & 0x0F0F0F0F0F0F0F0Full; v = (v | (v << 2)) & 0x3333333333333333ull;
+                                                             v = (v | (v << 1)) & 0x5555555555555555ull; return v; };
                 W = (unsigned long long)sym_byte | ((spread(b0) | (spread(b1) << 1)) << (2 * sym_n)); nbits = 2 * (sym_n + nsym);
             }
             const int nbytes = nbits >> 3;
@@ -731,7 +752,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             const unsigned long long O = (S >> 7) ^ (S >> 3) ^ S;
             if (nbytes > 0) {
                 byte_reg = (uint32_t)(W >> (8 * nbytes - 7)) & 0x7Fu;
-                if (mode == 1) {                                        // TBB11bPlcpSwitch -> TBB11bPlcpParser's burst (at most five bytes: the sixth is the event)
+                // TBB11bPlcpSwitch -> TBB11bPlcpParser's burst (at most five bytes: the sixth is the event)
+                if (mode == 1) {
                     for (int i = 0; i < nbytes; i++) {
                         const uint32_t sh = ((uint32_t)(O >> (8 * i)) & 0xFFu) << (8 * (hdr_n & 3));
                         hdr_lo |= hdr_n < 4 ? sh : 0u; hdr_hi |= hdr_n < 4 ? 0u : sh;
@@ -776,7 +798,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
     uint32_t c_start = 0, c_take = 28, c_stale = 0;                    // the current call
     uint32_t p_start = 0, p_take = 28, p_stale = 0;                    // the call before it (its last qoff entries may still be queued)
     int qoff = 0;                                                       // entries queued in front of TSymTiming (a multiple of 4, < 28)
-    auto entry = [&](uint32_t start, uint32_t take, uint32_t stale, int j) __attribute__((always_inline)) { return (uint32_t)j < take ? start + (uint32_t)j : stale + (uint32_t)j; };
+    auto entry = [&](uint32_t start, uint32_t take, uint32_t stale,
+            int j) __attribute__((always_inline)) { return (uint32_t)j < take ? start + (uint32_t)j : stale + (uint32_t)j; };
     // The next 28 samples are requested one source call ahead (the chain is latency-bound: a block's arithmetic must not
     // wait for its own HBM read).  pf_raw holds samples pf_base .. pf_base+27 when pf_ok; a Seek or a partial call simply misses.
     uint32_t pf_base = 0, pf_raw = lane < 28 && cap_n >= 28 ? x[lane] : 0u; bool pf_ok = cap_n >= 28;
@@ -807,9 +830,11 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 // prefix sums over the bursts; what lies behind the burst that raises power (or gives up) is not committed.
                 const cpx r = unpack(fetch28(c_start, c_take == 28, entry(c_start, c_take, c_stale, lane)));
                 const int bq = lane >> 2;                               // this lane's burst
-                auto burst_prefix = [&](int v) __attribute__((always_inline)) {        // inclusive prefix over bursts of a per-burst value (same in a quad's lanes)
+                // inclusive prefix over bursts of a per-burst value (same in a quad's lanes)
+                auto burst_prefix = [&](int v) __attribute__((always_inline)) {
                     v = (int)((uint32_t)v + (uint32_t)dpp<0x114>(v)); v = (int)((uint32_t)v + (uint32_t)dpp<0x118>(v));     // row_shr:4, row_shr:8
-                    return (int)((uint32_t)v + (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));        // + row 0's total (its lane 15) in row 1
+                    // + row 0's total (its lane 15) in row 1
+                    return (int)((uint32_t)v + (uint32_t)__builtin_amdgcn_update_dpp(0, v, 0x142, 0xA, 0xF, false));
                 };
                 const int j0 = (int)update_cnt;
                 const int v1re = w16(r.re - dc_re), v1im = w16(r.im - dc_im);
@@ -842,7 +867,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 if (js < 7) { if (ecount + (uint32_t)js + 1u >= 100u) error_code = E_CS_TIMEOUT; else power = 1; }
                 ecount += (uint32_t)np;
                 if (nd > 0) {
-                    if (j0 < nd) {                                      // the estimate was renewed after burst j0; bursts j0 + 1 .. nd - 1 went into the new sum
+                    // the estimate was renewed after burst j0; bursts j0 + 1 .. nd - 1 went into the new sum
+                    if (j0 < nd) {
                         dc_re = dcn_re; dc_im = dcn_im;
                         sdc_re = w16(lane_of(p2re, 4 * (nd - 1))); sdc_im = w16(lane_of(p2im, 4 * (nd - 1)));
                         update_cnt = (uint32_t)(8 - (nd - j0));
@@ -861,7 +887,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
                 // calls are taken right here.  Same semantics as going round the outer loop -- MAC11b_Receive only looks at
                 // error_code after a call -- but in a loop of its own the compiler keeps just this phase's state in registers.
                 while (error_code == 0 && sync_flag == BARKER_SYNCED && remain >= 28 && c_take == 28 && c_start + 28 == pos) {
-                    if ((uni(rxrate) <= RATE_2M || (CCK && uni(plcp_data))) && bulk_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28; pf_ok = false; continue; }
+                    if ((uni(rxrate) <= RATE_2M || (CCK && uni(plcp_data))) && bulk_pass(pos, remain, c_start, c_stale, p_start, p_stale, qoff)) { p_take = 28;
+                        pf_ok = false; continue; }
                     p_start = c_start; p_take = 28; p_stale = c_stale;
                     c_stale = c_start; c_start = pos; pos += 28; remain -= 28;
                     const uint32_t base = c_start - (uint32_t)qoff;
@@ -894,7 +921,8 @@ __device__ __forceinline__ void rx11b_capture(const Rx11bArgs& A)
             // the switch flushes the branch its state selects, the rate selector pads its current port only
             if (power) {
                 if (qoff > 0) {                                         // pad() fills with COMPLEX16() = 0: TDCRemove has already been applied upstream,
-                    const cpx q = unpack(lane < qoff ? x[entry(c_start, c_take, c_stale, 28 - qoff + lane)] : 0u);   // so the padding must come out of sym_timing's subtraction as 0
+                    // so the padding must come out of sym_timing's subtraction as 0
+                    const cpx q = unpack(lane < qoff ? x[entry(c_start, c_take, c_stale, 28 - qoff + lane)] : 0u);
                     const uint32_t padded = lane < qoff ? pack(mk(q.re, q.im)) : pack(mk(dc_re, dc_im));
                     sym_timing(padded); qoff = 0;
                 }
@@ -963,7 +991,8 @@ struct sora_rx11b {
     sora_complex16* d_iq_own = nullptr;
     const uint32_t* d_crc = nullptr;
     bool have_results = false;
-    int  pass_plan = 2;             // sora_rx11b_set_single_pass: 0 = two passes, 1 = every capture straight through the CCK-capable instantiation, 2 (default) = automatic
+    // sora_rx11b_set_single_pass: 0 = two passes, 1 = every capture straight through the CCK-capable instantiation, 2 (default) = automatic
+    int  pass_plan = 2;
     bool auto_single = false;       // automatic plan: what the most recent measurement said (more than half of a call's captures carried CCK frames)
     uint32_t auto_calls = 0;        // ... and every 16th call of a single-pass run is a two-pass call again, to measure
 };
@@ -976,7 +1005,8 @@ static void rx11b_free(sora_rx11b_t* rx)
     for (Slot11b& S : rx->slot) {
         if (S.stream) { (void)hipStreamSynchronize(S.stream); (void)hipStreamDestroy(S.stream); }
         (void)hipFree(S.d_caps); (void)hipFree(S.d_rows); (void)hipFree(S.d_nframes); (void)hipFree(S.d_mpdu); (void)hipFree(S.d_needs_cck);
-        (void)hipFree(S.d_flagged); if (S.h_flagged) (void)hipHostFree(S.h_flagged); if (S.ev_flagged) (void)hipEventDestroy(S.ev_flagged); if (S.ev_done) (void)hipEventDestroy(S.ev_done);
+        (void)hipFree(S.d_flagged); if (S.h_flagged) (void)hipHostFree(S.h_flagged); if (S.ev_flagged) (void)hipEventDestroy(S.ev_flagged);
+            if (S.ev_done) (void)hipEventDestroy(S.ev_done);
         sora_internal_dense_free(&S.dense);
     }
     (void)hipFree(rx->d_iq_own);
@@ -1063,7 +1093,8 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
         if (!Q.flagged_pending) continue;
         const hipError_t qe = hipEventQuery(Q.ev_flagged);
         if (qe == hipSuccess) { Q.flagged_pending = false; rx->auto_single = 2u * Q.h_flagged[0] > Q.h_flagged[1]; }
-        else (void)hipGetLastError();                                           // (hipErrorNotReady is sticky for hipGetLastError: the check at the end of this call must not see it -- ADVICE r4)
+        // (hipErrorNotReady is sticky for hipGetLastError: the check at the end of this call must not see it -- ADVICE r4)
+        else (void)hipGetLastError();
     }
     bool single = one_kernel || rx->pass_plan == 1;
     if (rx->pass_plan == 2 && rx->auto_single && (++rx->auto_calls & 15u) != 0u) single = true;
@@ -1076,7 +1107,8 @@ int sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const s
         HIPCHK11(hipEventRecord(S.ev_flagged, S.stream));
         S.flagged_pending = true;
     }
-    hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);          // redoes the captures the first pass flagged (a wave of any other capture returns at once)
+    // redoes the captures the first pass flagged (a wave of any other capture returns at once)
+    hipLaunchKernelGGL(k_rx11b_cck, dim3((unsigned)((ncaps + 3) / 4)), dim3(256), 0, S.stream, A);
     HIPCHK11(hipGetLastError());
     return SORA_OK;
 }
@@ -1086,7 +1118,8 @@ int sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsam
     if (!rx || (nsamples && !h_iq)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11b_process: null argument", 0);
     if (nsamples > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11b_process: more samples than max_total_samples", 0);
     for (size_t i = 0; i < ncaps; i++)                                               // the buffer's size is known here: no descriptor may reach past it
-        if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer", 0);
+        if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+                "a capture descriptor reaches past the end of the sample buffer", 0);
     HIPCHK11(hipSetDevice(rx->cfg.device));
     if (!rx->d_iq_own) HIPCHK11(hipMalloc((void**)&rx->d_iq_own, sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
     for (Slot11b& S : rx->slot) HIPCHK11(hipStreamSynchronize(S.stream));             // one upload buffer: no call may still be reading it

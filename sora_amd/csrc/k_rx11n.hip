@@ -57,7 +57,8 @@ struct WaveLds {
     uint8_t  out[1536];                                             // decoded bytes (service field first)
 };
 
-__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+__device__ __forceinline__ void wsync() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
 
 __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); }            // a value every lane holds alike -> SGPR
 __device__ __forceinline__ unsigned long long uni64(unsigned long long v)
@@ -110,7 +111,8 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
     auto nosync = []() __attribute__((always_inline)) { wsync(); };
 
     // MimoAutoCorr / TCCA11n state: lives for the whole capture (only the peak counter is reset between frames)
-    for (int k = lane; k < 64; k += 64) { W.his[0][k & 31] = 0; W.his[1][k & 31] = 0; W.hcr[k >> 5][k & 31] = 0; W.hci[k >> 5][k & 31] = 0; W.he[k >> 5][k & 31] = 0; W.his_e[k] = 0x7FFFFFFFFFFFFFFFll; }
+    for (int k = lane; k < 64; k += 64) { W.his[0][k & 31] = 0; W.his[1][k & 31] = 0; W.hcr[k >> 5][k & 31] = 0; W.hci[k >> 5][k & 31] = 0;
+        W.he[k >> 5][k & 31] = 0; W.his_e[k] = 0x7FFFFFFFFFFFFFFFll; }
     wsync();
     int sr[2] = { 0, 0 }, si[2] = { 0, 0 }, se[2] = { 0, 0 };                // running sums
     int ring_pos = 0, his_index = 0;
@@ -266,10 +268,14 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
             unsigned other;                                                  // the metric of the lane whose state differs in the top state bit
             if constexpr (PH == 0) { const auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false); other = lane < 32 ? r[1] : r[0]; }
             else if constexpr (PH == 1) { const auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false); other = (lane & 16) ? r[0] : r[1]; }
-            else if constexpr (PH == 2) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true);                     // row_ror:8 = lane ^ 8
-            else if constexpr (PH == 3) other = (unsigned)__builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);   // row_half_mirror, then quads reversed = lane ^ 4
-            else if constexpr (PH == 4) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);                      // quad_perm [2,3,0,1] = lane ^ 2
-            else other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);                                          // quad_perm [1,0,3,2] = lane ^ 1
+            // row_ror:8 = lane ^ 8
+            else if constexpr (PH == 2) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x128, 0xF, 0xF, true);
+            // row_half_mirror, then quads reversed = lane ^ 4
+            else if constexpr (PH == 3) other = (unsigned)__builtin_amdgcn_update_dpp(0, __builtin_amdgcn_update_dpp(0, (int)m, 0x141, 0xF, 0xF, true), 0x1B, 0xF, 0xF, true);
+            // quad_perm [2,3,0,1] = lane ^ 2
+            else if constexpr (PH == 4) other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0x4E, 0xF, 0xF, true);
+            // quad_perm [1,0,3,2] = lane ^ 1
+            else other = (unsigned)__builtin_amdgcn_update_dpp(0, (int)m, 0xB1, 0xF, 0xF, true);
             const bool hi = (lane >> (5 - PH)) & 1;                          // this lane holds predecessor j + 32 (and will hold successor 2j + 1)
             const unsigned m0 = hi ? other : m, m1 = hi ? m : other;
             const unsigned pb = pbits >> (4 * Q);
@@ -280,7 +286,8 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
             m = min(c0, c1);
             tr++; ph = Q;
             const unsigned long long d = __ballot(m & 1);
-            *dslot = d;                                                      // the decision word of column tr; every lane stores the same word: no exec juggling in the step
+            // the decision word of column tr; every lane stores the same word: no exec juggling in the step
+            *dslot = d;
         };
         auto acs = [&](int which, int va, int vb) __attribute__((always_inline)) {      // the same from a run-time phase (symbol edges)
             switch (ph) {
@@ -339,7 +346,8 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
             uint32_t k = 0;
             // the symbol's soft values, four per lane, fetched from LDS once; a step reads them with v_readlane (no LDS round trip per step)
             const uint32_t jw = pad ? 0u : reinterpret_cast<const uint32_t*>(W.joined)[lane & 63];
-            auto sv = [&](uint32_t i) __attribute__((always_inline)) -> int { return (int)(((uint32_t)__builtin_amdgcn_readlane((int)jw, (int)(i >> 2)) >> (8 * (i & 3))) & 0xFFu); };
+            auto sv = [&](uint32_t i) __attribute__((always_inline)) -> int { return (int)(((uint32_t)__builtin_amdgcn_readlane((int)jw,
+                    (int)(i >> 2)) >> (8 * (i & 3))) & 0xFFu); };
             using std::integral_constant;
             while (k < n) {
                 // six steps with the exchange pattern known at compile time, where no trace-back can become due inside them (only the
@@ -365,7 +373,8 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
                     acs_c(integral_constant<int, 0>{}, 0, (int)(w0 & 255), (int)((w0 >> 8) & 255), d0); acs_c(integral_constant<int, 1>{}, 1, (int)((w0 >> 16) & 255), 0, d0 + 1);
                     acs_c(integral_constant<int, 2>{}, 2, 0, (int)(w0 >> 24), d0 + 2);
                     if ((tr & 7) == 0) normalize();
-                    acs_c(integral_constant<int, 3>{}, 0, (int)(w1 & 255), (int)((w1 >> 8) & 255), d0 + 3); acs_c(integral_constant<int, 4>{}, 1, (int)((w1 >> 16) & 255), 0, d0 + 4);
+                    acs_c(integral_constant<int, 3>{}, 0, (int)(w1 & 255), (int)((w1 >> 8) & 255), d0 + 3); acs_c(integral_constant<int, 4>{}, 1,
+                            (int)((w1 >> 16) & 255), 0, d0 + 4);
                     acs_c(integral_constant<int, 5>{}, 2, 0, (int)(w1 >> 24), d0 + 5);
                     if ((tr & 7) == 0) normalize();
                     k += 8;
@@ -438,7 +447,8 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
                 tr_end = hl * 8 + 16 + 6;
                 ok = true;
             } while (0);
-            type = ok ? (int)SYM_HT_STF : type; err = ok ? err : E_PLCP;     // (two selects: `if (ok) a = ..; else b = ..;` would become a store through a selected pointer and pin both to scratch)
+            // (two selects: `if (ok) a = ..; else b = ..;` would become a store through a selected pointer and pin both to scratch)
+            type = ok ? (int)SYM_HT_STF : type; err = ok ? err : E_PLCP;
             // the Viterbi of the data field starts from a clean trellis (T11aViterbi::Reset at the frame reset)
             m = (lane == 0) ? 0u : 0x30u; tr = 0; ph = 0; ob = 0; nout = 0; soft_n = 0;
             if (lane == 0) W.dec[0] = 0;
@@ -562,7 +572,8 @@ __global__ void __launch_bounds__(256, 3) k_rx11n_mono(Rx11nArgs A)
         const uint32_t call = (abs_end - 1) / 14;                            // the call that delivered that burst's last sample
         const uint32_t next = min(14 * (call + 1), n20);
         if (lane == 0 && nfr < A.max_frames) {
-            Rx11bRow r; r.end_sample = 2 * next; r.error_code = err; r.rate_kbps = err == E_PLCP ? 0u : mcs; r.length = err == E_PLCP ? 0u : ht_len; r.crc32 = err == E_PLCP ? 0u : frame_crc;
+            Rx11bRow r; r.end_sample = 2 * next; r.error_code = err; r.rate_kbps = err == E_PLCP ? 0u : mcs; r.length = err == E_PLCP ? 0u : ht_len;
+                r.crc32 = err == E_PLCP ? 0u : frame_crc;
             rows[nfr] = r;
         }
         nfr++;
@@ -671,7 +682,8 @@ __device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* fo
     const Fft64Tw tw = fft64_twiddles(A.T, lane & 15);
     auto nosync = []() __attribute__((always_inline)) { wsync(); };
 
-    for (int k = lane; k < 64; k += 64) { W.his[0][k & 31] = 0; W.his[1][k & 31] = 0; W.hcr[k >> 5][k & 31] = 0; W.hci[k >> 5][k & 31] = 0; W.he[k >> 5][k & 31] = 0; W.his_e[k] = 0x7FFFFFFFFFFFFFFFll; }
+    for (int k = lane; k < 64; k += 64) { W.his[0][k & 31] = 0; W.his[1][k & 31] = 0; W.hcr[k >> 5][k & 31] = 0; W.hci[k >> 5][k & 31] = 0;
+        W.he[k >> 5][k & 31] = 0; W.his_e[k] = 0x7FFFFFFFFFFFFFFFll; }
     wsync();
     int sr[2] = { 0, 0 }, si[2] = { 0, 0 }, se[2] = { 0, 0 };
     int ring_pos = 0, his_index = 0;
@@ -801,8 +813,10 @@ __device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* fo
         }
         wsync();
         float noise_var = 0.0f;
-        if (HT40) {                                                          // the two L-LTF symbols differ by noise only: E|Y1 - Y2|^2 = 2 var(FFT<64> bin); an FFT<128> bin of the
-            float acc = 0.0f;                                                // 40 MHz stream carries half that (same noise per sample, twice the 1/N), so noise_var = sum / (4 x 104 bins)
+        // the two L-LTF symbols differ by noise only: E|Y1 - Y2|^2 = 2 var(FFT<64> bin); an FFT<128> bin of the
+        if (HT40) {
+            // 40 MHz stream carries half that (same noise per sample, twice the 1/N), so noise_var = sum / (4 x 104 bins)
+            float acc = 0.0f;
             if (lane != 0 && (lane < 27 || lane >= 38)) {
 #pragma unroll
                 for (int r = 0; r < 2; r++) {
@@ -862,7 +876,8 @@ __device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* fo
             nsig++; a += 80;
             wsync();
         }
-        if (at_end && nsig > 0) { for (int k = lane; k < 64 * (3 - nsig); k += 64) W.sig[64 * nsig + k] = 0; }   // T11nSymSel::Flush: the missing symbols are zeros
+        // T11nSymSel::Flush: the missing symbols are zeros
+        if (at_end && nsig > 0) { for (int k = lane; k < 64 * (3 - nsig); k += 64) W.sig[64 * nsig + k] = 0; }
         if (!at_end || nsig > 0) {
             // T11nSigDemap -> T11aDeinterleaveBPSK -> T11nViterbiSig -> T11nSigParser on W.sig
             decoded = true;
@@ -956,7 +971,8 @@ __device__ __forceinline__ void scan11n_body(const Scan11nArgs& A, Ht40Found* fo
                     F.nproc = nproc; F.nsoft = nsoft; F.slot0 = cd.slot_base + (origin + a + 240) / 80;
                     for (int k = 0; k < 6; k++) F.pad[k] = 0;
                     A.frames[(size_t)list * A.nrows + idx] = F;
-                    VitJob J; J.soft_off = F.slot0 * (uint32_t)kSoftPerSlot; J.soft_bits = 8; J.nsoft = nsoft; J.length = ht_len; J.dec_off = 0; J.out_off = F.slot0 * (uint32_t)kOutPerSlot;
+                    VitJob J; J.soft_off = F.slot0 * (uint32_t)kSoftPerSlot; J.soft_bits = 8; J.nsoft = nsoft; J.length = ht_len; J.dec_off = 0;
+                        J.out_off = F.slot0 * (uint32_t)kOutPerSlot;
                     J.valid = 1; J.code_rate = code_rate;
                     A.jobs[(size_t)list * A.nrows + idx] = J;
                 }
@@ -1002,7 +1018,8 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
     const uint32_t* iq[2] = { A.iq0 + cd.offset, A.iq1 + cd.offset };
     const uint32_t n20 = cd.nsamples / 2;
     auto fetch = [&](int r, uint32_t i) __attribute__((always_inline)) -> uint32_t { return i < n20 ? iq[r][2 * (size_t)i] : 0u; };
-    const Fft64TwPk tw = fft64_twiddles_pk(A.T, lane & 15);                     // the packed-arithmetic FFT<64> of k_frame (dev_arith.h): half the instructions of the unpacked one
+    // the packed-arithmetic FFT<64> of k_frame (dev_arith.h): half the instructions of the unpacked one
+    const Fft64TwPk tw = fft64_twiddles_pk(A.T, lane & 15);
     auto nosync = []() __attribute__((always_inline)) { wsync(); };
     const int cfo = uni(F.cfo);
     const uint32_t l0 = (uint32_t)uni((int)F.l0), mcs = (uint32_t)uni((int)F.mcs), nproc = (uint32_t)uni((int)F.nproc);
@@ -1062,7 +1079,8 @@ __global__ void __launch_bounds__(256) k_frame11n(Frame11nArgs A)
     // ---- the data symbols, in order
     const uint32_t a_data = a_ltf + 160;
     const uint32_t S = 104u * (uint32_t)nb;
-    uint8_t* dst = A.soft + (size_t)F.slot0 * kSoftPerSlot;                  // the frame's soft stream, one byte per value (VitJob::soft_bits = 8), in its own symbol slots
+    // the frame's soft stream, one byte per value (VitJob::soft_bits = 8), in its own symbol slots
+    uint8_t* dst = A.soft + (size_t)F.slot0 * kSoftPerSlot;
     uint32_t nx0 = fetch(0, a_data + 16 + lane), nx1 = fetch(1, a_data + 16 + lane);     // the next symbol's samples are requested one symbol ahead
     for (uint32_t d = 0; d < nproc; d++) {
         const uint32_t pos = a_data + 80 * d;
@@ -1219,10 +1237,12 @@ static hipError_t pipe11n_create(sora_rx11n_t* rx, Pipe11n** out, int index = 0)
         // every array starts out defined: the decoder reads its soft stream in 12-step chunks (the tail of a frame's last chunk is read, never used)
         if (e == hipSuccess) {
             (void)hipMemsetAsync(p->d_frames, 0, 3 * sizeof(N11Frame) * rows, p->stream); (void)hipMemsetAsync(p->d_jobs, 0, 3 * sizeof(VitJob) * rows, p->stream);
-            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot + kSoftSlack, p->stream); (void)hipMemsetAsync(p->d_vout, 0, (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
+            (void)hipMemsetAsync(p->d_soft, 0, (size_t)rx->cap_slots * kSoftPerSlot + kSoftSlack, p->stream); (void)hipMemsetAsync(p->d_vout, 0,
+                    (size_t)rx->cap_slots * kOutPerSlot + 256, p->stream);
         }
     }
-    if (e == hipSuccess) { (void)hipMemsetAsync(p->d_rows, 0, sizeof(Rx11bRow) * rows, p->stream); (void)hipMemsetAsync(p->d_nframes, 0, 4 * (size_t)cfg->max_captures, p->stream); }
+    if (e == hipSuccess) { (void)hipMemsetAsync(p->d_rows, 0, sizeof(Rx11bRow) * rows, p->stream); (void)hipMemsetAsync(p->d_nframes, 0,
+            4 * (size_t)cfg->max_captures, p->stream); }
     if (e != hipSuccess) { pipe11n_free(p); return e; }
     *out = p;
     return hipSuccess;
@@ -1239,11 +1259,13 @@ int sora_rx11n_create(const sora_rx_cfg* cfg, sora_rx11n_t** out)
     HIPCHK11N(hipSetDevice(cfg->device));
     sora_rx11n_t* rx = new sora_rx11n();
     rx->cfg = *cfg;
-    if (!(sora_internal_tables(cfg->device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: tables", 0); }
+    if (!(sora_internal_tables(cfg->device, &rx->T) == SORA_OK && sora_internal_dsp_tables(&rx->sincos, &rx->atan) == SORA_OK)) { rx11n_free(rx);
+        return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: tables", 0); }
     if (!rx->mono) {
         // symbol slots: 80 samples at 20 MHz each, + 4 per capture (the decoder's padded last burst and its chunked reads may reach past the last symbol)
         rx->cap_slots = cfg->max_total_samples / 2 / 80 + 4 * (uint64_t)cfg->max_captures + 4;
-        if (rx->cap_slots * (uint64_t)kSoftPerSlot * 2 >= (1ull << 32)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_create: max_total_samples exceeds the 32-bit slot geometry of one handle (split the batch over several handles)", 0); }
+        if (rx->cap_slots * (uint64_t)kSoftPerSlot * 2 >= (1ull << 32)) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_CAPACITY,
+                "sora_rx11n_create: max_total_samples exceeds the 32-bit slot geometry of one handle (split the batch over several handles)", 0); }
     }
     const hipError_t e = pipe11n_create(rx, &rx->pipes[0]);
     if (e != hipSuccess) { rx11n_free(rx); return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_create: device allocation", (int)e); }
@@ -1263,7 +1285,8 @@ int sora_rx11n_set_depth(sora_rx11n_t* rx, int depth)
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
     for (int i = 0; i < depth; i++)
-        if (!rx->pipes[i]) { const hipError_t e = pipe11n_create(rx, &rx->pipes[i], i); if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_set_depth: device allocation", (int)e); }
+        if (!rx->pipes[i]) { const hipError_t e = pipe11n_create(rx, &rx->pipes[i], i);
+            if (e != hipSuccess) return sora_internal_fail(SORA_ERR_HARDWARE_FAILED, "sora_rx11n_set_depth: device allocation", (int)e); }
     // a shrink keeps the most recent call addressable: its pipeline moves into the surviving range (the tickets of the pipelines that
     // fall outside it become stale, as the header says)
     if (rx->cur >= depth) { std::swap(rx->pipes[0], rx->pipes[rx->cur]); rx->cur = 0; }
@@ -1284,7 +1307,8 @@ static Pipe11n* pipe11n_of(sora_rx11n_t* rx, int ticket);
 int sora_rx11n_deliver_async(sora_rx11n_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_counts, uint8_t* h_mpdu, size_t mpdu_cap)
 {
     Pipe11n* P = pipe11n_of(rx, ticket);
-    if (!P || !P->have_results) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_deliver_async: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
+    if (!P || !P->have_results) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+            "sora_rx11n_deliver_async: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     const int rc = sora_internal_dense_deliver(&P->dense, P->d_rows, P->d_nframes, P->d_caps, nullptr, P->ncaps, rx->cfg.max_frames_per_capture, P->d_mpdu, P->stream,
                                                h_rows, max_rows, h_counts, h_mpdu, mpdu_cap);
@@ -1313,7 +1337,8 @@ int sora_rx11n_ticket(sora_rx11n_t* rx) { return rx && rx->started ? rx->pipes[r
 int sora_rx11n_wait(sora_rx11n_t* rx, int ticket)
 {
     Pipe11n* p = pipe11n_of(rx, ticket);
-    if (!p) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_wait: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
+    if (!p) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+            "sora_rx11n_wait: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
     HIPCHK11N(hipStreamSynchronize(p->stream));
     if (p->delivered) p->released = true;
@@ -1372,7 +1397,8 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
         h[i].slot_base = (uint32_t)slots; h[i].nslots = caps[i].nsamples / 2 / 80 + 4;
         slots += h[i].nslots; total += caps[i].nsamples;
     }
-    if (total > rx->cfg.max_total_samples || (!rx->mono && slots > rx->cap_slots)) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process_dev: more samples than max_total_samples", 0);
+    if (total > rx->cfg.max_total_samples || (!rx->mono && slots > rx->cap_slots)) return sora_internal_fail(SORA_ERR_CAPACITY,
+            "sora_rx11n_process_dev: more samples than max_total_samples", 0);
     HIPCHK11N(hipStreamSynchronize(P->stream));                                  // the call that used this pipeline `depth` calls ago has finished
     P->h_desc.swap(h);
     P->h_caps.assign(caps, caps + ncaps); P->ncaps = (uint32_t)ncaps; P->have_results = true; P->ticket = ++rx->next_ticket; P->delivered = P->released = false;
@@ -1398,9 +1424,11 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     F.soft = P->d_soft; F.jobs = P->d_jobs; F.vout = P->d_vout; F.rows = P->d_rows; F.mpdu = P->d_mpdu;
     hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
     if (rx->lanes16)
-        hipLaunchKernelGGL(k_viterbi16_11n, dim3((nrows + 7) / 8 + 2), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint8_t*)P->d_soft, P->d_vout);
+        hipLaunchKernelGGL(k_viterbi16_11n, dim3((nrows + 7) / 8 + 2), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u,
+                nrows, (const uint8_t*)P->d_soft, P->d_vout);
     else
-        hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u, nrows, (const uint8_t*)P->d_soft, P->d_vout);
+        hipLaunchKernelGGL(k_viterbi11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u,
+                nrows, (const uint8_t*)P->d_soft, P->d_vout);
     hipLaunchKernelGGL(k_finish11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
     HIPCHK11N(hipGetLastError());
     return SORA_OK;
@@ -1411,9 +1439,11 @@ int sora_rx11n_process(sora_rx11n_t* rx, const sora_complex16* h_iq0, const sora
     if (!rx || (nsamples && (!h_iq0 || !h_iq1))) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_process: null argument", 0);
     if (nsamples > rx->cfg.max_total_samples) return sora_internal_fail(SORA_ERR_CAPACITY, "sora_rx11n_process: more samples than max_total_samples", 0);
     for (size_t i = 0; i < ncaps; i++)                                               // the buffer's size is known here: no descriptor may reach past it
-        if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer", 0);
+        if (caps && (caps[i].offset > nsamples || caps[i].nsamples > nsamples - caps[i].offset)) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+                "a capture descriptor reaches past the end of the sample buffer", 0);
     HIPCHK11N(hipSetDevice(rx->cfg.device));
-    for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));   // the handle's own sample buffers are shared by its pipelines: calls in flight read them
+    // the handle's own sample buffers are shared by its pipelines: calls in flight read them
+    for (Pipe11n* p : rx->pipes) if (p) HIPCHK11N(hipStreamSynchronize(p->stream));
     const sora_complex16* src[2] = { h_iq0, h_iq1 };
     for (int k = 0; k < 2; k++) {
         if (!rx->d_iq_own[k]) HIPCHK11N(hipMalloc((void**)&rx->d_iq_own[k], sizeof(sora_complex16) * (rx->cfg.max_total_samples + 64)));
@@ -1474,6 +1504,7 @@ int sora_rx11n_results_of(sora_rx11n_t* rx, int ticket, sora_frame_result* out, 
 {
     if (!rx || !nout) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results_of: null argument", 0);
     Pipe11n* P = pipe11n_of(rx, ticket);
-    if (!P) { *nout = 0; return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_results_of: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0); }
+    if (!P) { *nout = 0; return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+            "sora_rx11n_results_of: stale ticket (its pipeline has been reused by a later process call, or the ticket was never issued)", 0); }
     return pipe11n_results(rx, P, out, max_out, nout, h_mpdu, mpdu_cap);
 }

@@ -274,7 +274,8 @@ __device__ __noinline__ void cont_store(uint32_t* crec, uint32_t* consumed, uint
                                         int dc_re, int dc_im, uint32_t at)
 {
     const int l = threadIdx.x;
-    const uint32_t zr = (uint32_t)__shfl((int)Zr, 4 * (l & 3)), zi = (uint32_t)__shfl((int)Zi, 4 * (l & 3)), ze = (uint32_t)__shfl((int)Ze, 4 * (l & 3));   // window element (l & 3) sits in lanes 4 (l & 3) ..
+    // window element (l & 3) sits in lanes 4 (l & 3) ..
+    const uint32_t zr = (uint32_t)__shfl((int)Zr, 4 * (l & 3)), zi = (uint32_t)__shfl((int)Zi, 4 * (l & 3)), ze = (uint32_t)__shfl((int)Ze, 4 * (l & 3));
     const uint32_t hv = (uint32_t)__shfl((int)Hv, l & 15);
     uint32_t v = l < 16 ? hv : l < 20 ? zr : l < 24 ? zi : l < 28 ? ze : 0u;
     const uint32_t sc[16] = { (uint32_t)rr, (uint32_t)ri, (uint32_t)re, sense_count, high_count, (uint32_t)peak_corr, (uint32_t)peak_index, dc_cnt,
@@ -338,9 +339,11 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     // pending): everything the graph knows there is the record below.  The capture's last resume point is published (A.consumed) and its
     // record kept; the next call's capture k starts AT that point of the stream and the record is its initial state -- so what the graph
     // reports from there on is what it reports on the uncut stream, and a frame cut by the end of a capture is simply found again.
-    const bool streaming = A.cont != nullptr;                                   // (one flag lives through the loop; the pointers are re-derived where they are used)
+    // (one flag lives through the loop; the pointers are re-derived where they are used)
+    const bool streaming = A.cont != nullptr;
     auto cont_save = [&](uint32_t at) {
-        cont_store(A.cont + (size_t)cap_i * kContWords, A.consumed + cap_i, Hv, ac_re.Z, ac_im.Z, energy.Z, ac_re.reg, ac_im.reg, energy.reg, sense_count, high_count, peak_corr, peak_index,
+        cont_store(A.cont + (size_t)cap_i * kContWords, A.consumed + cap_i, Hv, ac_re.Z, ac_im.Z, energy.Z, ac_re.reg, ac_im.reg, energy.reg, sense_count,
+                high_count, peak_corr, peak_index,
                    dc_cnt, sum_dc_re, sum_dc_im, dc_re, dc_im, at);
     };
     if (streaming) {
@@ -349,7 +352,8 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         if ((uint32_t)__builtin_amdgcn_readlane((int)v, 41) == kContMagic) {       // a record exists: this capture continues a stream
             auto sc = [&](int k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, 28 + k); };
             Hv = (uint32_t)__shfl((int)v, lane & 15);
-            ac_re.Z = (uint32_t)__shfl((int)v, 16 + ((lane & 15) >> 2)); ac_im.Z = (uint32_t)__shfl((int)v, 20 + ((lane & 15) >> 2)); energy.Z = (uint32_t)__shfl((int)v, 24 + ((lane & 15) >> 2));
+            ac_re.Z = (uint32_t)__shfl((int)v, 16 + ((lane & 15) >> 2)); ac_im.Z = (uint32_t)__shfl((int)v, 20 + ((lane & 15) >> 2));
+                energy.Z = (uint32_t)__shfl((int)v, 24 + ((lane & 15) >> 2));
             ac_re.reg = (int)sc(0); ac_im.reg = (int)sc(1); energy.reg = (int)sc(2); sense_count = sc(3); high_count = sc(4); peak_corr = (int)sc(5); peak_index = (int)sc(6);
             dc_cnt = sc(7); sum_dc_re = (int)sc(8); sum_dc_im = (int)sc(9); dc_re = (int)sc(10); dc_im = (int)sc(11);
         }
@@ -417,7 +421,8 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         // (cca.hpp:386-437) in every group, and the first burst whose test is true ends the pass.
         const bool second_row = (l & 16u) != 0u;
         const uint32_t m16 = hi | ((l - 16u) & 31u);
-        const uint32_t pr = (uint32_t)__shfl((int)vr, (int)m16), pim = (uint32_t)__shfl((int)vi, (int)m16), pe = (uint32_t)__shfl((int)ve, (int)m16);   // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
+        // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
+        const uint32_t pr = (uint32_t)__shfl((int)vr, (int)m16), pim = (uint32_t)__shfl((int)vi, (int)m16), pe = (uint32_t)__shfl((int)ve, (int)m16);
         const uint32_t zr = second_row ? pr : ac_re.Z, zi = second_row ? pim : ac_im.Z, ze = second_row ? pe : energy.Z;
         const uint32_t Rr = (uint32_t)ac_re.reg + group_scan(vr - zr), Ri = (uint32_t)ac_im.reg + group_scan(vi - zi), Re = (uint32_t)energy.reg + group_scan(ve - ze);
         const int iAuto_v = abs((int)Rr) + abs((int)Ri), iEnergy_v = (int)Re;
@@ -506,12 +511,14 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     for (uint32_t c = 0; c < nchunks; c++) {
         const uint32_t avail_end = (c + 1) * APP;
         while (vpos + BUR <= avail_end) {
-            if (streaming && vpos == avail_end - APP && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);   // (inside this loop the only multiple of APP vpos can be is the chunk's start)
+            // (inside this loop the only multiple of APP vpos can be is the chunk's start)
+            if (streaming && vpos == avail_end - APP && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);
             if (!cca_detected && !sync_high && auto_count == 0) {
                 // bursts until the carrier-sense time-out is raised; if that is near, stay inside this source call
                 const uint32_t to_timeout = sense_count >= 84 ? 0u : (84u - sense_count + 3u) / 4u;
                 uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
-                if (streaming) {                                                   // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen:
+                // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen:
+                if (streaming) {
                     // in units of half a burst vpos sits m past the chunk's start and a source call is 7; j bursts further it is m + 2 j: j = -m / 2 = 3 m (mod 7), 0 -> 7
                     const uint32_t m7 = (((vpos + APP - (avail_end - APP)) / (BUR / 2u)) % 7u);
                     const uint32_t j = (3u * m7) % 7u;
@@ -597,7 +604,8 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                     const uint32_t last_v = vpos + 35u * BUR;
                     if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }       // the capture ends inside the LTS: nothing more to report
                     lts_n = 140; vpos = last_v;
-                    c = (vpos + BUR + APP - 1) / APP - 2;                                   // the for-loop increment lands on the chunk that delivers that burst
+                    // the for-loop increment lands on the chunk that delivers that burst
+                    c = (vpos + BUR + APP - 1) / APP - 2;
                     break;
                 }
                 lts_n += 4;
@@ -610,7 +618,8 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
             } else {
                 // ================= T11aDataSymbol: IPORT COMPLEX16 x 80 (PHY_11a.hpp:389-428)
                 if (sym_n == 0) sym_start = vpos;
-                if (sym_n == 0 && error_code == 0) {                                        // likewise: to the symbol's 20th burst (not once an event is pending: the rest of that source call still counts bursts)
+                // likewise: to the symbol's 20th burst (not once an event is pending: the rest of that source call still counts bursts)
+                if (sym_n == 0 && error_code == 0) {
                     const uint32_t last_v = vpos + 19u * BUR;
                     if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }
                     sym_n = 76; vpos = last_v;
@@ -646,7 +655,8 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                         if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }   // frame runs past the capture: nothing more to report
                         sym_idx += remain_symbols - 1; remain_symbols = 1; sym_n = 76; sym_start = (uint32_t)(last_v + BUR) - 80u * STR;
                         vpos = (uint32_t)last_v;
-                        c = (vpos + BUR + APP - 1) / APP - 2;                               // the for-loop increment lands on the chunk that delivers that burst
+                        // the for-loop increment lands on the chunk that delivers that burst
+                        c = (vpos + BUR + APP - 1) / APP - 2;
                         break;
                     }
                     if (remain_symbols == 0 && plcp_is_data) {
@@ -671,7 +681,8 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                 else if (has_row) {
                     // queue the frame for the per-frame kernels
                     if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
-                    if (A.slot_row) for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[r_slot0 + sy] = cap_i * A.max_frames + nfr;   // its data symbols' slots (k_sym_front / k_sym_back)
+                    // its data symbols' slots (k_sym_front / k_sym_back)
+                    if (A.slot_row) for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[r_slot0 + sy] = cap_i * A.max_frames + nfr;
                 }
                 if (lane == 0 && has_row) {
                     FrameRow row;
@@ -685,13 +696,15 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                     A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
                 }
                 nfr++;
-                if (!A.keep_queue) vpos = avail_end;                                // Flush + Reset drop the queued tail (TMemSamples' queue; not TDownSample44_40's)
+                // Flush + Reset drop the queued tail (TMemSamples' queue; not TDownSample44_40's)
+                if (!A.keep_queue) vpos = avail_end;
                 frame_reset();
             }
         }
         PROBE_A(_tc, 7);
     }
-    if (streaming && vpos == nunits && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);   // the capture ends in plain carrier sense: all of it is final
+    // the capture ends in plain carrier sense: all of it is final
+    if (streaming && vpos == nunits && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);
     if (lane == 0) A.nframes[cap_i] = nfr;
     PROBE_ADDK(5);
 }

@@ -83,7 +83,8 @@ constexpr int kFftTiles = 4;                                                 // 
 // T11aDataSymbol -> TFreqCompensation -> TFFT64 -> TChannelEqualization.  16 lanes per symbol, 16 symbols per tile; the 64
 // samples behind the cyclic prefix arrive as one 16-byte load per lane (samples 4e..4e+3), go through the group's LDS
 // slice to the 4-points-per-lane layout of the butterflies, and the equalised bins 4e..4e+3 leave as one 16-byte store.
-__global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* __restrict__ in, const uint32_t* __restrict__ ctx, const uint32_t* __restrict__ ctx_index, uint32_t* __restrict__ eq, uint32_t n, Tables T)
+__global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* __restrict__ in, const uint32_t* __restrict__ ctx,
+        const uint32_t* __restrict__ ctx_index, uint32_t* __restrict__ eq, uint32_t n, Tables T)
 {
     __shared__ uint32_t s_all[16][64];
     const int g = threadIdx.x >> 4, e = threadIdx.x & 15;
@@ -128,7 +129,8 @@ __global__ void __launch_bounds__(256) k_symfront_batch(const uint32_t* __restri
 // Symbol i multiplies by the 64 coefficients at coef + cstride x cindex[i] + coff words (cindex == nullptr: set 0): a frame's coefficients serve all its symbols, so
 // a symbol is 256 bytes in and 256 out.  16 lanes per symbol, one 16-byte load and store per lane, every load of a thread's tiles in flight before the first product.
 template <int KIND>
-__global__ void __launch_bounds__(256) k_cmul64_batch(const uint32_t* __restrict__ in, const uint32_t* __restrict__ coef, uint32_t cstride, uint32_t coff, const uint32_t* __restrict__ cindex,
+__global__ void __launch_bounds__(256) k_cmul64_batch(const uint32_t* __restrict__ in, const uint32_t* __restrict__ coef, uint32_t cstride, uint32_t coff,
+        const uint32_t* __restrict__ cindex,
                                                       uint32_t* __restrict__ out, uint32_t n)
 {
     constexpr int kTiles = 8;
@@ -143,15 +145,18 @@ __global__ void __launch_bounds__(256) k_cmul64_batch(const uint32_t* __restrict
 #pragma unroll
     for (int t = 0; t < kTiles; t++) {
         const uint32_t i = (blockIdx.x * kTiles + t) * 16 + g;
-        const uint32_t* c = coef + (size_t)ci[t] * cstride + coff + 4 * e;           // (a context's coefficient arrays start on a word, not on 16 bytes: four word loads, L2-resident)
+        // (a context's coefficient arrays start on a word, not on 16 bytes: four word loads, L2-resident)
+        const uint32_t* c = coef + (size_t)ci[t] * cstride + coff + 4 * e;
         const uint32_t x[4] = { v[t].x, v[t].y, v[t].z, v[t].w };
-        const uint32_t keep = (e == 7 || e == 8) ? 0u : 0xFFFFFFFFu;                 // bins 28 .. 35 = lanes 7 and 8 of the symbol: zero (channel_11a.hpp:545-546)
+        // bins 28 .. 35 = lanes 7 and 8 of the symbol: zero (channel_11a.hpp:545-546)
+        const uint32_t keep = (e == 7 || e == 8) ? 0u : 0xFFFFFFFFu;
         uint32_t o[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) {
             const PkTw w = pk_tw_mul(c[q]);
             if (KIND == 0)      o[q] = pk_cmul<15>(pk_sra(x[q], 1), w);
-            else if (KIND == 1) o[q] = pk_cmul<8>(x[q], w) & keep;                  // (a mask, not a branch: the select on 4e + q made the compiler fetch every coefficient under its own exec mask)
+            // (a mask, not a branch: the select on 4e + q made the compiler fetch every coefficient under its own exec mask)
+            else if (KIND == 1) o[q] = pk_cmul<8>(x[q], w) & keep;
             else                o[q] = pk_cmul<15>(x[q], w);
         }
         if (i < n) reinterpret_cast<uint4*>(out)[(size_t)i * 16 + e] = uint4{o[0], o[1], o[2], o[3]};
@@ -424,7 +429,8 @@ __global__ void __launch_bounds__(256) k_ingest_tile(const uint8_t* __restrict__
         for (int j = 0; j < PER; j++) {
             const int m = tid + 256 * j;
             pcx a = s_raw[ia[j]], b = s_raw[ib[j]];
-            if (fix) { a = __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, a) << (short)2)); b = __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, b) << (short)2)); }
+            if (fix) { a = __builtin_bit_cast(pcx, (s16x2_t)(__builtin_bit_cast(s16x2_t, a) << (short)2)); b = __builtin_bit_cast(pcx,
+                    (s16x2_t)(__builtin_bit_cast(s16x2_t, b) << (short)2)); }
             const pcx re2 = (a & 0xFFFFu) | (b << 16), im2 = (a >> 16) | (b & 0xFFFF0000u);          // (a.re, b.re), (a.im, b.im)
             const int vr = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, re2), __builtin_bit_cast(s16x2_t, wrl[j]), 0, false);
             const int vi = __builtin_amdgcn_sdot2(__builtin_bit_cast(s16x2_t, im2), __builtin_bit_cast(s16x2_t, wrl[j]), 0, false);

@@ -48,7 +48,8 @@ __device__ __forceinline__ void ifft_emit(uint32_t* s_bins, uint32_t* s_sym, int
     for (int m = 0; m < 4; m++) x[m] = s_bins[e + 32 * m];
     ifft128_core_pk(x, s_bins, e, tw, sync);                                     // IFFT<128> on packed COMPLEX16 (bit-exact with fft128_core<true>)
 #pragma unroll
-    for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pk_sra(s_bins[__brev((unsigned)(e + 32 * q)) >> 25], 4);      // FFT128LUTMap = 7-bit bit reversal; >> 4
+    // FFT128LUTMap = 7-bit bit reversal; >> 4
+    for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pk_sra(s_bins[__brev((unsigned)(e + 32 * q)) >> 25], 4);
     sync();
     s_sym[e] = s_sym[128 + e];
     sync();
@@ -116,14 +117,16 @@ __device__ __forceinline__ unsigned coded_bit(BIT bit, int c, int code_rate)
 __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
 {
     __shared__ alignas(4) uint8_t s_data[2608];
-    __shared__ uint32_t s_ga[656], s_gb[656];                                    // generator outputs A (133) / B (171) of the whole data field, bit i of the stream = bit i & 31 of word i >> 5
+    // generator outputs A (133) / B (171) of the whole data field, bit i of the stream = bit i & 31 of word i >> 5
+    __shared__ uint32_t s_ga[656], s_gb[656];
     __shared__ uint32_t s_crc[256];
     __shared__ uint32_t s_z[6 * 8 * 16];
     __shared__ uint32_t s_bins[8][128];
     __shared__ uint32_t s_sym[8][160];
     __shared__ uint8_t  s_ib[8][288];
     __shared__ uint32_t s_fcs;
-    __shared__ uint16_t s_map[288 + 48];                                         // interleaver positions of the frame's modulation, then of the SIGNAL symbol (BPSK)
+    // interleaver positions of the frame's modulation, then of the SIGNAL symbol (BPSK)
+    __shared__ uint16_t s_map[288 + 48];
     const uint32_t f = blockIdx.x;
     const int tid = threadIdx.x, g = tid >> 5, e = tid & 31;
     const Tables& T = A.T;
@@ -146,7 +149,8 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
 
     s_crc[tid] = T.crc[tid];
     for (int i = tid; i < 6 * 8 * 16; i += 256) s_z[i] = T.crcz[i];
-    for (uint32_t i = tid; i < nbytes + 8; i += 256) s_data[i] = (i >= 2 && i < 2 + L) ? mp[i - 2] : (uint8_t)0;       // (+ 8: the word-wise encoder reads up to 3 bytes past nbytes)
+    // (+ 8: the word-wise encoder reads up to 3 bytes past nbytes)
+    for (uint32_t i = tid; i < nbytes + 8; i += 256) s_data[i] = (i >= 2 && i < 2 + L) ? mp[i - 2] : (uint8_t)0;
     __syncthreads();
     if (tid < 64) {                                                              // FCS of the MPDU (PHY_11a.hpp:87,160-170)
         uint32_t crc;

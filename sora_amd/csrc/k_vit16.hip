@@ -58,7 +58,8 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     const unsigned v0 = v_of_lane(l16);
     const uint32_t row_steps = max(nstepsA, nstepsB);
     const uint32_t nsteps = wave_max_u32(row_steps);
-    const uint32_t my_last = max(my_nsoft, 1u) - 1u;                            // the last soft value of this lane's frame (fetches past it repeat it: well-formed operands nobody uses)
+    // the last soft value of this lane's frame (fetches past it repeat it: well-formed operands nobody uses)
+    const uint32_t my_last = max(my_nsoft, 1u) - 1u;
 
     auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };
     Vit16 V;
@@ -68,7 +69,8 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
 #pragma unroll
     for (int jb = 0; jb < 3; jb++)
 #pragma unroll
-        for (int i = 0; i < 4; i++) V.sadr[jb][i] = ring_base + ((row * 64u + rev6u(rol6(v0 ^ kW[i], jb == 0 ? 2 : jb == 1 ? 4 : 0))) << 1);   // (8 jb + 8) mod 6
+        // (8 jb + 8) mod 6
+        for (int i = 0; i < 4; i++) V.sadr[jb][i] = ring_base + ((row * 64u + rev6u(rol6(v0 ^ kW[i], jb == 0 ? 2 : jb == 1 ? 4 : 0))) << 1);
 #pragma unroll
     for (int t = 0; t < 24; t++) {
         const int ph = t % 6, k = t % 8;
@@ -118,7 +120,8 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     };
 
     struct Chunk { uint32_t v[CW]; };
-    constexpr int NV = (CW + 7) / 8;                                            // soft values a lane fetches per chunk: operands j, j + 8 (, j + 16) of its frame
+    // soft values a lane fetches per chunk: operands j, j + 8 (, j + 16) of its frame
+    constexpr int NV = (CW + 7) / 8;
     struct Raw { SoftRaw r[NV]; };
     const uint32_t my_j = l16 >> 1;
     SoftCursor<BITS, CW> cur[NV];
@@ -134,7 +137,8 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     const uint4* row_ops = reinterpret_cast<const uint4*>(&S.ops[row][0][0]);
     auto unpack = [&](const Raw& R) -> Chunk {                                  // ... their values -> the row's operand table -> every lane's registers
 #pragma unroll
-        for (int v = 0; v < NV; v++) my_ops[16 * v] = (uint16_t)cur[v].field(R.r[v]);      // (operand j + 8 v; slots up to 23 exist, those past CW are never read)
+        // (operand j + 8 v; slots up to 23 exist, those past CW are never read)
+        for (int v = 0; v < NV; v++) my_ops[16 * v] = (uint16_t)cur[v].field(R.r[v]);
         lds_fence();
         Chunk K;
 #pragma unroll
@@ -157,7 +161,8 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
     };
     auto end_row = [&]() { pos = pos_of(pos, 3); set_row_pos(); };
     set_row_pos();
-    auto group = [&](const Chunk& K, int h, int i0) {                           // one puncture group = GS steps; i0 = step inside the chunk, h = half of the 24-step row
+    // one puncture group = GS steps; i0 = step inside the chunk, h = half of the 24-step row
+    auto group = [&](const Chunk& K, int h, int i0) {
         const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
         acs16<0, P>(V, t24, K.v[k0], K.v[k0 + 1], pos512);                      // ACS(A,B)
         if (CR != 0) acs16<1, P>(V, t24 + 1, K.v[k0 + 2], 0, pos512);           // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
@@ -231,7 +236,8 @@ __device__ __forceinline__ void forward16(Lds16<WIN, LOOK>& S, const uint8_t* __
                 end_row();
                 c += 4;
             }
-            lds_fence();                                                        // (the tables share their bytes with unpack()'s and the trace-back's: nothing of them is pending past here)
+            // (the tables share their bytes with unpack()'s and the trace-back's: nothing of them is pending past here)
+            lds_fence();
             // b0 holds chunk c's raw values, b1 / b2 those of c + 1 / c + 2: what the code below expects of b0, b1
         }
         if (!(tr < nsteps)) break;
@@ -284,20 +290,24 @@ __device__ __forceinline__ void viterbi16_body(const VitJob* __restrict__ jobs, 
 #else
 #define SORA_VIT16_BOUNDS __launch_bounds__(64)
 #endif
-__global__ void SORA_VIT16_BOUNDS k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__global__ void SORA_VIT16_BOUNDS k_viterbi16(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride,
+        const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 {
 #ifdef SORA_EXP_STAGGER                                         // experiment (round 4): waves of one launch start up to SORA_EXP_STAGGER x 16 x 1.75 us apart (a hash of the workgroup), so that the
-    {                                                           // two waves of a SIMD are not in the add-compare-select stretch and in the trace-back at the same time
+    // two waves of a SIMD are not in the add-compare-select stretch and in the trace-back at the same time
+    {
         const uint32_t d = ((blockIdx.x * 2654435761u) >> 28) * SORA_EXP_STAGGER;
         for (uint32_t i = 0; i < d; i++) __builtin_amdgcn_s_sleep(63);
     }
 #endif
 #ifdef SORA_EXP_VIT_PRIO
-    __builtin_amdgcn_s_setprio(SORA_EXP_VIT_PRIO);              // experiment (round 4): the issue-bound trellis waves ahead of the latency-bound front-end waves on their SIMD
+    // experiment (round 4): the issue-bound trellis waves ahead of the latency-bound front-end waves on their SIMD
+    __builtin_amdgcn_s_setprio(SORA_EXP_VIT_PRIO);
 #endif
     viterbi16_body<256, 24, 3>(jobs, njobs3, njobs_single, stride, soft, out);
 }
-__global__ void __launch_bounds__(64) k_viterbi16_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
+__global__ void __launch_bounds__(64) k_viterbi16_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ njobs3, uint32_t njobs_single,
+        uint32_t stride, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out)
 { viterbi16_body<192, 36, 8>(jobs, njobs3, njobs_single, stride, soft, out); }
 
 }  // namespace sora

@@ -33,7 +33,8 @@ struct ScanArgs {
     uint32_t        nrows;      // list stride = ncaps * max_frames
     uint32_t*       slot_row;   // [total slots] frame-table row that owns a symbol slot (the data symbols of every queued frame); the host presets 0xFFFFFFFF
     // stream continuation (sora_rx_set_stream_mode): capture k of this call continues capture k of the call before it
-    uint32_t*       cont;       // [ncaps][kContWords] the carrier-sense state at the capture's last resume point (read at entry when valid, rewritten at every later one); null = off
+    // [ncaps][kContWords] the carrier-sense state at the capture's last resume point (read at entry when valid, rewritten at every later one); null = off
+    uint32_t*       cont;
     uint32_t*       consumed;   // [ncaps] input-rate samples of this capture that are final: the host submits the stream from there on next time
     // what the NEXT call needs cleared, done here instead of by a fill kernel in front of every call (sora_hip.cpp: a pipeline's calls alternate between two sets of
     // job counters; workgroup 0 zeroes the set this call does not use, and k_pipe's hand-off words): null = the host's fill has done it
@@ -86,13 +87,16 @@ __global__ void k_pipe(RxArgs A, PipeArgs P);
 __global__ void k_decode(RxArgs A);
 __global__ void k_viterbi(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_viterbi11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
-__global__ void k_viterbi16(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);       // k_vit16.hip
+// k_vit16.hip
+__global__ void k_viterbi16(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 __global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint32_t njobs_single, uint32_t stride, const uint8_t* soft, uint8_t* out);
 // k_vitwin.hip: the window-parallel trellis.  hdr = the call's counter block (njobs per code rate in its first three words); jstride = capacity of a list of jobs;
 // target = units the call is cut into at least, frames permitting; vstride = vectors per code-rate list
 __global__ void k_viterbi16w(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
-__global__ void k_win_redo(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats);
-__global__ void k_win_redo_finish(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats,
+__global__ void k_win_redo(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
+        const uint8_t* soft, uint8_t* out, unsigned long long* stats);
+__global__ void k_win_redo_finish(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
+        const uint8_t* soft, uint8_t* out, unsigned long long* stats,
                                   RxArgs A);   // ... and k_finish behind it, in the same waves   // k_rx.hip
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
@@ -135,7 +139,8 @@ struct Rx11bArgs {
     uint32_t*       nframes;    // [ncaps]
     uint8_t*        mpdu;       // [ncaps*max_frames][4096]
     const uint32_t* crc;        // CRC-32 table
-    uint32_t*       needs_cck;  // [ncaps]: set by the first pass for a capture in which a header announces 5.5 / 11 Mbps; such captures are redone by k_rx11b_cck
+    // [ncaps]: set by the first pass for a capture in which a header announces 5.5 / 11 Mbps; such captures are redone by k_rx11b_cck
+    uint32_t*       needs_cck;
 };
 __global__ void k_rx11b(Rx11bArgs A);
 __global__ void k_rx11b_cck(Rx11bArgs A);
@@ -153,7 +158,8 @@ struct Ht40Found {
 
 // ---- completion order for the handles whose calls sit in a small array of slots (sora_rx11b_*, sora_ht40_*): the rules of sora_rx_wait_any
 // (include/sora_hip.h).  A slot type has { hipStream_t stream; int ticket; hipEvent_t ev_done; bool delivered, released; }.
-template <typename Slot> inline int slots_next(const Slot* s, int n)           // the slot of the next call: unused, else the released call with the oldest ticket, else the oldest call
+// the slot of the next call: unused, else the released call with the oldest ticket, else the oldest call
+template <typename Slot> inline int slots_next(const Slot* s, int n)
 {
     int best = 0, best_rel = -1;
     for (int i = 0; i < n; i++) {
@@ -202,7 +208,9 @@ void sora_internal_dense_free(DenseStage* D);
 int sora_internal_dense_deliver(DenseStage* D, const sora::Rx11bRow* d_rows, const uint32_t* d_nframes, const sora::CapDesc* d_caps, const sora_frame_result* h_tmpl,
                                 uint32_t ncaps, uint32_t mf, const uint8_t* d_slots, hipStream_t st,
                                 sora_frame_result* h_rows, size_t max_rows, uint32_t* h_meta, uint8_t* h_mpdu, size_t mpdu_cap,
-                                const sora_frame_result* d_tmpl = nullptr, const uint32_t* d_ncaps = nullptr, const uint32_t* d_evbase = nullptr);   // (a template already on the device; the real number of "captures" where the host only knows a bound; per "capture" the row its rows start at, k_dense_rows)
+                                // (a template already on the device; the real number of "captures" where the host
+                                // only knows a bound; per "capture" the row its rows start at, k_dense_rows)
+                                const sora_frame_result* d_tmpl = nullptr, const uint32_t* d_ncaps = nullptr, const uint32_t* d_evbase = nullptr);
 
 // sora_hip.cpp: the i-th stream of a handle (its i-th pipeline / slot), non-blocking, on priority level i % 3: the runtime keeps GPU_MAX_HW_QUEUES
 // hardware queues per level, so a handle's streams get a hardware queue each without the application setting an environment variable
@@ -215,4 +223,5 @@ extern "C" int sora_internal_rx_device(sora_rx* rx);                           /
 int sora_internal_tables(int device, sora::Tables* out);                  // the per-device tables of the stage entry points (uploaded on first use)
 void sora_internal_dsp_host_tables(std::vector<uint32_t>& sincos, std::vector<short>& atan);   // k_11n.hip: the two dsp_math tables as the host generates them
 int sora_internal_pin_table(const char* name, const void* data, size_t bytes);   // sora_hip.cpp: SORA_OK iff the bytes are the pinned sha256 of table `name`
-int sora_internal_dsp_tables(const uint32_t** sincos, const short** atan);  // dsp_math tables of the current device (k_11n.hip)   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr
+// dsp_math tables of the current device (k_11n.hip)   // device pointer to the 256-entry CRC-32 table of `device` (uploaded on first use), or nullptr
+int sora_internal_dsp_tables(const uint32_t** sincos, const short** atan);

@@ -56,13 +56,16 @@ struct VitJob {             // one Viterbi decode: a frame of the RX path or one
     uint32_t out_off;       // bytes from the output base
     uint32_t valid;
     uint32_t code_rate;
-    uint32_t soft_bits;     // 3: packed three bits per soft value; 8: one byte per soft value (its low three bits) -- informative: the trellis kernel's template parameter decides
+    // 3: packed three bits per soft value; 8: one byte per soft value (its low three bits) -- informative: the trellis kernel's template parameter decides
+    uint32_t soft_bits;
 };
 
 // ---- the window-parallel trellis (k_vitwin.hip, round 5).  A frame's trace-back windows (256 decoded bits each, viterbi.hpp:196-214) are cut into UNITS of m
 // consecutive windows; a unit is decoded on its own -- from all-zero metrics kWinWarm steps before its verify point b = floor24(WIN k0) -- and proven afterwards:
 // its metric vector at b must equal the vector the unit before it had there; a frame with any mismatch is decoded again serially (k_win_redo does both).
-constexpr int kWinWarm = 144;                 // warm-up steps in front of a verify point (a multiple of 24).  tools/winmodel: with 96 no frame that passes its CRC failed a verification at any rate; 144 leaves a margin
+// warm-up steps in front of a verify point (a multiple of 24).  tools/winmodel: with 96
+// no frame that passes its CRC failed a verification at any rate; 144 leaves a margin
+constexpr int kWinWarm = 144;
 constexpr int kWinVecBytes = 256;             // per unit: two vectors of 64 16-bit metric fields in the kernel's own lane order
 constexpr unsigned kWinStatBanks = 64;        // k_win_redo spreads its record over this many banks of four counters (a power of two)
 

@@ -131,8 +131,10 @@ static void build_tables(HostTables& H)
     std::vector<hostfft::c> t64[3], t16[3];
     H.tw64.resize(48); H.tw16.resize(12);
     for (int k = 1; k <= 3; k++) {
-        for (int j = 0; j < 16; j++) { double a = 2 * PI * k * j / 64.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a)); H.tw64[(k - 1) * 16 + j] = pk(re, im); t64[k - 1].push_back(hostfft::mk(re, im)); }
-        for (int j = 0; j < 4; j++)  { double a = 2 * PI * k * j / 16.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a)); H.tw16[(k - 1) * 4 + j] = pk(re, im);  t16[k - 1].push_back(hostfft::mk(re, im)); }
+        for (int j = 0; j < 16; j++) { double a = 2 * PI * k * j / 64.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a));
+            H.tw64[(k - 1) * 16 + j] = pk(re, im); t64[k - 1].push_back(hostfft::mk(re, im)); }
+        for (int j = 0; j < 4; j++)  { double a = 2 * PI * k * j / 16.0; int re = (int)(32767.0 * std::cos(a)), im = (int)(-32767.0 * std::sin(a));
+            H.tw16[(k - 1) * 4 + j] = pk(re, im);  t16[k - 1].push_back(hostfft::mk(re, im)); }
     }
     H.tw128.resize(96); H.tw32.resize(24); H.tw8.resize(4);
     for (int k = 1; k <= 3; k++) {
@@ -176,7 +178,8 @@ static void build_tables(HostTables& H)
                 H.crcz[(k * 8 + j) * 16 + v] = c;
             }
     H.scr.resize(128);
-    for (int i = 0; i < 128; i++) { uint8_t x = (uint8_t)(i << 1); for (int k = 0; k < 8; k++) { uint8_t o1 = ((x >> 1) ^ (x >> 4)) & 1; x = (uint8_t)((x >> 1) | (o1 << 7)); } H.scr[i] = x; }
+    for (int i = 0; i < 128; i++) { uint8_t x = (uint8_t)(i << 1); for (int k = 0; k < 8; k++) { uint8_t o1 = ((x >> 1) ^ (x >> 4)) & 1;
+        x = (uint8_t)((x >> 1) | (o1 << 7)); } H.scr[i] = x; }
     // The descrambler (scramble.hpp:319-349) walks reg -> scr[reg] -> reg>>1 ...: a period-127 cycle of 7-bit
     // states.  Lay the cycle out once: position q holds state st[q]; byte produced from that state = scr[st[q]];
     // 8 positions later comes the state of the next byte.
@@ -201,7 +204,8 @@ static void build_tables(HostTables& H)
         H.trk.assign(sizeof(TrkTables) / 4, 0u);
         TrkTables& t = *reinterpret_cast<TrkTables*>(H.trk.data());
         for (int i = 0; i <= 16384; i++) t.q[i] = H.usin[i];
-        for (unsigned a = 0; a < 65536; a++) {                                    // (the corrections start at zero: trk_usin / trk_ucos return the mirrored quarter wave)
+        // (the corrections start at zero: trk_usin / trk_ucos return the mirrored quarter wave)
+        for (unsigned a = 0; a < 65536; a++) {
             const int ds = H.usin[a] - trk_usin(t, a), dc = H.ucos[a] - trk_ucos(t, a);
             t.e2s[a >> 4] |= ((uint32_t)ds & 3u) << (2u * (a & 15u));            // (a difference beyond +-1 does not fit: trk_tables_exact fails the load)
             t.e2c[a >> 4] |= ((uint32_t)dc & 3u) << (2u * (a & 15u));
@@ -239,7 +243,8 @@ struct Sha256 {
             0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,0x682e6ff3,0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2 };
         uint32_t w[64];
         for (int i = 0; i < 16; i++) w[i] = ((uint32_t)p[4 * i] << 24) | ((uint32_t)p[4 * i + 1] << 16) | ((uint32_t)p[4 * i + 2] << 8) | p[4 * i + 3];
-        for (int i = 16; i < 64; i++) { const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10); w[i] = w[i - 16] + s0 + w[i - 7] + s1; }
+        for (int i = 16; i < 64; i++) { const uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ror(w[i - 2], 17) ^ ror(w[i - 2],
+                19) ^ (w[i - 2] >> 10); w[i] = w[i - 16] + s0 + w[i - 7] + s1; }
         uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
         for (int i = 0; i < 64; i++) {
             const uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
@@ -409,18 +414,22 @@ struct RxPipe {
     // device arrays
     CapDesc* d_caps = nullptr; FrameRow* d_frames = nullptr; FrameCtx* d_fctx = nullptr; uint32_t* d_nframes = nullptr;
     uint8_t* d_soft = nullptr; VitJob* d_jobs = nullptr;        // split decode path only (allocated on its first use)
-    uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;   // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
-    int  front = 1;                                             // symbol chain: 1 = k_frame (one wave per frame), 3 = k_sym_front -> k_track_lds -> k_sym_back (few frames in flight),
-                                                                // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
+    // ... the three symbol kernels' tables: slot owners, equalised bins (256 B per slot), rotation parameters
+    uint32_t* d_slot_row = nullptr; uint32_t* d_eq = nullptr; TrackRec* d_track = nullptr; uint32_t* d_pil = nullptr;
+    // symbol chain: 1 = k_frame (one wave per frame), 3 = k_sym_front -> k_track_lds -> k_sym_back (few frames in flight),
+    // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
+    int  front = 1;
     uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed for every call
     // A call needs its job counters zero, k_pipe's words zero and (three-kernel chain) no symbol slot owned: the call BEFORE it on this pipeline arranges that inside its k_scan
     // (the pipeline's calls alternate between two sets of counters, words 0-3 and 8-11 of the 64-byte block in front of the frame table) -- no fill kernel in front of a call
     // unless counters_ready says that nothing has: the first call, a call recorded into a hipGraph (its arguments are frozen: it always uses set 0 behind its own fill)
     uint32_t parity = 0; bool counters_ready = false;
     bool fused = false;                                         // data field decoded by k_decode (soft values stay in LDS) instead of k_frame + k_viterbi
-    int  lanes16 = 0;                                           // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
-                                                                // 2 = k_viterbi16w + k_win_redo (the proof, and the serial decode of what fails it) (window-parallel, k_vitwin.hip)
-    uint16_t* d_wvecs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;   // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
+    // trellis kernel of the split path: 0 = k_viterbi (64 lanes per frame pair), 1 = k_viterbi16 (16 lanes per pair, k_vit16.hip),
+    // 2 = k_viterbi16w + k_win_redo (the proof, and the serial decode of what fails it) (window-parallel, k_vitwin.hip)
+    int  lanes16 = 0;
+    // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
+    uint16_t* d_wvecs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
@@ -453,8 +462,10 @@ struct RxPipe {
     unsigned only = 0xF;         // tool hook (sora_internal_rx_only): which kernels of the chain a call launches (1 scan, 2 frame, 4 trellis, 8 finish)
 };
 
-constexpr uint32_t kWinLoneWaves = 3 * sora::kWinLonePad / 8;   // waves a call may need on top of its units' eight per wave: a code-rate list of ONE frame is laid out with gaps (dev_winplan.h)
-constexpr uint32_t kWinUnitsTarget = 16384;                     // units a call of the window-parallel trellis is cut into at least, frames permitting: one round of the chip's 2048 eight-unit trellis slots
+// waves a call may need on top of its units' eight per wave: a code-rate list of ONE frame is laid out with gaps (dev_winplan.h)
+constexpr uint32_t kWinLoneWaves = 3 * sora::kWinLonePad / 8;
+// units a call of the window-parallel trellis is cut into at least, frames permitting: one round of the chip's 2048 eight-unit trellis slots
+constexpr uint32_t kWinUnitsTarget = 16384;
 // Probe hooks (which kernels of the chain a call launches, empty launches appended to a call, the calls' kernel boundaries on one time base, the device arrays between the
 // kernels) exist in the TOOLS variant of the library only -- sora_amd.build.build_variant("tools", ["SORA_TOOLS"]), loaded by the scripts under tools/ through SORA_HIP_LIB.
 // The product build has neither the entry points nor the branches they steer.
@@ -469,8 +480,10 @@ static const char* const kKernelNames[kNumTimed] = { "memset+caps", "k_scan", "k
 static const char* const kKernelNamesFused[kNumTimed] = { "memset+caps", "k_scan", "k_decode", "", "k_finish" };   // "" = not launched
 
 namespace sora {
-__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16, uint4* __restrict__ ones = nullptr, uint32_t m16 = 0,   // n16 16-byte words <- 0, then m16 of `ones` <- all ones,
-                                                 uint4* __restrict__ z2 = nullptr, uint32_t k16 = 0)                                             // then k16 of `z2` <- 0
+// n16 16-byte words <- 0, then m16 of `ones` <- all ones,
+__global__ void __launch_bounds__(256) k_clear16(uint4* __restrict__ p, uint32_t n16, uint4* __restrict__ ones = nullptr, uint32_t m16 = 0,
+                                                 // then k16 of `z2` <- 0
+                                                 uint4* __restrict__ z2 = nullptr, uint32_t k16 = 0)
 {
     const uint32_t i = blockIdx.x * 256u + threadIdx.x;
     if (i < n16) p[i] = make_uint4(0u, 0u, 0u, 0u);
@@ -526,13 +539,18 @@ int sora_hip_device_count(void)
 }
 // ---- the pinned look-up tables, by name (include/sora_hip.h)
 namespace { struct NamedTable { const char* name; const void* host; size_t bytes; const void* const* dev; }; }
-static std::vector<NamedTable> named_tables(const HostTables& H, const std::vector<uint32_t>& sc, const std::vector<short>& at, const Tables* T, const uint32_t* const* dsc, const short* const* dat)
+static std::vector<NamedTable> named_tables(const HostTables& H, const std::vector<uint32_t>& sc, const std::vector<short>& at, const Tables* T,
+        const uint32_t* const* dsc, const short* const* dat)
 {
 #define NT(n, v, d) { n, (v).data(), (v).size() * sizeof((v)[0]), (const void* const*)(d) }
-    return { NT("usin", H.usin, T ? &T->usin : nullptr), NT("ucos", H.ucos, T ? &T->ucos : nullptr), NT("rot", H.rot, T ? &T->rot : nullptr), NT("uatan2", H.uatan2, T ? &T->uatan2 : nullptr),
-             NT("demap", H.demap, T ? &T->demap : nullptr), NT("tw64", H.tw64, T ? &T->tw64 : nullptr), NT("tw16", H.tw16, T ? &T->tw16 : nullptr), NT("sts", H.sts, T ? &T->sts : nullptr),
-             NT("deint", H.deint, T ? &T->deint : nullptr), NT("crc", H.crc, T ? &T->crc : nullptr), NT("scr", H.scr, T ? &T->scr : nullptr), NT("scr_seq", H.scr_seq, T ? &T->scr_seq : nullptr),
-             NT("scr_phase", H.scr_phase, T ? &T->scr_phase : nullptr), NT("tw128", H.tw128, T ? &T->tw128 : nullptr), NT("tw32", H.tw32, T ? &T->tw32 : nullptr), NT("tw8", H.tw8, T ? &T->tw8 : nullptr),
+    return { NT("usin", H.usin, T ? &T->usin : nullptr), NT("ucos", H.ucos, T ? &T->ucos : nullptr), NT("rot", H.rot, T ? &T->rot : nullptr), NT("uatan2",
+            H.uatan2, T ? &T->uatan2 : nullptr),
+             NT("demap", H.demap, T ? &T->demap : nullptr), NT("tw64", H.tw64, T ? &T->tw64 : nullptr), NT("tw16", H.tw16, T ? &T->tw16 : nullptr), NT("sts",
+                     H.sts, T ? &T->sts : nullptr),
+             NT("deint", H.deint, T ? &T->deint : nullptr), NT("crc", H.crc, T ? &T->crc : nullptr), NT("scr", H.scr, T ? &T->scr : nullptr), NT("scr_seq",
+                     H.scr_seq, T ? &T->scr_seq : nullptr),
+             NT("scr_phase", H.scr_phase, T ? &T->scr_phase : nullptr), NT("tw128", H.tw128, T ? &T->tw128 : nullptr), NT("tw32", H.tw32,
+                     T ? &T->tw32 : nullptr), NT("tw8", H.tw8, T ? &T->tw8 : nullptr),
              NT("crcz", H.crcz, T ? &T->crcz : nullptr), NT("trk", H.trk, T ? &T->trk : nullptr), NT("dsp_sincos", sc, dsc), NT("dsp_atan", at, dat) };
 #undef NT
 }
@@ -624,7 +642,8 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out, int index = 0)
         { (void**)&rx->d_vout, (size_t)kOutPerSlot * rx->cap_slots }, { (void**)&rx->d_mpdu, (size_t)kOutPerSlot * rx->cap_slots },
         { (void**)&rx->d_rows, sizeof(sora_frame_result) * rx->cap_rows },
         { (void**)&rx->d_nrows, 4 }, { (void**)&rx->d_joblist, 3 * 4 * (size_t)rx->cap_rows },
-        { (void**)&rx->d_njobs, 64 + sizeof(FrameRow) * rx->cap_rows },             // the three job counters AND, 64 bytes on, the frame table: one fill clears both at the start of a call
+        // the three job counters AND, 64 bytes on, the frame table: one fill clears both at the start of a call
+        { (void**)&rx->d_njobs, 64 + sizeof(FrameRow) * rx->cap_rows },
     };
     for (auto& a : allocs) {
         e = hipMalloc(a.p, a.bytes);
@@ -692,12 +711,14 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 #else
     const bool split = rx->front >= 3 && !rx->fused;
 #endif
-    const bool pipe = split && rx->front == 4 && rx->lanes16 == 2;               // (the handle only asks for k_pipe where its workgroups are all resident at once: pipe_fits)
+    // (the handle only asks for k_pipe where its workgroups are all resident at once: pipe_fits)
+    const bool pipe = split && rx->front == 4 && rx->lanes16 == 2;
     if (pipe && !rx->d_pflags) {
         rx->pflag_words = (4u + 4u * rx->cap_rows + (rx->cap_slots + 63u) / 64u + 4u + 3u) / 4u * 4u;
         HIPCHK(hipMalloc((void**)&rx->d_pflags, 4 * ((size_t)rx->pflag_words + 1024)));   // (+ the tools variant's time stamps)
     }
-    if (split && !rx->d_slot_row) {                                              // the three-kernel symbol chain's arrays, on its first use: slot owners, equalised bins (256 B per slot), pilots, rotation parameters
+    // the three-kernel symbol chain's arrays, on its first use: slot owners, equalised bins (256 B per slot), pilots, rotation parameters
+    if (split && !rx->d_slot_row) {
         HIPCHK(hipMalloc((void**)&rx->d_slot_row, 4 * ((size_t)rx->cap_slots + 64)));
         HIPCHK(hipMalloc((void**)&rx->d_eq, 256 * ((size_t)rx->cap_slots + 64)));
         HIPCHK(hipMalloc((void**)&rx->d_track, sizeof(TrackRec) * ((size_t)rx->cap_slots + 64)));
@@ -722,7 +743,8 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
 
     auto enqueue = [&](bool recording) -> int {                                  // the kernel chain of one call, in stream order (recording: into a hipGraph)
 #ifdef SORA_TOOLS
-        const bool self_clean = false;                                           // (the tools variant's partial chains and array dumps want the plain protocol: a fill in front of every call)
+        // (the tools variant's partial chains and array dumps want the plain protocol: a fill in front of every call)
+        const bool self_clean = false;
 #else
         const bool self_clean = !recording && !rx->fused;
 #endif
@@ -734,16 +756,20 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             // the job counters and the frame table behind them, the slot owners (no symbol slot has an owner yet; only the three-kernel chain reads them) and k_pipe's hand-off
             // words: ONE fill (every packet of a call costs the command processor a few microseconds: DESIGN.md section 3.6) -- by a kernel of this library: a hipMemsetAsync
             // of 64 + 64 n bytes recorded into a hipGraph faults on replay
-            const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16), m16 = split ? (slots + 3) / 4 : 0u;   // (the owners' array has 64 words of slack)
+            // (the owners' array has 64 words of slack)
+            const uint32_t n16 = (uint32_t)((64 + sizeof(FrameRow) * (size_t)nrows) / 16), m16 = split ? (slots + 3) / 4 : 0u;
             const uint32_t k16 = (pipe_words + 3u) / 4u;
-            hipLaunchKernelGGL(k_clear16, dim3((n16 + m16 + k16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16, reinterpret_cast<uint4*>(rx->d_slot_row), m16,
+            hipLaunchKernelGGL(k_clear16, dim3((n16 + m16 + k16 + 255) / 256), dim3(256), 0, st, reinterpret_cast<uint4*>(rx->d_njobs), n16,
+                    reinterpret_cast<uint4*>(rx->d_slot_row), m16,
                                reinterpret_cast<uint4*>(rx->d_pflags), k16);
         }
         ScanArgs S{};
-        S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str; S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
+        S.iq = reinterpret_cast<const uint32_t*>(d_iq); S.caps = rx->d_caps; S.ncaps = rx->ncaps; S.str = rx->str;
+            S.keep_queue = rx->cfg.sample_rate_mhz == 44 ? 1u : 0u; S.thr = rx->cfg.cca_pwr_threshold;
         S.max_frames = rx->cfg.max_frames_per_capture; S.T = rx->tabs.T; S.frames = rx->d_frames; S.fctx = rx->d_fctx; S.nframes = rx->d_nframes;
         S.njobs = counters; S.joblist = rx->d_joblist; S.nrows = nrows; S.slot_row = split ? rx->d_slot_row : nullptr; S.cont = rx->cont; S.consumed = rx->consumed;
-        if (self_clean) {                                                        // this call's k_scan prepares the next one's (and its own slot owners and hand-off words)
+        // this call's k_scan prepares the next one's (and its own slot owners and hand-off words)
+        if (self_clean) {
             S.zero_a = rx->d_njobs + 8u * (1u - par); S.nzero_a = 4; S.zero_b = pipe ? rx->d_pflags : nullptr; S.nzero_b = pipe_words; S.own_slots = 1;
         }
         rx->parity = self_clean ? 1u - par : 0u; rx->counters_ready = self_clean;
@@ -766,18 +792,21 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         {
             R.soft = rx->d_soft; R.jobs = rx->d_jobs; R.slot_row = rx->d_slot_row; R.eq = rx->d_eq; R.track = rx->d_track; R.pil = rx->d_pil;
             redo_finish = rx->lanes16 == 2 && RX_ONLY(rx, 4u) && RX_ONLY(rx, 8u);
-            const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);   // the window-parallel trellis: a frame has at most 80 windows
+            // the window-parallel trellis: a frame has at most 80 windows
+            const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kWinUnitsTarget, nrows), 80ull * nrows);
             if (pipe) {
                 R.pipe_flags = rx->d_pflags;
                 // a handful of frames: the symbol chain AND the window-parallel trellis as one launch (k_rx.hip: k_pipe), the proof behind it
                 if (RX_ONLY(rx, 2u)) {
                     PipeArgs P{};
-                    P.nfront = (slots + 63) / 64; P.ntrack = nrows; P.flags = rx->d_pflags; P.target = kWinUnitsTarget; P.vstride = rx->wstride; P.vecs = rx->d_wvecs; P.stamp_base = rx->pflag_words;
+                    P.nfront = (slots + 63) / 64; P.ntrack = nrows; P.flags = rx->d_pflags; P.target = kWinUnitsTarget; P.vstride = rx->wstride;
+                        P.vecs = rx->d_wvecs; P.stamp_base = rx->pflag_words;
                     hipLaunchKernelGGL(k_pipe, dim3(P.nfront + P.ntrack + ((units_max + 7) / 8 + 3 + kWinLoneWaves + 3) / 4), dim3(256), 0, st, R, P);
                 }
                 mark();
                 if (RX_ONLY(rx, 4u) && !redo_finish)
-                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
+                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters,
+                            nrows, kWinUnitsTarget, rx->wstride,
                                        (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
                 mark();
             } else {
@@ -800,22 +829,29 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             else if (rx->lanes16 == 2) {
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), then the proof
                 // and the serial decode of the pairs of frames that fail it (none, normally: k_win_redo's waves check and return)
-                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
+                hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs,
+                        (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
                                    (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
                 if (!redo_finish)
-                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
+                    hipLaunchKernelGGL(k_win_redo, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters,
+                            nrows, kWinUnitsTarget, rx->wstride,
                                        (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats);
             }
             else if (rx->lanes16)   // eight frames per one-wave workgroup: at most ceil(n / 8) + 2 waves over the three lists
-                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);
+                hipLaunchKernelGGL(k_viterbi16, dim3((nrows + 7) / 8 + 2), dim3(64), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows,
+                        (const uint8_t*)rx->d_soft, rx->d_vout);
             else
-                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows, (const uint8_t*)rx->d_soft, rx->d_vout);   // at most ceil(n/2) + 2 pairs over the three lists
+                // at most ceil(n/2) + 2 pairs over the three lists
+                hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows,
+                        (const uint8_t*)rx->d_soft, rx->d_vout);
             mark();
             }
         }
-        // (behind the window-parallel trellis the proof, the decode of what fails it and T11aDesc / the frame sink are ONE launch: the wave that holds a pair of frames finishes them)
+        // (behind the window-parallel trellis the proof, the decode of what fails it and T11aDesc
+        // / the frame sink are ONE launch: the wave that holds a pair of frames finishes them)
         if (redo_finish)
-            hipLaunchKernelGGL(k_win_redo_finish, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
+            hipLaunchKernelGGL(k_win_redo_finish, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows,
+                    kWinUnitsTarget, rx->wstride,
                                (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats, R);
         else if (RX_ONLY(rx, 8u)) hipLaunchKernelGGL(k_finish, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
 #ifdef SORA_TOOLS
@@ -872,11 +908,13 @@ static int pipe_process(RxPipe* rx, const sora_complex16* h_iq, size_t total_sam
 static int pipe_process_dump(RxPipe* rx, const void* h_dump, size_t dump_bytes, unsigned flags, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx || !h_dump || dump_bytes == 0) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dump: null argument");
-    if ((flags & ~15u) || (dump_bytes & 3)) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dump: unknown ingest flag, or a dump that is not a whole number of 4-byte samples");
+    if ((flags & ~15u) || (dump_bytes & 3)) return fail(SORA_ERR_INVALID_PARAM,
+            "sora_rx_process_dump: unknown ingest flag, or a dump that is not a whole number of 4-byte samples");
     const size_t n = sora_hip_ingest_count(dump_bytes, flags);
     if (n > rx->cfg.max_total_samples) return fail(SORA_ERR_CAPACITY, "sora_rx_process_dump: the dump holds more samples than sora_rx_cfg.max_total_samples");
     HIPCHK(hipSetDevice(rx->cfg.device));
-    if (rx->dump_cap < dump_bytes || rx->iq_own_samples < n) HIPCHK(hipStreamSynchronize(rx->stream));   // (growing: the previous call of this pipeline may still read them)
+    // (growing: the previous call of this pipeline may still read them)
+    if (rx->dump_cap < dump_bytes || rx->iq_own_samples < n) HIPCHK(hipStreamSynchronize(rx->stream));
     if (rx->dump_cap < dump_bytes) {
         if (rx->d_dump) (void)hipFree(rx->d_dump);
         rx->d_dump = nullptr; rx->dump_cap = 0;
@@ -974,7 +1012,8 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
     if (!rx || !h_rows || !h_nrows) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_deliver_async: null argument");
     if (!rx->have_results) return fail(SORA_ERR_FAILED, "no process call to report");
     const size_t need = (size_t)kOutPerSlot * rx->total_slots;
-    if (h_mpdu && mpdu_bytes < need) return fail(SORA_ERR_CAPACITY, "sora_rx_deliver_async: h_mpdu is smaller than sora_rx_mpdu_bytes()");   // (checked before anything is enqueued)
+    // (checked before anything is enqueued)
+    if (h_mpdu && mpdu_bytes < need) return fail(SORA_ERR_CAPACITY, "sora_rx_deliver_async: h_mpdu is smaller than sora_rx_mpdu_bytes()");
     HIPCHK(hipSetDevice(rx->cfg.device));
     { const int rc = pipe_pack(rx); if (rc) return rc; }
     const size_t nr = std::min<size_t>(max_rows, (size_t)rx->ncaps * rx->cfg.max_frames_per_capture);
@@ -994,9 +1033,10 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
 // front end of one call (k_scan) overlaps the issue-bound decode kernel of the call before it -- the overlap
 // the reference gets from running ViterbiThread beside RxThread (fb11a_demod.cpp:117-120, TThreadSeparator
 // stdbrick.hpp:89-248).  Independent streams with no cross-stream events: kernels of different calls share the CUs.
-constexpr long long kAutoLanes16Captures = 32768;               // captures in flight (depth x the handle's max_captures) from which the automatic choice is k_viterbi16: below that the
-                                                                // window-parallel form wins (gpurun r05: one to four 4096-capture calls in flight 0.60 / 0.51 / 0.48 / 0.46 ms per call against
-                                                                // 0.71 / 0.52 / 0.51 / 0.51 for the better of the two serial kernels; eight calls: k_viterbi16 0.40 against 0.42)
+// captures in flight (depth x the handle's max_captures) from which the automatic choice is k_viterbi16: below that the
+// window-parallel form wins (gpurun r05: one to four 4096-capture calls in flight 0.60 / 0.51 / 0.48 / 0.46 ms per call
+// against 0.71 / 0.52 / 0.51 / 0.51 for the better of the two serial kernels; eight calls: k_viterbi16 0.40 against 0.42)
+constexpr long long kAutoLanes16Captures = 32768;
 struct sora_rx {
     static constexpr int kMaxDepth = 16;
     sora_rx_cfg cfg{};
@@ -1101,8 +1141,10 @@ static int lanes16_for(const sora_rx* rx)                                       
 
 // The symbol chain: one wave per frame (k_frame) is the cheaper one when the chip is full of frames; the three-kernel chain spreads a frame's symbols over the
 // chip and runs the tracker's chain out of LDS: the one for few, long frames.
-constexpr long long kAutoSplitRows = 512;                       // frame rows in flight (depth x max_captures x max_frames_per_capture) up to which the automatic choice is the three-kernel chain
-constexpr long long kAutoPipeRows = 16;                         // ... and up to which it is k_pipe (the chain and the window-parallel trellis as one launch), if that launch fits
+// frame rows in flight (depth x max_captures x max_frames_per_capture) up to which the automatic choice is the three-kernel chain
+constexpr long long kAutoSplitRows = 512;
+// ... and up to which it is k_pipe (the chain and the window-parallel trellis as one launch), if that launch fits
+constexpr long long kAutoPipeRows = 16;
 // k_pipe's workgroups wait for one another inside the launch: it is only used where ALL workgroups of ALL the handle's calls in flight are resident at once -- one per CU
 // (160 KB of LDS each), and a good part of the chip left to whatever else runs
 static bool pipe_fits(const sora_rx* rx)
@@ -1215,7 +1257,8 @@ int sora_rx_set_stream_mode(sora_rx_t* rx, int enable)
     if (!rx) return SORA_ERR_INVALID_PARAM;
     const int old = rx->stream_mode ? 1 : 0;
     if (enable < 0) return old;
-    if (enable && rx->cfg.sample_rate_mhz == 44) return fail(SORA_E_NOT_SUPPORTED, "sora_rx_set_stream_mode: not for the 44 MHz graph (its resampler's queue is not part of the continuation record)");
+    if (enable && rx->cfg.sample_rate_mhz == 44) return fail(SORA_E_NOT_SUPPORTED,
+            "sora_rx_set_stream_mode: not for the 44 MHz graph (its resampler's queue is not part of the continuation record)");
     HIPCHK(hipSetDevice(rx->cfg.device));
     for (RxPipe* q : rx->pipes) if (q) { const int rc = pipe_flush(q); if (rc) return rc; }
     if (enable && !rx->d_cont) {
@@ -1477,7 +1520,8 @@ int sora_hip_lts11a(const sora_complex16* d_in, sora_lts11a_ctx* d_ctx, size_t n
     static_assert(sizeof(sora_lts11a_ctx) == 516, "sora_lts11a_ctx layout");
     if (n == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_lts_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in), reinterpret_cast<uint32_t*>(d_ctx), (uint32_t)n, D->T);
+    hipLaunchKernelGGL(k_lts_batch, dim3((unsigned)n), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_in),
+            reinterpret_cast<uint32_t*>(d_ctx), (uint32_t)n, D->T);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
@@ -1496,7 +1540,8 @@ int sora_hip_symfront11a(const sora_complex16* d_in, const sora_lts11a_ctx* d_ct
 }
 
 // The symbol chain's three one-multiply bricks on their own (k_stage.hip: k_cmul64_batch)
-static int cmul64_stage(int kind, const char* who, const sora_complex16* d_in, const void* d_coef, uint32_t cstride_words, uint32_t coff_words, const uint32_t* d_index, sora_complex16* d_out, size_t n, void* stream)
+static int cmul64_stage(int kind, const char* who, const sora_complex16* d_in, const void* d_coef, uint32_t cstride_words, uint32_t coff_words,
+        const uint32_t* d_index, sora_complex16* d_out, size_t n, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
     if (!d_in || !d_coef || !d_out) return fail(SORA_ERR_INVALID_PARAM, who);
@@ -1504,7 +1549,8 @@ static int cmul64_stage(int kind, const char* who, const sora_complex16* d_in, c
     if (n >= (1ull << 31)) return fail(SORA_ERR_CAPACITY, who);
     if (((uintptr_t)d_in | (uintptr_t)d_out) & 15) return fail(SORA_ERR_INVALID_PARAM, "symbol buffers must be 16-byte aligned");
     const dim3 grid((unsigned)((n + 127) / 128)); const hipStream_t st = (hipStream_t)stream;
-    const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in); const uint32_t* cf = reinterpret_cast<const uint32_t*>(d_coef); uint32_t* out = reinterpret_cast<uint32_t*>(d_out);
+    const uint32_t* in = reinterpret_cast<const uint32_t*>(d_in); const uint32_t* cf = reinterpret_cast<const uint32_t*>(d_coef);
+        uint32_t* out = reinterpret_cast<uint32_t*>(d_out);
     if (kind == 0)      hipLaunchKernelGGL(k_cmul64_batch<0>, grid, dim3(256), 0, st, in, cf, cstride_words, coff_words, d_index, out, (uint32_t)n);
     else if (kind == 1) hipLaunchKernelGGL(k_cmul64_batch<1>, grid, dim3(256), 0, st, in, cf, cstride_words, coff_words, d_index, out, (uint32_t)n);
     else                hipLaunchKernelGGL(k_cmul64_batch<2>, grid, dim3(256), 0, st, in, cf, cstride_words, coff_words, d_index, out, (uint32_t)n);
@@ -1526,7 +1572,8 @@ int sora_hip_phase_comp11a(const sora_complex16* d_in, const sora_track11a_state
     return cmul64_stage(2, "sora_hip_phase_comp11a: null pointer", d_in, d_state, 67u, 3u, d_state_index, d_out, n, stream);
 }
 
-int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out, size_t nframes, void* stream)
+int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out,
+        size_t nframes, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
     if (!d_eq || !d_first || !d_nsym || !d_state || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_pilot_track11a: null pointer");
@@ -1657,12 +1704,14 @@ int sora_hip_ingest(const void* d_raw, size_t raw_bytes, unsigned flags, sora_co
         const uint64_t per_tile = (flags & SORA_INGEST_DECIMATE2) ? 700 : 1400;
         const uint64_t tiles = std::min<uint64_t>(raw_bytes / (55 * 128), n / per_tile);
         if (tiles) {
-            hipLaunchKernelGGL(k_ingest_tile, dim3((unsigned)std::min<uint64_t>(tiles, 8 * 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw, reinterpret_cast<uint32_t*>(d_out), flags, (uint32_t)tiles);
+            hipLaunchKernelGGL(k_ingest_tile, dim3((unsigned)std::min<uint64_t>(tiles, 8 * 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw,
+                    reinterpret_cast<uint32_t*>(d_out), flags, (uint32_t)tiles);
             done = tiles * per_tile;
         }
     }
     if (done < n)
-        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n - done + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw, reinterpret_cast<uint32_t*>(d_out), done, (uint64_t)n, flags);
+        hipLaunchKernelGGL(k_ingest, dim3((unsigned)((n - done + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const uint8_t*)d_raw,
+                reinterpret_cast<uint32_t*>(d_out), done, (uint64_t)n, flags);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
@@ -1680,20 +1729,25 @@ int sora_hip_viterbi11a_ws(const uint8_t* d_soft, size_t soft_span_bytes, const 
                            int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* d_workspace, size_t workspace_bytes, int lanes_per_pair, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-    if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: bad argument");
+    if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM,
+            "sora_hip_viterbi11a: bad argument");
     if (n == 0) return SORA_OK;
-    if (lanes_per_pair != 0 && lanes_per_pair != 16 && lanes_per_pair != 64) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a_ws: lanes_per_pair is 0 (default: 64), 16 or 64");
+    if (lanes_per_pair != 0 && lanes_per_pair != 16 && lanes_per_pair != 64) return fail(SORA_ERR_INVALID_PARAM,
+            "sora_hip_viterbi11a_ws: lanes_per_pair is 0 (default: 64), 16 or 64");
     if (!d_workspace || ((uintptr_t)d_workspace & 15)) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a_ws: the workspace must be a 16-byte aligned device buffer");
-    if (workspace_bytes < sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a_ws: workspace smaller than sora_hip_viterbi11a_workspace_bytes()");
+    if (workspace_bytes < sora_hip_viterbi11a_workspace_bytes(soft_span_bytes, n)) return fail(SORA_ERR_CAPACITY,
+            "sora_hip_viterbi11a_ws: workspace smaller than sora_hip_viterbi11a_workspace_bytes()");
     if (soft_span_bytes >= (1ull << 32) || n >= (1ull << 31)) return fail(SORA_ERR_CAPACITY, "sora_hip_viterbi11a: batch too large");
     hipStream_t st = (hipStream_t)stream;
     uint8_t* packed = (uint8_t*)d_workspace;
     VitJob* jobs = (VitJob*)((uint8_t*)d_workspace + vit_ws_packed_bytes(soft_span_bytes));
     hipLaunchKernelGGL(k_soft_pack3, dim3((unsigned)n), dim3(256), 0, st, d_soft, d_soft_off, d_nsoft, d_frame_len, d_out_off, code_rate, packed, jobs);
     if (lanes_per_pair == 16)
-        hipLaunchKernelGGL(k_viterbi16, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)packed, d_out);
+        hipLaunchKernelGGL(k_viterbi16, dim3((unsigned)((n + 7) / 8)), dim3(64), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u,
+                (const uint8_t*)packed, d_out);
     else
-        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u, (const uint8_t*)packed, d_out);
+        hipLaunchKernelGGL(k_viterbi, dim3((unsigned)((n + 7) / 8)), dim3(256), 0, st, (const VitJob*)jobs, (const uint32_t*)nullptr, (uint32_t)n, 0u,
+                (const uint8_t*)packed, d_out);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
@@ -1708,7 +1762,8 @@ int sora_hip_viterbi11a(const uint8_t* d_soft, const uint32_t* d_soft_off, const
                         int code_rate, uint8_t* d_out, const uint32_t* d_out_off, size_t n, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-    if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_viterbi11a: bad argument");
+    if (!d_soft || !d_soft_off || !d_nsoft || !d_frame_len || !d_out || !d_out_off || code_rate < 0 || code_rate > 2) return fail(SORA_ERR_INVALID_PARAM,
+            "sora_hip_viterbi11a: bad argument");
     if (n == 0) return SORA_OK;
     hipStream_t st = (hipStream_t)stream;
     // This signature does not say how far the soft buffer reaches: read the extent back once (the _ws entry point takes it as an argument).

@@ -165,7 +165,8 @@ void sora_shard_partition(size_t n_items, int world_size, int rank, size_t* firs
 int sora_shard_gather_rows(sora_shard_t* sh, const sora_frame_result* d_rows, const uint32_t* d_nrows, size_t max_rows_per_rank,
                            sora_frame_result* d_all_rows, uint32_t* d_all_counts, void* stream)
 {
-    if (!sh || !d_rows || !d_nrows || !d_all_rows || !d_all_counts || max_rows_per_rank == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_shard_gather_rows: bad argument", 0);
+    if (!sh || !d_rows || !d_nrows || !d_all_rows || !d_all_counts || max_rows_per_rank == 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM,
+            "sora_shard_gather_rows: bad argument", 0);
     const Rccl* R = rccl();
     SHARD_HIP(hipSetDevice(sh->device));
     hipStream_t st = (hipStream_t)stream;
@@ -225,7 +226,8 @@ int sora_shard_gather_results_mpdu(sora_shard_t* sh, sora_rx_t* rx, int ticket, 
     const sora_frame_result* d_rows = nullptr; const uint32_t* d_nrows = nullptr; const uint8_t* d_mpdu = nullptr;
     hipStream_t st = nullptr;
     uint32_t mine[2] = { 0, 0 };
-    if (sora_internal_rx_device(rx) != sh->device) { lrc = SORA_ERR_INVALID_PARAM; lwhat = "sora_shard_gather_results: the receive handle lives on another device than the shard handle"; }
+    if (sora_internal_rx_device(rx) != sh->device) { lrc = SORA_ERR_INVALID_PARAM;
+        lwhat = "sora_shard_gather_results: the receive handle lives on another device than the shard handle"; }
     if (lrc == SORA_OK) {
         lrc = ticket > 0 ? sora_rx_results_dev_of(rx, ticket, &d_rows, &d_nrows, &d_mpdu) : sora_rx_results_dev(rx, &d_rows, &d_nrows, &d_mpdu);
         if (lrc != SORA_OK) lwhat = "sora_shard_gather_results: the call's results are not available (stale ticket?)";
@@ -243,11 +245,14 @@ int sora_shard_gather_results_mpdu(sora_shard_t* sh, sora_rx_t* rx, int ticket, 
         if (e == hipSuccess && mpdu_block && mine[0]) {
             // dense MPDU block of this rank: row i's bytes at the running sum of the lengths of the rows before it; the rows' mpdu_offset is rewritten to it
             hipLaunchKernelGGL(sora::k_shard_mpdu_offsets, dim3(1), dim3(1024), 0, st, sh->d_mine, mine[0], sh->d_off, sh->d_pair + 2 * W);
-            hipLaunchKernelGGL(sora::k_shard_mpdu_pack, dim3((mine[0] + 3) / 4), dim3(256), 0, st, sh->d_mine, mine[0], (const uint32_t*)sh->d_off, d_mpdu, sh->d_mpdu_mine, (uint32_t)max_mpdu_bytes_per_rank);   // the CALLER's limit: the 16-byte rounding is only the staging / AllGather granule
+            // the CALLER's limit: the 16-byte rounding is only the staging / AllGather granule
+            hipLaunchKernelGGL(sora::k_shard_mpdu_pack, dim3((mine[0] + 3) / 4), dim3(256), 0, st, sh->d_mine, mine[0], (const uint32_t*)sh->d_off, d_mpdu,
+                    sh->d_mpdu_mine, (uint32_t)max_mpdu_bytes_per_rank);
             if (e == hipSuccess) e = hipMemcpyAsync(&mine[1], sh->d_pair + 2 * W, 4, hipMemcpyDeviceToHost, st);
             if (e == hipSuccess) e = hipStreamSynchronize(st);
             if (e == hipSuccess) e = hipGetLastError();
-            if (e == hipSuccess && mine[1] > max_mpdu_bytes_per_rank) { lrc = SORA_ERR_CAPACITY; lwhat = "sora_shard_gather_results: this rank's MPDUs exceed max_mpdu_bytes_per_rank"; }
+            if (e == hipSuccess && mine[1] > max_mpdu_bytes_per_rank) { lrc = SORA_ERR_CAPACITY;
+                lwhat = "sora_shard_gather_results: this rank's MPDUs exceed max_mpdu_bytes_per_rank"; }
         }
         if (e != hipSuccess) { lrc = SORA_ERR_HARDWARE_FAILED; lwhat = "sora_shard_gather_results: staging this rank's rows"; }
     }
