@@ -877,7 +877,9 @@ __global__ void __launch_bounds__(256) k_pipe(RxArgs A, PipeArgs P)
         sym_front_block<true>(A, b, reinterpret_cast<uint32_t (*)[4][64]>(lds));
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every storing wave drains, then ONE flag
         __syncthreads();
+#ifndef SORA_DBG_PIPE_LOSE_FLAGS                                                 // (tools/pipe_timeout_check.py: what happens when a hand-off never arrives)
         if (threadIdx.x == 0) store4_through(P.flags + 4u + 4u * A.nrows + b, 1u);
+#endif
         if (b == 0) PIPE_STAMP(P, 8);
         return;
     }

@@ -21,6 +21,11 @@ if "--fsample6" in sys.argv:                                               # the
     iq = g["iq_i8"].astype(np.int16) << 8
     iq = np.ascontiguousarray(iq[:len(iq) // 28 * 28]); n = 1; descs = [(0, len(iq), 0)]
     rx = sora_amd.Rx(1, len(iq), sample_rate_mhz=40, max_frames_per_capture=2)
+elif "--shard" in sys.argv:                                                # BASELINE configs[4]'s per-GPU share: 32 captures x 16 frames back to back (the probe sums capture 0's sixteen frames)
+    from benchlib.common import CAPTURE_SAMPLES
+    iq, _, _ = bench.make_workload(o, 32 * 16, seed0=5151)
+    n = 32; descs = [(i * 16 * CAPTURE_SAMPLES, 16 * CAPTURE_SAMPLES, i) for i in range(32)]
+    rx = sora_amd.Rx(32, len(iq), sample_rate_mhz=20, max_frames_per_capture=18)
 else:
     n = 4096
     iq, descs, _ = bench.make_workload(o, n, 0, distinct=64)
