@@ -57,11 +57,31 @@ __device__ __forceinline__ uint32_t group_scan(uint32_t t)
     return t;
 }
 
+// Cross-lane sums and minima as DPP moves and row swaps (VALU latency) instead of ds_bpermute round trips through the LDS pipeline: this kernel is one wave per capture
+// walking a serial state machine, and what it waits for is mostly these (round 5: a lone capture's, or a sixteen-frame capture's, k_scan is 35 us per frame).
+template <int CTRL> __device__ __forceinline__ unsigned sdpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
+__device__ __forceinline__ unsigned quad_sum(unsigned v) { v += sdpp<0xB1>(v); v += sdpp<0x4E>(v); return v; }                // over lanes 4q .. 4q + 3, in all four
+__device__ __forceinline__ unsigned row_sum(unsigned v) { v = quad_sum(v); v += sdpp<0x141>(v); v += sdpp<0x140>(v); return v; }   // over the 16 lanes of a row (^7 then ^15 pair up what ^1, ^2 left)
+__device__ __forceinline__ unsigned other_row_even(unsigned v)                   // for the lanes of rows 1 and 3: the value of the lane 16 below (rows 0 and 2 get their own)
+{
+    auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    return r[0];
+}
 __device__ __forceinline__ int wave_sum(int v)
 {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v = (int)((unsigned)v + (unsigned)__shfl_xor(v, o));
-    return v;
+    unsigned u = row_sum((unsigned)v);
+    auto r16 = __builtin_amdgcn_permlane16_swap(u, u, false, false);
+    u = r16[0] + r16[1];
+    auto r32 = __builtin_amdgcn_permlane32_swap(u, u, false, false);
+    return (int)(r32[0] + r32[1]);
+}
+__device__ __forceinline__ unsigned wave_min(unsigned v)
+{
+    v = min(v, sdpp<0xB1>(v)); v = min(v, sdpp<0x4E>(v)); v = min(v, sdpp<0x141>(v)); v = min(v, sdpp<0x140>(v));
+    auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+    v = min(r16[0], r16[1]);
+    auto r32 = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+    return min(r32[0], r32[1]);
 }
 
 // LTS_Sequence_11a (channel_11a.hpp:13-18): 1 -> +norm_one, 0 -> -norm_one
@@ -160,7 +180,6 @@ __device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_
     const uint32_t sym_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym_start_), STR = (uint32_t)__builtin_amdgcn_readfirstlane((int)STR_);
     __shared__ uint32_t s_fft[64];
     __shared__ uint8_t  s_soft[48];
-    __shared__ uint64_t s_dec[25];                   // Viterbi_sig11 decision words (wave-uniform ballots)
     const int lane = threadIdx.x;
     auto sync = []() { __syncthreads(); };
                             // ---- the SIGNAL symbol: full header chain, lane-parallel
@@ -209,7 +228,8 @@ __device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_
                             const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
                             const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
                             unsigned m = (n == 0) ? 0u : 0x30u;
-                            if (lane == 0) s_dec[0] = 0;
+                            uint64_t dec[25];                                           // the 64 states' decisions per step: scalars (the loops are unrolled), not an LDS array
+                            dec[0] = 0;
     #pragma unroll
                             for (int t = 1; t <= 24; t++) {
                                 const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
@@ -218,28 +238,20 @@ __device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_
                                 const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
                                 const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
                                 m = min(c0, c1);
-                                { const uint64_t d = __ballot(m & 1); if (lane == 0) s_dec[t] = d; }
-                                if ((t & 7) == 0) {
-                                    unsigned mn = m;
-    #pragma unroll
-                                    for (int o = 32; o > 0; o >>= 1) mn = min(mn, (unsigned)__shfl_xor((int)mn, o));
-                                    m = (m - (mn & 0xFE)) & 0xFF;
-                                }
+                                dec[t] = __ballot(m & 1);
+                                if ((t & 7) == 0) m = (m - (wave_min(m) & 0xFE)) & 0xFF;
                             }
                             // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
-                            unsigned key = (m << 8) | ((unsigned)n << 2), kmin = key;
-    #pragma unroll
-                            for (int o = 32; o > 0; o >>= 1) kmin = min(kmin, (unsigned)__shfl_xor((int)kmin, o));
-                            kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)kmin);
+                            const unsigned key = (m << 8) | ((unsigned)n << 2);
+                            const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min(key));
                             int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
-                            sync();                                                     // s_dec complete
                             uint32_t sig = 0;
     #pragma unroll
                             for (int b = 0; b < 24; b++) {
                                 // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
                                 sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
                                 pos = (pos >> 1) & 0x3F;
-                                pos |= (int)((s_dec[23 - b] >> pos) & 1) << 6;
+                                pos |= (int)((dec[23 - b] >> pos) & 1) << 6;
                             }
                             sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;     // viterbi.hpp:39 (wave-uniform)
                             // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
@@ -408,21 +420,18 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));                // TDCRemoveEx
         const cpx pii = sra(pi, 2);
         const uint32_t ppk = pack(pii);
-        const uint32_t prev = (uint32_t)__shfl((int)ppk, (int)(hi | ((l - 16u) & 31u)));
+        const uint32_t prev = other_row_even(ppk);                              // the sample 16 lanes below (used by the second row of each half only)
         int re, im; conj_mul32(pii, unpack(l < 16u ? Hv : prev), re, im);       // against the sample 16 earlier
         unsigned vr = (unsigned)(re >> 4), vi = (unsigned)(im >> 4), ve = (unsigned)(sqnorm(pii) >> 4);
         unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);     // TDCEstimator terms
-        vr += (unsigned)__shfl_xor((int)vr, 1); vi += (unsigned)__shfl_xor((int)vi, 1); ve += (unsigned)__shfl_xor((int)ve, 1);
-        dr += (unsigned)__shfl_xor((int)dr, 1); di += (unsigned)__shfl_xor((int)di, 1);
-        vr += (unsigned)__shfl_xor((int)vr, 2); vi += (unsigned)__shfl_xor((int)vi, 2); ve += (unsigned)__shfl_xor((int)ve, 2);
-        dr += (unsigned)__shfl_xor((int)dr, 2); di += (unsigned)__shfl_xor((int)di, 2);
+        vr = quad_sum(vr); vi = quad_sum(vi); ve = quad_sum(ve);                // a burst's four samples sit in one quad
+        dr = quad_sum(dr); di = quad_sum(di);
         // ---- the K bursts' sliding sums at once.  After burst b the accumulator holds reg + sum_{i<=b} (d_i - z_i), z = the value that leaves the
         // 4-element window: the old elements for b < 4, d_{b-4} after that.  One prefix sum per stream over the burst groups, the reference's test
         // (cca.hpp:386-437) in every group, and the first burst whose test is true ends the pass.
         const bool second_row = (l & 16u) != 0u;
-        const uint32_t m16 = hi | ((l - 16u) & 31u);
         // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
-        const uint32_t pr = (uint32_t)__shfl((int)vr, (int)m16), pim = (uint32_t)__shfl((int)vi, (int)m16), pe = (uint32_t)__shfl((int)ve, (int)m16);
+        const uint32_t pr = other_row_even(vr), pim = other_row_even(vi), pe = other_row_even(ve);
         const uint32_t zr = second_row ? pr : ac_re.Z, zi = second_row ? pim : ac_im.Z, ze = second_row ? pe : energy.Z;
         const uint32_t Rr = (uint32_t)ac_re.reg + group_scan(vr - zr), Ri = (uint32_t)ac_im.reg + group_scan(vi - zi), Re = (uint32_t)energy.reg + group_scan(ve - ze);
         const int iAuto_v = abs((int)Rr) + abs((int)Ri), iEnergy_v = (int)Re;
@@ -479,8 +488,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         if (high_count % 4 == 0) {
             int re, im; conj_mul32(unpack(T.sts[peak_index * 16 + (int)l]), unpack(Hv), re, im);   // GetCrossCorrelation, one tap per lane
             unsigned ur = (unsigned)re, ui = (unsigned)im;
-#pragma unroll
-            for (int o = 1; o < 16; o <<= 1) { ur += (unsigned)__shfl_xor((int)ur, o); ui += (unsigned)__shfl_xor((int)ui, o); }
+            ur = row_sum(ur); ui = row_sum(ui);
             const int corr = abs(__builtin_amdgcn_readfirstlane((int)ur)) + abs(__builtin_amdgcn_readfirstlane((int)ui));
             if (corr < (peak_corr >> 1)) {
                 if (high_count > 8) { cca_detected = 1; frame_start = last_v / STR + 4; }
@@ -488,8 +496,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                     sync_high = 0; sense_count = 0;
                     // the burst that dropped the lock also feeds TDCEstimator (dc.hpp:92-166)
                     unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);
-                    dr += (unsigned)__shfl_xor((int)dr, 1); di += (unsigned)__shfl_xor((int)di, 1);
-                    dr += (unsigned)__shfl_xor((int)dr, 2); di += (unsigned)__shfl_xor((int)di, 2);
+                    dr = quad_sum(dr); di = quad_sum(di);
                     sum_dc_re = w16(sum_dc_re + w16(__builtin_amdgcn_readlane((int)dr, (int)(4 * (K - 1)))));
                     sum_dc_im = w16(sum_dc_im + w16(__builtin_amdgcn_readlane((int)di, (int)(4 * (K - 1)))));
                     if (dc_cnt == 0) {
@@ -702,6 +709,12 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
             }
         }
         PROBE_A(_tc, 7);
+        // Nothing pending and the next burst lies source calls ahead (an idle pass takes up to eight bursts, a source call holds three and a half): go straight to the call
+        // that delivers it -- the calls in between would find no burst to run and no event to report.  (x / APP for APP = 14 or 28 as a multiply: exact below 2^31.)
+        if (error_code == 0 && !streaming && vpos + BUR > avail_end + APP && vpos < 0x7FFFFF00u) {
+            const uint32_t calls = (uint32_t)(((uint64_t)(vpos + BUR + APP - 1u) * 0x92492493ull) >> (STR == 1u ? 35 : 36));   // ceil((vpos + BUR) / APP)
+            c = calls - 2u;                                                      // (the for-loop's increment lands on call `calls - 1`, whose avail_end = calls x APP)
+        }
     }
     // the capture ends in plain carrier sense: all of it is final
     if (streaming && vpos == nunits && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);
