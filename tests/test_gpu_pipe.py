@@ -114,3 +114,27 @@ def test_repeated_calls_graph_replay_and_calls_in_flight(sora, torch_cuda, oracl
     big.set_depth(1); big.set_front(4)
     assert big.front() == 3
     big.close()
+
+
+def test_edges_silent_tiny_truncated_overlong_and_the_row_limit(sora, torch_cuda, oracle):
+    """What test_gpu_parity's edge cases hold, explicitly through k_pipe: a capture of four frames of four rates, silence, a capture shorter than a symbol, a frame cut
+    by the capture's end, a frame of the longest length the header admits -- and a row limit below the number of frames found (the last row carries the flag)."""
+    from gpu_util import awgn
+    rng = np.random.default_rng(11)
+    parts = []
+    for i, rate in enumerate((54000, 6000, 36000, 48000)):
+        parts.append(oracle.tx_capture(rng.integers(0, 256, 200 + 100 * i).astype(np.uint8).tobytes(), rate, lead=0, tail=400 + 52 * i))
+    multi = pad_capture(awgn(np.concatenate(parts), 120, 3), 40)
+    silent = np.zeros((2800, 2), np.int16)
+    tiny = np.zeros((28, 2), np.int16)
+    trunc = pad_capture(oracle.tx_capture(bytes(1000), 12000)[:9000], 40)
+    overmtu = pad_capture(oracle.tx_capture(bytes(2497), 54000), 40)
+    for caps, mf in (([multi, silent], 8), ([tiny, trunc, overmtu], 4), ([multi], 16)):
+        ok, why = same_results(run_pipe(sora, torch_cuda, caps, 40, max_frames=mf), oracle_results(oracle, caps, 40))
+        assert ok, why
+    want = oracle_results(oracle, [multi], 40)
+    assert len(want) == 4
+    for mf in (1, 2, 3):
+        got = run_pipe(sora, torch_cuda, [multi], 40, max_frames=mf)
+        ok, why = same_results(got, want[:mf]); assert ok, (mf, why)
+        assert [r["flags"] for r in got] == [0] * (mf - 1) + [1], (mf, [r["flags"] for r in got])
