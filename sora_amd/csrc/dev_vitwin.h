@@ -31,16 +31,12 @@ struct UnitGeom {
 
 // position p of a code-rate list of n frames -> the unit it holds (if any)
 // (job_at(idx): the VitJob of place idx of the list -- out of jobs[] behind the symbol kernels, worked out from the frame table inside k_pipe)
-template <int CR, int WIN, int LOOK, typename JOBS>
-__device__ __forceinline__ UnitGeom unit_geom(JOBS job_at, uint32_t n, uint32_t p, uint32_t q, uint32_t vbase, uint8_t* __restrict__ out)
+// unit uu (kWinNone: none) of the frame at place idx of its list, the frame cut into units of m windows (nun of them)
+template <int CR, int WIN, int LOOK>
+__device__ __forceinline__ UnitGeom unit_of(const VitJob& J, uint32_t idx, uint32_t uu, uint32_t m, uint32_t nun, uint32_t q, uint32_t vbase, uint8_t* __restrict__ out)
 {
     constexpr uint32_t GB = CR == 0 ? 2 : CR == 2 ? 4 : 3, GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;
     UnitGeom g;
-    const bool inside = p < win_slots(n, q);
-    const uint32_t upos = inside ? p / n : 0u, idx = inside ? p - upos * n : 0u;
-    const VitJob J = job_at(idx);
-    const uint32_t nev = win_events(J.length, CR, WIN, LOOK), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
-    const uint32_t uu = !inside ? kWinNone : m != 1u ? (upos < nun ? upos : kWinNone) : n == 1u ? win_unit_lone(upos, nun) : (upos < nun ? win_unit_at(upos, nun) : kWinNone);
     const bool has = uu != kWinNone;
     const uint32_t u = has ? uu : 0u;
     const uint32_t k0 = u * m, k1 = (u + 1u) * m;
@@ -63,6 +59,25 @@ __device__ __forceinline__ UnitGeom unit_geom(JOBS job_at, uint32_t n, uint32_t 
     g.need = last ? J.nsoft : min(J.nsoft, (((uint32_t)WIN * k1 + (uint32_t)LOOK + 6u + GS) / GS + 1u) * GB);
     g.idx = idx;
     return g;
+}
+
+template <int CR, int WIN, int LOOK, typename JOBS>
+__device__ __forceinline__ UnitGeom unit_geom(JOBS job_at, uint32_t n, uint32_t p, uint32_t q, uint32_t vbase, uint8_t* __restrict__ out)
+{
+    const bool inside = p < win_slots(n, q);
+    const uint32_t upos = inside ? p / n : 0u, idx = inside ? p - upos * n : 0u;
+    const VitJob J = job_at(idx);
+    const uint32_t nev = win_events(J.length, CR, WIN, LOOK), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
+    const uint32_t uu = !inside ? kWinNone : m != 1u ? (upos < nun ? upos : kWinNone) : n == 1u ? win_unit_lone(upos, nun) : (upos < nun ? win_unit_at(upos, nun) : kWinNone);
+    return unit_of<CR, WIN, LOOK>(J, idx, uu, m, nun, q, vbase, out);
+}
+// ... and unit `u` itself of the frame at place idx (the 64-lane form inside k_pipe: a wave holds unit u of two frames, or of one)
+template <int CR, int WIN, int LOOK, typename JOBS>
+__device__ __forceinline__ UnitGeom unit_geom_direct(JOBS job_at, uint32_t idx, uint32_t u, bool exists, uint32_t q, uint32_t vbase, uint8_t* __restrict__ out)
+{
+    const VitJob J = job_at(idx);
+    const uint32_t nev = win_events(J.length, CR, WIN, LOOK), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
+    return unit_of<CR, WIN, LOOK>(J, idx, exists && u < nun ? u : kWinNone, m, nun, q, vbase, out);
 }
 
 // (ready(): called once, behind the wave's set-up and in front of its first soft value: false = give up)

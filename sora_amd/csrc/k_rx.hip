@@ -830,6 +830,30 @@ __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs
     PIPE_STAMP(P, 4 + h);
 }
 
+// A trellis wave in front of its first soft value: wait until the three counts of its frames cover everything its units will read (M: this lane's unit; polls: whether
+// this lane is the one that looks for it), then acquire.  false: the wait ran into its bound.
+__device__ __forceinline__ bool pipe_units_ready(const RxArgs& A, const PipeArgs& P, uint32_t list, const UnitGeom& M, bool polls_, uint32_t wave_index)
+{
+    const unsigned lane = threadIdx.x & 63;
+    const bool polls = polls_ && M.valid;
+    const uint32_t f = A.joblist[(size_t)list * A.nrows + M.idx];
+    const uint32_t ncbps = 48u * A.frames[f].nbpsc;
+    const uint32_t quads = polls ? ((M.need + ncbps - 1u) / ncbps + 3u) / 4u : 0u;   // quads of symbols that hold the unit's soft values
+    const uint32_t* c = P.flags + 4u + 4u * f;
+    const long long t0 = wall_clock64();
+    for (;;) {
+        bool ok = true;
+#pragma unroll
+        for (uint32_t h = 0; h < 3; h++) ok = ok && flag_load(c + h) >= (quads + 2u - h) / 3u;   // helper h has the quads = h (mod 3)
+        if (__all(ok)) break;
+        if (pipe_expired(t0)) { if (lane == 0) atomicOr(P.flags, 1u); return false; }
+        __builtin_amdgcn_s_sleep(2);
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    PIPE_STAMP(P, 16 + 2 * wave_index);
+    return true;
+}
+
 // ---- role 3: a wave of the window-parallel trellis
 __device__ __forceinline__ void pipe_trellis_wave(const RxArgs& A, const PipeArgs& P, uint32_t wave_index, Lds16<256, 24>& S)
 {
@@ -844,50 +868,14 @@ __device__ __forceinline__ void pipe_trellis_wave(const RxArgs& A, const PipeArg
         };
     };
     auto ready = [&](const UnitGeom& GA, const UnitGeom& GB_, uint32_t list) -> bool {
-        const unsigned lane = threadIdx.x & 63, l16 = lane & 15;
-        const UnitGeom& M = (lane & 1u) ? GB_ : GA;
-        const bool polls = l16 < 2u && M.valid;                                  // one lane per unit
-        const uint32_t f = A.joblist[(size_t)list * A.nrows + M.idx];
-        const uint32_t ncbps = 48u * A.frames[f].nbpsc;
-        const uint32_t quads = polls ? ((M.need + ncbps - 1u) / ncbps + 3u) / 4u : 0u;   // quads of symbols that hold the unit's soft values
-        const uint32_t* c = P.flags + 4u + 4u * f;
-        const long long t0 = wall_clock64();
-        for (;;) {
-            bool ok = true;
-#pragma unroll
-            for (uint32_t h = 0; h < 3; h++) ok = ok && flag_load(c + h) >= (quads + 2u - h) / 3u;   // helper h has the quads = h (mod 3)
-            if (__all(ok)) break;
-            if (pipe_expired(t0)) { if (lane == 0) atomicOr(P.flags, 1u); return false; }
-            __builtin_amdgcn_s_sleep(2);
-        }
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        PIPE_STAMP(P, 16 + 2 * wave_index);
-        return true;
+        const unsigned lane = threadIdx.x & 63;
+        return pipe_units_ready(A, P, list, (lane & 1u) ? GB_ : GA, (lane & 15u) < 2u, wave_index);      // one lane per unit polls
     };
     viterbi16w_wave<256, 24, 3>(S, wave_index, jobs_of, ready, A.njobs, P.target, P.vstride, (const uint8_t*)A.soft, A.vout, P.vecs);
     PIPE_STAMP(P, 17 + 2 * wave_index);
 }
 
-__global__ void __launch_bounds__(256) k_pipe(RxArgs A, PipeArgs P)
-{
-    __shared__ __attribute__((aligned(16))) char lds[kPipeLdsBytes];
-    uint32_t b = blockIdx.x;
-    if (b == 0) PIPE_STAMP(P, 0);
-    if (b < P.nfront) {
-        sym_front_block<true>(A, b, reinterpret_cast<uint32_t (*)[4][64]>(lds));
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every storing wave drains, then ONE flag
-        __syncthreads();
-#ifndef SORA_DBG_PIPE_LOSE_FLAGS                                                 // (tools/pipe_timeout_check.py: what happens when a hand-off never arrives)
-        if (threadIdx.x == 0) store4_through(P.flags + 4u + 4u * A.nrows + b, 1u);
-#endif
-        if (b == 0) PIPE_STAMP(P, 8);
-        return;
-    }
-    b -= P.nfront;
-    if (b < P.ntrack) { pipe_track_block(A, P, b, *reinterpret_cast<PipeTrackLds*>(lds)); return; }
-    b -= P.ntrack;
-    pipe_trellis_wave(A, P, b * 4u + (threadIdx.x >> 6), reinterpret_cast<Lds16<256, 24>*>(lds)[threadIdx.x >> 6]);
-}
+// (k_pipe's 64-lane trellis role and the kernel itself follow viterbi_forward_unit below)
 
 // (the trellis machinery -- metric representation, ACS step, trace-back -- lives in dev_viterbi.h)
 struct VitSide {            // wave-uniform per-frame bookkeeping
@@ -1059,6 +1047,237 @@ __device__ __forceinline__ void viterbi_forward(const VitJob& JA, const VitJob& 
         end_row();
     }
 }
+
+// The same wave decoding one UNIT of the window-parallel trellis per half instead of a whole frame (dev_vitwin.h; k_pipe's 64-lane form for a lone capture: a unit is
+// 33 ns per step here against 50 in the sixteen-lane layout, and the launch's last unit is what the capture waits for).  GA / GB_ are unit `u` of two frames of one
+// code-rate list (or GB_ invalid): the same unit index, hence the same distance ob between the unit's first step and its first window and ONE trace-back schedule for
+// the wave, as in the whole-frame form.  What a unit adds: all-equal metrics at its start (the frame's first unit starts like the frame), its stream read from its
+// first step on, its metric vector stored at its verify point and at the next unit's, and an end after its windows.  ready(): see forward16w.
+template <int CR, int WIN, int LOOK, int BITS, typename READY>
+__device__ __forceinline__ void viterbi_forward_unit(const UnitGeom& GA, const UnitGeom& GB_, const uint8_t* __restrict__ soft_base, uint16_t* ring, uint16_t* ops,
+        uint16_t* __restrict__ vecs, READY ready)
+{
+    const bool hasB = GB_.valid;
+    using RG = RingGeom<WIN, LOOK>;
+    constexpr int P = RG::P;
+    constexpr int GB = CR == 0 ? 2 : CR == 2 ? 4 : 3;                           // soft values per puncture group (CR: 0=1/2, 1=2/3, 2=3/4)
+    constexpr int GS = CR == 0 ? 1 : CR == 2 ? 3 : 2;                           // trellis steps per group
+    constexpr int CW = 12 / GS * GB;                                            // operands (dwords) per 12-step chunk: 24 / 18 / 16
+    const unsigned lane = threadIdx.x & 63;
+    VitSide A, B;
+    A.out = GA.out; A.nsteps = GA.nsteps; A.tr_end = GA.tr_end; A.done = false;
+    B.out = GB_.out; B.nsteps = hasB ? GB_.nsteps : 0u; B.tr_end = hasB ? GB_.tr_end : 0u; B.done = !hasB;
+    const uint32_t nsteps = max(A.nsteps, B.nsteps);
+    // this lane's part in fetching a chunk: value (lane & 31) of frame lane >> 5
+    const bool mineB = lane >= 32u && hasB;
+    const uint32_t my_soft_off = mineB ? GB_.soft_off : GA.soft_off;
+    const uint32_t my_last = mineB ? GB_.last : GA.last, my_k = lane & 31u;
+    const uint32_t my_first = my_k + (mineB ? GB_.i0 : GA.i0);                 // (the unit's first value: a whole number of puncture groups into the stream)
+
+    auto which_of = [](int ph) { return CR == 0 ? 0 : CR == 1 ? (ph & 1) : ph % 3; };   // step kinds of a puncture group (viterbi.hpp:167-187)
+    VitLane V;
+    const unsigned vl = lane_map(lane);                                         // label lane: holds state rol6^t(vl) after t steps
+    V.U = vl == 0 ? 0u : ((GA.first ? 0x18u << 9 : 0u) | ((hasB && GB_.first) ? 0x18u << 25 : 0u));   // a frame's first unit: ALL_INIT0 / ALL_INIT (viterbilut.h:22-30); any other: all equal
+    V.ring = ring; V.rowpos = 0;
+    V.sidx[0] = __brev(rol6(vl, 2)) >> 26; V.sidx[1] = __brev(rol6(vl, 4)) >> 26; V.sidx[2] = __brev(vl) >> 26;   // rev6 of the state: (8j + 8) mod 6 = 2, 4, 0
+#pragma unroll
+    for (int t = 0; t < 24; t++) {
+        const int ph = t % 6, k = t % 8;
+        const unsigned n = rol6(vl, ph + 1);                                    // state held after a phase-ph step
+        const bool own1 = ph >= 2 && ((vl >> (5 - ph)) & 1);                    // DPP phases: the lane's own metric is the decision-1 candidate
+        const unsigned ma = (__popc(n & 0155) & 1) ? 7u * kFld : 0u, mb = (__popc(n & 0117) & 1) ? 7u * kFld : 0u;
+        const unsigned mx = which_of(ph) == 2 ? mb : ma;
+        V.MX[t] = own1 ? ((mx ^ (7u * kFld)) | (kOne << k)) : mx;
+        if (t < 6) V.MY[t] = own1 ? (mb ^ (7u * kFld)) : mb;
+    }
+
+    uint32_t tr = 0, ob = GA.ob;                                                // steps taken / where the next window's bits begin, both in the units' own step count (the same for both)
+    uint32_t wA = GA.wleft, wB = GB_.wleft;
+    uint32_t vstepA = GA.vstep, vstepB = hasB ? GB_.vstep : kNever, estepA = GA.estep, estepB = hasB ? GB_.estep : kNever;
+    // a vector: the lane's 16-bit field of the unit's half -- taken at a multiple of 24 of the unit's own steps: straight after a normalisation, marks and guard clear,
+    // the state <-> lane map the identity (the same at both ends of a comparison)
+    auto save = [&](uint32_t vec, int which, bool hi) { vecs[((size_t)vec * 2u + (uint32_t)which) * 64u + lane] = (uint16_t)(hi ? V.U >> 16 : V.U); };
+
+    // Normalize (viterbicore.h:444-465), both frames; marks and guard are clear here and no half borrows (its minimum is subtracted): one 32-bit VOP2
+    auto normalize = [&]() { V.U = V.U - dpp_pkmin_wave(V.U); };
+#ifdef SORA_DBG_NO_TRACE                                                        // experiment (tools/ab_decode.sh): the forward pass alone -- results are wrong, only the duration means something
+    auto trace = [&](unsigned, unsigned, uint32_t, uint32_t, uint32_t) {};
+#else
+    auto trace = [&](unsigned mA, unsigned mB, uint32_t cntA, uint32_t cntB, uint32_t top) { viterbi_trace<RG::kMaxWalk>(V.U, ring, tr, ob, mA, mB, cntA, cntB,
+            A.out, B.out, top); };
+#endif
+    auto next_event = [&]() -> uint32_t {
+        uint32_t t = ob + (uint32_t)(WIN + LOOK + 6);
+        if (!A.done) t = min(t, A.tr_end);
+        if (!B.done) t = min(t, B.tr_end);
+        return min(min(t, min(vstepA, vstepB)), min(estepA, estepB));
+    };
+    uint32_t next_thr = next_event();
+    auto check = [&](int t24_last) {                                            // trace-back schedule (viterbi.hpp:196-214), per frame
+        if (tr >= next_thr) {
+            if (tr == vstepA) { save(GA.vec, 0, false); vstepA = kNever; }
+            if (tr == vstepB) { save(GB_.vec, 0, true); vstepB = kNever; }
+            if (tr == estepA) { save(GA.vec, 1, false); estepA = kNever; }
+            if (tr == estepB) { save(GB_.vec, 1, true); estepB = kNever; }
+            const int k = t24_last % 8;                                         // the last decision: mark k of the field, or bit 7 of the block just banked
+            const uint32_t pos = V.rowpos + (uint32_t)(t24_last / 8) * 64u;     // ring position (x 64) of block (tr - 1) >> 3
+            unsigned lastA, lastB;
+            if (k == 7) { const unsigned w = ring[pos + V.sidx[t24_last / 8]]; lastA = (w >> 7) & 1u; lastB = (w >> 15) & 1u; }
+            else { lastA = (V.U >> k) & 1u; lastB = (V.U >> (17 + k)) & 1u; }
+            const unsigned mA = ((V.U & 0xFFFFu) >> 9 << 1) | lastA, mB = (V.U >> 25 << 1) | lastB;
+            const bool partial = tr >= ob + (uint32_t)(WIN + LOOK + 6);
+            uint32_t cntA = 0, cntB = 0;
+            if (!A.done) {
+                if (tr >= A.tr_end) { cntA = A.tr_end - ob - 6; A.done = true; }
+                else if (partial) cntA = WIN;
+            }
+            if (!B.done) {
+                if (tr >= B.tr_end) { cntB = B.tr_end - ob - 6; B.done = true; }
+                else if (partial) cntB = WIN;
+            }
+            if (cntA | cntB) trace(mA, mB, cntA, cntB, (pos >> 6) + (uint32_t)P);
+            if (partial) {                                                      // a unit ends behind its last window (the frame's last unit: at the frame's end)
+                ob += WIN;
+                if (!A.done && --wA == 0) A.done = true;
+                if (!B.done && --wB == 0) B.done = true;
+            }
+            next_thr = next_event();
+        }
+    };
+    struct Chunk { uint32_t v[(CW + 3) / 4 * 4]; };
+    SoftCursor<BITS, CW> cur;
+    cur.init(my_soft_off, my_first, my_last);
+    auto fetch = [&](uint32_t c) -> SoftRaw { return cur.fetch(soft_base, c); };
+    // operand k, frame's half (k up to 31: the table has 32 operands, those past CW are never read)
+    uint16_t* my_op = ops + 2u * my_k + (lane >> 5);
+    auto lds_order = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
+    auto unpack = [&](const SoftRaw& R) -> Chunk {
+        *my_op = (uint16_t)cur.field(R);
+        lds_order();
+        Chunk K;
+#pragma unroll
+        for (int i = 0; i < (CW + 3) / 4; i++) {
+            const uint4 x = reinterpret_cast<const uint4*>(ops)[i];
+            K.v[4 * i] = x.x; K.v[4 * i + 1] = x.y; K.v[4 * i + 2] = x.z; K.v[4 * i + 3] = x.w;
+        }
+        lds_order();
+        return K;
+    };
+    auto op = [](const Chunk& K, int i) -> uint32_t { return K.v[i]; };
+    // one puncture group = GS steps; i0 = step index inside the 12-step chunk, h = which half of the 24-step row
+    auto group = [&](const Chunk& K, int h, int i0) {
+        const int k0 = i0 / GS * GB, t24 = 12 * h + i0;
+        acs_step<0, P>(V, t24, op(K, k0), op(K, k0 + 1));                       // ACS(A,B)
+        if (CR != 0) acs_step<1, P>(V, t24 + 1, op(K, k0 + 2), 0);              // ACS(A)     2/3, 3/4 (viterbi.hpp:173-187)
+        if (CR == 2) acs_step<2, P>(V, t24 + 2, 0, op(K, k0 + 3));              // ACS(B)     3/4
+        if ((t24 + GS) % 8 == 0) normalize();                                   // (trellis index & 7) == 0 after a group
+    };
+    auto end_row = [&]() { V.rowpos = V.rowpos + 3 * 64 == (unsigned)P * 64 ? 0u : V.rowpos + 3 * 64; };   // P is a multiple of 3: the wrap falls between rows
+    auto fast_chunk = [&](const Chunk& K, int h) {                              // 12 steps, no trace-back due inside: straight-line code
+#pragma unroll
+        for (int g = 0; g < 12 / GS; g++) group(K, h, g * GS);
+        tr += 12;
+    };
+    auto slow_chunk = [&](const Chunk& K, int h) {                              // up to 12 steps with the schedule examined after every group
+#pragma unroll
+        for (int g = 0; g < 12 / GS; g++) {
+            if (tr < nsteps && !(A.done && B.done)) {
+                group(K, h, g * GS);
+                tr += GS;
+                check(12 * h + g * GS + GS - 1);
+            }
+        }
+    };
+    auto chunk = [&](const Chunk& K, int h) {                                   // tr % 24 == 12 h on entry
+        if (tr + 12 <= nsteps && next_thr > tr + 12) fast_chunk(K, h); else slow_chunk(K, h);
+    };
+
+    // Vector loads return in order: chunk c + 2 is requested before chunk c is stepped through (the compiler's vmcnt waits follow from that).
+    uint32_t c = 0;
+    if (!ready()) return;
+    SoftRaw r0 = fetch(0), r1 = fetch(1);
+    while (tr < nsteps && !(A.done && B.done)) {
+        // rows (2 chunks) that certainly need no look at the schedule: run them back to back, 9 rows out of 10
+        const uint32_t lim = min(nsteps, next_thr - 1);
+        for (uint32_t rows = lim > tr ? (lim - tr) / 24 : 0; rows > 0; rows--) {
+            const Chunk K0 = unpack(r0); r0 = fetch(c + 2);
+            fast_chunk(K0, 0);
+            const Chunk K1 = unpack(r1); r1 = fetch(c + 3);
+            fast_chunk(K1, 1);
+            c += 2;
+            end_row();
+        }
+        if (!(tr < nsteps)) break;
+        const Chunk K0 = unpack(r0); r0 = fetch(c + 2);
+        chunk(K0, 0);
+        if (!(tr < nsteps && !(A.done && B.done))) break;
+        const Chunk K1 = unpack(r1); r1 = fetch(c + 3);
+        chunk(K1, 1);
+        c += 2;
+        end_row();
+    }
+}
+
+// ---- role 3, 64-lane form (P.lanes64: the handle's calls in flight are so few that two units per wave still fit the chip): wave w of a code-rate list of n frames holds
+// unit w / ceil(n / 2) of frames 2 j and 2 j + 1, j = w mod ceil(n / 2)
+struct PipeUnitLds { uint16_t ring[RingGeom<256, 24>::kEntries]; uint16_t ops[64]; };
+static_assert(4 * sizeof(PipeUnitLds) <= kPipeLdsBytes, "k_pipe: four 64-lane trellis waves' LDS");
+__device__ __forceinline__ void pipe_trellis_wave64(const RxArgs& A, const PipeArgs& P, uint32_t wave_index, PipeUnitLds& L)
+{
+    auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
+    const uint32_t n[3] = { A.njobs[0], A.njobs[1], A.njobs[2] };
+    const uint32_t q = uni(win_units_per_frame(n[0] + n[1] + n[2], P.target));
+    uint32_t w = uni(wave_index), list = 0;
+    while (list < 3 && w >= q * ((n[list] + 1u) / 2u)) { w -= q * ((n[list] + 1u) / 2u); list++; }
+    if (list >= 3) return;
+    const uint32_t nl = uni(n[list]), pairs = (nl + 1u) / 2u, u = w / pairs, ia = 2u * (w - u * pairs), ib = ia + 1u;
+    const uint32_t* jl = A.joblist + (size_t)list * A.nrows; const FrameRow* fr = A.frames;
+    auto job_at = [jl, fr](uint32_t idx) {
+        const FrameRow& r = fr[jl[idx]];
+        VitJob J;
+        J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = (uint32_t)r.nsym * 48u * r.nbpsc; J.length = r.length;
+        J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
+        return J;
+    };
+    const uint32_t code_rate = uni(job_at(0).code_rate), vbase = list * P.vstride;
+    auto run = [&](auto cr) {
+        constexpr int CR = decltype(cr)::value;
+        UnitGeom GA = unit_geom_direct<CR, 256, 24>(job_at, ia, u, true, q, vbase, A.vout);
+        UnitGeom GB_ = unit_geom_direct<CR, 256, 24>(job_at, ib < nl ? ib : ia, u, ib < nl, q, vbase, A.vout);
+        if (GB_.valid && (!GA.valid || GB_.ob != GA.ob)) { if (!GA.valid) { GA = GB_; } const bool no = false; GB_.valid = no; }   // (the second frame is shorter / the first is: one unit in the wave; unequal cuts do not occur for so few frames)
+        if (!GA.valid) return;
+        const unsigned lane = threadIdx.x & 63;
+        viterbi_forward_unit<CR, 256, 24, 3>(GA, GB_, (const uint8_t*)A.soft, L.ring, L.ops, P.vecs,
+                                             [&]() { return pipe_units_ready(A, P, list, lane >= 32u ? GB_ : GA, (lane & 31u) == 0u, wave_index); });
+    };
+    if (code_rate == 0) run(std::integral_constant<int, 0>{});
+    else if (code_rate == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 2>{});
+    PIPE_STAMP(P, 17 + 2 * wave_index);
+}
+
+__global__ void __launch_bounds__(256) k_pipe(RxArgs A, PipeArgs P)
+{
+    __shared__ __attribute__((aligned(16))) char lds[kPipeLdsBytes];
+    uint32_t b = blockIdx.x;
+    if (b == 0) PIPE_STAMP(P, 0);
+    if (b < P.nfront) {
+        sym_front_block<true>(A, b, reinterpret_cast<uint32_t (*)[4][64]>(lds));
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                        // every storing wave drains, then ONE flag
+        __syncthreads();
+#ifndef SORA_DBG_PIPE_LOSE_FLAGS                                                 // (tools/pipe_timeout_check.py: what happens when a hand-off never arrives)
+        if (threadIdx.x == 0) store4_through(P.flags + 4u + 4u * A.nrows + b, 1u);
+#endif
+        if (b == 0) PIPE_STAMP(P, 8);
+        return;
+    }
+    b -= P.nfront;
+    if (b < P.ntrack) { pipe_track_block(A, P, b, *reinterpret_cast<PipeTrackLds*>(lds)); return; }
+    b -= P.ntrack;
+    if (P.lanes64) pipe_trellis_wave64(A, P, b * 4u + (threadIdx.x >> 6), reinterpret_cast<PipeUnitLds*>(lds)[threadIdx.x >> 6]);
+    else pipe_trellis_wave(A, P, b * 4u + (threadIdx.x >> 6), reinterpret_cast<Lds16<256, 24>*>(lds)[threadIdx.x >> 6]);
+}
+
 
 // Four waves per 256-thread workgroup, two frames per wave (no cross-wave traffic).  One-wave workgroups were kept to
 // 8 per CU by the dispatcher: 2 waves per SIMD and a second round for a 4096-frame batch.

@@ -75,6 +75,7 @@ struct PipeArgs {
     uint32_t  target, vstride;     // the window-parallel trellis's unit target and its vectors' stride per code-rate list
     uint16_t* vecs;
     uint32_t  stamp_base;          // (tools variant, SORA_DBG_PIPE_TIMELINE: where the launch's time stamps go, in words from flags)
+    uint32_t  lanes64;             // 1: the trellis role decodes its units two per wave in the 64-lane layout (a lone capture: a third faster per unit), 0: eight per wave
 };
 
 __global__ void k_scan(ScanArgs A);

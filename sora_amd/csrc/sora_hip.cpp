@@ -420,6 +420,7 @@ struct RxPipe {
     // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
     int  front = 1;
     uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed for every call
+    bool pipe64 = false;                                        // ... its trellis role in the 64-lane form (two units per wave: the handle's calls in flight are few enough for that many workgroups)
     // A call needs its job counters zero, k_pipe's words zero and (three-kernel chain) no symbol slot owned: the call BEFORE it on this pipeline arranges that inside its k_scan
     // (the pipeline's calls alternate between two sets of counters, words 0-3 and 8-11 of the 64-byte block in front of the frame table) -- no fill kernel in front of a call
     // unless counters_ready says that nothing has: the first call, a call recorded into a hipGraph (its arguments are frozen: it always uses set 0 behind its own fill)
@@ -801,7 +802,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                     PipeArgs P{};
                     P.nfront = (slots + 63) / 64; P.ntrack = nrows; P.flags = rx->d_pflags; P.target = kWinUnitsTarget; P.vstride = rx->wstride;
                         P.vecs = rx->d_wvecs; P.stamp_base = rx->pflag_words;
-                    hipLaunchKernelGGL(k_pipe, dim3(P.nfront + P.ntrack + ((units_max + 7) / 8 + 3 + kWinLoneWaves + 3) / 4), dim3(256), 0, st, R, P);
+                    P.lanes64 = rx->pipe64 ? 1u : 0u;
+                    // trellis waves: eight units each (+ a partly filled one per code-rate list + the lone layout's gaps), or -- 64-lane form -- unit u of two frames each
+                    const uint32_t waves = rx->pipe64 ? kWinMaxUnits * ((nrows + 3) / 2) : (units_max + 7) / 8 + 3 + kWinLoneWaves;
+                    hipLaunchKernelGGL(k_pipe, dim3(P.nfront + P.ntrack + (waves + 3) / 4), dim3(256), 0, st, R, P);
                 }
                 mark();
                 if (RX_ONLY(rx, 4u) && !redo_finish)
@@ -1147,13 +1151,15 @@ constexpr long long kAutoSplitRows = 512;
 constexpr long long kAutoPipeRows = 16;
 // k_pipe's workgroups wait for one another inside the launch: it is only used where ALL workgroups of ALL the handle's calls in flight are resident at once -- one per CU
 // (160 KB of LDS each), and a good part of the chip left to whatever else runs
-static bool pipe_fits(const sora_rx* rx)
+static bool pipe_fits(const sora_rx* rx, bool lanes64 = false)
 {
     const uint64_t str = rx->cfg.sample_rate_mhz == 20 ? 1 : 2, rows = (uint64_t)rx->cfg.max_captures * rx->cfg.max_frames_per_capture;
     const uint64_t slots = rx->cfg.max_total_samples / str / 80 + rx->cfg.max_captures + 16;
     const uint64_t units = std::min<uint64_t>(std::max<uint64_t>(kWinUnitsTarget, rows), 80ull * rows);
-    const uint64_t groups = (slots + 63) / 64 + rows + ((units + 7) / 8 + 3 + kWinLoneWaves + 3) / 4;
-    return groups * (uint64_t)rx->depth <= 192;
+    const uint64_t waves = lanes64 ? (uint64_t)kWinMaxUnits * ((rows + 3) / 2) : (units + 7) / 8 + 3 + kWinLoneWaves;
+    const uint64_t groups = (slots + 63) / 64 + rows + (waves + 3) / 4;
+    // (64-lane form: every frame must come out cut into single windows, i.e. get its full 80 units: 16384 / 80 frames at most)
+    return groups * (uint64_t)rx->depth <= 192 && (!lanes64 || rows * (uint64_t)rx->depth <= 204);
 }
 static int front_for(const sora_rx* rx)                                        // -> RxPipe::front
 {
@@ -1295,6 +1301,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
+    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1309,6 +1316,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
+    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;
@@ -1323,6 +1331,7 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
+    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
     return rc;

@@ -46,12 +46,14 @@ def run_pipe(sora, torch, caps, mhz, max_frames=4, depth=1):
     return res
 
 
-def test_random_captures_equal_the_oracle(sora, torch_cuda, oracle):
-    rng = np.random.default_rng(20260928)
-    for mhz, n, reps in ((20, 1, 12), (40, 1, 12), (20, 3, 6), (40, 2, 6)):
+@pytest.mark.parametrize("depth", [1, 4])
+def test_random_captures_equal_the_oracle(sora, torch_cuda, oracle, depth):
+    """(depth 1: so few workgroups that the trellis role runs in its 64-lane form, two units per wave; depth 4: the sixteen-lane form, eight per wave)"""
+    rng = np.random.default_rng(20260928 + depth)
+    for mhz, n, reps in ((20, 1, 12), (40, 1, 12), (20, 3 if depth == 1 else 1, 6), (40, 2 if depth == 1 else 1, 6)):
         for _ in range(reps):
             caps = [random_capture(oracle, rng, mhz, multipath_p=0.2) for _ in range(n)]
-            ok, why = same_results(run_pipe(sora, torch_cuda, caps, mhz), oracle_results(oracle, caps, mhz))
+            ok, why = same_results(run_pipe(sora, torch_cuda, caps, mhz, depth=depth), oracle_results(oracle, caps, mhz))
             assert ok, (mhz, n, why)
 
 
@@ -62,7 +64,7 @@ def test_every_rate_one_symbol_to_835(sora, torch_cuda, oracle):
             if (i + j) % 2:
                 continue
             cap = make_capture(oracle, rate, ln, seed=9000 + 16 * i + j, rate_mhz=20, sigma=(30, 200, 700, 1500)[(i + j) % 4], tail=160, cfo_hz=(-70e3, 0, 35e3)[j % 3])[0]
-            ok, why = same_results(run_pipe(sora, torch_cuda, [cap], 20, max_frames=2), oracle_results(oracle, [cap], 20))
+            ok, why = same_results(run_pipe(sora, torch_cuda, [cap], 20, max_frames=2, depth=1 + 3 * (k % 2)), oracle_results(oracle, [cap], 20))
             assert ok, (rate, ln, why)
             k += 1
     assert k >= 30

@@ -41,7 +41,7 @@ for rep in range(4):
     if rep == 3:
         for i in (8, 1, 2, 3, 4, 5, 6):
             print("%-40s %8.2f us" % (names[i], us(i)))
-        for w in range(32):
+        for w in range(96):
             if st[16 + 2 * w]:                                           # (a wave without units leaves no start stamp)
                 print("trellis wave %2d: starts %8.2f us, ends %8.2f us" % (w, us(16 + 2 * w), us(17 + 2 * w)))
     st[:] = 0
