@@ -223,7 +223,8 @@ int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
  *                    are bounded waits: should one ever expire, the call's frames are reported with error_code SORA_E_INTERNAL_TIMEOUT instead of a result;
  *                    it is the form for an otherwise idle chip -- each of its workgroups takes a whole CU's LDS, so beside a chip kept full by other handles its launch waits for CUs
  *                    to drain and form 3 is the faster one (measured: 3.3 against 1.3 ms median beside eight 4096-capture calls in flight; tools/pipe_under_load.py);
- *   0   (default)    chosen by the library: 4 while depth x max_captures x max_frames_per_capture <= 16 (and it fits), 3 up to 512, else 1.
+ *   0   (default)    chosen by the library: 4 while depth x max_captures x max_frames_per_capture <= 16 (and it fits, and no batch-sized handle of this process has used
+ *                    the device within the last 20 ms), 3 up to 512, else 1.
  * Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_front(sora_rx_t* rx, int kernels);
 int  sora_rx_front(sora_rx_t* rx);              /* 1, 3 or 4: what the next process call will use */

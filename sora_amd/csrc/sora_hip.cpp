@@ -9,6 +9,8 @@
 #include <cstdlib>
 #include <cstring>
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1059,7 +1061,29 @@ struct sora_rx {
     uint32_t* d_cont = nullptr; uint32_t* d_consumed = nullptr;
     // tool hook (sora_internal_rx_timeline)
     std::vector<float> tl; hipEvent_t tl_base = nullptr;
+    std::atomic<long long> last_call_ns{0};   // when this handle last took a process call (steady clock): what OTHER handles' automatic kernel choice looks at (chip_is_shared)
 };
+
+// The handles of this process, for ONE question: is the chip being kept full by somebody else?  k_pipe is the chain for an otherwise idle chip (each of its workgroups
+// takes a whole CU's LDS: beside a full chip its launch waits for CUs to drain, tools/pipe_under_load.py), so a handle's automatic choice leaves it alone while another
+// handle of the process on the same device -- one sized for a batch -- has taken a call within the last few milliseconds.  (Other processes are not seen.)
+static std::mutex g_rx_mu;
+static std::vector<sora_rx*> g_rx_all;
+constexpr long long kSharedWindowNs = 20000000;                 // 20 ms
+constexpr long long kBatchRows = 1024;                          // frame rows in flight from which a handle counts as one that fills the chip
+static long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
+static bool chip_is_shared(const sora_rx* me)
+{
+    const long long now = steady_ns();
+    std::lock_guard<std::mutex> lk(g_rx_mu);
+    for (const sora_rx* h : g_rx_all) {
+        if (h == me || h->cfg.device != me->cfg.device) continue;
+        const long long rows = (long long)h->depth * (long long)h->cfg.max_captures * (long long)h->cfg.max_frames_per_capture;
+        const long long t = h->last_call_ns.load(std::memory_order_relaxed);
+        if (rows >= kBatchRows && t != 0 && now - t < kSharedWindowNs) return true;
+    }
+    return false;
+}
 
 static RxPipe* pipe_of(sora_rx* rx, int ticket)
 {
@@ -1106,6 +1130,7 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     if (rc != SORA_OK) return rc;
     sora_rx* rx = new sora_rx();
     rx->cfg = *cfg; rx->pipes[0] = p0; rx->fused = p0->fused;
+    { std::lock_guard<std::mutex> lk(g_rx_mu); g_rx_all.push_back(rx); }
     *out = rx;
     return SORA_OK;
 }
@@ -1113,6 +1138,7 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
 void sora_rx_destroy(sora_rx_t* rx)
 {
     if (!rx) return;
+    { std::lock_guard<std::mutex> lk(g_rx_mu); g_rx_all.erase(std::remove(g_rx_all.begin(), g_rx_all.end(), rx), g_rx_all.end()); }
     for (RxPipe* p : rx->pipes) if (p) pipe_destroy(p);
     if (rx->d_cont) (void)hipFree(rx->d_cont);
     if (rx->d_consumed) (void)hipFree(rx->d_consumed);
@@ -1167,7 +1193,7 @@ static int front_for(const sora_rx* rx)                                        /
     const bool can_pipe = lanes16_for(rx) == 2 && pipe_fits(rx);
     if (rx->front == 4) return can_pipe ? 4 : 3;
     const long long rows = (long long)rx->depth * (long long)rx->cfg.max_captures * (long long)rx->cfg.max_frames_per_capture;
-    return rows <= kAutoPipeRows && can_pipe ? 4 : rows <= kAutoSplitRows ? 3 : 1;
+    return rows <= kAutoPipeRows && can_pipe && !chip_is_shared(rx) ? 4 : rows <= kAutoSplitRows ? 3 : 1;
 }
 int sora_rx_set_front(sora_rx_t* rx, int kernels)
 {
@@ -1300,10 +1326,10 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
+    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
     { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
-    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; rx->last_call_ns.store(steady_ns(), std::memory_order_relaxed); }
     return rc;
 }
 
@@ -1315,10 +1341,10 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
+    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
     { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
-    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; rx->last_call_ns.store(steady_ns(), std::memory_order_relaxed); }
     return rc;
 }
 
@@ -1330,10 +1356,10 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    if (p->front != front_for(rx)) { p->front = front_for(rx); p->last_valid = false; }
+    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
     { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
-    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; }
+    if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; rx->last_call_ns.store(steady_ns(), std::memory_order_relaxed); }
     return rc;
 }
 

@@ -140,3 +140,27 @@ def test_edges_silent_tiny_truncated_overlong_and_the_row_limit(sora, torch_cuda
         got = run_pipe(sora, torch_cuda, [multi], 40, max_frames=mf)
         ok, why = same_results(got, want[:mf]); assert ok, (mf, why)
         assert [r["flags"] for r in got] == [0] * (mf - 1) + [1], (mf, [r["flags"] for r in got])
+
+
+def test_the_automatic_choice_leaves_k_pipe_alone_while_a_batch_handle_keeps_the_chip_full(sora, torch_cuda, oracle, golden_dir):
+    """k_pipe's workgroups take a whole CU's LDS each: beside a full chip the three-kernel chain is the faster one (tools/pipe_under_load.py), so a handle's automatic
+    choice looks at the process's other handles on the device -- a batch-sized one that has just taken a call switches it to 3, and back a few milliseconds later."""
+    import time
+    iq = np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8
+    cap = pad_capture(iq, 40)
+    small = sora.Rx(max_captures=1, max_total_samples=len(cap), sample_rate_mhz=40, max_frames_per_capture=2)
+    assert small.front() == 4
+    caps = [make_capture(oracle, 54000, 300, seed=i, rate_mhz=20, sigma=50, tail=160)[0] for i in range(4)]
+    big_iq, descs = batch(caps * 64)
+    big = sora.Rx(max_captures=256, max_total_samples=len(big_iq), sample_rate_mhz=20, max_frames_per_capture=2)     # 8 x 256 x 2 rows in flight: a batch handle
+    d_big = torch_cuda.from_numpy(big_iq).cuda()
+    assert small.front() == 4                                                      # (a handle that has not taken a call does not count)
+    big.wait(big.process_dev(d_big, descs))
+    assert small.front() == 3
+    res = small.results(ticket=small.process_dev(torch_cuda.from_numpy(cap).cuda(), [(0, len(cap), 0)]))     # ... and decodes through the three kernels
+    assert len(res) == 1 and res[0]["error_code"] == 1
+    small.set_front(4); assert small.front() == 4                                  # an explicit request is an explicit request
+    small.set_front(0)
+    time.sleep(0.05)
+    assert small.front() == 4
+    big.close(); small.close()
