@@ -219,7 +219,7 @@ int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
  *   4   k_pipe       form 3 AND the window-parallel trellis as ONE launch whose workgroups hand symbols on as the tracker passes them (the reference's demod || Viterbi
  *                    overlap, fb11a_demod.cpp:109-112, inside a frame): the one for a handful of frames (a single capture).  (Its trellis units run two per wave in k_viterbi's
  *                    64-lane layout while the handle's calls in flight are few enough for that many workgroups -- a lone capture with up to three calls in flight --, eight per wave otherwise.)  Used only with the window-parallel trellis and
- *                    where every workgroup of the handle's calls in flight is resident at once (at most 192 of them); otherwise a request for 4 runs as 3.  Its hand-offs
+ *                    where every workgroup of the handle's calls in flight is resident at once (at most three quarters of the device's compute units: 192 on an MI355X); otherwise a request for 4 runs as 3.  Its hand-offs
  *                    are bounded waits: should one ever expire, the call's frames are reported with error_code SORA_E_INTERNAL_TIMEOUT instead of a result;
  *                    it is the form for an otherwise idle chip -- each of its workgroups takes a whole CU's LDS, so beside a chip kept full by other handles its launch waits for CUs
  *                    to drain and form 3 is the faster one (measured: 3.3 against 1.3 ms median beside eight 4096-capture calls in flight; tools/pipe_under_load.py);

@@ -1177,6 +1177,14 @@ constexpr long long kAutoSplitRows = 512;
 constexpr long long kAutoPipeRows = 16;
 // k_pipe's workgroups wait for one another inside the launch: it is only used where ALL workgroups of ALL the handle's calls in flight are resident at once -- one per CU
 // (160 KB of LDS each), and a good part of the chip left to whatever else runs
+static uint64_t device_cus(int device)                                         // compute units of the device (the partition this process sees), looked up once
+{
+    static std::mutex mu; static std::vector<int> cus;
+    std::lock_guard<std::mutex> lk(mu);
+    if ((size_t)device >= cus.size()) cus.resize((size_t)device + 1, 0);
+    if (cus[device] == 0) { hipDeviceProp_t pr; cus[device] = hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
+    return (uint64_t)cus[device];
+}
 static bool pipe_fits(const sora_rx* rx, bool lanes64 = false)
 {
     const uint64_t str = rx->cfg.sample_rate_mhz == 20 ? 1 : 2, rows = (uint64_t)rx->cfg.max_captures * rx->cfg.max_frames_per_capture;
@@ -1185,7 +1193,7 @@ static bool pipe_fits(const sora_rx* rx, bool lanes64 = false)
     const uint64_t waves = lanes64 ? (uint64_t)kWinMaxUnits * ((rows + 3) / 2) : (units + 7) / 8 + 3 + kWinLoneWaves;
     const uint64_t groups = (slots + 63) / 64 + rows + (waves + 3) / 4;
     // (64-lane form: every frame must come out cut into single windows, i.e. get its full 80 units: 16384 / 80 frames at most)
-    return groups * (uint64_t)rx->depth <= 192 && (!lanes64 || rows * (uint64_t)rx->depth <= 204);
+    return groups * (uint64_t)rx->depth <= device_cus(rx->cfg.device) * 3 / 4 && (!lanes64 || rows * (uint64_t)rx->depth <= 204);   // (three quarters of the CUs: 192 of an MI355X's 256)
 }
 static int front_for(const sora_rx* rx)                                        // -> RxPipe::front
 {
