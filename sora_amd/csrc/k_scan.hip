@@ -1,14 +1,21 @@
 // k_scan.hip -- per-capture front end: carrier sense + frame synchronisation + LTS + SIGNAL decode.
 //
-// One wave64 per capture walks the sample stream exactly the way the reference's source thread does
-// (kernel/bb/demod11/fb11a_demod.cpp:29-81 driving CreateDemodGraph11a_40M, fb11ademod_config.hpp:168-233):
-// 28 raw samples per TMemSamples::Process() call, 4-sample bursts through
+// One wave64 per capture reproduces what the reference's source thread reports (kernel/bb/demod11/fb11a_demod.cpp:29-81 driving
+// CreateDemodGraph11a_40M, fb11ademod_config.hpp:168-233): 28 raw samples per TMemSamples::Process() call, 4-sample bursts through
 //   TDownSample2 -> TBB11bRxSwitch -> [TDCRemoveEx -> TCCA11a -> TDCEstimator] | [T11aLTS | T11aDataSymbol ...]
-// with the error_code test after every source call.  The carrier-sense state machine is inherently serial
-// and runs wave-uniform; the per-frame work it triggers (T11aLTS: CFO estimate, frequency shift, FFT<64>,
-// channel inverse; the SIGNAL symbol: FFT<64>, equalise, pilot track, BPSK demap, de-interleave, 24-step
-// Viterbi, parse) is spread over the 64 lanes.  Output: the frame table, per-frame contexts and the
-// symbol-slot map that the batched per-symbol kernels consume.  Data symbols are NOT decoded here.
+// with the error_code test after every source call.  Round 6: the walk is no longer a loop over source calls.  Positions are kept in
+// 20 MHz-rate samples s (a burst = 4, a source call = 14 at either input rate; a 40 MHz capture only ever uses its even samples), and the
+// graph's behaviour between two observable events is evaluated in PASSES:
+//   * carrier sense (cca.hpp:386-437) up to eight bursts at a time, one sample per lane: sliding sums by prefix sums, the carrier test of
+//     every burst, and the detection counters (auto_count / sense_count / the time-out) from the ballot of those tests with bit arithmetic;
+//     a pass ends with the burst that calls establish_sync (cca.hpp:220-243: sixteen patterns x sixteen taps, four taps per lane);
+//   * the short training symbols (check_sync, cca.hpp:245-265) sixteen bursts at a time: a row of sixteen lanes per check;
+//   * T11aLTS, the SIGNAL symbol and the frame's end are positions computed from the detection point; the source-call grid only matters
+//     where the reference looks at it: a carrier-sense time-out resets the bricks at the END of the call that raised it, and a frame event
+//     drops the rest of its call's queue (Flush + Reset, fb11a_demod.cpp:64-70).
+// The samples come from an LDS ring that is filled 256 samples ahead of the walk (four coalesced loads in flight while the passes run), so
+// a pass waits for LDS, not for HBM.  Output: the frame table, per-frame contexts and the symbol-slot map that the batched per-symbol
+// kernels consume.  Data symbols are NOT decoded here.
 //
 // Capture contract: nsamples is a whole number of source bursts (28 raw samples @40 MHz / 14 @20 MHz) --
 // true of every Sora dump (RX_BLOCK = 28 samples, core/inc/_rx_manager.h:96-137); a trailing partial burst
@@ -17,6 +24,10 @@
 #include "kernels.h"
 
 namespace sora {
+
+// The capture's samples around the walk, one packed COMPLEX16 per word: sample i (20 MHz-rate index) at s_ring[i & 511] (k_scan keeps [lo, hi) valid).
+constexpr uint32_t kRing = 512;
+__shared__ uint32_t s_ring[kRing];
 
 #ifdef SORA_SCAN_PROBE
 __device__ unsigned long long g_scan_probe[16];              // [0..7] ticks per region, [8..15] how often (capture 0 only; tools/probe_scan.py)
@@ -116,21 +127,18 @@ __device__ __forceinline__ Tables tables_of(const ScanTabs& b)
 
 // ---- T11aLTS on the 144 samples at lts_start (channel_11a.hpp:206-330): CFO estimate, frequency shift, FFT<64>, channel inverse -> *fx.
 // Out of line (once per frame): its temporaries and table pointers stay out of the carrier-sense loop's register allocation.  Returns the CFO.
-__device__ __noinline__ int lts_section(ScanTabs tabs, const uint32_t* iq_, uint32_t lts_start_, uint32_t STR_, FrameCtx* fx_)
+__device__ __noinline__ int lts_section(ScanTabs tabs, uint32_t lts_start_, FrameCtx* fx_)
 {
     const Tables T = tables_of(tabs);
-    const uint32_t* iq = uni_ptr(iq_); FrameCtx* fx = uni_ptr(fx_);
-    const uint32_t lts_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)lts_start_), STR = (uint32_t)__builtin_amdgcn_readfirstlane((int)STR_);
+    FrameCtx* fx = uni_ptr(fx_);
+    const uint32_t lts_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)lts_start_);
     __shared__ uint32_t s_fft[64];
-    __shared__ uint32_t s_x[144];
+    __shared__ uint32_t s_x[64];
     const int lane = threadIdx.x;
     auto sync = []() { __syncthreads(); };
-                        // stage the 144 samples (20 MHz rate) in LDS
-                        for (int i = lane; i < 144; i += 64) s_x[i] = iq[lts_start + (uint32_t)i * STR];
-                        sync();
-                        // x[n] = s_x[8+n]; first 64 are >>1 (rep_shift_right<16>, :216)
-                        cpx x1 = sra(unpack(s_x[8 + lane]), 1);
-                        cpx x2 = unpack(s_x[8 + 64 + lane]);
+                        // the 144 samples sit in the ring; x[n] = sample 8 + n; the first 64 are >>1 (rep_shift_right<16>, :216)
+                        cpx x1 = sra(unpack(s_ring[(lts_start + 8u + (uint32_t)lane) & (kRing - 1u)]), 1);
+                        cpx x2 = unpack(s_ring[(lts_start + 72u + (uint32_t)lane) & (kRing - 1u)]);
                         int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
                         const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
                         const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
@@ -173,11 +181,11 @@ __device__ __noinline__ int lts_section(ScanTabs tabs, const uint32_t* iq_, uint
 // ---- the SIGNAL symbol at sym_start: T11aDataSymbol .. T11aViterbiSig .. T11aPLCPParser (PHY_11a.hpp:389-580), lane-parallel; out of line
 // like lts_section.  Every field of the result is wave-uniform.
 struct SigOut { uint32_t ok, kbps, len, nsym, cr, nb; int cfo_comp, sfo_comp, cfo_tr, sfo_tr; };
-__device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_, uint32_t sym_start_, uint32_t STR_, const FrameCtx* fx_)
+__device__ __noinline__ SigOut signal_section(ScanTabs tabs, uint32_t sym_start_, const FrameCtx* fx_)
 {
     const Tables T = tables_of(tabs);
-    const uint32_t* iq = uni_ptr(iq_); const FrameCtx* fx = uni_ptr(fx_);
-    const uint32_t sym_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym_start_), STR = (uint32_t)__builtin_amdgcn_readfirstlane((int)STR_);
+    const FrameCtx* fx = uni_ptr(fx_);
+    const uint32_t sym_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym_start_);
     __shared__ uint32_t s_fft[64];
     __shared__ uint8_t  s_soft[48];
     const int lane = threadIdx.x;
@@ -188,7 +196,7 @@ __device__ __noinline__ SigOut signal_section(ScanTabs tabs, const uint32_t* iq_
     #pragma unroll
                             for (int m = 0; m < 4; m++) {                              // skip CP 8, >>1, x FreqCoeffs (channel_11a.hpp:643-644)
                                 const int n = e + 16 * m;
-                                cpx x = sra(unpack(iq[sym_start + (uint32_t)(8 + n) * STR]), 1);
+                                cpx x = sra(unpack(s_ring[(sym_start + 8u + (uint32_t)n) & (kRing - 1u)]), 1);
                                 xin[m] = mul_q15(x, unpack(fx->freq[n]));
                             }
                             fft64_group(xin, Y, s_fft, e, T, sync);
@@ -298,6 +306,10 @@ __device__ __noinline__ void cont_store(uint32_t* crec, uint32_t* consumed, uint
     if (l == 0) *consumed = at;
 }
 
+// x / 14 and ceil(x / 14) for x < 2^31 (a source call = 14 samples at the 20 MHz rate) as a multiply: 0x92492493 = ceil(2^35 / 14)
+__device__ __forceinline__ uint32_t div14(uint32_t x) { return (uint32_t)(((uint64_t)x * 0x92492493ull) >> 35); }
+__device__ __forceinline__ uint32_t call_end(uint32_t burst_end) { return div14(burst_end + 13u) * 14u; }   // end of the source call that delivers the burst ending at burst_end
+
 __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
 {
     const uint32_t cap_i = blockIdx.x;
@@ -305,16 +317,44 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     const int lane = threadIdx.x;
     const CapDesc cd = A.caps[cap_i];
     const uint32_t* iq = A.iq + cd.offset;
-    const uint32_t STR = A.str, APP = 28 / (2 / STR), BUR = 8 / (2 / STR);
-    const uint32_t nunits = (cd.nsamples / APP) * APP;
+    const uint32_t sh = A.str - 1u;                                     // 40 MHz input: 20 MHz-rate sample s is raw sample 2 s (TDownSample2 keeps the even ones, samples.hpp:27-45)
+    const uint32_t NS = (cd.nsamples / (14u << sh)) * 14u;              // 20 MHz-rate samples in whole source calls
     const Tables& T = A.T;
     const ScanTabs tabs = { T.uatan2, T.rot, T.demap, T.deint, T.tw64, T.tw16 };
+
+    // ---- the sample ring: s_ring holds [r_lo, r_hi), the 256 samples behind r_hi are in flight in four registers
+    uint32_t n0 = 0, n1 = 0, n2 = 0, n3 = 0, r_lo = 0, r_hi = 0;
+    auto issue = [&](uint32_t base) {
+        const uint32_t i = base + (uint32_t)lane;
+        n0 = i < NS ? iq[(size_t)i << sh] : 0u;
+        n1 = i + 64u < NS ? iq[(size_t)(i + 64u) << sh] : 0u;
+        n2 = i + 128u < NS ? iq[(size_t)(i + 128u) << sh] : 0u;
+        n3 = i + 192u < NS ? iq[(size_t)(i + 192u) << sh] : 0u;
+    };
+    auto aim = [&](uint32_t at) { if (at < r_lo || at >= r_hi + 256u) { r_lo = r_hi = at; issue(at); } };      // the walk goes on at `at`: start fetching there unless it is at hand
+    auto fill = [&](uint32_t at, uint32_t len) {                        // [at, at + len) readable from s_ring (len <= 256)
+        aim(at);
+        while (at + len > r_hi) {
+            const uint32_t w = r_hi + (uint32_t)lane;
+            s_ring[w & (kRing - 1u)] = n0; s_ring[(w + 64u) & (kRing - 1u)] = n1; s_ring[(w + 128u) & (kRing - 1u)] = n2; s_ring[(w + 192u) & (kRing - 1u)] = n3;
+            r_hi += 256u;
+            if (r_hi - r_lo > kRing) r_lo = r_hi - kRing;
+            issue(r_hi);
+        }
+    };
+    issue(0);
+
     // the fills a call used to get from a kernel of their own in front of this one (kernels.h ScanArgs): nobody reads any of these words before this kernel has ended
     if (A.own_slots && A.slot_row) for (uint32_t i = (uint32_t)lane; i < cd.nslots; i += 64u) A.slot_row[cd.slot_base + i] = 0xFFFFFFFFu;
     if (cap_i == 0) {
         if (A.zero_a) for (uint32_t i = (uint32_t)lane; i < A.nzero_a; i += 64u) A.zero_a[i] = 0u;
         if (A.zero_b) for (uint32_t i = (uint32_t)lane; i < A.nzero_b; i += 64u) A.zero_b[i] = 0u;
     }
+    // STS correlation patterns (cca.hpp:268-277), held for the whole walk: check_sync only ever uses patterns 0..3, one tap per lane of a row;
+    // establish_sync all sixteen: pattern lane >> 2, taps 4 (lane & 3) .. + 3
+    const uint32_t chk0 = T.sts[lane & 15], chk1 = T.sts[16 + (lane & 15)], chk2 = T.sts[32 + (lane & 15)], chk3 = T.sts[48 + (lane & 15)];
+    const uint32_t est_base = (uint32_t)(lane >> 2) * 16u + 4u * (uint32_t)(lane & 3);
+    const uint32_t est0 = T.sts[est_base], est1 = T.sts[est_base + 1], est2 = T.sts[est_base + 2], est3 = T.sts[est_base + 3];
 
     // ---- carrier-sense state (cca.hpp:126-158), wave-uniform
     uint32_t Hv = 0;                         // sample_his in TIME ORDER, one packed sample per lane (lane & 15, oldest = 0): 4 bursts of 4, already >>2
@@ -322,14 +362,9 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     uint32_t auto_count = 0, sense_count = 0, high_count = 0; int sync_high = 0, peak_corr = 0, peak_index = 0;
     uint32_t dc_cnt = 8; int sum_dc_re = 0, sum_dc_im = 0;            // TDCEstimator (dc.hpp:92-166); all 4 lanes of the vcs are equal
     int dc_re = 0, dc_im = 0;                                          // CF_VecDC (survives frame resets)
-    // ---- context
-    uint32_t error_code = 0; int cca_detected = 0, symbol_is_data = 0, plcp_is_data = 0;
-    uint32_t lts_n = 0, sym_n = 0, lts_start = 0, sym_start = 0, frame_start = 0;
-    uint32_t remain_symbols = 0, sym_idx = 0;
-    uint32_t nfr = 0;
-    // the frame row being assembled (wave-uniform scalars; written out once)
-    uint32_t r_start = 0, r_end = 0, r_rate = 0, r_slot0 = 0, r_data_start = 0, r_len = 0, r_nsym = 0, r_cr = 0, r_nb = 0;
-    int r_cfo = 0, r_cfo_comp = 0, r_sfo_comp = 0, r_cfo_tr = 0, r_sfo_tr = 0;
+    int cca_detected = 0;
+    uint32_t frame_start = 0, nfr = 0;
+    bool to_pending = false; uint32_t pend_end = 0;                    // E_CS_TIMEOUT raised: RxThread resets the bricks at the end of that source call (fb11a_demod.cpp:41-45)
 
     auto cs_reset = [&]() {
         Hv = 0;
@@ -337,13 +372,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         auto_count = sense_count = high_count = 0; sync_high = 0; peak_corr = 0; peak_index = 0;
         dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
     };
-    auto frame_reset = [&]() {
-        error_code = 0; cca_detected = 0; symbol_is_data = 0; plcp_is_data = 0;
-        lts_n = sym_n = 0; remain_symbols = 0; sym_idx = 0;
-        cs_reset();
-    };
     cs_reset();
-    auto sync = []() { __syncthreads(); };
 
     // ---- stream continuation (sora_rx_set_stream_mode; TRxStream hands the graph an endless stream, rxstream.hpp:34-66: the DC estimate of
     // dc.hpp:92-166 integrates for ever, the carrier-sense windows and counters carry over from read to read).  A RESUME POINT is a position
@@ -351,12 +380,11 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     // pending): everything the graph knows there is the record below.  The capture's last resume point is published (A.consumed) and its
     // record kept; the next call's capture k starts AT that point of the stream and the record is its initial state -- so what the graph
     // reports from there on is what it reports on the uncut stream, and a frame cut by the end of a capture is simply found again.
-    // (one flag lives through the loop; the pointers are re-derived where they are used)
     const bool streaming = A.cont != nullptr;
     auto cont_save = [&](uint32_t at) {
         cont_store(A.cont + (size_t)cap_i * kContWords, A.consumed + cap_i, Hv, ac_re.Z, ac_im.Z, energy.Z, ac_re.reg, ac_im.reg, energy.reg, sense_count,
                 high_count, peak_corr, peak_index,
-                   dc_cnt, sum_dc_re, sum_dc_im, dc_re, dc_im, at);
+                   dc_cnt, sum_dc_re, sum_dc_im, dc_re, dc_im, at << sh);
     };
     if (streaming) {
         if (lane == 0) A.consumed[cap_i] = 0;
@@ -371,353 +399,253 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         }
     }
 
-    // GetCrossCorrelation (cca.hpp:202-218) for pattern p: the reference starts at the oldest burst, i.e. h[0]
-    auto cross_corr = [&](int p) -> int {
-        int sre[4] = {0, 0, 0, 0}, sim[4] = {0, 0, 0, 0};
-#pragma unroll
-        for (int v = 0; v < 4; v++) {
-#pragma unroll
-            for (int e = 0; e < 4; e++) {
-                int re, im; conj_mul32(unpack(T.sts[p * 16 + 4 * v + e]), unpack((uint32_t)__builtin_amdgcn_readlane((int)Hv, 4 * v + e)), re, im);
-                sre[e] = (int)((unsigned)sre[e] + (unsigned)re); sim[e] = (int)((unsigned)sim[e] + (unsigned)im);
-            }
-        }
-        int r = (int)((unsigned)sre[0] + (unsigned)sre[1] + (unsigned)sre[2] + (unsigned)sre[3]);
-        int i = (int)((unsigned)sim[0] + (unsigned)sim[1] + (unsigned)sim[2] + (unsigned)sim[3]);
-        return abs(r) + abs(i);
-    };
-    auto his_push = [&](const cpx (&v)[4]) {                                    // drop the oldest burst, append v (wave-uniform values)
-        const uint32_t l = (uint32_t)lane & 15u;
-        const uint32_t fresh = (l & 3u) == 0 ? pack(v[0]) : (l & 3u) == 1 ? pack(v[1]) : (l & 3u) == 2 ? pack(v[2]) : pack(v[3]);
-        const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)(((uint32_t)lane & 48u) | ((l + 4u) & 15u)));
-        Hv = l < 12u ? keep : fresh;
-    };
-
-    // Carrier sense reads the stream 4 samples at a time, wave-uniformly: stage 64 consecutive units per
-    // coalesced 256-byte load (one per lane) and hand them out with v_readlane instead of paying one global
-    // round trip per burst.  (Keeping the following 64 units in flight in a second register was measured in round 4: the kernel
-    // alone stays at 0.102-0.108 ms -- the loads are L2 hits behind the staging kernel, not what the wave waits for -- so it is not done.)
-    uint32_t win_base = 0xFFFFFFFFu, win = 0;
-    auto stage = [&](uint32_t u) { win_base = u; win = (u + (uint32_t)lane < nunits) ? iq[u + (uint32_t)lane] : 0u; };
-    auto sample = [&](uint32_t u) -> uint32_t {
-        if (u - win_base >= 64u) stage(u);
-        return (uint32_t)__builtin_amdgcn_readlane((int)win, (int)(u - win_base));
-    };
-
-    uint32_t vpos = 0;                              // next burst start, in queue units
-    // ---- idle fast path.  While no carrier is in sight (energy/auto-correlation test false, cca.hpp:386-437) a burst only
-    // feeds the sliding sums, the history, the DC estimator and the time-out counter.  Up to 8 bursts are then taken at
-    // once, one sample per lane (lane = 4 b + e): the per-sample products run once instead of per burst per lane, the
-    // per-burst bookkeeping (sliding-sum updates, the test, counters) stays scalar.  The group contains a DC update at
-    // most at its last burst (the estimate changes what the next burst sees), stays inside the source call when the
-    // carrier-sense time-out will fire in it (error_code is examined, and the brick reset, at the end of that call), and
-    // stops in front of the first burst whose test is true -- that burst goes through the full path below.
-    auto fast_idle = [&](uint32_t K) -> uint32_t {
-        if (vpos - win_base + K * BUR > 64u || win_base == 0xFFFFFFFFu) stage(vpos);
-        const uint32_t l = (uint32_t)lane & 31u, hi = (uint32_t)lane & 32u;    // lanes 32..63 mirror lanes 0..31
-        const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
-        const cpx x = unpack(raw);
-        const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));                // TDCRemoveEx
-        const cpx pii = sra(pi, 2);
-        const uint32_t ppk = pack(pii);
-        const uint32_t prev = other_row_even(ppk);                              // the sample 16 lanes below (used by the second row of each half only)
-        int re, im; conj_mul32(pii, unpack(l < 16u ? Hv : prev), re, im);       // against the sample 16 earlier
-        unsigned vr = (unsigned)(re >> 4), vi = (unsigned)(im >> 4), ve = (unsigned)(sqnorm(pii) >> 4);
-        unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);     // TDCEstimator terms
-        vr = quad_sum(vr); vi = quad_sum(vi); ve = quad_sum(ve);                // a burst's four samples sit in one quad
-        dr = quad_sum(dr); di = quad_sum(di);
-        // ---- the K bursts' sliding sums at once.  After burst b the accumulator holds reg + sum_{i<=b} (d_i - z_i), z = the value that leaves the
-        // 4-element window: the old elements for b < 4, d_{b-4} after that.  One prefix sum per stream over the burst groups, the reference's test
-        // (cca.hpp:386-437) in every group, and the first burst whose test is true ends the pass.
-        const bool second_row = (l & 16u) != 0u;
-        // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
-        const uint32_t pr = other_row_even(vr), pim = other_row_even(vi), pe = other_row_even(ve);
-        const uint32_t zr = second_row ? pr : ac_re.Z, zi = second_row ? pim : ac_im.Z, ze = second_row ? pe : energy.Z;
-        const uint32_t Rr = (uint32_t)ac_re.reg + group_scan(vr - zr), Ri = (uint32_t)ac_im.reg + group_scan(vi - zi), Re = (uint32_t)energy.reg + group_scan(ve - ze);
-        const int iAuto_v = abs((int)Rr) + abs((int)Ri), iEnergy_v = (int)Re;
-        const bool carrier = iEnergy_v > (int)A.thr && iAuto_v >= iEnergy_v - (iEnergy_v >> 3);
-        const uint32_t hits = (uint32_t)__ballot(carrier) & 0x11111111u & (K >= 8u ? 0xFFFFFFFFu : ((1u << (4u * K)) - 1u));
-        const uint32_t done = hits ? (uint32_t)__builtin_ctz(hits) >> 2 : K;
-        if (done) {
-            const int last = (int)(4u * (done - 1u));
-            ac_re.reg = __builtin_amdgcn_readlane((int)Rr, last); ac_im.reg = __builtin_amdgcn_readlane((int)Ri, last); energy.reg = __builtin_amdgcn_readlane((int)Re, last);
-            {   // the windows <- the last four of {old window, d_0 .. d_{done-1}} (element g in lanes 4 g .. 4 g + 3 of every row)
-                const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;
-                const int from_old = (int)(((uint32_t)lane & 48u) | (src & 15u)), from_new = (int)(hi | ((src - 16u) & 31u));
-                const bool old = src < 16u;
-                const uint32_t kr = (uint32_t)__shfl((int)ac_re.Z, from_old), fr = (uint32_t)__shfl((int)vr, from_new);
-                const uint32_t ki = (uint32_t)__shfl((int)ac_im.Z, from_old), fi = (uint32_t)__shfl((int)vi, from_new);
-                const uint32_t ke = (uint32_t)__shfl((int)energy.Z, from_old), fe = (uint32_t)__shfl((int)ve, from_new);
-                ac_re.Z = old ? kr : fr; ac_im.Z = old ? ki : fi; energy.Z = old ? ke : fe;
-            }
-            auto_count = 0; sense_count += 4u * done;
-            // TDCEstimator (dc.hpp:92-166): 16-bit running sums of the bursts taken; the estimate moves at most at the pass's last burst (K <= dc_cnt + 1)
-            sum_dc_re = w16(sum_dc_re + __builtin_amdgcn_readlane((int)group_scan(dr), last));
-            sum_dc_im = w16(sum_dc_im + __builtin_amdgcn_readlane((int)group_scan(di), last));
-            if (done == dc_cnt + 1u) {
-                dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
-                dc_cnt = 7; sum_dc_re = sum_dc_im = 0;
-            } else dc_cnt -= done;
-            if (sense_count >= 84) error_code = E_CS_TIMEOUT;                   // cca.hpp:433-437
-        }
-        if (done) {                                                             // history <- its last 16 samples
-            const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;   // index in {old history 0..15, new samples 16..47}
-            const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)(((uint32_t)lane & 48u) | (src & 15u)));
-            const uint32_t fresh = (uint32_t)__shfl((int)ppk, (int)(hi | ((src - 16u) & 31u)));
-            Hv = src < 16u ? keep : fresh;
-            vpos += done * BUR;
-        }
-        return done;
-    };
-
-    // ---- the same for the phase between establish_sync and the end of the short training symbols (check_sync,
-    // cca.hpp:245-265): a burst only enters the history; every fourth one the history is correlated with the winning
-    // STS pattern.  Up to 4 bursts per pass, one sample per lane; the correlation runs one tap per lane.
-    auto fast_sync = [&](uint32_t K) {                                          // K = bursts taken (1..4), at most up to the next check
-        if (vpos - win_base + 4u * BUR > 64u || win_base == 0xFFFFFFFFu) stage(vpos);
-        const uint32_t l = (uint32_t)lane & 15u;
-        const uint32_t raw = (uint32_t)__shfl((int)win, (int)(vpos - win_base + (l >> 2) * BUR + (l & 3u) * STR));
-        const cpx x = unpack(raw);
-        const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));
-        const uint32_t src = ((uint32_t)lane & 48u) | ((l + 4u * K) & 15u);
-        const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)src), fresh = (uint32_t)__shfl((int)pack(sra(pi, 2)), (int)src);
-        Hv = (l + 4u * K < 16u) ? keep : fresh;
-        const uint32_t last_v = vpos + (K - 1u) * BUR;                          // the burst that may carry the check
-        vpos += K * BUR;
-        high_count += K;
-        if (high_count % 4 == 0) {
-            int re, im; conj_mul32(unpack(T.sts[peak_index * 16 + (int)l]), unpack(Hv), re, im);   // GetCrossCorrelation, one tap per lane
-            unsigned ur = (unsigned)re, ui = (unsigned)im;
-            ur = row_sum(ur); ui = row_sum(ui);
-            const int corr = abs(__builtin_amdgcn_readfirstlane((int)ur)) + abs(__builtin_amdgcn_readfirstlane((int)ui));
-            if (corr < (peak_corr >> 1)) {
-                if (high_count > 8) { cca_detected = 1; frame_start = last_v / STR + 4; }
-                else {
-                    sync_high = 0; sense_count = 0;
-                    // the burst that dropped the lock also feeds TDCEstimator (dc.hpp:92-166)
-                    unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);
-                    dr = quad_sum(dr); di = quad_sum(di);
-                    sum_dc_re = w16(sum_dc_re + w16(__builtin_amdgcn_readlane((int)dr, (int)(4 * (K - 1)))));
-                    sum_dc_im = w16(sum_dc_im + w16(__builtin_amdgcn_readlane((int)di, (int)(4 * (K - 1)))));
-                    if (dc_cnt == 0) {
-                        dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
-                        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
-                    }
-                    dc_cnt--;
-                }
-            } else if (corr > peak_corr) peak_corr = corr;
-        }
-    };
-
-    const uint32_t nchunks = nunits / APP;
+    uint32_t s = 0;                                 // next burst, 20 MHz-rate sample index
     PROBE_DECL();
     PROBE_TK();
     // Every frame of the capture is found and counted, as RxThread reports every frame; those past the row limit get no row and
     // no decode job (their per-frame context goes to the capture's spare FrameCtx), and the host flags the capture's last row.
     auto ctx_of = [&](uint32_t k) { return A.fctx + (k < A.max_frames ? (size_t)cap_i * A.max_frames + k : (size_t)A.nrows + cap_i); };
-    for (uint32_t c = 0; c < nchunks; c++) {
-        const uint32_t avail_end = (c + 1) * APP;
-        while (vpos + BUR <= avail_end) {
-            // (inside this loop the only multiple of APP vpos can be is the chunk's start)
-            if (streaming && vpos == avail_end - APP && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);
-            if (!cca_detected && !sync_high && auto_count == 0) {
-                // bursts until the carrier-sense time-out is raised; if that is near, stay inside this source call
-                const uint32_t to_timeout = sense_count >= 84 ? 0u : (84u - sense_count + 3u) / 4u;
-                uint32_t room = to_timeout <= 8u ? (avail_end - vpos) / BUR : (nunits - vpos) / BUR;
-                // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen:
-                if (streaming) {
-                    // in units of half a burst vpos sits m past the chunk's start and a source call is 7; j bursts further it is m + 2 j: j = -m / 2 = 3 m (mod 7), 0 -> 7
-                    const uint32_t m7 = (((vpos + APP - (avail_end - APP)) / (BUR / 2u)) % 7u);
-                    const uint32_t j = (3u * m7) % 7u;
-                    room = min(room, j ? j : 7u);
-                }
-                PROBE_T0();
-                const uint32_t took = fast_idle(min(min(room, dc_cnt + 1u), 8u));
-                PROBE_ADD(3);
-                if (took) continue;
+    auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
+
+    for (;;) {
+        if (to_pending && s + 4u > pend_end) {      // the source call that raised E_CS_TIMEOUT is over: ResetCarrierSense(); scs->Reset()
+            to_pending = false; cca_detected = 0; cs_reset();
+        }
+        if (s + 4u > NS) break;
+        if (!sync_high) {
+            // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator, up to eight bursts at once, one sample per lane (lane = 4 b + e; lanes 32..63 mirror
+            // lanes 0..31).  The per-sample products run once, the sliding sums are prefix sums over the burst groups, and the reference's test (cca.hpp:386-437)
+            // is evaluated for every burst of the pass; what the tests mean -- auto_count reaching four (establish_sync), sense_count, the time-out -- follows
+            // from the ballot.  A pass holds a DC update at most at its last burst (the estimate changes what the next burst sees) and ends with the burst
+            // that calls establish_sync.
+            const bool plain = !to_pending && auto_count == 0;
+            uint32_t K = min(min((NS - s) >> 2, dc_cnt + 1u), 8u);
+            uint32_t jraise = 0xFFFFu, ce_raise = 0;                             // the burst of this pass at which E_CS_TIMEOUT would be raised, and the end of its source call
+            if (to_pending) K = min(K, (pend_end - s) >> 2);
+            else {
+                // sense_count reaches 84 at burst jraise unless a test before it is true; the bursts behind it that the same source call delivers still run, and the
+                // bricks are reset at that call's end: a pass does not go beyond it
+                jraise = sense_count >= 84u ? 0u : (84u - sense_count + 3u) / 4u - 1u;
+                if (jraise < K) { const uint32_t be = s + 4u * jraise + 4u; ce_raise = call_end(be); K = min(K, jraise + 1u + ((ce_raise - be) >> 2)); }
             }
-            if (!cca_detected && sync_high) {
-                PROBE_T0();
-                fast_sync(min((avail_end - vpos) / BUR, 4u - high_count % 4u));
-                PROBE_ADD(4);
-                continue;
+            if (streaming) {
+                const uint32_t m = s - div14(s) * 14u;                          // position in the source call
+                if (m == 0u && plain) cont_save(s);
+                // a pass ends at the next resume point (burst boundary = source-call boundary), so that it is seen: j bursts on, m + 4 j = 0 (mod 14): j = 3 (m / 2) (mod 7), 0 -> 7
+                const uint32_t j = (3u * (m >> 1)) % 7u;
+                K = min(K, j ? j : 7u);
             }
-            const uint32_t pos20 = vpos / STR;
-            PROBE_T(_tb);
-            if (!cca_detected) {
+            PROBE_T0();
+            fill(s, 32u);
+            const uint32_t l = (uint32_t)lane & 31u, hi = (uint32_t)lane & 32u;
+            const cpx x = unpack(s_ring[(s + l) & (kRing - 1u)]);
+            const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));                // TDCRemoveEx
+            const cpx pii = sra(pi, 2);
+            const uint32_t ppk = pack(pii);
+            const uint32_t prev = other_row_even(ppk);                              // the sample 16 lanes below (used by the second row of each half only)
+            int re, im; conj_mul32(pii, unpack(l < 16u ? Hv : prev), re, im);       // GetAutoCorrelation (cca.hpp:165-186): against the sample 16 earlier
+            unsigned vr = (unsigned)(re >> 4), vi = (unsigned)(im >> 4), ve = (unsigned)(sqnorm(pii) >> 4);   // GetEnergy (cca.hpp:188-193)
+            unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);     // TDCEstimator terms
+            vr = quad_sum(vr); vi = quad_sum(vi); ve = quad_sum(ve);                // a burst's four samples sit in one quad
+            dr = quad_sum(dr); di = quad_sum(di);
+            // the K bursts' sliding sums at once.  After burst b the accumulator holds reg + sum_{i<=b} (d_i - z_i), z = the value that leaves the
+            // 4-element window: the old elements for b < 4, d_{b-4} after that.  One prefix sum per stream over the burst groups.
+            const bool second_row = (l & 16u) != 0u;
+            // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
+            const uint32_t pr = other_row_even(vr), pim = other_row_even(vi), pe = other_row_even(ve);
+            const uint32_t zr = second_row ? pr : ac_re.Z, zi = second_row ? pim : ac_im.Z, ze = second_row ? pe : energy.Z;
+            const uint32_t Rr = (uint32_t)ac_re.reg + group_scan(vr - zr), Ri = (uint32_t)ac_im.reg + group_scan(vi - zi), Re = (uint32_t)energy.reg + group_scan(ve - ze);
+            const uint32_t Dr = group_scan(dr), Di = group_scan(di);
+            const int iAuto_v = abs((int)Rr) + abs((int)Ri), iEnergy_v = (int)Re;
+            const bool carrier = iEnergy_v > (int)A.thr && iAuto_v >= iEnergy_v - (iEnergy_v >> 3);
+            const uint32_t hits = (uint32_t)__ballot(carrier) & 0x11111111u & (K >= 8u ? 0xFFFFFFFFu : ((1u << (4u * K)) - 1u));   // bit 4 b: burst b's test
+            // auto_count (cca.hpp:400-414): consecutive true tests, establish_sync at every true test from the fourth on: the first run of four in
+            // {the a tests that were true before the pass, this pass's tests}
+            const uint32_t a = min(auto_count, 3u);
+            const uint64_t M = ((uint64_t)hits << (4u * a)) | (uint64_t)(0x111u >> (12u - 4u * a));
+            const uint64_t run = M & (M >> 4) & (M >> 8) & (M >> 12);
+            const bool est = run != 0;
+            const uint32_t done = est ? ((uint32_t)__builtin_ctzll(run) >> 2) + 4u - a : K;          // bursts taken
+            const uint32_t bits = done >= 8u ? 0x11111111u : (0x11111111u & ((1u << (4u * done)) - 1u));
+            const uint32_t th = hits & bits;                                         // the tests of the bursts taken
+            if (est) auto_count = 4;
+            else {
+                const uint32_t inv = ~th & bits;                                     // ... that were false: auto_count = the true tests behind the last of them
+                auto_count = inv ? done - 1u - ((31u - (uint32_t)__builtin_clz(inv)) >> 2) : min(auto_count + done, 4u);
+            }
+            // sense_count (cca.hpp:398, :402, :433-437): + 4 per burst, 0 at a true test; E_CS_TIMEOUT from 84 on
+            if (!to_pending && jraise < min(th ? (uint32_t)__builtin_ctz(th) >> 2 : done, done)) { to_pending = true; pend_end = ce_raise; }
+            sense_count = th ? 4u * (done - 1u - ((31u - (uint32_t)__builtin_clz(th)) >> 2)) : sense_count + 4u * done;
+            {
+                const int last = (int)(4u * (done - 1u));
+                ac_re.reg = __builtin_amdgcn_readlane((int)Rr, last); ac_im.reg = __builtin_amdgcn_readlane((int)Ri, last); energy.reg = __builtin_amdgcn_readlane((int)Re, last);
+                // the windows <- the last four of {old window, d_0 .. d_{done-1}} (element g in lanes 4 g .. 4 g + 3 of every row); history <- its last 16 samples
+                const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;   // index in {old 0..15, new 16..47}
+                const int from_old = (int)(((uint32_t)lane & 48u) | (src & 15u)), from_new = (int)(hi | ((src - 16u) & 31u));
+                const bool old = src < 16u;
+                const uint32_t kr = (uint32_t)__shfl((int)ac_re.Z, from_old), fr = (uint32_t)__shfl((int)vr, from_new);
+                const uint32_t ki = (uint32_t)__shfl((int)ac_im.Z, from_old), fi = (uint32_t)__shfl((int)vi, from_new);
+                const uint32_t ke = (uint32_t)__shfl((int)energy.Z, from_old), fe = (uint32_t)__shfl((int)ve, from_new);
+                const uint32_t keep = (uint32_t)__shfl((int)Hv, from_old), fresh = (uint32_t)__shfl((int)ppk, from_new);
+                ac_re.Z = old ? kr : fr; ac_im.Z = old ? ki : fi; energy.Z = old ? ke : fe;
+                Hv = old ? keep : fresh;
+            }
+            s += 4u * done;
+            PROBE_ADD(3);
+            if (est) {
                 PROBE_T0();
-                // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator (power_clear path)
-                uint32_t raw[4]; cpx pi[4];
-#pragma unroll
-                for (int e = 0; e < 4; e++) { raw[e] = sample(vpos + e * STR); cpx x = unpack(raw[e]); pi[e] = mk(w16(x.re - dc_re), w16(x.im - dc_im)); }
-                if (!sync_high) {
-                    cpx pii[4];
-#pragma unroll
-                    for (int e = 0; e < 4; e++) pii[e] = sra(pi[e], 2);
-                    int sr = 0, si = 0, se = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; e++) {
-                        int re, im; conj_mul32(pii[e], unpack((uint32_t)__builtin_amdgcn_readlane((int)Hv, e)), re, im);   // sample_his.First(): 16 samples ago
-                        sr = (int)((unsigned)sr + (unsigned)(re >> 4)); si = (int)((unsigned)si + (unsigned)(im >> 4));
-                        se = (int)((unsigned)se + (unsigned)(sqnorm(pii[e]) >> 4));
-                    }
-                    acc_push(ac_re, sr); acc_push(ac_im, si);
-                    const int iAuto = abs(ac_re.reg) + abs(ac_im.reg);
-                    acc_push(energy, se);
-                    const int iEnergy = energy.reg;
-                    his_push(pii);
-                    sense_count += 4;
-                    if (iEnergy > (int)A.thr && iAuto >= iEnergy - (iEnergy >> 3)) {
-                        auto_count++; sense_count = 0;
-                        if (auto_count >= 4) {
-                            // establish_sync (cca.hpp:220-243): lanes 0..15 take one pattern each
-                            int corr = cross_corr(lane & 15);
-                            int sum_corr = 0, best = 0, best_i = 0;
-#pragma unroll
-                            for (int p = 0; p < 16; p++) {
-                                const int cp = __builtin_amdgcn_readlane(corr, p);          // wave-uniform from here on
-                                if (cp > best) { best = cp; best_i = p; }
-                                sum_corr += cp;
-                            }
-                            peak_corr = best; if (best > 0) peak_index = best_i;
-                            if (peak_corr > (sum_corr >> 3)) {
-                                sync_high = 1; high_count = 0;
-                                if (peak_index > 3) { high_count = (uint32_t)peak_index / 4; peak_index &= 3; }
-                            }
-                        }
-                    } else {
-                        auto_count = 0;
-                    }
+                // establish_sync (cca.hpp:220-243) on the history as it is after this burst: GetCrossCorrelation (cca.hpp:202-218) with all sixteen patterns,
+                // four taps per lane (the partial sums are 32-bit wrapping adds: any order)
+                unsigned sr = 0, si = 0;
+                {
+                    const int q4 = 4 * (lane & 3);
+                    const uint32_t h0 = (uint32_t)__shfl((int)Hv, q4), h1 = (uint32_t)__shfl((int)Hv, q4 + 1), h2 = (uint32_t)__shfl((int)Hv, q4 + 2), h3 = (uint32_t)__shfl((int)Hv, q4 + 3);
+                    int cr_, ci_;
+                    conj_mul32(unpack(est0), unpack(h0), cr_, ci_); sr += (unsigned)cr_; si += (unsigned)ci_;
+                    conj_mul32(unpack(est1), unpack(h1), cr_, ci_); sr += (unsigned)cr_; si += (unsigned)ci_;
+                    conj_mul32(unpack(est2), unpack(h2), cr_, ci_); sr += (unsigned)cr_; si += (unsigned)ci_;
+                    conj_mul32(unpack(est3), unpack(h3), cr_, ci_); sr += (unsigned)cr_; si += (unsigned)ci_;
                 }
-                if (!sync_high) {
-                    int hr = 0, hi = 0;
+                sr = quad_sum(sr); si = quad_sum(si);
+                const int corr = abs((int)sr) + abs((int)si);
+                int sum_corr = 0, best = 0, best_i = 0;
 #pragma unroll
-                    for (int e = 0; e < 4; e++) { hr = w16(hr + (pi[e].re >> 5)); hi = w16(hi + (pi[e].im >> 5)); }
-                    sum_dc_re = w16(sum_dc_re + hr); sum_dc_im = w16(sum_dc_im + hi);
-                    if (dc_cnt == 0) {
-                        dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
-                        dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
-                    }
-                    dc_cnt--;
+                for (int p = 0; p < 16; p++) {
+                    const int cp = __builtin_amdgcn_readlane(corr, 4 * p);
+                    if (cp > best) { best = cp; best_i = p; }
+                    sum_corr += cp;
                 }
-                if (sense_count >= 84 && !sync_high) error_code = E_CS_TIMEOUT;     // cca.hpp:433-437
+                peak_corr = best; if (best > 0) peak_index = best_i;
+                if (peak_corr > (sum_corr >> 3)) {
+                    sync_high = 1; high_count = 0;
+                    if (peak_index > 3) { high_count = (uint32_t)peak_index / 4; peak_index &= 3; }
+                }
                 PROBE_ADD(0);
-            } else if (!symbol_is_data) {
-                // ================= T11aLTS: IPORT COMPLEX16 x 144 (channel_11a.hpp:206-229)
-                if (lts_n == 0) {
-                    // Nothing observable happens while the brick collects its 144 samples (no carrier sense, no error source): go straight
-                    // to the burst that completes them instead of counting 35 bursts.
-                    lts_start = vpos;
-                    const uint32_t last_v = vpos + 35u * BUR;
-                    if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }       // the capture ends inside the LTS: nothing more to report
-                    lts_n = 140; vpos = last_v;
-                    // the for-loop increment lands on the chunk that delivers that burst
-                    c = (vpos + BUR + APP - 1) / APP - 2;
-                    break;
-                }
-                lts_n += 4;
-                if (lts_n == 144) {
-                    PROBE_T0();
-                    lts_n = 0; symbol_is_data = 1;
-                    r_cfo = __builtin_amdgcn_readfirstlane(lts_section(tabs, iq, lts_start, STR, ctx_of(nfr)));
-                    PROBE_ADD(1);
-                }
-            } else {
-                // ================= T11aDataSymbol: IPORT COMPLEX16 x 80 (PHY_11a.hpp:389-428)
-                if (sym_n == 0) sym_start = vpos;
-                // likewise: to the symbol's 20th burst (not once an event is pending: the rest of that source call still counts bursts)
-                if (sym_n == 0 && error_code == 0) {
-                    const uint32_t last_v = vpos + 19u * BUR;
-                    if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }
-                    sym_n = 76; vpos = last_v;
-                    c = (vpos + BUR + APP - 1) / APP - 2;
-                    break;
-                }
-                sym_n += 4;
-                if (sym_n == 80) {
-                    sym_n = 0;
-                    if (sym_idx == 0) {
-                        PROBE_T0();
-                        // ---- the SIGNAL symbol: full header chain, lane-parallel (signal_section, out of line)
-                        const SigOut so = signal_section(tabs, iq, sym_start, STR, ctx_of(nfr));
-                        auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
-                        r_start = frame_start; r_slot0 = cd.slot_base + (sym_start / STR) / 80; r_data_start = sym_start / STR;
-                        r_cfo_comp = uni(so.cfo_comp); r_sfo_comp = uni(so.sfo_comp); r_cfo_tr = uni(so.cfo_tr); r_sfo_tr = uni(so.sfo_tr);
-                        if (uni((int)so.ok)) {
-                            r_rate = (uint32_t)uni((int)so.kbps); r_len = (uint32_t)uni((int)so.len); r_nsym = (uint32_t)uni((int)so.nsym);
-                            r_cr = (uint32_t)uni((int)so.cr); r_nb = (uint32_t)uni((int)so.nb);
-                            remain_symbols = r_nsym + 1; plcp_is_data = 1;
-                        } else {
-                            r_rate = 0; r_len = 0; r_nsym = 0; r_cr = 0; r_nb = 0;
-                            error_code = E_PLCP_HEADER_FAIL;
+            }
+            // TDCEstimator (dc.hpp:92-166) is fed by every burst that leaves carrier sense unlocked: 16-bit running sums; the estimate moves at most at the pass's last burst
+            const uint32_t ndc = done - (sync_high ? 1u : 0u);
+            if (ndc) {
+                const int lastd = (int)(4u * (ndc - 1u));
+                sum_dc_re = w16(sum_dc_re + __builtin_amdgcn_readlane((int)Dr, lastd));
+                sum_dc_im = w16(sum_dc_im + __builtin_amdgcn_readlane((int)Di, lastd));
+            }
+            if (ndc == dc_cnt + 1u) {
+                dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
+                dc_cnt = 7; sum_dc_re = sum_dc_im = 0;
+            } else dc_cnt -= ndc;
+            continue;
+        }
+
+        // ================= locked to the short training symbols: a burst only enters the history, every fourth one the history is correlated with the winning
+        // pattern (check_sync, cca.hpp:245-265).  Sixteen bursts = four checks per pass: lane l holds sample l - 4 o of the pass, o = bursts of the current group
+        // of four that are already in the history (lanes below 4 o carry those), so that row r of sixteen lanes is exactly the history check r looks at.
+        {
+            PROBE_T0();
+            const uint32_t o = high_count & 3u;
+            uint32_t Kn = min(16u - o, (NS - s) >> 2);
+            if (to_pending) Kn = min(Kn, (pend_end - s) >> 2);
+            fill(s, 64u);
+            const cpx x = unpack(s_ring[(s + (uint32_t)lane - 4u * o) & (kRing - 1u)]);
+            const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));
+            const uint32_t ppk = pack(sra(pi, 2));
+            uint32_t hvr = Hv;                                                       // row_ror:4 o: lane l < 4 o <- history element 16 - 4 o + l
+            if (o == 1u) hvr = sdpp<0x124>(Hv); else if (o == 2u) hvr = sdpp<0x128>(Hv); else if (o == 3u) hvr = sdpp<0x12C>(Hv);
+            const uint32_t c = (uint32_t)lane < 4u * o ? hvr : ppk;
+            const uint32_t pat = peak_index == 0 ? chk0 : peak_index == 1 ? chk1 : peak_index == 2 ? chk2 : chk3;
+            int re, im; conj_mul32(unpack(pat), unpack(c), re, im);                  // GetCrossCorrelation, one tap per lane
+            const unsigned ur = row_sum((unsigned)re), ui = row_sum((unsigned)im);
+            unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);      // (the burst that drops the lock also feeds TDCEstimator)
+            dr = quad_sum(dr); di = quad_sum(di);
+            const uint32_t nchk = (o + Kn) >> 2;
+            uint32_t taken = Kn;
+#pragma unroll
+            for (uint32_t r = 0; r < 4u; r++) {
+                if (r < nchk && taken == Kn) {
+                    const int corr = abs(__builtin_amdgcn_readlane((int)ur, 16 * (int)r)) + abs(__builtin_amdgcn_readlane((int)ui, 16 * (int)r));
+                    if (corr < (peak_corr >> 1)) {
+                        const uint32_t b = 4u * (r + 1u) - o - 1u;                  // the burst that carried the failing check
+                        taken = b + 1u;
+                        if (high_count + taken > 8u) { cca_detected = 1; frame_start = s + 4u * b + 4u; }
+                        else {
+                            sync_high = 0; sense_count = 0;
+                            sum_dc_re = w16(sum_dc_re + w16(__builtin_amdgcn_readlane((int)dr, 16 * (int)r + 12)));
+                            sum_dc_im = w16(sum_dc_im + w16(__builtin_amdgcn_readlane((int)di, 16 * (int)r + 12)));
+                            if (dc_cnt == 0) {
+                                dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
+                                dc_cnt = 8; sum_dc_re = sum_dc_im = 0;
+                            }
+                            dc_cnt--;
                         }
-                        PROBE_ADD(2);
-                    }
-                    sym_idx++;
-                    remain_symbols = (remain_symbols - 1) & 0xFFFF;                // ushort (PHY_11a.hpp:405)
-                    if (sym_idx == 1 && plcp_is_data && remain_symbols > 1) {
-                        // Nothing observable happens between here and the last burst of the frame (no carrier sense,
-                        // no error source): jump straight to it instead of counting ~20 bursts per symbol.
-                        const uint64_t last_v = (uint64_t)sym_start + 80ull * STR * (remain_symbols + 1) - BUR;
-                        if (last_v + BUR > nunits) { c = nchunks; vpos = nunits; break; }   // frame runs past the capture: nothing more to report
-                        sym_idx += remain_symbols - 1; remain_symbols = 1; sym_n = 76; sym_start = (uint32_t)(last_v + BUR) - 80u * STR;
-                        vpos = (uint32_t)last_v;
-                        // the for-loop increment lands on the chunk that delivers that burst
-                        c = (vpos + BUR + APP - 1) / APP - 2;
-                        break;
-                    }
-                    if (remain_symbols == 0 && plcp_is_data) {
-                        // all data symbols are in: the Viterbi sub-graph will raise FRAME_OK / CRC32_FAIL
-                        r_end = pos20 + 4;
-                        error_code = E_FRAME_OK;                                    // provisional: "frame complete"
-                    }
+                        // (taken < Kn now ends the checks -- unless this was the pass's last burst, behind which there is no check anyway)
+                        if (taken == Kn) break;
+                    } else if (corr > peak_corr) peak_corr = corr;
                 }
             }
-            vpos += BUR;
-            PROBE_A(_tb, 6);
+            high_count += taken;
+            {   // history <- the last 16 samples of {history, the bursts taken}
+                const uint32_t src = ((uint32_t)lane & 15u) + 4u * taken;           // index in {old 0..15, new 16..}
+                const uint32_t fresh = (uint32_t)__shfl((int)ppk, (int)((src - 16u + 4u * o) & 63u));
+                if (taken < 4u) { const uint32_t keep = (uint32_t)__shfl((int)Hv, (int)(((uint32_t)lane & 48u) | (src & 15u))); Hv = src < 16u ? keep : fresh; }
+                else Hv = fresh;
+            }
+            s += 4u * taken;
+            PROBE_ADD(4);
         }
-        // ---- RxThread bookkeeping after each source call (fb11a_demod.cpp:37-71)
+        if (!cca_detected) continue;
+
+        // ================= a frame: T11aLTS takes the 144 samples behind the detection point (channel_11a.hpp:206-229), T11aDataSymbol 80 per symbol
+        // (PHY_11a.hpp:389-428).  Nothing observable happens while the bricks collect their samples (no carrier sense, no error source): the SIGNAL symbol and
+        // the frame's last burst are positions.
+        const uint32_t lts_start = s, sym_start = s + 144u;
+        if (sym_start + 80u > NS) break;                                             // the capture ends inside the preamble: nothing more to report
+        fill(lts_start, 224u);
+        FrameCtx* const fx = ctx_of(nfr);
+        PROBE_T(_tl);
+        const int r_cfo = uni(lts_section(tabs, lts_start, fx));
+        PROBE_A(_tl, 1);
+        PROBE_T(_ts);
+        const SigOut so = signal_section(tabs, sym_start, fx);
+        PROBE_A(_ts, 2);
         PROBE_T(_tc);
-        if (error_code != 0) {
-            if (error_code == E_CS_TIMEOUT) {
-                error_code = 0; cca_detected = 0; cs_reset();
-            } else {
-                const bool plcp_fail = error_code == E_PLCP_HEADER_FAIL;
-                const bool has_row = nfr < A.max_frames;
-                if (plcp_fail) r_end = vpos / STR;
-                else if (has_row) {
-                    // queue the frame for the per-frame kernels
-                    if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
-                    // its data symbols' slots (k_sym_front / k_sym_back)
-                    if (A.slot_row) for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[r_slot0 + sy] = cap_i * A.max_frames + nfr;
-                }
-                if (lane == 0 && has_row) {
-                    FrameRow row;
-                    row.capture = cap_i; row.start_sample = r_start; row.end_sample = r_end;
-                    row.error_code = plcp_fail ? E_PLCP_HEADER_FAIL : 0u;                 // 0 = pending: decided by k_finish
-                    row.rate_kbps = r_rate; row.length = (uint16_t)r_len; row.nsym = (uint16_t)r_nsym;
-                    row.code_rate = (uint16_t)r_cr; row.nbpsc = (uint16_t)r_nb; row.slot0 = r_slot0; row.crc32 = 0;
-                    row.cfo_est = (int16_t)r_cfo; row.cfo_comp = (int16_t)r_cfo_comp; row.sfo_comp = (int16_t)r_sfo_comp;
-                    row.cfo_tracker = (int16_t)r_cfo_tr; row.sfo_tracker = (int16_t)r_sfo_tr; row.valid = 1;
-                    row.data_start = r_data_start; row.pad[0] = row.pad[1] = row.pad[2] = 0;
-                    A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
-                }
-                nfr++;
-                // Flush + Reset drop the queued tail (TMemSamples' queue; not TDownSample44_40's)
-                if (!A.keep_queue) vpos = avail_end;
-                frame_reset();
+        const bool ok = uni((int)so.ok) != 0;
+        const uint32_t r_nsym = ok ? (uint32_t)uni((int)so.nsym) : 0u, r_cr = ok ? (uint32_t)uni((int)so.cr) : 0u;
+        // the burst that carries the event: the SIGNAL symbol's last one (E_PLCP_HEADER_FAIL), else the last burst of the last data symbol (the Viterbi
+        // sub-graph will raise FRAME_OK / CRC32_FAIL); remain_symbols is a ushort (PHY_11a.hpp:405), nsym <= 835
+        const uint64_t ev = ok ? (uint64_t)sym_start + 80ull * (r_nsym + 1u) : (uint64_t)sym_start + 80ull;      // end of that burst
+        if (ev > NS) break;                                                          // frame runs past the capture: nothing more to report
+        // RxThread looks at error_code after the source call: the bursts that call still delivers are consumed, then Flush + Reset drop the queued tail
+        // (TMemSamples' queue; not TDownSample44_40's)
+        const uint32_t ce = call_end((uint32_t)ev), consumed_to = (uint32_t)ev + (((ce - (uint32_t)ev) >> 2) << 2);
+        const uint32_t s_next = A.keep_queue ? consumed_to : ce;
+        aim(s_next);                                                                 // (its samples are on their way while the row is written)
+        {
+            const bool has_row = nfr < A.max_frames;
+            const uint32_t slot0 = cd.slot_base + sym_start / 80u;
+            if (ok && has_row) {
+                // queue the frame for the per-frame kernels
+                if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
+                // its data symbols' slots (k_sym_front / k_sym_back)
+                if (A.slot_row) for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[slot0 + sy] = cap_i * A.max_frames + nfr;
+            }
+            if (lane == 0 && has_row) {
+                FrameRow row;
+                row.capture = cap_i; row.start_sample = frame_start; row.end_sample = ok ? (uint32_t)ev : consumed_to;
+                row.error_code = ok ? 0u : E_PLCP_HEADER_FAIL;                         // 0 = pending: decided by k_finish
+                row.rate_kbps = ok ? (uint32_t)uni((int)so.kbps) : 0u; row.length = (uint16_t)(ok ? (uint32_t)uni((int)so.len) : 0u); row.nsym = (uint16_t)r_nsym;
+                row.code_rate = (uint16_t)r_cr; row.nbpsc = (uint16_t)(ok ? (uint32_t)uni((int)so.nb) : 0u); row.slot0 = slot0; row.crc32 = 0;
+                row.cfo_est = (int16_t)r_cfo; row.cfo_comp = (int16_t)uni(so.cfo_comp); row.sfo_comp = (int16_t)uni(so.sfo_comp);
+                row.cfo_tracker = (int16_t)uni(so.cfo_tr); row.sfo_tracker = (int16_t)uni(so.sfo_tr); row.valid = 1;
+                row.data_start = sym_start; row.pad[0] = row.pad[1] = row.pad[2] = 0;
+                A.frames[(size_t)cap_i * A.max_frames + nfr] = row;
             }
         }
+        nfr++;
+        s = s_next;
+        to_pending = false; cca_detected = 0; cs_reset();                            // BB11aDemodCtx.Reset(), every brick's Reset (fb11a_demod.cpp:64-70)
         PROBE_A(_tc, 7);
-        // Nothing pending and the next burst lies source calls ahead (an idle pass takes up to eight bursts, a source call holds three and a half): go straight to the call
-        // that delivers it -- the calls in between would find no burst to run and no event to report.  (x / APP for APP = 14 or 28 as a multiply: exact below 2^31.)
-        if (error_code == 0 && !streaming && vpos + BUR > avail_end + APP && vpos < 0x7FFFFF00u) {
-            const uint32_t calls = (uint32_t)(((uint64_t)(vpos + BUR + APP - 1u) * 0x92492493ull) >> (STR == 1u ? 35 : 36));   // ceil((vpos + BUR) / APP)
-            c = calls - 2u;                                                      // (the for-loop's increment lands on call `calls - 1`, whose avail_end = calls x APP)
-        }
     }
     // the capture ends in plain carrier sense: all of it is final
-    if (streaming && vpos == nunits && !cca_detected && !sync_high && auto_count == 0 && error_code == 0) cont_save(vpos);
+    if (streaming && s == NS && !cca_detected && !sync_high && auto_count == 0 && !to_pending) cont_save(s);
     if (lane == 0) A.nframes[cap_i] = nfr;
     PROBE_ADDK(5);
 }

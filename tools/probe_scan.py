@@ -40,6 +40,6 @@ buf = (ctypes.c_ulonglong * 16)()
 L.sora_debug_scan_probe(buf, 1)
 rx.process_dev(d, descs); rx.flush()
 L.sora_debug_scan_probe(buf, 0)
-names = ["carrier sense, burst by burst", "T11aLTS", "SIGNAL chain", "fast_idle passes", "fast_sync passes", "whole kernel (capture 0)", "burst-by-burst iterations (incl. the first three rows)", "bookkeeping after a source call"]
+names = ["establish_sync", "T11aLTS", "SIGNAL chain", "carrier-sense passes (<= 8 bursts)", "check_sync passes (<= 16 bursts)", "whole kernel (capture 0)", "(unused)", "frame row + reset"]
 for i, nme in enumerate(names):
     print("%-32s %9d ticks  %5d times" % (nme, buf[i], buf[8 + i]))
