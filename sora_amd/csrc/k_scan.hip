@@ -68,6 +68,32 @@ __device__ __forceinline__ uint32_t group_scan(uint32_t t)
     return t;
 }
 
+// inclusive prefix sum over the sixteen 4-lane groups of the wave: row_shr:4, row_shr:8, row_bcast:15 into rows 1 / 3, row_bcast:31 into rows 2 and 3
+__device__ __forceinline__ uint32_t group_scan64(uint32_t t)
+{
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x114, 0xF, 0xF, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x118, 0xF, 0xF, true);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x142, 0xA, 0xF, false);
+    t += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)t, 0x143, 0xC, 0xF, false);
+    return t;
+}
+// the value of the lane 16 below; row 0 takes `first` (its own lanes')
+__device__ __forceinline__ uint32_t shift16(uint32_t v, uint32_t first)
+{
+    auto r16 = __builtin_amdgcn_permlane16_swap(v, v, false, false);             // [0] = rows {0, 0, 2, 2}, [1] = rows {1, 1, 3, 3}
+    auto r32 = __builtin_amdgcn_permlane32_swap(r16[1], r16[1], false, false);    // [0] = rows {1, 1, 1, 1}
+    const uint32_t l = threadIdx.x;
+    return l < 16u ? first : (l & 48u) == 32u ? r32[0] : r16[0];
+}
+// bits 0, 4, 8 .. 60 of x (nothing else set) -> bits 0 .. 15
+__device__ __forceinline__ uint32_t compress4(uint64_t x)
+{
+    x = (x | (x >> 3)) & 0x0303030303030303ull;
+    x = (x | (x >> 6)) & 0x000F000F000F000Full;
+    x = (x | (x >> 12)) & 0x000000FF000000FFull;
+    return (uint32_t)((x | (x >> 24)) & 0xFFFFull);
+}
+
 // Cross-lane sums and minima as DPP moves and row swaps (VALU latency) instead of ds_bpermute round trips through the LDS pipeline: this kernel is one wave per capture
 // walking a serial state machine, and what it waits for is mostly these (round 5: a lone capture's, or a sixteen-frame capture's, k_scan is 35 us per frame).
 template <int CTRL> __device__ __forceinline__ unsigned sdpp(unsigned v) { return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, true); }
@@ -125,164 +151,139 @@ __device__ __forceinline__ Tables tables_of(const ScanTabs& b)
     return T;
 }
 
-// ---- T11aLTS on the 144 samples at lts_start (channel_11a.hpp:206-330): CFO estimate, frequency shift, FFT<64>, channel inverse -> *fx.
-// Out of line (once per frame): its temporaries and table pointers stay out of the carrier-sense loop's register allocation.  Returns the CFO.
-__device__ __noinline__ int lts_section(ScanTabs tabs, uint32_t lts_start_, FrameCtx* fx_)
+// ---- the frame's header, out of line (once per frame: its temporaries and table pointers stay out of the carrier-sense loop's register allocation).
+// T11aLTS on the 144 samples at lts_start (channel_11a.hpp:206-330): CFO estimate, frequency shift, FFT<64>, channel inverse -> *fx; and the SIGNAL symbol
+// behind them: T11aDataSymbol .. T11aViterbiSig .. T11aPLCPParser (PHY_11a.hpp:389-580).  Nothing observable happens between the two bricks' firings, so
+// they run as one section: the two FFTs side by side in two groups of sixteen lanes (packed arithmetic, dev_arith.h), the frequency and channel
+// coefficients handed on in registers (and stored for the per-symbol kernels).  Every field of the result is wave-uniform.
+struct SigOut { uint32_t ok, kbps, len, nsym, cr, nb; int cfo_comp, sfo_comp, cfo_tr, sfo_tr, cfo; };
+__device__ __noinline__ SigOut header_section(ScanTabs tabs, uint32_t lts_start_, FrameCtx* fx_)
 {
     const Tables T = tables_of(tabs);
     FrameCtx* fx = uni_ptr(fx_);
-    const uint32_t lts_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)lts_start_);
-    __shared__ uint32_t s_fft[64];
-    __shared__ uint32_t s_x[64];
-    const int lane = threadIdx.x;
-    auto sync = []() { __syncthreads(); };
-                        // the 144 samples sit in the ring; x[n] = sample 8 + n; the first 64 are >>1 (rep_shift_right<16>, :216)
-                        cpx x1 = sra(unpack(s_ring[(lts_start + 8u + (uint32_t)lane) & (kRing - 1u)]), 1);
-                        cpx x2 = unpack(s_ring[(lts_start + 72u + (uint32_t)lane) & (kRing - 1u)]);
-                        int re, im; conj_mul32(x2, x1, re, im);                       // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
-                        const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
-                        const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
-                        const int cfo = arg >> 6;                   // size_t divisor: unsigned division = floor (dspalg.hpp:242)
-                        // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
-                        const cpx fc = rot_coeff(T, w16(lane * cfo));
-                        fx->freq[lane] = pack(fc);
-                        cpx xs = mul_q15(x1, fc);                                     // FrequencyShift (:120)
-                        sync();
-                        s_x[lane] = pack(xs);
-                        sync();
-                        // FFT<64> on lanes 0..15
-                        cpx Y[4];
-                        {
-                            const int e = lane & 15;
-                            cpx xin[4];
-    #pragma unroll
-                            for (int m = 0; m < 4; m++) xin[m] = unpack(s_x[e + 16 * m]);
-                            fft64_group(xin, Y, s_fft, e, T, sync);                    // all lanes call (barriers); results identical per 16-lane group
-                        }
-                        // lane L (0..63) takes bin L: Y of group lane (L&15), register (L>>4)
-                        {
-                            cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
-                            uint32_t coef = 0;
-                            if (!(lane >= 28 && lane < 36)) {                          // _channel_estimation (:125-178)
-                                const int e = sqnorm(Yb) >> 8;
-                                const cpx L = mk(kLtsSeq[lane] ? 1600 : -1600, 0);
-                                int cre, cim; conj_mul32(L, Yb, cre, cim);
-                                int rre = 0, rim = 0;
-                                if (e != 0) { rre = cre / e; rim = cim / e; }
-                                coef = pack(mk(w16(rre), w16(rim)));
-                            }
-                            fx->chan[lane] = coef;
-                        }
-                        __threadfence_block();
-                        sync();
-    return cfo;
-}
-
-// ---- the SIGNAL symbol at sym_start: T11aDataSymbol .. T11aViterbiSig .. T11aPLCPParser (PHY_11a.hpp:389-580), lane-parallel; out of line
-// like lts_section.  Every field of the result is wave-uniform.
-struct SigOut { uint32_t ok, kbps, len, nsym, cr, nb; int cfo_comp, sfo_comp, cfo_tr, sfo_tr; };
-__device__ __noinline__ SigOut signal_section(ScanTabs tabs, uint32_t sym_start_, const FrameCtx* fx_)
-{
-    const Tables T = tables_of(tabs);
-    const FrameCtx* fx = uni_ptr(fx_);
-    const uint32_t sym_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)sym_start_);
-    __shared__ uint32_t s_fft[64];
-    __shared__ uint8_t  s_soft[48];
-    const int lane = threadIdx.x;
-    auto sync = []() { __syncthreads(); };
-                            // ---- the SIGNAL symbol: full header chain, lane-parallel
-                            const int e = lane & 15;
-                            cpx xin[4], Y[4];
-    #pragma unroll
-                            for (int m = 0; m < 4; m++) {                              // skip CP 8, >>1, x FreqCoeffs (channel_11a.hpp:643-644)
-                                const int n = e + 16 * m;
-                                cpx x = sra(unpack(s_ring[(sym_start + 8u + (uint32_t)n) & (kRing - 1u)]), 1);
-                                xin[m] = mul_q15(x, unpack(fx->freq[n]));
-                            }
-                            fft64_group(xin, Y, s_fft, e, T, sync);
-                            cpx Yb = (lane >> 4) == 0 ? Y[0] : (lane >> 4) == 1 ? Y[1] : (lane >> 4) == 2 ? Y[2] : Y[3];
-                            cpx eq = mk(0, 0);
-                            if (!(lane >= 28 && lane < 36)) {                          // TChannelEqualization (channel_11a.hpp:548-574)
-                                int re, im; mul32(Yb, unpack(fx->chan[lane]), re, im);
-                                eq = mk(w16(re >> 8), w16(im >> 8));
-                            }
-                            // TPhaseCompensate with the reset CompCoeffs (0x7fff, 0) (ieee80211facade.hpp:198-206)
-                            cpx pc = mul_q15(eq, mk(0x7fff, 0));
-                            sync();
-                            s_fft[lane] = pack(pc);
-                            sync();
-                            // _pilot_track (pilot.hpp:166-233), symbol_count = 127 -> PilotSgn[127] = 0
-                            cpx p43 = unpack(s_fft[43]), p57 = unpack(s_fft[57]), p7 = unpack(s_fft[7]), p21 = unpack(s_fft[21]);
-                            const int th1 = __builtin_amdgcn_readfirstlane(uatan2(T, p43.im, p43.re)), th2 = __builtin_amdgcn_readfirstlane(uatan2(T, p57.im, p57.re));
-                            const int th3 = __builtin_amdgcn_readfirstlane(uatan2(T, p7.im, p7.re)),   th4 = __builtin_amdgcn_readfirstlane(uatan2(T, -p21.im, -p21.re));
-                            const int avg = w16((th1 + th2 + th3 + th4) / 4);
-                            const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
-                            const int cfo_tracker = w16(avg >> 2), sfo_tracker = w16(del >> 2);
-                            const int cfo_comp = w16(avg + cfo_tracker), sfo_comp = w16(del + sfo_tracker);
-                            // T11aDemapBPSK on the rotated carriers -> T11aDeinterleaveBPSK
-                            if (lane < 48) {
-                                const int bin = carrier_bin(lane);
-                                const int cidx = bin < 32 ? bin : bin - 64;            // signed carrier number
-                                cpx r = mul_q15(unpack(s_fft[bin]), rot_coeff(T, w16(avg + cidx * del)));
-                                int v = r.re >> 4; v = min(max(v, -128), 127);         // demap_limit (demapper.h:141-151)
-                                s_soft[lane] = T.demap[(unsigned)v & 0xFF];
-                            }
-                            sync();
-                            uint8_t sa = 0, sb = 0;                                     // de-interleaved soft pair of trellis step t = lane (t < 24)
-                            if (lane < 24) { sa = s_soft[T.deint[2 * lane]]; sb = s_soft[T.deint[2 * lane + 1]]; }
-                            // ---- Viterbi_sig11 (viterbicore.h:35-261): lane = state
-                            const int n = lane;
-                            const int r0 = n, r1 = 64 | n;
-                            const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
-                            const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
-                            unsigned m = (n == 0) ? 0u : 0x30u;
-                            uint64_t dec[25];                                           // the 64 states' decisions per step: scalars (the loops are unrolled), not an LDS array
-                            dec[0] = 0;
-    #pragma unroll
-                            for (int t = 1; t <= 24; t++) {
-                                const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
-                                const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
-                                const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
-                                const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
-                                const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
-                                m = min(c0, c1);
-                                dec[t] = __ballot(m & 1);
-                                if ((t & 7) == 0) m = (m - (wave_min(m) & 0xFE)) & 0xFF;
-                            }
-                            // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
-                            const unsigned key = (m << 8) | ((unsigned)n << 2);
-                            const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min(key));
-                            int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
-                            uint32_t sig = 0;
-    #pragma unroll
-                            for (int b = 0; b < 24; b++) {
-                                // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
-                                sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
-                                pos = (pos >> 1) & 0x3F;
-                                pos |= (int)((dec[23 - b] >> pos) & 1) << 6;
-                            }
-                            sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;     // viterbi.hpp:39 (wave-uniform)
-                            // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
-                            bool ok = true;
-                            sig &= 0xFFFFFF;
-                            if (sig & 0xFC0010) ok = false;
-                            uint32_t par = (sig >> 16) ^ sig; par = (par >> 8) ^ par; par = (par >> 4) ^ par; par = (par >> 2) ^ par; par = (par >> 1) ^ par;
-                            if (par & 1) ok = false;
-                            uint32_t kbps = 0; int nd = 0, nb = 0, cr = 0;
-                            switch (sig & 0xF) {                                        // ieee80211a_cmn.h:97-107, :65-94, :114-149
-                            case 0x8: kbps = 48000; nd = 192; nb = 6; cr = 1; break;  case 0x9: kbps = 24000; nd = 96;  nb = 4; cr = 0; break;
-                            case 0xA: kbps = 12000; nd = 48;  nb = 2; cr = 0; break;  case 0xB: kbps = 6000;  nd = 24;  nb = 1; cr = 0; break;
-                            case 0xC: kbps = 54000; nd = 216; nb = 6; cr = 2; break;  case 0xD: kbps = 36000; nd = 144; nb = 4; cr = 2; break;
-                            case 0xE: kbps = 18000; nd = 72;  nb = 2; cr = 2; break;  case 0xF: kbps = 9000;  nd = 36;  nb = 1; cr = 2; break;
-                            default: ok = false; break;
-                            }
-                            const uint32_t len = (sig >> 5) & 0xFFF;
-                            if (len > 2500) ok = false;
-                            SigOut O;
-                            O.ok = ok ? 1u : 0u; O.kbps = kbps; O.len = len; O.cr = (uint32_t)cr; O.nb = (uint32_t)nb;
-                            O.nsym = ok ? (len * 8 + 16 + 6 + (uint32_t)nd - 1) / (uint32_t)nd : 0u;                  // B11aGetSymbolCount
-                            O.cfo_comp = cfo_comp; O.sfo_comp = sfo_comp; O.cfo_tr = cfo_tracker; O.sfo_tr = sfo_tracker;
-                            sync();
+    const uint32_t lts_start = (uint32_t)__builtin_amdgcn_readfirstlane((int)lts_start_), sym_start = lts_start + 144u;
+    __shared__ uint32_t s_a[64], s_b[64];
+    __shared__ uint8_t  s_soft[64];
+    const int lane = threadIdx.x, e = lane & 15;
+    auto sync = []() { wave_lds_sync(); };
+    // table reads that depend on no sample: issued first
+    const Fft64TwPk W = fft64_twiddles_pk(T, e);
+    const int t2 = lane < 24 ? 2 * lane : 0;
+    const int d0 = T.deint[t2], d1 = T.deint[t2 + 1];                          // T11aDeinterleaveBPSK: the two carriers of trellis step t = lane
+    // the samples sit in the ring.  LTS: x[n] = sample 8 + n, the first 64 are >>1 (rep_shift_right<16>, :216); SIGNAL: skip CP 8, >>1 (channel_11a.hpp:643-644)
+    const cpx x1 = sra(unpack(s_ring[(lts_start + 8u + (uint32_t)lane) & (kRing - 1u)]), 1);
+    const cpx x2 = unpack(s_ring[(lts_start + 72u + (uint32_t)lane) & (kRing - 1u)]);
+    const cpx sg = sra(unpack(s_ring[(sym_start + 8u + (uint32_t)lane) & (kRing - 1u)]), 1);
+    int re, im; conj_mul32(x2, x1, re, im);                                    // FreqOffsetEstimate<16> (dspalg.hpp:226-243)
+    const int sum_re = __builtin_amdgcn_readfirstlane(wave_sum(re >> 5)), sum_im = __builtin_amdgcn_readfirstlane(wave_sum(im >> 5));
+    const int arg = __builtin_amdgcn_readfirstlane(uatan2(T, sum_im, sum_re));
+    const int cfo = arg >> 6;                                                  // size_t divisor: unsigned division = floor (dspalg.hpp:242)
+    // BuildFrequencyShiftCoeffs<64>(.., 0, CFO_est): ph = lane*cfo (mod 2^16)   (dspalg.hpp:200-208)
+    const cpx fc = rot_coeff(T, w16(lane * cfo));
+    fx->freq[lane] = pack(fc);
+    s_a[lane] = pack(mul_q15(x1, fc));                                         // FrequencyShift (:120)
+    s_b[lane] = pack(mul_q15(sg, fc));                                         // TFreqCompensation
+    // FFT<64> twice: lanes 0..15 the LTS, lanes 16..31 the SIGNAL symbol (lanes 32..63 mirror them: same values to the same words)
+    {
+        uint32_t* const sf = (lane & 16) ? s_b : s_a;
+        sync();
+        const pcx xin[4] = { sf[e], sf[e + 16], sf[e + 32], sf[e + 48] };
+        fft64_core_pk(xin, sf, e, W, sync);                                    // bin j at slot bitrev6(j)
+    }
+    const unsigned slot = __brev((unsigned)lane) >> 26;                        // lane L takes bin L
+    const cpx Yl = unpack(s_a[slot]), Ys = unpack(s_b[slot]);
+    cpx eq = mk(0, 0);
+    {
+        uint32_t coef = 0;
+        if (!(lane >= 28 && lane < 36)) {                                      // _channel_estimation (:125-178)
+            const int en = sqnorm(Yl) >> 8;
+            const cpx L = mk(kLtsSeq[lane] ? 1600 : -1600, 0);
+            int cre, cim; conj_mul32(L, Yl, cre, cim);
+            int rre = 0, rim = 0;
+            if (en != 0) { rre = cre / en; rim = cim / en; }
+            coef = pack(mk(w16(rre), w16(rim)));
+            int qr, qi; mul32(Ys, unpack(coef), qr, qi);                       // TChannelEqualization (channel_11a.hpp:548-574)
+            eq = mk(w16(qr >> 8), w16(qi >> 8));
+        }
+        fx->chan[lane] = coef;
+    }
+    // TPhaseCompensate with the reset CompCoeffs (0x7fff, 0) (ieee80211facade.hpp:198-206)
+    const cpx pc = mul_q15(eq, mk(0x7fff, 0));
+    const uint32_t ppc = pack(pc);
+    // _pilot_track (pilot.hpp:166-233), symbol_count = 127 -> PilotSgn[127] = 0
+    const cpx p43 = unpack((uint32_t)__builtin_amdgcn_readlane((int)ppc, 43)), p57 = unpack((uint32_t)__builtin_amdgcn_readlane((int)ppc, 57));
+    const cpx p7 = unpack((uint32_t)__builtin_amdgcn_readlane((int)ppc, 7)), p21 = unpack((uint32_t)__builtin_amdgcn_readlane((int)ppc, 21));
+    const int th1 = __builtin_amdgcn_readfirstlane(uatan2(T, p43.im, p43.re)), th2 = __builtin_amdgcn_readfirstlane(uatan2(T, p57.im, p57.re));
+    const int th3 = __builtin_amdgcn_readfirstlane(uatan2(T, p7.im, p7.re)),   th4 = __builtin_amdgcn_readfirstlane(uatan2(T, -p21.im, -p21.re));
+    const int avg = w16((th1 + th2 + th3 + th4) / 4);
+    const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+    const int cfo_tracker = w16(avg >> 2), sfo_tracker = w16(del >> 2);
+    const int cfo_comp = w16(avg + cfo_tracker), sfo_comp = w16(del + sfo_tracker);
+    // T11aDemapBPSK on the rotated carriers, every bin in its own lane -> T11aDeinterleaveBPSK
+    {
+        const int cidx = lane < 32 ? lane : lane - 64;                         // signed carrier number
+        const cpx r = mul_q15(pc, rot_coeff(T, w16(avg + cidx * del)));
+        int v = r.re >> 4; v = min(max(v, -128), 127);                         // demap_limit (demapper.h:141-151)
+        // DemapperCore's BPSK step function (demapper.h:55-130): the soft value is the number of steps at or below v
+        s_soft[lane] = (uint8_t)((v >= -30) + (v >= -17) + (v >= -8) + (v >= 0) + (v >= 9) + (v >= 18) + (v >= 31));
+    }
+    sync();
+    uint8_t sa = 0, sb = 0;                                                     // de-interleaved soft pair of trellis step t = lane (t < 24)
+    if (lane < 24) { sa = s_soft[carrier_bin(d0)]; sb = s_soft[carrier_bin(d1)]; }
+    // ---- Viterbi_sig11 (viterbicore.h:35-261): lane = state
+    const int n = lane;
+    const int r0 = n, r1 = 64 | n;
+    const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
+    const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
+    unsigned m = (n == 0) ? 0u : 0x30u;
+    uint64_t dec[25];                                                           // the 64 states' decisions per step: scalars (the loops are unrolled), not an LDS array
+    dec[0] = 0;
+#pragma unroll
+    for (int t = 1; t <= 24; t++) {
+        const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
+        const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
+        const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
+        const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
+        const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
+        m = min(c0, c1);
+        dec[t] = __ballot(m & 1);
+        if ((t & 7) == 0) m = (m - (wave_min(m) & 0xFE)) & 0xFF;
+    }
+    // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
+    const unsigned key = (m << 8) | ((unsigned)n << 2);
+    const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min(key));
+    int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
+    uint32_t sig = 0;
+#pragma unroll
+    for (int b = 0; b < 24; b++) {
+        // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
+        sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
+        pos = (pos >> 1) & 0x3F;
+        pos |= (int)((dec[23 - b] >> pos) & 1) << 6;
+    }
+    sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;             // viterbi.hpp:39 (wave-uniform)
+    // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
+    bool ok = true;
+    sig &= 0xFFFFFF;
+    if (sig & 0xFC0010) ok = false;
+    uint32_t par = (sig >> 16) ^ sig; par = (par >> 8) ^ par; par = (par >> 4) ^ par; par = (par >> 2) ^ par; par = (par >> 1) ^ par;
+    if (par & 1) ok = false;
+    uint32_t kbps = 0; int nd = 0, nb = 0, cr = 0;
+    switch (sig & 0xF) {                                                        // ieee80211a_cmn.h:97-107, :65-94, :114-149
+    case 0x8: kbps = 48000; nd = 192; nb = 6; cr = 1; break;  case 0x9: kbps = 24000; nd = 96;  nb = 4; cr = 0; break;
+    case 0xA: kbps = 12000; nd = 48;  nb = 2; cr = 0; break;  case 0xB: kbps = 6000;  nd = 24;  nb = 1; cr = 0; break;
+    case 0xC: kbps = 54000; nd = 216; nb = 6; cr = 2; break;  case 0xD: kbps = 36000; nd = 144; nb = 4; cr = 2; break;
+    case 0xE: kbps = 18000; nd = 72;  nb = 2; cr = 2; break;  case 0xF: kbps = 9000;  nd = 36;  nb = 1; cr = 2; break;
+    default: ok = false; break;
+    }
+    const uint32_t len = (sig >> 5) & 0xFFF;
+    if (len > 2500) ok = false;
+    SigOut O;
+    O.ok = ok ? 1u : 0u; O.kbps = kbps; O.len = len; O.cr = (uint32_t)cr; O.nb = (uint32_t)nb;
+    O.nsym = ok ? (len * 8 + 16 + 6 + (uint32_t)nd - 1) / (uint32_t)nd : 0u;                  // B11aGetSymbolCount
+    O.cfo_comp = cfo_comp; O.sfo_comp = sfo_comp; O.cfo_tr = cfo_tracker; O.sfo_tr = sfo_tracker; O.cfo = cfo;
+    __threadfence_block();
+    sync();
     return O;
 }
 
@@ -408,18 +409,21 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     auto uni = [](int v) { return __builtin_amdgcn_readfirstlane(v); };
 
     for (;;) {
+        PROBE_T(_tg);
         if (to_pending && s + 4u > pend_end) {      // the source call that raised E_CS_TIMEOUT is over: ResetCarrierSense(); scs->Reset()
             to_pending = false; cca_detected = 0; cs_reset();
         }
         if (s + 4u > NS) break;
         if (!sync_high) {
-            // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator, up to eight bursts at once, one sample per lane (lane = 4 b + e; lanes 32..63 mirror
-            // lanes 0..31).  The per-sample products run once, the sliding sums are prefix sums over the burst groups, and the reference's test (cca.hpp:386-437)
+            // ================= TDCRemoveEx<4> -> TCCA11a -> TDCEstimator, up to sixteen bursts at once, one sample per lane (lane = 4 b + e).
+            // The per-sample products run once, the sliding sums are prefix sums over the burst groups, and the reference's test (cca.hpp:386-437)
             // is evaluated for every burst of the pass; what the tests mean -- auto_count reaching four (establish_sync), sense_count, the time-out -- follows
-            // from the ballot.  A pass holds a DC update at most at its last burst (the estimate changes what the next burst sees) and ends with the burst
-            // that calls establish_sync.
+            // from the ballot.  The DC estimate moves every eighth burst and changes what the bursts behind it see: a pass holds at most one such update
+            // inside (burst p: the lanes behind it subtract the new estimate, which only needs the sums up to p) and one at its last burst.  A pass ends with
+            // the burst that calls establish_sync.
             const bool plain = !to_pending && auto_count == 0;
-            uint32_t K = min(min((NS - s) >> 2, dc_cnt + 1u), 8u);
+            const uint32_t p = dc_cnt;                                           // the burst of this pass that updates the estimate
+            uint32_t K = min(min((NS - s) >> 2, p + 9u), 16u);
             uint32_t jraise = 0xFFFFu, ce_raise = 0;                             // the burst of this pass at which E_CS_TIMEOUT would be raised, and the end of its source call
             if (to_pending) K = min(K, (pend_end - s) >> 2);
             else {
@@ -435,60 +439,66 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                 const uint32_t j = (3u * (m >> 1)) % 7u;
                 K = min(K, j ? j : 7u);
             }
+            PROBE_A(_tg, 1);
             PROBE_T0();
-            fill(s, 32u);
-            const uint32_t l = (uint32_t)lane & 31u, hi = (uint32_t)lane & 32u;
-            const cpx x = unpack(s_ring[(s + l) & (kRing - 1u)]);
-            const cpx pi = mk(w16(x.re - dc_re), w16(x.im - dc_im));                // TDCRemoveEx
+            fill(s, 64u);
+            const cpx x = unpack(s_ring[(s + (uint32_t)lane) & (kRing - 1u)]);
+            int dcr = dc_re, dci = dc_im;                                        // TDCRemoveEx's operand, per lane
+            if (p + 1u < K) {
+                // the update at burst p: TDCEstimator's sums (dc.hpp:132-163) over bursts 0 .. p with the present estimate
+                const unsigned hr = group_scan64(quad_sum((unsigned)(w16(x.re - dc_re) >> 5))), hi_ = group_scan64(quad_sum((unsigned)(w16(x.im - dc_im) >> 5)));
+                const int sr = w16(sum_dc_re + __builtin_amdgcn_readlane((int)hr, (int)(4u * p))), si = w16(sum_dc_im + __builtin_amdgcn_readlane((int)hi_, (int)(4u * p)));
+                const int d1r = w16(dc_re + (sr >> 2)), d1i = w16(dc_im + (si >> 2));
+                const bool behind = (uint32_t)lane > 4u * p + 3u;
+                dcr = behind ? d1r : dc_re; dci = behind ? d1i : dc_im;
+            }
+            const cpx pi = mk(w16(x.re - dcr), w16(x.im - dci));                    // TDCRemoveEx
             const cpx pii = sra(pi, 2);
             const uint32_t ppk = pack(pii);
-            const uint32_t prev = other_row_even(ppk);                              // the sample 16 lanes below (used by the second row of each half only)
-            int re, im; conj_mul32(pii, unpack(l < 16u ? Hv : prev), re, im);       // GetAutoCorrelation (cca.hpp:165-186): against the sample 16 earlier
+            const uint32_t prev = shift16(ppk, Hv);                                 // the sample 16 earlier: the history for the first four bursts
+            int re, im; conj_mul32(pii, unpack(prev), re, im);                      // GetAutoCorrelation (cca.hpp:165-186)
             unsigned vr = (unsigned)(re >> 4), vi = (unsigned)(im >> 4), ve = (unsigned)(sqnorm(pii) >> 4);   // GetEnergy (cca.hpp:188-193)
-            unsigned dr = (unsigned)(pi.re >> 5), di = (unsigned)(pi.im >> 5);     // TDCEstimator terms
             vr = quad_sum(vr); vi = quad_sum(vi); ve = quad_sum(ve);                // a burst's four samples sit in one quad
-            dr = quad_sum(dr); di = quad_sum(di);
+            const uint32_t Dr = group_scan64(quad_sum((unsigned)(pi.re >> 5))), Di = group_scan64(quad_sum((unsigned)(pi.im >> 5)));   // TDCEstimator terms
             // the K bursts' sliding sums at once.  After burst b the accumulator holds reg + sum_{i<=b} (d_i - z_i), z = the value that leaves the
             // 4-element window: the old elements for b < 4, d_{b-4} after that.  One prefix sum per stream over the burst groups.
-            const bool second_row = (l & 16u) != 0u;
-            // (every lane takes part: a cross-lane read inside a lane-dependent branch would find its source lanes switched off)
-            const uint32_t pr = other_row_even(vr), pim = other_row_even(vi), pe = other_row_even(ve);
-            const uint32_t zr = second_row ? pr : ac_re.Z, zi = second_row ? pim : ac_im.Z, ze = second_row ? pe : energy.Z;
-            const uint32_t Rr = (uint32_t)ac_re.reg + group_scan(vr - zr), Ri = (uint32_t)ac_im.reg + group_scan(vi - zi), Re = (uint32_t)energy.reg + group_scan(ve - ze);
-            const uint32_t Dr = group_scan(dr), Di = group_scan(di);
+            const uint32_t Rr = (uint32_t)ac_re.reg + group_scan64(vr - shift16(vr, ac_re.Z)), Ri = (uint32_t)ac_im.reg + group_scan64(vi - shift16(vi, ac_im.Z)),
+                           Re = (uint32_t)energy.reg + group_scan64(ve - shift16(ve, energy.Z));
             const int iAuto_v = abs((int)Rr) + abs((int)Ri), iEnergy_v = (int)Re;
             const bool carrier = iEnergy_v > (int)A.thr && iAuto_v >= iEnergy_v - (iEnergy_v >> 3);
-            const uint32_t hits = (uint32_t)__ballot(carrier) & 0x11111111u & (K >= 8u ? 0xFFFFFFFFu : ((1u << (4u * K)) - 1u));   // bit 4 b: burst b's test
+            // bit b: burst b's test
+            const uint32_t hits = compress4((uint64_t)__ballot(carrier) & 0x1111111111111111ull) & ((1u << K) - 1u);
             // auto_count (cca.hpp:400-414): consecutive true tests, establish_sync at every true test from the fourth on: the first run of four in
             // {the a tests that were true before the pass, this pass's tests}
             const uint32_t a = min(auto_count, 3u);
-            const uint64_t M = ((uint64_t)hits << (4u * a)) | (uint64_t)(0x111u >> (12u - 4u * a));
-            const uint64_t run = M & (M >> 4) & (M >> 8) & (M >> 12);
+            const uint32_t M = (hits << a) | ((1u << a) - 1u);
+            const uint32_t run = M & (M >> 1) & (M >> 2) & (M >> 3);
             const bool est = run != 0;
-            const uint32_t done = est ? ((uint32_t)__builtin_ctzll(run) >> 2) + 4u - a : K;          // bursts taken
-            const uint32_t bits = done >= 8u ? 0x11111111u : (0x11111111u & ((1u << (4u * done)) - 1u));
+            const uint32_t done = est ? (uint32_t)__builtin_ctz(run) + 4u - a : K;                   // bursts taken
+            const uint32_t bits = (1u << done) - 1u;
             const uint32_t th = hits & bits;                                         // the tests of the bursts taken
             if (est) auto_count = 4;
             else {
                 const uint32_t inv = ~th & bits;                                     // ... that were false: auto_count = the true tests behind the last of them
-                auto_count = inv ? done - 1u - ((31u - (uint32_t)__builtin_clz(inv)) >> 2) : min(auto_count + done, 4u);
+                auto_count = inv ? done - 1u - (31u - (uint32_t)__builtin_clz(inv)) : min(auto_count + done, 4u);
             }
             // sense_count (cca.hpp:398, :402, :433-437): + 4 per burst, 0 at a true test; E_CS_TIMEOUT from 84 on
-            if (!to_pending && jraise < min(th ? (uint32_t)__builtin_ctz(th) >> 2 : done, done)) { to_pending = true; pend_end = ce_raise; }
-            sense_count = th ? 4u * (done - 1u - ((31u - (uint32_t)__builtin_clz(th)) >> 2)) : sense_count + 4u * done;
+            if (!to_pending && jraise < min(th ? (uint32_t)__builtin_ctz(th) : done, done)) { to_pending = true; pend_end = ce_raise; }
+            sense_count = th ? 4u * (done - 1u - (31u - (uint32_t)__builtin_clz(th))) : sense_count + 4u * done;
             {
                 const int last = (int)(4u * (done - 1u));
                 ac_re.reg = __builtin_amdgcn_readlane((int)Rr, last); ac_im.reg = __builtin_amdgcn_readlane((int)Ri, last); energy.reg = __builtin_amdgcn_readlane((int)Re, last);
                 // the windows <- the last four of {old window, d_0 .. d_{done-1}} (element g in lanes 4 g .. 4 g + 3 of every row); history <- its last 16 samples
-                const uint32_t a16 = (uint32_t)lane & 15u, src = a16 + 4u * done;   // index in {old 0..15, new 16..47}
-                const int from_old = (int)(((uint32_t)lane & 48u) | (src & 15u)), from_new = (int)(hi | ((src - 16u) & 31u));
-                const bool old = src < 16u;
-                const uint32_t kr = (uint32_t)__shfl((int)ac_re.Z, from_old), fr = (uint32_t)__shfl((int)vr, from_new);
-                const uint32_t ki = (uint32_t)__shfl((int)ac_im.Z, from_old), fi = (uint32_t)__shfl((int)vi, from_new);
-                const uint32_t ke = (uint32_t)__shfl((int)energy.Z, from_old), fe = (uint32_t)__shfl((int)ve, from_new);
-                const uint32_t keep = (uint32_t)__shfl((int)Hv, from_old), fresh = (uint32_t)__shfl((int)ppk, from_new);
-                ac_re.Z = old ? kr : fr; ac_im.Z = old ? ki : fi; energy.Z = old ? ke : fe;
-                Hv = old ? keep : fresh;
+                const uint32_t src = ((uint32_t)lane & 15u) + 4u * done;            // index in {old 0..15, new 16..79}
+                const int from_old = (int)(((uint32_t)lane & 48u) | (src & 15u)), from_new = (int)(src - 16u);
+                const uint32_t fr = (uint32_t)__shfl((int)vr, from_new), fi = (uint32_t)__shfl((int)vi, from_new), fe = (uint32_t)__shfl((int)ve, from_new);
+                const uint32_t fresh = (uint32_t)__shfl((int)ppk, from_new);
+                if (done < 4u) {
+                    const bool old = src < 16u;
+                    const uint32_t kr = (uint32_t)__shfl((int)ac_re.Z, from_old), ki = (uint32_t)__shfl((int)ac_im.Z, from_old), ke = (uint32_t)__shfl((int)energy.Z, from_old);
+                    const uint32_t keep = (uint32_t)__shfl((int)Hv, from_old);
+                    ac_re.Z = old ? kr : fr; ac_im.Z = old ? ki : fi; energy.Z = old ? ke : fe; Hv = old ? keep : fresh;
+                } else { ac_re.Z = fr; ac_im.Z = fi; energy.Z = fe; Hv = fresh; }
             }
             s += 4u * done;
             PROBE_ADD(3);
@@ -522,17 +532,23 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
                 }
                 PROBE_ADD(0);
             }
-            // TDCEstimator (dc.hpp:92-166) is fed by every burst that leaves carrier sense unlocked: 16-bit running sums; the estimate moves at most at the pass's last burst
+            // TDCEstimator (dc.hpp:92-166) is fed by every burst that leaves carrier sense unlocked: 16-bit running sums, the estimate moves when dc_cnt is used up
+            // (burst p, and eight bursts on: a pass's last burst at most)
             const uint32_t ndc = done - (sync_high ? 1u : 0u);
-            if (ndc) {
+            if (ndc > p) {
+                const int at_p = __builtin_amdgcn_readlane((int)Dr, (int)(4u * p)), at_pi = __builtin_amdgcn_readlane((int)Di, (int)(4u * p));
+                dc_re = w16(dc_re + (w16(sum_dc_re + at_p) >> 2)); dc_im = w16(dc_im + (w16(sum_dc_im + at_pi) >> 2));
+                const uint32_t n1 = ndc - 1u - p;                                    // bursts fed behind the update
+                const int lastd = (int)(4u * (ndc - 1u));
+                const int seg_re = w16(__builtin_amdgcn_readlane((int)Dr, lastd) - at_p), seg_im = w16(__builtin_amdgcn_readlane((int)Di, lastd) - at_pi);
+                if (n1 == 8u) { dc_re = w16(dc_re + (seg_re >> 2)); dc_im = w16(dc_im + (seg_im >> 2)); sum_dc_re = sum_dc_im = 0; dc_cnt = 7; }
+                else { sum_dc_re = seg_re; sum_dc_im = seg_im; dc_cnt = 7u - n1; }
+            } else if (ndc) {
                 const int lastd = (int)(4u * (ndc - 1u));
                 sum_dc_re = w16(sum_dc_re + __builtin_amdgcn_readlane((int)Dr, lastd));
                 sum_dc_im = w16(sum_dc_im + __builtin_amdgcn_readlane((int)Di, lastd));
+                dc_cnt -= ndc;
             }
-            if (ndc == dc_cnt + 1u) {
-                dc_re = w16(dc_re + (sum_dc_re >> 2)); dc_im = w16(dc_im + (sum_dc_im >> 2));
-                dc_cnt = 7; sum_dc_re = sum_dc_im = 0;
-            } else dc_cnt -= ndc;
             continue;
         }
 
@@ -598,13 +614,13 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         // the frame's last burst are positions.
         const uint32_t lts_start = s, sym_start = s + 144u;
         if (sym_start + 80u > NS) break;                                             // the capture ends inside the preamble: nothing more to report
+        PROBE_T(_tf);
         fill(lts_start, 224u);
+        PROBE_A(_tf, 6);
         FrameCtx* const fx = ctx_of(nfr);
-        PROBE_T(_tl);
-        const int r_cfo = uni(lts_section(tabs, lts_start, fx));
-        PROBE_A(_tl, 1);
         PROBE_T(_ts);
-        const SigOut so = signal_section(tabs, sym_start, fx);
+        const SigOut so = header_section(tabs, lts_start, fx);
+        const int r_cfo = uni(so.cfo);
         PROBE_A(_ts, 2);
         PROBE_T(_tc);
         const bool ok = uni((int)so.ok) != 0;
