@@ -35,7 +35,8 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-#define SORA_HIP_ABI_VERSION 3
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats. */
+#define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */
 typedef struct { int16_t re, im; } sora_complex16;
@@ -46,7 +47,7 @@ typedef struct { int16_t re, im; } sora_complex16;
 #define SORA_E_PARAMETER         ((int)0x80000001)
 #define SORA_E_PLCP_HEADER_FAIL  ((int)0x80000005)
 #define SORA_E_CRC32_FAIL        ((int)0x80000006)
-#define SORA_E_INTERNAL_TIMEOUT  ((int)0x8000F001) /* not a code of the reference: a bounded wait inside k_pipe expired (sora_rx_set_front) -- no result for the frame */
+#define SORA_E_INTERNAL_TIMEOUT  ((int)0x8000F001) /* retired (ABI 3 reported a frame with it when a bounded wait inside k_pipe expired); since ABI 4 no row carries it: the call is redone on the device */
 #define SORA_ERR_FAILED          ((int)0x8000FFFF)  /* BK_ERROR_FAILED */
 #define SORA_ERR_HARDWARE_FAILED ((int)0x8000FFFE)  /* BK_ERROR_HARDWARE_FAILED: a HIP call failed */
 #define SORA_ERR_INVALID_PARAM   (-1)               /* BK_ERROR_INVALID_PARAM */
@@ -220,7 +221,9 @@ int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
  *                    overlap, fb11a_demod.cpp:109-112, inside a frame): the one for a handful of frames (a single capture).  (Its trellis units run two per wave in k_viterbi's
  *                    64-lane layout while the handle's calls in flight are few enough for that many workgroups -- a lone capture with up to three calls in flight --, eight per wave otherwise.)  Used only with the window-parallel trellis and
  *                    where every workgroup of the handle's calls in flight is resident at once (at most three quarters of the device's compute units: 192 on an MI355X); otherwise a request for 4 runs as 3.  Its hand-offs
- *                    are bounded waits: should one ever expire, the call's frames are reported with error_code SORA_E_INTERNAL_TIMEOUT instead of a result;
+ *                    are bounded waits (sora_rx_set_pipe_wait_us): should one expire -- another process or other GPU work holds the compute units its workgroups need -- the
+ *                    launch's finishing kernel makes the call's data field again with form 1's code and the serial trellis, so the call still delivers the reference's rows
+ *                    (never an error code of this library's own), and the handle keeps to form 3 for its next 64 calls (sora_rx_pipe_stats counts both);
  *                    it is the form for an otherwise idle chip -- each of its workgroups takes a whole CU's LDS, so beside a chip kept full by other handles its launch waits for CUs
  *                    to drain and form 3 is the faster one (measured: 3.3 against 1.3 ms median beside eight 4096-capture calls in flight; tools/pipe_under_load.py);
  *   0   (default)    chosen by the library: 4 while depth x max_captures x max_frames_per_capture <= 16 (and it fits, and no batch-sized handle of this process has used
@@ -228,6 +231,12 @@ int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
  * Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_front(sora_rx_t* rx, int kernels);
 int  sora_rx_front(sora_rx_t* rx);              /* 1, 3 or 4: what the next process call will use */
+/* k_pipe's safety net.  The bound of every wait inside its launch, in microseconds (default 20000; 0 = a wait that is not satisfied at first look gives up: every call
+ * then takes the redo path -- what tests/test_gpu_pipe.py does to prove that path delivers the reference's rows).  Returns the previous bound; a negative argument only queries. */
+int  sora_rx_set_pipe_wait_us(sora_rx_t* rx, long long us);
+/* out[0] = calls since the handle was created whose data field was made again because a wait inside k_pipe gave up, out[1] = times the handle then switched itself to
+ * form 3 for 64 calls.  Waits for the handle's calls in flight. */
+int  sora_rx_pipe_stats(sora_rx_t* rx, unsigned long long out[2]);
 /* Identical consecutive calls (same buffer, same capture set) may be replayed as ONE hipGraph launch instead of a chain of
  * kernel launches: 1 = on, 0 = off (default).  Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_graph(sora_rx_t* rx, int enable);

@@ -30,18 +30,17 @@ __device__ __constant__ uint8_t kPilotSgn[128] = {        // pilot.hpp:10-28: 1 
 // leaves LDS; the small tables (demap steps, de-interleaver map) live in LDS, the FFT twiddles in registers; the next
 // pass's samples are requested before the tracking loop so that their latency hides behind it.
 //   algorithmic bytes per data symbol: 256 read (64 of the 80 samples) + 3 N_CBPS / 8 written (the packed soft stream, rx_types.h)
-__global__ void __launch_bounds__(256) k_frame(RxArgs A)
+struct FrameLds {
+    uint32_t eq[4][4][64];                                                       // [wave][symbol of the pass]: FFT staging, then the equalised bins
+    uint8_t  soft[4][4][288];                                                    // [wave][symbol of the pass]: soft values in carrier order
+    uint8_t  demap[1024];                                                        // DemapperCore step tables (filled by the caller, 256 threads, in front of a block barrier)
+};
+// one wave, the frame queued at slot j of jobs[] / joblist[]: its VitJob and its packed soft stream
+__device__ __forceinline__ void frame_symbols(const RxArgs& A, uint32_t j, FrameLds& lds)
 {
-    __shared__ uint32_t s_eq[4][4][64];                                          // [wave][symbol of the pass]: FFT staging, then the equalised bins
-    __shared__ uint8_t  s_soft[4][4][288];                                       // [wave][symbol of the pass]: soft values in carrier order
-    __shared__ uint8_t  s_demap[1024];                                           // DemapperCore step tables
+    uint32_t (&s_eq)[4][4][64] = lds.eq; uint8_t (&s_soft)[4][4][288] = lds.soft; const uint8_t* s_demap = lds.demap;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
     const Tables& T = A.T;
-    reinterpret_cast<uint32_t*>(s_demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(T.demap)[threadIdx.x];
-    __syncthreads();                                                             // the only block barrier: the waves are independent from here on
-    const JobRef jr = locate_job(blockIdx.x * 4 + w, A.njobs);
-    if (!jr.ok) return;
-    const uint32_t j = jr.list * A.nrows + jr.idx;                               // slot of the job in jobs[] / joblist[]
     const uint32_t f = A.joblist[j];
     const FrameRow r = A.frames[f];
     const uint32_t my_nsoft = (uint32_t)r.nsym * 48u * r.nbpsc;
@@ -170,6 +169,15 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
         }
         wsync();
     }
+}
+__global__ void __launch_bounds__(256) k_frame(RxArgs A)
+{
+    __shared__ FrameLds lds;
+    reinterpret_cast<uint32_t*>(lds.demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.T.demap)[threadIdx.x];
+    __syncthreads();                                                             // the only block barrier: the waves are independent from here on
+    const JobRef jr = locate_job(blockIdx.x * 4 + (threadIdx.x >> 6), A.njobs);
+    if (!jr.ok) return;
+    frame_symbols(A, jr.list * A.nrows + jr.idx, lds);                           // slot of the job in jobs[] / joblist[]
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -662,8 +670,8 @@ __global__ void __launch_bounds__(256) k_sym_back(RxArgs A)
 //   the rest                    four waves each, a wave = eight units of the window-parallel trellis (dev_vitwin.h) -- it works out its units, waits until the
 //                               three counters of its frames say that every soft value it will read has been written, acquires, and decodes
 // Waiting only ever looks at a workgroup of a LOWER role, the launch is small enough for every workgroup to be resident at once (sora_hip.cpp: pipe_fits -- 160 KB
-// of LDS each, one per CU, at most ~190 of the 256), and every wait is bounded: a wait that expires sets flags[0] and gives up, k_finish then reports every frame
-// of the call as SORA_E_INTERNAL_TIMEOUT instead of a result (never seen; the bound is one second).  Hand-offs follow cdna_hip_programming.md guideline 16.
+// of LDS each, one per CU, at most ~190 of the 256), and every wait is bounded (PipeArgs::wait_ticks): a wait that expires sets flags[0] and gives up, and the finishing
+// kernel behind this launch (k_win_redo_finish_pipe) then makes the whole data field again with the plain chain's code -- a call never delivers anything but the reference's rows.  Hand-offs follow cdna_hip_programming.md guideline 16.
 // The proof of the units and the serial decode of what fails it stay a kernel of their own behind this one (k_win_redo), then k_finish.
 // pilots kept in LDS: 1366 data symbols (4095 bytes at 6 Mbps) + the chain's overshoot to a multiple of eight
 constexpr uint32_t kPipeMaxSym = 1376;
@@ -691,7 +699,7 @@ static_assert(4 * sizeof(Lds16<256, 24>) <= kPipeLdsBytes, "k_pipe: four trellis
 #define PIPE_STAMP(P, i) do {} while (0)
 #endif
 __device__ __forceinline__ uint32_t flag_load(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ bool pipe_expired(long long t0) { return wall_clock64() - t0 > 100000000ll; }   // one second of the 100 MHz counter
+__device__ __forceinline__ bool pipe_expired(long long t0, uint32_t wait_ticks) { return wall_clock64() - t0 > (long long)wait_ticks; }   // ticks of the 100 MHz counter
 
 // ---- role 2: one frame's chain and everything behind it up to the soft stream
 __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs& P, uint32_t t, PipeTrackLds& L)
@@ -720,7 +728,7 @@ __device__ __forceinline__ void pipe_track_block(const RxArgs& A, const PipeArgs
         const long long t0 = wall_clock64();
         bool gave_up = false;
         while (!__all(!mine || flag_load(fl) != 0u)) {
-            if (pipe_expired(t0)) { gave_up = true; break; }
+            if (pipe_expired(t0, P.wait_ticks)) { gave_up = true; break; }
             __builtin_amdgcn_s_sleep(8);
         }
         if (gave_up && lane == 0) { L.give_up = 1; atomicOr(P.flags, 1u); }
@@ -846,7 +854,7 @@ __device__ __forceinline__ bool pipe_units_ready(const RxArgs& A, const PipeArgs
 #pragma unroll
         for (uint32_t h = 0; h < 3; h++) ok = ok && flag_load(c + h) >= (quads + 2u - h) / 3u;   // helper h has the quads = h (mod 3)
         if (__all(ok)) break;
-        if (pipe_expired(t0)) { if (lane == 0) atomicOr(P.flags, 1u); return false; }
+        if (pipe_expired(t0, P.wait_ticks)) { if (lane == 0) atomicOr(P.flags, 1u); return false; }
         __builtin_amdgcn_s_sleep(2);
     }
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
@@ -1244,7 +1252,10 @@ __device__ __forceinline__ void pipe_trellis_wave64(const RxArgs& A, const PipeA
         constexpr int CR = decltype(cr)::value;
         UnitGeom GA = unit_geom_direct<CR, 256, 24>(job_at, ia, u, true, q, vbase, A.vout);
         UnitGeom GB_ = unit_geom_direct<CR, 256, 24>(job_at, ib < nl ? ib : ia, u, ib < nl, q, vbase, A.vout);
-        if (GB_.valid && (!GA.valid || GB_.ob != GA.ob)) { if (!GA.valid) { GA = GB_; } const bool no = false; GB_.valid = no; }   // (the second frame is shorter / the first is: one unit in the wave; unequal cuts do not occur for so few frames)
+        // the second frame is shorter / the first is: one unit in the wave.  Unequal cuts of a pair do not occur for as few frames as this form is used for (every frame comes
+        // out cut into single windows); should they ever, the second frame's unit would go undecoded: say so, and the finishing kernel makes the call again (PipeFallbackGate)
+        if (GB_.valid && GA.valid && GB_.ob != GA.ob && (threadIdx.x & 63) == 0) atomicOr(P.flags, 1u);
+        if (GB_.valid && (!GA.valid || GB_.ob != GA.ob)) { if (!GA.valid) { GA = GB_; } const bool no = false; GB_.valid = no; }
         if (!GA.valid) return;
         const unsigned lane = threadIdx.x & 63;
         viterbi_forward_unit<CR, 256, 24, 3>(GA, GB_, (const uint8_t*)A.soft, L.ring, L.ops, P.vecs,
@@ -1407,11 +1418,6 @@ __device__ __forceinline__ void finish_frame(const RxArgs& A, uint32_t f, Finish
     FrameRow& r = A.frames[f];
     if (!r.valid || r.error_code != 0) return;
     const int lane = threadIdx.x & 63;
-    // a hand-off inside k_pipe ran into its one-second bound: no result is better than a wrong one
-    if (A.pipe_flags && A.pipe_flags[0] != 0u) {
-        if (lane == 0) r.error_code = E_INTERNAL_TIMEOUT;
-        return;
-    }
     uint32_t* s_buf = s_bufs[threadIdx.x >> 6];
     const uint32_t* dec32 = reinterpret_cast<const uint32_t*>(A.vout + (size_t)r.slot0 * kOutPerSlot);   // (32-byte aligned; the MPDU starts at its byte 2)
     uint32_t* mp32 = reinterpret_cast<uint32_t*>(A.mpdu + (size_t)r.slot0 * kOutPerSlot);
@@ -1470,18 +1476,56 @@ __global__ void __launch_bounds__(256) k_finish(RxArgs A)
 
 // Behind the window-parallel trellis: k_win_redo AND k_finish as one launch -- the wave that holds a pair's proof (and decodes the pair again if it fails) descrambles and
 // checks its two frames itself.  A kernel boundary less for a lone capture (1.5 us of packet + the next kernel's ramp); the same work for a batch.
-__global__ void __launch_bounds__(256) k_win_redo_finish(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
-                                                         const uint16_t* __restrict__ vecs, const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, unsigned long long* __restrict__ stats, RxArgs A)
+//
+// PIPE = the launch behind k_pipe.  k_pipe's workgroups wait for one another inside one launch, and every such wait is bounded (PipeArgs::wait_ticks): when one of them
+// gave up (flags[0] != 0 -- the chip was not the launch's alone) the call's data field is simply made again HERE by the plain chain's code: the wave that owns a pair
+// of frames runs k_frame's body for them (frame_symbols: VitJob + packed soft stream), decodes them with the serial trellis and finishes them.  What a call delivers
+// is the reference's result whatever happened inside k_pipe; the only trace is the count in the handle's record (stats[4 kWinStatBanks]) and the note the host reads to
+// leave k_pipe alone for a while (sora_hip.cpp: pipe_backoff).
+struct PipeFallbackGate {
+    WinProofGate proof; const RxArgs* A; FrameLds* lds; bool gave_up;
+    __device__ __forceinline__ bool operator()(uint32_t list, uint32_t fa, uint32_t fb, bool hasB) const
+    {
+        if (!gave_up) return proof(list, fa, fb, hasB);
+        frame_symbols(*A, list * A->nrows + fa, *lds);
+        if (hasB) frame_symbols(*A, list * A->nrows + fb, *lds);
+        // (the same wave reads the jobs and the soft stream back through the L2)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        return true;
+    }
+};
+template <bool PIPE>
+__device__ __forceinline__ void win_redo_finish_body(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
+                                                     const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats, const RxArgs& A, uint32_t* host_note)
 {
     __shared__ FinishLds L;
     finish_tables_to_lds(A, L);
-    __syncthreads();
     auto after = [&](uint32_t list, uint32_t fa, uint32_t fb, bool hasB) {
         finish_frame(A, A.joblist[list * A.nrows + fa], L);
         if (hasB) finish_frame(A, A.joblist[list * A.nrows + fb], L);
     };
-    viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, WinProofGate{ jobs, hdr, jstride, target, vstride, vecs, stats }, after);
+    const WinProofGate proof{ jobs, hdr, jstride, target, vstride, vecs, stats };
+    if constexpr (PIPE) {
+        __shared__ FrameLds F;
+        reinterpret_cast<uint32_t*>(F.demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.T.demap)[threadIdx.x];
+        __syncthreads();
+        const bool gave_up = __builtin_amdgcn_readfirstlane((int)A.pipe_flags[0]) != 0;
+        if (gave_up && blockIdx.x == 0 && threadIdx.x == 0) {
+            if (stats) atomicAdd(&stats[4u * kWinStatBanks], 1ull);
+            if (host_note) __hip_atomic_store(host_note, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, PipeFallbackGate{ proof, &A, &F, gave_up }, after);
+    } else {
+        __syncthreads();
+        viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, proof, after);
+    }
 }
+__global__ void __launch_bounds__(256) k_win_redo_finish(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
+                                                         const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats, RxArgs A)
+{ win_redo_finish_body<false>(jobs, hdr, jstride, target, vstride, vecs, soft, out, stats, A, nullptr); }
+__global__ void __launch_bounds__(256) k_win_redo_finish_pipe(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
+                                                              const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats, RxArgs A, uint32_t* host_note)
+{ win_redo_finish_body<true>(jobs, hdr, jstride, target, vstride, vecs, soft, out, stats, A, host_note); }
 
 // ------------------------------------------------------------------------------------------------
 // k_pack: compacts the per-capture frame table into dense sora_frame_result rows in (capture, time) order, on the

@@ -76,6 +76,7 @@ struct PipeArgs {
     uint16_t* vecs;
     uint32_t  stamp_base;          // (tools variant, SORA_DBG_PIPE_TIMELINE: where the launch's time stamps go, in words from flags)
     uint32_t  lanes64;             // 1: the trellis role decodes its units two per wave in the 64-lane layout (a lone capture: a third faster per unit), 0: eight per wave
+    uint32_t  wait_ticks;          // bound of every wait inside the launch, in ticks of the 100 MHz counter (sora_rx_set_pipe_wait_us)
 };
 
 __global__ void k_scan(ScanArgs A);
@@ -99,6 +100,9 @@ __global__ void k_win_redo(const VitJob* jobs, const uint32_t* hdr, uint32_t jst
 __global__ void k_win_redo_finish(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
         const uint8_t* soft, uint8_t* out, unsigned long long* stats,
                                   RxArgs A);   // ... and k_finish behind it, in the same waves   // k_rx.hip
+// ... behind k_pipe: the same, and the plain chain's code for the whole call if a hand-off inside k_pipe gave up (host_note: a host-mapped word that is set then)
+__global__ void k_win_redo_finish_pipe(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
+        const uint8_t* soft, uint8_t* out, unsigned long long* stats, RxArgs A, uint32_t* host_note);
 __global__ void k_finish(RxArgs A);
 struct PackedRow;
 __global__ void k_pack(const FrameRow* frames, const uint32_t* nframes, const CapDesc* caps, uint32_t ncaps, uint32_t max_frames, PackedRow* rows, uint32_t* nrows_out);

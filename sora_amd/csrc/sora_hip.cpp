@@ -422,6 +422,7 @@ struct RxPipe {
     // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
     int  front = 1;
     uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed for every call
+    uint32_t pipe_wait_ticks = 2000000; uint32_t* d_note = nullptr;   // ... the bound of its waits (100 MHz ticks) and the handle's host-mapped note "a wait gave up" (sora_rx)
     bool pipe64 = false;                                        // ... its trellis role in the 64-lane form (two units per wave: the handle's calls in flight are few enough for that many workgroups)
     // A call needs its job counters zero, k_pipe's words zero and (three-kernel chain) no symbol slot owned: the call BEFORE it on this pipeline arranges that inside its k_scan
     // (the pipeline's calls alternate between two sets of counters, words 0-3 and 8-11 of the 64-byte block in front of the frame table) -- no fill kernel in front of a call
@@ -704,10 +705,11 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMalloc((void**)&rx->d_jobs, 3 * sizeof(VitJob) * rx->cap_rows));
     }
     if (rx->lanes16 == 2 && !rx->d_wvecs) {                                      // the window-parallel trellis's arrays, on its first use
-        rx->wstride = kWinUnitsTarget + rx->cap_rows;
+        // (a call is cut into at most max(target, rows) units and a frame into at most 80: a single-capture handle needs 80 vectors per row, not the target's 16384)
+        rx->wstride = (uint32_t)std::min<uint64_t>(std::max<uint64_t>(kWinUnitsTarget, rx->cap_rows), 80ull * rx->cap_rows) + rx->cap_rows;
         HIPCHK(hipMalloc((void**)&rx->d_wvecs, 3 * (size_t)kWinVecBytes * rx->wstride));
-        HIPCHK(hipMalloc((void**)&rx->d_wstats, 4 * kWinStatBanks * sizeof(unsigned long long)));
-        HIPCHK(hipMemset(rx->d_wstats, 0, 4 * kWinStatBanks * sizeof(unsigned long long)));
+        HIPCHK(hipMalloc((void**)&rx->d_wstats, (4 * kWinStatBanks + 1) * sizeof(unsigned long long)));   // (+ 1: calls whose data field k_win_redo_finish_pipe made again)
+        HIPCHK(hipMemset(rx->d_wstats, 0, (4 * kWinStatBanks + 1) * sizeof(unsigned long long)));
     }
 #ifdef SORA_FRAME_SPLIT3
     const bool split = true;
@@ -804,7 +806,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                     PipeArgs P{};
                     P.nfront = (slots + 63) / 64; P.ntrack = nrows; P.flags = rx->d_pflags; P.target = kWinUnitsTarget; P.vstride = rx->wstride;
                         P.vecs = rx->d_wvecs; P.stamp_base = rx->pflag_words;
-                    P.lanes64 = rx->pipe64 ? 1u : 0u;
+                    P.lanes64 = rx->pipe64 ? 1u : 0u; P.wait_ticks = rx->pipe_wait_ticks;
                     // trellis waves: eight units each (+ a partly filled one per code-rate list + the lone layout's gaps), or -- 64-lane form -- unit u of two frames each
                     const uint32_t waves = rx->pipe64 ? kWinMaxUnits * ((nrows + 3) / 2) : (units_max + 7) / 8 + 3 + kWinLoneWaves;
                     hipLaunchKernelGGL(k_pipe, dim3(P.nfront + P.ntrack + (waves + 3) / 4), dim3(256), 0, st, R, P);
@@ -855,7 +857,11 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         }
         // (behind the window-parallel trellis the proof, the decode of what fails it and T11aDesc
         // / the frame sink are ONE launch: the wave that holds a pair of frames finishes them)
-        if (redo_finish)
+        if (redo_finish && pipe)                                                 // (behind k_pipe: ... and the plain chain's code for the whole call if a wait inside k_pipe gave up)
+            hipLaunchKernelGGL(k_win_redo_finish_pipe, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows,
+                    kWinUnitsTarget, rx->wstride,
+                               (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats, R, rx->d_note);
+        else if (redo_finish)
             hipLaunchKernelGGL(k_win_redo_finish, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, nrows,
                     kWinUnitsTarget, rx->wstride,
                                (const uint16_t*)rx->d_wvecs, (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wstats, R);
@@ -1046,7 +1052,7 @@ constexpr long long kAutoLanes16Captures = 32768;
 struct sora_rx {
     static constexpr int kMaxDepth = 16;
     sora_rx_cfg cfg{};
-    int depth = 8;
+    std::atomic<int> depth{8};   // (read by other handles' automatic kernel choice under g_rx_mu)
     int trellis = 0;             // sora_rx_set_trellis: 0 = chosen from the depth, 64 / 16 = lanes per frame pair
     int front = 0;               // sora_rx_set_front: 0 = chosen from the capacity in flight, 1 = k_frame, 3 = the three-kernel symbol chain
     bool use_graph = false;
@@ -1061,12 +1067,18 @@ struct sora_rx {
     uint32_t* d_cont = nullptr; uint32_t* d_consumed = nullptr;
     // tool hook (sora_internal_rx_timeline)
     std::vector<float> tl; hipEvent_t tl_base = nullptr;
+    // k_pipe's safety net: the bound of the waits inside its launch; the host-mapped word its finishing kernel sets when one of them gave up (the call's rows are
+    // right all the same: k_rx.hip, k_win_redo_finish_pipe); the calls this handle then keeps to the three-kernel chain; how often that happened
+    uint32_t pipe_wait_us = 20000;
+    uint32_t* h_note = nullptr; uint32_t* d_note = nullptr;
+    int pipe_backoff = 0; unsigned long long pipe_backoffs = 0;
     std::atomic<long long> last_call_ns{0};   // when this handle last took a process call (steady clock): what OTHER handles' automatic kernel choice looks at (chip_is_shared)
 };
 
 // The handles of this process, for ONE question: is the chip being kept full by somebody else?  k_pipe is the chain for an otherwise idle chip (each of its workgroups
 // takes a whole CU's LDS: beside a full chip its launch waits for CUs to drain, tools/pipe_under_load.py), so a handle's automatic choice leaves it alone while another
 // handle of the process on the same device -- one sized for a batch -- has taken a call within the last few milliseconds.  (Other processes are not seen.)
+constexpr int kPipeBackoffCalls = 64;       // calls a handle keeps to the three-kernel chain after a wait inside one of its k_pipe launches gave up
 static std::mutex g_rx_mu;
 static std::vector<sora_rx*> g_rx_all;
 constexpr long long kSharedWindowNs = 20000000;                 // 20 ms
@@ -1116,6 +1128,7 @@ static RxPipe* pipe_at(sora_rx* rx, int i)
         rx->pipes[i]->fused = rx->fused; rx->pipes[i]->use_graph = rx->use_graph;
         if (rx->profiling) (void)pipe_set_profiling(rx->pipes[i], 1);
         rx->pipes[i]->tl = &rx->tl; rx->pipes[i]->tl_base = &rx->tl_base; rx->pipes[i]->index = i;
+        rx->pipes[i]->d_note = rx->d_note;
     }
     return rx->pipes[i];
 }
@@ -1130,6 +1143,10 @@ int sora_rx_create(const sora_rx_cfg* cfg, sora_rx_t** out)
     if (rc != SORA_OK) return rc;
     sora_rx* rx = new sora_rx();
     rx->cfg = *cfg; rx->pipes[0] = p0; rx->fused = p0->fused;
+    // (host-mapped, written by k_win_redo_finish_pipe; without it the safety net still works, the handle just does not learn from it)
+    if (hipHostMalloc((void**)&rx->h_note, 64, hipHostMallocMapped) == hipSuccess && hipHostGetDevicePointer((void**)&rx->d_note, rx->h_note, 0) == hipSuccess) *rx->h_note = 0;
+    else { (void)hipGetLastError(); if (rx->h_note) (void)hipHostFree(rx->h_note); rx->h_note = rx->d_note = nullptr; }
+    p0->d_note = rx->d_note;
     { std::lock_guard<std::mutex> lk(g_rx_mu); g_rx_all.push_back(rx); }
     *out = rx;
     return SORA_OK;
@@ -1143,6 +1160,7 @@ void sora_rx_destroy(sora_rx_t* rx)
     if (rx->d_cont) (void)hipFree(rx->d_cont);
     if (rx->d_consumed) (void)hipFree(rx->d_consumed);
     if (rx->tl_base) (void)hipEventDestroy(rx->tl_base);
+    if (rx->h_note) (void)hipHostFree(rx->h_note);
     delete rx;
 }
 
@@ -1185,20 +1203,44 @@ static uint64_t device_cus(int device)                                         /
     if (cus[device] == 0) { hipDeviceProp_t pr; cus[device] = hipGetDeviceProperties(&pr, device) == hipSuccess && pr.multiProcessorCount > 0 ? pr.multiProcessorCount : 256; }
     return (uint64_t)cus[device];
 }
-static bool pipe_fits(const sora_rx* rx, bool lanes64 = false)
+static uint64_t pipe_groups(const sora_rx* rx, bool lanes64)                   // workgroups of one k_pipe launch of this handle
 {
     const uint64_t str = rx->cfg.sample_rate_mhz == 20 ? 1 : 2, rows = (uint64_t)rx->cfg.max_captures * rx->cfg.max_frames_per_capture;
     const uint64_t slots = rx->cfg.max_total_samples / str / 80 + rx->cfg.max_captures + 16;
     const uint64_t units = std::min<uint64_t>(std::max<uint64_t>(kWinUnitsTarget, rows), 80ull * rows);
     const uint64_t waves = lanes64 ? (uint64_t)kWinMaxUnits * ((rows + 3) / 2) : (units + 7) / 8 + 3 + kWinLoneWaves;
-    const uint64_t groups = (slots + 63) / 64 + rows + (waves + 3) / 4;
+    return (slots + 63) / 64 + rows + (waves + 3) / 4;
+}
+// frame rows in flight up to which the automatic choice is k_pipe
+// Is handle h one whose calls are k_pipe launches right now (as far as another handle can tell without asking front_for, which asks this)?
+static bool pipe_candidate(const sora_rx* h, long long now)
+{
+    if (h->front != 4 && h->front != 0) return false;
+    if (h->trellis != 0 && h->trellis != SORA_TRELLIS_WINDOWED) return false;
+    const long long rows = (long long)h->depth * (long long)h->cfg.max_captures * (long long)h->cfg.max_frames_per_capture;
+    if (h->front == 0 && rows > kAutoPipeRows) return false;
+    const long long t = h->last_call_ns.load(std::memory_order_relaxed);
+    return t != 0 && now - t < kSharedWindowNs;
+}
+// The CUs are shared by every handle of the process on the device: the launches of ALL of them that are k_pipe's (each workgroup a whole CU's LDS) must be resident together
+static bool pipe_fits(const sora_rx* rx, bool lanes64 = false)
+{
+    const uint64_t rows = (uint64_t)rx->cfg.max_captures * rx->cfg.max_frames_per_capture;
+    uint64_t groups = pipe_groups(rx, lanes64) * (uint64_t)rx->depth;
+    {
+        const long long now = steady_ns();
+        std::lock_guard<std::mutex> lk(g_rx_mu);
+        for (const sora_rx* h : g_rx_all)
+            if (h != rx && h->cfg.device == rx->cfg.device && pipe_candidate(h, now)) groups += pipe_groups(h, false) * (uint64_t)h->depth;
+    }
     // (64-lane form: every frame must come out cut into single windows, i.e. get its full 80 units: 16384 / 80 frames at most)
-    return groups * (uint64_t)rx->depth <= device_cus(rx->cfg.device) * 3 / 4 && (!lanes64 || rows * (uint64_t)rx->depth <= 204);   // (three quarters of the CUs: 192 of an MI355X's 256)
+    return groups <= device_cus(rx->cfg.device) * 3 / 4 && (!lanes64 || rows * (uint64_t)rx->depth <= 204);   // (three quarters of the CUs: 192 of an MI355X's 256)
 }
 static int front_for(const sora_rx* rx)                                        // -> RxPipe::front
 {
     if (rx->front == 1 || rx->front == 3) return rx->front;
-    const bool can_pipe = lanes16_for(rx) == 2 && pipe_fits(rx);
+    // (a wait inside one of this handle's k_pipe launches gave up a few calls ago: somebody else -- another process, other GPU work -- holds CUs; the chain for a while)
+    const bool can_pipe = rx->pipe_backoff == 0 && lanes16_for(rx) == 2 && pipe_fits(rx);
     if (rx->front == 4) return can_pipe ? 4 : 3;
     const long long rows = (long long)rx->depth * (long long)rx->cfg.max_captures * (long long)rx->cfg.max_frames_per_capture;
     return rows <= kAutoPipeRows && can_pipe && !chip_is_shared(rx) ? 4 : rows <= kAutoSplitRows ? 3 : 1;
@@ -1238,6 +1280,31 @@ int sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4])
         HIPCHK(hipMemcpy(v, p->d_wstats, sizeof v, hipMemcpyDeviceToHost));
         for (unsigned i = 0; i < 4 * kWinStatBanks; i++) out[i & 3u] += v[i];
     }
+    return SORA_OK;
+}
+
+// k_pipe's safety net: the bound of the waits inside its launch ...
+int sora_rx_set_pipe_wait_us(sora_rx_t* rx, long long us)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = (int)rx->pipe_wait_us;
+    if (us >= 0) rx->pipe_wait_us = (uint32_t)std::min<long long>(us, 40000000ll);
+    return old;
+}
+// ... and its record: out[0] = calls whose data field the finishing kernel made again because a wait gave up, out[1] = times the handle then left k_pipe alone
+int sora_rx_pipe_stats(sora_rx_t* rx, unsigned long long out[2])
+{
+    if (!rx || !out) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_pipe_stats: null argument");
+    HIPCHK(hipSetDevice(rx->cfg.device));
+    out[0] = 0;
+    for (RxPipe* p : rx->pipes) if (p && p->d_wstats) {
+        unsigned long long v = 0;
+        HIPCHK(hipStreamSynchronize(p->stream));
+        HIPCHK(hipMemcpy(&v, p->d_wstats + 4 * kWinStatBanks, sizeof v, hipMemcpyDeviceToHost));
+        out[0] += v;
+    }
+    if (rx->h_note && *(volatile uint32_t*)rx->h_note != 0u) { *(volatile uint32_t*)rx->h_note = 0u; rx->pipe_backoff = kPipeBackoffCalls; rx->pipe_backoffs++; }
+    out[1] = rx->pipe_backoffs;
     return SORA_OK;
 }
 
@@ -1326,6 +1393,18 @@ int sora_rx_stream_consumed(sora_rx_t* rx, int ticket, uint32_t* h_consumed, siz
     return SORA_OK;
 }
 
+// The kernels of the next call on pipeline p (the handle's settings, its capacity in flight, what else the chip is doing).  k_pipe's finishing kernel leaves a note when a
+// wait inside that launch gave up (the call's rows are right all the same); the handle then keeps to the three-kernel chain for the next kPipeBackoffCalls calls.
+static void choose_kernels(sora_rx* rx, RxPipe* p)
+{
+    if (rx->h_note && *(volatile uint32_t*)rx->h_note != 0u) { *(volatile uint32_t*)rx->h_note = 0u; rx->pipe_backoff = kPipeBackoffCalls; rx->pipe_backoffs++; }
+    else if (rx->pipe_backoff > 0) rx->pipe_backoff--;
+    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
+    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
+    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
+    { const uint32_t wt = rx->pipe_wait_us > 40000000u ? 0xFFFFFFFFu : rx->pipe_wait_us * 100u; if (p->pipe_wait_ticks != wt) { p->pipe_wait_ticks = wt; p->last_valid = false; } }
+}
+
 int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_capture_desc* caps, size_t ncaps)
 {
     if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_process_dev: null argument");
@@ -1333,9 +1412,7 @@ int sora_rx_process_dev(sora_rx_t* rx, const sora_complex16* d_iq, const sora_ca
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
-    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
-    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
+    choose_kernels(rx, p);
     const int rc = pipe_process_dev(p, d_iq, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; rx->last_call_ns.store(steady_ns(), std::memory_order_relaxed); }
     return rc;
@@ -1348,9 +1425,7 @@ int sora_rx_process(sora_rx_t* rx, const sora_complex16* h_iq, size_t total_samp
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
-    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
-    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
+    choose_kernels(rx, p);
     const int rc = pipe_process(p, h_iq, total_samples, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; rx->last_call_ns.store(steady_ns(), std::memory_order_relaxed); }
     return rc;
@@ -1363,9 +1438,7 @@ int sora_rx_process_dump(sora_rx_t* rx, const void* h_dump, size_t dump_bytes, u
     RxPipe* p = pipe_at(rx, next);
     if (!p) return SORA_ERR_HARDWARE_FAILED;
     { const int rc = stream_prologue(rx, p); if (rc) return rc; }
-    if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
-    { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
-    { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
+    choose_kernels(rx, p);
     const int rc = pipe_process_dump(p, h_dump, dump_bytes, ingest_flags, caps, ncaps);
     if (rc == SORA_OK) { rx->cur = next; rx->started = true; p->ticket = ++rx->seq; rx->last_call_ns.store(steady_ns(), std::memory_order_relaxed); }
     return rc;

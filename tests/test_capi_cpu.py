@@ -37,7 +37,7 @@ def test_binding_covers_the_header():
 
 def test_abi_version_and_struct_layout(lib):
     from sora_amd import capi
-    assert lib.sora_hip_abi_version() == 3
+    assert lib.sora_hip_abi_version() == 4
     assert ctypes.sizeof(capi.FrameResult) == 36          # 9 x 32-bit words: the unit of the multi-GPU gather
     assert ctypes.sizeof(capi.CaptureDesc) == 16
     assert ctypes.sizeof(capi.RxCfg) == 32

@@ -164,3 +164,65 @@ def test_the_automatic_choice_leaves_k_pipe_alone_while_a_batch_handle_keeps_the
     time.sleep(0.05)
     assert small.front() == 4
     big.close(); small.close()
+
+
+@pytest.mark.parametrize("depth", [1, 4])
+def test_a_wait_that_gives_up_still_delivers_the_reference_rows(sora, torch_cuda, oracle, golden_dir, depth):
+    """k_pipe's safety net: with the bound of the waits inside the launch at zero every hand-off that is not there at first look gives up -- what
+    happens to a launch whose workgroups cannot all be resident because somebody else holds the compute units.  The finishing kernel then makes the call's data field
+    again with k_frame's code and the serial trellis: the rows and MPDU bytes are the oracle's (no SORA_E_INTERNAL_TIMEOUT, no missing frame), the record counts the calls,
+    and the handle leaves k_pipe alone for its next calls."""
+    rng = np.random.default_rng(606 + depth)
+    want_sha = "5a13a47743867e307040a009e1172b916c9015cd34fac586cafb2d0f1fd64b62"
+    iq6 = pad_capture(np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8, 40)
+    sets = [([iq6], 40, 2)]
+    for mhz, n in ((20, 1), (40, 1), (20, 3 if depth == 1 else 1), (40, 2 if depth == 1 else 1)):   # (what fits the chip depth times over)
+        for _ in range(3):
+            sets.append(([random_capture(oracle, rng, mhz, multipath_p=0.2) for _ in range(n)], mhz, 4))
+    made_again = 0
+    for caps, mhz, mf in sets:
+        iq, descs = batch(caps)
+        rx = sora.Rx(max_captures=len(caps), max_total_samples=max(64, len(iq)), sample_rate_mhz=mhz, max_frames_per_capture=mf)
+        rx.set_depth(depth); rx.set_front(4)
+        assert rx.set_pipe_wait_us(0) == 20000
+        assert rx.front() == 4
+        d = torch_cuda.from_numpy(iq).cuda()
+        got = rx.results(ticket=rx.process_dev(d, descs))
+        want = oracle_results(oracle, caps, mhz)
+        ok, why = same_results(got, want)
+        assert ok, (mhz, len(caps), why)
+        assert all(r["error_code"] != E_INTERNAL_TIMEOUT for r in got)
+        if caps[0] is iq6:
+            assert len(got) == 1 and got[0]["error_code"] == 1 and hashlib.sha256(got[0]["mpdu"]).hexdigest() == want_sha
+        st = rx.pipe_stats()
+        # (a call without a data field has no hand-off to wait for, and a frame of a symbol or two may be through before anybody looks)
+        assert st["calls_made_again"] in (0, 1) and st["backoffs"] == st["calls_made_again"], st
+        if caps[0] is iq6:
+            assert st["calls_made_again"] == 1, st                              # 465 symbols: the trellis waves certainly looked before the soft values were there
+        if st["calls_made_again"]:
+            made_again += 1
+            assert rx.front() == 3                                              # the handle has learnt: the three-kernel chain for a while ...
+            got2 = rx.results(ticket=rx.process_dev(d, descs))
+            ok, why = same_results(got2, want); assert ok, why
+            assert rx.pipe_stats()["calls_made_again"] == 1                     # ... and that call was not a k_pipe launch
+        rx.close()
+    assert made_again >= 6, made_again
+
+
+def test_the_back_off_ends(sora, torch_cuda, golden_dir):
+    cap = pad_capture(np.load(os.path.join(golden_dir, "fsample6_40mhz_i8.npz"))["iq_i8"].astype(np.int16) << 8, 40)
+    d = torch_cuda.from_numpy(cap).cuda(); one = [(0, len(cap), 0)]
+    rx = sora.Rx(max_captures=1, max_total_samples=len(cap), sample_rate_mhz=40, max_frames_per_capture=2)
+    rx.set_depth(1); rx.set_pipe_wait_us(0)
+    assert rx.front() == 4
+    assert rx.results(ticket=rx.process_dev(d, one))[0]["error_code"] == 1
+    assert rx.pipe_stats() == {"calls_made_again": 1, "backoffs": 1}
+    rx.set_pipe_wait_us(20000)
+    n = 0
+    while rx.front() == 3 and n < 200:
+        assert rx.results(ticket=rx.process_dev(d, one))[0]["error_code"] == 1
+        n += 1
+    assert 60 <= n <= 66, n                                                      # 64 calls on the chain, then k_pipe again
+    assert rx.results(ticket=rx.process_dev(d, one))[0]["error_code"] == 1
+    assert rx.pipe_stats() == {"calls_made_again": 1, "backoffs": 1}
+    rx.close()
