@@ -8,9 +8,12 @@ restated reference transmitter (oracle/so_tx11a.c), AWGN at ~30/27 dB SNR on 3 o
 A "step" = one sora_rx_process_dev call over the whole batch, inputs resident in HBM.  `value` counts the
 4880 frame samples per capture (19.99 Msamples per 4096 frames).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): captures are the natural shard -- each rank runs
-its own 4096-capture batch end to end (weak scaling), no data-path collective; one all-reduce of the
-frame counters after the timed region is the only exchange.
+Multi-GPU (--gpus N): captures are the natural shard -- each rank runs its own batch end to end (weak scaling), no
+data-path collective; the RCCL all-gather of the result rows and MPDUs and one all-reduce of the frame counters
+after the timed region are the only exchanges.  Under torch.distributed.run (RANK / WORLD_SIZE in the environment)
+this process is one rank; a plain `python bench.py --gpus N` starts the N ranks itself (one process per GPU,
+rendezvous on 127.0.0.1) and rank 0 prints the line.  --shape shard is BASELINE configs[4] literally: 32 captures
+of sixteen back-to-back frames per GPU (256 concurrent captures over 8 GPUs) instead of 4096 captures of one frame.
 
 The timed region: the K-step block (--steps) is repeated until at least --min-seconds have passed; every step is a
 process call whose dense result rows AND MPDU array are delivered to page-locked host memory behind the kernels, and the
@@ -65,6 +68,53 @@ from benchlib.latency import bench_e2e, bench_large_call, bench_latency  # noqa:
 from benchlib.rows import bench_11b, bench_11n, bench_ht40, bench_shard_shape  # noqa: E402,F401
 
 
+def _free_port():
+    import socket
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]
+
+
+def launch_ranks(n, argv, extra_env=None):
+    """`python bench.py --gpus N` without torch.distributed.run: start the N ranks (one process per GPU, the environment torch.distributed.run would set,
+    rendezvous on 127.0.0.1), pass rank 0's output through, return the first non-zero exit code."""
+    import subprocess
+    port = str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1", MASTER_PORT=port,
+                   HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env, stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    try:
+        while any(pr.poll() is None for pr in procs):
+            time.sleep(0.2)
+            rc = next((pr.returncode for pr in procs if pr.returncode not in (None, 0)), 0)
+            if rc:                              # a rank that died leaves the others in a rendezvous or a collective: end exactly the processes started here, now
+                break
+        rc = rc or next((pr.returncode for pr in procs if pr.returncode not in (None, 0)), 0)
+    finally:
+        for pr in procs:
+            if pr.poll() is None:
+                pr.kill()
+    return rc
+
+
+def launcher_selftest():
+    """What tests/test_bench_launcher.py runs on CPU: the ranks launch_ranks started find each other (gloo) and rank 0 prints one line."""
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ["RANK"]); world = int(os.environ["WORLD_SIZE"])
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    t = torch.tensor([rank + 1], dtype=torch.int64)
+    dist.all_reduce(t)
+    if rank == 0:
+        print(json.dumps({"launcher": "ok", "n_gpus": world, "sum_of_rank_plus_one": int(t.item()), "master": os.environ["MASTER_ADDR"] + ":" + os.environ["MASTER_PORT"]}), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) == 3 and sys.argv[1] == "--cpu-mt-worker":                 # one instance of the reference's two-thread harness (cpu_baseline.two_thread): never returns normally
         p_, nf, first, stride, secs = sys.argv[2].split(",")
@@ -88,8 +138,20 @@ def main():
     ap.add_argument("--min-seconds", type=float, default=1.0, help="the timed region repeats the K-step block until it has lasted this long")
     ap.add_argument("--no-deliver", action="store_true", help="do not deliver rows + MPDUs to the host inside the timed region (round-1 behaviour)")
     ap.add_argument("--hw-queues", type=int, default=0, help="GPU_MAX_HW_QUEUES for this process (read before HIP starts); 0 = leave the runtime default")
+    ap.add_argument("--shape", default="batch", choices=["batch", "shard"], help="batch: --frames captures of one frame per GPU (BASELINE configs[2], the headline); "
+                    "shard: 32 captures of 16 back-to-back frames per GPU (BASELINE configs[4]: 256 concurrent captures over 8 GPUs)")
+    ap.add_argument("--launcher-selftest", action="store_true", help="only start the ranks, let them find each other (gloo) and print one line: the CPU test of --gpus N's own launcher")
     ap.add_argument("--only", default="", help="run just one of the extra sections (stages, ingest, tx, rx11b, rx11b_cck, rx11n, rx11n_40, shard_32x16, latency) and print its object: for profiling that section alone")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "RANK" not in os.environ:                               # not under torch.distributed.run: this process becomes the launcher of the N ranks
+        if not args.launcher_selftest:
+            import torch
+            if torch.cuda.device_count() < args.gpus:
+                sys.exit("bench.py: --gpus %d, but this node shows %d device(s)" % (args.gpus, torch.cuda.device_count()))
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    if args.launcher_selftest:
+        return launcher_selftest()
 
     import torch
     import sora_amd
@@ -97,11 +159,14 @@ def main():
 
     rank = int(os.environ.get("RANK", "0")); world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.exit("bench.py: --gpus %d but WORLD_SIZE is %d: start it as `python bench.py --gpus N` or under torch.distributed.run --nproc-per-node N with the same N" % (args.gpus, world))
+    if torch.cuda.device_count() < min(world, local_rank + 1):
+        sys.exit("bench.py: rank %d needs device %d, this node shows %d" % (rank, local_rank, torch.cuda.device_count()))
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -114,9 +179,14 @@ def main():
         print(json.dumps({args.only: sections[args.only]()}))
         return
     oracle = Oracle()
-    nfr = args.frames
-    MAXF = 2
-    iq, descs, payloads = make_workload(oracle, nfr, seed0=rank * 100003)
+    shard = args.shape == "shard"
+    # captures per rank x frames per capture: 4096 x 1 (configs[2]) | 32 x 16 (configs[4]: k_scan walks a capture's frames one after the other, the other kernels see 512 frames)
+    nfr = 32 if shard and args.frames == FRAMES_PER_GPU else args.frames
+    fpc = 16 if shard else 1
+    MAXF = fpc + 2 if shard else 2
+    iq, descs, payloads = make_workload(oracle, nfr * fpc, seed0=rank * 100003)
+    if shard:
+        descs = [(i * fpc * CAPTURE_SAMPLES, fpc * CAPTURE_SAMPLES, i) for i in range(nfr)]
     d_iq = torch.from_numpy(iq).to(dev)
     # one 80 MB input re-read every step sits in the 256 MiB Infinity Cache.  The timed steps rotate through NCOPIES device
     # copies of the batch at different addresses (same samples, so every call's table can be compared with the verified one): 320 MB of input in
@@ -146,13 +216,17 @@ def main():
     # ---- the first call is checked before anything is timed: every capture against the reference (or --check of them)
     t = rx.process_dev(d_iq, descs)
     res = rx.results(ticket=t)
-    kind, want = reference_rows(iq, nfr, oracle)
+    kind, want = reference_rows(iq, nfr, oracle, fpc)
     idx = list(range(nfr)) if args.check <= 0 or args.check >= nfr else list(range(0, nfr, max(1, nfr // args.check)))[:args.check]
     parity_ok, why = check_against_reference(res, kind, want, idx)
     if not parity_ok:
         print("PARITY MISMATCH vs %s: %s" % (kind, why), file=sys.stderr)
     n_ok = sum(1 for r in res if r["error_code"] == sora_amd.E_FRAME_OK)
-    n_payload_ok = sum(1 for r in res if r["error_code"] == sora_amd.E_FRAME_OK and r["mpdu"][:-4] == payloads[r["capture_id"]])
+    seen = {}                                                       # (rows come in capture, time order: the k-th row of a capture is its k-th frame)
+    n_payload_ok = 0
+    for r in res:
+        k = seen.get(r["capture_id"], 0); seen[r["capture_id"]] = k + 1
+        n_payload_ok += r["error_code"] == sora_amd.E_FRAME_OK and k < fpc and r["mpdu"][:-4] == payloads[r["capture_id"] * fpc + k]
 
     # ---- result delivery inside the timed region: after every process call its dense rows and its MPDU array are copied
     # to page-locked host memory behind the kernels (sora_rx_deliver_async), and the oldest call in flight is waited for
@@ -273,7 +347,7 @@ def main():
     # handle's streams in use -- fewer than the runtime's default four hardware queues, so GPU_MAX_HW_QUEUES plays no part -- same timed-region
     # protocol (delivery + comparison inside), each trellis kernel pinned in turn.
     plain = {}
-    if world == 1 and not args.no_plain:
+    if world == 1 and not args.no_plain and not shard:
         if order["any"] and deliver:                                 # the headline's calls in flight with the round-3 loop: always wait for the OLDEST ticket
             rx.set_trellis(lanes); rx.set_depth(depth); rx.flush(); order["any"] = False
             run_block(args.warmup, deliver); rx.flush(); chk.drain(); bad0 = chk.bad
@@ -309,7 +383,7 @@ def main():
                          "issue rate) or 4096 of k_viterbi (1.7x the instructions): DESIGN.md section 3.6, profiles/r04_a_depth_table.txt" % (depth, " on %s hardware queues" % os.environ["GPU_MAX_HW_QUEUES"] if os.environ.get("GPU_MAX_HW_QUEUES") else ""))
     rx.set_trellis(trellis_setting); rx.set_depth(depth); rx.flush()
     latency = e2e = None
-    if world == 1 and not args.no_extras:
+    if world == 1 and not args.no_extras and not shard:
         latency = bench_latency(torch, sora_amd, dev, rx, d_iq, descs, nfr)
         e2e = bench_e2e(torch, sora_amd, dev, rx, iq, nfr, exp_rows, exp_mpdu)
 
@@ -325,28 +399,30 @@ def main():
         # the path's one exchange step: RCCL all-gathers of the device-packed result rows AND the MPDUs (every MPDU
         # reaches the one host buffer, fb11a_demod.cpp:64-70) + all-reduce of counters.  Per rank and exchange: 8 bytes of counts,
         # 36 bytes x 2 x captures of rows, MPDU_LEN x captures of MPDU bytes.
-        gathered = exchange_results(torch, rx, d_iq, descs, dev, nfr, MAXF)
+        gathered = exchange_results(torch, rx, d_iq, descs, dev, nfr, MAXF, fpc)
         gathered_rows = gathered["rows"]
         dist.all_reduce(counters)
     tot_frames, tot_ok, tot_payload_ok, tot_delivered, tot_bad = [int(v) for v in counters.tolist()]
 
-    total_samples = float(nfr) * FRAME_SAMPLES * world * timed_steps
+    total_samples = float(nfr * fpc) * FRAME_SAMPLES * world * timed_steps
     msps = total_samples / elapsed / 1e6
     ms_per_step = elapsed / timed_steps * 1e3
     if rank == 0:
         dom = max((k for k in ktimes if k.startswith("k_")), key=lambda k: ktimes[k])
-        launch_bytes = nfr * FRAME_SAMPLES * ALG_BYTES_PER_SAMPLE
+        launch_bytes = nfr * fpc * FRAME_SAMPLES * ALG_BYTES_PER_SAMPLE
         ach = launch_bytes / (ktimes[dom] * 1e-3)
         ach1 = launch_bytes / (ktimes1[dom] * 1e-3)
-        air_s = nfr * CAPTURE_SAMPLES / 20e6                                   # what one step's captures last on the air
+        air_s = nfr * fpc * CAPTURE_SAMPLES / 20e6                                   # what one step's captures last on the air
         out = {
             "metric": "IQ Msamples/s through 802.11a 54 Mbps RX PHY",
             "value": round(msps, 3), "unit": "Msamples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "timed_steps": timed_steps, "timed_seconds": round(elapsed, 4),
             "ms_per_step": round(ms_per_step, 4), "ms_per_step_profiled": round((t3 - t2) / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "int16 IQ / u8 path metrics", "data": "synthetic",
-            "config": {"workload": "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
-                       "frames_per_gpu": nfr, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "input_copies_rotated": NCOPIES, "input_bytes_in_play": int(NCOPIES * iq.nbytes), "calls_in_flight": depth, "completions": "as they happen (sora_rx_wait_any)" if order["any"] else "oldest ticket first (sora_rx_wait)", "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
+            "config": {"workload": ("802.11a 54 Mbps (64-QAM r=3/4) RX, %d concurrent captures/GPU x %d back-to-back 1500-byte frames (4880 samples @20 MHz, +160 silence each), AWGN 30/27 dB on 3 of 4: BASELINE configs[4]" % (nfr, fpc)) if shard else
+                                   "802.11a 54 Mbps (64-QAM r=3/4) RX, %d captures/GPU x one 1500-byte frame (4880 samples @20 MHz, +160 silence), AWGN 30/27 dB on 3 of 4" % nfr,
+                       "shape": args.shape, "captures_per_gpu": nfr, "frames_per_capture": fpc,
+                       "frames_per_gpu": nfr * fpc, "samples_per_frame": FRAME_SAMPLES, "capture_samples": CAPTURE_SAMPLES, "input_copies_rotated": NCOPIES, "input_bytes_in_play": int(NCOPIES * iq.nbytes), "calls_in_flight": depth, "completions": "as they happen (sora_rx_wait_any)" if order["any"] else "oldest ticket first (sora_rx_wait)", "trellis_kernel": tname[lanes], "hw_queues": os.environ.get("GPU_MAX_HW_QUEUES"),
                        "sharding": "captures per rank, no data-path collective",
                        "timed_region": "%d x %d steps in one continuous run; every step = process call + pack + async delivery of rows and MPDUs to pinned host memory + wait for %s, whose rows and MPDU bytes are compared with the verified ones by %d host threads%s" % (repeats, args.steps, "whichever call in flight finishes first (sora_rx_wait_any)" if order["any"] else "the oldest call in flight", TableChecker.EXTRA, "" if world == 1 else " (every rank pins its submit thread and its checker threads to its own slice of the host's cores)")
                                        if deliver else "%d x %d process calls, nothing delivered" % (repeats, args.steps)},
@@ -360,7 +436,7 @@ def main():
             "realtime": {"factor": round(ms_per_step * 1e-3 / air_s, 7), "channels_20mhz_in_real_time": round(air_s / (ms_per_step * 1e-3), 1),
                          "call_latency_ms_one_in_flight": round(sum(v for k, v in ktimes1.items()), 4)},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": round(ach1 / 1e9, 2), "peak": HBM_PEAK / 1e9, "unit": "GB/s",
-                         "frac": round(ach1 / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU else None,
+                         "frac": round(ach1 / HBM_PEAK, 5), "traffic": measured_traffic(dom) if nfr == FRAMES_PER_GPU and not shard else None,
                          "traffic_source": _traffic_profile()[1],
                          "algorithmic_bytes_per_launch": launch_bytes, "kernel_ms": round(ktimes1[dom], 4),
                          "kernel_ms_note": "mean launch duration with ONE call in flight (the kernel alone on the chip); with %d calls overlapped the same launch lasts %.4f ms (frac %.5f) because it shares the CUs" % (depth, ktimes[dom], ach / HBM_PEAK),
@@ -368,7 +444,7 @@ def main():
                          "other_trellis_kernels": {tname[l]: {"kernel_ms": round(kt[tname[l]], 4), "frac": round(launch_bytes / (kt[tname[l]] * 1e-3) / HBM_PEAK, 5)} for l, kt in ktimes1_others.items()},
                          "other_trellis_kernels_note": "sora_rx_set_trellis, each alone on the chip: k_viterbi = two frames per wave, k_viterbi16 = eight per wave (the one for 32768 and more captures in flight), k_viterbi16w = the frames' "
                                                        "trace-back windows decoded side by side and proven afterwards (the one below that; the automatic choice follows depth x max_captures; the proof runs in the waves of the finishing kernel, k_win_redo_finish)",
-                         "valu": valu_roofline(nfr, ms_per_step)},
+                         "valu": valu_roofline(nfr, ms_per_step) if not shard else None},
             "kernel_ms": {k: round(v, 4) for k, v in ktimes.items()},
             "kernel_ms_one_call_in_flight": {k: round(v, 4) for k, v in ktimes1.items()},
         }
@@ -383,7 +459,7 @@ def main():
             out["latency"] = latency
         if e2e is not None:
             out["e2e"] = e2e
-        if world == 1 and not args.no_extras:
+        if world == 1 and not args.no_extras and not shard:
             out["stages"] = bench_stages(torch, sora_amd, dev)
             out["ingest"] = bench_ingest(torch, sora_amd, dev)
             out["tx"] = bench_tx(torch, sora_amd)
@@ -393,7 +469,7 @@ def main():
             out["rx11n_40"] = bench_ht40(torch, sora_amd, dev)
             out["shard_32x16"] = bench_shard_shape(torch, sora_amd, dev, oracle)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(iq, nfr)
+            out["cpu_baseline"] = cpu_baseline(iq, nfr * fpc)
             out["realtime"]["cpu_reference_factor_one_core"] = round(20.0 / out["cpu_baseline"]["single_core_value"], 4) if out["cpu_baseline"].get("single_core_value") else None
         print(json.dumps(out))
     if world > 1:

@@ -251,15 +251,15 @@ def reference_gate(first, ncaps, ref_events, same):
     return {"against": "reference", "captures_checked": ncaps, "ok": bad == 0, "captures_with_differences": bad}
 
 
-def reference_rows(iq, nfr, oracle):
+def reference_rows(iq, nfr, oracle, fpc=1):
     """What the reference reports for every capture of the workload: the compiled reference graph (oracle/_ref, fresh
     graph state per capture is not needed: a capture ends in silence and the graph resets after every frame) where it is
     present, else the C restatement.  -> (kind, {capture: [events]})"""
     from oracle.pyoracle import ReferenceGraph
-    x = iq.reshape(nfr, CAPTURE_SAMPLES, 2)
+    x = iq.reshape(nfr, fpc * CAPTURE_SAMPLES, 2)                      # (fpc frames back to back per capture: the --shape shard workload)
     g = ReferenceGraph()
     if g.available():
-        return "reference", {i: g.rx11a(np.repeat(x[i], 2, axis=0)) for i in range(nfr)}     # the 40 MHz stream TDownSample2 halves
+        return "reference", {i: g.rx11a(np.repeat(x[i], 2, axis=0), max_frames=fpc + 4) for i in range(nfr)}     # the 40 MHz stream TDownSample2 halves
     return "port", {i: oracle.rx_capture(x[i], 20) for i in range(nfr)}
 
 
@@ -283,7 +283,7 @@ def check_against_reference(res, kind, want, idx):
     return True, ""
 
 
-def exchange_results(torch, rx, d_iq, descs, dev, nfr, maxf):
+def exchange_results(torch, rx, d_iq, descs, dev, nfr, maxf, fpc=1):
     """The multi-GPU path's one exchange step, on an initialised process group: one more call, then RCCL all-gathers of
     {rows, MPDU bytes} per rank, the device-packed result rows and the dense MPDU blocks (sora_amd.shard.gather_mpdus) -- every MPDU of
     every rank reaches every host (fb11a_demod.cpp:64-70 for a sharded batch) -- and a check of every gathered MPDU against the payload
@@ -304,10 +304,12 @@ def exchange_results(torch, rx, d_iq, descs, dev, nfr, maxf):
     ar = allrows.cpu().numpy().view(np.uint32); am = allmp.cpu().numpy()
     okm = 0; k = 0
     for rr, cnt in enumerate(per_rank):                                  # rank rr's rows: its captures were made from seed0 = rr * 100003
+        seen = {}                                                        # (capture, time order: the j-th row of a capture is its j-th frame = frame capture * fpc + j of the rank's workload)
         for w in ar[k:k + cnt]:
-            if int(w[3]) == 1:
+            j = seen.get(int(w[0]), 0); seen[int(w[0])] = j + 1
+            if int(w[3]) == 1 and j < fpc:
                 o_, ln = int(w[8]), int(w[5] & 0xFFFF)
-                okm += bytes(am[o_:o_ + ln - 4]) == workload_payload(rr * 100003, int(w[0]), nfr)
+                okm += bytes(am[o_:o_ + ln - 4]) == workload_payload(rr * 100003, int(w[0]) * fpc + j, nfr * fpc)
         k += cnt
     return {"rows": int(allrows.shape[0]), "rows_per_rank": per_rank, "mpdu_bytes": int(am.size), "mpdus_equal_to_the_transmitted_payloads": int(okm),
             "exchange_ms": round((tg1 - tg0) * 1e3, 3),
