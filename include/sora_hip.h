@@ -35,7 +35,7 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats. */
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a. */
 #define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */
@@ -287,6 +287,11 @@ typedef struct { int16_t cfo_comp, sfo_comp, cfo_tracker, sfo_tracker; uint32_t 
 int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state,
                             sora_complex16* d_out, size_t nframes, void* stream);
 int sora_hip_phase_comp11a(const sora_complex16* d_in, const sora_track11a_state* d_state, const uint32_t* d_state_index, sora_complex16* d_out, size_t n, void* stream);
+/* TPilotTrack alone (pilot.hpp:121-269): the same frame tables, d_in = TPhaseCompensate's output (what sora_hip_phase_comp11a wrote for the symbol with the state as it
+ * was); rotates the symbol by the pilots' mean phase and slope and advances d_state (the trackers, CFO_comp / SFO_comp, symbol_count, CompCoeffs for the NEXT symbol).
+ * The brick that replaces TPilotTrack where TPhaseCompensate stays the reference's (or sora_hip_phase_comp11a's): new in ABI 4. */
+int sora_hip_pilot11a(const sora_complex16* d_in, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state,
+                      sora_complex16* d_out, size_t nframes, void* stream);
 /* T11aDemap<N_BPSC>::Filter (demapper11a.hpp:10-79): IPORT COMPLEX16x64 -> OPORT uchar x 48*n_bpsc */
 int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream);
 /* T11aDeinterleave{BPSK,QPSK,QAM16,QAM64} (deinterleaver.hpp): IPORT uchar x N_CBPS -> OPORT uchar x N_CBPS */

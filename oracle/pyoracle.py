@@ -56,10 +56,10 @@ def build(force=False):
         subprocess.check_call(["make", "-s", "-C", HERE])
     ref_root = os.environ.get("SORA_REFERENCE", "/root/reference")
     if os.path.isdir(os.path.join(ref_root, "kernel", "core", "inc")):
-        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_graph_mt_shim.cpp", "ref_legacy_shim.cpp", "ref_legacy_pre.h", "ref_legacy_rxstream.h",
+        srcs = [os.path.join(HERE, f) for f in ("ref_shim.cpp", "ref_graph_shim.cpp", "ref_graph_mt_shim.cpp", "ref_graph_hip_shim.cpp", "ref_legacy_shim.cpp", "ref_legacy_pre.h", "ref_legacy_rxstream.h",
                                                 "ref_flatten.py", "ref_compat.h", "build_ref.sh")]
         if force or any(not os.path.exists(so) or any(os.path.getmtime(f) > os.path.getmtime(so) for f in srcs)
-                        for so in (REF_SO, REFGRAPH_SO, os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_mt.so"), REFLEGACY_SO)):
+                        for so in (REF_SO, REFGRAPH_SO, os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_mt.so"), os.path.join(os.path.dirname(REFGRAPH_SO), "libsora_refgraph_hip.so"), REFLEGACY_SO)):
             subprocess.check_call(["bash", os.path.join(HERE, "build_ref.sh")])
 
 

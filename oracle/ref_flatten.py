@@ -147,9 +147,14 @@ if HIPBRICKS:
            ("T11aDemapQAM64::Filter", "THip11aDemap<6>::Filter"),
            ("T11aDeinterleaveBPSK, BB11aDemodCtx", "THip11aDeinterleave<1>::Filter, BB11aDemodCtx"), ("T11aDeinterleaveQPSK, BB11aDemodCtx", "THip11aDeinterleave<2>::Filter, BB11aDemodCtx"),
            ("T11aDeinterleaveQAM16, BB11aDemodCtx", "THip11aDeinterleave<4>::Filter, BB11aDemodCtx"), ("T11aDeinterleaveQAM64, BB11aDemodCtx", "THip11aDeinterleave<6>::Filter, BB11aDemodCtx")]
-    write("fb11ademod_config_hip.hpp", "#pragma once\n" + variant("CreateDemodGraph11a_40M_HipFFT", fft) + "\n" + variant("CreateDemodGraph11a_40M_HipFFTDemapDeint", fft + dmd))
+    # round 6: the five bricks that work on the context facades -- the decoder (viterbi), the tracker (pilot) and the three one-multiply bricks (pcomp, chequ, fcomp)
+    ctxb = [("typedef T11aViterbi <5000*8, 48, 256> T11aViterbiComm;", "typedef THip11aViterbi <5000*8, 48, 256> T11aViterbiComm;"), ("TPilotTrack, BB11aDemodCtx", "THip11aPilotTrack, BB11aDemodCtx"),
+            ("TPhaseCompensate, BB11aDemodCtx", "THipPhaseCompensate, BB11aDemodCtx"), ("TChannelEqualization, BB11aDemodCtx", "THipChannelEqualization, BB11aDemodCtx"),
+            ("TFreqCompensation, BB11aDemodCtx", "THipFreqCompensation, BB11aDemodCtx")]
+    write("fb11ademod_config_hip.hpp", "#pragma once\n" + variant("CreateDemodGraph11a_40M_HipFFT", fft) + "\n" + variant("CreateDemodGraph11a_40M_HipFFTDemapDeint", fft + dmd)
+          + "\n" + variant("CreateDemodGraph11a_40M_HipAll", fft + dmd + ctxb))
     diff = ["--- kernel/bb/demod11/fb11ademod_config.hpp (CreateDemodGraph11a_40M)", "+++ the same with HIP bricks"]
-    for a, b in fft + dmd:
+    for a, b in fft + dmd + ctxb:
         for line in body.split("\n"):
             if a in line:
                 diff += ["-" + line.strip(), "+" + line.strip().replace(a, b)]

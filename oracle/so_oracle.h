@@ -66,6 +66,11 @@ void so_rx11a_ctx_reset(so_rx11a_ctx* c);                                   /* f
 void so_lts(so_rx11a_ctx* c, const so_c16 in144[144]);                       /* T11aLTS  channel_11a.hpp:206-229 */
 void so_sym_front(const so_rx11a_ctx* c, const so_c16 in80[80], so_c16 eq[64]);/* T11aDataSymbol..TChannelEqualization */
 void so_sym_track(so_rx11a_ctx* c, const so_c16 eq[64], so_c16 out[64]);     /* TPhaseCompensate + TPilotTrack */
+/* ... and the five bricks of those two, one by one */
+void so_freq_comp(const so_rx11a_ctx* c, const so_c16 in[64], so_c16 out[64]);   /* TFreqCompensation (in = the 64 samples behind the cyclic prefix) */
+void so_equalize(const so_rx11a_ctx* c, const so_c16 in[64], so_c16 out[64]);    /* TChannelEqualization */
+void so_phase_comp(const so_rx11a_ctx* c, const so_c16 in[64], so_c16 out[64]);  /* TPhaseCompensate */
+void so_pilot_track(so_rx11a_ctx* c, const so_c16 pc[64], so_c16 out[64]);       /* TPilotTrack (pc = TPhaseCompensate's output) */
 void so_demap(int nbpsc, const so_c16 in[64], uint8_t* soft);                /* T11aDemap<N_BPSC> -> 48*nbpsc soft */
 void so_deinterleave(int nbpsc, const uint8_t* in, uint8_t* out);            /* T11aDeinterleave* */
 uint32_t so_viterbi_sig(const uint8_t soft48[48]);                           /* Viterbi_sig11 + >>6 */

@@ -74,18 +74,25 @@ void so_lts(so_rx11a_ctx* c, const so_c16 in144[144])
     }
 }
 
-/* ------------------------------------------------------------------ data symbol, up to the equaliser */
+/* ------------------------------------------------------------------ data symbol, up to the equaliser: brick by brick */
+void so_freq_comp(const so_rx11a_ctx* c, const so_c16 in[64], so_c16 out[64])           /* TFreqCompensation (channel_11a.hpp:636-652) */
+{
+    for (int i = 0; i < 64; i++) out[i] = so_mul_q15(so_sra(in[i], 1), c->FreqCoeffs[i]);   /* rep_shift_right<16>(pi, pi, 1) :643; FrequencyShift :644 */
+}
+void so_equalize(const so_rx11a_ctx* c, const so_c16 in[64], so_c16 out[64])            /* TChannelEqualization (channel_11a.hpp:548-574) */
+{
+    for (int i = 0; i < 64; i++) {
+        if (i >= 28 && i < 36) { out[i] = so_c(0, 0); continue; }
+        int32_t re, im; so_mul32(in[i], c->ChannelCoeffs[i], &re, &im);
+        out[i] = so_c(so_w16(re >> 8), so_w16(im >> 8));
+    }
+}
 void so_sym_front(const so_rx11a_ctx* c, const so_c16 in80[80], so_c16 eq[64])
 {
     so_c16 x[64], Y[64];
-    for (int i = 0; i < 64; i++) x[i] = so_sra(in80[8 + i], 1);        /* T11aDataSymbol skip_cp=8 (PHY_11a.hpp:393-397); TFreqCompensation >>1 (channel_11a.hpp:643) */
-    for (int i = 0; i < 64; i++) x[i] = so_mul_q15(x[i], c->FreqCoeffs[i]);      /* :644 */
+    so_freq_comp(c, in80 + 8, x);                                      /* T11aDataSymbol skip_cp=8 (PHY_11a.hpp:393-397) */
     so_fft64(x, Y);                                                    /* TFFT64 (fft.hpp:121-134) */
-    for (int i = 0; i < 64; i++) {                                     /* TChannelEqualization (channel_11a.hpp:548-574) */
-        if (i >= 28 && i < 36) { eq[i] = so_c(0, 0); continue; }
-        int32_t re, im; so_mul32(Y[i], c->ChannelCoeffs[i], &re, &im);
-        eq[i] = so_c(so_w16(re >> 8), so_w16(im >> 8));
-    }
+    so_equalize(c, Y, eq);
 }
 
 /* ------------------------------------------------------------------ TPhaseCompensate + TPilotTrack */
@@ -104,12 +111,19 @@ static void build_coeff(so_c16* p, int16_t ave, int16_t delta)        /* pilot.h
     for (int i = 1; i <= 26; i++)      { p[i].re = ucos[(uint16_t)th]; p[i].im = (int16_t)(-usin[(uint16_t)th]); th = (int16_t)(th + delta); }
 }
 
+void so_phase_comp(const so_rx11a_ctx* c, const so_c16 in[64], so_c16 out[64])          /* TPhaseCompensate: rep_mul<16> (freqoffset.hpp:28-30) */
+{
+    for (int i = 0; i < 64; i++) out[i] = so_mul_q15(in[i], c->CompCoeffs[i]);
+}
 void so_sym_track(so_rx11a_ctx* c, const so_c16 eq[64], so_c16 out[64])
 {
-    so_init();
     so_c16 pc[64];
-    for (int i = 0; i < 64; i++) pc[i] = so_mul_q15(eq[i], c->CompCoeffs[i]);   /* TPhaseCompensate: rep_mul<16> (freqoffset.hpp:28-30) */
-
+    so_phase_comp(c, eq, pc);
+    so_pilot_track(c, pc, out);
+}
+void so_pilot_track(so_rx11a_ctx* c, const so_c16 pc[64], so_c16 out[64])               /* TPilotTrack alone: pc = TPhaseCompensate's output */
+{
+    so_init();
     /* _pilot_track (pilot.hpp:166-233) */
     int16_t th1 = so_uatan2(pc[64 - 21].im, pc[64 - 21].re);
     int16_t th2 = so_uatan2(pc[64 - 7].im,  pc[64 - 7].re);

@@ -280,6 +280,8 @@ template __global__ void k_deint_batch<4>(const uint8_t*, uint8_t*, uint32_t, Ta
 template __global__ void k_deint_batch<6>(const uint8_t*, uint8_t*, uint32_t, Tables);
 
 // sora_track11a_state: { int16 cfo_comp, sfo_comp, cfo_tracker, sfo_tracker; uint32 symbol_count; COMPLEX16 comp[64]; } = 67 words
+// PHASE = false: TPilotTrack alone (its input is TPhaseCompensate's output)
+template <bool PHASE>
 __global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T)
 {
     const uint32_t f = blockIdx.x;
@@ -294,7 +296,8 @@ __global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const u
     const bool data_bin = (lane >= 1 && lane <= 26) || lane >= 38;              // bins _build_coeff writes (pilot.hpp:138-164)
     const uint32_t s0 = first[f], ns = nsym[f];
     for (uint32_t s = 0; s < ns; s++) {
-        const cpx pc = mul_q15(unpack(eq[(size_t)(s0 + s) * 64 + lane]), comp);    // TPhaseCompensate: rep_mul<16>
+        const cpx in = unpack(eq[(size_t)(s0 + s) * 64 + lane]);
+        const cpx pc = PHASE ? mul_q15(in, comp) : in;                           // TPhaseCompensate: rep_mul<16>
         const uint32_t pk = pack(pc);
         const cpx p43 = unpack((uint32_t)__shfl((int)pk, 43)), p57 = unpack((uint32_t)__shfl((int)pk, 57));
         const cpx p7 = unpack((uint32_t)__shfl((int)pk, 7)),   p21 = unpack((uint32_t)__shfl((int)pk, 21));
@@ -318,6 +321,8 @@ __global__ void __launch_bounds__(64) k_ptrack_batch(const uint32_t* eq, const u
         st[2] = symbol_count;
     }
 }
+template __global__ void k_ptrack_batch<true>(const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, Tables);
+template __global__ void k_ptrack_batch<false>(const uint32_t*, const uint32_t*, const uint32_t*, uint32_t*, uint32_t*, uint32_t, Tables);
 
 // ---------------------------------------------------------------------------------------------------------------
 // FFT<128>: 32 lanes per transform, 4 points per lane, 8 transforms per tile, 4 tiles per 256-thread block (fft128_core,

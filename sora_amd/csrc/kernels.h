@@ -111,7 +111,7 @@ template <int NB> __global__ void k_demap_batch(const uint32_t* in, uint8_t* sof
 template <int NB> __global__ void k_deint_batch(const uint8_t* in, uint8_t* out, uint32_t n, Tables T);
 __global__ void k_lts_batch(const uint32_t* in, uint32_t* ctx, uint32_t n, Tables T);
 __global__ void k_symfront_batch(const uint32_t* in, const uint32_t* ctx, const uint32_t* ctx_index, uint32_t* eq, uint32_t n, Tables T);
-__global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
+template <bool PHASE> __global__ void k_ptrack_batch(const uint32_t* eq, const uint32_t* first, const uint32_t* nsym, uint32_t* state, uint32_t* out, uint32_t nframes, Tables T);
 template <int KIND> __global__ void k_cmul64_batch(const uint32_t* in, const uint32_t* coef, uint32_t cstride, uint32_t coff, const uint32_t* cindex, uint32_t* out, uint32_t n);
 __global__ void k_fft128_batch(const uint32_t* in, uint32_t* out, uint32_t n, Tables T);
 struct TxArgs {                // sora_hip_tx11a (k_tx.hip)

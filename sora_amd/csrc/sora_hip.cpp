@@ -1688,19 +1688,29 @@ int sora_hip_phase_comp11a(const sora_complex16* d_in, const sora_track11a_state
     return cmul64_stage(2, "sora_hip_phase_comp11a: null pointer", d_in, d_state, 67u, 3u, d_state_index, d_out, n, stream);
 }
 
-int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out,
-        size_t nframes, void* stream)
+static int ptrack_stage(bool phase, const char* who, const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out,
+                        size_t nframes, void* stream)
 {
     if (sora_hip_device_count() <= 0) return fail(SORA_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
-    if (!d_eq || !d_first || !d_nsym || !d_state || !d_out) return fail(SORA_ERR_INVALID_PARAM, "sora_hip_pilot_track11a: null pointer");
+    if (!d_eq || !d_first || !d_nsym || !d_state || !d_out) return fail(SORA_ERR_INVALID_PARAM, who);
     static_assert(sizeof(sora_track11a_state) == 268, "sora_track11a_state layout");
     if (nframes == 0) return SORA_OK;
     DevTables* D = stage_tables(); if (!D) return fail(SORA_ERR_HARDWARE_FAILED, "table upload failed");
-    hipLaunchKernelGGL(k_ptrack_batch, dim3((unsigned)nframes), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_eq), d_first, d_nsym,
-                       reinterpret_cast<uint32_t*>(d_state), reinterpret_cast<uint32_t*>(d_out), (uint32_t)nframes, D->T);
+    if (phase)
+        hipLaunchKernelGGL(k_ptrack_batch<true>, dim3((unsigned)nframes), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_eq), d_first, d_nsym,
+                           reinterpret_cast<uint32_t*>(d_state), reinterpret_cast<uint32_t*>(d_out), (uint32_t)nframes, D->T);
+    else
+        hipLaunchKernelGGL(k_ptrack_batch<false>, dim3((unsigned)nframes), dim3(64), 0, (hipStream_t)stream, reinterpret_cast<const uint32_t*>(d_eq), d_first, d_nsym,
+                           reinterpret_cast<uint32_t*>(d_state), reinterpret_cast<uint32_t*>(d_out), (uint32_t)nframes, D->T);
     HIPCHK(hipGetLastError());
     return SORA_OK;
 }
+int sora_hip_pilot_track11a(const sora_complex16* d_eq, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out,
+        size_t nframes, void* stream)
+{ return ptrack_stage(true, "sora_hip_pilot_track11a: null pointer", d_eq, d_first, d_nsym, d_state, d_out, nframes, stream); }
+int sora_hip_pilot11a(const sora_complex16* d_in, const uint32_t* d_first, const uint32_t* d_nsym, sora_track11a_state* d_state, sora_complex16* d_out,
+        size_t nframes, void* stream)
+{ return ptrack_stage(false, "sora_hip_pilot11a: null pointer", d_in, d_first, d_nsym, d_state, d_out, nframes, stream); }
 
 int sora_hip_demap11a(const sora_complex16* d_in, uint8_t* d_soft, int n_bpsc, size_t n, void* stream)
 {

@@ -80,6 +80,18 @@ def test_lts_symfront_track_chain(env, oracle):
         assert int(st_h[i, 4:6].view(np.uint32)[0]) == k.symbol_count
         assert np.array_equal(st_h[i, 6:].reshape(64, 2)[used], np.array(k.CompCoeffs[:], np.int16).reshape(64, 2)[used])
 
+    # ---- TPhaseCompensate and TPilotTrack as two bricks (sora_hip_phase_comp11a -> sora_hip_pilot11a), symbol by symbol as the graph runs them: the same outputs and
+    # the same state as the fused entry point left
+    st2 = torch.from_numpy(st).cuda()
+    one_first = torch.zeros(1, dtype=torch.int32).cuda(); one_n = torch.ones(1, dtype=torch.int32).cuda()
+    for i in range(min(2, len(frames))):
+        for s_i in range(min(nsym[i], 12)):
+            pcs = sora.phase_comp11a(eq[first[i] + s_i:first[i] + s_i + 1], st2[i:i + 1])
+            o2 = sora.pilot11a(pcs, one_first, one_n, st2[i:i + 1]).cpu().numpy()[0]
+            assert np.array_equal(o2[used], trk_h[first[i] + s_i][used]), (i, s_i)
+        if nsym[i] <= 12:
+            assert np.array_equal(st2[i].cpu().numpy(), st_h[i])
+
 
 def test_fft128_bit_exact(env, oracle):
     torch, sora = env
