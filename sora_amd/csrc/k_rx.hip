@@ -34,17 +34,29 @@ struct FrameLds {
     uint32_t eq[4][4][64];                                                       // [wave][symbol of the pass]: FFT staging, then the equalised bins
     uint8_t  soft[4][4][288];                                                    // [wave][symbol of the pass]: soft values in carrier order
     uint8_t  demap[1024];                                                        // DemapperCore step tables (filled by the caller, 256 threads, in front of a block barrier)
+    // SHARED tracker (k_frame): what wave 0 -- which runs the pilot tracker of all four frames of the workgroup -- hands back per [frame][symbol of the pass]:
+    // {CFO_comp, SFO_comp before the symbol, the symbol's mean phase and slope}; and what it needs of the frames at the start
+    int4     trk[4][4];
+    int      nsym_of[4];
+    short    st0[4][4];                                                          // [frame] { CFO_comp, SFO_comp, CFO_tracker, SFO_tracker } behind the SIGNAL symbol
 };
-// one wave, the frame queued at slot j of jobs[] / joblist[]: its VitJob and its packed soft stream
-__device__ __forceinline__ void frame_symbols(const RxArgs& A, uint32_t j, FrameLds& lds)
+// One wave, the frame queued at slot j of jobs[] / joblist[]: its VitJob and its packed soft stream.
+// SHARED (k_frame; all four waves of the workgroup call it together, `valid` = the wave has a frame): the loop-carried part -- TPilotTrack's chain (pilot.hpp:166-233:
+// four pilot bins, two dependent LUT reads per symbol) -- of the workgroup's four frames runs in wave 0, four lanes per frame, between two block barriers per pass.
+// A wave spent 36 % of its vector instructions on that chain for the four lanes that hold ONE frame's pilots (and 40 scalar instructions per symbol on its state);
+// one wave doing it for four frames at once is the same latency chain at a quarter of the instructions -- and this path is priced by its instructions.
+// !SHARED: a wave on its own (the redo path behind k_pipe runs a frame at a time).
+template <bool SHARED>
+__device__ __forceinline__ void frame_symbols(const RxArgs& A, uint32_t j, FrameLds& lds, bool valid = true)
 {
     uint32_t (&s_eq)[4][4][64] = lds.eq; uint8_t (&s_soft)[4][4][288] = lds.soft; const uint8_t* s_demap = lds.demap;
     const int w = threadIdx.x >> 6, lane = threadIdx.x & 63, g = lane >> 4, e = lane & 15;
     const Tables& T = A.T;
-    const uint32_t f = A.joblist[j];
-    const FrameRow r = A.frames[f];
+    const uint32_t f = valid ? A.joblist[j] : 0u;
+    FrameRow r = A.frames[f];
+    if (!valid) { r.nsym = 0; r.nbpsc = 1; }
     const uint32_t my_nsoft = (uint32_t)r.nsym * 48u * r.nbpsc;
-    if (lane == 0) {
+    if (lane == 0 && valid) {
         VitJob J;
         J.valid = 1; J.soft_off = r.slot0 * (uint32_t)kSoftBytesPerSlot; J.nsoft = my_nsoft; J.length = r.length;
         J.dec_off = 0; J.out_off = r.slot0 * (uint32_t)kOutPerSlot; J.code_rate = r.code_rate; J.soft_bits = 3;
@@ -81,11 +93,24 @@ __device__ __forceinline__ void frame_symbols(const RxArgs& A, uint32_t j, Frame
 #pragma unroll
         for (int m = 0; m < 4; m++) raw[m] = (s0 + g <= nsym) ? iq[(size_t)(p0 + (uint32_t)(e + 16 * m)) * A.str] : 0u;
     };
+    // ---- SHARED: the frames' lengths and tracker states to wave 0, lanes 4 f + k (pilot k of the frame of wave f)
+    int nsym_loop = nsym, nsym_f = nsym;
+    if (SHARED) {
+        if (lane == 0) { lds.nsym_of[w] = nsym; lds.st0[w][0] = (short)cfo_comp; lds.st0[w][1] = (short)sfo_comp; lds.st0[w][2] = (short)cfo_tr; lds.st0[w][3] = (short)sfo_tr; }
+        __syncthreads();
+        nsym_loop = max(max(lds.nsym_of[0], lds.nsym_of[1]), max(lds.nsym_of[2], lds.nsym_of[3]));
+        const int fr = (lane >> 2) & 3;
+        nsym_f = lds.nsym_of[fr];
+        cfo_comp = lds.st0[fr][0]; sfo_comp = lds.st0[fr][1]; cfo_tr = lds.st0[fr][2]; sfo_tr = lds.st0[fr][3];   // (only wave 0 uses them from here on)
+    }
     uint32_t raw[4];
     load_samples(1, raw);
-    for (int s0 = 1; s0 <= nsym; s0 += 4) {
+    for (int s0 = 1; s0 <= nsym_loop; s0 += 4) {
         const int sym = s0 + g;
         const bool active = sym <= nsym;
+        const bool mine = s0 <= nsym;                                            // (SHARED: a wave whose frame is shorter only keeps the barriers company)
+        int my_cfo = 0, my_sfo = 0, my_avg = 0, my_del = 0;
+        if (mine) {
         // ---- TFreqCompensation + TFFT64 + TChannelEqualization on packed COMPLEX16 (dev_arith.h), symbol `sym` in group g
         pcx x[4], Y[4];
 #pragma unroll
@@ -101,7 +126,41 @@ __device__ __forceinline__ void frame_symbols(const RxArgs& A, uint32_t j, Frame
             s_eq[w][g][bin] = (bin >= 28 && bin < 36) ? 0u : pk_cmul<8>(Y[q], ch[q]);
         }
         wsync();
+        }
         // ---- the loop-carried part, symbols s0 .. s0+3 in order
+        if (SHARED) {
+            __syncthreads();                                                     // every wave's four equalised symbols are in LDS
+            if (w == 0) {
+                const int fr = (lane >> 2) & 3;                                  // lanes 16 .. 63 repeat lanes 0 .. 15 (one instruction stream either way)
+#pragma unroll
+                for (int gg = 0; gg < 4; gg++) {
+                    const bool act = s0 + gg <= nsym_f;
+                    const int c0 = cfo_comp, s0c = sfo_comp;
+                    const cpx p = mul_q15(unpack(s_eq[fr][gg][pbin]), rot_coeff(T, w16(cfo_comp + pc * sfo_comp)));
+                    int th = pk == 3 ? uatan2(T, -p.im, -p.re) : uatan2(T, p.im, p.re);
+                    // (the symbol index is the same for every frame -- all of them start behind their SIGNAL symbol -- and wave-uniform: a scalar)
+                    if (kPilotSgn[(symbol_count + (unsigned)gg) % 127u]) th = w16(th + 0x8000);
+                    // the frame's four angles in each of its four lanes: quad_perm broadcasts
+                    int th1 = __builtin_amdgcn_update_dpp(0, th, 0x00, 0xF, 0xF, true), th2 = __builtin_amdgcn_update_dpp(0, th, 0x55, 0xF, 0xF, true);
+                    int th3 = __builtin_amdgcn_update_dpp(0, th, 0xAA, 0xF, 0xF, true), th4 = __builtin_amdgcn_update_dpp(0, th, 0xFF, 0xF, 0xF, true);
+                    // The four moves stay moves.  Left alone, hipcc (ROCm 7.2) folds them into the sums below as v_add_u32_dpp / v_subrev_u32_dpp, and on gfx950 that
+                    // form gave th2 - th4 where the source says th4 - th2 (measured round 6: one frame in sixteen lost its CRC through the slope's sign; the same
+                    // arithmetic through four separate v_mov_b32_dpp, or through ds_bpermute, is bit-exact: DESIGN.md section 3.11).
+                    asm volatile("" : "+v"(th1), "+v"(th2), "+v"(th3), "+v"(th4));
+                    const int avg = w16((th1 + th2 + th3 + th4) / 4);
+                    const int del = w16(((th3 - th1) / 28 + (th4 - th2) / 28) >> 1);
+                    if (act) {
+                        cfo_tr = w16(cfo_tr + (avg >> 2)); sfo_tr = w16(sfo_tr + (del >> 2));
+                        cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
+                    }
+                    if (lane < 16 && pk == 0) lds.trk[fr][gg] = int4{ c0, s0c, act ? avg : 0, act ? del : 0 };
+                }
+            }
+            symbol_count = (symbol_count + 4u) % 127u;
+            __syncthreads();
+            const int4 t = lds.trk[w][g];
+            my_cfo = t.x; my_sfo = t.y; my_avg = t.z; my_del = t.w;
+        } else {
         int t_cfo[4], t_sfo[4], t_avg[4], t_del[4];
 #pragma unroll
         for (int gg = 0; gg < 4; gg++) {
@@ -120,12 +179,14 @@ __device__ __forceinline__ void frame_symbols(const RxArgs& A, uint32_t j, Frame
                 cfo_comp = w16(cfo_comp + avg + cfo_tr); sfo_comp = w16(sfo_comp + del + sfo_tr);
             }
         }
+        my_cfo = g == 0 ? t_cfo[0] : g == 1 ? t_cfo[1] : g == 2 ? t_cfo[2] : t_cfo[3];
+        my_sfo = g == 0 ? t_sfo[0] : g == 1 ? t_sfo[1] : g == 2 ? t_sfo[2] : t_sfo[3];
+        my_avg = g == 0 ? t_avg[0] : g == 1 ? t_avg[1] : g == 2 ? t_avg[2] : t_avg[3];
+        my_del = g == 0 ? t_del[0] : g == 1 ? t_del[1] : g == 2 ? t_del[2] : t_del[3];
+        }
+        if (!mine) continue;
         // ---- TPhaseCompensate + TPilotTrack::_rotate + T11aDemap, 3 data carriers per lane
         if (active) {
-            const int my_cfo = g == 0 ? t_cfo[0] : g == 1 ? t_cfo[1] : g == 2 ? t_cfo[2] : t_cfo[3];
-            const int my_sfo = g == 0 ? t_sfo[0] : g == 1 ? t_sfo[1] : g == 2 ? t_sfo[2] : t_sfo[3];
-            const int my_avg = g == 0 ? t_avg[0] : g == 1 ? t_avg[1] : g == 2 ? t_avg[2] : t_avg[3];
-            const int my_del = g == 0 ? t_del[0] : g == 1 ? t_del[1] : g == 2 ? t_del[2] : t_del[3];
             cpx c1[3], c2[3];
 #pragma unroll
             for (int m = 0; m < 3; m++) {                                        // all six coefficient reads in flight together
@@ -175,9 +236,13 @@ __global__ void __launch_bounds__(256) k_frame(RxArgs A)
     __shared__ FrameLds lds;
     reinterpret_cast<uint32_t*>(lds.demap)[threadIdx.x] = reinterpret_cast<const uint32_t*>(A.T.demap)[threadIdx.x];
     __syncthreads();                                                             // the only block barrier: the waves are independent from here on
+    if (!locate_job(blockIdx.x * 4, A.njobs).ok) return;                         // (the whole workgroup)
     const JobRef jr = locate_job(blockIdx.x * 4 + (threadIdx.x >> 6), A.njobs);
-    if (!jr.ok) return;
-    frame_symbols(A, jr.list * A.nrows + jr.idx, lds);                           // slot of the job in jobs[] / joblist[]
+#ifdef SORA_DBG_KFRAME_PRIVATE                                                   // (tools variant: every wave tracks its own frame, as before round 6)
+    if (jr.ok) frame_symbols<false>(A, jr.list * A.nrows + jr.idx, lds);
+#else
+    frame_symbols<true>(A, jr.ok ? jr.list * A.nrows + jr.idx : 0u, lds, jr.ok);   // slot of the job in jobs[] / joblist[]; a wave without one still meets the others at the barriers
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1487,8 +1552,8 @@ struct PipeFallbackGate {
     __device__ __forceinline__ bool operator()(uint32_t list, uint32_t fa, uint32_t fb, bool hasB) const
     {
         if (!gave_up) return proof(list, fa, fb, hasB);
-        frame_symbols(*A, list * A->nrows + fa, *lds);
-        if (hasB) frame_symbols(*A, list * A->nrows + fb, *lds);
+        frame_symbols<false>(*A, list * A->nrows + fa, *lds);
+        if (hasB) frame_symbols<false>(*A, list * A->nrows + fb, *lds);
         // (the same wave reads the jobs and the soft stream back through the L2)
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent"); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         return true;

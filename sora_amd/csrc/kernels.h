@@ -9,7 +9,7 @@
 // Experiment and probe switches (SORA_EXP_*, SORA_DBG_*) belong to the TOOLS variant of the library (sora_amd.build.build_variant adds -DSORA_TOOLS for them): the product
 // build refuses them, so no measurement scaffolding can reach it by accident.
 #if !defined(SORA_TOOLS) && (defined(SORA_EXP_NORING) || defined(SORA_EXP_LB) || defined(SORA_EXP_STAGGER) || defined(SORA_EXP_VIT_PRIO) || defined(SORA_DBG_TRACK_TH) || \
-                             defined(SORA_DBG_NO_TRACE) || defined(SORA_DBG_NO_SYMBOLS) || defined(SORA_DBG_NO_TRELLIS) || defined(SORA_SCAN_PROBE))
+                             defined(SORA_DBG_NO_TRACE) || defined(SORA_DBG_KFRAME_PRIVATE) || defined(SORA_DBG_NO_SYMBOLS) || defined(SORA_DBG_NO_TRELLIS) || defined(SORA_SCAN_PROBE))
 #error "SORA_EXP_* / SORA_DBG_* switches need -DSORA_TOOLS (sora_amd.build.build_variant)"
 #endif
 
