@@ -47,7 +47,8 @@ typedef struct { int16_t re, im; } sora_complex16;
 #define SORA_E_PARAMETER         ((int)0x80000001)
 #define SORA_E_PLCP_HEADER_FAIL  ((int)0x80000005)
 #define SORA_E_CRC32_FAIL        ((int)0x80000006)
-#define SORA_E_INTERNAL_TIMEOUT  ((int)0x8000F001) /* retired (ABI 3 reported a frame with it when a bounded wait inside k_pipe expired); since ABI 4 no row carries it: the call is redone on the device */
+/* retired: ABI 3 reported a frame with it when a bounded wait inside k_pipe expired; since ABI 4 no row carries it (the call is made again on the device) */
+#define SORA_E_INTERNAL_TIMEOUT  ((int)0x8000F001)
 #define SORA_ERR_FAILED          ((int)0x8000FFFF)  /* BK_ERROR_FAILED */
 #define SORA_ERR_HARDWARE_FAILED ((int)0x8000FFFE)  /* BK_ERROR_HARDWARE_FAILED: a HIP call failed */
 #define SORA_ERR_INVALID_PARAM   (-1)               /* BK_ERROR_INVALID_PARAM */
@@ -219,8 +220,10 @@ int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
  *                    three look-up tables folded into LDS: a frame's symbols spread over the chip -- the one for few, long frames (fsample-6: 465 symbols);
  *   4   k_pipe       form 3 AND the window-parallel trellis as ONE launch whose workgroups hand symbols on as the tracker passes them (the reference's demod || Viterbi
  *                    overlap, fb11a_demod.cpp:109-112, inside a frame): the one for a handful of frames (a single capture).  (Its trellis units run two per wave in k_viterbi's
- *                    64-lane layout while the handle's calls in flight are few enough for that many workgroups -- a lone capture with up to three calls in flight --, eight per wave otherwise.)  Used only with the window-parallel trellis and
- *                    where every workgroup of the handle's calls in flight is resident at once (at most three quarters of the device's compute units: 192 on an MI355X); otherwise a request for 4 runs as 3.  Its hand-offs
+ *                    64-lane layout while the handle's calls in flight are few enough for that many workgroups -- a lone capture with up to three calls in flight --, eight per wave
+ *                    otherwise.)  Used only with the window-parallel trellis and
+ *                    where every workgroup of the handle's calls in flight is resident at once (at most three quarters of the device's compute units: 192 on an MI355X); otherwise a request
+ *                    for 4 runs as 3.  Its hand-offs
  *                    are bounded waits (sora_rx_set_pipe_wait_us): should one expire -- another process or other GPU work holds the compute units its workgroups need -- the
  *                    launch's finishing kernel makes the call's data field again with form 1's code and the serial trellis, so the call still delivers the reference's rows
  *                    (never an error code of this library's own), and the handle keeps to form 3 for its next 64 calls (sora_rx_pipe_stats counts both);
@@ -412,7 +415,8 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
 /* Calls in flight, as for sora_rx_t: consecutive process calls rotate over `depth` pipelines (own stream and result arrays; default 1, at most 8), so
  * the latency-bound scan / symbol kernels of one call overlap the issue-bound trellis kernel of the call before it.  Every call has a ticket;
  * sora_rx11n_results / _stream refer to the most recent call, sora_rx11n_wait / _results_of to the call whose ticket is given (valid until `depth`
- * further calls have been made, or until the call is released: delivered and waited for, see sora_rx_wait_any); an input buffer must stay untouched until the call that reads it has finished.  sora_rx11n_set_depth returns the
+ * further calls have been made, or until the call is released: delivered and waited for, see sora_rx_wait_any); an input buffer must stay untouched until the call that reads it has
+ * finished.  sora_rx11n_set_depth returns the
  * previous value (depth <= 0 only queries) and waits for the calls in flight; sora_rx11n_process (host buffers) also does. */
 int   sora_rx11n_set_depth(sora_rx11n_t* rx, int depth);
 /* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
@@ -476,7 +480,8 @@ int   sora_ht40_results(sora_ht40_t* rx, sora_frame_result* h_out, size_t max_ou
 int   sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0, const sora_complex16* d_iq1, const sora_capture_desc* h_caps, size_t ncaps,
                                      uint32_t max_frames_per_capture);
 /* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_ht40_calls_in_flight() (8) further calls have reused its
- * slot (or, once the call is released -- delivered and waited for -- until the next call, which takes a released slot first) -- so back-to-back calls are all collectable, each by its own ticket, while later ones run.  The INPUT buffers of a call must stay
+ * slot (or, once the call is released -- delivered and waited for -- until the next call, which takes a released slot first) -- so back-to-back calls are all collectable, each by its own
+ * ticket, while later ones run.  The INPUT buffers of a call must stay
  * untouched until sora_ht40_wait(its ticket) (or _results_of, or _synchronize) has returned. */
 int   sora_ht40_ticket(sora_ht40_t* rx);                       /* ticket of the most recent process call (0: none) */
 int   sora_ht40_calls_in_flight(sora_ht40_t* rx);              /* how many calls the handle keeps addressable */
@@ -552,7 +557,8 @@ int  sora_rx11b_process_dev(sora_rx11b_t* rx, const sora_complex16* d_iq, const 
 int  sora_rx11b_process(sora_rx11b_t* rx, const sora_complex16* h_iq, size_t nsamples, const sora_capture_desc* caps, size_t ncaps);
 int  sora_rx11b_results(sora_rx11b_t* rx, sora_frame_result* out, size_t max_out, size_t* nout, uint8_t* h_mpdu, size_t mpdu_cap);
 /* Tickets, as for sora_rx_t: every process call has one; it stays valid until sora_rx11b_calls_in_flight() (2) further calls have reused its
- * slot (or, once the call is released -- delivered and waited for -- until the next call, which takes a released slot first) -- back-to-back calls are all collectable, each by its own ticket, while the next one runs (what fb11b_demod.cpp does per frame,
+ * slot (or, once the call is released -- delivered and waited for -- until the next call, which takes a released slot first) -- back-to-back calls are all collectable, each by its own
+ * ticket, while the next one runs (what fb11b_demod.cpp does per frame,
  * per call).  The INPUT buffer of a call must stay untouched until sora_rx11b_wait(its ticket) (or _results_of, or _synchronize) has returned. */
 int   sora_rx11b_ticket(sora_rx11b_t* rx);                     /* ticket of the most recent process call (0: none) */
 int   sora_rx11b_calls_in_flight(sora_rx11b_t* rx);            /* how many calls the handle keeps addressable */

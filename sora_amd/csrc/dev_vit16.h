@@ -16,7 +16,8 @@ template <int WIN, int LOOK> struct Geom16 {
 };
 
 template <int WIN, int LOOK> struct Lds16 {
-#ifdef SORA_EXP_NORING                                                           // experiment (tools/r04_exp_noring.sh): no survivor ring, no trace-back -- results are wrong, only the duration means something
+// SORA_EXP_NORING: experiment (tools/r04_exp_noring.sh): no survivor ring, no trace-back -- results are wrong, only the duration means something
+#ifdef SORA_EXP_NORING
     uint16_t ring[1][4][64];
 #else
     // [block % P][row][rev6(state)] {frame A's byte, frame B's byte}: 18944 / 15872 B

@@ -651,7 +651,9 @@ int sora_ht40_process_captures_dev(sora_ht40_t* rx, const sora_complex16* d_iq0,
 // a raw-capture call whose stream has been waited for: the front end's records (in page-locked memory by now) -> the call's events
 static int ht40_collect_events(Ht40Slot& S)
 {
-    if (!S.events_pending) return S.plan_error ? sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: the captures hold more frames / soft values than the handle was created for (max_frames, max_soft_values)", 0) : SORA_OK;
+    if (!S.events_pending)
+        return S.plan_error ? sora_internal_fail(SORA_ERR_CAPACITY, "sora_ht40_process_captures_dev: the captures hold more frames / soft values than the handle was created for "
+                                                                    "(max_frames, max_soft_values)", 0) : SORA_OK;
     S.events_pending = false;
     S.plan_error = S.h_plan[3] != 0;
     S.events.clear();

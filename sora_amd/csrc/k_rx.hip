@@ -736,7 +736,8 @@ __global__ void __launch_bounds__(256) k_sym_back(RxArgs A)
 //                               three counters of its frames say that every soft value it will read has been written, acquires, and decodes
 // Waiting only ever looks at a workgroup of a LOWER role, the launch is small enough for every workgroup to be resident at once (sora_hip.cpp: pipe_fits -- 160 KB
 // of LDS each, one per CU, at most ~190 of the 256), and every wait is bounded (PipeArgs::wait_ticks): a wait that expires sets flags[0] and gives up, and the finishing
-// kernel behind this launch (k_win_redo_finish_pipe) then makes the whole data field again with the plain chain's code -- a call never delivers anything but the reference's rows.  Hand-offs follow cdna_hip_programming.md guideline 16.
+// kernel behind this launch (k_win_redo_finish_pipe) then makes the whole data field again with the plain chain's code
+// -- a call never delivers anything but the reference's rows.  Hand-offs follow cdna_hip_programming.md guideline 16.
 // The proof of the units and the serial decode of what fails it stay a kernel of their own behind this one (k_win_redo), then k_finish.
 // pilots kept in LDS: 1366 data symbols (4095 bytes at 6 Mbps) + the chain's overshoot to a multiple of eight
 constexpr uint32_t kPipeMaxSym = 1376;

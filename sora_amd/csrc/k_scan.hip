@@ -37,7 +37,8 @@ __device__ unsigned long long g_scan_probe[16];              // [0..7] ticks per
 #define PROBE_T(n) const long long n = clock64()
 #define PROBE_A(n, i) do { _pa[i] += clock64() - n; _pn[i]++; } while (0)
 #define PROBE_TK() const long long _tk = clock64()
-#define PROBE_ADDK(i) do { _pa[i] += clock64() - _tk; _pn[i]++; if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 0; q < 8; q++) { g_scan_probe[q] += (unsigned long long)_pa[q]; g_scan_probe[8 + q] += _pn[q]; } } while (0)
+#define PROBE_ADDK(i) do { _pa[i] += clock64() - _tk; _pn[i]++; \
+    if (blockIdx.x == 0 && threadIdx.x == 0) for (int q = 0; q < 8; q++) { g_scan_probe[q] += (unsigned long long)_pa[q]; g_scan_probe[8 + q] += _pn[q]; } } while (0)
 #else
 #define PROBE_DECL()
 #define PROBE_T0()
@@ -230,27 +231,51 @@ __device__ __noinline__ SigOut header_section(ScanTabs tabs, uint32_t lts_start_
     sync();
     uint8_t sa = 0, sb = 0;                                                     // de-interleaved soft pair of trellis step t = lane (t < 24)
     if (lane < 24) { sa = s_soft[carrier_bin(d0)]; sb = s_soft[carrier_bin(d1)]; }
-    // ---- Viterbi_sig11 (viterbicore.h:35-261): lane = state
-    const int n = lane;
-    const int r0 = n, r1 = 64 | n;
-    const int cA0 = __popc(r0 & 0155) & 1, cB0 = __popc(r0 & 0117) & 1;
-    const int cA1 = __popc(r1 & 0155) & 1, cB1 = __popc(r1 & 0117) & 1;
-    unsigned m = (n == 0) ? 0u : 0x30u;
-    uint64_t dec[25];                                                           // the 64 states' decisions per step: scalars (the loops are unrolled), not an LDS array
+    // ---- Viterbi_sig11 (viterbicore.h:35-261), the 64 states in the 64 lanes, IN PLACE: the butterfly (j, j + 32) -> (2 j, 2 j + 1) leaves new state rol6(s)
+    // in the lane that held s, so after u steps lane p holds state rol6^u(p) and a step's partner is lane p ^ (32 >> (u - 1) % 6): a permlane swap, a row
+    // rotation or a quad permutation -- no LDS round trip in the 24-step chain (round 5: two ds_bpermute per step, 5 k of the section's 9 k cycles).
+    // Both generators hold the register's oldest and newest bit (0155, 0117), so the branch to (64 | n) costs 28 - (the branch to n): one metric per step.
+    auto rol6c = [](unsigned x, unsigned k) { return ((x << k) | (x >> (6u - k))) & 63u; };
+    int selV[6], negV[6], n29V[6];                                              // per step phase k = u % 6: the lane's state is rol6(lane, k)
+#pragma unroll
+    for (int k = 0; k < 6; k++) {
+        const unsigned n = k ? rol6c((unsigned)lane, (unsigned)k) : (unsigned)lane;
+        const int cA = __popc(n & 0155) & 1, cB = __popc(n & 0117) & 1;
+        selV[k] = (cA ^ cB) ? -1 : 0; negV[k] = cB ? -1 : 0; n29V[k] = cB ? 29 : 0;
+    }
+    unsigned m = (lane == 0) ? 0u : 0x30u;
+    uint64_t dec[25];                                                           // decision of the state in lane p at step u: bit p of dec[u] (scalars: the loops are unrolled)
     dec[0] = 0;
 #pragma unroll
-    for (int t = 1; t <= 24; t++) {
-        const int va = __shfl((int)sa, t - 1), vb = __shfl((int)sb, t - 1);
-        const unsigned m0 = (unsigned)__shfl((int)m, n >> 1), m1 = (unsigned)__shfl((int)m, 32 + (n >> 1));
-        const unsigned b0 = (cA0 ? 2 * (7 - va) : 2 * va) + (cB0 ? 2 * (7 - vb) : 2 * vb);
-        const unsigned b1 = (cA1 ? 2 * (7 - va) : 2 * va) + (cB1 ? 2 * (7 - vb) : 2 * vb);
+    for (int u = 1; u <= 24; u++) {
+        const int ph = (u - 1) % 6, k = u % 6;
+        const unsigned X = 32u >> ph;
+        // the partner's metric (lane ^ X)
+        unsigned pm;
+        if (ph == 0) { auto r = __builtin_amdgcn_permlane32_swap(m, m, false, false); pm = lane < 32 ? r[1] : r[0]; }
+        else if (ph == 1) { auto r = __builtin_amdgcn_permlane16_swap(m, m, false, false); pm = (lane & 16) ? r[0] : r[1]; }
+        else if (ph == 2) pm = sdpp<0x128>(m);                                  // row_ror:8
+        else if (ph == 3) {                                                     // lanes with bit 2 set take lane - 4 (row_shr:4, banks 1 and 3), the others lane + 4 (row_shl:4, banks 0 and 2)
+            const int t4 = __builtin_amdgcn_update_dpp(0, (int)m, 0x114, 0xF, 0xA, false);
+            pm = (unsigned)__builtin_amdgcn_update_dpp(t4, (int)m, 0x104, 0xF, 0x5, false);
+        }
+        else if (ph == 4) pm = sdpp<0x4E>(m);                                   // quad_perm [2,3,0,1]
+        else pm = sdpp<0xB1>(m);                                                // quad_perm [1,0,3,2]
+        asm volatile("" : "+v"(pm));                                            // (the exchange stays a move: see k_rx.hip on DPP operands folded into subtractions)
+        const bool own_hi = ((unsigned)lane & X) != 0u;                         // the lane's old state has bit 5 set: it is the (j + 32) of its butterfly
+        const unsigned m0 = own_hi ? pm : m, m1 = own_hi ? m : pm;              // metrics of the predecessors n >> 1 and 32 + (n >> 1) of the new state n
+        // branch metrics (VIT_MA / VIT_MB, viterbilut.h): soft values of step u, wave-uniform
+        const int va = __builtin_amdgcn_readlane((int)sa, u - 1), vb = __builtin_amdgcn_readlane((int)sb, u - 1);
+        const int P = 2 * va + 2 * vb, dQP = 14 - 4 * va;                       // (cA, cB) = (0, 0): P; (1, 0): Q = 14 - 2 va + 2 vb = P + dQP; (., 1): 28 - that
+        const int x = P + (selV[k] & dQP);
+        const unsigned b0 = (unsigned)((x ^ negV[k]) + n29V[k]), b1 = 28u - b0;
         const unsigned c0 = (m0 + b0) & 0xFE, c1 = ((m1 + b1) & 0xFF) | 1;
         m = min(c0, c1);
-        dec[t] = __ballot(m & 1);
-        if ((t & 7) == 0) m = (m - (wave_min(m) & 0xFE)) & 0xFF;
+        dec[u] = __ballot(m & 1);
+        if ((u & 7) == 0) m = (m - (wave_min(m) & 0xFE)) & 0xFF;
     }
-    // (the extra normalisation before the trace-back does not change LSBs or the arg-min order)
-    const unsigned key = (m << 8) | ((unsigned)n << 2);
+    // (24 steps = four turns of the rotation: lane p holds state p again; the extra normalisation before the trace-back does not change LSBs or the arg-min order)
+    const unsigned key = (m << 8) | ((unsigned)lane << 2);
     const unsigned kmin = (unsigned)__builtin_amdgcn_readfirstlane((int)wave_min(key));
     int pos = (int)((kmin >> 2) & 0x3F) | (int)(((kmin >> 8) & 1) << 6);
     uint32_t sig = 0;
@@ -259,7 +284,10 @@ __device__ __noinline__ SigOut header_section(ScanTabs tabs, uint32_t lts_start_
         // reference emits MSB-first per byte while walking back: bit b of the walk is output bit (23-b)
         sig |= (uint32_t)((pos >> 6) & 1) << (23 - b);
         pos = (pos >> 1) & 0x3F;
-        pos |= (int)((dec[23 - b] >> pos) & 1) << 6;
+        // the decision of state pos at step 23 - b sits in the lane that held it then: ror6^(23 - b)(pos)
+        const unsigned r = (unsigned)(23 - b) % 6u;
+        const unsigned ln = r ? rol6c((unsigned)pos, 6u - r) : (unsigned)pos;
+        pos |= (int)((dec[23 - b] >> ln) & 1) << 6;
     }
     sig = (uint32_t)__builtin_amdgcn_readfirstlane((int)sig) >> 6;             // viterbi.hpp:39 (wave-uniform)
     // ---- T11aPLCPParser::_parse_plcp (PHY_11a.hpp:548-580)
@@ -400,6 +428,24 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
         }
     }
 
+    // frames queued for the per-frame kernels and not yet in joblist[]: lane q < nq holds (code rate << 28) | frame-table row
+    uint32_t q_job = 0, nq = 0;
+    auto flush_jobs = [&]() {
+        if (nq == 0) return;
+        const bool have = (uint32_t)lane < nq;
+        const uint32_t cr = q_job >> 28, row = q_job & 0x0FFFFFFFu;
+        const uint64_t m0 = __ballot(have && cr == 0u), m1 = __ballot(have && cr == 1u), m2 = __ballot(have && cr == 2u);
+        // lane r < 3 reserves list r's entries (the three atomics are in flight together)
+        const uint32_t cnt = lane == 0 ? (uint32_t)__popcll(m0) : lane == 1 ? (uint32_t)__popcll(m1) : (uint32_t)__popcll(m2);
+        uint32_t base = 0;
+        if (lane < 3 && cnt) base = atomicAdd(A.njobs + lane, cnt);
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_readlane((int)base, 0), b1 = (uint32_t)__builtin_amdgcn_readlane((int)base, 1), b2 = (uint32_t)__builtin_amdgcn_readlane((int)base, 2);
+        if (have) {
+            const uint64_t mine = cr == 0u ? m0 : cr == 1u ? m1 : m2, below = ((uint64_t)1 << lane) - 1u;
+            A.joblist[(size_t)cr * A.nrows + (cr == 0u ? b0 : cr == 1u ? b1 : b2) + (uint32_t)__popcll(mine & below)] = row;
+        }
+        nq = 0;
+    };
     uint32_t s = 0;                                 // next burst, 20 MHz-rate sample index
     PROBE_DECL();
     PROBE_TK();
@@ -638,8 +684,10 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
             const bool has_row = nfr < A.max_frames;
             const uint32_t slot0 = cd.slot_base + sym_start / 80u;
             if (ok && has_row) {
-                // queue the frame for the per-frame kernels
-                if (lane == 0) A.joblist[(size_t)r_cr * A.nrows + atomicAdd(A.njobs + r_cr, 1u)] = cap_i * A.max_frames + nfr;
+                // queue the frame for the per-frame kernels: remembered here (lane q holds the q-th frame's code rate and row), handed over when the walk is done or the
+                // lanes are used up -- ONE round trip to the counters per capture instead of one per frame in the walk's critical path
+                if ((uint32_t)lane == nq) q_job = (r_cr << 28) | (cap_i * A.max_frames + nfr);
+                if (++nq == 64u) flush_jobs();
                 // its data symbols' slots (k_sym_front / k_sym_back)
                 if (A.slot_row) for (uint32_t sy = 1u + (uint32_t)lane; sy <= r_nsym; sy += 64u) A.slot_row[slot0 + sy] = cap_i * A.max_frames + nfr;
             }
@@ -662,6 +710,7 @@ __global__ void __launch_bounds__(64, 4) k_scan(ScanArgs A)
     }
     // the capture ends in plain carrier sense: all of it is final
     if (streaming && s == NS && !cca_detected && !sync_high && auto_count == 0 && !to_pending) cont_save(s);
+    flush_jobs();
     if (lane == 0) A.nframes[cap_i] = nfr;
     PROBE_ADDK(5);
 }

@@ -303,7 +303,9 @@ int sora_internal_pin_table(const char* name, const void* data, size_t bytes)
     const std::string got = table_digest(data, bytes);
     for (const TablePin& t : kTablePins) if (!strcmp(t.name, name)) {
         if (got == t.sha256) return SORA_OK;
-        char msg[256]; snprintf(msg, sizeof msg, "look-up table '%s' does not have its pinned sha256 (this host's libm or the build's floating-point flags generate different tables): got %s", name, got.c_str());
+        char msg[256];
+        snprintf(msg, sizeof msg, "look-up table '%s' does not have its pinned sha256 (this host's libm or the build's floating-point flags generate different tables): got %s",
+                 name, got.c_str());
         return fail(SORA_ERR_FAILED, msg);
     }
     return fail(SORA_ERR_FAILED, "look-up table without a pinned digest");
@@ -636,7 +638,8 @@ static int pipe_create(const sora_rx_cfg* cfg, RxPipe** out, int index = 0)
     const uint64_t want_slots = n20 / 80 + cfg->max_captures + 16, want_rows = (uint64_t)cfg->max_captures * cfg->max_frames_per_capture;
     if (want_slots * (1ull * kSoftPerSlot) >= (1ull << 32) || want_rows >= (1ull << 31) / 3 || cfg->max_total_samples >= (1ull << 32)) {
         rx_free(rx);
-        return fail(SORA_ERR_CAPACITY, "sora_rx_create: max_total_samples / max_captures x max_frames_per_capture exceed the 32-bit slot geometry of one handle (split the batch over several handles)");
+        return fail(SORA_ERR_CAPACITY, "sora_rx_create: max_total_samples / max_captures x max_frames_per_capture exceed the 32-bit slot geometry of one handle "
+                                       "(split the batch over several handles)");
     }
     rx->cap_slots = (uint32_t)want_slots;
     rx->cap_rows = (uint32_t)want_rows;
@@ -1169,7 +1172,8 @@ int sora_rx_set_fused(sora_rx_t* rx, int enable)
     if (!rx) return SORA_ERR_INVALID_PARAM;
     const int old = rx->fused ? 1 : 0;
 #ifndef SORA_WITH_K_DECODE
-    if (enable > 0) return fail(SORA_E_NOT_SUPPORTED, "sora_rx_set_fused: k_decode is not part of this build of the library (a build variant since round 4: sora_amd.build.build_variant(\"fused\", [\"SORA_WITH_K_DECODE\"]))");
+    if (enable > 0) return fail(SORA_E_NOT_SUPPORTED, "sora_rx_set_fused: k_decode is not part of this build of the library "
+                                                      "(a build variant since round 4: sora_amd.build.build_variant(\"fused\", [\"SORA_WITH_K_DECODE\"]))");
 #endif
     if (enable >= 0) {
         rx->fused = enable != 0;

@@ -25,6 +25,7 @@ def main():
     ap.add_argument("--front", type=int, default=0, help="0: the library's choice, 1: k_frame, 3: k_sym_front -> k_track_lds -> k_sym_back, 4: k_pipe (needs few rows in flight: --batch 1 or 2, --depth 1)")
     ap.add_argument("--depth", type=int, default=0, help="calls in flight the handle is sized for (0: its default)")
     ap.add_argument("--max-frames", type=int, default=8)
+    ap.add_argument("--pipe-wait-us", type=int, default=-1, help="bound of the waits inside a k_pipe launch (0: every wait that is not satisfied at once gives up -> the finishing kernel makes the call again)")
     ap.add_argument("--noise-frames", type=float, default=0.0, help="share of captures whose data field is replaced by noise behind an intact SIGNAL symbol (the window-parallel trellis's proof fails: the serial path)")
     args = ap.parse_args()
     import torch
@@ -33,6 +34,7 @@ def main():
     rng = np.random.default_rng(args.seed)
     t0 = time.time(); nfr = 0; nok = 0
     rec = {"boundaries": 0, "boundaries_failed": 0, "frames_decoded_again": 0, "units": 0}
+    pipe = {"calls_made_again": 0, "backoffs": 0, "calls": 0}
     for b0 in range(0, args.captures, args.batch):
         mhz = int(rng.choice([20, 40]))
         caps = [random_capture(o, rng, mhz) for _ in range(min(args.batch, args.captures - b0))]
@@ -49,10 +51,16 @@ def main():
         if args.front:
             rx.set_front(args.front)
             assert rx.front() == args.front, "the handle does not run front %d in this shape (it would run %d)" % (args.front, rx.front())
+        if args.pipe_wait_us >= 0:
+            rx.set_pipe_wait_us(args.pipe_wait_us)
         rx.process_dev(torch.from_numpy(iq).cuda(), descs)
         got = rx.results()
         for k, v in rx.window_stats().items():
             rec[k] += v
+        if args.front == 4:
+            for k, v in rx.pipe_stats().items():
+                pipe[k] += v
+            pipe["calls"] += 1
         rx.close()
         want = []
         for i, c in enumerate(caps):
@@ -71,7 +79,8 @@ def main():
             print("FAILED:", why)
             return 1
         nfr += len(want); nok += sum(r["error_code"] == 1 for r in want)
-    print("stress parity OK: %d captures, %d frames (%d FRAME_OK) identical, %.1f s; window-parallel trellis: %s" % (args.captures, nfr, nok, time.time() - t0, rec))
+    print("stress parity OK: %d captures, %d frames (%d FRAME_OK) identical, %.1f s; window-parallel trellis: %s%s" % (args.captures, nfr, nok, time.time() - t0, rec,
+          "; k_pipe: %s" % pipe if args.front == 4 else ""))
     return 0
 
 
