@@ -70,6 +70,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
         cpu_ms = (time.perf_counter() - t0) / k * 1e3
         out["fsample6_single_capture"]["cpu_reference_decode_ms_one_core"] = round(cpu_ms, 4)
         out["fsample6_single_capture"]["cpu_reference_realtime_factor_one_core"] = round(cpu_ms / air_ms, 4)
+    out.update(bench_latency_11b_11n(torch, sora_amd, dev, reps))
     if rx_batch is None:
         return out
     # (b) the batch, one call in flight
@@ -96,6 +97,84 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
                                             "all %d frames of a call complete together) and required = %d samples / 40 MHz; >= 1.0 means a frame's result arrives later than its own air time, although "
                                             "the batch as a whole is decoded far faster than real time (realtime.factor, the amortised cost)" % (nfr, 2 * FRAME_SAMPLES),
                               "by_trellis_kernel": dist}
+    return out
+
+
+def bench_latency_11b_11n(torch, sora_amd, dev, reps=40):
+    """a lone 802.11b capture (one 1 Mbps frame, 500-byte MPDU, 44 MHz) and a lone 802.11n capture (one MCS 10 frame, 1000-byte MPDU, two chains at
+    40 MHz) -- wall time of process -> wait with one call in flight on the GPU, beside the compiled reference graphs (CreateDemodGraph of fb11bdemod_config.hpp /
+    CreateDemodGraph11n of fb11ndemod_config.hpp) on one host core over the same samples.  Both GPU paths are one-wave-per-capture front ends and a serial trellis:
+    neither has the 802.11a path's machinery for an under-filled chip, and the numbers say so."""
+    from oracle.pyoracle import ReferenceGraph
+    g = ReferenceGraph()
+    if not g.available():
+        return {}
+    out = {}
+    # ---- 802.11b
+    s8 = g.tx11b(np.random.default_rng(11).integers(0, 256, 500).astype(np.uint8).tobytes(), 1000)
+    n = (len(s8) + 1200 + 2800 + 27) // 28 * 28
+    cap = np.zeros((n, 2), np.int16); cap[1200:1200 + len(s8)] = s8.astype(np.int16) << 8
+    cap = np.clip(cap + np.rint(np.random.default_rng(5).normal(0, 40, cap.shape)), -32768, 32767).astype(np.int16)
+    want = g.rx11b(cap)
+    rx = sora_amd.Rx11b(1, 2 * n + 4096, max_frames_per_capture=4)
+    d = torch.from_numpy(cap).to(dev); one = [(0, n, 0)]
+    torch.cuda.synchronize(); rx.wait_for_producer = False
+    res = rx.results(ticket=rx.process_dev(d, one))
+    ok = len(res) == len(want) and all(r["error_code"] == w["error_code"] and r["mpdu"] == w["mpdu"] for r, w in zip(res, want))
+    for _ in range(5):
+        rx.wait(rx.process_dev(d, one))
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter(); rx.wait(rx.process_dev(d, one)); ts.append(time.perf_counter() - t0)
+    rx.close()
+    caps = np.ascontiguousarray(cap[None]); g.rx11b_bench(caps)
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 1.0:
+        g.rx11b_bench(caps, 4); k += 4
+    cpu_ms = (time.perf_counter() - t0) / k * 1e3
+    air = n / 44e3
+    out["rx11b_single_capture"] = {"workload": "one 1 Mbps DBPSK frame, 500-byte MPDU, long preamble: %d samples @44 MHz" % n, "air_time_ms": round(air, 4),
+                                   "decode_ms": round(float(np.median(ts)) * 1e3, 4), "realtime_factor": round(float(np.median(ts)) * 1e3 / air, 4),
+                                   "cpu_reference_decode_ms_one_core": round(cpu_ms, 4), "events_equal_the_reference": bool(ok),
+                                   "protocol": "sora_rx11b_process_dev + sora_rx11b_wait, one call in flight, samples resident in HBM; median of %d calls" % reps}
+    # ---- 802.11n
+    s0, s1 = g.tx11n(np.random.default_rng(12).integers(0, 256, 1000).astype(np.uint8).tobytes(), 10)
+    n = (len(s0) + 800 + 1200 + 27) // 28 * 28
+    c = np.zeros((2, n, 2), np.float64)
+    c[0, 800:800 + len(s0)] = s0 + 0.1 * s1; c[1, 800:800 + len(s0)] = s1 + 0.1 * s0
+    c = np.clip(np.rint(c + np.random.default_rng(6).normal(0, 20, c.shape)), -32768, 32767).astype(np.int16)
+    want = g.rx11n(c[0], c[1])
+    rx = sora_amd.Rx11n(1, 2 * n + 4096, max_frames_per_capture=4)
+    d0 = torch.from_numpy(c[0]).to(dev); d1 = torch.from_numpy(c[1]).to(dev); one = [(0, n, 0)]
+    torch.cuda.synchronize(); rx.wait_for_producer = False
+    res = rx.results(ticket=rx.process_dev(d0, d1, one))
+    ok = len(res) == len(want) and all(r["error_code"] == w["error_code"] and r["mpdu"] == w["mpdu"] for r, w in zip(res, want))
+    per = {}
+    names = {64: "k_viterbi11n", 16: "k_viterbi16_11n", 1: "k_viterbi16w_11n"}
+    for lanes in (64, 16, 1, 0):
+        rx.set_trellis(lanes); rx.set_depth(1)
+        for _ in range(5):
+            rx.wait(rx.process_dev(d0, d1, one))
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter(); rx.wait(rx.process_dev(d0, d1, one)); ts.append(time.perf_counter() - t0)
+        if lanes:
+            per[names[lanes]] = round(float(np.median(ts)) * 1e3, 4)
+        else:
+            auto_ms = round(float(np.median(ts)) * 1e3, 4); auto_name = names[rx.trellis()]
+    wst = rx.window_stats()
+    rx.close()
+    a0 = np.ascontiguousarray(c[0][None]); a1 = np.ascontiguousarray(c[1][None]); g.rx11n_bench(a0, a1)
+    t0 = time.perf_counter(); k = 0
+    while time.perf_counter() - t0 < 1.0:
+        g.rx11n_bench(a0, a1, 4); k += 4
+    cpu_ms = (time.perf_counter() - t0) / k * 1e3
+    air = n / 40e3
+    out["rx11n_single_capture"] = {"workload": "one MCS 10 frame, 1000-byte MPDU, two chains: %d samples @40 MHz each" % n, "air_time_ms": round(air, 4),
+                                   "decode_ms": auto_ms, "trellis_kernel": auto_name + " (the library's automatic choice)", "decode_ms_by_trellis_kernel": per,
+                                   "realtime_factor": round(auto_ms / air, 4), "window_trellis_record": wst,
+                                   "cpu_reference_decode_ms_one_core": round(cpu_ms, 4), "events_equal_the_reference": bool(ok),
+                                   "protocol": "sora_rx11n_process_dev + sora_rx11n_wait, one call in flight, samples resident in HBM; median of %d calls" % reps}
     return out
 
 

@@ -35,7 +35,7 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a. */
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx11n_trellis, sora_rx11n_window_stats, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
 #define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */
@@ -419,8 +419,14 @@ int   sora_rx11n_results(sora_rx11n_t* rx, sora_frame_result* out, size_t max_ou
  * finished.  sora_rx11n_set_depth returns the
  * previous value (depth <= 0 only queries) and waits for the calls in flight; sora_rx11n_process (host buffers) also does. */
 int   sora_rx11n_set_depth(sora_rx11n_t* rx, int depth);
-/* 64 (default) / 16: as sora_rx_set_trellis, for T11aViterbi<..,192,36>; returns the previous value, a negative argument only queries */
+/* As sora_rx_set_trellis, for T11aViterbi<..,192,36>: 64 = k_viterbi11n, 16 = k_viterbi16_11n, SORA_TRELLIS_WINDOWED = the frame's 192-bit trace-back windows decoded side
+ * by side and proven afterwards (k_viterbi16w_11n + k_win_redo_11n: bit-exact by construction like the 802.11a form; new in ABI 4), 0 (default since ABI 4; it was 64) =
+ * chosen by the library: window-parallel while depth x max_captures x max_frames_per_capture <= 2048 (a frame per wave-slot leaves the chip idle: a lone capture's
+ * frame), k_viterbi11n above that.  Returns the previous setting, a negative argument only queries; sora_rx11n_trellis resolves the automatic choice;
+ * sora_rx11n_window_stats is sora_rx_window_stats for this handle. */
 int   sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair);
+int   sora_rx11n_trellis(sora_rx11n_t* rx);
+int   sora_rx11n_window_stats(sora_rx11n_t* rx, unsigned long long out[4]);
 int   sora_rx11n_ticket(sora_rx11n_t* rx);
 int   sora_rx11n_synchronize(sora_rx11n_t* rx);                                                       /* every call issued so far has finished */
 int   sora_rx11n_wait(sora_rx11n_t* rx, int ticket);

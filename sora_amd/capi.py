@@ -58,7 +58,7 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
            "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_set_single_pass", "sora_rx11b_wait", "sora_rx11b_wait_any", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
-           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_wait_any", "sora_rx11n_results_of",
+           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_trellis", "sora_rx11n_window_stats", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_wait_any", "sora_rx11n_results_of",
            "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_process_captures_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_wait_any", "sora_ht40_stream_of", "sora_ht40_results_of",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results", "sora_shard_gather_results_mpdu"]
@@ -164,6 +164,8 @@ def load(build_if_missing=True):
     L.sora_hip_table_digest.argtypes = [ctypes.c_char_p, ctypes.c_char_p]
     L.sora_hip_table_read.argtypes = [ctypes.c_char_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.POINTER(ctypes.c_size_t)]
     L.sora_rx11n_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
+    L.sora_rx11n_trellis.argtypes = [ctypes.c_void_p]
+    L.sora_rx11n_window_stats.argtypes = [ctypes.c_void_p, ctypes.POINTER(ctypes.c_ulonglong)]
     L.sora_ht40_set_trellis.argtypes = [ctypes.c_void_p, ctypes.c_int]
     L.sora_rx_kernel_name_fused.argtypes = [ctypes.c_size_t]; L.sora_rx_kernel_name_fused.restype = ctypes.c_char_p
     L.sora_ht40_symbols.argtypes = [ctypes.c_uint32] * 4; L.sora_ht40_symbols.restype = ctypes.c_uint32
@@ -666,6 +668,15 @@ class Rx11n:
         r = int(self._L.sora_rx11n_set_trellis(self._h, int(lanes_per_pair)))
         if r < 0: _check(r)
         return r
+
+    def trellis(self):
+        """the trellis kernel the next call uses: 64, 16 or 1 (TRELLIS_WINDOWED)"""
+        return int(self._L.sora_rx11n_trellis(self._h))
+
+    def window_stats(self):
+        v = (ctypes.c_ulonglong * 4)()
+        _check(self._L.sora_rx11n_window_stats(self._h, v))
+        return {"boundaries": int(v[0]), "boundaries_failed": int(v[1]), "frames_decoded_again": int(v[2]), "units": int(v[3])}
 
     def wait(self, ticket):
         _check(self._L.sora_rx11n_wait(self._h, int(ticket)))

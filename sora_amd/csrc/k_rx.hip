@@ -1414,7 +1414,8 @@ __global__ void __launch_bounds__(256) k_viterbi11n(const VitJob* __restrict__ j
 // launches cost a lone capture a kernel and a queue gap).  A wave owns a PAIR of frames of one code-rate list, as in k_viterbi: its lower half compares the unit
 // boundaries of frame A (unit u's vector at its verify point against unit u - 1's vector at the same step), its upper half those of frame B; if every boundary of both
 // holds the wave is done -- what k_viterbi16w wrote is the reference's decode -- else it decodes the pair serially, overwriting it.
-struct WinProofGate {
+template <uint32_t WIN, uint32_t LOOK>
+struct WinProofGateT {
     const VitJob* jobs; const uint32_t* hdr; uint32_t jstride, target, vstride; const uint16_t* vecs; unsigned long long* stats;
     __device__ __forceinline__ bool operator()(uint32_t list, uint32_t fa, uint32_t fb, bool hasB) const
     {
@@ -1423,7 +1424,7 @@ struct WinProofGate {
         const uint32_t idx = side ? fb : fa;
         const bool have = side ? hasB : true;
         const VitJob& J = jobs[(size_t)list * jstride + (have ? idx : fa)];
-        const uint32_t nev = win_events(J.length, J.code_rate, 256u, 24u), m = win_per_unit(nev, q), nun = have ? (nev + m - 1u) / m : 1u;
+        const uint32_t nev = win_events(J.length, J.code_rate, WIN, LOOK), m = win_per_unit(nev, q), nun = have ? (nev + m - 1u) / m : 1u;
         const size_t vec0 = (size_t)list * vstride + (size_t)idx * q;
         uint32_t bad = 0;
         for (uint32_t u = 1u + l32; u < nun; u += 32u) {
@@ -1446,10 +1447,16 @@ struct WinProofGate {
         return ba != 0ull;
     }
 };
+using WinProofGate = WinProofGateT<256u, 24u>;
 __global__ void __launch_bounds__(256) k_win_redo(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target,
         uint32_t vstride, const uint16_t* __restrict__ vecs,
                                                   const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, unsigned long long* __restrict__ stats)
 { viterbi_kernel_body<256, 24, 3>(jobs, hdr, 0u, jstride, soft, out, WinProofGate{ jobs, hdr, jstride, target, vstride, vecs, stats }); }
+// ... for the 802.11n graph's decoder (windows of 192 bits, 36 of look-ahead, one byte per soft value)
+__global__ void __launch_bounds__(256) k_win_redo_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target,
+        uint32_t vstride, const uint16_t* __restrict__ vecs,
+                                                      const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, unsigned long long* __restrict__ stats)
+{ viterbi_kernel_body<192, 36, 8>(jobs, hdr, 0u, jstride, soft, out, WinProofGateT<192u, 36u>{ jobs, hdr, jstride, target, vstride, vecs, stats }); }
 
 // ------------------------------------------------------------------------------------------------
 // k_finish: T11aDesc (scramble.hpp:267-353) + TBB11aFrameSink (PHY_11a.hpp:607-702).  One wave per frame.

@@ -20,6 +20,7 @@
 //     partly filled queue with zero items (see oracle/so_rx11n.c, flush_graph).
 // HBM traffic = the samples, once (8 bytes per 40 MHz sample pair of the two chains, of which the even half is used).
 #include "kernels.h"
+#include "dev_winplan.h"
 #include "dev_11n.h"
 #include "../../include/sora_hip.h"
 #include <type_traits>
@@ -1177,6 +1178,7 @@ struct Pipe11n {                         // one call in flight: a stream and eve
     hipStream_t stream = nullptr;
     CapDesc* d_caps = nullptr; Rx11bRow* d_rows = nullptr; uint32_t* d_nframes = nullptr; uint8_t* d_mpdu = nullptr;
     N11Frame* d_frames = nullptr; VitJob* d_jobs = nullptr; uint32_t* d_njobs = nullptr; uint8_t* d_soft = nullptr; uint8_t* d_vout = nullptr;
+    uint16_t* d_wvecs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;   // the window-parallel trellis's vectors and proof record (on its first use)
     std::vector<sora_capture_desc> h_caps; std::vector<CapDesc> h_desc;
     uint32_t ncaps = 0; bool have_results = false; int ticket = 0;
     DenseStage dense;                       // sora_rx11n_deliver_async
@@ -1192,7 +1194,10 @@ struct sora_rx11n {
 #else
     static constexpr bool mono = false;
 #endif
-    int lanes16 = 0;             // trellis kernel: 0 = k_viterbi11n (64 lanes per frame pair), 1 = k_viterbi16_11n (sora_rx11n_set_trellis)
+    // trellis kernel (sora_rx11n_set_trellis): 64 = k_viterbi11n (64 lanes per frame pair), 16 = k_viterbi16_11n, SORA_TRELLIS_WINDOWED = k_viterbi16w_11n + k_win_redo_11n
+    // (round 6: the frame's 192-bit trace-back windows side by side, proven afterwards -- k_vitwin.hip), 0 = automatic: window-parallel while the handle holds few
+    // frames in flight (one wave-slot per frame leaves the chip idle: a lone capture's 8000-step frame was 0.23 ms of a 0.37 ms call), k_viterbi11n above that
+    int trellis = 0;
     uint64_t cap_slots = 0;
     static constexpr int kMaxDepth = 8;
     Pipe11n* pipes[kMaxDepth] = {};
@@ -1208,6 +1213,7 @@ static void pipe11n_free(Pipe11n* p)
     if (p->ev_done) (void)hipEventDestroy(p->ev_done);
     (void)hipFree(p->d_caps); (void)hipFree(p->d_rows); (void)hipFree(p->d_nframes); (void)hipFree(p->d_mpdu);
     (void)hipFree(p->d_frames); (void)hipFree(p->d_jobs); (void)hipFree(p->d_njobs); (void)hipFree(p->d_soft); (void)hipFree(p->d_vout);
+    (void)hipFree(p->d_wvecs); (void)hipFree(p->d_wstats);
     sora_internal_dense_free(&p->dense);
     delete p;
 }
@@ -1294,13 +1300,36 @@ int sora_rx11n_set_depth(sora_rx11n_t* rx, int depth)
     return prev;
 }
 
+// frame rows in flight (depth x max_captures x max_frames_per_capture) up to which the automatic choice is the window-parallel trellis
+constexpr long long kAutoWindowedRows11n = 2048;
+static int trellis11n_for(const sora_rx11n_t* rx)
+{
+    if (rx->trellis) return rx->trellis;
+    const long long rows = (long long)rx->depth * (long long)rx->cfg.max_captures * (long long)rx->cfg.max_frames_per_capture;
+    return rows <= kAutoWindowedRows11n ? SORA_TRELLIS_WINDOWED : 64;
+}
 int sora_rx11n_set_trellis(sora_rx11n_t* rx, int lanes_per_pair)
 {
     if (!rx) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_trellis: null handle", 0);
-    const int old = rx->lanes16 ? 16 : 64;
-    if (lanes_per_pair == 16 || lanes_per_pair == 64) rx->lanes16 = lanes_per_pair == 16;
-    else if (lanes_per_pair >= 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_trellis: 16 or 64 lanes per frame pair", 0);
+    const int old = rx->trellis;
+    if (lanes_per_pair == 0 || lanes_per_pair == 16 || lanes_per_pair == 64 || lanes_per_pair == SORA_TRELLIS_WINDOWED) rx->trellis = lanes_per_pair;
+    else if (lanes_per_pair > 0) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_set_trellis: 0 (automatic), 16 or 64 lanes per frame pair, or SORA_TRELLIS_WINDOWED", 0);
     return old;
+}
+int sora_rx11n_trellis(sora_rx11n_t* rx) { return rx ? trellis11n_for(rx) : SORA_ERR_INVALID_PARAM; }
+// the window-parallel trellis's proof record since the handle was created (as sora_rx_window_stats)
+int sora_rx11n_window_stats(sora_rx11n_t* rx, unsigned long long out[4])
+{
+    if (!rx || !out) return sora_internal_fail(SORA_ERR_INVALID_PARAM, "sora_rx11n_window_stats: null argument", 0);
+    HIPCHK11N(hipSetDevice(rx->cfg.device));
+    for (int i = 0; i < 4; i++) out[i] = 0;
+    for (Pipe11n* p : rx->pipes) if (p && p->d_wstats) {
+        unsigned long long v[4 * kWinStatBanks];
+        HIPCHK11N(hipStreamSynchronize(p->stream));
+        HIPCHK11N(hipMemcpy(v, p->d_wstats, sizeof v, hipMemcpyDeviceToHost));
+        for (unsigned i = 0; i < 4 * kWinStatBanks; i++) out[i & 3u] += v[i];
+    }
+    return SORA_OK;
 }
 
 static Pipe11n* pipe11n_of(sora_rx11n_t* rx, int ticket);
@@ -1423,7 +1452,24 @@ int sora_rx11n_process_dev(sora_rx11n_t* rx, const sora_complex16* d_iq0, const 
     F.iq0 = A.iq0; F.iq1 = A.iq1; F.caps = P->d_caps; F.frames = P->d_frames; F.njobs = P->d_njobs; F.nrows = nrows; F.T = rx->T; F.sincos = rx->sincos; F.atan = rx->atan;
     F.soft = P->d_soft; F.jobs = P->d_jobs; F.vout = P->d_vout; F.rows = P->d_rows; F.mpdu = P->d_mpdu;
     hipLaunchKernelGGL(k_frame11n, dim3((nrows + 3) / 4), dim3(256), 0, P->stream, F);
-    if (rx->lanes16)
+    const int trellis = trellis11n_for(rx);
+    if (trellis == SORA_TRELLIS_WINDOWED) {
+        constexpr uint32_t kTarget = 16384, kLoneWaves = 3 * kWinLonePad / 8;
+        if (!P->d_wvecs) {
+            const uint64_t cap_rows = (uint64_t)rx->cfg.max_captures * rx->cfg.max_frames_per_capture;
+            P->wstride = (uint32_t)(std::min<uint64_t>(std::max<uint64_t>(kTarget, cap_rows), (uint64_t)kWinMaxUnits * cap_rows) + cap_rows);
+            HIPCHK11N(hipMalloc((void**)&P->d_wvecs, 3 * (size_t)kWinVecBytes * P->wstride));
+            HIPCHK11N(hipMalloc((void**)&P->d_wstats, 4 * kWinStatBanks * sizeof(unsigned long long)));
+            HIPCHK11N(hipMemsetAsync(P->d_wstats, 0, 4 * kWinStatBanks * sizeof(unsigned long long), P->stream));
+        }
+        const uint32_t units_max = (uint32_t)std::min<uint64_t>(std::max<uint32_t>(kTarget, nrows), (uint64_t)kWinMaxUnits * nrows);
+        hipLaunchKernelGGL(k_viterbi16w_11n, dim3((units_max + 7) / 8 + 3 + kLoneWaves), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs,
+                nrows, kTarget, P->wstride, (const uint8_t*)P->d_soft, P->d_vout, P->d_wvecs);
+        // the proof, and the serial decode of the pairs of frames that fail it (none, normally)
+        hipLaunchKernelGGL(k_win_redo_11n, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs,
+                nrows, kTarget, P->wstride, (const uint16_t*)P->d_wvecs, (const uint8_t*)P->d_soft, P->d_vout, P->d_wstats);
+    }
+    else if (trellis == 16)
         hipLaunchKernelGGL(k_viterbi16_11n, dim3((nrows + 7) / 8 + 2), dim3(64), 0, P->stream, (const VitJob*)P->d_jobs, (const uint32_t*)P->d_njobs, 0u,
                 nrows, (const uint8_t*)P->d_soft, P->d_vout);
     else

@@ -33,6 +33,11 @@ namespace sora {
 __global__ void __launch_bounds__(64) k_viterbi16w(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
                                                    const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
 { viterbi16w_body<256, 24, 3>(jobs, hdr, jstride, target, vstride, soft, out, vecs); }
+// the 802.11n graph's decoder, T11aViterbi<5000*8, 312, 192, 36> (fb11ndemod_config.hpp:199), one byte per soft value: the same body -- a unit's verify point
+// floor24(192 k0) is 192 k0 itself
+__global__ void __launch_bounds__(64) k_viterbi16w_11n(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
+                                                       const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
+{ viterbi16w_body<192, 36, 8>(jobs, hdr, jstride, target, vstride, soft, out, vecs); }
 
 // (the proof itself -- every unit's vector at its verify point against its predecessor's at the same step -- and the serial decode of what fails it are ONE kernel, k_win_redo in
 // k_rx.hip, beside the serial trellis it shares its body with)

@@ -95,6 +95,9 @@ __global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint
 // k_vitwin.hip: the window-parallel trellis.  hdr = the call's counter block (njobs per code rate in its first three words); jstride = capacity of a list of jobs;
 // target = units the call is cut into at least, frames permitting; vstride = vectors per code-rate list
 __global__ void k_viterbi16w(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
+__global__ void k_viterbi16w_11n(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
+__global__ void k_win_redo_11n(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
+        const uint8_t* soft, uint8_t* out, unsigned long long* stats);
 __global__ void k_win_redo(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
         const uint8_t* soft, uint8_t* out, unsigned long long* stats);
 __global__ void k_win_redo_finish(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,

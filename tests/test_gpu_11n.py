@@ -199,6 +199,66 @@ def test_both_trellis_kernels_decode_the_11n_graph_alike():
             assert [key(e) for e in b[i]] == [key(e) for e in o.rx11n_capture(*caps[i])], i
 
 
+def test_window_parallel_trellis_for_the_11n_decoder():
+    """Round 6: T11aViterbi<5000*8, 312, 192, 36> decoded window-parallel with the units' proof (k_viterbi16w_11n + k_win_redo_11n, the 802.11a
+    machinery instantiated for 192-bit windows and one byte per soft value).  Same rows and MPDUs as k_viterbi11n and the oracle on random captures (cut frames
+    included); frames of up to 1500 bytes from the reference's own modulator against the compiled reference graph; a data field replaced by noise behind intact
+    headers fails the proof and is decoded again by the serial kernel; it is the automatic choice for a handle with few frames in flight."""
+    import torch
+    import sora_amd
+    from oracle.pyoracle import Oracle, ReferenceGraph
+    z = np.load(__import__("test_oracle_11n_graph").GOLD)
+    frames = [(z["tx%d_0" % i], z["tx%d_1" % i]) for i in range(4)]
+    rng = np.random.default_rng(79)
+    caps = []
+    for t in range(120):
+        fr = [frames[int(i)] for i in rng.integers(0, 4, size=int(rng.integers(1, 5)))]
+        caps.append(capture_11n(rng, fr, sigma=float(rng.choice([5, 60, 600, 1500])), cut=float(rng.uniform(0.05, 1.0)) if t % 2 else None))
+    a = run_batch(caps, trellis=64)
+    b = run_batch(caps, trellis=sora_amd.TRELLIS_WINDOWED)
+    key = lambda e: (e["error_code"], e["end_sample"], e["rate_kbps"], e["length"], e["crc32"], e["mpdu"])
+    assert sum(len(x) for x in a) > 120
+    for i in range(len(caps)):
+        assert [key(e) for e in a[i]] == [key(e) for e in b[i]], i
+    # long frames, the compiled reference as the judge; one capture at a time = the lone-capture layout (units of one window), and a batch of them
+    g = ReferenceGraph()
+    if g.available():
+        big = []
+        for k, (ln, mcs) in enumerate(((1000, 10), (1490, 9), (1496, 8), (700, 10), (64, 8))):
+            s0, s1 = g.tx11n(np.random.default_rng(900 + k).integers(0, 256, ln).astype(np.uint8).tobytes(), mcs)
+            n = (len(s0) + 800 + 1200 + 27) // 28 * 28
+            c = np.zeros((2, n, 2), np.float64)
+            c[0, 800:800 + len(s0)] = s0 + 0.1 * s1; c[1, 800:800 + len(s0)] = s1 + 0.1 * s0
+            c = np.clip(np.rint(c + np.random.default_rng(k).normal(0, 20, c.shape)), -32768, 32767).astype(np.int16)
+            big.append((c[0], c[1]))
+        noisy = [(x.copy(), y.copy()) for x, y in big[:2]]
+        for x, y in noisy:                                                   # the data field replaced by noise: the headers stay, the units' proof fails
+            x[2400:len(x) - 1400] = np.rint(rng.normal(0, 2500, (len(x) - 3800, 2))); y[2400:len(y) - 1400] = np.rint(rng.normal(0, 2500, (len(y) - 3800, 2)))
+        want = [key_ref(g.rx11n(x, y)) for x, y in big + noisy]
+        for group in ([[c] for c in big + noisy] + [big + noisy]):
+            rx = sora_amd.Rx11n(len(group), sum(len(x) for x, _ in group) + 4096, max_frames_per_capture=4)
+            assert rx.trellis() == sora_amd.TRELLIS_WINDOWED                 # the automatic choice for so few frames
+            iq0 = np.concatenate([x for x, _ in group]); iq1 = np.concatenate([y for _, y in group])
+            descs = []; off = 0
+            for i, (x, _) in enumerate(group):
+                descs.append((off, len(x), i)); off += len(x)
+            rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), descs)
+            per = [[] for _ in group]
+            for r in rx.results():
+                per[r["capture_id"]].append(r)
+            st = rx.window_stats(); rx.close()
+            assert st["units"] > 0
+            for i, c in enumerate(group):
+                j = next(k for k, d in enumerate(big + noisy) if d[0] is c[0])
+                assert [(e["error_code"], e["rate_kbps"], e["length"], e["crc32"], e["mpdu"]) for e in per[i]] == want[j], (len(group), i)
+            if len(group) > 1:
+                assert st["boundaries_failed"] >= 1 and st["frames_decoded_again"] >= 1, st
+
+
+def key_ref(events):
+    return [(e["error_code"], e["rate_kbps"], e["length"], e["crc32"], e["mpdu"]) for e in events]
+
+
 @pytest.mark.parametrize("depth", [1, 2, 3])
 def test_11n_calls_in_flight_are_collectable_by_ticket(depth):
     """sora_rx11n_set_depth: consecutive calls on different batches rotate over the handle's pipelines; each call's rows and MPDUs are read back by its
