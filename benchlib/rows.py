@@ -267,6 +267,25 @@ def bench_shard_shape(torch, sora_amd, dev, oracle, ncaps=32, nframes=16, reps=6
         ms = (time.perf_counter() - t0) / n * 1e3
         by["calls_in_flight_%d" % depth] = {"ms_per_call": round(ms, 4), "msamples_per_s": round(samples / ms / 1e3, 1), "kernels": chains + " (the library's choice)",
                                             "hbm_frac": round(samples * ALG_BYTES_PER_SAMPLE / (ms * 1e-3) / HBM_PEAK, 5)}
+    # the same eight calls in flight with every pipeline's chain replayed as ONE hipGraph launch (sora_rx_set_graph: the calls are identical -- same buffer, same capture
+    # set): what is left of the host's share when a call is one enqueue instead of five
+    rx.set_depth(8); rx.set_graph(1); rx.flush()
+    for _ in range(24):
+        rx.process_dev(d_iq, descs)
+    rx.flush()
+    n = reps * 8
+    torch.cuda.synchronize(); t0 = time.perf_counter(); tickets = []
+    for _ in range(n):
+        tickets.append(rx.process_dev(d_iq, descs))
+        if len(tickets) >= 8:
+            rx.wait(tickets.pop(0))
+    for t in tickets:
+        rx.wait(t)
+    ms = (time.perf_counter() - t0) / n * 1e3
+    g_res = rx.results(ticket=rx.process_dev(d_iq, descs))
+    by["calls_in_flight_8_graph_replay"] = {"ms_per_call": round(ms, 4), "msamples_per_s": round(samples / ms / 1e3, 1), "hbm_frac": round(samples * ALG_BYTES_PER_SAMPLE / (ms * 1e-3) / HBM_PEAK, 5),
+                                             "same_rows_as_the_checked_call": [(r["capture_id"], r["error_code"], r["crc32"], r["mpdu"]) for r in g_res] == [(r["capture_id"], r["error_code"], r["crc32"], r["mpdu"]) for r in res]}
+    rx.set_graph(0)
     rx.set_depth(1); rx.flush(); rx.set_profiling(True)
     for _ in range(10):
         rx.wait(rx.process_dev(d_iq, descs))

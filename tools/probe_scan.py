@@ -6,7 +6,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 from sora_amd import build as b
 so = os.path.join(ROOT, "sora_amd", "lib", "variants", "scan_probe.so")
-if not os.path.exists(so) or "--rebuild" in sys.argv:                     # (build it where there is no GPU to pay for: python tools/probe_scan.py --build-only)
+stale = os.path.exists(so) and any(os.path.getmtime(os.path.join(b.CSRC, f)) > os.path.getmtime(so) for f in b.SOURCES + b.HEADERS)
+if not os.path.exists(so) or stale or "--rebuild" in sys.argv:                     # (build it where there is no GPU to pay for: python tools/probe_scan.py --build-only)
     so = b.build_variant("scan_probe", ["SORA_SCAN_PROBE"])
 if "--build-only" in sys.argv:
     sys.exit(0)
