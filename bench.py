@@ -265,13 +265,15 @@ def main():
         free.append(bi)
         stats["t_check"] += time.perf_counter() - tb
 
-    def run_block(k, deliver, dep=None):
+    def run_block(k, deliver, dep=None, bound=False):
         dep = dep or depth                                          # calls in flight on the handle right now (<= len(bufs) - EXTRA)
         for _ in range(k):
             ta = time.perf_counter()
             if deliver:
                 bi = free.popleft()
                 chk.release(bi)                                     # the buffer the next call will be delivered into: its comparison must be over
+                if bound:
+                    rx.bind_mpdu(bufs[bi])                          # sora_rx_bind_mpdu: the call's frame sink writes its MPDUs into this buffer itself; deliver_async copies rows only
             tk = rx.process_dev(d_iqs[(rx.ticket() + 1) % NCOPIES], descs)
             if deliver:
                 rx.deliver_async(tk, bufs[bi]); inflight[tk] = bi
@@ -370,6 +372,17 @@ def main():
                 ms_p = (time.perf_counter() - tp0) / (nblk * args.steps) * 1e3
                 plain["calls_in_flight_%d_%s" % (dval, tname[l])] = {"ms_per_step": round(ms_p, 4), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms_p / 1e3, 1),
                                                                       "calls_with_wrong_rows": chk.bad - bad0}
+        # ... and with the MPDUs written to the host's buffer by the frame sink itself (sora_rx_bind_mpdu, round 6) instead of copied behind the call
+        for dval in (1, 2):
+            rx.set_trellis(1); rx.set_depth(dval); rx.flush()
+            run_block(args.warmup, deliver, dval, bound=True); rx.flush(); chk.drain(); bad0 = chk.bad
+            nblk = max(1, repeats // 6)
+            tp0 = time.perf_counter()
+            run_block(args.steps * nblk, deliver, dval, bound=True)
+            rx.flush(); chk.drain()
+            ms_p = (time.perf_counter() - tp0) / (nblk * args.steps) * 1e3
+            plain["calls_in_flight_%d_%s_bound_mpdu" % (dval, tname[1])] = {"ms_per_step": round(ms_p, 4), "msamples_per_s": round(nfr * FRAME_SAMPLES / ms_p / 1e3, 1),
+                                                                           "calls_with_wrong_rows": chk.bad - bad0, "delivery": "sora_rx_bind_mpdu + sora_rx_deliver_async (rows and count)"}
         best1 = min((k for k in plain if k.startswith("calls_in_flight_1_")), key=lambda k: plain[k]["ms_per_step"])
         plain["calls_in_flight_1"] = dict(plain[best1], config=best1)           # (the library's automatic choice for one lone call of this size is the window-parallel trellis)
         best2 = min((k for k in plain if k.startswith("calls_in_flight_2")), key=lambda k: plain[k]["ms_per_step"])

@@ -35,7 +35,7 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx11n_trellis, sora_rx11n_window_stats, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
 #define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */
@@ -175,6 +175,13 @@ int    sora_rx_results_of(sora_rx_t* rx, int ticket, sora_frame_result* h_out, s
 void*  sora_rx_stream_of(sora_rx_t* rx, int ticket);
 size_t sora_rx_mpdu_bytes(sora_rx_t* rx, int ticket);
 int    sora_rx_deliver_async(sora_rx_t* rx, int ticket, sora_frame_result* h_rows, size_t max_rows, uint32_t* h_nrows, uint8_t* h_mpdu, size_t mpdu_bytes);
+/* A lone call's delivery without the copy behind it (round 6, ABI 4).  sora_rx_bind_mpdu names, for the NEXT process call of the handle only, a page-locked array from
+ * sora_hip_host_alloc of at least that call's sora_rx_mpdu_bytes() (SORA_ERR_CAPACITY from the process call otherwise; the array's geometry is the device array's: 32 bytes per
+ * symbol slot): the call's frame sink then writes every MPDU there as well, straight over PCIe while the frames are being finished, and sora_rx_deliver_async(ticket, ..) with
+ * the SAME h_mpdu copies rows and count only.  The bytes are valid when the ticket has been waited for; words of the array that no frame of the call owns are left as they were.
+ * For a host that keeps ONE or TWO calls in flight (the MPDU copy is a lone 4096-frame call's 0.22 ms tail); with many calls in flight their copies overlap anyway and
+ * waves that wait on PCIe writes hold compute units the other calls' kernels want (measured in round 3): do not bind there.  h_mpdu = NULL cancels a binding not yet used. */
+int    sora_rx_bind_mpdu(sora_rx_t* rx, uint8_t* h_mpdu, size_t mpdu_bytes);
 /* Per-kernel timing with HIP events recorded on the streams the kernels run on (SoraStopwatch / MACStopwatch analogue,
  * kernel/bb/demod11/MACStopwatch.h:84-128).  With profiling enabled every process call brackets each kernel launch
  * with events; sora_rx_kernel_times waits for the calls in flight and returns, in launch order, the MEAN duration (ms)

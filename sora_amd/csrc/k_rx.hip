@@ -1494,6 +1494,8 @@ __device__ __forceinline__ void finish_frame(const RxArgs& A, uint32_t f, Finish
     uint32_t* s_buf = s_bufs[threadIdx.x >> 6];
     const uint32_t* dec32 = reinterpret_cast<const uint32_t*>(A.vout + (size_t)r.slot0 * kOutPerSlot);   // (32-byte aligned; the MPDU starts at its byte 2)
     uint32_t* mp32 = reinterpret_cast<uint32_t*>(A.mpdu + (size_t)r.slot0 * kOutPerSlot);
+    // (sora_rx_bind_mpdu: the same words straight into the host's array, 256 contiguous bytes per store instruction -- a lone call's MPDUs travel while the frames finish)
+    uint32_t* hp32 = A.mpdu_host ? reinterpret_cast<uint32_t*>(A.mpdu_host + (size_t)r.slot0 * kOutPerSlot) : nullptr;
     const uint32_t L = min((uint32_t)r.length, 2500u), nwords = (L + 3u) / 4u;   // (k_scan queues nothing longer)
     // Four bytes per lane and pass, every load of the frame in flight before the first is used (a byte per lane and pass with the store behind it was a memory round
     // trip per 64 bytes: 22 of them in a row for fsample-6, most of what this kernel cost a lone capture).  Word w of the MPDU = bytes 2 + 4w .. 5 + 4w of the decoder's
@@ -1516,6 +1518,7 @@ __device__ __forceinline__ void finish_frame(const RxArgs& A, uint32_t f, Finish
             const uint32_t o = __builtin_amdgcn_alignbyte(hi[k], lo[k], 2u) ^ sb;
             s_buf[w] = o;
             mp32[w] = o;
+            if (hp32) hp32[w] = o;
         }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");

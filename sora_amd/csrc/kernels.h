@@ -64,6 +64,7 @@ struct RxArgs {
     TrackRec*       track;          // [total_slots] rotation parameters of a data symbol (k_track -> k_sym_back)
     uint32_t*       pil;            // [total_slots][4] the four pilot bins (43, 57, 7, 21) of eq[] once more, densely: all k_track reads
     const uint32_t* pipe_flags;     // k_finish behind k_pipe: word 0 != 0 = a hand-off inside that launch gave up (else null)
+    uint8_t*        mpdu_host;      // sora_rx_bind_mpdu: the caller's page-locked MPDU array (the geometry of mpdu[]): the frame sink writes every MPDU there as well, over PCIe, as it finishes the frame (else null)
 };
 
 // k_pipe (k_rx.hip): the data field of a handful of frames as ONE launch.  Workgroups [0, nfront) are k_sym_front's, [nfront, nfront + ntrack) one frame's tracker and

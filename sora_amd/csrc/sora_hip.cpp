@@ -424,6 +424,7 @@ struct RxPipe {
     // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
     int  front = 1;
     uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed for every call
+    uint8_t* bound_mpdu = nullptr; size_t bound_bytes = 0; const void* last_bound = nullptr;   // sora_rx_bind_mpdu: this call's MPDUs go straight to the host's array (what the last enqueue / recorded graph carries)
     uint32_t pipe_wait_ticks = 2000000; uint32_t* d_note = nullptr;   // ... the bound of its waits (100 MHz ticks) and the handle's host-mapped note "a wait gave up" (sora_rx)
     bool pipe64 = false;                                        // ... its trellis role in the 64-lane form (two units per wave: the handle's calls in flight are few enough for that many workgroups)
     // A call needs its job counters zero, k_pipe's words zero and (three-kernel chain) no symbol slot owned: the call BEFORE it on this pipeline arranges that inside its k_scan
@@ -699,6 +700,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             return fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer");
     }
     if (total > rx->cfg.max_total_samples || slots64 > rx->cap_slots) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
+    if (rx->bound_mpdu && rx->bound_bytes < (size_t)kOutPerSlot * slots64) { rx->bound_mpdu = nullptr; return fail(SORA_ERR_CAPACITY, "sora_rx_bind_mpdu: the bound array is smaller than the call's sora_rx_mpdu_bytes()"); }
     const uint32_t slots = (uint32_t)slots64;
     rx->h_caps.swap(hc);
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false; rx->delivered = rx->released = false;
@@ -788,7 +790,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         bool redo_finish = false;
         R.iq = S.iq; R.caps = rx->d_caps; R.str = rx->str; R.total_slots = slots; R.nrows = nrows; R.T = rx->tabs.T;
         R.frames = rx->d_frames; R.fctx = rx->d_fctx;
-        R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = counters; R.joblist = rx->d_joblist;
+        R.vout = rx->d_vout; R.mpdu = rx->d_mpdu; R.njobs = counters; R.joblist = rx->d_joblist; R.mpdu_host = rx->bound_mpdu;
 #ifdef SORA_WITH_K_DECODE
         if (rx->fused) {
             // the data field of every frame, samples -> decoded bytes, in one kernel: two frames per trellis wave, two pairs per
@@ -876,7 +878,8 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         return SORA_OK;
     };
 
-    const bool repeat = rx->last_valid && !caps_changed && rx->last_iq == (const void*)d_iq;
+    const bool repeat = rx->last_valid && !caps_changed && rx->last_iq == (const void*)d_iq && rx->last_bound == (const void*)rx->bound_mpdu;
+    rx->last_bound = rx->bound_mpdu;
     if (!repeat && rx->graph_exec) {
         (void)hipGraphExecDestroy(rx->graph_exec); rx->graph_exec = nullptr;
         (void)hipGraphDestroy(rx->graph); rx->graph = nullptr;
@@ -1034,7 +1037,8 @@ static int pipe_deliver_async(RxPipe* rx, sora_frame_result* h_rows, size_t max_
     const size_t nr = std::min<size_t>(max_rows, (size_t)rx->ncaps * rx->cfg.max_frames_per_capture);
     HIPCHK(hipMemcpyAsync(h_nrows, rx->d_nrows, 4, hipMemcpyDeviceToHost, rx->stream));
     if (nr) HIPCHK(hipMemcpyAsync(h_rows, rx->d_rows, sizeof(sora_frame_result) * nr, hipMemcpyDeviceToHost, rx->stream));
-    if (h_mpdu && need) HIPCHK(hipMemcpyAsync(h_mpdu, rx->d_mpdu, need, hipMemcpyDeviceToHost, rx->stream));
+    // (a call bound to this very array has written its MPDUs there already: sora_rx_bind_mpdu)
+    if (h_mpdu && need && h_mpdu != rx->bound_mpdu) HIPCHK(hipMemcpyAsync(h_mpdu, rx->d_mpdu, need, hipMemcpyDeviceToHost, rx->stream));
     if (!rx->ev_done) HIPCHK(hipEventCreateWithFlags(&rx->ev_done, hipEventDisableTiming));
     HIPCHK(hipEventRecord(rx->ev_done, rx->stream));
     rx->delivered = true;
@@ -1075,6 +1079,7 @@ struct sora_rx {
     uint32_t pipe_wait_us = 20000;
     uint32_t* h_note = nullptr; uint32_t* d_note = nullptr;
     int pipe_backoff = 0; unsigned long long pipe_backoffs = 0;
+    uint8_t* next_bound = nullptr; size_t next_bound_bytes = 0;               // sora_rx_bind_mpdu: for the next process call only
     std::atomic<long long> last_call_ns{0};   // when this handle last took a process call (steady clock): what OTHER handles' automatic kernel choice looks at (chip_is_shared)
 };
 
@@ -1287,6 +1292,15 @@ int sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4])
     return SORA_OK;
 }
 
+// The NEXT process call's frame sink writes every MPDU straight into the caller's page-locked array as well (same geometry as the device's: sora_frame_result::mpdu_offset of
+// sora_rx_deliver_async's rows indexes it); sora_rx_deliver_async with that array then delivers rows and count only.
+int sora_rx_bind_mpdu(sora_rx_t* rx, uint8_t* h_mpdu, size_t mpdu_bytes)
+{
+    if (!rx) return fail(SORA_ERR_INVALID_PARAM, "sora_rx_bind_mpdu: null handle");
+    rx->next_bound = h_mpdu; rx->next_bound_bytes = h_mpdu ? mpdu_bytes : 0;
+    return SORA_OK;
+}
+
 // k_pipe's safety net: the bound of the waits inside its launch ...
 int sora_rx_set_pipe_wait_us(sora_rx_t* rx, long long us)
 {
@@ -1403,6 +1417,7 @@ static void choose_kernels(sora_rx* rx, RxPipe* p)
 {
     if (rx->h_note && *(volatile uint32_t*)rx->h_note != 0u) { *(volatile uint32_t*)rx->h_note = 0u; rx->pipe_backoff = kPipeBackoffCalls; rx->pipe_backoffs++; }
     else if (rx->pipe_backoff > 0) rx->pipe_backoff--;
+    p->bound_mpdu = rx->next_bound; p->bound_bytes = rx->next_bound_bytes; rx->next_bound = nullptr; rx->next_bound_bytes = 0;
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
     { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
