@@ -35,7 +35,7 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, sora_rx_call_front, sora_hip_set_share_window_us, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
 #define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */
@@ -241,6 +241,11 @@ int  sora_rx_window_stats(sora_rx_t* rx, unsigned long long out[4]);
  * Returns the previous setting; a negative argument only queries. */
 int  sora_rx_set_front(sora_rx_t* rx, int kernels);
 int  sora_rx_front(sora_rx_t* rx);              /* 1, 3 or 4: what the next process call will use */
+/* The automatic choice looks at the clock (has another, batch-sized handle of the process taken a call on this device within the share window?), so sora_rx_front is a
+ * forecast.  What a call WAS launched with is latched at its process call: sora_rx_call_front (ticket 0 = the most recent call) answers 1, 3 or 4 for as long as the handle
+ * holds the ticket.  sora_hip_set_share_window_us sets the window for the whole process (default 20000; 0 = other handles are never looked at) and returns the old value. */
+int  sora_rx_call_front(sora_rx_t* rx, int ticket);
+uint32_t sora_hip_set_share_window_us(uint32_t us);
 /* k_pipe's safety net.  The bound of every wait inside its launch, in microseconds (default 20000; 0 = a wait that is not satisfied at first look gives up: every call
  * then takes the redo path -- what tests/test_gpu_pipe.py does to prove that path delivers the reference's rows).  Returns the previous bound; a negative argument only queries. */
 int  sora_rx_set_pipe_wait_us(sora_rx_t* rx, long long us);

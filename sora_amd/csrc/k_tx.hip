@@ -118,12 +118,14 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
 {
     __shared__ alignas(4) uint8_t s_data[2608];
     // generator outputs A (133) / B (171) of the whole data field, bit i of the stream = bit i & 31 of word i >> 5
-    __shared__ uint32_t s_ga[656], s_gb[656];
+    __shared__ uint32_t s_gab[2][656];
+    uint32_t* const s_ga = s_gab[0]; uint32_t* const s_gb = s_gab[1];
     __shared__ uint32_t s_crc[256];
     __shared__ uint32_t s_z[6 * 8 * 16];
     __shared__ uint32_t s_bins[8][128];
     __shared__ uint32_t s_sym[8][160];
-    __shared__ uint8_t  s_ib[8][288];
+    // the interleaver inverted: position -> coded bit of the symbol, for the frame's modulation and for the SIGNAL symbol (BPSK)
+    __shared__ uint16_t s_inv[288 + 48];
     __shared__ uint32_t s_fcs;
     // interleaver positions of the frame's modulation, then of the SIGNAL symbol (BPSK)
     __shared__ uint16_t s_map[288 + 48];
@@ -195,6 +197,33 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
     if (tid < 48) s_map[288 + tid] = T.deint[tid];
     const Fft128Tw tw = fft128_twiddles(T, e);
     __syncthreads();
+    for (int k = tid; k < 48 * nb; k += 256) s_inv[s_map[k]] = (uint16_t)k;
+    if (tid < 48) s_inv[288 + s_map[288 + tid]] = (uint16_t)tid;
+    __syncthreads();
+    // Round 6: the mapper reads its bits where the encoder left them.  A symbol is 96 components (carrier c, I or Q; 48 for BPSK), three per lane of the symbol's 32:
+    // component q = e + 32 t.  Its M bits sit at interleaved positions c N_BPSC + h M + m, i.e. are coded bits k = inverse(position) of the symbol, and coded bit k of
+    // a symbol is generator `which` at input bit (s - 1) N_DBPS + il -- (il, which) follow from k and the puncturing pattern and do NOT depend on the symbol (N_CBPS is a
+    // whole number of puncture periods): nine bits per entry, three entries per component, held in one register per component.  (Round 5 wrote every coded bit into a byte
+    // array at its interleaved position and read the bytes back: 9 + 9 LDS byte accesses and their address arithmetic per lane and symbol.)
+    const int M = nb == 1 ? 1 : nb / 2;
+    auto entry_of = [&](int k) -> uint32_t {                                    // coded bit k of a data symbol -> il | which << 8
+        int il, which;
+        if (cr == 0) { il = k >> 1; which = k & 1; }
+        else if (cr == 1) { const int q3 = k / 3, r = k - 3 * q3; il = 2 * q3 + (r == 2); which = r == 1; }
+        else { const int q4 = k >> 2, r = k & 3; il = 3 * q4 + (r == 2 ? 1 : r == 3 ? 2 : 0); which = r & 1; }
+        return (uint32_t)il | ((uint32_t)which << 8);
+    };
+    uint32_t E[3] = { 0, 0, 0 }, ES[2] = { 0, 0 };
+#pragma unroll
+    for (int t = 0; t < 3; t++) {
+        const int q = e + 32 * t;
+        if (nb == 1) { if (t < 2 && q < 48) E[t] = entry_of(s_inv[q]); }
+        else {
+            const int c = q >> 1, h = q & 1;
+            for (int m = 0; m < M; m++) E[t] |= entry_of(s_inv[c * nb + h * M + m]) << (9 * m);
+        }
+        if (t < 2 && q < 48) { const int k = s_inv[288 + q]; ES[t] = (uint32_t)(k >> 1) | ((uint32_t)(k & 1) << 8); }
+    }
     auto sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     const uint32_t total = 1 + nsym;                                             // SIGNAL + data symbols
     for (uint32_t s0 = 0; s0 < total; s0 += 8) {
@@ -204,34 +233,44 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
         const int snb = is_sig ? 1 : nb, N = 48 * snb;
         for (int i = e; i < 128; i += 32) s_bins[g][i] = 0;
         if (active) {
-            // coded bits of the symbol, written at their interleaved positions
-            const uint16_t* map = is_sig ? s_map + 288 : s_map;
-            for (int k = e; k < N; k += 32) {
-                unsigned b;
-                if (is_sig) b = coded_bit([&](int i) -> unsigned { return i < 0 ? 0u : (sig >> i) & 1u; }, k, 0);
-                else {
-                    // punctured position c of the data field -> (input bit i, generator): 1/2 A B per bit, 2/3 A B A per 2 bits, 3/4 A1 B1 A2 B3 per 3 bits
-                    const int c = (int)(s - 1) * N + k;
-                    int i, which;
-                    if (cr == 0) { i = c >> 1; which = c & 1; }
-                    else if (cr == 1) { const int q = c / 3, r = c - 3 * q; i = 2 * q + (r == 2); which = r == 1; }
-                    else { const int q = c >> 2, r = c & 3; i = 3 * q + (r == 2 ? 1 : r == 3 ? 2 : 0); which = r & 1; }
-                    b = ((which ? s_gb : s_ga)[i >> 5] >> (i & 31)) & 1u;
+            // TMap11a* + T11aAddPilot (mapper11a.hpp, pilot.hpp:76-118): carriers in the order -26..-1, +1..+26 without pilots; TIFFTx: bins 32..63 go to 96..127
+            auto bin_of = [](int c) { int bin; if (c < 24) { bin = 38 + c; if (bin >= 43) bin++; if (bin >= 57) bin++; } else { bin = 1 + (c - 24); if (bin >= 7) bin++; if (bin >= 21) bin++; }
+                                      return bin < 32 ? bin : bin + 64; };
+            if (is_sig) {
+                // the SIGNAL symbol: rate 1/2 over the 24 header bits (encoder state 0), BPSK
+                const uint32_t A_ = sig ^ (sig << 2) ^ (sig << 3) ^ (sig << 5) ^ (sig << 6), B_ = sig ^ (sig << 1) ^ (sig << 2) ^ (sig << 3) ^ (sig << 6);
+#pragma unroll
+                for (int t = 0; t < 2; t++) {
+                    const int c = e + 32 * t;
+                    if (c < 48) { const unsigned bit = (((ES[t] >> 8) ? B_ : A_) >> (ES[t] & 255u)) & 1u; s_bins[g][bin_of(c)] = pack(mk(bit ? kBpskMod : -kBpskMod, 0)); }
                 }
-                s_ib[g][map[k]] = (uint8_t)b;
-            }
-        }
-        sync();
-        if (active) {
-            // TMap11a* + T11aAddPilot (mapper11a.hpp, pilot.hpp:76-118): carriers in the order -26..-1, +1..+26 without pilots
-            const int kmod = kmod_of(snb);
-            for (int c = e; c < 48; c += 32) {
-                const uint8_t* b = s_ib[g] + c * snb;
-                cpx v = snb == 1 ? mk(b[0] ? kBpskMod : -kBpskMod, 0) : mk(w16(qam_level(b, snb / 2, kmod)), w16(qam_level(b + snb / 2, snb / 2, kmod)));
-                int bin;
-                if (c < 24) { bin = 38 + c; if (bin >= 43) bin++; if (bin >= 57) bin++; }
-                else { bin = 1 + (c - 24); if (bin >= 7) bin++; if (bin >= 21) bin++; }
-                s_bins[g][bin < 32 ? bin : bin + 64] = pack(v);                   // TIFFTx: bins 32..63 go to 96..127
+            } else {
+                const uint32_t ibase = (s - 1u) * (uint32_t)nd;
+                const int kmod = kmod_of(nb);
+                if (nb == 1) {
+#pragma unroll
+                    for (int t = 0; t < 2; t++) {
+                        const int c = e + 32 * t;
+                        if (c < 48) {
+                            const uint32_t idx = ibase + (E[t] & 255u);
+                            const unsigned bit = (s_gab[(E[t] >> 8) & 1u][idx >> 5] >> (idx & 31u)) & 1u;
+                            s_bins[g][bin_of(c)] = pack(mk(bit ? kBpskMod : -kBpskMod, 0));
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int t = 0; t < 3; t++) {
+                        const int q = e + 32 * t, c = q >> 1, h = q & 1;
+                        unsigned v = 0;                                         // the component's bits, first-transmitted = MSB (InitQamMapLut's reversal)
+                        for (int m = 0; m < M; m++) {
+                            const uint32_t en = (E[t] >> (9 * m)) & 511u, idx = ibase + (en & 255u);
+                            v |= ((s_gab[en >> 8][idx >> 5] >> (idx & 31u)) & 1u) << (M - 1 - m);
+                        }
+                        unsigned bb = v ^ (v >> 1); bb ^= bb >> 2;                // Gray -> binary (M <= 3)
+                        const int level = w16(((int)bb * 2 - ((1 << M) - 1)) * kmod);
+                        reinterpret_cast<uint16_t*>(&s_bins[g][bin_of(c)])[h] = (uint16_t)level;
+                    }
+                }
             }
             if (e < 4) {
                 const unsigned pidx = is_sig ? 127u : (unsigned)((s - 1) % 127u);  // m_PilotIndex 127 -> 0 after SIGNAL (pilot.hpp:66-69)

@@ -1089,7 +1089,7 @@ struct sora_rx {
 constexpr int kPipeBackoffCalls = 64;       // calls a handle keeps to the three-kernel chain after a wait inside one of its k_pipe launches gave up
 static std::mutex g_rx_mu;
 static std::vector<sora_rx*> g_rx_all;
-constexpr long long kSharedWindowNs = 20000000;                 // 20 ms
+static std::atomic<long long> g_shared_window_ns{20000000};     // 20 ms (sora_hip_set_share_window_us: a test -- or a host with its own idea of "recently" -- sets it)
 constexpr long long kBatchRows = 1024;                          // frame rows in flight from which a handle counts as one that fills the chip
 static long long steady_ns() { return std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static bool chip_is_shared(const sora_rx* me)
@@ -1100,7 +1100,7 @@ static bool chip_is_shared(const sora_rx* me)
         if (h == me || h->cfg.device != me->cfg.device) continue;
         const long long rows = (long long)h->depth * (long long)h->cfg.max_captures * (long long)h->cfg.max_frames_per_capture;
         const long long t = h->last_call_ns.load(std::memory_order_relaxed);
-        if (rows >= kBatchRows && t != 0 && now - t < kSharedWindowNs) return true;
+        if (rows >= kBatchRows && t != 0 && now - t < g_shared_window_ns.load(std::memory_order_relaxed)) return true;
     }
     return false;
 }
@@ -1229,7 +1229,7 @@ static bool pipe_candidate(const sora_rx* h, long long now)
     const long long rows = (long long)h->depth * (long long)h->cfg.max_captures * (long long)h->cfg.max_frames_per_capture;
     if (h->front == 0 && rows > kAutoPipeRows) return false;
     const long long t = h->last_call_ns.load(std::memory_order_relaxed);
-    return t != 0 && now - t < kSharedWindowNs;
+    return t != 0 && now - t < g_shared_window_ns.load(std::memory_order_relaxed);
 }
 // The CUs are shared by every handle of the process on the device: the launches of ALL of them that are k_pipe's (each workgroup a whole CU's LDS) must be resident together
 static bool pipe_fits(const sora_rx* rx, bool lanes64 = false)
@@ -1265,6 +1265,17 @@ int sora_rx_set_front(sora_rx_t* rx, int kernels)
     return old;
 }
 int sora_rx_front(sora_rx_t* rx) { return rx ? front_for(rx) : SORA_ERR_INVALID_PARAM; }
+int sora_rx_call_front(sora_rx_t* rx, int ticket)                              // what call `ticket` WAS launched with: latched at its process call
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    if (ticket == 0) ticket = rx->seq;
+    RxPipe* p = pipe_of(rx, ticket);
+    return p ? p->front : fail(SORA_ERR_INVALID_PARAM, "sora_rx_call_front: no call with this ticket is held by the handle");
+}
+uint32_t sora_hip_set_share_window_us(uint32_t us)
+{
+    return (uint32_t)(g_shared_window_ns.exchange((long long)us * 1000, std::memory_order_relaxed) / 1000);
+}
 
 int sora_rx_set_trellis(sora_rx_t* rx, int lanes_per_pair)
 {

@@ -155,14 +155,25 @@ def test_the_automatic_choice_leaves_k_pipe_alone_while_a_batch_handle_keeps_the
     big = sora.Rx(max_captures=256, max_total_samples=len(big_iq), sample_rate_mhz=20, max_frames_per_capture=2)     # 8 x 256 x 2 rows in flight: a batch handle
     d_big = torch_cuda.from_numpy(big_iq).cuda()
     assert small.front() == 4                                                      # (a handle that has not taken a call does not count)
-    big.wait(big.process_dev(d_big, descs))
-    assert small.front() == 3
-    res = small.results(ticket=small.process_dev(torch_cuda.from_numpy(cap).cuda(), [(0, len(cap), 0)]))     # ... and decodes through the three kernels
-    assert len(res) == 1 and res[0]["error_code"] == 1
-    small.set_front(4); assert small.front() == 4                                  # an explicit request is an explicit request
-    small.set_front(0)
-    time.sleep(0.05)
-    assert small.front() == 4
+    # (no sleeps: the window is set, not waited for -- an hour while the batch handle counts as busy, zero for "that was long ago")
+    old_window = sora.set_share_window_us(4000000000)
+    try:
+        big.wait(big.process_dev(d_big, descs))
+        assert small.front() == 3
+        t = small.process_dev(torch_cuda.from_numpy(cap).cuda(), [(0, len(cap), 0)])
+        assert small.call_front(t) == 3 and small.call_front() == 3                # what the call was launched with is latched with its ticket
+        res = small.results(ticket=t)                                              # ... and decodes through the three kernels
+        assert len(res) == 1 and res[0]["error_code"] == 1
+        small.set_front(4); assert small.front() == 4                              # an explicit request is an explicit request
+        small.set_front(0)
+        sora.set_share_window_us(0)
+        assert small.front() == 4
+        t2 = small.process_dev(torch_cuda.from_numpy(cap).cuda(), [(0, len(cap), 0)])
+        assert small.call_front(t2) == 4
+        res = small.results(ticket=t2); assert len(res) == 1 and res[0]["error_code"] == 1
+    finally:
+        sora.set_share_window_us(old_window)
+    assert old_window == 20000
     big.close(); small.close()
 
 

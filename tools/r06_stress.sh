@@ -22,3 +22,6 @@ i = b.build_info(); print("sources_sha256", i["sources_sha256_now"], "built_from
 PY
 for j in $(seq 1 $i); do tail -1 $OUT/r06_stress_$j.txt; done; } > $OUT/r06_stress.txt
 cat $OUT/r06_stress.txt
+# ... and the 802.11n graph with each of its trellis kernels (1 = the window-parallel form new this round), the 802.11b graph once
+( for cfg in "600 71 1" "600 72 1" "2000 73 1" "150 74 1" "600 75 64" "600 76 16"; do python $R/tools/stress_parity_11n.py $cfg 2>&1 | tail -1; done; python $R/tools/stress_parity_11b.py --captures 4000 --seed 77 2>&1 | tail -1 ) > $OUT/r06_stress_11n_11b.txt 2>&1
+cat $OUT/r06_stress_11n_11b.txt >> $OUT/r06_stress.txt; cat $OUT/r06_stress_11n_11b.txt

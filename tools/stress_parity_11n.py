@@ -1,6 +1,6 @@
 """GPU (sora_rx11n_*) against the CPU oracle on many random two-chain 802.11n captures built from the recorded waveforms of the
 reference modulator (tests/golden/refgraph_11n.npz): decoded frames, FCS failures, header failures (MCS 12), frames cut by the end
-of the capture, several frames per capture.  usage: python tools/stress_parity_11n.py [captures] [seed]"""
+of the capture, several frames per capture.  usage: python tools/stress_parity_11n.py [captures] [seed] [trellis: 64 | 16 | 1 | 0]"""
 import os
 import sys
 import time
@@ -36,6 +36,8 @@ def main():
     for i, (a, _) in enumerate(caps):
         descs.append((off, len(a), i)); off += len(a)
     rx = sora_amd.Rx11n(ncap, len(iq0), max_frames_per_capture=8)
+    if len(sys.argv) > 3:                                                  # trellis kernel: 64, 16, 1 (the window-parallel form, round 6), 0 = automatic
+        rx.set_trellis(int(sys.argv[3]))
     t0 = time.perf_counter()
     rx.process_dev(torch.from_numpy(iq0).cuda(), torch.from_numpy(iq1).cuda(), descs)
     per = [[] for _ in caps]
