@@ -1105,9 +1105,9 @@ def tx11a_samples(mpdu_len_nofcs, rate_kbps):
     return int(load().sora_hip_tx11a_samples(int(mpdu_len_nofcs), int(rate_kbps)))
 
 
-def tx11a(mpdus, rates_kbps, seeds=None, device=0, stream=None, sync=True):
+def tx11a(mpdus, rates_kbps, seeds=None, device=0, stream=None, sync=True, gaps=None):
     """Modulate a batch of MPDUs (bytes WITHOUT FCS) on the GPU.  -> (int8 CUDA tensor [total,2] COMPLEX8 @40 MHz, offsets list).
-    Frame f occupies samples offsets[f] .. offsets[f+1]."""
+    Frame f occupies samples offsets[f] .. offsets[f+1] (gaps[f] zero samples in front of frame f, if given, included at its start)."""
     import torch
     n = len(mpdus)
     seeds = [0xFF] * n if seeds is None else list(seeds)
@@ -1119,12 +1119,14 @@ def tx11a(mpdus, rates_kbps, seeds=None, device=0, stream=None, sync=True):
     ns = [tx11a_samples(l, r) for l, r in zip(lens, rates_kbps)]
     if any(v == 0 for v in ns):
         raise SoraError(-1, "tx11a: unsupported rate or length")
-    ooff = np.zeros(n + 1, np.uint64); np.cumsum(ns, out=ooff[1:])
+    gaps = [0] * n if gaps is None else [int(v) for v in gaps]
+    ooff = np.zeros(n + 1, np.uint64); np.cumsum([a + b for a, b in zip(ns, gaps)], out=ooff[1:])
+    first = ooff[:-1] + np.asarray(gaps, np.uint64)
     dev = torch.device("cuda", device)
     t = lambda a, dt: torch.from_numpy(np.ascontiguousarray(a, dt)).to(dev)
     d_blob = t(blob, np.uint8); d_off = torch.from_numpy(off[:-1].astype(np.int32)).to(dev)
     d_len = torch.from_numpy(np.asarray(lens, np.int32)).to(dev); d_rate = torch.from_numpy(np.asarray(rates_kbps, np.int32)).to(dev)
-    d_seed = t(np.asarray(seeds, np.uint8), np.uint8); d_ooff = torch.from_numpy(ooff[:-1].astype(np.int64)).to(dev)
+    d_seed = t(np.asarray(seeds, np.uint8), np.uint8); d_ooff = torch.from_numpy(first.astype(np.int64)).to(dev)
     out = torch.zeros((int(ooff[-1]), 2), dtype=torch.int8, device=dev)
     _check(load().sora_hip_tx11a(_dev_ptr(d_blob), _dev_ptr(d_off), _dev_ptr(d_len), _dev_ptr(d_rate), _dev_ptr(d_seed), n,
                                  _dev_ptr(out), _dev_ptr(d_ooff), _stream_ptr(stream)))

@@ -17,47 +17,64 @@ namespace sora {
 __device__ __constant__ uint8_t kLtsPos[64] = {              // LTS_Positive_table (ieee80211const.h:23-28)
     0,1,0,0,1,1,0,1,0,1,0,0,0,0,0,1, 1,0,0,1,0,1,0,1,1,1,1,0,0,0,0,0,
     0,0,0,0,0,0,1,1,0,0,1,1,0,1,0,1, 1,1,1,1,1,0,0,1,1,0,1,0,1,1,1,1 };
-__device__ __constant__ uint8_t kPilotSgnTx[128] = {         // pilot.hpp:10-28: 1 <=> polarity -1
+constexpr uint8_t kPilotSgnTx[128] = {         // pilot.hpp:10-28: 1 <=> polarity -1
     0,0,0,1,1,1,0,1, 1,1,1,0,0,1,0,1, 1,0,0,1,0,0,1,0, 0,0,0,0,0,1,0,0,
     0,1,0,0,1,1,0,0, 0,1,0,1,1,1,0,1, 0,1,1,0,1,1,0,0, 0,0,0,1,1,0,0,1,
     1,0,1,0,1,0,0,1, 1,1,0,0,1,1,1,1, 0,1,1,0,1,0,0,0, 0,1,0,1,0,1,0,1,
     1,1,1,1,0,1,0,0, 1,0,1,0,0,0,1,1, 0,1,1,1,0,0,0,1, 1,1,1,1,1,1,0,0 };
 
+constexpr uint32_t pilot_word(int w) { uint32_t v = 0; for (int j = 0; j < 32; j++) v |= (uint32_t)kPilotSgnTx[32 * w + j] << j; return v; }   // bit n of word n >> 5 = kPilotSgnTx[n]
+constexpr uint32_t kPilotW0 = pilot_word(0), kPilotW1 = pilot_word(1), kPilotW2 = pilot_word(2), kPilotW3 = pilot_word(3);
+static_assert(kPilotW0 == 0x2049a7b8u && kPilotW3 == 0x3f8ec52fu, "pilot polarity words");
 constexpr int kBpskMod = 10720;                              // mapper11a.hpp:8-11
 __device__ __forceinline__ int kmod_of(int nb) { return nb == 1 ? kBpskMod : nb == 2 ? (int)(kBpskMod / 1.414) : nb == 4 ? (int)(kBpskMod / 3.162) : (int)(kBpskMod / 6.481); }
 __device__ __forceinline__ int sat8(int v) { return min(max(v, -128), 127); }          // _mm_packs_epi16 (stdbrick.hpp:430)
 
-// InitQamMapLut (mapper11a.hpp:16-43): M bits, first-transmitted = MSB after reversal, Gray -> level
-__device__ __forceinline__ int qam_level(const uint8_t* bits, int M, int kmod)
-{
-    unsigned rev = 0;
-    for (int i = 0; i < M; i++) rev |= (unsigned)bits[i] << (M - 1 - i);
-    unsigned b = rev ^ (rev >> 1); b ^= b >> 2;                                         // Gray -> binary (M <= 3)
-    return ((int)b * 2 - ((1 << M) - 1)) * kmod;
-}
-
 // 160 time samples of one OFDM symbol from its 64 frequency bins (TIFFTx, fft.hpp:21-59): bins 0..31 -> 0..31, 32..63 ->
 // 96..127 of a 128-point IFFT, >> 4, GI = last 32, first/last two samples halved, saturating 16 -> 8 bit pack.
-// s_bins: 128 words (zero outside the 64 bins), s_sym: 160 words; 32 lanes, e = lane of the group.
+// s_bins: 128 words (zero outside the 64 bins); 32 lanes, e = lane of the group.
+// Round 6: the samples leave straight from where the IFFT's last stage put them -- time sample n at word brev7(n) (FFT128LUTMap), output sample i of the symbol is
+// n = (i + 96) & 127 -- four per lane as one 8-byte store, the shift, the clamp (_mm_packs_epi16, stdbrick.hpp:430) and the byte pick on packed halves.  (Round 5
+// un-reversed into a 160-word symbol buffer, copied the GI behind a barrier and stored two bytes per lane and pass.)
+// Output sample i of a symbol is time sample n = (i + 96) & 127, which the IFFT's last stage left at word brev7(n).  A lane's four samples in a row, i = 4 e + k, sit at
+// brev5((e + 24) & 31) + 32 brev2(k); its one sample of the last 32, i = 128 + e, at 4 brev5(e) + 3.
+struct EmitPlan { uint32_t a4, a1; uint32_t sh01, shs; };
+__device__ __forceinline__ EmitPlan emit_plan(int e)
+{
+    EmitPlan P;
+    P.a4 = __brev((unsigned)((e + 24) & 31)) >> 27;
+    P.a1 = 4u * (__brev((unsigned)e) >> 27) + 3u;
+    P.sh01 = e == 0 ? 0x00050005u : 0x00040004u;                                 // samples 0, 1 ...
+    P.shs = e >= 30 ? 0x00050005u : 0x00040004u;                                 // ... and 158, 159 are halved
+    return P;
+}
+__device__ __forceinline__ uint32_t pk_sra_clamp8(uint32_t v, uint32_t sh)
+{
+    const s16x2_t lo = { (short)-128, (short)-128 }, hi = { (short)127, (short)127 };
+    const s16x2_t x = __builtin_bit_cast(s16x2_t, v) >> __builtin_bit_cast(s16x2_t, sh);
+    return __builtin_bit_cast(uint32_t, __builtin_elementwise_min(__builtin_elementwise_max(x, lo), hi));
+}
 template <typename SYNC>
-__device__ __forceinline__ void ifft_emit(uint32_t* s_bins, uint32_t* s_sym, int e, const Fft128Tw& tw, int8_t* out8, SYNC sync)
+__device__ __forceinline__ void ifft_emit(uint32_t* s_bins, int e, const Fft128Tw& tw, const EmitPlan& P, int8_t* out8, SYNC sync)
 {
     pcx x[4];
     sync();
 #pragma unroll
     for (int m = 0; m < 4; m++) x[m] = s_bins[e + 32 * m];
     ifft128_core_pk(x, s_bins, e, tw, sync);                                     // IFFT<128> on packed COMPLEX16 (bit-exact with fft128_core<true>)
-#pragma unroll
-    // FFT128LUTMap = 7-bit bit reversal; >> 4
-    for (int q = 0; q < 4; q++) s_sym[32 + e + 32 * q] = pk_sra(s_bins[__brev((unsigned)(e + 32 * q)) >> 25], 4);
-    sync();
-    s_sym[e] = s_sym[128 + e];
-    sync();
     if (out8 == nullptr) return;                                                 // (a group past the last symbol only keeps the barriers company)
-    for (int i = e; i < 160; i += 32) {
-        cpx v = unpack(s_sym[i]);
-        if (i < 2 || i >= 158) v = sra(v, 1);
-        reinterpret_cast<uint16_t*>(out8)[i] = (uint16_t)(((unsigned)sat8(v.re) & 0xFFu) | (((unsigned)sat8(v.im) & 0xFFu) << 8));
+    if ((reinterpret_cast<uintptr_t>(out8) & 7u) == 0) {
+        const uint32_t w0 = pk_sra_clamp8(s_bins[P.a4], P.sh01), w1 = pk_sra_clamp8(s_bins[P.a4 + 64], P.sh01);
+        const uint32_t w2 = pk_sra_clamp8(s_bins[P.a4 + 32], 0x00040004u), w3 = pk_sra_clamp8(s_bins[P.a4 + 96], 0x00040004u), w4 = pk_sra_clamp8(s_bins[P.a1], P.shs);
+        uint2 o;                                                                 // low bytes of (re0, im0, re1, im1)
+        o.x = __builtin_amdgcn_perm(w1, w0, 0x06040200u); o.y = __builtin_amdgcn_perm(w3, w2, 0x06040200u);
+        reinterpret_cast<uint2*>(out8)[e] = o;
+        reinterpret_cast<uint16_t*>(out8)[128 + e] = (uint16_t)__builtin_amdgcn_perm(0u, w4, 0x0c0c0200u);
+    } else {                                                                     // (a frame the caller placed at a sample offset that is not a multiple of four)
+        for (int i = e; i < 160; i += 32) {
+            const uint32_t w = pk_sra_clamp8(s_bins[__brev((unsigned)((i + 96) & 127)) >> 25], (i < 2 || i >= 158) ? 0x00050005u : 0x00040004u);
+            reinterpret_cast<uint16_t*>(out8)[i] = (uint16_t)__builtin_amdgcn_perm(0u, w, 0x0c0c0200u);
+        }
     }
 }
 
@@ -101,20 +118,7 @@ __global__ void __launch_bounds__(64) k_tx_preamble(int8_t* out8, Tables T)
     }
 }
 
-// coded bit c of a stream whose input bits are read by `bit(i)` (0 for i < 0); code_rate 0 = 1/2, 1 = 2/3, 2 = 3/4
-// (TConvEncode_12/_23/_34, conv_enc.hpp:18-330: 2/3 sends A B A per 2 bits, 3/4 sends A1 B1 A2 B3 per 3 bits)
-template <typename BIT>
-__device__ __forceinline__ unsigned coded_bit(BIT bit, int c, int code_rate)
-{
-    int i, which;
-    if (code_rate == 0) { i = c >> 1; which = c & 1; }
-    else if (code_rate == 1) { const int g = c / 3, r = c - 3 * g; i = 2 * g + (r == 2); which = r == 1; }
-    else { const int g = c >> 2, r = c & 3; i = 3 * g + (r == 2 ? 1 : r == 3 ? 2 : 0); which = r & 1; }
-    const unsigned x = bit(i), s1 = bit(i - 1), s2 = bit(i - 2), s3 = bit(i - 3), s5 = bit(i - 5), s6 = bit(i - 6);
-    return which ? (x ^ s1 ^ s2 ^ s3 ^ s6) : (x ^ s2 ^ s3 ^ s5 ^ s6);           // G1 = 171, G0 = 133 (conv_enc.hpp:6-14)
-}
-
-__global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
+__global__ void __launch_bounds__(256, 8) k_tx11a(TxArgs A)
 {
     __shared__ alignas(4) uint8_t s_data[2608];
     // generator outputs A (133) / B (171) of the whole data field, bit i of the stream = bit i & 31 of word i >> 5
@@ -123,7 +127,6 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
     __shared__ uint32_t s_crc[256];
     __shared__ uint32_t s_z[6 * 8 * 16];
     __shared__ uint32_t s_bins[8][128];
-    __shared__ uint32_t s_sym[8][160];
     // the interleaver inverted: position -> coded bit of the symbol, for the frame's modulation and for the SIGNAL symbol (BPSK)
     __shared__ uint16_t s_inv[288 + 48];
     __shared__ uint32_t s_fcs;
@@ -213,29 +216,42 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
         else { const int q4 = k >> 2, r = k & 3; il = 3 * q4 + (r == 2 ? 1 : r == 3 ? 2 : 0); which = r & 1; }
         return (uint32_t)il | ((uint32_t)which << 8);
     };
-    uint32_t E[3] = { 0, 0, 0 }, ES[2] = { 0, 0 };
+    // (registers, not a packed word: the loop below neither unpacks nor recomputes anything that depends on the lane alone)
+    // bit offset within s_gab of each of the component's bits at symbol 0: input bit within the symbol + 656 * 32 for generator B (a whole number of words)
+    uint32_t il[3][3], ES[2] = { 0, 0 };
+    uint32_t cw[3];                                                              // byte address of the component's 16-bit half in the symbol's bins
+    // TMap11a* + T11aAddPilot (mapper11a.hpp, pilot.hpp:76-118): carriers in the order -26..-1, +1..+26 without pilots; TIFFTx: bins 32..63 go to 96..127
+    auto bin_of = [](int c) { int bin; if (c < 24) { bin = 38 + c; if (bin >= 43) bin++; if (bin >= 57) bin++; } else { bin = 1 + (c - 24); if (bin >= 7) bin++; if (bin >= 21) bin++; }
+                              return bin < 32 ? bin : bin + 64; };
 #pragma unroll
     for (int t = 0; t < 3; t++) {
         const int q = e + 32 * t;
-        if (nb == 1) { if (t < 2 && q < 48) E[t] = entry_of(s_inv[q]); }
-        else {
+#pragma unroll
+        for (int m = 0; m < 3; m++) il[t][m] = 0;
+        if (nb == 1) {
+            if (t < 2 && q < 48) { const uint32_t en = entry_of(s_inv[q]); il[t][0] = (en & 255u) + (en >> 8) * (656u * 32u); }
+            cw[t] = (uint32_t)bin_of(t < 2 && q < 48 ? q : 0) * 4u;
+        } else {
             const int c = q >> 1, h = q & 1;
-            for (int m = 0; m < M; m++) E[t] |= entry_of(s_inv[c * nb + h * M + m]) << (9 * m);
+#pragma unroll
+            for (int m = 0; m < 3; m++) if (m < M) { const uint32_t en = entry_of(s_inv[c * nb + h * M + m]); il[t][m] = (en & 255u) + (en >> 8) * (656u * 32u); }
+            cw[t] = (uint32_t)bin_of(c) * 4u + 2u * (uint32_t)h;
         }
         if (t < 2 && q < 48) { const int k = s_inv[288 + q]; ES[t] = (uint32_t)(k >> 1) | ((uint32_t)(k & 1) << 8); }
     }
+    const EmitPlan plan = emit_plan(e);
+    const int kmod = kmod_of(nb), lvl0 = -((1 << M) - 1) * kmod, kmod2 = 2 * kmod;
     auto sync = []() { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); };
     const uint32_t total = 1 + nsym;                                             // SIGNAL + data symbols
+    const uint32_t* const gab = &s_gab[0][0];
+    char* const bins = reinterpret_cast<char*>(s_bins[g]);
     for (uint32_t s0 = 0; s0 < total; s0 += 8) {
         const uint32_t s = s0 + (uint32_t)g;
         const bool active = s < total;
         const bool is_sig = s == 0;
-        const int snb = is_sig ? 1 : nb, N = 48 * snb;
         for (int i = e; i < 128; i += 32) s_bins[g][i] = 0;
         if (active) {
-            // TMap11a* + T11aAddPilot (mapper11a.hpp, pilot.hpp:76-118): carriers in the order -26..-1, +1..+26 without pilots; TIFFTx: bins 32..63 go to 96..127
-            auto bin_of = [](int c) { int bin; if (c < 24) { bin = 38 + c; if (bin >= 43) bin++; if (bin >= 57) bin++; } else { bin = 1 + (c - 24); if (bin >= 7) bin++; if (bin >= 21) bin++; }
-                                      return bin < 32 ? bin : bin + 64; };
+            auto gen_bit = [&](uint32_t idx) -> uint32_t { return (gab[idx >> 5] >> (idx & 31u)) & 1u; };      // (idx >= 656 * 32: generator B's stream)
             if (is_sig) {
                 // the SIGNAL symbol: rate 1/2 over the 24 header bits (encoder state 0), BPSK
                 const uint32_t A_ = sig ^ (sig << 2) ^ (sig << 3) ^ (sig << 5) ^ (sig << 6), B_ = sig ^ (sig << 1) ^ (sig << 2) ^ (sig << 3) ^ (sig << 6);
@@ -246,40 +262,31 @@ __global__ void __launch_bounds__(256) k_tx11a(TxArgs A)
                 }
             } else {
                 const uint32_t ibase = (s - 1u) * (uint32_t)nd;
-                const int kmod = kmod_of(nb);
                 if (nb == 1) {
 #pragma unroll
-                    for (int t = 0; t < 2; t++) {
-                        const int c = e + 32 * t;
-                        if (c < 48) {
-                            const uint32_t idx = ibase + (E[t] & 255u);
-                            const unsigned bit = (s_gab[(E[t] >> 8) & 1u][idx >> 5] >> (idx & 31u)) & 1u;
-                            s_bins[g][bin_of(c)] = pack(mk(bit ? kBpskMod : -kBpskMod, 0));
-                        }
-                    }
+                    for (int t = 0; t < 2; t++)
+                        if (e + 32 * t < 48) *reinterpret_cast<uint32_t*>(bins + cw[t]) = pack(mk(gen_bit(ibase + il[t][0]) ? kBpskMod : -kBpskMod, 0));
                 } else {
 #pragma unroll
                     for (int t = 0; t < 3; t++) {
-                        const int q = e + 32 * t, c = q >> 1, h = q & 1;
-                        unsigned v = 0;                                         // the component's bits, first-transmitted = MSB (InitQamMapLut's reversal)
-                        for (int m = 0; m < M; m++) {
-                            const uint32_t en = (E[t] >> (9 * m)) & 511u, idx = ibase + (en & 255u);
-                            v |= ((s_gab[en >> 8][idx >> 5] >> (idx & 31u)) & 1u) << (M - 1 - m);
-                        }
+                        unsigned v = 0;                                         // the component's bits, first-transmitted = MSB (InitQamMapLut's reversal, mapper11a.hpp:16-43)
+#pragma unroll
+                        for (int m = 0; m < 3; m++) if (m < M) v |= gen_bit(ibase + il[t][m]) << (M - 1 - m);
                         unsigned bb = v ^ (v >> 1); bb ^= bb >> 2;                // Gray -> binary (M <= 3)
-                        const int level = w16(((int)bb * 2 - ((1 << M) - 1)) * kmod);
-                        reinterpret_cast<uint16_t*>(&s_bins[g][bin_of(c)])[h] = (uint16_t)level;
+                        *reinterpret_cast<uint16_t*>(bins + cw[t]) = (uint16_t)((int)bb * kmod2 + lvl0);
                     }
                 }
             }
             if (e < 4) {
-                const unsigned pidx = is_sig ? 127u : (unsigned)((s - 1) % 127u);  // m_PilotIndex 127 -> 0 after SIGNAL (pilot.hpp:66-69)
-                const int p = kPilotSgnTx[pidx] ? -kBpskMod : kBpskMod;
+                // pilot.hpp:10-28 as four words, bit n = 1 <=> polarity -1 at index n; m_PilotIndex 127 -> 0 after SIGNAL (pilot.hpp:66-69)
+                const unsigned pidx = is_sig ? 127u : (unsigned)((s - 1) % 127u);
+                const uint32_t pw = pidx < 64 ? (pidx < 32 ? kPilotW0 : kPilotW1) : (pidx < 96 ? kPilotW2 : kPilotW3);
+                const int p = (pw >> (pidx & 31u)) & 1u ? -kBpskMod : kBpskMod;
                 const int bin = e == 0 ? 7 : e == 1 ? 21 : e == 2 ? 64 - 7 : 64 - 21;
                 s_bins[g][bin < 32 ? bin : bin + 64] = pack(mk(e == 1 ? -p : p, 0));
             }
         }
-        ifft_emit(s_bins[g], s_sym[g], e, tw, active ? out + 2 * (640 + 160 * (size_t)s) : (int8_t*)nullptr, sync);
+        ifft_emit(s_bins[g], e, tw, plan, active ? out + 2 * (640 + 160 * (size_t)s) : (int8_t*)nullptr, sync);
         sync();
     }
 }

@@ -30,6 +30,20 @@ def test_tx_matches_oracle(sora, oracle, rate):
         assert np.array_equal(got[off[f]:off[f + 1]], want), (rate, len(mp), hex(sd))
 
 
+def test_tx_frames_at_sample_offsets_that_are_not_multiples_of_four(sora, oracle):
+    """The kernel stores four samples at a time where a frame starts on an 8-byte boundary and two bytes at a time elsewhere: frames behind gaps of 1, 2, 3, 5 .. samples
+    come out sample for sample as the oracle's, and the gaps stay untouched."""
+    rng = np.random.default_rng(99)
+    rates = [RATES[i % 8] for i in range(16)]
+    gaps = [(1, 2, 3, 5, 0, 7, 4, 6)[i % 8] for i in range(16)]
+    mpdus = [bytes(rng.integers(0, 256, 20 + 41 * i).astype(np.uint8)) for i in range(16)]
+    out, off = sora.tx11a(mpdus, rates, [0x5B] * 16, gaps=gaps)
+    got = out.cpu().numpy()
+    for f in range(16):
+        assert not got[off[f]:off[f] + gaps[f]].any()
+        assert np.array_equal(got[off[f] + gaps[f]:off[f + 1]], oracle.tx(mpdus[f], rates[f], 0x5B)), (f, rates[f], gaps[f])
+
+
 def test_tx_matches_the_reference_modulation_graph(sora):
     """Against the reference itself: CreateModGraph11a_40M + CreatePreamble11a_40M compiled from the reference sources
     (oracle/_ref/libsora_refgraph.so, oracle/build_ref.sh)."""
