@@ -164,7 +164,7 @@ def bench_11n(torch, sora_amd, dev, ncaps=8192, reps=5):
     return out
 
 
-def bench_ht40(torch, sora_amd, dev, nframes=4096):
+def bench_ht40(torch, sora_amd, dev, nframes=4096, trellis=(64, 16)):
     """BASELINE configs[3] (802.11n 2x2 40 MHz HT: 128-point FFT, MMSE detection, one decoder per spatial stream) on RAW CAPTURES -- parity
     unpinned for the 40 MHz extension, the reference has no such receiver; its own 20 MHz front-end bricks find
     and parse the frames.  `nframes` two-chain 40 MHz captures of one HT-mixed frame each: legacy preamble + HT-SIG + HT-STF + 2 HT-LTF +
@@ -195,7 +195,7 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
     rx.wait_for_producer = False
     depth = rx.calls_in_flight()
     res = {}
-    for lanes in (64, 16):
+    for lanes in trellis:
         rx.set_trellis(lanes)
         res[lanes] = timed_with_delivery(sora_amd, rx, lambda: rx.process_captures_dev(f0, f1, caps, max_frames_per_capture=2), depth, 20, 4 * nframes, 2 * nframes * 1500 + 4096)   # (room for two rows per event the captures could hold)
     best = min(res, key=lambda l: res[l][0])
@@ -211,7 +211,7 @@ def bench_ht40(torch, sora_amd, dev, nframes=4096):
     return {"workload": "%d two-chain 40 MHz captures x one HT-mixed frame, MCS 14 (64-QAM 3/4 on both streams), 1500-byte PSDU per stream (%d data symbols; %d samples per chain and capture), 2x2 cross-talk, AWGN; front end + unbiased MMSE on the estimated noise variance" % (nframes, nsym, n),
             "parity": "unpinned for the 40 MHz extension (the reference has no 40 MHz / MMSE / per-stream-decoder receiver): loop-back against oracle/py_ht40.py; the front end is the reference's 20 MHz bricks (pinned), the model's preamble is pinned through the restated reference receiver (tests/test_ht40_preamble_model.py)",
             "ms": round(ms, 3), "calls_in_flight": depth, "trellis_kernel": {64: "k_viterbi11n", 16: "k_viterbi16_11n"}[best],
-            "ms_by_trellis_kernel": {"k_viterbi11n": round(res[64][0], 3), "k_viterbi16_11n": round(res[16][0], 3)},
+            "ms_by_trellis_kernel": {{64: "k_viterbi11n", 16: "k_viterbi16_11n"}[l]: round(res[l][0], 3) for l in res},
             "ms_data_field_only": round(ms_df, 3), "psdus_ok_data_field_only": ok_df,
             "msamples_per_s": round(samples / ms / 1e3, 1), "decoded_mbit_per_s": round(2 * 1500 * 8 * nframes / ms / 1e3, 1),
             "psdus_ok": ok, "psdus": 2 * nframes, "delivery": delivery, "bound": "hbm", "algorithmic_bytes": int(alg), "achieved": round(alg / ms / 1e6, 1), "peak": HBM_PEAK / 1e9, "unit": "GB/s",

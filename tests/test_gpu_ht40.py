@@ -3,7 +3,8 @@ receiver.  What is checked: (1) loop-back with the independent numpy model of th
 every modulation and code rate, 2x2 channels with cross-talk, CFO, noise -- both streams' PSDUs come back with a good FCS; (2) the pieces the
 reference does have: with noise_var = 0 the detection weights are TMimoChannelEst's zero-forcing inverse bit for bit (sora_hip_mimo_est11n, itself
 pinned to the reference brick, on the same channel matrices); (3) the MMSE weights against a float64 evaluation, tolerance +-1 LSB of the int16
-weight (single-precision arithmetic on the GPU); (4) the unchanged trellis kernel decodes the two streams of a frame in one wave."""
+weight (single-precision arithmetic on the GPU), and against float64 ALL the way from the raw samples, tolerance +-32 LSB (the fixed-point FFT<128>);
+(4) the unchanged trellis kernel decodes the two streams of a frame in one wave."""
 import numpy as np
 import pytest
 
@@ -235,6 +236,52 @@ def test_mmse_weights_against_float64(env):
                 continue
             worst = max(worst, float(np.abs(w[f, :, b].astype(float) - want).max()))
     assert worst <= 1.0, worst
+
+
+# The stated tolerance of the FFT<128> path's intermediates: the detection weights the data field works with -- the first
+# quantity behind the two HT-LTF transforms -- against an evaluation that is float64 ALL the way (numpy's FFT of the raw int16 samples, no fixed-point step
+# anywhere), weights in the kernel's Q16 (1.0 = 65536).  Two sources of difference: the fixed-point transform (its stages shift and saturate; gain 1/128) and the
+# single-precision solve.  Bound: |difference| <= kWeightTolLsb LSB on every data / pilot carrier whose weight fits the int16 (the others saturate by design).
+kFft128Gain = 1.0 / 128.0
+kWeightTolLsb = 32.0                                                   # (measured: 12.7 LSB worst over 684 carriers; 32 LSB = 2^-11 of a unit gain)
+
+
+def test_detection_weights_against_an_all_float64_chain(env):
+    torch, sora = env
+    rng = np.random.default_rng(66)
+    iq, descs, _ = make_frames(rng, [(4, 0, 80, 80)] * 6, sigma=10.0)
+    nv = 3000.0
+    descs = [d[:6] + (nv,) + d[7:] for d in descs]
+    _, w = run(env, iq, descs, want_w=True)
+    worst = 0.0; gains = []; checked = 0
+    for f, d in enumerate(descs):
+        off = d[0]
+        Yf = np.zeros((2, 2, 128), complex)
+        for s in range(2):
+            for r in range(2):
+                x = iq[r, off + 160 * s + 32: off + 160 * s + 160].astype(np.float64)
+                Yf[s, r] = np.fft.fft(x[:, 0] + 1j * x[:, 1]) * kFft128Gain
+        sym = comp0(np.stack([iq[r, off + 160 * s + 32: off + 160 * s + 160] for s in range(2) for r in range(2)]))
+        Yg = sora.fft128(torch.from_numpy(sym.copy()).cuda()).cpu().numpy().reshape(2, 2, 128, 2).astype(np.float64)
+        for k in range(-58, 59):
+            v = int(m.HTLTF40[k + 58])
+            if v == 0:
+                continue
+            b = k % 128
+            gains.append(np.abs(Yg[0, 0, b, 0] + 1j * Yg[0, 0, b, 1]) / max(np.abs(Yf[0, 0, b]), 1e-9))
+            H = np.zeros((2, 2), complex)
+            for r in range(2):
+                H[r, 0] = v * (Yf[0, r, b] - Yf[1, r, b]) / 2; H[r, 1] = v * (Yf[0, r, b] + Yf[1, r, b]) / 2
+            W = np.linalg.solve(H.conj().T @ H + nv * np.eye(2), H.conj().T)
+            W = W / np.real(np.diag(W @ H))[:, None] * 65536.0
+            want = np.array([[W[0, 0].real, W[0, 0].imag], [W[0, 1].real, W[0, 1].imag], [W[1, 0].real, W[1, 0].imag], [W[1, 1].real, W[1, 1].imag]])
+            if np.abs(want).max() > 32000:
+                continue
+            worst = max(worst, float(np.abs(w[f, :, b].astype(float) - want).max())); checked += 1
+    print("FFT<128> path, detection weights against float64 all the way: worst |difference| %.2f LSB of Q16 over %d carriers; fixed-point / float transform gain %.4f .. %.4f"
+          % (worst, checked, min(gains), max(gains)))
+    assert checked >= 6 * 100, checked
+    assert worst <= kWeightTolLsb, (worst, min(gains), max(gains))
 
 
 # ------------------------------------------------------------------ raw captures: the front end (sora_ht40_process_captures_dev)
