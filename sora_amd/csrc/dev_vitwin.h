@@ -61,15 +61,30 @@ __device__ __forceinline__ UnitGeom unit_of(const VitJob& J, uint32_t idx, uint3
     return g;
 }
 
+// position p of a list of n frames: the frame (place idx of the list), which of its nun units (kWinNone: none), windows per unit
+struct UnitRef { uint32_t idx, uu, m, nun; };
+template <int CR, int WIN, int LOOK>
+__device__ __forceinline__ UnitRef unit_ref(const VitJob& J, uint32_t n, uint32_t p, uint32_t q, bool inside, uint32_t upos, uint32_t idx)
+{
+    const uint32_t nev = win_events(J.length, CR, WIN, LOOK), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
+    const uint32_t uu = !inside ? kWinNone : m != 1u ? (upos < nun ? upos : kWinNone) : n == 1u ? win_unit_lone(upos, nun) : (upos < nun ? win_unit_at(upos, nun) : kWinNone);
+    return UnitRef{ idx, uu, m, nun };
+}
+template <int CR, int WIN, int LOOK, typename JOBS>
+__device__ __forceinline__ UnitRef unit_ref_at(JOBS job_at, uint32_t n, uint32_t p, uint32_t q)
+{
+    const bool inside = p < win_slots(n, q);
+    const uint32_t upos = inside ? p / n : 0u, idx = inside ? p - upos * n : 0u;
+    return unit_ref<CR, WIN, LOOK>(job_at(idx), n, p, q, inside, upos, idx);
+}
 template <int CR, int WIN, int LOOK, typename JOBS>
 __device__ __forceinline__ UnitGeom unit_geom(JOBS job_at, uint32_t n, uint32_t p, uint32_t q, uint32_t vbase, uint8_t* __restrict__ out)
 {
     const bool inside = p < win_slots(n, q);
     const uint32_t upos = inside ? p / n : 0u, idx = inside ? p - upos * n : 0u;
     const VitJob J = job_at(idx);
-    const uint32_t nev = win_events(J.length, CR, WIN, LOOK), m = win_per_unit(nev, q), nun = (nev + m - 1u) / m;
-    const uint32_t uu = !inside ? kWinNone : m != 1u ? (upos < nun ? upos : kWinNone) : n == 1u ? win_unit_lone(upos, nun) : (upos < nun ? win_unit_at(upos, nun) : kWinNone);
-    return unit_of<CR, WIN, LOOK>(J, idx, uu, m, nun, q, vbase, out);
+    const UnitRef R = unit_ref<CR, WIN, LOOK>(J, n, p, q, inside, upos, idx);
+    return unit_of<CR, WIN, LOOK>(J, idx, R.uu, R.m, R.nun, q, vbase, out);
 }
 // ... and unit `u` itself of the frame at place idx (the 64-lane form inside k_pipe: a wave holds unit u of two frames, or of one)
 template <int CR, int WIN, int LOOK, typename JOBS>
@@ -261,10 +276,13 @@ __device__ __forceinline__ void forward16w(Lds16<WIN, LOOK>& S, const uint8_t* _
 
 // (S: the wave's own LDS block.  wave_index: which eighth-of-units of the call.  jobs_of(list): that list's job_at.  ready(A, B, list): called once the wave's units are
 // known, before the first soft value is read -- k_pipe waits there for the symbol chain; false = give up.)
-template <int WIN, int LOOK, int BITS, typename JOBSOF, typename READY>
+// done(cr, list, nl, w, q, job_at): what the wave does once its eight units (positions 8 w .. 8 w + 7 of the list) have written their bytes and vectors -- nothing, or
+// k_viterbi16w_fin's tail (k_rx.hip): the LAST unit of a frame to arrive proves and finishes the frame
+struct NothingDone { template <typename CRT, typename JOBS> __device__ __forceinline__ void operator()(CRT, uint32_t, uint32_t, uint32_t, uint32_t, JOBS) const {} };
+template <int WIN, int LOOK, int BITS, typename JOBSOF, typename READY, typename DONE = NothingDone>
 __device__ __forceinline__ void viterbi16w_wave(Lds16<WIN, LOOK>& S, uint32_t wave_index, JOBSOF jobs_of, READY ready, const uint32_t* __restrict__ hdr,
         uint32_t target, uint32_t vstride,
-                                                const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs)
+                                                const uint8_t* __restrict__ soft, uint8_t* __restrict__ out, uint16_t* __restrict__ vecs, DONE done = DONE())
 {
     auto uni = [](uint32_t v) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)v); };
     const uint32_t n[3] = { hdr[0], hdr[1], hdr[2] };
@@ -285,6 +303,7 @@ __device__ __forceinline__ void viterbi16w_wave(Lds16<WIN, LOOK>& S, uint32_t wa
         if (!B.valid) { const bool v = false; B = A; B.valid = v; B.vstep = B.estep = kNever; B.nsteps = 0; }
         if (!A.valid) { const bool v = false; const UnitGeom T = B; A = T; A.valid = v; A.vstep = A.estep = kNever; A.nsteps = 0; }
         forward16w<CR, WIN, LOOK, BITS>(S, soft, A, B, vecs, [&]() { return ready(A, B, list); });
+        done(cr, list, nl, w, q, job_at);
     };
     if (code_rate == 0) run(std::integral_constant<int, 0>{});
     else if (code_rate == 1) run(std::integral_constant<int, 1>{});

@@ -1603,6 +1603,88 @@ __global__ void __launch_bounds__(256) k_win_redo_finish_pipe(const VitJob* jobs
                                                               const uint16_t* vecs, const uint8_t* soft, uint8_t* out, unsigned long long* stats, RxArgs A, uint32_t* host_note)
 { win_redo_finish_body<true>(jobs, hdr, jstride, target, vstride, vecs, soft, out, stats, A, host_note); }
 
+#ifdef SORA_EXP_FIN
+// Round 6, MEASURED AND NOT ADOPTED (tools variant only: -DSORA_EXP_FIN=3; profiles/r06_c_unit_finish_experiment.json): the window-parallel trellis whose LAST UNIT OF A
+// FRAME TO ARRIVE finishes the frame (a frame is complete when its own bytes are, not when the call's last kernel has run).  k_viterbi16w's wave, then a tail: the wave publishes its units' bytes and vectors (release), counts each of its up to eight
+// units in at its frame (wdone[list][idx]); the wave whose count completes a frame -- every other unit of the frame has published before it counted -- checks the
+// frame's boundaries exactly as k_win_redo's gate does and, if they all hold, descrambles the frame, checks its CRC, stores the MPDU (into the host's page-locked
+// array too when one is bound: sora_rx_bind_mpdu -- the bytes cross PCIe WHILE the other frames are still being decoded, which is what a lone call's 0.13 ms of
+// finishing kernel was) and writes the row's verdict.  Nobody waits for anybody: a frame whose proof fails is simply left to k_win_redo_finish behind this kernel,
+// which decodes it again and finishes it as before; for a frame finished here its finish_frame returns at once (error_code is set).  The counter is reset by the
+// wave that completes it: every call finds zeros.  The finishing tables live in the trellis's own LDS block, which is free by then.
+// Result, a lone 4096-capture call: identical rows, and SLOWER -- k_viterbi16w 0.262 -> 0.297 ms with the release and the counting alone (SORA_EXP_FIN=1), 0.317 with the
+// proofs' reads behind the acquire (=2), 0.372 with the frames finished (0.442 when the MPDUs also cross PCIe from here), against 0.027 (0.134) ms of k_win_redo_finish
+// saved: all units of a call run side by side (2048 waves on 1792 slots), so every frame's last unit arrives at the END of the launch, and the 512 waves that hold the
+// frames' last pieces then finish eight frames each, one after the other, where the finishing kernel has 2048 waves doing it at once.
+struct FinTail {
+    const RxArgs* A; uint32_t* wdone; uint32_t jstride, vstride; const uint16_t* vecs; Lds16<256, 24>* S; const VitJob* jobs;
+    // (out of line: the tail gets registers of its own instead of living beside the forward pass's 143)
+    template <typename CRT, typename JOBS>
+    __device__ __forceinline__ void operator()(CRT, uint32_t list, uint32_t nl, uint32_t w, uint32_t q, JOBS) const { tail<CRT::value>(list, nl, w, q); }
+    template <int CR>
+    __device__ __attribute__((noinline)) void tail(uint32_t list, uint32_t nl, uint32_t w, uint32_t q) const
+    {
+        const VitJob* __restrict__ jl = jobs + (size_t)list * jstride;
+        auto job_at = [jl](uint32_t idx) { return jl[idx]; };
+        static_assert(sizeof(FinishLds) <= sizeof(Lds16<256, 24>), "the finishing tables take the place of the trellis's LDS block");
+        const unsigned lane = threadIdx.x & 63;
+        FinishLds& L = *reinterpret_cast<FinishLds*>(S);
+        bool tables = false;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");                       // this wave's bytes and vectors, before its units are counted
+        for (uint32_t sidx = 0; sidx < 8u; sidx++) {
+            const UnitRef R = unit_ref_at<CR, 256, 24>(job_at, nl, 8u * w + sidx, q);      // (uniform: every lane works out the same position)
+            if (R.uu == kWinNone) continue;
+            uint32_t* cnt = wdone + (size_t)list * jstride + R.idx;
+            uint32_t old = 0;
+            if (lane == 0) old = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            old = (uint32_t)__builtin_amdgcn_readfirstlane((int)old);
+            if (old + 1u != R.nun) continue;
+            if (lane == 0) __hip_atomic_store(cnt, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if defined(SORA_EXP_FIN) && SORA_EXP_FIN == 1
+            continue;                                                            // experiment: what do the fence and the counting cost by themselves?
+#endif
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");                   // ... what the frame's other units published before they counted
+            const size_t vec0 = (size_t)list * vstride + (size_t)R.idx * q;
+            uint32_t bad = 0;
+            for (uint32_t u = 1u + lane; u < R.nun; u += 64u) {
+                const uint4* a = reinterpret_cast<const uint4*>(vecs + ((vec0 + u) * 2u) * 64u);
+                const uint4* b = reinterpret_cast<const uint4*>(vecs + ((vec0 + u - 1u) * 2u + 1u) * 64u);
+                uint32_t d = 0;
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const uint4 x = a[i], y = b[i]; d |= (x.x ^ y.x) | (x.y ^ y.y) | (x.z ^ y.z) | (x.w ^ y.w); }
+                bad |= d;
+            }
+            if (__ballot(bad != 0u) != 0ull) continue;                           // (k_win_redo_finish decodes the pair again and finishes it)
+#if defined(SORA_EXP_FIN) && SORA_EXP_FIN == 2
+            continue;                                                            // experiment: ... and the proof's reads behind the acquire?
+#endif
+            if (!tables) {
+                tables = true;
+                for (uint32_t i = lane; i < 256u; i += 64u) L.crc[i] = A->T.crc[i];
+                for (uint32_t i = lane; i < 6u * 8u * 16u; i += 64u) L.z[i] = A->T.crcz[i];
+                for (uint32_t pp = lane; pp < 127u; pp += 64u) {
+                    const uint8_t* qq = A->T.scr_seq;
+                    L.seq4[pp] = (uint32_t)qq[pp] | ((uint32_t)qq[(pp + 8u) % 127u] << 8) | ((uint32_t)qq[(pp + 16u) % 127u] << 16) | ((uint32_t)qq[(pp + 24u) % 127u] << 24);
+                }
+                for (uint32_t i = lane; i < 128u; i += 64u) L.phase[i] = A->T.scr_phase[i];
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            }
+            finish_frame(*A, A->joblist[list * A->nrows + R.idx], L);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+    }
+};
+__global__ void __launch_bounds__(64) k_viterbi16w_fin(const VitJob* __restrict__ jobs, const uint32_t* __restrict__ hdr, uint32_t jstride, uint32_t target, uint32_t vstride,
+                                                       const uint8_t* __restrict__ soft, uint8_t* out, uint16_t* vecs, uint32_t* wdone, RxArgs A)
+{
+    __shared__ Lds16<256, 24> S;
+    auto jobs_of = [&](uint32_t list) { const VitJob* __restrict__ jl = jobs + (size_t)list * jstride; return [jl](uint32_t idx) { return jl[idx]; }; };
+    auto ready = [](const UnitGeom&, const UnitGeom&, uint32_t) { return true; };
+    viterbi16w_wave<256, 24, 3>(S, blockIdx.x, jobs_of, ready, hdr, target, vstride, soft, out, vecs, FinTail{ &A, wdone, jstride, vstride, vecs, &S, jobs });
+}
+
+#endif  // SORA_EXP_FIN
+
 // ------------------------------------------------------------------------------------------------
 // k_pack: compacts the per-capture frame table into dense sora_frame_result rows in (capture, time) order, on the
 // device, so the rows can feed an RCCL all-gather without a host round trip.  mpdu_offset = slot0 * 32 indexes the

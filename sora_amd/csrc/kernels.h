@@ -9,7 +9,7 @@
 // Experiment and probe switches (SORA_EXP_*, SORA_DBG_*) belong to the TOOLS variant of the library (sora_amd.build.build_variant adds -DSORA_TOOLS for them): the product
 // build refuses them, so no measurement scaffolding can reach it by accident.
 #if !defined(SORA_TOOLS) && (defined(SORA_EXP_NORING) || defined(SORA_EXP_LB) || defined(SORA_EXP_STAGGER) || defined(SORA_EXP_VIT_PRIO) || defined(SORA_DBG_TRACK_TH) || \
-                             defined(SORA_DBG_NO_TRACE) || defined(SORA_DBG_KFRAME_PRIVATE) || defined(SORA_DBG_NO_SYMBOLS) || defined(SORA_DBG_NO_TRELLIS) || defined(SORA_SCAN_PROBE))
+                             defined(SORA_DBG_NO_TRACE) || defined(SORA_DBG_KFRAME_PRIVATE) || defined(SORA_DBG_NO_SYMBOLS) || defined(SORA_DBG_NO_TRELLIS) || defined(SORA_SCAN_PROBE) || defined(SORA_EXP_FIN))
 #error "SORA_EXP_* / SORA_DBG_* switches need -DSORA_TOOLS (sora_amd.build.build_variant)"
 #endif
 
@@ -96,6 +96,9 @@ __global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint
 // k_vitwin.hip: the window-parallel trellis.  hdr = the call's counter block (njobs per code rate in its first three words); jstride = capacity of a list of jobs;
 // target = units the call is cut into at least, frames permitting; vstride = vectors per code-rate list
 __global__ void k_viterbi16w(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
+#ifdef SORA_EXP_FIN
+__global__ void k_viterbi16w_fin(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs, uint32_t* wdone, RxArgs A);
+#endif
 __global__ void k_viterbi16w_11n(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
 __global__ void k_win_redo_11n(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,
         const uint8_t* soft, uint8_t* out, unsigned long long* stats);

@@ -437,6 +437,8 @@ struct RxPipe {
     int  lanes16 = 0;
     // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
     uint16_t* d_wvecs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;
+    bool unit_finish = true;       // (SORA_EXP_FIN builds; sora_internal_rx_unit_finish(0) = the plain k_viterbi16w in front of k_win_redo_finish, for A/B timing)
+    uint32_t* d_wdone = nullptr;   // k_viterbi16w_fin (SORA_EXP_FIN): units of a frame that have arrived, per code-rate list and place (zero between calls)
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
     sora_complex16* d_iq_own = nullptr; size_t iq_own_samples = 0;
     uint8_t* d_dump = nullptr; size_t dump_cap = 0;             // sora_rx_process_dump: the raw dump bytes of this pipeline's call
@@ -520,7 +522,7 @@ static void rx_free(RxPipe* rx)
     if (!rx) return;
     void* ptrs[] = { rx->d_caps, rx->d_fctx, rx->d_nframes,
                      rx->d_soft, rx->d_jobs, rx->d_vout, rx->d_mpdu, rx->d_iq_own, rx->d_rows, rx->d_nrows, rx->d_njobs, rx->d_joblist, rx->d_dump, rx->d_slot_row, rx->d_eq, rx->d_track, rx->d_pil,
-                     rx->d_wvecs, rx->d_wstats, rx->d_pflags };
+                     rx->d_wvecs, rx->d_wstats, rx->d_wdone, rx->d_pflags };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
@@ -715,6 +717,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
         HIPCHK(hipMalloc((void**)&rx->d_wvecs, 3 * (size_t)kWinVecBytes * rx->wstride));
         HIPCHK(hipMalloc((void**)&rx->d_wstats, (4 * kWinStatBanks + 1) * sizeof(unsigned long long)));   // (+ 1: calls whose data field k_win_redo_finish_pipe made again)
         HIPCHK(hipMemset(rx->d_wstats, 0, (4 * kWinStatBanks + 1) * sizeof(unsigned long long)));
+#ifdef SORA_EXP_FIN
+        HIPCHK(hipMalloc((void**)&rx->d_wdone, 3 * sizeof(uint32_t) * (size_t)rx->cap_rows));
+        HIPCHK(hipMemset(rx->d_wdone, 0, 3 * sizeof(uint32_t) * (size_t)rx->cap_rows));
+#endif
     }
 #ifdef SORA_FRAME_SPLIT3
     const bool split = true;
@@ -842,6 +848,14 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             else if (rx->lanes16 == 2) {
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), then the proof
                 // and the serial decode of the pairs of frames that fail it (none, normally: k_win_redo's waves check and return)
+#ifdef SORA_EXP_FIN
+                // (experiment, not adopted: the last unit of a frame to arrive finishes the frame -- k_rx.hip, k_viterbi16w_fin)
+                if (redo_finish && rx->unit_finish)
+                    hipLaunchKernelGGL(k_viterbi16w_fin, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs,
+                            (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
+                                       (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs, rx->d_wdone, R);
+                else
+#endif
                 hipLaunchKernelGGL(k_viterbi16w, dim3((units_max + 7) / 8 + 3 + kWinLoneWaves), dim3(64), 0, st, (const VitJob*)rx->d_jobs,
                         (const uint32_t*)counters, nrows, kWinUnitsTarget, rx->wstride,
                                    (const uint8_t*)rx->d_soft, rx->d_vout, rx->d_wvecs);
@@ -1495,6 +1509,14 @@ SORA_TOOL_HOOK int sora_internal_rx_only(sora_rx_t* rx, unsigned mask)
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
     for (int i = 0; i < sora_rx::kMaxDepth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->only = mask & 0xFu; p->last_valid = false; } if (i + 1 >= rx->depth) break; }
+    return SORA_OK;
+}
+
+// Test / tool hook: 0 = the plain k_viterbi16w in front of k_win_redo_finish (round 5's chain) instead of k_viterbi16w_fin -- for A/B timing (tools/r06_lone_call_timeline.py)
+SORA_TOOL_HOOK int sora_internal_rx_unit_finish(sora_rx_t* rx, int on)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    for (int i = 0; i < rx->depth; i++) { RxPipe* p = pipe_at(rx, i); if (p) { p->unit_finish = on != 0; p->last_valid = false; } }
     return SORA_OK;
 }
 
