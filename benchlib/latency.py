@@ -98,11 +98,11 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
     # to the completion of ITS call.  The last call finishes later than one big call would; the frames of the others do not wait for it.
     sub = {}
     d_all = sora_amd.Rx.captures(descs)                                      # (packed once: a call's descriptors are a slice of it)
-    for k in (2, 4, 8):
-        m = nfr // k
+    for k, ordered in ((2, 0), (4, 0), (8, 0), (2, 1), (4, 1)):
+        m = (nfr + k - 1) // k
         rs = sora_amd.Rx(max_captures=m, max_total_samples=int(d_iq.shape[0]), sample_rate_mhz=20, max_frames_per_capture=2)
-        rs.set_depth(k); rs.wait_for_producer = False
-        parts = [np.ascontiguousarray(d_all[i * m:(i + 1) * m]) for i in range(k)]
+        rs.set_depth(k); rs.wait_for_producer = False; rs.set_ordered(ordered)
+        parts = [np.ascontiguousarray(d_all[i * m:min((i + 1) * m, nfr)]) for i in range(k)]
         bufs = [sora_amd.HostResults(m * 2, rs.mpdu_bytes(rs.process_dev(d_iq, parts[0]))) for _ in range(k)]
         rs.flush()
         ratios = []; last = []
@@ -119,7 +119,7 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
             b.close()
         kern = TRELLIS_NAMES[rs.trellis()]; rs.close()
         r = np.concatenate(ratios)                                            # every call holds the same number of frames
-        sub["%d_calls_of_%d" % (k, m)] = {"trellis_kernel": kern, "last_call_done_ms": round(float(np.mean(last)) / 1e3, 4), "frames": int(nfr * len(ratios)),
+        sub["%d_calls_of_%d%s" % (k, m, "_ordered" if ordered else "")] = {"trellis_kernel": kern, "first_call_done_ms": round(float(np.mean([r_[0] for r_ in ratios])) * req_us / 1e3, 4), "last_call_done_ms": round(float(np.mean(last)) / 1e3, 4), "frames": int(nfr * len(ratios)),
                                           "ratio_mean": round(float(r.mean()), 3), "ratio_max": round(float(r.max()), 3), "ratio_std": round(float(r.std()), 3),
                                           "share_ge_1.0": round(float((r >= 1.0).mean()), 3)}
     out["batch_per_frame"] = {"definition": "MACStopwatch's per-frame ratio cost / required with cost = the latency of the call the frame is in (process -> deliver -> wait, one call in flight: "
@@ -128,7 +128,8 @@ def bench_latency(torch, sora_amd, dev, rx_batch, d_iq, descs, nfr, reps=40):
                               "by_trellis_kernel": dist,
                               "as_calls_in_flight_taken_as_they_complete": sub,
                               "as_calls_note": "the same 4096 captures as k calls of 4096 / k on one handle, all in flight, each call's table delivered and taken as it completes (sora_rx_deliver_async + "
-                                               "sora_rx_wait_any): cost of a frame = first submission -> completion of its call; the library's automatic kernel choice"}
+                                               "sora_rx_wait_any): cost of a frame = first submission -> completion of its call; the library's automatic kernel choice.  _ordered: "
+                                               "sora_rx_set_ordered(1) -- a call's trellis kernel starts behind the previous call's, so the calls complete one after the other"}
     return out
 
 

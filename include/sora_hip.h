@@ -35,7 +35,7 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, sora_rx_call_front, sora_hip_set_share_window_us, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, sora_rx_call_front, sora_rx_set_ordered, sora_hip_set_share_window_us, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
 #define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */
@@ -245,6 +245,12 @@ int  sora_rx_front(sora_rx_t* rx);              /* 1, 3 or 4: what the next proc
  * forecast.  What a call WAS launched with is latched at its process call: sora_rx_call_front (ticket 0 = the most recent call) answers 1, 3 or 4 for as long as the handle
  * holds the ticket.  sora_hip_set_share_window_us sets the window for the whole process (default 20000; 0 = other handles are never looked at) and returns the old value. */
 int  sora_rx_call_front(sora_rx_t* rx, int ticket);
+/* Completion in submission order (round 6; 0 / 1, returns the previous setting; default 0).  Calls in flight share the chip and, left alone, finish together: a host that hands a
+ * batch over in pieces to get its first frames early gets nothing.  With 1 the trellis kernel of a call starts behind the trellis kernel of the call submitted before it: the
+ * calls complete one after the other, a call's front kernels still run beside the trellis of the one before it and its delivery beside the trellis of the one after it.  For the
+ * host that wants frames as early as possible (the reference's per-frame hand-over, fb11a_demod.cpp:37-71); the throughput-oriented loop (eight unordered calls) is faster per
+ * sample.  Results are identical either way.  (An ordered call is launched kernel by kernel, not as a recorded hipGraph.) */
+int  sora_rx_set_ordered(sora_rx_t* rx, int on);
 uint32_t sora_hip_set_share_window_us(uint32_t us);
 /* k_pipe's safety net.  The bound of every wait inside its launch, in microseconds (default 20000; 0 = a wait that is not satisfied at first look gives up: every call
  * then takes the redo path -- what tests/test_gpu_pipe.py does to prove that path delivers the reference's rows).  Returns the previous bound; a negative argument only queries. */

@@ -437,6 +437,9 @@ struct RxPipe {
     int  lanes16 = 0;
     // ... its verification vectors (per code-rate list: wstride units), the frames to decode again, its record
     uint16_t* d_wvecs = nullptr; unsigned long long* d_wstats = nullptr; uint32_t wstride = 0;
+    // sora_rx_set_ordered: this call's trellis kernel starts behind the previous call's (wait_for = that call's ev_trellis), so that calls in flight COMPLETE in the order they were
+    // submitted -- the front kernels (latency chains) of a call still run beside the trellis of the one before it, and its delivery beside the trellis of the one after it
+    hipEvent_t ev_trellis = nullptr, wait_for = nullptr; bool ordered = false;
     bool unit_finish = true;       // (SORA_EXP_FIN builds; sora_internal_rx_unit_finish(0) = the plain k_viterbi16w in front of k_win_redo_finish, for A/B timing)
     uint32_t* d_wdone = nullptr;   // k_viterbi16w_fin (SORA_EXP_FIN): units of a frame that have arrived, per code-rate list and place (zero between calls)
     uint8_t* d_vout = nullptr; uint8_t* d_mpdu = nullptr; uint32_t* d_njobs = nullptr; uint32_t* d_joblist = nullptr;
@@ -525,6 +528,7 @@ static void rx_free(RxPipe* rx)
                      rx->d_wvecs, rx->d_wstats, rx->d_wdone, rx->d_pflags };
     for (void* p : ptrs) if (p) (void)hipFree(p);
     for (auto& e : rx->ev) if (e) (void)hipEventDestroy(e);
+    if (rx->ev_trellis) (void)hipEventDestroy(rx->ev_trellis);
     if (rx->graph_exec) (void)hipGraphExecDestroy(rx->graph_exec);
     if (rx->graph) (void)hipGraphDestroy(rx->graph);
     if (rx->ev_caps) (void)hipEventDestroy(rx->ev_caps);
@@ -844,6 +848,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                 }
             } else if (RX_ONLY(rx, 2u)) hipLaunchKernelGGL(k_frame, dim3((nrows + 3) / 4), dim3(256), 0, st, R);
             mark();
+            if (rx->wait_for && !recording) (void)hipStreamWaitEvent(st, rx->wait_for, 0);   // (sora_rx_set_ordered: behind the previous call's trellis)
             if (!RX_ONLY(rx, 4u)) {}
             else if (rx->lanes16 == 2) {
                 // window-parallel: the call's units (at most target + one per row, eight per wave, + a partly filled wave per code-rate list), then the proof
@@ -871,6 +876,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
                 // at most ceil(n/2) + 2 pairs over the three lists
                 hipLaunchKernelGGL(k_viterbi, dim3((nrows / 2 + 3 + 3) / 4), dim3(256), 0, st, (const VitJob*)rx->d_jobs, (const uint32_t*)counters, 0u, nrows,
                         (const uint8_t*)rx->d_soft, rx->d_vout);
+            if (rx->ordered && !recording && rx->ev_trellis) (void)hipEventRecord(rx->ev_trellis, st);
             mark();
             }
         }
@@ -900,7 +906,7 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
     }
     rx->last_iq = d_iq; rx->last_valid = true;
     bool launched = false;
-    if (rx->use_graph && !prof && repeat) {
+    if (rx->use_graph && !prof && repeat && !rx->ordered) {                      // (an ordered call waits for an event of another stream: the plain launches)
         if (!rx->graph_exec) {                                                   // second identical call: record the chain
             if (hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                 const int rc = enqueue(true);
@@ -1094,6 +1100,7 @@ struct sora_rx {
     uint32_t* h_note = nullptr; uint32_t* d_note = nullptr;
     int pipe_backoff = 0; unsigned long long pipe_backoffs = 0;
     uint8_t* next_bound = nullptr; size_t next_bound_bytes = 0;               // sora_rx_bind_mpdu: for the next process call only
+    bool ordered = false; hipEvent_t last_trellis = nullptr;                      // sora_rx_set_ordered
     std::atomic<long long> last_call_ns{0};   // when this handle last took a process call (steady clock): what OTHER handles' automatic kernel choice looks at (chip_is_shared)
 };
 
@@ -1279,6 +1286,13 @@ int sora_rx_set_front(sora_rx_t* rx, int kernels)
     return old;
 }
 int sora_rx_front(sora_rx_t* rx) { return rx ? front_for(rx) : SORA_ERR_INVALID_PARAM; }
+int sora_rx_set_ordered(sora_rx_t* rx, int on)
+{
+    if (!rx) return SORA_ERR_INVALID_PARAM;
+    const int old = rx->ordered ? 1 : 0;
+    if (on == 0 || on == 1) { rx->ordered = on != 0; if (!rx->ordered) rx->last_trellis = nullptr; for (RxPipe* p : rx->pipes) if (p) p->last_valid = false; }
+    return old;
+}
 int sora_rx_call_front(sora_rx_t* rx, int ticket)                              // what call `ticket` WAS launched with: latched at its process call
 {
     if (!rx) return SORA_ERR_INVALID_PARAM;
@@ -1443,6 +1457,10 @@ static void choose_kernels(sora_rx* rx, RxPipe* p)
     if (rx->h_note && *(volatile uint32_t*)rx->h_note != 0u) { *(volatile uint32_t*)rx->h_note = 0u; rx->pipe_backoff = kPipeBackoffCalls; rx->pipe_backoffs++; }
     else if (rx->pipe_backoff > 0) rx->pipe_backoff--;
     p->bound_mpdu = rx->next_bound; p->bound_bytes = rx->next_bound_bytes; rx->next_bound = nullptr; rx->next_bound_bytes = 0;
+    p->ordered = rx->ordered;
+    if (p->ordered && !p->ev_trellis && hipEventCreateWithFlags(&p->ev_trellis, hipEventDisableTiming) != hipSuccess) { p->ev_trellis = nullptr; p->ordered = false; (void)hipGetLastError(); }
+    p->wait_for = p->ordered && rx->last_trellis != p->ev_trellis ? rx->last_trellis : nullptr;     // (its own previous call is ahead of it in its stream anyway)
+    if (p->ordered) rx->last_trellis = p->ev_trellis; else rx->last_trellis = nullptr;
     if (p->lanes16 != lanes16_for(rx)) { p->lanes16 = lanes16_for(rx); p->last_valid = false; }
     { const int fr = front_for(rx); if (p->front != fr) { p->front = fr; p->last_valid = false; } }
     { const bool p64 = p->front == 4 && pipe_fits(rx, true); if (p->pipe64 != p64) { p->pipe64 = p64; p->last_valid = false; } }
