@@ -35,7 +35,9 @@ extern "C" {
  * sora_rx11b_set_single_pass defaults to 2 (automatic); sora_ht40_deliver_async needs max_rows >= 2 x captures x max_frames.  (ii) new this round, all additive:
  * SORA_TRELLIS_WINDOWED and sora_rx_window_stats, sora_rx_set_front / sora_rx_front, sora_hip_table_*, sora_hip_freq_comp11a / _equalize11a / _phase_comp11a,
  * and the automatic choices of sora_rx_set_trellis / sora_rx_set_front (results are identical whichever kernels run).  INTEGRATION.md section 1 lists them. */
-/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats, sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, sora_rx_call_front, sora_rx_set_ordered, sora_hip_set_share_window_us, SORA_TRELLIS_WINDOWED and the automatic choice for sora_rx11n_set_trellis. */
+/* 4 (round 6).  Against 3: no row is ever delivered with SORA_E_INTERNAL_TIMEOUT (see sora_rx_set_front, form 4); new, additive: sora_rx_set_pipe_wait_us, sora_rx_pipe_stats,
+ * sora_hip_pilot11a, sora_rx_bind_mpdu, sora_rx11n_trellis, sora_rx11n_window_stats, sora_rx_call_front, sora_rx_set_ordered, sora_hip_set_share_window_us, SORA_TRELLIS_WINDOWED and
+ * the automatic choice for sora_rx11n_set_trellis. */
 #define SORA_HIP_ABI_VERSION 4
 
 /* COMPLEX16: kernel/core/inc/complex.h */

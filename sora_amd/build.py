@@ -12,7 +12,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 OBJ = os.path.join(HERE, "lib", "obj")
 LIB = os.path.join(HERE, "lib", "libsora_hip.so")
-SOURCES = ["k_scan.hip", "k_rx.hip", "k_vit16.hip", "k_vitwin.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "k_ht40.hip", "k_deliver.hip", "sora_hip.cpp", "sora_shard.cpp"]
+SOURCES = ["k_scan.hip", "k_rx.hip", "k_vit16.hip", "k_vitwin.hip", "k_stage.hip", "k_tx.hip", "k_rx11b.hip", "k_11n.hip", "k_rx11n.hip", "k_ht40.hip", "k_deliver.hip",
+    "sora_hip.cpp", "sora_shard.cpp"]
 # k_decode.hip (the data field in one kernel, sora_rx_set_fused) left the default library in round 4: build_variant("fused", ["SORA_WITH_K_DECODE"])
 # compiles it in (the entry point answers SORA_E_NOT_SUPPORTED otherwise).
 VARIANT_SOURCES = {"SORA_WITH_K_DECODE": ["k_decode.hip"]}

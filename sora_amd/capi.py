@@ -54,12 +54,25 @@ EXPORTS = ["sora_hip_abi_version", "sora_hip_last_error", "sora_hip_device_count
            "sora_hip_memcpy_h2d", "sora_hip_memcpy_d2h", "sora_hip_memcpy_d2d", "sora_hip_stream_synchronize", "sora_rx_create", "sora_rx_destroy", "sora_rx_reset",
            "sora_rx_flush", "sora_rx_stream", "sora_rx_process_dev", "sora_rx_process_dump", "sora_rx_set_stream_mode", "sora_rx_stream_consumed", "sora_rx_process", "sora_rx_results",
            "sora_rx_results_dev", "sora_rx_ticket", "sora_rx_wait", "sora_rx_wait_any", "sora_rx_results_of", "sora_rx_results_dev_of", "sora_rx_stream_of",
-           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name", "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_window_stats", "sora_rx_set_front", "sora_rx_front", "sora_rx_call_front", "sora_rx_set_ordered", "sora_hip_set_share_window_us", "sora_rx_set_pipe_wait_us", "sora_rx_pipe_stats", "sora_rx_bind_mpdu", "sora_hip_table_count", "sora_hip_table_name", "sora_hip_table_pin", "sora_hip_table_digest", "sora_hip_table_read", "sora_rx_set_graph", "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_pilot11a", "sora_hip_freq_comp11a", "sora_hip_equalize11a", "sora_hip_phase_comp11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a", "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
+           "sora_rx_mpdu_bytes", "sora_rx_deliver_async", "sora_hip_host_alloc", "sora_hip_host_free", "sora_rx_set_profiling", "sora_rx_kernel_times", "sora_rx_kernel_name",
+                      "sora_rx_set_depth", "sora_rx_set_fused", "sora_rx_set_trellis", "sora_rx_trellis", "sora_rx_window_stats", "sora_rx_set_front", "sora_rx_front",
+                      "sora_rx_call_front", "sora_rx_set_ordered", "sora_hip_set_share_window_us", "sora_rx_set_pipe_wait_us", "sora_rx_pipe_stats", "sora_rx_bind_mpdu",
+                      "sora_hip_table_count", "sora_hip_table_name", "sora_hip_table_pin", "sora_hip_table_digest", "sora_hip_table_read", "sora_rx_set_graph",
+                      "sora_rx_kernel_name_fused", "sora_hip_fft64", "sora_hip_fft128", "sora_hip_lts11a", "sora_hip_symfront11a", "sora_hip_pilot_track11a", "sora_hip_pilot11a",
+                      "sora_hip_freq_comp11a", "sora_hip_equalize11a", "sora_hip_phase_comp11a", "sora_hip_demap11a", "sora_hip_deinterleave11a", "sora_hip_viterbi11a",
+                      "sora_hip_viterbi11a_ws", "sora_hip_viterbi11a_workspace_bytes",
            "sora_hip_ingest", "sora_hip_ingest_count", "sora_hip_tx11a", "sora_hip_tx11a_samples",
-           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n", "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create", "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket", "sora_rx11b_calls_in_flight", "sora_rx11b_set_single_pass", "sora_rx11b_wait", "sora_rx11b_wait_any", "sora_rx11b_stream_of", "sora_rx11b_results_of", "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
+           "sora_hip_demap11n", "sora_hip_deinterleave11n", "sora_hip_mimo_est11n", "sora_hip_mimo_comp11n", "sora_hip_cfo_est11n", "sora_hip_freq_comp11n",
+                      "sora_hip_pilot_track11n", "sora_hip_siso_est11n", "sora_hip_siso_comp11n", "sora_hip_sig_demap11n", "sora_hip_sig_decode11n", "sora_rx11b_create",
+                      "sora_rx11b_destroy", "sora_rx11b_stream", "sora_rx11b_synchronize", "sora_rx11b_process_dev", "sora_rx11b_process", "sora_rx11b_results", "sora_rx11b_ticket",
+                      "sora_rx11b_calls_in_flight", "sora_rx11b_set_single_pass", "sora_rx11b_wait", "sora_rx11b_wait_any", "sora_rx11b_stream_of", "sora_rx11b_results_of",
+                      "sora_rx11b_deliver_async", "sora_rx11n_deliver_async", "sora_ht40_deliver_async",
            "sora_rx11n_create", "sora_rx11n_destroy", "sora_rx11n_stream", "sora_rx11n_process_dev", "sora_rx11n_process", "sora_rx11n_results",
-           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_trellis", "sora_rx11n_window_stats", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait", "sora_rx11n_wait_any", "sora_rx11n_results_of",
-           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev", "sora_ht40_process_captures_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_wait_any", "sora_ht40_stream_of", "sora_ht40_results_of",
+           "sora_rx11n_set_depth", "sora_rx11n_set_trellis", "sora_rx11n_trellis", "sora_rx11n_window_stats", "sora_rx11n_synchronize", "sora_rx11n_ticket", "sora_rx11n_wait",
+                      "sora_rx11n_wait_any", "sora_rx11n_results_of",
+           "sora_ht40_symbols", "sora_ht40_create", "sora_ht40_destroy", "sora_ht40_stream", "sora_ht40_synchronize", "sora_ht40_set_trellis", "sora_ht40_process_dev",
+                      "sora_ht40_process_captures_dev", "sora_ht40_results", "sora_ht40_ticket", "sora_ht40_calls_in_flight", "sora_ht40_wait", "sora_ht40_wait_any",
+                      "sora_ht40_stream_of", "sora_ht40_results_of",
            "sora_shard_unique_id", "sora_shard_create", "sora_shard_destroy", "sora_shard_world", "sora_shard_partition", "sora_shard_gather_rows",
            "sora_shard_reduce_counters", "sora_shard_gather_results", "sora_shard_gather_results_mpdu"]
 

@@ -1605,7 +1605,8 @@ __global__ void __launch_bounds__(256) k_win_redo_finish_pipe(const VitJob* jobs
 
 #ifdef SORA_EXP_FIN
 // Round 6, MEASURED AND NOT ADOPTED (tools variant only: -DSORA_EXP_FIN=3; profiles/r06_c_unit_finish_experiment.json): the window-parallel trellis whose LAST UNIT OF A
-// FRAME TO ARRIVE finishes the frame (a frame is complete when its own bytes are, not when the call's last kernel has run).  k_viterbi16w's wave, then a tail: the wave publishes its units' bytes and vectors (release), counts each of its up to eight
+// FRAME TO ARRIVE finishes the frame (a frame is complete when its own bytes are, not when the call's last kernel has run).
+// k_viterbi16w's wave, then a tail: the wave publishes its units' bytes and vectors (release), counts each of its up to eight
 // units in at its frame (wdone[list][idx]); the wave whose count completes a frame -- every other unit of the frame has published before it counted -- checks the
 // frame's boundaries exactly as k_win_redo's gate does and, if they all hold, descrambles the frame, checks its CRC, stores the MPDU (into the host's page-locked
 // array too when one is bound: sora_rx_bind_mpdu -- the bytes cross PCIe WHILE the other frames are still being decoded, which is what a lone call's 0.13 ms of

@@ -9,7 +9,8 @@
 // Experiment and probe switches (SORA_EXP_*, SORA_DBG_*) belong to the TOOLS variant of the library (sora_amd.build.build_variant adds -DSORA_TOOLS for them): the product
 // build refuses them, so no measurement scaffolding can reach it by accident.
 #if !defined(SORA_TOOLS) && (defined(SORA_EXP_NORING) || defined(SORA_EXP_LB) || defined(SORA_EXP_STAGGER) || defined(SORA_EXP_VIT_PRIO) || defined(SORA_DBG_TRACK_TH) || \
-                             defined(SORA_DBG_NO_TRACE) || defined(SORA_DBG_KFRAME_PRIVATE) || defined(SORA_DBG_NO_SYMBOLS) || defined(SORA_DBG_NO_TRELLIS) || defined(SORA_SCAN_PROBE) || defined(SORA_EXP_FIN))
+                             defined(SORA_DBG_NO_TRACE) || defined(SORA_DBG_KFRAME_PRIVATE) || defined(SORA_DBG_NO_SYMBOLS) || defined(SORA_DBG_NO_TRELLIS) || defined(SORA_SCAN_PROBE) || \
+                             defined(SORA_EXP_FIN))
 #error "SORA_EXP_* / SORA_DBG_* switches need -DSORA_TOOLS (sora_amd.build.build_variant)"
 #endif
 
@@ -64,7 +65,8 @@ struct RxArgs {
     TrackRec*       track;          // [total_slots] rotation parameters of a data symbol (k_track -> k_sym_back)
     uint32_t*       pil;            // [total_slots][4] the four pilot bins (43, 57, 7, 21) of eq[] once more, densely: all k_track reads
     const uint32_t* pipe_flags;     // k_finish behind k_pipe: word 0 != 0 = a hand-off inside that launch gave up (else null)
-    uint8_t*        mpdu_host;      // sora_rx_bind_mpdu: the caller's page-locked MPDU array (the geometry of mpdu[]): the frame sink writes every MPDU there as well, over PCIe, as it finishes the frame (else null)
+    // sora_rx_bind_mpdu: the caller's page-locked MPDU array (the geometry of mpdu[]): the frame sink writes every MPDU there as well, over PCIe, as it finishes the frame (else null)
+    uint8_t*        mpdu_host;
 };
 
 // k_pipe (k_rx.hip): the data field of a handful of frames as ONE launch.  Workgroups [0, nfront) are k_sym_front's, [nfront, nfront + ntrack) one frame's tracker and
@@ -97,7 +99,8 @@ __global__ void k_viterbi16_11n(const VitJob* jobs, const uint32_t* njobs3, uint
 // target = units the call is cut into at least, frames permitting; vstride = vectors per code-rate list
 __global__ void k_viterbi16w(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
 #ifdef SORA_EXP_FIN
-__global__ void k_viterbi16w_fin(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs, uint32_t* wdone, RxArgs A);
+__global__ void k_viterbi16w_fin(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs,
+                                 uint32_t* wdone, RxArgs A);
 #endif
 __global__ void k_viterbi16w_11n(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint8_t* soft, uint8_t* out, uint16_t* vecs);
 __global__ void k_win_redo_11n(const VitJob* jobs, const uint32_t* hdr, uint32_t jstride, uint32_t target, uint32_t vstride, const uint16_t* vecs,

@@ -424,7 +424,8 @@ struct RxPipe {
     // 4 = k_pipe: those three AND the window-parallel trellis as one launch (a handful of frames; needs lanes16 == 2)
     int  front = 1;
     uint32_t* d_pflags = nullptr; uint32_t pflag_words = 0;     // ... k_pipe's hand-off words (kernels.h PipeArgs), zeroed for every call
-    uint8_t* bound_mpdu = nullptr; size_t bound_bytes = 0; const void* last_bound = nullptr;   // sora_rx_bind_mpdu: this call's MPDUs go straight to the host's array (what the last enqueue / recorded graph carries)
+    // sora_rx_bind_mpdu: this call's MPDUs go straight to the host's array (last_bound: what the last enqueue / recorded graph carries)
+    uint8_t* bound_mpdu = nullptr; size_t bound_bytes = 0; const void* last_bound = nullptr;
     uint32_t pipe_wait_ticks = 2000000; uint32_t* d_note = nullptr;   // ... the bound of its waits (100 MHz ticks) and the handle's host-mapped note "a wait gave up" (sora_rx)
     bool pipe64 = false;                                        // ... its trellis role in the 64-lane form (two units per wave: the handle's calls in flight are few enough for that many workgroups)
     // A call needs its job counters zero, k_pipe's words zero and (three-kernel chain) no symbol slot owned: the call BEFORE it on this pipeline arranges that inside its k_scan
@@ -706,7 +707,10 @@ static int pipe_process_dev(RxPipe* rx, const sora_complex16* d_iq, const sora_c
             return fail(SORA_ERR_INVALID_PARAM, "a capture descriptor reaches past the end of the sample buffer");
     }
     if (total > rx->cfg.max_total_samples || slots64 > rx->cap_slots) return fail(SORA_ERR_CAPACITY, "more samples than sora_rx_cfg.max_total_samples");
-    if (rx->bound_mpdu && rx->bound_bytes < (size_t)kOutPerSlot * slots64) { rx->bound_mpdu = nullptr; return fail(SORA_ERR_CAPACITY, "sora_rx_bind_mpdu: the bound array is smaller than the call's sora_rx_mpdu_bytes()"); }
+    if (rx->bound_mpdu && rx->bound_bytes < (size_t)kOutPerSlot * slots64) {
+        rx->bound_mpdu = nullptr;
+        return fail(SORA_ERR_CAPACITY, "sora_rx_bind_mpdu: the bound array is smaller than the call's sora_rx_mpdu_bytes()");
+    }
     const uint32_t slots = (uint32_t)slots64;
     rx->h_caps.swap(hc);
     rx->ncaps = (uint32_t)ncaps; rx->total_slots = slots; rx->have_results = false; rx->delivered = rx->released = false;
