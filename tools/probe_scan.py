@@ -41,6 +41,6 @@ buf = (ctypes.c_ulonglong * 16)()
 L.sora_debug_scan_probe(buf, 1)
 rx.process_dev(d, descs); rx.flush()
 L.sora_debug_scan_probe(buf, 0)
-names = ["establish_sync", "loop top .. start of a carrier-sense pass", "header section (LTS + SIGNAL)", "carrier-sense passes (<= 8 bursts)", "check_sync passes (<= 16 bursts)", "whole kernel (capture 0)", "ring fill for the header", "frame row + reset"]
+names = ["establish_sync", "loop top .. start of a carrier-sense pass", "header section (LTS + SIGNAL)", "carrier-sense passes (<= 16 bursts)", "check_sync passes (<= 16 bursts)", "whole kernel (capture 0)", "ring fill for the header", "frame row + reset"]
 for i, nme in enumerate(names):
     print("%-32s %9d ticks  %5d times" % (nme, buf[i], buf[8 + i]))
